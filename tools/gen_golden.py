@@ -1,0 +1,430 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+Run:  python3 -B tools/gen_golden.py
+Needs /root/reference; never runs on the GPU box.  Fixtures are data only: the inputs and
+the outputs the reference's own functions produced for them.  Functions that exist in the
+reference are called as-is (find_knn_within_radius, filter_triangles_by_radius,
+precompute_triangle_info, verify_spatial_preservation, compute_mip_start_pairs,
+calculate_signed_area, calc_ref_area, find_knn_with_cell_type_priority).  run_same's inline
+pre-MIP / sweep loops cannot be imported (they need a live gurobipy), so they
+are driven here on the reference's own frames with the expression order of the cited lines.
+"""
+import contextlib
+import io
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pandas as pd
+from scipy.spatial import Delaunay
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+from ref_loader import REF_ROOT, load_reference  # noqa: E402
+
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("same_synth", os.path.join(ROOT, "same_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+ref = load_reference()
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+# ------------------------------------------------------------------ inline loops of run_same
+def ref_pair_costs(aligned_df, ref_df, valid_pairs, commonCT, dist_ct_coeff):
+    """src/same.py:1180-1189."""
+    c = []
+    dist_coeff = dist_ct_coeff * 0.001
+    for idx, (i, j) in enumerate(valid_pairs):
+        dist_ct = np.sum(np.abs(aligned_df.iloc[i][commonCT] - ref_df.iloc[j][commonCT]))
+        dist_coords = np.abs(aligned_df.iloc[i]['X'] - ref_df.iloc[j]['X']) + \
+            np.abs(aligned_df.iloc[i]['Y'] - ref_df.iloc[j]['Y'])
+        c.append(dist_ct_coeff * dist_ct + dist_coeff * dist_coords)
+    return np.array(c, dtype=np.float64)
+
+
+def ref_weights_signs(aligned_df, tris):
+    """src/same.py:1128-1146."""
+    w, s = [], []
+    for tri in tris:
+        a, b, c = tri
+        w.append(aligned_df.iloc[a]['size'] + aligned_df.iloc[b]['size'] + aligned_df.iloc[c]['size'])
+        ax, ay = aligned_df.iloc[a]['X'], aligned_df.iloc[a]['Y']
+        bx, by = aligned_df.iloc[b]['X'], aligned_df.iloc[b]['Y']
+        cx, cy = aligned_df.iloc[c]['X'], aligned_df.iloc[c]['Y']
+        s.append(np.sign((bx - ax) * (cy - ay) - (by - ay) * (cx - ax)))
+    return np.array(w, dtype=np.float64), np.array(s, dtype=np.float64)
+
+
+def ref_lazy_sweep(x_vals, valid_pairs, tris, source_signs, ref_df):
+    """src/same.py:634-669 (the arithmetic body of _lazy_orientation_callback)."""
+    ref_coords = {j: (ref_df.iloc[j]['X'], ref_df.iloc[j]['Y']) for j in range(len(ref_df))}  # same.py:1158
+    matching = {}
+    for idx, (ip, jp) in enumerate(valid_pairs):
+        if x_vals[idx] > 0.5:
+            matching[ip] = jp
+    violating, checked = [], 0
+    for tri_idx, tri in enumerate(tris):
+        a, b, c = tri
+        if a not in matching or b not in matching or c not in matching:
+            continue
+        ax, ay = ref_coords[matching[a]]
+        bx, by = ref_coords[matching[b]]
+        cx, cy = ref_coords[matching[c]]
+        ref_sign = np.sign((bx - ax) * (cy - ay) - (by - ay) * (cx - ax))
+        source_sign = source_signs[tri_idx]
+        if source_sign == 0 or ref_sign == 0:
+            continue
+        checked += 1
+        if source_sign != ref_sign:
+            violating.append(tri_idx)
+    return checked, np.array(violating, dtype=np.int64)
+
+
+def ref_area_flips(aligned_df, ref_df, tris, aligned_to_ref):
+    """src/same.py:1362-1402 with helpers.calculate_signed_area."""
+    before, after, flipped, m3 = [], [], [], []
+    for tri_idx, triangle in enumerate(tris):
+        p1, p2, p3 = triangle
+        coords = [(aligned_df.iloc[p]['X'], aligned_df.iloc[p]['Y']) for p in (p1, p2, p3)]
+        before.append(ref.helpers.calculate_signed_area(*coords))
+    for tri_idx, triangle in enumerate(tris):
+        matched = [p in aligned_to_ref for p in triangle]
+        m3.append(matched)
+        if not all(matched):
+            after.append(np.nan)
+            continue
+        rc = [(ref_df.iloc[aligned_to_ref[p]]['X'], ref_df.iloc[aligned_to_ref[p]]['Y']) for p in triangle]
+        area = ref.helpers.calculate_signed_area(rc[0], rc[1], rc[2])
+        after.append(area)
+        if before[tri_idx] * area < 0:
+            flipped.append(tri_idx)
+    return np.array(before), np.array(after), np.array(flipped, dtype=np.int64), np.array(m3, dtype=np.uint8)
+
+
+def simplex_map(n, tris):
+    """src/same.py:1096-1099."""
+    m = {i: set() for i in range(n)}
+    for idx, simplex in enumerate(tris):
+        for i in simplex:
+            m[i].add(idx)
+    return m
+
+
+def violations_to_arrays(v):
+    def rows(lst):
+        return np.array([(d['triangle_idx'], d['point1']['aligned_idx'], d['point2']['aligned_idx'],
+                          d['point1']['ref_idx'], d['point2']['ref_idx']) for d in lst], dtype=np.int64).reshape(-1, 5)
+    s = v['violation_summary']
+    return {
+        'viol_x': rows(v['x_order_violations']), 'viol_y': rows(v['y_order_violations']),
+        'viol_tris': np.array(sorted(int(t) for t in v['triangles_with_violations']), dtype=np.int64),
+        'viol_points': np.array(sorted(int(p) for p in v['points_with_violations']), dtype=np.int64),
+        'viol_summary': np.array([s['total_triangles'], s['violated_triangles'], s['total_comparisons'],
+                                  s['total_violations']], dtype=np.int64),
+        'viol_percent': np.array([s['percent_triangles_violated'], s['percent_violations']], dtype=np.float64),
+    }
+
+
+def frame_arrays(prefix, df, commonCT):
+    return {f'{prefix}_xy': df[['X', 'Y']].to_numpy(dtype=np.float64),
+            f'{prefix}_types': df[list(commonCT)].to_numpy(dtype=np.float64),
+            f'{prefix}_cell_type': df['cell_type'].to_numpy().astype(str),
+            f'{prefix}_size': df['size'].to_numpy(dtype=np.float64)}
+
+
+def full_case(name, aligned_in, ref_in, commonCT, radius, knn, min_angle_deg, dist_ct_coeff, no_match_penalty,
+              cost_sample=None, seed=0, do_hungarian=True):
+    """One end-to-end pass of the pre-MIP path + sweeps through the reference, saved as a fixture."""
+    print(f"[{name}] n_mov={len(aligned_in)} n_ref={len(ref_in)} T={len(commonCT)} r={radius} k={knn}")
+    out = {'commonCT': np.array(commonCT), 'params': np.array([radius, knn, -1 if min_angle_deg is None else min_angle_deg,
+                                                                 dist_ct_coeff, no_match_penalty], dtype=np.float64)}
+    out.update(frame_arrays('in_aligned', aligned_in, commonCT))
+    out.update(frame_arrays('in_ref', ref_in, commonCT))
+
+    # a2 -------------------------------------------------------------------------------
+    a_df, r_df, pairs = quiet(ref.utils.find_knn_within_radius, aligned_in, ref_in, radius, knn=knn)
+    pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+    out['pairs'] = pairs
+    out['kept_aligned'] = a_df['__row'].to_numpy(dtype=np.int64)
+    out['kept_ref'] = r_df['__row'].to_numpy(dtype=np.int64)
+    print(f"  pairs={len(pairs)} aligned_kept={len(a_df)} ref_kept={len(r_df)}")
+
+    # a3 -------------------------------------------------------------------------------
+    _, _, prio = quiet(ref.knn_utils.find_knn_with_cell_type_priority, aligned_in, ref_in, radius, knn=knn)
+    out['pairs_priority'] = np.asarray(prio, dtype=np.int64).reshape(-1, 2)
+
+    # a4 -------------------------------------------------------------------------------
+    if cost_sample is not None and cost_sample < len(pairs):
+        sel = np.sort(np.random.default_rng(seed).choice(len(pairs), cost_sample, replace=False))
+    else:
+        sel = np.arange(len(pairs))
+    out['cost_sel'] = sel
+    out['costs'] = ref_pair_costs(a_df, r_df, [tuple(p) for p in pairs[sel]], list(commonCT), dist_ct_coeff)
+    out['costs_w2p5'] = ref_pair_costs(a_df, r_df, [tuple(p) for p in pairs[sel[:200]]], list(commonCT), 2.5)
+
+    # a6 (scipy, host input) + a7 ------------------------------------------------------
+    axy = a_df[['X', 'Y']].values
+    tris0 = Delaunay(axy).simplices
+    out['delaunay'] = tris0.astype(np.int64)
+    for tag, kw in (('plain', dict(ignore_same_type_triangles=False, min_angle_deg=min_angle_deg)),
+                    ('type', dict(ignore_same_type_triangles=True, min_angle_deg=min_angle_deg)),
+                    ('noangle', dict(ignore_same_type_triangles=True, min_angle_deg=None)),
+                    ('a30', dict(ignore_same_type_triangles=True, min_angle_deg=30, ensure_min_triangle_per_node=False))):
+        kept, unc = quiet(ref.helpers.filter_triangles_by_radius, axy, tris0, radius, aligned_df=a_df,
+                          remove_unconstrained_nodes=True, **kw)
+        out[f'tri_{tag}'] = np.array(kept, dtype=np.int64).reshape(-1, 3)
+        out[f'unc_{tag}'] = np.array(sorted(unc), dtype=np.int64)
+        print(f"  filter[{tag}]: {len(tris0)} -> {len(kept)} (unconstrained {len(unc)})")
+    # a tighter radius to exercise the radius rule and unconstrained nodes
+    kept, unc = quiet(ref.helpers.filter_triangles_by_radius, axy, tris0, radius * 0.35, aligned_df=a_df,
+                      ignore_same_type_triangles=True, remove_unconstrained_nodes=True, min_angle_deg=min_angle_deg)
+    out['tri_tight'] = np.array(kept, dtype=np.int64).reshape(-1, 3)
+    out['unc_tight'] = np.array(sorted(unc), dtype=np.int64)
+
+    tris = out['tri_plain']
+    # a8 -------------------------------------------------------------------------------
+    w, s = ref_weights_signs(a_df, tris)
+    out['tri_weights'], out['source_signs'] = w, s
+
+    # a9 -------------------------------------------------------------------------------
+    smap = simplex_map(len(a_df), tris)
+    tinfo = ref.helpers.precompute_triangle_info(a_df, tris, smap)
+    keys = list(tinfo.keys())
+    out['tinfo_keys'] = np.array(keys, dtype=np.int64)
+    out['tinfo_bounds'] = np.array([[tinfo[k]['bounds'][q] for q in ('min_x', 'max_x', 'min_y', 'max_y')] for k in keys]).reshape(-1, 4)
+    out['tinfo_extreme'] = np.array([[tinfo[k][q] for q in ('max_x_vertex', 'min_x_vertex', 'max_y_vertex', 'min_y_vertex')] for k in keys],
+                                    dtype=np.int64).reshape(-1, 4)
+
+    # a5 -------------------------------------------------------------------------------
+    full_costs = out['costs'] if len(sel) == len(pairs) else None
+    if full_costs is None:
+        # the start heuristics need every pair cost: take them from a vectorised evaluation that the
+        # sampled literal loop above pins (checked equal on the sample before use)
+        A = a_df[list(commonCT)].to_numpy(); R = r_df[list(commonCT)].to_numpy()
+        d = np.abs(A[pairs[:, 0]] - R[pairs[:, 1]])
+        acc = np.zeros(len(pairs))
+        for t in range(d.shape[1]):
+            acc = acc + d[:, t]
+        rxy = r_df[['X', 'Y']].values
+        full_costs = dist_ct_coeff * acc + (dist_ct_coeff * 0.001) * (np.abs(axy[pairs[:, 0], 0] - rxy[pairs[:, 1], 0]) +
+                                                                      np.abs(axy[pairs[:, 0], 1] - rxy[pairs[:, 1], 1]))
+        assert np.array_equal(full_costs[sel], out['costs'])
+    out['all_costs'] = full_costs
+    vp = [tuple(int(q) for q in p) for p in pairs]
+    sizes = a_df['size'].to_numpy(dtype=float)
+    chosen, unmatched = quiet(ref.init_helpers.compute_mip_start_pairs, valid_pairs=vp, costs=list(full_costs),
+                              n_aligned=len(a_df), n_ref=len(r_df), aligned_sizes=sizes, no_match_penalty=no_match_penalty,
+                              max_matches=1, init_method='greedy', verbose=False)
+    out['greedy_chosen'] = np.array(chosen, dtype=np.int64).reshape(-1, 3)
+    out['greedy_unmatched'] = np.array(sorted(unmatched), dtype=np.int64)
+    # a low penalty makes "prefer unmatched" bite
+    chosen_lo, unmatched_lo = quiet(ref.init_helpers.compute_mip_start_pairs, valid_pairs=vp, costs=list(full_costs),
+                                    n_aligned=len(a_df), n_ref=len(r_df), aligned_sizes=sizes,
+                                    no_match_penalty=float(np.median(full_costs)), max_matches=1, init_method='greedy', verbose=False)
+    out['greedy_lo_penalty'] = np.array([float(np.median(full_costs))])
+    out['greedy_lo_chosen'] = np.array(chosen_lo, dtype=np.int64).reshape(-1, 3)
+    out['greedy_lo_unmatched'] = np.array(sorted(unmatched_lo), dtype=np.int64)
+    if do_hungarian:
+        ch, un = quiet(ref.init_helpers.compute_mip_start_pairs, valid_pairs=vp, costs=list(full_costs),
+                       n_aligned=len(a_df), n_ref=len(r_df), aligned_sizes=sizes, no_match_penalty=no_match_penalty,
+                       max_matches=1, init_method='hungarian', init_hungarian_max_n=100000, verbose=False)
+        out['hungarian_chosen'] = np.array(ch, dtype=np.int64).reshape(-1, 3)
+        out['hungarian_unmatched'] = np.array(sorted(un), dtype=np.int64)
+    print(f"  greedy start: {len(chosen)} matched / {len(unmatched)} unmatched")
+
+    # a10 under the greedy matching ------------------------------------------------------
+    x_vals = np.zeros(len(pairs))
+    x_vals[out['greedy_chosen'][:, 2]] = 1.0
+    out['x_vals'] = x_vals
+    checked, viol = ref_lazy_sweep(x_vals, vp, tris, s, r_df)
+    out['lazy_checked'] = np.array([checked], dtype=np.int64)
+    out['lazy_violating'] = viol
+    print(f"  lazy sweep: checked={checked} violating={len(viol)}")
+
+    # a11 --------------------------------------------------------------------------------
+    matches_df = pd.DataFrame({'aligned_idx': out['greedy_chosen'][:, 0], 'ref_idx': out['greedy_chosen'][:, 1]})
+    v = ref.violationhelper.verify_spatial_preservation(aligned_df=a_df, ref_df=r_df, matches_df=matches_df, triangle_info=tinfo)
+    out.update(violations_to_arrays(v))
+    print(f"  xy-order: {v['violation_summary']}")
+
+    # a12 --------------------------------------------------------------------------------
+    a2r = {int(i): int(j) for i, j, _ in out['greedy_chosen']}
+    before, after, flipped, m3 = ref_area_flips(a_df, r_df, tris, a2r)
+    out.update({'area_before': before, 'area_after': after, 'area_flipped': flipped, 'area_matched3': m3})
+    print(f"  area flips: {len(flipped)}")
+
+    # a14 (sample) -----------------------------------------------------------------------
+    rng = np.random.default_rng(seed + 7)
+    rdict = {i: {'X': r_df.iloc[i]['X'], 'Y': r_df.iloc[i]['Y']} for i in range(len(r_df))}
+    combos = rng.integers(0, len(r_df), size=(2000, 3))
+    out['eager_combos'] = combos.astype(np.int64)
+    out['eager_signs'] = np.array([ref.helpers.calc_ref_area(((int(a), int(b), int(c)), rdict)) for a, b, c in combos], dtype=np.int8)
+
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **out)
+
+
+def add_row_ids(df):
+    df = df.copy()
+    df['__row'] = np.arange(len(df))
+    if 'size' not in df.columns:
+        df['size'] = 1
+    return df
+
+
+# ------------------------------------------------------------------ restricted unpickler
+class _Restricted(pickle.Unpickler):
+    ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+               ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy.core.multiarray', 'scalar'),
+               ('numpy._core.multiarray', 'scalar'), ('builtins', 'set')}
+
+    def find_class(self, module, name):
+        if (module, name) in self.ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"blocked global {module}.{name}")
+
+
+def load_var_out(path):
+    with open(path, 'rb') as f:
+        version = np.lib.format.read_magic(f)
+        np.lib.format._read_array_header(f, version)
+        obj = _Restricted(f).load()
+    return obj.item() if isinstance(obj, np.ndarray) else obj
+
+
+def stored_run_case(name):
+    """examples/simulated_{st,elastic}: outputs stored by the reference authors' own run."""
+    d = os.path.join(REF_ROOT, 'examples', name)
+    a_df = pd.read_csv(os.path.join(d, 'aligned_df.csv'))
+    r_df = pd.read_csv(os.path.join(d, 'ref_df.csv'))
+    m_df = pd.read_csv(os.path.join(d, 'matches_df.csv'))
+    var_out = load_var_out(os.path.join(d, 'var_out.npy'))
+    tinfo = var_out['triangle_data']['triangle_info']
+    keys = list(tinfo.keys())
+    out = {'aligned_xy': a_df[['X', 'Y']].to_numpy(dtype=np.float64), 'ref_xy': r_df[['X', 'Y']].to_numpy(dtype=np.float64),
+           'matches': m_df[['aligned_idx', 'ref_idx']].to_numpy(dtype=np.int64),
+           'tinfo_keys': np.array(keys, dtype=np.int64),
+           'tinfo_vertices': np.array([list(tinfo[k]['vertices']) for k in keys], dtype=np.int64)}
+    stored = violations_to_arrays(var_out['violations'])
+    out.update({f'stored_{k}': v for k, v in stored.items()})
+    v = ref.violationhelper.verify_spatial_preservation(aligned_df=a_df, ref_df=r_df, matches_df=m_df, triangle_info=tinfo)
+    out.update(violations_to_arrays(v))
+    print(f"[{name}] stored summary {stored['viol_summary']} recomputed {out['viol_summary']}")
+    np.savez_compressed(os.path.join(OUT, f'{name}.npz'), **out)
+
+
+def adversarial_case():
+    """Exact ties, collinear triples, duplicates, unmatched vertices, empty inputs."""
+    out = {}
+    # regular grid: many exact distance ties; reference order inside a tie group is unspecified
+    g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0)), -1).reshape(-1, 2)
+    a_df = add_row_ids(pd.DataFrame({'X': g[:, 0] + 0.25, 'Y': g[:, 1] + 0.25, 'cell_type': 'c1', 'c1': 100.0}))
+    r_df = add_row_ids(pd.DataFrame({'X': g[:, 0], 'Y': g[:, 1], 'cell_type': 'c1', 'c1': 100.0}))
+    _, _, pairs = quiet(ref.utils.find_knn_within_radius, a_df, r_df, 1.5, knn=6)
+    out['grid_axy'], out['grid_rxy'], out['grid_pairs'] = a_df[['X', 'Y']].values, r_df[['X', 'Y']].values, np.asarray(pairs, dtype=np.int64)
+    # sparse coverage: small radius drops aligned rows and refs, so the compaction re-indexing matters
+    rs = synth.make_cells(400, 4, seed=3, side=100.0)
+    ms = synth.make_cells(300, 4, seed=4, side=100.0)
+    sa, sr = add_row_ids(synth.to_frame(ms)), add_row_ids(synth.to_frame(rs))
+    na, nr, pairs = quiet(ref.utils.find_knn_within_radius, sa, sr, 4.0, knn=3)
+    out['sparse_axy'], out['sparse_rxy'] = ms['xy'], rs['xy']
+    out['sparse_pairs'] = np.asarray(pairs, dtype=np.int64)
+    out['sparse_kept_aligned'] = na['__row'].to_numpy(dtype=np.int64)
+    out['sparse_kept_ref'] = nr['__row'].to_numpy(dtype=np.int64)
+    # radius boundary: points at exactly r (3-4-5 triangles) must be included (<=)
+    a2 = add_row_ids(pd.DataFrame({'X': [0.0, 10.0], 'Y': [0.0, 10.0], 'cell_type': 'c1', 'c1': 1.0}))
+    r2 = add_row_ids(pd.DataFrame({'X': [3.0, 4.0, 5.0, 13.0, 10.0, 3.0000000001], 'Y': [4.0, 3.0, 0.0, 14.0, 15.0000001, 4.0],
+                                   'cell_type': 'c1', 'c1': 1.0}))
+    na, nr, pairs = quiet(ref.utils.find_knn_within_radius, a2, r2, 5.0, knn=4)
+    out['edge_axy'], out['edge_rxy'] = a2[['X', 'Y']].values, r2[['X', 'Y']].values
+    out['edge_pairs'] = np.asarray(pairs, dtype=np.int64)
+    out['edge_kept_ref'] = nr['__row'].to_numpy(dtype=np.int64)
+    # triangles: collinear, duplicate vertex, right isosceles at the 45-degree threshold, tiny
+    pts = np.array([[0, 0], [1, 0], [2, 0], [0, 1], [1, 1], [5, 5], [5.0000001, 5], [5, 5.0000001], [0, 0], [3, 0], [0, 3]], dtype=float)
+    tr = np.array([[0, 1, 2], [0, 1, 3], [1, 4, 3], [5, 6, 7], [0, 8, 1], [0, 9, 10], [3, 4, 1], [2, 1, 0]])
+    tdf = add_row_ids(pd.DataFrame({'X': pts[:, 0], 'Y': pts[:, 1], 'cell_type': ['a', 'a', 'a', 'b', 'a', 'a', 'a', 'a', 'a', 'b', 'b']}))
+    out['adv_pts'], out['adv_tris'] = pts, tr.astype(np.int64)
+    out['adv_type'] = tdf['cell_type'].to_numpy().astype(str)
+    for tag, kw in (('45', dict(min_angle_deg=45, ignore_same_type_triangles=False)),
+                    ('45t', dict(min_angle_deg=45, ignore_same_type_triangles=True)),
+                    ('none', dict(min_angle_deg=None, ignore_same_type_triangles=True)),
+                    ('0', dict(min_angle_deg=0, ignore_same_type_triangles=False)),
+                    ('15', dict(min_angle_deg=15, ignore_same_type_triangles=True))):
+        for rad in (10.0, 3.0, 1.0):
+            with np.errstate(all='ignore'):
+                kept, unc = quiet(ref.helpers.filter_triangles_by_radius, pts, tr, rad, aligned_df=tdf, remove_unconstrained_nodes=True, **kw)
+            out[f'adv_kept_{tag}_{rad}'] = np.array(kept, dtype=np.int64).reshape(-1, 3)
+            out[f'adv_unc_{tag}_{rad}'] = np.array(sorted(unc), dtype=np.int64)
+    w, s = ref_weights_signs(add_row_ids(tdf), tr)
+    out['adv_signs'] = s
+    # empty triangle list
+    kept = quiet(ref.helpers.filter_triangles_by_radius, pts, np.zeros((0, 3), dtype=int), 10.0, aligned_df=tdf, ignore_same_type_triangles=True)
+    out['adv_empty_kept'] = np.array(kept, dtype=np.int64).reshape(-1, 3)
+    # sweeps with unmatched vertices, duplicate aligned rows in matches (last wins), collinear ref triple
+    rxy = np.array([[0, 0], [1, 0], [2, 0], [0, 1], [1, 1], [0.5, 0.5], [2, 2]], dtype=float)
+    rdf = pd.DataFrame({'X': rxy[:, 0], 'Y': rxy[:, 1]})
+    adf = pd.DataFrame({'X': pts[:, 0], 'Y': pts[:, 1]})
+    m_df = pd.DataFrame({'aligned_idx': [0, 1, 3, 4, 1, 9, 10], 'ref_idx': [4, 1, 0, 3, 2, 5, 6]})
+    smap = simplex_map(len(adf), tr)
+    tinfo = ref.helpers.precompute_triangle_info(adf, tr, smap)
+    v = ref.violationhelper.verify_spatial_preservation(aligned_df=adf, ref_df=rdf, matches_df=m_df, triangle_info=tinfo)
+    out['sw_rxy'] = rxy
+    out['sw_matches'] = m_df.to_numpy(dtype=np.int64)
+    out['sw_tinfo_keys'] = np.array(list(tinfo.keys()), dtype=np.int64)
+    out.update({f'sw_{k}': val for k, val in violations_to_arrays(v).items()})
+    a2r = {}
+    for a, r in m_df.to_numpy():
+        a2r[int(a)] = int(r)
+    before, after, flipped, m3 = ref_area_flips(adf, rdf, tr, a2r)
+    out.update({'sw_area_before': before, 'sw_area_after': after, 'sw_area_flipped': flipped, 'sw_area_matched3': m3})
+    # lazy sweep: pairs listed so that a later x>0.5 overrides an earlier one
+    vp = [(0, 4), (1, 1), (1, 2), (3, 0), (4, 3), (9, 5), (10, 6), (2, 2)]
+    xv = np.array([1, 1, 0.9, 1, 0.6, 1, 1, 0.2])
+    checked, viol = ref_lazy_sweep(xv, vp, tr, s, rdf)
+    out['sw_pairs'], out['sw_x'] = np.array(vp, dtype=np.int64), xv
+    out['sw_lazy_checked'], out['sw_lazy_violating'] = np.array([checked]), viol
+    np.savez_compressed(os.path.join(OUT, 'adversarial.npz'), **out)
+    print(f"[adversarial] grid pairs {len(out['grid_pairs'])}, edge pairs {out['edge_pairs'].tolist()}, lazy {checked}/{viol.tolist()}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # (1) the shipped synthetic example with the paper's parameters (examples/synthetic/run_same.sh:34-54)
+    d = os.path.join(REF_ROOT, 'examples', 'synthetic', 'data')
+    ref_df = add_row_ids(pd.read_csv(os.path.join(d, 'ref.csv'), index_col=0))
+    qry_df = add_row_ids(pd.read_csv(os.path.join(d, 'query.csv'), index_col=0))
+    full_case('synthetic_example', qry_df, ref_df, ['c1', 'c2', 'c3'], radius=5, knn=8, min_angle_deg=5,
+              dist_ct_coeff=1, no_match_penalty=10000)
+    # (2) BASELINE cfg1 shape: 500x500, T=5, k=8, r=10 on side 100
+    r = synth.make_cells(500, 5, seed=0, side=100.0)
+    m = synth.make_cells(500, 5, seed=1, side=100.0)
+    full_case('cfg1_500', add_row_ids(synth.to_frame(m)), add_row_ids(synth.to_frame(r)), synth.type_columns(5),
+              radius=10, knn=8, min_angle_deg=15, dist_ct_coeff=1, no_match_penalty=100)
+    # (3) cfg2 shape at reduced size: T=20, k=32, r=25, density 0.01; moving = jittered ref
+    r = synth.make_cells(1500, 20, seed=0)
+    m = synth.make_jittered(r, seed=1)
+    full_case('cfg2_small', add_row_ids(synth.to_frame(m)), add_row_ids(synth.to_frame(r)), synth.type_columns(20),
+              radius=25, knn=32, min_angle_deg=15, dist_ct_coeff=1, no_match_penalty=100, cost_sample=3000,
+              do_hungarian=True)
+    # (4) outputs stored by the reference authors
+    stored_run_case('simulated_st')
+    stored_run_case('simulated_elastic')
+    # (5) adversarial
+    adversarial_case()
+    sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith('.npz')}
+    print(json.dumps(sizes, indent=1))
+
+
+if __name__ == '__main__':
+    main()
