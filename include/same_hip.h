@@ -1,0 +1,206 @@
+/*
+ * same_hip.h -- C ABI of libsame_hip.so: the MI355X (gfx950) implementation of SAME's
+ * pre-MIP data-parallel path.
+ *
+ * The reference (rohitsinghlab/SAME) is pure Python and has no FFI; its boundary for this
+ * path is a set of Python functions and inline loops.  Each entry
+ * point below names the reference code it replaces (file:line into the reference tree).
+ * The Python host layer in same_amd/ keeps the reference's signatures and calls these
+ * through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes only, no C++/torch types.
+ *  - every function returns 0 on success or a negative SAME_E* code; on failure outputs are
+ *    unspecified but never written out of bounds.  same_strerror() names the code and
+ *    same_last_error() returns the HIP/RCCL detail recorded on the context.
+ *  - "host" entry points take caller-owned, C-contiguous host buffers; the library copies
+ *    in, runs on the context's own stream, copies out and is synchronous on return.  It
+ *    never keeps a host pointer past the call.
+ *  - "_dev" entry points take device pointers obtained from same_dev_alloc() and only
+ *    enqueue work on the context's stream (call same_ctx_sync() to wait).  They exist so
+ *    large operands (the dense cost matrix is 80 GB at 100k x 100k) stay resident in HBM.
+ *  - indices are int32, sizes int64.  pairs are int32 [P][2] = (aligned i, ref j).
+ *    triangles are int32 [Tr][3] of aligned-row indices.  xy arrays are double [n][2].
+ *    type matrices are row-major double [n][T] (the commonCT columns, in commonCT order).
+ *  - threading: a context is used by one caller at a time; any thread may make the call
+ *    (every entry point selects the context's device itself).
+ */
+#ifndef SAME_HIP_H
+#define SAME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAME_OK 0
+#define SAME_EINVAL (-22)   /* bad shape / NULL / unsupported size */
+#define SAME_ENOMEM (-12)   /* host or device allocation failed */
+#define SAME_EIO (-5)       /* HIP or RCCL call failed; see same_last_error() */
+#define SAME_ENODEV (-19)   /* no usable GPU */
+#define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
+
+#define SAME_ABI_VERSION 1
+#define SAME_MAX_KNN 64      /* largest k supported by the prune kernel */
+#define SAME_MAX_TYPES 4096  /* largest T (type columns) */
+
+typedef struct same_ctx same_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int same_abi_version(void);
+int same_device_count(int *out_count);
+int same_ctx_create(int device, same_ctx **out);
+void same_ctx_destroy(same_ctx *ctx);
+int same_ctx_sync(same_ctx *ctx);
+const char *same_strerror(int code);
+const char *same_last_error(same_ctx *ctx);
+/* device name, CU count, HBM bytes (any pointer may be NULL) */
+int same_ctx_info(same_ctx *ctx, char *name, size_t name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- device memory + timing (for resident operands and in-library kernel timing) ------ */
+int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr);
+int same_dev_free(same_ctx *ctx, void *dptr);
+int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* HIP events recorded on the context's stream (where the kernels run). */
+int same_timer_start(same_ctx *ctx);
+int same_timer_stop(same_ctx *ctx, float *out_ms); /* records, synchronises, returns elapsed ms */
+
+/* ---- a4: pair costs -------------------------------------------------------------------
+ * Replaces the loop at src/same.py:1180-1189:
+ *   c[p] = w * sum_t |A[i,t]-R[j,t]|  +  (w*0.001) * (|ax-rx| + |ay-ry|),  (i,j) = pairs[p]
+ * with the type sum accumulated left to right in fp64 and no fused multiply-add. */
+int same_pair_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r,
+                       int T, const double *axy, const double *rxy, const int32_t *pairs,
+                       int64_t P, double w, double *out_c);
+
+/* ---- dense cost tile builder ----------------------------------------------------------
+ * The same expression for every (i, j), i in [row_begin,row_end), j in [0,n_r):
+ *   out[(i-row_begin)*ld + j].  Generalises the only dense matrix of the reference
+ * (src/init_helpers.py:151-155) to the metric of BASELINE.json (100k x 100k).
+ * _dev: all pointers are device pointers; A/R/axy/rxy hold the full arrays. */
+int same_dense_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
+                            const double *daxy, const double *drxy, int64_t n_r,
+                            int64_t row_begin, int64_t row_end, double w, double *dout, int64_t ld);
+int same_dense_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T,
+                            const float *daxy, const float *drxy, int64_t n_r, int64_t row_begin,
+                            int64_t row_end, float w, float *dout, int64_t ld);
+/* host-buffer forms (copy in, build, copy out) */
+int same_dense_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r,
+                        int T, const double *axy, const double *rxy, int64_t row_begin,
+                        int64_t row_end, double w, double *out, int64_t ld);
+int same_dense_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_m, int64_t n_r,
+                        int T, const float *axy, const float *rxy, int64_t row_begin,
+                        int64_t row_end, float w, float *out, int64_t ld);
+
+/* ---- a2: KNN prune within a radius ----------------------------------------------------
+ * Replaces the per-row body of utils.find_knn_within_radius (src/utils.py:720-728):
+ * for aligned rows [row_begin,row_end): refs with dx*dx+dy*dy <= radius*radius (cKDTree
+ * query_ball_point, p=2), ranked by (squared distance, ref index) ascending, first k kept.
+ * out_idx[(i-row_begin)*k + q] (-1 padded), out_d2 likewise (+inf padded; may be NULL),
+ * out_cnt[i-row_begin] = number kept.  The frame compaction of src/utils.py:734-742 stays
+ * on the host (same_amd/knn.py). */
+int same_knn_prune(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy, int64_t n_r,
+                   int64_t row_begin, int64_t row_end, double radius, int k, int32_t *out_idx,
+                   double *out_d2, int32_t *out_cnt);
+int same_knn_prune_dev(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r,
+                       int64_t row_begin, int64_t row_end, double radius, int k,
+                       int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt);
+/* costs of the padded candidate lists (a2 + a4 fused for the sharded path):
+ * out_cost[(i-row_begin)*k + q] = pair cost of (i, idx[..]) or +inf where idx == -1. */
+int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
+                             const double *daxy, const double *drxy, int64_t row_begin,
+                             int64_t row_end, int k, const int32_t *didx, double w,
+                             double *dout_cost);
+
+/* ---- a7: triangle classes -------------------------------------------------------------
+ * Replaces the per-triangle decisions of helpers.filter_triangles_by_radius
+ * (src/helpers.py:303-341).  out_class: 0 kept, 1 max side >= radius, 2 min angle too
+ * small, 3 passed both but all three type_id equal (type_id NULL = test off).
+ * The angle rule degrees(arccos(c)) < min_angle_deg is passed as a cosine threshold
+ * (angle_enabled, cos_thr): fails iff clipped cosine >= cos_thr; out_maxcos gets the
+ * largest clipped corner cosine (2.0 if a side has zero length).  out_perim = s1+s2+s3.
+ * The re-add pass (src/helpers.py:365-389) stays on the host (same_amd/triangles.py). */
+int same_tri_classify(same_ctx *ctx, const double *xy, int64_t n_pts, const int32_t *tris,
+                      int64_t Tr, double radius, int angle_enabled, double cos_thr,
+                      const int32_t *type_id, uint8_t *out_class, double *out_perim,
+                      double *out_maxcos);
+
+/* ---- a8: triangle weights and source orientation signs --------------------------------
+ * Replaces src/same.py:1128-1135 and :1139-1146.  size/out_weight may both be NULL. */
+int same_tri_sign_weight(same_ctx *ctx, const double *xy, const double *size, int64_t n_pts,
+                         const int32_t *tris, int64_t Tr, int8_t *out_sign, double *out_weight);
+
+/* ---- a10: lazy-constraint orientation sweep -------------------------------------------
+ * Replaces the body of _lazy_orientation_callback (src/same.py:631-669).
+ * same_sweep_bind keeps triangles, source signs, reference XY and the pair list resident
+ * (the model._* state of src/same.py:1153-1158); pairs may be NULL when only
+ * same_orient_sweep (match-vector form) is used.
+ * same_orient_sweep_x: x_vals[P] -> matching (last pair with x > 0.5 wins per aligned row,
+ * src/same.py:634-639) -> sweep.  out_viol_idx needs room for Tr entries and comes out
+ * ascending; out_flag (may be NULL): 0 skipped, 1 checked, 2 flipped;
+ * out_match / out_pair_idx (may be NULL): the matching and its pair indices (for cbLazy). */
+int same_sweep_bind(same_ctx *ctx, const int32_t *tris, int64_t Tr, const int8_t *src_sign,
+                    const double *rxy, int64_t n_r, int64_t n_m, const int32_t *pairs, int64_t P);
+int same_orient_sweep(same_ctx *ctx, const int32_t *match, int64_t *out_checked,
+                      int32_t *out_viol_idx, int64_t *out_nviol, uint8_t *out_flag);
+int same_orient_sweep_x(same_ctx *ctx, const double *x_vals, int64_t *out_checked,
+                        int32_t *out_viol_idx, int64_t *out_nviol, uint8_t *out_flag,
+                        int32_t *out_match, int32_t *out_pair_idx);
+
+/* ---- a11: XY-order preservation sweep -------------------------------------------------
+ * Replaces the triangle loop of violationhelper.verify_spatial_preservation
+ * (src/violationhelper.py:53-117).  edge_flags[t*3+e]: bit0 compared, bit1 X violated,
+ * bit2 Y violated; e = (v0,v1),(v0,v2),(v1,v2).  counts = {comparisons, violations,
+ * violated triangles}.  point_flag[n_m]. */
+int same_xyorder_sweep(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy,
+                       int64_t n_r, const int32_t *tris, int64_t Tr, const int32_t *match,
+                       uint8_t *edge_flags, uint8_t *tri_flag, uint8_t *point_flag,
+                       int64_t counts[3]);
+
+/* ---- a12: signed areas before/after and flips -----------------------------------------
+ * Replaces src/same.py:1362-1402 with helpers.calculate_signed_area (src/helpers.py:73-77).
+ * after = NaN unless all three vertices are matched. */
+int same_area_flip(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy, int64_t n_r,
+                   const int32_t *tris, int64_t Tr, const int32_t *match, double *out_before,
+                   double *out_after, uint8_t *out_matched3, uint8_t *out_flipped);
+
+/* ---- a5: MIP-start helpers ------------------------------------------------------------
+ * Per-row minimum pair cost (src/init_helpers.py:118-122; +inf for rows without pairs) and
+ * the dense assignment matrix [n_m][n_r+n_m] (src/init_helpers.py:151-155). */
+int same_pair_rowmin(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P,
+                     int64_t n_m, double *out_min);
+int same_assign_matrix(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P,
+                       const double *unmatched, int64_t n_m, int64_t n_r, double big_m,
+                       double *out);
+
+/* ---- a14: eager reference-orientation signs -------------------------------------------
+ * Replaces calc_ref_area over all candidate combinations (src/helpers.py:425-441,455-510):
+ * out[((t*k+x)*k+y)*k+z] = sign(round(cross, 3)) for cand[tris[t][0]][x], ..., 2 if any is -1. */
+int same_eager_signs(same_ctx *ctx, const double *rxy, int64_t n_r, const int32_t *tris,
+                     int64_t Tr, const int32_t *cand, int64_t n_m, int k, int8_t *out);
+
+/* ---- a13: window membership -----------------------------------------------------------
+ * subset_data (src/same.py:293-295) for a batch of boxes: boxes[b] = {x0,x1,y0,y1},
+ * half-open.  out_count[b] = rows inside; out_mask (may be NULL) [n_boxes][n]. */
+int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *boxes,
+                      int64_t n_boxes, int64_t *out_count, uint8_t *out_mask);
+
+/* ---- multi-GPU: RCCL all-gather of the pruned candidate lists -------------
+ * One process per GPU.  Rank 0 calls same_comm_unique_id and hands the 128 bytes to the
+ * other ranks by any host channel; all ranks then call same_comm_init.  same_allgather_dev
+ * gathers equal-sized device blocks (send_bytes each) into recv (nranks*send_bytes) on the
+ * context's stream. */
+#define SAME_UNIQUE_ID_BYTES 128
+int same_comm_unique_id(char out_id[SAME_UNIQUE_ID_BYTES]);
+int same_comm_init(same_ctx *ctx, int nranks, int rank, const char id[SAME_UNIQUE_ID_BYTES]);
+int same_comm_destroy(same_ctx *ctx);
+int same_allgather_dev(same_ctx *ctx, const void *dsend, void *drecv, size_t send_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAME_HIP_H */

@@ -1,0 +1,222 @@
+"""ctypes binding of libsame_hip.so (include/same_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no MI355X is
+visible when a compute entry point is called, this module raises.  Nothing here imports the
+oracle.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsame_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_flt = ctypes.c_float
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+UNIQUE_ID_BYTES = 128
+MAX_KNN = 64
+MAX_TYPES = 4096
+
+# name -> argtypes, exactly the declarations of include/same_hip.h (restype int unless noted)
+_PROTOTYPES = {
+    "same_abi_version": [],
+    "same_device_count": [ctypes.POINTER(c_int)],
+    "same_ctx_create": [c_int, ctypes.POINTER(c_vp)],
+    "same_ctx_destroy": [c_vp],
+    "same_ctx_sync": [c_vp],
+    "same_strerror": [c_int],
+    "same_last_error": [c_vp],
+    "same_ctx_info": [c_vp, ctypes.c_char_p, c_sz, ctypes.POINTER(c_int), ctypes.POINTER(c_i64)],
+    "same_dev_alloc": [c_vp, c_sz, ctypes.POINTER(c_vp)],
+    "same_dev_free": [c_vp, c_vp],
+    "same_h2d": [c_vp, c_vp, c_vp, c_sz],
+    "same_d2h": [c_vp, c_vp, c_vp, c_sz],
+    "same_dev_memset": [c_vp, c_vp, c_int, c_sz],
+    "same_timer_start": [c_vp],
+    "same_timer_stop": [c_vp, ctypes.POINTER(c_flt)],
+    "same_pair_cost_f64": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_dbl, c_vp],
+    "same_dense_cost_f64_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64],
+    "same_dense_cost_f32_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_flt, c_vp, c_i64],
+    "same_dense_cost_f64": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_i64],
+    "same_dense_cost_f32": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_flt, c_vp, c_i64],
+    "same_knn_prune": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp, c_vp, c_vp],
+    "same_knn_prune_dev": [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp, c_vp, c_vp],
+    "same_padded_cost_f64_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_dbl, c_vp],
+    "same_tri_classify": [c_vp, c_vp, c_i64, c_vp, c_i64, c_dbl, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
+    "same_tri_sign_weight": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "same_sweep_bind": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64],
+    "same_orient_sweep": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp],
+    "same_orient_sweep_x": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp, c_vp, c_vp],
+    "same_xyorder_sweep": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "same_area_flip": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "same_pair_rowmin": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
+    "same_assign_matrix": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_dbl, c_vp],
+    "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
+    "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "same_comm_unique_id": [c_vp],
+    "same_comm_init": [c_vp, c_int, c_int, c_vp],
+    "same_comm_destroy": [c_vp],
+    "same_allgather_dev": [c_vp, c_vp, c_vp, c_sz],
+}
+EXPORTS = tuple(_PROTOTYPES)
+
+
+class SameHipError(RuntimeError):
+    """A libsame_hip entry point returned a negative code."""
+
+    def __init__(self, code, what, detail=""):
+        self.code = code
+        super().__init__(f"{what}: {detail}" if detail else what)
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load libsame_hip.so (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise SameHipError(-2, f"{LIB_PATH} is missing; build it with `make -C same_amd/csrc` "
+                                       "(the product path has no CPU fallback)")
+            L = ctypes.CDLL(LIB_PATH)
+            for name, argtypes in _PROTOTYPES.items():
+                fn = getattr(L, name)
+                fn.argtypes = argtypes
+                fn.restype = c_int
+            L.same_strerror.restype = ctypes.c_char_p
+            L.same_last_error.restype = ctypes.c_char_p
+            L.same_ctx_destroy.restype = None
+            if L.same_abi_version() != 1:
+                raise SameHipError(-22, "libsame_hip ABI version mismatch")
+            _lib = L
+    return _lib
+
+
+def device_count():
+    n = c_int(0)
+    load().same_device_count(ctypes.byref(n))
+    return n.value
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def as_c(a, dtype):
+    """C-contiguous array of `dtype` (no copy when already so)."""
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class DeviceBuffer:
+    """A block of HBM owned by a Context (same_dev_alloc)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = c_vp()
+        ctx.check(ctx.lib.same_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(p)), "same_dev_alloc")
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.same_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes), "same_h2d")
+        return self
+
+    def download(self, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.same_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset_bytes, out.nbytes), "same_d2h")
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle:
+            self.ctx.lib.same_dev_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU, one stream (same_ctx).  Not shared between concurrent callers."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = c_vp()
+        rc = self.lib.same_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise SameHipError(rc, f"same_ctx_create(device={device})", self.lib.same_strerror(rc).decode())
+        self.handle = h.value
+        self.device = int(device)
+        self.lock = threading.Lock()
+
+    def check(self, rc, what):
+        if rc != 0:
+            detail = self.lib.same_last_error(self.handle).decode() if self.handle else ""
+            raise SameHipError(rc, f"{what}: {self.lib.same_strerror(rc).decode()}", detail)
+
+    def info(self):
+        name = ctypes.create_string_buffer(128)
+        cu, hbm = c_int(0), c_i64(0)
+        self.check(self.lib.same_ctx_info(self.handle, name, 128, ctypes.byref(cu), ctypes.byref(hbm)), "same_ctx_info")
+        return {"arch": name.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.alloc(max(arr.nbytes, 16)).upload(arr)
+
+    def sync(self):
+        self.check(self.lib.same_ctx_sync(self.handle), "same_ctx_sync")
+
+    def timer_start(self):
+        self.check(self.lib.same_timer_start(self.handle), "same_timer_start")
+
+    def timer_stop(self):
+        ms = c_flt(0)
+        self.check(self.lib.same_timer_stop(self.handle, ctypes.byref(ms)), "same_timer_stop")
+        return ms.value
+
+    def close(self):
+        if self.handle:
+            self.lib.same_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+_default_lock = threading.Lock()
+
+
+def default_context(device=None):
+    """Process-wide context for `device` (default: $SAME_HIP_DEVICE or LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("SAME_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device %= n
+    with _default_lock:
+        ctx = _default_ctx.get(device)
+        if ctx is None or not ctx.handle:
+            ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,498 @@
+"""Drop-in host layer: run_same / sliding_window_matching with the reference's signatures
+(src/same.py:706-716, :297-307), built on the HIP kernels.
+
+`prepare_same_inputs` is everything run_same does before the Gurobi model exists
+(src/same.py:933-1189): KNN prune + frame compaction, triangulation + filter, unconstrained
+node removal, simplex map / triangle_info, triangle weights, source signs, pair costs.  It is
+exposed separately so parity can be tested without a solver licence.  run_same hands those
+artefacts to gurobipy unchanged (same variable order, same constraint names) and replaces the
+per-incumbent Python loop of _lazy_orientation_callback with the device sweep.
+gurobipy is imported lazily: the pre-MIP path and the sweeps work without it.
+"""
+import os
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import pandas as pd
+
+from . import sweeps
+from .cost import pair_costs
+from .init_helpers import apply_mip_start
+from .knn import find_knn_with_cell_type_priority, find_knn_within_radius
+from .params import init_gurobi_params, init_optim_params
+from .triangles import (_remap_triangles_by_vertex_ids, build_simplex_map, filter_triangles_by_radius,
+                        precompute_coordinate_maps, precompute_triangle_info, triangle_weights_and_signs)
+
+
+def _say(verbose, *a):
+    if verbose:
+        print(*a)
+
+
+@dataclass
+class PreparedInputs:
+    """Every pre-MIP artefact of run_same, in the shapes Gurobi consumes."""
+    aligned_df: pd.DataFrame
+    ref_df: pd.DataFrame
+    valid_pairs: Any                      # (P,2) ndarray, or list of tuples after unconstrained-node removal
+    costs: List[float]                    # c[idx], same order as valid_pairs
+    aligned_delaunay: Any                 # list / array of 3-int rows; index = q_tri id
+    triangle_weights: List[float]
+    source_signs: List[float]
+    triangle_info: Dict[int, dict]
+    aligned_simplex_map: Dict[int, set]
+    valid_pairs_map: Dict[int, list]
+    aligned_coords: Dict[int, dict]
+    ref_coords: Dict[int, dict]
+    ref_coords_xy: Dict[int, tuple]       # model._ref_coords
+    unconstrained_nodes: set
+    using_precomputed: bool
+    n_aligned: int
+    n_ref: int
+    optim_params: Dict[str, Any] = field(default_factory=dict)
+    gurobi_params: Dict[str, Any] = field(default_factory=dict)
+
+
+def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, aligned_delaunay_vertex_col=None,
+                        optim_params=None, gurobi_params=None, ignore_precomputed_triangulation=False,
+                        verbose=True, ctx=None) -> PreparedInputs:
+    from scipy.spatial import Delaunay  # Qhull stays on the host: it is an input to the kernels
+
+    optim_params = dict(optim_params or {})
+    gurobi_params = dict(gurobi_params or {})
+    # MetaCell duck-typing (src/same.py:891-899)
+    if hasattr(aligned_df, "metacell_df") and hasattr(aligned_df, "metacell_delaunay"):
+        mc = aligned_df
+        aligned_df = mc.metacell_df
+        if aligned_delaunay is None and not ignore_precomputed_triangulation:
+            aligned_delaunay = mc.metacell_delaunay
+        if aligned_delaunay_vertex_col is None and hasattr(mc, "metacell_idx_col"):
+            aligned_delaunay_vertex_col = mc.metacell_idx_col
+        if (optim_params.get("cell_id_col") is None) and hasattr(mc, "metacell_idx_col"):
+            optim_params["cell_id_col"] = mc.metacell_idx_col
+    optim_params = init_optim_params(**optim_params)
+    gurobi_params = init_gurobi_params(**gurobi_params)
+    radius, knn = optim_params["radius"], optim_params["knn"]
+    dist_ct_coeff = optim_params["dist_ct_coeff"]
+    min_angle_deg = optim_params.get("min_angle_deg", 15)
+
+    # size defaults, stable ids (src/same.py:934-970)
+    if "size" not in aligned_df.columns:
+        aligned_df = aligned_df.copy()
+        aligned_df["size"] = 1
+    if "size" not in ref_df.columns:
+        ref_df = ref_df.copy()
+        ref_df["size"] = 1
+    aligned_df = aligned_df.copy()
+    ref_df = ref_df.copy()
+    if "__orig_idx" not in aligned_df.columns:
+        aligned_df["__orig_idx"] = aligned_df.index.to_numpy()
+    if "__orig_idx" not in ref_df.columns:
+        ref_df["__orig_idx"] = ref_df.index.to_numpy()
+    if aligned_delaunay_vertex_col is None:
+        aligned_df["__tri_vid"] = aligned_df.index.to_numpy()
+    else:
+        if aligned_delaunay_vertex_col not in aligned_df.columns:
+            raise ValueError(f"aligned_delaunay_vertex_col='{aligned_delaunay_vertex_col}' not in aligned_df")
+        aligned_df["__tri_vid"] = aligned_df[aligned_delaunay_vertex_col].to_numpy()
+
+    # KNN prune (src/same.py:972-979)
+    if optim_params["ignore_knn_if_matched"]:
+        aligned_df, ref_df, valid_pairs = find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+    else:
+        aligned_df, ref_df, valid_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+    n_aligned, n_ref = len(aligned_df), len(ref_df)
+    if len(valid_pairs) == 0:
+        raise ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
+
+    aligned_coords, ref_coords, valid_pairs_map = precompute_coordinate_maps(aligned_df, ref_df, valid_pairs)
+
+    # triangulation (src/same.py:1016-1031)
+    aligned_coords_array = aligned_df[["X", "Y"]].values
+    using_precomputed = False
+    if aligned_delaunay is None or ignore_precomputed_triangulation:
+        aligned_delaunay = Delaunay(aligned_coords_array).simplices
+    else:
+        using_precomputed = True
+        aligned_delaunay = _remap_triangles_by_vertex_ids(aligned_delaunay, vertex_ids=aligned_df["__tri_vid"].to_numpy())
+
+    # filter (src/same.py:1033-1053)
+    unconstrained_nodes = set()
+    if using_precomputed:
+        aligned_delaunay, unconstrained_nodes = filter_triangles_by_radius(
+            aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
+            ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], remove_unconstrained_nodes=True,
+            min_angle_deg=min_angle_deg, verbose=verbose, ctx=ctx)
+    else:
+        aligned_delaunay = filter_triangles_by_radius(
+            aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
+            ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], min_angle_deg=min_angle_deg,
+            verbose=verbose, ctx=ctx)
+
+    # unconstrained-node removal + re-index (src/same.py:1055-1085)
+    if unconstrained_nodes:
+        _say(verbose, f"\nRemoving {len(unconstrained_nodes)} unconstrained nodes from optimization...")
+        vp = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
+        keep_node = np.ones(len(aligned_df), bool)
+        keep_node[list(unconstrained_nodes)] = False
+        constrained_nodes = np.flatnonzero(keep_node)
+        old_to_new = np.full(len(aligned_df), -1, np.int64)
+        old_to_new[constrained_nodes] = np.arange(len(constrained_nodes))
+        vp = vp[keep_node[vp[:, 0]]]
+        valid_pairs = [(int(old_to_new[i]), int(j)) for i, j in vp]
+        tri = np.asarray(aligned_delaunay).reshape(-1, 3) if len(aligned_delaunay) else np.zeros((0, 3), dtype=int)
+        tri = tri[keep_node[tri].all(axis=1)] if len(tri) else tri
+        aligned_delaunay = old_to_new[tri] if len(tri) else np.array([]).reshape(0, 3)
+        aligned_df = aligned_df.iloc[constrained_nodes].reset_index(drop=True)
+        n_aligned = len(aligned_df)
+        aligned_coords, ref_coords, valid_pairs_map = precompute_coordinate_maps(aligned_df, ref_df, valid_pairs)
+
+    aligned_simplex_map = build_simplex_map(len(aligned_df), aligned_delaunay)
+    triangle_info = precompute_triangle_info(aligned_df, aligned_delaunay, aligned_simplex_map)
+    triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx)
+    rxy = ref_df[["X", "Y"]].to_numpy(dtype=np.float64)
+    ref_coords_xy = {j: (rxy[j, 0], rxy[j, 1]) for j in range(len(ref_df))}
+    costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx)
+
+    return PreparedInputs(aligned_df=aligned_df, ref_df=ref_df, valid_pairs=valid_pairs, costs=costs,
+                          aligned_delaunay=aligned_delaunay, triangle_weights=triangle_weights, source_signs=source_signs,
+                          triangle_info=triangle_info, aligned_simplex_map=aligned_simplex_map,
+                          valid_pairs_map=valid_pairs_map, aligned_coords=aligned_coords, ref_coords=ref_coords,
+                          ref_coords_xy=ref_coords_xy, unconstrained_nodes=unconstrained_nodes,
+                          using_precomputed=using_precomputed, n_aligned=n_aligned, n_ref=n_ref,
+                          optim_params=optim_params, gurobi_params=gurobi_params)
+
+
+# ------------------------------------------------------------------------------------------ callback
+def make_lazy_callback(GRB, sweep):
+    """cb(model, where) with the control flow of _lazy_orientation_callback (src/same.py:621-703);
+    the per-triangle loop is one device sweep."""
+
+    def _lazy_orientation_callback(model, where):
+        if where != GRB.Callback.MIPSOL:
+            return
+        max_cuts = getattr(model, "_lazy_max_cuts", None)
+        if max_cuts is not None and model._cuts_added >= max_cuts:
+            return
+        x_vals = model.cbGetSolution(model._x)
+        n = len(model._valid_pairs)
+        x_arr = np.fromiter((x_vals[i] for i in range(n)), dtype=np.float64, count=n)
+        remaining = None if max_cuts is None else max(0, max_cuts - model._cuts_added)
+        cuts = sweep.select_cuts(x_arr, getattr(model, "_lazy_allowed_flip_fraction", None),
+                                 getattr(model, "_lazy_max_cuts_per_incumbent", None), remaining)
+        for tri_idx, pa, pb, pc in cuts:
+            model.cbLazy(model._x[pa] + model._x[pb] + model._x[pc] <= 2 + model._q_tri[tri_idx])
+            model._cuts_added += 1
+
+    return _lazy_orientation_callback
+
+
+def _load_gurobi_config():
+    """KEY=VALUE licence file next to the package, or GUROBI_* environment (src/same.py:598-618)."""
+    config = {}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".gurobienv")
+    try:
+        with open(path, "r") as f:
+            for line in f:
+                line = line.strip()
+                if line and not line.startswith("#") and "=" in line:
+                    k, v = line.split("=", 1)
+                    config[k.strip()] = v.strip()
+    except OSError:
+        pass
+    return config
+
+
+# ------------------------------------------------------------------------------------------ run_same
+def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None, aligned_delaunay_vertex_col=None,
+             optim_params: Optional[Dict[str, Any]] = None, gurobi_params: Optional[Dict[str, Any]] = None,
+             ignore_precomputed_triangulation: bool = False):
+    """Same contract as src/same.py:706-1489: returns (matches_df, var_out)."""
+    try:
+        import gurobipy as gp
+        from gurobipy import GRB, Model, quicksum
+    except ImportError as e:  # the solver is proprietary; everything before it is available without it
+        raise ImportError("run_same needs gurobipy for the MIP solve; use prepare_same_inputs() for the pre-MIP "
+                          "artefacts and same_amd.sweeps for the violation sweeps") from e
+
+    log_dir = os.path.join(os.getcwd(), "gurobi_logs")
+    os.makedirs(log_dir, exist_ok=True)
+    cfg = _load_gurobi_config()
+    options = {
+        "WLSACCESSID": os.environ.get("GUROBI_WLSACCESSID", "") or cfg.get("WLSACCESSID", ""),
+        "WLSSECRET": os.environ.get("GUROBI_WLSSECRET", "") or cfg.get("WLSSECRET", ""),
+        "LICENSEID": int(os.environ.get("GUROBI_LICENSEID", 0)) or int(cfg.get("LICENSEID", 0)),
+        "OutputFlag": 1,
+        "LogFile": os.path.join(log_dir, f"gurobi_{os.getpid()}.log"),
+    }
+    try:
+        env = gp.Env(params=options)
+        prep = prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay, aligned_delaunay_vertex_col,
+                                   optim_params, gurobi_params, ignore_precomputed_triangulation)
+        op, gpar = prep.optim_params, prep.gurobi_params
+        aligned_df, ref_df = prep.aligned_df, prep.ref_df
+        valid_pairs, c, tris = prep.valid_pairs, prep.costs, prep.aligned_delaunay
+        n_aligned, n_ref = prep.n_aligned, prep.n_ref
+        lazy = op["lazy_constraints"]
+        if not lazy:
+            raise NotImplementedError("lazy_constraints=False builds O(n*k^3) Gurobi constraints "
+                                      "(src/helpers.py:444-573); that model builder is outside this package's scope. "
+                                      "same_amd.ops.eager_signs provides its orientation table.")
+        cell_id_col = op["cell_id_col"]
+
+        model = Model("optimal_matches", env=env)
+        x = model.addVars(len(valid_pairs), vtype=GRB.BINARY, lb=0, ub=1, name="x")
+        penalty_vars = model.addVars(n_ref, vtype=GRB.CONTINUOUS, lb=0, ub=1000, name="penalty")
+        no_match_vars = model.addVars(n_aligned, vtype=GRB.CONTINUOUS, lb=0, ub=1, name="no_match")
+        model.update()
+        _add_basic_constraints(model, quicksum, valid_pairs, op["max_matches"], x, penalty_vars, no_match_vars, ref_df,
+                               op["ref_metacell_match_multiplier"])
+
+        q_tri = model.addVars(len(tris), vtype=GRB.CONTINUOUS, lb=0, name="q_tri")
+        model.update()
+        model._x, model._q_tri, model._valid_pairs = x, q_tri, valid_pairs
+        model._aligned_delaunay, model._source_signs, model._ref_coords = tris, prep.source_signs, prep.ref_coords_xy
+        model._cuts_added = 0
+        model._lazy_max_cuts = gpar["lazy_max_cuts"]
+        model._lazy_allowed_flip_fraction = gpar["lazy_allowed_flip_fraction"]
+        model._lazy_max_cuts_per_incumbent = gpar["lazy_max_cuts_per_incumbent"]
+        model.Params.LazyConstraints = 1
+        model.Params.Method = gp.GRB.METHOD_PDHG
+        model.Params.PDHGGPU = 1
+        area_penalty_vars = [q_tri[i] for i in range(len(tris))]
+        model.update()
+
+        sizes = aligned_df["size"].to_numpy()
+        model.setObjective(
+            quicksum(c[idx] * x[idx] for idx in range(len(valid_pairs)))
+            + op["penalty_coeff"] * quicksum(penalty_vars[j] for j in range(n_ref))
+            + op["no_match_penalty"] * quicksum(sizes[i] * no_match_vars[i] for i in range(n_aligned))
+            + op["delaunay_penalty"] * quicksum(prep.triangle_weights[idx] * v for idx, v in enumerate(area_penalty_vars)),
+            GRB.MINIMIZE)
+        apply_mip_start(x_vars=x, no_match_vars=no_match_vars, valid_pairs=valid_pairs, costs=c, n_aligned=n_aligned,
+                        n_ref=n_ref, aligned_sizes=aligned_df["size"].to_numpy(dtype=float),
+                        no_match_penalty=op["no_match_penalty"], max_matches=op["max_matches"],
+                        init_method=gpar["init_method"], init_big_m=gpar["init_big_m"],
+                        init_hungarian_max_n=gpar["init_hungarian_max_n"], verbose=True)
+
+        if outprefix:
+            os.makedirs(outprefix, exist_ok=True)
+            model_file = os.path.join(outprefix, "matching_model.lp")
+        else:
+            model_file = "matching_model.lp"
+        model.write(model_file)
+        model.Params.timeLimit = float(gpar["time_limit"]) if gpar["time_limit"] is not None else float("inf")
+        model.Params.MIPGap = float(gpar["mip_gap"])
+        if gpar["mip_focus"] is not None:
+            model.Params.MIPFocus = int(gpar["mip_focus"])
+        if gpar["cuts"] is not None:
+            model.Params.Cuts = int(gpar["cuts"])
+        if gpar["heuristics"] is not None:
+            model.Params.Heuristics = float(gpar["heuristics"])
+
+        sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.source_signs, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
+        model.optimize(make_lazy_callback(GRB, sweep))
+        print(f"Lazy cuts added: {model._cuts_added}")
+        time_limit_reached = model.status == GRB.TIME_LIMIT
+        solve_time = model.Runtime
+
+        if model.status == GRB.OPTIMAL or model.status == GRB.TIME_LIMIT:
+            out_df, var_out = _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_vars, model,
+                                          cell_id_col, time_limit_reached, solve_time, outprefix)
+        else:
+            print("No optimal solution found")
+            out_df, var_out = pd.DataFrame(), {}
+        if outprefix:
+            out_df.to_csv(os.path.join(outprefix, "matches_df.csv"), index=False)
+        return out_df, var_out
+    finally:
+        try:
+            if os.path.exists(log_dir) and not os.listdir(log_dir):
+                os.rmdir(log_dir)
+        except OSError:
+            pass
+
+
+def _add_basic_constraints(model, quicksum, valid_pairs, max_matches, x, penalty_vars, no_match_vars, ref_df, multiplier):
+    """Assignment constraints in the order and with the names of src/helpers.py:102-161."""
+    pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
+    by_ref, by_aligned = {}, {}
+    for idx, (ip, jp) in enumerate(pairs.tolist()):
+        by_ref.setdefault(jp, []).append(idx)
+        by_aligned.setdefault(ip, []).append(idx)
+    rsize = ref_df["size"].to_numpy() if "size" in ref_df.columns else None
+    has_meta = rsize is not None and bool((rsize > 1).any())
+    if has_meta and multiplier is None:
+        multiplier = int(rsize.max())
+    for j, idxs in by_ref.items():
+        limit = multiplier * max_matches if (has_meta and rsize[j] > 1) else max_matches
+        model.addConstr(quicksum(x[i] for i in idxs) <= limit, name=f"max_matches_{j}")
+    model.update()
+    for i, idxs in by_aligned.items():
+        model.addConstr(quicksum(x[q] for q in idxs) <= 1, name=f"one_match_{i}")
+    model.update()
+    for j, idxs in by_ref.items():
+        model.addConstr(quicksum(x[i] for i in idxs) - penalty_vars[j] <= 1, name=f"penalty_{j}")
+    model.update()
+    for i, idxs in by_aligned.items():
+        model.addConstr(quicksum(x[q] for q in idxs) + no_match_vars[i] == 1, name=f"no_match_{i}")
+    model.update()
+
+
+def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_vars, model, cell_id_col,
+                time_limit_reached, solve_time, outprefix):
+    """Match table + violation analysis (src/same.py:1258-1472)."""
+    aligned_df, ref_df, valid_pairs, tris = prep.aligned_df, prep.ref_df, prep.valid_pairs, prep.aligned_delaunay
+    n_pairs = len(valid_pairs)
+    xv = np.fromiter((x[i].x for i in range(n_pairs)), dtype=np.float64, count=n_pairs)
+    pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
+    sel = np.flatnonzero(xv > 0.5)
+    out_df = pd.DataFrame([(int(i), int(j)) for i, j in pairs[sel]], columns=["aligned_idx", "ref_idx"])
+    for ct in list(commonCT) + ["X", "Y"]:
+        out_df[ct] = out_df["aligned_idx"].map(aligned_df[ct])
+    for ct in ["X", "Y"]:
+        out_df[f"ref_{ct}"] = out_df["ref_idx"].map(ref_df[ct])
+    out_df["size"] = out_df["aligned_idx"].map(aligned_df["size"])
+    out_df["ref_size"] = out_df["ref_idx"].map(ref_df["size"])
+    out_df[f"Ref_{cell_id_col}"] = out_df["ref_idx"].map(ref_df[cell_id_col])
+    out_df[f"Aligned_{cell_id_col}"] = out_df["aligned_idx"].map(aligned_df[cell_id_col])
+    out_df["time_limit_reached"] = time_limit_reached
+
+    violations = sweeps.verify_spatial_preservation(aligned_df=aligned_df, ref_df=ref_df, matches_df=out_df,
+                                                    triangle_info=prep.triangle_info)
+    sweeps.print_violation_report(violations)
+
+    violation_points = set(violations["points_with_violations"])
+    penalty_points = set()
+    for idx, var in enumerate(area_penalty_vars):
+        if var.x > 1e-6:
+            for p in tris[idx]:
+                penalty_points.add(p)
+    points_both = violation_points & penalty_points
+
+    aligned_to_ref = {int(i): int(j) for i, j in pairs[sel]}  # later pairs win (src/same.py:1370-1373)
+    before, after, flipped, matched_vertices = sweeps.triangle_area_flips(aligned_df, ref_df, tris, aligned_to_ref)
+
+    var_out = {
+        "x": list(xv),
+        "no_match_vars": [no_match_vars[i].x for i in range(prep.n_aligned)],
+        "penalty_vars": [penalty_vars[j].x for j in range(prep.n_ref)],
+        "area_penalty_vars": [v.x for v in area_penalty_vars],
+        "violations": violations,
+        "violation_penalty_comparison": {"points_both": list(points_both),
+                                         "points_only_violations": list(violation_points - penalty_points),
+                                         "points_only_penalties": list(penalty_points - violation_points)},
+        "triangle_data": {"triangles": tris, "triangle_info": prep.triangle_info,
+                          "aligned_simplex_map": prep.aligned_simplex_map, "areas_before": before, "areas_after": after,
+                          "flipped_triangles": flipped, "matched_vertices": matched_vertices},
+        "lazy_constraints": True,
+        "lazy_cuts_added": model._cuts_added,
+    }
+    if outprefix:
+        np.save(os.path.join(outprefix, "var_out.npy"), var_out, allow_pickle=True)
+        aligned_df.to_csv(os.path.join(outprefix, "aligned_df.csv"), index=False)
+        ref_df.to_csv(os.path.join(outprefix, "ref_df.csv"), index=False)
+    flipped_nodes = set()
+    for t in flipped:
+        for v in tris[t]:
+            flipped_nodes.add(v)
+    out_df["triangle_violation"] = out_df["aligned_idx"].isin(flipped_nodes)
+    out_df["filtered_violation"] = out_df["aligned_idx"].isin(points_both)
+    out_df["run_time"] = solve_time
+    return out_df, var_out
+
+
+# ------------------------------------------------------------------------------------------ windows
+def subset_data(df, x_min, x_max, y_min, y_max):
+    """src/same.py:293-295."""
+    return df[(df["X"] >= x_min) & (df["X"] < x_max) & (df["Y"] >= y_min) & (df["Y"] < y_max)]
+
+
+def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None,
+                            moving_delaunay_vertex_col=None, optim_params: Optional[Dict[str, Any]] = None,
+                            gurobi_params: Optional[Dict[str, Any]] = None,
+                            ignore_precomputed_triangulation: bool = False, _run_window=None):
+    """Same contract as src/same.py:297-595.  `_run_window` (testing hook) replaces run_same."""
+    from .windows import window_plan
+
+    ref_cell_type_col = moving_cell_type_col = "cell_type"
+    optim_params = {} if optim_params is None else optim_params
+    gurobi_params = {} if gurobi_params is None else gurobi_params
+    if hasattr(ref, "metacell_df"):
+        mc_ref = ref
+        ref = mc_ref.metacell_df
+        ref_cell_type_col = getattr(mc_ref, "cell_type_col", ref_cell_type_col)
+        if (optim_params.get("cell_id_col") is None) and hasattr(mc_ref, "metacell_idx_col"):
+            optim_params["cell_id_col"] = mc_ref.metacell_idx_col
+    if hasattr(moving, "metacell_df") and hasattr(moving, "metacell_delaunay"):
+        mc = moving
+        moving = mc.metacell_df
+        if moving_delaunay is None and not ignore_precomputed_triangulation:
+            moving_delaunay = mc.metacell_delaunay
+        if moving_delaunay_vertex_col is None and hasattr(mc, "metacell_idx_col"):
+            moving_delaunay_vertex_col = mc.metacell_idx_col
+        moving_cell_type_col = getattr(mc, "cell_type_col", moving_cell_type_col)
+        if (optim_params.get("cell_id_col") is None) and hasattr(mc, "metacell_idx_col"):
+            optim_params["cell_id_col"] = mc.metacell_idx_col
+    optim_params = init_optim_params(**(optim_params or {}))
+    gurobi_params = init_gurobi_params(**(gurobi_params or {}))
+    window_size, overlap = optim_params["window_size"], optim_params["overlap"]
+    min_cells = optim_params["min_cells_per_window"]
+
+    ref_types = mov_types = None
+    if ref_cell_type_col in ref.columns and moving_cell_type_col in moving.columns:
+        ref_types = set(pd.Series(ref[ref_cell_type_col]).dropna().unique().tolist())
+        mov_types = set(pd.Series(moving[moving_cell_type_col]).dropna().unique().tolist())
+        if ref_types != mov_types:
+            raise ValueError(
+                "Cell type categories differ between ref and moving.\n"
+                f"ref ({ref_cell_type_col}) has {len(ref_types)} types, moving ({moving_cell_type_col}) has {len(mov_types)} types.\n"
+                f"Only-in-ref: {sorted(ref_types - mov_types)[:20]}\nOnly-in-moving: {sorted(mov_types - ref_types)[:20]}")
+    if commonCT is None:
+        if ref_types is None:
+            raise ValueError("commonCT is None, but cell_type columns were not found to infer it. Pass commonCT explicitly "
+                             f"or ensure both dataframes have '{ref_cell_type_col}'/'{moving_cell_type_col}'.")
+        commonCT = sorted(ref_types)
+        missing_ref = [c for c in commonCT if c not in ref.columns]
+        missing_mov = [c for c in commonCT if c not in moving.columns]
+        if missing_ref or missing_mov:
+            raise ValueError("commonCT is None so it was inferred as the unique values of the cell_type column, but those "
+                             f"names are not present as probability/one-hot columns.\nMissing in ref columns (first 20): "
+                             f"{missing_ref[:20]}\nMissing in moving columns (first 20): {missing_mov[:20]}")
+
+    output_file = None
+    all_matches = []
+    if outprefix:
+        os.makedirs(outprefix, exist_ok=True)
+        output_file = os.path.join(outprefix, "matchedDF.csv")
+    plan = window_plan(ref[["X", "Y"]].to_numpy(dtype=np.float64), moving[["X", "Y"]].to_numpy(dtype=np.float64),
+                       window_size, overlap, min_cells)
+    done_ids = set()
+    if output_file and os.path.exists(output_file):  # resume (src/helpers.py:21-70): skip windows already in the file
+        existing = pd.read_csv(output_file)
+        if "window_id" in existing.columns:
+            done_ids = set(int(w) for w in existing["window_id"].unique())
+            all_matches.append(existing)
+    runner = _run_window or run_same
+    for w in plan:
+        if w["grid_id"] in done_ids:
+            continue
+        x0, x1, y0, y1 = w["box"]
+        ref_subset = subset_data(ref, x0, x1, y0, y1)
+        moving_subset = subset_data(moving, x0, x1, y0, y1)
+        window_outprefix = os.path.join(outprefix, f"window_{w['window_id']}") if outprefix else None
+        window_matches, _ = runner(aligned_df=moving_subset, ref_df=ref_subset, commonCT=commonCT, optim_params=optim_params,
+                                   gurobi_params=gurobi_params, outprefix=window_outprefix, aligned_delaunay=moving_delaunay,
+                                   aligned_delaunay_vertex_col=moving_delaunay_vertex_col,
+                                   ignore_precomputed_triangulation=ignore_precomputed_triangulation)
+        if window_matches.shape[0] > 0:
+            tx0, tx1, ty0, ty1 = w["trim"]
+            central = window_matches[(window_matches["X"] >= tx0) & (window_matches["X"] < tx1)
+                                     & (window_matches["Y"] >= ty0) & (window_matches["Y"] < ty1)].copy()
+            central["window_id"] = w["window_id"]
+            if len(central) > 0:
+                all_matches.append(central)
+                if outprefix:
+                    pd.concat(all_matches, ignore_index=True).to_csv(output_file, index=False)
+    return pd.concat(all_matches, ignore_index=True) if all_matches else pd.DataFrame()

@@ -1,0 +1,24 @@
+"""Pair costs (the objective coefficients, src/same.py:1180-1189) and the dense cost builder."""
+import numpy as np
+
+from . import ops
+
+
+def _xy(df):
+    return np.ascontiguousarray(df[["X", "Y"]].to_numpy(dtype=np.float64))
+
+
+def pair_costs(aligned_df, ref_df, valid_pairs, commonCT, dist_ct_coeff, ctx=None):
+    """-> list of np.float64, one per pair, in pair order (what run_same calls `c`)."""
+    cols = list(commonCT)
+    A = aligned_df[cols].to_numpy(dtype=np.float64)
+    R = ref_df[cols].to_numpy(dtype=np.float64)
+    pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
+    return list(ops.pair_cost(A, R, _xy(aligned_df), _xy(ref_df), pairs, dist_ct_coeff, ctx=ctx))
+
+
+def dense_cost_matrix(aligned_df, ref_df, commonCT, dist_ct_coeff, row_begin=0, row_end=None, dtype=np.float64, ctx=None):
+    """The same cost for every (aligned i, ref j): rows [row_begin,row_end) x all refs."""
+    cols = list(commonCT)
+    return ops.dense_cost(aligned_df[cols].to_numpy(dtype=np.float64), ref_df[cols].to_numpy(dtype=np.float64),
+                          _xy(aligned_df), _xy(ref_df), dist_ct_coeff, row_begin, row_end, dtype, ctx=ctx)

@@ -1,0 +1,64 @@
+// comm.hip -- the path's only exchange step: an RCCL all-gather of the fixed-width pruned
+// candidate lists (int32 idx[rows][k], double cost[rows][k]) across the ranks that own
+// aligned-row blocks.  One process per GPU; the unique id travels over whatever
+// host channel the launcher has (bench.py uses the torch.distributed store).
+#include <rccl/rccl.h>
+
+#include "common.h"
+
+static int nccl_fail(same_ctx *ctx, const char *what, ncclResult_t r) {
+    if (ctx) ctx->err = std::string(what) + ": " + ncclGetErrorString(r);
+    return SAME_EIO;
+}
+#define NCCL_TRY(ctx, call)                                   \
+    do {                                                      \
+        ncclResult_t r_ = (call);                             \
+        if (r_ != ncclSuccess) return nccl_fail((ctx), #call, r_); \
+    } while (0)
+
+extern "C" {
+
+int same_comm_unique_id(char out_id[SAME_UNIQUE_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == SAME_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!out_id) return SAME_EINVAL;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return SAME_EIO;
+    memcpy(out_id, &id, sizeof id);
+    return SAME_OK;
+}
+
+int same_comm_init(same_ctx *ctx, int nranks, int rank, const char id[SAME_UNIQUE_ID_BYTES]) {
+    REQUIRE(ctx, ctx && id && nranks >= 1 && rank >= 0 && rank < nranks && ctx->comm == nullptr);
+    SAME_TRY(same_use(ctx));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(ctx, ncclCommInitRank(&comm, nranks, uid, rank));
+    ctx->comm = comm;
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return SAME_OK;
+}
+
+int same_comm_destroy(same_ctx *ctx) {
+    REQUIRE(ctx, ctx != nullptr);
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ncclCommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->nranks = 1;
+        ctx->rank = 0;
+    }
+    return SAME_OK;
+}
+
+int same_allgather_dev(same_ctx *ctx, const void *dsend, void *drecv, size_t send_bytes) {
+    REQUIRE(ctx, ctx && ctx->comm && (send_bytes == 0 || (dsend && drecv)));
+    SAME_TRY(same_use(ctx));
+    if (send_bytes == 0) return SAME_OK;
+    NCCL_TRY(ctx, ncclAllGather(dsend, drecv, send_bytes, ncclInt8, ctx->comm, ctx->stream));
+    return SAME_OK;
+}
+
+}  // extern "C"

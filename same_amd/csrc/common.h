@@ -1,0 +1,95 @@
+// common.h -- context, error plumbing and scratch arena shared by the libsame_hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "same_hip.h"
+
+struct ncclComm;
+
+// Named device scratch slots: each grows on demand and is reused across calls, so the
+// host-buffer entry points do not hipMalloc per call.
+enum Slot {
+    SL_A = 0, SL_R, SL_AXY, SL_RXY, SL_PAIRS, SL_OUT0, SL_OUT1, SL_OUT2, SL_TRIS, SL_MATCH,
+    SL_SIGN, SL_SIZE, SL_TYPE, SL_FLAG0, SL_FLAG1, SL_FLAG2, SL_COUNTS, SL_X, SL_MASK,
+    // bound sweep state (same_sweep_bind)
+    SL_B_TRIS, SL_B_SIGN, SL_B_RXY, SL_B_PAIRS, SL_B_MATCH, SL_B_PIDX, SL_B_FLAG, SL_B_VIOL,
+    SL_B_MASK, SL_B_CNT, SL_B_X,
+    SL_COUNT
+};
+
+struct same_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *slot[SL_COUNT] = {};
+    size_t slot_bytes[SL_COUNT] = {};
+    void *pinned = nullptr;  // small pinned staging block for scalar results
+    size_t pinned_bytes = 0;
+    std::string err;
+    int cu_count = 0;
+    // bound sweep shapes
+    int64_t b_Tr = 0, b_nr = 0, b_nm = 0, b_P = 0;
+    bool bound = false;
+    ncclComm *comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+inline int same_fail(same_ctx *ctx, int code, const char *what, hipError_t e) {
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                    \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) return same_fail((ctx), e_ == hipErrorOutOfMemory ? SAME_ENOMEM : SAME_EIO, #call, e_); \
+    } while (0)
+
+#define SAME_TRY(call)            \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != SAME_OK) return rc_; \
+    } while (0)
+
+#define REQUIRE(ctx, cond)                                           \
+    do {                                                             \
+        if (!(cond)) {                                               \
+            if (ctx) (ctx)->err = "invalid argument: " #cond;        \
+            return SAME_EINVAL;                                      \
+        }                                                            \
+    } while (0)
+
+int same_use(same_ctx *ctx);                                  // hipSetDevice(ctx->device)
+int same_slot(same_ctx *ctx, Slot s, size_t bytes, void **out);  // grow-on-demand scratch
+int same_up(same_ctx *ctx, Slot s, const void *host, size_t bytes, void **out);  // slot + async H2D
+int same_down(same_ctx *ctx, void *host, const void *dev, size_t bytes);          // async D2H
+
+template <typename T>
+inline int slot_as(same_ctx *ctx, Slot s, size_t n, T **out) {
+    void *p = nullptr;
+    int rc = same_slot(ctx, s, n * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+template <typename T>
+inline int up_as(same_ctx *ctx, Slot s, const T *host, size_t n, T **out) {
+    void *p = nullptr;
+    int rc = same_up(ctx, s, host, n * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Host-side index validation: a bad index must come back as SAME_ERANGE, never as a GPU fault.
+int check_index_range(same_ctx *ctx, const int32_t *idx, int64_t n, int64_t lo, int64_t hi, const char *what);

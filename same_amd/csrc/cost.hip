@@ -1,0 +1,299 @@
+// cost.hip -- L1 cell-type + coordinate cost kernels (SURVEY 8a4 / dense generalisation).
+//
+//   c(i,j) = w * sum_t |A[i,t] - R[j,t]|  +  (w*0.001) * (|ax-rx| + |ay-ry|)
+//
+// Reference: src/same.py:1180-1189 (per pair), src/init_helpers.py:151-155 (the dense matrix
+// these costs are scattered into).  Parity contract: the type sum is a left-to-right fp64
+// accumulation and nothing is fused (-ffp-contract=off), so results are bit-identical to
+// the reference's object-dtype pandas row arithmetic.
+//
+// Dense kernel design (MI355X): L1 distance is not a contraction, so MFMA does not apply;
+// the kernel is a store stream (8 B out per 2T+6 fp64 VALU ops) that sits near the fp64
+// VALU / HBM ridge at T=20.  Each lane OWNS CPL adjacent ref columns and keeps their T type
+// values + XY in VGPRs for the whole row chunk; the aligned row (T+2 values) is wave-uniform
+// and is fetched with scalar loads into SGPRs, so the inner loop is exactly
+//   v_add_f64 d, s[a_t], -v[r_t]  ;  v_add_f64 acc, acc, |d|
+// with no LDS or vector-memory instruction per element.  Every lane stores 16 B per row
+// (CPL=2 doubles / 4 floats): one wave-instruction writes 1 KiB of one output row, a
+// workgroup 4 KiB.
+#include "common.h"
+
+namespace {
+
+template <typename F> struct vec_of;
+template <> struct vec_of<double> { static constexpr int cpl = 2; };
+template <> struct vec_of<float> { static constexpr int cpl = 4; };
+
+template <typename F> __device__ __forceinline__ F absf(F x);
+template <> __device__ __forceinline__ double absf<double>(double x) { return __builtin_fabs(x); }
+template <> __device__ __forceinline__ float absf<float>(float x) { return __builtin_fabsf(x); }
+
+// Block = 256 threads = 4 waves side by side over 256*CPL ref columns; it sweeps `rows_per_block`
+// aligned rows.  grid = col_tiles * row_chunks, column tile fastest (neighbouring blocks write
+// neighbouring 4 KiB pieces of the same rows).
+template <typename F, int T, int CPL, bool VEC_STORE>
+__global__ __launch_bounds__(256) void dense_cost_kernel(
+    const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
+    const F *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w, F dcoef,
+    F *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block) {
+    const int tile = blockIdx.x % col_tiles;
+    const int chunk = blockIdx.x / col_tiles;
+    const int64_t j0 = ((int64_t)tile * 256 + threadIdx.x) * CPL;
+    const int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
+    const int64_t i1 = (i0 + rows_per_block < row_end) ? i0 + rows_per_block : row_end;
+
+    F r[CPL][T > 0 ? T : 1];
+    F rx[CPL], ry[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        int64_t j = j0 + c;
+        if (j >= n_r) j = n_r - 1;  // clamp: lanes past the edge compute a valid column and do not store
+        const F *rp = R + j * T;
+#pragma unroll
+        for (int t = 0; t < T; ++t) r[c][t] = rp[t];
+        rx[c] = rxy[2 * j];
+        ry[c] = rxy[2 * j + 1];
+    }
+    if (j0 >= n_r) return;
+
+    F *orow = out + (i0 - row_begin) * ld + j0;
+    for (int64_t i = i0; i < i1; ++i, orow += ld) {
+        const F *__restrict__ a = A + i * T;  // wave-uniform -> scalar loads
+        const F ax = axy[2 * i], ay = axy[2 * i + 1];
+        F v[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            F s = F(0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - r[c][t]);
+            const F dc = absf<F>(ax - rx[c]) + absf<F>(ay - ry[c]);
+            v[c] = w * s + dcoef * dc;
+        }
+        if (VEC_STORE && j0 + CPL <= n_r) {
+            typedef F vecF __attribute__((ext_vector_type(CPL)));
+            vecF pk;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) pk[c] = v[c];
+            __builtin_nontemporal_store(pk, reinterpret_cast<vecF *>(orow));
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (j0 + c < n_r) orow[c] = v[c];
+        }
+    }
+}
+
+// Any T (used above the unrolled range): type values come from global memory (L1/L2 hits).
+template <typename F, int CPL>
+__global__ __launch_bounds__(256) void dense_cost_generic_kernel(
+    const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
+    const F *__restrict__ rxy, int T, int64_t n_r, int64_t row_begin, int64_t row_end, F w, F dcoef,
+    F *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block) {
+    const int tile = blockIdx.x % col_tiles;
+    const int chunk = blockIdx.x / col_tiles;
+    const int64_t j0 = ((int64_t)tile * 256 + threadIdx.x) * CPL;
+    const int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
+    const int64_t i1 = (i0 + rows_per_block < row_end) ? i0 + rows_per_block : row_end;
+    if (j0 >= n_r) return;
+    for (int64_t i = i0; i < i1; ++i) {
+        const F *a = A + i * T;
+        const F ax = axy[2 * i], ay = axy[2 * i + 1];
+        for (int c = 0; c < CPL; ++c) {
+            const int64_t j = j0 + c;
+            if (j >= n_r) break;
+            const F *rp = R + j * T;
+            F s = F(0);
+            for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - rp[t]);
+            const F dc = absf<F>(ax - rxy[2 * j]) + absf<F>(ay - rxy[2 * j + 1]);
+            out[(i - row_begin) * ld + j] = w * s + dcoef * dc;
+        }
+    }
+}
+
+// One lane per pair (a4).  Consecutive pairs share the aligned row (L1 broadcast); ref rows
+// are gathered.  Gather-bound, P*(2*(T+2)+1)*8 B of touched data.
+__global__ __launch_bounds__(256) void pair_cost_kernel(
+    const double *__restrict__ A, const double *__restrict__ R, int T, const double *__restrict__ axy,
+    const double *__restrict__ rxy, const int32_t *__restrict__ pairs, int64_t P, double w, double dcoef,
+    double *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
+    const double *a = A + i * T, *r = R + j * T;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(a[t] - r[t]);
+    const double dc = __builtin_fabs(axy[2 * i] - rxy[2 * j]) + __builtin_fabs(axy[2 * i + 1] - rxy[2 * j + 1]);
+    out[p] = w * s + dcoef * dc;
+}
+
+// Costs of padded candidate lists idx[(i-row_begin)*k + q] (-1 = empty -> +inf).
+__global__ __launch_bounds__(256) void padded_cost_kernel(
+    const double *__restrict__ A, const double *__restrict__ R, int T, const double *__restrict__ axy,
+    const double *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
+    double w, double dcoef, double *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_slots) return;
+    const int64_t j = idx[q];
+    if (j < 0) { out[q] = __builtin_inf(); return; }
+    const int64_t i = row_begin + q / k;
+    const double *a = A + i * T, *r = R + j * T;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(a[t] - r[t]);
+    const double dc = __builtin_fabs(axy[2 * i] - rxy[2 * j]) + __builtin_fabs(axy[2 * i + 1] - rxy[2 * j + 1]);
+    out[q] = w * s + dcoef * dc;
+}
+
+template <typename F, int T>
+int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
+                   int64_t re, F w, F *out, int64_t ld) {
+    constexpr int CPLV = vec_of<F>::cpl;
+    // T large: one column per lane keeps the register file within budget
+    constexpr int CPL = (T * CPLV * (int)(sizeof(F) / 4) <= 96) ? CPLV : 1;
+    const int64_t rows = re - rb;
+    const int col_tiles = (int)ceil_div(n_r, 256 * CPL);
+    // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
+    int rows_per_block = 256;
+    while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
+    const int64_t chunks = ceil_div(rows, rows_per_block);
+    const int64_t blocks = chunks * col_tiles;
+    if (blocks <= 0) return SAME_OK;
+    REQUIRE(ctx, blocks < (int64_t)1 << 31);
+    const F dcoef = w * F(0.001);
+    const bool vec_ok = CPL > 1 && (ld % CPL == 0) && (reinterpret_cast<uintptr_t>(out) % (CPL * sizeof(F)) == 0);
+    if (vec_ok)
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy,
+                           rxy, n_r, rb, re, w, dcoef, out, ld, col_tiles, rows_per_block);
+    else
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy,
+                           rxy, n_r, rb, re, w, dcoef, out, ld, col_tiles, rows_per_block);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+template <typename F>
+int launch_dense(same_ctx *ctx, const F *A, const F *R, int T, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
+                 int64_t re, F w, F *out, int64_t ld) {
+    REQUIRE(ctx, ctx && A && R && axy && rxy && out);
+    REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && n_r >= 0 && rb >= 0 && re >= rb && ld >= n_r);
+    SAME_TRY(same_use(ctx));
+    if (n_r == 0 || re == rb) return SAME_OK;
+    switch (T) {
+#define CASE_T(n) case n: return launch_dense_T<F, n>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld);
+        CASE_T(0) CASE_T(1) CASE_T(2) CASE_T(3) CASE_T(4) CASE_T(5) CASE_T(6) CASE_T(7) CASE_T(8)
+        CASE_T(9) CASE_T(10) CASE_T(11) CASE_T(12) CASE_T(13) CASE_T(14) CASE_T(15) CASE_T(16)
+        CASE_T(17) CASE_T(18) CASE_T(19) CASE_T(20) CASE_T(21) CASE_T(22) CASE_T(23) CASE_T(24)
+        CASE_T(25) CASE_T(26) CASE_T(27) CASE_T(28) CASE_T(29) CASE_T(30) CASE_T(31) CASE_T(32)
+        CASE_T(33) CASE_T(34) CASE_T(35) CASE_T(36) CASE_T(37) CASE_T(38) CASE_T(39) CASE_T(40)
+        CASE_T(41) CASE_T(42) CASE_T(43) CASE_T(44) CASE_T(45) CASE_T(46) CASE_T(47) CASE_T(48)
+#undef CASE_T
+        default: break;
+    }
+    constexpr int CPL = 1;
+    const int64_t rows = re - rb;
+    const int col_tiles = (int)ceil_div(n_r, 256 * CPL);
+    const int rows_per_block = 16;
+    const int64_t blocks = ceil_div(rows, rows_per_block) * col_tiles;
+    REQUIRE(ctx, blocks < (int64_t)1 << 31);
+    hipLaunchKernelGGL((dense_cost_generic_kernel<F, CPL>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy, rxy,
+                       T, n_r, rb, re, w, w * F(0.001), out, ld, col_tiles, rows_per_block);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+template <typename F>
+int dense_host(same_ctx *ctx, const F *A, const F *R, int64_t n_m, int64_t n_r, int T, const F *axy, const F *rxy,
+               int64_t rb, int64_t re, F w, F *out, int64_t ld) {
+    REQUIRE(ctx, ctx && out && (n_m == 0 || axy) && (n_r == 0 || rxy));
+    REQUIRE(ctx, n_m >= 0 && n_r >= 0 && T >= 0 && rb >= 0 && re >= rb && re <= n_m && ld >= n_r);
+    REQUIRE(ctx, T == 0 || ((n_m == 0 || A) && (n_r == 0 || R)));
+    SAME_TRY(same_use(ctx));
+    if (re == rb || n_r == 0) return SAME_OK;
+    F *dA, *dR, *dax, *drx, *dout;
+    SAME_TRY(up_as(ctx, SL_A, A, (size_t)n_m * T, &dA));
+    SAME_TRY(up_as(ctx, SL_R, R, (size_t)n_r * T, &dR));
+    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n_m * 2, &dax));
+    SAME_TRY(up_as(ctx, SL_RXY, rxy, (size_t)n_r * 2, &drx));
+    const int64_t rows = re - rb;
+    const int64_t dld = (n_r + 3) & ~int64_t(3);  // device tile is padded so the 16 B store path is taken
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)rows * dld, &dout));
+    SAME_TRY(launch_dense<F>(ctx, dA, dR, T, dax, drx, n_r, rb, re, w, dout, dld));
+    HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)ld * sizeof(F), dout, (size_t)dld * sizeof(F), (size_t)n_r * sizeof(F),
+                                  (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int same_dense_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T, const double *daxy,
+                            const double *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, double w,
+                            double *dout, int64_t ld) {
+    return launch_dense<double>(ctx, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, dout, ld);
+}
+
+int same_dense_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T, const float *daxy,
+                            const float *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, float w,
+                            float *dout, int64_t ld) {
+    return launch_dense<float>(ctx, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, dout, ld);
+}
+
+int same_dense_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r, int T,
+                        const double *axy, const double *rxy, int64_t row_begin, int64_t row_end, double w,
+                        double *out, int64_t ld) {
+    return dense_host<double>(ctx, A, R, n_m, n_r, T, axy, rxy, row_begin, row_end, w, out, ld);
+}
+
+int same_dense_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_m, int64_t n_r, int T,
+                        const float *axy, const float *rxy, int64_t row_begin, int64_t row_end, float w, float *out,
+                        int64_t ld) {
+    return dense_host<float>(ctx, A, R, n_m, n_r, T, axy, rxy, row_begin, row_end, w, out, ld);
+}
+
+int same_pair_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r, int T,
+                       const double *axy, const double *rxy, const int32_t *pairs, int64_t P, double w,
+                       double *out_c) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, n_m >= 0 && n_r >= 0 && T >= 0 && T <= SAME_MAX_TYPES && P >= 0);
+    if (P == 0) return SAME_OK;
+    REQUIRE(ctx, axy && rxy && pairs && out_c && (T == 0 || (A && R)));
+    SAME_TRY(same_use(ctx));
+    // validate on the host: a bad index must never become a device fault
+    for (int64_t p = 0; p < P; ++p) {
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
+            ctx->err = "pair index out of range";
+            return SAME_ERANGE;
+        }
+    }
+    double *dA, *dR, *dax, *drx, *dout;
+    int32_t *dp;
+    SAME_TRY(up_as(ctx, SL_A, A, (size_t)n_m * T, &dA));
+    SAME_TRY(up_as(ctx, SL_R, R, (size_t)n_r * T, &dR));
+    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n_m * 2, &dax));
+    SAME_TRY(up_as(ctx, SL_RXY, rxy, (size_t)n_r * 2, &drx));
+    SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)P, &dout));
+    hipLaunchKernelGGL(pair_cost_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, dA, dR, T, dax, drx,
+                       dp, P, w, w * 0.001, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out_c, dout, (size_t)P * sizeof(double)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T, const double *daxy,
+                             const double *drxy, int64_t row_begin, int64_t row_end, int k, const int32_t *didx,
+                             double w, double *dout_cost) {
+    REQUIRE(ctx, ctx && daxy && drxy && didx && dout_cost && (T == 0 || (dA && dR)));
+    REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && k >= 1 && row_begin >= 0 && row_end >= row_begin);
+    SAME_TRY(same_use(ctx));
+    const int64_t n_slots = (row_end - row_begin) * k;
+    if (n_slots == 0) return SAME_OK;
+    hipLaunchKernelGGL(padded_cost_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, ctx->stream, dA, dR, T,
+                       daxy, drxy, row_begin, n_slots, k, didx, w, w * 0.001, dout_cost);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+}  // extern "C"

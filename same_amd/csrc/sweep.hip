@@ -1,0 +1,458 @@
+// sweep.hip -- violation sweeps under a candidate matching: the lazy-constraint orientation
+// sweep (a10, src/same.py:631-669), the XY-order report sweep (a11,
+// src/violationhelper.py:53-117), plus the small integer/index kernels around them (matching
+// from the solver's x vector, per-row minimum cost and dense assignment matrix for the MIP
+// start (a5), window membership (a13)).
+//
+// The orientation sweep runs once per solver incumbent, so it is latency-bound: triangles,
+// source signs, reference XY and the pair list stay resident (same_sweep_bind); a call uploads
+// only x (or the match vector), runs 2-3 small kernels and downloads two counters plus the
+// ascending list of flipped triangles.  Ordered compaction: kernel 1 ballots the flipped
+// predicate into one 64-bit word per wave; kernel 2 (one block) scans the popcounts and writes
+// the indices, so the list is ascending without a sort and bit-reproducible.
+#include <algorithm>
+#include <utility>
+
+#include "common.h"
+
+namespace {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2_t ld2(const double *xy, int64_t i) {
+    return *reinterpret_cast<const double2_t *>(xy + 2 * i);
+}
+__device__ __forceinline__ int8_t orient_sign(double2_t a, double2_t b, double2_t c) {
+    const double v = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);  // src/same.py:658
+    return (int8_t)((v > 0.0) - (v < 0.0));
+}
+
+// ---- matching from x: last pair (highest pair index) with x > 0.5 wins per aligned row -----
+__global__ __launch_bounds__(256) void match_init_kernel(int32_t *__restrict__ pidx, int64_t n_m) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_m) pidx[i] = -1;
+}
+__global__ __launch_bounds__(256) void match_scan_kernel(const double *__restrict__ x, const int32_t *__restrict__ pairs,
+                                                          int64_t P, int32_t *__restrict__ pidx) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P && x[p] > 0.5) atomicMax(&pidx[pairs[2 * p]], (int32_t)p);  // src/same.py:636-639
+}
+__global__ __launch_bounds__(256) void match_resolve_kernel(const int32_t *__restrict__ pairs, const int32_t *__restrict__ pidx,
+                                                             int64_t n_m, int32_t *__restrict__ match) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_m) match[i] = pidx[i] >= 0 ? pairs[2 * (int64_t)pidx[i] + 1] : -1;
+}
+
+// ---- orientation sweep -------------------------------------------------------------------
+// counters[0] = checked, counters[1] = flipped (filled by the compaction kernel)
+__global__ __launch_bounds__(256) void orient_flag_kernel(
+    const int32_t *__restrict__ tris, int64_t Tr, const int8_t *__restrict__ src_sign, const double *__restrict__ rxy,
+    const int32_t *__restrict__ match, uint8_t *__restrict__ flag, unsigned long long *__restrict__ viol_mask,
+    unsigned long long *__restrict__ counters) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint8_t f = 0;
+    if (t < Tr) {
+        const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+        const int32_t ja = match[a], jb = match[b], jc = match[c];
+        if (ja >= 0 && jb >= 0 && jc >= 0) {                       // src/same.py:649-650
+            const int8_t rs = orient_sign(ld2(rxy, ja), ld2(rxy, jb), ld2(rxy, jc));
+            const int8_t ss = src_sign[t];
+            if (ss != 0 && rs != 0) f = (ss != rs) ? 2 : 1;        // src/same.py:663-669
+        }
+        flag[t] = f;
+    }
+    const unsigned long long checked = __ballot(f != 0);
+    const unsigned long long flipped = __ballot(f == 2);
+    if ((threadIdx.x & 63) == 0) {
+        const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        viol_mask[w] = flipped;
+        if (checked) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(checked));
+    }
+}
+
+// one block: exclusive scan of popcount(mask[w]) in chunks of 1024 words, then expand bits
+__global__ __launch_bounds__(1024) void compact_mask_kernel(const unsigned long long *__restrict__ mask, int64_t n_words,
+                                                             int64_t n_items, int32_t *__restrict__ out_idx,
+                                                             unsigned long long *__restrict__ counters) {
+    __shared__ int wave_sum[16];
+    __shared__ long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_words; base += 1024) {
+        const int64_t w = base + tid;
+        const unsigned long long m = w < n_words ? mask[w] : 0ull;
+        const int c = __builtin_popcountll(m);
+        int incl = c;  // inclusive scan within the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int q = 0; q < wave; ++q) wave_off += wave_sum[q];
+        long long pos = carry_s + wave_off + (incl - c);
+        unsigned long long bits = m;
+        while (bits) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const int64_t item = w * 64 + b;
+            if (item < n_items) out_idx[pos++] = (int32_t)item;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s += wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) counters[1] = (unsigned long long)carry_s;
+}
+
+// ---- XY-order sweep ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xyorder_kernel(
+    const double *__restrict__ axy, const double *__restrict__ rxy, const int32_t *__restrict__ tris, int64_t Tr,
+    const int32_t *__restrict__ match, uint8_t *__restrict__ edge_flags, uint8_t *__restrict__ tri_flag,
+    uint8_t *__restrict__ point_flag, unsigned long long *__restrict__ counts) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int ncmp = 0, nviol = 0, tv = 0;
+    if (t < Tr) {
+        int32_t v[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
+        int32_t m[3] = {match[v[0]], match[v[1]], match[v[2]]};
+        double2_t a[3], r[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            a[q] = ld2(axy, v[q]);
+            r[q] = m[q] >= 0 ? ld2(rxy, m[q]) : double2_t{0.0, 0.0};
+        }
+        const int E[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int p = E[e][0], q = E[e][1];
+            uint8_t f = 0;
+            if (m[p] >= 0 && m[q] >= 0) {  // both matched (implies >= 2 matched vertices, violationhelper.py:58-60)
+                f = 1;
+                ++ncmp;
+                const bool ox = a[p].x < a[q].x, oy = a[p].y < a[q].y;  // violationhelper.py:68-69
+                const bool mx = r[p].x < r[q].x, my = r[p].y < r[q].y;  // :74-75
+                if (ox != mx) { f |= 2; ++nviol; }
+                if (oy != my) { f |= 4; ++nviol; }
+                if (f & 6) { tv = 1; point_flag[v[p]] = 1; point_flag[v[q]] = 1; }  // benign: every writer stores 1
+            }
+            edge_flags[3 * t + e] = f;
+        }
+        tri_flag[t] = (uint8_t)tv;
+    }
+    // wave reduction -> one atomic per wave per counter (integer sums: order-independent)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ncmp += __shfl_down(ncmp, off, 64);
+        nviol += __shfl_down(nviol, off, 64);
+        tv += __shfl_down(tv, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (ncmp) atomicAdd(&counts[0], (unsigned long long)ncmp);
+        if (nviol) atomicAdd(&counts[1], (unsigned long long)nviol);
+        if (tv) atomicAdd(&counts[2], (unsigned long long)tv);
+    }
+}
+
+// ---- a5 helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long order_key(double v) {  // monotone u64 key of a double
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_to_double(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *__restrict__ p, int64_t n, unsigned long long v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(256) void rowmin_kernel(const int32_t *__restrict__ pairs, const double *__restrict__ costs,
+                                                      int64_t P, unsigned long long *__restrict__ keys) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) atomicMin(&keys[pairs[2 * p]], order_key(costs[p]));  // src/init_helpers.py:118-122
+}
+__global__ __launch_bounds__(256) void rowmin_decode_kernel(const unsigned long long *__restrict__ keys, int64_t n,
+                                                             double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = key_to_double(keys[i]);
+}
+__global__ __launch_bounds__(256) void fill_f64_kernel(double *__restrict__ p, int64_t n, double v) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<d2 *>(p + i) = d2{v, v};
+    } else if (i < n) {
+        p[i] = v;
+    }
+}
+// later duplicates win (src/init_helpers.py:152-153): keep the highest pair index per cell
+__global__ __launch_bounds__(256) void scatter_pairs_kernel(const int32_t *__restrict__ pairs, const double *__restrict__ costs,
+                                                             int64_t P, int64_t ld, double *__restrict__ out,
+                                                             const int32_t *__restrict__ winner) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P && winner[p] == (int32_t)p) out[(int64_t)pairs[2 * p] * ld + pairs[2 * p + 1]] = costs[p];
+}
+__global__ __launch_bounds__(256) void diag_kernel(const double *__restrict__ unmatched, int64_t n_m, int64_t n_r, int64_t ld,
+                                                    double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_m) out[i * ld + n_r + i] = unmatched[i];  // src/init_helpers.py:154-155
+}
+
+// ---- a13: window membership ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void window_count_kernel(const double *__restrict__ xy, int64_t n, const double *__restrict__ boxes,
+                                                            int64_t n_boxes, unsigned long long *__restrict__ counts,
+                                                            uint8_t *__restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const double2_t p = ld2(xy, valid ? i : 0);
+    for (int64_t b = 0; b < n_boxes; ++b) {
+        const double x0 = boxes[4 * b], x1 = boxes[4 * b + 1], y0 = boxes[4 * b + 2], y1 = boxes[4 * b + 3];
+        const bool in = valid && p.x >= x0 && p.x < x1 && p.y >= y0 && p.y < y1;  // src/same.py:293-295
+        if (mask && valid) mask[b * n + i] = in;
+        const unsigned long long bal = __ballot(in);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counts[b], (unsigned long long)__builtin_popcountll(bal));
+    }
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
+
+int run_orient(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol,
+               uint8_t *out_flag) {
+    const int64_t Tr = ctx->b_Tr;
+    *out_checked = 0;
+    *out_nviol = 0;
+    if (Tr == 0) return SAME_OK;
+    const int64_t n_words = ceil_div(Tr, 64);
+    unsigned long long *dcnt = static_cast<unsigned long long *>(ctx->slot[SL_B_CNT]);
+    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream,
+                       static_cast<const int32_t *>(ctx->slot[SL_B_TRIS]), Tr, static_cast<const int8_t *>(ctx->slot[SL_B_SIGN]),
+                       static_cast<const double *>(ctx->slot[SL_B_RXY]), dmatch, static_cast<uint8_t *>(ctx->slot[SL_B_FLAG]),
+                       static_cast<unsigned long long *>(ctx->slot[SL_B_MASK]), dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       static_cast<const unsigned long long *>(ctx->slot[SL_B_MASK]), n_words, Tr,
+                       static_cast<int32_t *>(ctx->slot[SL_B_VIOL]), dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
+    SAME_TRY(same_down(ctx, h, dcnt, 2 * sizeof(unsigned long long)));
+    if (out_flag) SAME_TRY(same_down(ctx, out_flag, ctx->slot[SL_B_FLAG], (size_t)Tr));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_checked = (int64_t)h[0];
+    *out_nviol = (int64_t)h[1];
+    if (h[1] && out_viol_idx) {
+        SAME_TRY(same_down(ctx, out_viol_idx, ctx->slot[SL_B_VIOL], (size_t)h[1] * sizeof(int32_t)));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SAME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int same_sweep_bind(same_ctx *ctx, const int32_t *tris, int64_t Tr, const int8_t *src_sign, const double *rxy,
+                    int64_t n_r, int64_t n_m, const int32_t *pairs, int64_t P) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, Tr >= 0 && n_r >= 0 && n_m >= 0 && P >= 0 && Tr < ((int64_t)1 << 31));
+    REQUIRE(ctx, (Tr == 0 || (tris && src_sign)) && (n_r == 0 || rxy) && (P == 0 || pairs));
+    SAME_TRY(same_use(ctx));
+    ctx->bound = false;
+    SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n_m, "triangles"));
+    for (int64_t p = 0; p < P; ++p)
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
+            ctx->err = "pair index out of range";
+            return SAME_ERANGE;
+        }
+    void *d;
+    SAME_TRY(same_up(ctx, SL_B_TRIS, tris, (size_t)Tr * 3 * sizeof(int32_t), &d));
+    SAME_TRY(same_up(ctx, SL_B_SIGN, src_sign, (size_t)Tr, &d));
+    SAME_TRY(same_up(ctx, SL_B_RXY, rxy, (size_t)n_r * 2 * sizeof(double), &d));
+    SAME_TRY(same_up(ctx, SL_B_PAIRS, pairs, (size_t)P * 2 * sizeof(int32_t), &d));
+    SAME_TRY(same_slot(ctx, SL_B_MATCH, (size_t)n_m * sizeof(int32_t), &d));
+    SAME_TRY(same_slot(ctx, SL_B_PIDX, (size_t)n_m * sizeof(int32_t), &d));
+    SAME_TRY(same_slot(ctx, SL_B_FLAG, (size_t)Tr, &d));
+    SAME_TRY(same_slot(ctx, SL_B_VIOL, (size_t)Tr * sizeof(int32_t), &d));
+    SAME_TRY(same_slot(ctx, SL_B_MASK, (size_t)(ceil_div(Tr, 256) * 4 + 4) * sizeof(unsigned long long), &d));
+    SAME_TRY(same_slot(ctx, SL_B_CNT, 4 * sizeof(unsigned long long), &d));
+    SAME_TRY(same_slot(ctx, SL_B_X, (size_t)P * sizeof(double), &d));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->b_Tr = Tr; ctx->b_nr = n_r; ctx->b_nm = n_m; ctx->b_P = P;
+    ctx->bound = true;
+    return SAME_OK;
+}
+
+int same_orient_sweep(same_ctx *ctx, const int32_t *match, int64_t *out_checked, int32_t *out_viol_idx,
+                      int64_t *out_nviol, uint8_t *out_flag) {
+    REQUIRE(ctx, ctx && ctx->bound && out_checked && out_nviol);
+    REQUIRE(ctx, ctx->b_nm == 0 || match);
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, match, ctx->b_nm, -1, ctx->b_nr, "match"));
+    int32_t *dmatch = static_cast<int32_t *>(ctx->slot[SL_B_MATCH]);
+    if (ctx->b_nm) HIP_TRY(ctx, hipMemcpyAsync(dmatch, match, (size_t)ctx->b_nm * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return run_orient(ctx, dmatch, out_checked, out_viol_idx, out_nviol, out_flag);
+}
+
+int same_orient_sweep_x(same_ctx *ctx, const double *x_vals, int64_t *out_checked, int32_t *out_viol_idx,
+                        int64_t *out_nviol, uint8_t *out_flag, int32_t *out_match, int32_t *out_pair_idx) {
+    REQUIRE(ctx, ctx && ctx->bound && out_checked && out_nviol);
+    REQUIRE(ctx, ctx->b_P == 0 || x_vals);
+    SAME_TRY(same_use(ctx));
+    const int64_t P = ctx->b_P, n_m = ctx->b_nm;
+    double *dx = static_cast<double *>(ctx->slot[SL_B_X]);
+    int32_t *dmatch = static_cast<int32_t *>(ctx->slot[SL_B_MATCH]);
+    int32_t *dpidx = static_cast<int32_t *>(ctx->slot[SL_B_PIDX]);
+    const int32_t *dpairs = static_cast<const int32_t *>(ctx->slot[SL_B_PAIRS]);
+    if (P) HIP_TRY(ctx, hipMemcpyAsync(dx, x_vals, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (n_m) {
+        hipLaunchKernelGGL(match_init_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dpidx, n_m);
+        if (P) hipLaunchKernelGGL(match_scan_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dx, dpairs, P, dpidx);
+        hipLaunchKernelGGL(match_resolve_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dpairs, dpidx, n_m, dmatch);
+        HIP_TRY(ctx, hipGetLastError());
+        if (out_match) SAME_TRY(same_down(ctx, out_match, dmatch, (size_t)n_m * sizeof(int32_t)));
+        if (out_pair_idx) SAME_TRY(same_down(ctx, out_pair_idx, dpidx, (size_t)n_m * sizeof(int32_t)));
+    }
+    return run_orient(ctx, dmatch, out_checked, out_viol_idx, out_nviol, out_flag);
+}
+
+int same_xyorder_sweep(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy, int64_t n_r,
+                       const int32_t *tris, int64_t Tr, const int32_t *match, uint8_t *edge_flags, uint8_t *tri_flag,
+                       uint8_t *point_flag, int64_t counts[3]) {
+    REQUIRE(ctx, ctx && counts);
+    REQUIRE(ctx, n_m >= 0 && n_r >= 0 && Tr >= 0 && (n_m == 0 || point_flag));
+    counts[0] = counts[1] = counts[2] = 0;
+    if (n_m) memset(point_flag, 0, (size_t)n_m);
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, axy && tris && match && edge_flags && tri_flag && (n_r == 0 || rxy));
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n_m, "triangles"));
+    SAME_TRY(check_index_range(ctx, match, n_m, -1, n_r, "match"));
+    double *dax, *drx;
+    int32_t *dtris, *dmatch;
+    uint8_t *dedge, *dtf, *dpf;
+    unsigned long long *dcnt;
+    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n_m * 2, &dax));
+    SAME_TRY(up_as(ctx, SL_RXY, rxy, (size_t)n_r * 2, &drx));
+    SAME_TRY(up_as(ctx, SL_TRIS, tris, (size_t)Tr * 3, &dtris));
+    SAME_TRY(up_as(ctx, SL_MATCH, match, (size_t)n_m, &dmatch));
+    SAME_TRY(slot_as(ctx, SL_FLAG0, (size_t)Tr * 3, &dedge));
+    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)Tr, &dtf));
+    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_m, &dpf));
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dcnt));
+    HIP_TRY(ctx, hipMemsetAsync(dpf, 0, (size_t)n_m, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(xyorder_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dax, drx, dtris, Tr, dmatch, dedge, dtf,
+                       dpf, dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
+    SAME_TRY(same_down(ctx, edge_flags, dedge, (size_t)Tr * 3));
+    SAME_TRY(same_down(ctx, tri_flag, dtf, (size_t)Tr));
+    SAME_TRY(same_down(ctx, point_flag, dpf, (size_t)n_m));
+    SAME_TRY(same_down(ctx, h, dcnt, 3 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < 3; ++q) counts[q] = (int64_t)h[q];
+    return SAME_OK;
+}
+
+int same_pair_rowmin(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P, int64_t n_m,
+                     double *out_min) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, P >= 0 && n_m >= 0);
+    if (n_m == 0) return SAME_OK;
+    REQUIRE(ctx, out_min && (P == 0 || (pairs && costs)));
+    SAME_TRY(same_use(ctx));
+    for (int64_t p = 0; p < P; ++p)
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m) { ctx->err = "pair row out of range"; return SAME_ERANGE; }
+    int32_t *dp;
+    double *dc, *dout;
+    unsigned long long *dk;
+    SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
+    SAME_TRY(up_as(ctx, SL_X, costs, (size_t)P, &dc));
+    SAME_TRY(slot_as(ctx, SL_MASK, (size_t)n_m, &dk));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_m, &dout));
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, 0xFFF0000000000000ull /* key(+inf) */);
+    if (P) hipLaunchKernelGGL(rowmin_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dk);
+    hipLaunchKernelGGL(rowmin_decode_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out_min, dout, (size_t)n_m * sizeof(double)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_assign_matrix(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P, const double *unmatched,
+                       int64_t n_m, int64_t n_r, double big_m, double *out) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, P >= 0 && n_m >= 0 && n_r >= 0);
+    if (n_m == 0) return SAME_OK;
+    REQUIRE(ctx, out && unmatched && (P == 0 || (pairs && costs)));
+    SAME_TRY(same_use(ctx));
+    const int64_t ld = n_r + n_m, total = n_m * ld;
+    // duplicate (i, j) entries: the reference's scatter keeps the last one; resolve on the host index-wise
+    std::vector<int32_t> winner((size_t)P);
+    {
+        // pairs are nearly always unique; detect duplicates with a sort-free pass over a hash of (i, j)
+        std::vector<int64_t> key((size_t)P);
+        for (int64_t p = 0; p < P; ++p) {
+            if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
+                ctx->err = "pair index out of range";
+                return SAME_ERANGE;
+            }
+            key[p] = (int64_t)pairs[2 * p] * n_r + pairs[2 * p + 1];
+            winner[p] = (int32_t)p;
+        }
+        std::vector<int64_t> order((size_t)P);
+        for (int64_t p = 0; p < P; ++p) order[p] = p;
+        bool sorted = true;
+        for (int64_t p = 1; p < P && sorted; ++p) sorted = key[p - 1] < key[p];
+        if (!sorted) {
+            std::vector<std::pair<int64_t, int64_t>> kv((size_t)P);
+            for (int64_t p = 0; p < P; ++p) kv[p] = {key[p], p};
+            std::sort(kv.begin(), kv.end());
+            for (int64_t p = 0; p + 1 < P; ++p)
+                if (kv[p].first == kv[p + 1].first) winner[kv[p].second] = -1;  // a later duplicate exists
+        }
+    }
+    int32_t *dp, *dwin;
+    double *dc, *dun, *dout;
+    SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
+    SAME_TRY(up_as(ctx, SL_MATCH, winner.data(), (size_t)P, &dwin));
+    SAME_TRY(up_as(ctx, SL_X, costs, (size_t)P, &dc));
+    SAME_TRY(up_as(ctx, SL_SIZE, unmatched, (size_t)n_m, &dun));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)total, &dout));
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(grid_for(ceil_div(total, 2))), dim3(256), 0, ctx->stream, dout, total, big_m);
+    if (P) hipLaunchKernelGGL(scatter_pairs_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, ld, dout, dwin);
+    hipLaunchKernelGGL(diag_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dun, n_m, n_r, ld, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out, dout, (size_t)total * sizeof(double)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *boxes, int64_t n_boxes,
+                      int64_t *out_count, uint8_t *out_mask) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, n >= 0 && n_boxes >= 0);
+    if (n_boxes == 0) return SAME_OK;
+    REQUIRE(ctx, boxes && out_count && (n == 0 || xy));
+    for (int64_t b = 0; b < n_boxes; ++b) out_count[b] = 0;
+    if (n == 0) return SAME_OK;
+    SAME_TRY(same_use(ctx));
+    double *dxy, *dbox;
+    unsigned long long *dcnt;
+    uint8_t *dmask = nullptr;
+    SAME_TRY(up_as(ctx, SL_AXY, xy, (size_t)n * 2, &dxy));
+    SAME_TRY(up_as(ctx, SL_X, boxes, (size_t)n_boxes * 4, &dbox));
+    SAME_TRY(slot_as(ctx, SL_MASK, (size_t)n_boxes, &dcnt));
+    if (out_mask) SAME_TRY(slot_as(ctx, SL_FLAG0, (size_t)n_boxes * n, &dmask));
+    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, (size_t)n_boxes * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(window_count_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dxy, n, dbox, n_boxes, dcnt, dmask);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out_count, dcnt, (size_t)n_boxes * sizeof(unsigned long long)));
+    if (out_mask) SAME_TRY(same_down(ctx, out_mask, dmask, (size_t)n_boxes * n));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+}  // extern "C"

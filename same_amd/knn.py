@@ -1,0 +1,73 @@
+"""KNN prune within a radius: utils.find_knn_within_radius (src/utils.py:709-742) and
+knn_utils.find_knn_with_cell_type_priority (src/knn_utils.py:5-78), same signatures.
+
+The per-row radius query + top-k runs in the HIP kernel (csrc/knn.hip); the frame compaction
+(np.unique of used rows, iloc + reset_index, pair re-indexing) is host work on small index
+arrays, vectorised here instead of the reference's dict lookups."""
+import numpy as np
+
+from . import ops
+
+
+def _xy(df):
+    return np.ascontiguousarray(df[["X", "Y"]].to_numpy(dtype=np.float64))
+
+
+def pairs_from_padded(idx, row_offset=0):
+    """Row-major walk of the -1 padded lists: aligned i ascending, rank ascending within i."""
+    rows, cols = np.nonzero(idx >= 0)
+    return np.column_stack((rows.astype(np.int64) + int(row_offset), idx[rows, cols].astype(np.int64)))
+
+
+def compact_pairs(aligned_df, ref_df, knn_pairs):
+    """src/utils.py:734-742."""
+    ua, inv_a = np.unique(knn_pairs[:, 0], return_inverse=True)
+    ur, inv_r = np.unique(knn_pairs[:, 1], return_inverse=True)
+    new_aligned_df = aligned_df.iloc[ua].reset_index(drop=True)
+    new_ref_df = ref_df.iloc[ur].reset_index(drop=True)
+    new_valid_pairs = np.column_stack((inv_a.reshape(-1), inv_r.reshape(-1))).astype(np.int64)
+    if len(knn_pairs) == 0:
+        new_valid_pairs = np.array([])  # what np.array([]) of an empty comprehension gives (src/utils.py:741)
+    return new_aligned_df, new_ref_df, new_valid_pairs
+
+
+def find_knn_within_radius(aligned_df, ref_df, radius=25, knn=5, verbose=True, ctx=None):
+    idx, _, _ = ops.knn_prune(_xy(aligned_df), _xy(ref_df), radius, knn, want_d2=False, ctx=ctx)
+    knn_pairs = pairs_from_padded(idx)
+    if verbose:
+        print(f"Number of valid pairs after knn: {len(knn_pairs)}")
+    return compact_pairs(aligned_df, ref_df, knn_pairs)
+
+
+def find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=5, verbose=True, ctx=None):
+    """Sequential by construction: `ref_points_matched` carries from one aligned row to the next
+    (src/knn_utils.py:28-65), so this pass stays on the host over the device-pruned lists."""
+    aligned_df, ref_df, all_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+    axy, rxy = _xy(aligned_df), _xy(ref_df)
+    atype = aligned_df["cell_type"].to_numpy()
+    rtype = ref_df["cell_type"].to_numpy()
+    all_pairs = np.asarray(all_pairs, dtype=np.int64).reshape(-1, 2)
+    # the reference re-sorts each row by sqrt(dx^2+dy^2) with a stable sort (src/knn_utils.py:40-49)
+    d = np.sqrt((axy[all_pairs[:, 0], 0] - rxy[all_pairs[:, 1], 0]) ** 2 + (axy[all_pairs[:, 0], 1] - rxy[all_pairs[:, 1], 1]) ** 2)
+    order = np.lexsort((np.arange(len(d)), d, all_pairs[:, 0]))
+    pi, pj = all_pairs[order, 0], all_pairs[order, 1]
+    starts = np.flatnonzero(np.r_[True, pi[1:] != pi[:-1]]) if len(pi) else np.array([], dtype=np.int64)
+    ends = np.r_[starts[1:], len(pi)] if len(pi) else starts
+    filtered, taken = [], set()
+    same_type = keep_all = 0
+    for s, e in zip(starts, ends):
+        i, j0 = int(pi[s]), int(pj[s])
+        if rtype[j0] == atype[i] and j0 not in taken:
+            filtered.append((i, j0))
+            taken.add(j0)
+            same_type += 1
+        else:
+            filtered.extend((i, int(j)) for j in pj[s:e])
+            keep_all += 1
+    if verbose:
+        print(f"Total pairs after filtering: {len(filtered)}")
+        # the reference divides unguarded here (src/knn_utils.py:76)
+        print(f"Average pairs per matched point: {len(filtered) / (same_type + keep_all):.2f}")
+    elif same_type + keep_all == 0:
+        raise ZeroDivisionError("division by zero")  # same failure as the reference's summary print
+    return aligned_df, ref_df, filtered

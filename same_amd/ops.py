@@ -1,0 +1,235 @@
+"""Array-level wrappers over the C ABI (one function per libsame_hip entry point).
+
+Inputs are NumPy arrays (converted to the ABI's dtypes / C order); outputs are fresh NumPy
+arrays.  These are the only callers of the library besides bench.py; the modules that mirror
+the reference's functions (knn.py, cost.py, triangles.py, sweeps.py, init_helpers.py) are
+written on top of them.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_c, c_i64, default_context
+
+F64, F32, I32, I8, U8, I64 = np.float64, np.float32, np.int32, np.int8, np.uint8, np.int64
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else default_context()
+
+
+def _tris(triangles):
+    t = np.asarray(triangles)
+    return as_c(t.reshape(-1, 3) if t.size else np.zeros((0, 3)), I32)
+
+
+def pair_cost(A, R, axy, rxy, pairs, w, ctx=None):
+    ctx = _ctx(ctx)
+    A, R = as_c(A, F64), as_c(R, F64)
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    pairs = as_c(pairs, I32).reshape(-1, 2)
+    T = A.shape[1] if A.ndim == 2 else 0
+    out = np.empty(len(pairs), F64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_pair_cost_f64(ctx.handle, A.ctypes.data, R.ctypes.data, len(axy), len(rxy), T, axy.ctypes.data,
+                                             rxy.ctypes.data, pairs.ctypes.data, len(pairs), float(w), out.ctypes.data),
+                  "same_pair_cost_f64")
+    return out
+
+
+def dense_cost(A, R, axy, rxy, w, row_begin=0, row_end=None, dtype=F64, ctx=None):
+    ctx = _ctx(ctx)
+    dt = np.dtype(dtype)
+    assert dt in (np.dtype(F64), np.dtype(F32))
+    A, R = as_c(A, dt), as_c(R, dt)
+    axy, rxy = as_c(axy, dt).reshape(-1, 2), as_c(rxy, dt).reshape(-1, 2)
+    n_m, n_r = len(axy), len(rxy)
+    row_end = n_m if row_end is None else int(row_end)
+    T = A.shape[1] if A.ndim == 2 else 0
+    out = np.empty((max(row_end - row_begin, 0), n_r), dt)
+    fn = ctx.lib.same_dense_cost_f64 if dt == np.dtype(F64) else ctx.lib.same_dense_cost_f32
+    with ctx.lock:
+        ctx.check(fn(ctx.handle, A.ctypes.data, R.ctypes.data, n_m, n_r, T, axy.ctypes.data, rxy.ctypes.data, int(row_begin),
+                     row_end, float(w), out.ctypes.data, n_r), "same_dense_cost")
+    return out
+
+
+def knn_prune(axy, rxy, radius, knn, row_begin=0, row_end=None, want_d2=True, ctx=None):
+    """-> (idx (rows,k) int32 -1 padded, d2 (rows,k) f64 +inf padded or None, cnt (rows,) int32)."""
+    ctx = _ctx(ctx)
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    n_m, n_r = len(axy), len(rxy)
+    row_end = n_m if row_end is None else int(row_end)
+    rows = max(row_end - row_begin, 0)
+    idx = np.empty((rows, int(knn)), I32)
+    d2 = np.empty((rows, int(knn)), F64) if want_d2 else None
+    cnt = np.empty(rows, I32)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_knn_prune(ctx.handle, axy.ctypes.data, n_m, rxy.ctypes.data, n_r, int(row_begin), row_end,
+                                         float(radius), int(knn), idx.ctypes.data, _lib._ptr(d2), cnt.ctypes.data),
+                  "same_knn_prune")
+    return idx, d2, cnt
+
+
+def tri_classify(xy, triangles, radius, angle_enabled, cos_thr, type_id=None, ctx=None):
+    ctx = _ctx(ctx)
+    xy = as_c(xy, F64).reshape(-1, 2)
+    tris = _tris(triangles)
+    Tr = len(tris)
+    tid = None if type_id is None else as_c(type_id, I32)
+    cls, perim, maxcos = np.empty(Tr, U8), np.empty(Tr, F64), np.empty(Tr, F64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_tri_classify(ctx.handle, xy.ctypes.data, len(xy), tris.ctypes.data, Tr, float(radius),
+                                            int(angle_enabled), float(cos_thr), _lib._ptr(tid), cls.ctypes.data,
+                                            perim.ctypes.data, maxcos.ctypes.data), "same_tri_classify")
+    return cls, perim, maxcos
+
+
+def tri_sign_weight(xy, size, triangles, ctx=None):
+    ctx = _ctx(ctx)
+    xy = as_c(xy, F64).reshape(-1, 2)
+    tris = _tris(triangles)
+    Tr = len(tris)
+    size = None if size is None else as_c(size, F64)
+    sign = np.empty(Tr, I8)
+    weight = None if size is None else np.empty(Tr, F64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_tri_sign_weight(ctx.handle, xy.ctypes.data, _lib._ptr(size), len(xy), tris.ctypes.data, Tr,
+                                               sign.ctypes.data, _lib._ptr(weight)), "same_tri_sign_weight")
+    return sign, weight
+
+
+class BoundSweep:
+    """Resident state of the lazy-constraint sweep (model._* of src/same.py:1153-1158)."""
+
+    def __init__(self, triangles, src_sign, rxy, n_aligned, pairs=None, ctx=None):
+        self.ctx = _ctx(ctx)
+        self.tris = _tris(triangles)
+        self.src_sign = as_c(np.asarray(src_sign), I8)
+        self.rxy = as_c(rxy, F64).reshape(-1, 2)
+        self.n_m = int(n_aligned)
+        self.pairs = None if pairs is None else as_c(pairs, I32).reshape(-1, 2)
+        self.P = 0 if self.pairs is None else len(self.pairs)
+        self.Tr = len(self.tris)
+        assert len(self.src_sign) == self.Tr
+        self._viol = np.empty(max(self.Tr, 1), I32)
+        self._bind()
+
+    def _bind(self):
+        c = self.ctx
+        with c.lock:
+            c.check(c.lib.same_sweep_bind(c.handle, self.tris.ctypes.data, self.Tr, self.src_sign.ctypes.data,
+                                          self.rxy.ctypes.data, len(self.rxy), self.n_m, _lib._ptr(self.pairs), self.P),
+                    "same_sweep_bind")
+        c._bound_owner = id(self)
+
+    def _ensure_bound(self):
+        if getattr(self.ctx, "_bound_owner", None) != id(self):
+            self._bind()
+
+    def sweep_match(self, match, want_flag=False):
+        """match (n_aligned,) int32, -1 unmatched -> (checked, violating idx ascending[, flag])."""
+        c = self.ctx
+        self._ensure_bound()
+        match = as_c(match, I32)
+        assert len(match) == self.n_m
+        checked, nviol = c_i64(0), c_i64(0)
+        flag = np.empty(self.Tr, U8) if want_flag else None
+        with c.lock:
+            c.check(c.lib.same_orient_sweep(c.handle, match.ctypes.data, ctypes.byref(checked), self._viol.ctypes.data,
+                                            ctypes.byref(nviol), _lib._ptr(flag)), "same_orient_sweep")
+        viol = self._viol[: nviol.value].copy()
+        return (checked.value, viol, flag) if want_flag else (checked.value, viol)
+
+    def sweep_x(self, x_vals):
+        """x_vals (P,) -> (checked, violating idx ascending, match, pair_idx)."""
+        c = self.ctx
+        self._ensure_bound()
+        assert self.pairs is not None
+        x = as_c(x_vals, F64)
+        assert len(x) == self.P
+        checked, nviol = c_i64(0), c_i64(0)
+        match, pidx = np.empty(self.n_m, I32), np.empty(self.n_m, I32)
+        with c.lock:
+            c.check(c.lib.same_orient_sweep_x(c.handle, x.ctypes.data, ctypes.byref(checked), self._viol.ctypes.data,
+                                              ctypes.byref(nviol), None, match.ctypes.data, pidx.ctypes.data),
+                    "same_orient_sweep_x")
+        return checked.value, self._viol[: nviol.value].copy(), match, pidx
+
+
+def xyorder_sweep(axy, rxy, triangles, match, ctx=None):
+    ctx = _ctx(ctx)
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    tris = _tris(triangles)
+    match = as_c(match, I32)
+    Tr, n_m = len(tris), len(axy)
+    assert len(match) == n_m
+    edge, tflag, pflag = np.empty((Tr, 3), U8), np.empty(Tr, U8), np.empty(n_m, U8)
+    counts = np.zeros(3, I64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_xyorder_sweep(ctx.handle, axy.ctypes.data, n_m, rxy.ctypes.data, len(rxy), tris.ctypes.data, Tr,
+                                             match.ctypes.data, edge.ctypes.data, tflag.ctypes.data, pflag.ctypes.data,
+                                             counts.ctypes.data), "same_xyorder_sweep")
+    return edge, tflag, pflag, counts
+
+
+def area_flip(axy, rxy, triangles, match, ctx=None):
+    ctx = _ctx(ctx)
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    tris = _tris(triangles)
+    match = as_c(match, I32)
+    Tr = len(tris)
+    assert len(match) == len(axy)
+    before, after = np.empty(Tr, F64), np.empty(Tr, F64)
+    m3, fl = np.empty((Tr, 3), U8), np.empty(Tr, U8)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_area_flip(ctx.handle, axy.ctypes.data, len(axy), rxy.ctypes.data, len(rxy), tris.ctypes.data, Tr,
+                                         match.ctypes.data, before.ctypes.data, after.ctypes.data, m3.ctypes.data,
+                                         fl.ctypes.data), "same_area_flip")
+    return before, after, m3, fl
+
+
+def pair_rowmin(pairs, costs, n_aligned, ctx=None):
+    ctx = _ctx(ctx)
+    pairs, costs = as_c(pairs, I32).reshape(-1, 2), as_c(costs, F64)
+    out = np.empty(int(n_aligned), F64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_pair_rowmin(ctx.handle, pairs.ctypes.data, costs.ctypes.data, len(pairs), int(n_aligned),
+                                           out.ctypes.data), "same_pair_rowmin")
+    return out
+
+
+def assign_matrix(pairs, costs, unmatched, n_aligned, n_ref, big_m, ctx=None):
+    ctx = _ctx(ctx)
+    pairs, costs, unmatched = as_c(pairs, I32).reshape(-1, 2), as_c(costs, F64), as_c(unmatched, F64)
+    out = np.empty((int(n_aligned), int(n_ref) + int(n_aligned)), F64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_assign_matrix(ctx.handle, pairs.ctypes.data, costs.ctypes.data, len(pairs), unmatched.ctypes.data,
+                                             int(n_aligned), int(n_ref), float(big_m), out.ctypes.data), "same_assign_matrix")
+    return out
+
+
+def eager_signs(rxy, triangles, cand, ctx=None):
+    ctx = _ctx(ctx)
+    rxy = as_c(rxy, F64).reshape(-1, 2)
+    tris = _tris(triangles)
+    cand = as_c(cand, I32)
+    n_m, k = cand.shape
+    out = np.empty((len(tris), k, k, k), I8)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_eager_signs(ctx.handle, rxy.ctypes.data, len(rxy), tris.ctypes.data, len(tris), cand.ctypes.data,
+                                           n_m, k, out.ctypes.data), "same_eager_signs")
+    return out
+
+
+def window_count(xy, boxes, want_mask=False, ctx=None):
+    ctx = _ctx(ctx)
+    xy = as_c(xy, F64).reshape(-1, 2)
+    boxes = as_c(boxes, F64).reshape(-1, 4)
+    counts = np.zeros(len(boxes), I64)
+    mask = np.empty((len(boxes), len(xy)), U8) if want_mask else None
+    with ctx.lock:
+        ctx.check(ctx.lib.same_window_count(ctx.handle, xy.ctypes.data, len(xy), boxes.ctypes.data, len(boxes),
+                                            counts.ctypes.data, _lib._ptr(mask)), "same_window_count")
+    return (counts, mask.astype(bool)) if want_mask else counts

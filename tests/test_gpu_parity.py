@@ -1,0 +1,398 @@
+"""GPU parity: the HIP path (through the ctypes C ABI) against the reference's golden fixtures
+and against the CPU oracle on seeded inputs.  Integer / index / flag outputs and fp64 costs are
+compared bit-exactly (the fp64 contract of BASELINE.json is 1e-6 relative; the kernels keep the
+reference's operation order, so equality is what we assert)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import FULL_CASES, frames_from_golden, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import same_amd
+    from same_amd import _lib
+
+    assert _lib.device_count() >= 1, "GPU tests need a device; the product path has no CPU fallback"
+    return same_amd
+
+
+@pytest.fixture(scope="module")
+def ops(hip):
+    from same_amd import ops as _ops
+
+    return _ops
+
+
+def _compacted(g):
+    a_df, r_df, cols = frames_from_golden(g)
+    return a_df.iloc[g["kept_aligned"]].reset_index(drop=True), r_df.iloc[g["kept_ref"]].reset_index(drop=True), cols
+
+
+# ------------------------------------------------------------------------------------------ a2 / a3
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_knn_golden(hip, case):
+    g = load_golden(case)
+    a_df, r_df, _ = frames_from_golden(g)
+    na, nr, pairs = hip.find_knn_within_radius(a_df, r_df, g["params"][0], knn=int(g["params"][1]), verbose=False)
+    assert np.array_equal(na["__row"].to_numpy(), g["kept_aligned"])
+    assert np.array_equal(nr["__row"].to_numpy(), g["kept_ref"])
+    assert np.array_equal(np.asarray(pairs, dtype=np.int64), g["pairs"])
+    _, _, prio = hip.find_knn_with_cell_type_priority(a_df, r_df, g["params"][0], knn=int(g["params"][1]), verbose=False)
+    assert np.array_equal(np.asarray(prio, dtype=np.int64).reshape(-1, 2), g["pairs_priority"])
+
+
+def test_knn_adversarial(hip, ops, oracle):
+    g = load_golden("adversarial")
+    a = pd.DataFrame({"X": g["edge_axy"][:, 0], "Y": g["edge_axy"][:, 1]})
+    r = pd.DataFrame({"X": g["edge_rxy"][:, 0], "Y": g["edge_rxy"][:, 1], "__row": np.arange(len(g["edge_rxy"]))})
+    _, nr, pairs = hip.find_knn_within_radius(a, r, 5.0, knn=4, verbose=False)
+    assert np.array_equal(np.asarray(pairs), g["edge_pairs"]) and np.array_equal(nr["__row"].to_numpy(), g["edge_kept_ref"])
+    a = pd.DataFrame({"X": g["sparse_axy"][:, 0], "Y": g["sparse_axy"][:, 1], "__row": np.arange(len(g["sparse_axy"]))})
+    r = pd.DataFrame({"X": g["sparse_rxy"][:, 0], "Y": g["sparse_rxy"][:, 1], "__row": np.arange(len(g["sparse_rxy"]))})
+    na, nr, pairs = hip.find_knn_within_radius(a, r, 4.0, knn=3, verbose=False)
+    assert np.array_equal(na["__row"].to_numpy(), g["sparse_kept_aligned"])
+    assert np.array_equal(nr["__row"].to_numpy(), g["sparse_kept_ref"])
+    assert np.array_equal(np.asarray(pairs), g["sparse_pairs"])
+    # exact ties on a grid: documented rule (d2, ref index) == oracle, bit for bit
+    idx, d2, cnt = ops.knn_prune(g["grid_axy"], g["grid_rxy"], 1.5, 6)
+    oidx, od2, ocnt = oracle.knn_prune(g["grid_axy"], g["grid_rxy"], 1.5, 6)
+    assert np.array_equal(idx, oidx) and np.array_equal(d2, od2) and np.array_equal(cnt, ocnt)
+    # empty reference set / no neighbour at all
+    idx, d2, cnt = ops.knn_prune(g["grid_axy"], np.zeros((0, 2)), 1.5, 6)
+    assert (idx == -1).all() and (cnt == 0).all() and np.isinf(d2).all()
+    idx, _, cnt = ops.knn_prune(g["grid_axy"], g["grid_rxy"] + 1000.0, 1.5, 6)
+    assert (idx == -1).all() and (cnt == 0).all()
+    with pytest.raises(ValueError):
+        hip.prepare_same_inputs(r.assign(c1=1.0, cell_type="c1"), a.assign(X=a["X"] + 1e6, c1=1.0, cell_type="c1"), ["c1"],
+                                optim_params={"radius": 1.0}, verbose=False)
+
+
+@pytest.mark.parametrize("n_m,n_r,k,radius", [(1000, 1300, 8, 10.0), (2500, 2500, 32, 25.0), (777, 4100, 64, 60.0), (513, 65, 5, 400.0),
+                                               (64, 5000, 1, 30.0)])
+def test_knn_vs_oracle_seeded(ops, oracle, n_m, n_r, k, radius):
+    from same_amd import synth
+
+    r = synth.make_cells(n_r, 3, seed=10, rho=0.01)
+    m = synth.make_cells(n_m, 3, seed=11, side=r["side"])
+    idx, d2, cnt = ops.knn_prune(m["xy"], r["xy"], radius, k)
+    oidx, od2, ocnt = oracle.knn_prune(m["xy"], r["xy"], radius, k)
+    assert np.array_equal(cnt, ocnt)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(d2, od2)
+    # row blocks are independent: any block equals the slice of the whole (sharding invariant)
+    b0, b1 = n_m // 3, n_m // 3 + 200
+    bidx, _, bcnt = ops.knn_prune(m["xy"], r["xy"], radius, k, row_begin=b0, row_end=min(b1, n_m))
+    assert np.array_equal(bidx, idx[b0:b1]) and np.array_equal(bcnt, cnt[b0:b1])
+
+
+def test_knn_overflow_prune_path(ops, oracle):
+    """More than KNN_CAP (128) in-radius candidates per row forces the in-kernel prune."""
+    rng = np.random.default_rng(5)
+    rxy = rng.uniform(0, 10, size=(3000, 2))
+    axy = rng.uniform(2, 8, size=(100, 2))
+    for k in (3, 32, 64):
+        idx, d2, cnt = ops.knn_prune(axy, rxy, 6.0, k)
+        oidx, od2, ocnt = oracle.knn_prune(axy, rxy, 6.0, k)
+        assert np.array_equal(idx, oidx) and np.array_equal(d2, od2) and np.array_equal(cnt, ocnt)
+    # duplicates (exact d2 ties) inside the overflow path
+    rxy2 = np.repeat(rxy[:600], 4, axis=0)
+    idx, d2, cnt = ops.knn_prune(axy, rxy2, 6.0, 48)
+    oidx, od2, ocnt = oracle.knn_prune(axy, rxy2, 6.0, 48)
+    assert np.array_equal(idx, oidx) and np.array_equal(d2, od2)
+
+
+# ------------------------------------------------------------------------------------------ a4 / dense
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_pair_cost_golden(hip, ops, oracle, case):
+    g = load_golden(case)
+    na, nr, cols = _compacted(g)
+    sel = g["cost_sel"]
+    c = np.array(hip.pair_costs(na, nr, g["pairs"][sel], cols, g["params"][3]))
+    assert np.array_equal(c, g["costs"])  # bit-exact vs the reference's pandas loop
+    c2 = np.array(hip.pair_costs(na, nr, g["pairs"][sel[:200]], cols, 2.5))
+    assert np.array_equal(c2, g["costs_w2p5"])
+    call = np.array(hip.pair_costs(na, nr, g["pairs"], cols, g["params"][3]))
+    assert np.array_equal(call, g["all_costs"])
+    D = hip.dense_cost_matrix(na, nr, cols, g["params"][3])
+    p = g["pairs"]
+    assert np.array_equal(D[p[:, 0], p[:, 1]], g["all_costs"])
+    A, R = na[cols].to_numpy(), nr[cols].to_numpy()
+    axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
+    assert np.array_equal(D, oracle.dense_cost(A, R, axy, rxy, float(g["params"][3])))
+    D32 = ops.dense_cost(A, R, axy, rxy, float(g["params"][3]), dtype=np.float32)
+    O32 = oracle.dense_cost(A, R, axy, rxy, float(g["params"][3]), dtype=np.float32)
+    assert np.array_equal(D32, O32)
+    np.testing.assert_allclose(D32, D, rtol=2e-6)  # fp32 variant vs fp64 (tolerance: 1e-6-class, BASELINE cfg 5)
+
+
+@pytest.mark.parametrize("T", [0, 1, 2, 7, 20, 24, 25, 33, 48, 49, 70])
+@pytest.mark.parametrize("w", [1.0, 0.37])
+def test_dense_cost_all_T(ops, oracle, T, w):
+    rng = np.random.default_rng(T)
+    n_m, n_r = 257, 1031  # ragged: not multiples of the tile
+    A = rng.dirichlet(np.full(max(T, 1), 0.3), size=n_m)[:, :T] * 100 if T else np.zeros((n_m, 0))
+    R = rng.dirichlet(np.full(max(T, 1), 0.3), size=n_r)[:, :T] * 100 if T else np.zeros((n_r, 0))
+    axy, rxy = rng.uniform(0, 300, (n_m, 2)), rng.uniform(0, 300, (n_r, 2))
+    D = ops.dense_cost(A, R, axy, rxy, w, 3, 250)
+    assert np.array_equal(D, oracle.dense_cost(A, R, axy, rxy, w, 3, 250))
+    D32 = ops.dense_cost(A, R, axy, rxy, w, 3, 250, dtype=np.float32)
+    assert np.array_equal(D32, oracle.dense_cost(A, R, axy, rxy, w, 3, 250, dtype=np.float32))
+    # pair kernel == dense kernel on sampled pairs
+    pairs = np.column_stack((rng.integers(3, 250, 500), rng.integers(0, n_r, 500))).astype(np.int32)
+    c = ops.pair_cost(A, R, axy, rxy, pairs, w)
+    assert np.array_equal(c, D[pairs[:, 0] - 3, pairs[:, 1]])
+
+
+def test_cost_edge_shapes(ops):
+    z = np.zeros((0, 2))
+    assert ops.dense_cost(np.zeros((0, 4)), np.zeros((5, 4)), z, np.zeros((5, 2)), 1.0).shape == (0, 5)
+    assert ops.dense_cost(np.zeros((3, 4)), np.zeros((0, 4)), np.zeros((3, 2)), z, 1.0).shape == (3, 0)
+    assert len(ops.pair_cost(np.zeros((3, 4)), np.zeros((2, 4)), np.zeros((3, 2)), np.zeros((2, 2)), np.zeros((0, 2), np.int32), 1.0)) == 0
+    from same_amd._lib import SameHipError
+    with pytest.raises(SameHipError):  # out-of-range pair index is reported, never dereferenced
+        ops.pair_cost(np.zeros((3, 4)), np.zeros((2, 4)), np.zeros((3, 2)), np.zeros((2, 2)), np.array([[0, 2]], np.int32), 1.0)
+    with pytest.raises(SameHipError):
+        ops.knn_prune(np.zeros((3, 2)), np.zeros((3, 2)), 1.0, 65)
+
+
+# ------------------------------------------------------------------------------------------ a7 / a8 / a9
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_triangle_filter_golden(hip, case):
+    g = load_golden(case)
+    na, _, _ = _compacted(g)
+    pts = na[["X", "Y"]].to_numpy()
+    radius = g["params"][0]
+    mad = None if g["params"][2] < 0 else g["params"][2]
+    for tag, kw, rad in (("plain", dict(ignore_same_type_triangles=False, min_angle_deg=mad), radius),
+                         ("type", dict(ignore_same_type_triangles=True, min_angle_deg=mad), radius),
+                         ("noangle", dict(ignore_same_type_triangles=True, min_angle_deg=None), radius),
+                         ("a30", dict(ignore_same_type_triangles=True, min_angle_deg=30, ensure_min_triangle_per_node=False), radius),
+                         ("tight", dict(ignore_same_type_triangles=True, min_angle_deg=mad), radius * 0.35)):
+        kept, unc = hip.filter_triangles_by_radius(pts, g["delaunay"], rad, aligned_df=na, remove_unconstrained_nodes=True,
+                                                   verbose=False, **kw)
+        assert np.array_equal(np.array(kept, dtype=np.int64).reshape(-1, 3), g[f"tri_{tag}"]), tag
+        assert sorted(unc) == g[f"unc_{tag}"].tolist(), tag
+    tris = g["tri_plain"]
+    w, s = hip.triangle_weights_and_signs(na, tris)
+    assert np.array_equal(np.array(w, dtype=np.float64), g["tri_weights"]) and np.array_equal(np.array(s), g["source_signs"])
+    info = hip.precompute_triangle_info(na, tris, hip.build_simplex_map(len(na), tris))
+    keys = list(info.keys())
+    assert keys == g["tinfo_keys"].tolist()
+    b = np.array([[info[k]["bounds"][q] for q in ("min_x", "max_x", "min_y", "max_y")] for k in keys])
+    e = np.array([[info[k][q] for q in ("max_x_vertex", "min_x_vertex", "max_y_vertex", "min_y_vertex")] for k in keys])
+    assert np.array_equal(b, g["tinfo_bounds"]) and np.array_equal(e, g["tinfo_extreme"])
+
+
+def test_triangle_filter_adversarial(hip, ops):
+    g = load_golden("adversarial")
+    tdf = pd.DataFrame({"X": g["adv_pts"][:, 0], "Y": g["adv_pts"][:, 1], "cell_type": g["adv_type"].astype(object)})
+    for tag, kw in (("45", dict(min_angle_deg=45, ignore_same_type_triangles=False)),
+                    ("45t", dict(min_angle_deg=45, ignore_same_type_triangles=True)),
+                    ("none", dict(min_angle_deg=None, ignore_same_type_triangles=True)),
+                    ("0", dict(min_angle_deg=0, ignore_same_type_triangles=False)),
+                    ("15", dict(min_angle_deg=15, ignore_same_type_triangles=True))):
+        for rad in (10.0, 3.0, 1.0):
+            kept, unc = hip.filter_triangles_by_radius(g["adv_pts"], g["adv_tris"], rad, aligned_df=tdf,
+                                                       remove_unconstrained_nodes=True, verbose=False, **kw)
+            assert np.array_equal(np.array(kept, dtype=np.int64).reshape(-1, 3), g[f"adv_kept_{tag}_{rad}"]), (tag, rad)
+            assert sorted(unc) == g[f"adv_unc_{tag}_{rad}"].tolist(), (tag, rad)
+    assert hip.filter_triangles_by_radius(g["adv_pts"], np.zeros((0, 3), dtype=int), 10.0, aligned_df=tdf,
+                                          ignore_same_type_triangles=True, verbose=False) == []
+    sign, _ = ops.tri_sign_weight(g["adv_pts"], None, g["adv_tris"])
+    assert np.array_equal(sign.astype(np.float64), g["adv_signs"])
+
+
+def test_triangles_vs_oracle_seeded(ops, oracle):
+    from scipy.spatial import Delaunay
+    from same_amd import synth
+
+    m = synth.make_cells(20000, 6, seed=3)
+    tris = Delaunay(m["xy"]).simplices
+    for mad, rad in ((15, 25.0), (5, 12.0), (None, 30.0), (40, 100.0)):
+        en, thr = oracle.cos_threshold(mad)
+        cls, perim, mc = ops.tri_classify(m["xy"], tris, rad, en, thr, m["cell_type"])
+        ocls, operim, omc = oracle.tri_classify(m["xy"], tris, rad, mad, m["cell_type"])
+        assert np.array_equal(cls, ocls) and np.array_equal(perim, operim) and np.array_equal(mc, omc)
+    s, w = ops.tri_sign_weight(m["xy"], m["size"] * 1.5, tris)
+    os_, ow = oracle.tri_sign_weight(m["xy"], m["size"] * 1.5, tris)
+    assert np.array_equal(s, os_) and np.array_equal(w, ow)
+
+
+# ------------------------------------------------------------------------------------------ a5
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_mip_start_golden(hip, case):
+    g = load_golden(case)
+    na, nr, _ = _compacted(g)
+    vp = [tuple(p) for p in g["pairs"].tolist()]
+    kw = dict(valid_pairs=vp, costs=list(g["all_costs"]), n_aligned=len(na), n_ref=len(nr),
+              aligned_sizes=na["size"].to_numpy(dtype=float), max_matches=1, verbose=False)
+    ch, un = hip.compute_mip_start_pairs(no_match_penalty=g["params"][4], init_method="greedy", **kw)
+    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3), g["greedy_chosen"]) and sorted(un) == g["greedy_unmatched"].tolist()
+    ch, un = hip.compute_mip_start_pairs(no_match_penalty=float(g["greedy_lo_penalty"][0]), init_method="greedy", **kw)
+    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3), g["greedy_lo_chosen"]) and sorted(un) == g["greedy_lo_unmatched"].tolist()
+    ch, un = hip.compute_mip_start_pairs(no_match_penalty=g["params"][4], init_method="hungarian", init_hungarian_max_n=100000, **kw)
+    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3), g["hungarian_chosen"]) and sorted(un) == g["hungarian_unmatched"].tolist()
+    assert hip.compute_mip_start_pairs(no_match_penalty=1.0, init_method="hungarian", init_hungarian_max_n=10, **kw) == ([], set())
+    with pytest.raises(ValueError):
+        hip.compute_mip_start_pairs(no_match_penalty=1.0, init_method="bogus", **kw)
+    with pytest.raises(ValueError):
+        hip.compute_mip_start_pairs(no_match_penalty=1.0, init_method="hungarian", **{**kw, "max_matches": 2})
+
+
+def test_assign_matrix_duplicates(ops, oracle):
+    pairs = np.array([[0, 1], [1, 0], [0, 1], [2, 2], [0, 1]], np.int32)
+    costs = np.array([5.0, 6.0, 7.0, 8.0, 9.0])
+    un = np.array([100.0, 200.0, 300.0])
+    m = ops.assign_matrix(pairs, costs, un, 3, 4, 1e9)
+    o = np.empty((3, 7))
+    oracle.lib().orc_assign_matrix(pairs, costs, 5, un, 3, 4, 1e9, o.reshape(-1))
+    assert np.array_equal(m, o) and m[0, 1] == 9.0
+    assert np.array_equal(ops.pair_rowmin(pairs, costs, 4), np.array([5.0, 6.0, 8.0, np.inf]))
+
+
+# ------------------------------------------------------------------------------------------ a10 / a11 / a12 / a14
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_sweeps_golden(hip, ops, case):
+    g = load_golden(case)
+    na, nr, _ = _compacted(g)
+    tris = g["tri_plain"]
+    rxy = nr[["X", "Y"]].to_numpy()
+    sweep = hip.LazyOrientationSweep(g["pairs"], tris, g["source_signs"], rxy, len(na))
+    for _ in range(2):  # the bound state is reused across incumbents
+        checked, viol, pidx = sweep.sweep(g["x_vals"])
+        assert checked == int(g["lazy_checked"][0])
+        assert [v[0] for v in viol] == g["lazy_violating"].tolist()
+        assert all(tuple(tris[v[0]]) == tuple(v[1:]) for v in viol)
+    ch = g["greedy_chosen"]
+    assert np.array_equal(pidx[ch[:, 0]], ch[:, 2])
+    # cut selection logic (src/same.py:671-692)
+    n_v = len(g["lazy_violating"])
+    assert len(sweep.select_cuts(g["x_vals"], allowed_frac=None, per_inc_limit=None)) == n_v
+    assert len(sweep.select_cuts(g["x_vals"], allowed_frac=None, per_inc_limit=7)) == min(7, n_v)
+    assert sweep.select_cuts(g["x_vals"], allowed_frac=1.0) == []
+    assert len(sweep.select_cuts(g["x_vals"], allowed_frac=0.0, per_inc_limit=1000, remaining_global=3)) == min(3, n_v)
+    assert sweep.select_cuts(np.zeros(len(g["x_vals"]))) == []
+    # a11
+    m_df = pd.DataFrame({"aligned_idx": ch[:, 0], "ref_idx": ch[:, 1]})
+    info = hip.precompute_triangle_info(na, tris, hip.build_simplex_map(len(na), tris))
+    from test_oracle_golden import _check_violations
+    _check_violations(hip.verify_spatial_preservation(na, nr, m_df, info), g, "")
+    # a12
+    before, after, flipped, m3 = hip.triangle_area_flips(na, nr, tris, {int(i): int(j) for i, j, _ in ch})
+    assert np.array_equal(np.array([before[t] for t in range(len(tris))]), g["area_before"])
+    aft = np.array([np.nan if after[t] is None else after[t] for t in range(len(tris))])
+    assert np.array_equal(aft, g["area_after"], equal_nan=True)
+    assert flipped == g["area_flipped"].tolist()
+    assert np.array_equal(np.array([m3[t] for t in range(len(tris))], dtype=np.uint8), g["area_matched3"])
+    # a14
+    combos = g["eager_combos"]
+    tr = np.arange(3 * len(combos), dtype=np.int32).reshape(-1, 3)
+    s = ops.eager_signs(rxy, tr, combos.reshape(-1, 1).astype(np.int32))
+    assert np.array_equal(s.reshape(-1), g["eager_signs"])
+
+
+@pytest.mark.parametrize("case", ["simulated_st", "simulated_elastic"])
+def test_stored_reference_runs(hip, case):
+    g = load_golden(case)
+    a = pd.DataFrame({"X": g["aligned_xy"][:, 0], "Y": g["aligned_xy"][:, 1]})
+    r = pd.DataFrame({"X": g["ref_xy"][:, 0], "Y": g["ref_xy"][:, 1]})
+    m = pd.DataFrame({"aligned_idx": g["matches"][:, 0], "ref_idx": g["matches"][:, 1]})
+    info = {int(k): {"vertices": vtx} for k, vtx in zip(g["tinfo_keys"], g["tinfo_vertices"])}
+    from test_oracle_golden import _check_violations
+    v = hip.verify_spatial_preservation(a, r, m, info)
+    _check_violations(v, g, "stored_")
+
+
+def test_sweeps_adversarial(hip, ops):
+    g = load_golden("adversarial")
+    pts, tris, rxy = g["adv_pts"], g["adv_tris"], g["sw_rxy"]
+    a = pd.DataFrame({"X": pts[:, 0], "Y": pts[:, 1]})
+    r = pd.DataFrame({"X": rxy[:, 0], "Y": rxy[:, 1]})
+    m = pd.DataFrame({"aligned_idx": g["sw_matches"][:, 0], "ref_idx": g["sw_matches"][:, 1]})
+    info = hip.precompute_triangle_info(a, tris, hip.build_simplex_map(len(a), tris))
+    assert list(info.keys()) == g["sw_tinfo_keys"].tolist()
+    from test_oracle_golden import _check_violations
+    _check_violations(hip.verify_spatial_preservation(a, r, m, info), g, "sw_")
+    a2r = {}
+    for ai, ri in g["sw_matches"]:
+        a2r[int(ai)] = int(ri)
+    before, after, flipped, m3 = hip.triangle_area_flips(a, r, tris, a2r)
+    assert np.array_equal(np.array([before[t] for t in range(len(tris))]), g["sw_area_before"])
+    assert flipped == g["sw_area_flipped"].tolist()
+    sweep = hip.LazyOrientationSweep(g["sw_pairs"], tris, g["adv_signs"], rxy, len(pts))
+    checked, viol, _ = sweep.sweep(g["sw_x"])  # a later pair with x>0.5 overrides an earlier one
+    assert checked == int(g["sw_lazy_checked"][0]) and [t[0] for t in viol] == g["sw_lazy_violating"].tolist()
+    # empty triangle list
+    e = hip.LazyOrientationSweep(g["sw_pairs"], np.zeros((0, 3), dtype=int), np.zeros(0), rxy, len(pts))
+    assert e.sweep(g["sw_x"])[:2] == (0, [])
+
+
+def test_sweeps_vs_oracle_seeded(ops, oracle):
+    from scipy.spatial import Delaunay
+    from same_amd import synth
+
+    ref = synth.make_cells(60000, 4, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    tris = Delaunay(mov["xy"]).simplices.astype(np.int32)  # ~114k triangles: several compaction chunks
+    sign, _ = ops.tri_sign_weight(mov["xy"], None, tris)
+    rng = np.random.default_rng(2)
+    match = rng.integers(-1, len(ref["xy"]), len(mov["xy"])).astype(np.int32)
+    near = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 1, want_d2=False)[0][:, 0]
+    match = np.where(rng.random(len(match)) < 0.8, near, match).astype(np.int32)
+    sweep = ops.BoundSweep(tris, sign, ref["xy"], len(mov["xy"]))
+    checked, viol, flag = sweep.sweep_match(match, want_flag=True)
+    ochecked, oviol, oflag = oracle.orient_sweep(tris, sign, ref["xy"], match)
+    assert checked == ochecked and np.array_equal(viol, oviol) and np.array_equal(flag, oflag)
+    assert np.all(np.diff(viol) > 0)  # ascending
+    e, tf, pf, counts = ops.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
+    oe, otf, opf, oc = oracle.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
+    assert np.array_equal(e, oe) and np.array_equal(tf, otf) and np.array_equal(pf, opf) and np.array_equal(counts, oc)
+    b, a, m3, fl = ops.area_flip(mov["xy"], ref["xy"], tris, match)
+    ob, oa, om3, ofl = oracle.area_flip(mov["xy"], ref["xy"], tris, match)
+    assert np.array_equal(b, ob) and np.array_equal(a, oa, equal_nan=True) and np.array_equal(m3, om3) and np.array_equal(fl, ofl)
+    # all unmatched / all matched to one point (every ref triangle collinear -> sign 0 -> skipped)
+    assert sweep.sweep_match(np.full(len(match), -1, np.int32))[0] == 0
+    assert sweep.sweep_match(np.zeros(len(match), np.int32))[0] == 0
+
+
+# ------------------------------------------------------------------------------------------ a13
+def test_window_plan_vs_oracle(hip, oracle):
+    from same_amd import synth
+
+    ref = synth.make_cells(6000, 3, seed=0, side=1000.0)
+    mov = synth.make_jittered(ref, seed=1)
+    mov["xy"][:, 0] = np.clip(mov["xy"][:, 0], 0, None)
+    # carve a hole so that merge-right / merge-down trigger
+    hole = (ref["xy"][:, 0] > 300) & (ref["xy"][:, 0] < 520) & (ref["xy"][:, 1] > 250) & (ref["xy"][:, 1] < 700)
+    rxy = ref["xy"][~hole]
+    for ws, ov, mc in ((300, 100, 60), (250, 0, 120), (400, 150, 10), (180, 60, 150)):
+        plan = hip.window_plan(rxy, mov["xy"], ws, ov, mc)
+        oplan = oracle.window_plan(rxy, mov["xy"], ws, ov, mc)
+        assert len(plan) == len(oplan) and len(plan) > 0
+        for p, o in zip(plan, oplan):
+            for key in ("i0", "j0", "i", "j", "window_id", "box", "trim", "n_ref", "n_mov"):
+                assert p[key] == o[key], (ws, ov, mc, key)
+        assert any((p["i"], p["j"]) != (p["i0"], p["j0"]) for p in plan) or mc <= 10
+
+
+# ------------------------------------------------------------------------------------------ end to end (pre-MIP)
+@pytest.mark.parametrize("case", FULL_CASES)
+def test_prepare_same_inputs_golden(hip, case):
+    g = load_golden(case)
+    a_df, r_df, cols = frames_from_golden(g)
+    mad = None if g["params"][2] < 0 else g["params"][2]
+    prep = hip.prepare_same_inputs(r_df, a_df, cols, optim_params=dict(radius=g["params"][0], knn=int(g["params"][1]),
+                                   min_angle_deg=mad, ignore_same_type_triangles=False, dist_ct_coeff=g["params"][3]),
+                                   verbose=False)
+    assert np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), g["pairs"])
+    assert np.array_equal(np.array(prep.costs), g["all_costs"])
+    assert np.array_equal(np.array(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), g["tri_plain"])
+    assert np.array_equal(np.array(prep.triangle_weights, dtype=np.float64), g["tri_weights"])
+    assert np.array_equal(np.array(prep.source_signs), g["source_signs"])
+    assert list(prep.triangle_info.keys()) == g["tinfo_keys"].tolist()
+    assert prep.n_aligned == len(g["kept_aligned"]) and prep.n_ref == len(g["kept_ref"])
+    assert prep.ref_coords_xy[0] == tuple(prep.ref_df[["X", "Y"]].iloc[0])
