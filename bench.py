@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- one timed pass of the pre-MIP hot path per step, on N MI355X (one rank per GPU).
+
+Workload `dense100k` (the configuration BASELINE.json's metric is quoted on; it fits one GPU):
+  per rank 100 000 reference cells x 100 000 aligned cells, 20 type columns, fp64:
+    1. dense L1 cost build, rows x n_ref -> 80 GB resident in HBM          (dominant kernel)
+    2. radius-25 / k=32 KNN prune + costs of the padded candidate lists
+    3. [N > 1] RCCL all-gather of the pruned candidate lists (idx int32 + cost fp64)
+    4. Delaunay-triangle classes (radius/angle/type), weights and source signs
+    5. orientation sweep (lazy-constraint body), XY-order sweep, signed-area flips under a
+       nearest-reference matching
+  Inputs are resident in HBM before the timed region (the Delaunay triangulation itself is an
+  input: scipy/Qhull on the host, as in the reference).  Weak scaling: every rank owns its own
+  block of 100 000 aligned rows against the replicated reference set.
+value = aligned-ref cell pairs covered per second, summed over ranks (n_ranks*1e10 per step).
+
+The `roofline` object is for the dense kernel: algorithmic bytes 8*N_r*rows + 8*(T+2)*(N_r+rows)
+ over its mean launch time, measured with HIP events on the stream it runs on.
+`cpu_baseline` times the CPU oracle (scalar C port of the reference's arithmetic, 1 thread) on
+a bounded row sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (n_ref, rows_per_rank, T, k, radius)
+    "dense100k": (100_000, 100_000, 20, 32, 25.0),
+    "cfg2": (10_000, 10_000, 20, 32, 25.0),
+    "tiny": (4_000, 4_000, 20, 32, 25.0),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="dense100k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=2000)
+    return ap.parse_args()
+
+
+class Dist:
+    """Host-side control plane: rendezvous, barrier, max-reduce.  torch.distributed (gloo) is
+    plumbing only; the data-path collective is RCCL inside libsame_hip."""
+
+    def __init__(self, n):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != n:
+            raise SystemExit(f"--gpus {n} but WORLD_SIZE={self.world}: launch with torch.distributed.run --nproc-per-node {n}")
+        self.dist = None
+        if self.world > 1:
+            import datetime
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max(self, v):
+        if not self.dist:
+            return v
+        import torch
+
+        t = torch.tensor([v], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def bcast_bytes(self, b):
+        if not self.dist:
+            return b
+        obj = [b]
+        self.dist.broadcast_object_list(obj, src=0)
+        return obj[0]
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    d = Dist(args.gpus)
+    from scipy.spatial import Delaunay
+
+    from same_amd import _lib, synth
+    from same_amd.dist import RcclGather
+    from same_amd.triangles import cos_threshold
+
+    n_ref, rows, T, k, radius = WORKLOADS[args.workload]
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libsame_hip has no CPU fallback")
+    ctx = _lib.Context(d.local_rank % _lib.device_count())
+    L, H = ctx.lib, ctx.handle
+
+    # ---- synthetic inputs (seeded), resident before timing ---------------------------------
+    ref = synth.make_cells(n_ref, T, seed=0)
+    mov = synth.make_cells(rows, T, seed=1 + d.rank, side=ref["side"])
+    tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)  # host input (Qhull), as in the reference
+    Tr = len(tris)
+    dA, dR = ctx.to_device(mov["types"]), ctx.to_device(ref["types"])
+    dax, drx = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"])
+    dsize, dtype_id = ctx.to_device(mov["size"]), ctx.to_device(mov["cell_type"])
+    dtris = ctx.to_device(tris)
+    ld = (n_ref + 1) & ~1
+    dD = ctx.alloc(rows * ld * 8)                       # the dense cost block (80 GB at dense100k)
+    didx, dcost, dcnt = ctx.alloc(rows * k * 4), ctx.alloc(rows * k * 8), ctx.alloc(rows * 4)
+    gidx = gcost = None
+    gather = None
+    if d.world > 1:
+        gather = RcclGather(ctx, d.world, d.rank, d.bcast_bytes)
+        gidx, gcost = ctx.alloc(rows * k * 4 * d.world), ctx.alloc(rows * k * 8 * d.world)
+    dcls, dperim, dmaxcos = ctx.alloc(Tr), ctx.alloc(Tr * 8), ctx.alloc(Tr * 8)
+    dsign, dweight = ctx.alloc(Tr), ctx.alloc(Tr * 8)
+    dedge, dtflag, dpflag, dcounts = ctx.alloc(Tr * 3), ctx.alloc(Tr), ctx.alloc(rows), ctx.alloc(32)
+    dbefore, dafter, dm3, dflip = ctx.alloc(Tr * 8), ctx.alloc(Tr * 8), ctx.alloc(Tr * 3), ctx.alloc(Tr)
+    en, thr = cos_threshold(15)
+    chk = ctx.check
+
+    # candidate matching for the sweeps: nearest reference within the radius (from one untimed prune)
+    chk(L.same_knn_prune_dev(H, dax.ptr, drx.ptr, n_ref, 0, rows, radius, k, didx.ptr, None, dcnt.ptr), "knn")
+    idx0 = didx.download((rows, k), np.int32)
+    match = np.ascontiguousarray(idx0[:, 0])
+    dmatch = ctx.to_device(match)
+    chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
+    sign0 = dsign.download((Tr,), np.int8)
+    chk(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, rows, None, 0), "bind")
+    import ctypes
+    checked, nviol = ctypes.c_int64(0), ctypes.c_int64(0)
+    viol = np.empty(max(Tr, 1), np.int32)
+
+    dense_ms = []
+
+    def step(timed_dense=True):
+        if timed_dense:
+            chk(L.same_timer_start(H), "timer")
+        chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense")
+        if timed_dense:
+            ms = ctypes.c_float(0)
+            chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
+            dense_ms.append(ms.value)
+        chk(L.same_knn_prune_dev(H, dax.ptr, drx.ptr, n_ref, 0, rows, radius, k, didx.ptr, None, dcnt.ptr), "knn")
+        chk(L.same_padded_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, 0, rows, k, didx.ptr, 1.0, dcost.ptr), "padded")
+        if gather is not None:
+            gather.allgather_dev(didx, gidx, rows * k * 4)
+            gather.allgather_dev(dcost, gcost, rows * k * 8)
+        chk(L.same_tri_classify_dev(H, dax.ptr, dtris.ptr, Tr, radius, en, thr, dtype_id.ptr, dcls.ptr, dperim.ptr, dmaxcos.ptr), "cls")
+        chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
+        chk(L.same_xyorder_sweep_dev(H, dax.ptr, rows, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")
+        chk(L.same_area_flip_dev(H, dax.ptr, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dbefore.ptr, dafter.ptr, dm3.ptr, dflip.ptr), "area")
+        chk(L.same_orient_sweep_dev(H, dmatch.ptr, ctypes.byref(checked), viol.ctypes.data, ctypes.byref(nviol)), "orient")
+
+    for _ in range(args.warmup):
+        step(timed_dense=False)
+    ctx.sync()
+    d.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    d.barrier()
+    dt = d.max(time.perf_counter() - t0)
+
+    # ---- sanity: spot-check this run's outputs against the oracle (not timed, rank 0) -----------
+    ok = True
+    cpu = None
+    if d.rank == 0:
+        from oracle import same_oracle as orc
+
+        rs = np.random.default_rng(0).choice(rows, 4, replace=False)
+        for i in rs:
+            got = dD.download((n_ref,), np.float64, offset_bytes=int(i) * ld * 8)
+            want = orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(i), int(i) + 1)[0]
+            ok &= bool(np.array_equal(got, want))
+        oidx, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, 256)
+        ok &= bool(np.array_equal(didx.download((256, k), np.int32), oidx))
+        och, oviol, _ = orc.orient_sweep(tris, sign0, ref["xy"], match)
+        ok &= (och == checked.value) and bool(np.array_equal(oviol, viol[: nviol.value]))
+        if not ok:
+            raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
+
+        if d.world == 1 and not args.no_cpu_baseline:
+            S = min(args.cpu_sample_rows, rows)
+            c0 = time.perf_counter()
+            orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, 0, S)
+            oi, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, S)
+            rr, cc = np.nonzero(oi >= 0)
+            orc.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oi[rr, cc])), 1.0)
+            c1 = time.perf_counter()
+            orc.tri_classify(mov["xy"], tris, radius, 15, mov["cell_type"])
+            orc.tri_sign_weight(mov["xy"], mov["size"], tris)
+            orc.orient_sweep(tris, sign0, ref["xy"], match)
+            orc.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
+            orc.area_flip(mov["xy"], ref["xy"], tris, match)
+            c2 = time.perf_counter()
+            t_cpu = (c1 - c0) + (c2 - c1) * S / rows
+            cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port",
+                   "sample": f"rows [0,{S}) of {rows} x {n_ref} refs: dense cost + knn prune + pair costs "
+                             f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{rows} "
+                             f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}"}
+
+    if d.rank == 0:
+        pairs_per_step = float(n_ref) * rows * d.world
+        t_dense = float(np.mean(dense_ms)) * 1e-3
+        dense_bytes = 8.0 * n_ref * rows + 8.0 * (T + 2) * (n_ref + rows)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        achieved = dense_bytes / t_dense / 1e9
+        out = {
+            "metric": "cell-pairs/sec on 100k x 100k cost build + edge-cross sweep; % HBM roofline",
+            "value": pairs_per_step * args.steps / dt, "unit": "cell-pairs/s",
+            "n_gpus": d.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {rows} aligned x {n_ref} ref cells per GPU, T={T} type cols, fp64 dense L1 cost "
+                                   f"+ r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay triangles classify/sign + "
+                                   "orientation / XY-order / area-flip sweeps",
+                       "parallelism": f"aligned-row blocks x{d.world}" + (", RCCL all-gather of pruned lists" if d.world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "dense_cost_kernel<double,20,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3},
+            "cpu_baseline": cpu,
+            "parity_spot_check": "dense rows, knn rows and orientation sweep equal the oracle bit-for-bit",
+        }
+        print(json.dumps(out))
+    if gather is not None:
+        gather.close()
+    d.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -168,6 +168,25 @@ int same_area_flip(same_ctx *ctx, const double *axy, int64_t n_m, const double *
                    const int32_t *tris, int64_t Tr, const int32_t *match, double *out_before,
                    double *out_after, uint8_t *out_matched3, uint8_t *out_flipped);
 
+/* ---- device-resident forms of the triangle kernels and sweeps -------------------------
+ * Same semantics as the host-buffer entry points above; every pointer is a device pointer
+ * and the call only enqueues on the context's stream.  Index ranges are the caller's
+ * responsibility here (the host-buffer forms validate them).  dcounts = 3 x uint64. */
+int same_tri_classify_dev(same_ctx *ctx, const double *dxy, const int32_t *dtris, int64_t Tr,
+                          double radius, int angle_enabled, double cos_thr, const int32_t *dtype_id,
+                          uint8_t *dout_class, double *dout_perim, double *dout_maxcos);
+int same_tri_sign_weight_dev(same_ctx *ctx, const double *dxy, const double *dsize,
+                             const int32_t *dtris, int64_t Tr, int8_t *dout_sign, double *dout_weight);
+int same_area_flip_dev(same_ctx *ctx, const double *daxy, const double *drxy, const int32_t *dtris,
+                       int64_t Tr, const int32_t *dmatch, double *dout_before, double *dout_after,
+                       uint8_t *dout_matched3, uint8_t *dout_flipped);
+int same_xyorder_sweep_dev(same_ctx *ctx, const double *daxy, int64_t n_m, const double *drxy,
+                           const int32_t *dtris, int64_t Tr, const int32_t *dmatch,
+                           uint8_t *dedge_flags, uint8_t *dtri_flag, uint8_t *dpoint_flag,
+                           uint64_t *dcounts);
+int same_orient_sweep_dev(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked,
+                          int32_t *out_viol_idx, int64_t *out_nviol);
+
 /* ---- a5: MIP-start helpers ------------------------------------------------------------
  * Per-row minimum pair cost (src/init_helpers.py:118-122; +inf for rows without pairs) and
  * the dense assignment matrix [n_m][n_r+n_m] (src/init_helpers.py:151-155). */

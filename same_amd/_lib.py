@@ -56,6 +56,11 @@ _PROTOTYPES = {
     "same_orient_sweep_x": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp, c_vp, c_vp],
     "same_xyorder_sweep": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_area_flip": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "same_tri_classify_dev": [c_vp, c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
+    "same_tri_sign_weight_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "same_area_flip_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "same_xyorder_sweep_dev": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "same_orient_sweep_dev": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64)],
     "same_pair_rowmin": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "same_assign_matrix": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_dbl, c_vp],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],

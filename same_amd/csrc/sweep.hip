@@ -455,4 +455,29 @@ int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *
     return SAME_OK;
 }
 
+// ---- device-resident forms -------------------------------------------------------------------
+// dcounts: 3 x uint64 in HBM {comparisons, violations, violated triangles}; dpoint_flag is zeroed here.
+int same_xyorder_sweep_dev(same_ctx *ctx, const double *daxy, int64_t n_m, const double *drxy, const int32_t *dtris,
+                           int64_t Tr, const int32_t *dmatch, uint8_t *dedge_flags, uint8_t *dtri_flag,
+                           uint8_t *dpoint_flag, uint64_t *dcounts) {
+    REQUIRE(ctx, ctx && Tr >= 0 && n_m >= 0 && dcounts && (n_m == 0 || dpoint_flag));
+    SAME_TRY(same_use(ctx));
+    if (n_m) HIP_TRY(ctx, hipMemsetAsync(dpoint_flag, 0, (size_t)n_m, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dcounts, 0, 3 * sizeof(uint64_t), ctx->stream));
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, daxy && drxy && dtris && dmatch && dedge_flags && dtri_flag);
+    hipLaunchKernelGGL(xyorder_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, daxy, drxy, dtris, Tr, dmatch, dedge_flags,
+                       dtri_flag, dpoint_flag, reinterpret_cast<unsigned long long *>(dcounts));
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+// orientation sweep on the bound state with a match vector that is already on the device
+int same_orient_sweep_dev(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx,
+                          int64_t *out_nviol) {
+    REQUIRE(ctx, ctx && ctx->bound && out_checked && out_nviol && (ctx->b_nm == 0 || dmatch));
+    SAME_TRY(same_use(ctx));
+    return run_orient(ctx, dmatch, out_checked, out_viol_idx, out_nviol, nullptr);
+}
+
 }  // extern "C"

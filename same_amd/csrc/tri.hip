@@ -237,4 +237,43 @@ int same_eager_signs(same_ctx *ctx, const double *rxy, int64_t n_r, const int32_
     return SAME_OK;
 }
 
+// ---- device-resident forms (operands already in HBM; enqueue only) --------------------------
+int same_tri_classify_dev(same_ctx *ctx, const double *dxy, const int32_t *dtris, int64_t Tr, double radius,
+                          int angle_enabled, double cos_thr, const int32_t *dtype_id, uint8_t *dout_class,
+                          double *dout_perim, double *dout_maxcos) {
+    REQUIRE(ctx, ctx && Tr >= 0);
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, dxy && dtris && dout_class && dout_perim && dout_maxcos);
+    SAME_TRY(same_use(ctx));
+    hipLaunchKernelGGL(tri_classify_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dxy, dtris, Tr, radius,
+                       angle_enabled, cos_thr, dtype_id, dout_class, dout_perim, dout_maxcos);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+int same_tri_sign_weight_dev(same_ctx *ctx, const double *dxy, const double *dsize, const int32_t *dtris, int64_t Tr,
+                             int8_t *dout_sign, double *dout_weight) {
+    REQUIRE(ctx, ctx && Tr >= 0 && ((dsize == nullptr) == (dout_weight == nullptr)));
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, dxy && dtris && dout_sign);
+    SAME_TRY(same_use(ctx));
+    hipLaunchKernelGGL(tri_sign_weight_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dxy, dsize, dtris, Tr, dout_sign,
+                       dout_weight);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+int same_area_flip_dev(same_ctx *ctx, const double *daxy, const double *drxy, const int32_t *dtris, int64_t Tr,
+                       const int32_t *dmatch, double *dout_before, double *dout_after, uint8_t *dout_matched3,
+                       uint8_t *dout_flipped) {
+    REQUIRE(ctx, ctx && Tr >= 0);
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, daxy && drxy && dtris && dmatch && dout_before && dout_after && dout_matched3 && dout_flipped);
+    SAME_TRY(same_use(ctx));
+    hipLaunchKernelGGL(area_flip_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, daxy, drxy, dtris, Tr, dmatch,
+                       dout_before, dout_after, dout_matched3, dout_flipped);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
 }  // extern "C"
