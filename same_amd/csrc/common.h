@@ -20,6 +20,8 @@ enum Slot {
     // bound sweep state (same_sweep_bind)
     SL_B_TRIS, SL_B_SIGN, SL_B_RXY, SL_B_PAIRS, SL_B_MATCH, SL_B_PIDX, SL_B_FLAG, SL_B_VIOL,
     SL_B_MASK, SL_B_CNT, SL_B_X,
+    // uniform-grid index of the reference cells (knn.hip)
+    SL_K_HIST, SL_K_RANK, SL_K_SXY, SL_K_SIDX, SL_K_BBOX,
     SL_COUNT
 };
 

@@ -16,6 +16,9 @@
 // with no LDS or vector-memory instruction per element.  Every lane stores 16 B per row
 // (CPL=2 doubles / 4 floats): one wave-instruction writes 1 KiB of one output row, a
 // workgroup 4 KiB.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -29,56 +32,162 @@ template <> __device__ __forceinline__ double absf<double>(double x) { return __
 template <> __device__ __forceinline__ float absf<float>(float x) { return __builtin_fabsf(x); }
 
 // Block = 256 threads = 4 waves side by side over 256*CPL ref columns; it sweeps `rows_per_block`
-// aligned rows.  grid = col_tiles * row_chunks, column tile fastest (neighbouring blocks write
-// neighbouring 4 KiB pieces of the same rows).
-template <typename F, int T, int CPL, bool VEC_STORE>
-__global__ __launch_bounds__(256) void dense_cost_kernel(
+// aligned rows.  Three things keep the fp64 VALU and the store stream overlapped:
+//
+// (1) Scalar-load pipelining.  SMEM returns out of order, so the only usable wait is lgkmcnt(0);
+//     the row is consumed in two halves and each half is fetched one phase ahead, always in the
+//     order  wait(current half) -> issue(next half) -> compute.  `touch` is an empty asm that
+//     merely *uses* one SGPR of the current half, which makes the compiler place its s_waitcnt
+//     there; the sched_barriers keep the next half's s_loads from moving above it; the loop body
+//     is a single basic block so nothing is sunk out of place.  Waits stay compiler-generated.
+// (2) Store decoupling.  A store holds its data VGPRs until the memory pipe has read them; if
+//     the next row's arithmetic wrote the same registers it would stall behind the (back-
+//     pressured) store.  DEPTH rows are therefore computed into DEPTH distinct result register
+//     sets per loop trip (`keep_alive` pins them), so a set is rewritten only DEPTH rows after its
+//     store was issued.  (Measured on MI355X: DEPTH 1/2/4/8 run within 1 % of each other at T=20 --
+//     the kernel is power-limited there, see DESIGN.md -- so DEPTH=2 is kept only because it is free.)
+// (3) Block -> tile map.  Blocks that share an XCD (blockIdx % 8) walk adjacent column tiles of
+//     the same row chunk, which gave the best store rate of the maps tried (6.8-7.0 TB/s store-only).
+__device__ __forceinline__ void touch(double v) { asm volatile("" ::"s"(v)); }
+__device__ __forceinline__ void touch(float v) { asm volatile("" ::"s"(v)); }
+__device__ __forceinline__ void keep_alive(double v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
+
+template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w, F dcoef,
-    F *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block) {
-    const int tile = blockIdx.x % col_tiles;
-    const int chunk = blockIdx.x / col_tiles;
-    const int64_t j0 = ((int64_t)tile * 256 + threadIdx.x) * CPL;
-    const int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
-    const int64_t i1 = (i0 + rows_per_block < row_end) ? i0 + rows_per_block : row_end;
+    F *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block, int64_t n_store, int map_mode,
+    int row_chunks) {
+    // VEC_STORE: every lane with j0 < n_store stores all CPL columns with one 16 B store (n_store is a
+    // multiple of CPL; columns in [n_r, n_store) are caller-owned padding).  Host guarantees
+    // rows_per_block % DEPTH == 0 and rows_per_block <= row_end - row_begin; the last chunk is shifted
+    // back to overlap its neighbour instead of being ragged (the overlap recomputes identical values).
+    static_assert(VEC_STORE || DEPTH == 1, "scalar-store variant is the simple one");
+    constexpr int H = (T + 1) / 2;  // first half: a[0..H); second half: a[H..T) + XY
+    constexpr int TT = T > 0 ? T : 1;
+    typedef F vecF __attribute__((ext_vector_type(CPL)));
+    int tile, chunk;
+    if (map_mode == 0) {  // column tile fastest
+        tile = blockIdx.x % col_tiles;
+        chunk = blockIdx.x / col_tiles;
+    } else if (map_mode == 1) {  // row chunk fastest
+        chunk = blockIdx.x % row_chunks;
+        tile = blockIdx.x / row_chunks;
+    } else {  // blocks that share an XCD (b % 8) take adjacent column tiles
+        const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
+        const unsigned per = (gridDim.x + 7u) >> 3;  // blocks per XCD group
+        const unsigned lin = xcd * per + k;          // may exceed the tile count: such blocks exit
+        tile = lin % col_tiles;
+        chunk = lin / col_tiles;
+        if (chunk >= row_chunks) return;
+    }
+    const int64_t j0 = ((int64_t)tile * (64 * WAVES) + threadIdx.x) * CPL;
+    int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
+    if (i0 + rows_per_block > row_end) i0 = row_end - rows_per_block;
 
-    F r[CPL][T > 0 ? T : 1];
+    F r[CPL][TT];
     F rx[CPL], ry[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         int64_t j = j0 + c;
-        if (j >= n_r) j = n_r - 1;  // clamp: lanes past the edge compute a valid column and do not store
+        if (j >= n_r) j = n_r - 1;  // clamp: lanes past the edge compute a valid column
         const F *rp = R + j * T;
 #pragma unroll
         for (int t = 0; t < T; ++t) r[c][t] = rp[t];
         rx[c] = rxy[2 * j];
         ry[c] = rxy[2 * j + 1];
     }
-    if (j0 >= n_r) return;
+    if (j0 >= (VEC_STORE ? n_store : n_r)) return;
 
-    F *orow = out + (i0 - row_begin) * ld + j0;
-    for (int64_t i = i0; i < i1; ++i, orow += ld) {
-        const F *__restrict__ a = A + i * T;  // wave-uniform -> scalar loads
-        const F ax = axy[2 * i], ay = axy[2 * i + 1];
-        F v[CPL];
+    F h0[H > 0 ? H : 1];
+    const F *__restrict__ arow = A + i0 * T;  // wave-uniform -> scalar loads
+    const F *__restrict__ axyrow = axy + 2 * i0;
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            F s = F(0);
+    for (int t = 0; t < H; ++t) h0[t] = arow[t];
+    char *orow = reinterpret_cast<char *>(out + (i0 - row_begin) * ld);  // wave-uniform row pointer
+    const unsigned lane_off = (unsigned)(j0 * sizeof(F));              // fixed per-lane byte offset (< 4 GiB rows)
+    const int64_t row_pitch = ld * (int64_t)sizeof(F);
+    constexpr int astride = T;
+    for (int q = 0; q < rows_per_block; q += DEPTH) {
+        vecF res[DEPTH];
 #pragma unroll
-            for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - r[c][t]);
-            const F dc = absf<F>(ax - rx[c]) + absf<F>(ay - ry[c]);
-            v[c] = w * s + dcoef * dc;
+        for (int d = 0; d < DEPTH; ++d) {
+            // ---- phase 0: wait(h0) -> issue(second half of this row) -> compute t in [0,H)
+            if (H > 0) touch(h0[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            F h1[T - H > 0 ? T - H : 1];
+#pragma unroll
+            for (int t = H; t < T; ++t) h1[t - H] = arow[t];
+            const F ax = axyrow[0], ay = axyrow[1];
+            __builtin_amdgcn_sched_barrier(0);
+            // columns interleaved per type: each dependent add sits CPL instructions after its subtract
+            F s[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) s[c] = F(0);
+#pragma unroll
+            for (int t = 0; t < H; ++t) {
+                F dd[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dd[c] = h0[t] - r[c][t];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) s[c] = s[c] + absf<F>(dd[c]);
+            }
+            // ---- phase 1: wait(h1, xy) -> issue(first half of the next row) -> compute t in [H,T), XY, store
+            touch(ax);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const bool last = (q + d + 1 >= rows_per_block);
+                const F *__restrict__ an = last ? arow : arow + astride;  // last row re-reads itself (harmless)
+#pragma unroll
+                for (int t = 0; t < H; ++t) h0[t] = an[t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = H; t < T; ++t) {
+                F dd[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dd[c] = h1[t - H] - r[c][t];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) s[c] = s[c] + absf<F>(dd[c]);
+            }
+            F v[CPL];
+            {
+                F dx[CPL], dy[CPL], dc[CPL], ws[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dx[c] = ax - rx[c];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dy[c] = ay - ry[c];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dc[c] = absf<F>(dx[c]) + absf<F>(dy[c]);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) ws[c] = w * s[c];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) dc[c] = dcoef * dc[c];
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) v[c] = ws[c] + dc[c];
+            }
+            if constexpr (VEC_STORE) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) res[d][c] = v[c];
+                vecF *dst = reinterpret_cast<vecF *>(orow + lane_off);
+                if constexpr (NT) __builtin_nontemporal_store(res[d], dst);
+                else *dst = res[d];
+            } else {
+                F *dst = reinterpret_cast<F *>(orow + lane_off);
+#pragma unroll
+                for (int c = 0; c < CPL; ++c)
+                    if (j0 + c < n_r) dst[c] = v[c];
+            }
+            orow += row_pitch;
+            arow += astride;
+            axyrow += 2;
         }
-        if (VEC_STORE && j0 + CPL <= n_r) {
-            typedef F vecF __attribute__((ext_vector_type(CPL)));
-            vecF pk;
+        if constexpr (VEC_STORE) {
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) pk[c] = v[c];
-            __builtin_nontemporal_store(pk, reinterpret_cast<vecF *>(orow));
-        } else {
+            for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-            for (int c = 0; c < CPL; ++c)
-                if (j0 + c < n_r) orow[c] = v[c];
+                for (int c = 0; c < CPL; ++c) keep_alive(res[d][c]);
         }
     }
 }
@@ -143,42 +252,94 @@ __global__ __launch_bounds__(256) void padded_cost_kernel(
     out[q] = w * s + dcoef * dc;
 }
 
-template <typename F, int T>
-int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
-                   int64_t re, F w, F *out, int64_t ld) {
-    constexpr int CPLV = vec_of<F>::cpl;
-    // T large: one column per lane keeps the register file within budget
-    constexpr int CPL = (T * CPLV * (int)(sizeof(F) / 4) <= 96) ? CPLV : 1;
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <typename F, int T, int CPL, bool VEC, int DEPTH, bool NT, int WAVES = 4>
+int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb, int64_t re,
+               F w, F *out_rb, int64_t ld, int64_t n_cols, int rows_per_block, int map_mode) {
+    // out_rb points at the output row of `rb`
     const int64_t rows = re - rb;
-    const int col_tiles = (int)ceil_div(n_r, 256 * CPL);
-    // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
-    int rows_per_block = 256;
-    while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
+    if (rows <= 0) return SAME_OK;
+    const int col_tiles = (int)ceil_div(n_cols, 64 * WAVES * CPL);
     const int64_t chunks = ceil_div(rows, rows_per_block);
-    const int64_t blocks = chunks * col_tiles;
-    if (blocks <= 0) return SAME_OK;
+    int64_t blocks = chunks * col_tiles;
+    if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
-    const F dcoef = w * F(0.001);
-    const bool vec_ok = CPL > 1 && (ld % CPL == 0) && (reinterpret_cast<uintptr_t>(out) % (CPL * sizeof(F)) == 0);
-    if (vec_ok)
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy,
-                           rxy, n_r, rb, re, w, dcoef, out, ld, col_tiles, rows_per_block);
-    else
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy,
-                           rxy, n_r, rb, re, w, dcoef, out, ld, col_tiles, rows_per_block);
+    hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, ctx->stream, A, R,
+                       axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols, map_mode,
+                       (int)chunks);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
 
+template <typename F, int T, int CPL, int DEPTH, bool NT>
+int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
+                     int64_t re, F w, F *out, int64_t ld, int64_t n_store) {
+    const int64_t rows = re - rb;
+    static const int rpb_env = env_int("SAME_DENSE_RPB", 0);
+    static const int map_env = env_int("SAME_DENSE_MAP", 2);
+    // vector stores need whole CPL-groups: n_store (a multiple of CPL, n_r <= n_store <= ld) says how many
+    // columns may be written; without such padding the scalar-store variant is used
+    const bool vec_ok = CPL > 1 && (ld % CPL == 0) && (n_store % CPL == 0) && n_store >= n_r && n_store <= ld &&
+                        (reinterpret_cast<uintptr_t>(out) % (CPL * sizeof(F)) == 0) && ld * (int64_t)sizeof(F) < ((int64_t)1 << 32);
+    if (!vec_ok) {
+        const int rpb = (int)std::min<int64_t>(rows, 64);
+        // ragged tail first (its own launch), then whole chunks with the overlapped-last-chunk rule
+        return launch_one<F, T, CPL, false, 1, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb, map_env == 2 ? 0 : map_env);
+    }
+    const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
+    // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
+    int rows_per_block = rpb_env > 0 ? rpb_env : 256;
+    while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
+    rows_per_block = std::max(DEPTH, rows_per_block / DEPTH * DEPTH);
+    if (rows >= rows_per_block)
+        return launch_one<F, T, CPL, true, DEPTH, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rows_per_block,
+                                                      map_env);
+    // fewer rows than one chunk: the largest DEPTH-multiple with the deep kernel, the remainder one row at a time
+    const int64_t main_rows = rows / DEPTH * DEPTH;
+    if (main_rows)
+        SAME_TRY((launch_one<F, T, CPL, true, DEPTH, NT>(ctx, A, R, axy, rxy, n_r, rb, rb + main_rows, w, out, ld, n_store,
+                                                         (int)main_rows, map_env)));
+    if (rows - main_rows)
+        SAME_TRY((launch_one<F, T, CPL, true, 1, NT>(ctx, A, R, axy, rxy, n_r, rb + main_rows, re, w, out + main_rows * ld, ld,
+                                                     n_store, (int)(rows - main_rows), map_env)));
+    return SAME_OK;
+}
+
+template <typename F, int T>
+int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
+                   int64_t re, F w, F *out, int64_t ld, int64_t n_store) {
+    constexpr int CPLV = vec_of<F>::cpl;
+    // T large: one column per lane keeps the register file within budget
+    constexpr int CPL = (T * CPLV * (int)(sizeof(F) / 4) <= 160) ? CPLV : 1;
+    constexpr int DEPTH = CPL > 1 ? 2 : 1;
+#ifdef SAME_DENSE_PROBE
+    // tuning probes (dev builds only)
+    if constexpr (T == 8 || T == 20) {
+        static const int waves = env_int("SAME_DENSE_WAVES", 4);
+        static const int rpb = std::max(2, env_int("SAME_DENSE_RPB", 256) / 2 * 2);
+        static const int mapm = env_int("SAME_DENSE_MAP", 2);
+        if (waves == 8) return launch_one<F, T, CPL, true, 2, true, 8>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
+        if (waves == 16) return launch_one<F, T, CPL, true, 2, true, 16>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
+        if (waves == 2) return launch_one<F, T, CPL, true, 2, true, 2>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
+        if (waves == 1) return launch_one<F, T, CPL, true, 2, true, 1>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
+    }
+#endif
+    return launch_dense_cfg<F, T, CPL, DEPTH, true>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
+}
+
 template <typename F>
 int launch_dense(same_ctx *ctx, const F *A, const F *R, int T, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
-                 int64_t re, F w, F *out, int64_t ld) {
+                 int64_t re, F w, F *out, int64_t ld, int64_t n_store) {
     REQUIRE(ctx, ctx && A && R && axy && rxy && out);
     REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && n_r >= 0 && rb >= 0 && re >= rb && ld >= n_r);
     SAME_TRY(same_use(ctx));
     if (n_r == 0 || re == rb) return SAME_OK;
     switch (T) {
-#define CASE_T(n) case n: return launch_dense_T<F, n>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld);
+#define CASE_T(n) case n: return launch_dense_T<F, n>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
         CASE_T(0) CASE_T(1) CASE_T(2) CASE_T(3) CASE_T(4) CASE_T(5) CASE_T(6) CASE_T(7) CASE_T(8)
         CASE_T(9) CASE_T(10) CASE_T(11) CASE_T(12) CASE_T(13) CASE_T(14) CASE_T(15) CASE_T(16)
         CASE_T(17) CASE_T(18) CASE_T(19) CASE_T(20) CASE_T(21) CASE_T(22) CASE_T(23) CASE_T(24)
@@ -216,7 +377,7 @@ int dense_host(same_ctx *ctx, const F *A, const F *R, int64_t n_m, int64_t n_r, 
     const int64_t rows = re - rb;
     const int64_t dld = (n_r + 3) & ~int64_t(3);  // device tile is padded so the 16 B store path is taken
     SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)rows * dld, &dout));
-    SAME_TRY(launch_dense<F>(ctx, dA, dR, T, dax, drx, n_r, rb, re, w, dout, dld));
+    SAME_TRY(launch_dense<F>(ctx, dA, dR, T, dax, drx, n_r, rb, re, w, dout, dld, dld));
     HIP_TRY(ctx, hipMemcpy2DAsync(out, (size_t)ld * sizeof(F), dout, (size_t)dld * sizeof(F), (size_t)n_r * sizeof(F),
                                   (size_t)rows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -230,13 +391,13 @@ extern "C" {
 int same_dense_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T, const double *daxy,
                             const double *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, double w,
                             double *dout, int64_t ld) {
-    return launch_dense<double>(ctx, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, dout, ld);
+    return launch_dense<double>(ctx, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, dout, ld, n_r);
 }
 
 int same_dense_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T, const float *daxy,
                             const float *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, float w,
                             float *dout, int64_t ld) {
-    return launch_dense<float>(ctx, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, dout, ld);
+    return launch_dense<float>(ctx, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, dout, ld, n_r);
 }
 
 int same_dense_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r, int T,

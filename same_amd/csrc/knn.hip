@@ -11,6 +11,10 @@
 // list in LDS at base + popcount(lower lanes).  When a list would overflow it is pruned in
 // place to its best k by rank counting; the same rank counting writes the final, sorted
 // rows.  No atomics, no inter-wave communication, results independent of sweep order.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -127,8 +131,227 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_prune_kernel(
     }
 }
 
-int launch_knn(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
-               double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
+// ---------------------------------------------------------------------------------------------
+// Grid-accelerated prune.  The reference cells are counting-sorted into a uniform grid whose cell
+// edge is a hair above the radius, so every in-radius neighbour of an aligned cell lies in the
+// 3 x 3 cells around it; in row-major cell order those are three contiguous runs of the sorted
+// array.  One wave per aligned row sweeps the three runs as one virtual index space (about one
+// 64-lane step at the reference's typical density), with the same exact fp64 inclusion test and
+// the same (d2, original ref index) ranking as the brute-force kernel -- the grid only prunes
+// candidates that cannot pass, so outputs are bit-identical.
+struct GridDesc {
+    double x0, y0, inv_cell;
+    int gx, gy;
+};
+
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// bbox[0..3] = keys of {min x, min y} (atomicMin) and {max x, max y} (atomicMax)
+__global__ __launch_bounds__(256) void bbox_kernel(const double *__restrict__ xy, int64_t n, unsigned long long *__restrict__ bbox) {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double2_t p = *reinterpret_cast<const double2_t *>(xy + 2 * (i < n ? i : n - 1));
+    unsigned long long kx0 = f64_key(p.x), ky0 = f64_key(p.y), kx1 = kx0, ky1 = ky0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kx0, off, 64), b = __shfl_xor(ky0, off, 64), c = __shfl_xor(kx1, off, 64),
+                                 d = __shfl_xor(ky1, off, 64);
+        kx0 = a < kx0 ? a : kx0; ky0 = b < ky0 ? b : ky0; kx1 = c > kx1 ? c : kx1; ky1 = d > ky1 ? d : ky1;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&bbox[0], kx0); atomicMin(&bbox[1], ky0); atomicMax(&bbox[2], kx1); atomicMax(&bbox[3], ky1);
+    }
+}
+
+__device__ __forceinline__ int cell_coord(double v, double v0, double inv_cell, int g) {
+    const double c = __builtin_floor((v - v0) * inv_cell);
+    return c < 0.0 ? 0 : (c >= (double)g ? g - 1 : (int)c);
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const double *__restrict__ rxy, int64_t n_r, GridDesc g,
+                                                          unsigned *__restrict__ hist, unsigned *__restrict__ rank) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_r) return;
+    const int cx = cell_coord(rxy[2 * j], g.x0, g.inv_cell, g.gx), cy = cell_coord(rxy[2 * j + 1], g.y0, g.inv_cell, g.gy);
+    rank[j] = atomicAdd(&hist[(int64_t)cy * g.gx + cx], 1u);
+}
+
+// in-place exclusive scan of hist[0..n] (n+1 entries; hist[n] receives the total), one block
+__global__ __launch_bounds__(1024) void grid_scan_kernel(unsigned *__restrict__ hist, int64_t n) {
+    __shared__ unsigned wave_sum[16];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t q = base + tid;
+        const unsigned c = q < n ? hist[q] : 0u;
+        unsigned incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        unsigned wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += wave_sum[w];
+        if (q < n) hist[q] = carry_s + wave_off + (incl - c);
+        __syncthreads();
+        if (tid == 1023) carry_s += wave_off + incl;
+        __syncthreads();
+    }
+    if (tid == 0) hist[n] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const double *__restrict__ rxy, int64_t n_r, GridDesc g,
+                                                            const unsigned *__restrict__ start, const unsigned *__restrict__ rank,
+                                                            double *__restrict__ sxy, int32_t *__restrict__ sidx) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_r) return;
+    const double x = rxy[2 * j], y = rxy[2 * j + 1];
+    const int cx = cell_coord(x, g.x0, g.inv_cell, g.gx), cy = cell_coord(y, g.y0, g.inv_cell, g.gy);
+    const unsigned pos = start[(int64_t)cy * g.gx + cx] + rank[j];
+    sxy[2 * (int64_t)pos] = x;
+    sxy[2 * (int64_t)pos + 1] = y;
+    sidx[pos] = (int32_t)j;
+}
+
+__global__ __launch_bounds__(64 * KNN_WAVES) void knn_grid_kernel(
+    const double *__restrict__ axy, const double *__restrict__ sxy, const int32_t *__restrict__ sidx,
+    const unsigned *__restrict__ start, GridDesc g, int64_t row_begin, int64_t row_end, double r2, int k,
+    int32_t *__restrict__ out_idx, double *__restrict__ out_d2, int32_t *__restrict__ out_cnt) {
+    __shared__ RowList lists[KNN_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t i = row_begin + (int64_t)blockIdx.x * KNN_WAVES + wave;
+    if (i >= row_end) return;
+    RowList &L = lists[wave];
+    const double ax = axy[2 * i], ay = axy[2 * i + 1];
+    // unclamped cell of the aligned point; neighbours clipped to the grid
+    const double fcx = __builtin_floor((ax - g.x0) * g.inv_cell), fcy = __builtin_floor((ay - g.y0) * g.inv_cell);
+    int cnt = 0;
+    // a point farther than one cell outside the grid has no neighbour within the radius
+    if (fcx >= -1.0 && fcx <= (double)g.gx && fcy >= -1.0 && fcy <= (double)g.gy) {
+        const int cx = (int)fcx, cy = (int)fcy;
+        const int xlo = cx - 1 < 0 ? 0 : cx - 1, xhi = cx + 1 > g.gx - 1 ? g.gx - 1 : cx + 1;
+        unsigned s[3], n[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int yy = cy - 1 + q;
+            s[q] = 0; n[q] = 0;
+            if (yy >= 0 && yy < g.gy && xlo <= xhi) {
+                s[q] = start[(int64_t)yy * g.gx + xlo];
+                n[q] = start[(int64_t)yy * g.gx + xhi + 1] - s[q];
+            }
+        }
+        const unsigned total = n[0] + n[1] + n[2];
+        typedef double double2_t __attribute__((ext_vector_type(2)));
+        for (unsigned base = 0; base < total; base += 64) {
+            const unsigned v = base + lane;
+            const bool valid = v < total;
+            unsigned pos = v < n[0] ? s[0] + v : (v < n[0] + n[1] ? s[1] + (v - n[0]) : s[2] + (v - n[0] - n[1]));
+            if (!valid) pos = s[0];
+            const double2_t p = *reinterpret_cast<const double2_t *>(sxy + 2 * (int64_t)pos);
+            const int32_t j = sidx[pos];
+            const double dx = p.x - ax, dy = p.y - ay;
+            const double d2 = dx * dx + dy * dy;
+            const bool in = valid && d2 <= r2;
+            const unsigned long long mask = __ballot(in);
+            if (mask) {
+                const int m = __builtin_popcountll(mask);
+                if (cnt + m > KNN_CAP) cnt = prune_in_place(L, cnt, k, lane);
+                const int slot = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (in) { L.d2[slot] = d2; L.j[slot] = j; }
+                cnt += m;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int keep = cnt < k ? cnt : k;
+    const int64_t o = (i - row_begin) * k;
+#pragma unroll
+    for (int p = 0; p < KNN_CAP / 64; ++p) {
+        const int c = lane + 64 * p;
+        if (c < cnt) {
+            const double d = L.d2[c];
+            const int32_t jj = L.j[c];
+            const int rk = rank_of(L, cnt, d, jj);
+            if (rk < k) {
+                out_idx[o + rk] = jj;
+                if (out_d2) out_d2[o + rk] = d;
+            }
+        }
+    }
+    for (int q = keep + lane; q < k; q += 64) {
+        out_idx[o + q] = -1;
+        if (out_d2) out_d2[o + q] = __builtin_inf();
+    }
+    if (lane == 0) out_cnt[i - row_begin] = keep;
+}
+
+static double key_to_f64(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double d;
+    memcpy(&d, &u, sizeof d);
+    return d;
+}
+
+int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
+                     double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt);
+
+int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
+                    double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
+    const int64_t rows = re - rb;
+    // bounding box of the reference cells (device reduction, one 32-byte read-back)
+    unsigned long long *dbbox;
+    SAME_TRY(slot_as(ctx, SL_K_BBOX, (size_t)4, &dbbox));
+    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
+    h[0] = h[1] = ~0ull; h[2] = h[3] = 0ull;
+    HIP_TRY(ctx, hipMemcpyAsync(dbbox, h, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, dbbox);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(h + 8, dbbox, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const double x0 = key_to_f64(h[8]), y0 = key_to_f64(h[9]), x1 = key_to_f64(h[10]), y1 = key_to_f64(h[11]);
+    if (!(x1 >= x0) || !(y1 >= y0) || !std::isfinite(x1 - x0) || !std::isfinite(y1 - y0))
+        return launch_knn_brute(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt);  // NaN/inf coordinates
+    // cell edge: a hair above the radius (so |dx| <= r can never skip a cell, rounding included), and
+    // large enough to keep the grid below ~1M cells and ~1 ref per cell on sparse inputs
+    const double ext = std::max(x1 - x0, y1 - y0);
+    double cell = radius * (1.0 + 1e-9);
+    cell = std::max(cell, ext / 1024.0);
+    cell = std::max(cell, std::sqrt((x1 - x0) * (y1 - y0) / (double)std::max<int64_t>(n_r, 1)) * 0.5);
+    if (!(cell > 0.0)) cell = 1.0;  // all references coincide and radius == 0
+    GridDesc g;
+    g.x0 = x0; g.y0 = y0; g.inv_cell = 1.0 / cell;
+    g.gx = (int)std::min(1025.0, std::floor((x1 - x0) / cell) + 1.0);
+    g.gy = (int)std::min(1025.0, std::floor((y1 - y0) / cell) + 1.0);
+    // inv_cell is rounded: make sure a coordinate at the far edge still maps inside [0, g)
+    const int64_t cells = (int64_t)g.gx * g.gy;
+    unsigned *dhist, *drank;
+    double *dsxy;
+    int32_t *dsidx;
+    SAME_TRY(slot_as(ctx, SL_K_HIST, (size_t)cells + 1, &dhist));
+    SAME_TRY(slot_as(ctx, SL_K_RANK, (size_t)n_r, &drank));
+    SAME_TRY(slot_as(ctx, SL_K_SXY, (size_t)n_r * 2, &dsxy));
+    SAME_TRY(slot_as(ctx, SL_K_SIDX, (size_t)n_r, &dsidx));
+    HIP_TRY(ctx, hipMemsetAsync(dhist, 0, (size_t)(cells + 1) * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dhist, cells);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank,
+                       dsxy, dsidx);
+    hipLaunchKernelGGL(knn_grid_kernel, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream, daxy, dsxy,
+                       dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
+                     double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
     const int64_t rows = re - rb;
     if (rows == 0) return SAME_OK;
     const int64_t blocks = ceil_div(rows, KNN_WAVES * KNN_RW);
@@ -137,6 +360,20 @@ int launch_knn(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_
                        radius * radius, k, didx, dd2, dcnt);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
+}
+
+// Small problems stay on the single brute-force launch (the grid build costs a few launches and a sync);
+// SAME_KNN_MODE=brute|grid overrides for testing.
+int launch_knn(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re, double radius,
+               int k, int32_t *didx, double *dd2, int32_t *dcnt) {
+    const int64_t rows = re - rb;
+    if (rows == 0) return SAME_OK;
+    const char *mode = getenv("SAME_KNN_MODE");
+    bool grid = n_r >= 4096 && (double)n_r * (double)rows >= 3.0e7;
+    if (mode && mode[0] == 'b') grid = false;
+    if (mode && mode[0] == 'g') grid = n_r > 0;
+    return grid ? launch_knn_grid(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt)
+                : launch_knn_brute(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt);
 }
 
 }  // namespace

@@ -89,6 +89,31 @@ def test_knn_vs_oracle_seeded(ops, oracle, n_m, n_r, k, radius):
     assert np.array_equal(bidx, idx[b0:b1]) and np.array_equal(bcnt, cnt[b0:b1])
 
 
+@pytest.mark.parametrize("mode", ["grid", "brute"])
+def test_knn_modes_agree(ops, oracle, mode, monkeypatch):
+    """The uniform-grid path and the brute-force path are the same function (bit for bit)."""
+    from same_amd import synth
+
+    monkeypatch.setenv("SAME_KNN_MODE", mode)
+    rng = np.random.default_rng(8)
+    cases = []
+    r = synth.make_cells(30000, 3, seed=20)
+    cases.append((synth.make_jittered(r, seed=21)["xy"], r["xy"], 25.0, 32))
+    cases.append((rng.uniform(-50, 1050, (3000, 2)), rng.uniform(0, 1000, (5000, 2)), 40.0, 16))      # aligned outside the ref box
+    cases.append((rng.uniform(0, 10, (500, 2)), rng.uniform(0, 10, (4000, 2)), 6.0, 64))               # dense: overflow prune path
+    cases.append((rng.uniform(0, 1e4, (2000, 2)), rng.uniform(0, 1e4, (3000, 2)), 0.5, 8))            # sparse: radius << spacing
+    cases.append((rng.uniform(0, 100, (300, 2)), np.repeat(rng.uniform(0, 100, (50, 2)), 20, 0), 15.0, 10))  # duplicates
+    cases.append((rng.uniform(0, 100, (300, 2)), np.column_stack((rng.uniform(0, 100, 700), np.full(700, 3.0))), 9.0, 7))  # collinear refs
+    cases.append((rng.uniform(0, 100, (300, 2)), np.tile([[5.0, 5.0]], (600, 1)), 200.0, 12))          # all refs coincide
+    g = np.stack(np.meshgrid(np.arange(40.0), np.arange(40.0)), -1).reshape(-1, 2)
+    cases.append((g + 0.5, g, 1.5, 9))                                                               # exact ties, cell-edge distances
+    cases.append((g, g * 1.0, 1.0, 5))                                                               # distance exactly == radius
+    for axy, rxy, radius, k in cases:
+        idx, d2, cnt = ops.knn_prune(axy, rxy, radius, k)
+        oidx, od2, ocnt = oracle.knn_prune(axy, rxy, radius, k)
+        assert np.array_equal(cnt, ocnt) and np.array_equal(idx, oidx) and np.array_equal(d2, od2)
+
+
 def test_knn_overflow_prune_path(ops, oracle):
     """More than KNN_CAP (128) in-radius candidates per row forces the in-kernel prune."""
     rng = np.random.default_rng(5)
