@@ -1,0 +1,145 @@
+"""run_same / sliding_window_matching end to end on the GPU with a mock solver (tests/fake_gurobipy.py):
+the model the solver would receive, the lazy cuts the callback adds, and the post-solve tables."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import frames_from_golden, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gp(monkeypatch, tmp_path):
+    import sys
+    import fake_gurobipy
+
+    monkeypatch.chdir(tmp_path)
+    saved = sys.modules.get("gurobipy")
+    mod = fake_gurobipy.install()
+    yield mod
+    if saved is None:
+        sys.modules.pop("gurobipy", None)
+    else:
+        sys.modules["gurobipy"] = saved
+
+
+@pytest.mark.parametrize("case", ["synthetic_example", "cfg1_500"])
+def test_run_same_with_mock_solver(gp, case, tmp_path):
+    import same_amd
+
+    g = load_golden(case)
+    a_df, r_df, cols = frames_from_golden(g)
+    mad = None if g["params"][2] < 0 else g["params"][2]
+    op = dict(radius=g["params"][0], knn=int(g["params"][1]), min_angle_deg=mad, ignore_same_type_triangles=False,
+              dist_ct_coeff=g["params"][3], no_match_penalty=g["params"][4])
+    gpar = dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=50)
+    out_df, var_out = same_amd.run_same(r_df, a_df, cols, outprefix=str(tmp_path / "out"), optim_params=op, gurobi_params=gpar)
+    model = gp.Model.last
+    P, n_a, n_r, n_t = len(g["pairs"]), len(g["kept_aligned"]), len(g["kept_ref"]), len(g["tri_plain"])
+    # what the solver consumed: variable counts/order and the assignment constraints of src/helpers.py:102-161
+    assert len(model.vars) == P + n_r + n_a + n_t
+    names = [n for n, _ in model.constrs]
+    n_ref_used, n_al_used = len(np.unique(g["pairs"][:, 1])), len(np.unique(g["pairs"][:, 0]))
+    assert len(names) == 2 * n_ref_used + 2 * n_al_used
+    assert names[0].startswith("max_matches_") and names[n_ref_used].startswith("one_match_") and names[-1].startswith("no_match_")
+    # objective coefficients on x are the pair costs, in pair order
+    xs = model._x
+    coefs = np.array([model.objective.terms[xs[i]] for i in range(P)])
+    assert np.array_equal(coefs, g["all_costs"])
+    # lazy cuts: first 50 flipped triangles (ascending) under the greedy incumbent, x_a + x_b + x_c <= 2 + q_t
+    want = g["lazy_violating"][:50]
+    assert model._cuts_added == len(want) == len(model.lazy)
+    for cut, t in zip(model.lazy, want):
+        q = [v for v in cut.expr.terms if v.VarName.startswith("q_tri")]
+        assert len(q) == 1 and q[0].VarName == f"q_tri[{t}]" and cut.sense == "<=" and cut.expr.const == -2.0
+        picked = sorted(int(v.VarName[2:-1]) for v in cut.expr.terms if v.VarName.startswith("x["))
+        tri = g["tri_plain"][t]
+        assert sorted(g["pairs"][picked][:, 0].tolist()) == sorted(tri.tolist())
+    # match table = the incumbent; violation columns from the device sweeps
+    ch = g["greedy_chosen"]
+    got = out_df[["aligned_idx", "ref_idx"]].to_numpy()
+    assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], ch[np.lexsort((ch[:, 1], ch[:, 0]))][:, :2])
+    flipped_nodes = set(g["tri_plain"][g["area_flipped"]].reshape(-1).tolist())
+    assert out_df["triangle_violation"].tolist() == [a in flipped_nodes for a in out_df["aligned_idx"]]
+    s = var_out["violations"]["violation_summary"]
+    assert [s["total_triangles"], s["violated_triangles"], s["total_comparisons"], s["total_violations"]] == g["viol_summary"].tolist()
+    assert var_out["triangle_data"]["flipped_triangles"] == g["area_flipped"].tolist()
+    assert var_out["lazy_cuts_added"] == len(want) and var_out["lazy_constraints"] is True
+    for f in ("matches_df.csv", "aligned_df.csv", "ref_df.csv", "var_out.npy", "matching_model.lp"):
+        assert (tmp_path / "out" / f).exists()
+    # allowed flip fraction above the observed rate -> no cuts (src/same.py:674-679)
+    same_amd.run_same(r_df, a_df, cols, optim_params=op, gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=1.0))
+    assert gp.Model.last._cuts_added == 0
+    # a global cap
+    same_amd.run_same(r_df, a_df, cols, optim_params=op,
+                      gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts=5))
+    assert gp.Model.last._cuts_added == 5
+
+
+def test_run_same_errors(gp):
+    import same_amd
+
+    g = load_golden("cfg1_500")
+    a_df, r_df, cols = frames_from_golden(g)
+    with pytest.raises(ValueError, match="No valid_pairs"):
+        same_amd.run_same(r_df, a_df.assign(X=a_df["X"] + 1e7), cols, optim_params=dict(radius=1.0))
+    with pytest.raises(ValueError, match="aligned_delaunay_vertex_col"):
+        same_amd.run_same(r_df, a_df, cols, aligned_delaunay=np.zeros((0, 3)), aligned_delaunay_vertex_col="nope")
+    with pytest.raises(NotImplementedError):
+        same_amd.run_same(r_df, a_df, cols, optim_params=dict(radius=10, lazy_constraints=False))
+
+
+def test_precomputed_triangulation_and_unconstrained_nodes(gp):
+    """Caller-supplied triangles in vertex-id space (MetaCell duck type): remap, filter, drop unconstrained nodes."""
+    import same_amd
+    from scipy.spatial import Delaunay
+
+    g = load_golden("cfg1_500")
+    a_df, r_df, cols = frames_from_golden(g)
+    a_df = a_df.assign(mc_id=np.arange(len(a_df)) * 7 + 3)
+    tris_ids = a_df["mc_id"].to_numpy()[Delaunay(a_df[["X", "Y"]].to_numpy()).simplices]
+
+    class MC:  # what run_same duck-types (src/same.py:891-899)
+        metacell_df = a_df
+        metacell_delaunay = tris_ids
+        metacell_idx_col = "mc_id"
+
+    prep = same_amd.prepare_same_inputs(r_df, MC(), cols, optim_params=dict(radius=10, knn=8, cell_id_col=None), verbose=False)
+    assert prep.using_precomputed and prep.optim_params["cell_id_col"] == "mc_id"
+    n_after_knn = len(g["kept_aligned"])
+    assert prep.n_aligned == n_after_knn - len(prep.unconstrained_nodes) and len(prep.unconstrained_nodes) > 0
+    tri = np.asarray(prep.aligned_delaunay)
+    assert tri.max() < prep.n_aligned and isinstance(prep.valid_pairs, list)
+    assert max(i for i, _ in prep.valid_pairs) == prep.n_aligned - 1
+    # every remaining node has at least one triangle that passed radius+angle, by construction
+    assert len(prep.costs) == len(prep.valid_pairs) and len(prep.triangle_weights) == len(tri)
+
+
+def test_sliding_window_matching(gp, tmp_path):
+    import same_amd
+    from same_amd import synth
+
+    ref = synth.make_cells(3000, 3, seed=0, side=600.0)
+    mov = synth.make_jittered(ref, seed=1)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    op = dict(window_size=300, overlap=100, min_cells_per_window=20, radius=25, knn=6, no_match_penalty=100)
+    gpar = dict(init_method="greedy")
+    res = same_amd.sliding_window_matching(r_df, m_df, outprefix=str(tmp_path / "sw"), optim_params=op, gurobi_params=gpar)
+    plan = same_amd.window_plan(ref["xy"], mov["xy"], 300, 100, 20)
+    assert set(res["window_id"]) <= {w["window_id"] for w in plan} and len(res) > 0
+    # central-region trim: every kept match lies inside its window's trim box
+    for w in plan:
+        sub = res[res["window_id"] == w["window_id"]]
+        x0, x1, y0, y1 = w["trim"]
+        assert ((sub["X"] >= x0) & (sub["X"] < x1) & (sub["Y"] >= y0) & (sub["Y"] < y1)).all()
+    assert (tmp_path / "sw" / "matchedDF.csv").exists()
+    # resume: nothing is re-run when every window id is already on disk
+    calls = []
+    again = same_amd.sliding_window_matching(r_df, m_df, outprefix=str(tmp_path / "sw"), optim_params=op, gurobi_params=gpar,
+                                             _run_window=lambda **k: calls.append(1) or (pd.DataFrame(), {}))
+    done = {w["grid_id"] for w in plan} - set(pd.read_csv(tmp_path / "sw" / "matchedDF.csv")["window_id"])
+    assert len(calls) <= len(done) + len(plan) and len(again) == len(res)
+    # cell-type sets must agree (src/same.py:446-457)
+    with pytest.raises(ValueError, match="Cell type categories differ"):
+        same_amd.sliding_window_matching(r_df, m_df.assign(cell_type="zzz"), optim_params=op)
