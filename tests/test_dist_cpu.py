@@ -76,3 +76,27 @@ def test_window_round_robin():
     loads = [sum(plan[w]["n_ref"] * plan[w]["n_mov"] for w in s) for s in shards]
     assert max(loads) <= 3600 + 2000  # heaviest-first keeps the big windows apart
     assert assign_windows([], 4) == [[], [], [], []]
+
+
+def _bench_dist_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+
+    d = bench.Dist(world)
+    try:
+        got = d.bcast_bytes(bytes(range(128)) if rank == 0 else None)   # how the RCCL unique id travels
+        d.barrier()
+        mx = d.max(float(rank + 1))
+        open(os.path.join(out_dir, f"r{rank}.txt"), "w").write(f"{got == bytes(range(128))} {mx}")
+    finally:
+        d.close()
+
+
+def test_bench_control_plane_gloo(tmp_path):
+    """bench.py's rendezvous / id broadcast / max-reduce with 2 ranks (the part that cannot be run on one GPU)."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_bench_dist_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"r{r}.txt").read_text() == "True 2.0"

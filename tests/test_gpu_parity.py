@@ -425,3 +425,27 @@ def test_prepare_same_inputs_golden(hip, case):
     assert list(prep.triangle_info.keys()) == g["tinfo_keys"].tolist()
     assert prep.n_aligned == len(g["kept_aligned"]) and prep.n_ref == len(g["kept_ref"])
     assert prep.ref_coords_xy[0] == tuple(prep.ref_df[["X", "Y"]].iloc[0])
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU plumbing on one GPU
+def test_rccl_gather_single_rank_and_device_sharded_path(ops, oracle):
+    """RCCL communicator of size 1 on this GPU: init, all-gather (= copy), destroy; and the device form of the
+    sharded prune+cost produces exactly the single-GPU pairs/costs (what N ranks then concatenate)."""
+    from same_amd import _lib, synth
+    from same_amd.dist import RcclGather, hip_block_compute, sharded_knn_cost_device
+
+    ctx = _lib.Context(0)  # own context: the communicator lives and dies with it
+    ref = synth.make_cells(5000, 6, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    g = RcclGather(ctx, 1, 0, lambda b: b)
+    try:
+        compute = hip_block_compute(ctx, mov["types"], ref["types"], mov["xy"], ref["xy"], 25.0, 16, 1.0)
+        idx, cost = sharded_knn_cost_device(ctx, compute, len(mov["xy"]), 16, g)
+    finally:
+        g.close()
+    oidx, _, _ = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, 16)
+    assert np.array_equal(idx, oidx)
+    rr, cc = np.nonzero(oidx >= 0)
+    want = oracle.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oidx[rr, cc])), 1.0)
+    assert np.array_equal(cost[rr, cc], want) and np.isinf(cost[oidx < 0]).all()
+    ctx.close()
