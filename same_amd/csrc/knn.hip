@@ -152,9 +152,12 @@ __device__ __forceinline__ unsigned long long f64_key(double v) {
 // bbox[0..3] = keys of {min x, min y} (atomicMin) and {max x, max y} (atomicMax)
 __global__ __launch_bounds__(256) void bbox_kernel(const double *__restrict__ xy, int64_t n, unsigned long long *__restrict__ bbox) {
     typedef double double2_t __attribute__((ext_vector_type(2)));
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const double2_t p = *reinterpret_cast<const double2_t *>(xy + 2 * (i < n ? i : n - 1));
-    unsigned long long kx0 = f64_key(p.x), ky0 = f64_key(p.y), kx1 = kx0, ky1 = ky0;
+    unsigned long long kx0 = ~0ull, ky0 = ~0ull, kx1 = 0ull, ky1 = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {  // grid-stride
+        const double2_t p = *reinterpret_cast<const double2_t *>(xy + 2 * i);
+        const unsigned long long kx = f64_key(p.x), ky = f64_key(p.y);
+        kx0 = kx < kx0 ? kx : kx0; ky0 = ky < ky0 ? ky : ky0; kx1 = kx > kx1 ? kx : kx1; ky1 = ky > ky1 ? ky : ky1;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long a = __shfl_xor(kx0, off, 64), b = __shfl_xor(ky0, off, 64), c = __shfl_xor(kx1, off, 64),
@@ -312,7 +315,7 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
     unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
     h[0] = h[1] = ~0ull; h[2] = h[3] = 0ull;
     HIP_TRY(ctx, hipMemcpyAsync(dbbox, h, 4 * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, dbbox);
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n_r, 256), 64)), dim3(256), 0, ctx->stream, drxy, n_r, dbbox);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(h + 8, dbbox, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

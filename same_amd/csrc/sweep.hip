@@ -62,10 +62,17 @@ __global__ __launch_bounds__(256) void orient_flag_kernel(
     }
     const unsigned long long checked = __ballot(f != 0);
     const unsigned long long flipped = __ballot(f == 2);
+    __shared__ int wave_checked[4];
+    const int wave_in_block = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         viol_mask[w] = flipped;
-        if (checked) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(checked));
+        wave_checked[wave_in_block] = __builtin_popcountll(checked);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per block, not per wave (integer sum: order-independent)
+        const int c = wave_checked[0] + wave_checked[1] + wave_checked[2] + wave_checked[3];
+        if (c) atomicAdd(&counters[0], (unsigned long long)c);
     }
 }
 
@@ -141,17 +148,24 @@ __global__ __launch_bounds__(256) void xyorder_kernel(
         }
         tri_flag[t] = (uint8_t)tv;
     }
-    // wave reduction -> one atomic per wave per counter (integer sums: order-independent)
+    // wave reduction, then block reduction through LDS -> one atomic per block per counter
+    // (integer sums: order-independent, bit-reproducible)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         ncmp += __shfl_down(ncmp, off, 64);
         nviol += __shfl_down(nviol, off, 64);
         tv += __shfl_down(tv, off, 64);
     }
+    __shared__ int part[4][3];
     if ((threadIdx.x & 63) == 0) {
-        if (ncmp) atomicAdd(&counts[0], (unsigned long long)ncmp);
-        if (nviol) atomicAdd(&counts[1], (unsigned long long)nviol);
-        if (tv) atomicAdd(&counts[2], (unsigned long long)tv);
+        part[threadIdx.x >> 6][0] = ncmp;
+        part[threadIdx.x >> 6][1] = nviol;
+        part[threadIdx.x >> 6][2] = tv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (v) atomicAdd(&counts[threadIdx.x], (unsigned long long)v);
     }
 }
 

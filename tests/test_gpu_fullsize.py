@@ -1,0 +1,203 @@
+"""BASELINE.json configurations at their full sizes.
+
+cfg2 and cfg3 are small enough for the CPU oracle to check every output.  The 100k x 100k dense
+build (the metric's configuration), cfg4 and cfg5 are checked through size-independent
+properties: row-block independence (the sharding invariant), transpose symmetry of the L1 cost
+(|a-r| == |r-a| bit for bit), agreement of the dense and pair kernels, agreement of the two
+independent prune paths (grid vs brute force) on every row, sampled rows against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from same_amd import _lib, ops, synth
+
+    assert _lib.device_count() >= 1
+    return _lib, ops, synth
+
+
+def test_cfg2_10k_full_vs_oracle(env, oracle):
+    """synthetic 10k x 10k, T=20, fp64 cost + k=32 KNN prune: every output against the oracle."""
+    _lib, ops, synth = env
+    ref = synth.make_cells(10_000, 20, seed=0)
+    mov = synth.make_cells(10_000, 20, seed=1, side=ref["side"])
+    idx, d2, cnt = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 32)
+    oidx, od2, ocnt = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, 32)
+    assert np.array_equal(idx, oidx) and np.array_equal(d2, od2) and np.array_equal(cnt, ocnt)
+    assert 150_000 < int(cnt.sum()) < 320_000  # SURVEY measured 192 600 at this shape
+    rr, cc = np.nonzero(idx >= 0)
+    pairs = np.column_stack((rr, idx[rr, cc]))
+    c = ops.pair_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], pairs, 1.0)
+    assert np.array_equal(c, oracle.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], pairs, 1.0))
+    D = ops.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0)      # 10k x 10k x 8 B = 0.8 GB
+    assert np.array_equal(D[pairs[:, 0], pairs[:, 1]], c)
+    for b in (0, 3333, 9000):  # oracle rows (the full 1e8-pair oracle pass would take a minute; 3 x 1000 rows suffice with the line above)
+        assert np.array_equal(D[b:b + 1000], oracle.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, b, b + 1000))
+
+
+def test_cfg3_50k_sweeps_full_vs_oracle(env, oracle):
+    """ISS-Heart scale: 50k x 50k, sweeps over the Delaunay triangulation (~100k triangles, ~300k edge tests)."""
+    from scipy.spatial import Delaunay
+    _lib, ops, synth = env
+    ref = synth.make_cells(50_000, 8, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    tris = Delaunay(mov["xy"]).simplices.astype(np.int32)
+    assert len(tris) > 90_000
+    en, thr = oracle.cos_threshold(15)
+    cls, perim, mc = ops.tri_classify(mov["xy"], tris, 25.0, en, thr, mov["cell_type"])
+    ocls, operim, omc = oracle.tri_classify(mov["xy"], tris, 25.0, 15, mov["cell_type"])
+    assert np.array_equal(cls, ocls) and np.array_equal(perim, operim) and np.array_equal(mc, omc)
+    kept = tris[cls == 0]
+    sign, w = ops.tri_sign_weight(mov["xy"], mov["size"], kept)
+    osign, ow = oracle.tri_sign_weight(mov["xy"], mov["size"], kept)
+    assert np.array_equal(sign, osign) and np.array_equal(w, ow)
+    idx, _, cnt = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 32, want_d2=False)
+    rng = np.random.default_rng(0)
+    pick = np.minimum((rng.random(len(cnt)) * np.maximum(cnt, 1)).astype(int), 31)  # a random candidate per row
+    match = np.where(cnt > 0, idx[np.arange(len(cnt)), pick], -1).astype(np.int32)
+    sweep = ops.BoundSweep(kept, sign, ref["xy"], len(mov["xy"]))
+    checked, viol, flag = sweep.sweep_match(match, want_flag=True)
+    och, oviol, oflag = oracle.orient_sweep(kept, sign, ref["xy"], match)
+    assert checked == och and np.array_equal(viol, oviol) and np.array_equal(flag, oflag) and len(viol) > 1000
+    e, tf, pf, counts = ops.xyorder_sweep(mov["xy"], ref["xy"], kept, match)
+    oe, otf, opf, oc = oracle.xyorder_sweep(mov["xy"], ref["xy"], kept, match)
+    assert np.array_equal(e, oe) and np.array_equal(tf, otf) and np.array_equal(pf, opf) and np.array_equal(counts, oc)
+    assert int(counts[0]) > 200_000  # ~3 edge tests per fully matched triangle
+    b, a, m3, fl = ops.area_flip(mov["xy"], ref["xy"], kept, match)
+    ob, oa, om3, ofl = oracle.area_flip(mov["xy"], ref["xy"], kept, match)
+    assert np.array_equal(b, ob) and np.array_equal(a, oa, equal_nan=True) and np.array_equal(fl, ofl) and np.array_equal(m3, om3)
+    # permutation invariance: shuffling triangles permutes the flags and leaves the counters alone
+    perm = rng.permutation(len(kept))
+    s2 = ops.BoundSweep(kept[perm], sign[perm], ref["xy"], len(mov["xy"]))
+    c2, v2, f2 = s2.sweep_match(match, want_flag=True)
+    assert c2 == checked and np.array_equal(f2, flag[perm]) and len(v2) == len(viol)
+
+
+def test_dense_100k_properties(env, oracle):
+    """The metric's configuration: 100k x 100k fp64, T=20 (80 GB per matrix, two matrices resident)."""
+    _lib, ops, synth = env
+    n, T = 100_000, 20
+    ctx = _lib.default_context()
+    L, H = ctx.lib, ctx.handle
+    ref = synth.make_cells(n, T, seed=0)
+    mov = synth.make_cells(n, T, seed=1, side=ref["side"])
+    dA, dR = ctx.to_device(mov["types"]), ctx.to_device(ref["types"])
+    dax, drx = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"])
+    C = ctx.alloc(n * n * 8)     # cost(mov rows, ref cols)
+    Ct = ctx.alloc(n * n * 8)    # cost(ref rows, mov cols): must be the exact transpose
+    ctx.check(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, C.ptr, n), "dense")
+    ctx.check(L.same_dense_cost_f64_dev(H, dR.ptr, dA.ptr, T, drx.ptr, dax.ptr, n, 0, n, 1.0, Ct.ptr, n), "dense")
+    ctx.sync()
+    rng = np.random.default_rng(0)
+    rows = np.sort(rng.choice(n, 24, replace=False))
+    got = {int(i): C.download((n,), np.float64, offset_bytes=int(i) * n * 8) for i in rows}
+    # (1) sampled rows == oracle rows
+    for i in rows[:6]:
+        assert np.array_equal(got[int(i)], oracle.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(i), int(i) + 1)[0])
+    # (2) transpose symmetry, bit for bit: C[i, :] == Ct[:, i] -- gather the column from 24 x 4096 row pieces
+    cols = np.sort(rng.choice(n, 4096, replace=False))
+    for i in rows[:8]:
+        col_piece = np.array([Ct.download((1,), np.float64, offset_bytes=(int(j) * n + int(i)) * 8)[0] for j in cols[:256]])
+        assert np.array_equal(col_piece, got[int(i)][cols[:256]])
+    # (3) dense == pair kernel on random pairs across the whole matrix
+    pj = rng.integers(0, n, size=(len(rows), 5000))
+    pairs = np.column_stack((np.repeat(rows, 5000), pj.reshape(-1))).astype(np.int32)
+    c = ops.pair_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], pairs, 1.0)
+    assert np.array_equal(c, np.concatenate([got[int(i)][pj[q]] for q, i in enumerate(rows)]))
+    # (4) row-block independence: any block computed alone equals the same rows of the full build
+    blk = ctx.alloc(1000 * n * 8)
+    for b in (0, 37_123, n - 1000):
+        ctx.check(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, b, b + 1000, 1.0, blk.ptr, n), "dense")
+        ctx.sync()
+        for q in (0, 499, 999):
+            full_row = C.download((n,), np.float64, offset_bytes=(b + q) * n * 8)
+            assert np.array_equal(blk.download((n,), np.float64, offset_bytes=q * n * 8), full_row)
+    # (5) a ragged sub-problem (odd column count -> scalar-store variant) agrees with the vector variant
+    odd = ctx.alloc(64 * 99_999 * 8)
+    ctx.check(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, 99_999, 500, 564, 1.0, odd.ptr, 99_999), "dense")
+    ctx.sync()
+    assert np.array_equal(odd.download((99_999,), np.float64, offset_bytes=63 * 99_999 * 8),
+                          C.download((n,), np.float64, offset_bytes=563 * n * 8)[:99_999])
+    for buf in (C, Ct, blk, odd):
+        buf.free()
+
+
+def test_knn_100k_grid_vs_brute_and_oracle(env, oracle, monkeypatch):
+    _lib, ops, synth = env
+    n = 100_000
+    ref = synth.make_cells(n, 2, seed=0)
+    mov = synth.make_cells(n, 2, seed=1, side=ref["side"])
+    monkeypatch.setenv("SAME_KNN_MODE", "grid")
+    gi, gd, gc = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 32)
+    monkeypatch.setenv("SAME_KNN_MODE", "brute")
+    bi, bd, bc = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 32)
+    assert np.array_equal(gi, bi) and np.array_equal(gd, bd) and np.array_equal(gc, bc)   # all 100k rows, two independent paths
+    oi, od, oc = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, 32, 40_000, 41_000)
+    assert np.array_equal(gi[40_000:41_000], oi) and np.array_equal(gd[40_000:41_000], od)
+    with np.errstate(invalid="ignore"):
+        dd = np.diff(gd, axis=1)
+    assert (dd[np.isfinite(gd[:, 1:])] >= 0).all()  # rows sorted by distance
+    # idempotence: pruning against only the refs that were ever selected gives the same lists
+    used = np.unique(gi[gi >= 0])
+    monkeypatch.delenv("SAME_KNN_MODE")
+    ri, rd, rc = ops.knn_prune(mov["xy"], ref["xy"][used], 25.0, 32)
+    assert np.array_equal(np.where(ri >= 0, used[np.maximum(ri, 0)], -1), gi) and np.array_equal(rd, gd)
+
+
+def test_cfg4_200k_row_block_sharding_invariant(env):
+    """200k x 200k in 8 row blocks of 25k (what 8 ranks compute) == the one-shot result."""
+    _lib, ops, synth = env
+    n, k, T = 200_000, 32, 20
+    ref = synth.make_cells(n, T, seed=0)
+    mov = synth.make_cells(n, T, seed=1, side=ref["side"])
+    ctx = _lib.default_context()
+    L, H = ctx.lib, ctx.handle
+    dA, dR = ctx.to_device(mov["types"]), ctx.to_device(ref["types"])
+    dax, drx = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"])
+    didx, dcost, dcnt = ctx.alloc(n * k * 4), ctx.alloc(n * k * 8), ctx.alloc(n * 4)
+
+    def run(b, e, off):
+        ctx.check(L.same_knn_prune_dev(H, dax.ptr, drx.ptr, n, b, e, 25.0, k, didx.ptr + off * k * 4, None, dcnt.ptr + off * 4), "knn")
+        ctx.check(L.same_padded_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, b, e, k, didx.ptr + off * k * 4, 1.0,
+                                             dcost.ptr + off * k * 8), "cost")
+
+    run(0, n, 0)
+    whole_idx, whole_cost = didx.download((n, k), np.int32), dcost.download((n, k), np.float64)
+    ctx.check(L.same_dev_memset(H, didx.ptr, 0, n * k * 4), "memset")
+    for r in range(8):
+        run(r * 25_000, (r + 1) * 25_000, r * 25_000)
+    assert np.array_equal(didx.download((n, k), np.int32), whole_idx)
+    assert np.array_equal(dcost.download((n, k), np.float64), whole_cost)
+    assert np.isinf(whole_cost[whole_idx < 0]).all() and np.isfinite(whole_cost[whole_idx >= 0]).all()
+
+
+def test_cfg5_1m_cells_windows_fp32(env, oracle):
+    """1M-cell section tiled into windows; fp32 cost on one window."""
+    _lib, ops, synth = env
+    from same_amd.windows import window_plan, assign_windows
+
+    ref = synth.make_cells(1_000_000, 4, seed=0)            # side 10 000
+    mov = synth.make_cells(1_000_000, 4, seed=1, side=ref["side"])
+    plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
+    assert len(plan) == 12 * 12 or len(plan) > 100
+    total_mov = 0
+    for w in plan[::17]:
+        x0, x1, y0, y1 = w["box"]
+        m = (mov["xy"][:, 0] >= x0) & (mov["xy"][:, 0] < x1) & (mov["xy"][:, 1] >= y0) & (mov["xy"][:, 1] < y1)
+        r = (ref["xy"][:, 0] >= x0) & (ref["xy"][:, 0] < x1) & (ref["xy"][:, 1] >= y0) & (ref["xy"][:, 1] < y1)
+        assert w["n_mov"] == int(m.sum()) and w["n_ref"] == int(r.sum())
+        total_mov += w["n_mov"]
+    shards = assign_windows(plan, 8)
+    assert sorted(q for s in shards for q in s) == list(range(len(plan)))
+    w = plan[len(plan) // 2]
+    x0, x1, y0, y1 = w["box"]
+    m = (mov["xy"][:, 0] >= x0) & (mov["xy"][:, 0] < x1) & (mov["xy"][:, 1] >= y0) & (mov["xy"][:, 1] < y1)
+    r = (ref["xy"][:, 0] >= x0) & (ref["xy"][:, 0] < x1) & (ref["xy"][:, 1] >= y0) & (ref["xy"][:, 1] < y1)
+    D = ops.dense_cost(mov["types"][m], ref["types"][r], mov["xy"][m], ref["xy"][r], 1.0, 0, 2000, dtype=np.float32)
+    O = oracle.dense_cost(mov["types"][m], ref["types"][r], mov["xy"][m], ref["xy"][r], 1.0, 0, 2000, dtype=np.float32)
+    assert np.array_equal(D, O) and D.shape[1] == int(r.sum()) > 10_000
