@@ -292,9 +292,9 @@ int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const 
     }
     const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
     // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
-    // 512 rows per block: the per-block column prologue (CPL*(T+2) values per lane) is then ~4 % of the
-    // block's output bytes instead of ~9 % at 256 (profiles/r01_pmc_fetch_summary.csv)
-    int rows_per_block = rpb_env > 0 ? rpb_env : 512;
+    // 256 rows per block measured best at 100k x 100k (store-bound T<=12: 6.4-6.9 TB/s vs 5.9 at 64 or 512;
+    // VALU-bound T=20: equal) -- profiles/r01_dense_probe_rpb.log
+    int rows_per_block = rpb_env > 0 ? rpb_env : 256;
     while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
     rows_per_block = std::max(DEPTH, rows_per_block / DEPTH * DEPTH);
     if (rows >= rows_per_block)

@@ -1,1 +1,2 @@
-for cfg in "SAME_DENSE_WAVES=4" "SAME_DENSE_WAVES=8" "SAME_DENSE_WAVES=16" "SAME_DENSE_WAVES=16 SAME_DENSE_MAP=0" "SAME_DENSE_WAVES=16 SAME_DENSE_RPB=64" "SAME_DENSE_WAVES=2" "SAME_DENSE_WAVES=1 SAME_DENSE_RPB=1024"; do echo "== $cfg"; env $cfg python tools/dense_probe.py 100000 8,20; done
+for rpb in 64 128 256 512; do echo "== RPB=$rpb"; SAME_DENSE_RPB=$rpb python tools/dense_probe.py 100000 3,8,12,16,20; done
+echo "== f32"; for rpb in 128 512; do echo "== RPB=$rpb"; SAME_DENSE_RPB=$rpb python tools/dense_probe.py 100000 3,8,20 f32; done
