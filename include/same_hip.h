@@ -196,6 +196,22 @@ int same_assign_matrix(same_ctx *ctx, const int32_t *pairs, const double *costs,
                        const double *unmatched, int64_t n_m, int64_t n_r, double big_m,
                        double *out);
 
+/* ---- f1: greedy MIP start resolved on the device, node-local flip statistics ----------
+ * same_greedy_match replaces the sort + sequential scan of src/init_helpers.py:109-133 with an
+ * equivalent parallel rule (a pair is taken when it is the (cost, pair index)-minimum at both of
+ * its endpoints among the pairs still alive).  prefer[i] = best_cost_i < unmatched_cost_i
+ * (:118-122).  out_match_pair[i] = index of the pair chosen for aligned row i, or -1.
+ * same_tri_flip_stats replaces the triangle loop of eval_utils.check_triangle_violations
+ * (src/eval_utils.py:123-187) on node-indexed arrays: out_tri_flag bit0 all matched, bit1 same
+ * type (type_id NULL = off), bit2 flipped; node counters over non-same-type triangles. */
+int same_greedy_match(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P,
+                      int64_t n_m, int64_t n_r, const uint8_t *prefer, int32_t *out_match_pair,
+                      int *out_rounds);
+int same_tri_flip_stats(same_ctx *ctx, const double *axy, const double *mapped_xy,
+                        const uint8_t *matched, int64_t n, const int32_t *type_id,
+                        const int32_t *tris, int64_t Tr, uint8_t *out_tri_flag,
+                        uint32_t *out_node_tri, uint32_t *out_node_flip);
+
 /* ---- a14: eager reference-orientation signs -------------------------------------------
  * Replaces calc_ref_area over all candidate combinations (src/helpers.py:425-441,455-510):
  * out[((t*k+x)*k+y)*k+z] = sign(round(cross, 3)) for cand[tris[t][0]][x], ..., 2 if any is -1. */

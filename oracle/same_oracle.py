@@ -57,6 +57,8 @@ def lib():
         L.orc_assign_matrix.argtypes = [_i32, _f64, _I64, _f64, _I64, _I64, _DBL, _f64]
         L.orc_eager_signs.argtypes = [_f64, _i32, _I64, _i32, _INT, _i8]
         L.orc_window_mask.argtypes = [_f64, _I64, _DBL, _DBL, _DBL, _DBL, _u8]
+        _u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+        L.orc_tri_flip_stats.argtypes = [_f64, _f64, _u8, _VP, _i32, _I64, _I64, _u8, _u32, _u32]
         _LIB = L
     return _LIB
 
@@ -526,3 +528,62 @@ def window_plan(ref_xy, mov_xy, window_size, overlap, min_cells):
             j += 1
         i += 1
     return plan
+
+
+# --------------------------------------------------------------------------- f1
+def tri_flip_stats(axy, mapped_xy, matched, triangles, type_id=None):
+    tris = _c(triangles, np.int32).reshape(-1, 3)
+    n = len(axy)
+    flag = np.empty(len(tris), np.uint8)
+    nt, nf = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    tid = None if type_id is None else _c(type_id, np.int32)
+    lib().orc_tri_flip_stats(_c(axy, np.float64), _c(mapped_xy, np.float64), _c(matched, np.uint8),
+                             None if tid is None else tid.ctypes.data, tris, len(tris), n, flag, nt, nf)
+    return flag, nt, nf
+
+
+def check_triangle_violations(outputDF, mc_align, aligned_id_col='aligned_metacell_index', ref_id_col='matched_ref_index',
+                              mapped_x_col='mapped_x', mapped_y_col='mapped_y', cell_type_col='cell_type',
+                              ignore_same_type_triangles=True, node_local=False, majority_threshold=0.5, min_flips=1,
+                              verbose=False):
+    """src/eval_utils.py:66-223, literal id bookkeeping around the C triangle loop."""
+    outputDF = outputDF.copy()
+    triangles = np.asarray(mc_align.metacell_delaunay).reshape(-1, 3)
+    mdf = mc_align.metacell_df
+    pos = {v: i for i, v in enumerate(mdf.index)}
+    row_of = {row[aligned_id_col]: idx for idx, row in outputDF.iterrows()}          # last row wins
+    n = len(mdf)
+    matched = np.zeros(n, np.uint8); mapped = np.zeros((n, 2)); type_id = np.full(n, -1, np.int32)
+    types = {}
+    for v, idx in row_of.items():
+        if v in pos:
+            p = pos[v]
+            matched[p] = 1
+            mapped[p] = (outputDF.loc[idx, mapped_x_col], outputDF.loc[idx, mapped_y_col])
+            type_id[p] = types.setdefault(outputDF.loc[idx, cell_type_col], len(types))
+    usable = [t for t in triangles if all(v in pos for v in t)]
+    lost = [t for t in triangles if not all(v in pos for v in t)]
+    tris = np.array([[pos[v] for v in t] for t in usable], dtype=np.int32).reshape(-1, 3)
+    flag, nt, nf = tri_flip_stats(mdf[['X', 'Y']].to_numpy(dtype=np.float64), mapped, matched, tris,
+                                  type_id if ignore_same_type_triangles else None)
+    lost_matched = [t for t in lost if all(v in row_of for v in t)]
+    lost_same = sum(1 for t in lost_matched if ignore_same_type_triangles and
+                    len({outputDF.loc[row_of[v], cell_type_col] for v in t}) == 1)
+    m, same, fl = (flag & 1).astype(bool), (flag & 2).astype(bool), (flag & 4).astype(bool)
+    sign_flips = fl[m & ~same]
+    node_viol = {}
+    for x in outputDF[aligned_id_col].unique():
+        n_tri = int(nt[pos[x]]) if x in pos else 0
+        n_flip = int(nf[pos[x]]) if x in pos else 0
+        if node_local:
+            node_viol[x] = bool(n_tri > 0 and n_flip >= min_flips and (n_flip / n_tri) >= majority_threshold)
+        else:
+            node_viol[x] = n_flip > 0
+    outputDF['in_violating_triangle'] = outputDF[aligned_id_col].map(node_viol).fillna(False)
+    stats = {'total_triangles': len(triangles), 'triangles_with_all_matched': int(m.sum()) + len(lost_matched),
+             'triangles_processed': int(m.sum()) + len(lost_matched), 'triangles_same_type_skipped': int(same.sum()) + lost_same,
+             'triangles_flipped': int(np.sum(sign_flips)) if len(sign_flips) else 0,
+             'percent_flipped': (100.0 * np.sum(sign_flips) / len(sign_flips) if len(sign_flips) else 0.0),
+             'nodes_in_violating_triangles': int(outputDF['in_violating_triangle'].sum()),
+             'percent_nodes_violating': 100.0 * outputDF['in_violating_triangle'].mean()}
+    return outputDF, stats

@@ -63,6 +63,8 @@ _PROTOTYPES = {
     "same_orient_sweep_dev": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64)],
     "same_pair_rowmin": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "same_assign_matrix": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_dbl, c_vp],
+    "same_greedy_match": [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_int)],
+    "same_tri_flip_stats": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "same_comm_unique_id": [c_vp],

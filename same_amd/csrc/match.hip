@@ -1,0 +1,211 @@
+// match.hip -- SURVEY 8(f1): the greedy MIP start of src/init_helpers.py:109-133 resolved on the
+// device, and the node-local flip statistics of eval_utils.check_triangle_violations
+// (src/eval_utils.py:66-223).
+//
+// Greedy.  The reference sorts all candidate pairs by cost (stable) and scans them once, taking
+// (i, j) when both ends are still free.  That sequential scan is equivalent to repeatedly taking
+// every pair that is the minimum -- under the same total order (cost, pair index) -- at BOTH of
+// its endpoints among the pairs still alive: such pairs cannot be pre-empted by anything the
+// scan would visit earlier, and the globally smallest alive pair always qualifies, so the rounds
+// terminate with exactly the scan's matching.  No sort is needed: each round is three maps over
+// the pairs with 64-bit atomicMin on a monotone key of the cost, then 32-bit atomicMin on the
+// pair index to break exact cost ties the way the stable sort does.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long cost_key(double v) {  // monotone u64 key of a double
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void greedy_init_kernel(const int32_t *__restrict__ pairs, int64_t P,
+                                                           const uint8_t *__restrict__ prefer, uint8_t *__restrict__ alive) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) alive[p] = prefer[pairs[2 * p]];  // rows that prefer "unmatched" never enter (init_helpers.py:122,128)
+}
+
+__global__ __launch_bounds__(256) void greedy_reset_kernel(unsigned long long *__restrict__ rkey, unsigned *__restrict__ ridx,
+                                                            int64_t n_m, unsigned long long *__restrict__ ckey,
+                                                            unsigned *__restrict__ cidx, int64_t n_r) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_m) { rkey[q] = ~0ull; ridx[q] = ~0u; }
+    if (q < n_r) { ckey[q] = ~0ull; cidx[q] = ~0u; }
+}
+
+__global__ __launch_bounds__(256) void greedy_min_key_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, uint8_t *__restrict__ alive,
+    const uint8_t *__restrict__ used_row, const uint8_t *__restrict__ used_col, unsigned long long *__restrict__ rkey,
+    unsigned long long *__restrict__ ckey) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P || !alive[p]) return;
+    const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+    if (used_row[i] || used_col[j]) { alive[p] = 0; return; }
+    const unsigned long long k = cost_key(costs[p]);
+    atomicMin(&rkey[i], k);
+    atomicMin(&ckey[j], k);
+}
+
+__global__ __launch_bounds__(256) void greedy_min_idx_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const uint8_t *__restrict__ alive,
+    const unsigned long long *__restrict__ rkey, const unsigned long long *__restrict__ ckey, unsigned *__restrict__ ridx,
+    unsigned *__restrict__ cidx) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P || !alive[p]) return;
+    const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+    const unsigned long long k = cost_key(costs[p]);
+    if (k == rkey[i]) atomicMin(&ridx[i], (unsigned)p);
+    if (k == ckey[j]) atomicMin(&cidx[j], (unsigned)p);
+}
+
+__global__ __launch_bounds__(256) void greedy_select_kernel(
+    const int32_t *__restrict__ pairs, int64_t P, uint8_t *__restrict__ alive, const unsigned *__restrict__ ridx,
+    const unsigned *__restrict__ cidx, uint8_t *__restrict__ used_row, uint8_t *__restrict__ used_col,
+    int32_t *__restrict__ match_pair, unsigned long long *__restrict__ n_selected) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool sel = false;
+    if (p < P && alive[p]) {
+        const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        if (ridx[i] == (unsigned)p && cidx[j] == (unsigned)p) {
+            sel = true;
+            alive[p] = 0;
+            used_row[i] = 1;
+            used_col[j] = 1;
+            match_pair[i] = (int32_t)p;
+        }
+    }
+    const unsigned long long bal = __ballot(sel);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_selected, (unsigned long long)__builtin_popcountll(bal));
+}
+
+// ---- node-local flip statistics (src/eval_utils.py:66-223) -------------------------------------
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2_t ld2(const double *xy, int64_t i) { return *reinterpret_cast<const double2_t *>(xy + 2 * i); }
+__device__ __forceinline__ double area3(double2_t p1, double2_t p2, double2_t p3) {  // _signed_area, eval_utils.py:116-121
+    return 0.5 * (p1.x * (p2.y - p3.y) + p2.x * (p3.y - p1.y) + p3.x * (p1.y - p2.y));
+}
+
+// tri_flag: bit0 all three matched, bit1 same type (only when type_id given), bit2 flipped
+__global__ __launch_bounds__(256) void tri_flip_stats_kernel(
+    const double *__restrict__ axy, const double *__restrict__ mxy, const uint8_t *__restrict__ matched,
+    const int32_t *__restrict__ type_id, const int32_t *__restrict__ tris, int64_t Tr, uint8_t *__restrict__ tri_flag,
+    unsigned *__restrict__ node_tri, unsigned *__restrict__ node_flip) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tr) return;
+    const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+    uint8_t f = 0;
+    if (matched[a] && matched[b] && matched[c]) {
+        f = 1;
+        const bool same = type_id && type_id[a] == type_id[b] && type_id[b] == type_id[c];
+        if (same) f |= 2;
+        const double sb = area3(ld2(axy, a), ld2(axy, b), ld2(axy, c));
+        const double sa = area3(ld2(mxy, a), ld2(mxy, b), ld2(mxy, c));
+        // np.sign semantics incl. NaN (a NaN sign compares unequal to everything, itself included): eval_utils.py:160-166
+        const int s0 = sb != sb ? 2 : (sb > 0.0) - (sb < 0.0), s1 = sa != sa ? 3 : (sa > 0.0) - (sa < 0.0);
+        const bool flipped = s0 != s1 && s0 != 0 && s1 != 0;
+        if (flipped) f |= 4;
+        if (!same) {  // integer counters: order-independent
+            atomicAdd(&node_tri[a], 1u); atomicAdd(&node_tri[b], 1u); atomicAdd(&node_tri[c], 1u);
+            if (flipped) { atomicAdd(&node_flip[a], 1u); atomicAdd(&node_flip[b], 1u); atomicAdd(&node_flip[c], 1u); }
+        }
+    }
+    tri_flag[t] = f;
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
+
+}  // namespace
+
+extern "C" {
+
+int same_greedy_match(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P, int64_t n_m, int64_t n_r,
+                      const uint8_t *prefer, int32_t *out_match_pair, int *out_rounds) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, P >= 0 && n_m >= 0 && n_r >= 0 && P < ((int64_t)1 << 32) - 1);
+    if (out_rounds) *out_rounds = 0;
+    REQUIRE(ctx, n_m == 0 || out_match_pair);
+    for (int64_t i = 0; i < n_m; ++i) out_match_pair[i] = -1;
+    if (P == 0 || n_m == 0) return SAME_OK;
+    REQUIRE(ctx, pairs && costs && prefer);
+    SAME_TRY(same_use(ctx));
+    for (int64_t p = 0; p < P; ++p)
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
+            ctx->err = "pair index out of range";
+            return SAME_ERANGE;
+        }
+    int32_t *dp, *dmatch;
+    double *dc;
+    uint8_t *dprefer, *dalive, *durow, *ducol;
+    unsigned long long *drkey, *dckey, *dsel;
+    unsigned *dridx, *dcidx;
+    SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
+    SAME_TRY(up_as(ctx, SL_X, costs, (size_t)P, &dc));
+    SAME_TRY(up_as(ctx, SL_FLAG0, prefer, (size_t)n_m, &dprefer));
+    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)P, &dalive));
+    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_m + n_r, &durow));
+    ducol = durow + n_m;
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_m + n_r, &drkey));
+    dckey = drkey + n_m;
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)n_m + n_r, &dridx));
+    dcidx = dridx + n_m;
+    SAME_TRY(slot_as(ctx, SL_MATCH, (size_t)n_m, &dmatch));
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dsel));
+    HIP_TRY(ctx, hipMemsetAsync(durow, 0, (size_t)(n_m + n_r), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dmatch, 0xFF, (size_t)n_m * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dprefer, dalive);
+    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
+    const int64_t nmax = n_m > n_r ? n_m : n_r;
+    int rounds = 0;
+    for (;; ++rounds) {
+        REQUIRE(ctx, rounds <= P + 1);  // each productive round removes at least one pair
+        HIP_TRY(ctx, hipMemsetAsync(dsel, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(greedy_reset_kernel, dim3(grid_for(nmax)), dim3(256), 0, ctx->stream, drkey, dridx, n_m, dckey, dcidx, n_r);
+        hipLaunchKernelGGL(greedy_min_key_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, durow, ducol, drkey, dckey);
+        hipLaunchKernelGGL(greedy_min_idx_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, drkey, dckey, dridx, dcidx);
+        hipLaunchKernelGGL(greedy_select_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dalive, dridx, dcidx, durow, ducol,
+                           dmatch, dsel);
+        HIP_TRY(ctx, hipGetLastError());
+        SAME_TRY(same_down(ctx, h, dsel, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[0] == 0) break;  // nothing alive: the smallest alive pair would always have been selected
+    }
+    if (out_rounds) *out_rounds = rounds;
+    SAME_TRY(same_down(ctx, out_match_pair, dmatch, (size_t)n_m * sizeof(int32_t)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_tri_flip_stats(same_ctx *ctx, const double *axy, const double *mapped_xy, const uint8_t *matched, int64_t n,
+                        const int32_t *type_id, const int32_t *tris, int64_t Tr, uint8_t *out_tri_flag,
+                        uint32_t *out_node_tri, uint32_t *out_node_flip) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, n >= 0 && Tr >= 0 && (n == 0 || (out_node_tri && out_node_flip)));
+    for (int64_t i = 0; i < n; ++i) { out_node_tri[i] = 0; out_node_flip[i] = 0; }
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, axy && mapped_xy && matched && tris && out_tri_flag && out_node_tri && out_node_flip);
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n, "triangles"));
+    double *dax, *dmx;
+    uint8_t *dmatched, *dflag;
+    int32_t *dtype = nullptr, *dtris;
+    unsigned *dnt, *dnf;
+    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n * 2, &dax));
+    SAME_TRY(up_as(ctx, SL_RXY, mapped_xy, (size_t)n * 2, &dmx));
+    SAME_TRY(up_as(ctx, SL_FLAG0, matched, (size_t)n, &dmatched));
+    if (type_id) SAME_TRY(up_as(ctx, SL_TYPE, type_id, (size_t)n, &dtype));
+    SAME_TRY(up_as(ctx, SL_TRIS, tris, (size_t)Tr * 3, &dtris));
+    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)Tr, &dflag));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n * 2, &dnt));
+    dnf = dnt + n;
+    HIP_TRY(ctx, hipMemsetAsync(dnt, 0, (size_t)n * 2 * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(tri_flip_stats_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dax, dmx, dmatched, dtype, dtris, Tr,
+                       dflag, dnt, dnf);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out_tri_flag, dflag, (size_t)Tr));
+    SAME_TRY(same_down(ctx, out_node_tri, dnt, (size_t)n * sizeof(unsigned)));
+    SAME_TRY(same_down(ctx, out_node_flip, dnf, (size_t)n * sizeof(unsigned)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+}  // extern "C"

@@ -1,8 +1,8 @@
 """MIP-start heuristics, same signatures as src/init_helpers.py.
 
-Device-worthy parts run in csrc/sweep.hip: the per-row minimum pair cost (greedy, :118-122)
-and the dense assignment matrix fill (hungarian, :151-155).  The sequential greedy scan and
-scipy's linear_sum_assignment stay on the host, as SURVEY 8a5 scopes them."""
+The per-row minimum pair cost (:118-122) and the dense assignment matrix fill (:151-155) run in
+csrc/sweep.hip; the greedy sort + scan (:109-133) is resolved on the device by an equivalent
+parallel rule (csrc/match.hip); scipy's linear_sum_assignment stays on the host."""
 from typing import List, Optional, Sequence, Set, Tuple
 
 import numpy as np
@@ -30,17 +30,14 @@ def compute_mip_start_pairs(*, valid_pairs, costs, n_aligned, n_ref, aligned_siz
     if method == "greedy":
         best_cost_per_i = ops.pair_rowmin(pairs, costs_arr, n_aligned, ctx=ctx)
         prefer_match = best_cost_per_i < unmatched_cost
-        order = np.argsort(costs_arr, kind="stable")  # list.sort is stable (src/init_helpers.py:111-112)
-        used_aligned = np.zeros(n_aligned, bool)
-        used_ref = np.zeros(n_ref, bool)
-        pi, pj = pairs[:, 0], pairs[:, 1]
-        for idx in order.tolist():
-            i, j = pi[idx], pj[idx]
-            if used_aligned[i] or used_ref[j] or not prefer_match[i]:
-                continue
-            chosen_pairs.append((int(i), int(j), idx))
-            used_aligned[i] = True
-            used_ref[j] = True
+        # the sort + sequential scan of the reference (:109-133), resolved on the device by an equivalent
+        # parallel rule (csrc/match.hip); the chosen pairs come back per aligned row and are put in the
+        # reference's order (cost, then pair index = its stable sort) here
+        match_pair, _rounds = ops.greedy_match(pairs, costs_arr, n_aligned, n_ref, prefer_match, ctx=ctx)
+        sel = match_pair[match_pair >= 0].astype(np.int64)
+        sel = sel[np.lexsort((sel, costs_arr[sel]))]
+        chosen_pairs = [(int(pairs[idx, 0]), int(pairs[idx, 1]), int(idx)) for idx in sel]
+        used_aligned = match_pair >= 0
         chosen_unmatched = set(np.flatnonzero(~used_aligned).tolist())
     else:
         if (n_aligned + n_ref) > int(init_hungarian_max_n):

@@ -233,3 +233,35 @@ def window_count(xy, boxes, want_mask=False, ctx=None):
         ctx.check(ctx.lib.same_window_count(ctx.handle, xy.ctypes.data, len(xy), boxes.ctypes.data, len(boxes),
                                             counts.ctypes.data, _lib._ptr(mask)), "same_window_count")
     return (counts, mask.astype(bool)) if want_mask else counts
+
+
+def greedy_match(pairs, costs, n_aligned, n_ref, prefer, ctx=None):
+    """Device form of the greedy scan (src/init_helpers.py:109-133) -> (match_pair (n_aligned,) int32, rounds)."""
+    ctx = _ctx(ctx)
+    pairs, costs = as_c(pairs, I32).reshape(-1, 2), as_c(costs, F64)
+    prefer = as_c(prefer, U8)
+    assert len(prefer) == int(n_aligned) and len(costs) == len(pairs)
+    out = np.empty(int(n_aligned), I32)
+    rounds = ctypes.c_int(0)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_greedy_match(ctx.handle, pairs.ctypes.data, costs.ctypes.data, len(pairs), int(n_aligned),
+                                            int(n_ref), prefer.ctypes.data, out.ctypes.data, ctypes.byref(rounds)),
+                  "same_greedy_match")
+    return out, rounds.value
+
+
+def tri_flip_stats(axy, mapped_xy, matched, triangles, type_id=None, ctx=None):
+    """-> (tri_flag (Tr,) uint8 [bit0 matched, bit1 same type, bit2 flipped], node_tri, node_flip (n,) uint32)."""
+    ctx = _ctx(ctx)
+    axy, mxy = as_c(axy, F64).reshape(-1, 2), as_c(mapped_xy, F64).reshape(-1, 2)
+    matched = as_c(matched, U8)
+    tris = _tris(triangles)
+    tid = None if type_id is None else as_c(type_id, I32)
+    n, Tr = len(axy), len(tris)
+    assert len(mxy) == n and len(matched) == n
+    flag, nt, nf = np.empty(Tr, U8), np.empty(n, np.uint32), np.empty(n, np.uint32)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_tri_flip_stats(ctx.handle, axy.ctypes.data, mxy.ctypes.data, matched.ctypes.data, n, _lib._ptr(tid),
+                                              tris.ctypes.data, Tr, flag.ctypes.data, nt.ctypes.data, nf.ctypes.data),
+                  "same_tri_flip_stats")
+    return flag, nt, nf

@@ -449,3 +449,66 @@ def test_rccl_gather_single_rank_and_device_sharded_path(ops, oracle):
     want = oracle.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oidx[rr, cc])), 1.0)
     assert np.array_equal(cost[rr, cc], want) and np.isinf(cost[oidx < 0]).all()
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8(f1)
+def test_check_triangle_violations_golden(hip):
+    from same_amd.eval_utils import check_triangle_violations
+    from test_oracle_golden import EVAL_CASES, EVAL_KEYS, eval_inputs
+
+    g = load_golden("eval_tri")
+    out_df, mc = eval_inputs(g)
+    for tag, kw in EVAL_CASES:
+        df, stats = check_triangle_violations(out_df, mc, **kw)
+        assert np.array_equal(df["in_violating_triangle"].to_numpy().astype(np.uint8), g[f"viol_{tag}"]), tag
+        assert np.array_equal(np.array([stats[k] for k in EVAL_KEYS], dtype=np.float64), g[f"stats_{tag}"]), tag
+
+
+def test_tri_flip_stats_vs_oracle_seeded(ops, oracle):
+    from scipy.spatial import Delaunay
+    from same_amd import synth
+
+    ref = synth.make_cells(40000, 5, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    tris = Delaunay(mov["xy"]).simplices.astype(np.int32)
+    rng = np.random.default_rng(3)
+    near = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 3, want_d2=False)[0]
+    pick = near[np.arange(len(near)), rng.integers(0, 3, len(near))]
+    matched = (pick >= 0) & (rng.random(len(pick)) > 0.05)
+    mapped = np.where(matched[:, None], ref["xy"][np.maximum(pick, 0)], 0.0)
+    mapped[rng.integers(0, len(mapped), 20)] = np.nan
+    for tid in (None, mov["cell_type"]):
+        f, nt, nf = ops.tri_flip_stats(mov["xy"], mapped, matched, tris, tid)
+        of, ont, onf = oracle.tri_flip_stats(mov["xy"], mapped, matched, tris, tid)
+        assert np.array_equal(f, of) and np.array_equal(nt, ont) and np.array_equal(nf, onf)
+    assert (f & 4).sum() > 100
+
+
+def test_greedy_match_equals_sequential_scan(ops, oracle):
+    """Device greedy (parallel local-minimum rule) == the reference's sort + scan, incl. exact cost ties."""
+    rng = np.random.default_rng(0)
+    for n_m, n_r, k, quant in ((3000, 2500, 8, None), (2000, 2000, 16, 0.5), (500, 40, 6, None), (50, 3000, 32, 1.0)):
+        pi = np.repeat(np.arange(n_m), k)
+        pj = rng.integers(0, n_r, n_m * k)
+        keep = rng.random(len(pi)) > 0.2
+        pairs = np.column_stack((pi, pj))[keep]
+        costs = rng.gamma(2.0, 20.0, len(pairs))
+        if quant:  # heavy ties: the (cost, pair index) order must decide
+            costs = np.round(costs / quant) * quant
+        sizes = rng.integers(1, 4, n_m).astype(float)
+        penalty = float(np.median(costs)) / 1.5
+        vp = [tuple(p) for p in pairs.tolist()]
+        want, want_un = oracle.compute_mip_start_pairs(valid_pairs=vp, costs=list(costs), n_aligned=n_m, n_ref=n_r,
+                                                       aligned_sizes=sizes, no_match_penalty=penalty, max_matches=1,
+                                                       init_method="greedy", verbose=False)
+        import same_amd
+        got, got_un = same_amd.compute_mip_start_pairs(valid_pairs=vp, costs=list(costs), n_aligned=n_m, n_ref=n_r,
+                                                       aligned_sizes=sizes, no_match_penalty=penalty, max_matches=1,
+                                                       init_method="greedy", verbose=False)
+        assert got == want and got_un == want_un
+        assert len(got) > 0
+    # degenerate: no pair at all / every row prefers to stay unmatched
+    mp, rounds = ops.greedy_match(np.zeros((0, 2), np.int32), np.zeros(0), 5, 5, np.ones(5, np.uint8))
+    assert (mp == -1).all()
+    mp, _ = ops.greedy_match(np.array([[0, 0], [1, 1]], np.int32), np.array([1.0, 2.0]), 2, 2, np.zeros(2, np.uint8))
+    assert (mp == -1).all()

@@ -244,3 +244,32 @@ def test_sweeps_adversarial(oracle):
     checked, viol = oracle.lazy_orientation_sweep(g["sw_x"], [tuple(p) for p in g["sw_pairs"].tolist()], tris,
                                                   g["adv_signs"], rxy, len(pts))
     assert checked == int(g["sw_lazy_checked"][0]) and [t[0] for t in viol] == g["sw_lazy_violating"].tolist()
+
+
+EVAL_KEYS = ('total_triangles', 'triangles_with_all_matched', 'triangles_processed', 'triangles_same_type_skipped',
+             'triangles_flipped', 'percent_flipped', 'nodes_in_violating_triangles', 'percent_nodes_violating')
+EVAL_CASES = (('default', {}), ('alltypes', dict(ignore_same_type_triangles=False)), ('local', dict(node_local=True)),
+              ('local_strict', dict(node_local=True, majority_threshold=0.3, min_flips=2)),
+              ('local_alltypes', dict(node_local=True, ignore_same_type_triangles=False, majority_threshold=0.75)))
+
+
+def eval_inputs(g):
+    mdf = pd.DataFrame({'X': g['mxy'][:, 0], 'Y': g['mxy'][:, 1]}, index=g['ids'])
+    out_df = pd.DataFrame({'aligned_metacell_index': g['o_id'], 'matched_ref_index': g['o_ref'], 'mapped_x': g['o_mx'],
+                           'mapped_y': g['o_my'], 'cell_type': g['o_type'].astype(object)})
+
+    class MC:
+        metacell_df = mdf
+        metacell_delaunay = g['tri_ids']
+
+    return out_df, MC()
+
+
+def test_check_triangle_violations(oracle):
+    """eval_utils.check_triangle_violations, incl. duplicate ids, a NaN coordinate, an unknown id."""
+    g = load_golden('eval_tri')
+    out_df, mc = eval_inputs(g)
+    for tag, kw in EVAL_CASES:
+        df, stats = oracle.check_triangle_violations(out_df, mc, **kw)
+        assert np.array_equal(df['in_violating_triangle'].to_numpy().astype(np.uint8), g[f'viol_{tag}']), tag
+        assert np.array_equal(np.array([stats[k] for k in EVAL_KEYS], dtype=np.float64), g[f'stats_{tag}']), tag

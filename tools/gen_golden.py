@@ -398,8 +398,54 @@ def adversarial_case():
     print(f"[adversarial] grid pairs {len(out['grid_pairs'])}, edge pairs {out['edge_pairs'].tolist()}, lazy {checked}/{viol.tolist()}")
 
 
+def eval_case():
+    """eval_utils.check_triangle_violations (src/eval_utils.py:66-223) on the shipped synthetic example."""
+    d = os.path.join(REF_ROOT, 'examples', 'synthetic', 'data')
+    ref_df = add_row_ids(pd.read_csv(os.path.join(d, 'ref.csv'), index_col=0))
+    qry_df = add_row_ids(pd.read_csv(os.path.join(d, 'query.csv'), index_col=0))
+    a_df, r_df, pairs = quiet(ref.utils.find_knn_within_radius, qry_df, ref_df, 5, knn=8)
+    pairs = np.asarray(pairs)
+    rng = np.random.default_rng(11)
+    first = np.flatnonzero(np.r_[True, pairs[1:, 0] != pairs[:-1, 0]])
+    pick = first + np.minimum(rng.integers(0, 3, len(first)), np.diff(np.r_[first, len(pairs)]) - 1)  # one of the 3 nearest
+    sel = pairs[pick]
+    sel = sel[rng.random(len(sel)) > 0.1]                      # ~10 % unmatched
+    ids = 1000 + 3 * np.arange(len(a_df))                      # metacell ids are labels, not positions
+    mdf = pd.DataFrame({'X': a_df['X'].to_numpy(), 'Y': a_df['Y'].to_numpy()}, index=ids)
+    tri_ids = ids[Delaunay(mdf[['X', 'Y']].to_numpy()).simplices]
+    tri_ids = np.vstack([tri_ids, [[ids[0], ids[1], 999999]]])  # a triangle with an id unknown to metacell_df
+    out_df = pd.DataFrame({'aligned_metacell_index': ids[sel[:, 0]], 'matched_ref_index': sel[:, 1],
+                           'mapped_x': r_df['X'].to_numpy()[sel[:, 1]], 'mapped_y': r_df['Y'].to_numpy()[sel[:, 1]],
+                           'cell_type': a_df['cell_type'].to_numpy()[sel[:, 0]]})
+    out_df = pd.concat([out_df, out_df.iloc[[5]].assign(mapped_x=out_df['mapped_x'].iloc[7], mapped_y=out_df['mapped_y'].iloc[9])],
+                       ignore_index=True)                       # duplicate id: the last row wins
+    out_df.loc[20, 'mapped_x'] = np.nan                         # NaN sign -> counted as a flip by the reference
+
+    class MC:
+        metacell_df = mdf
+        metacell_delaunay = tri_ids
+
+    out = {'ids': ids, 'mxy': mdf[['X', 'Y']].to_numpy(), 'tri_ids': tri_ids.astype(np.int64),
+           'o_id': out_df['aligned_metacell_index'].to_numpy(), 'o_ref': out_df['matched_ref_index'].to_numpy(),
+           'o_mx': out_df['mapped_x'].to_numpy(), 'o_my': out_df['mapped_y'].to_numpy(),
+           'o_type': out_df['cell_type'].to_numpy().astype(str)}
+    keys = ('total_triangles', 'triangles_with_all_matched', 'triangles_processed', 'triangles_same_type_skipped',
+            'triangles_flipped', 'percent_flipped', 'nodes_in_violating_triangles', 'percent_nodes_violating')
+    for tag, kw in (('default', {}), ('alltypes', dict(ignore_same_type_triangles=False)),
+                    ('local', dict(node_local=True)), ('local_strict', dict(node_local=True, majority_threshold=0.3, min_flips=2)),
+                    ('local_alltypes', dict(node_local=True, ignore_same_type_triangles=False, majority_threshold=0.75))):
+        df, stats = ref.eval_utils.check_triangle_violations(out_df, MC(), **kw)
+        out[f'viol_{tag}'] = df['in_violating_triangle'].to_numpy().astype(np.uint8)
+        out[f'stats_{tag}'] = np.array([stats[k] for k in keys], dtype=np.float64)
+        print(f"[eval_tri/{tag}] {stats}")
+    np.savez_compressed(os.path.join(OUT, 'eval_tri.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'eval':
+        eval_case()
+        return
     # (1) the shipped synthetic example with the paper's parameters (examples/synthetic/run_same.sh:34-54)
     d = os.path.join(REF_ROOT, 'examples', 'synthetic', 'data')
     ref_df = add_row_ids(pd.read_csv(os.path.join(d, 'ref.csv'), index_col=0))
@@ -422,6 +468,8 @@ def main():
     stored_run_case('simulated_elastic')
     # (5) adversarial
     adversarial_case()
+    # (6) SURVEY 8(f1): eval_utils.check_triangle_violations
+    eval_case()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith('.npz')}
     print(json.dumps(sizes, indent=1))
 
