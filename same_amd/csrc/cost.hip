@@ -53,7 +53,19 @@ __device__ __forceinline__ void touch(float v) { asm volatile("" ::"s"(v)); }
 __device__ __forceinline__ void keep_alive(double v) { asm volatile("" ::"v"(v)); }
 __device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
-template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4>
+// 16-byte nontemporal store, address = scalar row pointer + fixed per-lane byte offset: no VALU instruction
+// and no address VGPR is spent on addressing (hipcc otherwise keeps a 64-bit VGPR pointer and bumps it
+// with a v_lshl_add_u64 per row).  The trailing s_nop covers the ">64-bit store data, then VALU write of
+// those VGPRs" wait state that the compiler only inserts for its own instructions.
+template <typename V16>
+__device__ __forceinline__ void store16_nt_saddr(char *row_uniform, unsigned lane_byte_off, V16 v) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(V16) == 16, "16-byte vector expected");
+    const i4 bits = __builtin_bit_cast(i4, v);
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(lane_byte_off), "v"(bits), "s"(row_uniform) : "memory");
+}
+
+template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4, bool W1 = false>
 __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w, F dcoef,
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) dc[c] = absf<F>(dx[c]) + absf<F>(dy[c]);
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) ws[c] = w * s[c];
+                for (int c = 0; c < CPL; ++c) ws[c] = W1 ? s[c] : w * s[c];  // 1.0*s == s exactly: the multiply is skipped, not approximated
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) dc[c] = dcoef * dc[c];
 #pragma unroll
@@ -171,7 +183,8 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) res[d][c] = v[c];
                 vecF *dst = reinterpret_cast<vecF *>(orow + lane_off);
-                if constexpr (NT) __builtin_nontemporal_store(res[d], dst);
+                if constexpr (NT && sizeof(vecF) == 16) store16_nt_saddr(orow, lane_off, res[d]);
+                else if constexpr (NT) __builtin_nontemporal_store(res[d], dst);
                 else *dst = res[d];
             } else {
                 F *dst = reinterpret_cast<F *>(orow + lane_off);
@@ -268,9 +281,14 @@ int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy
     int64_t blocks = chunks * col_tiles;
     if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
-    hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), 0, ctx->stream, A, R,
-                       axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols, map_mode,
-                       (int)chunks);
+    if (w == F(1))
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
+                           ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
+                           map_mode, (int)chunks);
+    else
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
+                           ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
+                           map_mode, (int)chunks);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
