@@ -212,6 +212,21 @@ int same_tri_flip_stats(same_ctx *ctx, const double *axy, const double *mapped_x
                         const int32_t *tris, int64_t Tr, uint8_t *out_tri_flag,
                         uint32_t *out_node_tri, uint32_t *out_node_flip);
 
+/* ---- f2: metacell collapse (metacell_utils.greedy_triangle_collapse) -----------------------
+ * same_collapse_candidates replaces the per-triangle work of one collapse iteration
+ * (src/metacell_utils.py:233-260 validity, :393-431 candidate test and priority):
+ * out_flag bit0 = valid (no edge > r_max, no corner angle < min_angle, as a cosine threshold),
+ * bit1 = collapsible (valid, one cell type, size sum <= max_size); out_perim = priority;
+ * out_total = size sum.  same_greedy_disjoint replaces the sort + vertex-disjoint scan of
+ * :438-449 on items[M][3] with keys[M] (ties by item index), out_selected[M]. */
+int same_collapse_candidates(same_ctx *ctx, const double *xy, int64_t n, const int32_t *tris,
+                             int64_t Tr, int rmax_enabled, double r_max, int angle_enabled,
+                             double cos_thr, const int32_t *type_id, const double *size,
+                             double max_size, uint8_t *out_flag, double *out_perim,
+                             double *out_total);
+int same_greedy_disjoint(same_ctx *ctx, const int32_t *items, const double *keys, int64_t M,
+                         int64_t n_nodes, uint8_t *out_selected, int *out_rounds);
+
 /* ---- a14: eager reference-orientation signs -------------------------------------------
  * Replaces calc_ref_area over all candidate combinations (src/helpers.py:425-441,455-510):
  * out[((t*k+x)*k+y)*k+z] = sign(round(cross, 3)) for cand[tris[t][0]][x], ..., 2 if any is -1. */

@@ -587,3 +587,100 @@ def check_triangle_violations(outputDF, mc_align, aligned_id_col='aligned_metace
              'nodes_in_violating_triangles': int(outputDF['in_violating_triangle'].sum()),
              'percent_nodes_violating': 100.0 * outputDF['in_violating_triangle'].mean()}
     return outputDF, stats
+
+
+# --------------------------------------------------------------------------- f2
+def _mc_angle(p1, p2, p3):
+    """compute_angle of src/metacell_utils.py:233-239 (no zero-length guard)."""
+    v1, v2 = p1 - p2, p3 - p2
+    with np.errstate(all="ignore"):
+        c = np.dot(v1, v2) / (np.linalg.norm(v1) * np.linalg.norm(v2))
+        return np.degrees(np.arccos(np.clip(c, -1, 1)))
+
+
+def _mc_valid(tc, r_max, min_angle_deg):
+    """is_triangle_valid, src/metacell_utils.py:241-260."""
+    p1, p2, p3 = tc
+    if r_max is not None and max(np.linalg.norm(p2 - p1), np.linalg.norm(p3 - p2), np.linalg.norm(p1 - p3)) > r_max:
+        return False
+    if min_angle_deg is not None and min(_mc_angle(p2, p1, p3), _mc_angle(p1, p2, p3), _mc_angle(p1, p3, p2)) < min_angle_deg:
+        return False
+    return True
+
+
+def _mc_filter(coords, triangles, r_max, min_angle_deg):
+    kept = [tri for tri in triangles if _mc_valid(coords[tri], r_max, min_angle_deg)]
+    return np.array(kept) if kept else np.array([]).reshape(0, 3)
+
+
+def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=1000, r_max=None, min_angle_deg=10, *,
+                             original_idx_col="Cell_Num_Old", metacell_idx_col="metacell_id", x_col="X", y_col="Y",
+                             cell_type_col="cell_type"):
+    """src/metacell_utils.py:296-514 without the alpha shape -> (metacell_df, metacell_delaunay, original_delaunay)."""
+    import pandas as pd
+    from scipy.spatial import Delaunay
+
+    aligned_df = aligned_df.copy()
+    by_id = aligned_df.set_index(original_idx_col, drop=False)
+    oc = aligned_df[[x_col, y_col]].to_numpy()
+    ids = aligned_df[original_idx_col].to_numpy()
+    opos = _mc_filter(oc, Delaunay(oc).simplices, r_max, min_angle_deg) if len(oc) >= 4 else np.array([], dtype=int).reshape(0, 3)
+    original_delaunay = ids[opos.astype(int)] if opos.size else np.array([], dtype=ids.dtype).reshape(0, 3)
+    id_cols = [c for c in aligned_df.columns if c in ["Cell_Num", "Cell_Num_Old", "cell_id", "Cell_ID", "ID", "id"]]
+    if original_idx_col not in id_cols:
+        id_cols.append(original_idx_col)
+    if metacell_idx_col in aligned_df.columns and metacell_idx_col not in id_cols:
+        id_cols.append(metacell_idx_col)
+    rows = []
+    for _, row in aligned_df.iterrows():
+        rows.append({x_col: row[x_col], y_col: row[y_col], cell_type_col: row[cell_type_col], "size": 1,
+                     "members": [row[original_idx_col]],
+                     **{c: row[c] for c in aligned_df.columns if c not in [x_col, y_col, cell_type_col] + id_cols}})
+    mdf = pd.DataFrame(rows)
+    mdf[metacell_idx_col] = range(len(mdf))
+    for _ in range(max_iterations):
+        coords = mdf[[x_col, y_col]].values
+        if len(coords) < 4:
+            break
+        tris = _mc_filter(coords, Delaunay(coords).simplices, r_max, min_angle_deg)
+        if len(tris) == 0:
+            break
+        cands = []
+        ctype, csize = mdf[cell_type_col].to_numpy(), mdf["size"].to_numpy()
+        for tri in tris:
+            a, b, c = tri
+            if not (ctype[a] == ctype[b] == ctype[c]):
+                continue
+            total = csize[a] + csize[b] + csize[c]
+            if total > max_metacell_size:
+                continue
+            per = np.linalg.norm(coords[a] - coords[b]) + np.linalg.norm(coords[b] - coords[c]) + np.linalg.norm(coords[c] - coords[a])
+            cands.append((per, [a, b, c], total))
+        if not cands:
+            break
+        cands.sort(key=lambda q: q[0])
+        used, batch = set(), []
+        for cand in cands:
+            a, b, c = cand[1]
+            if a not in used and b not in used and c not in used:
+                batch.append(cand)
+                used.update([a, b, c])
+        merged, drop = [], []
+        for per, (a, b, c), total in batch:
+            drop.extend([a, b, c])
+            members = mdf.iloc[a]["members"] + mdf.iloc[b]["members"] + mdf.iloc[c]["members"]
+            mc = by_id.loc[members, [x_col, y_col]]
+            new = {x_col: mc[x_col].mean(), y_col: mc[y_col].mean(), cell_type_col: mdf.iloc[a][cell_type_col], "size": total,
+                   "members": members}
+            for col in mdf.columns:
+                if col in [x_col, y_col, cell_type_col, "size", "members", metacell_idx_col] + id_cols:
+                    continue
+                new[col] = by_id.loc[members, col].mean() if pd.api.types.is_numeric_dtype(mdf[col]) else mdf.iloc[a][col]
+            merged.append(new)
+        mdf = mdf.drop(drop).reset_index(drop=True)
+        if merged:
+            mdf = pd.concat([mdf, pd.DataFrame(merged)], ignore_index=True)
+        mdf[metacell_idx_col] = range(len(mdf))
+    fc = mdf[[x_col, y_col]].values
+    final = _mc_filter(fc, Delaunay(fc).simplices, r_max, min_angle_deg) if len(fc) >= 4 else np.array([]).reshape(0, 3)
+    return mdf, final, original_delaunay

@@ -65,6 +65,8 @@ _PROTOTYPES = {
     "same_assign_matrix": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_dbl, c_vp],
     "same_greedy_match": [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_int)],
     "same_tri_flip_stats": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "same_collapse_candidates": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_dbl, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp],
+    "same_greedy_disjoint": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(c_int)],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "same_comm_unique_id": [c_vp],

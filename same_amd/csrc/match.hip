@@ -112,6 +112,107 @@ __global__ __launch_bounds__(256) void tri_flip_stats_kernel(
     tri_flag[t] = f;
 }
 
+
+// ---- metacell collapse (metacell_utils.greedy_triangle_collapse) ----------------
+// Per triangle of the current metacell triangulation (src/metacell_utils.py:233-260, :393-431):
+//   valid     : no edge > r_max (strict, unlike a7) and no corner angle < min_angle_deg
+//   candidate : valid, all three cell types equal, size[a]+size[b]+size[c] <= max_size
+//   perimeter : |ab| + |bc| + |ca| with 1-D np.linalg.norm (= sqrt(ddot) = sqrt(fma(y,y,x*x)))
+// The angle rule is a cosine threshold as in tri.hip.  compute_angle here has no zero-length guard
+// (:236-238): a zero side gives cos = 0/0 = NaN; Python's min(angle1, angle2, angle3) keeps a NaN
+// that comes first and skips later ones, which is reproduced literally.
+__device__ __forceinline__ double nrm2(double x, double y) { return __builtin_sqrt(__builtin_fma(y, y, x * x)); }
+__device__ __forceinline__ double corner_cos_raw(double2_t p1, double2_t p2, double2_t p3) {  // corner at p2
+    const double v1x = p1.x - p2.x, v1y = p1.y - p2.y, v2x = p3.x - p2.x, v2y = p3.y - p2.y;
+    double c = __builtin_fma(v1y, v2y, v1x * v2x) / (nrm2(v1x, v1y) * nrm2(v2x, v2y));
+    c = c < -1.0 ? -1.0 : c;  // np.clip: NaN stays NaN, +-inf clip to +-1
+    c = c > 1.0 ? 1.0 : c;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void collapse_candidates_kernel(
+    const double *__restrict__ xy, const int32_t *__restrict__ tris, int64_t Tr, int rmax_enabled, double r_max,
+    int angle_enabled, double cos_thr, const int32_t *__restrict__ type_id, const double *__restrict__ size, double max_size,
+    uint8_t *__restrict__ out_flag, double *__restrict__ out_perim, double *__restrict__ out_total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tr) return;
+    const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+    const double2_t p1 = ld2(xy, a), p2 = ld2(xy, b), p3 = ld2(xy, c);
+    bool valid = true;
+    if (rmax_enabled) {  // is_triangle_valid, :247-252
+        const double e1 = nrm2(p2.x - p1.x, p2.y - p1.y), e2 = nrm2(p3.x - p2.x, p3.y - p2.y), e3 = nrm2(p1.x - p3.x, p1.y - p3.y);
+        double mx = e1 > e2 ? e1 : e2;
+        mx = mx > e3 ? mx : e3;
+        if (mx > r_max) valid = false;
+    }
+    if (valid && angle_enabled) {  // :255-260
+        const double c1 = corner_cos_raw(p2, p1, p3), c2 = corner_cos_raw(p1, p2, p3), c3 = corner_cos_raw(p1, p3, p2);
+        if (c1 == c1) {  // Python min(): a leading NaN wins (test passes); later NaNs are skipped
+            double mc = c1;
+            if (c2 == c2 && c2 > mc) mc = c2;
+            if (c3 == c3 && c3 > mc) mc = c3;
+            if (mc >= cos_thr) valid = false;
+        }
+    }
+    uint8_t f = valid ? 1 : 0;
+    // priority, :420-424: (|a-b| + |b-c|) + |c-a|
+    const double per = nrm2(p1.x - p2.x, p1.y - p2.y) + nrm2(p2.x - p3.x, p2.y - p3.y) + nrm2(p3.x - p1.x, p3.y - p1.y);
+    const double tot = size[a] + size[b] + size[c];  // :408-410
+    if (valid && type_id[a] == type_id[b] && type_id[b] == type_id[c] && !(tot > max_size)) f |= 2;
+    out_flag[t] = f;
+    out_perim[t] = per;
+    out_total[t] = tot;
+}
+
+// Greedy vertex-disjoint selection in (key, item index) order (src/metacell_utils.py:438-449): the same
+// local-minimum rule as the pair matching, with three endpoints per item.
+__global__ __launch_bounds__(256) void disjoint_min_key_kernel(const int32_t *__restrict__ items, const double *__restrict__ keys,
+                                                                int64_t M, uint8_t *__restrict__ alive,
+                                                                const uint8_t *__restrict__ used,
+                                                                unsigned long long *__restrict__ vkey) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M || !alive[m]) return;
+    const int32_t a = items[3 * m], b = items[3 * m + 1], c = items[3 * m + 2];
+    if (used[a] || used[b] || used[c]) { alive[m] = 0; return; }
+    const unsigned long long k = cost_key(keys[m]);
+    atomicMin(&vkey[a], k); atomicMin(&vkey[b], k); atomicMin(&vkey[c], k);
+}
+__global__ __launch_bounds__(256) void disjoint_min_idx_kernel(const int32_t *__restrict__ items, const double *__restrict__ keys,
+                                                                int64_t M, const uint8_t *__restrict__ alive,
+                                                                const unsigned long long *__restrict__ vkey,
+                                                                unsigned *__restrict__ vidx) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M || !alive[m]) return;
+    const unsigned long long k = cost_key(keys[m]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int32_t v = items[3 * m + q];
+        if (k == vkey[v]) atomicMin(&vidx[v], (unsigned)m);
+    }
+}
+__global__ __launch_bounds__(256) void disjoint_select_kernel(const int32_t *__restrict__ items, int64_t M, uint8_t *__restrict__ alive,
+                                                               const unsigned *__restrict__ vidx, uint8_t *__restrict__ used,
+                                                               uint8_t *__restrict__ selected,
+                                                               unsigned long long *__restrict__ n_selected) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool sel = false;
+    if (m < M && alive[m]) {
+        const int32_t a = items[3 * m], b = items[3 * m + 1], c = items[3 * m + 2];
+        if (vidx[a] == (unsigned)m && vidx[b] == (unsigned)m && vidx[c] == (unsigned)m) {
+            sel = true;
+            alive[m] = 0;
+            selected[m] = 1;
+            used[a] = 1; used[b] = 1; used[c] = 1;
+        }
+    }
+    const unsigned long long bal = __ballot(sel);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_selected, (unsigned long long)__builtin_popcountll(bal));
+}
+__global__ __launch_bounds__(256) void disjoint_reset_kernel(unsigned long long *__restrict__ vkey, unsigned *__restrict__ vidx, int64_t n) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) { vkey[q] = ~0ull; vidx[q] = ~0u; }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
 
 }  // namespace
@@ -204,6 +305,80 @@ int same_tri_flip_stats(same_ctx *ctx, const double *axy, const double *mapped_x
     SAME_TRY(same_down(ctx, out_tri_flag, dflag, (size_t)Tr));
     SAME_TRY(same_down(ctx, out_node_tri, dnt, (size_t)n * sizeof(unsigned)));
     SAME_TRY(same_down(ctx, out_node_flip, dnf, (size_t)n * sizeof(unsigned)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_collapse_candidates(same_ctx *ctx, const double *xy, int64_t n, const int32_t *tris, int64_t Tr, int rmax_enabled,
+                             double r_max, int angle_enabled, double cos_thr, const int32_t *type_id, const double *size,
+                             double max_size, uint8_t *out_flag, double *out_perim, double *out_total) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, n >= 0 && Tr >= 0);
+    if (Tr == 0) return SAME_OK;
+    REQUIRE(ctx, xy && tris && type_id && size && out_flag && out_perim && out_total);
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n, "triangles"));
+    double *dxy, *dsize, *dperim, *dtot;
+    int32_t *dtris, *dtype;
+    uint8_t *dflag;
+    SAME_TRY(up_as(ctx, SL_AXY, xy, (size_t)n * 2, &dxy));
+    SAME_TRY(up_as(ctx, SL_SIZE, size, (size_t)n, &dsize));
+    SAME_TRY(up_as(ctx, SL_TYPE, type_id, (size_t)n, &dtype));
+    SAME_TRY(up_as(ctx, SL_TRIS, tris, (size_t)Tr * 3, &dtris));
+    SAME_TRY(slot_as(ctx, SL_FLAG0, (size_t)Tr, &dflag));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)Tr, &dperim));
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)Tr, &dtot));
+    hipLaunchKernelGGL(collapse_candidates_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dxy, dtris, Tr, rmax_enabled, r_max,
+                       angle_enabled, cos_thr, dtype, dsize, max_size, dflag, dperim, dtot);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out_flag, dflag, (size_t)Tr));
+    SAME_TRY(same_down(ctx, out_perim, dperim, (size_t)Tr * sizeof(double)));
+    SAME_TRY(same_down(ctx, out_total, dtot, (size_t)Tr * sizeof(double)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_greedy_disjoint(same_ctx *ctx, const int32_t *items, const double *keys, int64_t M, int64_t n_nodes,
+                         uint8_t *out_selected, int *out_rounds) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, M >= 0 && n_nodes >= 0 && M < ((int64_t)1 << 32) - 1);
+    if (out_rounds) *out_rounds = 0;
+    if (M == 0) return SAME_OK;
+    REQUIRE(ctx, items && keys && out_selected);
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, items, M * 3, 0, n_nodes, "items"));
+    int32_t *ditems;
+    double *dkeys;
+    uint8_t *dalive, *dused, *dsel;
+    unsigned long long *dvkey, *dcount;
+    unsigned *dvidx;
+    SAME_TRY(up_as(ctx, SL_TRIS, items, (size_t)M * 3, &ditems));
+    SAME_TRY(up_as(ctx, SL_X, keys, (size_t)M, &dkeys));
+    SAME_TRY(slot_as(ctx, SL_FLAG0, (size_t)M, &dalive));
+    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)M, &dsel));
+    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_nodes, &dused));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_nodes, &dvkey));
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)n_nodes, &dvidx));
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dcount));
+    HIP_TRY(ctx, hipMemsetAsync(dalive, 1, (size_t)M, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dsel, 0, (size_t)M, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dused, 0, (size_t)n_nodes, ctx->stream));
+    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
+    int rounds = 0;
+    for (;; ++rounds) {
+        REQUIRE(ctx, rounds <= M + 1);
+        HIP_TRY(ctx, hipMemsetAsync(dcount, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(disjoint_reset_kernel, dim3(grid_for(n_nodes)), dim3(256), 0, ctx->stream, dvkey, dvidx, n_nodes);
+        hipLaunchKernelGGL(disjoint_min_key_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, dkeys, M, dalive, dused, dvkey);
+        hipLaunchKernelGGL(disjoint_min_idx_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, dkeys, M, dalive, dvkey, dvidx);
+        hipLaunchKernelGGL(disjoint_select_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, M, dalive, dvidx, dused, dsel, dcount);
+        HIP_TRY(ctx, hipGetLastError());
+        SAME_TRY(same_down(ctx, h, dcount, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[0] == 0) break;
+    }
+    if (out_rounds) *out_rounds = rounds;
+    SAME_TRY(same_down(ctx, out_selected, dsel, (size_t)M));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;
 }

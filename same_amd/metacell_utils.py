@@ -1,0 +1,228 @@
+"""Metacell creation, SURVEY 8(f2): `MetaCell` and `greedy_triangle_collapse` with the signatures of
+src/metacell_utils.py:25-157 and :160-561.
+
+Each collapse iteration is: Delaunay of the current metacells (scipy/Qhull on the host, as in the
+reference) -> per-triangle validity / same-type / size / perimeter (csrc/match.hip
+`collapse_candidates_kernel`) -> vertex-disjoint greedy selection in perimeter order
+(`same_greedy_disjoint`, the device form of the reference's sort + scan) -> merge the selected triples.
+The merge keeps the reference's arithmetic: centroids and numeric columns are true means over the
+ORIGINAL member cells (pandas `mean` = numpy pairwise sum / count), computed here for all merged
+metacells of equal member count at once with the reduced axis contiguous, which is bit-identical to
+the per-metacell calls.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import pandas as pd
+
+from . import ops
+from .triangles import cos_threshold
+
+
+@dataclass
+class MetaCell:
+    """Container for metacell collapse results (fields and helpers of src/metacell_utils.py:25-157)."""
+
+    original_df: pd.DataFrame
+    params: Dict[str, Any]
+    x_col: str
+    y_col: str
+    cell_type_col: str
+    original_idx_col: str
+    metacell_idx_col: str
+    original_delaunay: np.ndarray
+    metacell_df: pd.DataFrame
+    metacell_delaunay: np.ndarray
+
+    def metacell_members(self, metacell_idx: int) -> List[Any]:
+        return list(self.metacell_df.iloc[int(metacell_idx)]["members"])
+
+    def original_delaunay_to_row_indices(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
+        tri = self.original_delaunay if triangles is None else np.asarray(triangles)
+        if tri.size == 0:
+            return np.array([], dtype=int).reshape(0, 3)
+        if tri.ndim != 2 or tri.shape[1] != 3:
+            raise ValueError(f"triangles must have shape (n, 3); got {tri.shape}")
+        ids = pd.Index(self.original_df[self.original_idx_col].to_numpy())
+        flat = tri.reshape(-1)
+        remapped = ids.get_indexer(flat).astype(int).reshape(tri.shape)
+        if (remapped < 0).any():
+            if on_missing == "error":
+                missing = set(flat[remapped.reshape(-1) < 0].tolist())
+                raise KeyError(f"Found triangle vertices not in original_df[{self.original_idx_col}]: {list(missing)[:10]}")
+            remapped = remapped[(remapped >= 0).all(axis=1)]
+        return remapped
+
+    def original_delaunay_to_pos(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
+        return self.original_delaunay_to_row_indices(triangles=triangles, on_missing=on_missing)
+
+    def original_delaunay_to_xy(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
+        tri_pos = self.original_delaunay_to_row_indices(triangles=triangles, on_missing=on_missing)
+        if tri_pos.size == 0:
+            return np.array([], dtype=float).reshape(0, 3, 2)
+        return self.original_df[[self.x_col, self.y_col]].to_numpy(dtype=float, copy=False)[tri_pos]
+
+    def metacell_delaunay_to_xy(self) -> np.ndarray:
+        tri = np.asarray(self.metacell_delaunay)
+        if tri.size == 0:
+            return np.array([], dtype=float).reshape(0, 3, 2)
+        return self.metacell_df[[self.x_col, self.y_col]].to_numpy(dtype=float, copy=False)[tri.astype(int, copy=False)]
+
+    def to_summary_dict(self) -> Dict[str, Any]:
+        return {
+            "n_original": int(len(self.original_df)), "n_metacells": int(len(self.metacell_df)), "params": dict(self.params),
+            "x_col": self.x_col, "y_col": self.y_col, "cell_type_col": self.cell_type_col,
+            "original_idx_col": self.original_idx_col, "metacell_idx_col": self.metacell_idx_col,
+            "n_original_triangles": int(getattr(self.original_delaunay, "shape", [0])[0]),
+            "n_metacell_triangles": int(getattr(self.metacell_delaunay, "shape", [0])[0]),
+        }
+
+
+def _filter_valid(coords, triangles, r_max, min_angle_deg, ctx):
+    """filter_triangles (src/metacell_utils.py:262-293) without the alpha shape: rows of `triangles` that are valid."""
+    if len(triangles) == 0:
+        return np.array([]).reshape(0, 3)
+    en, thr = cos_threshold(min_angle_deg)
+    n = len(coords)
+    flag, _, _ = ops.collapse_candidates(coords, triangles, r_max, en, thr, np.zeros(n, np.int32), np.ones(n), 0.0, ctx=ctx)
+    kept = triangles[(flag & 1).astype(bool)]
+    return kept if len(kept) else np.array([]).reshape(0, 3)
+
+
+def _mean_over_members(values, groups):
+    """pandas `Series.mean()` of `values[pos]` for every group of positions: sum of the non-NaN entries in
+    member order (numpy pairwise, reduced axis contiguous) / their count."""
+    out = np.empty(len(groups))
+    by_len = {}
+    for g, pos in enumerate(groups):
+        by_len.setdefault(len(pos), []).append(g)
+    for m, gs in by_len.items():
+        v = values[np.array([groups[g] for g in gs], dtype=np.int64).reshape(len(gs), m)]
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        nan = np.isnan(v)
+        if nan.any():
+            cnt = (~nan).sum(axis=1)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out[gs] = np.where(nan, 0.0, v).sum(axis=1) / cnt
+        else:
+            out[gs] = v.sum(axis=1) / m
+    return out
+
+
+def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=1000, r_max=None, min_angle_deg=10,
+                             use_alpha_shape=False, alpha=0.05, *, original_idx_col: str = "Cell_Num_Old",
+                             metacell_idx_col: str = "metacell_id", x_col: str = "X", y_col: str = "Y",
+                             cell_type_col: str = "cell_type", return_object: bool = False, verbose: bool = True, ctx=None):
+    from scipy.spatial import Delaunay
+
+    if use_alpha_shape:
+        try:
+            from alphashape import alphashape  # noqa: F401
+            from shapely.geometry import Polygon  # noqa: F401
+            raise NotImplementedError("alpha-shape containment (shapely) is outside this package; pass use_alpha_shape=False")
+        except ImportError:  # the reference prints this and carries on without the alpha shape (:271-273)
+            print("Warning: alphashape not available, skipping alpha shape filtering")
+            use_alpha_shape = False
+
+    required = [x_col, y_col, cell_type_col, original_idx_col]
+    missing = [c for c in required if c not in aligned_df.columns]
+    if missing:
+        raise ValueError(f"Input dataframe missing required columns: {missing}")
+    aligned_df = aligned_df.copy()
+    if aligned_df[original_idx_col].duplicated().any():
+        dups = aligned_df.loc[aligned_df[original_idx_col].duplicated(), original_idx_col].head(5).tolist()
+        raise ValueError(f"'{original_idx_col}' must be unique per original cell. Found duplicates (examples): {dups}")
+
+    original_coords = aligned_df[[x_col, y_col]].to_numpy()
+    if len(original_coords) >= 4:
+        original_delaunay_pos = _filter_valid(original_coords, Delaunay(original_coords).simplices, r_max, min_angle_deg, ctx)
+    else:
+        original_delaunay_pos = np.array([], dtype=int).reshape(0, 3)
+    original_ids_by_pos = aligned_df[original_idx_col].to_numpy()
+    if original_delaunay_pos.size == 0:
+        original_delaunay = np.array([], dtype=original_ids_by_pos.dtype).reshape(0, 3)
+    else:
+        original_delaunay = original_ids_by_pos[original_delaunay_pos.astype(int)]
+
+    id_columns = ["Cell_Num", "Cell_Num_Old", "cell_id", "Cell_ID", "ID", "id"]
+    id_cols_present = [col for col in aligned_df.columns if col in id_columns]
+    if original_idx_col not in id_cols_present:
+        id_cols_present.append(original_idx_col)
+    if metacell_idx_col in aligned_df.columns and metacell_idx_col not in id_cols_present:
+        id_cols_present.append(metacell_idx_col)
+    other_cols = [c for c in aligned_df.columns if c not in [x_col, y_col, cell_type_col] + id_cols_present]
+
+    # every cell starts as a metacell of size 1 (:331-348); members are ORIGINAL ids
+    metacell_df = pd.DataFrame({x_col: aligned_df[x_col].to_numpy(), y_col: aligned_df[y_col].to_numpy(),
+                                cell_type_col: aligned_df[cell_type_col].to_numpy()})
+    metacell_df["size"] = 1
+    metacell_df["members"] = [[v] for v in original_ids_by_pos.tolist()]
+    for c in other_cols:
+        metacell_df[c] = aligned_df[c].to_numpy()
+    metacell_df[metacell_idx_col] = range(len(metacell_df))
+    member_pos = [[i] for i in range(len(aligned_df))]            # positions in aligned_df, parallel to `members`
+    orig_x = aligned_df[x_col].to_numpy(dtype=np.float64)
+    orig_y = aligned_df[y_col].to_numpy(dtype=np.float64)
+    en, thr = cos_threshold(min_angle_deg)
+
+    if verbose:
+        print(f"Starting greedy triangle collapse:\n  Initial cells: {len(aligned_df)}\n  Max metacell size: {max_metacell_size}")
+    for iteration in range(max_iterations):
+        coords = metacell_df[[x_col, y_col]].values
+        if len(coords) < 4:
+            break
+        triangles_raw = Delaunay(coords).simplices
+        type_id = pd.factorize(metacell_df[cell_type_col].to_numpy(), use_na_sentinel=False)[0].astype(np.int32)
+        size = metacell_df["size"].to_numpy(dtype=np.float64)
+        flag, perim, total = ops.collapse_candidates(coords, triangles_raw, r_max, en, thr, type_id, size, max_metacell_size, ctx=ctx)
+        if not (flag & 1).any():
+            break                                                   # no valid triangles (:386-389)
+        cand = np.flatnonzero(flag & 2)                             # in triangle order = the reference's candidate order
+        if len(cand) == 0:
+            break                                                   # nothing collapsible (:433-436)
+        tri_c = triangles_raw[cand]
+        selected, _ = ops.greedy_disjoint(tri_c, perim[cand], len(coords), ctx=ctx)
+        sel = np.flatnonzero(selected)
+        sel = sel[np.lexsort((sel, perim[cand][sel]))]              # batch order = stable sort by priority (:439)
+        batch = tri_c[sel]
+        groups = [member_pos[a] + member_pos[b] + member_pos[c] for a, b, c in batch.tolist()]
+        members = metacell_df["members"].tolist()
+        merged = {
+            x_col: _mean_over_members(orig_x, groups), y_col: _mean_over_members(orig_y, groups),
+            cell_type_col: metacell_df[cell_type_col].to_numpy()[batch[:, 0]],
+            "size": metacell_df["size"].to_numpy()[batch].sum(axis=1),
+            "members": [members[a] + members[b] + members[c] for a, b, c in batch.tolist()],
+        }
+        for col in metacell_df.columns:
+            if col in [x_col, y_col, cell_type_col, "size", "members", metacell_idx_col] + id_cols_present:
+                continue
+            if pd.api.types.is_numeric_dtype(metacell_df[col]):
+                merged[col] = _mean_over_members(aligned_df[col].to_numpy(dtype=np.float64), groups)   # true mean over original cells
+            else:
+                merged[col] = metacell_df[col].to_numpy()[batch[:, 0]]                                  # first vertex's value
+        remove = batch.reshape(-1)
+        keep_mask = np.ones(len(metacell_df), bool)
+        keep_mask[remove] = False
+        member_pos = [member_pos[i] for i in np.flatnonzero(keep_mask)] + groups
+        metacell_df = metacell_df.drop(remove).reset_index(drop=True)
+        metacell_df = pd.concat([metacell_df, pd.DataFrame(merged)], ignore_index=True)
+        metacell_df[metacell_idx_col] = range(len(metacell_df))
+
+    final_coords = metacell_df[[x_col, y_col]].values
+    if len(final_coords) >= 4:
+        final_delaunay = _filter_valid(final_coords, Delaunay(final_coords).simplices, r_max, min_angle_deg, ctx)
+    else:
+        final_delaunay = np.array([]).reshape(0, 3)
+    if verbose:
+        print(f"\nCollapse complete:\n  Original cells: {len(aligned_df)}\n  Final metacells: {len(metacell_df)}\n"
+              f"  Avg metacell size: {metacell_df['size'].mean():.1f}\n  Final triangles: {len(final_delaunay)}")
+    if return_object:
+        params = {"max_metacell_size": max_metacell_size, "max_iterations": max_iterations, "r_max": r_max,
+                  "min_angle_deg": min_angle_deg, "use_alpha_shape": use_alpha_shape, "alpha": alpha}
+        return MetaCell(original_df=aligned_df, params=params, x_col=x_col, y_col=y_col, cell_type_col=cell_type_col,
+                        original_idx_col=original_idx_col, metacell_idx_col=metacell_idx_col,
+                        original_delaunay=original_delaunay, metacell_df=metacell_df, metacell_delaunay=final_delaunay)
+    return metacell_df, final_delaunay

@@ -265,3 +265,32 @@ def tri_flip_stats(axy, mapped_xy, matched, triangles, type_id=None, ctx=None):
                                               tris.ctypes.data, Tr, flag.ctypes.data, nt.ctypes.data, nf.ctypes.data),
                   "same_tri_flip_stats")
     return flag, nt, nf
+
+
+def collapse_candidates(xy, triangles, r_max, angle_enabled, cos_thr, type_id, size, max_size, ctx=None):
+    """One collapse iteration's per-triangle work -> (flag [bit0 valid, bit1 collapsible], perimeter, total size)."""
+    ctx = _ctx(ctx)
+    xy = as_c(xy, F64).reshape(-1, 2)
+    tris = _tris(triangles)
+    type_id, size = as_c(type_id, I32), as_c(size, F64)
+    Tr = len(tris)
+    flag, perim, total = np.empty(Tr, U8), np.empty(Tr, F64), np.empty(Tr, F64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_collapse_candidates(ctx.handle, xy.ctypes.data, len(xy), tris.ctypes.data, Tr,
+                                                   0 if r_max is None else 1, 0.0 if r_max is None else float(r_max),
+                                                   int(angle_enabled), float(cos_thr), type_id.ctypes.data, size.ctypes.data,
+                                                   float(max_size), flag.ctypes.data, perim.ctypes.data, total.ctypes.data),
+                  "same_collapse_candidates")
+    return flag, perim, total
+
+
+def greedy_disjoint(items, keys, n_nodes, ctx=None):
+    """Vertex-disjoint greedy selection in (key, item index) order -> (selected (M,) bool, rounds)."""
+    ctx = _ctx(ctx)
+    items, keys = as_c(items, I32).reshape(-1, 3), as_c(keys, F64)
+    sel = np.zeros(len(items), U8)
+    rounds = ctypes.c_int(0)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_greedy_disjoint(ctx.handle, items.ctypes.data, keys.ctypes.data, len(items), int(n_nodes),
+                                               sel.ctypes.data, ctypes.byref(rounds)), "same_greedy_disjoint")
+    return sel.astype(bool), rounds.value

@@ -512,3 +512,58 @@ def test_greedy_match_equals_sequential_scan(ops, oracle):
     assert (mp == -1).all()
     mp, _ = ops.greedy_match(np.array([[0, 0], [1, 1]], np.int32), np.array([1.0, 2.0]), 2, 2, np.zeros(2, np.uint8))
     assert (mp == -1).all()
+
+
+# ------------------------------------------------------------------------------------------ SURVEY 8(f2)
+@pytest.mark.parametrize("which", ["s3", "s6", "s9", "s1", "seeded"])
+def test_greedy_triangle_collapse_golden(hip, which):
+    from same_amd.metacell_utils import greedy_triangle_collapse
+    from test_oracle_golden import check_metacells, metacell_inputs
+
+    g = load_golden("metacell")
+    df, kw, num_cols, other_cols = metacell_inputs(which)
+    mc = greedy_triangle_collapse(df, return_object=True, verbose=False, **kw)
+    check_metacells(g, "seeded" if which == "seeded" else f"q_{which}", mc.metacell_df, mc.metacell_delaunay,
+                    None if which == "seeded" else mc.original_delaunay, num_cols, other_cols)
+    assert mc.to_summary_dict()["n_metacells"] == len(mc.metacell_df)
+    assert mc.metacell_delaunay_to_xy().shape == (len(mc.metacell_delaunay), 3, 2)
+    assert mc.original_delaunay_to_row_indices().shape == np.asarray(mc.original_delaunay).shape
+
+
+def test_greedy_triangle_collapse_vs_oracle_seeded(hip, oracle, ops):
+    """A larger collapse (several iterations, metacells of up to 8 cells) against the oracle, and the metacell object
+    fed straight into the pre-MIP path the way the example scripts do."""
+    import same_amd
+    from same_amd import synth
+    from same_amd.metacell_utils import greedy_triangle_collapse
+
+    cells = synth.make_cells(6000, 3, seed=9)
+    df = synth.to_frame(cells)
+    kw = dict(max_metacell_size=8, r_max=40, min_angle_deg=10)
+    mc = greedy_triangle_collapse(df, return_object=True, verbose=False, **kw)
+    omdf, otri, oorig = oracle.greedy_triangle_collapse(df, **kw)
+    m = mc.metacell_df
+    assert list(m.columns) == list(omdf.columns) and len(m) == len(omdf) < 0.8 * len(df)
+    for col in ("X", "Y", "size", "c1", "c2", "c3", "metacell_id"):
+        assert np.array_equal(m[col].to_numpy(), omdf[col].to_numpy()), col
+    assert m["members"].tolist() == omdf["members"].tolist() and m["cell_type"].tolist() == omdf["cell_type"].tolist()
+    assert np.array_equal(np.asarray(mc.metacell_delaunay), otri) and np.array_equal(np.asarray(mc.original_delaunay), oorig)
+    assert int(m["size"].max()) > 3
+    ref_mc = greedy_triangle_collapse(synth.to_frame(synth.make_jittered(cells, seed=2)).assign(Cell_Num_Old=lambda d: np.arange(len(d))),
+                                      return_object=True, verbose=False, **kw)
+    prep = same_amd.prepare_same_inputs(ref_mc.metacell_df, mc, synth.type_columns(3),
+                                        optim_params=dict(radius=40, knn=6, cell_id_col=None), verbose=False)
+    assert prep.using_precomputed and prep.optim_params["cell_id_col"] == "metacell_id" and len(prep.valid_pairs) > 1000
+    # the device selection equals a sequential scan on a random hypergraph with heavy key ties
+    rng = np.random.default_rng(0)
+    items = rng.integers(0, 3000, size=(20000, 3)).astype(np.int32)
+    items = items[(items[:, 0] != items[:, 1]) & (items[:, 1] != items[:, 2]) & (items[:, 0] != items[:, 2])]
+    keys = np.round(rng.gamma(2.0, 3.0, len(items)), 1)
+    sel, rounds = ops.greedy_disjoint(items, keys, 3000)
+    used, want = set(), np.zeros(len(items), bool)
+    for q in np.argsort(keys, kind="stable"):
+        a, b, c = items[q]
+        if a not in used and b not in used and c not in used:
+            want[q] = True
+            used.update((a, b, c))
+    assert np.array_equal(sel, want) and rounds > 1

@@ -273,3 +273,44 @@ def test_check_triangle_violations(oracle):
         df, stats = oracle.check_triangle_violations(out_df, mc, **kw)
         assert np.array_equal(df['in_violating_triangle'].to_numpy().astype(np.uint8), g[f'viol_{tag}']), tag
         assert np.array_equal(np.array([stats[k] for k in EVAL_KEYS], dtype=np.float64), g[f'stats_{tag}']), tag
+
+
+def metacell_inputs(which):
+    """Inputs of the metacell fixture: the shipped synthetic query frame is rebuilt from the synthetic_example fixture."""
+    from same_amd import synth
+    if which == 'seeded':
+        df = synth.to_frame(synth.make_cells(1500, 4, seed=5))
+        df['batch'] = np.where(np.arange(len(df)) % 3 == 0, 'b0', 'b1')
+        df['flag'] = (np.arange(len(df)) % 2).astype(np.int64)
+        return df, dict(max_metacell_size=5, r_max=30, min_angle_deg=12), ['c1', 'c2', 'c3', 'c4', 'size', 'flag'], ['batch']
+    g = load_golden('metacell_inputs')
+    q = pd.DataFrame({'X': g['q_xy'][:, 0], 'Y': g['q_xy'][:, 1], 'cell_type': g['q_type'].astype(object), 'c1': g['q_c'][:, 0],
+                      'c2': g['q_c'][:, 1], 'c3': g['q_c'][:, 2], 'quadrant': g['q_quadrant'].astype(object), 'cell_idx': g['q_idx']})
+    kw = {'s3': dict(max_metacell_size=3, r_max=5, min_angle_deg=5), 's6': dict(max_metacell_size=6, r_max=None, min_angle_deg=10),
+          's9': dict(max_metacell_size=9, r_max=4, min_angle_deg=None), 's1': dict(max_metacell_size=1, r_max=5, min_angle_deg=5)}[which]
+    return q, dict(original_idx_col='cell_idx', **kw), ['c1', 'c2', 'c3'], ['quadrant']
+
+
+def check_metacells(g, prefix, mdf, tri, orig_tri, num_cols, other_cols):
+    assert list(mdf.columns) == g[f'{prefix}_cols'].tolist()
+    assert np.array_equal(mdf[['X', 'Y']].to_numpy(dtype=np.float64), g[f'{prefix}_xy'])      # centroids bit-exact
+    assert np.array_equal(mdf['size'].to_numpy(dtype=np.int64), g[f'{prefix}_size'])
+    assert np.array_equal(mdf['cell_type'].to_numpy().astype(str), g[f'{prefix}_type'])
+    members = mdf['members'].tolist()
+    assert np.array_equal(np.array([m for ms in members for m in ms], dtype=np.int64), g[f'{prefix}_members'])
+    assert np.array_equal(np.cumsum([0] + [len(ms) for ms in members]), g[f'{prefix}_member_off'])
+    assert np.array_equal(mdf[num_cols].to_numpy(dtype=np.float64), g[f'{prefix}_num'])
+    assert np.array_equal(mdf[other_cols].to_numpy().astype(str), g[f'{prefix}_other'])
+    assert np.array_equal(mdf['metacell_id'].to_numpy(dtype=np.int64), g[f'{prefix}_mcid'])
+    assert np.array_equal(np.asarray(tri, dtype=np.int64).reshape(-1, 3), g[f'{prefix}_tri'])
+    if orig_tri is not None:
+        assert np.array_equal(np.asarray(orig_tri, dtype=np.int64).reshape(-1, 3), g[f'{prefix}_orig_tri'])
+
+
+@pytest.mark.parametrize("which", ['s3', 's6', 's9', 's1', 'seeded'])
+def test_greedy_triangle_collapse(oracle, which):
+    """metacell_utils.greedy_triangle_collapse."""
+    g = load_golden('metacell')
+    df, kw, num_cols, other_cols = metacell_inputs(which)
+    mdf, tri, orig = oracle.greedy_triangle_collapse(df, **kw)
+    check_metacells(g, 'seeded' if which == 'seeded' else f'q_{which}', mdf, tri, None if which == 'seeded' else orig, num_cols, other_cols)

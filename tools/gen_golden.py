@@ -441,10 +441,51 @@ def eval_case():
     np.savez_compressed(os.path.join(OUT, 'eval_tri.npz'), **out)
 
 
+def metacell_arrays(prefix, mdf, tri, orig_tri, num_cols, other_cols):
+    members = mdf['members'].tolist()
+    return {f'{prefix}_xy': mdf[['X', 'Y']].to_numpy(dtype=np.float64), f'{prefix}_size': mdf['size'].to_numpy(dtype=np.int64),
+            f'{prefix}_type': mdf['cell_type'].to_numpy().astype(str),
+            f'{prefix}_members': np.array([m for ms in members for m in ms], dtype=np.int64),
+            f'{prefix}_member_off': np.cumsum([0] + [len(ms) for ms in members]).astype(np.int64),
+            f'{prefix}_num': mdf[num_cols].to_numpy(dtype=np.float64), f'{prefix}_other': mdf[other_cols].to_numpy().astype(str),
+            f'{prefix}_mcid': mdf['metacell_id'].to_numpy(dtype=np.int64), f'{prefix}_cols': np.array(list(mdf.columns)),
+            f'{prefix}_tri': np.asarray(tri, dtype=np.int64).reshape(-1, 3), f'{prefix}_orig_tri': np.asarray(orig_tri, dtype=np.int64).reshape(-1, 3)}
+
+
+def metacell_case():
+    """metacell_utils.greedy_triangle_collapse (src/metacell_utils.py:160-561) on the shipped example and a seeded case."""
+    out = {}
+    d = os.path.join(REF_ROOT, 'examples', 'synthetic', 'data')
+    q = pd.read_csv(os.path.join(d, 'query.csv'), index_col=0)
+    np.savez_compressed(os.path.join(OUT, 'metacell_inputs.npz'), q_xy=q[['X', 'Y']].to_numpy(), q_type=q['cell_type'].to_numpy().astype(str),
+                        q_c=q[['c1', 'c2', 'c3']].to_numpy(), q_quadrant=q['quadrant'].to_numpy().astype(str), q_idx=q['cell_idx'].to_numpy())
+    q = q[['X', 'Y', 'cell_type', 'c1', 'c2', 'c3', 'quadrant', 'cell_idx']]
+    for tag, kw in (('s3', dict(max_metacell_size=3, r_max=5, min_angle_deg=5)),
+                    ('s6', dict(max_metacell_size=6, r_max=None, min_angle_deg=10)),
+                    ('s9', dict(max_metacell_size=9, r_max=4, min_angle_deg=None)),
+                    ('s1', dict(max_metacell_size=1, r_max=5, min_angle_deg=5))):
+        mc = quiet(ref.metacell_utils.greedy_triangle_collapse, q, original_idx_col='cell_idx', use_alpha_shape=False,
+                   return_object=True, **kw)
+        out.update(metacell_arrays(f'q_{tag}', mc.metacell_df, mc.metacell_delaunay, mc.original_delaunay, ['c1', 'c2', 'c3'], ['quadrant']))
+        print(f"[metacell/query {tag}] {len(q)} -> {len(mc.metacell_df)} metacells, {len(mc.metacell_delaunay)} triangles, max size {mc.metacell_df['size'].max()}")
+    cells = synth.make_cells(1500, 4, seed=5)
+    df = synth.to_frame(cells)
+    df['batch'] = np.where(np.arange(len(df)) % 3 == 0, 'b0', 'b1')
+    df['flag'] = (np.arange(len(df)) % 2).astype(np.int64)
+    mdf, tri = quiet(ref.metacell_utils.greedy_triangle_collapse, df, max_metacell_size=5, r_max=30, min_angle_deg=12)
+    out['seeded_n'] = np.array([len(df)])
+    out.update(metacell_arrays('seeded', mdf, tri, np.zeros((0, 3)), ['c1', 'c2', 'c3', 'c4', 'size', 'flag'], ['batch']))
+    print(f"[metacell/seeded] {len(df)} -> {len(mdf)} metacells, {len(tri)} triangles")
+    np.savez_compressed(os.path.join(OUT, 'metacell.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'eval':
         eval_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'metacell':
+        metacell_case()
         return
     # (1) the shipped synthetic example with the paper's parameters (examples/synthetic/run_same.sh:34-54)
     d = os.path.join(REF_ROOT, 'examples', 'synthetic', 'data')
@@ -470,6 +511,8 @@ def main():
     adversarial_case()
     # (6) SURVEY 8(f1): eval_utils.check_triangle_violations
     eval_case()
+    # (7) SURVEY 8(f2): metacell_utils.greedy_triangle_collapse
+    metacell_case()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith('.npz')}
     print(json.dumps(sizes, indent=1))
 

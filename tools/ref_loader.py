@@ -53,7 +53,7 @@ def load_reference():
     pkg.__path__ = [REF_SRC]
     sys.modules[_PKG] = pkg
     ns = types.SimpleNamespace()
-    for name in ("utils", "helpers", "violationhelper", "init_helpers", "knn_utils", "eval_utils"):
+    for name in ("utils", "helpers", "violationhelper", "init_helpers", "knn_utils", "eval_utils", "metacell_utils"):
         spec = importlib.util.spec_from_file_location(f"{_PKG}.{name}", os.path.join(REF_SRC, f"{name}.py"))
         mod = importlib.util.module_from_spec(spec)
         sys.modules[f"{_PKG}.{name}"] = mod
