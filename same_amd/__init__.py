@@ -18,7 +18,8 @@ from .sweeps import (LazyOrientationSweep, verify_spatial_preservation, print_vi
 from .init_helpers import compute_mip_start_pairs, apply_mip_start  # noqa: F401
 from .api import prepare_same_inputs, run_same, sliding_window_matching, subset_data  # noqa: F401
 from .windows import window_plan  # noqa: F401
-from .metacell_utils import MetaCell, greedy_triangle_collapse  # noqa: F401
+from .metacell_utils import MetaCell, greedy_triangle_collapse, unpack_metacell_matches  # noqa: F401
+from .merge import merge_window_matches_unique_ref, load_matching_results  # noqa: F401
 from .eval_utils import check_triangle_violations  # noqa: F401
 
 __version__ = "0.1.0"
@@ -28,5 +29,5 @@ __all__ = [
     "filter_triangles_by_radius", "precompute_triangle_info", "triangle_weights_and_signs",
     "LazyOrientationSweep", "verify_spatial_preservation", "print_violation_report", "triangle_area_flips",
     "compute_mip_start_pairs", "apply_mip_start", "window_plan", "MetaCell", "greedy_triangle_collapse",
-    "check_triangle_violations",
+    "check_triangle_violations", "unpack_metacell_matches", "merge_window_matches_unique_ref", "load_matching_results",
 ]

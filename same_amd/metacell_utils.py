@@ -226,3 +226,59 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
                         original_idx_col=original_idx_col, metacell_idx_col=metacell_idx_col,
                         original_delaunay=original_delaunay, metacell_df=metacell_df, metacell_delaunay=final_delaunay)
     return metacell_df, final_delaunay
+
+
+def unpack_metacell_matches(metacell_matches, metacell_aligned_df, metacell_ref_df, aligned_df=None, ref_df=None,
+                            strategy="distribute", aligned_original_idx_col: Optional[str] = None,
+                            ref_original_idx_col: Optional[str] = None, x_col: str = "X", y_col: str = "Y"):
+    """Metacell-level matches -> individual cell matches, signature and results of src/metacell_utils.py:564-766
+    (SURVEY 8(f4)).  This is host bookkeeping on small lists; the per-match assignments stay
+    scipy.optimize.linear_sum_assignment on scipy cdist distances, so ties resolve exactly as in the reference."""
+    from scipy.optimize import linear_sum_assignment
+    from scipy.spatial.distance import cdist
+
+    aligned_lookup = ref_lookup = None
+    if aligned_df is not None and aligned_original_idx_col is not None:
+        if aligned_original_idx_col not in aligned_df.columns:
+            raise ValueError(f"aligned_df missing aligned_original_idx_col='{aligned_original_idx_col}'")
+        aligned_lookup = aligned_df.set_index(aligned_original_idx_col, drop=False)
+    if ref_df is not None and ref_original_idx_col is not None:
+        if ref_original_idx_col not in ref_df.columns:
+            raise ValueError(f"ref_df missing ref_original_idx_col='{ref_original_idx_col}'")
+        ref_lookup = ref_df.set_index(ref_original_idx_col, drop=False)
+    ref_has_metacells = ("members" in metacell_ref_df.columns
+                         and metacell_ref_df["members"].apply(lambda x: isinstance(x, list)).any())
+    if ref_has_metacells and strategy == "nearest" and (aligned_df is None or ref_df is None):
+        raise ValueError("When ref has metacells and strategy='nearest', must provide both aligned_df and ref_df "
+                         "for nearest neighbor unpacking.")
+    if strategy == "nearest" and aligned_df is None:
+        raise ValueError("strategy='nearest' requires aligned_df parameter")
+
+    a_members = metacell_aligned_df["members"].tolist()
+    r_members = metacell_ref_df["members"].tolist() if ref_has_metacells else None
+    out_a, out_r = [], []
+    for a_idx, r_idx in zip(metacell_matches["Aligned_metacell_id"].tolist(), metacell_matches["Ref_metacell_id"].tolist()):
+        am = a_members[a_idx]
+        if not ref_has_metacells:
+            if strategy in ("distribute", "nearest"):       # every member -> the same reference cell (:652-669)
+                out_a.extend(am)
+                out_r.extend([r_idx] * len(am))
+            continue
+        rm = r_members[r_idx]
+        if strategy == "distribute":                         # deal the ref members round-robin (:675-685)
+            out_a.extend(am)
+            out_r.extend(rm[i % len(rm)] for i in range(len(am)))
+        elif strategy == "nearest":                          # optimal assignment on pairwise distances (:687-742)
+            ac = (aligned_lookup if aligned_lookup is not None else aligned_df).loc[am, [x_col, y_col]].values
+            rc = (ref_lookup if ref_lookup is not None else ref_df).loc[rm, [x_col, y_col]].values
+            dist = cdist(ac, rc)
+            if len(am) > len(rm):                            # more aligned than ref: every ref may be used ceil(n_a/n_r) times
+                dist = np.tile(dist, (1, int(np.ceil(len(am) / len(rm)))))
+            rows, cols = linear_sum_assignment(dist)
+            out_a.extend(am[i] for i in rows)
+            out_r.extend(rm[j % len(rm)] for j in cols)
+        else:
+            raise ValueError(f"Unknown strategy: {strategy}")
+    if not out_a:
+        return pd.DataFrame([])
+    return pd.DataFrame({"Aligned_cell_id": out_a, "Ref_cell_id": out_r})

@@ -479,8 +479,48 @@ def metacell_case():
     np.savez_compressed(os.path.join(OUT, 'metacell.npz'), **out)
 
 
+def unpack_merge_case():
+    """unpack_metacell_matches (src/metacell_utils.py:564-766) and merge_window_matches_unique_ref (src/helpers.py:692-815)."""
+    out = {}
+    cells = synth.make_cells(900, 3, seed=21)
+    a_df = synth.to_frame(cells); a_df['Cell_Num_Old'] = np.arange(len(a_df)) * 2 + 5
+    r_df = synth.to_frame(synth.make_jittered(cells, seed=22)); r_df['Cell_Num_Old'] = np.arange(len(r_df)) * 3 + 1
+    mca = quiet(ref.metacell_utils.greedy_triangle_collapse, a_df, max_metacell_size=5, r_max=40, min_angle_deg=10, return_object=True)
+    mcr = quiet(ref.metacell_utils.greedy_triangle_collapse, r_df, max_metacell_size=4, r_max=40, min_angle_deg=10, return_object=True)
+    rng = np.random.default_rng(4)
+    n = 400
+    mm = pd.DataFrame({'Aligned_metacell_id': rng.choice(len(mca.metacell_df), n, replace=False),
+                       'Ref_metacell_id': rng.choice(len(mcr.metacell_df), n, replace=False)})
+    out['mm'] = mm.to_numpy(dtype=np.int64)
+    for tag, kw in (('dist_both', dict(strategy='distribute')),
+                    ('near_both', dict(strategy='nearest', aligned_df=a_df, ref_df=r_df, aligned_original_idx_col='Cell_Num_Old',
+                                       ref_original_idx_col='Cell_Num_Old'))):
+        res = ref.metacell_utils.unpack_metacell_matches(mm, mca.metacell_df, mcr.metacell_df, **kw)
+        out[f'unpack_{tag}'] = res[['Aligned_cell_id', 'Ref_cell_id']].to_numpy(dtype=np.int64)
+    res = ref.metacell_utils.unpack_metacell_matches(mm.assign(Ref_metacell_id=mm['Ref_metacell_id'] % len(r_df)), mca.metacell_df, r_df)
+    out['unpack_simple'] = res[['Aligned_cell_id', 'Ref_cell_id']].to_numpy(dtype=np.int64)
+    # window merge: overlapping windows proposing conflicting matches; built so that the maximum matching is unique
+    rows = []
+    for w in range(3):
+        for q in range(40):
+            a = 10 * w + q
+            rows.append({'window_id': w, 'Aligned_Cell_Num_Old': a, 'Ref_Cell_Num_Old': 1000 + a, 'X': float(a), 'Y': float(w),
+                         'filtered_violation': bool((a + w) % 5 == 0)})
+    dfm = pd.DataFrame(rows)
+    dfm.loc[dfm.index[7], 'filtered_violation'] = np.nan
+    lst = [dfm[dfm.window_id == w].copy() for w in range(3)]
+    res = ref.helpers.merge_window_matches_unique_ref(lst)
+    out['merge_rows'] = res[['window_id', 'Aligned_Cell_Num_Old', 'Ref_Cell_Num_Old']].to_numpy(dtype=np.int64)
+    out['merge_viol'] = res['filtered_violation'].to_numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'unpack_merge.npz'), **out)
+    print(f"[unpack/merge] {[ (k, v.shape) for k, v in out.items()]}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'unpack':
+        unpack_merge_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'eval':
         eval_case()
         return
@@ -513,6 +553,8 @@ def main():
     eval_case()
     # (7) SURVEY 8(f2): metacell_utils.greedy_triangle_collapse
     metacell_case()
+    # (8) SURVEY 8(f3, f4)
+    unpack_merge_case()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith('.npz')}
     print(json.dumps(sizes, indent=1))
 
