@@ -10,7 +10,6 @@ per-incumbent Python loop of _lazy_orientation_callback with the device sweep.
 gurobipy is imported lazily: the pre-MIP path and the sweeps work without it.
 """
 import os
-from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -30,28 +29,62 @@ def _say(verbose, *a):
         print(*a)
 
 
-@dataclass
 class PreparedInputs:
-    """Every pre-MIP artefact of run_same, in the shapes Gurobi consumes."""
-    aligned_df: pd.DataFrame
-    ref_df: pd.DataFrame
-    valid_pairs: Any                      # (P,2) ndarray, or list of tuples after unconstrained-node removal
-    costs: List[float]                    # c[idx], same order as valid_pairs
-    aligned_delaunay: Any                 # list / array of 3-int rows; index = q_tri id
-    triangle_weights: List[float]
-    source_signs: List[float]
-    triangle_info: Dict[int, dict]
-    aligned_simplex_map: Dict[int, set]
-    valid_pairs_map: Dict[int, list]
-    aligned_coords: Dict[int, dict]
-    ref_coords: Dict[int, dict]
-    ref_coords_xy: Dict[int, tuple]       # model._ref_coords
-    unconstrained_nodes: set
-    using_precomputed: bool
-    n_aligned: int
-    n_ref: int
-    optim_params: Dict[str, Any] = field(default_factory=dict)
-    gurobi_params: Dict[str, Any] = field(default_factory=dict)
+    """Every pre-MIP artefact of run_same, in the shapes Gurobi consumes.
+
+    The flat artefacts (frames, valid_pairs, costs, triangles, weights, signs) are computed eagerly on the
+    device path.  The dict-shaped ones the reference builds with per-element Python loops (coordinate maps,
+    valid_pairs_map, simplex map, triangle_info: src/helpers.py:164-210, src/same.py:1096-1099) are built on
+    first access: the lazy-constraint solve only needs triangle_info (post-solve report), and a window
+    pipeline that only wants pairs, costs and sweeps never pays for them."""
+
+    def __init__(self, aligned_df, ref_df, valid_pairs, costs, aligned_delaunay, triangle_weights, source_signs,
+                 unconstrained_nodes, using_precomputed, optim_params, gurobi_params):
+        self.aligned_df, self.ref_df = aligned_df, ref_df
+        self.valid_pairs = valid_pairs          # (P,2) ndarray, or list of tuples after unconstrained-node removal
+        self.costs = costs                      # c[idx], same order as valid_pairs
+        self.aligned_delaunay = aligned_delaunay  # list / array of 3-int rows; index = q_tri id
+        self.triangle_weights, self.source_signs = triangle_weights, source_signs
+        self.unconstrained_nodes, self.using_precomputed = unconstrained_nodes, using_precomputed
+        self.n_aligned, self.n_ref = len(aligned_df), len(ref_df)
+        self.optim_params, self.gurobi_params = optim_params, gurobi_params
+        self._cache = {}
+
+    def _maps(self):
+        if "maps" not in self._cache:
+            self._cache["maps"] = precompute_coordinate_maps(self.aligned_df, self.ref_df, self.valid_pairs)
+        return self._cache["maps"]
+
+    @property
+    def aligned_coords(self):
+        return self._maps()[0]
+
+    @property
+    def ref_coords(self):
+        return self._maps()[1]
+
+    @property
+    def valid_pairs_map(self):
+        return self._maps()[2]
+
+    @property
+    def aligned_simplex_map(self):
+        if "simplex" not in self._cache:
+            self._cache["simplex"] = build_simplex_map(len(self.aligned_df), self.aligned_delaunay)
+        return self._cache["simplex"]
+
+    @property
+    def triangle_info(self):
+        if "tinfo" not in self._cache:
+            self._cache["tinfo"] = precompute_triangle_info(self.aligned_df, self.aligned_delaunay, self.aligned_simplex_map)
+        return self._cache["tinfo"]
+
+    @property
+    def ref_coords_xy(self):                    # model._ref_coords (src/same.py:1158)
+        if "rxy" not in self._cache:
+            rxy = self.ref_df[["X", "Y"]].to_numpy(dtype=np.float64)
+            self._cache["rxy"] = {j: (rxy[j, 0], rxy[j, 1]) for j in range(len(rxy))}
+        return self._cache["rxy"]
 
 
 def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, aligned_delaunay_vertex_col=None,
@@ -106,8 +139,6 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
     if len(valid_pairs) == 0:
         raise ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
 
-    aligned_coords, ref_coords, valid_pairs_map = precompute_coordinate_maps(aligned_df, ref_df, valid_pairs)
-
     # triangulation (src/same.py:1016-1031)
     aligned_coords_array = aligned_df[["X", "Y"]].values
     using_precomputed = False
@@ -145,23 +176,11 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
         tri = tri[keep_node[tri].all(axis=1)] if len(tri) else tri
         aligned_delaunay = old_to_new[tri] if len(tri) else np.array([]).reshape(0, 3)
         aligned_df = aligned_df.iloc[constrained_nodes].reset_index(drop=True)
-        n_aligned = len(aligned_df)
-        aligned_coords, ref_coords, valid_pairs_map = precompute_coordinate_maps(aligned_df, ref_df, valid_pairs)
 
-    aligned_simplex_map = build_simplex_map(len(aligned_df), aligned_delaunay)
-    triangle_info = precompute_triangle_info(aligned_df, aligned_delaunay, aligned_simplex_map)
     triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx)
-    rxy = ref_df[["X", "Y"]].to_numpy(dtype=np.float64)
-    ref_coords_xy = {j: (rxy[j, 0], rxy[j, 1]) for j in range(len(ref_df))}
     costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx)
-
-    return PreparedInputs(aligned_df=aligned_df, ref_df=ref_df, valid_pairs=valid_pairs, costs=costs,
-                          aligned_delaunay=aligned_delaunay, triangle_weights=triangle_weights, source_signs=source_signs,
-                          triangle_info=triangle_info, aligned_simplex_map=aligned_simplex_map,
-                          valid_pairs_map=valid_pairs_map, aligned_coords=aligned_coords, ref_coords=ref_coords,
-                          ref_coords_xy=ref_coords_xy, unconstrained_nodes=unconstrained_nodes,
-                          using_precomputed=using_precomputed, n_aligned=n_aligned, n_ref=n_ref,
-                          optim_params=optim_params, gurobi_params=gurobi_params)
+    return PreparedInputs(aligned_df, ref_df, valid_pairs, costs, aligned_delaunay, triangle_weights, source_signs,
+                          unconstrained_nodes, using_precomputed, optim_params, gurobi_params)
 
 
 # ------------------------------------------------------------------------------------------ callback

@@ -43,6 +43,8 @@ struct same_ctx {
 };
 
 inline int same_fail(same_ctx *ctx, int code, const char *what, hipError_t e) {
+    (void)hipGetLastError();  // HIP keeps the failure as the thread's "last error": clear it, or a later
+                              // hipGetLastError() after a kernel launch would report this stale one
     if (ctx) {
         char buf[512];
         snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);

@@ -567,3 +567,39 @@ def test_greedy_triangle_collapse_vs_oracle_seeded(hip, oracle, ops):
             want[q] = True
             used.update((a, b, c))
     assert np.array_equal(sel, want) and rounds > 1
+
+
+# ------------------------------------------------------------------------------------------ C-ABI error convention
+def test_c_abi_error_codes(hip):
+    """Negative codes, outputs never written out of bounds, message available; no exception crosses the ABI."""
+    import ctypes
+    from same_amd import _lib
+
+    ctx = _lib.default_context()
+    L, H = ctx.lib, ctx.handle
+    z = np.zeros((4, 2))
+    idx = np.full((4, 3), 7, np.int32); cnt = np.full(4, 7, np.int32)
+    EINVAL, ERANGE = -22, -34
+    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, 1.0, 0, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL     # k = 0
+    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 9, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL     # row_end > n_m
+    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, float("nan"), 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL
+    assert L.same_knn_prune(H, None, 4, z.ctypes.data, 4, 0, 4, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL            # NULL input
+    assert (idx == 7).all() and (cnt == 7).all()                                                                                      # outputs untouched
+    assert L.same_knn_prune(None, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL  # NULL ctx
+    tri = np.array([[0, 1, 9]], np.int32)
+    out = np.zeros(1, np.int8)
+    assert L.same_tri_sign_weight(H, z.ctypes.data, None, 4, tri.ctypes.data, 1, out.ctypes.data, None) == ERANGE
+    assert b"triangles[2] = 9" in L.same_last_error(H)
+    m = np.array([0, 1, 2, 99], np.int32)
+    o8 = np.zeros(16, np.uint8); o64 = np.zeros(3, np.int64)
+    assert L.same_xyorder_sweep(H, z.ctypes.data, 4, z.ctypes.data, 4, np.array([[0, 1, 2]], np.int32).ctypes.data, 1, m.ctypes.data,
+                                o8.ctypes.data, o8.ctypes.data, o8.ctypes.data, o64.ctypes.data) == ERANGE
+    chk, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+    fresh = _lib.Context(0)
+    assert fresh.lib.same_orient_sweep(fresh.handle, m.ctypes.data, ctypes.byref(chk), None, ctypes.byref(nv), None) == EINVAL          # not bound
+    fresh.close()
+    big = ctypes.c_void_p()
+    assert L.same_dev_alloc(H, 1 << 46, ctypes.byref(big)) in (-12, -5)                                                               # 64 TiB: ENOMEM (or EIO)
+    assert L.same_dense_cost_f64_dev(H, None, None, 20, None, None, 10, 0, 5, 1.0, None, 10) == EINVAL
+    assert L.same_dense_cost_f64_dev(H, z.ctypes.data, z.ctypes.data, 5000, z.ctypes.data, z.ctypes.data, 10, 0, 5, 1.0, z.ctypes.data, 10) == EINVAL  # T > SAME_MAX_TYPES
+    assert L.same_ctx_create(99, ctypes.byref(big)) == EINVAL
