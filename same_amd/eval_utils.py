@@ -86,3 +86,24 @@ def check_triangle_violations(outputDF, mc_align, aligned_id_col="aligned_metace
     if verbose:
         print(stats)
     return outputDF, stats
+
+
+def check_alignment(queryDF, templateDF, xcol, ycol, ctype_col="cell_type", kNN=1, ctx=None):
+    """eval_utils.check_alignment (src/eval_utils.py:6-55), same signature: is the query cell's type among the
+    types of its kNN nearest template cells?  cKDTree.query(k) = the k nearest by Euclidean distance; here the
+    radius-free form of the prune kernel (radius = +inf, ranking by (d2, template index))."""
+    queryDF = queryDF.copy()
+    required = {xcol, ycol, ctype_col}
+    if not required.issubset(queryDF.columns) or not required.issubset(templateDF.columns):
+        raise ValueError(f"Both DataFrames must contain the columns: {required}")
+    q = queryDF[[xcol, ycol]].to_numpy(dtype=np.float64)
+    t = templateDF[[xcol, ycol]].to_numpy(dtype=np.float64)
+    idx, _, _ = ops.knn_prune(q, t, float("inf"), int(kNN), want_d2=False, ctx=ctx)
+    qt = queryDF[ctype_col].to_numpy()
+    tt = templateDF[ctype_col].to_numpy()
+    near_types = tt[np.maximum(idx, 0)]
+    col = "_" + str(kNN) + "NN_match"
+    queryDF.loc[:, col] = ((near_types == qt[:, None]) & (idx >= 0)).any(axis=1)
+    if kNN == 1:
+        queryDF.loc[:, "_" + str(kNN) + "NN_match_ctype"] = near_types[:, 0]
+    return queryDF, queryDF[col].mean()

@@ -603,3 +603,20 @@ def test_c_abi_error_codes(hip):
     assert L.same_dense_cost_f64_dev(H, None, None, 20, None, None, 10, 0, 5, 1.0, None, 10) == EINVAL
     assert L.same_dense_cost_f64_dev(H, z.ctypes.data, z.ctypes.data, 5000, z.ctypes.data, z.ctypes.data, 10, 0, 5, 1.0, z.ctypes.data, 10) == EINVAL  # T > SAME_MAX_TYPES
     assert L.same_ctx_create(99, ctypes.byref(big)) == EINVAL
+
+
+def test_check_alignment_golden(hip):
+    from same_amd import synth
+    from same_amd.eval_utils import check_alignment
+
+    g = load_golden("eval_tri")
+    q = synth.to_frame(synth.make_cells(700, 4, seed=31, side=100.0))
+    t = synth.to_frame(synth.make_cells(900, 4, seed=32, side=100.0))
+    for k in (1, 5):
+        df, score = check_alignment(q, t, "X", "Y", kNN=k)
+        assert np.array_equal(df[f"_{k}NN_match"].to_numpy().astype(np.uint8), g[f"align_match_{k}"])
+        assert score == float(g[f"align_score_{k}"][0])
+    assert df.shape[0] == 700 and np.array_equal(check_alignment(q, t, "X", "Y", kNN=1)[0]["_1NN_match_ctype"].to_numpy().astype(str),
+                                                 g["align_ctype_1"])
+    with pytest.raises(ValueError):
+        check_alignment(q.drop(columns=["cell_type"]), t, "X", "Y")

@@ -438,6 +438,15 @@ def eval_case():
         out[f'viol_{tag}'] = df['in_violating_triangle'].to_numpy().astype(np.uint8)
         out[f'stats_{tag}'] = np.array([stats[k] for k in keys], dtype=np.float64)
         print(f"[eval_tri/{tag}] {stats}")
+    # check_alignment (src/eval_utils.py:6-55) on tie-free coordinates
+    q = synth.to_frame(synth.make_cells(700, 4, seed=31, side=100.0))
+    t = synth.to_frame(synth.make_cells(900, 4, seed=32, side=100.0))
+    for k in (1, 5):
+        df, score = ref.eval_utils.check_alignment(q, t, 'X', 'Y', kNN=k)
+        out[f'align_match_{k}'] = df[f'_{k}NN_match'].to_numpy().astype(np.uint8)
+        out[f'align_score_{k}'] = np.array([score])
+        if k == 1:
+            out['align_ctype_1'] = df['_1NN_match_ctype'].to_numpy().astype(str)
     np.savez_compressed(os.path.join(OUT, 'eval_tri.npz'), **out)
 
 
