@@ -124,7 +124,7 @@ def main():
     didx, dcost, dcnt = ctx.alloc(rows * k * 4), ctx.alloc(rows * k * 8), ctx.alloc(rows * 4)
     gidx = gcost = None
     gather = None
-    if d.world > 1:
+    if d.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM"):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
         gather = RcclGather(ctx, d.world, d.rank, d.bcast_bytes)
         gidx, gcost = ctx.alloc(rows * k * 4 * d.world), ctx.alloc(rows * k * 8 * d.world)
     dcls, dperim, dmaxcos = ctx.alloc(Tr), ctx.alloc(Tr * 8), ctx.alloc(Tr * 8)
@@ -156,11 +156,13 @@ def main():
             ms = ctypes.c_float(0)
             chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
             dense_ms.append(ms.value)
+        if gather is not None:
+            gather.wait()   # the previous step's gather (still reading didx/dcost) overlapped the dense build above
         chk(L.same_knn_prune_dev(H, dax.ptr, drx.ptr, n_ref, 0, rows, radius, k, didx.ptr, None, dcnt.ptr), "knn")
         chk(L.same_padded_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, 0, rows, k, didx.ptr, 1.0, dcost.ptr), "padded")
-        if gather is not None:
-            gather.allgather_dev(didx, gidx, rows * k * 4)
-            gather.allgather_dev(dcost, gcost, rows * k * 8)
+        if gather is not None:  # on the communication stream: overlaps the sweeps below and the next step's dense build
+            gather.allgather_dev_async(didx, gidx, rows * k * 4)
+            gather.allgather_dev_async(dcost, gcost, rows * k * 8)
         chk(L.same_tri_classify_dev(H, dax.ptr, dtris.ptr, Tr, radius, en, thr, dtype_id.ptr, dcls.ptr, dperim.ptr, dmaxcos.ptr), "cls")
         chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
         chk(L.same_xyorder_sweep_dev(H, dax.ptr, rows, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")

@@ -249,6 +249,12 @@ int same_comm_unique_id(char out_id[SAME_UNIQUE_ID_BYTES]);
 int same_comm_init(same_ctx *ctx, int nranks, int rank, const char id[SAME_UNIQUE_ID_BYTES]);
 int same_comm_destroy(same_ctx *ctx);
 int same_allgather_dev(same_ctx *ctx, const void *dsend, void *drecv, size_t send_bytes);
+/* Overlapped form: the gather runs on a second stream of the context, ordered after all compute queued
+ * so far, and does not block later compute (e.g. the next row block's dense build).  same_comm_wait
+ * orders the compute stream after every gather issued so far; call it before overwriting the send
+ * buffers or reading the gathered ones.  same_ctx_sync waits for both streams. */
+int same_allgather_dev_async(same_ctx *ctx, const void *dsend, void *drecv, size_t send_bytes);
+int same_comm_wait(same_ctx *ctx);
 
 #ifdef __cplusplus
 }

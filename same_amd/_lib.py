@@ -73,6 +73,8 @@ _PROTOTYPES = {
     "same_comm_init": [c_vp, c_int, c_int, c_vp],
     "same_comm_destroy": [c_vp],
     "same_allgather_dev": [c_vp, c_vp, c_vp, c_sz],
+    "same_allgather_dev_async": [c_vp, c_vp, c_vp, c_sz],
+    "same_comm_wait": [c_vp],
 }
 EXPORTS = tuple(_PROTOTYPES)
 

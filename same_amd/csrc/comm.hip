@@ -45,6 +45,7 @@ int same_comm_destroy(same_ctx *ctx) {
     if (ctx->comm) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->comm_stream);
         ncclCommDestroy(ctx->comm);
         ctx->comm = nullptr;
         ctx->nranks = 1;
@@ -58,6 +59,29 @@ int same_allgather_dev(same_ctx *ctx, const void *dsend, void *drecv, size_t sen
     SAME_TRY(same_use(ctx));
     if (send_bytes == 0) return SAME_OK;
     NCCL_TRY(ctx, ncclAllGather(dsend, drecv, send_bytes, ncclInt8, ctx->comm, ctx->stream));
+    return SAME_OK;
+}
+
+// Overlapped form.  The gather is enqueued on the context's communication stream behind everything
+// queued so far on the compute stream (so the send buffers are complete), and returns at once: compute
+// queued afterwards (the next dense build) runs concurrently with it.  Before anything overwrites the
+// send buffers or reads the gathered ones, call same_comm_wait: it makes the compute stream wait for
+// every gather issued so far (a stream-side wait, the host does not block).
+int same_allgather_dev_async(same_ctx *ctx, const void *dsend, void *drecv, size_t send_bytes) {
+    REQUIRE(ctx, ctx && ctx->comm && (send_bytes == 0 || (dsend && drecv)));
+    SAME_TRY(same_use(ctx));
+    if (send_bytes == 0) return SAME_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_ready, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
+    NCCL_TRY(ctx, ncclAllGather(dsend, drecv, send_bytes, ncclInt8, ctx->comm, ctx->comm_stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_gathered, ctx->comm_stream));
+    return SAME_OK;
+}
+
+int same_comm_wait(same_ctx *ctx) {
+    REQUIRE(ctx, ctx != nullptr);
+    SAME_TRY(same_use(ctx));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gathered, 0));
     return SAME_OK;
 }
 

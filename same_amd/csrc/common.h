@@ -28,7 +28,9 @@ enum Slot {
 struct same_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;   // all-gather runs here so it can overlap compute on `stream`
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;  // producer-done / gather-done hand-offs between the two streams
     void *slot[SL_COUNT] = {};
     size_t slot_bytes[SL_COUNT] = {};
     void *pinned = nullptr;  // small pinned staging block for scalar results

@@ -25,6 +25,9 @@ int same_ctx_create(int device, same_ctx **out) {
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gathered, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) { ctx->pinned_bytes = 1 << 16; e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault); }
@@ -41,11 +44,15 @@ void same_ctx_destroy(same_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->comm) same_comm_destroy(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     for (int s = 0; s < SL_COUNT; ++s)
         if (ctx->slot[s]) (void)hipFree(ctx->slot[s]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
+    if (ctx->ev_gathered) (void)hipEventDestroy(ctx->ev_gathered);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -54,6 +61,7 @@ int same_ctx_sync(same_ctx *ctx) {
     REQUIRE(ctx, ctx != nullptr);
     SAME_TRY(same_use(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
     return SAME_OK;
 }
 

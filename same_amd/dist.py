@@ -61,6 +61,15 @@ class RcclGather:
         c = self.ctx
         c.check(c.lib.same_allgather_dev(c.handle, send_buf.ptr, recv_buf.ptr, send_bytes), "same_allgather_dev")
 
+    def allgather_dev_async(self, send_buf, recv_buf, send_bytes):
+        """Gather on the context's communication stream, overlapping whatever compute is queued next."""
+        c = self.ctx
+        c.check(c.lib.same_allgather_dev_async(c.handle, send_buf.ptr, recv_buf.ptr, send_bytes), "same_allgather_dev_async")
+
+    def wait(self):
+        """Order the compute stream after every gather issued so far (stream-side; the host does not block)."""
+        self.ctx.check(self.ctx.lib.same_comm_wait(self.ctx.handle), "same_comm_wait")
+
     def close(self):
         self.ctx.lib.same_comm_destroy(self.ctx.handle)
 

@@ -441,6 +441,17 @@ def test_rccl_gather_single_rank_and_device_sharded_path(ops, oracle):
     try:
         compute = hip_block_compute(ctx, mov["types"], ref["types"], mov["xy"], ref["xy"], 25.0, 16, 1.0)
         idx, cost = sharded_knn_cost_device(ctx, compute, len(mov["xy"]), 16, g)
+        # overlapped form: gather on the communication stream while more compute is queued, then wait + reuse
+        n = len(mov["xy"])
+        didx, dcost, _ = compute(0, n, n)
+        gidx, gcost = ctx.alloc(n * 16 * 4), ctx.alloc(n * 16 * 8)
+        g.wait()                                            # nothing issued yet: a no-op
+        g.allgather_dev_async(didx, gidx, n * 16 * 4)
+        g.allgather_dev_async(dcost, gcost, n * 16 * 8)
+        g.wait()                                            # compute stream now ordered after both gathers
+        ctx.check(ctx.lib.same_dev_memset(ctx.handle, didx.ptr, 0, n * 16 * 4), "memset")   # safe to overwrite the send buffer
+        ctx.sync()
+        assert np.array_equal(gidx.download((n, 16), np.int32), idx) and np.array_equal(gcost.download((n, 16), np.float64), cost)
     finally:
         g.close()
     oidx, _, _ = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, 16)
