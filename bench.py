@@ -246,6 +246,7 @@ def main():
             "parity_spot_check": "dense rows, knn rows and orientation sweep equal the oracle bit-for-bit",
         }
         print(json.dumps(out))
+    d.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
     if gather is not None:
         gather.close()
     d.close()

@@ -194,9 +194,11 @@ def make_lazy_callback(GRB, sweep):
         max_cuts = getattr(model, "_lazy_max_cuts", None)
         if max_cuts is not None and model._cuts_added >= max_cuts:
             return
-        x_vals = model.cbGetSolution(model._x)
-        n = len(model._valid_pairs)
-        x_arr = np.fromiter((x_vals[i] for i in range(n)), dtype=np.float64, count=n)
+        # ask the solver for a flat list in pair order (a list query returns a list: one C call, no dict walk)
+        x_list = getattr(model, "_x_list", None)
+        if x_list is None:
+            x_list = model._x_list = [model._x[i] for i in range(len(model._valid_pairs))]
+        x_arr = np.asarray(model.cbGetSolution(x_list), dtype=np.float64)
         remaining = None if max_cuts is None else max(0, max_cuts - model._cuts_added)
         cuts = sweep.select_cuts(x_arr, getattr(model, "_lazy_allowed_flip_fraction", None),
                                  getattr(model, "_lazy_max_cuts_per_incumbent", None), remaining)
