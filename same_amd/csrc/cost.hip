@@ -336,18 +336,6 @@ int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F 
     // T large: one column per lane keeps the register file within budget
     constexpr int CPL = (T * CPLV * (int)(sizeof(F) / 4) <= 160) ? CPLV : 1;
     constexpr int DEPTH = CPL > 1 ? 2 : 1;
-#ifdef SAME_DENSE_PROBE
-    // tuning probes (dev builds only)
-    if constexpr (T == 8 || T == 20) {
-        static const int waves = env_int("SAME_DENSE_WAVES", 4);
-        static const int rpb = std::max(2, env_int("SAME_DENSE_RPB", 256) / 2 * 2);
-        static const int mapm = env_int("SAME_DENSE_MAP", 2);
-        if (waves == 8) return launch_one<F, T, CPL, true, 2, true, 8>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
-        if (waves == 16) return launch_one<F, T, CPL, true, 2, true, 16>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
-        if (waves == 2) return launch_one<F, T, CPL, true, 2, true, 2>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
-        if (waves == 1) return launch_one<F, T, CPL, true, 2, true, 1>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rpb, mapm);
-    }
-#endif
     return launch_dense_cfg<F, T, CPL, DEPTH, true>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
 }
 
