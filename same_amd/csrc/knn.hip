@@ -333,8 +333,9 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
     g.x0 = x0; g.y0 = y0; g.inv_cell = 1.0 / cell;
     g.gx = (int)std::min(1025.0, std::floor((x1 - x0) / cell) + 1.0);
     g.gy = (int)std::min(1025.0, std::floor((y1 - y0) / cell) + 1.0);
-    // inv_cell is rounded: make sure a coordinate at the far edge still maps inside [0, g)
     const int64_t cells = (int64_t)g.gx * g.gy;
+    if (cells <= 9)  // the radius spans the whole reference set: the 3 x 3 neighbourhood is everything, sweep it 8 rows per wave
+        return launch_knn_brute(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt);
     unsigned *dhist, *drank;
     double *dsxy;
     int32_t *dsidx;
@@ -365,14 +366,15 @@ int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int6
     return SAME_OK;
 }
 
-// Small problems stay on the single brute-force launch (the grid build costs a few launches and a sync);
-// SAME_KNN_MODE=brute|grid overrides for testing.
+// Small problems stay on the single brute-force launch (the grid build costs four small launches and a
+// 32-byte read-back); measured crossover is below 3 000 x 3 000 (0.047 vs 0.052 ms; 0.128 vs 3.9 ms at
+// 100k x 100k, tools/knn_threshold_probe.py).  SAME_KNN_MODE=brute|grid overrides for testing.
 int launch_knn(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re, double radius,
                int k, int32_t *didx, double *dd2, int32_t *dcnt) {
     const int64_t rows = re - rb;
     if (rows == 0) return SAME_OK;
     const char *mode = getenv("SAME_KNN_MODE");
-    bool grid = n_r >= 4096 && (double)n_r * (double)rows >= 3.0e7;
+    bool grid = n_r >= 2048 && (double)n_r * (double)rows >= 4.0e6 && std::isfinite(radius);
     if (mode && mode[0] == 'b') grid = false;
     if (mode && mode[0] == 'g') grid = n_r > 0;
     return grid ? launch_knn_grid(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt)
