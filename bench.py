@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dense100k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=10000)  # ~10 s of single-thread oracle work at dense100k
+    ap.add_argument("--cpu-sample-rows", type=int, default=20000)  # 10-20 s of single-thread oracle work at dense100k
     return ap.parse_args()
 
 
