@@ -10,7 +10,8 @@ dtype = np.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else np.float
 ctx = _lib.Context(0)
 L, H = ctx.lib, ctx.handle
 es = np.dtype(dtype).itemsize
-dD = ctx.alloc(n * n * es)
+ld = int(os.environ.get("PROBE_LD", n))
+dD = ctx.alloc(n * ld * es)
 for T in Ts:
     ref = synth.make_cells(n, max(T, 1), seed=0); mov = synth.make_cells(n, max(T, 1), seed=1, side=ref["side"])
     A = mov["types"][:, :T].astype(dtype); R = ref["types"][:, :T].astype(dtype)
@@ -20,8 +21,8 @@ for T in Ts:
     ms_all = []
     for it in range(6):
         ctx.check(L.same_timer_start(H), "t")
-        ctx.check(fn(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, dD.ptr, n), "dense")
+        ctx.check(fn(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, dD.ptr, ld), "dense")
         ms = ctypes.c_float(0); ctx.check(L.same_timer_stop(H, ctypes.byref(ms)), "t"); ms_all.append(ms.value)
     best = min(ms_all[1:]); mean = float(np.mean(ms_all[1:]))
     byts = es * n * n + es * (T + 2) * 2 * n
-    print(f"T={T:3d} {np.dtype(dtype).name} best {best:8.3f} ms mean {mean:8.3f} ms  {byts/best/1e6:8.1f} GB/s  valu/pair~{2*T+5}", flush=True)
+    print(f"ld={ld} T={T:3d} {np.dtype(dtype).name} best {best:8.3f} ms mean {mean:8.3f} ms  {byts/best/1e6:8.1f} GB/s  valu/pair~{2*T+5}", flush=True)
