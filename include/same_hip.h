@@ -65,6 +65,9 @@ int same_dev_free(same_ctx *ctx, void *dptr);
 int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* The host-buffer entry points stage through per-context scratch blocks that grow on demand and are
+ * reused across calls; this frees them all (and drops the state bound by same_sweep_bind). */
+int same_ctx_release_scratch(same_ctx *ctx);
 /* HIP events recorded on the context's stream (where the kernels run). */
 int same_timer_start(same_ctx *ctx);
 int same_timer_stop(same_ctx *ctx, float *out_ms); /* records, synchronises, returns elapsed ms */

@@ -39,6 +39,7 @@ _PROTOTYPES = {
     "same_h2d": [c_vp, c_vp, c_vp, c_sz],
     "same_d2h": [c_vp, c_vp, c_vp, c_sz],
     "same_dev_memset": [c_vp, c_vp, c_int, c_sz],
+    "same_ctx_release_scratch": [c_vp],
     "same_timer_start": [c_vp],
     "same_timer_stop": [c_vp, ctypes.POINTER(c_flt)],
     "same_pair_cost_f64": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_dbl, c_vp],
@@ -194,6 +195,11 @@ class Context:
 
     def sync(self):
         self.check(self.lib.same_ctx_sync(self.handle), "same_ctx_sync")
+
+    def release_scratch(self):
+        """Free the staging blocks the host-buffer entry points grew (they are otherwise kept for reuse)."""
+        self.check(self.lib.same_ctx_release_scratch(self.handle), "same_ctx_release_scratch")
+        self._bound_owner = None
 
     def timer_start(self):
         self.check(self.lib.same_timer_start(self.handle), "same_timer_start")

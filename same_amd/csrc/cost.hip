@@ -40,12 +40,12 @@ template <> __device__ __forceinline__ float absf<float>(float x) { return __bui
 //     merely *uses* one SGPR of the current half, which makes the compiler place its s_waitcnt
 //     there; the sched_barriers keep the next half's s_loads from moving above it; the loop body
 //     is a single basic block so nothing is sunk out of place.  Waits stay compiler-generated.
-// (2) Store decoupling.  A store holds its data VGPRs until the memory pipe has read them; if
-//     the next row's arithmetic wrote the same registers it would stall behind the (back-
-//     pressured) store.  DEPTH rows are therefore computed into DEPTH distinct result register
-//     sets per loop trip (`keep_alive` pins them), so a set is rewritten only DEPTH rows after its
-//     store was issued.  (Measured on MI355X: DEPTH 1/2/4/8 run within 1 % of each other at T=20 --
-//     the kernel is power-limited there, see DESIGN.md -- so DEPTH=2 is kept only because it is free.)
+// (2) Result-register depth.  A store holds its data VGPRs until the memory pipe has read them, so the
+//     kernel can compute DEPTH rows into DEPTH distinct result sets per loop trip (`keep_alive` pins them).
+//     Measured on MI355X: DEPTH 1/2/4/8 run within 1 % of each other at every T (the kernel is bound by
+//     the board power cap at T=20), so the shipped depth is 1; the parameter stays for
+//     hardware where the store path back-pressures the VALU.  The store address is a scalar row pointer
+//     plus a fixed per-lane byte offset, so no address VGPR is rewritten per row.
 // (3) Block -> tile map.  Blocks that share an XCD (blockIdx % 8) walk adjacent column tiles of
 //     the same row chunk, which gave the best store rate of the maps tried (6.8-7.0 TB/s store-only).
 __device__ __forceinline__ void touch(double v) { asm volatile("" ::"s"(v)); }
@@ -335,7 +335,7 @@ int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F 
     constexpr int CPLV = vec_of<F>::cpl;
     // T large: one column per lane keeps the register file within budget
     constexpr int CPL = (T * CPLV * (int)(sizeof(F) / 4) <= 160) ? CPLV : 1;
-    constexpr int DEPTH = CPL > 1 ? 2 : 1;
+    constexpr int DEPTH = 1;
     return launch_dense_cfg<F, T, CPL, DEPTH, true>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
 }
 

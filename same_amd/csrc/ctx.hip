@@ -128,6 +128,21 @@ int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes) {
     return SAME_OK;
 }
 
+int same_ctx_release_scratch(same_ctx *ctx) {
+    REQUIRE(ctx, ctx != nullptr);
+    SAME_TRY(same_use(ctx));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    for (int s = 0; s < SL_COUNT; ++s)
+        if (ctx->slot[s]) {
+            HIP_TRY(ctx, hipFree(ctx->slot[s]));
+            ctx->slot[s] = nullptr;
+            ctx->slot_bytes[s] = 0;
+        }
+    ctx->bound = false;  // the bound sweep state lived in scratch slots
+    return SAME_OK;
+}
+
 int same_timer_start(same_ctx *ctx) {
     REQUIRE(ctx, ctx != nullptr);
     SAME_TRY(same_use(ctx));

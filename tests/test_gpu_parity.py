@@ -631,3 +631,19 @@ def test_check_alignment_golden(hip):
                                                  g["align_ctype_1"])
     with pytest.raises(ValueError):
         check_alignment(q.drop(columns=["cell_type"]), t, "X", "Y")
+
+
+def test_release_scratch_and_rebind(ops, oracle):
+    from same_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(1)
+    xy, rxy = rng.uniform(0, 50, (300, 2)), rng.uniform(0, 50, (200, 2))
+    tris = rng.integers(0, 300, (500, 3)).astype(np.int32)
+    sign, _ = ops.tri_sign_weight(xy, None, tris)
+    match = rng.integers(-1, 200, 300).astype(np.int32)
+    sw = ops.BoundSweep(tris, sign, rxy, 300)
+    before = sw.sweep_match(match)
+    ctx.release_scratch()                      # drops every staging block, including the bound sweep state
+    after = sw.sweep_match(match)              # re-binds transparently
+    assert before[0] == after[0] and np.array_equal(before[1], after[1])
+    assert np.array_equal(ops.knn_prune(xy, rxy, 5.0, 4)[0], oracle.knn_prune(xy, rxy, 5.0, 4)[0])
