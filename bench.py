@@ -254,7 +254,10 @@ def main():
             cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port",
                    "sample": f"rows [0,{S}) of {rows} x {n_ref} refs: dense cost + knn prune + pair costs "
                              f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{rows} "
-                             f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}"}
+                             f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}",
+                   "reference_note": "the reference itself (pure Python/pandas) cannot travel to this box; measured in the survey "
+                                     "container (BASELINE.md section 3, 1 of 8 vCPU): 1.0-1.3e3 pairs/s pair-cost loop, 6.5e3 triangles/s "
+                                     "filter, 2.7e5 triangles/s lazy sweep, 1.6e7 dense-equivalent cell-pairs/s KNN at 10k x 10k"}
 
     if d.rank == 0:
         pairs_per_step = float(n_ref) * rows * d.world
