@@ -282,7 +282,11 @@ def main():
                        "parallelism": f"aligned-row blocks x{d.world}" + (", " + transport if d.world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "dense_cost_kernel<double,20,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3},
+                         "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3,
+                         "note": "frac is against the 8.0 TB/s HBM spec as BASELINE.json asks; at T=20 fp64 the kernel runs at the "
+                                 "1400 W package power cap (rocm-smi 1395 W, sclk 1.78 GHz: profiles/r01_power_T20.log) with the fp64 VALU "
+                                 "~90 % busy, not at an HBM limit (store-only rate of the same kernel: 6.9-7.0 TB/s at T<=8); "
+                                 "traffic = WRITE_SIZE + 2*FETCH_SIZE from separate rocprofv3 --pmc passes (profiles/traffic.json)"},
             "cpu_baseline": cpu,
             "parity_spot_check": "dense rows, knn rows and orientation sweep equal the oracle bit-for-bit",
         }
