@@ -143,3 +143,36 @@ def test_sliding_window_matching(gp, tmp_path):
     # cell-type sets must agree (src/same.py:446-457)
     with pytest.raises(ValueError, match="Cell type categories differ"):
         same_amd.sliding_window_matching(r_df, m_df.assign(cell_type="zzz"), optim_params=op)
+
+
+@pytest.mark.parametrize("case", ["synthetic_example", "cfg1_500", "cfg2_small"])
+def test_prepare_default_flags_and_priority_filter(case, oracle):
+    """The reference's default flags (same-type triangles ignored, re-add pass) and the cell-type-priority prune."""
+    import same_amd
+
+    g = load_golden(case)
+    a_df, r_df, cols = frames_from_golden(g)
+    mad = None if g["params"][2] < 0 else g["params"][2]
+    base = dict(radius=g["params"][0], knn=int(g["params"][1]), min_angle_deg=mad, dist_ct_coeff=g["params"][3])
+    prep = same_amd.prepare_same_inputs(r_df, a_df.drop(columns=["size"]), cols, optim_params=base, verbose=False)  # ignore_same_type_triangles=True
+    assert np.array_equal(np.array(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), g["tri_type"])
+    assert (prep.aligned_df["size"] == 1).all()                                  # default size column (src/same.py:934-939)
+    w, s = oracle.tri_sign_weight(prep.aligned_df[["X", "Y"]].to_numpy(), np.ones(prep.n_aligned), g["tri_type"])
+    assert np.array_equal(np.array(prep.source_signs), w.astype(np.float64)) and list(prep.triangle_weights) == [3] * len(g["tri_type"])
+    assert list(prep.triangle_info.keys()) == list(oracle.precompute_triangle_info(
+        prep.aligned_df, g["tri_type"], oracle.simplex_map(prep.n_aligned, g["tri_type"])).keys())
+    # ignore_knn_if_matched=True (src/same.py:974-976): pairs come from the priority filter, as a list of tuples
+    prep2 = same_amd.prepare_same_inputs(r_df, a_df, cols, optim_params=dict(ignore_knn_if_matched=True, **base), verbose=False)
+    assert isinstance(prep2.valid_pairs, list)
+    assert np.array_equal(np.asarray(prep2.valid_pairs, dtype=np.int64), g["pairs_priority"])
+    want = oracle.pair_costs(prep2.aligned_df, prep2.ref_df, g["pairs_priority"], cols, g["params"][3])
+    assert prep2.costs == want
+    assert prep2.valid_pairs_map[int(g["pairs_priority"][0, 0])][0] == (0, int(g["pairs_priority"][0, 1]))
+    # a caller-supplied triangulation as a DataFrame in index space (aligned_delaunay_vertex_col=None -> frame index ids)
+    from scipy.spatial import Delaunay
+    tri_df = pd.DataFrame(Delaunay(a_df[["X", "Y"]].to_numpy()).simplices)
+    prep3 = same_amd.prepare_same_inputs(r_df, a_df, cols, aligned_delaunay=tri_df, optim_params=base, verbose=False)
+    assert prep3.using_precomputed and len(prep3.aligned_delaunay) > 0
+    prep4 = same_amd.prepare_same_inputs(r_df, a_df, cols, aligned_delaunay=tri_df, ignore_precomputed_triangulation=True,
+                                         optim_params=base, verbose=False)
+    assert not prep4.using_precomputed and np.array_equal(np.asarray(prep4.aligned_delaunay), np.asarray(prep.aligned_delaunay))
