@@ -1,0 +1,65 @@
+/* abi_demo.c -- the C ABI used from plain C (no Python, no C++): prune + pair costs + orientation sweep on a
+ * tiny instance, printing the results.  Build (from the repo root):
+ *   gcc -std=c11 -Iinclude examples/abi_demo.c -o /tmp/abi_demo -Lsame_amd -lsame_hip -Wl,-rpath,$PWD/same_amd -lm
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "same_hip.h"
+
+#define CHECK(call)                                                                            \
+    do {                                                                                       \
+        int rc_ = (call);                                                                      \
+        if (rc_ != SAME_OK) {                                                                  \
+            fprintf(stderr, "%s -> %d (%s) %s\n", #call, rc_, same_strerror(rc_), ctx ? same_last_error(ctx) : ""); \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+int main(void) {
+    same_ctx *ctx = NULL;
+    int n_dev = 0;
+    same_device_count(&n_dev);
+    if (n_dev < 1) { fprintf(stderr, "no GPU: %s\n", same_strerror(SAME_ENODEV)); return 2; }
+    CHECK(same_ctx_create(0, &ctx));
+    enum { NM = 6, NR = 7, T = 3, K = 3 };
+    /* aligned cells on a line, reference cells jittered around them */
+    double axy[NM * 2], rxy[NR * 2], A[NM * T], R[NR * T];
+    for (int i = 0; i < NM; ++i) { axy[2 * i] = 10.0 * i; axy[2 * i + 1] = (i % 2) * 8.0; for (int t = 0; t < T; ++t) A[i * T + t] = (t == i % T) ? 90.0 : 5.0; }
+    for (int j = 0; j < NR; ++j) { rxy[2 * j] = 10.0 * j + 1.5; rxy[2 * j + 1] = (j % 2) * 8.0 - 1.0; for (int t = 0; t < T; ++t) R[j * T + t] = (t == j % T) ? 80.0 : 10.0; }
+    int32_t idx[NM * K], cnt[NM];
+    double d2[NM * K];
+    CHECK(same_knn_prune(ctx, axy, NM, rxy, NR, 0, NM, 12.0, K, idx, d2, cnt));
+    int32_t pairs[NM * K * 2];
+    int P = 0;
+    for (int i = 0; i < NM; ++i)
+        for (int q = 0; q < cnt[i]; ++q) { pairs[2 * P] = i; pairs[2 * P + 1] = idx[i * K + q]; ++P; }
+    double cost[NM * K];
+    CHECK(same_pair_cost_f64(ctx, A, R, NM, NR, T, axy, rxy, pairs, P, 1.0, cost));
+    for (int p = 0; p < P; ++p) {
+        const int i = pairs[2 * p], j = pairs[2 * p + 1];
+        printf("pair (%d,%d) dist=%.3f cost=%.4f\n", i, j, hypot(rxy[2 * j] - axy[2 * i], rxy[2 * j + 1] - axy[2 * i + 1]), cost[p]);
+    }
+    /* triangles over the aligned cells, source signs, and the sweep under "nearest reference" matching */
+    int32_t tris[4 * 3] = {0, 1, 2, 1, 2, 3, 2, 3, 4, 3, 4, 5};
+    int8_t sign[4];
+    CHECK(same_tri_sign_weight(ctx, axy, NULL, NM, tris, 4, sign, NULL));
+    int32_t match[NM];
+    for (int i = 0; i < NM; ++i) match[i] = cnt[i] ? idx[i * K] : -1;
+    match[2] = cnt[4] ? idx[4 * K] : -1; /* swap two matches to fold a triangle */
+    match[4] = cnt[2] ? idx[2 * K] : -1;
+    CHECK(same_sweep_bind(ctx, tris, 4, sign, rxy, NR, NM, NULL, 0));
+    int64_t checked = 0, nviol = 0;
+    int32_t viol[4];
+    CHECK(same_orient_sweep(ctx, match, &checked, viol, &nviol, NULL));
+    printf("checked %lld triangles, %lld flipped:", (long long)checked, (long long)nviol);
+    for (int q = 0; q < nviol; ++q) printf(" %d", viol[q]);
+    printf("\n");
+    /* error convention: a bad index is reported, not dereferenced */
+    int32_t bad[2] = {0, 99};
+    int rc = same_pair_cost_f64(ctx, A, R, NM, NR, T, axy, rxy, bad, 1, 1.0, cost);
+    printf("bad pair -> %d (%s)\n", rc, same_strerror(rc));
+    same_ctx_destroy(ctx);
+    return rc == SAME_ERANGE ? 0 : 3;
+}

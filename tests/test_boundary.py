@@ -177,3 +177,23 @@ def test_row_block_partition():
         assert blocks[0][0] == 0 and blocks[-1][1] == n
         assert all(b[1] == blocks[i + 1][0] for i, b in enumerate(blocks[:-1]))
         assert len({b[2] for b in blocks}) == 1 and all(b[1] - b[0] <= b[2] for b in blocks)
+
+
+def test_plain_c_program_links_against_the_abi(tmp_path):
+    """examples/abi_demo.c (C11, no C++/Python) compiles against include/same_hip.h and links libsame_hip.so;
+    without a GPU it exits 2 with the ENODEV message (it is run for real by the GPU suite)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "abi_demo"
+    lib_dir = os.path.join(ROOT, "same_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", f"-I{os.path.join(ROOT, 'include')}", os.path.join(ROOT, "examples", "abi_demo.c"),
+                           "-o", str(exe), f"-L{lib_dir}", "-lsame_hip", f"-Wl,-rpath,{lib_dir}", "-lm"])
+    from same_amd import _lib
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if _lib.device_count() == 0:
+        assert r.returncode == 2 and "no usable GPU" in r.stderr
+    else:
+        assert r.returncode == 0 and "flipped" in r.stdout

@@ -647,3 +647,17 @@ def test_release_scratch_and_rebind(ops, oracle):
     after = sw.sweep_match(match)              # re-binds transparently
     assert before[0] == after[0] and np.array_equal(before[1], after[1])
     assert np.array_equal(ops.knn_prune(xy, rxy, 5.0, 4)[0], oracle.knn_prune(xy, rxy, 5.0, 4)[0])
+
+
+def test_plain_c_abi_demo_runs(tmp_path):
+    """The C ABI from a plain C11 program: prune, pair costs, sign, bind, sweep, error code."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_demo"
+    lib_dir = os.path.join(root, "same_amd")
+    subprocess.check_call(["gcc", "-std=c11", f"-I{os.path.join(root, 'include')}", os.path.join(root, "examples", "abi_demo.c"), "-o", str(exe),
+                           f"-L{lib_dir}", "-lsame_hip", f"-Wl,-rpath,{lib_dir}", "-lm"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "checked 4 triangles" in r.stdout and "bad pair -> -34" in r.stdout
+    assert sum(line.startswith("pair (") for line in r.stdout.splitlines()) >= 6
