@@ -10,7 +10,7 @@ per-incumbent Python loop of _lazy_orientation_callback with the device sweep.
 gurobipy is imported lazily: the pre-MIP path and the sweeps work without it.
 """
 import os
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, Optional
 
 import numpy as np
 import pandas as pd

@@ -3,7 +3,7 @@
 The per-row minimum pair cost (:118-122) and the dense assignment matrix fill (:151-155) run in
 csrc/sweep.hip; the greedy sort + scan (:109-133) is resolved on the device by an equivalent
 parallel rule (csrc/match.hip); scipy's linear_sum_assignment stays on the host."""
-from typing import List, Optional, Sequence, Set, Tuple
+from typing import List, Optional, Set, Tuple
 
 import numpy as np
 
