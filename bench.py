@@ -194,6 +194,21 @@ def main():
 
     dense_ms = []
 
+    def timed(call, what, reps=3):
+        best = float("inf")
+        for _ in range(reps):
+            chk(L.same_timer_start(H), "timer")
+            chk(call(), what)
+            ms = ctypes.c_float(0)
+            chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
+            best = min(best, ms.value)
+        return best * 1e-3
+
+    # measured store ceilings on this box (SURVEY 8d asks for "% of measured" beside "% of 8 TB/s"): the same kernel with
+    # T=0 (identical store pattern, 5 VALU ops per output instead of 45) and a plain hipMemsetAsync of the same block
+    t_store_only = timed(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense T=0")
+    t_memset = timed(lambda: L.same_dev_memset(H, dD.ptr, 0, rows * ld * 8), "memset")
+
     def step(timed_dense=True):
         if timed_dense:
             chk(L.same_timer_start(H), "timer")
@@ -259,7 +274,18 @@ def main():
             orc.area_flip(mov["xy"], ref["xy"], tris, match)
             c2 = time.perf_counter()
             t_cpu = (c1 - c0) + (c2 - c1) * S / rows
+            # best-effort CPU line: the same dense sample split over host threads (ctypes releases the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            cuts = np.linspace(0, S, nthr + 1).astype(int)
+            m0 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(lambda be: orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(be[0]), int(be[1])),
+                            zip(cuts[:-1], cuts[1:])))
+            t_mt = time.perf_counter() - m0
             cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port",
+                   "dense_only_threaded": {"value": S * n_ref / t_mt, "unit": "cell-pairs/s", "cores": nthr,
+                                           "sample": f"dense cost of the same {S} rows split over {nthr} host threads"},
                    "sample": f"rows [0,{S}) of {rows} x {n_ref} refs: dense cost + knn prune + pair costs "
                              f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{rows} "
                              f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}",
@@ -291,6 +317,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "dense_cost_kernel<double,20,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3,
+                         "measured_ceilings": {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
+                                               "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
+                                               "frac_of_T0_store_rate": (dense_bytes / t_dense) / (8.0 * n_ref * rows / t_store_only)},
                          "note": "frac is against the 8.0 TB/s HBM spec as BASELINE.json asks; at T=20 fp64 the kernel runs at the "
                                  "1400 W package power cap (rocm-smi 1395 W, sclk 1.78 GHz: profiles/r01_power_T20.log) with the fp64 VALU "
                                  "~90 % busy, not at an HBM limit (store-only rate of the same kernel: 6.9-7.0 TB/s at T<=8); "

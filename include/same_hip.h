@@ -230,6 +230,18 @@ int same_collapse_candidates(same_ctx *ctx, const double *xy, int64_t n, const i
 int same_greedy_disjoint(same_ctx *ctx, const int32_t *items, const double *keys, int64_t M,
                          int64_t n_nodes, uint8_t *out_selected, int *out_rounds);
 
+/* ---- f4: unpack_metacell_matches(strategy='nearest') --------------------------------------
+ * Replaces the per-match cdist + np.tile + scipy linear_sum_assignment of
+ * src/metacell_utils.py:711-761 with one batched launch.  Problem p assigns the aligned members
+ * axy[a_off[p]..a_off[p+1]) to the ref members rxy[r_off[p]..r_off[p+1]) (CSR offsets, n_prob+1
+ * entries, first 0); when there are more aligned than ref members every ref member may be used
+ * ceil(n_a/n_r) times (tiled columns, :744-748).  out_ref[a_off[p]+i] = index within problem p's
+ * ref members given to aligned member i; ties resolve as scipy's solver resolves them.
+ * SAME_ERANGE if a problem has non-finite coordinates (scipy raises ValueError there);
+ * SAME_EINVAL if a problem has aligned members but no ref member. */
+int same_batched_assign(same_ctx *ctx, int64_t n_prob, const int64_t *a_off, const int64_t *r_off,
+                        const double *axy, const double *rxy, int32_t *out_ref);
+
 /* ---- a14: eager reference-orientation signs -------------------------------------------
  * Replaces calc_ref_area over all candidate combinations (src/helpers.py:425-441,455-510):
  * out[((t*k+x)*k+y)*k+z] = sign(round(cross, 3)) for cand[tris[t][0]][x], ..., 2 if any is -1. */

@@ -59,6 +59,7 @@ def lib():
         L.orc_window_mask.argtypes = [_f64, _I64, _DBL, _DBL, _DBL, _DBL, _u8]
         _u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
         L.orc_tri_flip_stats.argtypes = [_f64, _f64, _u8, _VP, _i32, _I64, _I64, _u8, _u32, _u32]
+        L.orc_batched_assign.argtypes = [_I64, _i64, _i64, _f64, _f64, _i32]
         _LIB = L
     return _LIB
 
@@ -684,3 +685,34 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
     fc = mdf[[x_col, y_col]].values
     final = _mc_filter(fc, Delaunay(fc).simplices, r_max, min_angle_deg) if len(fc) >= 4 else np.array([]).reshape(0, 3)
     return mdf, final, original_delaunay
+
+
+def batched_assign(a_off, r_off, axy, rxy):
+    """f4 (src/metacell_utils.py:711-761): one small assignment per metacell match; CSR member lists.
+    -> int32 local ref-member index per aligned member."""
+    a_off, r_off = _c(a_off, np.int64), _c(r_off, np.int64)
+    axy, rxy = _c(np.asarray(axy, np.float64).reshape(-1, 2), np.float64), _c(np.asarray(rxy, np.float64).reshape(-1, 2), np.float64)
+    out = np.full(int(a_off[-1]), -1, np.int32)
+    rc = lib().orc_batched_assign(len(a_off) - 1, a_off, r_off, axy.reshape(-1), rxy.reshape(-1), out)
+    if rc:
+        raise RuntimeError(f"orc_batched_assign failed ({rc})")
+    return out
+
+
+def batched_assign_scipy(a_off, r_off, axy, rxy):
+    """The literal reference form of the same thing (cdist + np.tile + linear_sum_assignment per match)."""
+    from scipy.optimize import linear_sum_assignment
+    from scipy.spatial.distance import cdist
+
+    axy, rxy = np.asarray(axy, np.float64).reshape(-1, 2), np.asarray(rxy, np.float64).reshape(-1, 2)
+    out = np.full(int(a_off[-1]), -1, np.int32)
+    for p in range(len(a_off) - 1):
+        a, r = axy[a_off[p]:a_off[p + 1]], rxy[r_off[p]:r_off[p + 1]]
+        if len(a) == 0:
+            continue
+        d = cdist(a, r)
+        if len(a) > len(r):
+            d = np.tile(d, (1, int(np.ceil(len(a) / len(r)))))
+        rows, cols = linear_sum_assignment(d)
+        out[a_off[p] + rows] = cols % len(r)
+    return out

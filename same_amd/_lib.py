@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "same_tri_flip_stats": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
     "same_collapse_candidates": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_dbl, c_int, c_dbl, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp],
     "same_greedy_disjoint": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, ctypes.POINTER(c_int)],
+    "same_batched_assign": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "same_comm_unique_id": [c_vp],
@@ -78,6 +79,9 @@ _PROTOTYPES = {
     "same_comm_wait": [c_vp],
 }
 EXPORTS = tuple(_PROTOTYPES)
+
+
+SAME_EINVAL, SAME_ENOMEM, SAME_EIO, SAME_ENODEV, SAME_ERANGE = -22, -12, -5, -19, -34   # include/same_hip.h
 
 
 class SameHipError(RuntimeError):

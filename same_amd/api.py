@@ -15,7 +15,7 @@ from typing import Any, Dict, Optional
 import numpy as np
 import pandas as pd
 
-from . import sweeps
+from . import ops, sweeps
 from .cost import pair_costs
 from .init_helpers import apply_mip_start
 from .knn import find_knn_with_cell_type_priority, find_knn_within_radius
@@ -256,10 +256,6 @@ def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None
         valid_pairs, c, tris = prep.valid_pairs, prep.costs, prep.aligned_delaunay
         n_aligned, n_ref = prep.n_aligned, prep.n_ref
         lazy = op["lazy_constraints"]
-        if not lazy:
-            raise NotImplementedError("lazy_constraints=False builds O(n*k^3) Gurobi constraints "
-                                      "(src/helpers.py:444-573); that model builder is outside this package's scope. "
-                                      "same_amd.ops.eager_signs provides its orientation table.")
         cell_id_col = op["cell_id_col"]
 
         model = Model("optimal_matches", env=env)
@@ -270,18 +266,22 @@ def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None
         _add_basic_constraints(model, quicksum, valid_pairs, op["max_matches"], x, penalty_vars, no_match_vars, ref_df,
                                op["ref_metacell_match_multiplier"])
 
-        q_tri = model.addVars(len(tris), vtype=GRB.CONTINUOUS, lb=0, name="q_tri")
-        model.update()
-        model._x, model._q_tri, model._valid_pairs = x, q_tri, valid_pairs
-        model._aligned_delaunay, model._source_signs, model._ref_coords = tris, prep.source_signs, prep.ref_coords_xy
-        model._cuts_added = 0
-        model._lazy_max_cuts = gpar["lazy_max_cuts"]
-        model._lazy_allowed_flip_fraction = gpar["lazy_allowed_flip_fraction"]
-        model._lazy_max_cuts_per_incumbent = gpar["lazy_max_cuts_per_incumbent"]
-        model.Params.LazyConstraints = 1
-        model.Params.Method = gp.GRB.METHOD_PDHG
-        model.Params.PDHGGPU = 1
-        area_penalty_vars = [q_tri[i] for i in range(len(tris))]
+        if lazy:
+            q_tri = model.addVars(len(tris), vtype=GRB.CONTINUOUS, lb=0, name="q_tri")
+            model.update()
+            model._x, model._q_tri, model._valid_pairs = x, q_tri, valid_pairs
+            model._aligned_delaunay, model._source_signs, model._ref_coords = tris, prep.source_signs, prep.ref_coords_xy
+            model._cuts_added = 0
+            model._lazy_max_cuts = gpar["lazy_max_cuts"]
+            model._lazy_allowed_flip_fraction = gpar["lazy_allowed_flip_fraction"]
+            model._lazy_max_cuts_per_incumbent = gpar["lazy_max_cuts_per_incumbent"]
+            model.Params.LazyConstraints = 1
+            model.Params.Method = gp.GRB.METHOD_PDHG
+            model.Params.PDHGGPU = 1
+            area_penalty_vars = [q_tri[i] for i in range(len(tris))]
+        else:
+            print("Using EAGER constraint generation (O(n*k^3) memory)")
+            area_penalty_vars, _ = _add_spatial_constraints_eager(model, GRB, x, prep)
         model.update()
 
         sizes = aligned_df["size"].to_numpy()
@@ -312,9 +312,12 @@ def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None
         if gpar["heuristics"] is not None:
             model.Params.Heuristics = float(gpar["heuristics"])
 
-        sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.source_signs, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
-        model.optimize(make_lazy_callback(GRB, sweep))
-        print(f"Lazy cuts added: {model._cuts_added}")
+        if lazy:
+            sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.source_signs, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
+            model.optimize(make_lazy_callback(GRB, sweep))
+            print(f"Lazy cuts added: {model._cuts_added}")
+        else:
+            model.optimize()
         time_limit_reached = model.status == GRB.TIME_LIMIT
         solve_time = model.Runtime
 
@@ -359,6 +362,55 @@ def _add_basic_constraints(model, quicksum, valid_pairs, max_matches, x, penalty
     for i, idxs in by_aligned.items():
         model.addConstr(quicksum(x[q] for q in idxs) + no_match_vars[i] == 1, name=f"no_match_{i}")
     model.update()
+
+
+def _add_spatial_constraints_eager(model, GRB, x, prep):
+    """lazy_constraints=False: the variables and constraints of add_spatial_constraints_triangle_based
+    (src/helpers.py:444-573), in its order and with its names.  Per triangle one `area_penalty_tri{t}_{p1}_{p2}_{p3}`
+    and, for every combination (idx1, idx2, idx3) of its vertices' candidate pairs, `z_tri{t}_{idx1}_{idx2}_{idx3}` with
+    z <= x1, z <= x2, z <= x3, z >= x1 + x2 + x3 - 2 and (aligned sign * ref sign) * z >= -area_penalty.  Both signs are
+    sign(round(cross, 3)) (signed_area_terms :398-411, calc_ref_area :425-441); the Tr*k^3 reference signs come from one
+    `same_eager_signs` launch instead of the reference's process pool.  Building the Python constraint objects stays a
+    host loop -- that is the solver's API."""
+    pairs = np.asarray(prep.valid_pairs, dtype=np.int64).reshape(-1, 2)
+    tris = np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3)
+    n_aligned = prep.n_aligned
+    order = np.argsort(pairs[:, 0], kind="stable")          # valid_pairs_imap: pair indices per aligned row, in pair order
+    counts = np.bincount(pairs[:, 0], minlength=n_aligned)
+    k = max(int(counts.max()) if len(counts) else 0, 1)
+    starts = np.concatenate(([0], np.cumsum(counts)))[:-1]
+    slot = np.arange(len(pairs)) - np.repeat(starts, counts)
+    cand_ref = np.full((n_aligned, k), -1, np.int32)
+    cand_pair = np.full((n_aligned, k), -1, np.int64)
+    cand_ref[pairs[order, 0], slot] = pairs[order, 1]
+    cand_pair[pairs[order, 0], slot] = order
+    axy = prep.aligned_df[["X", "Y"]].to_numpy(dtype=np.float64)
+    rxy = prep.ref_df[["X", "Y"]].to_numpy(dtype=np.float64)
+    ref_sign = ops.eager_signs(rxy, tris, cand_ref)                                            # (Tr, k, k, k), 2 = no such combination
+    aligned_sign = ops.eager_signs(axy, tris, np.arange(n_aligned, dtype=np.int32)[:, None]).reshape(-1)
+
+    area_penalty_vars, z_penalty_vars, all_constraints = [], [], []
+    for t, (p1, p2, p3) in enumerate(tris.tolist()):
+        a_sign = int(aligned_sign[t])
+        apv = model.addVar(vtype=GRB.CONTINUOUS, lb=0, name=f"area_penalty_tri{t}_{p1}_{p2}_{p3}")
+        area_penalty_vars.append(apv)
+        for s1 in range(counts[p1]):
+            idx1 = int(cand_pair[p1, s1])
+            for s2 in range(counts[p2]):
+                idx2 = int(cand_pair[p2, s2])
+                for s3 in range(counts[p3]):
+                    idx3 = int(cand_pair[p3, s3])
+                    z = model.addVar(vtype=GRB.CONTINUOUS, lb=0, ub=1, name=f"z_tri{t}_{idx1}_{idx2}_{idx3}")
+                    z_penalty_vars.append(z)
+                    all_constraints.append(z <= x[idx1])
+                    all_constraints.append(z <= x[idx2])
+                    all_constraints.append(z <= x[idx3])
+                    all_constraints.append(z >= x[idx1] + x[idx2] + x[idx3] - 2)
+                    all_constraints.append(a_sign * int(ref_sign[t, s1, s2, s3]) * z >= -apv)
+    print(f"Adding {len(all_constraints)} constraints to model...")
+    model.addConstrs((constraint for constraint in all_constraints))
+    model.update()
+    return area_penalty_vars, z_penalty_vars
 
 
 def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_vars, model, cell_id_col,
@@ -407,8 +459,8 @@ def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_var
         "triangle_data": {"triangles": tris, "triangle_info": prep.triangle_info,
                           "aligned_simplex_map": prep.aligned_simplex_map, "areas_before": before, "areas_after": after,
                           "flipped_triangles": flipped, "matched_vertices": matched_vertices},
-        "lazy_constraints": True,
-        "lazy_cuts_added": model._cuts_added,
+        "lazy_constraints": bool(prep.optim_params["lazy_constraints"]),
+        "lazy_cuts_added": model._cuts_added if prep.optim_params["lazy_constraints"] else 0,
     }
     if outprefix:
         np.save(os.path.join(outprefix, "var_out.npy"), var_out, allow_pickle=True)

@@ -12,6 +12,8 @@
 // pair index to break exact cost ties the way the stable sort does.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ unsigned long long cost_key(double v) {  // monotone u64 key of a double
@@ -215,6 +217,85 @@ __global__ __launch_bounds__(256) void disjoint_reset_kernel(unsigned long long 
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
 
+// ---- the small assignments of unpack_metacell_matches(strategy='nearest') ------------
+// src/metacell_utils.py:711-761 solves, per metacell match, linear_sum_assignment on
+// cdist(aligned members, ref members) with the ref columns tiled ceil(n_a/n_r) times when there
+// are more aligned than ref members.  Problems are tiny (members <= max_metacell_size^iterations)
+// and independent, so one lane solves one problem start to finish with its work arrays in a
+// private slice of a scratch buffer; the algorithm is scipy's shortest-augmenting-path solver
+// (Crouse 2016) step for step -- same scan order of the remaining columns, same "prefer a free
+// column among equal minima" rule, same dual updates in the same fp64 operation order -- so
+// ties resolve exactly as in the reference.  rows <= cols always holds here.
+__global__ __launch_bounds__(256) void batched_assign_kernel(
+    int64_t n_prob, const int64_t *__restrict__ a_off, const int64_t *__restrict__ r_off, const double *__restrict__ axy,
+    const double *__restrict__ rxy, const int64_t *__restrict__ w_off, double *__restrict__ work, int32_t *__restrict__ out_ref,
+    unsigned *__restrict__ infeasible) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_prob) return;
+    const int64_t a0 = a_off[p], r0 = r_off[p];
+    const int na = (int)(a_off[p + 1] - a0), nref = (int)(r_off[p + 1] - r0);
+    if (na == 0) return;
+    const int nc = na <= nref ? nref : nref * ((na + nref - 1) / nref);
+    double *cost = work + w_off[p], *u = cost + (int64_t)na * nc, *v = u + na, *spc = v + nc;
+    int *path = reinterpret_cast<int *>(spc + nc), *row4col = path + nc, *remaining = row4col + nc, *col4row = remaining + nc;
+    uint8_t *SR = reinterpret_cast<uint8_t *>(col4row + na), *SC = SR + na;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    for (int i = 0; i < na; ++i) {
+        const double ax = axy[2 * (a0 + i)], ay = axy[2 * (a0 + i) + 1];
+        for (int j = 0; j < nref; ++j) {
+            const double dx = ax - rxy[2 * (r0 + j)], dy = ay - rxy[2 * (r0 + j) + 1];
+            const double d = sqrt(dx * dx + dy * dy);  // cdist euclidean: s = dx*dx; s += dy*dy; sqrt (contraction is off)
+            for (int jj = j; jj < nc; jj += nref) cost[(int64_t)i * nc + jj] = d;
+        }
+        u[i] = 0.0;
+        col4row[i] = -1;
+    }
+    for (int j = 0; j < nc; ++j) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
+    for (int cur = 0; cur < na; ++cur) {
+        double min_val = 0.0;
+        int num_remaining = nc, sink = -1, i = cur;
+        for (int it = 0; it < nc; ++it) { remaining[it] = nc - it - 1; SC[it] = 0; spc[it] = inf; }
+        for (int r = 0; r < na; ++r) SR[r] = 0;
+        while (sink == -1) {
+            int index = -1;
+            double lowest = inf;
+            SR[i] = 1;
+            const double ui = u[i];
+            for (int it = 0; it < num_remaining; ++it) {
+                const int j = remaining[it];
+                const double r = min_val + cost[(int64_t)i * nc + j] - ui - v[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = s = r; }
+                if (s < lowest || (s == lowest && row4col[j] == -1)) { lowest = s; index = it; }
+            }
+            min_val = lowest;
+            if (index < 0 || min_val == inf) {  // NaN / inf coordinates: no finite augmenting path (scipy raises)
+                atomicOr(infeasible, 1u);
+                return;
+            }
+            const int j = remaining[index];
+            if (row4col[j] == -1) sink = j; else i = row4col[j];
+            SC[j] = 1;
+            remaining[index] = remaining[--num_remaining];
+        }
+        u[cur] += min_val;
+        for (int r = 0; r < na; ++r)
+            if (SR[r] && r != cur) u[r] += min_val - spc[col4row[r]];
+        for (int j = 0; j < nc; ++j)
+            if (SC[j]) v[j] -= min_val - spc[j];
+        int j = sink;
+        for (;;) {
+            const int r = path[j];
+            row4col[j] = r;
+            const int t = col4row[r];
+            col4row[r] = j;
+            j = t;
+            if (r == cur) break;
+        }
+    }
+    for (int i = 0; i < na; ++i) out_ref[a0 + i] = col4row[i] % nref;
+}
+
 }  // namespace
 
 extern "C" {
@@ -379,6 +460,58 @@ int same_greedy_disjoint(same_ctx *ctx, const int32_t *items, const double *keys
     }
     if (out_rounds) *out_rounds = rounds;
     SAME_TRY(same_down(ctx, out_selected, dsel, (size_t)M));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+int same_batched_assign(same_ctx *ctx, int64_t n_prob, const int64_t *a_off, const int64_t *r_off, const double *axy,
+                        const double *rxy, int32_t *out_ref) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, n_prob >= 0);
+    if (n_prob == 0) return SAME_OK;
+    REQUIRE(ctx, a_off && r_off);
+    REQUIRE(ctx, a_off[0] == 0 && r_off[0] == 0);
+    // private work slice per problem, in 8-byte words: cost[na*nc] u[na] v[nc] spc[nc] | path,row4col,remaining[nc] col4row[na] | SR[na] SC[nc]
+    std::vector<int64_t> w_off((size_t)n_prob + 1);
+    int64_t words = 0;
+    for (int64_t p = 0; p < n_prob; ++p) {
+        const int64_t na = a_off[p + 1] - a_off[p], nref = r_off[p + 1] - r_off[p];
+        REQUIRE(ctx, na >= 0 && nref >= 0 && na < (1 << 20) && nref < (1 << 20));
+        REQUIRE(ctx, na == 0 || nref > 0);
+        w_off[(size_t)p] = words;
+        if (na == 0) continue;
+        const int64_t nc = na <= nref ? nref : nref * ((na + nref - 1) / nref);
+        words += na * nc + na + 2 * nc + (3 * nc + na + 1) / 2 + (na + nc + 7) / 8;
+    }
+    w_off[(size_t)n_prob] = words;
+    const int64_t n_a = a_off[n_prob], n_r = r_off[n_prob];
+    if (n_a == 0) return SAME_OK;
+    REQUIRE(ctx, axy && rxy && out_ref);
+    SAME_TRY(same_use(ctx));
+    int64_t *da_off, *dr_off, *dw_off;
+    double *daxy, *drxy, *dwork;
+    int32_t *dout;
+    unsigned *dflag;
+    SAME_TRY(up_as(ctx, SL_A, a_off, (size_t)n_prob + 1, &da_off));
+    SAME_TRY(up_as(ctx, SL_R, r_off, (size_t)n_prob + 1, &dr_off));
+    SAME_TRY(up_as(ctx, SL_X, w_off.data(), (size_t)n_prob + 1, &dw_off));
+    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n_a * 2, &daxy));
+    SAME_TRY(up_as(ctx, SL_RXY, rxy, (size_t)n_r * 2, &drxy));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)std::max<int64_t>(words, 1), &dwork));
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)n_a, &dout));
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dflag));
+    HIP_TRY(ctx, hipMemsetAsync(dflag, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(batched_assign_kernel, dim3(grid_for(n_prob)), dim3(256), 0, ctx->stream, n_prob, da_off, dr_off, daxy, drxy,
+                       dw_off, dwork, dout, dflag);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned *h = static_cast<unsigned *>(ctx->pinned);
+    SAME_TRY(same_down(ctx, h, dflag, sizeof(unsigned)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[0]) {
+        ctx->err = "same_batched_assign: a cost matrix is infeasible (non-finite coordinates)";
+        return SAME_ERANGE;
+    }
+    SAME_TRY(same_down(ctx, out_ref, dout, (size_t)n_a * sizeof(int32_t)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;
 }

@@ -18,7 +18,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import pandas as pd
 
-from . import ops
+from . import _lib, ops
 from .triangles import cos_threshold
 
 
@@ -228,15 +228,25 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
     return metacell_df, final_delaunay
 
 
+def _member_xy(frame, labels, x_col, y_col):
+    """frame.loc[labels, [x, y]].values for one flat label list (KeyError on a missing label, as .loc raises)."""
+    if not frame.index.is_unique:
+        raise ValueError("unpack_metacell_matches: the cell id index has duplicate labels")
+    pos = frame.index.get_indexer(labels)
+    if (pos < 0).any():
+        missing = [lab for lab, q in zip(labels, pos) if q < 0][:5]
+        raise KeyError(f"{missing} not in index")
+    return np.ascontiguousarray(frame[[x_col, y_col]].to_numpy(dtype=np.float64)[pos])
+
+
 def unpack_metacell_matches(metacell_matches, metacell_aligned_df, metacell_ref_df, aligned_df=None, ref_df=None,
                             strategy="distribute", aligned_original_idx_col: Optional[str] = None,
                             ref_original_idx_col: Optional[str] = None, x_col: str = "X", y_col: str = "Y"):
     """Metacell-level matches -> individual cell matches, signature and results of src/metacell_utils.py:564-766
-    (SURVEY 8(f4)).  This is host bookkeeping on small lists; the per-match assignments stay
-    scipy.optimize.linear_sum_assignment on scipy cdist distances, so ties resolve exactly as in the reference."""
-    from scipy.optimize import linear_sum_assignment
-    from scipy.spatial.distance import cdist
-
+    (SURVEY 8(f4)).  The list bookkeeping stays on the host; the per-match optimal assignments of
+    strategy='nearest' (cdist + np.tile + linear_sum_assignment per match, :711-761) run as ONE batched launch
+    (`same_batched_assign`, csrc/match.hip), which follows scipy's solver step for step so ties resolve as in the
+    reference.  Non-finite member coordinates raise ValueError (scipy: "cost matrix is infeasible")."""
     aligned_lookup = ref_lookup = None
     if aligned_df is not None and aligned_original_idx_col is not None:
         if aligned_original_idx_col not in aligned_df.columns:
@@ -256,29 +266,40 @@ def unpack_metacell_matches(metacell_matches, metacell_aligned_df, metacell_ref_
 
     a_members = metacell_aligned_df["members"].tolist()
     r_members = metacell_ref_df["members"].tolist() if ref_has_metacells else None
+    a_ids = metacell_matches["Aligned_metacell_id"].tolist()
+    r_ids = metacell_matches["Ref_metacell_id"].tolist()
     out_a, out_r = [], []
-    for a_idx, r_idx in zip(metacell_matches["Aligned_metacell_id"].tolist(), metacell_matches["Ref_metacell_id"].tolist()):
-        am = a_members[a_idx]
-        if not ref_has_metacells:
-            if strategy in ("distribute", "nearest"):       # every member -> the same reference cell (:652-669)
+    if ref_has_metacells and strategy == "nearest" and a_ids:      # optimal assignment on pairwise distances (:687-742)
+        a_lists, r_lists = [a_members[i] for i in a_ids], [r_members[j] for j in r_ids]
+        a_off = np.concatenate(([0], np.cumsum([len(m) for m in a_lists]))).astype(np.int64)
+        r_off = np.concatenate(([0], np.cumsum([len(m) for m in r_lists]))).astype(np.int64)
+        out_a = [m for ms in a_lists for m in ms]
+        r_flat = [m for ms in r_lists for m in ms]
+        if out_a:
+            axy = _member_xy(aligned_lookup if aligned_lookup is not None else aligned_df, out_a, x_col, y_col)
+            rxy = _member_xy(ref_lookup if ref_lookup is not None else ref_df, r_flat, x_col, y_col)
+            try:
+                local = ops.batched_assign(a_off, r_off, axy, rxy)
+            except _lib.SameHipError as e:
+                if e.code == _lib.SAME_ERANGE:
+                    raise ValueError("cost matrix is infeasible") from e
+                raise
+            pick = np.repeat(r_off[:-1], np.diff(a_off)) + local
+            out_r = [r_flat[q] for q in pick]
+    else:
+        for a_idx, r_idx in zip(a_ids, r_ids):
+            am = a_members[a_idx]
+            if not ref_has_metacells:
+                if strategy in ("distribute", "nearest"):       # every member -> the same reference cell (:652-669)
+                    out_a.extend(am)
+                    out_r.extend([r_idx] * len(am))
+                continue
+            rm = r_members[r_idx]
+            if strategy == "distribute":                         # deal the ref members round-robin (:675-685)
                 out_a.extend(am)
-                out_r.extend([r_idx] * len(am))
-            continue
-        rm = r_members[r_idx]
-        if strategy == "distribute":                         # deal the ref members round-robin (:675-685)
-            out_a.extend(am)
-            out_r.extend(rm[i % len(rm)] for i in range(len(am)))
-        elif strategy == "nearest":                          # optimal assignment on pairwise distances (:687-742)
-            ac = (aligned_lookup if aligned_lookup is not None else aligned_df).loc[am, [x_col, y_col]].values
-            rc = (ref_lookup if ref_lookup is not None else ref_df).loc[rm, [x_col, y_col]].values
-            dist = cdist(ac, rc)
-            if len(am) > len(rm):                            # more aligned than ref: every ref may be used ceil(n_a/n_r) times
-                dist = np.tile(dist, (1, int(np.ceil(len(am) / len(rm)))))
-            rows, cols = linear_sum_assignment(dist)
-            out_a.extend(am[i] for i in rows)
-            out_r.extend(rm[j % len(rm)] for j in cols)
-        else:
-            raise ValueError(f"Unknown strategy: {strategy}")
+                out_r.extend(rm[i % len(rm)] for i in range(len(am)))
+            else:
+                raise ValueError(f"Unknown strategy: {strategy}")
     if not out_a:
         return pd.DataFrame([])
     return pd.DataFrame({"Aligned_cell_id": out_a, "Ref_cell_id": out_r})

@@ -294,3 +294,19 @@ def greedy_disjoint(items, keys, n_nodes, ctx=None):
         ctx.check(ctx.lib.same_greedy_disjoint(ctx.handle, items.ctypes.data, keys.ctypes.data, len(items), int(n_nodes),
                                                sel.ctypes.data, ctypes.byref(rounds)), "same_greedy_disjoint")
     return sel.astype(bool), rounds.value
+
+
+def batched_assign(a_off, r_off, axy, rxy, ctx=None):
+    """One small optimal assignment per problem (CSR member lists) -> int32 local ref index per aligned member."""
+    ctx = _ctx(ctx)
+    a_off, r_off = as_c(a_off, np.int64), as_c(r_off, np.int64)
+    if len(a_off) != len(r_off) or len(a_off) < 1:
+        raise ValueError("a_off and r_off must both hold n_prob + 1 offsets")
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    if len(axy) != a_off[-1] or len(rxy) != r_off[-1]:
+        raise ValueError("coordinate arrays do not match the last offsets")
+    out = np.full(len(axy), -1, I32)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_batched_assign(ctx.handle, len(a_off) - 1, a_off.ctypes.data, r_off.ctypes.data, axy.ctypes.data,
+                                              rxy.ctypes.data, out.ctypes.data), "same_batched_assign")
+    return out

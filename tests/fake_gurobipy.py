@@ -36,6 +36,8 @@ class LinExpr:
     def __eq__(self, o): return TempConstr(self - o, "==")
     __hash__ = object.__hash__
 
+    def __neg__(self): return self * -1.0
+
 
 class Var:
     def __init__(self, name, vtype, lb, ub):
@@ -44,6 +46,7 @@ class Var:
         self.x = 0.0
 
     def _e(self): return LinExpr({self: 1.0})
+    def __neg__(self): return self._e() * -1.0
     def __add__(self, o): return self._e() + o
     __radd__ = __add__
     def __sub__(self, o): return self._e() - o
@@ -104,6 +107,15 @@ class Model:
         self.vars.extend(d.values())
         return d
 
+    def addVar(self, vtype=None, lb=0, ub=None, name="v"):
+        v = Var(name, vtype, lb, ub)
+        self.vars.append(v)
+        return v
+
+    def addConstrs(self, gen, name=None):
+        for c in gen:
+            self.addConstr(c, name=name)
+
     def addConstr(self, c, name=None):
         assert isinstance(c, TempConstr)
         self.constrs.append((name, c))
@@ -116,7 +128,8 @@ class Model:
         with open(path, "w") as f:
             f.write(f"\\ mock model: {len(self.vars)} vars, {len(self.constrs)} constraints\n")
             for name, _ in self.constrs:
-                f.write(f" {name}\n")
+                if name is not None:
+                    f.write(f" {name}\n")
 
     # callback API
     def cbGetSolution(self, vars_):
@@ -147,3 +160,13 @@ def install():
         setattr(m, k, v)
     sys.modules["gurobipy"] = m
     return m
+
+
+def canonical_constraints(constrs):
+    """[(name, TempConstr)] -> list of (sense, const, ((var name, coef), ...)) with zero coefficients dropped: the
+    comparable form of a model section (used to compare an assembled model with a recorded one)."""
+    out = []
+    for _, c in constrs:
+        terms = tuple(sorted((v.VarName, float(k)) for v, k in c.expr.terms.items() if k != 0.0))
+        out.append((c.sense, float(c.expr.const), terms))
+    return out

@@ -51,8 +51,8 @@ def _worker(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("case", ["cfg1_500", "cfg2_small"])
+@pytest.mark.parametrize("world,case", [(2, "cfg1_500"), (3, "cfg1_500"), (2, "cfg2_small"), (3, "cfg2_small"),
+                                        (8, "cfg1_500")])  # identical for G in {1 (fixtures), 2, 8}
 def test_sharded_knn_cost_gloo(tmp_path, world, case):
     import torch.multiprocessing as mp
     from conftest import load_golden

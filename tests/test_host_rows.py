@@ -1,5 +1,7 @@
 """SURVEY 8(f3, f4): host-side rows (window merge, metacell unpacking) against reference-generated fixtures.
-CPU only: these functions touch no kernel (the metacell objects they consume are rebuilt with the oracle)."""
+CPU part: the list bookkeeping touches no kernel (the metacell objects it consumes are rebuilt with the oracle); the
+batched assignments of strategy='nearest' are checked here for the ORACLE (against scipy, which is what the reference
+calls, and against the reference-generated fixture) and on the GPU for the product (test_unpack_nearest_on_device)."""
 import numpy as np
 import pandas as pd
 import pytest
@@ -25,9 +27,6 @@ def test_unpack_metacell_matches(oracle):
     mm = pd.DataFrame(g["mm"], columns=["Aligned_metacell_id", "Ref_metacell_id"])
     res = unpack_metacell_matches(mm, ma, mr, strategy="distribute")
     assert np.array_equal(res[["Aligned_cell_id", "Ref_cell_id"]].to_numpy(dtype=np.int64), g["unpack_dist_both"])
-    res = unpack_metacell_matches(mm, ma, mr, strategy="nearest", aligned_df=a_df, ref_df=r_df,
-                                  aligned_original_idx_col="Cell_Num_Old", ref_original_idx_col="Cell_Num_Old")
-    assert np.array_equal(res[["Aligned_cell_id", "Ref_cell_id"]].to_numpy(dtype=np.int64), g["unpack_near_both"])
     res = unpack_metacell_matches(mm.assign(Ref_metacell_id=mm["Ref_metacell_id"] % len(r_df)), ma, r_df)
     assert np.array_equal(res[["Aligned_cell_id", "Ref_cell_id"]].to_numpy(dtype=np.int64), g["unpack_simple"])
     with pytest.raises(ValueError, match="requires aligned_df"):
@@ -37,6 +36,98 @@ def test_unpack_metacell_matches(oracle):
     with pytest.raises(ValueError, match="Unknown strategy"):
         unpack_metacell_matches(mm, ma, mr, strategy="bogus")
     assert len(unpack_metacell_matches(mm.iloc[:0], ma, mr)) == 0
+
+
+def _unpack_csr(mm, ma, mr, a_df, r_df):
+    a_lists = [ma["members"].iloc[i] for i in mm["Aligned_metacell_id"]]
+    r_lists = [mr["members"].iloc[j] for j in mm["Ref_metacell_id"]]
+    a_off = np.concatenate(([0], np.cumsum([len(m) for m in a_lists])))
+    r_off = np.concatenate(([0], np.cumsum([len(m) for m in r_lists])))
+    a_flat, r_flat = np.concatenate(a_lists), np.concatenate(r_lists)
+    axy = a_df.set_index("Cell_Num_Old").loc[a_flat, ["X", "Y"]].to_numpy()
+    rxy = r_df.set_index("Cell_Num_Old").loc[r_flat, ["X", "Y"]].to_numpy()
+    return a_off, r_off, a_flat, r_flat, axy, rxy
+
+
+def test_oracle_batched_assign_matches_reference_fixture(oracle):
+    g = load_golden("unpack_merge")
+    a_df, r_df, ma, mr = _metacells(oracle)
+    mm = pd.DataFrame(g["mm"], columns=["Aligned_metacell_id", "Ref_metacell_id"])
+    a_off, r_off, a_flat, r_flat, axy, rxy = _unpack_csr(mm, ma, mr, a_df, r_df)
+    assert (np.diff(a_off) > np.diff(r_off)).any() and (np.diff(a_off) < np.diff(r_off)).any()   # tiled and plain cases
+    local = oracle.batched_assign(a_off, r_off, axy, rxy)
+    got = np.column_stack((a_flat, r_flat[np.repeat(r_off[:-1], np.diff(a_off)) + local]))
+    assert np.array_equal(got, g["unpack_near_both"])
+
+
+@pytest.mark.parametrize("mode", ["uniform", "lattice", "near_ties"])
+def test_oracle_batched_assign_equals_scipy(oracle, mode):
+    """The solver is scipy's in the reference: pin the restatement on random and heavily tied problems."""
+    rng = np.random.default_rng({"uniform": 1, "lattice": 2, "near_ties": 3}[mode])
+    for trial in range(8):
+        n = 1500
+        na, nr = rng.integers(0 if trial == 0 else 1, 14 + 20 * (trial % 2), n), rng.integers(1, 14 + 20 * (trial // 4), n)
+        a_off, r_off = np.concatenate(([0], np.cumsum(na))), np.concatenate(([0], np.cumsum(nr)))
+        if mode == "uniform":
+            axy, rxy = rng.uniform(0, 100, (a_off[-1], 2)), rng.uniform(0, 100, (r_off[-1], 2))
+        elif mode == "lattice":
+            axy, rxy = rng.integers(0, 4, (a_off[-1], 2)).astype(float), rng.integers(0, 4, (r_off[-1], 2)).astype(float)
+        else:
+            axy = rng.integers(0, 3, (a_off[-1], 2)) * 0.1 + rng.choice([0, 1e-9], (a_off[-1], 2))
+            rxy = rng.integers(0, 3, (r_off[-1], 2)) * 0.1
+        assert np.array_equal(oracle.batched_assign(a_off, r_off, axy, rxy), oracle.batched_assign_scipy(a_off, r_off, axy, rxy)), (mode, trial)
+
+
+@pytest.mark.gpu
+def test_unpack_nearest_on_device(oracle):
+    from same_amd.metacell_utils import unpack_metacell_matches
+
+    g = load_golden("unpack_merge")
+    a_df, r_df, ma, mr = _metacells(oracle)
+    mm = pd.DataFrame(g["mm"], columns=["Aligned_metacell_id", "Ref_metacell_id"])
+    res = unpack_metacell_matches(mm, ma, mr, strategy="nearest", aligned_df=a_df, ref_df=r_df,
+                                  aligned_original_idx_col="Cell_Num_Old", ref_original_idx_col="Cell_Num_Old")
+    assert np.array_equal(res[["Aligned_cell_id", "Ref_cell_id"]].to_numpy(dtype=np.int64), g["unpack_near_both"])
+    # frames indexed by the cell id directly (no *_original_idx_col), and a missing member label
+    res2 = unpack_metacell_matches(mm, ma, mr, strategy="nearest", aligned_df=a_df.set_index("Cell_Num_Old", drop=False),
+                                   ref_df=r_df.set_index("Cell_Num_Old", drop=False))
+    assert res2.equals(res)
+    with pytest.raises(KeyError):
+        unpack_metacell_matches(mm, ma, mr, strategy="nearest", aligned_df=a_df.iloc[:10], ref_df=r_df,
+                                aligned_original_idx_col="Cell_Num_Old", ref_original_idx_col="Cell_Num_Old")
+    bad = r_df.copy()
+    bad["X"] = np.nan
+    with pytest.raises(ValueError, match="infeasible"):
+        unpack_metacell_matches(mm, ma, mr, strategy="nearest", aligned_df=a_df, ref_df=bad,
+                                aligned_original_idx_col="Cell_Num_Old", ref_original_idx_col="Cell_Num_Old")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["uniform", "lattice", "near_ties"])
+def test_batched_assign_kernel_vs_oracle(oracle, mode):
+    from same_amd import ops
+
+    rng = np.random.default_rng({"uniform": 11, "lattice": 12, "near_ties": 13}[mode])
+    for trial in range(6):
+        n = [1, 7, 300, 5000, 20000, 257][trial]
+        na, nr = rng.integers(0 if trial == 2 else 1, 12 + 30 * (trial % 2), n), rng.integers(1, 12 + 30 * (trial // 3), n)
+        a_off, r_off = np.concatenate(([0], np.cumsum(na))), np.concatenate(([0], np.cumsum(nr)))
+        if mode == "uniform":
+            axy, rxy = rng.uniform(0, 100, (a_off[-1], 2)), rng.uniform(0, 100, (r_off[-1], 2))
+        elif mode == "lattice":
+            axy, rxy = rng.integers(0, 4, (a_off[-1], 2)).astype(float), rng.integers(0, 4, (r_off[-1], 2)).astype(float)
+        else:
+            axy = rng.integers(0, 3, (a_off[-1], 2)) * 0.1 + rng.choice([0, 1e-9], (a_off[-1], 2))
+            rxy = rng.integers(0, 3, (r_off[-1], 2)) * 0.1
+        assert np.array_equal(ops.batched_assign(a_off, r_off, axy, rxy), oracle.batched_assign(a_off, r_off, axy, rxy)), (mode, trial)
+    # degenerate shapes and the error codes of the ABI
+    assert len(ops.batched_assign([0], [0], np.empty((0, 2)), np.empty((0, 2)))) == 0
+    assert len(ops.batched_assign([0, 0], [0, 3], np.empty((0, 2)), np.zeros((3, 2)))) == 0
+    from same_amd._lib import SameHipError
+    with pytest.raises(SameHipError):            # aligned members but no ref member
+        ops.batched_assign([0, 2], [0, 0], np.zeros((2, 2)), np.empty((0, 2)))
+    with pytest.raises(SameHipError):
+        ops.batched_assign([0, 1], [0, 1], np.full((1, 2), np.inf), np.zeros((1, 2)))
 
 
 def _merge_input():

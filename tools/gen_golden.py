@@ -525,8 +525,58 @@ def unpack_merge_case():
     print(f"[unpack/merge] {[ (k, v.shape) for k, v in out.items()]}")
 
 
+def eager_model_case():
+    """lazy_constraints=False: add_spatial_constraints_triangle_based (src/helpers.py:444-573) RUN AS-IS against a recording
+    stand-in for the solver API (tests/fake_gurobipy.py); the fixture holds the variables and constraints it emitted."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import fake_gurobipy as fg
+
+    radius, knn = 14.0, 3
+    cells = synth.make_cells(140, 3, seed=31)
+    r_df = synth.to_frame(cells)
+    a_df = synth.to_frame(synth.make_jittered(cells, seed=32))
+    new_a, new_r, pairs = quiet(ref.utils.find_knn_within_radius, a_df, r_df, radius, knn)
+    valid_pairs = pairs
+    coords = new_a[['X', 'Y']].values
+    tris = Delaunay(coords).simplices
+    kept = quiet(ref.helpers.filter_triangles_by_radius, coords, tris, radius, aligned_df=new_a,
+                 ignore_same_type_triangles=True, min_angle_deg=15)
+    _, _, valid_pairs_map = ref.helpers.precompute_coordinate_maps(new_a, new_r, valid_pairs)
+    simplex_map = {i: set() for i in range(len(new_a))}
+    for idx, simplex in enumerate(kept):
+        for i in simplex:
+            simplex_map[i].add(idx)
+    model = fg.Model('optimal_matches')
+    x = model.addVars(len(valid_pairs), vtype=fg.GRB.BINARY, lb=0, ub=1, name='x')
+    n_x = len(model.vars)
+    ref.helpers.GRB = fg.GRB
+    apv, zpv = quiet(ref.helpers.add_spatial_constraints_triangle_based, model, valid_pairs_map, x, new_a, new_r, valid_pairs,
+                     simplex_map, kept)
+    names = [v.VarName for v in model.vars]
+    index = {n: i for i, n in enumerate(names)}
+    canon = fg.canonical_constraints(model.constrs)
+    sense = np.array([{'<=': -1, '==': 0, '>=': 1}[c[0]] for c in canon], dtype=np.int8)
+    const = np.array([c[1] for c in canon])
+    term_var = np.full((len(canon), 4), -1, np.int32)
+    term_coef = np.zeros((len(canon), 4))
+    for q, c in enumerate(canon):
+        for t, (n, k) in enumerate(c[2]):
+            term_var[q, t], term_coef[q, t] = index[n], k
+    out = {'params': np.array([radius, knn]), 'n_x': np.array([n_x]), 'pairs': np.asarray(valid_pairs, dtype=np.int64),
+           'triangles': np.asarray(kept, dtype=np.int64), 'var_names': np.array(names), 'var_lb': np.array([v.lb for v in model.vars], dtype=float),
+           'var_ub': np.array([np.inf if v.ub is None else v.ub for v in model.vars], dtype=float),
+           'area_penalty_names': np.array([v.VarName for v in apv]), 'z_names': np.array([v.VarName for v in zpv]),
+           'sense': sense, 'const': const, 'term_var': term_var, 'term_coef': term_coef}
+    zero = int(((term_coef == 0).all(axis=1) | ((term_var >= 0).sum(axis=1) == 1)).sum())
+    print(f"[eager model] {len(kept)} triangles, {len(zpv)} z vars, {len(canon)} constraints, {zero} with a zero orientation product")
+    np.savez_compressed(os.path.join(OUT, 'eager_model.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'eager':
+        eager_model_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'unpack':
         unpack_merge_case()
         return
