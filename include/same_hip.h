@@ -238,7 +238,10 @@ int same_greedy_disjoint(same_ctx *ctx, const int32_t *items, const double *keys
  * ceil(n_a/n_r) times (tiled columns, :744-748).  out_ref[a_off[p]+i] = index within problem p's
  * ref members given to aligned member i; ties resolve as scipy's solver resolves them.
  * SAME_ERANGE if a problem has non-finite coordinates (scipy raises ValueError there);
- * SAME_EINVAL if a problem has aligned members but no ref member. */
+ * SAME_EINVAL if a problem has aligned members but no ref member, or more than
+ * SAME_ASSIGN_MAX_MEMBERS on either side (one lane solves one problem in O(n^3): metacells are
+ * a handful of cells; the bound keeps a malformed input from occupying the GPU for minutes). */
+#define SAME_ASSIGN_MAX_MEMBERS 512
 int same_batched_assign(same_ctx *ctx, int64_t n_prob, const int64_t *a_off, const int64_t *r_off,
                         const double *axy, const double *rxy, int32_t *out_ref);
 

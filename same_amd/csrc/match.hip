@@ -476,7 +476,7 @@ int same_batched_assign(same_ctx *ctx, int64_t n_prob, const int64_t *a_off, con
     int64_t words = 0;
     for (int64_t p = 0; p < n_prob; ++p) {
         const int64_t na = a_off[p + 1] - a_off[p], nref = r_off[p + 1] - r_off[p];
-        REQUIRE(ctx, na >= 0 && nref >= 0 && na < (1 << 20) && nref < (1 << 20));
+        REQUIRE(ctx, na >= 0 && nref >= 0 && na <= SAME_ASSIGN_MAX_MEMBERS && nref <= SAME_ASSIGN_MAX_MEMBERS);
         REQUIRE(ctx, na == 0 || nref > 0);
         w_off[(size_t)p] = words;
         if (na == 0) continue;

@@ -211,3 +211,40 @@ def test_run_same_eager_mode_matches_reference_model(gp, tmp_path):
     assert len(var_out["area_penalty_vars"]) == len(g["area_penalty_names"]) == len(g["triangles"])
     assert not hasattr(model.Params, "LazyConstraints")
     assert len(out_df) > 0 and (tmp_path / "var_out.npy").exists()
+
+
+@pytest.mark.parametrize("force_comm", [False, True])
+def test_bench_contract_line(force_comm):
+    """bench.py prints ONE JSON line carrying the driver's keys plus roofline and cpu_baseline (tiny workload; with the
+    RCCL branch forced through a size-1 communicator in the second case)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if force_comm:
+        env["SAME_BENCH_FORCE_COMM"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1"]
+    if force_comm:
+        cmd.append("--no-cpu-baseline")
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["metric"] == json.load(open(os.path.join(root, "BASELINE.json"), encoding="utf-8"))["metric"]
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak" and out["dtype"] == "f64"
+    assert out["value"] > 0 and out["vs_baseline"] is None and "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    if force_comm:
+        assert out["cpu_baseline"] is None and "not checked" in out["parity_spot_check"]
+    else:
+        cb = out["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+        assert "equal the oracle bit-for-bit" in out["parity_spot_check"]

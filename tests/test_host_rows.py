@@ -128,6 +128,11 @@ def test_batched_assign_kernel_vs_oracle(oracle, mode):
         ops.batched_assign([0, 2], [0, 0], np.zeros((2, 2)), np.empty((0, 2)))
     with pytest.raises(SameHipError):
         ops.batched_assign([0, 1], [0, 1], np.full((1, 2), np.inf), np.zeros((1, 2)))
+    with pytest.raises(SameHipError):            # more members than SAME_ASSIGN_MAX_MEMBERS
+        ops.batched_assign([0, 513], [0, 1], np.zeros((513, 2)), np.zeros((1, 2)))
+    big = np.random.default_rng(3).uniform(0, 50, (300, 2))     # a large but allowed problem, tiled columns
+    assert np.array_equal(ops.batched_assign([0, 300], [0, 130], big, big[:130] + 0.25),
+                          oracle.batched_assign([0, 300], [0, 130], big, big[:130] + 0.25))
 
 
 def _merge_input():
