@@ -177,8 +177,9 @@ def test_prepare_default_flags_and_priority_filter(case, oracle):
 
 
 def test_run_same_eager_mode_matches_reference_model(gp, tmp_path):
-    """lazy_constraints=False: the spatial variables and constraints equal, one by one and in order, what the reference's
-    add_spatial_constraints_triangle_based emitted into the same recording solver double (tests/golden/eager_model.npz)."""
+    """lazy_constraints=False: every variable and constraint of the assembled model equals, one by one and in order, what the
+    reference's add_basic_constraints_optimized + add_spatial_constraints_triangle_based emitted into the same recording
+    solver double (tests/golden/eager_model.npz; some reference rows are metacells so both match limits occur)."""
     import fake_gurobipy
     import same_amd
     from same_amd import synth
@@ -187,25 +188,23 @@ def test_run_same_eager_mode_matches_reference_model(gp, tmp_path):
     radius, knn = float(g["params"][0]), int(g["params"][1])
     cells = synth.make_cells(140, 3, seed=31)
     r_df = synth.to_frame(cells)
+    r_df.loc[r_df.index % 7 == 0, "size"] = 3.0
     a_df = synth.to_frame(synth.make_jittered(cells, seed=32))
     out_df, var_out = same_amd.run_same(r_df, a_df, synth.type_columns(3), outprefix=str(tmp_path),
                                         optim_params=dict(radius=radius, knn=knn, min_angle_deg=15, lazy_constraints=False),
                                         gurobi_params=dict(init_method="greedy"))
     model = gp.Model.last
-    n_x = int(g["n_x"][0])
-    names = [v.VarName for v in model.vars]
-    spatial = [v for v in model.vars if v.VarName.startswith(("area_penalty_tri", "z_tri"))]
-    assert [v.VarName for v in spatial] == list(g["var_names"][n_x:])          # creation order and names
-    assert names[:n_x] == list(g["var_names"][:n_x])
-    want_lb, want_ub = g["var_lb"][n_x:], g["var_ub"][n_x:]
-    assert [float(v.lb) for v in spatial] == list(want_lb)
-    assert [np.inf if v.ub is None else float(v.ub) for v in spatial] == list(want_ub)
-    got = fake_gurobipy.canonical_constraints([c for c in model.constrs if c[0] is None])   # the unnamed addConstrs block
+    assert [v.VarName for v in model.vars] == list(g["var_names"])              # creation order and names
+    assert [float(v.lb) for v in model.vars] == list(g["var_lb"])
+    assert [np.inf if v.ub is None else float(v.ub) for v in model.vars] == list(g["var_ub"])
+    assert [n or "" for n, _ in model.constrs] == list(g["constr_names"])
+    got = fake_gurobipy.canonical_constraints(model.constrs)
     assert len(got) == len(g["sense"])
     sense = {-1: "<=", 0: "==", 1: ">="}
     for q, (sn, const, terms) in enumerate(got):
         want_terms = tuple(sorted((str(g["var_names"][v]), float(k)) for v, k in zip(g["term_var"][q], g["term_coef"][q]) if v >= 0))
         assert (sn, const, terms) == (sense[int(g["sense"][q])], float(g["const"][q]), want_terms), q
+    assert any(c[1] == -3.0 for c in got[:50]) and any(c[1] == -1.0 for c in got[:50])     # metacell and single-cell limits
     # eager mode: no callback, no lazy bookkeeping; post-solve tables still come out
     assert var_out["lazy_constraints"] is False and var_out["lazy_cuts_added"] == 0
     assert len(var_out["area_penalty_vars"]) == len(g["area_penalty_names"]) == len(g["triangles"])

@@ -534,6 +534,7 @@ def eager_model_case():
     radius, knn = 14.0, 3
     cells = synth.make_cells(140, 3, seed=31)
     r_df = synth.to_frame(cells)
+    r_df.loc[r_df.index % 7 == 0, 'size'] = 3.0          # some reference metacells
     a_df = synth.to_frame(synth.make_jittered(cells, seed=32))
     new_a, new_r, pairs = quiet(ref.utils.find_knn_within_radius, a_df, r_df, radius, knn)
     valid_pairs = pairs
@@ -548,8 +549,14 @@ def eager_model_case():
             simplex_map[i].add(idx)
     model = fg.Model('optimal_matches')
     x = model.addVars(len(valid_pairs), vtype=fg.GRB.BINARY, lb=0, ub=1, name='x')
+    penalty_vars = model.addVars(len(new_r), vtype=fg.GRB.CONTINUOUS, lb=0, ub=1000, name='penalty')   # src/same.py:1116-1118
+    no_match_vars = model.addVars(len(new_a), vtype=fg.GRB.CONTINUOUS, lb=0, ub=1, name='no_match')
     n_x = len(model.vars)
     ref.helpers.GRB = fg.GRB
+    ref.helpers.quicksum = fg.quicksum
+    # assignment constraints, run as-is (src/helpers.py:102-161); some ref rows are metacells so both limits occur
+    quiet(ref.helpers.add_basic_constraints_optimized, model, valid_pairs, len(new_r), len(new_a), 1, x, penalty_vars, no_match_vars,
+          aligned_df=new_a, ref_df=new_r, ref_metacell_match_multiplier=None)
     apv, zpv = quiet(ref.helpers.add_spatial_constraints_triangle_based, model, valid_pairs_map, x, new_a, new_r, valid_pairs,
                      simplex_map, kept)
     names = [v.VarName for v in model.vars]
@@ -557,8 +564,9 @@ def eager_model_case():
     canon = fg.canonical_constraints(model.constrs)
     sense = np.array([{'<=': -1, '==': 0, '>=': 1}[c[0]] for c in canon], dtype=np.int8)
     const = np.array([c[1] for c in canon])
-    term_var = np.full((len(canon), 4), -1, np.int32)
-    term_coef = np.zeros((len(canon), 4))
+    width = max(len(c[2]) for c in canon)
+    term_var = np.full((len(canon), width), -1, np.int32)
+    term_coef = np.zeros((len(canon), width))
     for q, c in enumerate(canon):
         for t, (n, k) in enumerate(c[2]):
             term_var[q, t], term_coef[q, t] = index[n], k
@@ -566,6 +574,7 @@ def eager_model_case():
            'triangles': np.asarray(kept, dtype=np.int64), 'var_names': np.array(names), 'var_lb': np.array([v.lb for v in model.vars], dtype=float),
            'var_ub': np.array([np.inf if v.ub is None else v.ub for v in model.vars], dtype=float),
            'area_penalty_names': np.array([v.VarName for v in apv]), 'z_names': np.array([v.VarName for v in zpv]),
+           'constr_names': np.array([n or '' for n, _ in model.constrs]),
            'sense': sense, 'const': const, 'term_var': term_var, 'term_coef': term_coef}
     zero = int(((term_coef == 0).all(axis=1) | ((term_var >= 0).sum(axis=1) == 1)).sum())
     print(f"[eager model] {len(kept)} triangles, {len(zpv)} z vars, {len(canon)} constraints, {zero} with a zero orientation product")
