@@ -247,3 +247,76 @@ def test_bench_contract_line(force_comm):
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
         assert "equal the oracle bit-for-bit" in out["parity_spot_check"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The whole boundary functions against the REFERENCE'S OWN run_same / sliding_window_matching, both driven through the
+# same recording solver double (tests/golden/run_same_mock.npz, written by tools/gen_golden.py runsame).
+def _mock_inputs():
+    from scipy.spatial import Delaunay
+    from same_amd import synth
+
+    cells = synth.make_cells(300, 4, seed=41)
+    r_df = synth.to_frame(cells)
+    a_df = synth.to_frame(synth.make_jittered(cells, seed=42))
+    ids = np.arange(len(a_df)) * 5 + 2
+    a_pre = a_df.assign(mc_id=ids)
+    tri_all = Delaunay(a_pre[["X", "Y"]].values).simplices
+    keep = ~np.isin(tri_all, np.arange(0, len(a_pre), 9)).any(axis=1)
+    cases = {
+        "lazy_greedy": (a_df, dict(radius=20, knn=4), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=25), {}),
+        "priority_hungarian": (a_df, dict(radius=20, knn=4, ignore_knn_if_matched=True, min_angle_deg=None, ignore_same_type_triangles=False,
+                                          dist_ct_coeff=2.5, no_match_penalty=40, penalty_coeff=3.0, delaunay_penalty=7.0),
+                               dict(init_method="hungarian", lazy_allowed_flip_fraction=0.0, lazy_max_cuts=9, time_limit=60, mip_focus=1,
+                                    cuts=2, heuristics=0.2), {}),
+        "eager": (a_df, dict(radius=14, knn=3, lazy_constraints=False), dict(init_method="greedy"), {}),
+        "precomputed": (a_pre, dict(radius=20, knn=4), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0),
+                        dict(aligned_delaunay=ids[tri_all[keep]], aligned_delaunay_vertex_col="mc_id")),
+    }
+    return r_df, synth.type_columns(4), cases
+
+
+@pytest.mark.parametrize("tag", ["lazy_greedy", "priority_hungarian", "eager", "precomputed"])
+def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
+    import os
+    import run_same_record as rec
+    import same_amd
+
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("run_same_mock")
+    r_df, cols, cases = _mock_inputs()
+    a_df, op, gpar, extra = cases[tag]
+    outprefix = str(tmp_path / tag)
+    out_df, var_out = same_amd.run_same(r_df.copy(), a_df.copy(), cols, outprefix=outprefix, optim_params=same_amd.init_optim_params(**op),
+                                        gurobi_params=same_amd.init_gurobi_params(**gpar), **extra)
+    got = rec.record_run(out_df, var_out, gp.Model.last)
+    got["files"] = np.array(sorted(os.listdir(outprefix)), dtype=str)
+    rec.assert_same_record(got, g, prefix=f"{tag}/")
+
+
+def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
+    import os
+    import pandas as pd
+    import run_same_record as rec
+    import same_amd
+    from same_amd import synth
+
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("run_same_mock")
+    cells = synth.make_cells(1500, 3, seed=51)
+    r_big = synth.to_frame(cells)
+    m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
+    m_big = m_big[~((m_big["X"] < 120) & (m_big["Y"] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
+    swp = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
+    gpar = dict(init_method="greedy", lazy_allowed_flip_fraction=0.0)
+    sw = str(tmp_path / "sw")
+    res = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), commonCT=synth.type_columns(3), outprefix=sw, optim_params=dict(swp),
+                                           gurobi_params=dict(gpar))
+    rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix="sw/res_")
+    assert sorted(d for d in os.listdir(sw) if d.startswith("window_")) == list(g["sw/dirs"])
+    assert len(pd.read_csv(os.path.join(sw, "matchedDF.csv"))) == int(g["sw/csv_rows"][0])
+    res2 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), commonCT=synth.type_columns(3), outprefix=sw, optim_params=dict(swp),
+                                            gurobi_params=dict(gpar))
+    assert len(res2) == int(g["sw/resume_rows"][0])
+    res3 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), optim_params=dict(swp, window_size=220, overlap=60), gurobi_params=dict(gpar))
+    rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res3).items()}, g, prefix="sw_infer/res_")

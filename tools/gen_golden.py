@@ -33,7 +33,13 @@ synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 OUT = os.path.join(ROOT, "tests", "golden")
-ref = load_reference()
+if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame"):
+    # solver-facing fixtures: the reference's model builders / run_same talk to the recording solver double of the tests
+    # (gurobipy itself is proprietary and absent), installed as `gurobipy` BEFORE the reference modules bind its names
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fake_gurobipy as _fg
+    _fg.install()
+ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] == "runsame")
 
 
 def quiet(fn, *a, **k):
@@ -581,10 +587,87 @@ def eager_model_case():
     np.savez_compressed(os.path.join(OUT, 'eager_model.npz'), **out)
 
 
+def run_same_mock_case():
+    """run_same (src/same.py:706-1489) and sliding_window_matching (:297-590) RUN AS-IS with the recording solver double in
+    place of gurobipy: `optimize` takes the MIP start as the incumbent, calls the lazy callback once and reports OPTIMAL.
+    Pins everything on either side of the solve: model variables / constraints / objective / starts / parameters, the
+    cuts the callback adds, the match table, var_out, the files written, the window tiling and central trimming."""
+    import fake_gurobipy as fg
+    import run_same_record as rec
+    import shutil
+    import tempfile
+
+    out = {}
+    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    cwd = os.getcwd()
+    os.chdir(work)                                           # run_same writes gurobi_logs/ and matching_model.lp into the cwd
+    try:
+        cells = synth.make_cells(300, 4, seed=41)
+        r_df = synth.to_frame(cells)
+        a_df = synth.to_frame(synth.make_jittered(cells, seed=42))
+        cols = synth.type_columns(4)
+        cases = {
+            'lazy_greedy': (dict(radius=20, knn=4), dict(init_method='greedy', lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=25), {}),
+            'priority_hungarian': (dict(radius=20, knn=4, ignore_knn_if_matched=True, min_angle_deg=None, ignore_same_type_triangles=False,
+                                        dist_ct_coeff=2.5, no_match_penalty=40, penalty_coeff=3.0, delaunay_penalty=7.0),
+                                   dict(init_method='hungarian', lazy_allowed_flip_fraction=0.0, lazy_max_cuts=9, time_limit=60, mip_focus=1,
+                                        cuts=2, heuristics=0.2), {}),
+            'eager': (dict(radius=14, knn=3, lazy_constraints=False), dict(init_method='greedy'), {}),
+        }
+        # caller-supplied triangulation in vertex-id space, missing some nodes -> unconstrained nodes are removed (:1054-1083)
+        ids = np.arange(len(a_df)) * 5 + 2
+        a_pre = a_df.assign(mc_id=ids)
+        tri_all = Delaunay(a_pre[['X', 'Y']].values).simplices
+        keep = ~np.isin(tri_all, np.arange(0, len(a_pre), 9)).any(axis=1)
+        cases['precomputed'] = (dict(radius=20, knn=4), dict(init_method='greedy', lazy_allowed_flip_fraction=0.0),
+                                dict(aligned_delaunay=ids[tri_all[keep]], aligned_delaunay_vertex_col='mc_id'))
+        for tag, (op, gpar, extra) in cases.items():
+            adf = a_pre if tag == 'precomputed' else a_df
+            outprefix = os.path.join(work, tag)
+            out_df, var_out = quiet(ref.same.run_same, r_df.copy(), adf.copy(), cols, outprefix=outprefix,
+                                    optim_params=ref.same.init_optim_params(**op), gurobi_params=ref.same.init_gurobi_params(**gpar), **extra)
+            r = rec.record_run(out_df, var_out, fg.Model.last)
+            r['files'] = np.array(sorted(os.listdir(outprefix)), dtype=str)
+            out.update({f'{tag}/{k}': v for k, v in r.items()})
+            print(f"[run_same/{tag}] {len(out_df)} matches, {len(fg.Model.last.vars)} vars, {len(fg.Model.last.constrs)} constraints, "
+                  f"{len(fg.Model.last.lazy)} cuts")
+
+        # sliding windows: tiling, merges of under-populated windows, central trimming, window ids, resume file
+        cells = synth.make_cells(1500, 3, seed=51)
+        r_big = synth.to_frame(cells)
+        m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
+        # thin out one corner so that some windows fall under min_cells_per_window and get merged right / down
+        m_big = m_big[~((m_big['X'] < 120) & (m_big['Y'] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
+        swp = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
+        res = quiet(ref.same.sliding_window_matching, r_big.copy(), m_big.copy(), commonCT=synth.type_columns(3), outprefix=os.path.join(work, 'sw'),
+                    optim_params=dict(swp), gurobi_params=dict(init_method='greedy', lazy_allowed_flip_fraction=0.0))
+        out.update({f'sw/{k}': v for k, v in rec.record_frame('res', res).items()})
+        out['sw/dirs'] = np.array(sorted(d for d in os.listdir(os.path.join(work, 'sw')) if d.startswith('window_')), dtype=str)
+        saved = pd.read_csv(os.path.join(work, 'sw', 'matchedDF.csv'))
+        out['sw/csv_rows'] = np.array([len(saved)])
+        print(f"[sliding_window] {len(res)} central matches from windows {sorted(res['window_id'].unique().tolist())}")
+        # resume: same call again with the CSV present -> nothing left to process, existing rows returned
+        res2 = quiet(ref.same.sliding_window_matching, r_big.copy(), m_big.copy(), commonCT=synth.type_columns(3), outprefix=os.path.join(work, 'sw'),
+                     optim_params=dict(swp), gurobi_params=dict(init_method='greedy', lazy_allowed_flip_fraction=0.0))
+        out['sw/resume_rows'] = np.array([len(res2)])
+        # commonCT inferred from cell_type, no outprefix
+        res3 = quiet(ref.same.sliding_window_matching, r_big.copy(), m_big.copy(), optim_params=dict(swp, window_size=220, overlap=60),
+                     gurobi_params=dict(init_method='greedy', lazy_allowed_flip_fraction=0.0))
+        out.update({f'sw_infer/{k}': v for k, v in rec.record_frame('res', res3).items()})
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(os.path.join(OUT, 'run_same_mock.npz'), **out)
+    print(f"[run_same_mock] {len(out)} arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'eager':
         eager_model_case()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'runsame':
+        run_same_mock_case()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'unpack':
         unpack_merge_case()

@@ -28,8 +28,9 @@ def _stub(name, **attrs):
     return m
 
 
-def load_reference():
-    """Return a namespace with the reference modules that hold hot-path functions."""
+def load_reference(with_run_same=False):
+    """Return a namespace with the reference modules that hold hot-path functions.  with_run_same=True also loads
+    src/same.py (run_same, sliding_window_matching); the caller must have put a solver double into sys.modules['gurobipy']."""
     if not os.path.isdir(REF_SRC):
         raise RuntimeError(f"reference not mounted at {REF_ROOT}; fixtures can only be generated in the build container")
     sys.dont_write_bytecode = True
@@ -43,9 +44,9 @@ def load_reference():
 
     _stub("gurobipy", Model=_Dummy, GRB=_Dummy(), quicksum=lambda *a, **k: None)
     _stub("scanpy")
-    _stub("alphashape")
+    _stub("alphashape", alphashape=None)
     shp = _stub("shapely")
-    geo = _stub("shapely.geometry", Point=_Dummy, Polygon=_Dummy, MultiPolygon=_Dummy)
+    geo = _stub("shapely.geometry", Point=_Dummy, Polygon=_Dummy, MultiPolygon=_Dummy, GeometryCollection=_Dummy)
     shp.geometry = geo
     _stub("shapely.ops", unary_union=lambda *a, **k: None)
 
@@ -53,7 +54,10 @@ def load_reference():
     pkg.__path__ = [REF_SRC]
     sys.modules[_PKG] = pkg
     ns = types.SimpleNamespace()
-    for name in ("utils", "helpers", "violationhelper", "init_helpers", "knn_utils", "eval_utils", "metacell_utils"):
+    names = ("utils", "helpers", "violationhelper", "init_helpers", "knn_utils", "eval_utils", "metacell_utils")
+    if with_run_same:
+        names += ("triangle_utils", "same")
+    for name in names:
         spec = importlib.util.spec_from_file_location(f"{_PKG}.{name}", os.path.join(REF_SRC, f"{name}.py"))
         mod = importlib.util.module_from_spec(spec)
         sys.modules[f"{_PKG}.{name}"] = mod
