@@ -320,3 +320,31 @@ def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
     assert len(res2) == int(g["sw/resume_rows"][0])
     res3 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), optim_params=dict(swp, window_size=220, overlap=60), gurobi_params=dict(gpar))
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res3).items()}, g, prefix="sw_infer/res_")
+
+
+def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
+    """collapse both sections -> run_same on a MetaCell object -> unpack with per-match assignments -> windows over MetaCell
+    objects: the reference's own pipeline, run there through the solver double, reproduced array for array."""
+    import run_same_record as rec
+    import same_amd
+    from same_amd import synth
+
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("run_same_mock")
+    cells = synth.make_cells(900, 3, seed=61)
+    r_c = synth.to_frame(cells)
+    a_c = synth.to_frame(synth.make_jittered(cells, seed=62))
+    a_c["Cell_Num_Old"] = np.arange(len(a_c)) * 2 + 7
+    mc_a = same_amd.greedy_triangle_collapse(a_c, max_metacell_size=4, r_max=40, min_angle_deg=10, return_object=True, verbose=False)
+    mc_r = same_amd.greedy_triangle_collapse(r_c, max_metacell_size=3, r_max=40, min_angle_deg=10, return_object=True, verbose=False)
+    mop = dict(radius=30, knn=4)
+    mgp = dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=40)
+    out_df, var_out = same_amd.run_same(mc_r.metacell_df, mc_a, synth.type_columns(3), outprefix=str(tmp_path / "mc"),
+                                        optim_params=dict(mop), gurobi_params=dict(mgp))
+    rec.assert_same_record(rec.record_run(out_df.drop(columns=["members"], errors="ignore"), var_out, gp.Model.last), g, prefix="metacell_flow/")
+    indiv = same_amd.unpack_metacell_matches(out_df, mc_a.metacell_df, mc_r.metacell_df, aligned_df=a_c, ref_df=r_c, strategy="nearest",
+                                             aligned_original_idx_col="Cell_Num_Old", ref_original_idx_col="Cell_Num_Old")
+    assert np.array_equal(indiv[["Aligned_cell_id", "Ref_cell_id"]].to_numpy(dtype=np.int64), g["metacell_flow_unpacked"])
+    res = same_amd.sliding_window_matching(mc_r, mc_a, commonCT=synth.type_columns(3),
+                                           optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
+    rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix="sw_metacell/res_")

@@ -632,6 +632,30 @@ def run_same_mock_case():
             print(f"[run_same/{tag}] {len(out_df)} matches, {len(fg.Model.last.vars)} vars, {len(fg.Model.last.constrs)} constraints, "
                   f"{len(fg.Model.last.lazy)} cuts")
 
+        # the metacell flow: collapse both sections, match metacells (MetaCell object passed as aligned_df: frame, triangulation,
+        # vertex column and cell_id_col are taken from it, src/same.py:889-899), unpack to cells with per-match assignments
+        cells = synth.make_cells(900, 3, seed=61)
+        r_c = synth.to_frame(cells)
+        a_c = synth.to_frame(synth.make_jittered(cells, seed=62))
+        a_c['Cell_Num_Old'] = np.arange(len(a_c)) * 2 + 7
+        mc_a = quiet(ref.metacell_utils.greedy_triangle_collapse, a_c, max_metacell_size=4, r_max=40, min_angle_deg=10, return_object=True)
+        mc_r = quiet(ref.metacell_utils.greedy_triangle_collapse, r_c, max_metacell_size=3, r_max=40, min_angle_deg=10, return_object=True)
+        mop = dict(radius=30, knn=4)
+        mgp = dict(init_method='greedy', lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=40)
+        out_df, var_out = quiet(ref.same.run_same, mc_r.metacell_df, mc_a, synth.type_columns(3), outprefix=os.path.join(work, 'mc'),
+                                optim_params=dict(mop), gurobi_params=dict(mgp))
+        r = rec.record_run(out_df.drop(columns=['members'], errors='ignore'), var_out, fg.Model.last)
+        out.update({f'metacell_flow/{k}': v for k, v in r.items()})
+        indiv = ref.metacell_utils.unpack_metacell_matches(out_df, mc_a.metacell_df, mc_r.metacell_df, aligned_df=a_c, ref_df=r_c,
+                                                           strategy='nearest', aligned_original_idx_col='Cell_Num_Old',
+                                                           ref_original_idx_col='Cell_Num_Old')
+        out['metacell_flow_unpacked'] = indiv[['Aligned_cell_id', 'Ref_cell_id']].to_numpy(dtype=np.int64)
+        print(f"[metacell flow] {len(mc_a.metacell_df)} x {len(mc_r.metacell_df)} metacells, {len(out_df)} metacell matches -> {len(indiv)} cell matches")
+        res_mc = quiet(ref.same.sliding_window_matching, mc_r, mc_a, commonCT=synth.type_columns(3),
+                       optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
+        out.update({f'sw_metacell/{k}': v for k, v in rec.record_frame('res', res_mc).items()})
+        print(f"[metacell windows] {len(res_mc)} central matches, columns {list(res_mc.columns)}")
+
         # sliding windows: tiling, merges of under-populated windows, central trimming, window ids, resume file
         cells = synth.make_cells(1500, 3, seed=51)
         r_big = synth.to_frame(cells)
