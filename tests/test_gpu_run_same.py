@@ -270,13 +270,16 @@ def _mock_inputs():
                                dict(init_method="hungarian", lazy_allowed_flip_fraction=0.0, lazy_max_cuts=9, time_limit=60, mip_focus=1,
                                     cuts=2, heuristics=0.2), {}),
         "eager": (a_df, dict(radius=14, knn=3, lazy_constraints=False), dict(init_method="greedy"), {}),
+        "max_matches2": (a_df, dict(radius=20, knn=5, max_matches=2, min_angle_deg=0), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0), {}),
+        "multiplier": (a_df, dict(radius=25, knn=6, ref_metacell_match_multiplier=2),
+                       dict(init_method="hungarian", init_hungarian_max_n=100, lazy_allowed_flip_fraction=0.0), {}),
         "precomputed": (a_pre, dict(radius=20, knn=4), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0),
                         dict(aligned_delaunay=ids[tri_all[keep]], aligned_delaunay_vertex_col="mc_id")),
     }
     return r_df, synth.type_columns(4), cases
 
 
-@pytest.mark.parametrize("tag", ["lazy_greedy", "priority_hungarian", "eager", "precomputed"])
+@pytest.mark.parametrize("tag", ["lazy_greedy", "priority_hungarian", "eager", "precomputed", "max_matches2", "multiplier"])
 def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
     import os
     import run_same_record as rec
@@ -287,6 +290,9 @@ def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
     r_df, cols, cases = _mock_inputs()
     a_df, op, gpar, extra = cases[tag]
     outprefix = str(tmp_path / tag)
+    if tag == "multiplier":
+        r_df = r_df.copy()
+        r_df.loc[r_df.index % 5 == 0, "size"] = 4.0
     out_df, var_out = same_amd.run_same(r_df.copy(), a_df.copy(), cols, outprefix=outprefix, optim_params=same_amd.init_optim_params(**op),
                                         gurobi_params=same_amd.init_gurobi_params(**gpar), **extra)
     got = rec.record_run(out_df, var_out, gp.Model.last)

@@ -613,6 +613,11 @@ def run_same_mock_case():
                                    dict(init_method='hungarian', lazy_allowed_flip_fraction=0.0, lazy_max_cuts=9, time_limit=60, mip_focus=1,
                                         cuts=2, heuristics=0.2), {}),
             'eager': (dict(radius=14, knn=3, lazy_constraints=False), dict(init_method='greedy'), {}),
+            # max_matches=2: no MIP start is applied (src/init_helpers.py:84-92); the callback sees the all-zero incumbent
+            'max_matches2': (dict(radius=20, knn=5, max_matches=2, min_angle_deg=0), dict(init_method='greedy', lazy_allowed_flip_fraction=0.0), {}),
+            # reference metacells with an explicit multiplier; Hungarian start skipped because the problem is above init_hungarian_max_n
+            'multiplier': (dict(radius=25, knn=6, ref_metacell_match_multiplier=2), dict(init_method='hungarian', init_hungarian_max_n=100,
+                                                                                       lazy_allowed_flip_fraction=0.0), {}),
         }
         # caller-supplied triangulation in vertex-id space, missing some nodes -> unconstrained nodes are removed (:1054-1083)
         ids = np.arange(len(a_df)) * 5 + 2
@@ -621,10 +626,12 @@ def run_same_mock_case():
         keep = ~np.isin(tri_all, np.arange(0, len(a_pre), 9)).any(axis=1)
         cases['precomputed'] = (dict(radius=20, knn=4), dict(init_method='greedy', lazy_allowed_flip_fraction=0.0),
                                 dict(aligned_delaunay=ids[tri_all[keep]], aligned_delaunay_vertex_col='mc_id'))
+        r_meta = r_df.copy()
+        r_meta.loc[r_meta.index % 5 == 0, 'size'] = 4.0
         for tag, (op, gpar, extra) in cases.items():
             adf = a_pre if tag == 'precomputed' else a_df
             outprefix = os.path.join(work, tag)
-            out_df, var_out = quiet(ref.same.run_same, r_df.copy(), adf.copy(), cols, outprefix=outprefix,
+            out_df, var_out = quiet(ref.same.run_same, (r_meta if tag == 'multiplier' else r_df).copy(), adf.copy(), cols, outprefix=outprefix,
                                     optim_params=ref.same.init_optim_params(**op), gurobi_params=ref.same.init_gurobi_params(**gpar), **extra)
             r = rec.record_run(out_df, var_out, fg.Model.last)
             r['files'] = np.array(sorted(os.listdir(outprefix)), dtype=str)
