@@ -354,3 +354,42 @@ def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     res = same_amd.sliding_window_matching(mc_r, mc_a, commonCT=synth.type_columns(3),
                                            optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix="sw_metacell/res_")
+
+
+def test_shipped_example_flow_equals_reference(gp, tmp_path, monkeypatch):
+    """The reference's own CPU-runnable case (BASELINE configs[0]): examples/synthetic driven as its run_same.sh drives it --
+    size-1 metacells, MetaCell objects into sliding_window_matching, commonCT inferred from cell_type, paper parameters."""
+    import pandas as pd
+    import run_same_record as rec
+    import same_amd
+
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("run_same_mock")
+
+    def frame(prefix):
+        cols = [str(c) for c in g[f"example/{prefix}_columns"]]
+        df = pd.DataFrame({c: g[f"example/{prefix}__{c}"] for c in cols})
+        df["cell_type"] = df["cell_type"].astype(object)
+        df["quadrant"] = df["quadrant"].astype(object)
+        return df
+
+    ex_ref, ex_query = frame("ref"), frame("query")
+    mck = dict(cell_type_col="cell_type", original_idx_col="cell_idx", x_col="X", y_col="Y", max_metacell_size=1, r_max=5, min_angle_deg=5,
+               use_alpha_shape=False, alpha=None, return_object=True, verbose=False)
+    mc_a = same_amd.greedy_triangle_collapse(ex_query, **mck)
+    mc_r = same_amd.greedy_triangle_collapse(ex_ref, **mck)
+    ex_gp = same_amd.init_gurobi_params()
+    ex_gp.update(mip_gap=0.025, lazy_allowed_flip_fraction=0.0, time_limit=7200, mip_focus=2, init_method="greedy")
+    ex_op = same_amd.init_optim_params()
+    ex_op.update({"window_size": 100, "overlap": 0, "min_cells_per_window": 30, "max_matches": 2, "radius": 5, "knn": 8,
+                  "no_match_penalty": 10000, "dist_ct_coeff": 1, "min_angle_deg": 5, "penalty_coeff": 100, "delaunay_penalty": 10,
+                  "cell_id_col": "metacell_id", "ref_metacell_match_multiplier": 1, "ignore_same_type_triangles": False,
+                  "lazy_constraints": True})
+    res = same_amd.sliding_window_matching(mc_r, mc_a, outprefix=str(tmp_path / "example"), optim_params=ex_op, gurobi_params=ex_gp,
+                                           ignore_precomputed_triangulation=False)
+    got = {k[4:]: v for k, v in rec.record_frame("res", res).items()}
+    want_keys = {k: v for k, v in g.items() if k.startswith("example/res_")}
+    rec.assert_same_record(got, want_keys, prefix="example/res_")
+    model_keys = rec.record_model(gp.Model.last)
+    rec.assert_same_record(model_keys, {f"m/{k}": g[f"example/{k}"] for k in model_keys}, prefix="m/")
+    assert len(res) == 351 and len(gp.Model.last.lazy) == 178      # SURVEY 8c: 351 matched under the greedy start, 178 flipped triangles

@@ -663,6 +663,31 @@ def run_same_mock_case():
         out.update({f'sw_metacell/{k}': v for k, v in rec.record_frame('res', res_mc).items()})
         print(f"[metacell windows] {len(res_mc)} central matches, columns {list(res_mc.columns)}")
 
+        # the shipped example exactly as examples/synthetic/run_same.sh drives it (its parameter block :31-54 and calls :84-131):
+        # size-1 "metacells" (Delaunay + filter only), MetaCell objects into sliding_window_matching, commonCT inferred
+        d = os.path.join(REF_ROOT, 'examples', 'synthetic', 'data')
+        ex_ref = pd.read_csv(os.path.join(d, 'ref.csv'), index_col=0)
+        ex_query = pd.read_csv(os.path.join(d, 'query.csv'), index_col=0)
+        out.update({f'example/{k}': v for k, v in rec.record_frame('ref', ex_ref).items()})
+        out.update({f'example/{k}': v for k, v in rec.record_frame('query', ex_query).items()})
+        mck = dict(cell_type_col='cell_type', original_idx_col='cell_idx', x_col='X', y_col='Y', max_metacell_size=1, r_max=5, min_angle_deg=5,
+                   use_alpha_shape=False, alpha=None, return_object=True)
+        ex_mc_a = quiet(ref.metacell_utils.greedy_triangle_collapse, ex_query, **mck)
+        ex_mc_r = quiet(ref.metacell_utils.greedy_triangle_collapse, ex_ref, **mck)
+        ex_gp = ref.same.init_gurobi_params()
+        ex_gp.update(mip_gap=0.025, lazy_allowed_flip_fraction=0.0, time_limit=7200, mip_focus=2, init_method='greedy')
+        ex_op = ref.same.init_optim_params()
+        ex_op.update({'window_size': 100, 'overlap': 0, 'min_cells_per_window': 30, 'max_matches': 2, 'radius': 5, 'knn': 8,
+                      'no_match_penalty': 10000, 'dist_ct_coeff': 1, 'min_angle_deg': 5, 'penalty_coeff': 100, 'delaunay_penalty': 10,
+                      'cell_id_col': 'metacell_id', 'ref_metacell_match_multiplier': 1, 'ignore_same_type_triangles': False,
+                      'lazy_constraints': True})
+        ex_res = quiet(ref.same.sliding_window_matching, ex_mc_r, ex_mc_a, outprefix=os.path.join(work, 'example'), optim_params=ex_op,
+                       gurobi_params=ex_gp, ignore_precomputed_triangulation=False)
+        out.update({f'example/{k}': v for k, v in rec.record_frame('res', ex_res).items()})
+        out.update({f'example/{k}': v for k, v in rec.record_model(fg.Model.last).items()})
+        print(f"[shipped example] {len(ex_mc_a.metacell_df)} x {len(ex_mc_r.metacell_df)} metacells, {len(ex_res)} matches, "
+              f"{len(fg.Model.last.lazy)} cuts in the last window")
+
         # sliding windows: tiling, merges of under-populated windows, central trimming, window ids, resume file
         cells = synth.make_cells(1500, 3, seed=51)
         r_big = synth.to_frame(cells)
