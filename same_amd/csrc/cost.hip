@@ -89,6 +89,26 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     } else if (map_mode == 1) {  // row chunk fastest
         chunk = blockIdx.x % row_chunks;
         tile = blockIdx.x / row_chunks;
+    } else if (map_mode == 3) {
+        // XCD-resident reference tiles: XCD x (= blockIdx % 8, the hardware's round-robin) owns the column tiles
+        // x, x+8, x+16, ... and sweeps ALL row chunks over them, chunk by chunk.  Its share of R ((T+2)*8 B per
+        // column, ~2.2 MB at 100k refs / T=20) then stays in that XCD's 4 MB L2 for the whole launch, and each
+        // chunk of A rows is fetched once per XCD instead of R being re-fetched once per chunk.
+        const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
+        const unsigned mine = ((unsigned)col_tiles + 7u - xcd) >> 3;  // tiles owned by this XCD
+        const unsigned widest = ((unsigned)col_tiles + 7u) >> 3;      // grid is sized for the widest owner
+        const unsigned m = k % widest;
+        chunk = k / widest;
+        if (m >= mine || chunk >= row_chunks) return;
+        tile = xcd + 8u * m;
+    } else if (map_mode == 4) {  // as 3, but XCD x owns the CONTIGUOUS tile range [x*ct/8, (x+1)*ct/8)
+        const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
+        const unsigned lo = xcd * (unsigned)col_tiles / 8u, hi = (xcd + 1u) * (unsigned)col_tiles / 8u;
+        const unsigned widest = ((unsigned)col_tiles + 7u) >> 3;
+        const unsigned m = k % widest;
+        chunk = k / widest;
+        if (m >= hi - lo || chunk >= row_chunks) return;
+        tile = lo + m;
     } else {  // blocks that share an XCD (b % 8) take adjacent column tiles
         const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
         const unsigned per = (gridDim.x + 7u) >> 3;  // blocks per XCD group
@@ -283,6 +303,7 @@ int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy
     const int64_t chunks = ceil_div(rows, rows_per_block);
     int64_t blocks = chunks * col_tiles;
     if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
+    if (map_mode == 3 || map_mode == 4) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
     if (w == F(1))
         hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
@@ -301,7 +322,12 @@ int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const 
                      int64_t re, F w, F *out, int64_t ld, int64_t n_store) {
     const int64_t rows = re - rb;
     static const int rpb_env = env_int("SAME_DENSE_RPB", 0);
-    static const int map_env = env_int("SAME_DENSE_MAP", 2);
+    // Block -> (tile, chunk) map.  Store-bound shapes want every XCD to stream whole output rows (map 2: 11.4 ms at
+    // 100k x 100k vs 14.1 ms for map 4); once the fp64 VALU / power budget is the limit (T >= 16, equal times) map 4 keeps
+    // each XCD's share of R in its own L2, which removes the per-block R re-fetch: FETCH_SIZE 3.46 GB -> 0.15 GB per launch
+    // (profiles/r01_dense_map_fetch.md).  SAME_DENSE_MAP overrides (probes).
+    static const int map_override = env_int("SAME_DENSE_MAP", -1);
+    const int map_env = map_override >= 0 ? map_override : ((sizeof(F) == 8 && T >= 16) ? 4 : 2);
     // vector stores need whole CPL-groups: n_store (a multiple of CPL, n_r <= n_store <= ld) says how many
     // columns may be written; without such padding the scalar-store variant is used
     const bool vec_ok = CPL > 1 && (ld % CPL == 0) && (n_store % CPL == 0) && n_store >= n_r && n_store <= ld &&
@@ -309,7 +335,7 @@ int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const 
     if (!vec_ok) {
         const int rpb = (int)std::min<int64_t>(rows, 64);
         // ragged tail first (its own launch), then whole chunks with the overlapped-last-chunk rule
-        return launch_one<F, T, CPL, false, 1, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb, map_env == 2 ? 0 : map_env);
+        return launch_one<F, T, CPL, false, 1, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb, (map_env == 2 || map_env == 4) ? 0 : map_env);
     }
     const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
     // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
