@@ -38,3 +38,12 @@ for n, c, ms, mb, gbs, pct, share in sorted(rowsout, key=lambda x: -x[6]):
     print(f"| `{n}` | {c} | {ms:.4f} | {mb:.2f} | {gbs:.0f} | {pct:.1f} | {share:.2f} |")
 print(f"\nbench line: {line['ms_per_step']:.2f} ms/step, {line['value']:.3e} cell-pairs/s, dense kernel {line['roofline']['kernel_ms']:.2f} ms "
       f"(live HIP-event mean over the timed steps), frac {line['roofline']['frac']:.3f}")
+
+if len(sys.argv) > 3:   # the kernel trace of the same run: per-launch durations (the --stats average includes bench.py's warm-up steps)
+    tr = pd.read_csv(sys.argv[3]).sort_values("Start_Timestamp")
+    dd = tr[tr["Kernel_Name"].str.contains("dense_cost_kernel<double, 20")]
+    dur = (dd["End_Timestamp"] - dd["Start_Timestamp"]) / 1e6
+    w = int(line["warmup"])
+    print(f"\nper-launch durations of the dense kernel in this trace (ms): {dur.round(2).tolist()}; the first {w} are bench.py's warm-up steps "
+          f"(first touch of the 80 GB block, clocks ramping), the {len(dur) - w} timed launches average {dur.iloc[w:].mean():.2f} ms under the "
+          f"profiler vs the live HIP-event mean printed above.")
