@@ -6,6 +6,7 @@ Everything order-sensitive in the reference's outputs is kept in order (variable
 violation lists, triangle_info insertion order); the two containers the reference builds from Python sets
 (triangles_with_violations, points_with_violations and the three comparison lists) are compared sorted."""
 import numpy as np
+import pandas as pd
 
 import fake_gurobipy as fg
 
@@ -117,3 +118,22 @@ def assert_same_record(got, want, prefix=""):
             assert np.array_equal(a, b.astype(a.dtype), equal_nan=True), k
         else:
             assert np.array_equal(a.astype(str) if a.dtype.kind in "US" else a, b.astype(str) if b.dtype.kind in "US" else b), k
+
+
+def tiler_inputs(cfg):
+    """Seeded frames for one window-tiler configuration (shared by the generator and the GPU test through the fixture's
+    parameter table: n_ref, n_mov, side, seed, window_size, overlap, min_cells, hole)."""
+    n_ref, n_mov, side, seed, ws, ov, mc, hole = cfg
+    rng = np.random.default_rng(int(seed))
+
+    def frame(n, id0):
+        xy = rng.uniform(0, side, (int(n), 2))
+        if hole:   # thin out a corner block so that some windows fall under min_cells and merge right / down
+            keep = ~((xy[:, 0] < side * 0.35) & (xy[:, 1] < side * 0.45) & (rng.random(int(n)) < 0.85))
+            xy = xy[keep]
+        df = pd.DataFrame({'X': xy[:, 0], 'Y': xy[:, 1]})
+        df['cell_type'] = 'a'
+        df['a'] = 1.0
+        df['Cell_Num_Old'] = np.arange(len(df)) + id0
+        return df
+    return frame(n_ref, 100000), frame(n_mov, 0)

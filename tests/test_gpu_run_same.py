@@ -393,3 +393,54 @@ def test_shipped_example_flow_equals_reference(gp, tmp_path, monkeypatch):
     model_keys = rec.record_model(gp.Model.last)
     rec.assert_same_record(model_keys, {f"m/{k}": g[f"example/{k}"] for k in model_keys}, prefix="m/")
     assert len(res) == 351 and len(gp.Model.last.lazy) == 178      # 351 matched under the greedy start, 178 flipped triangles
+
+
+def test_window_tiler_equals_reference_loop():
+    """Tiling, right/down merges of under-populated windows, window ids, central trimming, CSV resume: ten seeded
+    configurations, each compared call by call with what the reference's own sliding_window_matching loop did when its
+    run_same was replaced by a recorder (tests/golden/window_tiler.npz)."""
+    import os
+    import tempfile
+    import pandas as pd
+    import same_amd
+    from run_same_record import tiler_inputs
+
+    g = load_golden("window_tiler")
+    calls = []
+
+    def recorder(aligned_df, ref_df, commonCT, optim_params, gurobi_params, outprefix, aligned_delaunay, aligned_delaunay_vertex_col,
+                 ignore_precomputed_triangulation):
+        calls.append((os.path.basename(outprefix) if outprefix else "", aligned_df["Cell_Num_Old"].to_numpy().copy(),
+                      ref_df["Cell_Num_Old"].to_numpy().copy()))
+        return pd.DataFrame({"X": aligned_df["X"].to_numpy(), "Y": aligned_df["Y"].to_numpy(),
+                             "Aligned_Cell_Num_Old": aligned_df["Cell_Num_Old"].to_numpy()}), {}
+
+    def check(tag, res):
+        assert [c[0] for c in calls] == list(g[f"{tag}/prefix"]), tag
+        a_off, r_off = g[f"{tag}/a_off"], g[f"{tag}/r_off"]
+        for q, c in enumerate(calls):
+            assert np.array_equal(c[1], g[f"{tag}/a_ids"][a_off[q]:a_off[q + 1]]), (tag, q)
+            assert np.array_equal(c[2], g[f"{tag}/r_ids"][r_off[q]:r_off[q + 1]]), (tag, q)
+        got = res[["Aligned_Cell_Num_Old", "window_id"]].to_numpy(dtype=np.int64) if len(res) else np.zeros((0, 2), np.int64)
+        assert np.array_equal(got, g[f"{tag}/res"]), tag
+        calls.clear()
+
+    with tempfile.TemporaryDirectory() as work:
+        for q, cfg in enumerate(g["cfgs"]):
+            r_df, m_df = tiler_inputs(cfg)
+            op = dict(window_size=int(cfg[4]), overlap=int(cfg[5]), min_cells_per_window=int(cfg[6]))
+            res = same_amd.sliding_window_matching(r_df.copy(), m_df.copy(), commonCT=["a"], optim_params=dict(op), _run_window=recorder)
+            check(f"c{q}/plain", res)
+            pre = os.path.join(work, f"c{q}")
+            res = same_amd.sliding_window_matching(r_df.copy(), m_df.copy(), commonCT=["a"], outprefix=pre, optim_params=dict(op),
+                                                   _run_window=recorder)
+            check(f"c{q}/out", res)
+            csv = os.path.join(pre, "matchedDF.csv")
+            if f"c{q}/kept_ids" in g:
+                full = pd.read_csv(csv)
+                full[full["window_id"].isin(g[f"c{q}/kept_ids"].tolist())].to_csv(csv, index=False)
+                res = same_amd.sliding_window_matching(r_df.copy(), m_df.copy(), commonCT=["a"], outprefix=pre, optim_params=dict(op),
+                                                       _run_window=recorder)
+                check(f"c{q}/resume", res)
+            else:
+                assert not os.path.exists(csv)

@@ -33,13 +33,13 @@ synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 OUT = os.path.join(ROOT, "tests", "golden")
-if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame"):
+if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler"):
     # solver-facing fixtures: the reference's model builders / run_same talk to the recording solver double of the tests
     # (gurobipy itself is proprietary and absent), installed as `gurobipy` BEFORE the reference modules bind its names
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fake_gurobipy as _fg
     _fg.install()
-ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] == "runsame")
+ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler"))
 
 
 def quiet(fn, *a, **k):
@@ -717,8 +717,85 @@ def run_same_mock_case():
     print(f"[run_same_mock] {len(out)} arrays")
 
 
+def window_tiler_case():
+    """sliding_window_matching's tiling / merging / trimming / resume logic (src/same.py:481-590, src/helpers.py:21-70) RUN AS-IS
+    with run_same replaced by a recorder that returns every moving cell of the window as a 'match' (so the fixture holds which
+    cells each window received, in which order, under which outprefix, and what survived the central trim)."""
+    import shutil
+    import tempfile
+    from run_same_record import tiler_inputs
+
+    cfgs = np.array([
+        # n_ref n_mov side seed ws   ov  min hole
+        [1200, 1100, 400, 1, 150, 40, 60, 1],
+        [900, 900, 300, 2, 100, 0, 30, 0],
+        [1500, 1300, 520, 3, 200, 50, 120, 1],
+        [400, 380, 250, 4, 120, 30, 40, 1],
+        [2000, 1800, 610, 5, 130, 64, 25, 1],
+        [300, 300, 99, 6, 1000, 250, 10, 0],      # one window covers everything (the defaults)
+        [800, 700, 333, 7, 111, 11, 80, 1],
+        [600, 650, 480, 8, 160, 80, 90, 1],
+        [50, 40, 200, 9, 100, 20, 30, 0],         # too few cells everywhere: nothing is processed
+        [1000, 900, 350.5, 10, 90, 45, 35, 1],
+    ], dtype=float)
+    out = {'cfgs': cfgs}
+    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    calls = []
+
+    def recorder(aligned_df, ref_df, commonCT, optim_params, gurobi_params, outprefix, aligned_delaunay, aligned_delaunay_vertex_col,
+                 ignore_precomputed_triangulation):
+        calls.append((os.path.basename(outprefix) if outprefix else '', aligned_df['Cell_Num_Old'].to_numpy().copy(),
+                      ref_df['Cell_Num_Old'].to_numpy().copy()))
+        m = pd.DataFrame({'X': aligned_df['X'].to_numpy(), 'Y': aligned_df['Y'].to_numpy(),
+                          'Aligned_Cell_Num_Old': aligned_df['Cell_Num_Old'].to_numpy()})
+        return m, {}
+
+    def pack(tag):
+        out[f'{tag}/prefix'] = np.array([c[0] for c in calls], dtype=str)
+        out[f'{tag}/a_off'] = np.concatenate(([0], np.cumsum([len(c[1]) for c in calls]))).astype(np.int64)
+        out[f'{tag}/r_off'] = np.concatenate(([0], np.cumsum([len(c[2]) for c in calls]))).astype(np.int64)
+        out[f'{tag}/a_ids'] = np.concatenate([c[1] for c in calls] + [np.zeros(0, np.int64)]).astype(np.int64)
+        out[f'{tag}/r_ids'] = np.concatenate([c[2] for c in calls] + [np.zeros(0, np.int64)]).astype(np.int64)
+        calls.clear()
+
+    def result(tag, res):
+        if len(res) == 0:
+            out[f'{tag}/res'] = np.zeros((0, 2), np.int64)
+        else:
+            out[f'{tag}/res'] = res[['Aligned_Cell_Num_Old', 'window_id']].to_numpy(dtype=np.int64)
+
+    saved = ref.same.run_same
+    ref.same.run_same = recorder
+    try:
+        for q, cfg in enumerate(cfgs):
+            r_df, m_df = tiler_inputs(cfg)
+            op = dict(window_size=int(cfg[4]), overlap=int(cfg[5]), min_cells_per_window=int(cfg[6]))
+            res = quiet(ref.same.sliding_window_matching, r_df.copy(), m_df.copy(), commonCT=['a'], optim_params=dict(op))
+            pack(f'c{q}/plain'); result(f'c{q}/plain', res)
+            pre = os.path.join(work, f'c{q}')
+            res = quiet(ref.same.sliding_window_matching, r_df.copy(), m_df.copy(), commonCT=['a'], outprefix=pre, optim_params=dict(op))
+            pack(f'c{q}/out'); result(f'c{q}/out', res)
+            csv = os.path.join(pre, 'matchedDF.csv')
+            if os.path.exists(csv):          # partial progress: drop every other window id from the file, then resume
+                full = pd.read_csv(csv)
+                ids = sorted(full['window_id'].unique())
+                full[full['window_id'].isin(ids[::2])].to_csv(csv, index=False)
+                out[f'c{q}/kept_ids'] = np.array(ids[::2], dtype=np.int64)
+                res = quiet(ref.same.sliding_window_matching, r_df.copy(), m_df.copy(), commonCT=['a'], outprefix=pre, optim_params=dict(op))
+                pack(f'c{q}/resume'); result(f'c{q}/resume', res)
+            print(f"[tiler c{q}] ws={int(cfg[4])} ov={int(cfg[5])} min={int(cfg[6])}: {len(out[f'c{q}/plain/prefix'])} windows run, "
+                  f"{len(out[f'c{q}/plain/res'])} central rows; with outprefix {len(out[f'c{q}/out/prefix'])} windows")
+    finally:
+        ref.same.run_same = saved
+        shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(os.path.join(OUT, 'window_tiler.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'tiler':
+        window_tiler_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'eager':
         eager_model_case()
         return
