@@ -33,13 +33,13 @@ synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 OUT = os.path.join(ROOT, "tests", "golden")
-if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler"):
+if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler", "tongue"):
     # solver-facing fixtures: the reference's model builders / run_same talk to the recording solver double of the tests
     # (gurobipy itself is proprietary and absent), installed as `gurobipy` BEFORE the reference modules bind its names
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fake_gurobipy as _fg
     _fg.install()
-ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler"))
+ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler", "tongue"))
 
 
 def quiet(fn, *a, **k):
@@ -791,8 +791,67 @@ def window_tiler_case():
     np.savez_compressed(os.path.join(OUT, 'window_tiler.npz'), **out)
 
 
+TONGUE_TYPES = ['Endothelial cells', 'Epithelial cells', 'Fibroblasts', 'Lymphoid cells', 'Myeloid cells']
+
+
+def tongue_case():
+    """Real data: examples/tongue (protein section = query, RNA section = template; 64-bit cell ids) driven as its
+    run_same.sh drives it (parameter block :34-47, calls :75-121), once with MS=1 and once with MS=3 metacells + unpacking,
+    through the recording solver double."""
+    import fake_gurobipy as fg
+    import run_same_record as rec
+    import shutil
+    import tempfile
+
+    d = os.path.join(REF_ROOT, 'examples', 'tongue', 'data')
+    raw_a = pd.read_csv(os.path.join(d, 'prot_df.csv'), index_col=0)
+    raw_r = pd.read_csv(os.path.join(d, 'mer_df.csv'), index_col=0)
+    out = {}
+    out.update(rec.record_frame('prot', raw_a))
+    out.update(rec.record_frame('mer', raw_r))
+    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        for ms in (1, 3):
+            a_df, r_df = raw_a.copy(), raw_r.copy()
+            for df in (a_df, r_df):
+                df['X'] = df['transformed_x']
+                df['Y'] = df['transformed_y']
+                df[TONGUE_TYPES] = df[TONGUE_TYPES] * 100
+                df['cell_type'] = df[TONGUE_TYPES].idxmax(axis=1)
+            mck = dict(cell_type_col='cell_type', original_idx_col='Cell_Num', x_col='X', y_col='Y', max_metacell_size=ms, r_max=300,
+                       min_angle_deg=15, use_alpha_shape=False, return_object=True)
+            mc_a = quiet(ref.metacell_utils.greedy_triangle_collapse, a_df, **mck)
+            mc_r = quiet(ref.metacell_utils.greedy_triangle_collapse, r_df, **mck)
+            gp_ = ref.same.init_gurobi_params()
+            gp_.update(mip_gap=0.05, lazy_allowed_flip_fraction=0.05, init_method='greedy')
+            op = ref.same.init_optim_params()
+            op.update({'window_size': 4000, 'overlap': 300, 'min_cells_per_window': 30, 'max_matches': 1, 'radius': 300, 'knn': 8,
+                       'no_match_penalty': 10000, 'penalty_coeff': 100, 'dist_ct_coeff': 1, 'delaunay_penalty': 10,
+                       'cell_id_col': 'metacell_id', 'ref_metacell_match_multiplier': ms, 'lazy_constraints': True, 'min_angle_deg': 15})
+            res = quiet(ref.same.sliding_window_matching, mc_r, mc_a, commonCT=TONGUE_TYPES, outprefix=os.path.join(work, f'ms{ms}'),
+                        optim_params=op, gurobi_params=gp_, ignore_precomputed_triangulation=False)
+            out.update({f'ms{ms}/{k}': v for k, v in rec.record_frame('res', res).items()})
+            out.update({f'ms{ms}/{k}': v for k, v in rec.record_model(fg.Model.last).items()})
+            out[f'ms{ms}/n_metacells'] = np.array([len(mc_a.metacell_df), len(mc_r.metacell_df)])
+            indiv = ref.metacell_utils.unpack_metacell_matches(res, mc_a.metacell_df, mc_r.metacell_df, aligned_df=a_df, ref_df=r_df,
+                                                               strategy='nearest', aligned_original_idx_col='Cell_Num',
+                                                               ref_original_idx_col='Cell_Num')
+            out.update({f'ms{ms}/{k}': v for k, v in rec.record_frame('unp', indiv[['Aligned_cell_id', 'Ref_cell_id']]).items()})
+            print(f"[tongue MS={ms}] {len(mc_a.metacell_df)} x {len(mc_r.metacell_df)} metacells, windows {sorted(res['window_id'].unique().tolist())}, "
+                  f"{len(res)} matches -> {len(indiv)} cell matches")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(os.path.join(OUT, 'real_tongue.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'tongue':
+        tongue_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'tiler':
         window_tiler_case()
         return
