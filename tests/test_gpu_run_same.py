@@ -494,3 +494,49 @@ def test_real_tongue_flow_equals_reference(gp, ms, tmp_path, monkeypatch):
                                              aligned_original_idx_col="Cell_Num", ref_original_idx_col="Cell_Num")
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("unp", indiv[["Aligned_cell_id", "Ref_cell_id"]]).items()}, g,
                            prefix=f"ms{ms}/unp_")
+
+
+@pytest.mark.parametrize("ms", [1, 3])
+def test_real_heart_flow_equals_reference(gp, ms, tmp_path, monkeypatch):
+    """Real data with built-in degeneracy (examples/heart: ISS spots on a regular 242.5-unit lattice -> co-circular Delaunay
+    input and equal distances; percentages from small counts -> exact zeros and exact cost ties), 13 windows with merges."""
+    import pandas as pd
+    import run_same_record as rec
+    import same_amd
+
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("real_heart")
+    types = ["Smooth muscle cells", "Fibroblast", "Atrial cardiomyocytes", "Cardiomyocytes", "Endothelium", "Epicardium",
+             "Schwan progenitors", "Ventricular cardiomyocytes"]
+
+    def frame(prefix):
+        cols = [str(c) for c in g[f"{prefix}_columns"]]
+        return pd.DataFrame({c: g[f"{prefix}__{c}"] for c in cols})
+
+    a_df, r_df = frame("query"), frame("ref")
+    for df in (a_df, r_df):
+        df.rename(columns={f"{ct}_percentage": ct for ct in types}, inplace=True)
+        df["X"] = df["spot_x"] + 75
+        df["Y"] = df["spot_y"] + 75
+        df["cell_type"] = df[types].idxmax(axis=1)
+    mck = dict(cell_type_col="cell_type", original_idx_col="Cell_Num", x_col="X", y_col="Y", max_metacell_size=ms, r_max=500,
+               min_angle_deg=15, use_alpha_shape=False, return_object=True, verbose=False)
+    mc_a = same_amd.greedy_triangle_collapse(a_df, **mck)
+    mc_r = same_amd.greedy_triangle_collapse(r_df, **mck)
+    assert [len(mc_a.metacell_df), len(mc_r.metacell_df)] == g[f"ms{ms}/n_metacells"].tolist()
+    gpar = same_amd.init_gurobi_params()
+    gpar.update(mip_gap=0.05, lazy_allowed_flip_fraction=0.05, time_limit=7200, init_method="greedy")
+    op = same_amd.init_optim_params()
+    op.update({"window_size": 4000, "overlap": 100, "min_cells_per_window": 30, "max_matches": 1, "radius": 500, "knn": 8,
+               "no_match_penalty": 10000, "penalty_coeff": 100, "dist_ct_coeff": 1, "delaunay_penalty": 10,
+               "cell_id_col": "metacell_id", "ref_metacell_match_multiplier": ms, "ignore_same_type_triangles": True,
+               "lazy_constraints": True, "min_angle_deg": 15})
+    res = same_amd.sliding_window_matching(mc_r, mc_a, commonCT=types, outprefix=str(tmp_path / f"ms{ms}"), optim_params=op,
+                                           gurobi_params=gpar, ignore_precomputed_triangulation=False)
+    rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix=f"ms{ms}/res_")
+    model = rec.record_model(gp.Model.last)
+    rec.assert_same_record(model, {f"m/{k}": g[f"ms{ms}/{k}"] for k in model}, prefix="m/")
+    indiv = same_amd.unpack_metacell_matches(res, mc_a.metacell_df, mc_r.metacell_df, aligned_df=a_df, ref_df=r_df, strategy="nearest",
+                                             aligned_original_idx_col="Cell_Num", ref_original_idx_col="Cell_Num")
+    rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("unp", indiv[["Aligned_cell_id", "Ref_cell_id"]]).items()}, g,
+                           prefix=f"ms{ms}/unp_")

@@ -33,13 +33,13 @@ synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 OUT = os.path.join(ROOT, "tests", "golden")
-if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler", "tongue"):
+if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler", "tongue", "heart"):
     # solver-facing fixtures: the reference's model builders / run_same talk to the recording solver double of the tests
     # (gurobipy itself is proprietary and absent), installed as `gurobipy` BEFORE the reference modules bind its names
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fake_gurobipy as _fg
     _fg.install()
-ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler", "tongue"))
+ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler", "tongue", "heart"))
 
 
 def quiet(fn, *a, **k):
@@ -847,8 +847,72 @@ def tongue_case():
     np.savez_compressed(os.path.join(OUT, 'real_tongue.npz'), **out)
 
 
+HEART_TYPES = ['Smooth muscle cells', 'Fibroblast', 'Atrial cardiomyocytes', 'Cardiomyocytes', 'Endothelium', 'Epicardium',
+               'Schwan progenitors', 'Ventricular cardiomyocytes']
+
+
+def heart_case():
+    """Real data: examples/heart (ISS heart spots; percentages built from small cell counts, so exact zeros and exact cost
+    ties abound; spots sit on a 242.5-unit lattice, so Delaunay input is degenerate and equal distances are common) driven as
+    its run_same.sh drives it (parameters :39-52, calls :80-126; the `_percentage` suffix of the CSV columns is stripped as the
+    example's notebook does), with MS=1 and MS=3, through the recording solver double.  radius and r_max are 500 instead of the
+    script's 50: in spot_x/spot_y units 50 is below the lattice spacing, and the reference itself then dies with IndexError at
+    src/same.py:1253 on the first window whose nodes are all unconstrained."""
+    import fake_gurobipy as fg
+    import run_same_record as rec
+    import shutil
+    import tempfile
+
+    d = os.path.join(REF_ROOT, 'examples', 'heart', 'data')
+    raw_a = pd.read_csv(os.path.join(d, 'queryAD_valis.csv'))
+    raw_r = pd.read_csv(os.path.join(d, 'refAD_valis.csv'))
+    out = {}
+    out.update(rec.record_frame('query', raw_a))
+    out.update(rec.record_frame('ref', raw_r))
+    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        for ms in (1, 3):
+            a_df, r_df = raw_a.copy(), raw_r.copy()
+            for df in (a_df, r_df):
+                df.rename(columns={f'{ct}_percentage': ct for ct in HEART_TYPES}, inplace=True)
+                df['X'] = df['spot_x'] + 75
+                df['Y'] = df['spot_y'] + 75
+                df['cell_type'] = df[HEART_TYPES].idxmax(axis=1)
+            mck = dict(cell_type_col='cell_type', original_idx_col='Cell_Num', x_col='X', y_col='Y', max_metacell_size=ms, r_max=500,
+                       min_angle_deg=15, use_alpha_shape=False, return_object=True)
+            mc_a = quiet(ref.metacell_utils.greedy_triangle_collapse, a_df, **mck)
+            mc_r = quiet(ref.metacell_utils.greedy_triangle_collapse, r_df, **mck)
+            gp_ = ref.same.init_gurobi_params()
+            gp_.update(mip_gap=0.05, lazy_allowed_flip_fraction=0.05, time_limit=7200, init_method='greedy')
+            op = ref.same.init_optim_params()
+            op.update({'window_size': 4000, 'overlap': 100, 'min_cells_per_window': 30, 'max_matches': 1, 'radius': 500, 'knn': 8,
+                       'no_match_penalty': 10000, 'penalty_coeff': 100, 'dist_ct_coeff': 1, 'delaunay_penalty': 10,
+                       'cell_id_col': 'metacell_id', 'ref_metacell_match_multiplier': ms, 'ignore_same_type_triangles': True,
+                       'lazy_constraints': True, 'min_angle_deg': 15})
+            res = quiet(ref.same.sliding_window_matching, mc_r, mc_a, commonCT=HEART_TYPES, outprefix=os.path.join(work, f'ms{ms}'),
+                        optim_params=op, gurobi_params=gp_, ignore_precomputed_triangulation=False)
+            out.update({f'ms{ms}/{k}': v for k, v in rec.record_frame('res', res).items()})
+            out.update({f'ms{ms}/{k}': v for k, v in rec.record_model(fg.Model.last).items()})
+            out[f'ms{ms}/n_metacells'] = np.array([len(mc_a.metacell_df), len(mc_r.metacell_df)])
+            indiv = ref.metacell_utils.unpack_metacell_matches(res, mc_a.metacell_df, mc_r.metacell_df, aligned_df=a_df, ref_df=r_df,
+                                                               strategy='nearest', aligned_original_idx_col='Cell_Num',
+                                                               ref_original_idx_col='Cell_Num')
+            out.update({f'ms{ms}/{k}': v for k, v in rec.record_frame('unp', indiv[['Aligned_cell_id', 'Ref_cell_id']]).items()})
+            print(f"[heart MS={ms}] {len(mc_a.metacell_df)} x {len(mc_r.metacell_df)} metacells, windows {sorted(res['window_id'].unique().tolist())}, "
+                  f"{len(res)} matches -> {len(indiv)} cell matches")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(os.path.join(OUT, 'real_heart.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'heart':
+        heart_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'tongue':
         tongue_case()
         return
