@@ -252,6 +252,16 @@ def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None
         prep = prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay, aligned_delaunay_vertex_col,
                                    optim_params, gurobi_params, ignore_precomputed_triangulation)
         op, gpar = prep.optim_params, prep.gurobi_params
+        if len(prep.valid_pairs) == 0:
+            # every node was unconstrained under the caller's triangulation, so nothing is left to match.  (The reference
+            # builds and "solves" the empty model and then dies with IndexError at src/same.py:1253; the no-solution return
+            # of :1474-1477 is the usable form of the same outcome, and lets sliding windows carry on.)
+            print("No valid_pairs left after removing unconstrained nodes; nothing to optimise")
+            out_df = pd.DataFrame()
+            if outprefix:
+                os.makedirs(outprefix, exist_ok=True)
+                out_df.to_csv(os.path.join(outprefix, "matches_df.csv"), index=False)
+            return out_df, {}
         aligned_df, ref_df = prep.aligned_df, prep.ref_df
         valid_pairs, c, tris = prep.valid_pairs, prep.costs, prep.aligned_delaunay
         n_aligned, n_ref = prep.n_aligned, prep.n_ref

@@ -113,6 +113,16 @@ def test_precomputed_triangulation_and_unconstrained_nodes(gp):
     # every remaining node has at least one triangle that passed radius+angle, by construction
     assert len(prep.costs) == len(prep.valid_pairs) and len(prep.triangle_weights) == len(tri)
 
+    # a triangulation under which EVERY node is unconstrained: nothing is left to match; run_same returns its no-solution
+    # pair instead of the reference's IndexError (src/same.py:1253), so a window pipeline carries on
+    class Empty(MC):
+        metacell_delaunay = np.zeros((0, 3), dtype=np.int64)
+
+    prep0 = same_amd.prepare_same_inputs(r_df, Empty(), cols, optim_params=dict(radius=10, knn=8, cell_id_col=None), verbose=False)
+    assert len(prep0.valid_pairs) == 0 and prep0.n_aligned == 0 and len(prep0.costs) == 0 and len(prep0.aligned_delaunay) == 0
+    out_df, var_out = same_amd.run_same(r_df, Empty(), cols, optim_params=dict(radius=10, knn=8, cell_id_col=None))
+    assert len(out_df) == 0 and var_out == {}
+
 
 def test_sliding_window_matching(gp, tmp_path):
     import same_amd
