@@ -500,8 +500,8 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
     from .windows import window_plan
 
     ref_cell_type_col = moving_cell_type_col = "cell_type"
-    optim_params = {} if optim_params is None else optim_params
-    gurobi_params = {} if gurobi_params is None else gurobi_params
+    optim_params = dict(optim_params or {})
+    gurobi_params = dict(gurobi_params or {})
     if hasattr(ref, "metacell_df"):
         mc_ref = ref
         ref = mc_ref.metacell_df
