@@ -88,6 +88,26 @@ def test_run_same_errors(gp):
         same_amd.run_same(r_df, a_df, cols, aligned_delaunay=np.zeros((0, 3)), aligned_delaunay_vertex_col="nope")
 
 
+def test_error_conventions_of_the_boundary(gp):
+    """the ValueErrors the reference raises at the boundary (src/same.py:258, :451-457, :463-481)."""
+    import same_amd
+
+    g = load_golden("cfg1_500")
+    a_df, r_df, cols = frames_from_golden(g)
+    with pytest.raises(ValueError, match="must have shape"):                       # bad triangle shape
+        same_amd.run_same(r_df, a_df, cols, aligned_delaunay=np.zeros((4, 2), dtype=int), optim_params=dict(radius=10))
+    other = r_df.copy()
+    other["cell_type"] = np.where(np.arange(len(other)) % 2 == 0, "only_in_ref", other["cell_type"])
+    with pytest.raises(ValueError, match="Cell type categories differ"):           # sliding windows check the category sets
+        same_amd.sliding_window_matching(other, a_df, commonCT=cols, optim_params=dict(radius=10))
+    with pytest.raises(ValueError, match="not present as probability/one-hot columns"):   # commonCT inferred from cell_type names
+        same_amd.sliding_window_matching(r_df.assign(cell_type="zz"), a_df.assign(cell_type="zz"), optim_params=dict(radius=10))
+    with pytest.raises(ValueError, match="cell_type columns were not found"):
+        same_amd.sliding_window_matching(r_df.drop(columns=["cell_type"]), a_df.drop(columns=["cell_type"]), optim_params=dict(radius=10))
+    with pytest.raises(ValueError, match="Unknown init_method"):
+        same_amd.run_same(r_df, a_df, cols, optim_params=dict(radius=10), gurobi_params=dict(init_method="bogus"))
+
+
 def test_precomputed_triangulation_and_unconstrained_nodes(gp):
     """Caller-supplied triangles in vertex-id space (MetaCell duck type): remap, filter, drop unconstrained nodes."""
     import same_amd
