@@ -32,7 +32,18 @@ def compact_pairs(aligned_df, ref_df, knn_pairs):
 
 
 def find_knn_within_radius(aligned_df, ref_df, radius=25, knn=5, verbose=True, ctx=None):
-    idx, _, _ = ops.knn_prune(_xy(aligned_df), _xy(ref_df), radius, knn, want_d2=False, ctx=ctx)
+    axy, rxy = _xy(aligned_df), _xy(ref_df)
+    # the argument checks cKDTree makes for the reference (src/utils.py:714,722), with its messages
+    if not np.isfinite(rxy).all():
+        raise ValueError("data must be finite, check for nan or inf values")
+    if len(rxy) and not np.isfinite(axy).all():
+        raise ValueError("'x' must be finite, check for nan or inf values")
+    radius = float(radius)
+    if radius != radius or int(knn) <= 0 or len(rxy) == 0:   # NaN radius / knn=0 select nothing there (ValueError upstream in run_same)
+        idx = np.full((len(axy), 1), -1, np.int32)
+    else:
+        # cKDTree compares squared distances, so a negative radius acts as its magnitude
+        idx, _, _ = ops.knn_prune(axy, rxy, abs(radius), knn, want_d2=False, ctx=ctx)
     knn_pairs = pairs_from_padded(idx)
     if verbose:
         print(f"Number of valid pairs after knn: {len(knn_pairs)}")

@@ -197,3 +197,20 @@ def test_plain_c_program_links_against_the_abi(tmp_path):
         assert r.returncode == 2 and "no usable GPU" in r.stderr
     else:
         assert r.returncode == 0 and "flipped" in r.stdout
+
+
+def test_knn_argument_checks_mirror_ckdtree():
+    """Non-finite coordinates raise what cKDTree raises for the reference; a NaN radius or knn=0 selects nothing.  All of it is
+    decided on the host before any device call, so it runs without a GPU."""
+    import pandas as pd
+    from same_amd.knn import find_knn_within_radius
+
+    a = pd.DataFrame({"X": [0.0, 1.0], "Y": [0.0, 1.0]})
+    r = pd.DataFrame({"X": [0.0, 2.0], "Y": [0.5, np.nan]})
+    with pytest.raises(ValueError, match="data must be finite"):
+        find_knn_within_radius(a, r, 5, 2, verbose=False)
+    with pytest.raises(ValueError, match="'x' must be finite"):
+        find_knn_within_radius(r, a, 5, 2, verbose=False)
+    for radius, knn in ((float("nan"), 3), (5.0, 0)):
+        na, nr, pairs = find_knn_within_radius(a, a, radius, knn, verbose=False)
+        assert len(na) == 0 and len(nr) == 0 and len(pairs) == 0

@@ -661,3 +661,14 @@ def test_plain_c_abi_demo_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "checked 4 triangles" in r.stdout and "bad pair -> -34" in r.stdout
     assert sum(line.startswith("pair (") for line in r.stdout.splitlines()) >= 6
+
+
+def test_negative_radius_acts_as_its_magnitude(hip):
+    """cKDTree compares squared distances (the reference's query_ball_point with r=-10 returns the r=10 ball)."""
+    from conftest import frames_from_golden, load_golden
+
+    g = load_golden("cfg1_500")
+    a_df, r_df, _ = frames_from_golden(g)
+    pos = hip.find_knn_within_radius(a_df, r_df, 10, 8, verbose=False)
+    neg = hip.find_knn_within_radius(a_df, r_df, -10, 8, verbose=False)
+    assert np.array_equal(pos[2], neg[2]) and len(pos[0]) == len(neg[0]) and np.array_equal(pos[2], g["pairs"])
