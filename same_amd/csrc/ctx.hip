@@ -25,7 +25,11 @@ int same_ctx_create(int device, same_ctx **out) {
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking);
+    // the gather overlaps a dense build that keeps every CU busy: give its stream the highest queue priority so the
+    // collective's few workgroups are dispatched as CUs free up instead of queueing behind ~77k dense blocks
+    int least = 0, greatest = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gathered, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
