@@ -288,6 +288,48 @@ __global__ __launch_bounds__(256) void padded_cost_kernel(
     out[q] = w * s + dcoef * dc;
 }
 
+// Same result, staged: a wave owns 64 consecutive slots.  One lane per slot gathering its own reference row makes every
+// load instruction touch 64 different cache lines; here the wave first copies its 64 rows into LDS with lanes running
+// along the rows (each load instruction covers ~3 rows = a handful of lines), then every lane walks its row in LDS in the
+// reference's left-to-right order.  Row pitch in LDS is T|1 doubles (odd: 2-way bank aliasing at worst).
+__global__ void padded_cost_lds_kernel(
+    const double *__restrict__ A, const double *__restrict__ R, int T, const double *__restrict__ axy,
+    const double *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
+    double w, double dcoef, double *__restrict__ out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int P = T | 1;
+    double *rows = lds + (size_t)wave * 64 * P;
+    int *jl = reinterpret_cast<int *>(lds + (size_t)waves * 64 * P) + wave * 64;
+    const int64_t q0 = ((int64_t)blockIdx.x * waves + wave) * 64;
+    if (q0 >= n_slots) return;                       // whole wave out of range (wave-uniform)
+    const int64_t q = q0 + lane;
+    const int j = q < n_slots ? idx[q] : -1;
+    jl[lane] = j;
+    __builtin_amdgcn_wave_barrier();                 // jl is written and read by this wave only
+    {   // element e = slot * T + t of the wave's 64 x T block, e = lane, lane + 64, ...: (slot, t) advanced without dividing
+        const int ds = 64 / T, dt = 64 - ds * T;
+        int sl = lane / T, t = lane - sl * T;
+        for (int it = 0; it < T; ++it) {
+            const int js = jl[sl];
+            rows[sl * P + t] = js >= 0 ? R[(int64_t)js * T + t] : 0.0;
+            sl += ds;
+            t += dt;
+            if (t >= T) { t -= T; ++sl; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (q >= n_slots) return;
+    if (j < 0) { out[q] = __builtin_inf(); return; }
+    const int64_t i = row_begin + q / k;
+    const double *a = A + i * T;
+    const double *r = rows + lane * P;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(a[t] - r[t]);
+    const double dc = __builtin_fabs(axy[2 * i] - rxy[2 * (int64_t)j]) + __builtin_fabs(axy[2 * i + 1] - rxy[2 * (int64_t)j + 1]);
+    out[q] = w * s + dcoef * dc;
+}
+
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -488,8 +530,16 @@ int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, 
     SAME_TRY(same_use(ctx));
     const int64_t n_slots = (row_end - row_begin) * k;
     if (n_slots == 0) return SAME_OK;
-    hipLaunchKernelGGL(padded_cost_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, ctx->stream, dA, dR, T,
-                       daxy, drxy, row_begin, n_slots, k, didx, w, w * 0.001, dout_cost);
+    static const int mode = env_int("SAME_PADDED_MODE", 1);   // 0 = one lane gathers its row from global, 1 = LDS-staged rows
+    const size_t per_wave = (size_t)64 * (T | 1) * sizeof(double) + 64 * sizeof(int);
+    int waves = (int)std::min<size_t>(4, (size_t)65536 / per_wave);
+    if (mode == 1 && T >= 2 && waves >= 1 && n_slots >= 64 * 64) {
+        hipLaunchKernelGGL(padded_cost_lds_kernel, dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
+                           ctx->stream, dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * 0.001, dout_cost);
+    } else {
+        hipLaunchKernelGGL(padded_cost_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, ctx->stream, dA, dR, T,
+                           daxy, drxy, row_begin, n_slots, k, didx, w, w * 0.001, dout_cost);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }

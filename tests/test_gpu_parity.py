@@ -672,3 +672,28 @@ def test_negative_radius_acts_as_its_magnitude(hip):
     pos = hip.find_knn_within_radius(a_df, r_df, 10, 8, verbose=False)
     neg = hip.find_knn_within_radius(a_df, r_df, -10, 8, verbose=False)
     assert np.array_equal(pos[2], neg[2]) and len(pos[0]) == len(neg[0]) and np.array_equal(pos[2], g["pairs"])
+
+
+@pytest.mark.parametrize("T,k,n_m,n_r", [(20, 32, 3000, 2500), (2, 8, 700, 900), (3, 5, 1000, 50), (37, 16, 800, 1200),
+                                         (127, 4, 1100, 300), (130, 4, 1100, 300), (1, 64, 90, 400), (0, 8, 600, 600), (20, 32, 100, 100)])
+def test_padded_cost_kernels_vs_oracle(hip, oracle, T, k, n_m, n_r, monkeypatch):
+    """same_padded_cost_f64_dev (the all-gather payload): LDS-staged kernel and the plain gather kernel against the oracle's
+    pair costs, for type counts on both sides of every dispatch boundary, ragged last waves and sub-blocks of rows."""
+    from same_amd import _lib
+
+    rng = np.random.default_rng(T * 1000 + k)
+    A, R = rng.gamma(0.4, 20.0, (n_m, T)), rng.gamma(0.4, 20.0, (n_r, T))
+    axy, rxy = rng.uniform(0, 200, (n_m, 2)), rng.uniform(0, 200, (n_r, 2))
+    idx = rng.integers(-1, n_r, (n_m, k)).astype(np.int32)
+    idx[rng.random((n_m, k)) < 0.3] = -1
+    ctx = _lib.default_context()
+    dA, dR, dax, drx, didx = (ctx.to_device(np.ascontiguousarray(x)) for x in (A, R, axy, rxy, idx))
+    for b, e in ((0, n_m), (17, n_m - 5), (n_m // 2, n_m // 2 + 1)):
+        dout = ctx.alloc(max(e - b, 1) * k * 8)
+        ctx.check(ctx.lib.same_padded_cost_f64_dev(ctx.handle, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, b, e, k, didx.ptr + b * k * 4, 0.75,
+                                                   dout.ptr), "same_padded_cost_f64_dev")
+        got = dout.download((e - b, k), np.float64)
+        rr, cc = np.nonzero(idx[b:e] >= 0)
+        want = np.full((e - b, k), np.inf)
+        want[rr, cc] = oracle.pair_cost_arrays(A, R, axy, rxy, np.column_stack((rr + b, idx[b:e][rr, cc])), 0.75)
+        assert np.array_equal(got, want), (T, k, b, e)
