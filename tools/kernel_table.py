@@ -12,7 +12,7 @@ Tr = int(line["config"]["workload"].split(" Delaunay")[0].split("+ ")[-1])
 bytes_of = {
     "dense_cost_kernel": 8 * n_r * rows + 8 * (T + 2) * (n_r + rows),
     "knn_grid_kernel": 16 * n_r * 3 + 16 * rows + 4 * k * rows + 4 * rows,
-    "padded_cost_kernel": rows * k * (2 * 8 * (T + 2) + 4 + 8),
+    "padded_cost_kernel": rows * k * (2 * 8 * (T + 2) + 4 + 8), "padded_cost_lds_kernel": rows * k * (2 * 8 * (T + 2) + 4 + 8),
     "bbox_kernel": 16 * n_r, "grid_count_kernel": 16 * n_r + 8 * n_r, "grid_scatter_kernel": 16 * n_r + 28 * n_r,
     "grid_scan_kernel": 8 * 16641,
     "tri_classify_kernel": Tr * (12 + 48 + 12 + 1 + 16), "tri_sign_weight_kernel": Tr * (12 + 48 + 24 + 1 + 8),
