@@ -314,3 +314,42 @@ def test_greedy_triangle_collapse(oracle, which):
     df, kw, num_cols, other_cols = metacell_inputs(which)
     mdf, tri, orig = oracle.greedy_triangle_collapse(df, **kw)
     check_metacells(g, 'seeded' if which == 'seeded' else f'q_{which}', mdf, tri, None if which == 'seeded' else orig, num_cols, other_cols)
+
+
+def test_oracle_reproduces_reference_run_same_model(oracle):
+    """CPU cross-check of the oracle against the reference's own run_same (tests/golden/run_same_mock.npz, 'lazy_greedy'):
+    pairs, triangles, objective coefficients (pair costs, triangle weights), greedy MIP start and the callback's cuts that the
+    reference handed to the recording solver double are what the oracle computes from the same frames."""
+    from scipy.spatial import Delaunay
+    from same_amd import synth
+
+    g = load_golden("run_same_mock")
+    P = "lazy_greedy/"
+    cells = synth.make_cells(300, 4, seed=41)
+    r_df = synth.to_frame(cells)
+    a_df = synth.to_frame(synth.make_jittered(cells, seed=42))
+    cols = synth.type_columns(4)
+    na, nr, pairs = oracle.find_knn_within_radius(a_df, r_df, 20, 4)
+    names = [str(n) for n in g[P + "var_names"]]
+    n_x = sum(n.startswith("x[") for n in names)
+    assert n_x == len(pairs) and sum(n.startswith("penalty[") for n in names) == len(nr) and sum(n.startswith("no_match[") for n in names) == len(na)
+    costs = np.array(oracle.pair_costs(na, nr, pairs, cols, 1))
+    assert np.array_equal(g[P + "objective"][:n_x], costs)                                  # c[idx] * x[idx]
+    xy = na[["X", "Y"]].values
+    kept = oracle.filter_triangles_by_radius(xy, Delaunay(xy).simplices, 20, aligned_df=na, ignore_same_type_triangles=True, min_angle_deg=15)
+    assert np.array_equal(np.asarray(kept, dtype=np.int64).reshape(-1, 3), g[P + "triangles"])
+    sign, weight = oracle.tri_sign_weight(xy, na["size"].to_numpy(dtype=float), kept)
+    q0 = names.index("q_tri[0]")
+    from same_amd.params import init_optim_params
+    dflt = init_optim_params()
+    assert np.array_equal(g[P + "objective"][q0:q0 + len(kept)], dflt["delaunay_penalty"] * weight)
+    chosen, unmatched = oracle.compute_mip_start_pairs(valid_pairs=pairs, costs=list(costs), n_aligned=len(na), n_ref=len(nr),
+                                                       aligned_sizes=na["size"].to_numpy(dtype=float),
+                                                       no_match_penalty=dflt["no_match_penalty"], max_matches=1, init_method="greedy",
+                                                       verbose=False)
+    start = np.zeros(n_x)
+    start[[q for _, _, q in chosen]] = 1.0
+    assert np.array_equal(g[P + "var_start"][:n_x], start)
+    checked, viol = oracle.lazy_orientation_sweep(start, pairs, kept, sign, nr[["X", "Y"]].to_numpy(dtype=float), len(na))
+    cut_q = [names[v] for row, coef in zip(g[P + "cut_term_var"], g[P + "cut_term_coef"]) for v, c in zip(row, coef) if v >= 0 and c < 0]
+    assert cut_q == [f"q_tri[{t}]" for t, _, _, _ in viol[:25]] and int(g[P + "lazy"][1]) == len(cut_q)
