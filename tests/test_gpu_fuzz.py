@@ -1,10 +1,13 @@
 """Seeded randomised sweep of small shapes: every kernel against the oracle on ragged sizes, duplicate points,
 exact ties, radii from tiny to whole-set, k up to 64, T up to 40, sparse and full matchings.  Cheap per case;
 the point is to visit shape/edge combinations the fixed fixtures do not."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROUNDS = int(os.environ.get("SAME_FUZZ_ROUNDS", "1"))   # soak runs: more rounds = more seeds (round 0 is the default suite)
 
 
 @pytest.fixture(scope="module")
@@ -27,108 +30,117 @@ def _points(rng, n, side, mode):
 
 
 def test_fuzz_knn_and_costs(ops, oracle):
-    rng = np.random.default_rng(2024)
-    for case in range(120):
-        n_m, n_r = int(rng.integers(1, 700)), int(rng.integers(1, 900))
-        if case % 10 == 0:
-            n_r = int(rng.integers(2100, 5000))  # above the grid threshold
-        T, k = int(rng.integers(0, 41)), int(rng.choice([1, 2, 5, 8, 31, 32, 33, 64]))
-        side = float(rng.choice([10.0, 100.0, 1000.0]))
-        radius = float(rng.choice([0.0, 0.5, 3.0, side / 10, side / 3, side * 2]))
-        axy, rxy = _points(rng, n_m, side, int(rng.integers(0, 4))), _points(rng, n_r, side, int(rng.integers(0, 4)))
-        idx, d2, cnt = ops.knn_prune(axy, rxy, radius, k)
-        oidx, od2, ocnt = oracle.knn_prune(axy, rxy, radius, k)
-        assert np.array_equal(idx, oidx) and np.array_equal(d2, od2) and np.array_equal(cnt, ocnt), (case, n_m, n_r, k, radius)
-        A = rng.gamma(0.3, 30.0, (n_m, T))
-        R = rng.gamma(0.3, 30.0, (n_r, T))
-        w = float(rng.choice([1.0, 0.25, 3.7]))
-        rr, cc = np.nonzero(idx >= 0)
-        pairs = np.column_stack((rr, idx[rr, cc])).astype(np.int32)
-        if len(pairs):
-            c = ops.pair_cost(A, R, axy, rxy, pairs, w)
-            assert np.array_equal(c, oracle.pair_cost_arrays(A, R, axy, rxy, pairs, w)), (case, T)
-        b, e = sorted(rng.integers(0, n_m + 1, 2))
-        D = ops.dense_cost(A, R, axy, rxy, w, int(b), int(e))
-        assert np.array_equal(D, oracle.dense_cost(A, R, axy, rxy, w, int(b), int(e))), (case, T, n_r, b, e)
-        if case % 4 == 0:
-            D32 = ops.dense_cost(A, R, axy, rxy, w, int(b), int(e), dtype=np.float32)
-            assert np.array_equal(D32, oracle.dense_cost(A, R, axy, rxy, w, int(b), int(e), dtype=np.float32)), (case, T)
+    for rnd in range(ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"knn/cost soak round {rnd}", flush=True)
+        rng = np.random.default_rng(2024 + 7919 * rnd)
+        for case in range(120):
+            n_m, n_r = int(rng.integers(1, 700)), int(rng.integers(1, 900))
+            if case % 10 == 0:
+                n_r = int(rng.integers(2100, 5000))  # above the grid threshold
+            T, k = int(rng.integers(0, 41)), int(rng.choice([1, 2, 5, 8, 31, 32, 33, 64]))
+            side = float(rng.choice([10.0, 100.0, 1000.0]))
+            radius = float(rng.choice([0.0, 0.5, 3.0, side / 10, side / 3, side * 2]))
+            axy, rxy = _points(rng, n_m, side, int(rng.integers(0, 4))), _points(rng, n_r, side, int(rng.integers(0, 4)))
+            idx, d2, cnt = ops.knn_prune(axy, rxy, radius, k)
+            oidx, od2, ocnt = oracle.knn_prune(axy, rxy, radius, k)
+            assert np.array_equal(idx, oidx) and np.array_equal(d2, od2) and np.array_equal(cnt, ocnt), (case, n_m, n_r, k, radius)
+            A = rng.gamma(0.3, 30.0, (n_m, T))
+            R = rng.gamma(0.3, 30.0, (n_r, T))
+            w = float(rng.choice([1.0, 0.25, 3.7]))
+            rr, cc = np.nonzero(idx >= 0)
+            pairs = np.column_stack((rr, idx[rr, cc])).astype(np.int32)
+            if len(pairs):
+                c = ops.pair_cost(A, R, axy, rxy, pairs, w)
+                assert np.array_equal(c, oracle.pair_cost_arrays(A, R, axy, rxy, pairs, w)), (case, T)
+            b, e = sorted(rng.integers(0, n_m + 1, 2))
+            D = ops.dense_cost(A, R, axy, rxy, w, int(b), int(e))
+            assert np.array_equal(D, oracle.dense_cost(A, R, axy, rxy, w, int(b), int(e))), (case, T, n_r, b, e)
+            if case % 4 == 0:
+                D32 = ops.dense_cost(A, R, axy, rxy, w, int(b), int(e), dtype=np.float32)
+                assert np.array_equal(D32, oracle.dense_cost(A, R, axy, rxy, w, int(b), int(e), dtype=np.float32)), (case, T)
 
 
 def test_fuzz_triangles_and_sweeps(ops, oracle):
     from scipy.spatial import Delaunay
-    rng = np.random.default_rng(77)
-    for case in range(80):
-        n, n_r = int(rng.integers(4, 900)), int(rng.integers(1, 900))
-        side = float(rng.choice([10.0, 200.0]))
-        xy = _points(rng, n, side, int(rng.integers(0, 3)))
-        try:
-            tris = Delaunay(xy).simplices.astype(np.int32)
-        except Exception:  # degenerate input for Qhull: use random triples (incl. repeated vertices)
-            tris = rng.integers(0, n, (int(rng.integers(1, 300)), 3)).astype(np.int32)
-        if case % 5 == 0:
-            tris = np.vstack([tris, rng.integers(0, n, (20, 3)).astype(np.int32)])  # arbitrary, possibly degenerate triples
-        rxy = _points(rng, n_r, side, int(rng.integers(0, 4)))
-        types = rng.integers(0, 3, n).astype(np.int32)
-        size = rng.integers(1, 5, n).astype(float)
-        mad = rng.choice([None, 0, 5, 15, 45, 60, 90])
-        mad = None if mad is None else float(mad)
-        radius = float(rng.choice([side / 20, side / 5, side * 3]))
-        en, thr = oracle.cos_threshold(mad)
-        tid = types if case % 2 else None
-        cls, perim, mc = ops.tri_classify(xy, tris, radius, en, thr, tid)
-        ocls, operim, omc = oracle.tri_classify(xy, tris, radius, mad, tid)
-        assert np.array_equal(cls, ocls) and np.array_equal(perim, operim) and np.array_equal(mc, omc, equal_nan=True), case
-        sign, wgt = ops.tri_sign_weight(xy, size, tris)
-        osign, owgt = oracle.tri_sign_weight(xy, size, tris)
-        assert np.array_equal(sign, osign) and np.array_equal(wgt, owgt), case
-        match = rng.integers(-1, n_r, n).astype(np.int32)
-        match[rng.random(n) < rng.choice([0.0, 0.3, 0.9])] = -1
-        sweep = ops.BoundSweep(tris, sign, rxy, n)
-        checked, viol, flag = sweep.sweep_match(match, want_flag=True)
-        och, oviol, oflag = oracle.orient_sweep(tris, sign, rxy, match)
-        assert checked == och and np.array_equal(viol, oviol) and np.array_equal(flag, oflag), case
-        e, tf, pf, counts = ops.xyorder_sweep(xy, rxy, tris, match)
-        oe, otf, opf, oc = oracle.xyorder_sweep(xy, rxy, tris, match)
-        assert np.array_equal(e, oe) and np.array_equal(tf, otf) and np.array_equal(pf, opf) and np.array_equal(counts, oc), case
-        b, a, m3, fl = ops.area_flip(xy, rxy, tris, match)
-        ob, oa, om3, ofl = oracle.area_flip(xy, rxy, tris, match)
-        assert np.array_equal(b, ob) and np.array_equal(a, oa, equal_nan=True) and np.array_equal(m3, om3) and np.array_equal(fl, ofl), case
-        mapped = np.where((match >= 0)[:, None], rxy[np.maximum(match, 0)], 0.0)
-        f, nt, nf = ops.tri_flip_stats(xy, mapped, (match >= 0), tris, tid)
-        of, ont, onf = oracle.tri_flip_stats(xy, mapped, (match >= 0), tris, tid)
-        assert np.array_equal(f, of) and np.array_equal(nt, ont) and np.array_equal(nf, onf), case
+    for rnd in range(ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"triangle/sweep soak round {rnd}", flush=True)
+        rng = np.random.default_rng(77 + 7919 * rnd)
+        for case in range(80):
+            n, n_r = int(rng.integers(4, 900)), int(rng.integers(1, 900))
+            side = float(rng.choice([10.0, 200.0]))
+            xy = _points(rng, n, side, int(rng.integers(0, 3)))
+            try:
+                tris = Delaunay(xy).simplices.astype(np.int32)
+            except Exception:  # degenerate input for Qhull: use random triples (incl. repeated vertices)
+                tris = rng.integers(0, n, (int(rng.integers(1, 300)), 3)).astype(np.int32)
+            if case % 5 == 0:
+                tris = np.vstack([tris, rng.integers(0, n, (20, 3)).astype(np.int32)])  # arbitrary, possibly degenerate triples
+            rxy = _points(rng, n_r, side, int(rng.integers(0, 4)))
+            types = rng.integers(0, 3, n).astype(np.int32)
+            size = rng.integers(1, 5, n).astype(float)
+            mad = rng.choice([None, 0, 5, 15, 45, 60, 90])
+            mad = None if mad is None else float(mad)
+            radius = float(rng.choice([side / 20, side / 5, side * 3]))
+            en, thr = oracle.cos_threshold(mad)
+            tid = types if case % 2 else None
+            cls, perim, mc = ops.tri_classify(xy, tris, radius, en, thr, tid)
+            ocls, operim, omc = oracle.tri_classify(xy, tris, radius, mad, tid)
+            assert np.array_equal(cls, ocls) and np.array_equal(perim, operim) and np.array_equal(mc, omc, equal_nan=True), case
+            sign, wgt = ops.tri_sign_weight(xy, size, tris)
+            osign, owgt = oracle.tri_sign_weight(xy, size, tris)
+            assert np.array_equal(sign, osign) and np.array_equal(wgt, owgt), case
+            match = rng.integers(-1, n_r, n).astype(np.int32)
+            match[rng.random(n) < rng.choice([0.0, 0.3, 0.9])] = -1
+            sweep = ops.BoundSweep(tris, sign, rxy, n)
+            checked, viol, flag = sweep.sweep_match(match, want_flag=True)
+            och, oviol, oflag = oracle.orient_sweep(tris, sign, rxy, match)
+            assert checked == och and np.array_equal(viol, oviol) and np.array_equal(flag, oflag), case
+            e, tf, pf, counts = ops.xyorder_sweep(xy, rxy, tris, match)
+            oe, otf, opf, oc = oracle.xyorder_sweep(xy, rxy, tris, match)
+            assert np.array_equal(e, oe) and np.array_equal(tf, otf) and np.array_equal(pf, opf) and np.array_equal(counts, oc), case
+            b, a, m3, fl = ops.area_flip(xy, rxy, tris, match)
+            ob, oa, om3, ofl = oracle.area_flip(xy, rxy, tris, match)
+            assert np.array_equal(b, ob) and np.array_equal(a, oa, equal_nan=True) and np.array_equal(m3, om3) and np.array_equal(fl, ofl), case
+            mapped = np.where((match >= 0)[:, None], rxy[np.maximum(match, 0)], 0.0)
+            f, nt, nf = ops.tri_flip_stats(xy, mapped, (match >= 0), tris, tid)
+            of, ont, onf = oracle.tri_flip_stats(xy, mapped, (match >= 0), tris, tid)
+            assert np.array_equal(f, of) and np.array_equal(nt, ont) and np.array_equal(nf, onf), case
 
 
 def test_fuzz_matching_from_x_and_greedy(ops, oracle):
-    rng = np.random.default_rng(5)
-    for case in range(60):
-        n_m, n_r = int(rng.integers(1, 400)), int(rng.integers(1, 400))
-        P = int(rng.integers(0, 3000))
-        pairs = np.column_stack((np.sort(rng.integers(0, n_m, P)), rng.integers(0, n_r, P))).astype(np.int32)
-        x = rng.random(P) * rng.choice([0.6, 1.0, 1.4])
-        tris = rng.integers(0, n_m, (int(rng.integers(1, 200)), 3)).astype(np.int32)
-        sign = rng.integers(-1, 2, len(tris)).astype(np.int8)
-        rxy = rng.uniform(0, 50, (n_r, 2))
-        sw = ops.BoundSweep(tris, sign, rxy, n_m, pairs)
-        checked, viol, match, pidx = sw.sweep_x(x)
-        omatch, opidx = oracle.matching_from_x(x, pairs.tolist(), n_m)
-        assert np.array_equal(match, omatch) and np.array_equal(pidx.astype(np.int64), opidx), case
-        och, oviol, _ = oracle.orient_sweep(tris, sign, rxy, omatch)
-        assert checked == och and np.array_equal(viol, oviol), case
-        costs = np.round(rng.gamma(2.0, 5.0, P), int(rng.choice([1, 6])))
-        prefer = rng.random(n_m) < 0.8
-        mp, _ = ops.greedy_match(pairs, costs, n_m, n_r, prefer.astype(np.uint8))
-        used_a, used_r, want = set(), set(), np.full(n_m, -1, np.int32)
-        for q in np.argsort(costs, kind="stable"):
-            i, j = int(pairs[q, 0]), int(pairs[q, 1])
-            if i in used_a or j in used_r or not prefer[i]:
-                continue
-            want[i] = q; used_a.add(i); used_r.add(j)
-        assert np.array_equal(mp, want), case
-        un = rng.uniform(1, 100, n_m)
-        assert np.array_equal(ops.pair_rowmin(pairs, costs, n_m),
-                              np.array([costs[pairs[:, 0] == i].min() if (pairs[:, 0] == i).any() else np.inf for i in range(n_m)])), case
-        o = np.empty((n_m, n_r + n_m))
-        oracle.lib().orc_assign_matrix(pairs, costs, P, un, n_m, n_r, 1e9, o.reshape(-1))
-        assert np.array_equal(ops.assign_matrix(pairs, costs, un, n_m, n_r, 1e9), o), case
+    for rnd in range(ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"matching soak round {rnd}", flush=True)
+        rng = np.random.default_rng(5 + 7919 * rnd)
+        for case in range(60):
+            n_m, n_r = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+            P = int(rng.integers(0, 3000))
+            pairs = np.column_stack((np.sort(rng.integers(0, n_m, P)), rng.integers(0, n_r, P))).astype(np.int32)
+            x = rng.random(P) * rng.choice([0.6, 1.0, 1.4])
+            tris = rng.integers(0, n_m, (int(rng.integers(1, 200)), 3)).astype(np.int32)
+            sign = rng.integers(-1, 2, len(tris)).astype(np.int8)
+            rxy = rng.uniform(0, 50, (n_r, 2))
+            sw = ops.BoundSweep(tris, sign, rxy, n_m, pairs)
+            checked, viol, match, pidx = sw.sweep_x(x)
+            omatch, opidx = oracle.matching_from_x(x, pairs.tolist(), n_m)
+            assert np.array_equal(match, omatch) and np.array_equal(pidx.astype(np.int64), opidx), case
+            och, oviol, _ = oracle.orient_sweep(tris, sign, rxy, omatch)
+            assert checked == och and np.array_equal(viol, oviol), case
+            costs = np.round(rng.gamma(2.0, 5.0, P), int(rng.choice([1, 6])))
+            prefer = rng.random(n_m) < 0.8
+            mp, _ = ops.greedy_match(pairs, costs, n_m, n_r, prefer.astype(np.uint8))
+            used_a, used_r, want = set(), set(), np.full(n_m, -1, np.int32)
+            for q in np.argsort(costs, kind="stable"):
+                i, j = int(pairs[q, 0]), int(pairs[q, 1])
+                if i in used_a or j in used_r or not prefer[i]:
+                    continue
+                want[i] = q; used_a.add(i); used_r.add(j)
+            assert np.array_equal(mp, want), case
+            un = rng.uniform(1, 100, n_m)
+            assert np.array_equal(ops.pair_rowmin(pairs, costs, n_m),
+                                  np.array([costs[pairs[:, 0] == i].min() if (pairs[:, 0] == i).any() else np.inf for i in range(n_m)])), case
+            o = np.empty((n_m, n_r + n_m))
+            oracle.lib().orc_assign_matrix(pairs, costs, P, un, n_m, n_r, 1e9, o.reshape(-1))
+            assert np.array_equal(ops.assign_matrix(pairs, costs, un, n_m, n_r, 1e9), o), case
