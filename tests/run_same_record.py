@@ -137,3 +137,21 @@ def tiler_inputs(cfg):
         df['Cell_Num_Old'] = np.arange(len(df)) + id0
         return df
     return frame(n_ref, 100000), frame(n_mov, 0)
+
+
+def random_run_same_config(q):
+    """Seeded parameter combination #q for the run_same sweep fixture (shared by the generator and the GPU test):
+    -> (n_cells, n_types, optim overrides, gurobi overrides)."""
+    rng = np.random.default_rng(9000 + q)
+    lazy = bool(rng.random() < 0.75)
+    op = dict(radius=float(rng.choice([12.0, 18.0, 25.0])), knn=int(rng.choice([2, 3]) if not lazy else rng.choice([3, 5, 8])),
+              min_angle_deg=[None, 0, 10, 15, 30][int(rng.integers(0, 5))],
+              ignore_same_type_triangles=bool(rng.random() < 0.5), ignore_knn_if_matched=bool(rng.random() < 0.4),
+              lazy_constraints=lazy, max_matches=int(rng.choice([1, 1, 2])), dist_ct_coeff=float(rng.choice([1.0, 0.5, 3.0])),
+              no_match_penalty=float(rng.choice([5.0, 100.0, 10000.0])), penalty_coeff=float(rng.choice([1.0, 100.0])),
+              delaunay_penalty=float(rng.choice([1.0, 5.0, 10.0])))
+    gp = dict(init_method=[None, "greedy", "hungarian"][int(rng.integers(0, 3))], lazy_allowed_flip_fraction=float(rng.choice([0.0, 0.05, 0.5])),
+              lazy_max_cuts_per_incumbent=int(rng.choice([3, 1000])), lazy_max_cuts=[None, 7][int(rng.integers(0, 2))])
+    if gp["init_method"] == "hungarian" and op["max_matches"] != 1:
+        gp["init_method"] = "greedy"            # the reference raises for hungarian with max_matches != 1 (tested separately)
+    return int(rng.choice([120, 180])), int(rng.choice([2, 3, 5])), op, gp

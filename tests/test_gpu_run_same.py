@@ -570,3 +570,22 @@ def test_real_heart_flow_equals_reference(gp, ms, tmp_path, monkeypatch):
                                              aligned_original_idx_col="Cell_Num", ref_original_idx_col="Cell_Num")
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("unp", indiv[["Aligned_cell_id", "Ref_cell_id"]]).items()}, g,
                            prefix=f"ms{ms}/unp_")
+
+
+def test_run_same_parameter_sweep_equals_reference(gp, tmp_path, monkeypatch):
+    """Sixteen seeded parameter combinations (triangle flags x KNN priority x lazy/eager x start methods x max_matches x
+    penalties x cut limits): every recorded array of the reference's run_same is reproduced (tests/golden/run_same_sweep.npz)."""
+    import run_same_record as rec
+    import same_amd
+    from same_amd import synth
+
+    monkeypatch.chdir(tmp_path)
+    g = load_golden("run_same_sweep")
+    for q in range(int(g["n_cfg"][0])):
+        n, T, op, gpar = rec.random_run_same_config(q)
+        cells = synth.make_cells(n, T, seed=700 + q)
+        r_df = synth.to_frame(cells)
+        a_df = synth.to_frame(synth.make_jittered(cells, seed=800 + q))
+        out_df, var_out = same_amd.run_same(r_df.copy(), a_df.copy(), synth.type_columns(T), outprefix=str(tmp_path / f"c{q}"),
+                                            optim_params=same_amd.init_optim_params(**op), gurobi_params=same_amd.init_gurobi_params(**gpar))
+        rec.assert_same_record(rec.record_run(out_df, var_out, gp.Model.last), g, prefix=f"c{q}/")

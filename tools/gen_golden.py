@@ -33,13 +33,13 @@ synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 OUT = os.path.join(ROOT, "tests", "golden")
-if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler", "tongue", "heart"):
+if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler", "tongue", "heart", "sweep"):
     # solver-facing fixtures: the reference's model builders / run_same talk to the recording solver double of the tests
     # (gurobipy itself is proprietary and absent), installed as `gurobipy` BEFORE the reference modules bind its names
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import fake_gurobipy as _fg
     _fg.install()
-ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler", "tongue", "heart"))
+ref = load_reference(with_run_same=len(sys.argv) > 1 and sys.argv[1] in ("runsame", "tiler", "tongue", "heart", "sweep"))
 
 
 def quiet(fn, *a, **k):
@@ -908,8 +908,41 @@ def heart_case():
     np.savez_compressed(os.path.join(OUT, 'real_heart.npz'), **out)
 
 
+def run_same_sweep_case(n_cfg=16):
+    """run_same through the solver double on seeded random PARAMETER COMBINATIONS (flags x penalties x start methods x lazy/eager):
+    per configuration the match table, var_out and the model are recorded exactly as in run_same_mock."""
+    import fake_gurobipy as fg
+    import run_same_record as rec
+    import shutil
+    import tempfile
+
+    out = {'n_cfg': np.array([n_cfg])}
+    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        for q in range(n_cfg):
+            n, T, op, gp_ = rec.random_run_same_config(q)
+            cells = synth.make_cells(n, T, seed=700 + q)
+            r_df = synth.to_frame(cells)
+            a_df = synth.to_frame(synth.make_jittered(cells, seed=800 + q))
+            out_df, var_out = quiet(ref.same.run_same, r_df.copy(), a_df.copy(), synth.type_columns(T), outprefix=os.path.join(work, f'c{q}'),
+                                    optim_params=ref.same.init_optim_params(**op), gurobi_params=ref.same.init_gurobi_params(**gp_))
+            r = rec.record_run(out_df, var_out, fg.Model.last)
+            out.update({f'c{q}/{k}': v for k, v in r.items()})
+            print(f"[sweep c{q}] n={n} T={T} lazy={op['lazy_constraints']} prio={op['ignore_knn_if_matched']} init={gp_['init_method']} "
+                  f"mm={op['max_matches']}: {len(out_df)} matches, {len(fg.Model.last.constrs)} constraints, {len(fg.Model.last.lazy)} cuts")
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+    np.savez_compressed(os.path.join(OUT, 'run_same_sweep.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
+        run_same_sweep_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'heart':
         heart_case()
         return
