@@ -697,3 +697,21 @@ def test_padded_cost_kernels_vs_oracle(hip, oracle, T, k, n_m, n_r, monkeypatch)
         want = np.full((e - b, k), np.inf)
         want[rr, cc] = oracle.pair_cost_arrays(A, R, axy, rxy, np.column_stack((rr + b, idx[b:e][rr, cc])), 0.75)
         assert np.array_equal(got, want), (T, k, b, e)
+
+
+def test_dense_cost_f32_dev_entry_point(hip, oracle):
+    """same_dense_cost_f32_dev (resident operands, cfg-5 fp32 variant): equals the host-buffer form and the oracle's fp32 build."""
+    from same_amd import _lib, ops
+
+    rng = np.random.default_rng(8)
+    n_m, n_r, T = 700, 1000, 12
+    A, R = rng.gamma(0.4, 20.0, (n_m, T)).astype(np.float32), rng.gamma(0.4, 20.0, (n_r, T)).astype(np.float32)
+    axy, rxy = rng.uniform(0, 200, (n_m, 2)).astype(np.float32), rng.uniform(0, 200, (n_r, 2)).astype(np.float32)
+    ctx = _lib.default_context()
+    dA, dR, dax, drx = (ctx.to_device(x) for x in (A, R, axy, rxy))
+    b, e = 33, 650
+    out = ctx.alloc((e - b) * n_r * 4)
+    ctx.check(ctx.lib.same_dense_cost_f32_dev(ctx.handle, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_r, b, e, 0.5, out.ptr, n_r), "same_dense_cost_f32_dev")
+    got = out.download((e - b, n_r), np.float32)
+    assert np.array_equal(got, ops.dense_cost(A, R, axy, rxy, 0.5, b, e, dtype=np.float32))
+    assert np.array_equal(got, oracle.dense_cost(A, R, axy, rxy, 0.5, b, e, dtype=np.float32))
