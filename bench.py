@@ -288,7 +288,14 @@ def main():
             list(ex.map(lambda be: orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(be[0]), int(be[1])),
                         zip(cuts[:-1], cuts[1:])))
         t_mt = time.perf_counter() - m0
-        cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port",
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+        except OSError:
+            pass
+        cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
+               "host_cpus": os.cpu_count(),
                "dense_only_threaded": {"value": S * n_ref / t_mt, "unit": "cell-pairs/s", "cores": nthr,
                                        "sample": f"dense cost of the same {S} rows split over {nthr} host threads"},
                "sample": f"rows [0,{S}) of {rows} x {n_ref} refs: dense cost + knn prune + pair costs "
