@@ -329,6 +329,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "dense_cost_kernel<double,20,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3,
+                         # secondary ceiling: (2T+5) fp64 VALU lane-instructions per output against the vector issue
+                         # peak (78.6 TFLOP/s fp64 counts an FMA as two -> 39.3 T lane-instructions/s)
+                         "valu_fp64": {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": (2 * T + 5) * float(n_ref) * rows / t_dense / 1e12,
+                                       "peak_Tinstr_s": 39.3, "frac": (2 * T + 5) * float(n_ref) * rows / t_dense / 39.3e12},
                          "measured_ceilings": {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
                                                "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
                                                "frac_of_T0_store_rate": (dense_bytes / t_dense) / (8.0 * n_ref * rows / t_store_only)},
