@@ -1,6 +1,8 @@
 """Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
 
-Run:  python3 -B tools/gen_golden.py
+Run:  python3 -B tools/gen_golden.py            (the pre-MIP fixtures: synthetic_example, cfg1_500, cfg2_small, simulated_*, adversarial)
+      python3 -B tools/gen_golden.py <family>   (eval | metacell | unpack | eager | runsame | tiler | sweep | tongue | heart)
+      python3 -B tools/gen_golden.py all        (everything; ~8 min, dominated by the reference's own Python loops)
 Needs /root/reference; never runs on the GPU box.  Fixtures are data only: the inputs and
 the outputs the reference's own functions produced for them.  Functions that exist in the
 reference are called as-is (find_knn_within_radius, filter_triangles_by_radius,
@@ -938,8 +940,17 @@ def run_same_sweep_case(n_cfg=16):
     np.savez_compressed(os.path.join(OUT, 'run_same_sweep.npz'), **out)
 
 
+SUBCOMMANDS = ("base", "eval", "metacell", "unpack", "eager", "runsame", "tiler", "sweep", "tongue", "heart")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'all':      # every fixture, one process per family (the solver-facing ones install the double first)
+        import subprocess
+        for sub in SUBCOMMANDS:
+            print(f"== {sub}", flush=True)
+            subprocess.run([sys.executable, '-B', os.path.abspath(__file__)] + ([] if sub == 'base' else [sub]), check=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
         run_same_sweep_case()
         return
