@@ -21,8 +21,14 @@ def pairs_from_padded(idx, row_offset=0):
 
 def compact_pairs(aligned_df, ref_df, knn_pairs):
     """src/utils.py:734-742."""
-    ua, inv_a = np.unique(knn_pairs[:, 0], return_inverse=True)
-    ur, inv_r = np.unique(knn_pairs[:, 1], return_inverse=True)
+    # np.unique(..., return_inverse=True) of row / ref indices, without sorting: indices are positions in the frames
+    def _unique_inverse(col, n):
+        used = np.zeros(n, dtype=bool)
+        used[col] = True
+        return np.flatnonzero(used), (np.cumsum(used) - 1)[col]
+
+    ua, inv_a = _unique_inverse(knn_pairs[:, 0], len(aligned_df)) if len(knn_pairs) else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    ur, inv_r = _unique_inverse(knn_pairs[:, 1], len(ref_df)) if len(knn_pairs) else (np.zeros(0, np.int64), np.zeros(0, np.int64))
     new_aligned_df = aligned_df.iloc[ua].reset_index(drop=True)
     new_ref_df = ref_df.iloc[ur].reset_index(drop=True)
     new_valid_pairs = np.column_stack((inv_a.reshape(-1), inv_r.reshape(-1))).astype(np.int64)
