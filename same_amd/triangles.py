@@ -156,7 +156,9 @@ def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignor
             first = np.unique(v_sorted, return_index=True)[1]
             best_of = dict(zip(v_sorted[first].tolist(), t_sorted[first].tolist()))
             missing = np.flatnonzero(~has_kept & any_valid)
-            added_set = set(map(tuple, tris[keep_idx].tolist()))
+            # the reference de-duplicates against every triangle kept so far (src/helpers.py:375-381); a candidate contains a
+            # node that no kept triangle contains, so it can only collide with a triangle added in this pass
+            added_set = set()
             added = 0
             for i in missing.tolist():
                 t = best_of.get(i)
