@@ -43,7 +43,7 @@ extern "C" {
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
 #define SAME_ABI_VERSION 1
-#define SAME_MAX_KNN 64      /* largest k supported by the prune kernel */
+#define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
 typedef struct same_ctx same_ctx;

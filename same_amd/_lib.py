@@ -21,7 +21,7 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-MAX_KNN = 64
+MAX_KNN = 448
 MAX_TYPES = 4096
 
 # name -> argtypes, exactly the declarations of include/same_hip.h (restype int unless noted)

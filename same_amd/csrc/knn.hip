@@ -19,17 +19,21 @@
 
 namespace {
 
-constexpr int KNN_RW = 8;      // aligned rows per wave
 constexpr int KNN_WAVES = 4;   // waves per block
-constexpr int KNN_CAP = 128;   // candidate slots per row; needs k + 64 <= KNN_CAP
+// Candidate slots per row (CAP) and aligned rows per wave (RW) come in two sizes: CAP needs k + 64 <= CAP.
+//   k <= 64  : CAP 128, 8 rows per wave  (the reference default is k = 8)
+//   k <= 448 : CAP 512, 2 rows per wave  (same algorithm; LDS per block 48 KB)
+constexpr int KNN_CAP_SMALL = 128, KNN_RW_SMALL = 8, KNN_CAP_LARGE = 512, KNN_RW_LARGE = 2;
 
+template <int CAP>
 struct RowList {
-    double d2[KNN_CAP];
-    int32_t j[KNN_CAP];
+    double d2[CAP];
+    int32_t j[CAP];
 };
 
 // rank of candidate (d, j) among the m candidates of `L` under (d2, j) ascending
-__device__ __forceinline__ int rank_of(const RowList &L, int m, double d, int32_t j) {
+template <int CAP>
+__device__ __forceinline__ int rank_of(const RowList<CAP> &L, int m, double d, int32_t j) {
     int rank = 0;
     for (int q = 0; q < m; ++q) {
         const double dq = L.d2[q];   // uniform address: LDS broadcast
@@ -40,14 +44,15 @@ __device__ __forceinline__ int rank_of(const RowList &L, int m, double d, int32_
 }
 
 // keep the best min(m, k) candidates, sorted, in slots [0, min(m,k))
-__device__ __forceinline__ int prune_in_place(RowList &L, int m, int k, int lane) {
-    double d[KNN_CAP / 64];
-    int32_t j[KNN_CAP / 64];
-    int rk[KNN_CAP / 64];
+template <int CAP>
+__device__ __forceinline__ int prune_in_place(RowList<CAP> &L, int m, int k, int lane) {
+    double d[CAP / 64];
+    int32_t j[CAP / 64];
+    int rk[CAP / 64];
 #pragma unroll
-    for (int p = 0; p < KNN_CAP / 64; ++p) {
+    for (int p = 0; p < CAP / 64; ++p) {
         const int c = lane + 64 * p;
-        rk[p] = KNN_CAP;
+        rk[p] = CAP;
         if (c < m) {
             d[p] = L.d2[c];
             j[p] = L.j[c];
@@ -56,21 +61,22 @@ __device__ __forceinline__ int prune_in_place(RowList &L, int m, int k, int lane
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every read above has landed before the overwrite
 #pragma unroll
-    for (int p = 0; p < KNN_CAP / 64; ++p)
+    for (int p = 0; p < CAP / 64; ++p)
         if (rk[p] < k) { L.d2[rk[p]] = d[p]; L.j[rk[p]] = j[p]; }
     return m < k ? m : k;
 }
 
+template <int KNN_CAP, int KNN_RW>
 __global__ __launch_bounds__(64 * KNN_WAVES) void knn_prune_kernel(
     const double *__restrict__ axy, const double *__restrict__ rxy, int64_t n_r, int64_t row_begin,
     int64_t row_end, double r2, int k, int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
     int32_t *__restrict__ out_cnt) {
-    __shared__ RowList lists[KNN_WAVES * KNN_RW];
+    __shared__ RowList<KNN_CAP> lists[KNN_WAVES * KNN_RW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t row0 = row_begin + ((int64_t)blockIdx.x * KNN_WAVES + wave) * KNN_RW;
     if (row0 >= row_end) return;
-    RowList *L = lists + wave * KNN_RW;
+    RowList<KNN_CAP> *L = lists + wave * KNN_RW;
 
     double ax[KNN_RW], ay[KNN_RW];
     int cnt[KNN_RW];
@@ -223,16 +229,17 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const double *__restr
     sidx[pos] = (int32_t)j;
 }
 
+template <int KNN_CAP>
 __global__ __launch_bounds__(64 * KNN_WAVES) void knn_grid_kernel(
     const double *__restrict__ axy, const double *__restrict__ sxy, const int32_t *__restrict__ sidx,
     const unsigned *__restrict__ start, GridDesc g, int64_t row_begin, int64_t row_end, double r2, int k,
     int32_t *__restrict__ out_idx, double *__restrict__ out_d2, int32_t *__restrict__ out_cnt) {
-    __shared__ RowList lists[KNN_WAVES];
+    __shared__ RowList<KNN_CAP> lists[KNN_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t i = row_begin + (int64_t)blockIdx.x * KNN_WAVES + wave;
     if (i >= row_end) return;
-    RowList &L = lists[wave];
+    RowList<KNN_CAP> &L = lists[wave];
     const double ax = axy[2 * i], ay = axy[2 * i + 1];
     // unclamped cell of the aligned point; neighbours clipped to the grid
     const double fcx = __builtin_floor((ax - g.x0) * g.inv_cell), fcy = __builtin_floor((ay - g.y0) * g.inv_cell);
@@ -348,8 +355,12 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
     hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dhist, cells);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank,
                        dsxy, dsidx);
-    hipLaunchKernelGGL(knn_grid_kernel, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream, daxy, dsxy,
-                       dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
+    if (k <= KNN_CAP_SMALL - 64)
+        hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_SMALL>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
+                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
+    else
+        hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_LARGE>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
+                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -358,10 +369,15 @@ int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int6
                      double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
     const int64_t rows = re - rb;
     if (rows == 0) return SAME_OK;
-    const int64_t blocks = ceil_div(rows, KNN_WAVES * KNN_RW);
+    const bool small = k <= KNN_CAP_SMALL - 64;
+    const int64_t blocks = ceil_div(rows, KNN_WAVES * (small ? KNN_RW_SMALL : KNN_RW_LARGE));
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
-    hipLaunchKernelGGL(knn_prune_kernel, dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream, daxy, drxy, n_r, rb, re,
-                       radius * radius, k, didx, dd2, dcnt);
+    if (small)
+        hipLaunchKernelGGL((knn_prune_kernel<KNN_CAP_SMALL, KNN_RW_SMALL>), dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream,
+                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt);
+    else
+        hipLaunchKernelGGL((knn_prune_kernel<KNN_CAP_LARGE, KNN_RW_LARGE>), dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream,
+                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }

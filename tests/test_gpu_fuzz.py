@@ -38,7 +38,7 @@ def test_fuzz_knn_and_costs(ops, oracle):
             n_m, n_r = int(rng.integers(1, 700)), int(rng.integers(1, 900))
             if case % 10 == 0:
                 n_r = int(rng.integers(2100, 5000))  # above the grid threshold
-            T, k = int(rng.integers(0, 41)), int(rng.choice([1, 2, 5, 8, 31, 32, 33, 64]))
+            T, k = int(rng.integers(0, 41)), int(rng.choice([1, 2, 5, 8, 31, 32, 33, 64, 65, 100, 200, 448]))
             side = float(rng.choice([10.0, 100.0, 1000.0]))
             radius = float(rng.choice([0.0, 0.5, 3.0, side / 10, side / 3, side * 2]))
             axy, rxy = _points(rng, n_m, side, int(rng.integers(0, 4))), _points(rng, n_r, side, int(rng.integers(0, 4)))

@@ -72,7 +72,8 @@ def test_knn_adversarial(hip, ops, oracle):
 
 
 @pytest.mark.parametrize("n_m,n_r,k,radius", [(1000, 1300, 8, 10.0), (2500, 2500, 32, 25.0), (777, 4100, 64, 60.0), (513, 65, 5, 400.0),
-                                               (64, 5000, 1, 30.0)])
+                                               (64, 5000, 1, 30.0), (900, 3000, 65, 70.0), (300, 5000, 200, 150.0), (700, 2500, 448, 1e9),
+                                               (50, 600, 448, 40.0)])
 def test_knn_vs_oracle_seeded(ops, oracle, n_m, n_r, k, radius):
     from same_amd import synth
 
@@ -183,7 +184,7 @@ def test_cost_edge_shapes(ops):
     with pytest.raises(SameHipError):  # out-of-range pair index is reported, never dereferenced
         ops.pair_cost(np.zeros((3, 4)), np.zeros((2, 4)), np.zeros((3, 2)), np.zeros((2, 2)), np.array([[0, 2]], np.int32), 1.0)
     with pytest.raises(SameHipError):
-        ops.knn_prune(np.zeros((3, 2)), np.zeros((3, 2)), 1.0, 65)
+        ops.knn_prune(np.zeros((3, 2)), np.zeros((3, 2)), 1.0, 449)      # above SAME_MAX_KNN
 
 
 # ------------------------------------------------------------------------------------------ a7 / a8 / a9
