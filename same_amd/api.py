@@ -495,8 +495,9 @@ def subset_data(df, x_min, x_max, y_min, y_max):
 def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None,
                             moving_delaunay_vertex_col=None, optim_params: Optional[Dict[str, Any]] = None,
                             gurobi_params: Optional[Dict[str, Any]] = None,
-                            ignore_precomputed_triangulation: bool = False, _run_window=None):
-    """Same contract as src/same.py:297-595.  `_run_window` (testing hook) replaces run_same."""
+                            ignore_precomputed_triangulation: bool = False, _run_window=None, _shard=None):
+    """Same contract as src/same.py:297-595.  `_run_window` (testing hook) replaces run_same; `_shard=(rank, world)` makes this
+    call process only its share of the window plan (same_amd.dist.sharded_sliding_window_matching)."""
     from .windows import window_plan
 
     ref_cell_type_col = moving_cell_type_col = "cell_type"
@@ -558,8 +559,12 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
             done_ids = set(int(w) for w in existing["window_id"].unique())
             all_matches.append(existing)
     runner = _run_window or run_same
-    for w in plan:
-        if w["grid_id"] in done_ids:
+    mine = None
+    if _shard is not None:
+        from .windows import assign_windows
+        mine = set(assign_windows(plan, int(_shard[1]))[int(_shard[0])])
+    for pos, w in enumerate(plan):
+        if w["grid_id"] in done_ids or (mine is not None and pos not in mine):
             continue
         x0, x1, y0, y1 = w["box"]
         ref_subset = subset_data(ref, x0, x1, y0, y1)
@@ -574,6 +579,8 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
             central = window_matches[(window_matches["X"] >= tx0) & (window_matches["X"] < tx1)
                                      & (window_matches["Y"] >= ty0) & (window_matches["Y"] < ty1)].copy()
             central["window_id"] = w["window_id"]
+            if mine is not None:
+                central["__plan_pos"] = pos          # lets the sharded wrapper restore the single-process window order
             if len(central) > 0:
                 all_matches.append(central)
                 if outprefix:
