@@ -68,7 +68,7 @@ __device__ __forceinline__ void store16_nt_saddr(char *row_uniform, unsigned lan
     asm volatile("global_store_dwordx4 %0, %1, %2 " SAME_STORE_MODS "\n\ts_nop 0" ::"v"(lane_byte_off), "v"(bits), "s"(row_uniform) : "memory");
 }
 
-template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4, bool W1 = false>
+template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4, bool W1 = false, int G = 1>
 __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w, F dcoef,
@@ -79,6 +79,12 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     // rows_per_block % DEPTH == 0 and rows_per_block <= row_end - row_begin; the last chunk is shifted
     // back to overlap its neighbour instead of being ragged (the overlap recomputes identical values).
     static_assert(VEC_STORE || DEPTH == 1, "scalar-store variant is the simple one");
+    // G > 1: a lane owns G groups of CPL adjacent columns, group g sitting 64*CPL columns (one wave-wide 1 KiB store) after
+    // group g-1, so every store instruction still writes one contiguous run per wave while the scalar row fetch and loop
+    // control are shared by G times as many outputs.  A group past the edge aliases group 0 (it recomputes and re-stores
+    // identical values), which keeps the loop body free of branches.
+    static_assert(G == 1 || (VEC_STORE && NT && sizeof(F) * CPL == 16), "grouped columns use the 16-byte scalar-base store");
+    constexpr int CT = CPL * G;
     constexpr int H = (T + 1) / 2;  // first half: a[0..H); second half: a[H..T) + XY
     constexpr int TT = T > 0 ? T : 1;
     typedef F vecF __attribute__((ext_vector_type(CPL)));
@@ -117,15 +123,21 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
         chunk = lin / col_tiles;
         if (chunk >= row_chunks) return;
     }
-    const int64_t j0 = ((int64_t)tile * (64 * WAVES) + threadIdx.x) * CPL;
+    int64_t jg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        jg[g] = ((((int64_t)tile * WAVES + (threadIdx.x >> 6)) * G + g) * 64 + (threadIdx.x & 63)) * CPL;
+        if (g > 0 && jg[g] >= n_store) jg[g] = jg[0];
+    }
+    const int64_t j0 = jg[0];
     int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
     if (i0 + rows_per_block > row_end) i0 = row_end - rows_per_block;
 
-    F r[CPL][TT];
-    F rx[CPL], ry[CPL];
+    F r[CT][TT];
+    F rx[CT], ry[CT];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        int64_t j = j0 + c;
+    for (int c = 0; c < CT; ++c) {
+        int64_t j = jg[c / CPL] + c % CPL;
         if (j >= n_r) j = n_r - 1;  // clamp: lanes past the edge compute a valid column
         const F *rp = R + j * T;
 #pragma unroll
@@ -142,10 +154,13 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     for (int t = 0; t < H; ++t) h0[t] = arow[t];
     char *orow = reinterpret_cast<char *>(out + (i0 - row_begin) * ld);  // wave-uniform row pointer
     const unsigned lane_off = (unsigned)(j0 * sizeof(F));              // fixed per-lane byte offset (< 4 GiB rows)
+    unsigned lane_off_g[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) lane_off_g[g] = (unsigned)(jg[g] * sizeof(F));
     const int64_t row_pitch = ld * (int64_t)sizeof(F);
     constexpr int astride = T;
     for (int q = 0; q < rows_per_block; q += DEPTH) {
-        vecF res[DEPTH];
+        vecF res[DEPTH][G];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             // ---- phase 0: wait(h0) -> issue(second half of this row) -> compute t in [0,H)
@@ -157,16 +172,16 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
             const F ax = axyrow[0], ay = axyrow[1];
             __builtin_amdgcn_sched_barrier(0);
             // columns interleaved per type: each dependent add sits CPL instructions after its subtract
-            F s[CPL];
+            F s[CT];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) s[c] = F(0);
+            for (int c = 0; c < CT; ++c) s[c] = F(0);
 #pragma unroll
             for (int t = 0; t < H; ++t) {
-                F dd[CPL];
+                F dd[CT];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dd[c] = h0[t] - r[c][t];
+                for (int c = 0; c < CT; ++c) dd[c] = h0[t] - r[c][t];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) s[c] = s[c] + absf<F>(dd[c]);
+                for (int c = 0; c < CT; ++c) s[c] = s[c] + absf<F>(dd[c]);
             }
             // ---- phase 1: wait(h1, xy) -> issue(first half of the next row) -> compute t in [H,T), XY, store
             touch(ax);
@@ -180,35 +195,38 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = H; t < T; ++t) {
-                F dd[CPL];
+                F dd[CT];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dd[c] = h1[t - H] - r[c][t];
+                for (int c = 0; c < CT; ++c) dd[c] = h1[t - H] - r[c][t];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) s[c] = s[c] + absf<F>(dd[c]);
+                for (int c = 0; c < CT; ++c) s[c] = s[c] + absf<F>(dd[c]);
             }
-            F v[CPL];
+            F v[CT];
             {
-                F dx[CPL], dy[CPL], dc[CPL], ws[CPL];
+                F dx[CT], dy[CT], dc[CT], ws[CT];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dx[c] = ax - rx[c];
+                for (int c = 0; c < CT; ++c) dx[c] = ax - rx[c];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dy[c] = ay - ry[c];
+                for (int c = 0; c < CT; ++c) dy[c] = ay - ry[c];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dc[c] = absf<F>(dx[c]) + absf<F>(dy[c]);
+                for (int c = 0; c < CT; ++c) dc[c] = absf<F>(dx[c]) + absf<F>(dy[c]);
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) ws[c] = W1 ? s[c] : w * s[c];  // 1.0*s == s exactly: the multiply is skipped, not approximated
+                for (int c = 0; c < CT; ++c) ws[c] = W1 ? s[c] : w * s[c];  // 1.0*s == s exactly: the multiply is skipped, not approximated
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) dc[c] = dcoef * dc[c];
+                for (int c = 0; c < CT; ++c) dc[c] = dcoef * dc[c];
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) v[c] = ws[c] + dc[c];
+                for (int c = 0; c < CT; ++c) v[c] = ws[c] + dc[c];
             }
             if constexpr (VEC_STORE) {
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) res[d][c] = v[c];
-                vecF *dst = reinterpret_cast<vecF *>(orow + lane_off);
-                if constexpr (NT && sizeof(vecF) == 16) store16_nt_saddr(orow, lane_off, res[d]);
-                else if constexpr (NT) __builtin_nontemporal_store(res[d], dst);
-                else *dst = res[d];
+                for (int c = 0; c < CT; ++c) res[d][c / CPL][c % CPL] = v[c];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    vecF *dst = reinterpret_cast<vecF *>(orow + lane_off_g[g]);
+                    if constexpr (NT && sizeof(vecF) == 16) store16_nt_saddr(orow, lane_off_g[g], res[d][g]);
+                    else if constexpr (NT) __builtin_nontemporal_store(res[d][g], dst);
+                    else *dst = res[d][g];
+                }
             } else {
                 F *dst = reinterpret_cast<F *>(orow + lane_off);
 #pragma unroll
@@ -223,7 +241,7 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) keep_alive(res[d][c]);
+                for (int c = 0; c < CT; ++c) keep_alive(res[d][c / CPL][c % CPL]);
         }
     }
 }
@@ -335,24 +353,24 @@ static int env_int(const char *name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <typename F, int T, int CPL, bool VEC, int DEPTH, bool NT, int WAVES = 4>
+template <typename F, int T, int CPL, bool VEC, int DEPTH, bool NT, int WAVES = 4, int G = 1>
 int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb, int64_t re,
                F w, F *out_rb, int64_t ld, int64_t n_cols, int rows_per_block, int map_mode) {
     // out_rb points at the output row of `rb`
     const int64_t rows = re - rb;
     if (rows <= 0) return SAME_OK;
-    const int col_tiles = (int)ceil_div(n_cols, 64 * WAVES * CPL);
+    const int col_tiles = (int)ceil_div(n_cols, 64 * WAVES * CPL * G);
     const int64_t chunks = ceil_div(rows, rows_per_block);
     int64_t blocks = chunks * col_tiles;
     if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
     if (map_mode == 3 || map_mode == 4) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
     if (w == F(1))
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true, G>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
                            ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
                            map_mode, (int)chunks);
     else
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, false>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, false, G>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
                            ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
                            map_mode, (int)chunks);
     HIP_TRY(ctx, hipGetLastError());
@@ -386,6 +404,12 @@ int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const 
     int rows_per_block = rpb_env > 0 ? rpb_env : 256;
     while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
     rows_per_block = std::max(DEPTH, rows_per_block / DEPTH * DEPTH);
+    if constexpr (sizeof(F) == 8 && T == 20 && CPL == 2 && DEPTH == 1 && NT) {   // probe: two column groups per lane (SAME_DENSE_G=2)
+        static const int g_env = env_int("SAME_DENSE_G", 1);
+        if (g_env == 2 && rows >= rows_per_block)
+            return launch_one<F, T, CPL, true, DEPTH, NT, 4, 2>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rows_per_block,
+                                                                map_env);
+    }
     if (rows >= rows_per_block)
         return launch_one<F, T, CPL, true, DEPTH, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rows_per_block,
                                                       map_env);
