@@ -365,8 +365,9 @@ int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy
     if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
     if (map_mode == 3 || map_mode == 4) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
+    static const int lds_pad = env_int("SAME_DENSE_LDS_PAD", 0);   // probe: unused dynamic LDS per block caps the occupancy
     if (w == F(1))
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true, G>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true, G>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_pad,
                            ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
                            map_mode, (int)chunks);
     else
