@@ -716,3 +716,27 @@ def test_dense_cost_f32_dev_entry_point(hip, oracle):
     got = out.download((e - b, n_r), np.float32)
     assert np.array_equal(got, ops.dense_cost(A, R, axy, rxy, 0.5, b, e, dtype=np.float32))
     assert np.array_equal(got, oracle.dense_cost(A, R, axy, rxy, 0.5, b, e, dtype=np.float32))
+
+
+def test_integration_md_stub_runs_as_written(oracle):
+    """The ctypes stub INTEGRATION.md gives a reference maintainer is executed verbatim (only the library path is made absolute)
+    and its two wrappers are checked against the oracle."""
+    import os
+    import re
+    from same_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    block = re.search(r"```python\n(# src/_samehip\.py.*?)```", text, re.S).group(1)
+    assert 'ctypes.CDLL("libsame_hip.so")' in block
+    ns = {}
+    exec(compile(block.replace('ctypes.CDLL("libsame_hip.so")', f'ctypes.CDLL({_lib.LIB_PATH!r})'), "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(4)
+    axy, rxy = rng.uniform(0, 100, (300, 2)), rng.uniform(0, 100, (400, 2))
+    A, R = rng.gamma(0.5, 20.0, (300, 6)), rng.gamma(0.5, 20.0, (400, 6))
+    idx, cnt = ns["knn_prune"](axy, rxy, 9.0, 5)
+    oidx, _, ocnt = oracle.knn_prune(axy, rxy, 9.0, 5)
+    assert np.array_equal(idx, oidx) and np.array_equal(cnt, ocnt)
+    rr, cc = np.nonzero(idx >= 0)
+    pairs = np.column_stack((rr, idx[rr, cc]))
+    assert np.array_equal(ns["pair_cost"](A, R, axy, rxy, pairs, 1.5), oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.5))
