@@ -740,3 +740,38 @@ def test_integration_md_stub_runs_as_written(oracle):
     rr, cc = np.nonzero(idx >= 0)
     pairs = np.column_stack((rr, idx[rr, cc]))
     assert np.array_equal(ns["pair_cost"](A, R, axy, rxy, pairs, 1.5), oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.5))
+
+
+def test_sweep_called_from_other_threads(oracle):
+    """The lazy callback is re-entered from solver threads (src/same.py:1241): sweeps issued concurrently from several Python
+    threads on the shared default context return what the calling thread asked for (every entry selects the device itself;
+    the context lock serialises the bound state)."""
+    import threading
+    from conftest import load_golden
+    from same_amd import sweeps
+
+    g = load_golden("cfg2_small")
+    pairs, tris, sign = g["pairs"], g["tri_plain"], g["source_signs"].astype(np.int8)
+    n_a = int(pairs[:, 0].max()) + 1
+    rxy = g["in_ref_xy"][g["kept_ref"]]
+    sw = sweeps.LazyOrientationSweep(pairs, tris, sign, rxy, n_a)
+    rng = np.random.default_rng(0)
+    xs = [(rng.random(len(pairs)) < p).astype(float) for p in (0.05, 0.2, 0.5, 0.9, 0.0, 1.0)]
+    want = [oracle.lazy_orientation_sweep(x, pairs, tris, sign, rxy, n_a) for x in xs]
+    got = [None] * len(xs)
+    errors = []
+
+    def work(q):
+        try:
+            for _ in range(20):
+                checked, viol, _ = sw.sweep(xs[q])
+                got[q] = (checked, [(t, int(a), int(b), int(c)) for t, a, b, c in viol])
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(q,)) for q in range(len(xs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for q in range(len(xs)):
+        assert got[q][0] == want[q][0] and got[q][1] == [tuple(int(v) for v in row) for row in want[q][1]], q
