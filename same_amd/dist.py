@@ -129,28 +129,37 @@ def pairs_and_costs(aligned_df, ref_df, idx, cost):
     return new_a, new_r, new_pairs, c
 
 
-def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, **kwargs):
+def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, **kwargs):
     """BASELINE cfg 5 on N GPUs: windows are independent, so every rank (one process per GPU) runs its round-robin share of
     the window plan -- heaviest windows first, `windows.assign_windows` -- and the per-window match tables are exchanged once
-    over the host process group (`all_gather_object`; they are small frames, not a device collective).  Every rank returns
-    the frame a single process would return: windows in plan order, rows in window order.
+    over a host channel (they are small frames, not a device collective).  Every rank returns the frame a single process
+    would return: windows in plan order, rows in window order.
+
+    The host channel is `torch.distributed.all_gather_object` on `group` by default; any launcher can supply its own
+    `exchange(obj) -> [obj of rank 0, ..., obj of rank world-1]` together with `rank` and `world` (MPI, files, a queue).
     `outprefix`, if given, gets a per-rank subdirectory (`rank{r}`) so ranks never write the same CSV."""
     import os
 
     import pandas as pd
-    import torch.distributed as dist
 
     from .api import sliding_window_matching
 
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if exchange is None:
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def exchange(obj):
+            parts = [None] * world
+            dist.all_gather_object(parts, obj, group=group)
+            return parts
+    elif rank is None or world is None:
+        raise ValueError("a custom exchange needs rank and world")
     if kwargs.get("outprefix"):
         kwargs["outprefix"] = os.path.join(kwargs["outprefix"], f"rank{rank}")
-    part = sliding_window_matching(ref, moving, commonCT=commonCT, _shard=(rank, world), **kwargs)
-    parts = [None] * world
-    dist.all_gather_object(parts, part, group=group)
-    parts = [p for p in parts if p is not None and len(p)]
+    part = sliding_window_matching(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world)), **kwargs)
+    parts = [p for p in exchange(part) if p is not None and len(p)]
     if not parts:
         return pd.DataFrame()
     merged = pd.concat(parts, ignore_index=True)
-    merged = merged.sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
-    return merged
+    return merged.sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)

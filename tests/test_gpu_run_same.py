@@ -591,49 +591,64 @@ def test_run_same_parameter_sweep_equals_reference(gp, tmp_path, monkeypatch):
         rec.assert_same_record(rec.record_run(out_df, var_out, gp.Model.last), g, prefix=f"c{q}/")
 
 
-def _sharded_windows_worker(rank, world, port, out_dir):
+def _sharded_windows_worker(rank, world, out_dir):
     import os
+    import pickle
     import sys
+    import time
 
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import fake_gurobipy
     import numpy as np
-    import torch.distributed as dist
 
     fake_gurobipy.install()
     os.chdir(out_dir)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import run_same_record as rec
-        from same_amd import synth
-        from same_amd.dist import sharded_sliding_window_matching
+    import run_same_record as rec
+    from same_amd import synth
+    from same_amd.dist import sharded_sliding_window_matching
 
-        cells = synth.make_cells(1500, 3, seed=51)
-        r_big = synth.to_frame(cells)
-        m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
-        m_big = m_big[~((m_big["X"] < 120) & (m_big["Y"] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
-        res = sharded_sliding_window_matching(r_big, m_big, commonCT=synth.type_columns(3), outprefix=os.path.join(out_dir, "sw"),
-                                              optim_params=dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60),
-                                              gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0))
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **rec.record_frame("res", res))
-    finally:
-        dist.destroy_process_group()
+    def exchange(obj):          # a launcher-agnostic host channel: one pickle per rank in a shared directory
+        tmp = os.path.join(out_dir, f"part{rank}.tmp")
+        with open(tmp, "wb") as f:
+            pickle.dump(obj, f)
+        os.replace(tmp, os.path.join(out_dir, f"part{rank}.pkl"))
+        parts = []
+        for r in range(world):
+            path = os.path.join(out_dir, f"part{r}.pkl")
+            deadline = time.time() + 600
+            while not os.path.exists(path):
+                if time.time() > deadline:
+                    raise TimeoutError(path)
+                time.sleep(0.02)
+            with open(path, "rb") as f:
+                parts.append(pickle.load(f))
+        return parts
+
+    cells = synth.make_cells(1500, 3, seed=51)
+    r_big = synth.to_frame(cells)
+    m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
+    m_big = m_big[~((m_big["X"] < 120) & (m_big["Y"] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
+    res = sharded_sliding_window_matching(r_big, m_big, commonCT=synth.type_columns(3), exchange=exchange, rank=rank, world=world,
+                                          outprefix=os.path.join(out_dir, "sw"),
+                                          optim_params=dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60),
+                                          gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **rec.record_frame("res", res))
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_sliding_windows_equal_reference(tmp_path, world):
-    """BASELINE cfg 5 form: the window plan dealt round-robin to `world` ranks (one process each, gloo exchange of the match
-    tables); every rank ends up with exactly the frame the REFERENCE's single-process sliding_window_matching produced."""
-    import socket
-    import torch.multiprocessing as mp
+    """BASELINE cfg 5 form: the window plan dealt round-robin to `world` ranks (one process each, match tables exchanged over a
+    host channel); every rank ends up with exactly the frame the REFERENCE's single-process sliding_window_matching produced.
+    The processes use a file exchange rather than torch.distributed so the GPU suite never pays a cold `import torch`."""
+    import multiprocessing as mp
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    mp.spawn(_sharded_windows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_windows_worker, args=(rank, world, str(tmp_path))) for rank in range(world)]
+    [p.start() for p in procs]
+    [p.join(900) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     import run_same_record as rec
     g = load_golden("run_same_mock")
     for rank in range(world):
