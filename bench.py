@@ -95,6 +95,12 @@ class Dist:
             self.dist.destroy_process_group()
 
 
+def note(d, msg):
+    """Progress on stderr (rank 0): a cold box can spend minutes in imports / RCCL bootstrap, and stdout is reserved for the line."""
+    if d.rank == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def baseline_metric():
     """The metric string of BASELINE.json, verbatim (the file ships with the repo)."""
     try:
@@ -136,6 +142,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     d = Dist(args.gpus)
+    note(d, f"process group up: world {d.world}")
     from scipy.spatial import Delaunay
 
     from same_amd import _lib, synth
@@ -178,6 +185,7 @@ def main():
             gather = HostGatherAdapter(ctx, d)
             transport = "gloo HOST all-gather of pruned lists (RCCL init failed on this node)"
         gidx, gcost = ctx.alloc(rows * k * 4 * d.world), ctx.alloc(rows * k * 8 * d.world)
+    note(d, f"inputs resident ({rows} x {n_ref}, {Tr} triangles); gather transport: {transport if gather is not None else 'none (single rank)'}")
     dcls, dperim, dmaxcos = ctx.alloc(Tr), ctx.alloc(Tr * 8), ctx.alloc(Tr * 8)
     dsign, dweight = ctx.alloc(Tr), ctx.alloc(Tr * 8)
     dedge, dtflag, dpflag, dcounts = ctx.alloc(Tr * 3), ctx.alloc(Tr), ctx.alloc(rows), ctx.alloc(32)
@@ -239,12 +247,14 @@ def main():
         step(timed_dense=False)
     ctx.sync()
     d.barrier()
+    note(d, "warm-up done, timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     ctx.sync()
     d.barrier()
     dt = d.max(time.perf_counter() - t0)
+    note(d, f"{args.steps} steps in {dt:.3f} s")
 
     # ---- CPU baseline leg (rank 0, N=1, untimed region): the oracle runs a bounded sample of the same workload on the
     # host; its outputs double as a parity check of what the GPU just produced (the only place bench.py touches oracle/) ----
@@ -278,6 +288,7 @@ def main():
         if not ok:
             raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
         parity = f"dense rows, pruned lists and pair costs of rows [0,{S}) and the orientation sweep equal the oracle bit-for-bit"
+        note(d, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
         del want_dense
         # best-effort CPU line: the same dense sample split over host threads (ctypes releases the GIL)
         from concurrent.futures import ThreadPoolExecutor
