@@ -373,6 +373,19 @@ def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     a_c["Cell_Num_Old"] = np.arange(len(a_c)) * 2 + 7
     mc_a = same_amd.greedy_triangle_collapse(a_c, max_metacell_size=4, r_max=40, min_angle_deg=10, return_object=True, verbose=False)
     mc_r = same_amd.greedy_triangle_collapse(r_c, max_metacell_size=3, r_max=40, min_angle_deg=10, return_object=True, verbose=False)
+    # the MetaCell container's own helpers, against what the reference object returned
+    import json
+    probe = np.vstack([mc_a.original_delaunay[:5], [[7, 9, 123456789]], mc_a.original_delaunay[5:8]])
+    assert np.array_equal(np.asarray(mc_a.original_delaunay), g["mc_helpers/original_delaunay"])
+    assert [json.dumps([int(v) for v in mc_a.metacell_members(k)]) for k in (0, 5, len(mc_a.metacell_df) - 1)] == list(g["mc_helpers/members_0_5_last"])
+    assert np.array_equal(mc_a.original_delaunay_to_row_indices(), g["mc_helpers/rows"])
+    assert np.array_equal(mc_a.original_delaunay_to_pos(probe), g["mc_helpers/rows_probe_drop"])
+    assert np.array_equal(mc_a.original_delaunay_to_xy(), g["mc_helpers/xy"])
+    assert np.array_equal(mc_a.original_delaunay_to_xy(probe, on_missing="drop"), g["mc_helpers/xy_probe"])
+    assert np.array_equal(mc_a.metacell_delaunay_to_xy(), g["mc_helpers/mc_xy"])
+    assert json.dumps(mc_a.to_summary_dict(), sort_keys=True, default=str) == str(g["mc_helpers/summary"][0])
+    with pytest.raises(KeyError):
+        mc_a.original_delaunay_to_row_indices(probe, on_missing="error")
     mop = dict(radius=30, knn=4)
     mgp = dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=40)
     out_df, var_out = same_amd.run_same(mc_r.metacell_df, mc_a, synth.type_columns(3), outprefix=str(tmp_path / "mc"),

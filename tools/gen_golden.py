@@ -649,6 +649,22 @@ def run_same_mock_case():
         a_c['Cell_Num_Old'] = np.arange(len(a_c)) * 2 + 7
         mc_a = quiet(ref.metacell_utils.greedy_triangle_collapse, a_c, max_metacell_size=4, r_max=40, min_angle_deg=10, return_object=True)
         mc_r = quiet(ref.metacell_utils.greedy_triangle_collapse, r_c, max_metacell_size=3, r_max=40, min_angle_deg=10, return_object=True)
+        # the MetaCell container's own helpers (src/metacell_utils.py:55-157) on the reference object
+        probe = np.vstack([mc_a.original_delaunay[:5], [[7, 9, 123456789]], mc_a.original_delaunay[5:8]])   # one unknown vertex id
+        out['mc_helpers/original_delaunay'] = np.asarray(mc_a.original_delaunay)
+        out['mc_helpers/members_0_5_last'] = np.array([json.dumps([int(v) for v in mc_a.metacell_members(k)])
+                                                       for k in (0, 5, len(mc_a.metacell_df) - 1)])
+        out['mc_helpers/rows'] = mc_a.original_delaunay_to_row_indices()
+        out['mc_helpers/rows_probe_drop'] = mc_a.original_delaunay_to_pos(probe)
+        out['mc_helpers/xy'] = mc_a.original_delaunay_to_xy()
+        out['mc_helpers/xy_probe'] = mc_a.original_delaunay_to_xy(probe, on_missing='drop')
+        out['mc_helpers/mc_xy'] = mc_a.metacell_delaunay_to_xy()
+        out['mc_helpers/summary'] = np.array([json.dumps(mc_a.to_summary_dict(), sort_keys=True, default=str)])
+        try:
+            mc_a.original_delaunay_to_row_indices(probe, on_missing='error')
+            out['mc_helpers/error_raises'] = np.array([0])
+        except KeyError:
+            out['mc_helpers/error_raises'] = np.array([1])
         mop = dict(radius=30, knn=4)
         mgp = dict(init_method='greedy', lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=40)
         out_df, var_out = quiet(ref.same.run_same, mc_r.metacell_df, mc_a, synth.type_columns(3), outprefix=os.path.join(work, 'mc'),
