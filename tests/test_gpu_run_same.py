@@ -328,6 +328,14 @@ def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
     got = rec.record_run(out_df, var_out, gp.Model.last)
     got["files"] = np.array(sorted(os.listdir(outprefix)), dtype=str)
     rec.assert_same_record(got, g, prefix=f"{tag}/")
+    # what was written loads back through load_matching_results (src/helpers.py:667-689) and flattens to the same record
+    lv, la, lr, lm = same_amd.load_matching_results(outprefix)
+    if var_out:
+        back = rec.record_run(lm, lv, gp.Model.last)
+        for k in ("x", "no_match_vars", "area_penalty_vars", "viol_summary", "flipped_triangles", "areas_before", "info_keys", "out__aligned_idx",
+                  "out__ref_idx", "out__triangle_violation"):
+            assert np.array_equal(np.asarray(back[k]).astype(float), np.asarray(got[k]).astype(float), equal_nan=True), k
+        assert len(la) == len(var_out["no_match_vars"]) and len(lr) == len(var_out["penalty_vars"])
 
 
 def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
