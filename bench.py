@@ -1,43 +1,55 @@
 #!/usr/bin/env python3
-"""bench.py -- one timed pass of the pre-MIP hot path per step, on N MI355X (one rank per GPU).
+"""bench.py -- one timed pass of the pre-MIP hot path per step, on N MI355X (one process per GPU).
 
-Workload `dense100k` (the configuration BASELINE.json's metric is quoted on; it fits one GPU):
+`python3 bench.py --gpus N` starts its own N ranks: the parent touches no GPU, spawns N fresh children with
+RANK / LOCAL_RANK / WORLD_SIZE set, relays rank 0's single JSON line and exits non-zero if any child does.  Under
+`python -m torch.distributed.run` (RANK already in the environment) the process is a rank itself.  Either way the ranks
+meet through same_amd/rendezvous.py (loopback TCP, plain Python); no torch anywhere, so the only librccl mapped is the
+/opt/rocm one libsame_hip.so links against.
+
+Workload `dense100k`, weak scaling (the configuration BASELINE.json's metric is quoted on; it fits one GPU):
   per rank 100 000 reference cells x 100 000 aligned cells, 20 type columns, fp64:
     1. dense L1 cost build, rows x n_ref -> 80 GB resident in HBM          (dominant kernel)
-    2. radius-25 / k=32 KNN prune + costs of the padded candidate lists
-    3. [N > 1] RCCL all-gather of the pruned candidate lists (idx int32 + cost fp64)
+    2. radius-25 / k=32 KNN prune (caller-held grid index of the refs) + costs of the padded candidate lists
+    3. [N > 1] RCCL all-gather of the pruned candidate lists (idx int32 + cost fp64), overlapped on a second stream
     4. Delaunay-triangle classes (radius/angle/type), weights and source signs
-    5. orientation sweep (lazy-constraint body), XY-order sweep, signed-area flips under a
-       nearest-reference matching
-  Inputs are resident in HBM before the timed region (the Delaunay triangulation itself is an
-  input: scipy/Qhull on the host, as in the reference).  Weak scaling: every rank owns its own
-  block of 100 000 aligned rows against the replicated reference set.
-value = aligned-ref cell pairs covered per second, summed over ranks (n_ranks*1e10 per step).
+    5. orientation sweep (lazy-constraint body), XY-order sweep, signed-area flips under a nearest-reference matching
+  Inputs are resident in HBM before the timed region (the Delaunay triangulation itself is an input: scipy/Qhull on the
+  host, as in the reference).  Every rank owns its own block of 100 000 aligned rows against the replicated refs.
+`--scaling strong --workload cfg4` (BASELINE cfg 4): ONE 200k x 200k problem; ranks own aligned-row blocks of it (dense
+  build in 25k-row chunks through one 40 GB buffer), all-gather the candidate lists, derive the common matching, and
+  sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter all-reduce).
+value = aligned-ref cell pairs covered per second by the whole job.
 
-The `roofline` object is for the dense kernel: algorithmic bytes 8*N_r*rows + 8*(T+2)*(N_r+rows)
- over its mean launch time, measured with HIP events on the stream it runs on.
-`cpu_baseline` times the CPU oracle (scalar C port of the reference's arithmetic, 1 thread) on
-a bounded row sample of the same workload, rank 0, N=1 only.
+`roofline` is for the dense kernel: algorithmic bytes s*N_r*rows + s*(T+2)*(N_r+rows) over its mean launch
+time, HIP events on the stream it runs on.  Ceilings (same kernel at T=0, memset) are measured AFTER the timed loop on
+the warm chip, the note is composed from this run's numbers, `telemetry` is board power / shader clock sampled from
+sysfs while the dense kernel loops, `sweep` repeats the measurement at the type counts of the reference's real datasets.
+`cpu_baseline` times the CPU oracle (scalar C port of the reference's arithmetic, 1 thread) on a bounded row sample of
+the same workload, rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_ISSUE_PEAK_T = 39.3   # T lane-instructions/s: the 78.6 TFLOP/s fp64 vector spec counts an FMA as two
 
 WORKLOADS = {
-    # name: (n_ref, rows_per_rank, T, k, radius)
+    # name: (n_ref, aligned rows [per rank if weak, in total if strong], T, k, radius)
     "dense100k": (100_000, 100_000, 20, 32, 25.0),
+    "cfg4": (200_000, 200_000, 20, 32, 25.0),
     "cfg2": (10_000, 10_000, 20, 32, 25.0),
     "tiny": (4_000, 4_000, 20, 32, 25.0),
 }
+STRONG_CHUNK_BYTES = 40e9  # dense buffer of the strong mode (25k rows x 200k refs x 8 B)
 
 
 def parse():
@@ -45,59 +57,96 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="dense100k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip ceilings / telemetry leg / T sweep (profiling runs)")
     ap.add_argument("--cpu-sample-rows", type=int, default=20000)  # 10-20 s of single-thread oracle work at dense100k
-    return ap.parse_args()
+    ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
+    args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "cfg4" if args.scaling == "strong" else "dense100k"
+    return args
 
 
-class Dist:
-    """Host-side control plane: rendezvous, barrier, max-reduce.  torch.distributed (gloo) is
-    plumbing only; the data-path collective is RCCL inside libsame_hip."""
+# ======================================================================================================================
+# launcher: the parent of `python3 bench.py --gpus N`
+# ======================================================================================================================
+def launch(args):
+    """Spawn N rank processes (fresh children: nothing here has touched the GPU), relay rank 0's JSON line."""
+    n = args.gpus
+    rdv = tempfile.mkdtemp(prefix="same_bench_rdv_")
+    limit = float(os.environ.get("SAME_BENCH_LAUNCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SAME_RDV_DIR=rdv,
+                   MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = subprocess.PIPE if r == 0 else sys.stderr   # only rank 0 writes the line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    deadline = time.monotonic() + limit
+    rc, line = 0, None
+    try:
+        import selectors
 
-    def __init__(self, n):
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != n:
-            raise SystemExit(f"--gpus {n} but WORLD_SIZE={self.world}: launch with torch.distributed.run --nproc-per-node {n}")
-        self.dist = None
-        if self.world > 1:
-            import datetime
-            import torch.distributed as dist
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        buf, open_out = b"", True
+        while True:
+            if open_out:
+                for _key, _ in sel.select(timeout=0.2):
+                    chunk = os.read(procs[0].stdout.fileno(), 65536)
+                    if chunk:
+                        buf += chunk
+                    else:
+                        open_out = False
+                        sel.unregister(procs[0].stdout)
+            else:
+                time.sleep(0.1)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 1
+                print(f"[bench launcher] a rank exited with {bad[0]}; stopping the others", file=sys.stderr)
+                break
+            if all(c == 0 for c in codes) and not open_out:
+                break
+            if time.monotonic() > deadline:
+                rc = 124
+                print(f"[bench launcher] ranks still running after {limit:.0f} s; stopping them", file=sys.stderr)
+                break
+        for ln in buf.decode(errors="replace").splitlines():
+            if ln.startswith("{") and ln.rstrip().endswith("}"):
+                line = ln
+    finally:
+        for p in procs:      # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        try:
+            for f in os.listdir(rdv):
+                os.remove(os.path.join(rdv, f))
+            os.rmdir(rdv)
+        except OSError:
+            pass
+    if rc == 0 and line is None:
+        print("[bench launcher] rank 0 finished without a JSON line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    return rc
 
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
-            self.dist = dist
 
-    def barrier(self):
-        if self.dist:
-            self.dist.barrier()
-
-    def max(self, v):
-        if not self.dist:
-            return v
-        import torch
-
-        t = torch.tensor([v], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t[0])
-
-    def bcast_bytes(self, b):
-        if not self.dist:
-            return b
-        obj = [b]
-        self.dist.broadcast_object_list(obj, src=0)
-        return obj[0]
-
-    def close(self):
-        if self.dist:
-            self.dist.destroy_process_group()
-
-
-def note(d, msg):
+# ======================================================================================================================
+# one rank
+# ======================================================================================================================
+def note(group, msg):
     """Progress on stderr (rank 0): a cold box can spend minutes in imports / RCCL bootstrap, and stdout is reserved for the line."""
-    if d.rank == 0:
+    if group.rank == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
@@ -106,26 +155,34 @@ def baseline_metric():
     try:
         return json.load(open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8"))["metric"]
     except Exception:
-        return "cell-pairs/sec on 100k\u00d7100k cost build + edge-cross sweep; % HBM roofline"
+        return "cell-pairs/sec on 100k×100k cost build + edge-cross sweep; % HBM roofline"
 
 
-class HostGatherAdapter:
-    """Same interface as RcclGather, exchanging through the gloo host group (D2H, all_gather, H2D).  Used only when the
-    RCCL communicator cannot be created; synchronous, so nothing overlaps."""
+class HostTransport:
+    """Same interface as dist.RcclGroup for the candidate-list gather, through the host group (D2H, TCP all-gather, H2D).
+    A TRANSPORT fallback for when the RCCL communicator cannot be created (compute stays on the GPU); synchronous, so
+    nothing overlaps.  Reported in the JSON line when used."""
 
-    def __init__(self, ctx, d):
-        self.ctx, self.d = ctx, d
+    def __init__(self, ctx, group):
+        self.ctx, self.group, self.world, self.rank = ctx, group, group.world, group.rank
+
+    def allgather_dev(self, send_buf, recv_buf, send_bytes, send_offset=0):
+        import numpy as np
+
+        host = send_buf.download((send_bytes,), np.uint8, offset_bytes=send_offset)
+        recv_buf.upload(self.group.allgather_array(host))
 
     def allgather_dev_async(self, send_buf, recv_buf, send_bytes):
-        import torch
+        self.allgather_dev(send_buf, recv_buf, send_bytes)
 
-        host = send_buf.download((send_bytes,), np.uint8)
-        if self.d.dist is None:  # single process (test switch): the gather is a copy
-            recv_buf.upload(host)
-            return
-        outs = [torch.empty(send_bytes, dtype=torch.uint8) for _ in range(self.d.world)]
-        self.d.dist.all_gather(outs, torch.from_numpy(host))
-        recv_buf.upload(np.concatenate([o.numpy() for o in outs]))
+    def allreduce_dev(self, buf, count, dtype, op):
+        import numpy as np
+        from same_amd import _lib
+
+        dt = {_lib.DT_U8: np.uint8, _lib.DT_I32: np.int32, _lib.DT_U64: np.uint64, _lib.DT_F64: np.float64}[dtype]
+        parts = self.group.allgather_array(buf.download((1, count), dt))
+        red = {_lib.OP_SUM: parts.sum(axis=0, dtype=dt), _lib.OP_MAX: parts.max(axis=0), _lib.OP_MIN: parts.min(axis=0)}[op]
+        buf.upload(np.ascontiguousarray(red, dtype=dt))
 
     def wait(self):
         pass
@@ -134,30 +191,67 @@ class HostGatherAdapter:
         pass
 
 
-def main():
-    args = parse()
+def dense_kernel_label(dtype, T):
+    cpl = (2 if dtype == "f64" else 4)
+    if T * cpl * (2 if dtype == "f64" else 1) > 160:
+        cpl = 1
+    return f"dense_cost_kernel<{'double' if dtype == 'f64' else 'float'},{T},{cpl}>" if T <= 48 else "dense_cost_generic_kernel"
+
+
+def run_rank(args):
+    import ctypes
+
+    import numpy as np
+
+    from same_amd.rendezvous import HostGroup
+
     # stdout carries exactly ONE line (the JSON): native libraries print there too (RCCL writes a version banner to
     # stdout when the first communicator is created), so keep the real stdout aside and point fd 1 at stderr meanwhile
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    d = Dist(args.gpus)
-    note(d, f"process group up: world {d.world}")
+    group = HostGroup(timeout=float(os.environ.get("SAME_BENCH_RDV_TIMEOUT", "900")))
+    if group.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={group.world}")
+    local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
+    note(group, f"host group up: world {group.world} (rendezvous: loopback TCP, plain Python)")
+
+    if args.dry_launch:   # control-plane check, no GPU: id broadcast, barrier, max -- what the real run does on the host side
+        uid = group.bcast_bytes(bytes(range(128)) if group.rank == 0 else b"")
+        group.barrier()
+        mx = group.max(float(group.rank + 1))
+        ranks = group.allgather_object({"rank": group.rank, "pid": os.getpid(), "id_ok": uid == bytes(range(128))})
+        if group.rank == 0:
+            os.write(json_fd, (json.dumps({"dry_launch": True, "world": group.world, "max_of_rank_plus_1": mx,
+                                           "ranks": ranks}) + "\n").encode())
+        group.barrier()
+        group.close()
+        return
+
     from scipy.spatial import Delaunay
 
     from same_amd import _lib, synth
-    from same_amd.dist import RcclGather
+    from same_amd.dist import RcclGroup, ShardedSweeps, row_block
+    from same_amd.telemetry import GpuTelemetry
     from same_amd.triangles import cos_threshold
 
-    n_ref, rows, T, k, radius = WORKLOADS[args.workload]
+    strong = args.scaling == "strong"
+    n_ref, rows_cfg, T, k, radius = WORKLOADS[args.workload]
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libsame_hip has no CPU fallback")
-    ctx = _lib.Context(d.local_rank % _lib.device_count())
-    L, H = ctx.lib, ctx.handle
+    ctx = _lib.Context(local_rank % _lib.device_count())
+    L, H, chk = ctx.lib, ctx.handle, ctx.check
 
-    # ---- synthetic inputs (seeded), resident before timing ---------------------------------
+    # ---- synthetic inputs (seeded), resident before timing ---------------------------------------------------------
     ref = synth.make_cells(n_ref, T, seed=0)
-    mov = synth.make_cells(rows, T, seed=1 + d.rank, side=ref["side"])
+    if strong:   # ONE problem: every rank holds all aligned cells (XY/types are a few MB) and owns a row block of the work
+        mov = synth.make_cells(rows_cfg, T, seed=1, side=ref["side"])
+        rb, re, block = row_block(rows_cfg, group.world, group.rank)
+        n_mov = rows_cfg
+    else:        # weak: every rank owns its own section of rows_cfg aligned cells
+        mov = synth.make_cells(rows_cfg, T, seed=1 + group.rank, side=ref["side"])
+        rb, re, block, n_mov = 0, rows_cfg, rows_cfg, rows_cfg
+    rows = re - rb
     tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)  # host input (Qhull), as in the reference
     Tr = len(tris)
     dA, dR = ctx.to_device(mov["types"]), ctx.to_device(ref["types"])
@@ -165,105 +259,188 @@ def main():
     dsize, dtype_id = ctx.to_device(mov["size"]), ctx.to_device(mov["cell_type"])
     dtris = ctx.to_device(tris)
     ld = (n_ref + 1) & ~1
-    dD = ctx.alloc(rows * ld * 8)                       # the dense cost block (80 GB at dense100k)
-    didx, dcost, dcnt = ctx.alloc(rows * k * 4), ctx.alloc(rows * k * 8), ctx.alloc(rows * 4)
-    gidx = gcost = None
-    gather = None
-    transport = "RCCL all-gather of pruned lists (overlapped on a second stream)"
-    if d.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM"):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
+    chunk_rows = max(1, min(max(rows, 1), int(STRONG_CHUNK_BYTES // (ld * 8)))) if strong else rows
+    dD = ctx.alloc(max(chunk_rows, 1) * ld * 8)            # the dense cost block (80 GB at dense100k)
+    didx, dcost, dcnt = ctx.alloc(block * k * 4), ctx.alloc(block * k * 8), ctx.alloc(max(block, 1) * 4)
+    chk(L.same_dev_memset(H, didx.ptr, 0xFF, didx.nbytes), "memset")   # rows past a short last block stay -1
+    # caller-held grid index of the reference cells: built once, reused by every prune of the run
+    knn_index = ctypes.c_void_p()
+    chk(L.same_knn_index_build(H, drx.ptr, n_ref, radius, ctypes.byref(knn_index)), "same_knn_index_build")
+
+    comm, transport = None, "none (single rank)"
+    if group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM"):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
         try:
             if os.environ.get("SAME_BENCH_FAIL_RCCL"):
                 raise RuntimeError("forced by SAME_BENCH_FAIL_RCCL (test switch)")
-            gather = RcclGather(ctx, d.world, d.rank, d.bcast_bytes)
+            comm = RcclGroup(ctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
             ok_here = 1.0
         except Exception as e:  # TRANSPORT fallback only (compute stays on the GPU): reported in the JSON line
-            print(f"[rank {d.rank}] RCCL communicator init failed ({e}); gathering through the gloo host group instead", file=sys.stderr)
+            print(f"[rank {group.rank}] RCCL communicator init failed ({e}); gathering through the host group instead", file=sys.stderr)
             ok_here = 0.0
-        if -d.max(-ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
-            if gather is not None:
-                gather.close()
-            gather = HostGatherAdapter(ctx, d)
-            transport = "gloo HOST all-gather of pruned lists (RCCL init failed on this node)"
-        gidx, gcost = ctx.alloc(rows * k * 4 * d.world), ctx.alloc(rows * k * 8 * d.world)
-    note(d, f"inputs resident ({rows} x {n_ref}, {Tr} triangles); gather transport: {transport if gather is not None else 'none (single rank)'}")
+        if group.min(ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
+            if comm is not None:
+                comm.close()
+            comm = HostTransport(ctx, group)
+            transport = "HOST (loopback TCP) all-gather of pruned lists: RCCL init failed on this node"
+        else:
+            v = comm.rccl_version()
+            transport = f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100} all-gather of pruned lists" + \
+                        ("" if strong else " (overlapped on a second stream)")
+    gidx = gcost = None
+    if comm is not None:
+        gidx, gcost = ctx.alloc(block * k * 4 * group.world), ctx.alloc(block * k * 8 * group.world)
+    note(group, f"inputs resident ({rows} of {n_mov} aligned x {n_ref} ref, {Tr} triangles); gather transport: {transport}")
+
     dcls, dperim, dmaxcos = ctx.alloc(Tr), ctx.alloc(Tr * 8), ctx.alloc(Tr * 8)
     dsign, dweight = ctx.alloc(Tr), ctx.alloc(Tr * 8)
-    dedge, dtflag, dpflag, dcounts = ctx.alloc(Tr * 3), ctx.alloc(Tr), ctx.alloc(rows), ctx.alloc(32)
+    dedge, dtflag, dpflag, dcounts = ctx.alloc(Tr * 3), ctx.alloc(Tr), ctx.alloc(n_mov), ctx.alloc(32)
     dbefore, dafter, dm3, dflip = ctx.alloc(Tr * 8), ctx.alloc(Tr * 8), ctx.alloc(Tr * 3), ctx.alloc(Tr)
+    dmatch = ctx.alloc(n_mov * 4)
     en, thr = cos_threshold(15)
-    chk = ctx.check
 
-    # candidate matching for the sweeps: nearest reference within the radius (from one untimed prune)
-    chk(L.same_knn_prune_dev(H, dax.ptr, drx.ptr, n_ref, 0, rows, radius, k, didx.ptr, None, dcnt.ptr), "knn")
-    idx0 = didx.download((rows, k), np.int32)
-    match = np.ascontiguousarray(idx0[:, 0])
-    dmatch = ctx.to_device(match)
+    # source signs + the resident sweep state (one untimed pass)
     chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
     sign0 = dsign.download((Tr,), np.int8)
-    chk(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, rows, None, 0), "bind")
-    import ctypes
+    sweep = ctypes.c_void_p()
+    chk(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, n_mov, None, 0,
+                          ctypes.byref(sweep)), "bind")
+    sharded = ShardedSweeps(ctx, comm, sweep, dax, drx, dtris, Tr, n_mov) if (strong and comm is not None) else None
     checked, nviol = ctypes.c_int64(0), ctypes.c_int64(0)
     viol = np.empty(max(Tr, 1), np.int32)
-
+    last = {"checked": 0, "viol": viol[:0]}
     dense_ms = []
 
-    def timed(call, what, reps=3):
-        best = float("inf")
-        for _ in range(reps):
-            chk(L.same_timer_start(H), "timer")
-            chk(call(), what)
-            ms = ctypes.c_float(0)
-            chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
-            best = min(best, ms.value)
-        return best * 1e-3
+    def dense_all(T_=T, timed=None):
+        """the dense build of this rank's rows (strong mode: in chunks through the one buffer)"""
+        for c0 in range(rb, re, chunk_rows):
+            c1 = min(c0 + chunk_rows, re)
+            if timed is not None:
+                chk(L.same_timer_start(H), "timer")
+            chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T_, dax.ptr, drx.ptr, n_ref, c0, c1, 1.0, dD.ptr, ld), "dense")
+            if timed is not None:
+                ms = ctypes.c_float(0)
+                chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
+                timed.append((ms.value, c1 - c0))
 
-    # measured store ceilings on this box (SURVEY 8d asks for "% of measured" beside "% of 8 TB/s"): the same kernel with
-    # T=0 (identical store pattern, 5 VALU ops per output instead of 45) and a plain hipMemsetAsync of the same block
-    t_store_only = timed(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense T=0")
-    t_memset = timed(lambda: L.same_dev_memset(H, dD.ptr, 0, rows * ld * 8), "memset")
+    def prune_and_costs():
+        chk(L.same_knn_prune_indexed_dev(H, knn_index, dax.ptr, rb, re, k, didx.ptr, None, dcnt.ptr), "knn")
+        chk(L.same_padded_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, rb, re, k, didx.ptr, 1.0, dcost.ptr), "padded")
 
-    def step(timed_dense=True):
-        if timed_dense:
-            chk(L.same_timer_start(H), "timer")
-        chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense")
-        if timed_dense:
-            ms = ctypes.c_float(0)
-            chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
-            dense_ms.append(ms.value)
-        if gather is not None:
-            gather.wait()   # the previous step's gather (still reading didx/dcost) overlapped the dense build above
-        chk(L.same_knn_prune_dev(H, dax.ptr, drx.ptr, n_ref, 0, rows, radius, k, didx.ptr, None, dcnt.ptr), "knn")
-        chk(L.same_padded_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, 0, rows, k, didx.ptr, 1.0, dcost.ptr), "padded")
-        if gather is not None:  # on the communication stream: overlaps the sweeps below and the next step's dense build
-            gather.allgather_dev_async(didx, gidx, rows * k * 4)
-            gather.allgather_dev_async(dcost, gcost, rows * k * 8)
+    def tri_maps():
         chk(L.same_tri_classify_dev(H, dax.ptr, dtris.ptr, Tr, radius, en, thr, dtype_id.ptr, dcls.ptr, dperim.ptr, dmaxcos.ptr), "cls")
         chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
-        chk(L.same_xyorder_sweep_dev(H, dax.ptr, rows, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")
+
+    def local_sweeps():
+        chk(L.same_xyorder_sweep_dev(H, dax.ptr, n_mov, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")
         chk(L.same_area_flip_dev(H, dax.ptr, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dbefore.ptr, dafter.ptr, dm3.ptr, dflip.ptr), "area")
-        chk(L.same_orient_sweep_dev(H, dmatch.ptr, ctypes.byref(checked), viol.ctypes.data, ctypes.byref(nviol)), "orient")
+        chk(L.same_orient_sweep_dev(sweep, dmatch.ptr, ctypes.byref(checked), viol.ctypes.data, ctypes.byref(nviol)), "orient")
+        last["checked"], last["viol"] = checked.value, viol[: nviol.value]
+
+    def step_weak(timed=None):
+        dense_all(timed=timed)
+        if comm is not None:
+            comm.wait()   # the previous step's gather (still reading didx/dcost) overlapped the dense build above
+        prune_and_costs()
+        if comm is not None:  # on the communication stream: overlaps the sweeps below and the next step's dense build
+            comm.allgather_dev_async(didx, gidx, block * k * 4)
+            comm.allgather_dev_async(dcost, gcost, block * k * 8)
+        tri_maps()
+        local_sweeps()
+
+    def step_strong(timed=None):
+        dense_all(timed=timed)
+        prune_and_costs()
+        if comm is not None:
+            comm.allgather_dev(didx, gidx, block * k * 4)
+            comm.allgather_dev(dcost, gcost, block * k * 8)
+        # the common matching: nearest reference of every aligned cell, from the gathered lists (identical on every rank)
+        chk(L.same_first_candidate_dev(H, (gidx if comm is not None else didx).ptr, n_mov, k, dmatch.ptr), "match")
+        tri_maps()
+        if sharded is not None:
+            last["checked"], last["viol"] = sharded.run(dmatch)
+        else:
+            local_sweeps()
+
+    step = step_strong if strong else step_weak
+    if not strong:   # candidate matching for the sweeps: nearest reference within the radius (from one untimed prune)
+        prune_and_costs()
+        chk(L.same_first_candidate_dev(H, didx.ptr, n_mov, k, dmatch.ptr), "match")
 
     for _ in range(args.warmup):
-        step(timed_dense=False)
-    ctx.sync()
-    d.barrier()
-    note(d, "warm-up done, timing")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
         step()
     ctx.sync()
-    d.barrier()
-    dt = d.max(time.perf_counter() - t0)
-    note(d, f"{args.steps} steps in {dt:.3f} s")
+    group.barrier()
+    note(group, "warm-up done, timing")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed=dense_ms)
+    ctx.sync()
+    group.barrier()
+    dt = group.max(time.perf_counter() - t0)
+    note(group, f"{args.steps} steps in {dt:.3f} s")
+
+    # ---- after the timed region, rank 0 at N=1: ceilings, operating point, T sweep (all on the warm chip) ------------
+    match = dmatch.download((n_mov,), np.int32)
+    extras = {}
+    if group.rank == 0 and group.world == 1 and not args.no_extras and not strong:
+        def timed_ms(call, what, reps=5):
+            out = []
+            for _ in range(reps + 1):
+                chk(L.same_timer_start(H), "timer")
+                chk(call(), what)
+                ms = ctypes.c_float(0)
+                chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
+                out.append(ms.value)
+            return float(np.mean(out[1:])) * 1e-3   # first launch of a new shape is a warm-up
+
+        t_store_only = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense T=0")
+        t_memset = timed_ms(lambda: L.same_dev_memset(H, dD.ptr, 0, rows * ld * 8), "memset")
+        extras["ceilings"] = {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
+                              "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
+                              "measured": "after the timed loop, warm chip, mean of 5 launches each"}
+        # operating point: loop the dense kernel alone for ~2 s while a side thread reads board power and shader clock
+        tel = GpuTelemetry(ctx.pci_bus_id())
+        if tel.available():
+            loop_ms = []
+            tel.start()
+            t_end = time.perf_counter() + float(os.environ.get("SAME_BENCH_TELEMETRY_S", "2.0"))
+            while time.perf_counter() < t_end:
+                dense_all(timed=loop_ms)
+            tele = tel.stop()
+            tele["dense_ms_during_window"] = float(np.mean([m for m, _ in loop_ms]))
+            tele["what"] = f"dense kernel (T={T}, fp64) looped alone for the window; sysfs read every {tel.period * 1e3:.0f} ms by a side thread"
+        else:
+            tele = {"available": False, "reason": f"no readable power/clock nodes under {tel.dev_dir}"}
+        extras["telemetry"] = tele
+        # the same measurement at the type counts of the reference's real datasets (examples/*/run_same.sh: T = 3, 5, 8)
+        sweep_rows = []
+        for dt_name, T_s in (("f64", 3), ("f64", 5), ("f64", 8), ("f64", 16), ("f64", 20), ("f32", 20)):
+            npdt = np.float64 if dt_name == "f64" else np.float32
+            es = np.dtype(npdt).itemsize
+            r_s, m_s = synth.make_cells(n_ref, T_s, seed=0), synth.make_cells(rows, T_s, seed=1, side=ref["side"])
+            bufs = [ctx.to_device(m_s["types"].astype(npdt)), ctx.to_device(r_s["types"].astype(npdt)),
+                    ctx.to_device(m_s["xy"].astype(npdt)), ctx.to_device(r_s["xy"].astype(npdt))]
+            fn = L.same_dense_cost_f64_dev if dt_name == "f64" else L.same_dense_cost_f32_dev
+            ld_s = ld if dt_name == "f64" else (n_ref + 3) & ~3
+            t_s = timed_ms(lambda: fn(H, bufs[0].ptr, bufs[1].ptr, T_s, bufs[2].ptr, bufs[3].ptr, n_ref, 0, rows, 1.0, dD.ptr, ld_s), "dense sweep")
+            by = es * float(n_ref) * rows + es * (T_s + 2) * (n_ref + rows)
+            sweep_rows.append({"dtype": dt_name, "T": T_s, "kernel": dense_kernel_label(dt_name, T_s), "ms": t_s * 1e3,
+                               "GBs": by / t_s / 1e9, "frac": by / t_s / 1e9 / HBM_PEAK_GBS})
+            for b in bufs:
+                b.free()
+        extras["sweep"] = sweep_rows
 
     # ---- CPU baseline leg (rank 0, N=1, untimed region): the oracle runs a bounded sample of the same workload on the
     # host; its outputs double as a parity check of what the GPU just produced (the only place bench.py touches oracle/) ----
     cpu = None
     parity = "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
-    if d.rank == 0 and d.world == 1 and not args.no_cpu_baseline:
+    if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
         from oracle import same_oracle as orc
 
-        S = min(args.cpu_sample_rows, rows)
+        if strong or extras:   # the resident block was reused by the probes above: rebuild this rank's first chunk for the check
+            chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, rb, min(rb + chunk_rows, re), 1.0, dD.ptr, ld), "dense")
+            ctx.sync()
+        S = min(args.cpu_sample_rows, rows, chunk_rows)
         c0 = time.perf_counter()
         want_dense = orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, 0, S)
         oi, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, S)
@@ -276,7 +453,7 @@ def main():
         orc.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
         orc.area_flip(mov["xy"], ref["xy"], tris, match)
         c2 = time.perf_counter()
-        t_cpu = (c1 - c0) + (c2 - c1) * S / rows
+        t_cpu = (c1 - c0) + (c2 - c1) * S / n_mov
         # parity of this run's GPU outputs with what the baseline just computed
         ok = True
         for i in np.random.default_rng(0).choice(S, min(8, S), replace=False):
@@ -284,14 +461,17 @@ def main():
         ok &= bool(np.array_equal(didx.download((S, k), np.int32), oi))
         got_pc = dcost.download((S, k), np.float64)
         ok &= bool(np.array_equal(got_pc[rr, cc], want_pc))
-        ok &= (och == checked.value) and bool(np.array_equal(oviol, viol[: nviol.value]))
+        ok &= (och == last["checked"]) and bool(np.array_equal(oviol, last["viol"]))
         if not ok:
             raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
         parity = f"dense rows, pruned lists and pair costs of rows [0,{S}) and the orientation sweep equal the oracle bit-for-bit"
-        note(d, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
+        note(group, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
         del want_dense
-        # best-effort CPU line: the same dense sample split over host threads (ctypes releases the GIL)
+        # best-effort multi-core CPU lines: the dense sample split over host threads (ctypes releases the GIL),
+        # and the radius query + top-k of the prune with scipy's cKDTree on all cores (src/utils.py:714,722 with workers=-1)
         from concurrent.futures import ThreadPoolExecutor
+        from scipy.spatial import cKDTree
+
         nthr = max(1, min(16, os.cpu_count() or 1))
         cuts = np.linspace(0, S, nthr + 1).astype(int)
         m0 = time.perf_counter()
@@ -299,6 +479,15 @@ def main():
             list(ex.map(lambda be: orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(be[0]), int(be[1])),
                         zip(cuts[:-1], cuts[1:])))
         t_mt = time.perf_counter() - m0
+        k0 = time.perf_counter()
+        tree = cKDTree(ref["xy"])
+        balls = tree.query_ball_point(mov["xy"][:S], radius, workers=-1)
+        kd_pairs = 0
+        for i, b in enumerate(balls):
+            b = np.asarray(b, dtype=np.int64)
+            d = np.linalg.norm(ref["xy"][b] - mov["xy"][i], axis=1)
+            kd_pairs += len(b[np.argsort(d)[:k]])
+        t_kd = time.perf_counter() - k0
         cpu_model = "unknown"
         try:
             with open("/proc/cpuinfo") as f:
@@ -309,56 +498,96 @@ def main():
                "host_cpus": os.cpu_count(),
                "dense_only_threaded": {"value": S * n_ref / t_mt, "unit": "cell-pairs/s", "cores": nthr,
                                        "sample": f"dense cost of the same {S} rows split over {nthr} host threads"},
-               "sample": f"rows [0,{S}) of {rows} x {n_ref} refs: dense cost + knn prune + pair costs "
-                         f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{rows} "
+               "knn_ckdtree_threaded": {"value": S * n_ref / t_kd, "unit": "dense-equivalent cell-pairs/s", "cores": os.cpu_count(),
+                                        "sample": f"scipy cKDTree(refs) build + query_ball_point(rows [0,{S}), r={radius:g}, workers=-1) + "
+                                                  f"per-row norm/argsort top-{k} as src/utils.py:722-728 ({kd_pairs} pairs kept, {t_kd:.2f} s)"},
+               "sample": f"rows [0,{S}) of {n_mov} x {n_ref} refs: dense cost + knn prune + pair costs "
+                         f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{n_mov} "
                          f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}",
                "reference_note": "the reference itself (pure Python/pandas) cannot travel to this box; measured in the survey "
                                  "container (BASELINE.md section 3, 1 of 8 vCPU): 1.0-1.3e3 pairs/s pair-cost loop, 6.5e3 triangles/s "
                                  "filter, 2.7e5 triangles/s lazy sweep, 1.6e7 dense-equivalent cell-pairs/s KNN at 10k x 10k"}
 
-    if d.rank == 0:
-        pairs_per_step = float(n_ref) * rows * d.world
-        t_dense = float(np.mean(dense_ms)) * 1e-3
-        dense_bytes = 8.0 * n_ref * rows + 8.0 * (T + 2) * (n_ref + rows)
-        traffic = None
+    if group.rank == 0:
+        total_rows = n_mov if strong else rows * group.world
+        pairs_per_step = float(n_ref) * total_rows
+        ms_w = np.array([m for m, _ in dense_ms], float)
+        rows_w = np.array([r for _, r in dense_ms], float)
+        t_dense = float(ms_w.mean()) * 1e-3                       # mean launch duration
+        rows_launch = float(rows_w.mean())                        # rows one launch covers (== rows unless chunked)
+        dense_bytes = 8.0 * n_ref * rows_launch + 8.0 * (T + 2) * (n_ref + rows_launch)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                tj = json.load(open(tpath))
+                traffic, traffic_src = tj.get(args.workload), tj.get("_source")
             except Exception:
                 traffic = None
         achieved = dense_bytes / t_dense / 1e9
+        valu_rate = (2 * T + 5) * float(n_ref) * rows_launch / t_dense / 1e12
+        roof = {"bound": "hbm", "kernel": dense_kernel_label("f64", T), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src or "profiles/traffic.json (separate rocprofv3 --pmc passes: WRITE_SIZE + 2*FETCH_SIZE)",
+                "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3, "launches_timed": len(dense_ms),
+                # secondary ceiling: (2T+5) fp64 VALU lane-instructions per output against the vector issue peak
+                "valu_fp64": {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": valu_rate,
+                              "peak_Tinstr_s": FP64_ISSUE_PEAK_T, "frac": valu_rate / FP64_ISSUE_PEAK_T}}
+        msg = ["frac is against the 8.0 TB/s HBM spec as BASELINE.json asks"]
+        if "ceilings" in extras:
+            c = extras["ceilings"]
+            c["frac_of_T0_store_rate"] = achieved / c["same_kernel_T0_store_only_GBs"]
+            roof["measured_ceilings"] = c
+            msg.append(f"on this box the same kernel with T=0 (same stores, 5 instead of {2 * T + 5} VALU ops per output) streams "
+                       f"{c['same_kernel_T0_store_only_GBs']:.0f} GB/s and hipMemsetAsync {c['hipMemsetAsync_GBs']:.0f} GB/s, so the T={T} "
+                       f"build runs at {c['frac_of_T0_store_rate']:.2f} of its own store-only rate")
+        if "telemetry" in extras:
+            t = extras["telemetry"]
+            roof["telemetry"] = t
+            if t.get("available") and t.get("power"):
+                clk = t.get("sclk_hwmon") or t.get("sclk_dpm")
+                msg.append(f"while the kernel looped the board drew {t['power']['mean']:.0f} W (max {t['power']['max']:.0f} W"
+                           + (f", cap {t['power_cap_w']:.0f} W" if t.get("power_cap_w") else "") + ")"
+                           + (f" at a shader clock of {clk['mean']:.0f} MHz (min {clk['min']:.0f})" if clk else "")
+                           + f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
+                           + (f"{(2 * T + 5) * float(n_ref) * rows_launch / (1024 * 16 * clk['mean'] * 1e6) * 1e3:.1f} ms" if clk else "n/a")
+                           + f" of the {t_dense * 1e3:.1f} ms launch")
+            else:
+                msg.append("board power / clock could not be read from sysfs on this box")
+        if "sweep" in extras:
+            roof["sweep"] = extras["sweep"]
+            msg.append("sweep = same measurement at other type counts (the reference's datasets have T = 3, 5, 8)")
+        roof["note"] = "; ".join(msg)
         out = {
             "metric": baseline_metric(),
             "value": pairs_per_step * args.steps / dt, "unit": "cell-pairs/s",
-            "n_gpus": d.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {rows} aligned x {n_ref} ref cells per GPU, T={T} type cols, fp64 dense L1 cost "
-                                   f"+ r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay triangles classify/sign + "
-                                   "orientation / XY-order / area-flip sweeps",
-                       "parallelism": f"aligned-row blocks x{d.world}" + (", " + transport if d.world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "dense_cost_kernel<double,20,2>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3,
-                         # secondary ceiling: (2T+5) fp64 VALU lane-instructions per output against the vector issue
-                         # peak (78.6 TFLOP/s fp64 counts an FMA as two -> 39.3 T lane-instructions/s)
-                         "valu_fp64": {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": (2 * T + 5) * float(n_ref) * rows / t_dense / 1e12,
-                                       "peak_Tinstr_s": 39.3, "frac": (2 * T + 5) * float(n_ref) * rows / t_dense / 39.3e12},
-                         "measured_ceilings": {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
-                                               "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
-                                               "frac_of_T0_store_rate": (dense_bytes / t_dense) / (8.0 * n_ref * rows / t_store_only)},
-                         "note": "frac is against the 8.0 TB/s HBM spec as BASELINE.json asks; at T=20 fp64 the kernel runs at the "
-                                 "1400 W package power cap (rocm-smi 1395 W, sclk 1.78 GHz: profiles/r01_power_T20.log) with the fp64 VALU "
-                                 "~90 % busy, not at an HBM limit (store-only rate of the same kernel: 6.9-7.0 TB/s at T<=8); "
-                                 "traffic = WRITE_SIZE + 2*FETCH_SIZE from separate rocprofv3 --pmc passes (profiles/traffic.json)"},
+            "n_gpus": group.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: " + (f"ONE problem of {n_mov} aligned x {n_ref} ref cells, aligned-row blocks and triangle "
+                                                           f"blocks over {group.world} rank(s), dense build in {chunk_rows}-row chunks"
+                                                           if strong else f"{rows} aligned x {n_ref} ref cells per GPU")
+                                   + f", T={T} type cols, fp64 dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
+                                     "triangles classify/sign + orientation / XY-order / area-flip sweeps",
+                       "parallelism": f"aligned-row blocks x{group.world}" + (", " + transport if comm is not None else "")
+                                      + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if sharded is not None else "")},
+            "roofline": roof,
             "cpu_baseline": cpu,
             "parity_spot_check": parity,
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    d.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
-    if gather is not None:
-        gather.close()
-    d.close()
+    group.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
+    L.same_sweep_unbind(sweep)
+    L.same_knn_index_destroy(knn_index)
+    if comm is not None:
+        comm.close()
+    group.close()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -49,10 +49,12 @@ int main(void) {
     for (int i = 0; i < NM; ++i) match[i] = cnt[i] ? idx[i * K] : -1;
     match[2] = cnt[4] ? idx[4 * K] : -1; /* swap two matches to fold a triangle */
     match[4] = cnt[2] ? idx[2 * K] : -1;
-    CHECK(same_sweep_bind(ctx, tris, 4, sign, rxy, NR, NM, NULL, 0));
+    same_sweep *sweep = NULL;
+    CHECK(same_sweep_bind(ctx, tris, 4, sign, rxy, NR, NM, NULL, 0, &sweep));
     int64_t checked = 0, nviol = 0;
     int32_t viol[4];
-    CHECK(same_orient_sweep(ctx, match, &checked, viol, &nviol, NULL));
+    CHECK(same_orient_sweep(sweep, match, NM, &checked, viol, &nviol, NULL));
+    same_sweep_unbind(sweep);
     printf("checked %lld triangles, %lld flipped:", (long long)checked, (long long)nviol);
     for (int q = 0; q < nviol; ++q) printf(" %d", viol[q]);
     printf("\n");

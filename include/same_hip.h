@@ -42,11 +42,12 @@ extern "C" {
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
-#define SAME_ABI_VERSION 1
+#define SAME_ABI_VERSION 2
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
 typedef struct same_ctx same_ctx;
+typedef struct same_sweep same_sweep; /* resident state of one lazy-constraint sweep (same_sweep_bind) */
 
 /* ---- context ------------------------------------------------------------------------- */
 int same_abi_version(void);
@@ -58,6 +59,8 @@ const char *same_strerror(int code);
 const char *same_last_error(same_ctx *ctx);
 /* device name, CU count, HBM bytes (any pointer may be NULL) */
 int same_ctx_info(same_ctx *ctx, char *name, size_t name_len, int *cu_count, int64_t *hbm_bytes);
+/* "domain:bus:device.function" of the context's GPU (names its sysfs directory: power / clock telemetry) */
+int same_ctx_pci_bus_id(same_ctx *ctx, char *out, size_t out_len);
 
 /* ---- device memory + timing (for resident operands and in-library kernel timing) ------ */
 int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr);
@@ -66,7 +69,7 @@ int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);
 /* The host-buffer entry points stage through per-context scratch blocks that grow on demand and are
- * reused across calls; this frees them all (and drops the state bound by same_sweep_bind). */
+ * reused across calls; this frees them all (same_sweep handles own their blocks and are not affected). */
 int same_ctx_release_scratch(same_ctx *ctx);
 /* HIP events recorded on the context's stream (where the kernels run). */
 int same_timer_start(same_ctx *ctx);
@@ -112,6 +115,20 @@ int same_knn_prune(same_ctx *ctx, const double *axy, int64_t n_m, const double *
 int same_knn_prune_dev(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r,
                        int64_t row_begin, int64_t row_end, double radius, int k,
                        int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt);
+/* Caller-held index of one reference set for one radius.  same_knn_prune_dev rebuilds the uniform grid
+ * of the references (a counting sort) and reads their bounding box back on every call; when the same
+ * references are pruned against repeatedly -- windows that share a reference section, the row blocks of
+ * a sharded build, a benchmark step -- build the index once: same_knn_prune_indexed_dev then only
+ * enqueues the query kernel (no rebuild, no host synchronisation) and returns bit-identical lists.
+ * drxy is the caller's device array: it is not copied for the brute-force plan (small or degenerate
+ * sets), so it must stay valid and unchanged until same_knn_index_destroy. */
+typedef struct same_knn_index same_knn_index;
+int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double radius,
+                         same_knn_index **out);
+void same_knn_index_destroy(same_knn_index *index);
+int same_knn_prune_indexed_dev(same_ctx *ctx, const same_knn_index *index, const double *daxy,
+                               int64_t row_begin, int64_t row_end, int k, int32_t *dout_idx,
+                               double *dout_d2, int32_t *dout_cnt);
 /* costs of the padded candidate lists (a2 + a4 fused for the sharded path):
  * out_cost[(i-row_begin)*k + q] = pair cost of (i, idx[..]) or +inf where idx == -1. */
 int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
@@ -139,18 +156,24 @@ int same_tri_sign_weight(same_ctx *ctx, const double *xy, const double *size, in
 
 /* ---- a10: lazy-constraint orientation sweep -------------------------------------------
  * Replaces the body of _lazy_orientation_callback (src/same.py:631-669).
- * same_sweep_bind keeps triangles, source signs, reference XY and the pair list resident
- * (the model._* state of src/same.py:1153-1158); pairs may be NULL when only
- * same_orient_sweep (match-vector form) is used.
+ * same_sweep_bind uploads triangles, source signs, reference XY and the pair list once (the model._*
+ * state of src/same.py:1153-1158) into device blocks owned by the returned handle; pairs may be NULL
+ * when only the match-vector form is used.  Several handles may live on one context (one per window /
+ * per model); same_sweep_unbind frees one.  Every sweep call names the length of the array it passes and
+ * fails with SAME_EINVAL if it is not the bound one, so a handle can never be run against another
+ * model's shapes.  Calls on handles of one context must not overlap (the context has one stream), and
+ * every handle must be unbound before its context is destroyed.
  * same_orient_sweep_x: x_vals[P] -> matching (last pair with x > 0.5 wins per aligned row,
  * src/same.py:634-639) -> sweep.  out_viol_idx needs room for Tr entries and comes out
  * ascending; out_flag (may be NULL): 0 skipped, 1 checked, 2 flipped;
  * out_match / out_pair_idx (may be NULL): the matching and its pair indices (for cbLazy). */
 int same_sweep_bind(same_ctx *ctx, const int32_t *tris, int64_t Tr, const int8_t *src_sign,
-                    const double *rxy, int64_t n_r, int64_t n_m, const int32_t *pairs, int64_t P);
-int same_orient_sweep(same_ctx *ctx, const int32_t *match, int64_t *out_checked,
+                    const double *rxy, int64_t n_r, int64_t n_m, const int32_t *pairs, int64_t P,
+                    same_sweep **out);
+void same_sweep_unbind(same_sweep *sweep);
+int same_orient_sweep(same_sweep *sweep, const int32_t *match, int64_t n_m, int64_t *out_checked,
                       int32_t *out_viol_idx, int64_t *out_nviol, uint8_t *out_flag);
-int same_orient_sweep_x(same_ctx *ctx, const double *x_vals, int64_t *out_checked,
+int same_orient_sweep_x(same_sweep *sweep, const double *x_vals, int64_t P, int64_t *out_checked,
                         int32_t *out_viol_idx, int64_t *out_nviol, uint8_t *out_flag,
                         int32_t *out_match, int32_t *out_pair_idx);
 
@@ -187,8 +210,21 @@ int same_xyorder_sweep_dev(same_ctx *ctx, const double *daxy, int64_t n_m, const
                            const int32_t *dtris, int64_t Tr, const int32_t *dmatch,
                            uint8_t *dedge_flags, uint8_t *dtri_flag, uint8_t *dpoint_flag,
                            uint64_t *dcounts);
-int same_orient_sweep_dev(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked,
+int same_orient_sweep_dev(same_sweep *sweep, const int32_t *dmatch, int64_t *out_checked,
                           int32_t *out_viol_idx, int64_t *out_nviol);
+/* Triangle-block forms for the sweep sharded over GPUs (the loops being sharded are
+ * src/same.py:645-669 and src/violationhelper.py:53-117).  same_orient_flags_dev writes the flags of
+ * triangles [t_begin, t_end) at their absolute positions dflag[t] (t_begin a multiple of 64) and only
+ * enqueues; after the blocks of all ranks have been all-gathered into one flag array,
+ * same_orient_from_flags_dev produces what same_orient_sweep produces: checked count and the ascending
+ * list of flipped triangles (src/same.py:687-703 relies on that order).  The XY-order and area sweeps
+ * shard by calling their _dev forms on offset pointers (dtris + 3*t_begin, outputs + t_begin). */
+int same_orient_flags_dev(same_sweep *sweep, const int32_t *dmatch, int64_t t_begin, int64_t t_end,
+                          uint8_t *dflag);
+int same_orient_from_flags_dev(same_sweep *sweep, const uint8_t *dflag, int64_t *out_checked,
+                               int32_t *out_viol_idx, int64_t *out_nviol);
+/* dmatch[i] = didx[i*k]: the nearest candidate of every row of a padded candidate list (-1 = none). */
+int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, int k, int32_t *dmatch);
 
 /* ---- a5: MIP-start helpers ------------------------------------------------------------
  * Per-row minimum pair cost (src/init_helpers.py:118-122; +inf for rows without pairs) and
@@ -273,6 +309,18 @@ int same_allgather_dev(same_ctx *ctx, const void *dsend, void *drecv, size_t sen
  * buffers or reading the gathered ones.  same_ctx_sync waits for both streams. */
 int same_allgather_dev_async(same_ctx *ctx, const void *dsend, void *drecv, size_t send_bytes);
 int same_comm_wait(same_ctx *ctx);
+/* In-place all-reduce of count elements on the context's stream (sweep counters: U64 SUM; point flags:
+ * U8 MAX = logical OR; timings: F64 MAX). */
+#define SAME_DT_U8 0
+#define SAME_DT_I32 1
+#define SAME_DT_U64 2
+#define SAME_DT_F64 3
+#define SAME_OP_SUM 0
+#define SAME_OP_MAX 1
+#define SAME_OP_MIN 2
+int same_allreduce_dev(same_ctx *ctx, void *dbuf, size_t count, int dtype, int op);
+/* communicator size (0 = none), this rank, and the RCCL version the library is running against */
+int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version);
 
 #ifdef __cplusplus
 }

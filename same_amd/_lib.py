@@ -21,6 +21,9 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
+ABI_VERSION = 2
+DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
+OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
 MAX_KNN = 448
 MAX_TYPES = 4096
 
@@ -34,6 +37,7 @@ _PROTOTYPES = {
     "same_strerror": [c_int],
     "same_last_error": [c_vp],
     "same_ctx_info": [c_vp, ctypes.c_char_p, c_sz, ctypes.POINTER(c_int), ctypes.POINTER(c_i64)],
+    "same_ctx_pci_bus_id": [c_vp, ctypes.c_char_p, c_sz],
     "same_dev_alloc": [c_vp, c_sz, ctypes.POINTER(c_vp)],
     "same_dev_free": [c_vp, c_vp],
     "same_h2d": [c_vp, c_vp, c_vp, c_sz],
@@ -49,12 +53,16 @@ _PROTOTYPES = {
     "same_dense_cost_f32": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_flt, c_vp, c_i64],
     "same_knn_prune": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp, c_vp, c_vp],
     "same_knn_prune_dev": [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp, c_vp, c_vp],
+    "same_knn_index_build": [c_vp, c_vp, c_i64, c_dbl, ctypes.POINTER(c_vp)],
+    "same_knn_index_destroy": [c_vp],
+    "same_knn_prune_indexed_dev": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp],
     "same_padded_cost_f64_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_dbl, c_vp],
     "same_tri_classify": [c_vp, c_vp, c_i64, c_vp, c_i64, c_dbl, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "same_tri_sign_weight": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
-    "same_sweep_bind": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64],
-    "same_orient_sweep": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp],
-    "same_orient_sweep_x": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp, c_vp, c_vp],
+    "same_sweep_bind": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.POINTER(c_vp)],
+    "same_sweep_unbind": [c_vp],
+    "same_orient_sweep": [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp],
+    "same_orient_sweep_x": [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64), c_vp, c_vp, c_vp],
     "same_xyorder_sweep": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_area_flip": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_tri_classify_dev": [c_vp, c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
@@ -62,6 +70,9 @@ _PROTOTYPES = {
     "same_area_flip_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_xyorder_sweep_dev": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_orient_sweep_dev": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64)],
+    "same_orient_flags_dev": [c_vp, c_vp, c_i64, c_i64, c_vp],
+    "same_orient_from_flags_dev": [c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, ctypes.POINTER(c_i64)],
+    "same_first_candidate_dev": [c_vp, c_vp, c_i64, c_int, c_vp],
     "same_pair_rowmin": [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp],
     "same_assign_matrix": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_dbl, c_vp],
     "same_greedy_match": [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_int)],
@@ -77,6 +88,8 @@ _PROTOTYPES = {
     "same_allgather_dev": [c_vp, c_vp, c_vp, c_sz],
     "same_allgather_dev_async": [c_vp, c_vp, c_vp, c_sz],
     "same_comm_wait": [c_vp],
+    "same_allreduce_dev": [c_vp, c_vp, c_sz, c_int, c_int],
+    "same_comm_info": [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
 }
 EXPORTS = tuple(_PROTOTYPES)
 
@@ -112,7 +125,9 @@ def load():
             L.same_strerror.restype = ctypes.c_char_p
             L.same_last_error.restype = ctypes.c_char_p
             L.same_ctx_destroy.restype = None
-            if L.same_abi_version() != 1:
+            L.same_sweep_unbind.restype = None
+            L.same_knn_index_destroy.restype = None
+            if L.same_abi_version() != ABI_VERSION:
                 raise SameHipError(-22, "libsame_hip ABI version mismatch")
             _lib = L
     return _lib
@@ -177,7 +192,7 @@ class Context:
             raise SameHipError(rc, f"same_ctx_create(device={device})", self.lib.same_strerror(rc).decode())
         self.handle = h.value
         self.device = int(device)
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()
 
     def check(self, rc, what):
         if rc != 0:
@@ -189,6 +204,11 @@ class Context:
         cu, hbm = c_int(0), c_i64(0)
         self.check(self.lib.same_ctx_info(self.handle, name, 128, ctypes.byref(cu), ctypes.byref(hbm)), "same_ctx_info")
         return {"arch": name.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+    def pci_bus_id(self):
+        buf = ctypes.create_string_buffer(64)
+        self.check(self.lib.same_ctx_pci_bus_id(self.handle, buf, 64), "same_ctx_pci_bus_id")
+        return buf.value.decode().lower()
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
@@ -203,7 +223,6 @@ class Context:
     def release_scratch(self):
         """Free the staging blocks the host-buffer entry points grew (they are otherwise kept for reuse)."""
         self.check(self.lib.same_ctx_release_scratch(self.handle), "same_ctx_release_scratch")
-        self._bound_owner = None
 
     def timer_start(self):
         self.check(self.lib.same_timer_start(self.handle), "same_timer_start")

@@ -1,7 +1,8 @@
 // comm.hip -- the path's only exchange step: an RCCL all-gather of the fixed-width pruned
 // candidate lists (int32 idx[rows][k], double cost[rows][k]) across the ranks that own
 // aligned-row blocks.  One process per GPU; the unique id travels over whatever
-// host channel the launcher has (bench.py uses the torch.distributed store).
+// host channel the launcher has (same_amd/rendezvous.py: loopback TCP, plain Python).  The sharded sweeps add
+// an all-gather of per-triangle flags and a small all-reduce of their counters.
 #include <rccl/rccl.h>
 
 #include "common.h"
@@ -75,6 +76,42 @@ int same_allgather_dev_async(same_ctx *ctx, const void *dsend, void *drecv, size
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
     NCCL_TRY(ctx, ncclAllGather(dsend, drecv, send_bytes, ncclInt8, ctx->comm, ctx->comm_stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_gathered, ctx->comm_stream));
+    return SAME_OK;
+}
+
+// In-place all-reduce on the compute stream: sweep counters (u64 sum), point flags (u8 max = OR), timing (f64 max).
+int same_allreduce_dev(same_ctx *ctx, void *dbuf, size_t count, int dtype, int op) {
+    REQUIRE(ctx, ctx && ctx->comm && (count == 0 || dbuf));
+    ncclDataType_t dt;
+    switch (dtype) {
+        case SAME_DT_U8: dt = ncclUint8; break;
+        case SAME_DT_I32: dt = ncclInt32; break;
+        case SAME_DT_U64: dt = ncclUint64; break;
+        case SAME_DT_F64: dt = ncclFloat64; break;
+        default: ctx->err = "unknown SAME_DT_* code"; return SAME_EINVAL;
+    }
+    ncclRedOp_t ro;
+    switch (op) {
+        case SAME_OP_SUM: ro = ncclSum; break;
+        case SAME_OP_MAX: ro = ncclMax; break;
+        case SAME_OP_MIN: ro = ncclMin; break;
+        default: ctx->err = "unknown SAME_OP_* code"; return SAME_EINVAL;
+    }
+    SAME_TRY(same_use(ctx));
+    if (count == 0) return SAME_OK;
+    NCCL_TRY(ctx, ncclAllReduce(dbuf, dbuf, count, dt, ro, ctx->comm, ctx->stream));
+    return SAME_OK;
+}
+
+int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version) {
+    REQUIRE(ctx, ctx != nullptr);
+    if (out_nranks) *out_nranks = ctx->comm ? ctx->nranks : 0;
+    if (out_rank) *out_rank = ctx->rank;
+    if (out_rccl_version) {
+        int v = 0;
+        if (ncclGetVersion(&v) != ncclSuccess) v = 0;
+        *out_rccl_version = v;
+    }
     return SAME_OK;
 }
 

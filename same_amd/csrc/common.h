@@ -17,10 +17,7 @@ struct ncclComm;
 enum Slot {
     SL_A = 0, SL_R, SL_AXY, SL_RXY, SL_PAIRS, SL_OUT0, SL_OUT1, SL_OUT2, SL_TRIS, SL_MATCH,
     SL_SIGN, SL_SIZE, SL_TYPE, SL_FLAG0, SL_FLAG1, SL_FLAG2, SL_COUNTS, SL_X, SL_MASK,
-    // bound sweep state (same_sweep_bind)
-    SL_B_TRIS, SL_B_SIGN, SL_B_RXY, SL_B_PAIRS, SL_B_MATCH, SL_B_PIDX, SL_B_FLAG, SL_B_VIOL,
-    SL_B_MASK, SL_B_CNT, SL_B_X,
-    // uniform-grid index of the reference cells (knn.hip)
+    // uniform-grid index of the reference cells built per call by the un-indexed prune entry points (knn.hip)
     SL_K_HIST, SL_K_RANK, SL_K_SXY, SL_K_SIDX, SL_K_BBOX,
     SL_COUNT
 };
@@ -37,11 +34,24 @@ struct same_ctx {
     size_t pinned_bytes = 0;
     std::string err;
     int cu_count = 0;
-    // bound sweep shapes
-    int64_t b_Tr = 0, b_nr = 0, b_nm = 0, b_P = 0;
-    bool bound = false;
     ncclComm *comm = nullptr;
     int nranks = 1, rank = 0;
+};
+
+// Resident state of the lazy-constraint orientation sweep (same_sweep_bind): its own device blocks, so
+// several sweeps can live on one context and none can be run against another's shapes.
+struct same_sweep {
+    same_ctx *ctx = nullptr;
+    int64_t Tr = 0, n_r = 0, n_m = 0, P = 0;
+    int32_t *tris = nullptr;      // [Tr][3]
+    int8_t *sign = nullptr;       // [Tr]
+    double *rxy = nullptr;        // [n_r][2]
+    int32_t *pairs = nullptr;     // [P][2]
+    int32_t *match = nullptr, *pidx = nullptr;  // [n_m]
+    uint8_t *flag = nullptr;      // [Tr rounded up to 256]
+    int32_t *viol = nullptr;      // [Tr]
+    unsigned long long *mask = nullptr, *cnt = nullptr;
+    double *x = nullptr;          // [P]
 };
 
 inline int same_fail(same_ctx *ctx, int code, const char *what, hipError_t e) {

@@ -55,8 +55,8 @@ __device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v));
 
 // 16-byte nontemporal store, address = scalar row pointer + fixed per-lane byte offset: no VALU instruction
 // and no address VGPR is spent on addressing (hipcc otherwise keeps a 64-bit VGPR pointer and bumps it
-// with a v_lshl_add_u64 per row).  The trailing s_nop covers the ">64-bit store data, then VALU write of
-// those VGPRs" wait state that the compiler only inserts for its own instructions.
+// with a v_lshl_add_u64 per row).  The trailing `s_nop 1` gives the 2 wait states gfx940+ requires between a store of
+// more than 64 bits and a VALU write of its data VGPRs; the compiler only inserts them for its own instructions.
 #ifndef SAME_STORE_MODS
 #define SAME_STORE_MODS "nt"   // cache-policy bits of the output store; tools/probes/store_variants.sh sweeps the alternatives
 #endif
@@ -65,7 +65,7 @@ __device__ __forceinline__ void store16_nt_saddr(char *row_uniform, unsigned lan
     typedef int i4 __attribute__((ext_vector_type(4)));
     static_assert(sizeof(V16) == 16, "16-byte vector expected");
     const i4 bits = __builtin_bit_cast(i4, v);
-    asm volatile("global_store_dwordx4 %0, %1, %2 " SAME_STORE_MODS "\n\ts_nop 0" ::"v"(lane_byte_off), "v"(bits), "s"(row_uniform) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 " SAME_STORE_MODS "\n\ts_nop 1" ::"v"(lane_byte_off), "v"(bits), "s"(row_uniform) : "memory");
 }
 
 template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4, bool W1 = false, int G = 1>

@@ -93,6 +93,12 @@ int same_ctx_info(same_ctx *ctx, char *name, size_t name_len, int *cu_count, int
     return SAME_OK;
 }
 
+int same_ctx_pci_bus_id(same_ctx *ctx, char *out, size_t out_len) {
+    REQUIRE(ctx, ctx && out && out_len >= 16 && out_len <= 4096);
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(out, (int)out_len, ctx->device));
+    return SAME_OK;
+}
+
 int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr) {
     REQUIRE(ctx, ctx && out_dptr);
     SAME_TRY(same_use(ctx));
@@ -143,7 +149,6 @@ int same_ctx_release_scratch(same_ctx *ctx) {
             ctx->slot[s] = nullptr;
             ctx->slot_bytes[s] = 0;
         }
-    ctx->bound = false;  // the bound sweep state lived in scratch slots
     return SAME_OK;
 }
 

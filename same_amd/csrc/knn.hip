@@ -313,10 +313,11 @@ static double key_to_f64(unsigned long long k) {
 int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
                      double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt);
 
-int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
-                    double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
-    const int64_t rows = re - rb;
-    // bounding box of the reference cells (device reduction, one 32-byte read-back)
+// Grid geometry for a reference set: bounding box by a device reduction and one 32-byte read-back (the only host
+// synchronisation of the grid path -- which is why an unchanged reference set should keep its index, same_knn_index_build).
+// *usable = false when the grid would not help or cannot be built (NaN/inf coordinates, radius spanning everything).
+int grid_geometry(same_ctx *ctx, const double *drxy, int64_t n_r, double radius, GridDesc *out, bool *usable) {
+    *usable = false;
     unsigned long long *dbbox;
     SAME_TRY(slot_as(ctx, SL_K_BBOX, (size_t)4, &dbbox));
     unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
@@ -327,8 +328,7 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
     HIP_TRY(ctx, hipMemcpyAsync(h + 8, dbbox, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const double x0 = key_to_f64(h[8]), y0 = key_to_f64(h[9]), x1 = key_to_f64(h[10]), y1 = key_to_f64(h[11]);
-    if (!(x1 >= x0) || !(y1 >= y0) || !std::isfinite(x1 - x0) || !std::isfinite(y1 - y0))
-        return launch_knn_brute(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt);  // NaN/inf coordinates
+    if (!(x1 >= x0) || !(y1 >= y0) || !std::isfinite(x1 - x0) || !std::isfinite(y1 - y0)) return SAME_OK;  // NaN/inf coordinates
     // cell edge: a hair above the radius (so |dx| <= r can never skip a cell, rounding included), and
     // large enough to keep the grid below ~1M cells and ~1 ref per cell on sparse inputs
     const double ext = std::max(x1 - x0, y1 - y0);
@@ -340,21 +340,30 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
     g.x0 = x0; g.y0 = y0; g.inv_cell = 1.0 / cell;
     g.gx = (int)std::min(1025.0, std::floor((x1 - x0) / cell) + 1.0);
     g.gy = (int)std::min(1025.0, std::floor((y1 - y0) / cell) + 1.0);
+    *out = g;
+    // <= 9 cells: the radius spans the whole reference set, the 3 x 3 neighbourhood is everything -> brute force, 8 rows per wave
+    *usable = (int64_t)g.gx * g.gy > 9;
+    return SAME_OK;
+}
+
+// counting sort of the references by cell: start[cells+1] (exclusive scan), sorted XY and original indices
+int grid_fill(same_ctx *ctx, const double *drxy, int64_t n_r, const GridDesc &g, unsigned *dhist, unsigned *drank, double *dsxy,
+              int32_t *dsidx) {
     const int64_t cells = (int64_t)g.gx * g.gy;
-    if (cells <= 9)  // the radius spans the whole reference set: the 3 x 3 neighbourhood is everything, sweep it 8 rows per wave
-        return launch_knn_brute(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt);
-    unsigned *dhist, *drank;
-    double *dsxy;
-    int32_t *dsidx;
-    SAME_TRY(slot_as(ctx, SL_K_HIST, (size_t)cells + 1, &dhist));
-    SAME_TRY(slot_as(ctx, SL_K_RANK, (size_t)n_r, &drank));
-    SAME_TRY(slot_as(ctx, SL_K_SXY, (size_t)n_r * 2, &dsxy));
-    SAME_TRY(slot_as(ctx, SL_K_SIDX, (size_t)n_r, &dsidx));
     HIP_TRY(ctx, hipMemsetAsync(dhist, 0, (size_t)(cells + 1) * sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank);
     hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dhist, cells);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank,
                        dsxy, dsidx);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+int grid_query(same_ctx *ctx, const double *daxy, const GridDesc &g, const unsigned *dhist, const double *dsxy, const int32_t *dsidx,
+               int64_t rb, int64_t re, double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
+    const int64_t rows = re - rb;
+    if (rows <= 0) return SAME_OK;
+    REQUIRE(ctx, ceil_div(rows, KNN_WAVES) < (int64_t)1 << 31);
     if (k <= KNN_CAP_SMALL - 64)
         hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_SMALL>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
                            daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
@@ -363,6 +372,24 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
                            daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
+}
+
+int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
+                    double radius, int k, int32_t *didx, double *dd2, int32_t *dcnt) {
+    GridDesc g;
+    bool usable = false;
+    SAME_TRY(grid_geometry(ctx, drxy, n_r, radius, &g, &usable));
+    if (!usable) return launch_knn_brute(ctx, daxy, drxy, n_r, rb, re, radius, k, didx, dd2, dcnt);
+    const int64_t cells = (int64_t)g.gx * g.gy;
+    unsigned *dhist, *drank;
+    double *dsxy;
+    int32_t *dsidx;
+    SAME_TRY(slot_as(ctx, SL_K_HIST, (size_t)cells + 1, &dhist));
+    SAME_TRY(slot_as(ctx, SL_K_RANK, (size_t)n_r, &drank));
+    SAME_TRY(slot_as(ctx, SL_K_SXY, (size_t)n_r * 2, &dsxy));
+    SAME_TRY(slot_as(ctx, SL_K_SIDX, (size_t)n_r, &dsidx));
+    SAME_TRY(grid_fill(ctx, drxy, n_r, g, dhist, drank, dsxy, dsidx));
+    return grid_query(ctx, daxy, g, dhist, dsxy, dsidx, rb, re, radius, k, didx, dd2, dcnt);
 }
 
 int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t rb, int64_t re,
@@ -399,7 +426,77 @@ int launch_knn(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_
 
 }  // namespace
 
+// Caller-held index of one reference set for one radius: the grid (or the decision that brute force is the
+// better plan) is made once; prunes against it neither rebuild anything nor synchronise with the host.
+struct same_knn_index {
+    same_ctx *ctx = nullptr;
+    const double *drxy = nullptr;  // the caller's device array (not owned; must stay valid and unchanged)
+    int64_t n_r = 0;
+    double radius = 0.0;
+    bool grid = false;
+    GridDesc g{};
+    unsigned *hist = nullptr;
+    double *sxy = nullptr;
+    int32_t *sidx = nullptr;
+};
+
 extern "C" {
+
+int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double radius, same_knn_index **out) {
+    REQUIRE(ctx, ctx && out);
+    *out = nullptr;
+    REQUIRE(ctx, n_r >= 0 && (n_r == 0 || drxy) && radius >= 0.0);  // also rejects NaN
+    SAME_TRY(same_use(ctx));
+    same_knn_index *ix = new (std::nothrow) same_knn_index();
+    if (!ix) return SAME_ENOMEM;
+    ix->ctx = ctx; ix->drxy = drxy; ix->n_r = n_r; ix->radius = radius;
+    const char *mode = getenv("SAME_KNN_MODE");
+    bool want_grid = n_r >= 2048 && std::isfinite(radius);
+    if (mode && mode[0] == 'b') want_grid = false;
+    if (mode && mode[0] == 'g') want_grid = n_r > 0;
+    int rc = SAME_OK;
+    if (want_grid) {
+        bool usable = false;
+        rc = grid_geometry(ctx, drxy, n_r, radius, &ix->g, &usable);
+        if (rc == SAME_OK && usable) {
+            const int64_t cells = (int64_t)ix->g.gx * ix->g.gy;
+            void *rank = nullptr;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&ix->hist), (size_t)(cells + 1) * sizeof(unsigned));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ix->sxy), (size_t)n_r * 2 * sizeof(double));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ix->sidx), (size_t)n_r * sizeof(int32_t));
+            if (e == hipSuccess) e = hipMalloc(&rank, (size_t)n_r * sizeof(unsigned));
+            if (e != hipSuccess) rc = same_fail(ctx, e == hipErrorOutOfMemory ? SAME_ENOMEM : SAME_EIO, "hipMalloc(knn index)", e);
+            if (rc == SAME_OK) rc = grid_fill(ctx, drxy, n_r, ix->g, ix->hist, static_cast<unsigned *>(rank), ix->sxy, ix->sidx);
+            if (rc == SAME_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAME_EIO;
+            if (rank) (void)hipFree(rank);
+            ix->grid = rc == SAME_OK;
+        }
+    }
+    if (rc != SAME_OK) { same_knn_index_destroy(ix); return rc; }
+    *out = ix;
+    return SAME_OK;
+}
+
+void same_knn_index_destroy(same_knn_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->ctx->device);
+    (void)hipStreamSynchronize(ix->ctx->stream);
+    if (ix->hist) (void)hipFree(ix->hist);
+    if (ix->sxy) (void)hipFree(ix->sxy);
+    if (ix->sidx) (void)hipFree(ix->sidx);
+    delete ix;
+}
+
+int same_knn_prune_indexed_dev(same_ctx *ctx, const same_knn_index *ix, const double *daxy, int64_t row_begin,
+                               int64_t row_end, int k, int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt) {
+    REQUIRE(ctx, ctx && ix && ix->ctx == ctx && daxy && dout_idx && dout_cnt);
+    REQUIRE(ctx, row_begin >= 0 && row_end >= row_begin && k >= 1 && k <= SAME_MAX_KNN);
+    SAME_TRY(same_use(ctx));
+    if (row_end == row_begin) return SAME_OK;
+    if (ix->grid)
+        return grid_query(ctx, daxy, ix->g, ix->hist, ix->sxy, ix->sidx, row_begin, row_end, ix->radius, k, dout_idx, dout_d2, dout_cnt);
+    return launch_knn_brute(ctx, daxy, ix->drxy, ix->n_r, row_begin, row_end, ix->radius, k, dout_idx, dout_d2, dout_cnt);
+}
 
 int same_knn_prune_dev(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r, int64_t row_begin,
                        int64_t row_end, double radius, int k, int32_t *dout_idx, double *dout_d2,

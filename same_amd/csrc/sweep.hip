@@ -76,6 +76,27 @@ __global__ __launch_bounds__(256) void orient_flag_kernel(
     }
 }
 
+// per-wave flipped masks + checked count from a complete flag array (sharded sweep: the flags were all-gathered)
+__global__ __launch_bounds__(256) void flag_mask_kernel(const uint8_t *__restrict__ flag, int64_t Tr,
+                                                         unsigned long long *__restrict__ viol_mask,
+                                                         unsigned long long *__restrict__ counters) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint8_t f = t < Tr ? flag[t] : 0;
+    const unsigned long long checked = __ballot(f != 0);
+    const unsigned long long flipped = __ballot(f == 2);
+    if ((threadIdx.x & 63) == 0) {
+        viol_mask[t >> 6] = flipped;
+        if (checked) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(checked));
+    }
+}
+
+// nearest candidate of every row of a padded candidate list: match[i] = idx[i][0] (-1 = no candidate)
+__global__ __launch_bounds__(256) void first_candidate_kernel(const int32_t *__restrict__ idx, int64_t rows, int k,
+                                                               int32_t *__restrict__ match) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) match[i] = idx[i * k];
+}
+
 // one block: exclusive scan of popcount(mask[w]) in chunks of 1024 words, then expand bits
 __global__ __launch_bounds__(1024) void compact_mask_kernel(const unsigned long long *__restrict__ mask, int64_t n_words,
                                                              int64_t n_items, int32_t *__restrict__ out_idx,
@@ -232,34 +253,79 @@ __global__ __launch_bounds__(256) void window_count_kernel(const double *__restr
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
 
-int run_orient(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol,
-               uint8_t *out_flag) {
-    const int64_t Tr = ctx->b_Tr;
-    *out_checked = 0;
-    *out_nviol = 0;
-    if (Tr == 0) return SAME_OK;
-    const int64_t n_words = ceil_div(Tr, 64);
-    unsigned long long *dcnt = static_cast<unsigned long long *>(ctx->slot[SL_B_CNT]);
-    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream,
-                       static_cast<const int32_t *>(ctx->slot[SL_B_TRIS]), Tr, static_cast<const int8_t *>(ctx->slot[SL_B_SIGN]),
-                       static_cast<const double *>(ctx->slot[SL_B_RXY]), dmatch, static_cast<uint8_t *>(ctx->slot[SL_B_FLAG]),
-                       static_cast<unsigned long long *>(ctx->slot[SL_B_MASK]), dcnt);
+// flags of triangles [t_begin, t_end) of a bound sweep, written at their absolute positions in dflag; the
+// per-wave flipped masks and the checked counter are only produced when the block is the whole list
+int launch_orient_flags(same_sweep *s, const int32_t *dmatch, int64_t t_begin, int64_t t_end, uint8_t *dflag,
+                        unsigned long long *dmask, unsigned long long *dcnt) {
+    same_ctx *ctx = s->ctx;
+    const int64_t n = t_end - t_begin;
+    if (n <= 0) return SAME_OK;
+    hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, s->tris + 3 * t_begin, n,
+                       s->sign + t_begin, s->rxy, dmatch, dflag + t_begin, dmask, dcnt);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       static_cast<const unsigned long long *>(ctx->slot[SL_B_MASK]), n_words, Tr,
-                       static_cast<int32_t *>(ctx->slot[SL_B_VIOL]), dcnt);
+    return SAME_OK;
+}
+
+// ascending list of flipped triangles + counters from a complete flag array (the single-GPU sweep's own flags,
+// or the all-gathered flags of a triangle-block sharded sweep)
+int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, int64_t *out_checked, int32_t *out_viol_idx,
+                       int64_t *out_nviol) {
+    same_ctx *ctx = s->ctx;
+    const int64_t Tr = s->Tr, n_words = ceil_div(Tr, 64);
+    if (!masks_ready) {
+        HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(flag_mask_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dflag, Tr, s->mask, s->cnt);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->mask, n_words, Tr, s->viol, s->cnt);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
-    SAME_TRY(same_down(ctx, h, dcnt, 2 * sizeof(unsigned long long)));
-    if (out_flag) SAME_TRY(same_down(ctx, out_flag, ctx->slot[SL_B_FLAG], (size_t)Tr));
+    SAME_TRY(same_down(ctx, h, s->cnt, 2 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *out_checked = (int64_t)h[0];
     *out_nviol = (int64_t)h[1];
     if (h[1] && out_viol_idx) {
-        SAME_TRY(same_down(ctx, out_viol_idx, ctx->slot[SL_B_VIOL], (size_t)h[1] * sizeof(int32_t)));
+        SAME_TRY(same_down(ctx, out_viol_idx, s->viol, (size_t)h[1] * sizeof(int32_t)));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return SAME_OK;
+}
+
+int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol,
+               uint8_t *out_flag) {
+    same_ctx *ctx = s->ctx;
+    *out_checked = 0;
+    *out_nviol = 0;
+    if (s->Tr == 0) return SAME_OK;
+    HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    SAME_TRY(launch_orient_flags(s, dmatch, 0, s->Tr, s->flag, s->mask, s->cnt));
+    if (out_flag) SAME_TRY(same_down(ctx, out_flag, s->flag, (size_t)s->Tr));
+    return compact_from_flags(s, s->flag, true, out_checked, out_viol_idx, out_nviol);
+}
+
+template <typename T>
+int sweep_block(same_ctx *ctx, T **out, size_t n, const T *host) {
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    *out = static_cast<T *>(p);
+    if (host && n) HIP_TRY(ctx, hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return SAME_OK;
+}
+
+int sweep_fill(same_sweep *s, const int32_t *tris, const int8_t *src_sign, const double *rxy, const int32_t *pairs) {
+    same_ctx *ctx = s->ctx;
+    SAME_TRY(sweep_block(ctx, &s->tris, (size_t)s->Tr * 3, tris));
+    SAME_TRY(sweep_block(ctx, &s->sign, (size_t)s->Tr, src_sign));
+    SAME_TRY(sweep_block(ctx, &s->rxy, (size_t)s->n_r * 2, rxy));
+    SAME_TRY(sweep_block(ctx, &s->pairs, (size_t)s->P * 2, pairs));
+    SAME_TRY(sweep_block<int32_t>(ctx, &s->match, (size_t)s->n_m, nullptr));
+    SAME_TRY(sweep_block<int32_t>(ctx, &s->pidx, (size_t)s->n_m, nullptr));
+    SAME_TRY(sweep_block<uint8_t>(ctx, &s->flag, (size_t)ceil_div(s->Tr, 256) * 256 + 256, nullptr));
+    SAME_TRY(sweep_block<int32_t>(ctx, &s->viol, (size_t)s->Tr, nullptr));
+    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->mask, (size_t)ceil_div(s->Tr, 256) * 4 + 4, nullptr));
+    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->cnt, 4, nullptr));
+    SAME_TRY(sweep_block<double>(ctx, &s->x, (size_t)s->P, nullptr));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;
 }
 
@@ -268,67 +334,66 @@ int run_orient(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked, int32
 extern "C" {
 
 int same_sweep_bind(same_ctx *ctx, const int32_t *tris, int64_t Tr, const int8_t *src_sign, const double *rxy,
-                    int64_t n_r, int64_t n_m, const int32_t *pairs, int64_t P) {
-    REQUIRE(ctx, ctx != nullptr);
+                    int64_t n_r, int64_t n_m, const int32_t *pairs, int64_t P, same_sweep **out) {
+    REQUIRE(ctx, ctx && out);
+    *out = nullptr;
     REQUIRE(ctx, Tr >= 0 && n_r >= 0 && n_m >= 0 && P >= 0 && Tr < ((int64_t)1 << 31));
     REQUIRE(ctx, (Tr == 0 || (tris && src_sign)) && (n_r == 0 || rxy) && (P == 0 || pairs));
     SAME_TRY(same_use(ctx));
-    ctx->bound = false;
     SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n_m, "triangles"));
     for (int64_t p = 0; p < P; ++p)
         if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
             ctx->err = "pair index out of range";
             return SAME_ERANGE;
         }
-    void *d;
-    SAME_TRY(same_up(ctx, SL_B_TRIS, tris, (size_t)Tr * 3 * sizeof(int32_t), &d));
-    SAME_TRY(same_up(ctx, SL_B_SIGN, src_sign, (size_t)Tr, &d));
-    SAME_TRY(same_up(ctx, SL_B_RXY, rxy, (size_t)n_r * 2 * sizeof(double), &d));
-    SAME_TRY(same_up(ctx, SL_B_PAIRS, pairs, (size_t)P * 2 * sizeof(int32_t), &d));
-    SAME_TRY(same_slot(ctx, SL_B_MATCH, (size_t)n_m * sizeof(int32_t), &d));
-    SAME_TRY(same_slot(ctx, SL_B_PIDX, (size_t)n_m * sizeof(int32_t), &d));
-    SAME_TRY(same_slot(ctx, SL_B_FLAG, (size_t)Tr, &d));
-    SAME_TRY(same_slot(ctx, SL_B_VIOL, (size_t)Tr * sizeof(int32_t), &d));
-    SAME_TRY(same_slot(ctx, SL_B_MASK, (size_t)(ceil_div(Tr, 256) * 4 + 4) * sizeof(unsigned long long), &d));
-    SAME_TRY(same_slot(ctx, SL_B_CNT, 4 * sizeof(unsigned long long), &d));
-    SAME_TRY(same_slot(ctx, SL_B_X, (size_t)P * sizeof(double), &d));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->b_Tr = Tr; ctx->b_nr = n_r; ctx->b_nm = n_m; ctx->b_P = P;
-    ctx->bound = true;
+    same_sweep *s = new (std::nothrow) same_sweep();
+    if (!s) return SAME_ENOMEM;
+    s->ctx = ctx; s->Tr = Tr; s->n_r = n_r; s->n_m = n_m; s->P = P;
+    const int rc = sweep_fill(s, tris, src_sign, rxy, pairs);
+    if (rc != SAME_OK) { same_sweep_unbind(s); return rc; }
+    *out = s;
     return SAME_OK;
 }
 
-int same_orient_sweep(same_ctx *ctx, const int32_t *match, int64_t *out_checked, int32_t *out_viol_idx,
-                      int64_t *out_nviol, uint8_t *out_flag) {
-    REQUIRE(ctx, ctx && ctx->bound && out_checked && out_nviol);
-    REQUIRE(ctx, ctx->b_nm == 0 || match);
-    SAME_TRY(same_use(ctx));
-    SAME_TRY(check_index_range(ctx, match, ctx->b_nm, -1, ctx->b_nr, "match"));
-    int32_t *dmatch = static_cast<int32_t *>(ctx->slot[SL_B_MATCH]);
-    if (ctx->b_nm) HIP_TRY(ctx, hipMemcpyAsync(dmatch, match, (size_t)ctx->b_nm * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    return run_orient(ctx, dmatch, out_checked, out_viol_idx, out_nviol, out_flag);
+void same_sweep_unbind(same_sweep *s) {
+    if (!s) return;
+    same_ctx *ctx = s->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->viol, s->mask, s->cnt, s->x};
+    for (void *b : blocks)
+        if (b) (void)hipFree(b);
+    delete s;
 }
 
-int same_orient_sweep_x(same_ctx *ctx, const double *x_vals, int64_t *out_checked, int32_t *out_viol_idx,
-                        int64_t *out_nviol, uint8_t *out_flag, int32_t *out_match, int32_t *out_pair_idx) {
-    REQUIRE(ctx, ctx && ctx->bound && out_checked && out_nviol);
-    REQUIRE(ctx, ctx->b_P == 0 || x_vals);
+int same_orient_sweep(same_sweep *s, const int32_t *match, int64_t n_m, int64_t *out_checked, int32_t *out_viol_idx,
+                      int64_t *out_nviol, uint8_t *out_flag) {
+    if (!s) return SAME_EINVAL;
+    same_ctx *ctx = s->ctx;
+    REQUIRE(ctx, out_checked && out_nviol && n_m == s->n_m && (n_m == 0 || match));
     SAME_TRY(same_use(ctx));
-    const int64_t P = ctx->b_P, n_m = ctx->b_nm;
-    double *dx = static_cast<double *>(ctx->slot[SL_B_X]);
-    int32_t *dmatch = static_cast<int32_t *>(ctx->slot[SL_B_MATCH]);
-    int32_t *dpidx = static_cast<int32_t *>(ctx->slot[SL_B_PIDX]);
-    const int32_t *dpairs = static_cast<const int32_t *>(ctx->slot[SL_B_PAIRS]);
-    if (P) HIP_TRY(ctx, hipMemcpyAsync(dx, x_vals, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SAME_TRY(check_index_range(ctx, match, n_m, -1, s->n_r, "match"));
+    if (n_m) HIP_TRY(ctx, hipMemcpyAsync(s->match, match, (size_t)n_m * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    return run_orient(s, s->match, out_checked, out_viol_idx, out_nviol, out_flag);
+}
+
+int same_orient_sweep_x(same_sweep *s, const double *x_vals, int64_t P, int64_t *out_checked, int32_t *out_viol_idx,
+                        int64_t *out_nviol, uint8_t *out_flag, int32_t *out_match, int32_t *out_pair_idx) {
+    if (!s) return SAME_EINVAL;
+    same_ctx *ctx = s->ctx;
+    REQUIRE(ctx, out_checked && out_nviol && P == s->P && (P == 0 || x_vals));
+    SAME_TRY(same_use(ctx));
+    const int64_t n_m = s->n_m;
+    if (P) HIP_TRY(ctx, hipMemcpyAsync(s->x, x_vals, (size_t)P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (n_m) {
-        hipLaunchKernelGGL(match_init_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dpidx, n_m);
-        if (P) hipLaunchKernelGGL(match_scan_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dx, dpairs, P, dpidx);
-        hipLaunchKernelGGL(match_resolve_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dpairs, dpidx, n_m, dmatch);
+        hipLaunchKernelGGL(match_init_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, s->pidx, n_m);
+        if (P) hipLaunchKernelGGL(match_scan_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, s->x, s->pairs, P, s->pidx);
+        hipLaunchKernelGGL(match_resolve_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, s->pairs, s->pidx, n_m, s->match);
         HIP_TRY(ctx, hipGetLastError());
-        if (out_match) SAME_TRY(same_down(ctx, out_match, dmatch, (size_t)n_m * sizeof(int32_t)));
-        if (out_pair_idx) SAME_TRY(same_down(ctx, out_pair_idx, dpidx, (size_t)n_m * sizeof(int32_t)));
+        if (out_match) SAME_TRY(same_down(ctx, out_match, s->match, (size_t)n_m * sizeof(int32_t)));
+        if (out_pair_idx) SAME_TRY(same_down(ctx, out_pair_idx, s->pidx, (size_t)n_m * sizeof(int32_t)));
     }
-    return run_orient(ctx, dmatch, out_checked, out_viol_idx, out_nviol, out_flag);
+    return run_orient(s, s->match, out_checked, out_viol_idx, out_nviol, out_flag);
 }
 
 int same_xyorder_sweep(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy, int64_t n_r,
@@ -487,11 +552,43 @@ int same_xyorder_sweep_dev(same_ctx *ctx, const double *daxy, int64_t n_m, const
 }
 
 // orientation sweep on the bound state with a match vector that is already on the device
-int same_orient_sweep_dev(same_ctx *ctx, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx,
+int same_orient_sweep_dev(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx,
                           int64_t *out_nviol) {
-    REQUIRE(ctx, ctx && ctx->bound && out_checked && out_nviol && (ctx->b_nm == 0 || dmatch));
+    if (!s) return SAME_EINVAL;
+    REQUIRE(s->ctx, out_checked && out_nviol && (s->n_m == 0 || dmatch));
+    SAME_TRY(same_use(s->ctx));
+    return run_orient(s, dmatch, out_checked, out_viol_idx, out_nviol, nullptr);
+}
+
+// triangle-block form for the sharded sweep: flags of [t_begin, t_end) only, enqueued
+int same_orient_flags_dev(same_sweep *s, const int32_t *dmatch, int64_t t_begin, int64_t t_end, uint8_t *dflag) {
+    if (!s) return SAME_EINVAL;
+    same_ctx *ctx = s->ctx;
+    REQUIRE(ctx, t_begin >= 0 && t_begin <= t_end && t_end <= s->Tr && (t_begin == t_end || (dmatch && dflag)));
+    REQUIRE(ctx, t_begin == t_end || t_begin % 64 == 0);  // whole waves: a block's per-wave masks must not straddle its start
     SAME_TRY(same_use(ctx));
-    return run_orient(ctx, dmatch, out_checked, out_viol_idx, out_nviol, nullptr);
+    HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    return launch_orient_flags(s, dmatch, t_begin, t_end, dflag, s->mask + t_begin / 64, s->cnt);
+}
+
+int same_orient_from_flags_dev(same_sweep *s, const uint8_t *dflag, int64_t *out_checked, int32_t *out_viol_idx,
+                               int64_t *out_nviol) {
+    if (!s) return SAME_EINVAL;
+    REQUIRE(s->ctx, out_checked && out_nviol && (s->Tr == 0 || dflag));
+    SAME_TRY(same_use(s->ctx));
+    *out_checked = 0;
+    *out_nviol = 0;
+    if (s->Tr == 0) return SAME_OK;
+    return compact_from_flags(s, dflag, false, out_checked, out_viol_idx, out_nviol);
+}
+
+int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, int k, int32_t *dmatch) {
+    REQUIRE(ctx, ctx && rows >= 0 && k >= 1 && (rows == 0 || (didx && dmatch)));
+    SAME_TRY(same_use(ctx));
+    if (rows == 0) return SAME_OK;
+    hipLaunchKernelGGL(first_candidate_kernel, dim3(grid_for(rows)), dim3(256), 0, ctx->stream, didx, rows, k, dmatch);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
 }
 
 }  // extern "C"

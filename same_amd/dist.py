@@ -1,18 +1,29 @@
-"""Multi-GPU form of the cost build + prune: aligned-row blocks per rank, one all-gather.
+"""Multi-GPU forms of the path: one process per GPU, aligned-row blocks for the cost build + prune,
+triangle blocks for the violation sweeps, whole windows for the sliding-window plan.
 
-SURVEY 8e: every kernel on the path is a map over aligned rows with read-only shared inputs,
-so ranks own contiguous row blocks (refs replicated, no merge step) and the only exchange is
-an all-gather of the fixed-width pruned candidate lists -- int32 idx[rows][k] (-1 padded) and
-float64 cost[rows][k] (+inf padded).  One process per GPU; on GPUs the gather is RCCL over xGMI
-on the context's stream (csrc/comm.hip); `HostGather` does the same exchange through a
-torch.distributed process group on host arrays (used by the CPU tests and as a fallback
-transport -- never as a compute fallback).  Results are identical for any world size:
-blocks are concatenated in rank order, then compacted exactly like the single-GPU path.
+SURVEY 8e: every kernel on the path is a map over aligned rows / triangles / windows with read-only
+shared inputs, so ranks own contiguous blocks (refs, match vector and ref coordinates replicated, no
+merge step) and the exchanges are
+  * an all-gather of the fixed-width pruned candidate lists -- int32 idx[rows][k] (-1 padded) and
+    float64 cost[rows][k] (+inf padded);
+  * for the sweeps (src/same.py:645-669, src/violationhelper.py:53-117, src/same.py:1362-1402): an
+    all-gather of the per-triangle flag blocks plus an all-reduce of the counters (integer sums) and
+    of the per-point flags (OR).
+On GPUs both run over RCCL on the context's stream (`RcclGroup`, csrc/comm.hip); `HostGroup`
+(rendezvous.py: loopback TCP in plain Python) carries the same exchanges for host arrays -- that is
+the CPU-test transport and a transport-only fallback, never a compute fallback.  Results are
+identical for any world size: blocks concatenate in rank order, and the ascending flipped-triangle
+list (src/same.py:687-703 depends on that order) is rebuilt from the complete flag array.
 """
+import ctypes
+
 import numpy as np
 
 from . import _lib
 from .knn import compact_pairs, pairs_from_padded
+from .rendezvous import HostGroup  # noqa: F401  (re-exported: the host transport of this module)
+
+TRI_BLOCK_ALIGN = 256  # triangle blocks start on whole-workgroup boundaries (and whole 64-bit flag-mask words)
 
 
 def row_block(n_rows, world, rank):
@@ -22,49 +33,48 @@ def row_block(n_rows, world, rank):
     return begin, min(begin + block, n_rows), block
 
 
-class HostGather:
-    """all-gather of equal-sized host arrays through a torch.distributed group (gloo)."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-
-        self.dist, self.group = dist, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-
-    def allgather(self, arr):
-        import torch
-
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t, group=self.group)
-        return np.concatenate([o.numpy() for o in outs], axis=0)
+def tri_block(n_tri, world, rank):
+    """Triangle blocks for the sharded sweeps: equal width, a multiple of TRI_BLOCK_ALIGN, so block r starts at r*block in
+    the gathered arrays and a triangle's position there is its index.  -> (begin, end, block)."""
+    block = -(-max(n_tri, 1) // world)
+    block = -(-block // TRI_BLOCK_ALIGN) * TRI_BLOCK_ALIGN
+    begin = min(rank * block, n_tri)
+    return begin, min(begin + block, n_tri), block
 
 
-class RcclGather:
-    """RCCL communicator bound to a Context.  `exchange_id(bytes_or_None) -> bytes` is any host
-    broadcast from rank 0 (bench.py uses torch.distributed's store)."""
+class RcclGroup:
+    """RCCL communicator bound to a Context.  `exchange_id(bytes_or_None) -> bytes` is any host broadcast from rank 0
+    (HostGroup.bcast_bytes; a launcher with MPI or a file can pass its own)."""
 
     def __init__(self, ctx, world, rank, exchange_id):
-        self.ctx, self.world, self.rank = ctx, world, rank
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
         uid = None
-        if rank == 0:
-            import ctypes
-
+        if self.rank == 0:
             buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
             ctx.check(ctx.lib.same_comm_unique_id(buf), "same_comm_unique_id")
             uid = buf.raw
         uid = exchange_id(uid)
-        assert len(uid) == _lib.UNIQUE_ID_BYTES
-        ctx.check(ctx.lib.same_comm_init(ctx.handle, world, rank, uid), "same_comm_init")
+        if len(uid) != _lib.UNIQUE_ID_BYTES:
+            raise ValueError("the exchanged RCCL unique id has the wrong length")
+        ctx.check(ctx.lib.same_comm_init(ctx.handle, self.world, self.rank, uid), "same_comm_init")
 
-    def allgather_dev(self, send_buf, recv_buf, send_bytes):
+    def rccl_version(self):
+        v = ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.same_comm_info(self.ctx.handle, None, None, ctypes.byref(v)), "same_comm_info")
+        return v.value
+
+    def allgather_dev(self, send_buf, recv_buf, send_bytes, send_offset=0):
         c = self.ctx
-        c.check(c.lib.same_allgather_dev(c.handle, send_buf.ptr, recv_buf.ptr, send_bytes), "same_allgather_dev")
+        c.check(c.lib.same_allgather_dev(c.handle, send_buf.ptr + send_offset, recv_buf.ptr, send_bytes), "same_allgather_dev")
 
     def allgather_dev_async(self, send_buf, recv_buf, send_bytes):
         """Gather on the context's communication stream, overlapping whatever compute is queued next."""
         c = self.ctx
         c.check(c.lib.same_allgather_dev_async(c.handle, send_buf.ptr, recv_buf.ptr, send_bytes), "same_allgather_dev_async")
+
+    def allreduce_dev(self, buf, count, dtype, op):
+        c = self.ctx
+        c.check(c.lib.same_allreduce_dev(c.handle, buf.ptr, int(count), int(dtype), int(op)), "same_allreduce_dev")
 
     def wait(self):
         """Order the compute stream after every gather issued so far (stream-side; the host does not block)."""
@@ -74,6 +84,10 @@ class RcclGather:
         self.ctx.lib.same_comm_destroy(self.ctx.handle)
 
 
+RcclGather = RcclGroup  # round-1 name
+
+
+# ---- cost build + prune over aligned-row blocks ----------------------------------------------------
 def hip_block_compute(ctx, A, R, axy, rxy, radius, knn, w):
     """Per-rank compute on the GPU: resident operands, prune + padded costs for one row block."""
     A, R = _lib.as_c(A, np.float64), _lib.as_c(R, np.float64)
@@ -95,27 +109,27 @@ def hip_block_compute(ctx, A, R, axy, rxy, radius, knn, w):
     return compute
 
 
-def sharded_knn_cost_host(compute_block, n_aligned, knn, gather):
+def sharded_knn_cost_host(compute_block, n_aligned, knn, group):
     """Host-array form: compute_block(begin, end) -> (idx (rows,k) int32, cost (rows,k) f64);
     returns the gathered, unpadded (idx, cost) for all n_aligned rows on every rank."""
-    begin, end, block = row_block(n_aligned, gather.world, gather.rank)
+    begin, end, block = row_block(n_aligned, group.world, group.rank)
     idx_p = np.full((block, knn), -1, np.int32)
     cost_p = np.full((block, knn), np.inf, np.float64)
     if end > begin:
         idx, cost = compute_block(begin, end)
         idx_p[: end - begin], cost_p[: end - begin] = idx, cost
-    return gather.allgather(idx_p)[:n_aligned], gather.allgather(cost_p)[:n_aligned]
+    return group.allgather_array(idx_p)[:n_aligned], group.allgather_array(cost_p)[:n_aligned]
 
 
-def sharded_knn_cost_device(ctx, compute, n_aligned, knn, gather):
+def sharded_knn_cost_device(ctx, compute, n_aligned, knn, comm):
     """Device form: prune + cost for this rank's block, RCCL all-gather, one D2H of the result."""
-    begin, end, block = row_block(n_aligned, gather.world, gather.rank)
+    begin, end, block = row_block(n_aligned, comm.world, comm.rank)
     didx, dcost, _ = compute(begin, end, block)
-    gidx, gcost = ctx.alloc(block * knn * 4 * gather.world), ctx.alloc(block * knn * 8 * gather.world)
-    gather.allgather_dev(didx, gidx, block * knn * 4)
-    gather.allgather_dev(dcost, gcost, block * knn * 8)
-    idx = gidx.download((block * gather.world, knn), np.int32)[:n_aligned]
-    cost = gcost.download((block * gather.world, knn), np.float64)[:n_aligned]
+    gidx, gcost = ctx.alloc(block * knn * 4 * comm.world), ctx.alloc(block * knn * 8 * comm.world)
+    comm.allgather_dev(didx, gidx, block * knn * 4)
+    comm.allgather_dev(dcost, gcost, block * knn * 8)
+    idx = gidx.download((block * comm.world, knn), np.int32)[:n_aligned]
+    cost = gcost.download((block * comm.world, knn), np.float64)[:n_aligned]
     return idx, cost
 
 
@@ -129,36 +143,174 @@ def pairs_and_costs(aligned_df, ref_df, idx, cost):
     return new_a, new_r, new_pairs, c
 
 
+# ---- violation sweeps over triangle blocks -----------------------------------------------------------
+def _gather_blocks(group, part, block, n, width=None):
+    """Pad this rank's rows to `block`, all-gather, cut to n."""
+    shape = (block,) if width is None else (block, width)
+    padded = np.zeros(shape, part.dtype)
+    padded[: len(part)] = part
+    return group.allgather_array(padded)[:n]
+
+
+def sharded_orient_sweep_host(compute_flags, n_tri, group):
+    """Lazy-constraint orientation sweep (src/same.py:645-669) over triangle blocks.
+    compute_flags(t0, t1) -> uint8 flag per triangle of [t0, t1) (0 skipped, 1 checked, 2 flipped).
+    -> (checked, violating triangle indices ascending, flags of all triangles), identical on every rank."""
+    t0, t1, block = tri_block(n_tri, group.world, group.rank)
+    mine = np.asarray(compute_flags(t0, t1), np.uint8) if t1 > t0 else np.zeros(0, np.uint8)
+    flags = _gather_blocks(group, mine, block, n_tri)
+    checked = int(group.sum_int([np.count_nonzero(mine)])[0])
+    return checked, np.flatnonzero(flags == 2).astype(np.int32), flags
+
+
+def sharded_xyorder_sweep_host(compute_block, n_tri, n_aligned, group):
+    """XY-order sweep (src/violationhelper.py:53-117) over triangle blocks.
+    compute_block(t0, t1) -> (edge_flags (n,3) u8, tri_flag (n,) u8, point_flag (n_aligned,) u8, counts (3,) int64).
+    -> the same four for the whole triangle list on every rank."""
+    t0, t1, block = tri_block(n_tri, group.world, group.rank)
+    if t1 > t0:
+        edge, tflag, pflag, counts = compute_block(t0, t1)
+    else:
+        edge, tflag = np.zeros((0, 3), np.uint8), np.zeros(0, np.uint8)
+        pflag, counts = np.zeros(n_aligned, np.uint8), np.zeros(3, np.int64)
+    edge_all = _gather_blocks(group, np.asarray(edge, np.uint8).reshape(-1, 3), block, n_tri, 3)
+    tflag_all = _gather_blocks(group, np.asarray(tflag, np.uint8), block, n_tri)
+    pflag_all = group.allgather_array(np.asarray(pflag, np.uint8).reshape(1, -1)).max(axis=0)  # OR over ranks
+    return edge_all, tflag_all, pflag_all, group.sum_int(counts)
+
+
+def sharded_area_flip_host(compute_block, n_tri, group):
+    """Signed areas before / after and flips (src/same.py:1362-1402) over triangle blocks.
+    compute_block(t0, t1) -> (before f64, after f64, matched3 (n,3) u8, flipped u8)."""
+    t0, t1, block = tri_block(n_tri, group.world, group.rank)
+    if t1 > t0:
+        before, after, m3, fl = compute_block(t0, t1)
+    else:
+        before, after, m3, fl = np.zeros(0), np.zeros(0), np.zeros((0, 3), np.uint8), np.zeros(0, np.uint8)
+    return (_gather_blocks(group, np.asarray(before, np.float64), block, n_tri),
+            _gather_blocks(group, np.asarray(after, np.float64), block, n_tri),
+            _gather_blocks(group, np.asarray(m3, np.uint8).reshape(-1, 3), block, n_tri, 3),
+            _gather_blocks(group, np.asarray(fl, np.uint8), block, n_tri))
+
+
+def sharded_verify_spatial_preservation(aligned_df, ref_df, matches_df, triangle_info, group, block_sweep=None, ctx=None):
+    """verify_spatial_preservation (src/violationhelper.py:1-134) with the triangle loop split over the ranks of `group`;
+    every rank returns the single-process report.  block_sweep(axy, rxy, tris_block, match) defaults to the HIP sweep."""
+    from . import ops, sweeps
+
+    fn = block_sweep or (lambda a, r, t, m: ops.xyorder_sweep(a, r, t, m, ctx=ctx))
+
+    def sweep(axy, rxy, tris, match):
+        return sharded_xyorder_sweep_host(lambda t0, t1: fn(axy, rxy, tris[t0:t1], match), len(tris), len(axy), group)
+
+    return sweeps.verify_spatial_preservation(aligned_df, ref_df, matches_df, triangle_info, _sweep=sweep)
+
+
+def sharded_triangle_area_flips(aligned_df, ref_df, aligned_delaunay, aligned_to_ref, group, block_sweep=None, ctx=None):
+    """triangle_area_flips (src/same.py:1355-1402) over triangle blocks; every rank returns the single-process result."""
+    from . import ops, sweeps
+
+    fn = block_sweep or (lambda a, r, t, m: ops.area_flip(a, r, t, m, ctx=ctx))
+
+    def sweep(axy, rxy, tris, match):
+        return sharded_area_flip_host(lambda t0, t1: fn(axy, rxy, tris[t0:t1], match), len(tris), group)
+
+    return sweeps.triangle_area_flips(aligned_df, ref_df, aligned_delaunay, aligned_to_ref, _sweep=sweep)
+
+
+class ShardedSweeps:
+    """Device form: the three sweeps of ONE problem over this rank's triangle block, exchanged over RCCL.
+
+    Operands are resident and replicated on every rank (aligned / ref XY, triangles, match vector -- a few MB); outputs
+    are complete on every rank after `run()`.  All work is enqueued on the context's stream; only the orientation
+    sweep's two counters and its flipped list come back to the host (as in the single-GPU sweep)."""
+
+    def __init__(self, ctx, comm, sweep_handle, daxy, drxy, dtris, n_tri, n_aligned):
+        self.ctx, self.comm, self.sweep = ctx, comm, sweep_handle
+        self.daxy, self.drxy, self.dtris, self.Tr, self.n_m = daxy, drxy, dtris, int(n_tri), int(n_aligned)
+        world = comm.world
+        self.t0, self.t1, self.block = tri_block(self.Tr, world, comm.rank)
+        full = self.block * world
+        a = ctx.alloc
+        # this rank's blocks live at their absolute positions inside full-size arrays; gathers go into second arrays
+        self.flag_l, self.flag_g = a(full), a(full)
+        self.edge_l, self.edge_g = a(full * 3), a(full * 3)
+        self.tflag_l, self.tflag_g = a(full), a(full)
+        self.m3_l, self.m3_g = a(full * 3), a(full * 3)
+        self.flip_l, self.flip_g = a(full), a(full)
+        self.before_l, self.before_g = a(full * 8), a(full * 8)
+        self.after_l, self.after_g = a(full * 8), a(full * 8)
+        self.pflag, self.counts = a(max(self.n_m, 1)), a(32)
+        for b in (self.flag_l, self.edge_l, self.tflag_l, self.m3_l, self.flip_l, self.before_l, self.after_l):
+            ctx.check(ctx.lib.same_dev_memset(ctx.handle, b.ptr, 0, b.nbytes), "memset")  # padding past the last triangle
+        self.viol = np.empty(max(self.Tr, 1), np.int32)
+
+    def run(self, dmatch):
+        """Enqueue all three sweeps for this rank's block + the exchanges; -> (checked, violating idx ascending)."""
+        c, L, H = self.ctx, self.ctx.lib, self.ctx.handle
+        t0, n, B = self.t0, self.t1 - self.t0, self.block
+        off = self.comm.rank * B   # == t0 unless this rank's block is empty
+        chk = c.check
+        chk(L.same_orient_flags_dev(self.sweep, dmatch.ptr, t0, self.t1, self.flag_l.ptr), "same_orient_flags_dev")
+        chk(L.same_xyorder_sweep_dev(H, self.daxy.ptr, self.n_m, self.drxy.ptr, self.dtris.ptr + 12 * t0, n, dmatch.ptr,
+                                     self.edge_l.ptr + 3 * off, self.tflag_l.ptr + off, self.pflag.ptr, self.counts.ptr), "xyorder")
+        chk(L.same_area_flip_dev(H, self.daxy.ptr, self.drxy.ptr, self.dtris.ptr + 12 * t0, n, dmatch.ptr,
+                                 self.before_l.ptr + 8 * off, self.after_l.ptr + 8 * off, self.m3_l.ptr + 3 * off,
+                                 self.flip_l.ptr + off), "area_flip")
+        g = self.comm
+        for loc, glob, width in ((self.flag_l, self.flag_g, 1), (self.edge_l, self.edge_g, 3), (self.tflag_l, self.tflag_g, 1),
+                                 (self.m3_l, self.m3_g, 3), (self.flip_l, self.flip_g, 1), (self.before_l, self.before_g, 8),
+                                 (self.after_l, self.after_g, 8)):
+            g.allgather_dev(loc, glob, B * width, send_offset=off * width)
+        g.allreduce_dev(self.counts, 3, _lib.DT_U64, _lib.OP_SUM)
+        g.allreduce_dev(self.pflag, self.n_m, _lib.DT_U8, _lib.OP_MAX)
+        checked, nviol = ctypes.c_int64(0), ctypes.c_int64(0)
+        chk(L.same_orient_from_flags_dev(self.sweep, self.flag_g.ptr, ctypes.byref(checked), self.viol.ctypes.data,
+                                         ctypes.byref(nviol)), "same_orient_from_flags_dev")
+        return checked.value, self.viol[: nviol.value].copy()
+
+    def download(self):
+        """Complete outputs (any rank): dict of host arrays shaped like the single-GPU sweeps' outputs."""
+        Tr = self.Tr
+        return {"flag": self.flag_g.download((Tr,), np.uint8), "edge": self.edge_g.download((Tr, 3), np.uint8),
+                "tri_flag": self.tflag_g.download((Tr,), np.uint8), "point_flag": self.pflag.download((self.n_m,), np.uint8),
+                "counts": self.counts.download((3,), np.uint64).astype(np.int64),
+                "before": self.before_g.download((Tr,), np.float64), "after": self.after_g.download((Tr,), np.float64),
+                "matched3": self.m3_g.download((Tr, 3), np.uint8), "flipped": self.flip_g.download((Tr,), np.uint8)}
+
+
+# ---- sliding windows over ranks -------------------------------------------------------------------------
 def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, **kwargs):
     """BASELINE cfg 5 on N GPUs: windows are independent, so every rank (one process per GPU) runs its round-robin share of
     the window plan -- heaviest windows first, `windows.assign_windows` -- and the per-window match tables are exchanged once
     over a host channel (they are small frames, not a device collective).  Every rank returns the frame a single process
     would return: windows in plan order, rows in window order.
 
-    The host channel is `torch.distributed.all_gather_object` on `group` by default; any launcher can supply its own
-    `exchange(obj) -> [obj of rank 0, ..., obj of rank world-1]` together with `rank` and `world` (MPI, files, a queue).
-    `outprefix`, if given, gets a per-rank subdirectory (`rank{r}`) so ranks never write the same CSV."""
+    The host channel is `group.allgather_object` of a `HostGroup` (built from RANK / WORLD_SIZE when none is given); any
+    launcher can supply its own `exchange(obj) -> [obj of rank 0, ..., obj of rank world-1]` together with `rank` and
+    `world` (MPI, files, a queue).  `outprefix`, if given, gets a per-rank subdirectory (`rank{r}`) so ranks never write
+    the same CSV."""
     import os
 
     import pandas as pd
 
     from .api import sliding_window_matching
 
+    own_group = None
     if exchange is None:
-        import torch.distributed as dist
-
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
-
-        def exchange(obj):
-            parts = [None] * world
-            dist.all_gather_object(parts, obj, group=group)
-            return parts
+        if group is None:
+            group = own_group = HostGroup()
+        world, rank, exchange = group.world, group.rank, group.allgather_object
     elif rank is None or world is None:
         raise ValueError("a custom exchange needs rank and world")
-    if kwargs.get("outprefix"):
-        kwargs["outprefix"] = os.path.join(kwargs["outprefix"], f"rank{rank}")
-    part = sliding_window_matching(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world)), **kwargs)
-    parts = [p for p in exchange(part) if p is not None and len(p)]
+    try:
+        if kwargs.get("outprefix"):
+            kwargs["outprefix"] = os.path.join(kwargs["outprefix"], f"rank{rank}")
+        part = sliding_window_matching(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world)), **kwargs)
+        parts = [p for p in exchange(part) if p is not None and len(p)]
+    finally:
+        if own_group is not None:
+            own_group.close()
     if not parts:
         return pd.DataFrame()
     merged = pd.concat(parts, ignore_index=True)

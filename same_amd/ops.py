@@ -101,61 +101,65 @@ def tri_sign_weight(xy, size, triangles, ctx=None):
 
 
 class BoundSweep:
-    """Resident state of the lazy-constraint sweep (model._* of src/same.py:1153-1158)."""
+    """Resident state of the lazy-constraint sweep (model._* of src/same.py:1153-1158): one same_sweep handle that owns
+    its device blocks.  Any number of these may live on one context; calls are serialised on the context's lock (the
+    solver may call back from a thread other than the one that built the model)."""
 
     def __init__(self, triangles, src_sign, rxy, n_aligned, pairs=None, ctx=None):
-        self.ctx = _ctx(ctx)
-        self.tris = _tris(triangles)
-        self.src_sign = as_c(np.asarray(src_sign), I8)
-        self.rxy = as_c(rxy, F64).reshape(-1, 2)
+        self.ctx = c = _ctx(ctx)
+        tris = _tris(triangles)
+        src_sign = as_c(np.asarray(src_sign), I8)
+        rxy = as_c(rxy, F64).reshape(-1, 2)
         self.n_m = int(n_aligned)
-        self.pairs = None if pairs is None else as_c(pairs, I32).reshape(-1, 2)
-        self.P = 0 if self.pairs is None else len(self.pairs)
-        self.Tr = len(self.tris)
-        assert len(self.src_sign) == self.Tr
-        self._viol = np.empty(max(self.Tr, 1), I32)
-        self._bind()
-
-    def _bind(self):
-        c = self.ctx
+        pairs = None if pairs is None else as_c(pairs, I32).reshape(-1, 2)
+        self.P = 0 if pairs is None else len(pairs)
+        self.has_pairs = pairs is not None
+        self.Tr, self.n_r = len(tris), len(rxy)
+        assert len(src_sign) == self.Tr
+        h = ctypes.c_void_p()
         with c.lock:
-            c.check(c.lib.same_sweep_bind(c.handle, self.tris.ctypes.data, self.Tr, self.src_sign.ctypes.data,
-                                          self.rxy.ctypes.data, len(self.rxy), self.n_m, _lib._ptr(self.pairs), self.P),
-                    "same_sweep_bind")
-        c._bound_owner = id(self)
-
-    def _ensure_bound(self):
-        if getattr(self.ctx, "_bound_owner", None) != id(self):
-            self._bind()
+            c.check(c.lib.same_sweep_bind(c.handle, tris.ctypes.data, self.Tr, src_sign.ctypes.data, rxy.ctypes.data,
+                                          self.n_r, self.n_m, _lib._ptr(pairs), self.P, ctypes.byref(h)), "same_sweep_bind")
+        self.handle = h.value
 
     def sweep_match(self, match, want_flag=False):
         """match (n_aligned,) int32, -1 unmatched -> (checked, violating idx ascending[, flag])."""
         c = self.ctx
-        self._ensure_bound()
         match = as_c(match, I32)
-        assert len(match) == self.n_m
         checked, nviol = c_i64(0), c_i64(0)
         flag = np.empty(self.Tr, U8) if want_flag else None
+        viol = np.empty(max(self.Tr, 1), I32)   # per call: concurrent callers never share an output buffer
         with c.lock:
-            c.check(c.lib.same_orient_sweep(c.handle, match.ctypes.data, ctypes.byref(checked), self._viol.ctypes.data,
+            c.check(c.lib.same_orient_sweep(self.handle, match.ctypes.data, len(match), ctypes.byref(checked), viol.ctypes.data,
                                             ctypes.byref(nviol), _lib._ptr(flag)), "same_orient_sweep")
-        viol = self._viol[: nviol.value].copy()
+        viol = viol[: nviol.value].copy()
         return (checked.value, viol, flag) if want_flag else (checked.value, viol)
 
     def sweep_x(self, x_vals):
         """x_vals (P,) -> (checked, violating idx ascending, match, pair_idx)."""
         c = self.ctx
-        self._ensure_bound()
-        assert self.pairs is not None
+        assert self.has_pairs
         x = as_c(x_vals, F64)
-        assert len(x) == self.P
         checked, nviol = c_i64(0), c_i64(0)
         match, pidx = np.empty(self.n_m, I32), np.empty(self.n_m, I32)
+        viol = np.empty(max(self.Tr, 1), I32)
         with c.lock:
-            c.check(c.lib.same_orient_sweep_x(c.handle, x.ctypes.data, ctypes.byref(checked), self._viol.ctypes.data,
+            c.check(c.lib.same_orient_sweep_x(self.handle, x.ctypes.data, len(x), ctypes.byref(checked), viol.ctypes.data,
                                               ctypes.byref(nviol), None, match.ctypes.data, pidx.ctypes.data),
                     "same_orient_sweep_x")
-        return checked.value, self._viol[: nviol.value].copy(), match, pidx
+        return checked.value, viol[: nviol.value].copy(), match, pidx
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            with self.ctx.lock:
+                self.ctx.lib.same_sweep_unbind(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def xyorder_sweep(axy, rxy, triangles, match, ctx=None):

@@ -1,0 +1,203 @@
+"""Host control plane for the ranks of one node, in plain Python (no torch, no MPI).
+
+One process per GPU needs very little from the host side: hand the 128-byte RCCL unique id from
+rank 0 to the others, a barrier and a max-reduce around timed regions, and now and then an
+exchange of small host objects (per-window match tables).  `HostGroup` does that over loopback
+TCP as a star: rank 0 listens on an ephemeral port of 127.0.0.1 and publishes `{port, token}` in
+a rendezvous directory; the other ranks poll for that file and connect.  Every collective is one
+round trip through rank 0 (gather in rank order, answer to all), so results are ordered and
+identical on every rank.
+
+How ranks find the directory (`default_rdv_dir`):
+  * `SAME_RDV_DIR` if the launcher set it (bench.py's own launcher makes a fresh temp dir);
+  * otherwise a path under the temp dir keyed by MASTER_PORT, the parent's PID and the parent's
+    start time -- under `python -m torch.distributed.run` every worker is a child of the same
+    agent process, whose TCP store already occupies MASTER_PORT itself, so the ranks meet on a
+    port of their own.
+
+The data path never goes through here on GPUs: pruned candidate lists and sweep flags travel by
+RCCL (csrc/comm.hip).  `allgather_array` exists for CPU tests and as a transport (never compute)
+fallback when the RCCL communicator cannot be created.
+"""
+import json
+import os
+import pickle
+import secrets
+import socket
+import struct
+import tempfile
+import time
+
+import numpy as np
+
+_HDR = struct.Struct("<IQ")  # sequence number, payload length
+
+
+def _proc_start_time(pid):
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return f.read().rsplit(")", 1)[1].split()[19]  # field 22: starttime in clock ticks
+    except (OSError, IndexError):
+        return "0"
+
+
+def default_rdv_dir():
+    d = os.environ.get("SAME_RDV_DIR")
+    if d:
+        return d
+    ppid = os.getppid()
+    key = f"{os.environ.get('MASTER_PORT', '0')}_{ppid}_{_proc_start_time(ppid)}"
+    return os.path.join(tempfile.gettempdir(), f"same_rdv_{os.getuid()}_{key}")
+
+
+def _recv_exact(sock, n):
+    buf = bytearray(n)
+    view, got = memoryview(buf), 0
+    while got < n:
+        r = sock.recv_into(view[got:], n - got)
+        if r == 0:
+            raise ConnectionError("peer closed the rendezvous connection")
+        got += r
+    return bytes(buf)
+
+
+def _send_frame(sock, seq, payload):
+    sock.sendall(_HDR.pack(seq, len(payload)))
+    if payload:
+        sock.sendall(payload)
+
+
+def _recv_frame(sock, seq):
+    got_seq, n = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if got_seq != seq:
+        raise RuntimeError(f"rendezvous out of step: expected collective #{seq}, peer sent #{got_seq}")
+    return _recv_exact(sock, n) if n else b""
+
+
+class HostGroup:
+    """rank/world as given (or from RANK / WORLD_SIZE); world 1 needs no sockets."""
+
+    def __init__(self, rank=None, world=None, rdv_dir=None, timeout=600.0):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        if not (0 <= self.rank < self.world):
+            raise ValueError(f"rank {self.rank} outside world {self.world}")
+        self.timeout = float(timeout)
+        self._seq = 0
+        self._peers = {}    # rank 0: rank -> socket
+        self._hub = None    # other ranks: socket to rank 0
+        self._listener = None
+        self._dir = None
+        if self.world == 1:
+            return
+        self._dir = rdv_dir or default_rdv_dir()
+        hub_file = os.path.join(self._dir, "hub.json")
+        if self.rank == 0:
+            os.makedirs(self._dir, exist_ok=True)
+            token = secrets.token_hex(16)
+            ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            ls.bind(("127.0.0.1", 0))
+            ls.listen(self.world)
+            ls.settimeout(self.timeout)
+            self._listener = ls
+            tmp = hub_file + f".{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump({"port": ls.getsockname()[1], "token": token, "world": self.world}, f)
+            os.replace(tmp, hub_file)  # atomic: readers see nothing or the whole file
+            while len(self._peers) < self.world - 1:
+                conn, _ = ls.accept()
+                conn.settimeout(self.timeout)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                hello = _recv_exact(conn, 36)
+                peer = struct.unpack("<I", hello[32:])[0]
+                if hello[:32] != token.encode() or not (0 < peer < self.world) or peer in self._peers:
+                    conn.close()  # not one of this job's ranks
+                    continue
+                self._peers[peer] = conn
+        else:
+            deadline = time.monotonic() + self.timeout
+            info = None
+            while info is None:
+                try:
+                    with open(hub_file) as f:
+                        info = json.load(f)
+                except (OSError, ValueError):
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"rank {self.rank}: no rendezvous file {hub_file} after {self.timeout:.0f} s")
+                    time.sleep(0.02)
+            if info.get("world") != self.world:
+                raise RuntimeError(f"rendezvous file is for world {info.get('world')}, this rank expects {self.world}")
+            s = socket.create_connection(("127.0.0.1", int(info["port"])), timeout=self.timeout)
+            s.settimeout(self.timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.sendall(info["token"].encode() + struct.pack("<I", self.rank))
+            self._hub = s
+        self.barrier()
+
+    # -- the one primitive: ordered all-gather of byte strings ---------------------------------
+    def allgather_bytes(self, payload):
+        payload = bytes(payload)
+        if self.world == 1:
+            return [payload]
+        seq = self._seq = (self._seq + 1) & 0xFFFFFFFF
+        if self.rank == 0:
+            parts = [payload] + [_recv_frame(self._peers[r], seq) for r in range(1, self.world)]
+            blob = b"".join(struct.pack("<Q", len(p)) + p for p in parts)
+            for r in range(1, self.world):
+                _send_frame(self._peers[r], seq, blob)
+            return parts
+        _send_frame(self._hub, seq, payload)
+        blob, parts, off = _recv_frame(self._hub, seq), [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<Q", blob, off)
+            parts.append(blob[off + 8: off + 8 + n])
+            off += 8 + n
+        return parts
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def bcast_bytes(self, payload, src=0):
+        return self.allgather_bytes(payload if self.rank == src else b"")[src]
+
+    def max(self, v):
+        return max(struct.unpack("<d", p)[0] for p in self.allgather_bytes(struct.pack("<d", float(v))))
+
+    def min(self, v):
+        return min(struct.unpack("<d", p)[0] for p in self.allgather_bytes(struct.pack("<d", float(v))))
+
+    def sum_int(self, values):
+        """Element-wise sum of a short int64 vector over ranks (sweep counters)."""
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        return np.sum([np.frombuffer(p, np.int64) for p in self.allgather_bytes(v.tobytes())], axis=0).reshape(v.shape)
+
+    def allgather_array(self, arr):
+        """Concatenate equal-shaped arrays along axis 0 in rank order."""
+        a = np.ascontiguousarray(arr)
+        parts = [np.frombuffer(p, a.dtype).reshape((-1,) + a.shape[1:]) for p in self.allgather_bytes(a.tobytes())]
+        return np.concatenate(parts, axis=0)
+
+    def allgather_object(self, obj):
+        """Small host objects between this job's own ranks (pickle over the authenticated loopback connections)."""
+        return [pickle.loads(p) for p in self.allgather_bytes(pickle.dumps(obj, protocol=4))]
+
+    def close(self):
+        for s in list(self._peers.values()) + [self._hub, self._listener]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers, self._hub, self._listener = {}, None, None
+        if self.rank == 0 and self._dir:
+            try:
+                os.remove(os.path.join(self._dir, "hub.json"))
+                os.rmdir(self._dir)
+            except OSError:
+                pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -54,15 +54,17 @@ def match_vector(n_aligned, aligned_idx, ref_idx):
     return m
 
 
-def verify_spatial_preservation(aligned_df, ref_df, matches_df, triangle_info, tolerance=1e-6, ctx=None):
-    """Same report as src/violationhelper.py:1-134 (`tolerance` is unused there too)."""
+def verify_spatial_preservation(aligned_df, ref_df, matches_df, triangle_info, tolerance=1e-6, ctx=None, _sweep=None):
+    """Same report as src/violationhelper.py:1-134 (`tolerance` is unused there too).
+    `_sweep(axy, rxy, tris, match) -> (edge, tri_flag, point_flag, counts)` replaces the single-GPU launch (the
+    triangle-block sharded form in dist.py passes its own)."""
     axy = aligned_df[["X", "Y"]].to_numpy(dtype=np.float64)
     rxy = ref_df[["X", "Y"]].to_numpy(dtype=np.float64)
     match = match_vector(len(aligned_df), matches_df["aligned_idx"].to_numpy(), matches_df["ref_idx"].to_numpy())
     keys = list(triangle_info.keys())
     verts = [triangle_info[k]["vertices"] for k in keys]
     tris = np.array([list(v) for v in verts], dtype=np.int64).reshape(-1, 3)
-    edge, tflag, pflag, counts = ops.xyorder_sweep(axy, rxy, tris, match, ctx=ctx)
+    edge, tflag, pflag, counts = _sweep(axy, rxy, tris, match) if _sweep else ops.xyorder_sweep(axy, rxy, tris, match, ctx=ctx)
 
     violations = {"x_order_violations": [], "y_order_violations": [], "triangles_with_violations": set(),
                   "points_with_violations": set(),
@@ -109,16 +111,16 @@ def print_violation_report(violations):
     print(f"Number of points involved in violations: {len(violations['points_with_violations'])}")
 
 
-def triangle_area_flips(aligned_df, ref_df, aligned_delaunay, aligned_to_ref, ctx=None):
+def triangle_area_flips(aligned_df, ref_df, aligned_delaunay, aligned_to_ref, ctx=None, _sweep=None):
     """src/same.py:1355-1402 -> (areas_before dict, areas_after dict (None if unmatched),
-    flipped list ascending, matched_vertices dict)."""
+    flipped list ascending, matched_vertices dict).  `_sweep(axy, rxy, tris, match)` as in verify_spatial_preservation."""
     axy = aligned_df[["X", "Y"]].to_numpy(dtype=np.float64)
     rxy = ref_df[["X", "Y"]].to_numpy(dtype=np.float64)
     match = np.full(len(aligned_df), -1, np.int32)
     for i, j in aligned_to_ref.items():
         match[int(i)] = int(j)
     tris = np.asarray(aligned_delaunay).reshape(-1, 3) if len(aligned_delaunay) else np.zeros((0, 3), dtype=int)
-    before, after, m3, fl = ops.area_flip(axy, rxy, tris, match, ctx=ctx)
+    before, after, m3, fl = _sweep(axy, rxy, tris, match) if _sweep else ops.area_flip(axy, rxy, tris, match, ctx=ctx)
     n = len(tris)
     areas_before = {t: before[t] for t in range(n)}
     areas_after = {t: (after[t] if m3[t].all() else None) for t in range(n)}

@@ -45,29 +45,3 @@ def oracle():
 
 
 FULL_CASES = ["synthetic_example", "cfg1_500", "cfg2_small"]
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _progress_heartbeat():
-    """A run harness may treat several silent minutes as a hang.  pytest prints nothing while one test runs (a cold GPU box can
-    spend minutes paging in librccl / the HIP runtime inside a single test), so a daemon thread notes the time in
-    gpurun_out/pytest_heartbeat.log every 30 s for as long as the session lasts.  Best effort: any error disables it."""
-    import threading
-    import time
-
-    stop = threading.Event()
-    path = os.path.join(ROOT, "gpurun_out", "pytest_heartbeat.log")
-
-    def beat():
-        try:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            while not stop.wait(30.0):
-                with open(path, "a") as f:
-                    f.write(f"{time.strftime('%H:%M:%S')} pytest session alive\n")
-        except OSError:
-            pass
-
-    t = threading.Thread(target=beat, name="pytest-heartbeat", daemon=True)
-    t.start()
-    yield
-    stop.set()

@@ -433,7 +433,7 @@ def test_rccl_gather_single_rank_and_device_sharded_path(ops, oracle):
     """RCCL communicator of size 1 on this GPU: init, all-gather (= copy), destroy; and the device form of the
     sharded prune+cost produces exactly the single-GPU pairs/costs (what N ranks then concatenate)."""
     from same_amd import _lib, synth
-    from same_amd.dist import RcclGather, hip_block_compute, sharded_knn_cost_device
+    from same_amd.dist import RcclGroup as RcclGather, hip_block_compute, sharded_knn_cost_device
 
     ctx = _lib.Context(0)  # own context: the communicator lives and dies with it
     ref = synth.make_cells(5000, 6, seed=0)
@@ -460,6 +460,118 @@ def test_rccl_gather_single_rank_and_device_sharded_path(ops, oracle):
     rr, cc = np.nonzero(oidx >= 0)
     want = oracle.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oidx[rr, cc])), 1.0)
     assert np.array_equal(cost[rr, cc], want) and np.isinf(cost[oidx < 0]).all()
+    ctx.close()
+
+
+def test_sharded_sweeps_rccl_single_rank_and_block_forms(ops, oracle):
+    """The triangle-block sharded sweeps: (i) ShardedSweeps over a size-1 RCCL communicator -- every exchange a
+    real ncclAllGather / ncclAllReduce -- equals the single-GPU sweeps and the oracle; (ii) the block entry points run as
+    the blocks of 1, 2, 3 and 8 ranks on this one GPU (flags written block by block into one array, then compacted) give
+    the same checked count and ascending flipped list."""
+    import ctypes
+    from scipy.spatial import Delaunay
+    from same_amd import _lib, synth
+    from same_amd.dist import RcclGroup, ShardedSweeps, tri_block
+
+    ctx = _lib.Context(0)
+    L, H = ctx.lib, ctx.handle
+    ref = synth.make_cells(30000, 4, seed=3)
+    mov = synth.make_jittered(ref, seed=4, sigma=6.0)
+    n_m = len(mov["xy"])
+    tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)
+    Tr = len(tris)
+    idx, _, cnt = ops.knn_prune(mov["xy"], ref["xy"], 25.0, 4, ctx=ctx)
+    match = np.where(cnt > 0, idx[:, 0], -1).astype(np.int32)
+    match[::7] = -1                                                   # some unmatched vertices
+    sign, _ = ops.tri_sign_weight(mov["xy"], None, tris, ctx=ctx)
+    want_checked, want_viol, want_flag = oracle.orient_sweep(tris, sign, ref["xy"], match)
+    we, wtf, wpf, wcounts = oracle.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
+    wb, wa, wm3, wfl = oracle.area_flip(mov["xy"], ref["xy"], tris, match)
+    assert len(want_viol) > 50 and wcounts[1] > 0
+
+    sweep = ctypes.c_void_p()
+    ctx.check(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign.ctypes.data, ref["xy"].ctypes.data, len(ref["xy"]), n_m, None, 0,
+                                ctypes.byref(sweep)), "bind")
+    dax, drx, dtris, dmatch = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"]), ctx.to_device(tris), ctx.to_device(match)
+    comm = RcclGroup(ctx, 1, 0, lambda b: b)
+    try:
+        assert comm.rccl_version() > 20000
+        sh = ShardedSweeps(ctx, comm, sweep, dax, drx, dtris, Tr, n_m)
+        for _ in range(2):
+            checked, viol = sh.run(dmatch)
+            out = sh.download()
+            assert checked == want_checked and np.array_equal(viol, want_viol) and np.array_equal(out["flag"], want_flag)
+            assert np.array_equal(out["edge"], we) and np.array_equal(out["tri_flag"], wtf) and np.array_equal(out["point_flag"], wpf)
+            assert np.array_equal(out["counts"], wcounts)
+            assert np.array_equal(out["before"], wb) and np.array_equal(out["after"], wa, equal_nan=True)
+            assert np.array_equal(out["matched3"], wm3) and np.array_equal(out["flipped"], wfl)
+        # all-reduce forms on their own
+        buf = ctx.to_device(np.array([5, 7, 11], np.uint64))
+        comm.allreduce_dev(buf, 3, _lib.DT_U64, _lib.OP_SUM)
+        ctx.sync()
+        assert buf.download((3,), np.uint64).tolist() == [5, 7, 11]
+        assert L.same_allreduce_dev(H, buf.ptr, 3, 99, 0) == -22 and L.same_allreduce_dev(H, buf.ptr, 3, 0, 99) == -22
+    finally:
+        comm.close()
+    # (ii) block forms, as G ranks would issue them
+    chk, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+    viol = np.empty(Tr, np.int32)
+    for world in (1, 2, 3, 8):
+        _, _, block = tri_block(Tr, world, 0)
+        dflag = ctx.alloc(block * world)
+        ctx.check(L.same_dev_memset(H, dflag.ptr, 0, dflag.nbytes), "memset")
+        for r in range(world):
+            t0, t1, _ = tri_block(Tr, world, r)
+            ctx.check(L.same_orient_flags_dev(sweep, dmatch.ptr, t0, t1, dflag.ptr), "flags")
+        ctx.check(L.same_orient_from_flags_dev(sweep, dflag.ptr, ctypes.byref(chk), viol.ctypes.data, ctypes.byref(nv)), "from_flags")
+        assert chk.value == want_checked and np.array_equal(viol[: nv.value], want_viol)
+        assert np.array_equal(dflag.download((Tr,), np.uint8), want_flag)
+    assert L.same_orient_flags_dev(sweep, dmatch.ptr, 10, 300, dflag.ptr) == -22      # block start must be a multiple of 64
+    assert L.same_orient_flags_dev(sweep, dmatch.ptr, 0, Tr + 1, dflag.ptr) == -22
+    # first candidate of a padded list
+    didx = ctx.to_device(idx)
+    dm2 = ctx.alloc(n_m * 4)
+    ctx.check(L.same_first_candidate_dev(H, didx.ptr, n_m, 4, dm2.ptr), "first")
+    assert np.array_equal(dm2.download((n_m,), np.int32), idx[:, 0])
+    L.same_sweep_unbind(sweep)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["auto", "grid", "brute"])
+def test_knn_index_equals_unindexed_prune(ops, oracle, mode, monkeypatch):
+    """Caller-held index of the reference set (same_knn_index_build): pruning against it is bit-identical to the
+    rebuild-every-call entry point, for whole sets, row blocks, several k, and the degenerate sets that fall back to brute force."""
+    import ctypes
+    from same_amd import _lib, synth
+
+    if mode != "auto":
+        monkeypatch.setenv("SAME_KNN_MODE", mode)
+    ctx = _lib.Context(0)
+    L, H = ctx.lib, ctx.handle
+    rng = np.random.default_rng(12)
+    r = synth.make_cells(20000, 3, seed=20)
+    cases = [(synth.make_jittered(r, seed=21)["xy"], r["xy"], 25.0),
+             (rng.uniform(-50, 1050, (3000, 2)), rng.uniform(0, 1000, (5000, 2)), 40.0),
+             (rng.uniform(0, 100, (300, 2)), np.tile([[5.0, 5.0]], (2600, 1)), 200.0),       # all refs coincide: no usable grid
+             (rng.uniform(0, 10, (500, 2)), rng.uniform(0, 10, (1000, 2)), 6.0),              # small set: brute-force plan
+             (rng.uniform(0, 10, (50, 2)), np.zeros((0, 2)), 3.0)]                            # empty reference set
+    for axy, rxy, radius in cases:
+        dax, drx = ctx.to_device(axy), ctx.to_device(rxy)
+        ix = ctypes.c_void_p()
+        ctx.check(L.same_knn_index_build(H, drx.ptr, len(rxy), radius, ctypes.byref(ix)), "index_build")
+        n = len(axy)
+        for k in (1, 8, 32, 100):
+            for b, e in ((0, n), (n // 3, n // 3 + min(200, n - n // 3))):
+                rows = e - b
+                d1, d2, c1 = ctx.alloc(rows * k * 4), ctx.alloc(rows * k * 8), ctx.alloc(rows * 4)
+                ctx.check(L.same_knn_prune_indexed_dev(H, ix, dax.ptr, b, e, k, d1.ptr, d2.ptr, c1.ptr), "indexed")
+                oi, od2, ocnt = oracle.knn_prune(axy, rxy, radius, k, b, e)
+                assert np.array_equal(d1.download((rows, k), np.int32), oi)
+                assert np.array_equal(d2.download((rows, k), np.float64), od2) and np.array_equal(c1.download((rows,), np.int32), ocnt)
+        bad = _lib.Context(0)
+        assert L.same_knn_prune_indexed_dev(bad.handle, ix, dax.ptr, 0, 1, 4, d1.ptr, None, c1.ptr) == -22   # another context's index
+        bad.close()
+        L.same_knn_index_destroy(ix)
     ctx.close()
 
 
@@ -607,9 +719,15 @@ def test_c_abi_error_codes(hip):
     assert L.same_xyorder_sweep(H, z.ctypes.data, 4, z.ctypes.data, 4, np.array([[0, 1, 2]], np.int32).ctypes.data, 1, m.ctypes.data,
                                 o8.ctypes.data, o8.ctypes.data, o8.ctypes.data, o64.ctypes.data) == ERANGE
     chk, nv = ctypes.c_int64(0), ctypes.c_int64(0)
-    fresh = _lib.Context(0)
-    assert fresh.lib.same_orient_sweep(fresh.handle, m.ctypes.data, ctypes.byref(chk), None, ctypes.byref(nv), None) == EINVAL          # not bound
-    fresh.close()
+    assert L.same_orient_sweep(None, m.ctypes.data, 4, ctypes.byref(chk), None, ctypes.byref(nv), None) == EINVAL                       # no sweep handle
+    sw = ctypes.c_void_p()
+    t1, s1 = np.array([[0, 1, 2]], np.int32), np.ones(1, np.int8)
+    assert L.same_sweep_bind(H, t1.ctypes.data, 1, s1.ctypes.data, z.ctypes.data, 4, 4, None, 0, ctypes.byref(sw)) == 0
+    v1 = np.zeros(1, np.int32)
+    assert L.same_orient_sweep(sw, m.ctypes.data, 3, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None) == EINVAL             # not the bound length
+    assert L.same_orient_sweep(sw, m.ctypes.data, 4, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None) == ERANGE             # match[3] = 99
+    assert L.same_orient_sweep_x(sw, z.ctypes.data, 2, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None, None, None) == EINVAL  # bound without pairs (P = 0)
+    L.same_sweep_unbind(sw)
     big = ctypes.c_void_p()
     assert L.same_dev_alloc(H, 1 << 46, ctypes.byref(big)) in (-12, -5)                                                               # 64 TiB: ENOMEM (or EIO)
     assert L.same_dense_cost_f64_dev(H, None, None, 20, None, None, 10, 0, 5, 1.0, None, 10) == EINVAL
@@ -744,34 +862,45 @@ def test_integration_md_stub_runs_as_written(oracle):
 
 def test_sweep_called_from_other_threads(oracle):
     """The lazy callback is re-entered from solver threads (src/same.py:1241): sweeps issued concurrently from several Python
-    threads on the shared default context return what the calling thread asked for (every entry selects the device itself;
-    the context lock serialises the bound state)."""
+    threads on the shared default context return what the calling thread asked for.  Two sweep objects of DIFFERENT shapes
+    (two models alive at once, as with overlapping windows) are driven together: each owns its device state
+    (same_sweep handle) and every call gets its own output buffer, so neither can see the other's arrays."""
     import threading
     from conftest import load_golden
-    from same_amd import sweeps
+    from same_amd import _lib, sweeps
 
-    g = load_golden("cfg2_small")
-    pairs, tris, sign = g["pairs"], g["tri_plain"], g["source_signs"].astype(np.int8)
-    n_a = int(pairs[:, 0].max()) + 1
-    rxy = g["in_ref_xy"][g["kept_ref"]]
-    sw = sweeps.LazyOrientationSweep(pairs, tris, sign, rxy, n_a)
+    models = []
+    for case in ("cfg2_small", "cfg1_500"):
+        g = load_golden(case)
+        pairs, tris, sign = g["pairs"], g["tri_plain"], g["source_signs"].astype(np.int8)
+        n_a = int(pairs[:, 0].max()) + 1
+        rxy = g["in_ref_xy"][g["kept_ref"]]
+        models.append((sweeps.LazyOrientationSweep(pairs, tris, sign, rxy, n_a), pairs, tris, sign, rxy, n_a))
+    assert models[0][0].bound.Tr != models[1][0].bound.Tr and models[0][0].bound.P != models[1][0].bound.P
     rng = np.random.default_rng(0)
-    xs = [(rng.random(len(pairs)) < p).astype(float) for p in (0.05, 0.2, 0.5, 0.9, 0.0, 1.0)]
-    want = [oracle.lazy_orientation_sweep(x, pairs, tris, sign, rxy, n_a) for x in xs]
-    got = [None] * len(xs)
+    jobs = []   # (model index, x)
+    for q, p in enumerate((0.05, 0.2, 0.5, 0.9, 0.0, 1.0, 0.3, 0.7)):
+        m = q % 2
+        jobs.append((m, (rng.random(len(models[m][1])) < p).astype(float)))
+    want = [oracle.lazy_orientation_sweep(x, *models[m][1:]) for m, x in jobs]
+    got = [None] * len(jobs)
     errors = []
 
     def work(q):
         try:
+            m, x = jobs[q]
             for _ in range(20):
-                checked, viol, _ = sw.sweep(xs[q])
+                checked, viol, _ = models[m][0].sweep(x)
                 got[q] = (checked, [(t, int(a), int(b), int(c)) for t, a, b, c in viol])
         except Exception as e:   # noqa: BLE001
             errors.append(e)
 
-    threads = [threading.Thread(target=work, args=(q,)) for q in range(len(xs))]
+    threads = [threading.Thread(target=work, args=(q,)) for q in range(len(jobs))]
     [t.start() for t in threads]
     [t.join() for t in threads]
     assert not errors, errors
-    for q in range(len(xs)):
+    for q in range(len(jobs)):
         assert got[q][0] == want[q][0] and got[q][1] == [tuple(int(v) for v in row) for row in want[q][1]], q
+    # a vector of the other model's length is refused, not read
+    with pytest.raises(_lib.SameHipError):
+        models[0][0].bound.sweep_x(jobs[1][1])

@@ -651,7 +651,12 @@ def _sharded_windows_worker(rank, world, out_dir):
     r_big = synth.to_frame(cells)
     m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
     m_big = m_big[~((m_big["X"] < 120) & (m_big["Y"] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
-    res = sharded_sliding_window_matching(r_big, m_big, commonCT=synth.type_columns(3), exchange=exchange, rank=rank, world=world,
+    if world == 2:   # the default channel: same_amd.rendezvous.HostGroup (loopback TCP) built from RANK / WORLD_SIZE / SAME_RDV_DIR
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
+        channel = {}
+    else:            # a launcher's own channel
+        channel = dict(exchange=exchange, rank=rank, world=world)
+    res = sharded_sliding_window_matching(r_big, m_big, commonCT=synth.type_columns(3), **channel,
                                           outprefix=os.path.join(out_dir, "sw"),
                                           optim_params=dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60),
                                           gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0))
@@ -662,7 +667,7 @@ def _sharded_windows_worker(rank, world, out_dir):
 def test_sharded_sliding_windows_equal_reference(tmp_path, world):
     """BASELINE cfg 5 form: the window plan dealt round-robin to `world` ranks (one process each, match tables exchanged over a
     host channel); every rank ends up with exactly the frame the REFERENCE's single-process sliding_window_matching produced.
-    The processes use a file exchange rather than torch.distributed so the GPU suite never pays a cold `import torch`."""
+    World 2 goes through the package's own plain-Python host group, world 3 through a caller-supplied file exchange."""
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
