@@ -473,7 +473,12 @@ def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_var
         "lazy_cuts_added": model._cuts_added if prep.optim_params["lazy_constraints"] else 0,
     }
     if outprefix:
-        np.save(os.path.join(outprefix, "var_out.npy"), var_out, allow_pickle=True)
+        # the reference pickles this dict into var_out.npy (src/same.py:1455-1462); here it goes out as a JSON + npz pair
+        # that loads without executing anything (varout.py).  SAME_LEGACY_VAR_OUT=1 also writes the reference's file for
+        # notebooks that np.load(..., allow_pickle=True) it.
+        varout.save(outprefix, var_out)
+        if os.environ.get("SAME_LEGACY_VAR_OUT") == "1":
+            np.save(os.path.join(outprefix, "var_out.npy"), var_out, allow_pickle=True)
         aligned_df.to_csv(os.path.join(outprefix, "aligned_df.csv"), index=False)
         ref_df.to_csv(os.path.join(outprefix, "ref_df.csv"), index=False)
     flipped_nodes = set()

@@ -13,8 +13,15 @@ import pandas as pd
 
 
 def load_matching_results(outprefix):
-    """src/helpers.py:667-689 -> (var_out, aligned_df, ref_df, matches_df)."""
-    var_out = np.load(os.path.join(outprefix, "var_out.npy"), allow_pickle=True).item()
+    """src/helpers.py:667-689 -> (var_out, aligned_df, ref_df, matches_df).
+    Reads the pickle-free `var_out.json` + `var_out.npz` pair run_same writes (same_amd/varout.py); a directory written by
+    the reference itself (only `var_out.npy`, a pickle) is read through the numpy-only unpickler, never `allow_pickle=True`."""
+    from . import varout
+
+    if os.path.exists(os.path.join(outprefix, "var_out.json")):
+        var_out = varout.load(outprefix)
+    else:
+        var_out = varout.load_legacy_npy(os.path.join(outprefix, "var_out.npy"))
     return (var_out, pd.read_csv(os.path.join(outprefix, "aligned_df.csv")), pd.read_csv(os.path.join(outprefix, "ref_df.csv")),
             pd.read_csv(os.path.join(outprefix, "matches_df.csv")))
 

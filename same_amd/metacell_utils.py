@@ -12,7 +12,6 @@ the per-metacell calls.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -22,63 +21,81 @@ from . import _lib, ops
 from .triangles import cos_threshold
 
 
-@dataclass
+_EMPTY_TRI = (0, 3)
+_EMPTY_TRI_XY = (0, 3, 2)
+
+
 class MetaCell:
-    """Container for metacell collapse results (fields and helpers of src/metacell_utils.py:25-157)."""
+    """What a collapse returns when `return_object=True`: the input frame, the metacell frame, both triangulations and
+    the column names that tie them together.  The path itself only reads `metacell_df`, `metacell_delaunay`,
+    `metacell_idx_col` and `cell_type_col` (duck-typed in run_same / sliding_window_matching); the remaining members
+    are the reference container's conveniences (src/metacell_utils.py:25-157), kept under the same names and pinned
+    against the reference object by tests/golden/run_same_mock.npz (`mc_helpers/*`)."""
 
-    original_df: pd.DataFrame
-    params: Dict[str, Any]
-    x_col: str
-    y_col: str
-    cell_type_col: str
-    original_idx_col: str
-    metacell_idx_col: str
-    original_delaunay: np.ndarray
-    metacell_df: pd.DataFrame
-    metacell_delaunay: np.ndarray
+    FIELDS = ("original_df", "params", "x_col", "y_col", "cell_type_col", "original_idx_col", "metacell_idx_col",
+              "original_delaunay", "metacell_df", "metacell_delaunay")
 
-    def metacell_members(self, metacell_idx: int) -> List[Any]:
-        return list(self.metacell_df.iloc[int(metacell_idx)]["members"])
+    def __init__(self, *args, **fields):
+        fields.update(zip(self.FIELDS, args))
+        lacking = [f for f in self.FIELDS if f not in fields]
+        extra = [f for f in fields if f not in self.FIELDS]
+        if lacking or extra or len(args) > len(self.FIELDS):
+            raise TypeError(f"MetaCell takes exactly the fields {self.FIELDS}" + (f"; missing {lacking}" if lacking else "")
+                            + (f"; unknown {extra}" if extra else ""))
+        for name in self.FIELDS:
+            setattr(self, name, fields[name])
 
-    def original_delaunay_to_row_indices(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
-        tri = self.original_delaunay if triangles is None else np.asarray(triangles)
+    def __repr__(self):
+        return f"MetaCell({len(self.original_df)} cells -> {len(self.metacell_df)} metacells, idx col {self.metacell_idx_col!r})"
+
+    # -- id space -> row space -------------------------------------------------------------------------------------
+    def _vertex_rows(self, triangles, on_missing):
+        """Rows of original_df for triangles given in original_idx_col ids; triangles with an unknown id are dropped
+        (or reported, on_missing='error').  One vectorised lookup for the whole list."""
+        tri = np.asarray(self.original_delaunay if triangles is None else triangles)
         if tri.size == 0:
-            return np.array([], dtype=int).reshape(0, 3)
+            return np.empty(_EMPTY_TRI, dtype=int)
         if tri.ndim != 2 or tri.shape[1] != 3:
             raise ValueError(f"triangles must have shape (n, 3); got {tri.shape}")
-        ids = pd.Index(self.original_df[self.original_idx_col].to_numpy())
-        flat = tri.reshape(-1)
-        remapped = ids.get_indexer(flat).astype(int).reshape(tri.shape)
-        if (remapped < 0).any():
-            if on_missing == "error":
-                missing = set(flat[remapped.reshape(-1) < 0].tolist())
-                raise KeyError(f"Found triangle vertices not in original_df[{self.original_idx_col}]: {list(missing)[:10]}")
-            remapped = remapped[(remapped >= 0).all(axis=1)]
-        return remapped
+        lookup = pd.Index(self.original_df[self.original_idx_col].to_numpy())
+        rows = lookup.get_indexer(tri.ravel()).astype(int).reshape(-1, 3)
+        known = rows >= 0
+        if known.all():
+            return rows
+        if on_missing == "error":
+            unknown = sorted(set(tri[~known].tolist()), key=repr)
+            raise KeyError(f"Found triangle vertices not in original_df[{self.original_idx_col}]: {unknown[:10]}")
+        return rows[known.all(axis=1)]
 
-    def original_delaunay_to_pos(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
-        return self.original_delaunay_to_row_indices(triangles=triangles, on_missing=on_missing)
+    def original_delaunay_to_row_indices(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
+        return self._vertex_rows(triangles, on_missing)
+
+    original_delaunay_to_pos = original_delaunay_to_row_indices   # the reference offers both names for the same map
+
+    # -- coordinates of triangle corners -----------------------------------------------------------------------------
+    def _corner_xy(self, frame, rows):
+        if rows.size == 0:
+            return np.empty(_EMPTY_TRI_XY, dtype=float)
+        return frame[[self.x_col, self.y_col]].to_numpy(dtype=float)[rows]
 
     def original_delaunay_to_xy(self, triangles: Optional[np.ndarray] = None, *, on_missing: str = "drop") -> np.ndarray:
-        tri_pos = self.original_delaunay_to_row_indices(triangles=triangles, on_missing=on_missing)
-        if tri_pos.size == 0:
-            return np.array([], dtype=float).reshape(0, 3, 2)
-        return self.original_df[[self.x_col, self.y_col]].to_numpy(dtype=float, copy=False)[tri_pos]
+        return self._corner_xy(self.original_df, self._vertex_rows(triangles, on_missing))
 
     def metacell_delaunay_to_xy(self) -> np.ndarray:
-        tri = np.asarray(self.metacell_delaunay)
-        if tri.size == 0:
-            return np.array([], dtype=float).reshape(0, 3, 2)
-        return self.metacell_df[[self.x_col, self.y_col]].to_numpy(dtype=float, copy=False)[tri.astype(int, copy=False)]
+        return self._corner_xy(self.metacell_df, np.asarray(self.metacell_delaunay).astype(int, copy=False))
+
+    # -- bookkeeping ---------------------------------------------------------------------------------------------------
+    def metacell_members(self, metacell_idx: int) -> List[Any]:
+        return list(self.metacell_df["members"].iloc[int(metacell_idx)])
 
     def to_summary_dict(self) -> Dict[str, Any]:
-        return {
-            "n_original": int(len(self.original_df)), "n_metacells": int(len(self.metacell_df)), "params": dict(self.params),
-            "x_col": self.x_col, "y_col": self.y_col, "cell_type_col": self.cell_type_col,
-            "original_idx_col": self.original_idx_col, "metacell_idx_col": self.metacell_idx_col,
-            "n_original_triangles": int(getattr(self.original_delaunay, "shape", [0])[0]),
-            "n_metacell_triangles": int(getattr(self.metacell_delaunay, "shape", [0])[0]),
-        }
+        def n_tri(t):
+            return int(getattr(t, "shape", [0])[0])
+
+        out = {"n_original": len(self.original_df), "n_metacells": len(self.metacell_df), "params": dict(self.params)}
+        out.update({name: getattr(self, name) for name in self.FIELDS if name.endswith("_col")})
+        out.update(n_original_triangles=n_tri(self.original_delaunay), n_metacell_triangles=n_tri(self.metacell_delaunay))
+        return out
 
 
 def _filter_valid(coords, triangles, r_max, min_angle_deg, ctx):
