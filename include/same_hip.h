@@ -82,6 +82,12 @@ int same_timer_stop(same_ctx *ctx, float *out_ms); /* records, synchronises, ret
 int same_pair_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r,
                        int T, const double *axy, const double *rxy, const int32_t *pairs,
                        int64_t P, double w, double *out_c);
+/* fp32 variant (BASELINE.json config 5: "fp32 cost"): the same expression evaluated in float, operands given as
+ * float -- element (i, j) of same_dense_cost_f32.  The reference has no fp32 path; the oracle twin is
+ * orc_pair_cost_f32 and the check is bit-equality with it plus a relative bound against the fp64 costs. */
+int same_pair_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_m, int64_t n_r,
+                       int T, const float *axy, const float *rxy, const int32_t *pairs,
+                       int64_t P, float w, float *out_c);
 
 /* ---- dense cost tile builder ----------------------------------------------------------
  * The same expression for every (i, j), i in [row_begin,row_end), j in [0,n_r):
@@ -135,6 +141,10 @@ int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, 
                              const double *daxy, const double *drxy, int64_t row_begin,
                              int64_t row_end, int k, const int32_t *didx, double w,
                              double *dout_cost);
+int same_padded_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T,
+                             const float *daxy, const float *drxy, int64_t row_begin,
+                             int64_t row_end, int k, const int32_t *didx, float w,
+                             float *dout_cost);
 
 /* ---- a7: triangle classes -------------------------------------------------------------
  * Replaces the per-triangle decisions of helpers.filter_triangles_by_radius

@@ -47,6 +47,7 @@ def lib():
         L.orc_pair_cost_f64.argtypes = [_f64, _f64, _INT, _f64, _f64, _i32, _I64, _DBL, _f64]
         L.orc_dense_cost_f64.argtypes = [_f64, _f64, _INT, _f64, _f64, _I64, _I64, _I64, _DBL, _f64, _I64]
         L.orc_dense_cost_f32.argtypes = [_f32, _f32, _INT, _f32, _f32, _I64, _I64, _I64, ctypes.c_float, _f32, _I64]
+        L.orc_pair_cost_f32.argtypes = [_f32, _f32, _INT, _f32, _f32, _i32, _I64, ctypes.c_float, _f32]
         L.orc_knn_prune.argtypes = [_f64, _f64, _I64, _I64, _I64, _DBL, _INT, _i32, _f64, _i32]
         L.orc_tri_classify.argtypes = [_f64, _i32, _I64, _DBL, _INT, _DBL, _VP, _u8, _f64, _f64]
         L.orc_tri_sign_weight.argtypes = [_f64, _VP, _i32, _I64, _i8, _VP]
@@ -139,13 +140,14 @@ def find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=5):
 
 
 # --------------------------------------------------------------------------- a4
-def pair_cost_arrays(A, R, axy, rxy, pairs, w):
-    A, R = _c(A, np.float64), _c(R, np.float64)
+def pair_cost_arrays(A, R, axy, rxy, pairs, w, dtype=np.float64):
+    dt = np.dtype(dtype)
+    A, R = _c(A, dt), _c(R, dt)
     pairs = _c(pairs, np.int32).reshape(-1, 2)
-    out = np.empty(len(pairs), np.float64)
+    out = np.empty(len(pairs), dt)
     T = A.shape[1] if A.ndim == 2 else 0
-    lib().orc_pair_cost_f64(A.reshape(-1), R.reshape(-1), T, _c(axy, np.float64), _c(rxy, np.float64),
-                            pairs, len(pairs), float(w), out)
+    fn = lib().orc_pair_cost_f64 if dt == np.float64 else lib().orc_pair_cost_f32
+    fn(A.reshape(-1), R.reshape(-1), T, _c(axy, dt), _c(rxy, dt), pairs, len(pairs), float(w), out)
     return out
 
 

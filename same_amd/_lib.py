@@ -47,6 +47,7 @@ _PROTOTYPES = {
     "same_timer_start": [c_vp],
     "same_timer_stop": [c_vp, ctypes.POINTER(c_flt)],
     "same_pair_cost_f64": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_dbl, c_vp],
+    "same_pair_cost_f32": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_flt, c_vp],
     "same_dense_cost_f64_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64],
     "same_dense_cost_f32_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_flt, c_vp, c_i64],
     "same_dense_cost_f64": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_dbl, c_vp, c_i64],
@@ -57,6 +58,7 @@ _PROTOTYPES = {
     "same_knn_index_destroy": [c_vp],
     "same_knn_prune_indexed_dev": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp],
     "same_padded_cost_f64_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_dbl, c_vp],
+    "same_padded_cost_f32_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_flt, c_vp],
     "same_tri_classify": [c_vp, c_vp, c_i64, c_vp, c_i64, c_dbl, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "same_tri_sign_weight": [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "same_sweep_bind": [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, ctypes.POINTER(c_vp)],

@@ -87,11 +87,34 @@ class PreparedInputs:
         return self._cache["rxy"]
 
 
-def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, aligned_delaunay_vertex_col=None,
-                        optim_params=None, gurobi_params=None, ignore_precomputed_triangulation=False,
-                        verbose=True, ctx=None) -> PreparedInputs:
-    from scipy.spatial import Delaunay  # Qhull stays on the host: it is an input to the kernels
+class _Staged:
+    """A window after the first half of the pre-MIP path (frames compacted by the prune, pairs known) with its
+    triangulation either supplied by the caller or under way in a Qhull helper (qhull_pool).  Produced ahead of time by the
+    window loop so that window n+1 is triangulated while window n runs; an error met on the way is kept and raised when
+    the window is actually run, exactly where the serial flow would have raised it."""
 
+    __slots__ = ("error", "aligned_df", "ref_df", "valid_pairs", "optim_params", "gurobi_params", "commonCT", "caller_triangles",
+                 "ticket", "verbose")
+
+    def __init__(self):
+        for name in self.__slots__:
+            setattr(self, name, None)
+
+
+def _stage_prune(ref_df, aligned_df, commonCT, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
+                 ignore_precomputed_triangulation, verbose, ctx, prefetch):
+    st = _Staged()
+    st.verbose, st.commonCT = verbose, commonCT
+    try:
+        _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
+                          ignore_precomputed_triangulation, verbose, ctx, prefetch)
+    except Exception as e:   # noqa: BLE001 -- re-raised unchanged by prepare_same_inputs when the window is run
+        st.error = e
+    return st
+
+
+def _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
+                      ignore_precomputed_triangulation, verbose, ctx, prefetch):
     optim_params = dict(optim_params or {})
     gurobi_params = dict(gurobi_params or {})
     # MetaCell duck-typing (src/same.py:891-899)
@@ -104,11 +127,9 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
             aligned_delaunay_vertex_col = mc.metacell_idx_col
         if (optim_params.get("cell_id_col") is None) and hasattr(mc, "metacell_idx_col"):
             optim_params["cell_id_col"] = mc.metacell_idx_col
-    optim_params = init_optim_params(**optim_params)
-    gurobi_params = init_gurobi_params(**gurobi_params)
+    st.optim_params = optim_params = init_optim_params(**optim_params)
+    st.gurobi_params = init_gurobi_params(**gurobi_params)
     radius, knn = optim_params["radius"], optim_params["knn"]
-    dist_ct_coeff = optim_params["dist_ct_coeff"]
-    min_angle_deg = optim_params.get("min_angle_deg", 15)
 
     # size defaults, stable ids (src/same.py:934-970)
     if "size" not in aligned_df.columns:
@@ -135,18 +156,47 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
         aligned_df, ref_df, valid_pairs = find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
     else:
         aligned_df, ref_df, valid_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
-    n_aligned, n_ref = len(aligned_df), len(ref_df)
+    st.aligned_df, st.ref_df, st.valid_pairs = aligned_df, ref_df, valid_pairs
     if len(valid_pairs) == 0:
         raise ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
-
-    # triangulation (src/same.py:1016-1031)
-    aligned_coords_array = aligned_df[["X", "Y"]].values
-    using_precomputed = False
+    # triangulation (src/same.py:1016-1031): the caller's, or Qhull on the compacted aligned cells -- started now in a
+    # helper process when the window loop is running ahead, picked up in prepare_same_inputs
     if aligned_delaunay is None or ignore_precomputed_triangulation:
-        aligned_delaunay = Delaunay(aligned_coords_array).simplices
+        if prefetch:
+            from . import qhull_pool
+
+            st.ticket = qhull_pool.pool().submit(aligned_df[["X", "Y"]].values)
     else:
-        using_precomputed = True
-        aligned_delaunay = _remap_triangles_by_vertex_ids(aligned_delaunay, vertex_ids=aligned_df["__tri_vid"].to_numpy())
+        st.caller_triangles = aligned_delaunay
+
+
+def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, aligned_delaunay_vertex_col=None,
+                        optim_params=None, gurobi_params=None, ignore_precomputed_triangulation=False,
+                        verbose=True, ctx=None, _staged=None) -> PreparedInputs:
+    """Everything run_same computes before it talks to the solver (src/same.py:933-1189).  `_staged`: the first half done
+    ahead of time by the window loop (`_stage_prune`); the other arguments are then ignored."""
+    from scipy.spatial import Delaunay  # Qhull stays on the host (SURVEY 8a6): it is an input to the kernels
+
+    st = _staged if _staged is not None else _stage_prune(ref_df, aligned_df, commonCT, aligned_delaunay, aligned_delaunay_vertex_col,
+                                                          optim_params, gurobi_params, ignore_precomputed_triangulation, verbose,
+                                                          ctx, prefetch=False)
+    if st.error is not None:
+        raise st.error
+    aligned_df, ref_df, valid_pairs, commonCT = st.aligned_df, st.ref_df, st.valid_pairs, st.commonCT
+    optim_params, gurobi_params = st.optim_params, st.gurobi_params
+    radius = optim_params["radius"]
+    dist_ct_coeff = optim_params["dist_ct_coeff"]
+    min_angle_deg = optim_params.get("min_angle_deg", 15)
+    n_aligned, n_ref = len(aligned_df), len(ref_df)
+
+    aligned_coords_array = aligned_df[["X", "Y"]].values
+    using_precomputed = st.caller_triangles is not None
+    if using_precomputed:
+        aligned_delaunay = _remap_triangles_by_vertex_ids(st.caller_triangles, vertex_ids=aligned_df["__tri_vid"].to_numpy())
+    elif st.ticket is not None:
+        aligned_delaunay = st.ticket.result()
+    else:
+        aligned_delaunay = Delaunay(aligned_coords_array).simplices
 
     # filter (src/same.py:1033-1053)
     unconstrained_nodes = set()
@@ -178,7 +228,11 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
         aligned_df = aligned_df.iloc[constrained_nodes].reset_index(drop=True)
 
     triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx)
-    costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx)
+    # build-only key (not among init_optim_params' defaults, which stay the reference's): fp32 pair costs, BASELINE config 5
+    cost_dtype = np.dtype(optim_params.get("hip_cost_dtype", "float64"))
+    if cost_dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ValueError(f"hip_cost_dtype must be 'float64' or 'float32', got {optim_params['hip_cost_dtype']!r}")
+    costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx, dtype=cost_dtype)
     return PreparedInputs(aligned_df, ref_df, valid_pairs, costs, aligned_delaunay, triangle_weights, source_signs,
                           unconstrained_nodes, using_precomputed, optim_params, gurobi_params)
 
@@ -230,6 +284,13 @@ def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None
              optim_params: Optional[Dict[str, Any]] = None, gurobi_params: Optional[Dict[str, Any]] = None,
              ignore_precomputed_triangulation: bool = False):
     """Same contract as src/same.py:706-1489: returns (matches_df, var_out)."""
+    return _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned_delaunay_vertex_col, optim_params,
+                     gurobi_params, ignore_precomputed_triangulation, None)
+
+
+def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
+              ignore_precomputed_triangulation, staged):
+    """run_same; `staged` = the window's first half, done ahead of time by the window loop (None: do it now)."""
     try:
         import gurobipy as gp
         from gurobipy import GRB, Model, quicksum
@@ -250,7 +311,7 @@ def run_same(ref_df, aligned_df, commonCT, outprefix=None, aligned_delaunay=None
     try:
         env = gp.Env(params=options)
         prep = prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay, aligned_delaunay_vertex_col,
-                                   optim_params, gurobi_params, ignore_precomputed_triangulation)
+                                   optim_params, gurobi_params, ignore_precomputed_triangulation, _staged=staged)
         op, gpar = prep.optim_params, prep.gurobi_params
         if len(prep.valid_pairs) == 0:
             # every node was unconstrained under the caller's triangulation, so nothing is left to match.  (The reference
@@ -492,6 +553,27 @@ def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_var
 
 
 # ------------------------------------------------------------------------------------------ windows
+def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi_params=None, verbose=False, ctx=None):
+    """Pre-MIP artefacts of every window of `plan` (windows.window_plan), in plan order: yields (window, PreparedInputs).
+    Window n+1..n+k are pruned ahead and triangulated by the Qhull helpers while the consumer works on window n (the same
+    pipelining sliding_window_matching uses); a window whose prune leaves no pairs yields (window, the ValueError)."""
+    from . import qhull_pool
+
+    depth = qhull_pool.lookahead()
+    ahead = {}
+    for q, w in enumerate(plan):
+        for nxt in range(q, min(q + 1 + depth, len(plan))):
+            if nxt not in ahead:
+                x0, x1, y0, y1 = plan[nxt]["box"]
+                ahead[nxt] = _stage_prune(subset_data(ref, x0, x1, y0, y1), subset_data(moving, x0, x1, y0, y1), commonCT, None, None,
+                                          optim_params, gurobi_params, False, verbose, ctx, prefetch=True)
+        st = ahead.pop(q)
+        try:
+            yield w, prepare_same_inputs(None, None, commonCT, verbose=verbose, ctx=ctx, _staged=st)
+        except ValueError as e:
+            yield w, e
+
+
 def subset_data(df, x_min, x_max, y_min, y_max):
     """src/same.py:293-295."""
     return df[(df["X"] >= x_min) & (df["X"] < x_max) & (df["Y"] >= y_min) & (df["Y"] < y_max)]
@@ -563,22 +645,48 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
         if "window_id" in existing.columns:
             done_ids = set(int(w) for w in existing["window_id"].unique())
             all_matches.append(existing)
-    runner = _run_window or run_same
     mine = None
     if _shard is not None:
         from .windows import assign_windows
         mine = set(assign_windows(plan, int(_shard[1]))[int(_shard[0])])
-    for pos, w in enumerate(plan):
-        if w["grid_id"] in done_ids or (mine is not None and pos not in mine):
-            continue
+    todo = [(pos, w) for pos, w in enumerate(plan) if w["grid_id"] not in done_ids and (mine is None or pos in mine)]
+
+    def subsets(w):
         x0, x1, y0, y1 = w["box"]
-        ref_subset = subset_data(ref, x0, x1, y0, y1)
-        moving_subset = subset_data(moving, x0, x1, y0, y1)
+        return subset_data(ref, x0, x1, y0, y1), subset_data(moving, x0, x1, y0, y1)
+
+    # The reference runs the windows strictly one after another (src/same.py:507-593), each paying its own Qhull call in the
+    # middle of its pre-MIP path.  Here window n+1..n+k are subset, pruned and compacted while window n is still to run, and
+    # their triangulations are computed by helper processes meanwhile (qhull_pool); window n then finds its simplices ready.
+    # Outputs are unchanged: the same frames reach the same run_same body in the same order.
+    ahead = {}
+    depth = 0
+    if _run_window is None:
+        from . import qhull_pool
+        depth = qhull_pool.lookahead()
+
+    def stage(q):
+        pos_q, w_q = todo[q]
+        rs, ms = subsets(w_q)
+        ahead[q] = (rs, ms, _stage_prune(rs, ms, commonCT, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
+                                         ignore_precomputed_triangulation, True, None, prefetch=True))
+
+    for q, (pos, w) in enumerate(todo):
         window_outprefix = os.path.join(outprefix, f"window_{w['window_id']}") if outprefix else None
-        window_matches, _ = runner(aligned_df=moving_subset, ref_df=ref_subset, commonCT=commonCT, optim_params=optim_params,
-                                   gurobi_params=gurobi_params, outprefix=window_outprefix, aligned_delaunay=moving_delaunay,
-                                   aligned_delaunay_vertex_col=moving_delaunay_vertex_col,
-                                   ignore_precomputed_triangulation=ignore_precomputed_triangulation)
+        if _run_window is not None:
+            ref_subset, moving_subset = subsets(w)
+            window_matches, _ = _run_window(aligned_df=moving_subset, ref_df=ref_subset, commonCT=commonCT, optim_params=optim_params,
+                                            gurobi_params=gurobi_params, outprefix=window_outprefix, aligned_delaunay=moving_delaunay,
+                                            aligned_delaunay_vertex_col=moving_delaunay_vertex_col,
+                                            ignore_precomputed_triangulation=ignore_precomputed_triangulation)
+        else:
+            for nxt in range(q, min(q + 1 + depth, len(todo))):
+                if nxt not in ahead:
+                    stage(nxt)
+            ref_subset, moving_subset, staged = ahead.pop(q)
+            window_matches, _ = _run_same(ref_subset, moving_subset, commonCT, window_outprefix, moving_delaunay,
+                                          moving_delaunay_vertex_col, optim_params, gurobi_params,
+                                          ignore_precomputed_triangulation, staged)
         if window_matches.shape[0] > 0:
             tx0, tx1, ty0, ty1 = w["trim"]
             central = window_matches[(window_matches["X"] >= tx0) & (window_matches["X"] < tx1)

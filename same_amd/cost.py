@@ -8,13 +8,16 @@ def _xy(df):
     return np.ascontiguousarray(df[["X", "Y"]].to_numpy(dtype=np.float64))
 
 
-def pair_costs(aligned_df, ref_df, valid_pairs, commonCT, dist_ct_coeff, ctx=None):
-    """-> list of np.float64, one per pair, in pair order (what run_same calls `c`)."""
+def pair_costs(aligned_df, ref_df, valid_pairs, commonCT, dist_ct_coeff, ctx=None, dtype=np.float64):
+    """-> list of np.float64, one per pair, in pair order (what run_same calls `c`).
+    dtype=float32 (BASELINE config 5, `optim_params['hip_cost_dtype']='float32'`): operands and arithmetic in float;
+    the values are handed on as float64 (every float is one), so the solver-facing type does not change."""
     cols = list(commonCT)
     A = aligned_df[cols].to_numpy(dtype=np.float64)
     R = ref_df[cols].to_numpy(dtype=np.float64)
     pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
-    return list(ops.pair_cost(A, R, _xy(aligned_df), _xy(ref_df), pairs, dist_ct_coeff, ctx=ctx))
+    c = ops.pair_cost(A, R, _xy(aligned_df), _xy(ref_df), pairs, dist_ct_coeff, dtype=dtype, ctx=ctx)
+    return list(c.astype(np.float64, copy=False))
 
 
 def dense_cost_matrix(aligned_df, ref_df, commonCT, dist_ct_coeff, row_begin=0, row_end=None, dtype=np.float64, ctx=None):

@@ -273,51 +273,60 @@ __global__ __launch_bounds__(256) void dense_cost_generic_kernel(
     }
 }
 
+template <typename F> __device__ __forceinline__ F inf_of();
+template <> __device__ __forceinline__ double inf_of<double>() { return __builtin_inf(); }
+template <> __device__ __forceinline__ float inf_of<float>() { return __builtin_inff(); }
+
 // One lane per pair (a4).  Consecutive pairs share the aligned row (L1 broadcast); ref rows
-// are gathered.  Gather-bound, P*(2*(T+2)+1)*8 B of touched data.
+// are gathered.  Gather-bound, P*(2*(T+2)+1)*sizeof(F) B of touched data.  F = float is the config-5 variant:
+// the same expression evaluated in float (element (i, j) of the fp32 dense build).
+template <typename F>
 __global__ __launch_bounds__(256) void pair_cost_kernel(
-    const double *__restrict__ A, const double *__restrict__ R, int T, const double *__restrict__ axy,
-    const double *__restrict__ rxy, const int32_t *__restrict__ pairs, int64_t P, double w, double dcoef,
-    double *__restrict__ out) {
+    const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
+    const F *__restrict__ rxy, const int32_t *__restrict__ pairs, int64_t P, F w, F dcoef,
+    F *__restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     const int64_t i = pairs[2 * p], j = pairs[2 * p + 1];
-    const double *a = A + i * T, *r = R + j * T;
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(a[t] - r[t]);
-    const double dc = __builtin_fabs(axy[2 * i] - rxy[2 * j]) + __builtin_fabs(axy[2 * i + 1] - rxy[2 * j + 1]);
+    const F *a = A + i * T, *r = R + j * T;
+    F s = F(0);
+    for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - r[t]);
+    const F dc = absf<F>(axy[2 * i] - rxy[2 * j]) + absf<F>(axy[2 * i + 1] - rxy[2 * j + 1]);
     out[p] = w * s + dcoef * dc;
 }
 
 // Costs of padded candidate lists idx[(i-row_begin)*k + q] (-1 = empty -> +inf).
+template <typename F>
 __global__ __launch_bounds__(256) void padded_cost_kernel(
-    const double *__restrict__ A, const double *__restrict__ R, int T, const double *__restrict__ axy,
-    const double *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
-    double w, double dcoef, double *__restrict__ out) {
+    const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
+    const F *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
+    F w, F dcoef, F *__restrict__ out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_slots) return;
     const int64_t j = idx[q];
-    if (j < 0) { out[q] = __builtin_inf(); return; }
+    if (j < 0) { out[q] = inf_of<F>(); return; }
     const int64_t i = row_begin + q / k;
-    const double *a = A + i * T, *r = R + j * T;
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(a[t] - r[t]);
-    const double dc = __builtin_fabs(axy[2 * i] - rxy[2 * j]) + __builtin_fabs(axy[2 * i + 1] - rxy[2 * j + 1]);
+    const F *a = A + i * T, *r = R + j * T;
+    F s = F(0);
+    for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - r[t]);
+    const F dc = absf<F>(axy[2 * i] - rxy[2 * j]) + absf<F>(axy[2 * i + 1] - rxy[2 * j + 1]);
     out[q] = w * s + dcoef * dc;
 }
 
 // Same result, staged: a wave owns 64 consecutive slots.  One lane per slot gathering its own reference row makes every
 // load instruction touch 64 different cache lines; here the wave first copies its 64 rows into LDS with lanes running
 // along the rows (each load instruction covers ~3 rows = a handful of lines), then every lane walks its row in LDS in the
-// reference's left-to-right order.  Row pitch in LDS is T|1 doubles (odd: 2-way bank aliasing at worst).
+// reference's left-to-right order.  Row pitch in LDS is T|1 elements (odd: 2-way bank aliasing at worst).
+template <typename F>
 __global__ void padded_cost_lds_kernel(
-    const double *__restrict__ A, const double *__restrict__ R, int T, const double *__restrict__ axy,
-    const double *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
-    double w, double dcoef, double *__restrict__ out) {
-    extern __shared__ double lds[];
+    const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
+    const F *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
+    F w, F dcoef, F *__restrict__ out) {
+    extern __shared__ double lds_raw[];
+    F *lds = reinterpret_cast<F *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int P = T | 1;
-    double *rows = lds + (size_t)wave * 64 * P;
+    F *rows = lds + (size_t)wave * 64 * P;
     int *jl = reinterpret_cast<int *>(lds + (size_t)waves * 64 * P) + wave * 64;
     const int64_t q0 = ((int64_t)blockIdx.x * waves + wave) * 64;
     if (q0 >= n_slots) return;                       // whole wave out of range (wave-uniform)
@@ -330,7 +339,7 @@ __global__ void padded_cost_lds_kernel(
         int sl = lane / T, t = lane - sl * T;
         for (int it = 0; it < T; ++it) {
             const int js = jl[sl];
-            rows[sl * P + t] = js >= 0 ? R[(int64_t)js * T + t] : 0.0;
+            rows[sl * P + t] = js >= 0 ? R[(int64_t)js * T + t] : F(0);
             sl += ds;
             t += dt;
             if (t >= T) { t -= T; ++sl; }
@@ -338,13 +347,13 @@ __global__ void padded_cost_lds_kernel(
     }
     __builtin_amdgcn_wave_barrier();
     if (q >= n_slots) return;
-    if (j < 0) { out[q] = __builtin_inf(); return; }
+    if (j < 0) { out[q] = inf_of<F>(); return; }
     const int64_t i = row_begin + q / k;
-    const double *a = A + i * T;
-    const double *r = rows + lane * P;
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(a[t] - r[t]);
-    const double dc = __builtin_fabs(axy[2 * i] - rxy[2 * (int64_t)j]) + __builtin_fabs(axy[2 * i + 1] - rxy[2 * (int64_t)j + 1]);
+    const F *a = A + i * T;
+    const F *r = rows + lane * P;
+    F s = F(0);
+    for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - r[t]);
+    const F dc = absf<F>(axy[2 * i] - rxy[2 * (int64_t)j]) + absf<F>(axy[2 * i + 1] - rxy[2 * (int64_t)j + 1]);
     out[q] = w * s + dcoef * dc;
 }
 
@@ -488,6 +497,61 @@ int dense_host(same_ctx *ctx, const F *A, const F *R, int64_t n_m, int64_t n_r, 
     return SAME_OK;
 }
 
+template <typename F>
+int pair_cost_host(same_ctx *ctx, const F *A, const F *R, int64_t n_m, int64_t n_r, int T, const F *axy, const F *rxy,
+                   const int32_t *pairs, int64_t P, F w, F *out_c) {
+    REQUIRE(ctx, ctx != nullptr);
+    REQUIRE(ctx, n_m >= 0 && n_r >= 0 && T >= 0 && T <= SAME_MAX_TYPES && P >= 0);
+    if (P == 0) return SAME_OK;
+    REQUIRE(ctx, axy && rxy && pairs && out_c && (T == 0 || (A && R)));
+    SAME_TRY(same_use(ctx));
+    // validate on the host: a bad index must never become a device fault
+    for (int64_t p = 0; p < P; ++p) {
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
+            ctx->err = "pair index out of range";
+            return SAME_ERANGE;
+        }
+    }
+    F *dA, *dR, *dax, *drx, *dout;
+    int32_t *dp;
+    SAME_TRY(up_as(ctx, SL_A, A, (size_t)n_m * T, &dA));
+    SAME_TRY(up_as(ctx, SL_R, R, (size_t)n_r * T, &dR));
+    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n_m * 2, &dax));
+    SAME_TRY(up_as(ctx, SL_RXY, rxy, (size_t)n_r * 2, &drx));
+    SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)P, &dout));
+    hipLaunchKernelGGL(pair_cost_kernel<F>, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, dA, dR, T, dax, drx,
+                       dp, P, w, w * F(0.001), dout);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_down(ctx, out_c, dout, (size_t)P * sizeof(F)));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SAME_OK;
+}
+
+template <typename F>
+int padded_cost_dev(same_ctx *ctx, const F *dA, const F *dR, int T, const F *daxy, const F *drxy, int64_t row_begin,
+                    int64_t row_end, int k, const int32_t *didx, F w, F *dout_cost) {
+    REQUIRE(ctx, ctx && daxy && drxy && didx && dout_cost && (T == 0 || (dA && dR)));
+    REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && k >= 1 && row_begin >= 0 && row_end >= row_begin);
+    SAME_TRY(same_use(ctx));
+    const int64_t n_slots = (row_end - row_begin) * k;
+    if (n_slots == 0) return SAME_OK;
+    static const int mode = env_int("SAME_PADDED_MODE", 1);   // 0 = one lane gathers its row from global, 1 = LDS-staged rows
+    size_t per_wave = (size_t)64 * (T | 1) * sizeof(F) + 64 * sizeof(int);
+    per_wave = (per_wave + 7) & ~size_t(7);
+    int waves = (int)std::min<size_t>(4, (size_t)65536 / per_wave);
+    if (mode == 1 && T >= 2 && waves >= 1 && n_slots >= 64 * 64) {
+        // the per-wave index list sits after ALL waves' row blocks: keep it 4-byte aligned for float rows of odd pitch
+        hipLaunchKernelGGL(padded_cost_lds_kernel<F>, dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
+                           ctx->stream, dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost);
+    } else {
+        hipLaunchKernelGGL(padded_cost_kernel<F>, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, ctx->stream, dA, dR, T,
+                           daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -519,54 +583,25 @@ int same_dense_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n
 int same_pair_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r, int T,
                        const double *axy, const double *rxy, const int32_t *pairs, int64_t P, double w,
                        double *out_c) {
-    REQUIRE(ctx, ctx != nullptr);
-    REQUIRE(ctx, n_m >= 0 && n_r >= 0 && T >= 0 && T <= SAME_MAX_TYPES && P >= 0);
-    if (P == 0) return SAME_OK;
-    REQUIRE(ctx, axy && rxy && pairs && out_c && (T == 0 || (A && R)));
-    SAME_TRY(same_use(ctx));
-    // validate on the host: a bad index must never become a device fault
-    for (int64_t p = 0; p < P; ++p) {
-        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_r) {
-            ctx->err = "pair index out of range";
-            return SAME_ERANGE;
-        }
-    }
-    double *dA, *dR, *dax, *drx, *dout;
-    int32_t *dp;
-    SAME_TRY(up_as(ctx, SL_A, A, (size_t)n_m * T, &dA));
-    SAME_TRY(up_as(ctx, SL_R, R, (size_t)n_r * T, &dR));
-    SAME_TRY(up_as(ctx, SL_AXY, axy, (size_t)n_m * 2, &dax));
-    SAME_TRY(up_as(ctx, SL_RXY, rxy, (size_t)n_r * 2, &drx));
-    SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
-    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)P, &dout));
-    hipLaunchKernelGGL(pair_cost_kernel, dim3((unsigned)ceil_div(P, 256)), dim3(256), 0, ctx->stream, dA, dR, T, dax, drx,
-                       dp, P, w, w * 0.001, dout);
-    HIP_TRY(ctx, hipGetLastError());
-    SAME_TRY(same_down(ctx, out_c, dout, (size_t)P * sizeof(double)));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SAME_OK;
+    return pair_cost_host<double>(ctx, A, R, n_m, n_r, T, axy, rxy, pairs, P, w, out_c);
+}
+
+int same_pair_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_m, int64_t n_r, int T,
+                       const float *axy, const float *rxy, const int32_t *pairs, int64_t P, float w,
+                       float *out_c) {
+    return pair_cost_host<float>(ctx, A, R, n_m, n_r, T, axy, rxy, pairs, P, w, out_c);
 }
 
 int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T, const double *daxy,
                              const double *drxy, int64_t row_begin, int64_t row_end, int k, const int32_t *didx,
                              double w, double *dout_cost) {
-    REQUIRE(ctx, ctx && daxy && drxy && didx && dout_cost && (T == 0 || (dA && dR)));
-    REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && k >= 1 && row_begin >= 0 && row_end >= row_begin);
-    SAME_TRY(same_use(ctx));
-    const int64_t n_slots = (row_end - row_begin) * k;
-    if (n_slots == 0) return SAME_OK;
-    static const int mode = env_int("SAME_PADDED_MODE", 1);   // 0 = one lane gathers its row from global, 1 = LDS-staged rows
-    const size_t per_wave = (size_t)64 * (T | 1) * sizeof(double) + 64 * sizeof(int);
-    int waves = (int)std::min<size_t>(4, (size_t)65536 / per_wave);
-    if (mode == 1 && T >= 2 && waves >= 1 && n_slots >= 64 * 64) {
-        hipLaunchKernelGGL(padded_cost_lds_kernel, dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
-                           ctx->stream, dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * 0.001, dout_cost);
-    } else {
-        hipLaunchKernelGGL(padded_cost_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, ctx->stream, dA, dR, T,
-                           daxy, drxy, row_begin, n_slots, k, didx, w, w * 0.001, dout_cost);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return SAME_OK;
+    return padded_cost_dev<double>(ctx, dA, dR, T, daxy, drxy, row_begin, row_end, k, didx, w, dout_cost);
+}
+
+int same_padded_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T, const float *daxy,
+                             const float *drxy, int64_t row_begin, int64_t row_end, int k, const int32_t *didx,
+                             float w, float *dout_cost) {
+    return padded_cost_dev<float>(ctx, dA, dR, T, daxy, drxy, row_begin, row_end, k, didx, w, dout_cost);
 }
 
 }  // extern "C"

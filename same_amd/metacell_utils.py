@@ -153,11 +153,29 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
         dups = aligned_df.loc[aligned_df[original_idx_col].duplicated(), original_idx_col].head(5).tolist()
         raise ValueError(f"'{original_idx_col}' must be unique per original cell. Found duplicates (examples): {dups}")
 
+    # Qhull calls are the bulk of a collapse (1.14 of 1.35 s at 100k cells, one per iteration plus two).  Two of them repeat a
+    # triangulation that was just made -- iteration 0 triangulates the original cells again, and the final triangulation
+    # repeats the last iteration's when the loop stops for lack of candidates -- so those are reused; and each iteration's
+    # triangulation is started in a Qhull helper process as soon as the merged coordinates are known, while the rest of the
+    # frame merge is still being done here.  Same points -> same simplices: results are unchanged (tests/golden/metacell.npz).
+    from . import qhull_pool
+
     original_coords = aligned_df[[x_col, y_col]].to_numpy()
+    ready = None                      # (points, simplices or ticket) of a triangulation made ahead of its use
     if len(original_coords) >= 4:
-        original_delaunay_pos = _filter_valid(original_coords, Delaunay(original_coords).simplices, r_max, min_angle_deg, ctx)
+        original_raw = Delaunay(original_coords).simplices
+        ready = (np.asarray(original_coords, dtype=np.float64), original_raw)
+        original_delaunay_pos = _filter_valid(original_coords, original_raw, r_max, min_angle_deg, ctx)
     else:
         original_delaunay_pos = np.array([], dtype=int).reshape(0, 3)
+
+    def triangulate(points):
+        """Delaunay(points).simplices, from `ready` when it holds exactly these points."""
+        nonlocal ready
+        have, ready = ready, None
+        if have is not None and have[0].shape == points.shape and np.array_equal(have[0], points):
+            return have[1].result() if hasattr(have[1], "result") else have[1]
+        return Delaunay(points).simplices
     original_ids_by_pos = aligned_df[original_idx_col].to_numpy()
     if original_delaunay_pos.size == 0:
         original_delaunay = np.array([], dtype=original_ids_by_pos.dtype).reshape(0, 3)
@@ -185,13 +203,15 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
     orig_y = aligned_df[y_col].to_numpy(dtype=np.float64)
     en, thr = cos_threshold(min_angle_deg)
 
+    last_made = None
     if verbose:
         print(f"Starting greedy triangle collapse:\n  Initial cells: {len(aligned_df)}\n  Max metacell size: {max_metacell_size}")
     for iteration in range(max_iterations):
         coords = metacell_df[[x_col, y_col]].values
         if len(coords) < 4:
             break
-        triangles_raw = Delaunay(coords).simplices
+        triangles_raw = triangulate(coords)
+        last_made = (np.asarray(coords, dtype=np.float64), triangles_raw)
         type_id = pd.factorize(metacell_df[cell_type_col].to_numpy(), use_na_sentinel=False)[0].astype(np.int32)
         size = metacell_df["size"].to_numpy(dtype=np.float64)
         flag, perim, total = ops.collapse_candidates(coords, triangles_raw, r_max, en, thr, type_id, size, max_metacell_size, ctx=ctx)
@@ -213,6 +233,15 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
             "size": metacell_df["size"].to_numpy()[batch].sum(axis=1),
             "members": [members[a] + members[b] + members[c] for a, b, c in batch.tolist()],
         }
+        remove = batch.reshape(-1)
+        keep_mask = np.ones(len(metacell_df), bool)
+        keep_mask[remove] = False
+        # the next iteration's points are known now (kept metacells, then the merged ones): triangulate them in a helper
+        # while the remaining columns are merged below
+        next_coords = np.vstack((np.asarray(coords, dtype=np.float64)[keep_mask], np.column_stack((merged[x_col], merged[y_col]))))
+        last_made = None
+        if len(next_coords) >= 4:
+            ready = (next_coords, qhull_pool.pool().submit(next_coords))
         for col in metacell_df.columns:
             if col in [x_col, y_col, cell_type_col, "size", "members", metacell_idx_col] + id_cols_present:
                 continue
@@ -220,9 +249,6 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
                 merged[col] = _mean_over_members(aligned_df[col].to_numpy(dtype=np.float64), groups)   # true mean over original cells
             else:
                 merged[col] = metacell_df[col].to_numpy()[batch[:, 0]]                                  # first vertex's value
-        remove = batch.reshape(-1)
-        keep_mask = np.ones(len(metacell_df), bool)
-        keep_mask[remove] = False
         member_pos = [member_pos[i] for i in np.flatnonzero(keep_mask)] + groups
         metacell_df = metacell_df.drop(remove).reset_index(drop=True)
         metacell_df = pd.concat([metacell_df, pd.DataFrame(merged)], ignore_index=True)
@@ -230,7 +256,9 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
 
     final_coords = metacell_df[[x_col, y_col]].values
     if len(final_coords) >= 4:
-        final_delaunay = _filter_valid(final_coords, Delaunay(final_coords).simplices, r_max, min_angle_deg, ctx)
+        if last_made is not None and ready is None:   # the loop stopped on these very points: their triangulation exists
+            ready = last_made
+        final_delaunay = _filter_valid(final_coords, triangulate(np.asarray(final_coords)), r_max, min_angle_deg, ctx)
     else:
         final_delaunay = np.array([]).reshape(0, 3)
     if verbose:

@@ -24,17 +24,20 @@ def _tris(triangles):
     return as_c(t.reshape(-1, 3) if t.size else np.zeros((0, 3)), I32)
 
 
-def pair_cost(A, R, axy, rxy, pairs, w, ctx=None):
+def pair_cost(A, R, axy, rxy, pairs, w, dtype=F64, ctx=None):
+    """Costs of a pair list.  dtype float32 = the config-5 variant (operands converted to float, float arithmetic)."""
     ctx = _ctx(ctx)
-    A, R = as_c(A, F64), as_c(R, F64)
-    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    dt = np.dtype(dtype)
+    assert dt in (np.dtype(F64), np.dtype(F32))
+    A, R = as_c(A, dt), as_c(R, dt)
+    axy, rxy = as_c(axy, dt).reshape(-1, 2), as_c(rxy, dt).reshape(-1, 2)
     pairs = as_c(pairs, I32).reshape(-1, 2)
     T = A.shape[1] if A.ndim == 2 else 0
-    out = np.empty(len(pairs), F64)
+    out = np.empty(len(pairs), dt)
+    fn = ctx.lib.same_pair_cost_f64 if dt == np.dtype(F64) else ctx.lib.same_pair_cost_f32
     with ctx.lock:
-        ctx.check(ctx.lib.same_pair_cost_f64(ctx.handle, A.ctypes.data, R.ctypes.data, len(axy), len(rxy), T, axy.ctypes.data,
-                                             rxy.ctypes.data, pairs.ctypes.data, len(pairs), float(w), out.ctypes.data),
-                  "same_pair_cost_f64")
+        ctx.check(fn(ctx.handle, A.ctypes.data, R.ctypes.data, len(axy), len(rxy), T, axy.ctypes.data,
+                     rxy.ctypes.data, pairs.ctypes.data, len(pairs), float(w), out.ctypes.data), "same_pair_cost")
     return out
 
 

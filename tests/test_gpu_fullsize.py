@@ -149,8 +149,8 @@ def test_knn_100k_grid_vs_brute_and_oracle(env, oracle, monkeypatch):
     assert np.array_equal(np.where(ri >= 0, used[np.maximum(ri, 0)], -1), gi) and np.array_equal(rd, gd)
 
 
-def test_cfg4_200k_row_block_sharding_invariant(env):
-    """200k x 200k in 8 row blocks of 25k (what 8 ranks compute) == the one-shot result."""
+def test_cfg4_200k_row_block_sharding_invariant(env, oracle):
+    """200k x 200k in 8 row blocks of 25k (what 8 ranks compute) == the one-shot result == the oracle on sampled rows."""
     _lib, ops, synth = env
     n, k, T = 200_000, 32, 20
     ref = synth.make_cells(n, T, seed=0)
@@ -174,30 +174,102 @@ def test_cfg4_200k_row_block_sharding_invariant(env):
     assert np.array_equal(didx.download((n, k), np.int32), whole_idx)
     assert np.array_equal(dcost.download((n, k), np.float64), whole_cost)
     assert np.isinf(whole_cost[whole_idx < 0]).all() and np.isfinite(whole_cost[whole_idx >= 0]).all()
+    # not only self-consistent: three 1000-row samples (first block, a block boundary, the last rows) against the oracle
+    for b in (0, 24_500, 199_000):
+        oi, _, _ = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, k, b, b + 1000)
+        assert np.array_equal(whole_idx[b:b + 1000], oi)
+        rr, cc = np.nonzero(oi >= 0)
+        want = oracle.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr + b, oi[rr, cc])), 1.0)
+        assert np.array_equal(whole_cost[b:b + 1000][rr, cc], want)
+    # and the caller-held index (what the ranks of bench.py use) gives the same lists
+    ix = ctypes.c_void_p()
+    ctx.check(L.same_knn_index_build(H, drx.ptr, n, 25.0, ctypes.byref(ix)), "index")
+    ctx.check(L.same_dev_memset(H, didx.ptr, 0, n * k * 4), "memset")
+    for r in range(8):
+        ctx.check(L.same_knn_prune_indexed_dev(H, ix, dax.ptr, r * 25_000, (r + 1) * 25_000, k, didx.ptr + r * 25_000 * k * 4, None,
+                                               dcnt.ptr + r * 25_000 * 4), "indexed")
+    assert np.array_equal(didx.download((n, k), np.int32), whole_idx)
+    L.same_knn_index_destroy(ix)
 
 
 def test_cfg5_1m_cells_windows_fp32(env, oracle):
-    """1M-cell section tiled into windows; fp32 cost on one window."""
-    _lib, ops, synth = env
-    from same_amd.windows import window_plan, assign_windows
+    """1M-cell section tiled into windows (BASELINE config 5): the plan's counts against plain masks, the round-robin deal,
+    and THREE windows (a corner, the middle, the far edge) through the whole fp32 window pipeline at the Python boundary --
+    prune + compaction, Delaunay + filter, weights / signs, fp32 pair costs, greedy start on those costs, and all three
+    sweeps under that start -- every output against the oracle."""
+    import pandas as pd
+    from scipy.spatial import Delaunay
 
-    ref = synth.make_cells(1_000_000, 4, seed=0)            # side 10 000
-    mov = synth.make_cells(1_000_000, 4, seed=1, side=ref["side"])
+    import same_amd
+    from same_amd.windows import assign_windows, window_plan
+
+    _lib, ops, synth = env
+    T = 8
+    ref = synth.make_cells(1_000_000, T, seed=0)            # side 10 000
+    mov = synth.make_jittered(ref, seed=1)
     plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
-    assert len(plan) == 12 * 12 or len(plan) > 100
-    total_mov = 0
+    assert len(plan) > 100
     for w in plan[::17]:
         x0, x1, y0, y1 = w["box"]
         m = (mov["xy"][:, 0] >= x0) & (mov["xy"][:, 0] < x1) & (mov["xy"][:, 1] >= y0) & (mov["xy"][:, 1] < y1)
         r = (ref["xy"][:, 0] >= x0) & (ref["xy"][:, 0] < x1) & (ref["xy"][:, 1] >= y0) & (ref["xy"][:, 1] < y1)
         assert w["n_mov"] == int(m.sum()) and w["n_ref"] == int(r.sum())
-        total_mov += w["n_mov"]
     shards = assign_windows(plan, 8)
     assert sorted(q for s in shards for q in s) == list(range(len(plan)))
-    w = plan[len(plan) // 2]
-    x0, x1, y0, y1 = w["box"]
-    m = (mov["xy"][:, 0] >= x0) & (mov["xy"][:, 0] < x1) & (mov["xy"][:, 1] >= y0) & (mov["xy"][:, 1] < y1)
-    r = (ref["xy"][:, 0] >= x0) & (ref["xy"][:, 0] < x1) & (ref["xy"][:, 1] >= y0) & (ref["xy"][:, 1] < y1)
-    D = ops.dense_cost(mov["types"][m], ref["types"][r], mov["xy"][m], ref["xy"][r], 1.0, 0, 2000, dtype=np.float32)
-    O = oracle.dense_cost(mov["types"][m], ref["types"][r], mov["xy"][m], ref["xy"][r], 1.0, 0, 2000, dtype=np.float32)
-    assert np.array_equal(D, O) and D.shape[1] == int(r.sum()) > 10_000
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    cols = synth.type_columns(T)
+    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
+    for w in (plan[0], plan[len(plan) // 2], plan[-1]):
+        x0, x1, y0, y1 = w["box"]
+        rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
+        assert len(ms) > 5_000
+        prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
+        # a2: pairs + compaction
+        na, nr, pairs = oracle.find_knn_within_radius(ms, rs, 25, 8)
+        pairs = np.asarray(pairs, dtype=np.int64)
+        assert np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs)
+        assert np.array_equal(prep.aligned_df["Cell_Num_Old"].to_numpy(), na["Cell_Num_Old"].to_numpy())
+        assert np.array_equal(prep.ref_df["Cell_Num_Old"].to_numpy(), nr["Cell_Num_Old"].to_numpy())
+        # a4 in float: bit-equal to the oracle's float evaluation, 1e-5 relative to the fp64 costs
+        A, R = na[cols].to_numpy(), nr[cols].to_numpy()
+        axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
+        c32 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.0, dtype=np.float32)
+        got_c = np.array(prep.costs)
+        assert got_c.dtype == np.float64 and np.array_equal(got_c.astype(np.float32), c32) and np.array_equal(got_c, c32.astype(np.float64))
+        c64 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.0)
+        assert np.max(np.abs(got_c - c64) / c64) < 1e-5
+        # a6-a8: triangulation (Qhull on the host, as in the reference), filter, weights, signs
+        tri = oracle.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True, min_angle_deg=15)
+        tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+        assert np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri)
+        assert prep.triangle_weights == oracle.triangle_weights(na, tri) and prep.source_signs == oracle.source_signs(na, tri)
+        # a5 / f1 on the fp32 costs
+        kw = dict(valid_pairs=prep.valid_pairs, costs=prep.costs, n_aligned=prep.n_aligned, n_ref=prep.n_ref,
+                  aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
+        ch, un = same_amd.compute_mip_start_pairs(**kw)
+        och, oun = oracle.compute_mip_start_pairs(**kw)
+        assert ch == och and un == oun and len(ch) > 0.8 * prep.n_aligned
+        # a10 under that start
+        x = np.zeros(len(pairs))
+        x[[c[2] for c in ch]] = 1.0
+        sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
+        checked, viol, _ = sw.sweep(x)
+        ochecked, oviol = oracle.lazy_orientation_sweep(x, pairs, tri, prep.source_signs, rxy, prep.n_aligned)
+        assert checked == ochecked and [tuple(int(q) for q in v) for v in viol] == [tuple(int(q) for q in v) for v in oviol]
+        # a11 / a12
+        m_pairs = pd.DataFrame({"aligned_idx": [c[0] for c in ch], "ref_idx": [c[1] for c in ch]})
+        info = prep.triangle_info
+        rep, orep = same_amd.verify_spatial_preservation(na, nr, m_pairs, info), oracle.verify_spatial_preservation(na, nr, m_pairs, info)
+        assert rep["violation_summary"] == orep["violation_summary"]
+        assert rep["x_order_violations"] == orep["x_order_violations"] and rep["y_order_violations"] == orep["y_order_violations"]
+        assert sorted(rep["points_with_violations"]) == sorted(orep["points_with_violations"])
+        match = np.full(prep.n_aligned, -1, np.int32)
+        match[m_pairs["aligned_idx"].to_numpy()] = m_pairs["ref_idx"].to_numpy()
+        before, after, flipped, m3 = same_amd.triangle_area_flips(na, nr, tri, {int(i): int(j) for i, j, _ in ch})
+        ob, oa, om3, ofl = oracle.area_flip(axy, rxy, tri, match)
+        assert np.array_equal(np.array([before[t] for t in range(len(tri))]), ob)
+        assert np.array_equal(np.array([np.nan if after[t] is None else after[t] for t in range(len(tri))]), oa, equal_nan=True)
+        assert flipped == np.flatnonzero(ofl).tolist()
+    # an unknown cost dtype is refused at the boundary
+    with pytest.raises(ValueError):
+        same_amd.prepare_same_inputs(rs, ms, cols, optim_params=dict(op, hip_cost_dtype="float16"), verbose=False)

@@ -818,6 +818,46 @@ def test_padded_cost_kernels_vs_oracle(hip, oracle, T, k, n_m, n_r, monkeypatch)
         assert np.array_equal(got, want), (T, k, b, e)
 
 
+@pytest.mark.parametrize("T,k,n_m,n_r", [(1, 3, 200, 300), (2, 8, 513, 700), (5, 8, 1000, 900), (8, 32, 777, 1500), (20, 32, 600, 2000),
+                                        (33, 5, 300, 400), (64, 16, 260, 500), (150, 4, 200, 300)])
+def test_fp32_pair_and_padded_costs_vs_oracle(hip, oracle, T, k, n_m, n_r):
+    """BASELINE config 5's fp32 costs: same_pair_cost_f32 and same_padded_cost_f32_dev (both kernel forms) are bit-equal to
+    the oracle's float evaluation of src/same.py:1180-1189 and to the matching elements of the fp32 dense build, and stay
+    within 1e-5 relative of the fp64 costs (float has 24 bits; T+3 roundings on values of similar magnitude)."""
+    from same_amd import _lib, ops
+
+    rng = np.random.default_rng(T * 77 + k)
+    A, R = rng.gamma(0.4, 20.0, (n_m, T)), rng.gamma(0.4, 20.0, (n_r, T))
+    axy, rxy = rng.uniform(0, 200, (n_m, 2)), rng.uniform(0, 200, (n_r, 2))
+    idx = rng.integers(0, n_r, (n_m, k)).astype(np.int32)
+    idx[rng.random((n_m, k)) < 0.3] = -1
+    rr, cc = np.nonzero(idx >= 0)
+    pairs = np.column_stack((rr, idx[rr, cc]))
+    want = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 0.75, dtype=np.float32)
+    got = ops.pair_cost(A, R, axy, rxy, pairs, 0.75, dtype=np.float32)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    D = ops.dense_cost(A, R, axy, rxy, 0.75, dtype=np.float32)
+    assert np.array_equal(D[pairs[:, 0], pairs[:, 1]], got)
+    c64 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 0.75)
+    assert np.max(np.abs(got.astype(np.float64) - c64) / c64) < 1e-5
+    ctx = _lib.default_context()
+    f32 = [np.ascontiguousarray(x, dtype=np.float32) for x in (A, R, axy, rxy)]
+    dA, dR, dax, drx = (ctx.to_device(x) for x in f32)
+    didx = ctx.to_device(idx)
+    for b, e in ((0, n_m), (17, n_m - 5), (n_m // 2, n_m // 2 + 1)):
+        dout = ctx.alloc(max(e - b, 1) * k * 4)
+        ctx.check(ctx.lib.same_padded_cost_f32_dev(ctx.handle, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, b, e, k, didx.ptr + b * k * 4, 0.75,
+                                                   dout.ptr), "same_padded_cost_f32_dev")
+        gotp = dout.download((e - b, k), np.float32)
+        r2, c2 = np.nonzero(idx[b:e] >= 0)
+        wantp = np.full((e - b, k), np.inf, np.float32)
+        wantp[r2, c2] = oracle.pair_cost_arrays(A, R, axy, rxy, np.column_stack((r2 + b, idx[b:e][r2, c2])), 0.75, dtype=np.float32)
+        assert np.array_equal(gotp, wantp), (T, k, b, e)
+    bad = np.array([[0, n_r]], np.int32)
+    with pytest.raises(_lib.SameHipError):
+        ops.pair_cost(A, R, axy, rxy, bad, 1.0, dtype=np.float32)
+
+
 def test_dense_cost_f32_dev_entry_point(hip, oracle):
     """same_dense_cost_f32_dev (resident operands, cfg-5 fp32 variant): equals the host-buffer form and the oracle's fp32 build."""
     from same_amd import _lib, ops
