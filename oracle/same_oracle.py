@@ -32,11 +32,14 @@ _VP = ctypes.c_void_p
 
 
 def build(force=False):
-    """Compile libsame_oracle.so with gcc (no-op when up to date)."""
-    so = os.path.join(_HERE, "libsame_oracle.so")
+    """Compile libsame_oracle.so with gcc (no-op when up to date).  SAME_ORACLE_SANITIZE=1 selects the
+    -fsanitize=address,undefined build (libsame_oracle_asan.so; the process must run with libasan preloaded --
+    tests/test_oracle_sanitized.py does that in a child process, on the CPU only)."""
+    asan = os.environ.get("SAME_ORACLE_SANITIZE") == "1"
+    so = os.path.join(_HERE, "libsame_oracle_asan.so" if asan else "libsame_oracle.so")
     src = os.path.join(_HERE, "same_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-s", "-C", _HERE, os.path.basename(so)] + (["-B"] if force else []))
     return so
 
 

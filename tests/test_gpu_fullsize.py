@@ -236,8 +236,12 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
         c32 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.0, dtype=np.float32)
         got_c = np.array(prep.costs)
         assert got_c.dtype == np.float64 and np.array_equal(got_c.astype(np.float32), c32) and np.array_equal(got_c, c32.astype(np.float64))
+        # against the fp64 costs: a forward bound, not a relative one -- |ax - rx| is formed in float from coordinates of
+        # magnitude ~1e4, so a pair of near-identical cells (cost ~1e-3 here: jittered copies) keeps only the absolute
+        # accuracy of its operands: (T + 4) roundings of 2^-24 on the operand magnitudes
         c64 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.0)
-        assert np.max(np.abs(got_c - c64) / c64) < 1e-5
+        mag = (np.abs(A[pairs[:, 0]]) + np.abs(R[pairs[:, 1]])).sum(axis=1) + 0.001 * (np.abs(axy[pairs[:, 0]]) + np.abs(rxy[pairs[:, 1]])).sum(axis=1)
+        assert (np.abs(got_c - c64) <= (T + 4) * 2.0 ** -24 * mag).all()
         # a6-a8: triangulation (Qhull on the host, as in the reference), filter, weights, signs
         tri = oracle.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True, min_angle_deg=15)
         tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
