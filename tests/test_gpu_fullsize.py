@@ -219,10 +219,12 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
     r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
     cols = synth.type_columns(T)
     op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
-    for w in (plan[0], plan[len(plan) // 2], plan[-1]):
+    big_last = [w for w in plan if w["n_mov"] > 5_000][-1]
+    assert plan[0]["n_mov"] > 5_000 and plan[len(plan) // 2]["n_mov"] > 5_000 and plan[-1]["n_mov"] < 1_000   # + the thin edge strip
+    for w in (plan[0], plan[len(plan) // 2], big_last, plan[-1]):
         x0, x1, y0, y1 = w["box"]
         rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
-        assert len(ms) > 5_000
+        assert len(ms) == w["n_mov"] >= 10
         prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
         # a2: pairs + compaction
         na, nr, pairs = oracle.find_knn_within_radius(ms, rs, 25, 8)
@@ -252,7 +254,7 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
                   aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
         ch, un = same_amd.compute_mip_start_pairs(**kw)
         och, oun = oracle.compute_mip_start_pairs(**kw)
-        assert ch == och and un == oun and len(ch) > 0.8 * prep.n_aligned
+        assert ch == och and un == oun and len(ch) > 0.5 * prep.n_aligned
         # a10 under that start
         x = np.zeros(len(pairs))
         x[[c[2] for c in ch]] = 1.0
