@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip ceilings / telemetry leg / T sweep (profiling runs)")
     ap.add_argument("--cpu-sample-rows", type=int, default=20000)  # 10-20 s of single-thread oracle work at dense100k
+    ap.add_argument("--tail-stream", default="own", choices=("own", "shared"),
+                    help="own: prune / costs / triangle maps / sweeps run on a second context (stream) beside the dense build; "
+                         "shared: everything on one stream, strictly in order")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:
@@ -239,8 +242,13 @@ def run_rank(args):
     n_ref, rows_cfg, T, k, radius = WORKLOADS[args.workload]
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libsame_hip has no CPU fallback")
-    ctx = _lib.Context(local_rank % _lib.device_count())
+    ctx = _lib.Context(local_rank % _lib.device_count())          # the dense build's context (one context = one stream)
     L, H, chk = ctx.lib, ctx.handle, ctx.check
+    # The rest of the step (prune, candidate costs, gather, triangle maps, sweeps) does not read the dense block, so it
+    # runs on a context of its own: its small latency-bound kernels fill in beside the 16 ms dense kernel instead of
+    # queueing behind it, and the per-step read-back of the sweep waits for that stream only.
+    tctx = _lib.Context(ctx.device) if args.tail_stream == "own" else ctx
+    TH = tctx.handle
 
     # ---- synthetic inputs (seeded), resident before timing ---------------------------------------------------------
     ref = synth.make_cells(n_ref, T, seed=0)
@@ -261,18 +269,18 @@ def run_rank(args):
     ld = (n_ref + 1) & ~1
     chunk_rows = max(1, min(max(rows, 1), int(STRONG_CHUNK_BYTES // (ld * 8)))) if strong else rows
     dD = ctx.alloc(max(chunk_rows, 1) * ld * 8)            # the dense cost block (80 GB at dense100k)
-    didx, dcost, dcnt = ctx.alloc(block * k * 4), ctx.alloc(block * k * 8), ctx.alloc(max(block, 1) * 4)
-    chk(L.same_dev_memset(H, didx.ptr, 0xFF, didx.nbytes), "memset")   # rows past a short last block stay -1
+    didx, dcost, dcnt = tctx.alloc(block * k * 4), tctx.alloc(block * k * 8), tctx.alloc(max(block, 1) * 4)
+    chk(L.same_dev_memset(TH, didx.ptr, 0xFF, didx.nbytes), "memset")   # rows past a short last block stay -1
     # caller-held grid index of the reference cells: built once, reused by every prune of the run
     knn_index = ctypes.c_void_p()
-    chk(L.same_knn_index_build(H, drx.ptr, n_ref, radius, ctypes.byref(knn_index)), "same_knn_index_build")
+    chk(L.same_knn_index_build(TH, drx.ptr, n_ref, radius, ctypes.byref(knn_index)), "same_knn_index_build")
 
     comm, transport = None, "none (single rank)"
     if group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM"):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
         try:
             if os.environ.get("SAME_BENCH_FAIL_RCCL"):
                 raise RuntimeError("forced by SAME_BENCH_FAIL_RCCL (test switch)")
-            comm = RcclGroup(ctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
+            comm = RcclGroup(tctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
             ok_here = 1.0
         except Exception as e:  # TRANSPORT fallback only (compute stays on the GPU): reported in the JSON line
             print(f"[rank {group.rank}] RCCL communicator init failed ({e}); gathering through the host group instead", file=sys.stderr)
@@ -280,7 +288,7 @@ def run_rank(args):
         if group.min(ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
             if comm is not None:
                 comm.close()
-            comm = HostTransport(ctx, group)
+            comm = HostTransport(tctx, group)
             transport = "HOST (loopback TCP) all-gather of pruned lists: RCCL init failed on this node"
         else:
             v = comm.rccl_version()
@@ -288,51 +296,59 @@ def run_rank(args):
                         ("" if strong else " (overlapped on a second stream)")
     gidx = gcost = None
     if comm is not None:
-        gidx, gcost = ctx.alloc(block * k * 4 * group.world), ctx.alloc(block * k * 8 * group.world)
+        gidx, gcost = tctx.alloc(block * k * 4 * group.world), tctx.alloc(block * k * 8 * group.world)
     note(group, f"inputs resident ({rows} of {n_mov} aligned x {n_ref} ref, {Tr} triangles); gather transport: {transport}")
 
-    dcls, dperim, dmaxcos = ctx.alloc(Tr), ctx.alloc(Tr * 8), ctx.alloc(Tr * 8)
-    dsign, dweight = ctx.alloc(Tr), ctx.alloc(Tr * 8)
-    dedge, dtflag, dpflag, dcounts = ctx.alloc(Tr * 3), ctx.alloc(Tr), ctx.alloc(n_mov), ctx.alloc(32)
-    dbefore, dafter, dm3, dflip = ctx.alloc(Tr * 8), ctx.alloc(Tr * 8), ctx.alloc(Tr * 3), ctx.alloc(Tr)
-    dmatch = ctx.alloc(n_mov * 4)
+    ta = tctx.alloc
+    dcls, dperim, dmaxcos = ta(Tr), ta(Tr * 8), ta(Tr * 8)
+    dsign, dweight = ta(Tr), ta(Tr * 8)
+    dedge, dtflag, dpflag, dcounts = ta(Tr * 3), ta(Tr), ta(n_mov), ta(32)
+    dbefore, dafter, dm3, dflip = ta(Tr * 8), ta(Tr * 8), ta(Tr * 3), ta(Tr)
+    dmatch = ta(n_mov * 4)
     en, thr = cos_threshold(15)
 
     # source signs + the resident sweep state (one untimed pass)
-    chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
+    ctx.sync()   # the uploads above went through the dense context's stream
+    chk(L.same_tri_sign_weight_dev(TH, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
     sign0 = dsign.download((Tr,), np.int8)
     sweep = ctypes.c_void_p()
-    chk(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, n_mov, None, 0,
+    chk(L.same_sweep_bind(TH, tris.ctypes.data, Tr, sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, n_mov, None, 0,
                           ctypes.byref(sweep)), "bind")
-    sharded = ShardedSweeps(ctx, comm, sweep, dax, drx, dtris, Tr, n_mov) if (strong and comm is not None) else None
+    sharded = ShardedSweeps(tctx, comm, sweep, dax, drx, dtris, Tr, n_mov) if (strong and comm is not None) else None
     checked, nviol = ctypes.c_int64(0), ctypes.c_int64(0)
     viol = np.empty(max(Tr, 1), np.int32)
     last = {"checked": 0, "viol": viol[:0]}
     dense_ms = []
 
+    n_chunks = len(range(rb, re, chunk_rows))
+
     def dense_all(T_=T, timed=None):
-        """the dense build of this rank's rows (strong mode: in chunks through the one buffer)"""
+        """Enqueue the dense build of this rank's rows (strong mode: in chunks through the one buffer).  With `timed`, HIP
+        events on the dense stream bracket the launch(es); dense_time() reads them after the rest of the step was issued."""
+        if timed is not None:
+            chk(L.same_timer_start(H), "timer")
         for c0 in range(rb, re, chunk_rows):
-            c1 = min(c0 + chunk_rows, re)
-            if timed is not None:
-                chk(L.same_timer_start(H), "timer")
-            chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T_, dax.ptr, drx.ptr, n_ref, c0, c1, 1.0, dD.ptr, ld), "dense")
-            if timed is not None:
-                ms = ctypes.c_float(0)
-                chk(L.same_timer_stop(H, ctypes.byref(ms)), "timer")
-                timed.append((ms.value, c1 - c0))
+            chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T_, dax.ptr, drx.ptr, n_ref, c0, min(c0 + chunk_rows, re), 1.0, dD.ptr, ld), "dense")
+        if timed is not None:
+            chk(L.same_timer_mark(H), "timer")
+
+    def dense_time(timed):
+        if timed is not None:
+            ms = ctypes.c_float(0)
+            chk(L.same_timer_read(H, ctypes.byref(ms)), "timer")
+            timed.append((ms.value / max(n_chunks, 1), rows / max(n_chunks, 1)))   # per launch
 
     def prune_and_costs():
-        chk(L.same_knn_prune_indexed_dev(H, knn_index, dax.ptr, rb, re, k, didx.ptr, None, dcnt.ptr), "knn")
-        chk(L.same_padded_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, rb, re, k, didx.ptr, 1.0, dcost.ptr), "padded")
+        chk(L.same_knn_prune_indexed_dev(TH, knn_index, dax.ptr, rb, re, k, didx.ptr, None, dcnt.ptr), "knn")
+        chk(L.same_padded_cost_f64_dev(TH, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, rb, re, k, didx.ptr, 1.0, dcost.ptr), "padded")
 
     def tri_maps():
-        chk(L.same_tri_classify_dev(H, dax.ptr, dtris.ptr, Tr, radius, en, thr, dtype_id.ptr, dcls.ptr, dperim.ptr, dmaxcos.ptr), "cls")
-        chk(L.same_tri_sign_weight_dev(H, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
+        chk(L.same_tri_classify_dev(TH, dax.ptr, dtris.ptr, Tr, radius, en, thr, dtype_id.ptr, dcls.ptr, dperim.ptr, dmaxcos.ptr), "cls")
+        chk(L.same_tri_sign_weight_dev(TH, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
 
     def local_sweeps():
-        chk(L.same_xyorder_sweep_dev(H, dax.ptr, n_mov, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")
-        chk(L.same_area_flip_dev(H, dax.ptr, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dbefore.ptr, dafter.ptr, dm3.ptr, dflip.ptr), "area")
+        chk(L.same_xyorder_sweep_dev(TH, dax.ptr, n_mov, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")
+        chk(L.same_area_flip_dev(TH, dax.ptr, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dbefore.ptr, dafter.ptr, dm3.ptr, dflip.ptr), "area")
         chk(L.same_orient_sweep_dev(sweep, dmatch.ptr, ctypes.byref(checked), viol.ctypes.data, ctypes.byref(nviol)), "orient")
         last["checked"], last["viol"] = checked.value, viol[: nviol.value]
 
@@ -346,6 +362,7 @@ def run_rank(args):
             comm.allgather_dev_async(dcost, gcost, block * k * 8)
         tri_maps()
         local_sweeps()
+        dense_time(timed)
 
     def step_strong(timed=None):
         dense_all(timed=timed)
@@ -354,27 +371,30 @@ def run_rank(args):
             comm.allgather_dev(didx, gidx, block * k * 4)
             comm.allgather_dev(dcost, gcost, block * k * 8)
         # the common matching: nearest reference of every aligned cell, from the gathered lists (identical on every rank)
-        chk(L.same_first_candidate_dev(H, (gidx if comm is not None else didx).ptr, n_mov, k, dmatch.ptr), "match")
+        chk(L.same_first_candidate_dev(TH, (gidx if comm is not None else didx).ptr, n_mov, k, dmatch.ptr), "match")
         tri_maps()
         if sharded is not None:
             last["checked"], last["viol"] = sharded.run(dmatch)
         else:
             local_sweeps()
+        dense_time(timed)
 
     step = step_strong if strong else step_weak
     if not strong:   # candidate matching for the sweeps: nearest reference within the radius (from one untimed prune)
         prune_and_costs()
-        chk(L.same_first_candidate_dev(H, didx.ptr, n_mov, k, dmatch.ptr), "match")
+        chk(L.same_first_candidate_dev(TH, didx.ptr, n_mov, k, dmatch.ptr), "match")
 
     for _ in range(args.warmup):
         step()
     ctx.sync()
+    tctx.sync()
     group.barrier()
     note(group, "warm-up done, timing")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=dense_ms)
     ctx.sync()
+    tctx.sync()
     group.barrier()
     dt = group.max(time.perf_counter() - t0)
     note(group, f"{args.steps} steps in {dt:.3f} s")
@@ -406,6 +426,7 @@ def run_rank(args):
             t_end = time.perf_counter() + float(os.environ.get("SAME_BENCH_TELEMETRY_S", "2.0"))
             while time.perf_counter() < t_end:
                 dense_all(timed=loop_ms)
+                dense_time(loop_ms)
             tele = tel.stop()
             tele["dense_ms_during_window"] = float(np.mean([m for m, _ in loop_ms]))
             tele["what"] = f"dense kernel (T={T}, fp64) looped alone for the window; sysfs read every {tel.period * 1e3:.0f} ms by a side thread"
@@ -568,6 +589,8 @@ def run_rank(args):
                                                            if strong else f"{rows} aligned x {n_ref} ref cells per GPU")
                                    + f", T={T} type cols, fp64 dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
                                      "triangles classify/sign + orientation / XY-order / area-flip sweeps",
+                       "streams": ("dense build on one stream, prune / costs / triangle maps / sweeps on a second (own context)"
+                                   if tctx is not ctx else "one stream, in order"),
                        "parallelism": f"aligned-row blocks x{group.world}" + (", " + transport if comm is not None else "")
                                       + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if sharded is not None else "")},
             "roofline": roof,
@@ -580,6 +603,8 @@ def run_rank(args):
     L.same_knn_index_destroy(knn_index)
     if comm is not None:
         comm.close()
+    if tctx is not ctx:
+        tctx.close()
     group.close()
 
 

@@ -74,6 +74,9 @@ int same_ctx_release_scratch(same_ctx *ctx);
 /* HIP events recorded on the context's stream (where the kernels run). */
 int same_timer_start(same_ctx *ctx);
 int same_timer_stop(same_ctx *ctx, float *out_ms); /* records, synchronises, returns elapsed ms */
+/* the same in two steps: mark the end now (no wait), read the elapsed time later */
+int same_timer_mark(same_ctx *ctx);
+int same_timer_read(same_ctx *ctx, float *out_ms);
 
 /* ---- a4: pair costs -------------------------------------------------------------------
  * Replaces the loop at src/same.py:1180-1189:

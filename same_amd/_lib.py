@@ -46,6 +46,8 @@ _PROTOTYPES = {
     "same_ctx_release_scratch": [c_vp],
     "same_timer_start": [c_vp],
     "same_timer_stop": [c_vp, ctypes.POINTER(c_flt)],
+    "same_timer_mark": [c_vp],
+    "same_timer_read": [c_vp, ctypes.POINTER(c_flt)],
     "same_pair_cost_f64": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_dbl, c_vp],
     "same_pair_cost_f32": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_flt, c_vp],
     "same_dense_cost_f64_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_vp, c_i64],

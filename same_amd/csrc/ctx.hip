@@ -168,6 +168,23 @@ int same_timer_stop(same_ctx *ctx, float *out_ms) {
     return SAME_OK;
 }
 
+// split form of same_timer_stop: mark the end on the stream now, read the elapsed time later (the host can keep
+// enqueueing work -- on this or another context -- while the timed kernel runs)
+int same_timer_mark(same_ctx *ctx) {
+    REQUIRE(ctx, ctx != nullptr);
+    SAME_TRY(same_use(ctx));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    return SAME_OK;
+}
+
+int same_timer_read(same_ctx *ctx, float *out_ms) {
+    REQUIRE(ctx, ctx && out_ms);
+    SAME_TRY(same_use(ctx));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev0, ctx->ev1));
+    return SAME_OK;
+}
+
 }  // extern "C"
 
 int same_use(same_ctx *ctx) {
