@@ -15,7 +15,7 @@ from typing import Any, Dict, Optional
 import numpy as np
 import pandas as pd
 
-from . import ops, sweeps
+from . import ops, sweeps, varout
 from .cost import pair_costs
 from .init_helpers import apply_mip_start
 from .knn import find_knn_with_cell_type_priority, find_knn_within_radius

@@ -214,3 +214,14 @@ def test_knn_argument_checks_mirror_ckdtree():
     for radius, knn in ((float("nan"), 3), (5.0, 0)):
         na, nr, pairs = find_knn_within_radius(a, a, radius, knn, verbose=False)
         assert len(na) == 0 and len(nr) == 0 and len(pairs) == 0
+
+
+def test_no_name_is_read_without_being_bound():
+    """A forgotten import in a GPU-only code path cannot be caught by running it on this CPU box; catch it on the syntax tree."""
+    import glob
+    import subprocess
+    import sys
+
+    files = sorted(glob.glob(os.path.join(ROOT, "same_amd", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "undefined_names.py")] + files, capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout
