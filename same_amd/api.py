@@ -560,6 +560,7 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
     from . import qhull_pool
 
     depth = qhull_pool.lookahead()
+    qhull_pool.warm(min(depth, len(plan)))
     ahead = {}
     for q, w in enumerate(plan):
         for nxt in range(q, min(q + 1 + depth, len(plan))):
@@ -664,6 +665,7 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
     if _run_window is None:
         from . import qhull_pool
         depth = qhull_pool.lookahead()
+        qhull_pool.warm(min(depth, len(todo)))      # helpers start (import scipy) while the first window is being pruned
 
     def stage(q):
         pos_q, w_q = todo[q]
