@@ -566,8 +566,9 @@ def run_rank(args):
             t = extras["telemetry"]
             roof["telemetry"] = t
             if t.get("available") and t.get("power"):
-                clk = t.get("sclk_hwmon") or t.get("sclk_dpm")
-                msg.append(f"while the kernel looped the board drew {t['power']['mean']:.0f} W (max {t['power']['max']:.0f} W"
+                clk = t.get("sclk_steady") or t.get("sclk_hwmon") or t.get("sclk_dpm")
+                pw = t.get("power_steady") or t["power"]
+                msg.append(f"while the kernel looped the board drew {pw['mean']:.0f} W in steady state (max {t['power']['max']:.0f} W"
                            + (f", cap {t['power_cap_w']:.0f} W" if t.get("power_cap_w") else "") + ")"
                            + (f" at a shader clock of {clk['mean']:.0f} MHz (min {clk['min']:.0f})" if clk else "")
                            + f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "

@@ -85,8 +85,11 @@ class GpuTelemetry:
                 return None
             return {"mean": sum(vals) / len(vals), "min": min(vals), "max": max(vals), "unit": unit}
 
+        # the first quarter of the window is the ramp from idle (clocks up, power1_input is itself an average): steady = the rest
+        steady = s[len(s) // 4:] if len(s) >= 8 else s
         return {"available": self.available(), "samples": len(s),
                 "window_s": (s[-1][0] - s[0][0]) if len(s) > 1 else 0.0,
-                "power": stats([x[1] for x in s], "W"), "power_cap_w": self.cap_w,
+                "power": stats([x[1] for x in s], "W"), "power_steady": stats([x[1] for x in steady], "W"),
+                "sclk_steady": stats([x[2] if x[2] is not None else x[3] for x in steady], "MHz"), "power_cap_w": self.cap_w,
                 "sclk_hwmon": stats([x[2] for x in s], "MHz"), "sclk_dpm": stats([x[3] for x in s], "MHz"),
                 "source": {"power": self.power_path, "sclk_hwmon": self.freq_path, "sclk_dpm": self.dpm_path}}
