@@ -16,6 +16,7 @@ import numpy as np
 import pandas as pd
 
 from . import ops, sweeps, varout
+from ._rows import rows_array, values_array
 from .cost import pair_costs
 from .init_helpers import apply_mip_start
 from .knn import find_knn_with_cell_type_priority, find_knn_within_radius
@@ -222,7 +223,7 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
         old_to_new[constrained_nodes] = np.arange(len(constrained_nodes))
         vp = vp[keep_node[vp[:, 0]]]
         valid_pairs = [(int(old_to_new[i]), int(j)) for i, j in vp]
-        tri = np.asarray(aligned_delaunay).reshape(-1, 3) if len(aligned_delaunay) else np.zeros((0, 3), dtype=int)
+        tri = rows_array(aligned_delaunay)
         tri = tri[keep_node[tri].all(axis=1)] if len(tri) else tri
         aligned_delaunay = old_to_new[tri] if len(tri) else np.array([]).reshape(0, 3)
         aligned_df = aligned_df.iloc[constrained_nodes].reset_index(drop=True)
@@ -444,7 +445,7 @@ def _add_spatial_constraints_eager(model, GRB, x, prep):
     `same_eager_signs` launch instead of the reference's process pool.  Building the Python constraint objects stays a
     host loop -- that is the solver's API."""
     pairs = np.asarray(prep.valid_pairs, dtype=np.int64).reshape(-1, 2)
-    tris = np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3)
+    tris = rows_array(prep.aligned_delaunay, dtype=np.int64)
     n_aligned = prep.n_aligned
     order = np.argsort(pairs[:, 0], kind="stable")          # valid_pairs_imap: pair indices per aligned row, in pair order
     counts = np.bincount(pairs[:, 0], minlength=n_aligned)
@@ -561,12 +562,13 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
 
     depth = qhull_pool.lookahead()
     qhull_pool.warm(min(depth, len(plan)))
+    ref_rows, moving_rows = _WindowSubsetter(ref), _WindowSubsetter(moving)
     ahead = {}
     for q, w in enumerate(plan):
         for nxt in range(q, min(q + 1 + depth, len(plan))):
             if nxt not in ahead:
-                x0, x1, y0, y1 = plan[nxt]["box"]
-                ahead[nxt] = _stage_prune(subset_data(ref, x0, x1, y0, y1), subset_data(moving, x0, x1, y0, y1), commonCT, None, None,
+                box = plan[nxt]["box"]
+                ahead[nxt] = _stage_prune(ref_rows.subset(*box), moving_rows.subset(*box), commonCT, None, None,
                                           optim_params, gurobi_params, False, verbose, ctx, prefetch=True)
         st = ahead.pop(q)
         try:
@@ -578,6 +580,28 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
 def subset_data(df, x_min, x_max, y_min, y_max):
     """src/same.py:293-295."""
     return df[(df["X"] >= x_min) & (df["X"] < x_max) & (df["Y"] >= y_min) & (df["Y"] < y_max)]
+
+
+class _WindowSubsetter:
+    """subset_data for many boxes of one frame.  The reference evaluates four comparisons over the WHOLE frame for every
+    window (O(N * windows), src/same.py:521-526); here the rows are ordered by X once, a window's X range is two binary
+    searches, and only that slab is tested on Y.  The rows come back in frame order with their original labels, i.e. the
+    frame `subset_data` returns (NaN coordinates fall outside every box either way)."""
+
+    def __init__(self, df):
+        self.df = df
+        x = df["X"].to_numpy(dtype=np.float64)
+        self.y = df["Y"].to_numpy(dtype=np.float64)
+        self.order = np.argsort(x, kind="stable")        # NaN last
+        self.xs = x[self.order]
+
+    def subset(self, x_min, x_max, y_min, y_max):
+        lo = np.searchsorted(self.xs, x_min, side="left")    # first x >= x_min
+        hi = np.searchsorted(self.xs, x_max, side="left")    # first x >= x_max
+        slab = self.order[lo:hi]
+        yy = self.y[slab]
+        rows = np.sort(slab[(yy >= y_min) & (yy < y_max)])
+        return self.df.iloc[rows]
 
 
 def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None,
@@ -652,9 +676,10 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
         mine = set(assign_windows(plan, int(_shard[1]))[int(_shard[0])])
     todo = [(pos, w) for pos, w in enumerate(plan) if w["grid_id"] not in done_ids and (mine is None or pos in mine)]
 
+    ref_rows, moving_rows = _WindowSubsetter(ref), _WindowSubsetter(moving)
+
     def subsets(w):
-        x0, x1, y0, y1 = w["box"]
-        return subset_data(ref, x0, x1, y0, y1), subset_data(moving, x0, x1, y0, y1)
+        return ref_rows.subset(*w["box"]), moving_rows.subset(*w["box"])
 
     # The reference runs the windows strictly one after another (src/same.py:507-593), each paying its own Qhull call in the
     # middle of its pre-MIP path.  Here window n+1..n+k are subset, pruned and compacted while window n is still to run, and

@@ -2,6 +2,7 @@
 import numpy as np
 
 from . import ops
+from ._rows import ValueList
 
 
 def _xy(df):
@@ -17,7 +18,7 @@ def pair_costs(aligned_df, ref_df, valid_pairs, commonCT, dist_ct_coeff, ctx=Non
     R = ref_df[cols].to_numpy(dtype=np.float64)
     pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
     c = ops.pair_cost(A, R, _xy(aligned_df), _xy(ref_df), pairs, dist_ct_coeff, dtype=dtype, ctx=ctx)
-    return list(c.astype(np.float64, copy=False))
+    return ValueList(c.astype(np.float64, copy=False))
 
 
 def dense_cost_matrix(aligned_df, ref_df, commonCT, dist_ct_coeff, row_begin=0, row_end=None, dtype=np.float64, ctx=None):

@@ -8,6 +8,7 @@ from typing import List, Optional, Set, Tuple
 import numpy as np
 
 from . import ops
+from ._rows import values_array
 
 
 _METHODS = ("greedy", "hungarian")
@@ -39,7 +40,7 @@ def compute_mip_start_pairs(*, valid_pairs, costs, n_aligned, n_ref, aligned_siz
         if bad:
             raise ValueError(text)
 
-    cost = np.asarray(costs, dtype=float)
+    cost = values_array(costs, dtype=float)
     stay_cost = float(no_match_penalty) * np.asarray(aligned_sizes, dtype=float)     # price of leaving row i unmatched
     pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
 
@@ -51,7 +52,7 @@ def compute_mip_start_pairs(*, valid_pairs, costs, n_aligned, n_ref, aligned_siz
         pair_of_row, _rounds = ops.greedy_match(pairs, cost, n_aligned, n_ref, wants_match, ctx=ctx)
         taken = pair_of_row[pair_of_row >= 0].astype(np.int64)
         taken = taken[np.lexsort((taken, cost[taken]))]
-        started = [(int(pairs[p, 0]), int(pairs[p, 1]), int(p)) for p in taken]
+        started = list(zip(pairs[taken, 0].tolist(), pairs[taken, 1].tolist(), taken.tolist()))
         return started, set(np.flatnonzero(pair_of_row < 0).tolist())
 
     if n_aligned + n_ref > int(init_hungarian_max_n):

@@ -11,6 +11,7 @@
 import numpy as np
 
 from . import ops
+from ._rows import rows_array, values_array
 
 _EDGES = ((0, 1), (0, 2), (1, 2))
 
@@ -19,9 +20,9 @@ class LazyOrientationSweep:
     """Device-resident replacement for the model._* state the callback reads (src/same.py:1153-1158)."""
 
     def __init__(self, valid_pairs, aligned_delaunay, source_signs, ref_xy, n_aligned, ctx=None):
-        self.tris = np.asarray(aligned_delaunay).reshape(-1, 3) if len(aligned_delaunay) else np.zeros((0, 3), dtype=int)
+        self.tris = rows_array(aligned_delaunay)
         pairs = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
-        self.bound = ops.BoundSweep(self.tris, np.asarray(source_signs).astype(np.int8), ref_xy, n_aligned, pairs, ctx=ctx)
+        self.bound = ops.BoundSweep(self.tris, values_array(source_signs).astype(np.int8), ref_xy, n_aligned, pairs, ctx=ctx)
 
     def sweep(self, x_vals):
         """-> (checked, violating_tris [(tri_idx, a, b, c)] ascending, match_pair_idx array)."""
@@ -119,7 +120,7 @@ def triangle_area_flips(aligned_df, ref_df, aligned_delaunay, aligned_to_ref, ct
     match = np.full(len(aligned_df), -1, np.int32)
     for i, j in aligned_to_ref.items():
         match[int(i)] = int(j)
-    tris = np.asarray(aligned_delaunay).reshape(-1, 3) if len(aligned_delaunay) else np.zeros((0, 3), dtype=int)
+    tris = rows_array(aligned_delaunay)
     before, after, m3, fl = _sweep(axy, rxy, tris, match) if _sweep else ops.area_flip(axy, rxy, tris, match, ctx=ctx)
     n = len(tris)
     areas_before = {t: before[t] for t in range(n)}

@@ -7,6 +7,7 @@ import numpy as np
 import pandas as pd
 
 from . import ops
+from ._rows import RowList, ValueList, rows_array
 
 
 # ----------------------------------------------------------------------------- a6 (host)
@@ -118,8 +119,7 @@ def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignor
                                min_angle_deg=15, verbose=True, ctx=None):
     """Same signature and return shapes as src/helpers.py:233-395."""
     points = np.asarray(points)
-    tri_arr = np.asarray(triangles)
-    tris = tri_arr.reshape(-1, 3) if tri_arr.size else np.zeros((0, 3), dtype=int)
+    tris = rows_array(triangles)
     use_type = bool(ignore_same_type_triangles and aligned_df is not None)
     type_id = None
     if use_type:
@@ -173,7 +173,7 @@ def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignor
                 print(f"Added back {added} same-type triangles to ensure >=1 triangle per node")
                 print(f"Final triangles kept: {len(order)}")
 
-    filtered = list(tris[np.asarray(order, dtype=np.int64)]) if order else []
+    filtered = RowList(tris[np.asarray(order, dtype=np.int64)]) if order else []   # a list of triangle rows, as the reference returns
     if remove_unconstrained_nodes:
         return filtered, set(np.flatnonzero(~any_valid).tolist())
     return filtered
@@ -184,11 +184,11 @@ def triangle_weights_and_signs(aligned_df, triangles, ctx=None):
     """-> (list of weights, list of np.float64 signs) as run_same builds them (src/same.py:1128-1146)."""
     xy = aligned_df[["X", "Y"]].to_numpy(dtype=np.float64)
     size = aligned_df["size"].to_numpy(dtype=np.float64)
-    sign, weight = ops.tri_sign_weight(xy, size, np.asarray(triangles).reshape(-1, 3), ctx=ctx)
+    sign, weight = ops.tri_sign_weight(xy, size, rows_array(triangles), ctx=ctx)
     size_dtype = aligned_df["size"].dtype
     if np.issubdtype(size_dtype, np.integer):
         weight = weight.astype(np.int64)  # integer size columns sum to integers in the reference
-    return list(weight), list(sign.astype(np.float64))
+    return ValueList(weight), ValueList(sign.astype(np.float64))
 
 
 # ----------------------------------------------------------------------------- a9 (host, flat arrays -> dicts)

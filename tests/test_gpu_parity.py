@@ -157,7 +157,7 @@ def test_pair_cost_golden(hip, ops, oracle, case):
     np.testing.assert_allclose(D32, D, rtol=1e-5, atol=1e-6 * 100 * max(len(cols), 1))
 
 
-@pytest.mark.parametrize("T", [0, 1, 2, 7, 20, 24, 25, 33, 48, 49, 70])
+@pytest.mark.parametrize("T", [0, 1, 2, 7, 20, 24, 25, 33, 48, 49, 55, 56, 64, 70, 129, 300])   # > 48: the row-blocked kernel (pieces of 8 types + remainder)
 @pytest.mark.parametrize("w", [1.0, 0.37])
 def test_dense_cost_all_T(ops, oracle, T, w):
     rng = np.random.default_rng(T)
