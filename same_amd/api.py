@@ -528,7 +528,8 @@ def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_var
         "violation_penalty_comparison": {"points_both": list(points_both),
                                          "points_only_violations": list(violation_points - penalty_points),
                                          "points_only_penalties": list(penalty_points - violation_points)},
-        "triangle_data": {"triangles": tris, "triangle_info": prep.triangle_info,
+        "triangle_data": {"triangles": list(tris) if isinstance(tris, list) else tris,   # a plain list of rows, as the reference stores
+                          "triangle_info": prep.triangle_info,
                           "aligned_simplex_map": prep.aligned_simplex_map, "areas_before": before, "areas_after": after,
                           "flipped_triangles": flipped, "matched_vertices": matched_vertices},
         "lazy_constraints": bool(prep.optim_params["lazy_constraints"]),
