@@ -593,7 +593,7 @@ class _WindowSubsetter:
         self.df = df
         x = df["X"].to_numpy(dtype=np.float64)
         self.y = df["Y"].to_numpy(dtype=np.float64)
-        self.order = np.argsort(x, kind="stable")        # NaN last
+        self.order = np.argsort(x)                        # NaN last; ties may come in any order (rows are re-sorted per box)
         self.xs = x[self.order]
 
     def subset(self, x_min, x_max, y_min, y_max):

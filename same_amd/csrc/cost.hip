@@ -482,6 +482,10 @@ int launch_dense(same_ctx *ctx, const F *A, const F *R, int T, const F *axy, con
     REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && n_r >= 0 && rb >= 0 && re >= rb && ld >= n_r);
     SAME_TRY(same_use(ctx));
     if (n_r == 0 || re == rb) return SAME_OK;
+    // above this many type columns the row-blocked kernel takes over from the column-resident one (SAME_DENSE_ROWBLOCK_MIN_T
+    // overrides, for probing the crossover)
+    static const int rowblock_min_T = env_int("SAME_DENSE_ROWBLOCK_MIN_T", 49);
+    if (T < rowblock_min_T)
     switch (T) {
 #define CASE_T(n) case n: return launch_dense_T<F, n>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
         CASE_T(0) CASE_T(1) CASE_T(2) CASE_T(3) CASE_T(4) CASE_T(5) CASE_T(6) CASE_T(7) CASE_T(8)

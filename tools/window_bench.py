@@ -17,7 +17,7 @@ def main():
     from same_amd.windows import window_plan
 
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    max_windows = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    max_windows = int(sys.argv[2]) if len(sys.argv) > 2 else 10**9      # default: the whole plan
     f32 = len(sys.argv) > 3 and sys.argv[3] == "f32"
     T = 8
     ref = synth.make_cells(n, T, seed=0); mov = synth.make_jittered(ref, seed=1)
