@@ -252,8 +252,11 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
 // (one 64-byte run) and every row of the chunk consumes them, the row's own 8 values arriving as one wave-uniform scalar
 // load.  Per element that is still the two fp64 adds of the reference's left-to-right sum (the running sum is carried
 // across pieces, so the order of additions is unchanged) plus 1/32 of a vector load; stores are 8 B per lane, contiguous
-// across the wave.  Measured at 50k x 50k: T=49 35 ms / T=64 44 ms / T=128 84 ms (the one-column-per-lane,
-// load-per-element form it replaces: 497 / 616 / 1317 ms).
+// across the wave.  Measured at 50k x 50k fp64 (profiles/r02_dense_generic_kernel.log): T=49 17.7 ms, T=64 22.8 ms,
+// T=128 44.0 ms, i.e. ~14.5 T fp64 lane-instructions/s -- half the column-resident kernel's rate (one 64-byte scalar
+// load per 16 VALU instructions), against 497 / 616 / 1317 ms for the one-column-per-lane, load-per-element form it
+// replaces.  It also beats the column-resident kernel at fp64 T=48 (17.6 vs 20.6 ms, where that kernel is down to one
+// column per lane), not below (T=44: 16.2 vs 11.7 ms; fp32 T=48: 9.1 vs 5.8 ms).
 template <typename F, int RB>
 __global__ __launch_bounds__(256) void dense_cost_rowblock_kernel(
     const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
@@ -484,7 +487,7 @@ int launch_dense(same_ctx *ctx, const F *A, const F *R, int T, const F *axy, con
     if (n_r == 0 || re == rb) return SAME_OK;
     // above this many type columns the row-blocked kernel takes over from the column-resident one (SAME_DENSE_ROWBLOCK_MIN_T
     // overrides, for probing the crossover)
-    static const int rowblock_min_T = env_int("SAME_DENSE_ROWBLOCK_MIN_T", 49);
+    static const int rowblock_min_T = env_int("SAME_DENSE_ROWBLOCK_MIN_T", sizeof(F) == 8 ? 48 : 49);
     if (T < rowblock_min_T)
     switch (T) {
 #define CASE_T(n) case n: return launch_dense_T<F, n>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
