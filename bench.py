@@ -449,6 +449,22 @@ def run_rank(args):
                                "GBs": by / t_s / 1e9, "frac": by / t_s / 1e9 / HBM_PEAK_GBS})
             for b in bufs:
                 b.free()
+        # control: the opt-in fixed-point build at the bench's own T -- the same 80 GB of stores with the 2T fp64 adds replaced
+        # by T integer v_sad_u32 (exact sums on a 2^-s grid; NOT the reference's arithmetic, never the reported kernel)
+        if ld % 4 == 0 and T <= 32:
+            from same_amd import ops
+
+            off, l2 = ops.quantize_types(mov["types"], ref["types"])
+            dAq, dRq = ctx.alloc(mov["types"].size * 4), ctx.alloc(ref["types"].size * 4)
+            chk(L.same_quantize_u32_dev(H, dA.ptr, mov["types"].size, off, 2.0 ** l2, dAq.ptr), "quantize")
+            chk(L.same_quantize_u32_dev(H, dR.ptr, ref["types"].size, off, 2.0 ** l2, dRq.ptr), "quantize")
+            t_q = timed_ms(lambda: L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, 2.0 ** -l2, dD.ptr, ld), "dense q32")
+            by = 8.0 * n_ref * rows + (4.0 * T + 16.0) * (n_ref + rows)
+            sweep_rows.append({"dtype": "q32->f64", "T": T, "kernel": f"dense_cost_q32_kernel<{T},4>", "ms": t_q * 1e3, "GBs": by / t_q / 1e9,
+                               "frac": by / t_q / 1e9 / HBM_PEAK_GBS, "opt_in": True,
+                               "note": f"fixed-point control, not reference arithmetic: type sum exact on a 2^-{l2} grid, |error| <= {T * 2.0 ** -l2:.2e} absolute"})
+            dAq.free()
+            dRq.free()
         extras["sweep"] = sweep_rows
 
     # ---- CPU baseline leg (rank 0, N=1, untimed region): the oracle runs a bounded sample of the same workload on the

@@ -111,6 +111,23 @@ int same_dense_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n
                         int T, const float *axy, const float *rxy, int64_t row_begin,
                         int64_t row_end, float w, float *out, int64_t ld);
 
+/* ---- opt-in fixed-point dense build ---------------------------------------------------------
+ * NOT the reference's arithmetic and never a default: the type values are put on a common 32-bit
+ * fixed-point grid q(v) = rint((v - offset) * scale), the type sum becomes an exact integer sum of
+ * absolute differences (one v_sad_u32 per element instead of two fp64 adds), the rest of the expression
+ * is unchanged fp64:  out = w * (double(S_q) * inv_scale) + (w*0.001) * (|ax-rx| + |ay-ry|).
+ * Error against same_dense_cost_f64_dev: |S_q * inv_scale - S| <= T * inv_scale (plus fp64 rounding).  The caller
+ * chooses offset / scale so that every row-pair sum fits 32 bits (same_amd.ops.quantize_types); the row
+ * pitch ld must be a multiple of 4 doubles and columns [n_r, ld) are written too (padding owned by the
+ * caller).  T <= SAME_Q32_MAX_TYPES.  Meant for the dense matrix of the Hungarian MIP-start heuristic
+ * (src/init_helpers.py:151-155) and as the roofline control of DESIGN.md 5.1. */
+#define SAME_Q32_MAX_TYPES 32
+int same_quantize_u32_dev(same_ctx *ctx, const double *dsrc, int64_t n, double offset, double scale,
+                          uint32_t *ddst);
+int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, int T,
+                            const double *daxy, const double *drxy, int64_t n_r, int64_t row_begin,
+                            int64_t row_end, double w, double inv_scale, double *dout, int64_t ld);
+
 /* ---- a2: KNN prune within a radius ----------------------------------------------------
  * Replaces the per-row body of utils.find_knn_within_radius (src/utils.py:720-728):
  * for aligned rows [row_begin,row_end): refs with dx*dx+dy*dy <= radius*radius (cKDTree

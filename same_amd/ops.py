@@ -58,6 +58,54 @@ def dense_cost(A, R, axy, rxy, w, row_begin=0, row_end=None, dtype=F64, ctx=None
     return out
 
 
+def quantize_types(A, R):
+    """Grid for the opt-in fixed-point dense build: -> (offset, log2_scale) such that every value of A and R is >= offset and
+    every row-pair sum of absolute differences, on the grid, fits 32 bits.  sum_t |a_t - r_t| <= sum_t (a_t - offset) +
+    sum_t (r_t - offset), so the largest row sum of each matrix bounds it; each grid value may round up by half a step."""
+    A, R = np.asarray(A, dtype=F64), np.asarray(R, dtype=F64)
+    if A.size == 0 or R.size == 0 or A.shape[1] == 0:
+        return 0.0, 0
+    if not (np.isfinite(A).all() and np.isfinite(R).all()):
+        raise ValueError("the fixed-point build needs finite type values")
+    offset = float(min(A.min(), R.min()))
+    bound = float((A - offset).sum(axis=1).max() + (R - offset).sum(axis=1).max())
+    T = A.shape[1]
+    if bound <= 0.0:
+        return offset, 0
+    log2_scale = int(np.floor(np.log2((2.0 ** 32 - 1.0 - T) / bound)))
+    while (bound * 2.0 ** log2_scale + T) >= 2.0 ** 32:   # guard the floor() against the last ulp
+        log2_scale -= 1
+    return offset, min(log2_scale, 1000)
+
+
+def dense_cost_q32(A, R, axy, rxy, w, row_begin=0, row_end=None, grid=None, ctx=None):
+    """Opt-in fixed-point dense build (include/same_hip.h: same_dense_cost_q32_dev) -> (costs (rows, n_r) f64, T * 2^-s error bound
+    on the type sum).  NOT the reference's arithmetic; `dense_cost` is."""
+    ctx = _ctx(ctx)
+    A, R = as_c(A, F64), as_c(R, F64)
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
+    n_m, n_r = len(axy), len(rxy)
+    row_end = n_m if row_end is None else int(row_end)
+    rows = max(row_end - int(row_begin), 0)
+    T = A.shape[1] if A.ndim == 2 else 0
+    offset, log2_scale = quantize_types(A, R) if grid is None else grid
+    scale = float(2.0 ** log2_scale)
+    out = np.empty((rows, n_r), F64)
+    if rows == 0 or n_r == 0:
+        return out, T / scale
+    ld = (n_r + 3) & ~3
+    with ctx.lock:
+        dA, dR, dax, drx = ctx.to_device(A), ctx.to_device(R), ctx.to_device(axy), ctx.to_device(rxy)
+        dAq, dRq, dout = ctx.alloc(max(A.size, 1) * 4), ctx.alloc(max(R.size, 1) * 4), ctx.alloc(rows * ld * 8)
+        ctx.check(ctx.lib.same_quantize_u32_dev(ctx.handle, dA.ptr, A.size, offset, scale, dAq.ptr), "same_quantize_u32_dev")
+        ctx.check(ctx.lib.same_quantize_u32_dev(ctx.handle, dR.ptr, R.size, offset, scale, dRq.ptr), "same_quantize_u32_dev")
+        ctx.check(ctx.lib.same_dense_cost_q32_dev(ctx.handle, dAq.ptr, dRq.ptr, T, dax.ptr, drx.ptr, n_r, int(row_begin), row_end, float(w),
+                                                  1.0 / scale, dout.ptr, ld), "same_dense_cost_q32_dev")
+        full = dout.download((rows, ld), F64)
+    out[:] = full[:, :n_r]
+    return out, T / scale
+
+
 def knn_prune(axy, rxy, radius, knn, row_begin=0, row_end=None, want_d2=True, ctx=None):
     """-> (idx (rows,k) int32 -1 padded, d2 (rows,k) f64 +inf padded or None, cnt (rows,) int32)."""
     ctx = _ctx(ctx)

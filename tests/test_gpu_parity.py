@@ -859,6 +859,46 @@ def test_fp32_pair_and_padded_costs_vs_oracle(hip, oracle, T, k, n_m, n_r):
         ops.pair_cost(A, R, axy, rxy, bad, 1.0, dtype=np.float32)
 
 
+@pytest.mark.parametrize("T", [0, 1, 3, 8, 19, 20, 32])
+@pytest.mark.parametrize("w", [1.0, 0.37])
+def test_dense_cost_q32_opt_in_build(ops, oracle, T, w):
+    """The opt-in fixed-point dense build (v_sad_u32 on a common 32-bit grid; NOT reference arithmetic, never a default):
+    bit-equal to its oracle twin, and within w * T * 2^-s (+ fp64 rounding) of the reference-exact fp64 build."""
+    from same_amd import synth
+
+    n_m, n_r = 300, 1031   # ragged: not multiples of the tile; 1031 % 4 != 0 exercises the padded pitch
+    r = synth.make_cells(n_r, max(T, 1), seed=40 + T)
+    m = synth.make_cells(n_m, max(T, 1), seed=41 + T, side=r["side"])
+    A, R = m["types"][:, :T], r["types"][:, :T]
+    grid = ops.quantize_types(A, R)
+    got, bound = ops.dense_cost_q32(A, R, m["xy"], r["xy"], w, 7, 290, grid=grid)
+    want = oracle.dense_cost_q32(A, R, m["xy"], r["xy"], w, grid[0], grid[1], 7, 290)
+    assert np.array_equal(got, want)
+    exact = oracle.dense_cost(A, R, m["xy"], r["xy"], w, 7, 290)
+    assert bound == T * 2.0 ** -grid[1] and (T == 0 or grid[1] >= 22)            # rows on the 0-100 scale: 2^-24 steps
+    assert np.max(np.abs(got - exact)) <= w * bound + 1e-12 * np.max(exact)
+    if T == 20:
+        assert np.max(np.abs(got - exact) / exact) < 1e-7
+    # values far off the probability scale still get a grid that cannot overflow 32 bits
+    big = ops.quantize_types(A * 1e6 - 5e5, R * 1e6 - 5e5)
+    got2, bound2 = ops.dense_cost_q32(A * 1e6 - 5e5, R * 1e6 - 5e5, m["xy"], r["xy"], w, 0, 50, grid=big)
+    exact2 = oracle.dense_cost(A * 1e6 - 5e5, R * 1e6 - 5e5, m["xy"], r["xy"], w, 0, 50)
+    assert np.max(np.abs(got2 - exact2)) <= w * bound2 + 1e-12 * np.max(np.abs(exact2)) + 1e-9
+
+
+def test_dense_cost_q32_limits(ops):
+    from same_amd import _lib
+
+    ctx = _lib.default_context()
+    z = ctx.alloc(4096)
+    L, H = ctx.lib, ctx.handle
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, 33, z.ptr, z.ptr, 4, 0, 1, 1.0, 1.0, z.ptr, 4) == -22    # T > SAME_Q32_MAX_TYPES
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, 4, z.ptr, z.ptr, 5, 0, 1, 1.0, 1.0, z.ptr, 6) == -22     # pitch not a multiple of 4
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, 4, z.ptr, z.ptr, 4, 0, 1, 1.0, 0.0, z.ptr, 4) == -22     # inv_scale must be > 0
+    with pytest.raises(ValueError):
+        ops.quantize_types(np.array([[np.nan, 1.0]]), np.ones((2, 2)))
+
+
 def test_dense_cost_f32_dev_entry_point(hip, oracle):
     """same_dense_cost_f32_dev (resident operands, cfg-5 fp32 variant): equals the host-buffer form and the oracle's fp32 build."""
     from same_amd import _lib, ops

@@ -11,7 +11,7 @@ n_r = rows = 100_000; T = 20; k = 32
 Tr = int(line["config"]["workload"].split(" Delaunay")[0].split("+ ")[-1])
 bytes_of = {
     "dense_cost_kernel": 8 * n_r * rows + 8 * (T + 2) * (n_r + rows),
-    "knn_grid_kernel": 16 * n_r * 3 + 16 * rows + 4 * k * rows + 4 * rows,
+    "knn_grid_kernel": 16 * n_r * 3 + 16 * rows + 4 * k * rows + 4 * rows, "first_candidate_kernel": 4 * rows * k // 8 + 4 * rows,
     "padded_cost_kernel": rows * k * (2 * 8 * (T + 2) + 4 + 8), "padded_cost_lds_kernel": rows * k * (2 * 8 * (T + 2) + 4 + 8),
     "bbox_kernel": 16 * n_r, "grid_count_kernel": 16 * n_r + 8 * n_r, "grid_scatter_kernel": 16 * n_r + 28 * n_r,
     "grid_scan_kernel": 8 * 16641,
