@@ -86,8 +86,8 @@ int same_pair_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t 
                        int T, const double *axy, const double *rxy, const int32_t *pairs,
                        int64_t P, double w, double *out_c);
 /* fp32 variant (BASELINE.json config 5: "fp32 cost"): the same expression evaluated in float, operands given as
- * float -- element (i, j) of same_dense_cost_f32.  The reference has no fp32 path; the oracle twin is
- * orc_pair_cost_f32 and the check is bit-equality with it plus a relative bound against the fp64 costs. */
+ * float -- element (i, j) of same_dense_cost_f32.  The reference has no fp32 path; the check is bit-equality
+ * with the test oracle's float twin plus a forward error bound against the fp64 costs. */
 int same_pair_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_m, int64_t n_r,
                        int T, const float *axy, const float *rxy, const int32_t *pairs,
                        int64_t P, float w, float *out_c);
@@ -116,17 +116,22 @@ int same_dense_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n
  * fixed-point grid q(v) = rint((v - offset) * scale), the type sum becomes an exact integer sum of
  * absolute differences (one v_sad_u32 per element instead of two fp64 adds), the rest of the expression
  * is unchanged fp64:  out = w * (double(S_q) * inv_scale) + (w*0.001) * (|ax-rx| + |ay-ry|).
- * Error against same_dense_cost_f64_dev: |S_q * inv_scale - S| <= T * inv_scale (plus fp64 rounding).  The caller
- * chooses offset / scale so that every row-pair sum fits 32 bits (same_amd.ops.quantize_types); the row
- * pitch ld must be a multiple of 4 doubles and columns [n_r, ld) are written too (padding owned by the
- * caller).  T <= SAME_Q32_MAX_TYPES.  Meant for the dense matrix of the Hungarian MIP-start heuristic
- * (src/init_helpers.py:151-155) and as the roofline control of DESIGN.md 5.1. */
+ * Against same_dense_cost_f64_dev: |S_q * inv_scale - S| <= T * inv_scale.  With rel_tol > 0 every type
+ * sum of fewer than T / rel_tol + T grid steps (near-identical cells) is recomputed from the fp64
+ * matrices dA / dR with the reference's own expression, so EVERY output is within rel_tol (relative) of
+ * the fp64 build's -- rel_tol = 1e-6 is BASELINE.json's tolerance for fp64 costs; rel_tol = 0 keeps the
+ * pure grid result (dA / dR may then be NULL).  The caller chooses offset / scale so that every
+ * row-pair sum fits 32 bits (same_amd.ops.quantize_types); the row pitch ld must be even and columns
+ * [n_r, ld) are written too (padding owned by the caller).  T <= SAME_Q32_MAX_TYPES.  Meant for the
+ * dense matrix of the Hungarian MIP-start heuristic (src/init_helpers.py:151-155) and as the roofline
+ * control of DESIGN.md 5.1 (the same 80 GB of stores without the fp64 adds). */
 #define SAME_Q32_MAX_TYPES 32
 int same_quantize_u32_dev(same_ctx *ctx, const double *dsrc, int64_t n, double offset, double scale,
                           uint32_t *ddst);
-int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, int T,
-                            const double *daxy, const double *drxy, int64_t n_r, int64_t row_begin,
-                            int64_t row_end, double w, double inv_scale, double *dout, int64_t ld);
+int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, const double *dA,
+                            const double *dR, int T, const double *daxy, const double *drxy, int64_t n_r,
+                            int64_t row_begin, int64_t row_end, double w, double inv_scale,
+                            double rel_tol, double *dout, int64_t ld);
 
 /* ---- a2: KNN prune within a radius ----------------------------------------------------
  * Replaces the per-row body of utils.find_knn_within_radius (src/utils.py:720-728):

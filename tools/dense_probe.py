@@ -29,7 +29,8 @@ for T in Ts:
     for it in range(6):
         ctx.check(L.same_timer_start(H), "t")
         if q32:
-            ctx.check(L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, 2.0 ** -l2, dD.ptr, ld), "dense q32")
+            ctx.check(L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, 2.0 ** -l2,
+                                                float(os.environ.get("PROBE_REL_TOL", "1e-6")), dD.ptr, ld), "dense q32")
         else:
             ctx.check(fn(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, dD.ptr, ld), "dense")
         ms = ctypes.c_float(0); ctx.check(L.same_timer_stop(H, ctypes.byref(ms)), "t"); ms_all.append(ms.value)
