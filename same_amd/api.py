@@ -16,6 +16,7 @@ import numpy as np
 import pandas as pd
 
 from . import ops, sweeps, varout
+from ._trace import stage
 from ._rows import rows_array, values_array
 from .cost import pair_costs
 from .init_helpers import apply_mip_start
@@ -153,10 +154,11 @@ def _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay
         aligned_df["__tri_vid"] = aligned_df[aligned_delaunay_vertex_col].to_numpy()
 
     # KNN prune (src/same.py:972-979)
-    if optim_params["ignore_knn_if_matched"]:
-        aligned_df, ref_df, valid_pairs = find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
-    else:
-        aligned_df, ref_df, valid_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+    with stage("prune+compact"):
+        if optim_params["ignore_knn_if_matched"]:
+            aligned_df, ref_df, valid_pairs = find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+        else:
+            aligned_df, ref_df, valid_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
     st.aligned_df, st.ref_df, st.valid_pairs = aligned_df, ref_df, valid_pairs
     if len(valid_pairs) == 0:
         raise ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
@@ -192,25 +194,27 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
 
     aligned_coords_array = aligned_df[["X", "Y"]].values
     using_precomputed = st.caller_triangles is not None
-    if using_precomputed:
-        aligned_delaunay = _remap_triangles_by_vertex_ids(st.caller_triangles, vertex_ids=aligned_df["__tri_vid"].to_numpy())
-    elif st.ticket is not None:
-        aligned_delaunay = st.ticket.result()
-    else:
-        aligned_delaunay = Delaunay(aligned_coords_array).simplices
+    with stage("triangulate (qhull / remap / wait for helper)"):
+        if using_precomputed:
+            aligned_delaunay = _remap_triangles_by_vertex_ids(st.caller_triangles, vertex_ids=aligned_df["__tri_vid"].to_numpy())
+        elif st.ticket is not None:
+            aligned_delaunay = st.ticket.result()
+        else:
+            aligned_delaunay = Delaunay(aligned_coords_array).simplices
 
     # filter (src/same.py:1033-1053)
     unconstrained_nodes = set()
-    if using_precomputed:
-        aligned_delaunay, unconstrained_nodes = filter_triangles_by_radius(
-            aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
-            ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], remove_unconstrained_nodes=True,
-            min_angle_deg=min_angle_deg, verbose=verbose, ctx=ctx)
-    else:
-        aligned_delaunay = filter_triangles_by_radius(
-            aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
-            ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], min_angle_deg=min_angle_deg,
-            verbose=verbose, ctx=ctx)
+    with stage("triangle filter"):
+        if using_precomputed:
+            aligned_delaunay, unconstrained_nodes = filter_triangles_by_radius(
+                aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
+                ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], remove_unconstrained_nodes=True,
+                min_angle_deg=min_angle_deg, verbose=verbose, ctx=ctx)
+        else:
+            aligned_delaunay = filter_triangles_by_radius(
+                aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
+                ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], min_angle_deg=min_angle_deg,
+                verbose=verbose, ctx=ctx)
 
     # unconstrained-node removal + re-index (src/same.py:1055-1085)
     if unconstrained_nodes:
@@ -228,12 +232,14 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
         aligned_delaunay = old_to_new[tri] if len(tri) else np.array([]).reshape(0, 3)
         aligned_df = aligned_df.iloc[constrained_nodes].reset_index(drop=True)
 
-    triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx)
+    with stage("triangle weights + source signs"):
+        triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx)
     # build-only key (not among init_optim_params' defaults, which stay the reference's): fp32 pair costs, BASELINE config 5
     cost_dtype = np.dtype(optim_params.get("hip_cost_dtype", "float64"))
     if cost_dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
         raise ValueError(f"hip_cost_dtype must be 'float64' or 'float32', got {optim_params['hip_cost_dtype']!r}")
-    costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx, dtype=cost_dtype)
+    with stage("pair costs"):
+        costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx, dtype=cost_dtype)
     return PreparedInputs(aligned_df, ref_df, valid_pairs, costs, aligned_delaunay, triangle_weights, source_signs,
                           unconstrained_nodes, using_precomputed, optim_params, gurobi_params)
 
@@ -363,11 +369,12 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
             + op["no_match_penalty"] * quicksum(sizes[i] * no_match_vars[i] for i in range(n_aligned))
             + op["delaunay_penalty"] * quicksum(prep.triangle_weights[idx] * v for idx, v in enumerate(area_penalty_vars)),
             GRB.MINIMIZE)
-        apply_mip_start(x_vars=x, no_match_vars=no_match_vars, valid_pairs=valid_pairs, costs=c, n_aligned=n_aligned,
-                        n_ref=n_ref, aligned_sizes=aligned_df["size"].to_numpy(dtype=float),
-                        no_match_penalty=op["no_match_penalty"], max_matches=op["max_matches"],
-                        init_method=gpar["init_method"], init_big_m=gpar["init_big_m"],
-                        init_hungarian_max_n=gpar["init_hungarian_max_n"], verbose=True)
+        with stage("MIP start"):
+            apply_mip_start(x_vars=x, no_match_vars=no_match_vars, valid_pairs=valid_pairs, costs=c, n_aligned=n_aligned,
+                            n_ref=n_ref, aligned_sizes=aligned_df["size"].to_numpy(dtype=float),
+                            no_match_penalty=op["no_match_penalty"], max_matches=op["max_matches"],
+                            init_method=gpar["init_method"], init_big_m=gpar["init_big_m"],
+                            init_hungarian_max_n=gpar["init_hungarian_max_n"], verbose=True)
 
         if outprefix:
             os.makedirs(outprefix, exist_ok=True)
@@ -384,18 +391,20 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
         if gpar["heuristics"] is not None:
             model.Params.Heuristics = float(gpar["heuristics"])
 
-        if lazy:
-            sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.source_signs, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
-            model.optimize(make_lazy_callback(GRB, sweep))
-            print(f"Lazy cuts added: {model._cuts_added}")
-        else:
-            model.optimize()
+        with stage("solve (incl. lazy sweeps)"):
+            if lazy:
+                sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.source_signs, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
+                model.optimize(make_lazy_callback(GRB, sweep))
+                print(f"Lazy cuts added: {model._cuts_added}")
+            else:
+                model.optimize()
         time_limit_reached = model.status == GRB.TIME_LIMIT
         solve_time = model.Runtime
 
         if model.status == GRB.OPTIMAL or model.status == GRB.TIME_LIMIT:
-            out_df, var_out = _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_vars, model,
-                                          cell_id_col, time_limit_reached, solve_time, outprefix)
+            with stage("post-solve sweeps + tables"):
+                out_df, var_out = _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_vars, model,
+                                              cell_id_col, time_limit_reached, solve_time, outprefix)
         else:
             print("No optimal solution found")
             out_df, var_out = pd.DataFrame(), {}

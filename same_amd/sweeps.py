@@ -12,6 +12,7 @@ import numpy as np
 
 from . import ops
 from ._rows import rows_array, values_array
+from ._trace import stage
 
 _EDGES = ((0, 1), (0, 2), (1, 2))
 
@@ -26,7 +27,8 @@ class LazyOrientationSweep:
 
     def sweep(self, x_vals):
         """-> (checked, violating_tris [(tri_idx, a, b, c)] ascending, match_pair_idx array)."""
-        checked, viol, _match, pidx = self.bound.sweep_x(np.asarray(x_vals, dtype=np.float64))
+        with stage("lazy orientation sweep"):
+            checked, viol, _match, pidx = self.bound.sweep_x(np.asarray(x_vals, dtype=np.float64))
         t = self.tris
         violating = [(int(i), t[i][0], t[i][1], t[i][2]) for i in viol]
         return checked, violating, pidx

@@ -225,3 +225,28 @@ def test_no_name_is_read_without_being_bound():
     files = sorted(glob.glob(os.path.join(ROOT, "same_amd", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "undefined_names.py")] + files, capture_output=True, text=True)
     assert p.returncode == 0, p.stdout
+
+
+def test_stage_markers_are_inert_unless_asked_for(monkeypatch):
+    """same_amd._trace: no bookkeeping by default; with tracing on, wall time per stage accumulates (and rocTX ranges are emitted
+    when the library is there -- it loads without a GPU)."""
+    from same_amd import _trace
+
+    _trace.reset()
+    _trace.enable(False)
+    with _trace.stage("a"):
+        pass
+    assert _trace.report() == {}
+    _trace.enable(True)
+    try:
+        for _ in range(3):
+            with _trace.stage("a"):
+                pass
+        with pytest.raises(RuntimeError):
+            with _trace.stage("b"):
+                raise RuntimeError("x")
+        rep = _trace.report()
+        assert rep["a"][0] == 3 and rep["b"][0] == 1 and rep["a"][1] >= 0.0
+    finally:
+        _trace.enable(False)
+        _trace.reset()
