@@ -482,6 +482,30 @@ def run_rank(args):
     # host; its outputs double as a parity check of what the GPU just produced (the only place bench.py touches oracle/) ----
     cpu = None
     parity = "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
+    # ---- N > 1: did the exchange deliver the right rows to the right place?  Rank 0 recomputes the first rows of the LAST
+    # rank's block on its own GPU (weak mode: from that rank's seed) and compares them with what the gather put into its
+    # own copy of the gathered lists, bit for bit.  (A transport check; the arithmetic itself is checked at N=1.)
+    if comm is not None and group.rank == 0 and not args.dry_launch:
+        tctx.sync()
+        peer = group.world - 1
+        S = min(2000, block)
+        if strong:
+            peer_mov, p0 = mov, peer * block
+            S = max(0, min(S, n_mov - p0))
+        else:
+            peer_mov, p0 = synth.make_cells(rows_cfg, T, seed=1 + peer, side=ref["side"]), 0
+        if S > 0:
+            pA, pxy = tctx.to_device(peer_mov["types"]), tctx.to_device(peer_mov["xy"])
+            pidx, pcost, pcnt = tctx.alloc(S * k * 4), tctx.alloc(S * k * 8), tctx.alloc(S * 4)
+            chk(L.same_knn_prune_indexed_dev(TH, knn_index, pxy.ptr, p0, p0 + S, k, pidx.ptr, None, pcnt.ptr), "knn")
+            chk(L.same_padded_cost_f64_dev(TH, pA.ptr, dR.ptr, T, pxy.ptr, drx.ptr, p0, p0 + S, k, pidx.ptr, 1.0, pcost.ptr), "padded")
+            want_i, want_c = pidx.download((S, k), np.int32), pcost.download((S, k), np.float64)
+            got_i = gidx.download((S, k), np.int32, offset_bytes=peer * block * k * 4)
+            got_c = gcost.download((S, k), np.float64, offset_bytes=peer * block * k * 8)
+            if not (np.array_equal(got_i, want_i) and np.array_equal(got_c, want_c)):
+                raise SystemExit(f"gathered candidate lists of rank {peer} differ from a local recomputation: refusing to report a number")
+            parity = (f"transport: rows [0,{S}) of rank {peer}'s block in rank 0's gathered lists (idx + cost) equal a local recomputation "
+                      "bit for bit; arithmetic parity is the N=1 run's check")
     if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
         from oracle import same_oracle as orc
 
