@@ -93,7 +93,11 @@ class HostGroup:
         self._dir = rdv_dir or default_rdv_dir()
         hub_file = os.path.join(self._dir, "hub.json")
         if self.rank == 0:
-            os.makedirs(self._dir, exist_ok=True)
+            os.makedirs(self._dir, mode=0o700, exist_ok=True)
+            try:
+                os.chmod(self._dir, 0o700)       # the token below is this job's only credential: keep it to this user
+            except OSError:
+                pass
             token = secrets.token_hex(16)
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.bind(("127.0.0.1", 0))
@@ -101,7 +105,7 @@ class HostGroup:
             ls.settimeout(self.timeout)
             self._listener = ls
             tmp = hub_file + f".{os.getpid()}.tmp"
-            with open(tmp, "w") as f:
+            with os.fdopen(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600), "w") as f:
                 json.dump({"port": ls.getsockname()[1], "token": token, "world": self.world}, f)
             os.replace(tmp, hub_file)  # atomic: readers see nothing or the whole file
             while len(self._peers) < self.world - 1:
@@ -178,7 +182,8 @@ class HostGroup:
         return np.concatenate(parts, axis=0)
 
     def allgather_object(self, obj):
-        """Small host objects between this job's own ranks (pickle over the authenticated loopback connections)."""
+        """Small host objects between this job's own ranks (pickle; the connections are loopback-only and were admitted
+        with the job's token, which sits in a 0600 file of a 0700 directory: only this user's own ranks can be on them)."""
         return [pickle.loads(p) for p in self.allgather_bytes(pickle.dumps(obj, protocol=4))]
 
     def close(self):
