@@ -287,11 +287,18 @@ def test_bench_contract_line(force_comm):
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     if force_comm:
-        assert out["cpu_baseline"] is None and "not checked" in out["parity_spot_check"]
+        assert out["cpu_baseline"] is None and out["parity_spot_check"].startswith("transport: rows [0,2000) of rank 0's block")
+        assert "RCCL" in out["config"]["parallelism"]
     else:
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
         assert "equal the oracle bit-for-bit" in out["parity_spot_check"]
+        # live ceilings, telemetry and the T sweep of this very run (incl. the labelled fixed-point control)
+        assert rf["measured_ceilings"]["same_kernel_T0_store_only_GBs"] > 0 and "telemetry" in rf
+        kinds = [(e["dtype"], e["T"]) for e in rf["sweep"]]
+        assert ("f64", 3) in kinds and ("f32", 20) in kinds and ("q32->f64", 20) in kinds
+        q = [e for e in rf["sweep"] if e["dtype"] == "q32->f64"][0]
+        assert q["opt_in"] is True and q["max_rel_diff_vs_exact_on_16_rows"] <= 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------
