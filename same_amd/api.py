@@ -17,7 +17,7 @@ import pandas as pd
 
 from . import ops, sweeps, varout
 from ._trace import stage
-from ._rows import rows_array, values_array
+from ._rows import RowList, ValueList, rows_array, values_array
 from .cost import pair_costs
 from .init_helpers import apply_mip_start
 from .knn import find_knn_with_cell_type_priority, find_knn_within_radius
@@ -41,16 +41,41 @@ class PreparedInputs:
     pipeline that only wants pairs, costs and sweeps never pays for them."""
 
     def __init__(self, aligned_df, ref_df, valid_pairs, costs, aligned_delaunay, triangle_weights, source_signs,
-                 unconstrained_nodes, using_precomputed, optim_params, gurobi_params):
+                 unconstrained_nodes, using_precomputed, optim_params, gurobi_params, triangles_as_list=True):
         self.aligned_df, self.ref_df = aligned_df, ref_df
         self.valid_pairs = valid_pairs          # (P,2) ndarray, or list of tuples after unconstrained-node removal
-        self.costs = costs                      # c[idx], same order as valid_pairs
-        self.aligned_delaunay = aligned_delaunay  # list / array of 3-int rows; index = q_tri id
-        self.triangle_weights, self.source_signs = triangle_weights, source_signs
+        # the list-shaped artefacts are kept as the arrays the kernels produced; the lists the reference hands to the
+        # solver (c, aligned_delaunay, triangle_weights, source_signs) are made on first access
+        self.costs_array = np.asarray(costs, dtype=np.float64)        # c[idx], same order as valid_pairs
+        self.triangles_array = rows_array(aligned_delaunay)           # (Tr, 3); row index = q_tri id
+        self.weights_array, self.signs_array = np.asarray(triangle_weights), np.asarray(source_signs, dtype=np.float64)
+        self._triangles_as_list = triangles_as_list
         self.unconstrained_nodes, self.using_precomputed = unconstrained_nodes, using_precomputed
         self.n_aligned, self.n_ref = len(aligned_df), len(ref_df)
         self.optim_params, self.gurobi_params = optim_params, gurobi_params
         self._cache = {}
+
+    def _listed(self, key, make):
+        if key not in self._cache:
+            self._cache[key] = make()
+        return self._cache[key]
+
+    @property
+    def costs(self):
+        return self._listed("costs", lambda: ValueList(self.costs_array))
+
+    @property
+    def aligned_delaunay(self):          # list of 3-int rows (an array after unconstrained-node removal, as in the reference flow)
+        return self._listed("tris", lambda: (RowList(self.triangles_array) if len(self.triangles_array) else [])
+                            if self._triangles_as_list else self.triangles_array)
+
+    @property
+    def triangle_weights(self):
+        return self._listed("weights", lambda: ValueList(self.weights_array))
+
+    @property
+    def source_signs(self):
+        return self._listed("signs", lambda: ValueList(self.signs_array))
 
     def _maps(self):
         if "maps" not in self._cache:
@@ -209,15 +234,17 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
             aligned_delaunay, unconstrained_nodes = filter_triangles_by_radius(
                 aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
                 ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], remove_unconstrained_nodes=True,
-                min_angle_deg=min_angle_deg, verbose=verbose, ctx=ctx)
+                min_angle_deg=min_angle_deg, verbose=verbose, ctx=ctx, _rows_as_array=True)
         else:
             aligned_delaunay = filter_triangles_by_radius(
                 aligned_coords_array, aligned_delaunay, radius, aligned_df=aligned_df,
                 ignore_same_type_triangles=optim_params["ignore_same_type_triangles"], min_angle_deg=min_angle_deg,
-                verbose=verbose, ctx=ctx)
+                verbose=verbose, ctx=ctx, _rows_as_array=True)
 
     # unconstrained-node removal + re-index (src/same.py:1055-1085)
+    triangles_as_list = True
     if unconstrained_nodes:
+        triangles_as_list = False
         _say(verbose, f"\nRemoving {len(unconstrained_nodes)} unconstrained nodes from optimization...")
         vp = np.asarray(valid_pairs, dtype=np.int64).reshape(-1, 2)
         keep_node = np.ones(len(aligned_df), bool)
@@ -233,15 +260,15 @@ def prepare_same_inputs(ref_df, aligned_df, commonCT, aligned_delaunay=None, ali
         aligned_df = aligned_df.iloc[constrained_nodes].reset_index(drop=True)
 
     with stage("triangle weights + source signs"):
-        triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx)
+        triangle_weights, source_signs = triangle_weights_and_signs(aligned_df, aligned_delaunay, ctx=ctx, _as_arrays=True)
     # build-only key (not among init_optim_params' defaults, which stay the reference's): fp32 pair costs, BASELINE config 5
     cost_dtype = np.dtype(optim_params.get("hip_cost_dtype", "float64"))
     if cost_dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
         raise ValueError(f"hip_cost_dtype must be 'float64' or 'float32', got {optim_params['hip_cost_dtype']!r}")
     with stage("pair costs"):
-        costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx, dtype=cost_dtype)
+        costs = pair_costs(aligned_df, ref_df, valid_pairs, list(commonCT), dist_ct_coeff, ctx=ctx, dtype=cost_dtype, _as_array=True)
     return PreparedInputs(aligned_df, ref_df, valid_pairs, costs, aligned_delaunay, triangle_weights, source_signs,
-                          unconstrained_nodes, using_precomputed, optim_params, gurobi_params)
+                          unconstrained_nodes, using_precomputed, optim_params, gurobi_params, triangles_as_list=triangles_as_list)
 
 
 # ------------------------------------------------------------------------------------------ callback
@@ -331,7 +358,7 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
                 out_df.to_csv(os.path.join(outprefix, "matches_df.csv"), index=False)
             return out_df, {}
         aligned_df, ref_df = prep.aligned_df, prep.ref_df
-        valid_pairs, c, tris = prep.valid_pairs, prep.costs, prep.aligned_delaunay
+        valid_pairs, c, tris = prep.valid_pairs, prep.costs_array, prep.triangles_array   # same values as the reference's lists
         n_aligned, n_ref = prep.n_aligned, prep.n_ref
         lazy = op["lazy_constraints"]
         cell_id_col = op["cell_id_col"]
@@ -348,7 +375,7 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
             q_tri = model.addVars(len(tris), vtype=GRB.CONTINUOUS, lb=0, name="q_tri")
             model.update()
             model._x, model._q_tri, model._valid_pairs = x, q_tri, valid_pairs
-            model._aligned_delaunay, model._source_signs, model._ref_coords = tris, prep.source_signs, prep.ref_coords_xy
+            model._aligned_delaunay, model._source_signs, model._ref_coords = tris, prep.signs_array, prep.ref_coords_xy
             model._cuts_added = 0
             model._lazy_max_cuts = gpar["lazy_max_cuts"]
             model._lazy_allowed_flip_fraction = gpar["lazy_allowed_flip_fraction"]
@@ -367,7 +394,7 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
             quicksum(c[idx] * x[idx] for idx in range(len(valid_pairs)))
             + op["penalty_coeff"] * quicksum(penalty_vars[j] for j in range(n_ref))
             + op["no_match_penalty"] * quicksum(sizes[i] * no_match_vars[i] for i in range(n_aligned))
-            + op["delaunay_penalty"] * quicksum(prep.triangle_weights[idx] * v for idx, v in enumerate(area_penalty_vars)),
+            + op["delaunay_penalty"] * quicksum(prep.weights_array[idx] * v for idx, v in enumerate(area_penalty_vars)),
             GRB.MINIMIZE)
         with stage("MIP start"):
             apply_mip_start(x_vars=x, no_match_vars=no_match_vars, valid_pairs=valid_pairs, costs=c, n_aligned=n_aligned,
@@ -393,7 +420,7 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
 
         with stage("solve (incl. lazy sweeps)"):
             if lazy:
-                sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.source_signs, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
+                sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.signs_array, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
                 model.optimize(make_lazy_callback(GRB, sweep))
                 print(f"Lazy cuts added: {model._cuts_added}")
             else:
@@ -454,7 +481,7 @@ def _add_spatial_constraints_eager(model, GRB, x, prep):
     `same_eager_signs` launch instead of the reference's process pool.  Building the Python constraint objects stays a
     host loop -- that is the solver's API."""
     pairs = np.asarray(prep.valid_pairs, dtype=np.int64).reshape(-1, 2)
-    tris = rows_array(prep.aligned_delaunay, dtype=np.int64)
+    tris = np.asarray(prep.triangles_array, dtype=np.int64)
     n_aligned = prep.n_aligned
     order = np.argsort(pairs[:, 0], kind="stable")          # valid_pairs_imap: pair indices per aligned row, in pair order
     counts = np.bincount(pairs[:, 0], minlength=n_aligned)

@@ -116,8 +116,10 @@ def classify_triangles(points, triangles, radius, min_angle_deg, type_id=None, c
 
 def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignore_same_type_triangles=False,
                                ensure_min_triangle_per_node=True, remove_unconstrained_nodes=False,
-                               min_angle_deg=15, verbose=True, ctx=None):
-    """Same signature and return shapes as src/helpers.py:233-395."""
+                               min_angle_deg=15, verbose=True, ctx=None, _rows_as_array=False):
+    """Same signature and return shapes as src/helpers.py:233-395 (a list of kept triangle rows [+ set]).
+    `_rows_as_array` (package-internal): hand back the (n, 3) array the list would be made of, so a caller that only
+    feeds it to kernels does not pay for 10^5 little row objects."""
     points = np.asarray(points)
     tris = rows_array(triangles)
     use_type = bool(ignore_same_type_triangles and aligned_df is not None)
@@ -173,21 +175,27 @@ def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignor
                 print(f"Added back {added} same-type triangles to ensure >=1 triangle per node")
                 print(f"Final triangles kept: {len(order)}")
 
-    filtered = RowList(tris[np.asarray(order, dtype=np.int64)]) if order else []   # a list of triangle rows, as the reference returns
+    if _rows_as_array:
+        filtered = tris[np.asarray(order, dtype=np.int64)] if order else np.zeros((0, 3), dtype=tris.dtype)
+    else:
+        filtered = RowList(tris[np.asarray(order, dtype=np.int64)]) if order else []   # a list of triangle rows, as the reference returns
     if remove_unconstrained_nodes:
         return filtered, set(np.flatnonzero(~any_valid).tolist())
     return filtered
 
 
 # ----------------------------------------------------------------------------- a8
-def triangle_weights_and_signs(aligned_df, triangles, ctx=None):
-    """-> (list of weights, list of np.float64 signs) as run_same builds them (src/same.py:1128-1146)."""
+def triangle_weights_and_signs(aligned_df, triangles, ctx=None, _as_arrays=False):
+    """-> (list of weights, list of np.float64 signs) as run_same builds them (src/same.py:1128-1146);
+    `_as_arrays` (package-internal): the two arrays instead."""
     xy = aligned_df[["X", "Y"]].to_numpy(dtype=np.float64)
     size = aligned_df["size"].to_numpy(dtype=np.float64)
     sign, weight = ops.tri_sign_weight(xy, size, rows_array(triangles), ctx=ctx)
     size_dtype = aligned_df["size"].dtype
     if np.issubdtype(size_dtype, np.integer):
         weight = weight.astype(np.int64)  # integer size columns sum to integers in the reference
+    if _as_arrays:
+        return weight, sign.astype(np.float64)
     return ValueList(weight), ValueList(sign.astype(np.float64))
 
 

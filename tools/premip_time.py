@@ -18,6 +18,6 @@ _trace.reset()
 t = time.perf_counter()
 prep = same_amd.prepare_same_inputs(r_df, m_df, cols, optim_params=op, verbose=False)
 dt = time.perf_counter() - t
-print(f"n={n}: prepare_same_inputs {dt:.3f} s  pairs={len(prep.valid_pairs)} triangles={len(prep.aligned_delaunay)}")
+print(f"n={n}: prepare_same_inputs {dt:.3f} s  pairs={len(prep.valid_pairs)} triangles={len(prep.triangles_array)}")
 for name, (calls, sec) in sorted(_trace.report().items(), key=lambda kv: -kv[1][1]):
     print(f"  {name:48s} {sec * 1e3:9.2f} ms  ({100 * sec / dt:4.1f} %)")

@@ -32,14 +32,14 @@ def main():
     picked = plan[:: max(1, len(plan) // max_windows)][:max_windows]
 
     def consume(prep):
-        ch, un = same_amd.compute_mip_start_pairs(valid_pairs=prep.valid_pairs, costs=prep.costs, n_aligned=prep.n_aligned, n_ref=prep.n_ref,
+        ch, un = same_amd.compute_mip_start_pairs(valid_pairs=prep.valid_pairs, costs=prep.costs_array, n_aligned=prep.n_aligned, n_ref=prep.n_ref,
                                                   aligned_sizes=prep.aligned_df["size"].to_numpy(dtype=float), no_match_penalty=100,
                                                   max_matches=1, init_method="greedy", verbose=False)
         x = np.zeros(len(prep.valid_pairs)); x[[c[2] for c in ch]] = 1.0
-        sw = same_amd.LazyOrientationSweep(prep.valid_pairs, prep.aligned_delaunay, prep.source_signs, prep.ref_df[["X", "Y"]].to_numpy(), prep.n_aligned)
+        sw = same_amd.LazyOrientationSweep(prep.valid_pairs, prep.triangles_array, prep.signs_array, prep.ref_df[["X", "Y"]].to_numpy(), prep.n_aligned)
         checked, viol, _ = sw.sweep(x)
         sw.bound.close()
-        return prep.n_aligned, len(prep.valid_pairs), len(prep.aligned_delaunay), checked, len(viol)
+        return prep.n_aligned, len(prep.valid_pairs), len(prep.triangles_array), checked, len(viol)
 
     def serial():
         out = []
