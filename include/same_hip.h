@@ -354,6 +354,9 @@ int same_comm_wait(same_ctx *ctx);
 #define SAME_OP_MAX 1
 #define SAME_OP_MIN 2
 int same_allreduce_dev(same_ctx *ctx, void *dbuf, size_t count, int dtype, int op);
+/* collectives issued between these two calls go to RCCL as one group (ncclGroupStart / ncclGroupEnd): one fused launch */
+int same_comm_group_start(same_ctx *ctx);
+int same_comm_group_end(same_ctx *ctx);
 /* communicator size (0 = none), this rank, and the RCCL version the library is running against */
 int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version);
 

@@ -95,6 +95,8 @@ _PROTOTYPES = {
     "same_allgather_dev_async": [c_vp, c_vp, c_vp, c_sz],
     "same_comm_wait": [c_vp],
     "same_allreduce_dev": [c_vp, c_vp, c_sz, c_int, c_int],
+    "same_comm_group_start": [c_vp],
+    "same_comm_group_end": [c_vp],
     "same_comm_info": [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
 }
 EXPORTS = tuple(_PROTOTYPES)

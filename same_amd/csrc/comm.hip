@@ -103,6 +103,20 @@ int same_allreduce_dev(same_ctx *ctx, void *dbuf, size_t count, int dtype, int o
     return SAME_OK;
 }
 
+// Several collectives issued between these two calls are handed to RCCL as one group (one fused launch instead of one
+// launch per array): the seven per-triangle arrays of the sharded sweeps travel this way.
+int same_comm_group_start(same_ctx *ctx) {
+    REQUIRE(ctx, ctx && ctx->comm);
+    NCCL_TRY(ctx, ncclGroupStart());
+    return SAME_OK;
+}
+
+int same_comm_group_end(same_ctx *ctx) {
+    REQUIRE(ctx, ctx && ctx->comm);
+    NCCL_TRY(ctx, ncclGroupEnd());
+    return SAME_OK;
+}
+
 int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version) {
     REQUIRE(ctx, ctx != nullptr);
     if (out_nranks) *out_nranks = ctx->comm ? ctx->nranks : 0;

@@ -80,8 +80,32 @@ class RcclGroup:
         """Order the compute stream after every gather issued so far (stream-side; the host does not block)."""
         self.ctx.check(self.ctx.lib.same_comm_wait(self.ctx.handle), "same_comm_wait")
 
+    def group(self):
+        """`with comm.group():` -- the collectives issued inside go to RCCL as one group (one fused launch)."""
+        return _RcclGroupScope(self.ctx)
+
     def close(self):
         self.ctx.lib.same_comm_destroy(self.ctx.handle)
+
+
+class _RcclGroupScope:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.ctx.check(self.ctx.lib.same_comm_group_start(self.ctx.handle), "same_comm_group_start")
+
+    def __exit__(self, *exc):
+        self.ctx.check(self.ctx.lib.same_comm_group_end(self.ctx.handle), "same_comm_group_end")
+        return False
+
+
+class _NoGroup:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 RcclGather = RcclGroup  # round-1 name
@@ -258,12 +282,15 @@ class ShardedSweeps:
                                  self.before_l.ptr + 8 * off, self.after_l.ptr + 8 * off, self.m3_l.ptr + 3 * off,
                                  self.flip_l.ptr + off), "area_flip")
         g = self.comm
-        for loc, glob, width in ((self.flag_l, self.flag_g, 1), (self.edge_l, self.edge_g, 3), (self.tflag_l, self.tflag_g, 1),
-                                 (self.m3_l, self.m3_g, 3), (self.flip_l, self.flip_g, 1), (self.before_l, self.before_g, 8),
-                                 (self.after_l, self.after_g, 8)):
-            g.allgather_dev(loc, glob, B * width, send_offset=off * width)
-        g.allreduce_dev(self.counts, 3, _lib.DT_U64, _lib.OP_SUM)
-        g.allreduce_dev(self.pflag, self.n_m, _lib.DT_U8, _lib.OP_MAX)
+        grouped = g.group if hasattr(g, "group") else _NoGroup      # a host transport has nothing to fuse
+        with grouped():    # seven arrays, one fused RCCL launch
+            for loc, glob, width in ((self.flag_l, self.flag_g, 1), (self.edge_l, self.edge_g, 3), (self.tflag_l, self.tflag_g, 1),
+                                     (self.m3_l, self.m3_g, 3), (self.flip_l, self.flip_g, 1), (self.before_l, self.before_g, 8),
+                                     (self.after_l, self.after_g, 8)):
+                g.allgather_dev(loc, glob, B * width, send_offset=off * width)
+        with grouped():
+            g.allreduce_dev(self.counts, 3, _lib.DT_U64, _lib.OP_SUM)
+            g.allreduce_dev(self.pflag, self.n_m, _lib.DT_U8, _lib.OP_MAX)
         checked, nviol = ctypes.c_int64(0), ctypes.c_int64(0)
         chk(L.same_orient_from_flags_dev(self.sweep, self.flag_g.ptr, ctypes.byref(checked), self.viol.ctypes.data,
                                          ctypes.byref(nviol)), "same_orient_from_flags_dev")
