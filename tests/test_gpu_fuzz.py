@@ -1,5 +1,6 @@
 """Seeded randomised sweep of small shapes: every kernel against the oracle on ragged sizes, duplicate points,
-exact ties, radii from tiny to whole-set, k up to 64, T up to 40, sparse and full matchings.  Cheap per case;
+exact ties, radii from tiny to whole-set, k up to 448, T up to 90 (both dense kernels), fp32 and fixed-point cost variants,
+indexed prunes, triangle-block sweeps for random rank counts, sparse and full matchings.  Cheap per case;
 the point is to visit shape/edge combinations the fixed fixtures do not."""
 import os
 
@@ -39,6 +40,8 @@ def test_fuzz_knn_and_costs(ops, oracle):
             if case % 10 == 0:
                 n_r = int(rng.integers(2100, 5000))  # above the grid threshold
             T, k = int(rng.integers(0, 41)), int(rng.choice([1, 2, 5, 8, 31, 32, 33, 64, 65, 100, 200, 448]))
+            if case % 7 == 3:
+                T = int(rng.integers(41, 91))          # one column per lane, then the row-blocked kernel from 48
             side = float(rng.choice([10.0, 100.0, 1000.0]))
             radius = float(rng.choice([0.0, 0.5, 3.0, side / 10, side / 3, side * 2]))
             axy, rxy = _points(rng, n_m, side, int(rng.integers(0, 4))), _points(rng, n_r, side, int(rng.integers(0, 4)))
@@ -59,6 +62,17 @@ def test_fuzz_knn_and_costs(ops, oracle):
             if case % 4 == 0:
                 D32 = ops.dense_cost(A, R, axy, rxy, w, int(b), int(e), dtype=np.float32)
                 assert np.array_equal(D32, oracle.dense_cost(A, R, axy, rxy, w, int(b), int(e), dtype=np.float32)), (case, T)
+                if len(pairs):   # fp32 pair costs (config 5) == the oracle's float twin == elements of the fp32 dense build
+                    c32 = ops.pair_cost(A, R, axy, rxy, pairs, w, dtype=np.float32)
+                    assert np.array_equal(c32, oracle.pair_cost_arrays(A, R, axy, rxy, pairs, w, dtype=np.float32)), (case, T)
+                    inb = (pairs[:, 0] >= b) & (pairs[:, 0] < e)
+                    assert np.array_equal(c32[inb], D32[pairs[inb, 0] - int(b), pairs[inb, 1]]), (case, T)
+            if case % 3 == 1 and T <= 32 and e > b:   # opt-in fixed-point build: twin-equal, and within 1e-6 relative of the exact build
+                grid = ops.quantize_types(A, R)
+                Q, bound = ops.dense_cost_q32(A, R, axy, rxy, w, int(b), int(e), grid=grid)
+                assert np.array_equal(Q, oracle.dense_cost_q32(A, R, axy, rxy, w, grid[0], grid[1], int(b), int(e))), (case, T)
+                nz = D != 0
+                assert (np.abs(Q - D)[nz] <= 1e-6 * (1 + 1e-9) * np.abs(D)[nz]).all() and (np.abs(Q - D)[~nz] <= w * bound + 1e-300).all(), (case, T)
 
 
 def test_fuzz_triangles_and_sweeps(ops, oracle):
@@ -144,3 +158,59 @@ def test_fuzz_matching_from_x_and_greedy(ops, oracle):
             o = np.empty((n_m, n_r + n_m))
             oracle.lib().orc_assign_matrix(pairs, costs, P, un, n_m, n_r, 1e9, o.reshape(-1))
             assert np.array_equal(ops.assign_matrix(pairs, costs, un, n_m, n_r, 1e9), o), case
+
+
+def test_fuzz_knn_index_and_block_sweeps(ops, oracle):
+    """Caller-held KNN index == un-indexed prune on random shapes / row blocks; the orientation sweep issued as the triangle
+    blocks of a random number of ranks == the whole sweep."""
+    import ctypes
+    from same_amd import _lib
+    from same_amd.dist import tri_block
+
+    ctx = _lib.default_context()
+    L, H = ctx.lib, ctx.handle
+    for rnd in range(ROUNDS):
+        rng = np.random.default_rng(911 + 7919 * rnd)
+        for case in range(40):
+            n_m, n_r = int(rng.integers(1, 600)), int(rng.choice([0, 1, 50, 900, 2100, 4000]))
+            side = float(rng.choice([10.0, 100.0, 1000.0]))
+            radius = float(rng.choice([0.0, 0.5, 3.0, side / 10, side / 3, side * 2]))
+            k = int(rng.choice([1, 5, 32, 64, 65, 200]))
+            axy, rxy = _points(rng, n_m, side, int(rng.integers(0, 4))), _points(rng, n_r, side, int(rng.integers(0, 4)))
+            with ctx.lock:
+                dax, drx = ctx.to_device(axy), ctx.to_device(rxy)
+                ix = ctypes.c_void_p()
+                ctx.check(L.same_knn_index_build(H, drx.ptr, n_r, radius, ctypes.byref(ix)), "index")
+                b, e = sorted(int(v) for v in rng.integers(0, n_m + 1, 2))
+                rows = e - b
+                di, dd, dc = ctx.alloc(max(rows, 1) * k * 4), ctx.alloc(max(rows, 1) * k * 8), ctx.alloc(max(rows, 1) * 4)
+                ctx.check(L.same_knn_prune_indexed_dev(H, ix, dax.ptr, b, e, k, di.ptr, dd.ptr, dc.ptr), "indexed")
+                got = di.download((rows, k), np.int32), dd.download((rows, k), np.float64), dc.download((rows,), np.int32)
+                L.same_knn_index_destroy(ix)
+            want = oracle.knn_prune(axy, rxy, radius, k, b, e)
+            assert all(np.array_equal(g, w_) for g, w_ in zip(got, want)), (case, n_m, n_r, k, radius, b, e)
+            # triangle blocks
+            n = max(n_m, 3)
+            Tr = int(rng.integers(1, 2500))
+            tris = rng.integers(0, n, (Tr, 3)).astype(np.int32)
+            sign = rng.integers(-1, 2, Tr).astype(np.int8)
+            rr = _points(rng, max(n_r, 1), side, 0)
+            match = rng.integers(-1, len(rr), n).astype(np.int32)
+            och, oviol, oflag = oracle.orient_sweep(tris, sign, rr, match)
+            world = int(rng.choice([1, 2, 3, 5, 8]))
+            with ctx.lock:
+                sw = ctypes.c_void_p()
+                ctx.check(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign.ctypes.data, rr.ctypes.data, len(rr), n, None, 0, ctypes.byref(sw)), "bind")
+                dmatch = ctx.to_device(match)
+                _, _, block = tri_block(Tr, world, 0)
+                dflag = ctx.alloc(block * world)
+                ctx.check(L.same_dev_memset(H, dflag.ptr, 0, dflag.nbytes), "memset")
+                for r in rng.permutation(world):                     # ranks finish in any order
+                    t0, t1, _ = tri_block(Tr, world, int(r))
+                    ctx.check(L.same_orient_flags_dev(sw, dmatch.ptr, t0, t1, dflag.ptr), "flags")
+                chk, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+                viol = np.empty(Tr, np.int32)
+                ctx.check(L.same_orient_from_flags_dev(sw, dflag.ptr, ctypes.byref(chk), viol.ctypes.data, ctypes.byref(nv)), "from_flags")
+                flags = dflag.download((Tr,), np.uint8)
+                L.same_sweep_unbind(sw)
+            assert chk.value == och and np.array_equal(viol[: nv.value], oviol) and np.array_equal(flags, oflag), (case, Tr, world)
