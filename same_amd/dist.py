@@ -51,11 +51,12 @@ class RcclGroup:
         uid = None
         if self.rank == 0:
             buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
-            ctx.check(ctx.lib.same_comm_unique_id(buf), "same_comm_unique_id")
-            uid = buf.raw
+            # a failure here still goes through the exchange (as an empty id), so that every rank sees it and takes the same
+            # way out instead of waiting for a broadcast that never comes
+            uid = buf.raw if ctx.lib.same_comm_unique_id(buf) == 0 else b""
         uid = exchange_id(uid)
-        if len(uid) != _lib.UNIQUE_ID_BYTES:
-            raise ValueError("the exchanged RCCL unique id has the wrong length")
+        if uid is None or len(uid) != _lib.UNIQUE_ID_BYTES:
+            raise _lib.SameHipError(_lib.SAME_EIO, "no RCCL unique id (rank 0 could not create one, or the exchange lost it)")
         ctx.check(ctx.lib.same_comm_init(ctx.handle, self.world, self.rank, uid), "same_comm_init")
 
     def rccl_version(self):
