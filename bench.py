@@ -280,7 +280,22 @@ def run_rank(args):
         try:
             if os.environ.get("SAME_BENCH_FAIL_RCCL"):
                 raise RuntimeError("forced by SAME_BENCH_FAIL_RCCL (test switch)")
-            comm = RcclGroup(tctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
+            # ncclCommInitRank is a collective without a timeout: if it never returns (a rank lost, a bootstrap interface that
+            # does not route) say so and leave, so the launcher stops the job at once instead of at its own limit
+            import threading
+
+            def stuck():
+                print(f"[rank {group.rank}] RCCL communicator init has not returned after {limit_s:.0f} s; giving up", file=sys.stderr, flush=True)
+                os._exit(3)
+
+            limit_s = float(os.environ.get("SAME_BENCH_RCCL_TIMEOUT", "300"))
+            watchdog = threading.Timer(limit_s, stuck)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                comm = RcclGroup(tctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
+            finally:
+                watchdog.cancel()
             ok_here = 1.0
         except Exception as e:  # TRANSPORT fallback only (compute stays on the GPU): reported in the JSON line
             print(f"[rank {group.rank}] RCCL communicator init failed ({e}); gathering through the host group instead", file=sys.stderr)
