@@ -195,10 +195,14 @@ class HostTransport:
 
 
 def dense_kernel_label(dtype, T):
+    """The kernel csrc/cost.hip dispatches to for this dtype and type count."""
+    name = "double" if dtype == "f64" else "float"
+    if T >= (48 if dtype == "f64" else 49):
+        return f"dense_cost_rowblock_kernel<{name},32>"
     cpl = (2 if dtype == "f64" else 4)
     if T * cpl * (2 if dtype == "f64" else 1) > 160:
         cpl = 1
-    return f"dense_cost_kernel<{'double' if dtype == 'f64' else 'float'},{T},{cpl}>" if T <= 48 else "dense_cost_generic_kernel"
+    return f"dense_cost_kernel<{name},{T},{cpl}>"
 
 
 def run_rank(args):
