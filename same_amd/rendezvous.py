@@ -110,13 +110,18 @@ class HostGroup:
             os.replace(tmp, hub_file)  # atomic: readers see nothing or the whole file
             while len(self._peers) < self.world - 1:
                 conn, _ = ls.accept()
-                conn.settimeout(self.timeout)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                hello = _recv_exact(conn, 36)
-                peer = struct.unpack("<I", hello[32:])[0]
+                conn.settimeout(5.0)      # a rank says hello at once; something that connects and stalls must not hold up the others
+                try:
+                    hello = _recv_exact(conn, 36)
+                    peer = struct.unpack("<I", hello[32:])[0]
+                except (OSError, ConnectionError):
+                    conn.close()
+                    continue
                 if hello[:32] != token.encode() or not (0 < peer < self.world) or peer in self._peers:
                     conn.close()  # not one of this job's ranks
                     continue
+                conn.settimeout(self.timeout)
                 self._peers[peer] = conn
         else:
             deadline = time.monotonic() + self.timeout
