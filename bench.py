@@ -649,6 +649,12 @@ def run_rank(args):
         if "sweep" in extras:
             roof["sweep"] = extras["sweep"]
             msg.append("sweep = same measurement at other type counts (the reference's datasets have T = 3, 5, 8)")
+            ctl = [e for e in extras["sweep"] if e.get("opt_in")]
+            if ctl:
+                msg.append(f"control: the opt-in fixed-point build writes the same {dense_bytes / 1e9:.0f} GB with integer v_sad_u32 in place of the "
+                           f"fp64 adds, every output within 1e-6 relative of this kernel's (BASELINE's own tolerance for fp64 costs; max "
+                           f"{ctl[0]['max_rel_diff_vs_exact_on_16_rows']:.1e} on 16 sampled rows), in {ctl[0]['ms']:.2f} ms = {ctl[0]['frac']:.3f} of the "
+                           "HBM spec -- the gap to this kernel is the energy of the fp64 arithmetic, not memory traffic")
         roof["note"] = "; ".join(msg)
         out = {
             "metric": baseline_metric(),
