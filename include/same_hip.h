@@ -132,13 +132,6 @@ int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *
                             const double *dR, int T, const double *daxy, const double *drxy, int64_t n_r,
                             int64_t row_begin, int64_t row_end, double w, double inv_scale,
                             double rel_tol, double *dout, int64_t ld);
-/* float output (config 5's cost type): the same exact integer type sums, XY part and scaling in float on float
- * coordinates, ld a multiple of 4.  No tolerance guard: the float variants' contract is the forward bound
- * |c - c_fp64| <= (T+4) * 2^-24 * (sum of operand magnitudes), which an exact sum on a 2^-s grid sits far inside --
- * it is in fact closer to the fp64 costs than same_dense_cost_f32_dev's float accumulation. */
-int same_dense_cost_q32_f32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, int T,
-                                const float *daxy, const float *drxy, int64_t n_r, int64_t row_begin,
-                                int64_t row_end, float w, double inv_scale, float *dout, int64_t ld);
 
 /* ---- a2: KNN prune within a radius ----------------------------------------------------
  * Replaces the per-row body of utils.find_knn_within_radius (src/utils.py:720-728):

@@ -54,7 +54,6 @@ def lib():
         _u32q = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
         L.orc_quantize_u32.argtypes = [_f64, _I64, _DBL, _DBL, _u32q]
         L.orc_dense_cost_q32.argtypes = [_u32q, _u32q, _f64, _f64, _INT, _f64, _f64, _I64, _I64, _I64, _DBL, _DBL, _DBL, _f64, _I64]
-        L.orc_dense_cost_q32_f32.argtypes = [_u32q, _u32q, _INT, _f32, _f32, _I64, _I64, _I64, ctypes.c_float, _DBL, _f32, _I64]
         L.orc_knn_prune.argtypes = [_f64, _f64, _I64, _I64, _I64, _DBL, _INT, _i32, _f64, _i32]
         L.orc_tri_classify.argtypes = [_f64, _i32, _I64, _DBL, _INT, _DBL, _VP, _u8, _f64, _f64]
         L.orc_tri_sign_weight.argtypes = [_f64, _VP, _i32, _I64, _i8, _VP]
@@ -175,8 +174,8 @@ def dense_cost(A, R, axy, rxy, w, row_begin=0, row_end=None, dtype=np.float64):
     return out
 
 
-def dense_cost_q32(A, R, axy, rxy, w, offset, log2_scale, row_begin=0, row_end=None, rel_tol=1e-6, dtype=np.float64):
-    """Twin of the opt-in fixed-point dense build (ops.dense_cost_q32): same grid, exact integer sums, fp64 (or float) remainder."""
+def dense_cost_q32(A, R, axy, rxy, w, offset, log2_scale, row_begin=0, row_end=None, rel_tol=1e-6):
+    """Twin of the opt-in fixed-point dense build (ops.dense_cost_q32): same grid, exact integer sums, fp64 remainder."""
     A, R = _c(A, np.float64), _c(R, np.float64)
     row_end = len(A) if row_end is None else row_end
     T = A.shape[1]
@@ -184,11 +183,6 @@ def dense_cost_q32(A, R, axy, rxy, w, offset, log2_scale, row_begin=0, row_end=N
     scale = float(2.0 ** log2_scale)
     lib().orc_quantize_u32(A.reshape(-1), A.size, float(offset), scale, Aq.reshape(-1))
     lib().orc_quantize_u32(R.reshape(-1), R.size, float(offset), scale, Rq.reshape(-1))
-    if np.dtype(dtype) == np.float32:
-        out = np.empty((row_end - row_begin, len(R)), np.float32)
-        lib().orc_dense_cost_q32_f32(Aq.reshape(-1), Rq.reshape(-1), T, _c(axy, np.float32), _c(rxy, np.float32), len(R), row_begin, row_end,
-                                     float(w), 1.0 / scale, out.reshape(-1), len(R))
-        return out
     out = np.empty((row_end - row_begin, len(R)), np.float64)
     lib().orc_dense_cost_q32(Aq.reshape(-1), Rq.reshape(-1), A.reshape(-1), R.reshape(-1), T, _c(axy, np.float64), _c(rxy, np.float64),
                              len(R), row_begin, row_end, float(w), 1.0 / scale, float(rel_tol), out.reshape(-1), len(R))

@@ -56,7 +56,6 @@ _PROTOTYPES = {
     "same_dense_cost_f32": [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_i64, c_flt, c_vp, c_i64],
     "same_quantize_u32_dev": [c_vp, c_vp, c_i64, c_dbl, c_dbl, c_vp],
     "same_dense_cost_q32_dev": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_dbl, c_dbl, c_vp, c_i64],
-    "same_dense_cost_q32_f32_dev": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_flt, c_dbl, c_vp, c_i64],
     "same_knn_prune": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp, c_vp, c_vp],
     "same_knn_prune_dev": [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_dbl, c_int, c_vp, c_vp, c_vp],
     "same_knn_index_build": [c_vp, c_vp, c_i64, c_dbl, ctypes.POINTER(c_vp)],

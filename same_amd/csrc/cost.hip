@@ -337,19 +337,16 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t r, uint32_t acc
     return (a > r ? a - r : r - a) + acc;   // selected as v_sad_u32 (checked in the ISA)
 }
 
-// F = double: the tolerance-guarded fp64 build above.  F = float (config 5's cost type): the same integer type sums, the XY
-// part and the final scaling in float on float coordinates, 4 columns = 16 B per lane; no guard -- the float variant's
-// contract is a forward bound against the fp64 costs, which an exact type sum on a 2^-s grid sits far inside.
-template <int T, typename F>
+template <int T>
 __global__ __launch_bounds__(256) void dense_cost_q32_kernel(
     const uint32_t *__restrict__ Aq, const uint32_t *__restrict__ Rq, const double *__restrict__ A, const double *__restrict__ R,
-    const F *__restrict__ axy, const F *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w,
-    F wq, F dcoef, uint32_t guard, F *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block, int64_t n_store,
+    const double *__restrict__ axy, const double *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, double w,
+    double wq, double dcoef, uint32_t guard, double *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block, int64_t n_store,
     int row_chunks) {
-    constexpr int CPL = 16 / (int)sizeof(F);   // 16 B per lane per row: a wave writes 1 KiB of one output row (fp64 with 4 columns
-                                               // per lane = two stores 32 B apart measured 42 ms against 11.7 ms: half-line writes)
+    constexpr int CPL = 2;   // 16 B per lane per row: a wave writes 1 KiB of one output row (4 columns per lane, two stores 32 B
+                             // apart, measured 42 ms against 11.7 ms: half-line writes)
     constexpr int TT = T > 0 ? T : 1;
-    typedef F vecF __attribute__((ext_vector_type(CPL)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
     // store stream: blocks that share an XCD (blockIdx % 8) take adjacent column tiles of one row chunk (map 2 of the fp64 kernel)
     const unsigned b = blockIdx.x, xcd = b & 7u, kk = b >> 3;
     const unsigned per = (gridDim.x + 7u) >> 3;
@@ -360,7 +357,7 @@ __global__ __launch_bounds__(256) void dense_cost_q32_kernel(
     int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
     if (i0 + rows_per_block > row_end) i0 = row_end - rows_per_block;   // last chunk overlaps its neighbour (identical values)
     uint32_t r[CPL][TT];
-    F rx[CPL], ry[CPL];
+    double rx[CPL], ry[CPL];
     int64_t jj[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -375,23 +372,23 @@ __global__ __launch_bounds__(256) void dense_cost_q32_kernel(
     }
     if (j0 >= n_store) return;
     const uint32_t *__restrict__ arow = Aq + i0 * T;       // wave-uniform -> scalar loads
-    const F *__restrict__ axyrow = axy + 2 * i0;
+    const double *__restrict__ axyrow = axy + 2 * i0;
     char *orow = reinterpret_cast<char *>(out + (i0 - row_begin) * ld);
-    const unsigned lane_off = (unsigned)(j0 * sizeof(F));
-    const int64_t row_pitch = ld * (int64_t)sizeof(F);
+    const unsigned lane_off = (unsigned)(j0 * sizeof(double));
+    const int64_t row_pitch = ld * (int64_t)sizeof(double);
     uint32_t a[TT];
 #pragma unroll
     for (int t = 0; t < T; ++t) a[t] = arow[t];
-    F ax = axyrow[0], ay = axyrow[1];
+    double ax = axyrow[0], ay = axyrow[1];
     for (int q = 0; q < rows_per_block; ++q) {
         // next row's scalars are requested before this row is computed
         const bool last = q + 1 >= rows_per_block;
         const uint32_t *__restrict__ an_p = last ? arow : arow + T;
-        const F *__restrict__ axn_p = last ? axyrow : axyrow + 2;
+        const double *__restrict__ axn_p = last ? axyrow : axyrow + 2;
         uint32_t an[TT];
 #pragma unroll
         for (int t = 0; t < T; ++t) an[t] = an_p[t];
-        const F axn = axn_p[0], ayn = axn_p[1];
+        const double axn = axn_p[0], ayn = axn_p[1];
         uint32_t acc[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = 0u;
@@ -400,24 +397,22 @@ __global__ __launch_bounds__(256) void dense_cost_q32_kernel(
 #pragma unroll
             for (int c = 0; c < CPL; ++c) acc[c] = sad_u32(a[t], r[c][t], acc[c]);
         }
-        vecF v;
+        double v[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
-            const F dc = absf<F>(ax - rx[c]) + absf<F>(ay - ry[c]);
-            v[c] = (F)acc[c] * wq + dcoef * dc;
-            if constexpr (sizeof(F) == 8) {
-                if (acc[c] < guard) {
-                    // a type sum this small cannot carry the relative tolerance on a grid (T grid steps of error against fewer
-                    // than T / rel_tol steps of value): the reference's own fp64 expression instead -- near-identical cells, about
-                    // one column per row when the sections are jittered copies, none for unrelated ones
-                    const double *ap = A + (i0 + q) * (int64_t)T, *rp = R + jj[c] * (int64_t)T;
-                    double s = 0.0;
-                    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(ap[t] - rp[t]);
-                    v[c] = w * s + dcoef * dc;
-                }
+            const double dc = __builtin_fabs(ax - rx[c]) + __builtin_fabs(ay - ry[c]);
+            v[c] = (double)acc[c] * wq + dcoef * dc;
+            if (acc[c] < guard) {
+                // a type sum this small cannot carry the relative tolerance on a grid (T grid steps of error against fewer than
+                // T / rel_tol steps of value): the reference's own fp64 expression instead -- near-identical cells, about one
+                // column per row when the sections are jittered copies, none for unrelated ones
+                const double *ap = A + (i0 + q) * (int64_t)T, *rp = R + jj[c] * (int64_t)T;
+                double s = 0.0;
+                for (int t = 0; t < T; ++t) s = s + __builtin_fabs(ap[t] - rp[t]);
+                v[c] = w * s + dcoef * dc;
             }
         }
-        store16_nt_saddr(orow, lane_off, v);
+        store16_nt_saddr(orow, lane_off, d2{v[0], v[1]});
         orow += row_pitch;
         arow += T;
         axyrow += 2;
@@ -710,53 +705,22 @@ int padded_cost_dev(same_ctx *ctx, const F *dA, const F *dR, int T, const F *dax
     return SAME_OK;
 }
 
-template <int T, typename F>
-int launch_q32_T(same_ctx *ctx, const uint32_t *Aq, const uint32_t *Rq, const double *A, const double *R, const F *axy,
-                 const F *rxy, int64_t n_r, int64_t rb, int64_t re, F w, F wq, F dcoef, uint32_t guard, F *out, int64_t ld) {
+template <int T>
+int launch_q32_T(same_ctx *ctx, const uint32_t *Aq, const uint32_t *Rq, const double *A, const double *R, const double *axy,
+                 const double *rxy, int64_t n_r, int64_t rb, int64_t re, double w, double wq, double dcoef, uint32_t guard, double *out,
+                 int64_t ld) {
     const int64_t rows = re - rb;
     int rows_per_block = 256;
-    const int col_tiles = (int)ceil_div(ld, 256 * (16 / (int)sizeof(F)));
+    const int col_tiles = (int)ceil_div(ld, 256 * 2);
     while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
     if (rows_per_block > rows) rows_per_block = (int)rows;
     const int64_t chunks = ceil_div(rows, rows_per_block);
     const int64_t blocks = ceil_div(chunks * col_tiles, 8) * 8;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
-    hipLaunchKernelGGL((dense_cost_q32_kernel<T, F>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Aq, Rq, A, R, axy, rxy, n_r, rb, re, w,
+    hipLaunchKernelGGL((dense_cost_q32_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, Aq, Rq, A, R, axy, rxy, n_r, rb, re, w,
                        wq, dcoef, guard, out, ld, col_tiles, rows_per_block, ld, (int)chunks);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
-}
-
-template <typename F>
-int dense_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, const double *dA, const double *dR, int T, const F *daxy,
-                  const F *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w, double inv_scale, double rel_tol, F *dout,
-                  int64_t ld) {
-    constexpr int CPL = 16 / (int)sizeof(F);
-    REQUIRE(ctx, ctx && daxy && drxy && dout && (T == 0 || (dAq && dRq)));
-    REQUIRE(ctx, T >= 0 && T <= SAME_Q32_MAX_TYPES && n_r >= 0 && row_begin >= 0 && row_end >= row_begin && inv_scale > 0.0);
-    REQUIRE(ctx, rel_tol >= 0.0 && (rel_tol == 0.0 || T == 0 || (dA && dR)));
-    // 16-byte stores of whole column groups: the row pitch is the store width (columns [n_r, ld) are caller-owned padding)
-    REQUIRE(ctx, ld >= n_r && ld % CPL == 0 && reinterpret_cast<uintptr_t>(dout) % 16 == 0 && ld * (int64_t)sizeof(F) < ((int64_t)1 << 32));
-    SAME_TRY(same_use(ctx));
-    if (n_r == 0 || row_end == row_begin) return SAME_OK;
-    // sums below `guard` grid steps are recomputed in the reference's fp64 arithmetic: T steps of grid error are within
-    // rel_tol of any sum of at least T / rel_tol steps (+ T for the sum's own displacement)
-    uint32_t guard = 0;
-    if (rel_tol > 0.0 && T > 0) {
-        const double g = std::ceil((double)T / rel_tol) + (double)T;
-        guard = g >= 4294967295.0 ? 4294967295u : (uint32_t)g;
-    }
-    const F wq = (F)((double)w * inv_scale), dcoef = w * F(0.001);   // w * 2^-s: exact in double, one rounding into F
-    switch (T) {
-#define CASE_Q(n) case n: return launch_q32_T<n, F>(ctx, dAq, dRq, dA, dR, daxy, drxy, n_r, row_begin, row_end, w, wq, dcoef, guard, dout, ld);
-        CASE_Q(0) CASE_Q(1) CASE_Q(2) CASE_Q(3) CASE_Q(4) CASE_Q(5) CASE_Q(6) CASE_Q(7) CASE_Q(8)
-        CASE_Q(9) CASE_Q(10) CASE_Q(11) CASE_Q(12) CASE_Q(13) CASE_Q(14) CASE_Q(15) CASE_Q(16)
-        CASE_Q(17) CASE_Q(18) CASE_Q(19) CASE_Q(20) CASE_Q(21) CASE_Q(22) CASE_Q(23) CASE_Q(24)
-        CASE_Q(25) CASE_Q(26) CASE_Q(27) CASE_Q(28) CASE_Q(29) CASE_Q(30) CASE_Q(31) CASE_Q(32)
-#undef CASE_Q
-        default: break;
-    }
-    return SAME_EINVAL;
 }
 
 }  // namespace
@@ -823,13 +787,31 @@ int same_quantize_u32_dev(same_ctx *ctx, const double *dsrc, int64_t n, double o
 int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, const double *dA, const double *dR, int T,
                             const double *daxy, const double *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, double w,
                             double inv_scale, double rel_tol, double *dout, int64_t ld) {
-    return dense_q32_dev<double>(ctx, dAq, dRq, dA, dR, T, daxy, drxy, n_r, row_begin, row_end, w, inv_scale, rel_tol, dout, ld);
-}
-
-int same_dense_cost_q32_f32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, int T, const float *daxy,
-                                const float *drxy, int64_t n_r, int64_t row_begin, int64_t row_end, float w, double inv_scale,
-                                float *dout, int64_t ld) {
-    return dense_q32_dev<float>(ctx, dAq, dRq, nullptr, nullptr, T, daxy, drxy, n_r, row_begin, row_end, w, inv_scale, 0.0, dout, ld);
+    REQUIRE(ctx, ctx && daxy && drxy && dout && (T == 0 || (dAq && dRq)));
+    REQUIRE(ctx, T >= 0 && T <= SAME_Q32_MAX_TYPES && n_r >= 0 && row_begin >= 0 && row_end >= row_begin && inv_scale > 0.0);
+    REQUIRE(ctx, rel_tol >= 0.0 && (rel_tol == 0.0 || T == 0 || (dA && dR)));
+    // 16-byte stores of whole column pairs: the row pitch is the store width (columns [n_r, ld) are caller-owned padding)
+    REQUIRE(ctx, ld >= n_r && ld % 2 == 0 && reinterpret_cast<uintptr_t>(dout) % 16 == 0 && ld * (int64_t)sizeof(double) < ((int64_t)1 << 32));
+    SAME_TRY(same_use(ctx));
+    if (n_r == 0 || row_end == row_begin) return SAME_OK;
+    // sums below `guard` grid steps are recomputed in the reference's fp64 arithmetic: T steps of grid error are within
+    // rel_tol of any sum of at least T / rel_tol steps (+ T for the sum's own displacement)
+    uint32_t guard = 0;
+    if (rel_tol > 0.0 && T > 0) {
+        const double g = std::ceil((double)T / rel_tol) + (double)T;
+        guard = g >= 4294967295.0 ? 4294967295u : (uint32_t)g;
+    }
+    const double wq = w * inv_scale, dcoef = w * 0.001;
+    switch (T) {
+#define CASE_Q(n) case n: return launch_q32_T<n>(ctx, dAq, dRq, dA, dR, daxy, drxy, n_r, row_begin, row_end, w, wq, dcoef, guard, dout, ld);
+        CASE_Q(0) CASE_Q(1) CASE_Q(2) CASE_Q(3) CASE_Q(4) CASE_Q(5) CASE_Q(6) CASE_Q(7) CASE_Q(8)
+        CASE_Q(9) CASE_Q(10) CASE_Q(11) CASE_Q(12) CASE_Q(13) CASE_Q(14) CASE_Q(15) CASE_Q(16)
+        CASE_Q(17) CASE_Q(18) CASE_Q(19) CASE_Q(20) CASE_Q(21) CASE_Q(22) CASE_Q(23) CASE_Q(24)
+        CASE_Q(25) CASE_Q(26) CASE_Q(27) CASE_Q(28) CASE_Q(29) CASE_Q(30) CASE_Q(31) CASE_Q(32)
+#undef CASE_Q
+        default: break;
+    }
+    return SAME_EINVAL;
 }
 
 }  // extern "C"

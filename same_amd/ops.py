@@ -78,39 +78,31 @@ def quantize_types(A, R):
     return offset, min(log2_scale, 1000)
 
 
-def dense_cost_q32(A, R, axy, rxy, w, row_begin=0, row_end=None, grid=None, rel_tol=1e-6, dtype=F64, ctx=None):
-    """Opt-in fixed-point dense build (include/same_hip.h: same_dense_cost_q32_dev / _f32_dev) -> (costs (rows, n_r), T * 2^-s
-    absolute error bound on the type sum).  dtype float64: every output is also within `rel_tol` (relative) of `dense_cost`'s --
-    sums too small for the grid are recomputed in fp64 in the kernel.  dtype float32: float XY part and scaling, no guard (the
-    float variants' contract is a forward bound).  NOT the reference's arithmetic; `dense_cost` is."""
+def dense_cost_q32(A, R, axy, rxy, w, row_begin=0, row_end=None, grid=None, rel_tol=1e-6, ctx=None):
+    """Opt-in fixed-point dense build (include/same_hip.h: same_dense_cost_q32_dev) -> (costs (rows, n_r) f64, T * 2^-s absolute
+    error bound on the type sum).  Every output is also within `rel_tol` (relative) of `dense_cost`'s: sums too small for the
+    grid are recomputed in fp64 in the kernel.  NOT the reference's arithmetic; `dense_cost` is."""
     ctx = _ctx(ctx)
-    dt = np.dtype(dtype)
-    assert dt in (np.dtype(F64), np.dtype(F32))
     A, R = as_c(A, F64), as_c(R, F64)
-    axy, rxy = as_c(axy, dt).reshape(-1, 2), as_c(rxy, dt).reshape(-1, 2)
+    axy, rxy = as_c(axy, F64).reshape(-1, 2), as_c(rxy, F64).reshape(-1, 2)
     n_m, n_r = len(axy), len(rxy)
     row_end = n_m if row_end is None else int(row_end)
     rows = max(row_end - int(row_begin), 0)
     T = A.shape[1] if A.ndim == 2 else 0
     offset, log2_scale = quantize_types(A, R) if grid is None else grid
     scale = float(2.0 ** log2_scale)
-    out = np.empty((rows, n_r), dt)
+    out = np.empty((rows, n_r), F64)
     if rows == 0 or n_r == 0:
         return out, T / scale
-    cpl = 16 // dt.itemsize
-    ld = -(-n_r // cpl) * cpl
+    ld = (n_r + 1) & ~1
     with ctx.lock:
         dA, dR, dax, drx = ctx.to_device(A), ctx.to_device(R), ctx.to_device(axy), ctx.to_device(rxy)
-        dAq, dRq, dout = ctx.alloc(max(A.size, 1) * 4), ctx.alloc(max(R.size, 1) * 4), ctx.alloc(rows * ld * dt.itemsize)
+        dAq, dRq, dout = ctx.alloc(max(A.size, 1) * 4), ctx.alloc(max(R.size, 1) * 4), ctx.alloc(rows * ld * 8)
         ctx.check(ctx.lib.same_quantize_u32_dev(ctx.handle, dA.ptr, A.size, offset, scale, dAq.ptr), "same_quantize_u32_dev")
         ctx.check(ctx.lib.same_quantize_u32_dev(ctx.handle, dR.ptr, R.size, offset, scale, dRq.ptr), "same_quantize_u32_dev")
-        if dt == np.dtype(F64):
-            ctx.check(ctx.lib.same_dense_cost_q32_dev(ctx.handle, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_r, int(row_begin),
-                                                      row_end, float(w), 1.0 / scale, float(rel_tol), dout.ptr, ld), "same_dense_cost_q32_dev")
-        else:
-            ctx.check(ctx.lib.same_dense_cost_q32_f32_dev(ctx.handle, dAq.ptr, dRq.ptr, T, dax.ptr, drx.ptr, n_r, int(row_begin), row_end,
-                                                          float(w), 1.0 / scale, dout.ptr, ld), "same_dense_cost_q32_f32_dev")
-        full = dout.download((rows, ld), dt)
+        ctx.check(ctx.lib.same_dense_cost_q32_dev(ctx.handle, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_r, int(row_begin),
+                                                  row_end, float(w), 1.0 / scale, float(rel_tol), dout.ptr, ld), "same_dense_cost_q32_dev")
+        full = dout.download((rows, ld), F64)
     out[:] = full[:, :n_r]
     return out, T / scale
 

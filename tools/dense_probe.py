@@ -6,9 +6,8 @@ from same_amd import _lib, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 Ts = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 4, 8, 12, 16, 20, 24]
-q32 = len(sys.argv) > 3 and sys.argv[3] in ("q32", "q32f")      # the opt-in fixed-point build (fp64 / float output)
-q32f = len(sys.argv) > 3 and sys.argv[3] == "q32f"
-dtype = np.float32 if (len(sys.argv) > 3 and sys.argv[3] in ("f32", "q32f")) else np.float64
+q32 = len(sys.argv) > 3 and sys.argv[3] == "q32"      # the opt-in fixed-point build (fp64 output)
+dtype = np.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else np.float64
 ctx = _lib.Context(0)
 L, H = ctx.lib, ctx.handle
 es = np.dtype(dtype).itemsize
@@ -22,23 +21,19 @@ for T in Ts:
     fn = L.same_dense_cost_f64_dev if dtype == np.float64 else L.same_dense_cost_f32_dev
     if q32:
         from same_amd import ops
-        A64, R64 = np.ascontiguousarray(mov["types"][:, :T]), np.ascontiguousarray(ref["types"][:, :T])
-        dA64, dR64 = ctx.to_device(A64), ctx.to_device(R64)
-        off, l2 = ops.quantize_types(A64, R64) if T else (0.0, 0)
+        off, l2 = ops.quantize_types(A, R) if T else (0.0, 0)
         dAq, dRq = ctx.alloc(max(A.size, 1) * 4), ctx.alloc(max(R.size, 1) * 4)
-        ctx.check(L.same_quantize_u32_dev(H, dA64.ptr, A.size, off, 2.0 ** l2, dAq.ptr), "q")
-        ctx.check(L.same_quantize_u32_dev(H, dR64.ptr, R.size, off, 2.0 ** l2, dRq.ptr), "q")
+        ctx.check(L.same_quantize_u32_dev(H, dA.ptr, A.size, off, 2.0 ** l2, dAq.ptr), "q")
+        ctx.check(L.same_quantize_u32_dev(H, dR.ptr, R.size, off, 2.0 ** l2, dRq.ptr), "q")
     ms_all = []
     for it in range(6):
         ctx.check(L.same_timer_start(H), "t")
-        if q32f:
-            ctx.check(L.same_dense_cost_q32_f32_dev(H, dAq.ptr, dRq.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, 2.0 ** -l2, dD.ptr, ld), "dense q32f")
-        elif q32:
-            ctx.check(L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, dA64.ptr, dR64.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, 2.0 ** -l2,
+        if q32:
+            ctx.check(L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, 2.0 ** -l2,
                                                 float(os.environ.get("PROBE_REL_TOL", "1e-6")), dD.ptr, ld), "dense q32")
         else:
             ctx.check(fn(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, dD.ptr, ld), "dense")
         ms = ctypes.c_float(0); ctx.check(L.same_timer_stop(H, ctypes.byref(ms)), "t"); ms_all.append(ms.value)
     best = min(ms_all[1:]); mean = float(np.mean(ms_all[1:]))
     byts = es * n * n + es * (T + 2) * 2 * n
-    print(f"ld={ld} T={T:3d} {('q32->f32' if q32f else 'q32->f64') if q32 else np.dtype(dtype).name} best {best:8.3f} ms mean {mean:8.3f} ms  {byts/best/1e6:8.1f} GB/s  valu/pair~{2*T+5}", flush=True)
+    print(f"ld={ld} T={T:3d} {'q32->f64' if q32 else np.dtype(dtype).name} best {best:8.3f} ms mean {mean:8.3f} ms  {byts/best/1e6:8.1f} GB/s  valu/pair~{2*T+5}", flush=True)
