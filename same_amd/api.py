@@ -129,19 +129,21 @@ class _Staged:
 
 
 def _stage_prune(ref_df, aligned_df, commonCT, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
-                 ignore_precomputed_triangulation, verbose, ctx, prefetch):
+                 ignore_precomputed_triangulation, verbose, ctx, prefetch, fresh_frames=False):
+    """fresh_frames: the two frames were just cut out for this call (a window's subsets) and belong to nobody else, so the
+    helper columns can be added to a shallow copy instead of a deep one."""
     st = _Staged()
     st.verbose, st.commonCT = verbose, commonCT
     try:
         _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
-                          ignore_precomputed_triangulation, verbose, ctx, prefetch)
+                          ignore_precomputed_triangulation, verbose, ctx, prefetch, fresh_frames)
     except Exception as e:   # noqa: BLE001 -- re-raised unchanged by prepare_same_inputs when the window is run
         st.error = e
     return st
 
 
 def _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay_vertex_col, optim_params, gurobi_params,
-                      ignore_precomputed_triangulation, verbose, ctx, prefetch):
+                      ignore_precomputed_triangulation, verbose, ctx, prefetch, fresh_frames=False):
     optim_params = dict(optim_params or {})
     gurobi_params = dict(gurobi_params or {})
     # MetaCell duck-typing (src/same.py:891-899)
@@ -159,14 +161,13 @@ def _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay
     radius, knn = optim_params["radius"], optim_params["knn"]
 
     # size defaults, stable ids (src/same.py:934-970)
+    # only columns are ADDED below (size, __orig_idx, __tri_vid), never edited, so frames nobody else holds need no deep copy
+    aligned_df = aligned_df.copy(deep=not fresh_frames)
+    ref_df = ref_df.copy(deep=not fresh_frames)
     if "size" not in aligned_df.columns:
-        aligned_df = aligned_df.copy()
         aligned_df["size"] = 1
     if "size" not in ref_df.columns:
-        ref_df = ref_df.copy()
         ref_df["size"] = 1
-    aligned_df = aligned_df.copy()
-    ref_df = ref_df.copy()
     if "__orig_idx" not in aligned_df.columns:
         aligned_df["__orig_idx"] = aligned_df.index.to_numpy()
     if "__orig_idx" not in ref_df.columns:
@@ -606,7 +607,7 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
             if nxt not in ahead:
                 box = plan[nxt]["box"]
                 ahead[nxt] = _stage_prune(ref_rows.subset(*box), moving_rows.subset(*box), commonCT, None, None,
-                                          optim_params, gurobi_params, False, verbose, ctx, prefetch=True)
+                                          optim_params, gurobi_params, False, verbose, ctx, prefetch=True, fresh_frames=True)
         st = ahead.pop(q)
         try:
             yield w, prepare_same_inputs(None, None, commonCT, verbose=verbose, ctx=ctx, _staged=st)
@@ -621,23 +622,46 @@ def subset_data(df, x_min, x_max, y_min, y_max):
 
 class _WindowSubsetter:
     """subset_data for many boxes of one frame.  The reference evaluates four comparisons over the WHOLE frame for every
-    window (O(N * windows), src/same.py:521-526); here the rows are ordered by X once, a window's X range is two binary
-    searches, and only that slab is tested on Y.  The rows come back in frame order with their original labels, i.e. the
-    frame `subset_data` returns (NaN coordinates fall outside every box either way)."""
+    window (O(N * windows), src/same.py:521-526); here the rows are binned once into a uniform grid (counting sort by cell),
+    a window gathers the cells its box touches (one contiguous run per grid row) and only those rows are tested exactly.
+    The rows come back in frame order with their original labels, i.e. the frame `subset_data` returns (NaN / infinite
+    coordinates fall outside every box either way)."""
+
+    GRID = 256
 
     def __init__(self, df):
         self.df = df
-        x = df["X"].to_numpy(dtype=np.float64)
-        self.y = df["Y"].to_numpy(dtype=np.float64)
-        self.order = np.argsort(x)                        # NaN last; ties may come in any order (rows are re-sorted per box)
-        self.xs = x[self.order]
+        self.x = x = df["X"].to_numpy(dtype=np.float64)
+        self.y = y = df["Y"].to_numpy(dtype=np.float64)
+        ok = np.flatnonzero(np.isfinite(x) & np.isfinite(y))
+        self.nx = self.ny = 1
+        self.x0 = self.y0 = 0.0
+        self.inv = 1.0
+        if len(ok):
+            self.x0, self.y0 = float(x[ok].min()), float(y[ok].min())
+            extent = max(float(x[ok].max()) - self.x0, float(y[ok].max()) - self.y0)
+            if extent > 0.0:
+                self.inv = self.GRID / extent * (1.0 - 1e-12)
+                self.nx = self.ny = self.GRID
+        ix = np.minimum((x[ok] - self.x0) * self.inv, self.nx - 1).astype(np.int64)
+        iy = np.minimum((y[ok] - self.y0) * self.inv, self.ny - 1).astype(np.int64)
+        key = iy * self.nx + ix
+        order = np.argsort(key, kind="stable")
+        self.order = ok[order]
+        self.starts = np.searchsorted(key[order], np.arange(self.nx * self.ny + 1))
+
+    def _cell(self, v, v0, n):
+        c = np.floor((v - v0) * self.inv)
+        return int(min(max(c, 0), n - 1)) if c == c else 0
 
     def subset(self, x_min, x_max, y_min, y_max):
-        lo = np.searchsorted(self.xs, x_min, side="left")    # first x >= x_min
-        hi = np.searchsorted(self.xs, x_max, side="left")    # first x >= x_max
-        slab = self.order[lo:hi]
-        yy = self.y[slab]
-        rows = np.sort(slab[(yy >= y_min) & (yy < y_max)])
+        ix0, ix1 = self._cell(x_min, self.x0, self.nx), self._cell(x_max, self.x0, self.nx)
+        iy0, iy1 = self._cell(y_min, self.y0, self.ny), self._cell(y_max, self.y0, self.ny)
+        st, od = self.starts, self.order
+        runs = [od[st[iy * self.nx + ix0]: st[iy * self.nx + ix1 + 1]] for iy in range(iy0, iy1 + 1)]
+        cand = np.concatenate(runs) if runs else od[:0]
+        xx, yy = self.x[cand], self.y[cand]
+        rows = np.sort(cand[(xx >= x_min) & (xx < x_max) & (yy >= y_min) & (yy < y_max)])
         return self.df.iloc[rows]
 
 
@@ -733,7 +757,7 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
         pos_q, w_q = todo[q]
         rs, ms = subsets(w_q)
         ahead[q] = (rs, ms, _stage_prune(rs, ms, commonCT, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
-                                         ignore_precomputed_triangulation, True, None, prefetch=True))
+                                         ignore_precomputed_triangulation, True, None, prefetch=True, fresh_frames=True))
 
     for q, (pos, w) in enumerate(todo):
         window_outprefix = os.path.join(outprefix, f"window_{w['window_id']}") if outprefix else None
