@@ -645,7 +645,7 @@ class _WindowSubsetter:
                 self.nx = self.ny = self.GRID
         ix = np.minimum((x[ok] - self.x0) * self.inv, self.nx - 1).astype(np.int64)
         iy = np.minimum((y[ok] - self.y0) * self.inv, self.ny - 1).astype(np.int64)
-        key = iy * self.nx + ix
+        key = (iy * self.nx + ix).astype(np.uint16)     # GRID^2 cells fit 16 bits: numpy's stable sort of uint16 is a radix sort
         order = np.argsort(key, kind="stable")
         self.order = ok[order]
         self.starts = np.searchsorted(key[order], np.arange(self.nx * self.ny + 1))
