@@ -633,22 +633,26 @@ class _WindowSubsetter:
         self.df = df
         self.x = x = df["X"].to_numpy(dtype=np.float64)
         self.y = y = df["Y"].to_numpy(dtype=np.float64)
-        ok = np.flatnonzero(np.isfinite(x) & np.isfinite(y))
+        finite = np.isfinite(x) & np.isfinite(y)
+        ok = None if finite.all() else np.flatnonzero(finite)
+        xo, yo = (x, y) if ok is None else (x[ok], y[ok])
         self.nx = self.ny = 1
         self.x0 = self.y0 = 0.0
         self.inv = 1.0
-        if len(ok):
-            self.x0, self.y0 = float(x[ok].min()), float(y[ok].min())
-            extent = max(float(x[ok].max()) - self.x0, float(y[ok].max()) - self.y0)
+        if len(xo):
+            self.x0, self.y0 = float(xo.min()), float(yo.min())
+            extent = max(float(xo.max()) - self.x0, float(yo.max()) - self.y0)
             if extent > 0.0:
                 self.inv = self.GRID / extent * (1.0 - 1e-12)
                 self.nx = self.ny = self.GRID
-        ix = np.minimum((x[ok] - self.x0) * self.inv, self.nx - 1).astype(np.int64)
-        iy = np.minimum((y[ok] - self.y0) * self.inv, self.ny - 1).astype(np.int64)
+        ix = ((xo - self.x0) * self.inv).astype(np.int32)
+        iy = ((yo - self.y0) * self.inv).astype(np.int32)
+        np.minimum(ix, self.nx - 1, out=ix)
+        np.minimum(iy, self.ny - 1, out=iy)
         key = (iy * self.nx + ix).astype(np.uint16)     # GRID^2 cells fit 16 bits: numpy's stable sort of uint16 is a radix sort
         order = np.argsort(key, kind="stable")
-        self.order = ok[order]
-        self.starts = np.searchsorted(key[order], np.arange(self.nx * self.ny + 1))
+        self.order = order if ok is None else ok[order]
+        self.starts = np.concatenate(([0], np.cumsum(np.bincount(key, minlength=self.nx * self.ny))))
 
     def _cell(self, v, v0, n):
         c = np.floor((v - v0) * self.inv)
