@@ -161,39 +161,6 @@ def baseline_metric():
         return "cell-pairs/sec on 100k×100k cost build + edge-cross sweep; % HBM roofline"
 
 
-class HostTransport:
-    """Same interface as dist.RcclGroup for the candidate-list gather, through the host group (D2H, TCP all-gather, H2D).
-    A TRANSPORT fallback for when the RCCL communicator cannot be created (compute stays on the GPU); synchronous, so
-    nothing overlaps.  Reported in the JSON line when used."""
-
-    def __init__(self, ctx, group):
-        self.ctx, self.group, self.world, self.rank = ctx, group, group.world, group.rank
-
-    def allgather_dev(self, send_buf, recv_buf, send_bytes, send_offset=0):
-        import numpy as np
-
-        host = send_buf.download((send_bytes,), np.uint8, offset_bytes=send_offset)
-        recv_buf.upload(self.group.allgather_array(host))
-
-    def allgather_dev_async(self, send_buf, recv_buf, send_bytes):
-        self.allgather_dev(send_buf, recv_buf, send_bytes)
-
-    def allreduce_dev(self, buf, count, dtype, op):
-        import numpy as np
-        from same_amd import _lib
-
-        dt = {_lib.DT_U8: np.uint8, _lib.DT_I32: np.int32, _lib.DT_U64: np.uint64, _lib.DT_F64: np.float64}[dtype]
-        parts = self.group.allgather_array(buf.download((1, count), dt))
-        red = {_lib.OP_SUM: parts.sum(axis=0, dtype=dt), _lib.OP_MAX: parts.max(axis=0), _lib.OP_MIN: parts.min(axis=0)}[op]
-        buf.upload(np.ascontiguousarray(red, dtype=dt))
-
-    def wait(self):
-        pass
-
-    def close(self):
-        pass
-
-
 def dense_kernel_label(dtype, T):
     """The kernel csrc/cost.hip dispatches to for this dtype and type count."""
     name = "double" if dtype == "f64" else "float"
@@ -238,7 +205,7 @@ def run_rank(args):
     from scipy.spatial import Delaunay
 
     from same_amd import _lib, synth
-    from same_amd.dist import RcclGroup, ShardedSweeps, row_block
+    from same_amd.dist import HostTransport, RcclGroup, ShardedSweeps, row_block
     from same_amd.telemetry import GpuTelemetry
     from same_amd.triangles import cos_threshold
 

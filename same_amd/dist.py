@@ -112,6 +112,36 @@ class _NoGroup:
 RcclGather = RcclGroup  # round-1 name
 
 
+class HostTransport:
+    """RcclGroup's interface for device buffers, carried by a HostGroup instead (D2H, loopback TCP all-gather, H2D).
+    A TRANSPORT fallback for when the RCCL communicator cannot be created (e.g. several ranks sharing one GPU: RCCL refuses
+    duplicate devices) -- compute stays on the GPU; synchronous, so nothing overlaps.  bench.py reports it when used."""
+
+    def __init__(self, ctx, group):
+        self.ctx, self.group, self.world, self.rank = ctx, group, group.world, group.rank
+
+    def allgather_dev(self, send_buf, recv_buf, send_bytes, send_offset=0):
+        host = send_buf.download((send_bytes,), np.uint8, offset_bytes=send_offset)
+        recv_buf.upload(self.group.allgather_array(host))
+
+    def allgather_dev_async(self, send_buf, recv_buf, send_bytes):
+        self.allgather_dev(send_buf, recv_buf, send_bytes)
+
+    def allreduce_dev(self, buf, count, dtype, op):
+        dt = {_lib.DT_U8: np.uint8, _lib.DT_I32: np.int32, _lib.DT_U64: np.uint64, _lib.DT_F64: np.float64}[dtype]
+        parts = self.group.allgather_array(buf.download((1, count), dt))
+        red = {_lib.OP_SUM: parts.sum(axis=0, dtype=dt), _lib.OP_MAX: parts.max(axis=0), _lib.OP_MIN: parts.min(axis=0)}[op]
+        buf.upload(np.ascontiguousarray(red, dtype=dt))
+
+    def wait(self):
+        pass
+
+    def close(self):
+        pass
+
+
+
+
 # ---- cost build + prune over aligned-row blocks ----------------------------------------------------
 def hip_block_compute(ctx, A, R, axy, rxy, radius, knn, w):
     """Per-rank compute on the GPU: resident operands, prune + padded costs for one row block."""

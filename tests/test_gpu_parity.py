@@ -537,6 +537,81 @@ def test_sharded_sweeps_rccl_single_rank_and_block_forms(ops, oracle):
     ctx.close()
 
 
+def _sharded_device_worker(rank, world, rdv, out_dir):
+    """One rank of `world`, all on the one GPU: device-side sharded prune + cost and ShardedSweeps, exchanged through the host
+    transport (RCCL refuses several ranks on one device); every rank's complete outputs are written for the parent to check."""
+    import ctypes
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import numpy as np
+    from scipy.spatial import Delaunay
+    from same_amd import _lib, ops, synth
+    from same_amd.dist import HostGroup, HostTransport, ShardedSweeps, hip_block_compute, sharded_knn_cost_device
+
+    ctx = _lib.Context(0)
+    L, H = ctx.lib, ctx.handle
+    with HostGroup(rank, world, rdv_dir=rdv, timeout=300) as group:
+        comm = HostTransport(ctx, group)
+        ref = synth.make_cells(9000, 5, seed=3)
+        mov = synth.make_jittered(ref, seed=4, sigma=6.0)
+        n_m = len(mov["xy"])
+        compute = hip_block_compute(ctx, mov["types"], ref["types"], mov["xy"], ref["xy"], 25.0, 8, 1.0)
+        idx, cost = sharded_knn_cost_device(ctx, compute, n_m, 8, comm)          # row blocks of the cost build + prune
+        tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)
+        Tr = len(tris)
+        match = np.where(idx[:, 0] >= 0, idx[:, 0], -1).astype(np.int32)
+        match[::7] = -1
+        sign, _ = ops.tri_sign_weight(mov["xy"], None, tris, ctx=ctx)
+        sweep = ctypes.c_void_p()
+        ctx.check(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign.ctypes.data, ref["xy"].ctypes.data, len(ref["xy"]), n_m, None, 0,
+                                    ctypes.byref(sweep)), "bind")
+        dax, drx, dtris, dmatch = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"]), ctx.to_device(tris), ctx.to_device(match)
+        sh = ShardedSweeps(ctx, comm, sweep, dax, drx, dtris, Tr, n_m)           # triangle blocks of the three sweeps
+        checked, viol = sh.run(dmatch)
+        out = sh.download()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, cost=cost, checked=checked, viol=viol, match=match, tris=tris, sign=sign, **out)
+        group.barrier()
+        L.same_sweep_unbind(sweep)
+    ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_device_paths_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
+    """The DEVICE forms of the sharded cost build and of the sharded sweeps with 2 and 3 real ranks (one process each, sharing
+    this GPU, exchanging through the host transport): every rank ends up with the single-GPU outputs, equal to the oracle --
+    row blocks, triangle blocks, padded tails, gathers, OR / sum reductions and the rebuilt ascending list included."""
+    import multiprocessing as mp
+    import tempfile
+    from same_amd import synth
+
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory(prefix="same_rdv_gpu_") as rdv:
+        procs = [ctx.Process(target=_sharded_device_worker, args=(r, world, rdv, str(tmp_path))) for r in range(world)]
+        [p.start() for p in procs]
+        [p.join(600) for p in procs]
+        assert [p.exitcode for p in procs] == [0] * world
+    ref = synth.make_cells(9000, 5, seed=3)
+    mov = synth.make_jittered(ref, seed=4, sigma=6.0)
+    oidx, _, _ = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, 8)
+    rr, cc = np.nonzero(oidx >= 0)
+    ocost = oracle.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oidx[rr, cc])), 1.0)
+    for r in range(world):
+        o = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(o["idx"], oidx) and np.array_equal(o["cost"][rr, cc], ocost) and np.isinf(o["cost"][oidx < 0]).all()
+        tris, match, sign = o["tris"], o["match"], o["sign"]
+        och, oviol, oflag = oracle.orient_sweep(tris, sign, ref["xy"], match)
+        assert int(o["checked"]) == och and np.array_equal(o["viol"], oviol) and np.array_equal(o["flag"], oflag) and len(oviol) > 10
+        oe, otf, opf, oc = oracle.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
+        assert np.array_equal(o["edge"], oe) and np.array_equal(o["tri_flag"], otf) and np.array_equal(o["point_flag"], opf)
+        assert np.array_equal(o["counts"], oc)
+        ob, oa, om3, ofl = oracle.area_flip(mov["xy"], ref["xy"], tris, match)
+        assert np.array_equal(o["before"], ob) and np.array_equal(o["after"], oa, equal_nan=True)
+        assert np.array_equal(o["matched3"], om3) and np.array_equal(o["flipped"], ofl)
+
+
 @pytest.mark.parametrize("mode", ["auto", "grid", "brute"])
 def test_knn_index_equals_unindexed_prune(ops, oracle, mode, monkeypatch):
     """Caller-held index of the reference set (same_knn_index_build): pruning against it is bit-identical to the
