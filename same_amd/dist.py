@@ -81,8 +81,8 @@ class RcclGroup:
         """Order the compute stream after every gather issued so far (stream-side; the host does not block)."""
         self.ctx.check(self.ctx.lib.same_comm_wait(self.ctx.handle), "same_comm_wait")
 
-    def group(self):
-        """`with comm.group():` -- the collectives issued inside go to RCCL as one group (one fused launch)."""
+    def fused(self):
+        """`with comm.fused():` -- the collectives issued inside go to RCCL as one group (one fused launch)."""
         return _RcclGroupScope(self.ctx)
 
     def close(self):
@@ -313,7 +313,7 @@ class ShardedSweeps:
                                  self.before_l.ptr + 8 * off, self.after_l.ptr + 8 * off, self.m3_l.ptr + 3 * off,
                                  self.flip_l.ptr + off), "area_flip")
         g = self.comm
-        grouped = g.group if hasattr(g, "group") else _NoGroup      # a host transport has nothing to fuse
+        grouped = getattr(g, "fused", _NoGroup)                      # a host transport has nothing to fuse
         with grouped():    # seven arrays, one fused RCCL launch
             for loc, glob, width in ((self.flag_l, self.flag_g, 1), (self.edge_l, self.edge_g, 3), (self.tflag_l, self.tflag_g, 1),
                                      (self.m3_l, self.m3_g, 3), (self.flip_l, self.flip_g, 1), (self.before_l, self.before_g, 8),
