@@ -56,31 +56,40 @@ def find_knn_within_radius(aligned_df, ref_df, radius=25, knn=5, verbose=True, c
     return compact_pairs(aligned_df, ref_df, knn_pairs)
 
 
-def find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=5, verbose=True, ctx=None):
-    """Sequential by construction: `ref_points_matched` carries from one aligned row to the next
-    (src/knn_utils.py:28-65), so this pass stays on the host over the device-pruned lists."""
-    aligned_df, ref_df, all_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
-    axy, rxy = _xy(aligned_df), _xy(ref_df)
-    atype = aligned_df["cell_type"].to_numpy()
-    rtype = ref_df["cell_type"].to_numpy()
+def priority_filter(all_pairs, axy, rxy, atype, rtype):
+    """The pair filter of knn_utils.find_knn_with_cell_type_priority (src/knn_utils.py:28-65) on arrays.
+    -> (filtered pairs (n, 2) int64 in the reference's order, rows that kept one pair, rows that kept all).
+
+    The reference walks the aligned rows in ascending order carrying a set of already claimed references: a row whose NEAREST
+    reference has its cell type and is not yet claimed keeps only that pair and claims it; every other row keeps all its pairs.
+    Only nearest references are ever claimed, and only by such rows, so the walk has a closed form: among the rows whose
+    nearest reference j has their type, the first one (smallest row) gets j -- one `np.unique(..., return_index=True)`."""
     all_pairs = np.asarray(all_pairs, dtype=np.int64).reshape(-1, 2)
+    if len(all_pairs) == 0:
+        return all_pairs, 0, 0
     # the reference re-sorts each row by sqrt(dx^2+dy^2) with a stable sort (src/knn_utils.py:40-49)
     d = np.sqrt((axy[all_pairs[:, 0], 0] - rxy[all_pairs[:, 1], 0]) ** 2 + (axy[all_pairs[:, 0], 1] - rxy[all_pairs[:, 1], 1]) ** 2)
     order = np.lexsort((np.arange(len(d)), d, all_pairs[:, 0]))
     pi, pj = all_pairs[order, 0], all_pairs[order, 1]
-    starts = np.flatnonzero(np.r_[True, pi[1:] != pi[:-1]]) if len(pi) else np.array([], dtype=np.int64)
-    ends = np.r_[starts[1:], len(pi)] if len(pi) else starts
-    filtered, taken = [], set()
-    same_type = keep_all = 0
-    for s, e in zip(starts, ends):
-        i, j0 = int(pi[s]), int(pj[s])
-        if rtype[j0] == atype[i] and j0 not in taken:
-            filtered.append((i, j0))
-            taken.add(j0)
-            same_type += 1
-        else:
-            filtered.extend((i, int(j)) for j in pj[s:e])
-            keep_all += 1
+    starts = np.flatnonzero(np.r_[True, pi[1:] != pi[:-1]])
+    row_of_pair = np.cumsum(np.r_[True, pi[1:] != pi[:-1]]) - 1          # index into `starts` for every pair
+    nearest = pj[starts]
+    same = np.asarray(rtype)[nearest] == np.asarray(atype)[pi[starts]]
+    cand = np.flatnonzero(same)                                            # rows (in walk order) that may claim their nearest
+    _, first = np.unique(nearest[cand], return_index=True)                 # first row per claimed reference
+    winner = np.zeros(len(starts), bool)
+    winner[cand[first]] = True
+    keep = ~winner[row_of_pair]
+    keep[starts[winner]] = True                                            # a winning row keeps its nearest pair only
+    return np.column_stack((pi[keep], pj[keep])), int(winner.sum()), int(len(starts) - winner.sum())
+
+
+def find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=5, verbose=True, ctx=None):
+    """src/knn_utils.py:5-78: the radius / top-k prune, then the cell-type-priority filter over the pruned lists."""
+    aligned_df, ref_df, all_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+    pairs, same_type, keep_all = priority_filter(all_pairs, _xy(aligned_df), _xy(ref_df), aligned_df["cell_type"].to_numpy(),
+                                                 ref_df["cell_type"].to_numpy())
+    filtered = list(zip(pairs[:, 0].tolist(), pairs[:, 1].tolist()))       # a list of (i, j) tuples, as the reference returns
     if verbose:
         print(f"Total pairs after filtering: {len(filtered)}")
         # the reference divides unguarded here (src/knn_utils.py:76)

@@ -172,3 +172,46 @@ def test_merge_window_matches_unique_ref():
     d = pd.DataFrame({"window_id": [3, 1, 2], "Aligned_Cell_Num_Old": [7, 7, 7], "Ref_Cell_Num_Old": [9, 9, 9], "X": 0.0, "Y": 0.0,
                       "filtered_violation": [False, True, False]})
     assert merge_window_matches_unique_ref([d])["window_id"].tolist() == [2]
+
+
+def test_priority_filter_closed_form_equals_the_reference_walk():
+    """knn_utils.find_knn_with_cell_type_priority's pair filter (src/knn_utils.py:28-65) is written in the reference as a walk over
+    the aligned rows carrying a set of claimed references; same_amd.knn.priority_filter is its closed form.  Pinned against the
+    reference's own output on the three fixtures (`pairs_priority`) and against a literal restatement of the walk on 300 small
+    random cases with heavy distance ties."""
+    from conftest import frames_from_golden, load_golden
+    from same_amd.knn import priority_filter
+
+    for case in ("synthetic_example", "cfg1_500", "cfg2_small"):
+        g = load_golden(case)
+        a_df, r_df, _ = frames_from_golden(g)
+        na = a_df.iloc[g["kept_aligned"]].reset_index(drop=True)
+        nr = r_df.iloc[g["kept_ref"]].reset_index(drop=True)
+        got, one, all_ = priority_filter(g["pairs"], na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy(), na["cell_type"].to_numpy(),
+                                         nr["cell_type"].to_numpy())
+        assert np.array_equal(got, g["pairs_priority"]) and one + all_ == len(np.unique(g["pairs"][:, 0]))
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        n_m, n_r = (int(v) for v in rng.integers(1, 60, 2))
+        P = int(rng.integers(0, 400))
+        pairs = np.unique(np.column_stack((rng.integers(0, n_m, P), rng.integers(0, n_r, P))), axis=0).reshape(-1, 2)
+        rng.shuffle(pairs)
+        pairs = pairs[np.argsort(pairs[:, 0], kind="stable")]
+        axy, rxy = rng.integers(0, 6, (n_m, 2)).astype(float), rng.integers(0, 6, (n_r, 2)).astype(float)
+        at, rt = rng.integers(0, 3, n_m), rng.integers(0, 3, n_r)
+        got, one, all_ = priority_filter(pairs, axy, rxy, at, rt)
+        want, taken, n_one, n_all = [], set(), 0, 0
+        for i in (np.unique(pairs[:, 0]) if len(pairs) else []):
+            rows = [(q, int(j)) for q, (ii, j) in enumerate(pairs) if ii == i]
+            d = [np.sqrt((axy[i, 0] - rxy[j, 0]) ** 2 + (axy[i, 1] - rxy[j, 1]) ** 2) for _, j in rows]
+            js = [rows[z][1] for z in sorted(range(len(rows)), key=lambda z: (d[z], rows[z][0]))]   # stable sort by distance (:40-49)
+            if rt[js[0]] == at[i] and js[0] not in taken:                                          # :56-59
+                want.append((int(i), js[0]))
+                taken.add(js[0])
+                n_one += 1
+            else:                                                                                   # :64
+                want.extend((int(i), j) for j in js)
+                n_all += 1
+        assert [tuple(r) for r in got.tolist()] == want and (one, all_) == (n_one, n_all), trial
+    empty, a, b = priority_filter(np.array([]), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0), np.zeros(0))
+    assert len(empty) == 0 and (a, b) == (0, 0)
