@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--tail-stream", default="own", choices=("own", "shared"),
                     help="own: prune / costs / triangle maps / sweeps run on a second context (stream) beside the dense build; "
                          "shared: everything on one stream, strictly in order")
+    ap.add_argument("--dense", default="exact", choices=("exact", "q32"),
+                    help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
+                         "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:
@@ -308,6 +311,21 @@ def run_rank(args):
     dense_ms = []
 
     n_chunks = len(range(rb, re, chunk_rows))
+    use_q32 = args.dense == "q32"
+    if use_q32:
+        from same_amd import ops
+
+        if T > 32:
+            raise SystemExit("--dense q32 supports T <= 32")
+        q_off, q_l2 = ops.quantize_types(mov["types"], ref["types"])
+        dAq, dRq = ctx.alloc(mov["types"].size * 4), ctx.alloc(ref["types"].size * 4)
+        chk(L.same_quantize_u32_dev(H, dA.ptr, mov["types"].size, q_off, 2.0 ** q_l2, dAq.ptr), "quantize")
+        chk(L.same_quantize_u32_dev(H, dR.ptr, ref["types"].size, q_off, 2.0 ** q_l2, dRq.ptr), "quantize")
+
+    def dense_launch(c0, c1):
+        if use_q32:
+            return L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, c0, c1, 1.0, 2.0 ** -q_l2, 1e-6, dD.ptr, ld)
+        return L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, c0, c1, 1.0, dD.ptr, ld)
 
     def dense_all(T_=T, timed=None):
         """Enqueue the dense build of this rank's rows (strong mode: in chunks through the one buffer).  With `timed`, HIP
@@ -315,7 +333,7 @@ def run_rank(args):
         if timed is not None:
             chk(L.same_timer_start(H), "timer")
         for c0 in range(rb, re, chunk_rows):
-            chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T_, dax.ptr, drx.ptr, n_ref, c0, min(c0 + chunk_rows, re), 1.0, dD.ptr, ld), "dense")
+            chk(dense_launch(c0, min(c0 + chunk_rows, re)), "dense")
         if timed is not None:
             chk(L.same_timer_mark(H), "timer")
 
@@ -497,11 +515,16 @@ def run_rank(args):
         from oracle import same_oracle as orc
 
         if strong or extras:   # the resident block was reused by the probes above: rebuild this rank's first chunk for the check
-            chk(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, rb, min(rb + chunk_rows, re), 1.0, dD.ptr, ld), "dense")
+            chk(dense_launch(rb, min(rb + chunk_rows, re)), "dense")
             ctx.sync()
         S = min(args.cpu_sample_rows, rows, chunk_rows)
         c0 = time.perf_counter()
         want_dense = orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, 0, S)
+        exact_dense = want_dense
+        if use_q32:   # the fixed-point build is checked against ITS twin bit for bit, and against the exact costs within the tolerance
+            want_dense = orc.dense_cost_q32(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, q_off, q_l2, 0, S)
+            if float(np.max(np.abs(want_dense - exact_dense) / exact_dense)) > 1e-6:
+                raise SystemExit("fixed-point dense costs are outside 1e-6 relative of the exact ones: refusing to report a number")
         oi, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, S)
         rr, cc = np.nonzero(oi >= 0)
         want_pc = orc.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oi[rr, cc])), 1.0)
@@ -524,6 +547,9 @@ def run_rank(args):
         if not ok:
             raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
         parity = f"dense rows, pruned lists and pair costs of rows [0,{S}) and the orientation sweep equal the oracle bit-for-bit"
+        if use_q32:
+            parity = (f"dense rows of [0,{S}) equal the fixed-point build's oracle twin bit-for-bit and are within 1e-6 relative of the exact "
+                      f"fp64 costs on all {S} x {n_ref} pairs; pruned lists, pair costs and the orientation sweep equal the oracle bit-for-bit")
         note(group, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
         del want_dense
         # best-effort multi-core CPU lines: the dense sample split over host threads (ctypes releases the GIL),
@@ -585,14 +611,23 @@ def run_rank(args):
                 traffic = None
         achieved = dense_bytes / t_dense / 1e9
         valu_rate = (2 * T + 5) * float(n_ref) * rows_launch / t_dense / 1e12
-        roof = {"bound": "hbm", "kernel": dense_kernel_label("f64", T), "achieved": achieved, "peak": HBM_PEAK_GBS,
+        if use_q32:
+            dense_bytes = 8.0 * n_ref * rows_launch + (4.0 * T + 16.0) * (n_ref + rows_launch)
+            achieved = dense_bytes / t_dense / 1e9
+            traffic, traffic_src = None, "not collected for the fixed-point build"
+        roof = {"bound": "hbm", "kernel": f"dense_cost_q32_kernel<{T},double> (opt-in fixed-point build, --dense q32)" if use_q32 else dense_kernel_label("f64", T),
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src or "profiles/traffic.json (separate rocprofv3 --pmc passes: WRITE_SIZE + 2*FETCH_SIZE)",
                 "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3, "launches_timed": len(dense_ms),
                 # secondary ceiling: (2T+5) fp64 VALU lane-instructions per output against the vector issue peak
-                "valu_fp64": {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": valu_rate,
-                              "peak_Tinstr_s": FP64_ISSUE_PEAK_T, "frac": valu_rate / FP64_ISSUE_PEAK_T}}
+                "valu_fp64": None if use_q32 else {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": valu_rate,
+                                                   "peak_Tinstr_s": FP64_ISSUE_PEAK_T, "frac": valu_rate / FP64_ISSUE_PEAK_T}}
         msg = ["frac is against the 8.0 TB/s HBM spec as BASELINE.json asks"]
+        if use_q32:
+            msg.append("THIS LINE WAS RUN WITH --dense q32: the step's dense build is the opt-in fixed-point kernel (exact integer type sums on a "
+                       f"2^-{q_l2} grid, sums too small for the grid recomputed in fp64: every output within 1e-6 relative of the reference's "
+                       "fp64 cost, which is BASELINE.json's tolerance) -- not the reference's arithmetic; the default run reports the bit-exact kernel")
         if "ceilings" in extras:
             c = extras["ceilings"]
             c["frac_of_T0_store_rate"] = achieved / c["same_kernel_T0_store_only_GBs"]
@@ -609,9 +644,9 @@ def run_rank(args):
                 msg.append(f"while the kernel looped the board drew {pw['mean']:.0f} W in steady state (max {t['power']['max']:.0f} W"
                            + (f", cap {t['power_cap_w']:.0f} W" if t.get("power_cap_w") else "") + ")"
                            + (f" at a shader clock of {clk['mean']:.0f} MHz (min {clk['min']:.0f})" if clk else "")
-                           + f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
-                           + (f"{(2 * T + 5) * float(n_ref) * rows_launch / (1024 * 16 * clk['mean'] * 1e6) * 1e3:.1f} ms" if clk else "n/a")
-                           + f" of the {t_dense * 1e3:.1f} ms launch")
+                           + ("" if use_q32 else f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
+                              + (f"{(2 * T + 5) * float(n_ref) * rows_launch / (1024 * 16 * clk['mean'] * 1e6) * 1e3:.1f} ms" if clk else "n/a")
+                              + f" of the {t_dense * 1e3:.1f} ms launch"))
             else:
                 msg.append("board power / clock could not be read from sysfs on this box")
         if "sweep" in extras:
@@ -628,11 +663,12 @@ def run_rank(args):
             "metric": baseline_metric(),
             "value": pairs_per_step * args.steps / dt, "unit": "cell-pairs/s",
             "n_gpus": group.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f64" if use_q32 else "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: " + (f"ONE problem of {n_mov} aligned x {n_ref} ref cells, aligned-row blocks and triangle "
                                                            f"blocks over {group.world} rank(s), dense build in {chunk_rows}-row chunks"
                                                            if strong else f"{rows} aligned x {n_ref} ref cells per GPU")
-                                   + f", T={T} type cols, fp64 dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
+                                   + f", T={T} type cols, " + ("fixed-point (2^-%d grid, every output within 1e-6 relative of the fp64 one) " % q_l2 if use_q32 else "fp64 ")
+                                   + f"dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
                                      "triangles classify/sign + orientation / XY-order / area-flip sweeps",
                        "streams": ("dense build on one stream, prune / costs / triangle maps / sweeps on a second (own context)"
                                    if tctx is not ctx else "one stream, in order"),
