@@ -456,14 +456,14 @@ def run_rank(args):
                 b.free()
         # control: the opt-in fixed-point build at the bench's own T -- the same 80 GB of stores with the 2T fp64 adds replaced
         # by T integer v_sad_u32 (exact sums on a 2^-s grid; NOT the reference's arithmetic, never the reported kernel)
-        if T <= 32:
+        if T <= 32 and not use_q32:
             from same_amd import ops
 
             off, l2 = ops.quantize_types(mov["types"], ref["types"])
-            dAq, dRq = ctx.alloc(mov["types"].size * 4), ctx.alloc(ref["types"].size * 4)
-            chk(L.same_quantize_u32_dev(H, dA.ptr, mov["types"].size, off, 2.0 ** l2, dAq.ptr), "quantize")
-            chk(L.same_quantize_u32_dev(H, dR.ptr, ref["types"].size, off, 2.0 ** l2, dRq.ptr), "quantize")
-            t_q = timed_ms(lambda: L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0,
+            cAq, cRq = ctx.alloc(mov["types"].size * 4), ctx.alloc(ref["types"].size * 4)
+            chk(L.same_quantize_u32_dev(H, dA.ptr, mov["types"].size, off, 2.0 ** l2, cAq.ptr), "quantize")
+            chk(L.same_quantize_u32_dev(H, dR.ptr, ref["types"].size, off, 2.0 ** l2, cRq.ptr), "quantize")
+            t_q = timed_ms(lambda: L.same_dense_cost_q32_dev(H, cAq.ptr, cRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0,
                                                              2.0 ** -l2, 1e-6, dD.ptr, ld), "dense q32")
             by = 8.0 * n_ref * rows + (4.0 * T + 16.0) * (n_ref + rows)
             # its outputs against the bit-exact kernel's, on 16 sampled rows of this very run
@@ -479,8 +479,8 @@ def run_rank(args):
                                "note": f"fixed-point control, NOT the reference's arithmetic and not the kernel this line reports: type sums "
                                        f"exact on a 2^-{l2} grid (|error| <= {T * 2.0 ** -l2:.2e} absolute), sums too small for the grid "
                                        "recomputed in fp64, so every output is within 1e-6 relative of the bit-exact build by construction"})
-            dAq.free()
-            dRq.free()
+            cAq.free()
+            cRq.free()
         extras["sweep"] = sweep_rows
 
     # ---- CPU baseline leg (rank 0, N=1, untimed region): the oracle runs a bounded sample of the same workload on the
