@@ -301,6 +301,23 @@ def test_bench_contract_line(force_comm):
         assert q["opt_in"] is True and q["max_rel_diff_vs_exact_on_16_rows"] <= 1e-6
 
 
+def test_bench_step_with_the_fixed_point_dense_build():
+    """`bench.py --dense q32`: the step's dense build is the opt-in fixed-point kernel; the line says so (dtype, kernel name, note)
+    and its own check -- twin-equal and within 1e-6 relative of the exact costs on every sampled pair -- passed."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--dense", "q32",
+                          "--no-extras"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert out["dtype"] == "u32+f64" and "dense_cost_q32_kernel" in out["roofline"]["kernel"] and "--dense q32" in out["roofline"]["note"]
+    assert "within 1e-6 relative of the exact fp64 costs" in out["parity_spot_check"] and out["roofline"]["valu_fp64"] is None
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # The whole boundary functions against the REFERENCE'S OWN run_same / sliding_window_matching, both driven through the
 # same recording solver double (tests/golden/run_same_mock.npz, written by tools/gen_golden.py runsame).
