@@ -757,7 +757,7 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
         depth = qhull_pool.lookahead()
         qhull_pool.warm(min(depth, len(todo)))      # helpers start (import scipy) while the first window is being pruned
 
-    def stage(q):
+    def stage_window(q):
         pos_q, w_q = todo[q]
         rs, ms = subsets(w_q)
         ahead[q] = (rs, ms, _stage_prune(rs, ms, commonCT, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
@@ -774,7 +774,7 @@ def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_d
         else:
             for nxt in range(q, min(q + 1 + depth, len(todo))):
                 if nxt not in ahead:
-                    stage(nxt)
+                    stage_window(nxt)
             ref_subset, moving_subset, staged = ahead.pop(q)
             window_matches, _ = _run_same(ref_subset, moving_subset, commonCT, window_outprefix, moving_delaunay,
                                           moving_delaunay_vertex_col, optim_params, gurobi_params,
