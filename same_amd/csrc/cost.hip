@@ -333,6 +333,14 @@ __global__ __launch_bounds__(256) void quantize_u32_kernel(const double *__restr
     dst[i] = (uint32_t)q;
 }
 
+// the rare exact path of the fixed-point build (a type sum too small for the grid): kept out of line so that the row loop
+// stays small -- it runs for about one output per aligned row at most
+__device__ __attribute__((noinline)) double exact_type_sum(const double *__restrict__ ap, const double *__restrict__ rp, int T) {
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s = s + __builtin_fabs(ap[t] - rp[t]);
+    return s;
+}
+
 __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t r, uint32_t acc) {
     return (a > r ? a - r : r - a) + acc;   // selected as v_sad_u32 (checked in the ISA)
 }
@@ -376,19 +384,8 @@ __global__ __launch_bounds__(256) void dense_cost_q32_kernel(
     char *orow = reinterpret_cast<char *>(out + (i0 - row_begin) * ld);
     const unsigned lane_off = (unsigned)(j0 * sizeof(double));
     const int64_t row_pitch = ld * (int64_t)sizeof(double);
-    uint32_t a[TT];
-#pragma unroll
-    for (int t = 0; t < T; ++t) a[t] = arow[t];
-    double ax = axyrow[0], ay = axyrow[1];
-    for (int q = 0; q < rows_per_block; ++q) {
-        // next row's scalars are requested before this row is computed
-        const bool last = q + 1 >= rows_per_block;
-        const uint32_t *__restrict__ an_p = last ? arow : arow + T;
-        const double *__restrict__ axn_p = last ? axyrow : axyrow + 2;
-        uint32_t an[TT];
-#pragma unroll
-        for (int t = 0; t < T; ++t) an[t] = an_p[t];
-        const double axn = axn_p[0], ayn = axn_p[1];
+    // one output row: T integer SADs per column, the fp64 remainder, the guard, one 16-byte store
+    auto row = [&](const uint32_t (&a)[TT], double ax, double ay, int64_t i, char *dst) {
         uint32_t acc[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; ++c) acc[c] = 0u;
@@ -406,21 +403,37 @@ __global__ __launch_bounds__(256) void dense_cost_q32_kernel(
                 // a type sum this small cannot carry the relative tolerance on a grid (T grid steps of error against fewer than
                 // T / rel_tol steps of value): the reference's own fp64 expression instead -- near-identical cells, about one
                 // column per row when the sections are jittered copies, none for unrelated ones
-                const double *ap = A + (i0 + q) * (int64_t)T, *rp = R + jj[c] * (int64_t)T;
-                double s = 0.0;
-                for (int t = 0; t < T; ++t) s = s + __builtin_fabs(ap[t] - rp[t]);
-                v[c] = w * s + dcoef * dc;
+                v[c] = w * exact_type_sum(A + i * (int64_t)T, R + jj[c] * (int64_t)T, T) + dcoef * dc;
             }
         }
-        store16_nt_saddr(orow, lane_off, d2{v[0], v[1]});
-        orow += row_pitch;
-        arow += T;
-        axyrow += 2;
+        store16_nt_saddr(dst, lane_off, d2{v[0], v[1]});
+    };
+    // Rows go in pairs through two scalar register sets: while one row is computed from set A the next row's scalars are
+    // on their way into set B, and the other way round -- no copies between the sets (the one-set form spent 3.5e9 scalar
+    // moves per launch on them).
+    uint32_t a[TT], b2[TT];
 #pragma unroll
-        for (int t = 0; t < T; ++t) a[t] = an[t];
-        ax = axn;
-        ay = ayn;
+    for (int t = 0; t < T; ++t) a[t] = arow[t];
+    double ax = axyrow[0], ay = axyrow[1];
+    int q = 0;
+    for (; q + 1 < rows_per_block; q += 2) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) b2[t] = arow[T + t];
+        const double bx = axyrow[2], by = axyrow[3];
+        row(a, ax, ay, i0 + q, orow);
+        const bool more = q + 2 < rows_per_block;
+        const uint32_t *__restrict__ an_p = more ? arow + 2 * T : arow;
+        const double *__restrict__ axn_p = more ? axyrow + 4 : axyrow;
+#pragma unroll
+        for (int t = 0; t < T; ++t) a[t] = an_p[t];
+        ax = axn_p[0];
+        ay = axn_p[1];
+        row(b2, bx, by, i0 + q + 1, orow + row_pitch);
+        orow += 2 * row_pitch;
+        arow += 2 * T;
+        axyrow += 4;
     }
+    if (q < rows_per_block) row(a, ax, ay, i0 + q, orow);
 }
 
 template <typename F> __device__ __forceinline__ F inf_of();
