@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from same_amd import _lib, synth
 
 n = 100000
-lds = [100000, 100002, 100032, 100096, 100352, 100864, 102400, 131072]
+lds = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else [100000, 100002, 100032, 100096, 100352, 100864, 102400, 131072]
+tag = ' '.join(f'{k}={v}' for k, v in os.environ.items() if k.startswith('SAME_DENSE_'))
 ctx = _lib.Context(0); L, H = ctx.lib, ctx.handle
 ref = synth.make_cells(n, 1, seed=0); mov = synth.make_cells(n, 1, seed=1, side=ref["side"])
 dax, drx = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"])
@@ -26,4 +27,4 @@ for b in bufs:
         ms = t(lambda: L.same_dense_cost_f64_dev(H, dz.ptr, dz.ptr, 0, dax.ptr, drx.ptr, n, 0, n, 1.0, b.ptr, ld))
         res.append(f"ld={ld}: {ms:6.2f}")
     mm = t(lambda: L.same_dev_memset(H, b.ptr, 0, n * n * 8))
-    print(f"@{b.ptr:#x}  " + "  ".join(res) + f"  memset80GB {mm:6.2f}", flush=True)
+    print(f"{tag} @{b.ptr:#x}  " + "  ".join(res) + f"  memset80GB {mm:6.2f}", flush=True)
