@@ -93,7 +93,7 @@ int main() {
         for (size_t r = 0; r < refs.size(); ++r) {
             double g = pair_rate(va + (uint64_t)refs[r] * CH, va + (uint64_t)i * CH);
             lo_hi.push_back(g);
-            if (g < 5600.0 && found < 0) found = (int)r;       // threshold refined from the printed histogram if needed
+            if (g < 6350.0 && found < 0) found = (int)r;       // threshold refined from the printed histogram if needed
         }
         if (found < 0 && refs.size() < 6) { refs.push_back(i); found = (int)refs.size() - 1; }
         label[i] = found;
