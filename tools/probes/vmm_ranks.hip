@@ -128,9 +128,10 @@ int main() {
 
     // (3) the 100000 x 100000 fp64 matrix (80 GB) through a range mapped from one region vs round-robin over regions
     const uint64_t need = (100000ull * 800000ull + CH - 1) / CH;   // 75 chunks
-    auto run80 = [&](std::vector<int> order, const char *what) {
+    auto run80 = [&](std::vector<int> order, const char *what, size_t align = 0) {
         if (order.size() < need) { printf("  %s: not enough chunks (%zu)\n", what, order.size()); return; }
-        char *v2; CK(hipMemAddressReserve((void **)&v2, need * CH, 0, nullptr, 0));
+        char *v2; CK(hipMemAddressReserve((void **)&v2, need * CH, align, nullptr, 0));
+        printf("  [range at %p] ", (void *)v2);
         for (uint64_t i = 0; i < need; ++i) { CK(hipMemUnmap(va + (uint64_t)order[i] * CH, CH)); CK(hipMemMap(v2 + i * CH, CH, 0, h[order[i]], 0)); }
         CK(hipMemSetAccess(v2, need * CH, &acc, 1));
         const int rows = 100000, rpb2 = 256, ch2 = (rows + rpb2 - 1) / rpb2, nt2 = (800000 + 4095) / 4096;
@@ -143,6 +144,13 @@ int main() {
         CK(hipMemSetAccess(va, n * CH, &acc, 1));
         CK(hipMemAddressFree(v2, need * CH));
     };
+    {
+        std::vector<int> nat; for (int i = 0; i < n; ++i) nat.push_back(i);
+        run80(nat, "allocation order, align 0");
+        run80(nat, "allocation order, align 2 MiB", 2u << 20);
+        run80(nat, "allocation order, align 1 GiB", 1u << 30);
+        run80(nat, "allocation order, align 0 again");
+    }
     if (by.size() >= 3) {
         run80(by[0], "one region (A)");
         run80(by[1], "one region (B)");
