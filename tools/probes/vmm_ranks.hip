@@ -142,14 +142,11 @@ int main() {
         printf("  80 GB matrix, %-34s dense pattern %.2f ms (%.0f GB/s)   single front %.2f ms\n", what, ms, 80e9 / ms * 1e-6, lin);
         for (uint64_t i = 0; i < need; ++i) { CK(hipMemUnmap(v2 + i * CH, CH)); CK(hipMemMap(va + (uint64_t)order[i] * CH, CH, 0, h[order[i]], 0)); }
         CK(hipMemSetAccess(va, n * CH, &acc, 1));
-        CK(hipMemAddressFree(v2, need * CH));
+        // the range is left reserved on purpose: a freed range is handed out again and the next mapping did not take effect there
     };
     {
         std::vector<int> nat; for (int i = 0; i < n; ++i) nat.push_back(i);
         run80(nat, "allocation order, align 0");
-        run80(nat, "allocation order, align 2 MiB", 2u << 20);
-        run80(nat, "allocation order, align 1 GiB", 1u << 30);
-        run80(nat, "allocation order, align 0 again");
     }
     if (by.size() >= 3) {
         run80(by[0], "one region (A)");
