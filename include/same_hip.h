@@ -64,7 +64,18 @@ int same_ctx_pci_bus_id(same_ctx *ctx, char *out, size_t out_len);
 
 /* ---- device memory + timing (for resident operands and in-library kernel timing) ------ */
 int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr);
-int same_dev_free(same_ctx *ctx, void *dptr);
+int same_dev_free(same_ctx *ctx, void *dptr);   /* either kind of buffer */
+/* For LARGE STREAMING OUTPUTS (the dense cost matrix).  MI355X's HBM is three physical regions of 96 GiB and a streaming
+ * store confined to one of them runs ~20 % below one spread over two or three (profiles/r02_hbm_regions.md); hipMalloc
+ * places a buffer wherever its free lists point.  This call takes the memory in 1 GiB chunks through the virtual-memory
+ * API, finds each chunk's region by timed stores and maps the chunks round-robin over the regions into one contiguous
+ * range.  The result is used and freed like any same_dev_alloc buffer.  Costs ~10 ms per GiB once; may hold up to 32 GiB
+ * more than `bytes` while it looks for balance.  Buffers under 6 GiB, SAME_SPREAD=0 in the environment, or a card
+ * without that much free memory give a plain same_dev_alloc.
+ * out_info (may be NULL), SAME_SPREAD_INFO_LEN int64: [0] 1 = spread, 0 = plain; [1] GiB chunks mapped; [2..4] chunks from
+ * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s. */
+#define SAME_SPREAD_INFO_LEN 9
+int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t *out_info);
 int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);

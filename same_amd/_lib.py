@@ -24,6 +24,7 @@ UNIQUE_ID_BYTES = 128
 ABI_VERSION = 2
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
+SPREAD_INFO_LEN = 9                            # SAME_SPREAD_INFO_LEN
 MAX_KNN = 448
 MAX_TYPES = 4096
 
@@ -40,6 +41,7 @@ _PROTOTYPES = {
     "same_ctx_pci_bus_id": [c_vp, ctypes.c_char_p, c_sz],
     "same_dev_alloc": [c_vp, c_sz, ctypes.POINTER(c_vp)],
     "same_dev_free": [c_vp, c_vp],
+    "same_dev_alloc_spread": [c_vp, c_sz, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)],
     "same_h2d": [c_vp, c_vp, c_vp, c_sz],
     "same_d2h": [c_vp, c_vp, c_vp, c_sz],
     "same_dev_memset": [c_vp, c_vp, c_int, c_sz],
@@ -159,10 +161,18 @@ def as_c(a, dtype):
 class DeviceBuffer:
     """A block of HBM owned by a Context (same_dev_alloc)."""
 
-    def __init__(self, ctx, nbytes):
+    def __init__(self, ctx, nbytes, spread=False):
         self.ctx, self.nbytes = ctx, int(nbytes)
         p = c_vp()
-        ctx.check(ctx.lib.same_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(p)), "same_dev_alloc")
+        self.spread_info = None
+        if spread:
+            info = (c_i64 * SPREAD_INFO_LEN)()
+            ctx.check(ctx.lib.same_dev_alloc_spread(ctx.handle, self.nbytes, ctypes.byref(p), info), "same_dev_alloc_spread")
+            self.spread_info = {"spread": bool(info[0]), "chunks_gib": int(info[1]), "per_region": [int(info[2]), int(info[3]), int(info[4])],
+                                "straddling": int(info[5]), "examined": int(info[6]), "seconds": info[7] * 1e-6,
+                                "same_region_level_gbps": int(info[8])}
+        else:
+            ctx.check(ctx.lib.same_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(p)), "same_dev_alloc")
         self.ptr = p.value
 
     def upload(self, arr):
@@ -220,6 +230,10 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def alloc_spread(self, nbytes):
+        """A large streaming-output buffer laid over the card's HBM regions (same_dev_alloc_spread); `.spread_info` says how."""
+        return DeviceBuffer(self, nbytes, spread=True)
 
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)

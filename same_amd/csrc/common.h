@@ -22,6 +22,14 @@ enum Slot {
     SL_COUNT
 };
 
+// A buffer built by same_dev_alloc_spread (spread.hip): 1 GiB physical chunks mapped into one address range.
+struct same_spread_alloc {
+    char *va = nullptr;
+    size_t bytes = 0;
+    std::vector<void *> handles;   // hipMemGenericAllocationHandle_t of each GiB, in address order
+};
+void same_spread_release(same_spread_alloc &a);
+
 struct same_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -36,6 +44,7 @@ struct same_ctx {
     int cu_count = 0;
     ncclComm *comm = nullptr;
     int nranks = 1, rank = 0;
+    std::vector<same_spread_alloc> spread;
 };
 
 // Resident state of the lazy-constraint orientation sweep (same_sweep_bind): its own device blocks, so

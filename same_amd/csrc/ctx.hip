@@ -51,6 +51,7 @@ void same_ctx_destroy(same_ctx *ctx) {
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     for (int s = 0; s < SL_COUNT; ++s)
         if (ctx->slot[s]) (void)hipFree(ctx->slot[s]);
+    for (auto &a : ctx->spread) same_spread_release(a);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -111,6 +112,12 @@ int same_dev_free(same_ctx *ctx, void *dptr) {
     REQUIRE(ctx, ctx != nullptr);
     SAME_TRY(same_use(ctx));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->spread.size(); ++i)
+        if (ctx->spread[i].va == dptr) {   // a same_dev_alloc_spread buffer
+            same_spread_release(ctx->spread[i]);
+            ctx->spread.erase(ctx->spread.begin() + i);
+            return SAME_OK;
+        }
     if (dptr) HIP_TRY(ctx, hipFree(dptr));
     return SAME_OK;
 }

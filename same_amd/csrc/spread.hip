@@ -1,0 +1,277 @@
+// spread.hip -- HBM-region-aware allocation for the large streaming outputs of libsame_hip (the dense cost matrix).
+//
+// Measured on MI355X (profiles/r02_hbm_regions.md): the card's 288 GiB are three physical regions of 96 GiB, and a
+// streaming store confined to ONE region runs at ~5.5-5.8 TB/s while the same store spread over two or three regions runs
+// at ~7.0 TB/s.  hipMalloc hands an 80 GB buffer out of whatever regions its free lists hold, so the store time of the
+// 100k x 100k build moved between 11.4 and 14.4 ms from one allocation to the next (what round 1 read as a per-box
+// "store ceiling").  The regions are not visible in any address; they only show in timing.
+//
+// same_dev_alloc_spread therefore builds the buffer itself through the virtual-memory API: physical memory is taken in
+// 1 GiB chunks (hipMemCreate); every chunk is labelled by timing a store into it TOGETHER with a store into a reference
+// chunk of each region found so far (same region: slow level, different region: fast level, ~20 % apart); and the chunks
+// are mapped into one contiguous address range round-robin over the regions, so ANY access pattern -- the dense kernel's
+// eight XCD fronts, a single linear front, a copy -- is spread over the regions at all times.  Surplus chunks go back to
+// the driver.
+//
+// One rule found the hard way (tools/probes/vmm_remap.hip): on this ROCm a virtual address that has carried a mapping
+// keeps translating to the OLD chunk after hipMemUnmap + hipMemMap of another one, silently.  So every address here is
+// mapped at most once in the life of the process: labelling happens in a scratch range whose slots are used once, the final
+// range is fresh, and neither range is ever handed back with hipMemAddressFree (address space is the one thing in ample
+// supply: 2^47 bytes against a few hundred GiB per allocation).
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+constexpr size_t CHUNK = size_t(1) << 30;
+constexpr int MAX_REGIONS = 3;
+constexpr int MIXED = MAX_REGIONS;       // label of a chunk whose own two halves already run at the fast level (it straddles)
+constexpr size_t MIN_CHUNKS = 6;         // below this a plain allocation: nothing to spread
+constexpr double LEVEL_RATIO = 1.10;     // a rate above this multiple of the same-region level is the fast level (measured: ~1.2x)
+constexpr size_t MAX_SHARE_PERMILLE = 500;   // chosen chunks: no region above half (4+4 over two regions runs within 2 % of 3+3+2)
+constexpr size_t EXTRA_CHUNKS = 32;      // how far past the buffer's own chunks to look for a better balance
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// XCD share r (= blockIdx % 8, the hardware's round-robin) writes a quarter of the `span` bytes at a (r < 4) or at b
+// (r >= 4), `passes` times over: 256 KB rows, 64 rows per block, the same 4 KB-per-block store the dense kernels issue.
+constexpr uint64_t P_ROW = 1 << 18;
+constexpr int P_TILES = (int)(P_ROW / 4096), P_RPB = 64;
+__global__ __launch_bounds__(256) void spread_pair_kernel(char *a, char *b, uint64_t span, int passes) {
+    const unsigned share = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const unsigned tile = k % P_TILES, chunk = k / P_TILES;              // grid = 8 * P_TILES * (span / 4 / P_ROW / P_RPB)
+    char *p = (share < 4 ? a : b) + (uint64_t)(share & 3u) * (span / 4) + (uint64_t)chunk * P_RPB * P_ROW + (uint64_t)tile * 4096 + threadIdx.x * 16;
+    const v2d val = {0.0, 0.0};
+    for (int s = 0; s < passes; ++s) {
+        char *q = p;
+        for (int r = 0; r < P_RPB; ++r, q += P_ROW) __builtin_nontemporal_store(val, (v2d *)q);
+    }
+}
+
+struct Timer {
+    same_ctx *ctx;
+    int rc = SAME_OK;
+    // GB/s of writing `span` bytes at a and `span` bytes at b at once, 4 GiB in all per launch; best of three after one untimed
+    double rate(char *a, char *b, uint64_t span) {
+        const int passes = (int)(2 * CHUNK / span);
+        const unsigned grid = 8u * (unsigned)P_TILES * (unsigned)(span / 4 / P_ROW / P_RPB);
+        float best = 1e30f;
+        for (int r = 0; r < 4; ++r) {
+            if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
+            hipLaunchKernelGGL(spread_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, span, passes);
+            float ms = 0.f;
+            if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
+                hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }
+            if (r && ms < best) best = ms;
+        }
+        if (hipGetLastError() != hipSuccess) { rc = SAME_EIO; return 0.0; }
+        return 4.0 * (double)CHUNK / best * 1e-6;
+    }
+    double halves(char *a) { return rate(a, a + CHUNK / 2, CHUNK / 2); }   // a chunk against itself: the same-region level
+    double pair(char *a, char *b) { return rate(a, b, CHUNK); }
+};
+
+// Order in which to lay the chosen chunks: always the class with the most chunks left, but not the class just used when
+// another one still has chunks -- for counts (a, b, c) this is a, b, c, a, b, c ... until the smaller ones run out.
+std::vector<int> interleave(const std::vector<std::vector<int>> &by_class, const std::vector<size_t> &take) {
+    std::vector<size_t> left = take, pos(take.size(), 0);
+    std::vector<int> order;
+    int prev = -1;
+    for (;;) {
+        int pick = -1;
+        for (int c = 0; c < (int)left.size(); ++c)
+            if (left[c] && c != prev && (pick < 0 || left[c] > left[pick])) pick = c;
+        if (pick < 0 && prev >= 0 && left[prev]) pick = prev;
+        if (pick < 0) break;
+        order.push_back(by_class[pick][pos[pick]++]);
+        --left[pick];
+        prev = pick;
+    }
+    return order;
+}
+
+struct Chunk {
+    hipMemGenericAllocationHandle_t h;
+    char *at;          // scratch address while mapped there, else nullptr
+    double halves;     // first half against second half
+    int label;         // -1 until labelled
+};
+
+}  // namespace
+
+void same_spread_release(same_spread_alloc &a) {
+    for (size_t i = 0; i < a.handles.size(); ++i) {
+        (void)hipMemUnmap(a.va + i * CHUNK, CHUNK);
+        (void)hipMemRelease((hipMemGenericAllocationHandle_t)a.handles[i]);
+    }
+    a.handles.clear();   // the address range itself stays reserved for the life of the process (header comment)
+}
+
+extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t *out_info) {
+    REQUIRE(ctx, ctx && out_dptr);
+    SAME_TRY(same_use(ctx));
+    *out_dptr = nullptr;
+    int64_t info[SAME_SPREAD_INFO_LEN] = {};
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t n_need = (bytes + CHUNK - 1) / CHUNK;
+    const char *env = getenv("SAME_SPREAD");
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t reserve = size_t(4) << 30;                        // left to the rest of the process while labelling
+    const size_t budget = free_b > reserve ? (free_b - reserve) / CHUNK : 0;
+    // small buffers, an explicit opt-out, or a card without room for the chunks: the plain allocation
+    if ((env && env[0] == '0') || n_need < MIN_CHUNKS || budget < n_need) {
+        SAME_TRY(same_dev_alloc(ctx, bytes, out_dptr));
+        if (out_info) memcpy(out_info, info, sizeof info);
+        return SAME_OK;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+
+    char *scratch = nullptr;
+    HIP_TRY(ctx, hipMemAddressReserve((void **)&scratch, budget * CHUNK, size_t(2) << 20, nullptr, 0));
+    std::vector<Chunk> ch;
+    std::vector<int> refs;                                          // reference chunk of each region found so far
+    std::vector<std::vector<int>> by_class(MAX_REGIONS + 1);
+    std::vector<size_t> take(MAX_REGIONS + 1, 0);
+    Timer tm{ctx};
+    double slow = 0.0;                                              // same-region level (settle_level)
+    auto give_back = [&]() {
+        for (auto &c : ch) {
+            if (c.at) (void)hipMemUnmap(c.at, CHUNK);
+            (void)hipMemRelease(c.h);
+        }
+        ch.clear();
+    };
+    auto take_chunk = [&]() -> int {                                // 1 = got one, 0 = the driver has no more, < 0 = error
+        Chunk c{};
+        hipError_t e = hipMemCreate(&c.h, CHUNK, &prop, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+        c.at = scratch + ch.size() * CHUNK;                         // every scratch slot is used once
+        e = hipMemMap(c.at, CHUNK, 0, c.h, 0);
+        if (e == hipSuccess) e = hipMemSetAccess(c.at, CHUNK, &acc, 1);
+        if (e != hipSuccess) { (void)hipMemRelease(c.h); return same_fail(ctx, SAME_EIO, "hipMemMap/hipMemSetAccess (labelling a chunk)", e); }
+        c.halves = tm.halves(c.at);
+        c.label = -1;
+        if (tm.rc != SAME_OK) { (void)hipMemUnmap(c.at, CHUNK); (void)hipMemRelease(c.h); ctx->err = "timing a labelling store failed"; return tm.rc; }
+        ch.push_back(c);
+        return 1;
+    };
+    auto settle_level = [&]() {                                     // lower quartile of the halves rates: inside the same-region cluster
+        std::vector<double> v;
+        for (auto &c : ch) v.push_back(c.halves);
+        std::sort(v.begin(), v.end());
+        slow = v[v.size() / 4];
+    };
+    // timing noise only ever lowers a rate, so a reading under the threshold but well above the level is taken again
+    auto is_fast = [&](double g, char *a, char *b, uint64_t span) {
+        const double fast_above = slow * LEVEL_RATIO;
+        if (g < fast_above && g > slow * 1.04) g = std::max(g, tm.rate(a, b, span));
+        return g >= fast_above;
+    };
+    auto label_from = [&](size_t first) -> int {                    // label chunks [first, size) against the references
+        for (size_t i = first; i < ch.size(); ++i) {
+            Chunk &c = ch[i];
+            if (is_fast(c.halves, c.at, c.at + CHUNK / 2, CHUNK / 2)) c.label = MIXED;
+            else {
+                c.label = -1;
+                for (size_t r = 0; r < refs.size() && c.label < 0; ++r) {
+                    const double g = tm.pair(ch[refs[r]].at, c.at);
+                    if (tm.rc != SAME_OK) { ctx->err = "timing a labelling store failed"; return tm.rc; }
+                    if (!is_fast(g, ch[refs[r]].at, c.at, CHUNK)) c.label = (int)r;
+                }
+                if (c.label < 0) {
+                    if ((int)refs.size() < MAX_REGIONS) { refs.push_back((int)i); c.label = (int)refs.size() - 1; }
+                    else c.label = MIXED;                           // fast with all three references: treat as a straddler
+                }
+            }
+            by_class[c.label].push_back((int)i);
+        }
+        return SAME_OK;
+    };
+    auto choose = [&]() {                                           // water-fill: the most balanced n_need chunks of those labelled
+        std::fill(take.begin(), take.end(), 0);
+        size_t got = 0;
+        while (got < n_need) {
+            int best = -1;
+            for (int c = 0; c <= MAX_REGIONS; ++c)
+                if (take[c] < by_class[c].size() && (best < 0 || take[c] < take[best])) best = c;
+            if (best < 0) break;
+            ++take[best];
+            ++got;
+        }
+        return got;
+    };
+    auto lopsided = [&]() {
+        size_t mx = 0;
+        for (int c = 0; c < MAX_REGIONS; ++c) mx = std::max(mx, take[c]);
+        return mx * 1000 > MAX_SHARE_PERMILLE * n_need + 1000;
+    };
+
+    // 1. the chunks the buffer needs (the same-region level settles over these: most chunks lie inside one region);
+    // 2. label them; 3. while the best choice is lop-sided, take and label more, within the look-ahead and the card's memory
+    int got = 1;
+    while (got == 1 && ch.size() < n_need) got = take_chunk();
+    if (got < 0) { give_back(); return got; }
+    if (ch.size() < n_need) { give_back(); return same_fail(ctx, SAME_ENOMEM, "hipMemCreate (1 GiB chunks for a spread buffer)", hipErrorOutOfMemory); }
+    settle_level();
+    int rc = label_from(0);
+    if (rc != SAME_OK) { give_back(); return rc; }
+    while (choose() == n_need && lopsided() && ch.size() < budget && ch.size() < n_need + EXTRA_CHUNKS) {
+        got = take_chunk();
+        if (got < 0) { give_back(); return got; }
+        if (got == 0) break;
+        rc = label_from(ch.size() - 1);
+        if (rc != SAME_OK) { give_back(); return rc; }
+    }
+    choose();
+
+    // the final range, chunks laid round-robin over the regions
+    std::vector<int> order = interleave(by_class, take);
+    char *va = nullptr;
+    hipError_t e = hipMemAddressReserve((void **)&va, n_need * CHUNK, size_t(2) << 20, nullptr, 0);
+    if (e != hipSuccess) { give_back(); return same_fail(ctx, SAME_ENOMEM, "hipMemAddressReserve", e); }
+    same_spread_alloc out;
+    out.va = va;
+    out.bytes = n_need * CHUNK;
+    std::vector<char> used(ch.size(), 0);
+    for (size_t i = 0; i < order.size() && e == hipSuccess; ++i) {
+        Chunk &c = ch[order[i]];
+        e = hipMemUnmap(c.at, CHUNK);
+        c.at = nullptr;
+        if (e == hipSuccess) e = hipMemMap(va + i * CHUNK, CHUNK, 0, c.h, 0);
+        if (e == hipSuccess) { out.handles.push_back((void *)c.h); used[order[i]] = 1; }
+    }
+    if (e == hipSuccess) e = hipMemSetAccess(va, n_need * CHUNK, &acc, 1);
+    const size_t examined = ch.size();
+    for (size_t i = 0; i < ch.size(); ++i)
+        if (!used[i]) {
+            if (ch[i].at) (void)hipMemUnmap(ch[i].at, CHUNK);
+            (void)hipMemRelease(ch[i].h);
+        }
+    ch.clear();
+    if (e != hipSuccess) {
+        same_spread_release(out);
+        return same_fail(ctx, SAME_EIO, "hipMemMap/hipMemSetAccess (spread buffer)", e);
+    }
+    ctx->spread.push_back(out);
+    *out_dptr = va;
+    info[0] = 1;
+    info[1] = (int64_t)n_need;
+    for (int c = 0; c <= MAX_REGIONS; ++c) info[2 + c] = (int64_t)take[c];
+    info[6] = (int64_t)examined;
+    info[7] = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    info[8] = (int64_t)(slow + 0.5);
+    if (out_info) memcpy(out_info, info, sizeof info);
+    return SAME_OK;
+}
