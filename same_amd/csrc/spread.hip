@@ -37,18 +37,15 @@ constexpr size_t EXTRA_CHUNKS = 32;      // how far past the buffer's own chunks
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 // XCD share r (= blockIdx % 8, the hardware's round-robin) writes a quarter of the `span` bytes at a (r < 4) or at b
-// (r >= 4), `passes` times over: 256 KB rows, 64 rows per block, the same 4 KB-per-block store the dense kernels issue.
+// (r >= 4): 256 KB rows, 64 rows per block, the same 4 KB-per-block store the dense kernels issue.
 constexpr uint64_t P_ROW = 1 << 18;
 constexpr int P_TILES = (int)(P_ROW / 4096), P_RPB = 64;
-__global__ __launch_bounds__(256) void spread_pair_kernel(char *a, char *b, uint64_t span, int passes) {
-    const unsigned share = blockIdx.x & 7u, k = blockIdx.x >> 3;
-    const unsigned tile = k % P_TILES, chunk = k / P_TILES;              // grid = 8 * P_TILES * (span / 4 / P_ROW / P_RPB)
+__global__ __launch_bounds__(256) void spread_pair_kernel(char *a, char *b, uint64_t span, unsigned blocks_per_pass) {
+    const unsigned share = blockIdx.x & 7u, k = (blockIdx.x >> 3) % blocks_per_pass;   // the grid holds several passes, one after the other
+    const unsigned tile = k % P_TILES, chunk = k / P_TILES;              // blocks_per_pass = P_TILES * (span / 4 / P_ROW / P_RPB)
     char *p = (share < 4 ? a : b) + (uint64_t)(share & 3u) * (span / 4) + (uint64_t)chunk * P_RPB * P_ROW + (uint64_t)tile * 4096 + threadIdx.x * 16;
     const v2d val = {0.0, 0.0};
-    for (int s = 0; s < passes; ++s) {
-        char *q = p;
-        for (int r = 0; r < P_RPB; ++r, q += P_ROW) __builtin_nontemporal_store(val, (v2d *)q);
-    }
+    for (int r = 0; r < P_RPB; ++r, p += P_ROW) __builtin_nontemporal_store(val, (v2d *)p);
 }
 
 struct Timer {
@@ -56,12 +53,13 @@ struct Timer {
     int rc = SAME_OK;
     // GB/s of writing `span` bytes at a and `span` bytes at b at once, 4 GiB in all per launch; best of three after one untimed
     double rate(char *a, char *b, uint64_t span) {
-        const int passes = (int)(2 * CHUNK / span);
-        const unsigned grid = 8u * (unsigned)P_TILES * (unsigned)(span / 4 / P_ROW / P_RPB);
+        const unsigned passes = (unsigned)(2 * CHUNK / span);
+        const unsigned per_pass = (unsigned)P_TILES * (unsigned)(span / 4 / P_ROW / P_RPB);
+        const unsigned grid = 8u * per_pass * passes;
         float best = 1e30f;
         for (int r = 0; r < 4; ++r) {
             if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
-            hipLaunchKernelGGL(spread_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, span, passes);
+            hipLaunchKernelGGL(spread_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, span, per_pass);
             float ms = 0.f;
             if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
                 hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }

@@ -30,6 +30,7 @@ def rows(buf, r0, k):
 plain = ctx.alloc(n * n * 8)
 p0, pT, pm = t(build(plain, 0)), t(build(plain, T)), t(lambda: L.same_dev_memset(H, plain.ptr, 0, n * n * 8))
 probe_rows = [0, 1, n // 3, n // 2 + 7, n - 2]
+ctx.check(build(plain, T)(), "k"); ctx.sync()
 want = {r: rows(plain, r, 2) for r in probe_rows}          # T-type costs from the plain buffer
 print(f"plain  hipMalloc @{plain.ptr:#x}: T=0 {p0:6.2f} ms  T={T} {pT:6.2f} ms  memset {pm:6.2f} ms", flush=True)
 plain.free()
