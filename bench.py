@@ -243,7 +243,9 @@ def run_rank(args):
     dtris = ctx.to_device(tris)
     ld = (n_ref + 1) & ~1
     chunk_rows = max(1, min(max(rows, 1), int(STRONG_CHUNK_BYTES // (ld * 8)))) if strong else rows
-    dD = ctx.alloc(max(chunk_rows, 1) * ld * 8)            # the dense cost block (80 GB at dense100k)
+    # the dense cost block (80 GB at dense100k), laid over the card's three HBM regions: a streaming store confined to one
+    # region runs ~20 % below one spread over them, and a plain hipMalloc lands wherever the free lists point (spread.hip)
+    dD = ctx.alloc_spread(max(chunk_rows, 1) * ld * 8)
     didx, dcost, dcnt = tctx.alloc(block * k * 4), tctx.alloc(block * k * 8), tctx.alloc(max(block, 1) * 4)
     chk(L.same_dev_memset(TH, didx.ptr, 0xFF, didx.nbytes), "memset")   # rows past a short last block stay -1
     # caller-held grid index of the reference cells: built once, reused by every prune of the run
@@ -423,6 +425,21 @@ def run_rank(args):
         extras["ceilings"] = {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
                               "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
                               "measured": "after the timed loop, warm chip, mean of 5 launches each"}
+        # the same two stores into a plain hipMalloc buffer of this process, when the card has room for a second block
+        if dD.spread_info and dD.spread_info["spread"]:
+            try:
+                plain = ctx.alloc(rows * ld * 8)
+            except _lib.SameHipError:
+                plain = None
+            if plain is not None:
+                t_p = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, plain.ptr, ld), "dense T=0 (plain)")
+                t_pm = timed_ms(lambda: L.same_dev_memset(H, plain.ptr, 0, rows * ld * 8), "memset (plain)")
+                t_pT = None if use_q32 else timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, plain.ptr, ld), "dense (plain)")
+                extras["ceilings"]["plain_hipMalloc_buffer"] = {
+                    "same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_p / 1e9, "hipMemsetAsync_GBs": 8.0 * ld * rows / t_pm / 1e9,
+                    "bench_kernel_ms": None if t_pT is None else t_pT * 1e3,
+                    "what": "one hipMalloc of the same size in this process: its rate depends on which HBM regions the driver drew it from"}
+                plain.free()
         # operating point: loop the dense kernel alone for ~2 s while a side thread reads board power and shader clock
         tel = GpuTelemetry(ctx.pci_bus_id())
         if tel.available():
@@ -628,10 +645,21 @@ def run_rank(args):
             msg.append("THIS LINE WAS RUN WITH --dense q32: the step's dense build is the opt-in fixed-point kernel (exact integer type sums on a "
                        f"2^-{q_l2} grid, sums too small for the grid recomputed in fp64: every output within 1e-6 relative of the reference's "
                        "fp64 cost, which is BASELINE.json's tolerance) -- not the reference's arithmetic; the default run reports the bit-exact kernel")
+        roof["output_buffer"] = dD.spread_info
+        if dD.spread_info and dD.spread_info["spread"]:
+            si = dD.spread_info
+            msg.append(f"the cost block is {si['chunks_gib']} GiB mapped round-robin from the card's three HBM regions ({si['per_region']} GiB per region, "
+                       f"{si['straddling']} straddling; found by timed stores in {si['seconds']:.1f} s before the timed region): a streaming store confined to "
+                       "one region runs ~20 % below one spread over them")
         if "ceilings" in extras:
             c = extras["ceilings"]
             c["frac_of_T0_store_rate"] = achieved / c["same_kernel_T0_store_only_GBs"]
             roof["measured_ceilings"] = c
+            if "plain_hipMalloc_buffer" in c:
+                pb = c["plain_hipMalloc_buffer"]
+                msg.append(f"a plain hipMalloc buffer of the same size in this process: T=0 store {pb['same_kernel_T0_store_only_GBs']:.0f} GB/s, "
+                           f"hipMemsetAsync {pb['hipMemsetAsync_GBs']:.0f} GB/s"
+                           + (f", this kernel {pb['bench_kernel_ms']:.2f} ms" if pb.get("bench_kernel_ms") else ""))
             msg.append(f"on this box the same kernel with T=0 (same stores, 5 instead of {2 * T + 5} VALU ops per output) streams "
                        f"{c['same_kernel_T0_store_only_GBs']:.0f} GB/s and hipMemsetAsync {c['hipMemsetAsync_GBs']:.0f} GB/s, so the T={T} "
                        f"build runs at {c['frac_of_T0_store_rate']:.2f} of its own store-only rate")
