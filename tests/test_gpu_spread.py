@@ -51,7 +51,8 @@ def test_spread_buffer_holds_what_a_plain_one_holds(ctx):
     si = sp.spread_info
     assert si["spread"] is True and si["chunks_gib"] == 8
     assert sum(si["per_region"]) + si["straddling"] == 8 and si["examined"] >= 8
-    assert max(si["per_region"]) <= 5, si          # not all from one region (no region above half, within one chunk)
+    # no region above half (within one chunk) -- unless the card had nothing else within the look-ahead
+    assert max(si["per_region"]) <= 5 or si["examined"] >= 8 + 128, si
     _build(ctx, d, T, sp)
     got = _bands(sp)
     assert all(np.array_equal(g, w) for g, w in zip(got, want))
