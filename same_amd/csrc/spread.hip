@@ -109,24 +109,9 @@ void same_spread_release(same_spread_alloc &a) {
     a.handles.clear();   // the address range itself stays reserved for the life of the process (header comment)
 }
 
-extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t *out_info) {
-    REQUIRE(ctx, ctx && out_dptr);
-    SAME_TRY(same_use(ctx));
-    *out_dptr = nullptr;
-    int64_t info[SAME_SPREAD_INFO_LEN] = {};
+// The virtual-memory path proper.  Leaves nothing behind on failure (every chunk given back).
+static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_dptr, int64_t *info) {
     const auto t0 = std::chrono::steady_clock::now();
-    const size_t n_need = (bytes + CHUNK - 1) / CHUNK;
-    const char *env = getenv("SAME_SPREAD");
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-    const size_t reserve = size_t(4) << 30;                        // left to the rest of the process while labelling
-    const size_t budget = free_b > reserve ? (free_b - reserve) / CHUNK : 0;
-    // small buffers, an explicit opt-out, or a card without room for the chunks: the plain allocation
-    if ((env && env[0] == '0') || n_need < MIN_CHUNKS || budget < n_need) {
-        SAME_TRY(same_dev_alloc(ctx, bytes, out_dptr));
-        if (out_info) memcpy(out_info, info, sizeof info);
-        return SAME_OK;
-    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     hipMemAllocationProp prop = {};
@@ -271,6 +256,36 @@ extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dpt
     info[6] = (int64_t)examined;
     info[7] = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     info[8] = (int64_t)(slow + 0.5);
+    return SAME_OK;
+}
+
+extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t *out_info) {
+    REQUIRE(ctx, ctx && out_dptr);
+    SAME_TRY(same_use(ctx));
+    *out_dptr = nullptr;
+    int64_t info[SAME_SPREAD_INFO_LEN] = {};
+    const size_t n_need = (bytes + CHUNK - 1) / CHUNK;
+    const char *env = getenv("SAME_SPREAD");
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t reserve = size_t(4) << 30;                        // left to the rest of the process while labelling
+    const size_t budget = free_b > reserve ? (free_b - reserve) / CHUNK : 0;
+    // small buffers, an explicit opt-out, or a card without room for the chunks: the plain allocation.  So does a failure of
+    // the virtual-memory path itself (a driver without it, a sibling process taking the memory meanwhile): WHERE the buffer
+    // lies is a matter of speed, never of results, and the reason stays readable through same_last_error()
+    int rc = SAME_EIO;
+    if (!(env && env[0] == '0') && n_need >= MIN_CHUNKS && budget >= n_need) {
+        rc = spread_build(ctx, n_need, budget, out_dptr, info);
+        if (rc != SAME_OK) {
+            memset(info, 0, sizeof info);
+            *out_dptr = nullptr;
+        }
+    }
+    if (rc != SAME_OK) {
+        const std::string why = ctx->err;
+        SAME_TRY(same_dev_alloc(ctx, bytes, out_dptr));
+        ctx->err = why;
+    }
     if (out_info) memcpy(out_info, info, sizeof info);
     return SAME_OK;
 }
