@@ -25,6 +25,20 @@ __global__ __launch_bounds__(256) void multi_kernel(Bases b, int n_rows, int n_t
     for (int r = 0; r < rpb; ++r, p += row_bytes) __builtin_nontemporal_store(val, (v2d *)p);
 }
 
+// the same shape, reading: every lane sums its 16-byte loads (the sum is written once per block so the loads stay)
+__global__ __launch_bounds__(256) void multi_read_kernel(Bases b, int n_rows, int n_tiles, uint64_t row_bytes, int rpb, int chunks, double *sink) {
+    const unsigned region = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const int tile = (int)(k % n_tiles), chunk = (int)(k / n_tiles);
+    if (chunk >= chunks) return;
+    int r0 = chunk * rpb; if (r0 + rpb > n_rows) r0 = n_rows - rpb;
+    const uint64_t col = (uint64_t)tile * 4096 + threadIdx.x * 16;
+    if (col + 16 > row_bytes) return;
+    const char *p = b.p[region] + (uint64_t)r0 * row_bytes + col;
+    v2d acc = {0.0, 0.0};
+    for (int r = 0; r < rpb; ++r, p += row_bytes) acc += __builtin_nontemporal_load((const v2d *)p);
+    if (acc.x + acc.y == 12345.678) sink[blockIdx.x & 1023] = acc.x;
+}
+
 // the dense build's pattern (map 2: one contiguous share of the (chunk, tile) space per XCD)
 __global__ __launch_bounds__(256) void pattern_kernel(char *base, uint64_t pitch, int n_rows, int n_tiles, uint64_t row_bytes, int rpb,
                                                       int chunks, unsigned R, unsigned per) {
@@ -115,7 +129,17 @@ int main() {
             float ms = best_ms([&] { hipLaunchKernelGGL(multi_kernel, dim3(8 * n_tiles * w_chunks), dim3(256), 0, 0, B, w_rows, n_tiles, row_bytes, rpb, w_chunks); }, 6);
             printf("  8 GiB over %-28s %.3f ms  %.0f GB/s\n", what, ms, 8.0 * CH / ms * 1e-6);
         };
+        double *sink; CK(hipMalloc(&sink, 1024 * 8));
+        auto rspread = [&](std::vector<int> pick, const char *what) {
+            Bases B; for (int r = 0; r < 8; ++r) B.p[r] = va + (uint64_t)pick[r] * CH;
+            float ms = best_ms([&] { hipLaunchKernelGGL(multi_read_kernel, dim3(8 * n_tiles * w_chunks), dim3(256), 0, 0, B, w_rows, n_tiles, row_bytes, rpb, w_chunks, sink); }, 6);
+            printf("  8 GiB READ over %-23s %.3f ms  %.0f GB/s\n", what, ms, 8.0 * CH / ms * 1e-6);
+        };
         auto &A = by[0], &Bq = by[1], &C = by[2];
+        rspread({A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7]}, "one region (A)");
+        rspread({C[0], C[1], C[2], C[3], C[4], C[5], C[6], C[7]}, "one region (C)");
+        rspread({A[0], Bq[0], A[1], Bq[1], A[2], Bq[2], A[3], Bq[3]}, "two regions (A,B) 4+4");
+        rspread({A[0], Bq[0], C[0], A[1], Bq[1], C[1], A[2], Bq[2]}, "three regions 3+3+2");
         spread({A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7]}, "one region (A)");
         spread({Bq[0], Bq[1], Bq[2], Bq[3], Bq[4], Bq[5], Bq[6], Bq[7]}, "one region (B)");
         spread({C[0], C[1], C[2], C[3], C[4], C[5], C[6], C[7]}, "one region (C)");
