@@ -12,7 +12,8 @@ ctx = _lib.Context(0)
 L, H = ctx.lib, ctx.handle
 es = np.dtype(dtype).itemsize
 ld = int(os.environ.get("PROBE_LD", n))
-dD = ctx.alloc(n * ld * es)
+dD = ctx.alloc_spread(n * ld * es)   # over the HBM regions (SAME_SPREAD=0: plain hipMalloc)
+print("output buffer:", dD.spread_info, flush=True)
 for T in Ts:
     ref = synth.make_cells(n, max(T, 1), seed=0); mov = synth.make_cells(n, max(T, 1), seed=1, side=ref["side"])
     A = mov["types"][:, :T].astype(dtype); R = ref["types"][:, :T].astype(dtype)

@@ -13,7 +13,7 @@ ctx = _lib.Context(0)
 L, H = ctx.lib, ctx.handle
 tel = GpuTelemetry(ctx.pci_bus_id())
 ld = (n + 1) & ~1
-dD = ctx.alloc(n * ld * 8)
+dD = ctx.alloc_spread(n * ld * 8)   # over the HBM regions (SAME_SPREAD=0: plain hipMalloc)
 idle = None
 if tel.available():
     tel.start(); time.sleep(1.0); idle = tel.stop()
