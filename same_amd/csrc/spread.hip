@@ -158,9 +158,13 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
         slow = v[v.size() / 4];
     };
     // timing noise only ever lowers a rate, so a reading under the threshold but well above the level is taken again
+    static const bool debug = getenv("SAME_SPREAD_DEBUG") != nullptr;   // every rate read while labelling, on stderr
     auto is_fast = [&](double g, char *a, char *b, uint64_t span) {
         const double fast_above = slow * LEVEL_RATIO;
+        const double first = g;
         if (g < fast_above && g > slow * 1.04) g = std::max(g, tm.rate(a, b, span));
+        if (debug) fprintf(stderr, "[spread] %s rate %.0f%s vs level %.0f -> %s\n", span == CHUNK ? "pair" : "halves", first,
+                           g != first ? (" (again: " + std::to_string((int)g) + ")").c_str() : "", slow, g >= fast_above ? "fast" : "slow");
         return g >= fast_above;
     };
     auto label_from = [&](size_t first) -> int {                    // label chunks [first, size) against the references
