@@ -30,7 +30,8 @@ constexpr size_t CHUNK = size_t(1) << 30;
 constexpr int MAX_REGIONS = 3;
 constexpr int MIXED = MAX_REGIONS;       // label of a chunk whose own two halves already run at the fast level (it straddles)
 constexpr size_t MIN_CHUNKS = 6;         // below this a plain allocation: nothing to spread
-constexpr double LEVEL_RATIO = 1.10;     // a rate above this multiple of the same-region level is the fast level (measured: ~1.2x)
+constexpr double LEVEL_RATIO = 1.12;     // a rate above this multiple of the same-region level is the fast level (measured: same
+                                         // region 0.95-1.08x of the level, other region 1.18-1.27x: profiles/r02_spread_levels.log)
 constexpr size_t MAX_SHARE_PERMILLE = 500;   // chosen chunks: no region above half (4+4 over two regions runs within 2 % of 3+3+2)
 constexpr size_t EXTRA_CHUNKS = 128;     // how far past the buffer's own chunks to look for balance: the driver hands chunks out in
                                          // runs of up to a whole region (96), and a chunk costs ~10 ms to take and label
