@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "spread_plan.h"
 
 namespace {
 
@@ -73,25 +74,6 @@ struct Timer {
     double halves(char *a) { return rate(a, a + CHUNK / 2, CHUNK / 2); }   // a chunk against itself: the same-region level
     double pair(char *a, char *b) { return rate(a, b, CHUNK); }
 };
-
-// Order in which to lay the chosen chunks: always the class with the most chunks left, but not the class just used when
-// another one still has chunks -- for counts (a, b, c) this is a, b, c, a, b, c ... until the smaller ones run out.
-std::vector<int> interleave(const std::vector<std::vector<int>> &by_class, const std::vector<size_t> &take) {
-    std::vector<size_t> left = take, pos(take.size(), 0);
-    std::vector<int> order;
-    int prev = -1;
-    for (;;) {
-        int pick = -1;
-        for (int c = 0; c < (int)left.size(); ++c)
-            if (left[c] && c != prev && (pick < 0 || left[c] > left[pick])) pick = c;
-        if (pick < 0 && prev >= 0 && left[prev]) pick = prev;
-        if (pick < 0) break;
-        order.push_back(by_class[pick][pos[pick]++]);
-        --left[pick];
-        prev = pick;
-    }
-    return order;
-}
 
 struct Chunk {
     hipMemGenericAllocationHandle_t h;
@@ -188,24 +170,15 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
         }
         return SAME_OK;
     };
-    auto choose = [&]() {                                           // water-fill: the most balanced n_need chunks of those labelled
-        std::fill(take.begin(), take.end(), 0);
+    auto choose = [&]() {                                           // the most balanced n_need chunks of those labelled
+        std::vector<size_t> have;
+        for (auto &v : by_class) have.push_back(v.size());
+        take = spread_plan::water_fill(have, n_need);
         size_t got = 0;
-        while (got < n_need) {
-            int best = -1;
-            for (int c = 0; c <= MAX_REGIONS; ++c)
-                if (take[c] < by_class[c].size() && (best < 0 || take[c] < take[best])) best = c;
-            if (best < 0) break;
-            ++take[best];
-            ++got;
-        }
+        for (size_t t : take) got += t;
         return got;
     };
-    auto lopsided = [&]() {
-        size_t mx = 0;
-        for (int c = 0; c < MAX_REGIONS; ++c) mx = std::max(mx, take[c]);
-        return mx * 1000 > MAX_SHARE_PERMILLE * n_need + 1000;
-    };
+    auto lopsided = [&]() { return spread_plan::lopsided(take, MAX_REGIONS, n_need, MAX_SHARE_PERMILLE); };
 
     // 1. the chunks the buffer needs (the same-region level settles over these: most chunks lie inside one region);
     // 2. label them; 3. while the best choice is lop-sided, take and label more, within the look-ahead and the card's memory
@@ -226,7 +199,7 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     choose();
 
     // the final range, chunks laid round-robin over the regions
-    std::vector<int> order = interleave(by_class, take);
+    std::vector<int> order = spread_plan::interleave(by_class, take);
     char *va = nullptr;
     hipError_t e = hipMemAddressReserve((void **)&va, n_need * CHUNK, size_t(2) << 20, nullptr, 0);
     if (e != hipSuccess) { give_back(); return same_fail(ctx, SAME_ENOMEM, "hipMemAddressReserve", e); }
