@@ -19,6 +19,7 @@
 // range is fresh, and neither range is ever handed back with hipMemAddressFree (address space is the one thing in ample
 // supply: 2^47 bytes against a few hundred GiB per allocation).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 
@@ -34,6 +35,7 @@ constexpr size_t MIN_CHUNKS = 6;         // below this a plain allocation: nothi
 constexpr double LEVEL_RATIO = 1.12;     // a rate above this multiple of the same-region level is the fast level (measured: same
                                          // region 0.95-1.08x of the level, other region 1.18-1.27x: profiles/r02_spread_levels.log)
 constexpr size_t MAX_SHARE_PERMILLE = 500;   // chosen chunks: no region above half (4+4 over two regions runs within 2 % of 3+3+2)
+constexpr size_t VA_BUDGET = size_t(32) << 40;   // address space this process may spend on spread buffers, in all (of 2^47)
 constexpr size_t EXTRA_CHUNKS = 128;     // how far past the buffer's own chunks to look for balance: the driver hands chunks out in
                                          // runs of up to a whole region (96), and a chunk costs ~10 ms to take and label
 
@@ -105,8 +107,16 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
 
+    // Address ranges are never handed back (header comment), so the process has a budget of them: a long-lived process that
+    // allocates and frees spread buffers for ever ends up on the plain allocation instead of running out of address space.
+    static std::atomic<size_t> va_used{0};
+    const size_t slots = std::min(budget, n_need + EXTRA_CHUNKS);   // most chunks this call can examine
+    if (va_used.fetch_add((slots + n_need) * CHUNK) + (slots + n_need) * CHUNK > VA_BUDGET) {
+        ctx->err = "address-space budget for spread buffers is used up (ranges are never reused); plain allocation";
+        return SAME_ENOMEM;
+    }
     char *scratch = nullptr;
-    HIP_TRY(ctx, hipMemAddressReserve((void **)&scratch, budget * CHUNK, size_t(2) << 20, nullptr, 0));
+    HIP_TRY(ctx, hipMemAddressReserve((void **)&scratch, slots * CHUNK, size_t(2) << 20, nullptr, 0));
     std::vector<Chunk> ch;
     std::vector<int> refs;                                          // reference chunk of each region found so far
     std::vector<std::vector<int>> by_class(MAX_REGIONS + 1);
@@ -189,7 +199,7 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     settle_level();
     int rc = label_from(0);
     if (rc != SAME_OK) { give_back(); return rc; }
-    while (choose() == n_need && lopsided() && ch.size() < budget && ch.size() < n_need + EXTRA_CHUNKS) {
+    while (choose() == n_need && lopsided() && ch.size() < slots) {
         got = take_chunk();
         if (got < 0) { give_back(); return got; }
         if (got == 0) break;
