@@ -72,7 +72,8 @@ int same_dev_free(same_ctx *ctx, void *dptr);   /* either kind of buffer */
  * range.  The result is used and freed like any same_dev_alloc buffer.  Costs ~10 ms per GiB once; may hold up to 128 GiB
  * more than `bytes` for up to ~1.5 s while it looks for chunks of a second region.  Buffers under 6 GiB, SAME_SPREAD=0 in the environment, a card
  * without that much free memory, or a failure of the virtual-memory calls themselves give a plain same_dev_alloc (placement is a
- * matter of speed, never of results; out_info[0] says which it was).
+ * matter of speed, never of results; out_info[0] says which it was).  Address ranges of spread buffers are never reused (a ROCm
+ * mapping quirk, see spread.hip); a process may spend 32 TiB of its 128 TiB address space on them, after which the plain allocation is used.
  * out_info (may be NULL), SAME_SPREAD_INFO_LEN int64: [0] 1 = spread, 0 = plain; [1] GiB chunks mapped; [2..4] chunks from
  * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s. */
 #define SAME_SPREAD_INFO_LEN 9
