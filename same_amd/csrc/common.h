@@ -58,8 +58,13 @@ struct same_sweep {
     int32_t *pairs = nullptr;     // [P][2]
     int32_t *match = nullptr, *pidx = nullptr;  // [n_m]
     uint8_t *flag = nullptr;      // [Tr rounded up to 256]
-    int32_t *viol = nullptr;      // [Tr]
-    unsigned long long *mask = nullptr, *cnt = nullptr;
+    // one block: cnt[2] = {checked, flipped}, then viol[Tr] -- so the counters and the head of the ascending flipped list
+    // come back in ONE device-to-host copy
+    unsigned long long *cnt = nullptr;
+    int32_t *viol = nullptr;      // = (int32_t *)(cnt + 2)
+    unsigned long long *mask = nullptr;
+    hipGraphExec_t orient_graph = nullptr;   // memset + flag kernel + compaction + read-back of a whole-list sweep from s->match
+    hipGraph_t orient_graph_src = nullptr;
     double *x = nullptr;          // [P]
 };
 

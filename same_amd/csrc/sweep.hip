@@ -268,6 +268,33 @@ int launch_orient_flags(same_sweep *s, const int32_t *dmatch, int64_t t_begin, i
 
 // ascending list of flipped triangles + counters from a complete flag array (the single-GPU sweep's own flags,
 // or the all-gathered flags of a triangle-block sharded sweep)
+// How many entries of the flipped list travel with the counters in the first read-back (through the context's pinned block)
+constexpr int64_t VIOL_HEAD = 4096;
+inline size_t head_bytes(const same_sweep *s) { return 2 * sizeof(unsigned long long) + (size_t)std::min<int64_t>(s->Tr, VIOL_HEAD) * sizeof(int32_t); }
+
+// after the compaction kernel: counters + head of the list in one copy, the rest of a long list in a second one
+int read_back(same_sweep *s, bool copy_enqueued, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol) {
+    same_ctx *ctx = s->ctx;
+    unsigned char *h = static_cast<unsigned char *>(ctx->pinned);
+    if (!copy_enqueued) HIP_TRY(ctx, hipMemcpyAsync(h, s->cnt, head_bytes(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long c[2];
+    memcpy(c, h, sizeof c);
+    *out_checked = (int64_t)c[0];
+    *out_nviol = (int64_t)c[1];
+    if (c[1] && out_viol_idx) {
+        const int64_t head = std::min<int64_t>((int64_t)c[1], VIOL_HEAD);
+        memcpy(out_viol_idx, h + sizeof c, (size_t)head * sizeof(int32_t));
+        if ((int64_t)c[1] > head) {
+            SAME_TRY(same_down(ctx, out_viol_idx + head, s->viol + head, (size_t)((int64_t)c[1] - head) * sizeof(int32_t)));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    return SAME_OK;
+}
+
+// ascending list of flipped triangles + counters from a complete flag array (the single-GPU sweep's own flags,
+// or the all-gathered flags of a triangle-block sharded sweep)
 int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, int64_t *out_checked, int32_t *out_viol_idx,
                        int64_t *out_nviol) {
     same_ctx *ctx = s->ctx;
@@ -279,15 +306,38 @@ int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, in
     }
     hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->mask, n_words, Tr, s->viol, s->cnt);
     HIP_TRY(ctx, hipGetLastError());
-    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
-    SAME_TRY(same_down(ctx, h, s->cnt, 2 * sizeof(unsigned long long)));
+    return read_back(s, false, out_checked, out_viol_idx, out_nviol);
+}
+
+// The per-incumbent sweep from the handle's own match block is the launch-bound inner loop of the path (the solver calls it
+// for every incumbent): its five stream operations -- counter memset, flag kernel, compaction, read-back -- are captured
+// once per handle and replayed as one graph launch.  SAME_SWEEP_GRAPH=0 keeps the plain launches (for measuring the two).
+int orient_graph_build(same_sweep *s) {
+    same_ctx *ctx = s->ctx;
+    const int64_t Tr = s->Tr, n_words = ceil_div(Tr, 64);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *out_checked = (int64_t)h[0];
-    *out_nviol = (int64_t)h[1];
-    if (h[1] && out_viol_idx) {
-        SAME_TRY(same_down(ctx, out_viol_idx, s->viol, (size_t)h[1] * sizeof(int32_t)));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, s->tris, Tr, s->sign, s->rxy, s->match,
+                           s->flag, s->mask, s->cnt);
+        hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->mask, n_words, Tr, s->viol, s->cnt);
+        e = hipMemcpyAsync(ctx->pinned, s->cnt, head_bytes(s), hipMemcpyDeviceToHost, ctx->stream);
     }
+    hipGraph_t g = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &g);   // always end the capture, whatever happened inside it
+    if (e != hipSuccess || e_end != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        return same_fail(ctx, SAME_EIO, "stream capture of the orientation sweep", e != hipSuccess ? e : e_end);
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return same_fail(ctx, SAME_EIO, "hipGraphInstantiate (orientation sweep)", e);
+    }
+    s->orient_graph_src = g;
+    s->orient_graph = x;
     return SAME_OK;
 }
 
@@ -297,6 +347,12 @@ int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32
     *out_checked = 0;
     *out_nviol = 0;
     if (s->Tr == 0) return SAME_OK;
+    static const bool use_graph = !(getenv("SAME_SWEEP_GRAPH") && getenv("SAME_SWEEP_GRAPH")[0] == '0');
+    if (use_graph && dmatch == s->match && !out_flag && head_bytes(s) <= ctx->pinned_bytes) {
+        if (!s->orient_graph) SAME_TRY(orient_graph_build(s));
+        HIP_TRY(ctx, hipGraphLaunch(s->orient_graph, ctx->stream));
+        return read_back(s, true, out_checked, out_viol_idx, out_nviol);
+    }
     HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
     SAME_TRY(launch_orient_flags(s, dmatch, 0, s->Tr, s->flag, s->mask, s->cnt));
     if (out_flag) SAME_TRY(same_down(ctx, out_flag, s->flag, (size_t)s->Tr));
@@ -321,9 +377,9 @@ int sweep_fill(same_sweep *s, const int32_t *tris, const int8_t *src_sign, const
     SAME_TRY(sweep_block<int32_t>(ctx, &s->match, (size_t)s->n_m, nullptr));
     SAME_TRY(sweep_block<int32_t>(ctx, &s->pidx, (size_t)s->n_m, nullptr));
     SAME_TRY(sweep_block<uint8_t>(ctx, &s->flag, (size_t)ceil_div(s->Tr, 256) * 256 + 256, nullptr));
-    SAME_TRY(sweep_block<int32_t>(ctx, &s->viol, (size_t)s->Tr, nullptr));
     SAME_TRY(sweep_block<unsigned long long>(ctx, &s->mask, (size_t)ceil_div(s->Tr, 256) * 4 + 4, nullptr));
-    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->cnt, 4, nullptr));
+    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->cnt, 2 + (size_t)(s->Tr + 1) / 2 + 2, nullptr));   // counters, then the list
+    s->viol = reinterpret_cast<int32_t *>(s->cnt + 2);
     SAME_TRY(sweep_block<double>(ctx, &s->x, (size_t)s->P, nullptr));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;
@@ -360,7 +416,9 @@ void same_sweep_unbind(same_sweep *s) {
     same_ctx *ctx = s->ctx;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->viol, s->mask, s->cnt, s->x};
+    if (s->orient_graph) (void)hipGraphExecDestroy(s->orient_graph);
+    if (s->orient_graph_src) (void)hipGraphDestroy(s->orient_graph_src);
+    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->mask, s->cnt, s->x};   // viol lives in cnt's block
     for (void *b : blocks)
         if (b) (void)hipFree(b);
     delete s;
