@@ -310,8 +310,10 @@ int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, in
 }
 
 // The per-incumbent sweep from the handle's own match block is the launch-bound inner loop of the path (the solver calls it
-// for every incumbent): its five stream operations -- counter memset, flag kernel, compaction, read-back -- are captured
-// once per handle and replayed as one graph launch.  SAME_SWEEP_GRAPH=0 keeps the plain launches (for measuring the two).
+// for every incumbent).  Its four stream operations -- counter memset, flag kernel, compaction, read-back -- can be captured
+// once per handle and replayed as one graph launch (SAME_SWEEP_GRAPH=1).  Measured at BASELINE cfg 3 scale (95k triangles,
+// profiles/r02_sweep_latency.log): 61 us per call with the plain launches, 69 us replayed as a graph -- hipGraphLaunch costs
+// more than four enqueues on this ROCm -- so the plain launches are the default and the graph stays an opt-in that is tested.
 int orient_graph_build(same_sweep *s) {
     same_ctx *ctx = s->ctx;
     const int64_t Tr = s->Tr, n_words = ceil_div(Tr, 64);
@@ -347,7 +349,7 @@ int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32
     *out_checked = 0;
     *out_nviol = 0;
     if (s->Tr == 0) return SAME_OK;
-    static const bool use_graph = !(getenv("SAME_SWEEP_GRAPH") && getenv("SAME_SWEEP_GRAPH")[0] == '0');
+    static const bool use_graph = getenv("SAME_SWEEP_GRAPH") && getenv("SAME_SWEEP_GRAPH")[0] == '1';
     if (use_graph && dmatch == s->match && !out_flag && head_bytes(s) <= ctx->pinned_bytes) {
         if (!s->orient_graph) SAME_TRY(orient_graph_build(s));
         HIP_TRY(ctx, hipGraphLaunch(s->orient_graph, ctx->stream));
