@@ -11,7 +11,7 @@ int main() {
     hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
     hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
     printf("start: free %.1f GiB\n", free_gib());
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 5; ++variant) {
         std::vector<hipMemGenericAllocationHandle_t> h(N);
         char *va, *vb; CK(hipMemAddressReserve((void **)&va, N * CH, 0, nullptr, 0)); CK(hipMemAddressReserve((void **)&vb, N * CH, 0, nullptr, 0));
         for (int i = 0; i < N; ++i) { CK(hipMemCreate(&h[i], CH, &prop, 0)); CK(hipMemMap(va + i * CH, CH, 0, h[i], 0)); CK(hipMemSetAccess(va + i * CH, CH, &acc, 1)); }
@@ -24,7 +24,10 @@ int main() {
             for (int i = 0; i < N; ++i) { CK(hipMemUnmap(vb + i * CH, CH)); CK(hipMemRelease(h[i])); }
         }
         if (variant == 2) { for (int i = 0; i < N; ++i) { CK(hipMemRelease(h[i])); CK(hipMemUnmap(va + i * CH, CH)); } }
-        printf("           after unmap + release: free %.1f GiB\n", free_gib());
+        if (variant == 3) { for (int i = 0; i < N; ++i) { CK(hipMemUnmap(va + i * CH, CH)); CK(hipMemRelease(h[i])); } CK(hipMemAddressFree(va, N * CH)); CK(hipMemAddressFree(vb, N * CH)); }
+        if (variant == 4) { for (int i = 0; i < N; ++i) CK(hipMemUnmap(va + i * CH, CH)); CK(hipMemAddressFree(va, N * CH)); CK(hipMemAddressFree(vb, N * CH)); for (int i = 0; i < N; ++i) CK(hipMemRelease(h[i])); }
+        CK(hipDeviceSynchronize());
+        printf("           after unmap + release%s: free %.1f GiB\n", variant >= 3 ? " + address free" : "", free_gib());
     }
     void *p; hipError_t e = hipMalloc(&p, size_t(250) << 30);
     printf("hipMalloc(250 GiB) afterwards: %s; free %.1f GiB\n", hipGetErrorString(e), free_gib());
