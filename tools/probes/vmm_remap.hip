@@ -21,13 +21,17 @@ int main() {
         CK(hipMemset(bad, 0, 8)); hipLaunchKernelGGL(count_ne, dim3(4096), dim3(256), 0, 0, (const uint32_t *)at, want, N, bad);
         unsigned long long h; CK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost)); printf("  %-40s %s (%llu words differ)\n", what, h ? "WRONG" : "ok", h);
     };
-    for (int variant = 0; variant < 2; ++variant) {
-        printf(variant ? "free and re-reserve the range between the two mappings:\n" : "same reservation, unmap then map:\n");
+    for (int variant = 0; variant < 4; ++variant) {
+        const char *names[] = {"same reservation, unmap then map:", "free and re-reserve the range between the two mappings:",
+                               "same reservation, access revoked (ProtNone) before the unmap:", "access revoked, unmap, free and re-reserve:"};
+        printf("%s\n", names[variant]);
+        hipMemAccessDesc none = acc; none.flags = hipMemAccessFlagsProtNone;
         char *p, *q; CK(hipMemAddressReserve((void **)&p, CH, 0, nullptr, 0)); CK(hipMemAddressReserve((void **)&q, CH, 0, nullptr, 0));
         CK(hipMemMap(p, CH, 0, X, 0)); CK(hipMemSetAccess(p, CH, &acc, 1));
         hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (uint32_t *)p, 1u, N); CK(hipDeviceSynchronize());
+        if (variant >= 2) { hipError_t e = hipMemSetAccess(p, CH, &none, 1); printf("  hipMemSetAccess(ProtNone): %s\n", hipGetErrorString(e)); (void)hipGetLastError(); }
         CK(hipMemUnmap(p, CH));
-        if (variant) { CK(hipMemAddressFree(p, CH)); char *p2; CK(hipMemAddressReserve((void **)&p2, CH, 0, nullptr, 0)); printf("  range %p -> %p\n", (void *)p, (void *)p2); p = p2; }
+        if (variant & 1) { CK(hipMemAddressFree(p, CH)); char *p2; CK(hipMemAddressReserve((void **)&p2, CH, 0, nullptr, 0)); printf("  range %p -> %p\n", (void *)p, (void *)p2); p = p2; }
         CK(hipMemMap(p, CH, 0, Y, 0)); CK(hipMemSetAccess(p, CH, &acc, 1));
         hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (uint32_t *)p, 2u, N); CK(hipDeviceSynchronize());
         CK(hipMemMap(q, CH, 0, X, 0)); CK(hipMemSetAccess(q, CH, &acc, 1));
