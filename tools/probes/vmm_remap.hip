@@ -19,7 +19,9 @@ int main() {
     unsigned long long *bad; CK(hipMalloc(&bad, 8));
     auto check = [&](char *at, uint32_t want, const char *what) {
         CK(hipMemset(bad, 0, 8)); hipLaunchKernelGGL(count_ne, dim3(4096), dim3(256), 0, 0, (const uint32_t *)at, want, N, bad);
-        unsigned long long h; CK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost)); printf("  %-40s %s (%llu words differ)\n", what, h ? "WRONG" : "ok", h);
+        unsigned long long h; CK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
+        uint32_t w0, wm; CK(hipMemcpy(&w0, at, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&wm, at + CH / 2, 4, hipMemcpyDeviceToHost));
+        printf("  %-40s %s (%llu words differ; first word %u, middle word %u)\n", what, h ? "WRONG" : "ok", h, w0, wm);
     };
     for (int variant = 0; variant < 4; ++variant) {
         const char *names[] = {"same reservation, unmap then map:", "free and re-reserve the range between the two mappings:",
