@@ -72,8 +72,9 @@ int same_dev_free(same_ctx *ctx, void *dptr);   /* either kind of buffer */
  * range.  The result is used and freed like any same_dev_alloc buffer.  Costs ~10 ms per GiB once; may hold up to 128 GiB
  * more than `bytes` for up to ~1.5 s while it looks for chunks of a second region.  Buffers under 6 GiB, SAME_SPREAD=0 in the environment, a card
  * without that much free memory, or a failure of the virtual-memory calls themselves give a plain same_dev_alloc (placement is a
- * matter of speed, never of results; out_info[0] says which it was).  Address ranges of spread buffers are never reused (a ROCm
- * mapping quirk, see spread.hip); a process may spend 32 TiB of its 128 TiB address space on them, after which the plain allocation is used.
+ * matter of speed, never of results; out_info[0] says which it was).  The memory goes back to the card on same_dev_free; the ADDRESSES of a
+ * spread buffer are never used for another mapping (a ROCm quirk, see spread.hip): they come from a 48 TiB stretch of the process's address
+ * space, after which the plain allocation is used.
  * out_info (may be NULL), SAME_SPREAD_INFO_LEN int64: [0] 1 = spread, 0 = plain; [1] GiB chunks mapped; [2..4] chunks from
  * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s. */
 #define SAME_SPREAD_INFO_LEN 9
@@ -81,6 +82,8 @@ int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t 
 int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* free and total bytes of the context's card right now (hipMemGetInfo); either pointer may be NULL */
+int same_dev_mem_info(same_ctx *ctx, int64_t *out_free, int64_t *out_total);
 /* The host-buffer entry points stage through per-context scratch blocks that grow on demand and are
  * reused across calls; this frees them all (same_sweep handles own their blocks and are not affected). */
 int same_ctx_release_scratch(same_ctx *ctx);

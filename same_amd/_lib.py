@@ -45,6 +45,7 @@ _PROTOTYPES = {
     "same_h2d": [c_vp, c_vp, c_vp, c_sz],
     "same_d2h": [c_vp, c_vp, c_vp, c_sz],
     "same_dev_memset": [c_vp, c_vp, c_int, c_sz],
+    "same_dev_mem_info": [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     "same_ctx_release_scratch": [c_vp],
     "same_timer_start": [c_vp],
     "same_timer_stop": [c_vp, ctypes.POINTER(c_flt)],
@@ -227,6 +228,15 @@ class Context:
         buf = ctypes.create_string_buffer(64)
         self.check(self.lib.same_ctx_pci_bus_id(self.handle, buf, 64), "same_ctx_pci_bus_id")
         return buf.value.decode().lower()
+
+    def mem_info(self):
+        """(free bytes, total bytes) of the card right now."""
+        f, t = c_i64(0), c_i64(0)
+        self.check(self.lib.same_dev_mem_info(self.handle, ctypes.byref(f), ctypes.byref(t)), "same_dev_mem_info")
+        return f.value, t.value
+
+    def mem_free(self):
+        return self.mem_info()[0]
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

@@ -138,6 +138,16 @@ int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     return SAME_OK;
 }
 
+int same_dev_mem_info(same_ctx *ctx, int64_t *out_free, int64_t *out_total) {
+    REQUIRE(ctx, ctx != nullptr);
+    SAME_TRY(same_use(ctx));
+    size_t f = 0, t = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&f, &t));
+    if (out_free) *out_free = (int64_t)f;
+    if (out_total) *out_total = (int64_t)t;
+    return SAME_OK;
+}
+
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes) {
     REQUIRE(ctx, ctx && (bytes == 0 || dst_dev));
     SAME_TRY(same_use(ctx));

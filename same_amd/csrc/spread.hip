@@ -13,13 +13,20 @@
 // eight XCD fronts, a single linear front, a copy -- is spread over the regions at all times.  Surplus chunks go back to
 // the driver.
 //
-// One rule found the hard way (tools/probes/vmm_remap.hip): on this ROCm a virtual address that has carried a mapping
-// keeps translating to the OLD chunk after hipMemUnmap + hipMemMap of another one, silently.  So every address here is
-// mapped at most once in the life of the process: labelling happens in a scratch range whose slots are used once, the final
-// range is fresh, and neither range is ever handed back with hipMemAddressFree (address space is the one thing in ample
-// supply: 2^47 bytes against a few hundred GiB per allocation).
+// Two behaviours of this ROCm's virtual-memory calls shape the code (tools/probes/vmm_{remap,release,protocol}.hip,
+// profiles/r02_hbm_vmm_*.log):
+//  * memory taken with hipMemCreate only returns to the card when the ADDRESS RANGE it was mapped in is handed back with
+//    hipMemAddressFree -- hipMemUnmap + hipMemRelease alone leave it charged;
+//  * an address that carried chunk X keeps reaching X after hipMemUnmap + hipMemMap of another chunk there for as long as
+//    X is alive somewhere, silently -- even across hipMemAddressFree and a new reservation that lands on the same address.
+//    (A plain hipMalloc landing on such an address is fine: measured.)
+// So: labelling happens in a scratch range whose slots are used once and which is freed when the call returns (the surplus
+// chunks' memory goes back with it); the final range is freed when the buffer is; and every range is reserved at an address
+// this process has never used for a mapping before -- a process-wide cursor walks up a 48 TiB stretch of the address space
+// as the hint, and a reservation that comes back anywhere on used ground is parked, never mapped.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <cstdlib>
 
@@ -35,7 +42,8 @@ constexpr size_t MIN_CHUNKS = 6;         // below this a plain allocation: nothi
 constexpr double LEVEL_RATIO = 1.12;     // a rate above this multiple of the same-region level is the fast level (measured: same
                                          // region 0.95-1.08x of the level, other region 1.18-1.27x: profiles/r02_spread_levels.log)
 constexpr size_t MAX_SHARE_PERMILLE = 500;   // chosen chunks: no region above half (4+4 over two regions runs within 2 % of 3+3+2)
-constexpr size_t VA_BUDGET = size_t(32) << 40;   // address space this process may spend on spread buffers, in all (of 2^47)
+constexpr uintptr_t VA_FIRST = uintptr_t(0x100000000000);   // 16 TiB: far below where mmap / hipMalloc hand out addresses
+constexpr uintptr_t VA_LAST = uintptr_t(0x400000000000);    // 64 TiB: 48 TiB of never-reused addresses for this process
 constexpr size_t EXTRA_CHUNKS = 128;     // how far past the buffer's own chunks to look for balance: the driver hands chunks out in
                                          // runs of up to a whole region (96), and a chunk costs ~10 ms to take and label
 
@@ -86,12 +94,34 @@ struct Chunk {
 
 }  // namespace
 
+// A range at addresses this process has not mapped anything at before (header comment).  nullptr when there is none.
+static char *reserve_fresh(size_t bytes) {
+    static std::mutex mu;
+    static uintptr_t cursor = VA_FIRST;
+    static std::vector<std::pair<uintptr_t, uintptr_t>> used;      // every range ever handed out here, [begin, end)
+    std::lock_guard<std::mutex> lock(mu);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (cursor + bytes + CHUNK > VA_LAST) return nullptr;
+        void *hint = (void *)cursor, *p = nullptr;
+        cursor += bytes + CHUNK;                                    // a gap of one chunk between ranges
+        if (hipMemAddressReserve(&p, bytes, size_t(2) << 20, hint, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        const uintptr_t b = (uintptr_t)p, e = b + bytes;
+        bool fresh = true;
+        for (auto &u : used) fresh = fresh && (e <= u.first || b >= u.second);
+        if (fresh) { used.emplace_back(b, e); return (char *)p; }
+        // the hint was not honoured and the range lies on used ground: keep it reserved (parked) so it is not offered again
+    }
+    return nullptr;
+}
+
 void same_spread_release(same_spread_alloc &a) {
     for (size_t i = 0; i < a.handles.size(); ++i) {
         (void)hipMemUnmap(a.va + i * CHUNK, CHUNK);
         (void)hipMemRelease((hipMemGenericAllocationHandle_t)a.handles[i]);
     }
-    a.handles.clear();   // the address range itself stays reserved for the life of the process (header comment)
+    a.handles.clear();
+    if (a.va) (void)hipMemAddressFree(a.va, a.bytes);   // this is what returns the memory to the card (header comment)
+    a.va = nullptr;
 }
 
 // The virtual-memory path proper.  Leaves nothing behind on failure (every chunk given back).
@@ -107,28 +137,25 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
 
-    // Address ranges are never handed back (header comment), so the process has a budget of them: a long-lived process that
-    // allocates and frees spread buffers for ever ends up on the plain allocation instead of running out of address space.
-    static std::atomic<size_t> va_used{0};
     const size_t slots = std::min(budget, n_need + EXTRA_CHUNKS);   // most chunks this call can examine
-    if (va_used.fetch_add((slots + n_need) * CHUNK) + (slots + n_need) * CHUNK > VA_BUDGET) {
-        ctx->err = "address-space budget for spread buffers is used up (ranges are never reused); plain allocation";
+    char *scratch = reserve_fresh(slots * CHUNK);
+    if (!scratch) {
+        ctx->err = "no unused address range left for a spread buffer (addresses are never reused for mappings); plain allocation";
         return SAME_ENOMEM;
     }
-    char *scratch = nullptr;
-    HIP_TRY(ctx, hipMemAddressReserve((void **)&scratch, slots * CHUNK, size_t(2) << 20, nullptr, 0));
     std::vector<Chunk> ch;
     std::vector<int> refs;                                          // reference chunk of each region found so far
     std::vector<std::vector<int>> by_class(MAX_REGIONS + 1);
     std::vector<size_t> take(MAX_REGIONS + 1, 0);
     Timer tm{ctx};
     double slow = 0.0;                                              // same-region level (settle_level)
-    auto give_back = [&]() {
+    auto give_back = [&]() {                                        // everything still held by the labelling, and its range
         for (auto &c : ch) {
             if (c.at) (void)hipMemUnmap(c.at, CHUNK);
             (void)hipMemRelease(c.h);
         }
         ch.clear();
+        (void)hipMemAddressFree(scratch, slots * CHUNK);
     };
     auto take_chunk = [&]() -> int {                                // 1 = got one, 0 = the driver has no more, < 0 = error
         Chunk c{};
@@ -210,9 +237,9 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
 
     // the final range, chunks laid round-robin over the regions
     std::vector<int> order = spread_plan::interleave(by_class, take);
-    char *va = nullptr;
-    hipError_t e = hipMemAddressReserve((void **)&va, n_need * CHUNK, size_t(2) << 20, nullptr, 0);
-    if (e != hipSuccess) { give_back(); return same_fail(ctx, SAME_ENOMEM, "hipMemAddressReserve", e); }
+    char *va = reserve_fresh(n_need * CHUNK);
+    if (!va) { give_back(); ctx->err = "no unused address range left for a spread buffer; plain allocation"; return SAME_ENOMEM; }
+    hipError_t e = hipSuccess;
     same_spread_alloc out;
     out.va = va;
     out.bytes = n_need * CHUNK;
@@ -232,6 +259,7 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
             (void)hipMemRelease(ch[i].h);
         }
     ch.clear();
+    (void)hipMemAddressFree(scratch, slots * CHUNK);   // the surplus chunks' memory goes back to the card with their range
     if (e != hipSuccess) {
         same_spread_release(out);
         return same_fail(ctx, SAME_EIO, "hipMemMap/hipMemSetAccess (spread buffer)", e);

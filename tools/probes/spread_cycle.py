@@ -7,6 +7,7 @@ from same_amd import _lib
 
 cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 ctx = _lib.Context(0); L, H = ctx.lib, ctx.handle
+hbm_free = lambda: ctx.mem_free() / 2**30
 rng = np.random.default_rng(0)
 seen = set()
 keep = None
@@ -26,9 +27,10 @@ for c in range(cycles):
         kb, kval, kgib = keep
         assert (kb.download((1 << 20,), np.uint8, offset_bytes=(kgib << 29)) == kval).all(), c
         kb.free()
-    print(f"cycle {c}: {gib} GiB {b.spread_info['per_region']} straddling {b.spread_info['straddling']} examined {b.spread_info['examined']} in {dt:.2f} s @{b.ptr:#x}", flush=True)
+    print(f"cycle {c}: free after alloc {hbm_free():.1f} GiB; {gib} GiB {b.spread_info['per_region']} straddling {b.spread_info['straddling']} examined {b.spread_info['examined']} in {dt:.2f} s @{b.ptr:#x}", flush=True)
     keep = (b, val, gib)
 keep[0].free()
+print(f"all freed: {hbm_free():.1f} GiB free")
 plain = ctx.alloc(64 << 30)
 ctx.check(L.same_dev_memset(H, plain.ptr, 0x77, 64 << 30), "memset"); ctx.sync()
 assert (plain.download((1 << 20,), np.uint8, offset_bytes=32 << 30) == 0x77).all()
