@@ -75,6 +75,30 @@ def test_spread_buffer_holds_what_a_plain_one_holds(ctx):
         b.free()
 
 
+def test_memory_returns_and_addresses_are_not_reused(ctx):
+    """Six allocate / write / check / free cycles: the card's free memory is back after every free (surplus chunks of the
+    labelling included), no address is handed out twice, and a buffer kept across a cycle keeps its bytes."""
+    ctx.sync()
+    base = ctx.mem_free()
+    seen, kept = set(), None
+    for c, gib in enumerate((8, 11, 6, 16, 9, 7)):
+        b = ctx.alloc_spread(gib << 30)
+        assert b.spread_info["spread"] is True and b.ptr not in seen
+        seen.add(b.ptr)
+        ctx.check(ctx.lib.same_dev_memset(ctx.handle, b.ptr, 0x20 + c, gib << 30), "memset")
+        ctx.sync()
+        for off in (0, gib << 29, (gib << 30) - (1 << 20)):
+            assert (b.download((1 << 20,), np.uint8, offset_bytes=off) == 0x20 + c).all()
+        held = (gib << 30) + (kept[2] << 30 if kept else 0)
+        assert abs((base - ctx.mem_free()) - held) < (1 << 30), (c, base - ctx.mem_free(), held)   # nothing but the live buffers is charged
+        if kept:
+            assert (kept[0].download((1 << 20,), np.uint8, offset_bytes=kept[2] << 29) == kept[1]).all()
+            kept[0].free()
+        kept = (b, 0x20 + c, gib)
+    kept[0].free()
+    assert abs(base - ctx.mem_free()) < (1 << 30)
+
+
 def test_opt_out_by_environment(ctx, monkeypatch):
     monkeypatch.setenv("SAME_SPREAD", "0")
     b = ctx.alloc_spread(6 << 30)
