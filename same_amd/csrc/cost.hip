@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
         chunk = k / widest;
         if (m >= mine || chunk >= row_chunks) return;
         tile = xcd + 8u * m;
-    } else if (map_mode == 4) {  // as 3, but XCD x owns the CONTIGUOUS tile range [x*ct/8, (x+1)*ct/8)
+    } else if (map_mode == 4 || map_mode == 5) {  // as 3, but XCD x owns the CONTIGUOUS tile range [x*ct/8, (x+1)*ct/8)
         const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
         const unsigned lo = xcd * (unsigned)col_tiles / 8u, hi = (xcd + 1u) * (unsigned)col_tiles / 8u;
         const unsigned widest = ((unsigned)col_tiles + 7u) >> 3;
@@ -115,6 +115,10 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
         chunk = k / widest;
         if (m >= hi - lo || chunk >= row_chunks) return;
         tile = lo + m;
+        // 5: every XCD starts its sweep an eighth of the rows further down (and wraps), so the eight store fronts lie an
+        // eighth of the block apart instead of in one band of rows: a band is one stretch of addresses, i.e. ONE HBM region
+        // at a time (spread.hip), and a store stream confined to one region is the slow one
+        if (map_mode == 5) chunk = (int)(((unsigned)chunk + xcd * ((unsigned)row_chunks / 8u)) % (unsigned)row_chunks);
     } else {  // blocks that share an XCD (b % 8) take adjacent column tiles
         const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
         const unsigned per = (gridDim.x + 7u) >> 3;  // blocks per XCD group
@@ -535,7 +539,7 @@ int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy
     const int64_t chunks = ceil_div(rows, rows_per_block);
     int64_t blocks = chunks * col_tiles;
     if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
-    if (map_mode == 3 || map_mode == 4) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
+    if (map_mode == 3 || map_mode == 4 || map_mode == 5) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
     static const int lds_pad = env_int("SAME_DENSE_LDS_PAD", 0);   // probe: unused dynamic LDS per block caps the occupancy
     if (w == F(1))
@@ -568,7 +572,7 @@ int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const 
     if (!vec_ok) {
         const int rpb = (int)std::min<int64_t>(rows, 64);
         // ragged tail first (its own launch), then whole chunks with the overlapped-last-chunk rule
-        return launch_one<F, T, CPL, false, 1, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb, (map_env == 2 || map_env == 4) ? 0 : map_env);
+        return launch_one<F, T, CPL, false, 1, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb, (map_env == 2 || map_env == 4 || map_env == 5) ? 0 : map_env);
     }
     const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
     // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
