@@ -58,6 +58,24 @@ int main(void) {
     printf("checked %lld triangles, %lld flipped:", (long long)checked, (long long)nviol);
     for (int q = 0; q < nviol; ++q) printf(" %d", viol[q]);
     printf("\n");
+    /* resident operands: the dense tile of all NM x NR costs built on the device into a block from same_dev_alloc_spread
+     * (large blocks are laid over the card's HBM regions; one this small is a plain allocation -- info[0] says which) */
+    int64_t mem_free = 0, mem_total = 0, info[SAME_SPREAD_INFO_LEN];
+    CHECK(same_dev_mem_info(ctx, &mem_free, &mem_total));
+    void *dA = NULL, *dR = NULL, *dax = NULL, *drx = NULL, *dD = NULL;
+    const int64_t ld = NR + (NR & 1);   /* even leading dimension: 16-byte rows */
+    CHECK(same_dev_alloc(ctx, sizeof A, &dA));   CHECK(same_h2d(ctx, dA, A, sizeof A));
+    CHECK(same_dev_alloc(ctx, sizeof R, &dR));   CHECK(same_h2d(ctx, dR, R, sizeof R));
+    CHECK(same_dev_alloc(ctx, sizeof axy, &dax)); CHECK(same_h2d(ctx, dax, axy, sizeof axy));
+    CHECK(same_dev_alloc(ctx, sizeof rxy, &drx)); CHECK(same_h2d(ctx, drx, rxy, sizeof rxy));
+    CHECK(same_dev_alloc_spread(ctx, (size_t)NM * ld * sizeof(double), &dD, info));
+    CHECK(same_dense_cost_f64_dev(ctx, dA, dR, T, dax, drx, NR, 0, NM, 1.0, dD, ld));
+    double D[NM * (NR + 1)];
+    CHECK(same_d2h(ctx, D, dD, (size_t)NM * ld * sizeof(double)));
+    printf("card: %.1f of %.1f GiB free; dense tile (%s allocation): D[0][0]=%.4f D[%d][%d]=%.4f\n", mem_free / 1073741824.0,
+           mem_total / 1073741824.0, info[0] ? "spread" : "plain", D[0], NM - 1, NR - 1, D[(NM - 1) * ld + NR - 1]);
+    void *blocks[] = {dA, dR, dax, drx, dD};
+    for (int q = 0; q < 5; ++q) CHECK(same_dev_free(ctx, blocks[q]));
     /* error convention: a bad index is reported, not dereferenced */
     int32_t bad[2] = {0, 99};
     int rc = same_pair_cost_f64(ctx, A, R, NM, NR, T, axy, rxy, bad, 1, 1.0, cost);
