@@ -1137,3 +1137,42 @@ print(json.dumps({{"small": out, "big_checked": int(bc), "big_n": int(len(bv))}}
     assert got["big_checked"] == pc and np.array_equal(np.load(tmp_path / "big_viol.npy"), pv)
     wc, wv, _ = oracle.orient_sweep(big_tris, np.asarray(bsign).astype(np.int8), ref["xy"], big_match)
     assert pc == wc and np.array_equal(pv, np.asarray(wv, dtype=np.int32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("map_mode", [0, 1, 3, 4, 5])
+def test_dense_cost_is_bit_exact_under_every_block_map(oracle, map_mode, tmp_path):
+    """SAME_DENSE_MAP selects the dense kernel's block -> (column tile, row chunk) map (probes; the library picks 2 or 4 itself).
+    Whatever the map, every output is computed by the same instruction sequence, so the matrix must not change: a child process
+    per map builds ragged fp64 and fp32 tiles at several T, the parent compares with the oracle."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    rng = np.random.default_rng(100 + map_mode)
+    n_m, n_r = 1500, 2311
+    cases = {}
+    for T in (0, 5, 16, 20):
+        A = rng.dirichlet(np.full(max(T, 1), 0.3), size=n_m)[:, :T] * 100 if T else np.zeros((n_m, 0))
+        R = rng.dirichlet(np.full(max(T, 1), 0.3), size=n_r)[:, :T] * 100 if T else np.zeros((n_r, 0))
+        cases[T] = (A, R, rng.uniform(0, 300, (n_m, 2)), rng.uniform(0, 300, (n_r, 2)))
+    np.savez(tmp_path / "in.npz", **{f"{k}_{T}": v for T, c in cases.items() for k, v in zip("ARxy", c)})
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {str(ROOT)!r})
+from same_amd import ops
+d = np.load({str(tmp_path / 'in.npz')!r})
+out = {{}}
+for T in (0, 5, 16, 20):
+    a = [d[f"{{k}}_{{T}}"] for k in "ARxy"]
+    out[f"f64_{{T}}"] = ops.dense_cost(*a, 1.0, 7, 1400)
+    out[f"f32_{{T}}"] = ops.dense_cost(*a, 2.5, 7, 1400, dtype=np.float32)
+np.savez({str(tmp_path / 'out.npz')!r}, **out)
+"""
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SAME_DENSE_MAP=str(map_mode)), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = np.load(tmp_path / "out.npz")
+    for T, a in cases.items():
+        assert np.array_equal(got[f"f64_{T}"], oracle.dense_cost(*a, 1.0, 7, 1400)), T
+        assert np.array_equal(got[f"f32_{T}"], oracle.dense_cost(*a, 2.5, 7, 1400, dtype=np.float32)), T
