@@ -157,15 +157,21 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
         ch.clear();
         (void)hipMemAddressFree(scratch, slots * CHUNK);
     };
+    double t_create = 0.0, t_time = 0.0;                            // seconds in hipMemCreate/Map/SetAccess and in timed stores (debug)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto take_chunk = [&]() -> int {                                // 1 = got one, 0 = the driver has no more, < 0 = error
         Chunk c{};
+        const double tc0 = now();
         hipError_t e = hipMemCreate(&c.h, CHUNK, &prop, 0);
         if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
         c.at = scratch + ch.size() * CHUNK;                         // every scratch slot is used once
         e = hipMemMap(c.at, CHUNK, 0, c.h, 0);
         if (e == hipSuccess) e = hipMemSetAccess(c.at, CHUNK, &acc, 1);
         if (e != hipSuccess) { (void)hipMemRelease(c.h); return same_fail(ctx, SAME_EIO, "hipMemMap/hipMemSetAccess (labelling a chunk)", e); }
+        const double tc1 = now();
         c.halves = tm.halves(c.at);
+        t_create += tc1 - tc0;
+        t_time += now() - tc1;
         c.label = -1;
         if (tm.rc != SAME_OK) { (void)hipMemUnmap(c.at, CHUNK); (void)hipMemRelease(c.h); ctx->err = "timing a labelling store failed"; return tm.rc; }
         ch.push_back(c);
@@ -194,7 +200,9 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
             else {
                 c.label = -1;
                 for (size_t r = 0; r < refs.size() && c.label < 0; ++r) {
+                    const double tp0 = now();
                     const double g = tm.pair(ch[refs[r]].at, c.at);
+                    t_time += now() - tp0;
                     if (tm.rc != SAME_OK) { ctx->err = "timing a labelling store failed"; return tm.rc; }
                     if (!is_fast(g, ch[refs[r]].at, c.at, CHUNK)) c.label = (int)r;
                 }
@@ -264,6 +272,8 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
         same_spread_release(out);
         return same_fail(ctx, SAME_EIO, "hipMemMap/hipMemSetAccess (spread buffer)", e);
     }
+    if (debug) fprintf(stderr, "[spread] %zu chunks examined: %.2f s in hipMemCreate/Map/SetAccess, %.2f s in timed stores, %.2f s in all\n", examined,
+                       t_create, t_time, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     ctx->spread.push_back(out);
     *out_dptr = va;
     info[0] = 1;
