@@ -69,12 +69,15 @@ int same_dev_free(same_ctx *ctx, void *dptr);   /* either kind of buffer */
  * store confined to one of them runs ~20 % below one spread over two or three (profiles/r02_hbm_regions.md); hipMalloc
  * places a buffer wherever its free lists point.  This call takes the memory in 1 GiB chunks through the virtual-memory
  * API, finds each chunk's region by timed stores and maps the chunks round-robin over the regions into one contiguous
- * range.  The result is used and freed like any same_dev_alloc buffer.  Costs ~10 ms per GiB once; may hold up to 128 GiB
- * more than `bytes` for up to ~1.5 s while it looks for chunks of a second region.  Buffers under 6 GiB, SAME_SPREAD=0 in the environment, a card
- * without that much free memory, or a failure of the virtual-memory calls themselves give a plain same_dev_alloc (placement is a
- * matter of speed, never of results; out_info[0] says which it was).  The memory goes back to the card on same_dev_free; the ADDRESSES of a
- * spread buffer are never used for another mapping (a ROCm quirk, see spread.hip): they come from a 48 TiB stretch of the process's address
- * space, after which the plain allocation is used.
+ * range.  The result is used and freed like any same_dev_alloc buffer.
+ *  - Cost: 1-4 s once for 75 GiB (most of it the driver's own hipMemCreate); may hold up to 128 GiB more than `bytes`
+ *    while it looks for chunks of a second region; all of that goes back to the card before the call returns.
+ *  - Buffers under 6 GiB, SAME_SPREAD=0 in the environment, a card without that much free memory, or a failure of the
+ *    virtual-memory calls themselves give a plain same_dev_alloc: placement is a matter of speed, never of results
+ *    (out_info[0] says which it was; same_last_error() keeps the reason).
+ *  - The memory goes back to the card on same_dev_free.  The ADDRESSES of a spread buffer are never used for another
+ *    mapping (a ROCm quirk, see spread.hip): they come from a 48 TiB stretch of the process's address space, after which
+ *    the plain allocation is used.
  * out_info (may be NULL), SAME_SPREAD_INFO_LEN int64: [0] 1 = spread, 0 = plain; [1] GiB chunks mapped; [2..4] chunks from
  * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s. */
 #define SAME_SPREAD_INFO_LEN 9
