@@ -137,15 +137,7 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
     if (i0 + rows_per_block > row_end) i0 = row_end - rows_per_block;
 
-    // fp32 with an even number of columns per lane: the columns are kept as PAIRS (two floats in an aligned register pair), so
-    // that the subtraction of a row value from two columns is one v_pk_add_f32 (row value broadcast from its SGPR by op_sel,
-    // the column pair negated by neg_lo/neg_hi) -- 3 instead of 4 VALU instructions per type for two columns.  The |.| of the
-    // accumulation has no packed form (VOP3P has no abs modifier), so the two adds stay scalar with the free |x| modifier.  Same
-    // IEEE operations on the same values in the same order: bit-identical to the unpacked form.
-    constexpr bool PK = sizeof(F) == 4 && (CT % 2 == 0);
-    typedef F pairF __attribute__((ext_vector_type(2)));
-    F r[PK ? 1 : CT][TT];
-    pairF r2[PK ? CT / 2 : 1][TT];
+    F r[CT][TT];
     F rx[CT], ry[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -153,10 +145,7 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
         if (j >= n_r) j = n_r - 1;  // clamp: lanes past the edge compute a valid column
         const F *rp = R + j * T;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if constexpr (PK) r2[c / 2][t][c % 2] = rp[t];
-            else r[c][t] = rp[t];
-        }
+        for (int t = 0; t < T; ++t) r[c][t] = rp[t];
         rx[c] = rxy[2 * j];
         ry[c] = rxy[2 * j + 1];
     }
@@ -193,17 +182,8 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
 #pragma unroll
             for (int t = 0; t < H; ++t) {
                 F dd[CT];
-                if constexpr (PK) {
 #pragma unroll
-                    for (int c = 0; c < CT; c += 2) {
-                        const pairF d2 = pairF{h0[t], h0[t]} - r2[c / 2][t];
-                        dd[c] = d2[0];
-                        dd[c + 1] = d2[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) dd[c] = h0[t] - r[c][t];
-                }
+                for (int c = 0; c < CT; ++c) dd[c] = h0[t] - r[c][t];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) s[c] = s[c] + absf<F>(dd[c]);
             }
@@ -220,17 +200,8 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
 #pragma unroll
             for (int t = H; t < T; ++t) {
                 F dd[CT];
-                if constexpr (PK) {
 #pragma unroll
-                    for (int c = 0; c < CT; c += 2) {
-                        const pairF d2 = pairF{h1[t - H], h1[t - H]} - r2[c / 2][t];
-                        dd[c] = d2[0];
-                        dd[c + 1] = d2[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) dd[c] = h1[t - H] - r[c][t];
-                }
+                for (int c = 0; c < CT; ++c) dd[c] = h1[t - H] - r[c][t];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) s[c] = s[c] + absf<F>(dd[c]);
             }
