@@ -672,6 +672,8 @@ def run_rank(args):
                 msg.append(f"while the kernel looped the board drew {pw['mean']:.0f} W in steady state (max {t['power']['max']:.0f} W"
                            + (f", cap {t['power_cap_w']:.0f} W" if t.get("power_cap_w") else "") + ")"
                            + (f" at a shader clock of {clk['mean']:.0f} MHz (min {clk['min']:.0f})" if clk else "")
+                           + ("".join(f", {n} {v['mean']:.0f} C" + (f" (critical {t['temperature_crit_c'][n]:.0f})" if (t.get('temperature_crit_c') or {}).get(n) else "")
+                                      for n, v in (t.get("temperature_steady") or {}).items() if v))
                            + ("" if use_q32 else f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
                               + (f"{(2 * T + 5) * float(n_ref) * rows_launch / (1024 * 16 * clk['mean'] * 1e6) * 1e3:.1f} ms" if clk else "n/a")
                               + f" of the {t_dense * 1e3:.1f} ms launch"))

@@ -2,7 +2,8 @@
 
 Used by bench.py to record the operating point the dense kernel actually ran at (the T=20 fp64 build is bounded by
 the package power cap): `power1_average` / `power1_input` (microwatts) and `freq1_input` (Hz) of the
-amdgpu hwmon node, `pp_dpm_sclk` (the line marked `*`) as a second clock source, `power1_cap` for the cap itself.
+amdgpu hwmon node, `pp_dpm_sclk` (the line marked `*`) as a second clock source, `power1_cap` for the cap itself, and the
+`junction` / `mem` temperatures (a chip that throttles below the power cap is usually at a thermal limit).
 Every source is optional; what could not be read is reported as such, never guessed.
 """
 import glob
@@ -32,9 +33,9 @@ def _dpm_current_mhz(text):
 
 
 class GpuTelemetry:
-    def __init__(self, pci_bus_id, period_s=0.02):
+    def __init__(self, pci_bus_id, period_s=0.02, sysfs_root="/sys/bus/pci/devices"):
         self.period = float(period_s)
-        self.dev_dir = os.path.join("/sys/bus/pci/devices", pci_bus_id)
+        self.dev_dir = os.path.join(sysfs_root, pci_bus_id)
         hw = sorted(glob.glob(os.path.join(self.dev_dir, "hwmon", "hwmon*")))
         self.hwmon = hw[0] if hw else None
         self.power_path = None
@@ -45,6 +46,17 @@ class GpuTelemetry:
                     break
         self.freq_path = os.path.join(self.hwmon, "freq1_input") if self.hwmon and _read(os.path.join(self.hwmon, "freq1_input")) else None
         self.dpm_path = os.path.join(self.dev_dir, "pp_dpm_sclk") if _read(os.path.join(self.dev_dir, "pp_dpm_sclk")) else None
+        # junction (hot spot) and HBM temperatures, millidegrees; found by label because the numbering differs between parts
+        self.temp_paths = {}
+        if self.hwmon:
+            for lab in sorted(glob.glob(os.path.join(self.hwmon, "temp*_label"))):
+                name = _read(lab)
+                if name in ("junction", "mem", "edge") and _read(lab.replace("_label", "_input")) is not None:
+                    self.temp_paths[name] = lab.replace("_label", "_input")
+            self.temp_crit_c = {n: (float(v) / 1e3 if (v := _read(p.replace("_input", "_crit"))) and v.lstrip("-").isdigit() else None)
+                                for n, p in self.temp_paths.items()}
+        else:
+            self.temp_crit_c = {}
         cap = _read(os.path.join(self.hwmon, "power1_cap")) if self.hwmon else None
         self.cap_w = float(cap) / 1e6 if cap and cap.isdigit() else None
         self._samples = []
@@ -58,8 +70,9 @@ class GpuTelemetry:
         p = _read(self.power_path) if self.power_path else None
         f = _read(self.freq_path) if self.freq_path else None
         d = _dpm_current_mhz(_read(self.dpm_path)) if self.dpm_path else None
+        temps = {n: (float(v) / 1e3 if (v := _read(path)) and v.lstrip("-").isdigit() else None) for n, path in self.temp_paths.items()}
         return (time.perf_counter(), float(p) / 1e6 if p and p.isdigit() else None,
-                float(f) / 1e6 if f and f.isdigit() else None, d)
+                float(f) / 1e6 if f and f.isdigit() else None, d, temps)
 
     def start(self):
         self._samples, self._stop = [], threading.Event()
@@ -92,4 +105,6 @@ class GpuTelemetry:
                 "power": stats([x[1] for x in s], "W"), "power_steady": stats([x[1] for x in steady], "W"),
                 "sclk_steady": stats([x[2] if x[2] is not None else x[3] for x in steady], "MHz"), "power_cap_w": self.cap_w,
                 "sclk_hwmon": stats([x[2] for x in s], "MHz"), "sclk_dpm": stats([x[3] for x in s], "MHz"),
+                "temperature_steady": {n: stats([x[4].get(n) for x in steady], "C") for n in self.temp_paths} or None,
+                "temperature_crit_c": self.temp_crit_c or None,
                 "source": {"power": self.power_path, "sclk_hwmon": self.freq_path, "sclk_dpm": self.dpm_path}}

@@ -215,3 +215,28 @@ def test_priority_filter_closed_form_equals_the_reference_walk():
         assert [tuple(r) for r in got.tolist()] == want and (one, all_) == (n_one, n_all), trial
     empty, a, b = priority_filter(np.array([]), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0), np.zeros(0))
     assert len(empty) == 0 and (a, b) == (0, 0)
+
+
+def test_gpu_telemetry_reads_a_hwmon_tree(tmp_path):
+    """same_amd/telemetry.py against a hand-made sysfs tree: power, clock, junction / HBM temperatures found by label, the cap,
+    and the steady-state window; a node that is missing is reported as missing, never guessed."""
+    import time
+    from same_amd.telemetry import GpuTelemetry
+
+    hw = tmp_path / "0000:05:00.0" / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    files = {"power1_input": "1372000000", "power1_cap": "1400000000", "freq1_input": "1800000000",
+             "temp1_label": "edge", "temp1_input": "61000", "temp2_label": "junction", "temp2_input": "83000", "temp2_crit": "100000",
+             "temp3_label": "mem", "temp3_input": "72000", "temp3_crit": "115000", "temp4_label": "other", "temp4_input": "1000"}
+    for name, text in files.items():
+        (hw / name).write_text(text + "\n")
+    t = GpuTelemetry("0000:05:00.0", period_s=0.005, sysfs_root=str(tmp_path))
+    assert t.available() and t.cap_w == 1400.0 and set(t.temp_paths) == {"edge", "junction", "mem"}
+    t.start()
+    time.sleep(0.1)
+    s = t.stop()
+    assert s["samples"] >= 8 and s["power_steady"]["mean"] == 1372.0 and s["sclk_steady"]["mean"] == 1800.0
+    assert s["temperature_steady"]["junction"]["mean"] == 83.0 and s["temperature_steady"]["mem"]["max"] == 72.0
+    assert s["temperature_crit_c"] == {"edge": None, "junction": 100.0, "mem": 115.0}
+    none = GpuTelemetry("0000:06:00.0", sysfs_root=str(tmp_path))
+    assert not none.available() and none.sample()[1:4] == (None, None, None)
