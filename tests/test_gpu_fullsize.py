@@ -88,8 +88,9 @@ def test_dense_100k_properties(env, oracle):
     mov = synth.make_cells(n, T, seed=1, side=ref["side"])
     dA, dR = ctx.to_device(mov["types"]), ctx.to_device(ref["types"])
     dax, drx = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"])
-    C = ctx.alloc(n * n * 8)     # cost(mov rows, ref cols)
-    Ct = ctx.alloc(n * n * 8)    # cost(ref rows, mov cols): must be the exact transpose
+    C = ctx.alloc_spread(n * n * 8)   # cost(mov rows, ref cols), in a block laid over the HBM regions (csrc/spread.hip) ...
+    assert C.spread_info["spread"] is True and C.spread_info["chunks_gib"] == 75
+    Ct = ctx.alloc(n * n * 8)         # ... and cost(ref rows, mov cols) in a plain one: must be the exact transpose
     ctx.check(L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n, 0, n, 1.0, C.ptr, n), "dense")
     ctx.check(L.same_dense_cost_f64_dev(H, dR.ptr, dA.ptr, T, drx.ptr, dax.ptr, n, 0, n, 1.0, Ct.ptr, n), "dense")
     ctx.sync()
