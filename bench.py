@@ -16,15 +16,20 @@ Workload `dense100k`, weak scaling (the configuration BASELINE.json's metric is 
     5. orientation sweep (lazy-constraint body), XY-order sweep, signed-area flips under a nearest-reference matching
   Inputs are resident in HBM before the timed region (the Delaunay triangulation itself is an input: scipy/Qhull on the
   host, as in the reference).  Every rank owns its own block of 100 000 aligned rows against the replicated refs.
-`--scaling strong --workload cfg4` (BASELINE cfg 4): ONE 200k x 200k problem; ranks own aligned-row blocks of it (dense
-  build in 25k-row chunks through one 40 GB buffer), all-gather the candidate lists, derive the common matching, and
-  sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter all-reduce).
+At N > 1 the same run then measures BASELINE cfg 4 as a second, embedded record (`strong_cfg4`): ONE 200k x 200k problem;
+  ranks own aligned-row blocks of it (dense build in 25k-row chunks through the resident buffer), all-gather the candidate
+  lists, derive the common matching, and sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter
+  all-reduce).  `--scaling strong --workload cfg4` runs that configuration as the main record instead.
+`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see run_cfg5.
 value = aligned-ref cell pairs covered per second by the whole job.
 
 `roofline` is for the dense kernel: algorithmic bytes s*N_r*rows + s*(T+2)*(N_r+rows) over its mean launch
-time, HIP events on the stream it runs on.  Ceilings (same kernel at T=0, memset) are measured AFTER the timed loop on
-the warm chip, the note is composed from this run's numbers, `telemetry` is board power / shader clock sampled from
-sysfs while the dense kernel loops, `sweep` repeats the measurement at the type counts of the reference's real datasets.
+time, HIP events on the stream it runs on.  Ceilings (same kernel at T=0, memset, device copy) are measured AFTER the timed
+loop on the warm chip, `telemetry` is board power / shader clock sampled from sysfs while the dense kernel loops,
+`valu_floor_ms_at_held_clock` / `valu_busy_frac` price the kernel's 2T+5 fp64 instructions per output at that clock,
+`sweep` repeats the measurement at the type counts of the reference's real datasets.
+At N > 1 the line explains itself: `rccl` is what the communicator reports (ncclCommCount, not the launcher's word),
+`gather` times the all-gather on its own stream and against a second loop without it, `per_rank_dense_ms` shows slow dies.
 `cpu_baseline` times the CPU oracle (scalar C port of the reference's arithmetic, 1 thread) on a bounded row sample of
 the same workload, rank 0, N=1 only.
 """
@@ -41,6 +46,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_ISSUE_PEAK_T = 39.3   # T lane-instructions/s: the 78.6 TFLOP/s fp64 vector spec counts an FMA as two
+SIMDS, FP64_LANES_PER_CLK = 1024, 16   # 256 CUs x 4 SIMDs; a wave64 fp64 instruction occupies its SIMD for 4 cycles
 
 WORKLOADS = {
     # name: (n_ref, aligned rows [per rank if weak, in total if strong], T, k, radius)
@@ -48,7 +54,9 @@ WORKLOADS = {
     "cfg4": (200_000, 200_000, 20, 32, 25.0),
     "cfg2": (10_000, 10_000, 20, 32, 25.0),
     "tiny": (4_000, 4_000, 20, 32, 25.0),
+    "cfg5": None,              # sliding windows, see run_cfg5
 }
+STRONG_OF = {"dense100k": "cfg4"}   # the ONE-problem configuration embedded after a weak run of the key (else: the same shape)
 STRONG_CHUNK_BYTES = 40e9  # dense buffer of the strong mode (25k rows x 200k refs x 8 B)
 
 
@@ -61,6 +69,7 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip ceilings / telemetry leg / T sweep (profiling runs)")
+    ap.add_argument("--no-strong-record", action="store_true", help="N > 1: skip the embedded ONE-problem (cfg 4) record")
     ap.add_argument("--cpu-sample-rows", type=int, default=20000)  # 10-20 s of single-thread oracle work at dense100k
     ap.add_argument("--tail-stream", default="own", choices=("own", "shared"),
                     help="own: prune / costs / triangle maps / sweeps run on a second context (stream) beside the dense build; "
@@ -68,6 +77,7 @@ def parse():
     ap.add_argument("--dense", default="exact", choices=("exact", "q32"),
                     help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
+    ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:
@@ -176,6 +186,354 @@ def dense_kernel_label(dtype, T):
     return f"dense_cost_kernel<{name},{T},{cpl}>"
 
 
+def stats3(values):
+    """[min, mean, max] of a list of numbers."""
+    v = [float(x) for x in values]
+    return [min(v), sum(v) / len(v), max(v)] if v else None
+
+
+class Env:
+    """What every problem of this rank shares: the host group, the two contexts, the communicator."""
+
+    def __init__(self, args, group, ctx, tctx, comm, transport):
+        self.args, self.group, self.ctx, self.tctx, self.comm, self.transport = args, group, ctx, tctx, comm, transport
+        self.L, self.H, self.TH, self.chk = ctx.lib, ctx.handle, tctx.handle, ctx.check
+
+
+class Problem:
+    """One workload resident on this rank: inputs, output buffers, the caller-held KNN index, the bound sweep -- and the step.
+
+    weak: this rank owns its own section of `rows_cfg` aligned cells against the replicated refs.
+    strong: ONE problem; every rank holds all aligned cells (XY / types are a few MB) and owns a row block of the work and a
+    triangle block of the sweeps."""
+
+    def __init__(self, env, name, strong, dense_buf=None):
+        import ctypes
+
+        import numpy as np
+        from scipy.spatial import Delaunay
+
+        from same_amd import synth
+        from same_amd.dist import ShardedSweeps, row_block
+        from same_amd.triangles import cos_threshold
+
+        self.env, self.name, self.strong = env, name, strong
+        args, group, ctx, tctx, comm = env.args, env.group, env.ctx, env.tctx, env.comm
+        L, TH, chk = env.L, env.TH, env.chk
+        self.np, self.ctypes = np, ctypes
+        self.n_ref, self.rows_cfg, self.T, self.k, self.radius = WORKLOADS[name]
+        n_ref, rows_cfg, T, k, radius = self.n_ref, self.rows_cfg, self.T, self.k, self.radius
+        self.ref = ref = synth.make_cells(n_ref, T, seed=0)
+        if strong:
+            self.mov = mov = synth.make_cells(rows_cfg, T, seed=1, side=ref["side"])
+            self.rb, self.re, self.block = row_block(rows_cfg, group.world, group.rank)
+            self.n_mov = rows_cfg
+        else:
+            self.mov = mov = synth.make_cells(rows_cfg, T, seed=1 + group.rank, side=ref["side"])
+            self.rb, self.re, self.block, self.n_mov = 0, rows_cfg, rows_cfg, rows_cfg
+        rb, re, block, n_mov = self.rb, self.re, self.block, self.n_mov
+        self.rows = rows = re - rb
+        self.tris = tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)  # host input (Qhull), as in the reference
+        self.Tr = Tr = len(tris)
+        self.bufs = []   # everything allocated here, for close()
+
+        def keep(b):
+            self.bufs.append(b)
+            return b
+
+        self.dA, self.dR = keep(ctx.to_device(mov["types"])), keep(ctx.to_device(ref["types"]))
+        self.dax, self.drx = keep(ctx.to_device(mov["xy"])), keep(ctx.to_device(ref["xy"]))
+        self.dsize, self.dtype_id = keep(ctx.to_device(mov["size"])), keep(ctx.to_device(mov["cell_type"]))
+        self.dtris = keep(ctx.to_device(tris))
+        self.ld = ld = (n_ref + 1) & ~1
+        self.chunk_rows = max(1, min(max(rows, 1), int(STRONG_CHUNK_BYTES // (ld * 8)))) if strong else rows
+        need = max(self.chunk_rows, 1) * ld * 8
+        if dense_buf is not None and dense_buf.nbytes >= need:
+            self.dD, self.own_dense = dense_buf, False      # the resident block of the run's main problem, reused
+        else:
+            # the dense cost block (80 GB at dense100k), laid over the card's three HBM regions: a streaming store confined to
+            # one region runs ~20 % below one spread over them, and a plain hipMalloc lands wherever the free lists point
+            self.dD, self.own_dense = ctx.alloc_spread(need), True
+        ta = lambda n: keep(tctx.alloc(n))
+        self.didx, self.dcost, self.dcnt = ta(block * k * 4), ta(block * k * 8), ta(max(block, 1) * 4)
+        chk(L.same_dev_memset(TH, self.didx.ptr, 0xFF, self.didx.nbytes), "memset")   # rows past a short last block stay -1
+        self.knn_index = ctypes.c_void_p()   # caller-held grid index of the reference cells: built once, reused by every prune
+        chk(L.same_knn_index_build(TH, self.drx.ptr, n_ref, radius, ctypes.byref(self.knn_index)), "same_knn_index_build")
+        self.gidx = self.gcost = None
+        if comm is not None:
+            self.gidx, self.gcost = ta(block * k * 4 * group.world), ta(block * k * 8 * group.world)
+        self.dcls, self.dperim, self.dmaxcos = ta(Tr), ta(Tr * 8), ta(Tr * 8)
+        self.dsign, self.dweight = ta(Tr), ta(Tr * 8)
+        self.dedge, self.dtflag, self.dpflag, self.dcounts = ta(Tr * 3), ta(Tr), ta(n_mov), ta(32)
+        self.dbefore, self.dafter, self.dm3, self.dflip = ta(Tr * 8), ta(Tr * 8), ta(Tr * 3), ta(Tr)
+        self.dmatch = ta(n_mov * 4)
+        self.en, self.thr = cos_threshold(15)
+        # source signs + the resident sweep state (one untimed pass)
+        ctx.sync()   # the uploads above went through the dense context's stream
+        chk(L.same_tri_sign_weight_dev(TH, self.dax.ptr, self.dsize.ptr, self.dtris.ptr, Tr, self.dsign.ptr, self.dweight.ptr), "sign")
+        self.sign0 = self.dsign.download((Tr,), np.int8)
+        self.sweep = ctypes.c_void_p()
+        chk(L.same_sweep_bind(TH, tris.ctypes.data, Tr, self.sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, n_mov, None, 0,
+                              ctypes.byref(self.sweep)), "bind")
+        self.sharded = ShardedSweeps(tctx, comm, self.sweep, self.dax, self.drx, self.dtris, Tr, n_mov) if (strong and comm is not None) else None
+        self.checked, self.nviol = ctypes.c_int64(0), ctypes.c_int64(0)
+        self.viol = np.empty(max(Tr, 1), np.int32)
+        self.last = {"checked": 0, "viol": self.viol[:0]}
+        self.n_chunks = len(range(rb, re, self.chunk_rows))
+        self.gather_ms = []     # per step: device (or, host transport, wall) time of the candidate-list all-gather
+        self.gather_bytes = 0
+        self.use_q32 = args.dense == "q32"
+        if self.use_q32:
+            from same_amd import ops
+
+            if T > 32:
+                raise SystemExit("--dense q32 supports T <= 32")
+            self.q_off, self.q_l2 = ops.quantize_types(mov["types"], ref["types"])
+            self.dAq, self.dRq = keep(ctx.alloc(mov["types"].size * 4)), keep(ctx.alloc(ref["types"].size * 4))
+            chk(L.same_quantize_u32_dev(env.H, self.dA.ptr, mov["types"].size, self.q_off, 2.0 ** self.q_l2, self.dAq.ptr), "quantize")
+            chk(L.same_quantize_u32_dev(env.H, self.dR.ptr, ref["types"].size, self.q_off, 2.0 ** self.q_l2, self.dRq.ptr), "quantize")
+        if not strong:   # candidate matching for the sweeps: nearest reference within the radius (from one untimed prune)
+            self.prune_and_costs()
+            chk(L.same_first_candidate_dev(TH, self.didx.ptr, n_mov, k, self.dmatch.ptr), "match")
+
+    # ---- the pieces of a step --------------------------------------------------------------------------------------
+    def dense_launch(self, c0, c1):
+        e, L, H = self.env, self.env.L, self.env.H
+        if self.use_q32:
+            return L.same_dense_cost_q32_dev(H, self.dAq.ptr, self.dRq.ptr, self.dA.ptr, self.dR.ptr, self.T, self.dax.ptr, self.drx.ptr,
+                                             self.n_ref, c0, c1, 1.0, 2.0 ** -self.q_l2, 1e-6, self.dD.ptr, self.ld)
+        return L.same_dense_cost_f64_dev(H, self.dA.ptr, self.dR.ptr, self.T, self.dax.ptr, self.drx.ptr, self.n_ref, c0, c1, 1.0,
+                                         self.dD.ptr, self.ld)
+
+    def dense_all(self, timed=None):
+        """Enqueue the dense build of this rank's rows (strong mode: in chunks through the one buffer).  With `timed`, HIP
+        events on the dense stream bracket the launch(es); dense_time() reads them after the rest of the step was issued."""
+        L, H, chk = self.env.L, self.env.H, self.env.chk
+        if timed is not None:
+            chk(L.same_timer_start(H), "timer")
+        for c0 in range(self.rb, self.re, self.chunk_rows):
+            chk(self.dense_launch(c0, min(c0 + self.chunk_rows, self.re)), "dense")
+        if timed is not None:
+            chk(L.same_timer_mark(H), "timer")
+
+    def dense_time(self, timed):
+        if timed is not None:
+            ms = self.ctypes.c_float(0)
+            self.env.chk(self.env.L.same_timer_read(self.env.H, self.ctypes.byref(ms)), "timer")
+            timed.append((ms.value / max(self.n_chunks, 1), self.rows / max(self.n_chunks, 1)))   # per launch
+
+    def prune_and_costs(self):
+        L, TH, chk = self.env.L, self.env.TH, self.env.chk
+        chk(L.same_knn_prune_indexed_dev(TH, self.knn_index, self.dax.ptr, self.rb, self.re, self.k, self.didx.ptr, None, self.dcnt.ptr), "knn")
+        chk(L.same_padded_cost_f64_dev(TH, self.dA.ptr, self.dR.ptr, self.T, self.dax.ptr, self.drx.ptr, self.rb, self.re, self.k,
+                                       self.didx.ptr, 1.0, self.dcost.ptr), "padded")
+
+    def tri_maps(self):
+        L, TH, chk = self.env.L, self.env.TH, self.env.chk
+        chk(L.same_tri_classify_dev(TH, self.dax.ptr, self.dtris.ptr, self.Tr, self.radius, self.en, self.thr, self.dtype_id.ptr,
+                                    self.dcls.ptr, self.dperim.ptr, self.dmaxcos.ptr), "cls")
+        chk(L.same_tri_sign_weight_dev(TH, self.dax.ptr, self.dsize.ptr, self.dtris.ptr, self.Tr, self.dsign.ptr, self.dweight.ptr), "sign")
+
+    def local_sweeps(self):
+        L, TH, chk, c = self.env.L, self.env.TH, self.env.chk, self.ctypes
+        chk(L.same_xyorder_sweep_dev(TH, self.dax.ptr, self.n_mov, self.drx.ptr, self.dtris.ptr, self.Tr, self.dmatch.ptr, self.dedge.ptr,
+                                     self.dtflag.ptr, self.dpflag.ptr, self.dcounts.ptr), "xy")
+        chk(L.same_area_flip_dev(TH, self.dax.ptr, self.drx.ptr, self.dtris.ptr, self.Tr, self.dmatch.ptr, self.dbefore.ptr, self.dafter.ptr,
+                                 self.dm3.ptr, self.dflip.ptr), "area")
+        chk(L.same_orient_sweep_dev(self.sweep, self.dmatch.ptr, c.byref(self.checked), self.viol.ctypes.data, c.byref(self.nviol)), "orient")
+        self.last["checked"], self.last["viol"] = self.checked.value, self.viol[: self.nviol.value]
+
+    def _gather_read(self):
+        ms, nb = self.env.comm.gather_time()
+        self.gather_ms.append(ms)
+        self.gather_bytes = nb
+
+    def step(self, timed=None, gather=True):
+        comm, k, block = self.env.comm, self.k, self.block
+        gather = gather and comm is not None
+        self.dense_all(timed=timed)
+        if self.strong:
+            self.prune_and_costs()
+            if gather:
+                comm.wait()                                   # closes the previous step's timing batch
+                comm.allgather_dev(self.didx, self.gidx, block * k * 4)
+                comm.allgather_dev(self.dcost, self.gcost, block * k * 8)
+                if comm.synchronous:
+                    self._gather_read()
+            # the common matching: nearest reference of every aligned cell, from the gathered lists (identical on every rank;
+            # a loop run without the gather reuses the lists of the last gather)
+            src = self.gidx if comm is not None else self.didx
+            self.env.chk(self.env.L.same_first_candidate_dev(self.env.TH, src.ptr, self.n_mov, k, self.dmatch.ptr), "match")
+            self.tri_maps()
+            if self.sharded is not None:
+                self.last["checked"], self.last["viol"] = self.sharded.run(self.dmatch)
+            else:
+                self.local_sweeps()
+            self.dense_time(timed)
+            if gather and not comm.synchronous:
+                self._gather_read()
+        else:
+            if gather:
+                comm.wait()   # the previous step's gather (still reading didx/dcost) overlapped the dense build above
+            self.prune_and_costs()
+            if gather:  # on the communication stream: overlaps the sweeps below and the next step's dense build
+                comm.allgather_dev_async(self.didx, self.gidx, block * k * 4)
+                comm.allgather_dev_async(self.dcost, self.gcost, block * k * 8)
+            self.tri_maps()
+            self.local_sweeps()
+            self.dense_time(timed)       # waits for the dense kernel: the gather issued above has long finished by then
+            if gather:
+                self._gather_read()
+
+    def timed_loop(self, steps, warmup, gather=True):
+        """warm-up, barrier + sync, exactly `steps` steps, sync + barrier; -> (seconds, max over ranks; [(dense ms, rows)] of this rank)."""
+        env = self.env
+        for _ in range(warmup):
+            self.step(gather=gather)
+        env.ctx.sync()
+        env.tctx.sync()
+        env.group.barrier()
+        self.gather_ms = []
+        dense_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(timed=dense_ms, gather=gather)
+        env.ctx.sync()
+        env.tctx.sync()
+        env.group.barrier()
+        return env.group.max(time.perf_counter() - t0), dense_ms
+
+    def transport_check(self):
+        """Did the exchange deliver the right rows to the right place?  Rank 0 recomputes the first rows of the LAST rank's
+        block on its own GPU (weak mode: from that rank's seed) and compares them with what the gather put into its own copy of
+        the gathered lists, bit for bit.  (A transport check; the arithmetic itself is checked at N=1.)  -> description."""
+        from same_amd import synth
+
+        env, np = self.env, self.np
+        L, TH, chk, tctx, group = env.L, env.TH, env.chk, env.tctx, env.group
+        tctx.sync()
+        peer, k = group.world - 1, self.k
+        S = min(2000, self.block)
+        if self.strong:
+            peer_mov, p0 = self.mov, peer * self.block
+            S = max(0, min(S, self.n_mov - p0))
+        else:
+            peer_mov, p0 = synth.make_cells(self.rows_cfg, self.T, seed=1 + peer, side=self.ref["side"]), 0
+        if S <= 0:
+            return "transport: the last rank's block is empty, nothing to compare"
+        pA, pxy = tctx.to_device(peer_mov["types"]), tctx.to_device(peer_mov["xy"])
+        pidx, pcost, pcnt = tctx.alloc(S * k * 4), tctx.alloc(S * k * 8), tctx.alloc(S * 4)
+        chk(L.same_knn_prune_indexed_dev(TH, self.knn_index, pxy.ptr, p0, p0 + S, k, pidx.ptr, None, pcnt.ptr), "knn")
+        chk(L.same_padded_cost_f64_dev(TH, pA.ptr, self.dR.ptr, self.T, pxy.ptr, self.drx.ptr, p0, p0 + S, k, pidx.ptr, 1.0, pcost.ptr), "padded")
+        want_i, want_c = pidx.download((S, k), np.int32), pcost.download((S, k), np.float64)
+        got_i = self.gidx.download((S, k), np.int32, offset_bytes=peer * self.block * k * 4)
+        got_c = self.gcost.download((S, k), np.float64, offset_bytes=peer * self.block * k * 8)
+        for b in (pA, pxy, pidx, pcost, pcnt):
+            b.free()
+        if not (np.array_equal(got_i, want_i) and np.array_equal(got_c, want_c)):
+            raise SystemExit(f"gathered candidate lists of rank {peer} differ from a local recomputation: refusing to report a number")
+        return (f"transport: rows [0,{S}) of rank {peer}'s block in rank 0's gathered lists (idx + cost) equal a local recomputation "
+                "bit for bit; arithmetic parity is the N=1 run's check")
+
+    def workload_text(self):
+        w = self.env.group.world
+        shape = (f"ONE problem of {self.n_mov} aligned x {self.n_ref} ref cells, aligned-row blocks and triangle blocks over {w} rank(s), "
+                 f"dense build in {self.chunk_rows}-row chunks" if self.strong else f"{self.rows} aligned x {self.n_ref} ref cells per GPU")
+        arith = ("fixed-point (2^-%d grid, every output within 1e-6 relative of the fp64 one) " % self.q_l2) if self.use_q32 else "fp64 "
+        return (f"{self.name}: {shape}, T={self.T} type cols, {arith}dense L1 cost + r={self.radius:g}/k={self.k} KNN prune + pair costs + "
+                f"{self.Tr} Delaunay triangles classify/sign + orientation / XY-order / area-flip sweeps")
+
+    def close(self, keep_dense=False):
+        L = self.env.L
+        self.env.ctx.sync()
+        self.env.tctx.sync()
+        L.same_sweep_unbind(self.sweep)
+        L.same_knn_index_destroy(self.knn_index)
+        if self.sharded is not None:
+            for b in vars(self.sharded).values():
+                if hasattr(b, "free"):
+                    b.free()
+        for b in self.bufs:
+            b.free()
+        if self.own_dense and not keep_dense:
+            self.dD.free()
+
+
+def make_comm(args, group, tctx):
+    """The communicator, BEFORE any spread allocation (spread.hip never reuses an address for a mapping, but it cannot speak
+    for RCCL's own use of the virtual-memory calls).  -> (comm or None, transport text)."""
+    from same_amd.dist import HostTransport, RcclGroup
+
+    if not (group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM")):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
+        return None, "none (single rank)"
+    comm = None
+    try:
+        if os.environ.get("SAME_BENCH_FAIL_RCCL"):
+            raise RuntimeError("forced by SAME_BENCH_FAIL_RCCL (test switch)")
+        # ncclCommInitRank is a collective without a timeout: if it never returns (a rank lost, a bootstrap interface that
+        # does not route) say so and leave, so the launcher stops the job at once instead of at its own limit
+        import threading
+
+        limit_s = float(os.environ.get("SAME_BENCH_RCCL_TIMEOUT", "300"))
+
+        def stuck():
+            print(f"[rank {group.rank}] RCCL communicator init has not returned after {limit_s:.0f} s; giving up", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        watchdog = threading.Timer(limit_s, stuck)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            comm = RcclGroup(tctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
+        finally:
+            watchdog.cancel()
+        ok_here = 1.0
+    except Exception as e:  # TRANSPORT fallback only (compute stays on the GPU): reported in the JSON line
+        print(f"[rank {group.rank}] RCCL communicator init failed ({e}); gathering through the host group instead", file=sys.stderr)
+        ok_here = 0.0
+    if group.min(ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
+        if comm is not None:
+            comm.close()
+        return HostTransport(tctx, group), "HOST (loopback TCP) all-gather of pruned lists: RCCL init failed on this node"
+    v = comm.rccl_version()
+    return comm, f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100} all-gather of pruned lists"
+
+
+def comm_report(env, np):
+    """`rccl`: what every rank's communicator says about itself -- the size and rank from ncclCommCount / ncclCommUserRank."""
+    me = dict(env.comm.info(), host_rank=env.group.rank, local_rank=int(os.environ.get("LOCAL_RANK", str(env.group.rank))),
+              hip_device=env.tctx.device, kind="rccl" if not env.comm.synchronous else "host")
+    every = env.group.allgather_object(me)
+    if env.group.rank != 0:
+        return None
+    v = me["version"]
+    return {"kind": me["kind"], "nranks": me["nranks"], "rank": me["rank"], "device": me["device"],
+            "version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None,
+            "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the live communicator" if me["kind"] == "rccl"
+                      else "host transport (no RCCL communicator): the host group's world and rank",
+            "every_rank": [[r["host_rank"], r["rank"], r["nranks"], r["device"]] for r in every],
+            "every_rank_columns": ["host rank", "communicator rank", "communicator size", "device"],
+            "consistent": all(r["nranks"] == env.group.world and r["rank"] == r["host_rank"] for r in every),
+            "distinct_devices": len({r["device"] for r in every})}
+
+
+def gather_report(prob, dt_with, steps_with, dt_without, steps_without):
+    """`gather`: the candidate-list all-gather by itself (events on its stream) and what it costs the step."""
+    env = prob.env
+    ms = stats3(prob.gather_ms)
+    world = env.group.world
+    with_ms, without_ms = dt_with / steps_with * 1e3, (dt_without / steps_without * 1e3 if dt_without is not None else None)
+    out = {"bytes_per_rank": int(prob.gather_bytes), "bytes_total": int(prob.gather_bytes) * world,
+           "ms": ms[1] if ms else None, "ms_min_mean_max": ms,
+           "GBs": (prob.gather_bytes * world / (ms[1] * 1e-3) / 1e9) if ms and ms[1] > 0 else None,
+           "GBs_means": "bytes every rank ends up holding (nranks x bytes_per_rank) over the gather's time on this rank",
+           "timed_with": ("HIP events on the stream the all-gathers run on (same_comm_gather_time), rank 0" if not env.comm.synchronous
+                          else "host wall time around the synchronous host-transport exchange, rank 0"),
+           "step_ms_with_gather": with_ms, "step_ms_without_gather": without_ms,
+           "steps_without_gather": steps_without if dt_without is not None else 0}
+    return out, (with_ms - without_ms if without_ms is not None else None)
+
+
 def run_rank(args):
     import ctypes
 
@@ -206,208 +564,57 @@ def run_rank(args):
         group.close()
         return
 
-    from scipy.spatial import Delaunay
-
     from same_amd import _lib, synth
-    from same_amd.dist import HostTransport, RcclGroup, ShardedSweeps, row_block
     from same_amd.telemetry import GpuTelemetry
-    from same_amd.triangles import cos_threshold
 
-    strong = args.scaling == "strong"
-    n_ref, rows_cfg, T, k, radius = WORKLOADS[args.workload]
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libsame_hip has no CPU fallback")
+    if args.workload == "cfg5":
+        return run_cfg5(args, group, json_fd)
+    strong = args.scaling == "strong"
     ctx = _lib.Context(local_rank % _lib.device_count())          # the dense build's context (one context = one stream)
     L, H, chk = ctx.lib, ctx.handle, ctx.check
     # The rest of the step (prune, candidate costs, gather, triangle maps, sweeps) does not read the dense block, so it
     # runs on a context of its own: its small latency-bound kernels fill in beside the 16 ms dense kernel instead of
     # queueing behind it, and the per-step read-back of the sweep waits for that stream only.
     tctx = _lib.Context(ctx.device) if args.tail_stream == "own" else ctx
-    TH = tctx.handle
+    comm, transport = make_comm(args, group, tctx)
+    if comm is not None and not comm.synchronous and not strong:
+        transport += " (overlapped on a second stream)"
+    env = Env(args, group, ctx, tctx, comm, transport)
+    rccl = comm_report(env, np) if comm is not None else None
 
-    # ---- synthetic inputs (seeded), resident before timing ---------------------------------------------------------
-    ref = synth.make_cells(n_ref, T, seed=0)
-    if strong:   # ONE problem: every rank holds all aligned cells (XY/types are a few MB) and owns a row block of the work
-        mov = synth.make_cells(rows_cfg, T, seed=1, side=ref["side"])
-        rb, re, block = row_block(rows_cfg, group.world, group.rank)
-        n_mov = rows_cfg
-    else:        # weak: every rank owns its own section of rows_cfg aligned cells
-        mov = synth.make_cells(rows_cfg, T, seed=1 + group.rank, side=ref["side"])
-        rb, re, block, n_mov = 0, rows_cfg, rows_cfg, rows_cfg
-    rows = re - rb
-    tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)  # host input (Qhull), as in the reference
-    Tr = len(tris)
-    dA, dR = ctx.to_device(mov["types"]), ctx.to_device(ref["types"])
-    dax, drx = ctx.to_device(mov["xy"]), ctx.to_device(ref["xy"])
-    dsize, dtype_id = ctx.to_device(mov["size"]), ctx.to_device(mov["cell_type"])
-    dtris = ctx.to_device(tris)
-    ld = (n_ref + 1) & ~1
-    chunk_rows = max(1, min(max(rows, 1), int(STRONG_CHUNK_BYTES // (ld * 8)))) if strong else rows
-    # the dense cost block (80 GB at dense100k), laid over the card's three HBM regions: a streaming store confined to one
-    # region runs ~20 % below one spread over them, and a plain hipMalloc lands wherever the free lists point (spread.hip)
-    dD = ctx.alloc_spread(max(chunk_rows, 1) * ld * 8)
-    didx, dcost, dcnt = tctx.alloc(block * k * 4), tctx.alloc(block * k * 8), tctx.alloc(max(block, 1) * 4)
-    chk(L.same_dev_memset(TH, didx.ptr, 0xFF, didx.nbytes), "memset")   # rows past a short last block stay -1
-    # caller-held grid index of the reference cells: built once, reused by every prune of the run
-    knn_index = ctypes.c_void_p()
-    chk(L.same_knn_index_build(TH, drx.ptr, n_ref, radius, ctypes.byref(knn_index)), "same_knn_index_build")
-
-    comm, transport = None, "none (single rank)"
-    if group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM"):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
-        try:
-            if os.environ.get("SAME_BENCH_FAIL_RCCL"):
-                raise RuntimeError("forced by SAME_BENCH_FAIL_RCCL (test switch)")
-            # ncclCommInitRank is a collective without a timeout: if it never returns (a rank lost, a bootstrap interface that
-            # does not route) say so and leave, so the launcher stops the job at once instead of at its own limit
-            import threading
-
-            def stuck():
-                print(f"[rank {group.rank}] RCCL communicator init has not returned after {limit_s:.0f} s; giving up", file=sys.stderr, flush=True)
-                os._exit(3)
-
-            limit_s = float(os.environ.get("SAME_BENCH_RCCL_TIMEOUT", "300"))
-            watchdog = threading.Timer(limit_s, stuck)
-            watchdog.daemon = True
-            watchdog.start()
-            try:
-                comm = RcclGroup(tctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
-            finally:
-                watchdog.cancel()
-            ok_here = 1.0
-        except Exception as e:  # TRANSPORT fallback only (compute stays on the GPU): reported in the JSON line
-            print(f"[rank {group.rank}] RCCL communicator init failed ({e}); gathering through the host group instead", file=sys.stderr)
-            ok_here = 0.0
-        if group.min(ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
-            if comm is not None:
-                comm.close()
-            comm = HostTransport(tctx, group)
-            transport = "HOST (loopback TCP) all-gather of pruned lists: RCCL init failed on this node"
-        else:
-            v = comm.rccl_version()
-            transport = f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100} all-gather of pruned lists" + \
-                        ("" if strong else " (overlapped on a second stream)")
-    gidx = gcost = None
-    if comm is not None:
-        gidx, gcost = tctx.alloc(block * k * 4 * group.world), tctx.alloc(block * k * 8 * group.world)
+    prob = Problem(env, args.workload, strong)
+    n_ref, T, k, radius, rows, n_mov, Tr, ld = prob.n_ref, prob.T, prob.k, prob.radius, prob.rows, prob.n_mov, prob.Tr, prob.ld
+    dD, dA, dR, dax, drx = prob.dD, prob.dA, prob.dR, prob.dax, prob.drx
+    mov, ref, tris, use_q32 = prob.mov, prob.ref, prob.tris, prob.use_q32
     note(group, f"inputs resident ({rows} of {n_mov} aligned x {n_ref} ref, {Tr} triangles); gather transport: {transport}")
 
-    ta = tctx.alloc
-    dcls, dperim, dmaxcos = ta(Tr), ta(Tr * 8), ta(Tr * 8)
-    dsign, dweight = ta(Tr), ta(Tr * 8)
-    dedge, dtflag, dpflag, dcounts = ta(Tr * 3), ta(Tr), ta(n_mov), ta(32)
-    dbefore, dafter, dm3, dflip = ta(Tr * 8), ta(Tr * 8), ta(Tr * 3), ta(Tr)
-    dmatch = ta(n_mov * 4)
-    en, thr = cos_threshold(15)
-
-    # source signs + the resident sweep state (one untimed pass)
-    ctx.sync()   # the uploads above went through the dense context's stream
-    chk(L.same_tri_sign_weight_dev(TH, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
-    sign0 = dsign.download((Tr,), np.int8)
-    sweep = ctypes.c_void_p()
-    chk(L.same_sweep_bind(TH, tris.ctypes.data, Tr, sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, n_mov, None, 0,
-                          ctypes.byref(sweep)), "bind")
-    sharded = ShardedSweeps(tctx, comm, sweep, dax, drx, dtris, Tr, n_mov) if (strong and comm is not None) else None
-    checked, nviol = ctypes.c_int64(0), ctypes.c_int64(0)
-    viol = np.empty(max(Tr, 1), np.int32)
-    last = {"checked": 0, "viol": viol[:0]}
-    dense_ms = []
-
-    n_chunks = len(range(rb, re, chunk_rows))
-    use_q32 = args.dense == "q32"
-    if use_q32:
-        from same_amd import ops
-
-        if T > 32:
-            raise SystemExit("--dense q32 supports T <= 32")
-        q_off, q_l2 = ops.quantize_types(mov["types"], ref["types"])
-        dAq, dRq = ctx.alloc(mov["types"].size * 4), ctx.alloc(ref["types"].size * 4)
-        chk(L.same_quantize_u32_dev(H, dA.ptr, mov["types"].size, q_off, 2.0 ** q_l2, dAq.ptr), "quantize")
-        chk(L.same_quantize_u32_dev(H, dR.ptr, ref["types"].size, q_off, 2.0 ** q_l2, dRq.ptr), "quantize")
-
-    def dense_launch(c0, c1):
-        if use_q32:
-            return L.same_dense_cost_q32_dev(H, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, c0, c1, 1.0, 2.0 ** -q_l2, 1e-6, dD.ptr, ld)
-        return L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, c0, c1, 1.0, dD.ptr, ld)
-
-    def dense_all(T_=T, timed=None):
-        """Enqueue the dense build of this rank's rows (strong mode: in chunks through the one buffer).  With `timed`, HIP
-        events on the dense stream bracket the launch(es); dense_time() reads them after the rest of the step was issued."""
-        if timed is not None:
-            chk(L.same_timer_start(H), "timer")
-        for c0 in range(rb, re, chunk_rows):
-            chk(dense_launch(c0, min(c0 + chunk_rows, re)), "dense")
-        if timed is not None:
-            chk(L.same_timer_mark(H), "timer")
-
-    def dense_time(timed):
-        if timed is not None:
-            ms = ctypes.c_float(0)
-            chk(L.same_timer_read(H, ctypes.byref(ms)), "timer")
-            timed.append((ms.value / max(n_chunks, 1), rows / max(n_chunks, 1)))   # per launch
-
-    def prune_and_costs():
-        chk(L.same_knn_prune_indexed_dev(TH, knn_index, dax.ptr, rb, re, k, didx.ptr, None, dcnt.ptr), "knn")
-        chk(L.same_padded_cost_f64_dev(TH, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, rb, re, k, didx.ptr, 1.0, dcost.ptr), "padded")
-
-    def tri_maps():
-        chk(L.same_tri_classify_dev(TH, dax.ptr, dtris.ptr, Tr, radius, en, thr, dtype_id.ptr, dcls.ptr, dperim.ptr, dmaxcos.ptr), "cls")
-        chk(L.same_tri_sign_weight_dev(TH, dax.ptr, dsize.ptr, dtris.ptr, Tr, dsign.ptr, dweight.ptr), "sign")
-
-    def local_sweeps():
-        chk(L.same_xyorder_sweep_dev(TH, dax.ptr, n_mov, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dedge.ptr, dtflag.ptr, dpflag.ptr, dcounts.ptr), "xy")
-        chk(L.same_area_flip_dev(TH, dax.ptr, drx.ptr, dtris.ptr, Tr, dmatch.ptr, dbefore.ptr, dafter.ptr, dm3.ptr, dflip.ptr), "area")
-        chk(L.same_orient_sweep_dev(sweep, dmatch.ptr, ctypes.byref(checked), viol.ctypes.data, ctypes.byref(nviol)), "orient")
-        last["checked"], last["viol"] = checked.value, viol[: nviol.value]
-
-    def step_weak(timed=None):
-        dense_all(timed=timed)
-        if comm is not None:
-            comm.wait()   # the previous step's gather (still reading didx/dcost) overlapped the dense build above
-        prune_and_costs()
-        if comm is not None:  # on the communication stream: overlaps the sweeps below and the next step's dense build
-            comm.allgather_dev_async(didx, gidx, block * k * 4)
-            comm.allgather_dev_async(dcost, gcost, block * k * 8)
-        tri_maps()
-        local_sweeps()
-        dense_time(timed)
-
-    def step_strong(timed=None):
-        dense_all(timed=timed)
-        prune_and_costs()
-        if comm is not None:
-            comm.allgather_dev(didx, gidx, block * k * 4)
-            comm.allgather_dev(dcost, gcost, block * k * 8)
-        # the common matching: nearest reference of every aligned cell, from the gathered lists (identical on every rank)
-        chk(L.same_first_candidate_dev(TH, (gidx if comm is not None else didx).ptr, n_mov, k, dmatch.ptr), "match")
-        tri_maps()
-        if sharded is not None:
-            last["checked"], last["viol"] = sharded.run(dmatch)
-        else:
-            local_sweeps()
-        dense_time(timed)
-
-    step = step_strong if strong else step_weak
-    if not strong:   # candidate matching for the sweeps: nearest reference within the radius (from one untimed prune)
-        prune_and_costs()
-        chk(L.same_first_candidate_dev(TH, didx.ptr, n_mov, k, dmatch.ptr), "match")
-
-    for _ in range(args.warmup):
-        step()
-    ctx.sync()
-    tctx.sync()
-    group.barrier()
-    note(group, "warm-up done, timing")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=dense_ms)
-    ctx.sync()
-    tctx.sync()
-    group.barrier()
-    dt = group.max(time.perf_counter() - t0)
+    dt, dense_ms = prob.timed_loop(args.steps, args.warmup)
     note(group, f"{args.steps} steps in {dt:.3f} s")
 
+    # ---- N > 1 (or the forced communicator): the line explains itself ------------------------------------------------
+    gather = gather_hidden_ms = per_rank = parity_transport = strong_rec = None
+    if comm is not None:
+        gather_steps = list(prob.gather_ms)
+        steps_ng = max(1, min(args.steps, 5))
+        dt_ng, _ = prob.timed_loop(steps_ng, 1, gather=False)       # the same step without the candidate-list gather
+        prob.gather_ms = gather_steps
+        gather, gather_hidden_ms = gather_report(prob, dt, args.steps, dt_ng, steps_ng)
+        mine = {"rank": group.rank, "device": ctx.device, "pci": ctx.pci_bus_id(), "dense_ms": stats3([m for m, _ in dense_ms]),
+                "gather_ms": stats3(gather_steps)}
+        every = group.allgather_object(mine)
+        per_rank = {"dense_ms_min_mean_max_over_ranks": stats3([r["dense_ms"][1] for r in every]),
+                    "dense_ms_by_rank": [r["dense_ms"][1] for r in every], "gather_ms_by_rank": [(r["gather_ms"] or [None, None])[1] for r in every],
+                    "device_by_rank": [r["device"] for r in every], "pci_by_rank": [r["pci"] for r in every]}
+        prob.step()                                                    # one more step WITH the gather: the lists the check reads
+        if group.rank == 0:
+            parity_transport = prob.transport_check()
+        note(group, f"gather {gather['ms']} ms per step on its stream; step {gather['step_ms_with_gather']:.3f} ms with it, "
+                    f"{gather['step_ms_without_gather']:.3f} ms without")
+
     # ---- after the timed region, rank 0 at N=1: ceilings, operating point, T sweep (all on the warm chip) ------------
-    match = dmatch.download((n_mov,), np.int32)
+    match = prob.dmatch.download((n_mov,), np.int32)
     extras = {}
     if group.rank == 0 and group.world == 1 and not args.no_extras and not strong:
         def timed_ms(call, what, reps=5):
@@ -422,8 +629,13 @@ def run_rank(args):
 
         t_store_only = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense T=0")
         t_memset = timed_ms(lambda: L.same_dev_memset(H, dD.ptr, 0, rows * ld * 8), "memset")
+        # device copy of half the block onto the other half: reads N bytes and writes N bytes, 2N bytes of HBM traffic
+        half = (rows * ld * 8 // 2) & ~0xFFF
+        t_copy = timed_ms(lambda: L.same_d2d(H, dD.ptr + half, dD.ptr, half), "d2d copy") if half > 0 else None
         extras["ceilings"] = {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
                               "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
+                              "device_copy_GBs": (2.0 * half / t_copy / 1e9) if t_copy else None,
+                              "device_copy_means": f"hipMemcpyAsync device-to-device of {half / 1e9:.1f} GB inside the cost block; read + written bytes over its time",
                               "measured": "after the timed loop, warm chip, mean of 5 launches each"}
         # the same two stores into a plain hipMalloc buffer of this process, when the card has room for a second block
         if dD.spread_info and dD.spread_info["spread"]:
@@ -447,8 +659,8 @@ def run_rank(args):
             tel.start()
             t_end = time.perf_counter() + float(os.environ.get("SAME_BENCH_TELEMETRY_S", "2.0"))
             while time.perf_counter() < t_end:
-                dense_all(timed=loop_ms)
-                dense_time(loop_ms)
+                prob.dense_all(timed=loop_ms)
+                prob.dense_time(loop_ms)
             tele = tel.stop()
             tele["dense_ms_during_window"] = float(np.mean([m for m, _ in loop_ms]))
             tele["what"] = f"dense kernel (T={T}, fp64) looped alone for the window; sysfs read every {tel.period * 1e3:.0f} ms by a side thread"
@@ -503,43 +715,19 @@ def run_rank(args):
     # ---- CPU baseline leg (rank 0, N=1, untimed region): the oracle runs a bounded sample of the same workload on the
     # host; its outputs double as a parity check of what the GPU just produced (the only place bench.py touches oracle/) ----
     cpu = None
-    parity = "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
-    # ---- N > 1: did the exchange deliver the right rows to the right place?  Rank 0 recomputes the first rows of the LAST
-    # rank's block on its own GPU (weak mode: from that rank's seed) and compares them with what the gather put into its
-    # own copy of the gathered lists, bit for bit.  (A transport check; the arithmetic itself is checked at N=1.)
-    if comm is not None and group.rank == 0 and not args.dry_launch:
-        tctx.sync()
-        peer = group.world - 1
-        S = min(2000, block)
-        if strong:
-            peer_mov, p0 = mov, peer * block
-            S = max(0, min(S, n_mov - p0))
-        else:
-            peer_mov, p0 = synth.make_cells(rows_cfg, T, seed=1 + peer, side=ref["side"]), 0
-        if S > 0:
-            pA, pxy = tctx.to_device(peer_mov["types"]), tctx.to_device(peer_mov["xy"])
-            pidx, pcost, pcnt = tctx.alloc(S * k * 4), tctx.alloc(S * k * 8), tctx.alloc(S * 4)
-            chk(L.same_knn_prune_indexed_dev(TH, knn_index, pxy.ptr, p0, p0 + S, k, pidx.ptr, None, pcnt.ptr), "knn")
-            chk(L.same_padded_cost_f64_dev(TH, pA.ptr, dR.ptr, T, pxy.ptr, drx.ptr, p0, p0 + S, k, pidx.ptr, 1.0, pcost.ptr), "padded")
-            want_i, want_c = pidx.download((S, k), np.int32), pcost.download((S, k), np.float64)
-            got_i = gidx.download((S, k), np.int32, offset_bytes=peer * block * k * 4)
-            got_c = gcost.download((S, k), np.float64, offset_bytes=peer * block * k * 8)
-            if not (np.array_equal(got_i, want_i) and np.array_equal(got_c, want_c)):
-                raise SystemExit(f"gathered candidate lists of rank {peer} differ from a local recomputation: refusing to report a number")
-            parity = (f"transport: rows [0,{S}) of rank {peer}'s block in rank 0's gathered lists (idx + cost) equal a local recomputation "
-                      "bit for bit; arithmetic parity is the N=1 run's check")
+    parity = parity_transport or "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
     if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
         from oracle import same_oracle as orc
 
         if strong or extras:   # the resident block was reused by the probes above: rebuild this rank's first chunk for the check
-            chk(dense_launch(rb, min(rb + chunk_rows, re)), "dense")
+            chk(prob.dense_launch(prob.rb, min(prob.rb + prob.chunk_rows, prob.re)), "dense")
             ctx.sync()
-        S = min(args.cpu_sample_rows, rows, chunk_rows)
+        S = min(args.cpu_sample_rows, rows, prob.chunk_rows)
         c0 = time.perf_counter()
         want_dense = orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, 0, S)
         exact_dense = want_dense
         if use_q32:   # the fixed-point build is checked against ITS twin bit for bit, and against the exact costs within the tolerance
-            want_dense = orc.dense_cost_q32(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, q_off, q_l2, 0, S)
+            want_dense = orc.dense_cost_q32(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, prob.q_off, prob.q_l2, 0, S)
             if float(np.max(np.abs(want_dense - exact_dense) / exact_dense)) > 1e-6:
                 raise SystemExit("fixed-point dense costs are outside 1e-6 relative of the exact ones: refusing to report a number")
         oi, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, S)
@@ -548,7 +736,7 @@ def run_rank(args):
         c1 = time.perf_counter()
         orc.tri_classify(mov["xy"], tris, radius, 15, mov["cell_type"])
         orc.tri_sign_weight(mov["xy"], mov["size"], tris)
-        och, oviol, _ = orc.orient_sweep(tris, sign0, ref["xy"], match)
+        och, oviol, _ = orc.orient_sweep(tris, prob.sign0, ref["xy"], match)
         orc.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
         orc.area_flip(mov["xy"], ref["xy"], tris, match)
         c2 = time.perf_counter()
@@ -557,16 +745,18 @@ def run_rank(args):
         ok = True
         for i in np.random.default_rng(0).choice(S, min(8, S), replace=False):
             ok &= bool(np.array_equal(dD.download((n_ref,), np.float64, offset_bytes=int(i) * ld * 8), want_dense[i]))
-        ok &= bool(np.array_equal(didx.download((S, k), np.int32), oi))
-        got_pc = dcost.download((S, k), np.float64)
+        ok &= bool(np.array_equal(prob.didx.download((S, k), np.int32), oi))
+        got_pc = prob.dcost.download((S, k), np.float64)
         ok &= bool(np.array_equal(got_pc[rr, cc], want_pc))
-        ok &= (och == last["checked"]) and bool(np.array_equal(oviol, last["viol"]))
+        ok &= (och == prob.last["checked"]) and bool(np.array_equal(oviol, prob.last["viol"]))
         if not ok:
             raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
         parity = f"dense rows, pruned lists and pair costs of rows [0,{S}) and the orientation sweep equal the oracle bit-for-bit"
         if use_q32:
             parity = (f"dense rows of [0,{S}) equal the fixed-point build's oracle twin bit-for-bit and are within 1e-6 relative of the exact "
                       f"fp64 costs on all {S} x {n_ref} pairs; pruned lists, pair costs and the orientation sweep equal the oracle bit-for-bit")
+        if parity_transport:
+            parity += "; " + parity_transport
         note(group, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
         del want_dense
         # best-effort multi-core CPU lines: the dense sample split over host threads (ctypes releases the GIL),
@@ -610,6 +800,39 @@ def run_rank(args):
                                  "container (BASELINE.md section 3, 1 of 8 vCPU): 1.0-1.3e3 pairs/s pair-cost loop, 6.5e3 triangles/s "
                                  "filter, 2.7e5 triangles/s lazy sweep, 1.6e7 dense-equivalent cell-pairs/s KNN at 10k x 10k"}
 
+    # ---- N > 1, weak run: BASELINE cfg 4 as an embedded record (ONE problem over the ranks; the resident block is reused) ----
+    if comm is not None and not strong and not args.no_strong_record:
+        sname = STRONG_OF.get(args.workload, args.workload)
+        note(group, f"embedded strong record: {sname} as ONE problem over {group.world} rank(s)")
+        prob.close(keep_dense=True)
+        sp = Problem(env, sname, True, dense_buf=dD)
+        s_steps = max(1, min(args.steps, 5))
+        s_dt, s_dense = sp.timed_loop(s_steps, 1)
+        s_gather_steps = list(sp.gather_ms)
+        s_ng_steps = max(1, min(s_steps, 3))
+        s_dt_ng, _ = sp.timed_loop(s_ng_steps, 1, gather=False)
+        sp.gather_ms = s_gather_steps
+        s_gather, s_hidden = gather_report(sp, s_dt, s_steps, s_dt_ng, s_ng_steps)
+        s_every = group.allgather_object(stats3([m for m, _ in s_dense]) if s_dense else None)
+        sp.step()
+        s_check = sp.transport_check() if group.rank == 0 else None
+        if group.rank == 0:
+            ms_launch = float(np.mean([m for m, _ in s_dense])) if s_dense else None
+            rows_launch = float(np.mean([r for _, r in s_dense])) if s_dense else 0.0
+            s_bytes = 8.0 * sp.n_ref * rows_launch + 8.0 * (sp.T + 2) * (sp.n_ref + rows_launch)
+            strong_rec = {"config": {"workload": sp.workload_text(),
+                                     "parallelism": f"aligned-row blocks x{group.world}, {transport.replace(' (overlapped on a second stream)', '')}"
+                                                    + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if sp.sharded is not None else "")},
+                          "scaling": "strong", "value": float(sp.n_ref) * sp.n_mov * s_steps / s_dt, "unit": "cell-pairs/s", "steps": s_steps, "warmup": 1,
+                          "ms_per_step": s_dt / s_steps * 1e3, "rows_this_rank": sp.rows, "dense_launches_per_step": sp.n_chunks,
+                          "dense_kernel_ms": ms_launch, "dense_GBs": (s_bytes / (ms_launch * 1e-3) / 1e9) if ms_launch else None,
+                          "dense_frac_of_hbm_peak": (s_bytes / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_launch else None,
+                          "per_rank_dense_ms": stats3([e[1] for e in s_every if e]), "dense_ms_by_rank": [e[1] if e else None for e in s_every],
+                          "gather": s_gather, "gather_hidden_ms": s_hidden, "parity_spot_check": s_check,
+                          "sweep_outputs": {"checked": int(sp.last["checked"]), "flipped": int(len(sp.last["viol"]))}}
+        sp.close(keep_dense=True)
+        prob = None
+
     if group.rank == 0:
         total_rows = n_mov if strong else rows * group.world
         pairs_per_step = float(n_ref) * total_rows
@@ -627,7 +850,8 @@ def run_rank(args):
             except Exception:
                 traffic = None
         achieved = dense_bytes / t_dense / 1e9
-        valu_rate = (2 * T + 5) * float(n_ref) * rows_launch / t_dense / 1e12
+        lane_instr = (2 * T + 5) * float(n_ref) * rows_launch      # fp64 VALU lane-instructions of one launch
+        valu_rate = lane_instr / t_dense / 1e12
         if use_q32:
             dense_bytes = 8.0 * n_ref * rows_launch + (4.0 * T + 16.0) * (n_ref + rows_launch)
             achieved = dense_bytes / t_dense / 1e9
@@ -639,22 +863,29 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3, "launches_timed": len(dense_ms),
                 # secondary ceiling: (2T+5) fp64 VALU lane-instructions per output against the vector issue peak
                 "valu_fp64": None if use_q32 else {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": valu_rate,
-                                                   "peak_Tinstr_s": FP64_ISSUE_PEAK_T, "frac": valu_rate / FP64_ISSUE_PEAK_T}}
+                                                   "peak_Tinstr_s": FP64_ISSUE_PEAK_T, "frac": valu_rate / FP64_ISSUE_PEAK_T},
+                "valu_floor_ms_at_held_clock": None, "valu_busy_frac": None, "frac_of_measured_copy_bw": None}
         msg = ["frac is against the 8.0 TB/s HBM spec as BASELINE.json asks"]
         if use_q32:
             msg.append("THIS LINE WAS RUN WITH --dense q32: the step's dense build is the opt-in fixed-point kernel (exact integer type sums on a "
-                       f"2^-{q_l2} grid, sums too small for the grid recomputed in fp64: every output within 1e-6 relative of the reference's "
+                       f"2^-{prob.q_l2 if prob else '?'} grid, sums too small for the grid recomputed in fp64: every output within 1e-6 relative of the reference's "
                        "fp64 cost, which is BASELINE.json's tolerance) -- not the reference's arithmetic; the default run reports the bit-exact kernel")
         roof["output_buffer"] = dD.spread_info
         if dD.spread_info and dD.spread_info["spread"]:
             si = dD.spread_info
             msg.append(f"the cost block is {si['chunks_gib']} GiB mapped round-robin from the card's three HBM regions ({si['per_region']} GiB per region, "
-                       f"{si['straddling']} straddling; found by timed stores in {si['seconds']:.1f} s before the timed region): a streaming store confined to "
-                       "one region runs ~20 % below one spread over them")
+                       f"{si['straddling']} straddling; found by timed stores in {si['seconds']:.1f} s before the timed region; "
+                       + (f"verified: one store over the finished range ran at {si['final_store_gbps']} GB/s against a same-region level of "
+                          f"{si['same_region_level_gbps']}" if si.get("verified") else "NOT verified: a store over the finished range did not reach the fast level")
+                       + "): a streaming store confined to one region runs ~20 % below one spread over them")
         if "ceilings" in extras:
             c = extras["ceilings"]
             c["frac_of_T0_store_rate"] = achieved / c["same_kernel_T0_store_only_GBs"]
             roof["measured_ceilings"] = c
+            if c.get("device_copy_GBs"):
+                roof["frac_of_measured_copy_bw"] = achieved / c["device_copy_GBs"]
+                msg.append(f"a device-to-device copy on this box moves {c['device_copy_GBs']:.0f} GB/s (read + written): the kernel's {achieved:.0f} GB/s is "
+                           f"{roof['frac_of_measured_copy_bw']:.2f} of that")
             if "plain_hipMalloc_buffer" in c:
                 pb = c["plain_hipMalloc_buffer"]
                 msg.append(f"a plain hipMalloc buffer of the same size in this process: T=0 store {pb['same_kernel_T0_store_only_GBs']:.0f} GB/s, "
@@ -669,14 +900,21 @@ def run_rank(args):
             if t.get("available") and t.get("power"):
                 clk = t.get("sclk_steady") or t.get("sclk_hwmon") or t.get("sclk_dpm")
                 pw = t.get("power_steady") or t["power"]
+                if clk and not use_q32:
+                    # every fp64 VALU instruction of a wave64 holds its SIMD for 4 cycles: the time the launch's instructions need
+                    # at the clock the board held while this kernel looped, and the share of the launch they fill
+                    floor_ms = lane_instr / (SIMDS * FP64_LANES_PER_CLK * clk["mean"] * 1e6) * 1e3
+                    roof["valu_floor_ms_at_held_clock"] = floor_ms
+                    roof["valu_busy_frac"] = floor_ms / (t.get("dense_ms_during_window") or t_dense * 1e3)
+                    roof["held_clock_mhz"], roof["board_power_w"], roof["board_power_cap_w"] = clk["mean"], pw["mean"], t.get("power_cap_w")
                 msg.append(f"while the kernel looped the board drew {pw['mean']:.0f} W in steady state (max {t['power']['max']:.0f} W"
                            + (f", cap {t['power_cap_w']:.0f} W" if t.get("power_cap_w") else "") + ")"
                            + (f" at a shader clock of {clk['mean']:.0f} MHz (min {clk['min']:.0f})" if clk else "")
                            + ("".join(f", {n} {v['mean']:.0f} C" + (f" (critical {t['temperature_crit_c'][n]:.0f})" if (t.get('temperature_crit_c') or {}).get(n) else "")
                                       for n, v in (t.get("temperature_steady") or {}).items() if v))
-                           + ("" if use_q32 else f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
-                              + (f"{(2 * T + 5) * float(n_ref) * rows_launch / (1024 * 16 * clk['mean'] * 1e6) * 1e3:.1f} ms" if clk else "n/a")
-                              + f" of the {t_dense * 1e3:.1f} ms launch"))
+                           + ("" if use_q32 or not clk else f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
+                              f"{roof['valu_floor_ms_at_held_clock']:.1f} ms of the {t.get('dense_ms_during_window') or t_dense * 1e3:.1f} ms launch "
+                              f"(VALU busy {roof['valu_busy_frac']:.2f}): the bound of this kernel is fp64 issue under the board power cap, not HBM"))
             else:
                 msg.append("board power / clock could not be read from sysfs on this box")
         if "sweep" in extras:
@@ -689,34 +927,51 @@ def run_rank(args):
                            f"{ctl[0]['max_rel_diff_vs_exact_on_16_rows']:.1e} on 16 sampled rows), in {ctl[0]['ms']:.2f} ms = {ctl[0]['frac']:.3f} of the "
                            "HBM spec -- the gap to this kernel is the energy of the fp64 arithmetic, not memory traffic")
         roof["note"] = "; ".join(msg)
+        chunk_rows = int(rows_launch)
+        wl = (f"{args.workload}: " + (f"ONE problem of {n_mov} aligned x {n_ref} ref cells, aligned-row blocks and triangle "
+                                      f"blocks over {group.world} rank(s), dense build in {chunk_rows}-row chunks"
+                                      if strong else f"{rows} aligned x {n_ref} ref cells per GPU")
+              + f", T={T} type cols, " + ("fixed-point (every output within 1e-6 relative of the fp64 one) " if use_q32 else "fp64 ")
+              + f"dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
+                "triangles classify/sign + orientation / XY-order / area-flip sweeps")
         out = {
             "metric": baseline_metric(),
             "value": pairs_per_step * args.steps / dt, "unit": "cell-pairs/s",
             "n_gpus": group.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f64" if use_q32 else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: " + (f"ONE problem of {n_mov} aligned x {n_ref} ref cells, aligned-row blocks and triangle "
-                                                           f"blocks over {group.world} rank(s), dense build in {chunk_rows}-row chunks"
-                                                           if strong else f"{rows} aligned x {n_ref} ref cells per GPU")
-                                   + f", T={T} type cols, " + ("fixed-point (2^-%d grid, every output within 1e-6 relative of the fp64 one) " % q_l2 if use_q32 else "fp64 ")
-                                   + f"dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
-                                     "triangles classify/sign + orientation / XY-order / area-flip sweeps",
+            "config": {"workload": wl,
                        "streams": ("dense build on one stream, prune / costs / triangle maps / sweeps on a second (own context)"
                                    if tctx is not ctx else "one stream, in order"),
                        "parallelism": f"aligned-row blocks x{group.world}" + (", " + transport if comm is not None else "")
-                                      + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if sharded is not None else "")},
+                                      + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if (strong and comm is not None) else "")},
             "roofline": roof,
             "cpu_baseline": cpu,
             "parity_spot_check": parity,
         }
+        if comm is not None:
+            out["rccl"] = rccl
+            out["gather"] = gather
+            out["gather_hidden_ms"] = gather_hidden_ms
+            out["gather_hidden_ms_means"] = ("ms_per_step of the timed loop minus ms_per_step of a second, shorter loop of the same step without the "
+                                             "candidate-list all-gather: what the gather costs the step (about 0 = fully hidden behind the dense build)")
+            out["per_rank_dense_ms"] = per_rank["dense_ms_min_mean_max_over_ranks"]
+            out["per_rank"] = per_rank
+            if strong_rec is not None:
+                out["strong_cfg4" if STRONG_OF.get(args.workload) == "cfg4" else "strong_record"] = strong_rec
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
-    L.same_sweep_unbind(sweep)
-    L.same_knn_index_destroy(knn_index)
+    if prob is not None:
+        prob.close(keep_dense=True)
+    dD.free()
     if comm is not None:
         comm.close()
     if tctx is not ctx:
         tctx.close()
     group.close()
+
+
+def run_cfg5(args, group, json_fd):
+    raise SystemExit("--workload cfg5 is not available in this build")
 
 
 def main():

@@ -42,7 +42,7 @@ extern "C" {
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
-#define SAME_ABI_VERSION 2
+#define SAME_ABI_VERSION 3
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
@@ -78,13 +78,22 @@ int same_dev_free(same_ctx *ctx, void *dptr);   /* either kind of buffer */
  *  - The memory goes back to the card on same_dev_free.  The ADDRESSES of a spread buffer are never used for another
  *    mapping (a ROCm quirk, see spread.hip): they come from a 48 TiB stretch of the process's address space, after which
  *    the plain allocation is used.
+ *  - The finished range is checked, not trusted: one store over all of it is timed and sampled neighbouring chunks are
+ *    timed against each other; out_info[9] says whether the store ran at the fast level and the pairs behaved as labelled.
+ *    An unverified buffer is still returned (and is still correct memory): only its speed is in question.
+ *  - Wall time is bounded: past SAME_SPREAD_MAX_SECONDS (default 3) the search for better-balanced chunks stops and the best
+ *    choice so far is mapped; past twice that while still taking the buffer's own chunks, the plain allocation is used.
  * out_info (may be NULL), SAME_SPREAD_INFO_LEN int64: [0] 1 = spread, 0 = plain; [1] GiB chunks mapped; [2..4] chunks from
- * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s. */
-#define SAME_SPREAD_INFO_LEN 9
+ * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s;
+ * [9] 1 = verified; [10] GB/s of one store over the finished range; [11] neighbouring pairs timed, [12] of them as labelled;
+ * [13] 1 = the search stopped at the time bound. */
+#define SAME_SPREAD_INFO_LEN 14
 int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t *out_info);
 int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* device-to-device copy, enqueued on the context's stream (no wait) */
+int same_d2d(same_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
 /* free and total bytes of the context's card right now (hipMemGetInfo); either pointer may be NULL */
 int same_dev_mem_info(same_ctx *ctx, int64_t *out_free, int64_t *out_total);
 /* The host-buffer entry points stage through per-context scratch blocks that grow on demand and are
@@ -376,8 +385,15 @@ int same_allreduce_dev(same_ctx *ctx, void *dbuf, size_t count, int dtype, int o
 /* collectives issued between these two calls go to RCCL as one group (ncclGroupStart / ncclGroupEnd): one fused launch */
 int same_comm_group_start(same_ctx *ctx);
 int same_comm_group_end(same_ctx *ctx);
-/* communicator size (0 = none), this rank, and the RCCL version the library is running against */
+/* What the communicator itself reports -- ncclCommCount (0 = no communicator) and ncclCommUserRank, not the arguments
+ * same_comm_init was given -- and the RCCL version the library is running against.  Any pointer may be NULL. */
 int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version);
+/* ncclCommCuDevice of the communicator (-1 = none) */
+int same_comm_device(same_ctx *ctx, int *out_device);
+/* Device time (HIP events on the stream they ran on) of the all-gathers issued since the last same_comm_wait -- the
+ * overlapped ones, or the in-stream ones issued outside a group -- and the bytes this rank sent in them (may be NULL);
+ * waits for the last of them.  0 ms if none. */
+int same_comm_gather_time(same_ctx *ctx, float *out_ms, int64_t *out_send_bytes);
 
 #ifdef __cplusplus
 }

@@ -21,10 +21,10 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
-SPREAD_INFO_LEN = 9                            # SAME_SPREAD_INFO_LEN
+SPREAD_INFO_LEN = 14                           # SAME_SPREAD_INFO_LEN
 MAX_KNN = 448
 MAX_TYPES = 4096
 
@@ -45,6 +45,7 @@ _PROTOTYPES = {
     "same_h2d": [c_vp, c_vp, c_vp, c_sz],
     "same_d2h": [c_vp, c_vp, c_vp, c_sz],
     "same_dev_memset": [c_vp, c_vp, c_int, c_sz],
+    "same_d2d": [c_vp, c_vp, c_vp, c_sz],
     "same_dev_mem_info": [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     "same_ctx_release_scratch": [c_vp],
     "same_timer_start": [c_vp],
@@ -101,6 +102,8 @@ _PROTOTYPES = {
     "same_comm_group_start": [c_vp],
     "same_comm_group_end": [c_vp],
     "same_comm_info": [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
+    "same_comm_device": [c_vp, ctypes.POINTER(c_int)],
+    "same_comm_gather_time": [c_vp, ctypes.POINTER(c_flt), ctypes.POINTER(c_i64)],
 }
 EXPORTS = tuple(_PROTOTYPES)
 
@@ -171,7 +174,8 @@ class DeviceBuffer:
             ctx.check(ctx.lib.same_dev_alloc_spread(ctx.handle, self.nbytes, ctypes.byref(p), info), "same_dev_alloc_spread")
             self.spread_info = {"spread": bool(info[0]), "chunks_gib": int(info[1]), "per_region": [int(info[2]), int(info[3]), int(info[4])],
                                 "straddling": int(info[5]), "examined": int(info[6]), "seconds": info[7] * 1e-6,
-                                "same_region_level_gbps": int(info[8])}
+                                "same_region_level_gbps": int(info[8]), "verified": bool(info[9]), "final_store_gbps": int(info[10]),
+                                "pairs_checked": int(info[11]), "pairs_as_labelled": int(info[12]), "stopped_at_time_bound": bool(info[13])}
         else:
             ctx.check(ctx.lib.same_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(p)), "same_dev_alloc")
         self.ptr = p.value

@@ -59,7 +59,20 @@ int same_allgather_dev(same_ctx *ctx, const void *dsend, void *drecv, size_t sen
     REQUIRE(ctx, ctx && ctx->comm && (send_bytes == 0 || (dsend && drecv)));
     SAME_TRY(same_use(ctx));
     if (send_bytes == 0) return SAME_OK;
+    // outside an RCCL group the gather is stamped like the overlapped form (same_comm_gather_time reads it); inside a group
+    // nothing is enqueued before same_comm_group_end, so stamps recorded here would bracket nothing
+    const bool stamp = !ctx->in_group;
+    if (stamp && !ctx->gather_open) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_gather0, ctx->stream));
+        ctx->gather_open = true;
+        ctx->gather_bytes = 0;
+    }
     NCCL_TRY(ctx, ncclAllGather(dsend, drecv, send_bytes, ncclInt8, ctx->comm, ctx->stream));
+    if (stamp) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_gathered, ctx->stream));
+        ctx->gather_bytes += send_bytes;
+        ctx->gather_stamped = true;
+    }
     return SAME_OK;
 }
 
@@ -74,8 +87,15 @@ int same_allgather_dev_async(same_ctx *ctx, const void *dsend, void *drecv, size
     if (send_bytes == 0) return SAME_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_ready, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_ready, 0));
+    if (!ctx->gather_open) {   // first gather since the last same_comm_wait: the start stamp of same_comm_gather_time
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_gather0, ctx->comm_stream));
+        ctx->gather_open = true;
+        ctx->gather_bytes = 0;
+    }
     NCCL_TRY(ctx, ncclAllGather(dsend, drecv, send_bytes, ncclInt8, ctx->comm, ctx->comm_stream));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_gathered, ctx->comm_stream));
+    ctx->gather_bytes += send_bytes;
+    ctx->gather_stamped = true;
     return SAME_OK;
 }
 
@@ -108,19 +128,28 @@ int same_allreduce_dev(same_ctx *ctx, void *dbuf, size_t count, int dtype, int o
 int same_comm_group_start(same_ctx *ctx) {
     REQUIRE(ctx, ctx && ctx->comm);
     NCCL_TRY(ctx, ncclGroupStart());
+    ctx->in_group = true;
     return SAME_OK;
 }
 
 int same_comm_group_end(same_ctx *ctx) {
     REQUIRE(ctx, ctx && ctx->comm);
+    ctx->in_group = false;
     NCCL_TRY(ctx, ncclGroupEnd());
     return SAME_OK;
 }
 
+// What the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what same_comm_init was told: a
+// launcher that hands every rank world = 1, or ranks that each built a communicator of their own, show up here.
 int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version) {
     REQUIRE(ctx, ctx != nullptr);
-    if (out_nranks) *out_nranks = ctx->comm ? ctx->nranks : 0;
-    if (out_rank) *out_rank = ctx->rank;
+    int n = 0, r = 0;
+    if (ctx->comm) {
+        NCCL_TRY(ctx, ncclCommCount(ctx->comm, &n));
+        NCCL_TRY(ctx, ncclCommUserRank(ctx->comm, &r));
+    }
+    if (out_nranks) *out_nranks = n;
+    if (out_rank) *out_rank = r;
     if (out_rccl_version) {
         int v = 0;
         if (ncclGetVersion(&v) != ncclSuccess) v = 0;
@@ -133,6 +162,29 @@ int same_comm_wait(same_ctx *ctx) {
     REQUIRE(ctx, ctx != nullptr);
     SAME_TRY(same_use(ctx));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gathered, 0));
+    ctx->gather_open = false;
+    return SAME_OK;
+}
+
+// Device time of the overlapped gathers issued since the last same_comm_wait: from the moment the communication stream
+// was released by the producer (its first gather could start) to the end of its last gather, HIP events on that stream.
+// Blocks the host until that last gather has finished.
+int same_comm_gather_time(same_ctx *ctx, float *out_ms, int64_t *out_send_bytes) {
+    REQUIRE(ctx, ctx && out_ms);
+    SAME_TRY(same_use(ctx));
+    *out_ms = 0.0f;
+    if (out_send_bytes) *out_send_bytes = (int64_t)ctx->gather_bytes;
+    if (!ctx->gather_stamped) return SAME_OK;   // no gather issued yet
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_gathered));
+    HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev_gather0, ctx->ev_gathered));
+    return SAME_OK;
+}
+
+// Device the communicator was created on (ncclCommCuDevice), -1 without a communicator.
+int same_comm_device(same_ctx *ctx, int *out_device) {
+    REQUIRE(ctx, ctx && out_device);
+    *out_device = -1;
+    if (ctx->comm) NCCL_TRY(ctx, ncclCommCuDevice(ctx->comm, out_device));
     return SAME_OK;
 }
 

@@ -36,6 +36,9 @@ struct same_ctx {
     hipStream_t comm_stream = nullptr;   // all-gather runs here so it can overlap compute on `stream`
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;  // producer-done / gather-done hand-offs between the two streams
+    hipEvent_t ev_gather0 = nullptr;     // start stamp of the gathers issued since the last same_comm_wait (same_comm_gather_time)
+    bool gather_open = false, gather_stamped = false, in_group = false;
+    size_t gather_bytes = 0;
     void *slot[SL_COUNT] = {};
     size_t slot_bytes[SL_COUNT] = {};
     void *pinned = nullptr;  // small pinned staging block for scalar results

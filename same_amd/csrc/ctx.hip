@@ -31,7 +31,8 @@ int same_ctx_create(int device, same_ctx **out) {
     if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_gathered, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_gathered);   // timing-enabled: the end stamp of same_comm_gather_time
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_gather0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e == hipSuccess) { ctx->pinned_bytes = 1 << 16; e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault); }
@@ -57,6 +58,7 @@ void same_ctx_destroy(same_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->ev_gathered) (void)hipEventDestroy(ctx->ev_gathered);
+    if (ctx->ev_gather0) (void)hipEventDestroy(ctx->ev_gather0);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -152,6 +154,14 @@ int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes) {
     REQUIRE(ctx, ctx && (bytes == 0 || dst_dev));
     SAME_TRY(same_use(ctx));
     if (bytes) HIP_TRY(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return SAME_OK;
+}
+
+// device-to-device copy on the context's stream (the measured copy bandwidth bench.py reports beside the HBM spec)
+int same_d2d(same_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) {
+    REQUIRE(ctx, ctx && (bytes == 0 || (dst_dev && src_dev)));
+    SAME_TRY(same_use(ctx));
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return SAME_OK;
 }
 

@@ -61,9 +61,50 @@ __global__ __launch_bounds__(256) void spread_pair_kernel(char *a, char *b, uint
     for (int r = 0; r < P_RPB; ++r, p += P_ROW) __builtin_nontemporal_store(val, (v2d *)p);
 }
 
+// Share r (= blockIdx % 8) writes the chunks r, r + 8, r + 16, ... of the range one after the other, so at any moment the
+// eight fronts lie in eight CONSECUTIVE chunks: with the chunks laid round-robin over the regions that is the spread the
+// buffer was built for, and the rate of this store over the finished range is what same_dev_alloc_spread reports as verified.
+__global__ __launch_bounds__(256) void spread_sweep_kernel(char *va, unsigned n_chunks) {
+    constexpr unsigned PER_CHUNK = (unsigned)(CHUNK / (P_RPB * 4096));       // blocks per chunk: 64 tiles x 64 row groups
+    const unsigned share = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const unsigned chunk = (k / PER_CHUNK) * 8u + share, within = k % PER_CHUNK;
+    if (chunk >= n_chunks) return;
+    const unsigned tile = within % P_TILES, rows = within / P_TILES;
+    char *p = va + (uint64_t)chunk * CHUNK + (uint64_t)rows * P_RPB * P_ROW + (uint64_t)tile * 4096 + threadIdx.x * 16;
+    const v2d val = {0.0, 0.0};
+    for (int r = 0; r < P_RPB; ++r, p += P_ROW) __builtin_nontemporal_store(val, (v2d *)p);
+}
+
 struct Timer {
     same_ctx *ctx;
     int rc = SAME_OK;
+    // events of its own: the context's ev0 / ev1 belong to same_timer_start / stop, which a caller may have open around
+    // an allocation (ops.dense_cost_q32 allocates inside a region callers time)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    explicit Timer(same_ctx *c) : ctx(c) {
+        if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) rc = SAME_EIO;
+    }
+    ~Timer() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+    Timer(const Timer &) = delete;
+    Timer &operator=(const Timer &) = delete;
+    // GB/s of one store over the whole finished range (spread_sweep_kernel); best of two after one untimed
+    double sweep(char *va, size_t n_chunks) {
+        const unsigned grid = 8u * (unsigned)((n_chunks + 7) / 8) * (unsigned)(CHUNK / (P_RPB * 4096));
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            if (hipEventRecord(ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
+            hipLaunchKernelGGL(spread_sweep_kernel, dim3(grid), dim3(256), 0, ctx->stream, va, (unsigned)n_chunks);
+            float ms = 0.f;
+            if (hipEventRecord(ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
+                hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }
+            if (r && ms < best) best = ms;
+        }
+        if (hipGetLastError() != hipSuccess) { rc = SAME_EIO; return 0.0; }
+        return (double)n_chunks * (double)CHUNK / best * 1e-6;
+    }
     // GB/s of writing `span` bytes at a and `span` bytes at b at once, 4 GiB in all per launch; best of two after one untimed (the two levels are ~20 % apart, the readings within ~5 %)
     double rate(char *a, char *b, uint64_t span) {
         const unsigned passes = (unsigned)(2 * CHUNK / span);
@@ -71,11 +112,11 @@ struct Timer {
         const unsigned grid = 8u * per_pass * passes;
         float best = 1e30f;
         for (int r = 0; r < 3; ++r) {
-            if (hipEventRecord(ctx->ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
+            if (hipEventRecord(ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
             hipLaunchKernelGGL(spread_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, span, per_pass);
             float ms = 0.f;
-            if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess ||
-                hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }
+            if (hipEventRecord(ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
+                hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }
             if (r && ms < best) best = ms;
         }
         if (hipGetLastError() != hipSuccess) { rc = SAME_EIO; return 0.0; }
@@ -125,8 +166,21 @@ void same_spread_release(same_spread_alloc &a) {
 }
 
 // The virtual-memory path proper.  Leaves nothing behind on failure (every chunk given back).
+static double env_seconds(const char *name, double dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    const double x = strtod(v, &end);
+    return (end != v && x > 0.0) ? x : dflt;
+}
+
 static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_dptr, int64_t *info) {
     const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    // Wall-time bound (SAME_SPREAD_MAX_SECONDS, default 3): past it the search for better-balanced chunks stops and the
+    // best choice so far is mapped; if even taking and labelling the buffer's own chunks runs past twice the bound the call
+    // gives everything back and the caller gets the plain allocation (hipMemCreate itself is most of the time: ~25 ms / GiB).
+    const double limit_s = env_seconds("SAME_SPREAD_MAX_SECONDS", 3.0);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     hipMemAllocationProp prop = {};
@@ -137,7 +191,12 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
 
-    const size_t slots = std::min(budget, n_need + EXTRA_CHUNKS);   // most chunks this call can examine
+    // most chunks this call can examine: the look-ahead (SAME_SPREAD_MAX_EXTRA_GIB overrides the 128) never takes more than
+    // half of what the card has free beyond the buffer itself, so ranks sharing a card leave each other room while labelling
+    size_t extra = EXTRA_CHUNKS;
+    if (const char *v = getenv("SAME_SPREAD_MAX_EXTRA_GIB")) extra = (size_t)std::max(0L, atol(v));
+    extra = std::min(extra, (budget - n_need) / 2);
+    const size_t slots = n_need + extra;
     char *scratch = reserve_fresh(slots * CHUNK);
     if (!scratch) {
         ctx->err = "no unused address range left for a spread buffer (addresses are never reused for mappings); plain allocation";
@@ -147,7 +206,12 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     std::vector<int> refs;                                          // reference chunk of each region found so far
     std::vector<std::vector<int>> by_class(MAX_REGIONS + 1);
     std::vector<size_t> take(MAX_REGIONS + 1, 0);
-    Timer tm{ctx};
+    Timer tm(ctx);
+    if (tm.rc != SAME_OK) {
+        (void)hipMemAddressFree(scratch, slots * CHUNK);
+        ctx->err = "hipEventCreate (labelling timer) failed; plain allocation";
+        return SAME_EIO;
+    }
     double slow = 0.0;                                              // same-region level (settle_level)
     auto give_back = [&]() {                                        // everything still held by the labelling, and its range
         for (auto &c : ch) {
@@ -228,13 +292,20 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     // 1. the chunks the buffer needs (the same-region level settles over these: most chunks lie inside one region);
     // 2. label them; 3. while the best choice is lop-sided, take and label more, within the look-ahead and the card's memory
     int got = 1;
-    while (got == 1 && ch.size() < n_need) got = take_chunk();
+    while (got == 1 && ch.size() < n_need && elapsed() < 2.0 * limit_s) got = take_chunk();
     if (got < 0) { give_back(); return got; }
+    if (got == 1 && ch.size() < n_need) {
+        give_back();
+        ctx->err = "taking the chunks of a spread buffer ran past twice SAME_SPREAD_MAX_SECONDS; plain allocation";
+        return SAME_EIO;
+    }
     if (ch.size() < n_need) { give_back(); return same_fail(ctx, SAME_ENOMEM, "hipMemCreate (1 GiB chunks for a spread buffer)", hipErrorOutOfMemory); }
     settle_level();
     int rc = label_from(0);
     if (rc != SAME_OK) { give_back(); return rc; }
+    bool timed_out = false;
     while (choose() == n_need && lopsided() && ch.size() < slots) {
+        if (elapsed() > limit_s) { timed_out = true; break; }   // keep what there is: the verification below says what it is worth
         got = take_chunk();
         if (got < 0) { give_back(); return got; }
         if (got == 0) break;
@@ -261,6 +332,8 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     }
     if (e == hipSuccess) e = hipMemSetAccess(va, n_need * CHUNK, &acc, 1);
     const size_t examined = ch.size();
+    std::vector<int> label_of(ch.size());
+    for (size_t i = 0; i < ch.size(); ++i) label_of[i] = ch[i].label;
     for (size_t i = 0; i < ch.size(); ++i)
         if (!used[i]) {
             if (ch[i].at) (void)hipMemUnmap(ch[i].at, CHUNK);
@@ -272,6 +345,30 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
         same_spread_release(out);
         return same_fail(ctx, SAME_EIO, "hipMemMap/hipMemSetAccess (spread buffer)", e);
     }
+    // Check the finished mapping instead of trusting the plan: (a) one store over the whole range must run at the fast level;
+    // (b) neighbouring chunks of the range, sampled, must time against each other as their labels say (different regions:
+    // fast, same region: slow) -- an address that still reached an earlier chunk (header comment) would show here.
+    const double final_rate = tm.sweep(va, n_need);
+    int pairs_checked = 0, pairs_agree = 0;
+    {
+        const size_t n_pairs = order.size() > 1 ? std::min<size_t>(8, order.size() - 1) : 0;
+        for (size_t q = 0; q < n_pairs && tm.rc == SAME_OK; ++q) {
+            const size_t i = q * (order.size() - 1) / n_pairs;
+            const int la = label_of[order[i]], lb = label_of[order[i + 1]];
+            if (la == MIXED || lb == MIXED) continue;            // a straddler is fast against anything, itself included
+            double g = tm.pair(va + i * CHUNK, va + (i + 1) * CHUNK);
+            const bool want_fast = la != lb;
+            if (want_fast && g < slow * LEVEL_RATIO) g = std::max(g, tm.pair(va + i * CHUNK, va + (i + 1) * CHUNK));   // noise only lowers a rate
+            ++pairs_checked;
+            pairs_agree += ((g >= slow * LEVEL_RATIO) == want_fast) ? 1 : 0;
+        }
+    }
+    if (tm.rc != SAME_OK) {
+        same_spread_release(out);
+        ctx->err = "timing the finished spread buffer failed; plain allocation";
+        return SAME_EIO;
+    }
+    const bool verified = final_rate >= slow * LEVEL_RATIO && pairs_agree == pairs_checked;
     if (debug) fprintf(stderr, "[spread] %zu chunks examined: %.2f s in hipMemCreate/Map/SetAccess, %.2f s in timed stores, %.2f s in all\n", examined,
                        t_create, t_time, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     ctx->spread.push_back(out);
@@ -282,6 +379,12 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     info[6] = (int64_t)examined;
     info[7] = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     info[8] = (int64_t)(slow + 0.5);
+    info[9] = verified ? 1 : 0;
+    info[10] = (int64_t)(final_rate + 0.5);
+    info[11] = pairs_checked;
+    info[12] = pairs_agree;
+    info[13] = timed_out ? 1 : 0;
+    if (!verified) ctx->err = "spread buffer mapped, but a store over it did not reach the fast level (info[9] = 0): it is used as it is";
     return SAME_OK;
 }
 
@@ -300,7 +403,9 @@ extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dpt
     // the virtual-memory path itself (a driver without it, a sibling process taking the memory meanwhile): WHERE the buffer
     // lies is a matter of speed, never of results, and the reason stays readable through same_last_error()
     int rc = SAME_EIO;
+    bool tried = false;
     if (!(env && env[0] == '0') && n_need >= MIN_CHUNKS && budget >= n_need) {
+        tried = true;
         rc = spread_build(ctx, n_need, budget, out_dptr, info);
         if (rc != SAME_OK) {
             memset(info, 0, sizeof info);
@@ -308,7 +413,9 @@ extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dpt
         }
     }
     if (rc != SAME_OK) {
-        const std::string why = ctx->err;
+        // the reason the spread path gave up stays readable after the plain allocation succeeded -- but only a reason of THIS
+        // call: when the spread path was not attempted at all there is nothing to report
+        const std::string why = tried ? ctx->err : std::string();
         SAME_TRY(same_dev_alloc(ctx, bytes, out_dptr));
         ctx->err = why;
     }

@@ -46,6 +46,8 @@ class RcclGroup:
     """RCCL communicator bound to a Context.  `exchange_id(bytes_or_None) -> bytes` is any host broadcast from rank 0
     (HostGroup.bcast_bytes; a launcher with MPI or a file can pass its own)."""
 
+    synchronous = False   # collectives are enqueued on the context's streams
+
     def __init__(self, ctx, world, rank, exchange_id):
         self.ctx, self.world, self.rank = ctx, int(world), int(rank)
         uid = None
@@ -60,9 +62,22 @@ class RcclGroup:
         ctx.check(ctx.lib.same_comm_init(ctx.handle, self.world, self.rank, uid), "same_comm_init")
 
     def rccl_version(self):
-        v = ctypes.c_int(0)
-        self.ctx.check(self.ctx.lib.same_comm_info(self.ctx.handle, None, None, ctypes.byref(v)), "same_comm_info")
-        return v.value
+        return self.info()["version"]
+
+    def info(self):
+        """What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) and the RCCL version."""
+        n, r, v, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(-1)
+        c = self.ctx
+        c.check(c.lib.same_comm_info(c.handle, ctypes.byref(n), ctypes.byref(r), ctypes.byref(v)), "same_comm_info")
+        c.check(c.lib.same_comm_device(c.handle, ctypes.byref(d)), "same_comm_device")
+        return {"nranks": n.value, "rank": r.value, "device": d.value, "version": v.value}
+
+    def gather_time(self):
+        """(ms, bytes this rank sent) of the all-gathers since the last wait(): HIP events on the stream they ran on."""
+        ms, nb = ctypes.c_float(0), ctypes.c_int64(0)
+        c = self.ctx
+        c.check(c.lib.same_comm_gather_time(c.handle, ctypes.byref(ms), ctypes.byref(nb)), "same_comm_gather_time")
+        return ms.value, nb.value
 
     def allgather_dev(self, send_buf, recv_buf, send_bytes, send_offset=0):
         c = self.ctx
@@ -117,12 +132,27 @@ class HostTransport:
     A TRANSPORT fallback for when the RCCL communicator cannot be created (e.g. several ranks sharing one GPU: RCCL refuses
     duplicate devices) -- compute stays on the GPU; synchronous, so nothing overlaps.  bench.py reports it when used."""
 
+    synchronous = True    # every exchange has completed when its call returns
+
     def __init__(self, ctx, group):
         self.ctx, self.group, self.world, self.rank = ctx, group, group.world, group.rank
+        self._ms, self._bytes = 0.0, 0
 
     def allgather_dev(self, send_buf, recv_buf, send_bytes, send_offset=0):
+        import time
+
+        t0 = time.perf_counter()
         host = send_buf.download((send_bytes,), np.uint8, offset_bytes=send_offset)
         recv_buf.upload(self.group.allgather_array(host))
+        self._ms += (time.perf_counter() - t0) * 1e3
+        self._bytes += send_bytes
+
+    def info(self):
+        return {"nranks": self.world, "rank": self.rank, "device": self.ctx.device, "version": 0}
+
+    def gather_time(self):
+        """(ms, bytes) of the gathers since the last wait(): host wall time (D2H + loopback TCP + H2D, synchronous)."""
+        return self._ms, self._bytes
 
     def allgather_dev_async(self, send_buf, recv_buf, send_bytes):
         self.allgather_dev(send_buf, recv_buf, send_bytes)
@@ -134,7 +164,7 @@ class HostTransport:
         buf.upload(np.ascontiguousarray(red, dtype=dt))
 
     def wait(self):
-        pass
+        self._ms, self._bytes = 0.0, 0
 
     def close(self):
         pass

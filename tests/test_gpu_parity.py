@@ -537,9 +537,10 @@ def test_sharded_sweeps_rccl_single_rank_and_block_forms(ops, oracle):
     ctx.close()
 
 
-def _sharded_device_worker(rank, world, rdv, out_dir):
-    """One rank of `world`, all on the one GPU: device-side sharded prune + cost and ShardedSweeps, exchanged through the host
-    transport (RCCL refuses several ranks on one device); every rank's complete outputs are written for the parent to check."""
+def _sharded_device_worker(rank, world, rdv, out_dir, transport="host"):
+    """One rank of `world`: device-side sharded prune + cost and ShardedSweeps; every rank's complete outputs are written for
+    the parent to check.  transport "host": all ranks on GPU 0, exchanging through the host transport (RCCL refuses several
+    ranks on one device); "rccl": rank r on GPU r, a real RCCL communicator between the devices."""
     import ctypes
     import os
     import sys
@@ -549,12 +550,17 @@ def _sharded_device_worker(rank, world, rdv, out_dir):
     import numpy as np
     from scipy.spatial import Delaunay
     from same_amd import _lib, ops, synth
-    from same_amd.dist import HostGroup, HostTransport, ShardedSweeps, hip_block_compute, sharded_knn_cost_device
+    from same_amd.dist import HostGroup, HostTransport, RcclGroup, ShardedSweeps, hip_block_compute, sharded_knn_cost_device
 
-    ctx = _lib.Context(0)
+    ctx = _lib.Context(rank if transport == "rccl" else 0)
     L, H = ctx.lib, ctx.handle
     with HostGroup(rank, world, rdv_dir=rdv, timeout=300) as group:
-        comm = HostTransport(ctx, group)
+        if transport == "rccl":
+            comm = RcclGroup(ctx, world, rank, lambda b: group.bcast_bytes(b or b""))
+            info = comm.info()     # what the communicator itself says: ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+            assert info["nranks"] == world and info["rank"] == rank and info["device"] == rank, info
+        else:
+            comm = HostTransport(ctx, group)
         ref = synth.make_cells(9000, 5, seed=3)
         mov = synth.make_jittered(ref, seed=4, sigma=6.0)
         n_m = len(mov["xy"])
@@ -575,24 +581,13 @@ def _sharded_device_worker(rank, world, rdv, out_dir):
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, cost=cost, checked=checked, viol=viol, match=match, tris=tris, sign=sign, **out)
         group.barrier()
         L.same_sweep_unbind(sweep)
+        comm.close()
     ctx.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_device_paths_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
-    """The DEVICE forms of the sharded cost build and of the sharded sweeps with 2 and 3 real ranks (one process each, sharing
-    this GPU, exchanging through the host transport): every rank ends up with the single-GPU outputs, equal to the oracle --
-    row blocks, triangle blocks, padded tails, gathers, OR / sum reductions and the rebuilt ascending list included."""
-    import multiprocessing as mp
-    import tempfile
+def _check_sharded_rank_outputs(tmp_path, oracle, world):
     from same_amd import synth
 
-    ctx = mp.get_context("spawn")
-    with tempfile.TemporaryDirectory(prefix="same_rdv_gpu_") as rdv:
-        procs = [ctx.Process(target=_sharded_device_worker, args=(r, world, rdv, str(tmp_path))) for r in range(world)]
-        [p.start() for p in procs]
-        [p.join(600) for p in procs]
-        assert [p.exitcode for p in procs] == [0] * world
     ref = synth.make_cells(9000, 5, seed=3)
     mov = synth.make_jittered(ref, seed=4, sigma=6.0)
     oidx, _, _ = oracle.knn_prune(mov["xy"], ref["xy"], 25.0, 8)
@@ -610,6 +605,49 @@ def test_sharded_device_paths_with_several_ranks_on_one_gpu(tmp_path, oracle, wo
         ob, oa, om3, ofl = oracle.area_flip(mov["xy"], ref["xy"], tris, match)
         assert np.array_equal(o["before"], ob) and np.array_equal(o["after"], oa, equal_nan=True)
         assert np.array_equal(o["matched3"], om3) and np.array_equal(o["flipped"], ofl)
+
+
+def test_rccl_between_devices_sharded_paths(tmp_path, oracle):
+    """RCCL WITH PEERS (needs at least two GPUs; skipped on a one-GPU box): rank r on device r, a real communicator between them
+    -- ncclAllGather of the pruned candidate lists (sharded_knn_cost_device), then ShardedSweeps' grouped flag all-gathers and
+    counter / point-flag all-reduces -- and every rank's complete outputs equal the oracle's, bit for bit.  Fresh child
+    processes (the parent never creates a communicator), at most 4 ranks."""
+    import multiprocessing as mp
+    import tempfile
+    from same_amd import _lib
+
+    ndev = _lib.device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} GPU visible: RCCL between devices needs at least two")
+    world = min(ndev, 4)
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory(prefix="same_rdv_rccl_") as rdv:
+        procs = [ctx.Process(target=_sharded_device_worker, args=(r, world, rdv, str(tmp_path), "rccl")) for r in range(world)]
+        [p.start() for p in procs]
+        [p.join(600) for p in procs]
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        assert [p.exitcode for p in procs] == [0] * world
+    _check_sharded_rank_outputs(tmp_path, oracle, world)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_device_paths_with_several_ranks_on_one_gpu(tmp_path, oracle, world):
+    """The DEVICE forms of the sharded cost build and of the sharded sweeps with 2 and 3 real ranks (one process each, sharing
+    this GPU, exchanging through the host transport): every rank ends up with the single-GPU outputs, equal to the oracle --
+    row blocks, triangle blocks, padded tails, gathers, OR / sum reductions and the rebuilt ascending list included."""
+    import multiprocessing as mp
+    import tempfile
+    from same_amd import synth
+
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory(prefix="same_rdv_gpu_") as rdv:
+        procs = [ctx.Process(target=_sharded_device_worker, args=(r, world, rdv, str(tmp_path))) for r in range(world)]
+        [p.start() for p in procs]
+        [p.join(600) for p in procs]
+        assert [p.exitcode for p in procs] == [0] * world
+    _check_sharded_rank_outputs(tmp_path, oracle, world)
 
 
 @pytest.mark.parametrize("mode", ["auto", "grid", "brute"])

@@ -289,7 +289,14 @@ def test_bench_contract_line(force_comm):
     if force_comm:
         assert out["cpu_baseline"] is None and out["parity_spot_check"].startswith("transport: rows [0,2000) of rank 0's block")
         assert "RCCL" in out["config"]["parallelism"]
+        _check_multi_rank_keys(out, world=1, kind="rccl")
     else:
+        assert "rccl" not in out and "gather" not in out
+        # the bound as fields, from this run's telemetry; and the kernel against the measured device copy
+        if rf["telemetry"].get("available") and rf["telemetry"].get("sclk_steady"):
+            assert 0.0 < rf["valu_busy_frac"] <= 1.05 and rf["valu_floor_ms_at_held_clock"] > 0 and rf["held_clock_mhz"] > 500
+        assert rf["measured_ceilings"]["device_copy_GBs"] > 0 and rf["frac_of_measured_copy_bw"] > 0
+        assert "verified" in rf["output_buffer"]
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
         assert "equal the oracle bit-for-bit" in out["parity_spot_check"]
@@ -299,6 +306,48 @@ def test_bench_contract_line(force_comm):
         assert ("f64", 3) in kinds and ("f32", 20) in kinds and ("q32->f64", 20) in kinds
         q = [e for e in rf["sweep"] if e["dtype"] == "q32->f64"][0]
         assert q["opt_in"] is True and q["max_rel_diff_vs_exact_on_16_rows"] <= 1e-6
+
+
+def _check_multi_rank_keys(out, world, kind):
+    """What the N > 1 line must carry to explain itself."""
+    r = out["rccl"]
+    assert r["kind"] == kind and r["nranks"] == world and r["rank"] == 0 and r["consistent"] is True
+    assert [e[0] for e in r["every_rank"]] == list(range(world)) and all(e[2] == world for e in r["every_rank"])
+    if kind == "rccl":
+        assert "ncclCommCount" in r["source"] and r["version"] and r["device"] == 0
+    g = out["gather"]
+    assert g["bytes_per_rank"] == 4000 * 32 * 12 // (world if out["scaling"] == "strong" else 1) and g["ms"] is not None and g["ms"] >= 0
+    assert g["GBs"] is None or g["GBs"] > 0
+    assert g["step_ms_with_gather"] > 0 and g["step_ms_without_gather"] > 0 and g["steps_without_gather"] >= 1
+    assert abs(out["gather_hidden_ms"] - (g["step_ms_with_gather"] - g["step_ms_without_gather"])) < 1e-9
+    lo, mean, hi = out["per_rank_dense_ms"]
+    assert 0 < lo <= mean <= hi and len(out["per_rank"]["dense_ms_by_rank"]) == world
+    s = out["strong_record"]                      # tiny has no BASELINE-named strong twin: the same shape as ONE problem
+    assert s["scaling"] == "strong" and s["value"] > 0 and s["steps"] >= 1 and "ONE problem" in s["config"]["workload"]
+    assert s["gather"]["bytes_per_rank"] == -(-4000 // world) * 32 * 12 and s["gather_hidden_ms"] is not None
+    assert s["parity_spot_check"].startswith("transport: rows [0,") and len(s["dense_ms_by_rank"]) == world
+    assert s["sweep_outputs"]["checked"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_carry_the_diagnosis():
+    """`bench.py --gpus 2` on this one GPU (RCCL refuses two ranks on one device, so the exchanges go through the host
+    transport): the line carries every key the 8-GPU run needs to explain itself, and the embedded ONE-problem record."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "HOST" in out["config"]["parallelism"]
+    _check_multi_rank_keys(out, world=2, kind="host")
+    assert out["per_rank"]["device_by_rank"] == [0, 0]
 
 
 def test_bench_step_with_the_fixed_point_dense_build():

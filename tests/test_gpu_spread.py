@@ -112,3 +112,90 @@ def test_too_large_a_request_fails_cleanly(ctx):
     assert rc in (-12, -5) and not p.value
     ok = ctx.alloc(1 << 20)        # the context is still usable
     ok.free()
+
+
+def test_finished_range_is_verified_and_reported(ctx):
+    """The finished mapping is checked, not trusted: one store over the whole range is timed against the same-region level and
+    sampled neighbouring chunks are timed against each other as their labels say (spread.hip)."""
+    b = ctx.alloc_spread(12 << 30)
+    si = b.spread_info
+    assert si["spread"] is True and si["final_store_gbps"] > 0 and si["pairs_checked"] >= 1
+    assert si["pairs_as_labelled"] <= si["pairs_checked"]
+    if max(si["per_region"]) <= 7:       # a balanced choice was available: it must have verified as fast
+        assert si["verified"] is True and si["final_store_gbps"] >= 1.12 * si["same_region_level_gbps"], si
+    assert isinstance(si["stopped_at_time_bound"], bool)
+    b.free()
+
+
+def test_time_bound_stops_the_search_not_the_allocation(ctx, monkeypatch):
+    """SAME_SPREAD_MAX_SECONDS: past the bound the search for better-balanced chunks stops and what there is gets mapped (or,
+    past twice the bound while still taking the buffer's own chunks, the plain allocation is used) -- either way a usable buffer."""
+    monkeypatch.setenv("SAME_SPREAD_MAX_SECONDS", "0.05")
+    b = ctx.alloc_spread(8 << 30)
+    si = b.spread_info
+    assert b.ptr and (si["spread"] is False or si["seconds"] < 3.0)
+    ctx.check(ctx.lib.same_dev_memset(ctx.handle, b.ptr, 0x11, 8 << 30), "memset")
+    ctx.sync()
+    assert (b.download((1 << 20,), np.uint8, offset_bytes=5 << 30) == 0x11).all()
+    b.free()
+
+
+def test_labelling_leaves_an_open_timer_alone(ctx):
+    """The labelling stores are timed with events of their own: a same_timer_start .. same_timer_stop pair open around a spread
+    allocation measures what the caller enqueued, not a labelling store (ops.dense_cost_q32 allocates inside timed regions)."""
+    ms = ctypes.c_float(0)
+    ctx.check(ctx.lib.same_timer_start(ctx.handle), "timer")
+    b = ctx.alloc_spread(8 << 30)
+    assert b.spread_info["spread"] is True
+    ctx.check(ctx.lib.same_timer_stop(ctx.handle, ctypes.byref(ms)), "timer")
+    assert ms.value >= b.spread_info["seconds"] * 1e3 * 0.5      # the whole allocation lies inside the pair (a labelling store is ~1 ms)
+    b.free()
+
+
+def test_rccl_collectives_through_fresh_buffers_after_a_spread_free(ctx):
+    """spread alloc -> free -> size-1 RCCL communicator -> all-gather + all-reduce through freshly allocated buffers, payload
+    checked: the addresses a spread buffer used are never mapped again by this library, and whatever RCCL or hipMalloc place
+    there afterwards must reach their own memory (the stale-mapping behaviour described in spread.hip's header)."""
+    from same_amd.dist import RcclGroup
+
+    c2 = _lib.Context(0)                         # own context: the communicator lives and dies with it
+    sp = c2.alloc_spread(8 << 30)
+    assert sp.spread_info["spread"] is True
+    c2.check(c2.lib.same_dev_memset(c2.handle, sp.ptr, 0x77, 8 << 30), "memset")
+    c2.sync()
+    sp.free()
+    comm = RcclGroup(c2, 1, 0, lambda b: b)
+    try:
+        info = comm.info()
+        assert info["nranks"] == 1 and info["rank"] == 0 and info["device"] == 0 and info["version"] > 20000
+        n = 1 << 22
+        rng = np.random.default_rng(5)
+        payload = rng.integers(0, 255, n, dtype=np.uint8)
+        send, recv = c2.to_device(payload), c2.alloc(n)
+        big = [c2.alloc(1 << 30) for _ in range(4)]        # fresh plain blocks, likely on recycled physical memory
+        for i, blk in enumerate(big):
+            c2.check(c2.lib.same_dev_memset(c2.handle, blk.ptr, 0x30 + i, 1 << 30), "memset")
+        comm.allgather_dev(send, recv, n)
+        comm.wait()
+        c2.sync()
+        assert np.array_equal(recv.download((n,), np.uint8), payload)
+        ms, nb = comm.gather_time()
+        assert nb == n and ms >= 0.0
+        counters = c2.to_device(np.array([3, 9, 27], np.uint64))
+        comm.allreduce_dev(counters, 3, _lib.DT_U64, _lib.OP_SUM)
+        c2.sync()
+        assert counters.download((3,), np.uint64).tolist() == [3, 9, 27]
+        for i, blk in enumerate(big):
+            assert (blk.download((1 << 16,), np.uint8, offset_bytes=(1 << 29) + i) == 0x30 + i).all()
+        # and a second spread buffer beside the live communicator
+        sp2 = c2.alloc_spread(6 << 30)
+        c2.check(c2.lib.same_dev_memset(c2.handle, sp2.ptr, 0x42, 6 << 30), "memset")
+        comm.allgather_dev_async(send, recv, n)
+        comm.wait()
+        c2.sync()
+        assert np.array_equal(recv.download((n,), np.uint8), payload)
+        assert (sp2.download((1 << 20,), np.uint8, offset_bytes=3 << 30) == 0x42).all()
+        sp2.free()
+    finally:
+        comm.close()
+    c2.close()
