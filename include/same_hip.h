@@ -356,6 +356,16 @@ int same_eager_signs(same_ctx *ctx, const double *rxy, int64_t n_r, const int32_
 int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *boxes,
                       int64_t n_boxes, int64_t *out_count, uint8_t *out_mask);
 
+/* ---- f3: window merge, the de-duplication step ------------------------------------------
+ * Replaces src/helpers.py:745-753 (merged_df.sort_values(['filtered_violation', 'window_id'], kind='mergesort') then
+ * drop_duplicates([aligned, ref], keep='first')): rows i = 0..n-1 of the concatenated per-window match tables carry a
+ * violation flag, a window id and integer codes of their aligned / ref ids (equal ids <=> equal codes; any
+ * non-negative int32).  out_rows receives the indices of the rows that survive, in the order the reference's frame has
+ * after those two calls (stable by violation, then window id; first row of every pair); *out_n their number.
+ * The maximum-cardinality matching that follows (:755-815) is sequential and stays with the caller. */
+int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_t *window_id, const int32_t *aligned_code,
+                     const int32_t *ref_code, int64_t n, int32_t *out_rows, int64_t *out_n);
+
 /* ---- multi-GPU: RCCL all-gather of the pruned candidate lists -------------
  * One process per GPU.  Rank 0 calls same_comm_unique_id and hands the 128 bytes to the
  * other ranks by any host channel; all ranks then call same_comm_init.  same_allgather_dev

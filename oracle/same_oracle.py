@@ -15,6 +15,7 @@ import subprocess
 from collections import defaultdict
 
 import numpy as np
+import pandas as pd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -67,6 +68,8 @@ def lib():
         _u32 = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
         L.orc_tri_flip_stats.argtypes = [_f64, _f64, _u8, _VP, _i32, _I64, _I64, _u8, _u32, _u32]
         L.orc_batched_assign.argtypes = [_I64, _i64, _i64, _f64, _f64, _i32]
+        L.orc_merge_dedup.argtypes = [_u8, _i32, _i32, _i32, _I64, _i32]
+        L.orc_merge_dedup.restype = ctypes.c_int64
         _LIB = L
     return _LIB
 
@@ -739,3 +742,22 @@ def batched_assign_scipy(a_off, r_off, axy, rxy):
         rows, cols = linear_sum_assignment(d)
         out[a_off[p] + rows] = cols % len(r)
     return out
+
+
+def merge_dedup(viol, window_id, aligned_code, ref_code):
+    """f3, the de-duplication step of merge_window_matches_unique_ref (src/helpers.py:745-753): stable sort by (violation,
+    window id), first row of every (aligned, ref) pair.  -> surviving row indices in the sorted order (int32)."""
+    viol = _c(np.asarray(viol).astype(bool), np.uint8)
+    w, a, r = _c(window_id, np.int32), _c(aligned_code, np.int32), _c(ref_code, np.int32)
+    out = np.empty(max(len(viol), 1), np.int32)
+    m = lib().orc_merge_dedup(viol, w, a, r, len(viol), out)
+    if m < 0:
+        raise RuntimeError(f"orc_merge_dedup failed ({m})")
+    return out[:m].copy()
+
+
+def merge_dedup_pandas(viol, window_id, aligned_code, ref_code):
+    """The literal reference form of the same step (pandas mergesort + drop_duplicates, src/helpers.py:748-753)."""
+    df = pd.DataFrame({"v": np.asarray(viol).astype(bool), "w": np.asarray(window_id), "a": np.asarray(aligned_code), "r": np.asarray(ref_code)})
+    df = df.sort_values(by=["v", "w"], ascending=[True, True], kind="mergesort").drop_duplicates(subset=["a", "r"], keep="first")
+    return df.index.to_numpy().astype(np.int32)

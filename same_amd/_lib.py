@@ -92,6 +92,7 @@ _PROTOTYPES = {
     "same_batched_assign": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
     "same_comm_unique_id": [c_vp],
     "same_comm_init": [c_vp, c_int, c_int, c_vp],
     "same_comm_destroy": [c_vp],

@@ -573,11 +573,11 @@ def _post_solve(prep, commonCT, x, no_match_vars, penalty_vars, area_penalty_var
         "lazy_cuts_added": model._cuts_added if prep.optim_params["lazy_constraints"] else 0,
     }
     if outprefix:
-        # the reference pickles this dict into var_out.npy (src/same.py:1455-1462); here it goes out as a JSON + npz pair
-        # that loads without executing anything (varout.py).  SAME_LEGACY_VAR_OUT=1 also writes the reference's file for
-        # notebooks that np.load(..., allow_pickle=True) it.
+        # the reference pickles this dict into var_out.npy (src/same.py:1455-1462) and its own reader and notebooks open that
+        # file (src/helpers.py:682), so a drop-in writes it too; beside it goes a JSON + npz pair that loads without executing
+        # anything (varout.py), which is what load_matching_results here prefers.  SAME_LEGACY_VAR_OUT=0 leaves the pickle out.
         varout.save(outprefix, var_out)
-        if os.environ.get("SAME_LEGACY_VAR_OUT") == "1":
+        if os.environ.get("SAME_LEGACY_VAR_OUT", "1") != "0":
             np.save(os.path.join(outprefix, "var_out.npy"), var_out, allow_pickle=True)
         aligned_df.to_csv(os.path.join(outprefix, "aligned_df.csv"), index=False)
         ref_df.to_csv(os.path.join(outprefix, "ref_df.csv"), index=False)

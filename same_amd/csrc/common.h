@@ -66,8 +66,6 @@ struct same_sweep {
     unsigned long long *cnt = nullptr;
     int32_t *viol = nullptr;      // = (int32_t *)(cnt + 2)
     unsigned long long *mask = nullptr;
-    hipGraphExec_t orient_graph = nullptr;   // memset + flag kernel + compaction + read-back of a whole-list sweep from s->match
-    hipGraph_t orient_graph_src = nullptr;
     double *x = nullptr;          // [P]
 };
 

@@ -15,7 +15,9 @@
 //   v_add_f64 d, s[a_t], -v[r_t]  ;  v_add_f64 acc, acc, |d|
 // with no LDS or vector-memory instruction per element.  Every lane stores 16 B per row
 // (CPL=2 doubles / 4 floats): one wave-instruction writes 1 KiB of one output row, a
-// workgroup 4 KiB.
+// workgroup 4 KiB.  Bound (MI355X, T=20): the board power cap -- the VALU is 92-94 % busy with fp64
+// (80 % with fp32) at the 1.76-1.9 GHz the board holds under its 1400 W cap, and idling the VALU
+// only raises the clock (profiles/r03_dense_occupancy.log); traffic is 1.004x the algorithmic bytes.
 #include <algorithm>
 #include <cstdlib>
 
@@ -32,7 +34,7 @@ template <> __device__ __forceinline__ double absf<double>(double x) { return __
 template <> __device__ __forceinline__ float absf<float>(float x) { return __builtin_fabsf(x); }
 
 // Block = 256 threads = 4 waves side by side over 256*CPL ref columns; it sweeps `rows_per_block`
-// aligned rows.  Three things keep the fp64 VALU and the store stream overlapped:
+// aligned rows.  What keeps the fp64 VALU and the store stream overlapped:
 //
 // (1) Scalar-load pipelining.  SMEM returns out of order, so the only usable wait is lgkmcnt(0);
 //     the row is consumed in two halves and each half is fetched one phase ahead, always in the
@@ -40,86 +42,60 @@ template <> __device__ __forceinline__ float absf<float>(float x) { return __bui
 //     merely *uses* one SGPR of the current half, which makes the compiler place its s_waitcnt
 //     there; the sched_barriers keep the next half's s_loads from moving above it; the loop body
 //     is a single basic block so nothing is sunk out of place.  Waits stay compiler-generated.
-// (2) Result-register depth.  A store holds its data VGPRs until the memory pipe has read them, so the
-//     kernel can compute DEPTH rows into DEPTH distinct result sets per loop trip (`keep_alive` pins them).
-//     Measured on MI355X: DEPTH 1/2/4/8 run within 1 % of each other at every T (the kernel is bound by
-//     the board power cap at T=20), so the shipped depth is 1; the parameter stays for
-//     hardware where the store path back-pressures the VALU.  The store address is a scalar row pointer
-//     plus a fixed per-lane byte offset, so no address VGPR is rewritten per row.
-// (3) Block -> tile map.  Blocks that share an XCD (blockIdx % 8) walk adjacent column tiles of
-//     the same row chunk, which gave the best store rate of the maps tried (6.8-7.0 TB/s store-only).
+// (2) The store address is a scalar row pointer plus a fixed per-lane byte offset, so no address VGPR
+//     is rewritten per row and no VALU instruction is spent on addressing.
+// (3) Block -> tile map (map_mode).  2: blocks that share an XCD (blockIdx % 8) walk adjacent column
+//     tiles of the same row chunk -- every XCD streams whole output rows, the best store rate (store-bound
+//     shapes).  4: XCD x owns a contiguous range of column tiles for the whole launch, so its share of R
+//     stays in its own L2 (shapes bound by fp64 issue, where the store pattern no longer matters and the
+//     R re-fetch does: FETCH_SIZE 3.46 GB -> 0.15 GB per launch).  0: column tile fastest, the plain map
+//     of the scalar-store fallback.
+// Variants that were measured and did not ship (two column groups per lane, DEPTH > 1 result sets, an LDS pad to cap
+// the occupancy, maps 1 / 3 / 5, non-nt store policies) are in the history of this file: tools/probes/README.md.
 __device__ __forceinline__ void touch(double v) { asm volatile("" ::"s"(v)); }
 __device__ __forceinline__ void touch(float v) { asm volatile("" ::"s"(v)); }
-__device__ __forceinline__ void keep_alive(double v) { asm volatile("" ::"v"(v)); }
-__device__ __forceinline__ void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 
-// 16-byte nontemporal store, address = scalar row pointer + fixed per-lane byte offset: no VALU instruction
-// and no address VGPR is spent on addressing (hipcc otherwise keeps a 64-bit VGPR pointer and bumps it
-// with a v_lshl_add_u64 per row).  The trailing `s_nop 1` gives the 2 wait states gfx940+ requires between a store of
-// more than 64 bits and a VALU write of its data VGPRs; the compiler only inserts them for its own instructions.
-#ifndef SAME_STORE_MODS
-#define SAME_STORE_MODS "nt"   // cache-policy bits of the output store; tools/probes/store_variants.sh sweeps the alternatives
-#endif
+// 16-byte nontemporal store, address = scalar row pointer + fixed per-lane byte offset (hipcc otherwise keeps a
+// 64-bit VGPR pointer and bumps it with a v_lshl_add_u64 per row).  The trailing `s_nop 1` gives the 2 wait states
+// gfx940+ requires between a store of more than 64 bits and a VALU write of its data VGPRs; the compiler only
+// inserts them for its own instructions.
 template <typename V16>
 __device__ __forceinline__ void store16_nt_saddr(char *row_uniform, unsigned lane_byte_off, V16 v) {
     typedef int i4 __attribute__((ext_vector_type(4)));
     static_assert(sizeof(V16) == 16, "16-byte vector expected");
     const i4 bits = __builtin_bit_cast(i4, v);
-    asm volatile("global_store_dwordx4 %0, %1, %2 " SAME_STORE_MODS "\n\ts_nop 1" ::"v"(lane_byte_off), "v"(bits), "s"(row_uniform) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(lane_byte_off), "v"(bits), "s"(row_uniform) : "memory");
 }
 
-template <typename F, int T, int CPL, bool VEC_STORE, int DEPTH, bool NT = true, int WAVES = 4, bool W1 = false, int G = 1>
-__global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
+enum : int { MAP_TILE_FASTEST = 0, MAP_XCD_ROWS = 2, MAP_XCD_TILES = 4 };
+
+template <typename F, int T, int CPL, bool VEC_STORE, bool W1>
+__global__ __launch_bounds__(256) void dense_cost_kernel(
     const F *__restrict__ A, const F *__restrict__ R, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t n_r, int64_t row_begin, int64_t row_end, F w, F dcoef,
     F *__restrict__ out, int64_t ld, int col_tiles, int rows_per_block, int64_t n_store, int map_mode,
     int row_chunks) {
     // VEC_STORE: every lane with j0 < n_store stores all CPL columns with one 16 B store (n_store is a
     // multiple of CPL; columns in [n_r, n_store) are caller-owned padding).  Host guarantees
-    // rows_per_block % DEPTH == 0 and rows_per_block <= row_end - row_begin; the last chunk is shifted
-    // back to overlap its neighbour instead of being ragged (the overlap recomputes identical values).
-    static_assert(VEC_STORE || DEPTH == 1, "scalar-store variant is the simple one");
-    // G > 1: a lane owns G groups of CPL adjacent columns, group g sitting 64*CPL columns (one wave-wide 1 KiB store) after
-    // group g-1, so every store instruction still writes one contiguous run per wave while the scalar row fetch and loop
-    // control are shared by G times as many outputs.  A group past the edge aliases group 0 (it recomputes and re-stores
-    // identical values), which keeps the loop body free of branches.
-    static_assert(G == 1 || (VEC_STORE && NT && sizeof(F) * CPL == 16), "grouped columns use the 16-byte scalar-base store");
-    constexpr int CT = CPL * G;
+    // rows_per_block <= row_end - row_begin; the last chunk is shifted back to overlap its neighbour
+    // instead of being ragged (the overlap recomputes identical values).
+    static_assert(!VEC_STORE || sizeof(F) * CPL == 16, "the vector store is the 16-byte scalar-base one");
     constexpr int H = (T + 1) / 2;  // first half: a[0..H); second half: a[H..T) + XY
     constexpr int TT = T > 0 ? T : 1;
     typedef F vecF __attribute__((ext_vector_type(CPL)));
     int tile, chunk;
-    if (map_mode == 0) {  // column tile fastest
+    if (map_mode == MAP_TILE_FASTEST) {
         tile = blockIdx.x % col_tiles;
         chunk = blockIdx.x / col_tiles;
-    } else if (map_mode == 1) {  // row chunk fastest
-        chunk = blockIdx.x % row_chunks;
-        tile = blockIdx.x / row_chunks;
-    } else if (map_mode == 3) {
-        // XCD-resident reference tiles: XCD x (= blockIdx % 8, the hardware's round-robin) owns the column tiles
-        // x, x+8, x+16, ... and sweeps ALL row chunks over them, chunk by chunk.  Its share of R ((T+2)*8 B per
-        // column, ~2.2 MB at 100k refs / T=20) then stays in that XCD's 4 MB L2 for the whole launch, and each
-        // chunk of A rows is fetched once per XCD instead of R being re-fetched once per chunk.
-        const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
-        const unsigned mine = ((unsigned)col_tiles + 7u - xcd) >> 3;  // tiles owned by this XCD
-        const unsigned widest = ((unsigned)col_tiles + 7u) >> 3;      // grid is sized for the widest owner
-        const unsigned m = k % widest;
-        chunk = k / widest;
-        if (m >= mine || chunk >= row_chunks) return;
-        tile = xcd + 8u * m;
-    } else if (map_mode == 4 || map_mode == 5) {  // as 3, but XCD x owns the CONTIGUOUS tile range [x*ct/8, (x+1)*ct/8)
+    } else if (map_mode == MAP_XCD_TILES) {  // XCD x (= blockIdx % 8, the hardware's round-robin) owns the tiles [x*ct/8, (x+1)*ct/8)
         const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
         const unsigned lo = xcd * (unsigned)col_tiles / 8u, hi = (xcd + 1u) * (unsigned)col_tiles / 8u;
-        const unsigned widest = ((unsigned)col_tiles + 7u) >> 3;
+        const unsigned widest = ((unsigned)col_tiles + 7u) >> 3;      // the grid is sized for the widest owner
         const unsigned m = k % widest;
         chunk = k / widest;
         if (m >= hi - lo || chunk >= row_chunks) return;
         tile = lo + m;
-        // 5: every XCD starts its sweep an eighth of the rows further down (and wraps), so the eight store fronts lie an
-        // eighth of the block apart instead of in one band of rows: a band is one stretch of addresses, i.e. ONE HBM region
-        // at a time (spread.hip), and a store stream confined to one region is the slow one
-        if (map_mode == 5) chunk = (int)(((unsigned)chunk + xcd * ((unsigned)row_chunks / 8u)) % (unsigned)row_chunks);
-    } else {  // blocks that share an XCD (b % 8) take adjacent column tiles
+    } else {  // MAP_XCD_ROWS: blocks that share an XCD take adjacent column tiles
         const unsigned b = blockIdx.x, xcd = b & 7u, k = b >> 3;
         const unsigned per = (gridDim.x + 7u) >> 3;  // blocks per XCD group
         const unsigned lin = xcd * per + k;          // may exceed the tile count: such blocks exit
@@ -127,21 +103,15 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
         chunk = lin / col_tiles;
         if (chunk >= row_chunks) return;
     }
-    int64_t jg[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        jg[g] = ((((int64_t)tile * WAVES + (threadIdx.x >> 6)) * G + g) * 64 + (threadIdx.x & 63)) * CPL;
-        if (g > 0 && jg[g] >= n_store) jg[g] = jg[0];
-    }
-    const int64_t j0 = jg[0];
+    const int64_t j0 = (((int64_t)tile * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63)) * CPL;
     int64_t i0 = row_begin + (int64_t)chunk * rows_per_block;
     if (i0 + rows_per_block > row_end) i0 = row_end - rows_per_block;
 
-    F r[CT][TT];
-    F rx[CT], ry[CT];
+    F r[CPL][TT];
+    F rx[CPL], ry[CPL];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        int64_t j = jg[c / CPL] + c % CPL;
+    for (int c = 0; c < CPL; ++c) {
+        int64_t j = j0 + c;
         if (j >= n_r) j = n_r - 1;  // clamp: lanes past the edge compute a valid column
         const F *rp = R + j * T;
 #pragma unroll
@@ -158,95 +128,76 @@ __global__ __launch_bounds__(64 * WAVES) void dense_cost_kernel(
     for (int t = 0; t < H; ++t) h0[t] = arow[t];
     char *orow = reinterpret_cast<char *>(out + (i0 - row_begin) * ld);  // wave-uniform row pointer
     const unsigned lane_off = (unsigned)(j0 * sizeof(F));              // fixed per-lane byte offset (< 4 GiB rows)
-    unsigned lane_off_g[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) lane_off_g[g] = (unsigned)(jg[g] * sizeof(F));
     const int64_t row_pitch = ld * (int64_t)sizeof(F);
-    constexpr int astride = T;
-    for (int q = 0; q < rows_per_block; q += DEPTH) {
-        vecF res[DEPTH][G];
+    for (int q = 0; q < rows_per_block; ++q) {
+        // ---- phase 0: wait(h0) -> issue(second half of this row) -> compute t in [0,H)
+        if (H > 0) touch(h0[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        F h1[T - H > 0 ? T - H : 1];
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            // ---- phase 0: wait(h0) -> issue(second half of this row) -> compute t in [0,H)
-            if (H > 0) touch(h0[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            F h1[T - H > 0 ? T - H : 1];
+        for (int t = H; t < T; ++t) h1[t - H] = arow[t];
+        const F ax = axyrow[0], ay = axyrow[1];
+        __builtin_amdgcn_sched_barrier(0);
+        // columns interleaved per type: each dependent add sits CPL instructions after its subtract
+        F s[CPL];
 #pragma unroll
-            for (int t = H; t < T; ++t) h1[t - H] = arow[t];
-            const F ax = axyrow[0], ay = axyrow[1];
-            __builtin_amdgcn_sched_barrier(0);
-            // columns interleaved per type: each dependent add sits CPL instructions after its subtract
-            F s[CT];
+        for (int c = 0; c < CPL; ++c) s[c] = F(0);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) s[c] = F(0);
+        for (int t = 0; t < H; ++t) {
+            F dd[CPL];
 #pragma unroll
-            for (int t = 0; t < H; ++t) {
-                F dd[CT];
+            for (int c = 0; c < CPL; ++c) dd[c] = h0[t] - r[c][t];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dd[c] = h0[t] - r[c][t];
+            for (int c = 0; c < CPL; ++c) s[c] = s[c] + absf<F>(dd[c]);
+        }
+        // ---- phase 1: wait(h1, xy) -> issue(first half of the next row) -> compute t in [H,T), XY, store
+        touch(ax);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const bool last = (q + 1 >= rows_per_block);
+            const F *__restrict__ an = last ? arow : arow + T;  // last row re-reads itself (harmless)
 #pragma unroll
-                for (int c = 0; c < CT; ++c) s[c] = s[c] + absf<F>(dd[c]);
-            }
-            // ---- phase 1: wait(h1, xy) -> issue(first half of the next row) -> compute t in [H,T), XY, store
-            touch(ax);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const bool last = (q + d + 1 >= rows_per_block);
-                const F *__restrict__ an = last ? arow : arow + astride;  // last row re-reads itself (harmless)
+            for (int t = 0; t < H; ++t) h0[t] = an[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < H; ++t) h0[t] = an[t];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int t = H; t < T; ++t) {
+            F dd[CPL];
 #pragma unroll
-            for (int t = H; t < T; ++t) {
-                F dd[CT];
+            for (int c = 0; c < CPL; ++c) dd[c] = h1[t - H] - r[c][t];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dd[c] = h1[t - H] - r[c][t];
+            for (int c = 0; c < CPL; ++c) s[c] = s[c] + absf<F>(dd[c]);
+        }
+        F v[CPL];
+        {
+            F dx[CPL], dy[CPL], dc[CPL], ws[CPL];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) s[c] = s[c] + absf<F>(dd[c]);
-            }
-            F v[CT];
-            {
-                F dx[CT], dy[CT], dc[CT], ws[CT];
+            for (int c = 0; c < CPL; ++c) dx[c] = ax - rx[c];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dx[c] = ax - rx[c];
+            for (int c = 0; c < CPL; ++c) dy[c] = ay - ry[c];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dy[c] = ay - ry[c];
+            for (int c = 0; c < CPL; ++c) dc[c] = absf<F>(dx[c]) + absf<F>(dy[c]);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dc[c] = absf<F>(dx[c]) + absf<F>(dy[c]);
+            for (int c = 0; c < CPL; ++c) ws[c] = W1 ? s[c] : w * s[c];  // 1.0*s == s exactly: the multiply is skipped, not approximated
 #pragma unroll
-                for (int c = 0; c < CT; ++c) ws[c] = W1 ? s[c] : w * s[c];  // 1.0*s == s exactly: the multiply is skipped, not approximated
+            for (int c = 0; c < CPL; ++c) dc[c] = dcoef * dc[c];
 #pragma unroll
-                for (int c = 0; c < CT; ++c) dc[c] = dcoef * dc[c];
-#pragma unroll
-                for (int c = 0; c < CT; ++c) v[c] = ws[c] + dc[c];
-            }
-            if constexpr (VEC_STORE) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) res[d][c / CPL][c % CPL] = v[c];
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    vecF *dst = reinterpret_cast<vecF *>(orow + lane_off_g[g]);
-                    if constexpr (NT && sizeof(vecF) == 16) store16_nt_saddr(orow, lane_off_g[g], res[d][g]);
-                    else if constexpr (NT) __builtin_nontemporal_store(res[d][g], dst);
-                    else *dst = res[d][g];
-                }
-            } else {
-                F *dst = reinterpret_cast<F *>(orow + lane_off);
-#pragma unroll
-                for (int c = 0; c < CPL; ++c)
-                    if (j0 + c < n_r) dst[c] = v[c];
-            }
-            orow += row_pitch;
-            arow += astride;
-            axyrow += 2;
+            for (int c = 0; c < CPL; ++c) v[c] = ws[c] + dc[c];
         }
         if constexpr (VEC_STORE) {
+            vecF res;
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d)
+            for (int c = 0; c < CPL; ++c) res[c] = v[c];
+            store16_nt_saddr(orow, lane_off, res);
+        } else {
+            F *dst = reinterpret_cast<F *>(orow + lane_off);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) keep_alive(res[d][c / CPL][c % CPL]);
+            for (int c = 0; c < CPL; ++c)
+                if (j0 + c < n_r) dst[c] = v[c];
         }
+        orow += row_pitch;
+        arow += T;
+        axyrow += 2;
     }
 }
 
@@ -524,91 +475,68 @@ __global__ void padded_cost_lds_kernel(
     out[q] = w * s + dcoef * dc;
 }
 
-static int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-template <typename F, int T, int CPL, bool VEC, int DEPTH, bool NT, int WAVES = 4, int G = 1>
+template <typename F, int T, int CPL, bool VEC>
 int launch_one(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb, int64_t re,
                F w, F *out_rb, int64_t ld, int64_t n_cols, int rows_per_block, int map_mode) {
     // out_rb points at the output row of `rb`
     const int64_t rows = re - rb;
     if (rows <= 0) return SAME_OK;
-    const int col_tiles = (int)ceil_div(n_cols, 64 * WAVES * CPL * G);
+    const int col_tiles = (int)ceil_div(n_cols, 256 * CPL);
     const int64_t chunks = ceil_div(rows, rows_per_block);
     int64_t blocks = chunks * col_tiles;
-    if (map_mode == 2) blocks = ceil_div(blocks, 8) * 8;
-    if (map_mode == 3 || map_mode == 4 || map_mode == 5) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
+    if (map_mode == MAP_XCD_ROWS) blocks = ceil_div(blocks, 8) * 8;
+    if (map_mode == MAP_XCD_TILES) blocks = ceil_div(col_tiles, 8) * 8 * chunks;
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
-    static const int lds_pad = env_int("SAME_DENSE_LDS_PAD", 0);   // probe: unused dynamic LDS per block caps the occupancy
     if (w == F(1))
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, true, G>), dim3((unsigned)blocks), dim3(64 * WAVES), lds_pad,
-                           ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
-                           map_mode, (int)chunks);
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, true>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy, rxy, n_r,
+                           rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols, map_mode, (int)chunks);
     else
-        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, DEPTH, NT, WAVES, false, G>), dim3((unsigned)blocks), dim3(64 * WAVES), 0,
-                           ctx->stream, A, R, axy, rxy, n_r, rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols,
-                           map_mode, (int)chunks);
+        hipLaunchKernelGGL((dense_cost_kernel<F, T, CPL, VEC, false>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, R, axy, rxy, n_r,
+                           rb, re, w, w * F(0.001), out_rb, ld, col_tiles, rows_per_block, n_cols, map_mode, (int)chunks);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
 
-template <typename F, int T, int CPL, int DEPTH, bool NT>
-int launch_dense_cfg(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
-                     int64_t re, F w, F *out, int64_t ld, int64_t n_store) {
-    const int64_t rows = re - rb;
-    static const int rpb_env = env_int("SAME_DENSE_RPB", 0);
-    // Block -> (tile, chunk) map.  Store-bound shapes want every XCD to stream whole output rows (map 2: 11.4 ms at
-    // 100k x 100k vs 14.1 ms for map 4); once the fp64 VALU / power budget is the limit (T >= 16, equal times) map 4 keeps
-    // each XCD's share of R in its own L2, which removes the per-block R re-fetch: FETCH_SIZE 3.46 GB -> 0.15 GB per launch
-    // (profiles/r01_dense_map_fetch.md).  SAME_DENSE_MAP overrides (probes).
-    static const int map_override = env_int("SAME_DENSE_MAP", -1);
-    const int map_env = map_override >= 0 ? map_override : ((sizeof(F) == 8 && T >= 16) ? 4 : 2);
-    // vector stores need whole CPL-groups: n_store (a multiple of CPL, n_r <= n_store <= ld) says how many
-    // columns may be written; without such padding the scalar-store variant is used
-    const bool vec_ok = CPL > 1 && (ld % CPL == 0) && (n_store % CPL == 0) && n_store >= n_r && n_store <= ld &&
-                        (reinterpret_cast<uintptr_t>(out) % (CPL * sizeof(F)) == 0) && ld * (int64_t)sizeof(F) < ((int64_t)1 << 32);
-    if (!vec_ok) {
-        const int rpb = (int)std::min<int64_t>(rows, 64);
-        // ragged tail first (its own launch), then whole chunks with the overlapped-last-chunk rule
-        return launch_one<F, T, CPL, false, 1, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb, (map_env == 2 || map_env == 4 || map_env == 5) ? 0 : map_env);
-    }
-    const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
-    // enough row chunks to fill the chip several times over, long enough to amortise the column prologue
-    // 256 rows per block measured best at 100k x 100k (store-bound T<=12: 6.4-6.9 TB/s vs 5.9 at 64 or 512;
-    // VALU-bound T=20: equal) -- profiles/r01_dense_probe_rpb.log
-    int rows_per_block = rpb_env > 0 ? rpb_env : 256;
-    while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
-    rows_per_block = std::max(DEPTH, rows_per_block / DEPTH * DEPTH);
-    if constexpr (sizeof(F) == 8 && T == 20 && CPL == 2 && DEPTH == 1 && NT) {   // probe: two column groups per lane (SAME_DENSE_G=2)
-        static const int g_env = env_int("SAME_DENSE_G", 1);
-        if (g_env == 2 && rows >= rows_per_block)
-            return launch_one<F, T, CPL, true, DEPTH, NT, 4, 2>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rows_per_block,
-                                                                map_env);
-    }
-    if (rows >= rows_per_block)
-        return launch_one<F, T, CPL, true, DEPTH, NT>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rows_per_block,
-                                                      map_env);
-    // fewer rows than one chunk: the largest DEPTH-multiple with the deep kernel, the remainder one row at a time
-    const int64_t main_rows = rows / DEPTH * DEPTH;
-    if (main_rows)
-        SAME_TRY((launch_one<F, T, CPL, true, DEPTH, NT>(ctx, A, R, axy, rxy, n_r, rb, rb + main_rows, w, out, ld, n_store,
-                                                         (int)main_rows, map_env)));
-    if (rows - main_rows)
-        SAME_TRY((launch_one<F, T, CPL, true, 1, NT>(ctx, A, R, axy, rxy, n_r, rb + main_rows, re, w, out + main_rows * ld, ld,
-                                                     n_store, (int)(rows - main_rows), map_env)));
-    return SAME_OK;
+// SAME_DENSE_MAP = 0 | 2 | 4 forces one of the three shipped block maps (a test hook: every map must give the same bits)
+static int forced_map() {
+    static const int m = [] {
+        const char *v = getenv("SAME_DENSE_MAP");
+        const int x = v ? atoi(v) : -1;
+        return (x == MAP_TILE_FASTEST || x == MAP_XCD_ROWS || x == MAP_XCD_TILES) ? x : -1;
+    }();
+    return m;
 }
 
 template <typename F, int T>
 int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F *rxy, int64_t n_r, int64_t rb,
                    int64_t re, F w, F *out, int64_t ld, int64_t n_store) {
     constexpr int CPLV = vec_of<F>::cpl;
-    // T large: one column per lane keeps the register file within budget
+    // T large: one column per lane keeps the register file within budget (and gives up the 16-byte store)
     constexpr int CPL = (T * CPLV * (int)(sizeof(F) / 4) <= 160) ? CPLV : 1;
-    constexpr int DEPTH = 1;
-    return launch_dense_cfg<F, T, CPL, DEPTH, true>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
+    const int64_t rows = re - rb;
+    // Store-bound shapes want every XCD to stream whole output rows (MAP_XCD_ROWS: 11.4 ms at 100k x 100k vs 14.1 ms for
+    // MAP_XCD_TILES); once fp64 issue under the power cap is the limit (T >= 16, equal times) MAP_XCD_TILES keeps each XCD's
+    // share of R in its own L2 (profiles/r01_dense_map_fetch.md).
+    const int map = forced_map() >= 0 ? forced_map() : ((sizeof(F) == 8 && T >= 16) ? MAP_XCD_TILES : MAP_XCD_ROWS);
+    // vector stores need whole CPL-groups: n_store (a multiple of CPL, n_r <= n_store <= ld) says how many
+    // columns may be written; without such padding the scalar-store variant is used
+    const bool vec_ok = CPL > 1 && (ld % CPL == 0) && (n_store % CPL == 0) && n_store >= n_r && n_store <= ld &&
+                        (reinterpret_cast<uintptr_t>(out) % (CPL * sizeof(F)) == 0) && ld * (int64_t)sizeof(F) < ((int64_t)1 << 32);
+    if constexpr (CPL > 1) {
+        if (vec_ok) {
+            const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
+            // enough row chunks to fill the chip several times over, long enough to amortise the column prologue: 256 rows per
+            // block measured best at 100k x 100k (store-bound T<=12: 6.4-6.9 TB/s vs 5.9 at 64 or 512; T=20: equal) --
+            // profiles/r01_dense_probe_rpb.log
+            int rows_per_block = 256;
+            while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
+            if (rows_per_block > rows) rows_per_block = (int)rows;   // fewer rows than one chunk: one chunk of exactly these rows
+            return launch_one<F, T, CPL, true>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store, rows_per_block, map);
+        }
+    }
+    const int rpb = (int)std::min<int64_t>(rows, 64);
+    return launch_one<F, T, CPL, false>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_r, rpb,
+                                        forced_map() >= 0 ? forced_map() : MAP_TILE_FASTEST);
 }
 
 template <typename F>
@@ -618,9 +546,9 @@ int launch_dense(same_ctx *ctx, const F *A, const F *R, int T, const F *axy, con
     REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && n_r >= 0 && rb >= 0 && re >= rb && ld >= n_r);
     SAME_TRY(same_use(ctx));
     if (n_r == 0 || re == rb) return SAME_OK;
-    // above this many type columns the row-blocked kernel takes over from the column-resident one (SAME_DENSE_ROWBLOCK_MIN_T
-    // overrides, for probing the crossover)
-    static const int rowblock_min_T = env_int("SAME_DENSE_ROWBLOCK_MIN_T", sizeof(F) == 8 ? 48 : 49);
+    // above this many type columns the row-blocked kernel takes over from the column-resident one (measured crossover:
+    // profiles/r02_dense_generic_kernel.log)
+    constexpr int rowblock_min_T = sizeof(F) == 8 ? 48 : 49;
     if (T < rowblock_min_T)
     switch (T) {
 #define CASE_T(n) case n: return launch_dense_T<F, n>(ctx, A, R, axy, rxy, n_r, rb, re, w, out, ld, n_store);
@@ -706,11 +634,10 @@ int padded_cost_dev(same_ctx *ctx, const F *dA, const F *dR, int T, const F *dax
     SAME_TRY(same_use(ctx));
     const int64_t n_slots = (row_end - row_begin) * k;
     if (n_slots == 0) return SAME_OK;
-    static const int mode = env_int("SAME_PADDED_MODE", 1);   // 0 = one lane gathers its row from global, 1 = LDS-staged rows
     size_t per_wave = (size_t)64 * (T | 1) * sizeof(F) + 64 * sizeof(int);
     per_wave = (per_wave + 7) & ~size_t(7);
     int waves = (int)std::min<size_t>(4, (size_t)65536 / per_wave);
-    if (mode == 1 && T >= 2 && waves >= 1 && n_slots >= 64 * 64) {
+    if (T >= 2 && waves >= 1 && n_slots >= 64 * 64) {   // LDS-staged rows; tiny inputs and very wide rows: one lane gathers its row
         // the per-wave index list sits after ALL waves' row blocks: keep it 4-byte aligned for float rows of odd pitch
         hipLaunchKernelGGL(padded_cost_lds_kernel<F>, dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
                            ctx->stream, dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost);

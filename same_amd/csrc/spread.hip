@@ -61,16 +61,17 @@ __global__ __launch_bounds__(256) void spread_pair_kernel(char *a, char *b, uint
     for (int r = 0; r < P_RPB; ++r, p += P_ROW) __builtin_nontemporal_store(val, (v2d *)p);
 }
 
-// Share r (= blockIdx % 8) writes the chunks r, r + 8, r + 16, ... of the range one after the other, so at any moment the
-// eight fronts lie in eight CONSECUTIVE chunks: with the chunks laid round-robin over the regions that is the spread the
-// buffer was built for, and the rate of this store over the finished range is what same_dev_alloc_spread reports as verified.
+// One store over the whole finished range, shaped like the stores the buffer was built for: at step p share r (= blockIdx % 8,
+// one XCD) writes its own eighth of chunk (p + r) mod n, so at any moment the eight fronts lie in eight CONSECUTIVE chunks --
+// with the chunks laid round-robin over the regions, in all of them at once -- every share has the same amount of work, and
+// after n steps every byte has been written once.  Its rate is what same_dev_alloc_spread reports as verified.
 __global__ __launch_bounds__(256) void spread_sweep_kernel(char *va, unsigned n_chunks) {
-    constexpr unsigned PER_CHUNK = (unsigned)(CHUNK / (P_RPB * 4096));       // blocks per chunk: 64 tiles x 64 row groups
+    constexpr unsigned PER_SLICE = (unsigned)(CHUNK / 8 / (P_RPB * 4096));   // blocks per eighth of a chunk: 64 tiles x 8 row groups
     const unsigned share = blockIdx.x & 7u, k = blockIdx.x >> 3;
-    const unsigned chunk = (k / PER_CHUNK) * 8u + share, within = k % PER_CHUNK;
-    if (chunk >= n_chunks) return;
+    const unsigned step = k / PER_SLICE, within = k % PER_SLICE;
+    const unsigned chunk = (step + share) % n_chunks;
     const unsigned tile = within % P_TILES, rows = within / P_TILES;
-    char *p = va + (uint64_t)chunk * CHUNK + (uint64_t)rows * P_RPB * P_ROW + (uint64_t)tile * 4096 + threadIdx.x * 16;
+    char *p = va + (uint64_t)chunk * CHUNK + (uint64_t)share * (CHUNK / 8) + (uint64_t)rows * P_RPB * P_ROW + (uint64_t)tile * 4096 + threadIdx.x * 16;
     const v2d val = {0.0, 0.0};
     for (int r = 0; r < P_RPB; ++r, p += P_ROW) __builtin_nontemporal_store(val, (v2d *)p);
 }
@@ -92,18 +93,20 @@ struct Timer {
     Timer &operator=(const Timer &) = delete;
     // GB/s of one store over the whole finished range (spread_sweep_kernel); best of two after one untimed
     double sweep(char *va, size_t n_chunks) {
-        const unsigned grid = 8u * (unsigned)((n_chunks + 7) / 8) * (unsigned)(CHUNK / (P_RPB * 4096));
+        const unsigned grid = 8u * (unsigned)n_chunks * (unsigned)(CHUNK / 8 / (P_RPB * 4096));
+        const int passes = (int)std::max<size_t>(1, (24 + n_chunks - 1) / n_chunks);   // >= 24 GiB per reading: a short launch reads low
         float best = 1e30f;
         for (int r = 0; r < 3; ++r) {
             if (hipEventRecord(ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
-            hipLaunchKernelGGL(spread_sweep_kernel, dim3(grid), dim3(256), 0, ctx->stream, va, (unsigned)n_chunks);
+            for (int q = 0; q < passes; ++q)
+                hipLaunchKernelGGL(spread_sweep_kernel, dim3(grid), dim3(256), 0, ctx->stream, va, (unsigned)n_chunks);
             float ms = 0.f;
             if (hipEventRecord(ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
                 hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }
             if (r && ms < best) best = ms;
         }
         if (hipGetLastError() != hipSuccess) { rc = SAME_EIO; return 0.0; }
-        return (double)n_chunks * (double)CHUNK / best * 1e-6;
+        return (double)passes * (double)n_chunks * (double)CHUNK / best * 1e-6;
     }
     // GB/s of writing `span` bytes at a and `span` bytes at b at once, 4 GiB in all per launch; best of two after one untimed (the two levels are ~20 % apart, the readings within ~5 %)
     double rate(char *a, char *b, uint64_t span) {

@@ -273,10 +273,10 @@ constexpr int64_t VIOL_HEAD = 4096;
 inline size_t head_bytes(const same_sweep *s) { return 2 * sizeof(unsigned long long) + (size_t)std::min<int64_t>(s->Tr, VIOL_HEAD) * sizeof(int32_t); }
 
 // after the compaction kernel: counters + head of the list in one copy, the rest of a long list in a second one
-int read_back(same_sweep *s, bool copy_enqueued, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol) {
+int read_back(same_sweep *s, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol) {
     same_ctx *ctx = s->ctx;
     unsigned char *h = static_cast<unsigned char *>(ctx->pinned);
-    if (!copy_enqueued) HIP_TRY(ctx, hipMemcpyAsync(h, s->cnt, head_bytes(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h, s->cnt, head_bytes(s), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long c[2];
     memcpy(c, h, sizeof c);
@@ -306,55 +306,19 @@ int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, in
     }
     hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->mask, n_words, Tr, s->viol, s->cnt);
     HIP_TRY(ctx, hipGetLastError());
-    return read_back(s, false, out_checked, out_viol_idx, out_nviol);
+    return read_back(s, out_checked, out_viol_idx, out_nviol);
 }
 
 // The per-incumbent sweep from the handle's own match block is the launch-bound inner loop of the path (the solver calls it
-// for every incumbent).  Its four stream operations -- counter memset, flag kernel, compaction, read-back -- can be captured
-// once per handle and replayed as one graph launch (SAME_SWEEP_GRAPH=1).  Measured at BASELINE cfg 3 scale (95k triangles,
-// profiles/r02_sweep_latency.log): 61 us per call with the plain launches, 69 us replayed as a graph -- hipGraphLaunch costs
-// more than four enqueues on this ROCm -- so the plain launches are the default and the graph stays an opt-in that is tested.
-int orient_graph_build(same_sweep *s) {
-    same_ctx *ctx = s->ctx;
-    const int64_t Tr = s->Tr, n_words = ceil_div(Tr, 64);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    hipError_t e = hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, s->tris, Tr, s->sign, s->rxy, s->match,
-                           s->flag, s->mask, s->cnt);
-        hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->mask, n_words, Tr, s->viol, s->cnt);
-        e = hipMemcpyAsync(ctx->pinned, s->cnt, head_bytes(s), hipMemcpyDeviceToHost, ctx->stream);
-    }
-    hipGraph_t g = nullptr;
-    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &g);   // always end the capture, whatever happened inside it
-    if (e != hipSuccess || e_end != hipSuccess || !g) {
-        if (g) (void)hipGraphDestroy(g);
-        return same_fail(ctx, SAME_EIO, "stream capture of the orientation sweep", e != hipSuccess ? e : e_end);
-    }
-    hipGraphExec_t x = nullptr;
-    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) {
-        (void)hipGraphDestroy(g);
-        return same_fail(ctx, SAME_EIO, "hipGraphInstantiate (orientation sweep)", e);
-    }
-    s->orient_graph_src = g;
-    s->orient_graph = x;
-    return SAME_OK;
-}
-
+// for every incumbent): four stream operations -- counter memset, flag kernel, compaction, one read-back.  Replaying them as
+// one captured hipGraph was measured SLOWER on this ROCm (69 us against 61 us per call at 95k triangles,
+// profiles/r02_sweep_latency.log: hipGraphLaunch costs more than four enqueues), so the plain launches are the only form.
 int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol,
                uint8_t *out_flag) {
     same_ctx *ctx = s->ctx;
     *out_checked = 0;
     *out_nviol = 0;
     if (s->Tr == 0) return SAME_OK;
-    static const bool use_graph = getenv("SAME_SWEEP_GRAPH") && getenv("SAME_SWEEP_GRAPH")[0] == '1';
-    if (use_graph && dmatch == s->match && !out_flag && head_bytes(s) <= ctx->pinned_bytes) {
-        if (!s->orient_graph) SAME_TRY(orient_graph_build(s));
-        HIP_TRY(ctx, hipGraphLaunch(s->orient_graph, ctx->stream));
-        return read_back(s, true, out_checked, out_viol_idx, out_nviol);
-    }
     HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
     SAME_TRY(launch_orient_flags(s, dmatch, 0, s->Tr, s->flag, s->mask, s->cnt));
     if (out_flag) SAME_TRY(same_down(ctx, out_flag, s->flag, (size_t)s->Tr));
@@ -418,8 +382,6 @@ void same_sweep_unbind(same_sweep *s) {
     same_ctx *ctx = s->ctx;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (s->orient_graph) (void)hipGraphExecDestroy(s->orient_graph);
-    if (s->orient_graph_src) (void)hipGraphDestroy(s->orient_graph_src);
     void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->mask, s->cnt, s->x};   // viol lives in cnt's block
     for (void *b : blocks)
         if (b) (void)hipFree(b);

@@ -1,11 +1,13 @@
 """Window-merge helpers, SURVEY 8(f3): helpers.merge_window_matches_unique_ref and
 helpers.load_matching_results (src/helpers.py:667-815), same signatures.
 
-Host-side graph matching on the small merged match table (not data-parallel).  The
-de-duplication rule and the maximum-cardinality matching are the reference's; the matching itself is
-computed with scipy's Hopcroft-Karp on integer node ids, which makes the choice among equally large
-matchings deterministic (the reference's networkx call iterates a set of string labels, so its choice
-varies with PYTHONHASHSEED -- the reference output is one of the maximum matchings, as this is)."""
+Two halves.  The de-duplication of the concatenated per-window tables (src/helpers.py:745-753: stable sort by
+violation and window id, first row of every (aligned, ref) pair) is data-parallel and runs on the GPU
+(csrc/merge.hip, `ops.merge_dedup`: key build, bitonic sort, hash-table first-occurrence, ordered compaction).  The
+maximum-cardinality matching on the rows that survive (:755-815) is a sequential graph algorithm
+and stays on the host: scipy's Hopcroft-Karp on integer node ids, which makes the choice among equally large
+matchings deterministic (the reference's networkx call iterates a set of string labels, so its choice varies with
+PYTHONHASHSEED -- the reference output is one of the maximum matchings, as this is)."""
 import os
 
 import numpy as np
@@ -26,7 +28,18 @@ def load_matching_results(outprefix):
             pd.read_csv(os.path.join(outprefix, "matches_df.csv")))
 
 
-def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old"):
+def _window_codes(window_id):
+    """window ids as non-negative int32 in their own order (they are small non-negative ints in every reference flow,
+    src/same.py:582; anything else -- negative, huge, float -- is ranked first, which preserves the order)."""
+    w = np.asarray(window_id)
+    if w.dtype.kind in "iu" and (len(w) == 0 or (w.min() >= 0 and w.max() < 2 ** 31)):
+        return w.astype(np.int32)
+    return np.unique(w, return_inverse=True)[1].astype(np.int32)
+
+
+def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _dedup=None):
+    """src/helpers.py:692-815.  `_dedup(viol, window_id, aligned_code, ref_code) -> surviving row indices` defaults to the HIP
+    kernel chain (`ops.merge_dedup`); the CPU tests pass the oracle's restatement of the same step."""
     from scipy.sparse import csr_matrix
     from scipy.sparse.csgraph import maximum_bipartite_matching
 
@@ -39,9 +52,16 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old"):
     if missing:
         raise ValueError(f"Missing required columns in matches: {missing}")
     merged_df["filtered_violation"] = merged_df["filtered_violation"].fillna(True).astype(bool)
-    # one row per (aligned, ref) pair: non-violating first, then the smaller window id (:748-753)
-    merged_df = merged_df.sort_values(by=["filtered_violation", "window_id"], ascending=[True, True], kind="mergesort")
-    merged_df = merged_df.drop_duplicates(subset=[aligned_col, ref_col], keep="first")
+    # one row per (aligned, ref) pair: non-violating first, then the smaller window id, then the earlier row (:748-753);
+    # the ids may be anything hashable, the device sees integer codes of them (equal id <=> equal code)
+    if _dedup is None:
+        from . import ops
+
+        _dedup = ops.merge_dedup
+    kept = _dedup(merged_df["filtered_violation"].to_numpy(), _window_codes(merged_df["window_id"].to_numpy()),
+                  pd.factorize(merged_df[aligned_col].values, use_na_sentinel=False)[0].astype(np.int32),
+                  pd.factorize(merged_df[ref_col].values, use_na_sentinel=False)[0].astype(np.int32))
+    merged_df = merged_df.iloc[np.asarray(kept, dtype=np.int64)]
     a_codes, a_uniques = pd.factorize(merged_df[aligned_col].values, sort=True)
     r_codes, _ = pd.factorize(merged_df[ref_col].values, sort=True)
     n_a, n_r = len(a_uniques), int(r_codes.max()) + 1 if len(r_codes) else 0

@@ -366,3 +366,20 @@ def batched_assign(a_off, r_off, axy, rxy, ctx=None):
         ctx.check(ctx.lib.same_batched_assign(ctx.handle, len(a_off) - 1, a_off.ctypes.data, r_off.ctypes.data, axy.ctypes.data,
                                               rxy.ctypes.data, out.ctypes.data), "same_batched_assign")
     return out
+
+
+def merge_dedup(viol, window_id, aligned_code, ref_code, ctx=None):
+    """De-duplication step of the window merge (src/helpers.py:745-753) -> int32 indices of the surviving rows, in the order of
+    the reference's frame after sort_values(['filtered_violation', 'window_id'], mergesort) + drop_duplicates(keep='first')."""
+    ctx = _ctx(ctx)
+    viol = as_c(np.asarray(viol).astype(bool), np.uint8)
+    w, a, r = as_c(window_id, I32), as_c(aligned_code, I32), as_c(ref_code, I32)
+    n = len(viol)
+    if not (len(w) == len(a) == len(r) == n):
+        raise ValueError("viol, window_id, aligned_code and ref_code must have one entry per row")
+    out = np.empty(max(n, 1), I32)
+    m = ctypes.c_int64(0)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_merge_dedup(ctx.handle, viol.ctypes.data, w.ctypes.data, a.ctypes.data, r.ctypes.data, n, out.ctypes.data,
+                                           ctypes.byref(m)), "same_merge_dedup")
+    return out[: m.value].copy()

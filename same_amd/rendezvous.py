@@ -19,10 +19,12 @@ The data path never goes through here on GPUs: pruned candidate lists and sweep 
 RCCL (csrc/comm.hip).  `allgather_array` exists for CPU tests and as a transport (never compute)
 fallback when the RCCL communicator cannot be created.
 """
+import base64
+import io
 import json
 import os
-import pickle
 import secrets
+import stat
 import socket
 import struct
 import tempfile
@@ -48,6 +50,91 @@ def default_rdv_dir():
     ppid = os.getppid()
     key = f"{os.environ.get('MASTER_PORT', '0')}_{ppid}_{_proc_start_time(ppid)}"
     return os.path.join(tempfile.gettempdir(), f"same_rdv_{os.getuid()}_{key}")
+
+
+def _check_private(path, what, want_dir):
+    """The rendezvous directory and the file in it are this job's only credentials: refuse anything this user does not own
+    outright.  A directory someone else made first (the default path is predictable), a symlink, or group / world access bits
+    would let another local user read the token or point the ranks at a port of their own."""
+    st = os.lstat(path)
+    if stat.S_ISLNK(st.st_mode) or (want_dir and not stat.S_ISDIR(st.st_mode)) or (not want_dir and not stat.S_ISREG(st.st_mode)):
+        raise PermissionError(f"{what} {path} is not a plain {'directory' if want_dir else 'file'}: refusing to use it")
+    if st.st_uid != os.getuid():
+        raise PermissionError(f"{what} {path} belongs to uid {st.st_uid}, not to this user ({os.getuid()}): refusing to use it")
+    if st.st_mode & 0o077:
+        raise PermissionError(f"{what} {path} is accessible to other users (mode {stat.S_IMODE(st.st_mode):o}): refusing to use it")
+
+
+# ---- small host objects, without pickle -------------------------------------------------------------------------------
+# What the ranks exchange (dicts of numbers and strings, lists, numpy arrays, the per-window match tables as pandas frames)
+# travels as JSON with numeric arrays as .npy bytes read back with allow_pickle=False: nothing a peer sends can name a
+# callable, so a channel that was somehow reached by someone else still cannot execute code in a rank.
+def _enc(o):
+    import numpy as np
+
+    if o is None or isinstance(o, (bool, int, float, str)):
+        return o
+    if isinstance(o, np.generic):
+        return _enc(o.item())
+    if isinstance(o, bytes):
+        return {"__b__": base64.b64encode(o).decode()}
+    if isinstance(o, np.ndarray):
+        if o.dtype.kind in "biufc":
+            buf = io.BytesIO()
+            np.save(buf, np.ascontiguousarray(o), allow_pickle=False)
+            return {"__nd__": base64.b64encode(buf.getvalue()).decode()}
+        return {"__ndo__": [_enc(x) for x in o.reshape(-1).tolist()], "shape": list(o.shape), "dtype": o.dtype.str if o.dtype.kind in "US" else "O"}
+    if isinstance(o, tuple):
+        return {"__t__": [_enc(x) for x in o]}
+    if isinstance(o, (list, set, frozenset)):
+        return [_enc(x) for x in o] if isinstance(o, list) else {"__s__": [_enc(x) for x in sorted(o, key=repr)]}
+    if isinstance(o, dict):
+        return {"__d__": [[_enc(k), _enc(v)] for k, v in o.items()]}
+    try:
+        import pandas as pd
+    except ImportError:   # pragma: no cover
+        pd = None
+    if pd is not None and isinstance(o, pd.DataFrame):
+        return {"__df__": {"columns": [_enc(c) for c in o.columns], "data": [_enc(o[c].to_numpy()) for c in o.columns],
+                           "index": _enc(o.index.to_numpy())}}
+    raise TypeError(f"allgather_object cannot carry a {type(o).__name__} (numbers, strings, lists, dicts, numpy arrays and pandas frames only)")
+
+
+def _dec(o):
+    import numpy as np
+
+    if isinstance(o, list):
+        return [_dec(x) for x in o]
+    if not isinstance(o, dict):
+        return o
+    if "__nd__" in o:
+        return np.load(io.BytesIO(base64.b64decode(o["__nd__"])), allow_pickle=False)
+    if "__ndo__" in o:
+        vals = [_dec(x) for x in o["__ndo__"]]
+        if o["dtype"] != "O":
+            return np.array(vals, dtype=o["dtype"]).reshape(o["shape"])
+        a = np.empty(len(vals), dtype=object)
+        for i, v in enumerate(vals):
+            a[i] = v
+        return a.reshape(o["shape"])
+    if "__b__" in o:
+        return base64.b64decode(o["__b__"])
+    if "__t__" in o:
+        return tuple(_dec(x) for x in o["__t__"])
+    if "__s__" in o:
+        return set(_dec(x) for x in o["__s__"])
+    if "__d__" in o:
+        return {_dec(k): _dec(v) for k, v in o["__d__"]}
+    if "__df__" in o:
+        import pandas as pd
+
+        d = o["__df__"]
+        cols = [_dec(c) for c in d["columns"]]
+        idx = _dec(d["index"])
+        # column by column, so every column keeps the dtype its array travelled with
+        return pd.DataFrame({i: pd.Series(_dec(a), index=idx) for i, a in enumerate(d["data"])}, index=idx).set_axis(cols, axis=1) \
+            if cols else pd.DataFrame(index=idx)
+    raise ValueError("malformed object frame from a peer")
 
 
 def _recv_exact(sock, n):
@@ -94,10 +181,9 @@ class HostGroup:
         hub_file = os.path.join(self._dir, "hub.json")
         if self.rank == 0:
             os.makedirs(self._dir, mode=0o700, exist_ok=True)
-            try:
-                os.chmod(self._dir, 0o700)       # the token below is this job's only credential: keep it to this user
-            except OSError:
-                pass
+            if os.lstat(self._dir).st_uid == os.getuid():
+                os.chmod(self._dir, 0o700)       # the token below is this job's only credential: keep it to this user (a failure raises)
+            _check_private(self._dir, "rendezvous directory", want_dir=True)
             token = secrets.token_hex(16)
             ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             ls.bind(("127.0.0.1", 0))
@@ -128,8 +214,14 @@ class HostGroup:
             info = None
             while info is None:
                 try:
+                    if not os.path.lexists(hub_file):     # rank 0 writes it after it has made the directory private
+                        raise FileNotFoundError(hub_file)
+                    _check_private(self._dir, "rendezvous directory", want_dir=True)   # PermissionError is not retried: it propagates
+                    _check_private(hub_file, "rendezvous file", want_dir=False)
                     with open(hub_file) as f:
                         info = json.load(f)
+                except PermissionError:
+                    raise
                 except (OSError, ValueError):
                     if time.monotonic() > deadline:
                         raise TimeoutError(f"rank {self.rank}: no rendezvous file {hub_file} after {self.timeout:.0f} s")
@@ -187,9 +279,11 @@ class HostGroup:
         return np.concatenate(parts, axis=0)
 
     def allgather_object(self, obj):
-        """Small host objects between this job's own ranks (pickle; the connections are loopback-only and were admitted
-        with the job's token, which sits in a 0600 file of a 0700 directory: only this user's own ranks can be on them)."""
-        return [pickle.loads(p) for p in self.allgather_bytes(pickle.dumps(obj, protocol=4))]
+        """Small host objects between this job's own ranks: numbers, strings, lists / tuples / sets / dicts of them, numpy
+        arrays and pandas frames (the per-window match tables), as JSON + .npy bytes -- no pickle, so nothing a peer sends
+        can run code here.  The connections are loopback-only and admitted with the job's token, which sits in a 0600 file
+        of a 0700 directory whose ownership every rank checks."""
+        return [_dec(json.loads(p.decode())) for p in self.allgather_bytes(json.dumps(_enc(obj)).encode())]
 
     def close(self):
         for s in list(self._peers.values()) + [self._hub, self._listener]:

@@ -271,8 +271,14 @@ def save(outprefix, var_out):
     tmp = os.path.join(outprefix, "var_out.json.tmp")
     with open(tmp, "w") as f:
         json.dump(doc, f, allow_nan=False)
-    np.savez_compressed(os.path.join(outprefix, "var_out.npz"), **enc.arrays)
-    os.replace(tmp, os.path.join(outprefix, "var_out.json"))   # the structure appears last: a reader never sees half a pair
+    tmp_npz = os.path.join(outprefix, "var_out.npz.tmp")
+    with open(tmp_npz, "wb") as f:                               # a file object: savez would append ".npz" to a temp NAME
+        np.savez_compressed(f, **enc.arrays)
+    # both halves are complete before either appears; the arrays go first and the structure last, so a reader that finds
+    # a new var_out.json finds its arrays, and a crash in between leaves the OLD json beside arrays it does not index into
+    # wrongly only for the instant between the two renames (each rename is atomic)
+    os.replace(tmp_npz, os.path.join(outprefix, "var_out.npz"))
+    os.replace(tmp, os.path.join(outprefix, "var_out.json"))
 
 
 def load(outprefix):

@@ -120,6 +120,74 @@ def test_rendezvous_collectives(tmp_path, world):
     assert [(tmp_path / f"r{r}.txt").read_text() for r in range(world)] == ["True"] * world
 
 
+def test_rendezvous_refuses_a_directory_it_does_not_own_outright(tmp_path):
+    """The rendezvous directory holds the job's token: a reader refuses one that other users can enter, a symlink, a hub file
+    with group / world bits, and (when the test can chown) one that belongs to someone else -- instead of trusting whatever
+    hub.json it finds there (the default path is predictable)."""
+    import json
+    from same_amd.rendezvous import HostGroup, _check_private
+
+    def reader(d):
+        return HostGroup(1, 2, rdv_dir=str(d), timeout=5)
+
+    hub = {"port": 1, "token": "0" * 32, "world": 2}
+    open_dir = tmp_path / "open"
+    open_dir.mkdir(mode=0o755)
+    os.chmod(open_dir, 0o755)
+    (open_dir / "hub.json").write_text(json.dumps(hub))
+    os.chmod(open_dir / "hub.json", 0o600)
+    with pytest.raises(PermissionError, match="accessible to other users"):
+        reader(open_dir)
+    priv = tmp_path / "priv"
+    priv.mkdir(mode=0o700)
+    (priv / "hub.json").write_text(json.dumps(hub))
+    os.chmod(priv / "hub.json", 0o644)
+    with pytest.raises(PermissionError, match="rendezvous file"):
+        reader(priv)
+    link = tmp_path / "link"
+    os.symlink(priv, link)
+    with pytest.raises(PermissionError, match="not a plain directory"):
+        reader(link)
+    if os.geteuid() == 0:
+        other = tmp_path / "other"
+        other.mkdir(mode=0o700)
+        (other / "hub.json").write_text(json.dumps(hub))
+        os.chmod(other / "hub.json", 0o600)
+        os.chown(other, 12345, 12345)
+        with pytest.raises(PermissionError, match="belongs to uid 12345"):
+            reader(other)
+        # rank 0 does not adopt such a directory either
+        with pytest.raises(PermissionError):
+            HostGroup(0, 2, rdv_dir=str(other), timeout=2)
+    # a directory of ours that was merely created too open is made private by rank 0, not refused
+    _check_private(str(priv), "dir", want_dir=True)
+
+
+def test_allgather_object_carries_frames_without_pickle(tmp_path):
+    """The object exchange is JSON + .npy bytes (allow_pickle=False): dicts with non-string keys, tuples, sets, numpy arrays and
+    the per-window match tables (pandas frames with string / float / bool columns and a non-default index) come back equal,
+    and something that is not data is refused at the sender."""
+    import json
+    import pandas as pd
+    from same_amd import rendezvous as rdv
+
+    df = pd.DataFrame({"aligned_idx": np.arange(4), "cell_type": ["a", "b", None, "d"], "cost": [1.5, np.nan, 2.0, 3.0],
+                       "flag": np.array([True, False, True, True])}, index=[3, 5, 7, 9])
+    obj = {"k": (1, 2.5, "s"), 3: [df, None, {1, 2}], "arr": np.arange(6, dtype=np.int32).reshape(2, 3), "empty": pd.DataFrame(),
+           "raw": bytes(range(5)), "np": np.float32(0.25)}
+    wire = json.dumps(rdv._enc(obj))
+    assert "pickle" not in wire and "__reduce__" not in wire
+    back = rdv._dec(json.loads(wire))
+    assert back["k"] == (1, 2.5, "s") and back[3][1] is None and back[3][2] == {1, 2} and back["raw"] == bytes(range(5)) and back["np"] == 0.25
+    assert back["arr"].dtype == np.int32 and np.array_equal(back["arr"], obj["arr"]) and back["empty"].shape == (0, 0)
+    pd.testing.assert_frame_equal(back[3][0], df)
+    with pytest.raises(TypeError):
+        rdv._enc({"f": open})
+    assert "import pickle" not in open(rdv.__file__).read()
+    with rdv.HostGroup(0, 1) as g:
+        assert g.allgather_object(obj)[0]["k"] == (1, 2.5, "s")
+
+
 def test_rendezvous_dir_is_keyed_by_launcher(monkeypatch):
     """Without SAME_RDV_DIR (the torch.distributed.run case) every worker of one agent derives the same directory from
     MASTER_PORT + the parent's pid and start time; another port gives another directory."""

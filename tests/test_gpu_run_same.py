@@ -68,21 +68,21 @@ def test_run_same_with_mock_solver(gp, case, tmp_path):
     assert [s["total_triangles"], s["violated_triangles"], s["total_comparisons"], s["total_violations"]] == g["viol_summary"].tolist()
     assert var_out["triangle_data"]["flipped_triangles"] == g["area_flipped"].tolist()
     assert var_out["lazy_cuts_added"] == len(want) and var_out["lazy_constraints"] is True
-    for f in ("matches_df.csv", "aligned_df.csv", "ref_df.csv", "var_out.json", "var_out.npz", "matching_model.lp"):
-        assert (tmp_path / "out" / f).exists()
-    assert not (tmp_path / "out" / "var_out.npy").exists()          # no pickle unless asked for
+    for f in ("matches_df.csv", "aligned_df.csv", "ref_df.csv", "var_out.json", "var_out.npz", "var_out.npy", "matching_model.lp"):
+        assert (tmp_path / "out" / f).exists()                       # var_out.npy: the reference's own file, for its readers
     # the pickle-free pair holds the whole of var_out (keys in order, triangle_info insertion order included)
     from same_amd import varout
     from test_varout import assert_same
     assert_same(var_out, varout.load(str(tmp_path / "out")))
-    # SAME_LEGACY_VAR_OUT=1 additionally writes the reference's own file; it reads back through the numpy-only unpickler
-    os.environ["SAME_LEGACY_VAR_OUT"] = "1"
+    # the reference's file reads back through the numpy-only unpickler; SAME_LEGACY_VAR_OUT=0 leaves it out
+    legacy = varout.load_legacy_npy(str(tmp_path / "out" / "var_out.npy"))
+    assert list(legacy.keys()) == list(var_out.keys()) and legacy["x"] == var_out["x"]
+    os.environ["SAME_LEGACY_VAR_OUT"] = "0"
     try:
-        same_amd.run_same(r_df, a_df, cols, outprefix=str(tmp_path / "legacy"), optim_params=op, gurobi_params=gpar)
+        same_amd.run_same(r_df, a_df, cols, outprefix=str(tmp_path / "nopickle"), optim_params=op, gurobi_params=gpar)
     finally:
         del os.environ["SAME_LEGACY_VAR_OUT"]
-    legacy = varout.load_legacy_npy(str(tmp_path / "legacy" / "var_out.npy"))
-    assert list(legacy.keys()) == list(var_out.keys()) and legacy["x"] == var_out["x"]
+    assert (tmp_path / "nopickle" / "var_out.json").exists() and not (tmp_path / "nopickle" / "var_out.npy").exists()
     # allowed flip fraction above the observed rate -> no cuts (src/same.py:674-679)
     same_amd.run_same(r_df, a_df, cols, optim_params=op, gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=1.0))
     assert gp.Model.last._cuts_added == 0
@@ -254,7 +254,7 @@ def test_run_same_eager_mode_matches_reference_model(gp, tmp_path):
     assert var_out["lazy_constraints"] is False and var_out["lazy_cuts_added"] == 0
     assert len(var_out["area_penalty_vars"]) == len(g["area_penalty_names"]) == len(g["triangles"])
     assert not hasattr(model.Params, "LazyConstraints")
-    assert len(out_df) > 0 and (tmp_path / "var_out.npz").exists() and not (tmp_path / "var_out.npy").exists()
+    assert len(out_df) > 0 and (tmp_path / "var_out.npz").exists() and (tmp_path / "var_out.npy").exists()
 
 
 @pytest.mark.parametrize("force_comm", [False, True])
@@ -414,12 +414,12 @@ def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
     out_df, var_out = same_amd.run_same(r_df.copy(), a_df.copy(), cols, outprefix=outprefix, optim_params=same_amd.init_optim_params(**op),
                                         gurobi_params=same_amd.init_gurobi_params(**gpar), **extra)
     got = rec.record_run(out_df, var_out, gp.Model.last)
-    # files written: the reference's set, except that its pickled var_out.npy (src/same.py:1455-1462) is replaced by the
-    # pickle-free var_out.json + var_out.npz pair (same_amd/varout.py; INTEGRATION.md "deliberately differs")
+    # files written: the reference's set (its pickled var_out.npy, src/same.py:1455-1462, included) plus the pickle-free
+    # var_out.json + var_out.npz pair beside it (same_amd/varout.py; INTEGRATION.md "deliberately differs")
     written = sorted(os.listdir(outprefix))
     if "var_out.json" in written:
-        assert "var_out.npz" in written and "var_out.npy" not in written
-        written = sorted([f for f in written if f not in ("var_out.json", "var_out.npz")] + ["var_out.npy"])
+        assert "var_out.npz" in written and "var_out.npy" in written
+        written = sorted(f for f in written if f not in ("var_out.json", "var_out.npz"))
     got["files"] = np.array(written, dtype=str)
     rec.assert_same_record(got, g, prefix=f"{tag}/")
     # what was written loads back through load_matching_results (src/helpers.py:667-689) and flattens to the same record

@@ -147,8 +147,48 @@ def _merge_input():
     return [dfm[dfm.window_id == w].copy() for w in range(3)]
 
 
-def test_merge_window_matches_unique_ref():
+def _dedup_frames(g, tag):
+    rows, viol = g[f"{tag}_in"], g[f"{tag}_in_viol"]
+    dfm = pd.DataFrame({"window_id": rows[:, 0], "Aligned_Cell_Num_Old": rows[:, 1], "Ref_Cell_Num_Old": rows[:, 2],
+                        "X": np.arange(len(rows), dtype=float), "Y": 0.0,
+                        "filtered_violation": [None if np.isnan(v) else bool(v) for v in viol]})
+    return [part.copy() for part in np.split(dfm, g[f"{tag}_cuts"])]
+
+
+def check_merge_dedup_golden(dedup):
+    """The reference's own output on tables built to show which duplicate of every (aligned, ref) pair survives its
+    de-duplication (tests/golden/merge_dedup.npz, tools/gen_golden.py mergededup): X names the surviving input row."""
     from same_amd.merge import merge_window_matches_unique_ref
+
+    g = load_golden("merge_dedup")
+    for tag in ("a", "b"):
+        res = merge_window_matches_unique_ref(_dedup_frames(g, tag), _dedup=dedup)
+        assert np.array_equal(res["X"].to_numpy().astype(np.int64), g[f"{tag}_out_rows"]), tag
+        assert np.array_equal(res[["window_id", "Aligned_Cell_Num_Old", "Ref_Cell_Num_Old"]].to_numpy(dtype=np.int64), g[f"{tag}_out"])
+        assert np.array_equal(res["filtered_violation"].to_numpy().astype(np.uint8), g[f"{tag}_out_viol"])
+
+
+def random_dedup_tables(rng, n, n_pairs, n_win):
+    a = rng.integers(0, max(1, int(np.sqrt(n_pairs)) * 2), n).astype(np.int32)
+    r = rng.integers(0, max(1, int(np.sqrt(n_pairs)) * 2), n).astype(np.int32)
+    return (rng.random(n) < 0.35), rng.integers(0, n_win, n).astype(np.int32), a, r
+
+
+def test_merge_dedup_oracle_is_the_reference_step(oracle):
+    """The oracle's de-duplication (oracle/same_oracle.c: orc_merge_dedup) against the reference's own outputs and against the
+    literal pandas calls of src/helpers.py:748-753 on random tables with heavy duplication and ties."""
+    check_merge_dedup_golden(oracle.merge_dedup)
+    rng = np.random.default_rng(8)
+    for n, n_pairs, n_win in ((0, 1, 1), (1, 1, 1), (63, 10, 2), (64, 900, 5), (65, 4, 1), (5000, 300, 12), (20000, 20000, 40)):
+        v, w, a, r = random_dedup_tables(rng, n, n_pairs, n_win)
+        assert np.array_equal(oracle.merge_dedup(v, w, a, r), oracle.merge_dedup_pandas(v, w, a, r)), n
+
+
+def test_merge_window_matches_unique_ref(oracle):
+    from same_amd.merge import merge_window_matches_unique_ref as merge_on_gpu
+
+    def merge_window_matches_unique_ref(lst, **kw):    # host logic of the merge, de-duplication by the oracle (no GPU here)
+        return merge_on_gpu(lst, _dedup=oracle.merge_dedup, **kw)
 
     g = load_golden("unpack_merge")
     res = merge_window_matches_unique_ref(_merge_input())
@@ -172,6 +212,11 @@ def test_merge_window_matches_unique_ref():
     d = pd.DataFrame({"window_id": [3, 1, 2], "Aligned_Cell_Num_Old": [7, 7, 7], "Ref_Cell_Num_Old": [9, 9, 9], "X": 0.0, "Y": 0.0,
                       "filtered_violation": [False, True, False]})
     assert merge_window_matches_unique_ref([d])["window_id"].tolist() == [2]
+    # ids of any hashable kind (strings) and window ids that are not small non-negative ints
+    d2 = pd.DataFrame({"window_id": [-5, 7.5, -5, 2 ** 40], "Aligned_Cell_Num_Old": ["c1", "c1", "c2", "c3"],
+                       "Ref_Cell_Num_Old": ["r9", "r9", "r9", "r1"], "X": 0.0, "Y": 0.0, "filtered_violation": [True, True, False, False]})
+    got = merge_window_matches_unique_ref([d2])
+    assert len(got) == 2 and set(got["Ref_Cell_Num_Old"]) == {"r9", "r1"}
 
 
 def test_priority_filter_closed_form_equals_the_reference_walk():
@@ -240,3 +285,36 @@ def test_gpu_telemetry_reads_a_hwmon_tree(tmp_path):
     assert s["temperature_crit_c"] == {"edge": None, "junction": 100.0, "mem": 115.0}
     none = GpuTelemetry("0000:06:00.0", sysfs_root=str(tmp_path))
     assert not none.available() and none.sample()[1:4] == (None, None, None)
+
+
+@pytest.mark.gpu
+def test_merge_dedup_on_device(oracle):
+    """f3 on the GPU (csrc/merge.hip through ops.merge_dedup): (i) the whole merge, default path, against the reference's own
+    outputs -- both the disjoint-pair tables that expose which duplicate survives and the small unpack_merge table; (ii) the
+    de-duplication against the oracle, bit for bit, from the empty table through sizes around the wave (64), the LDS sort
+    block (2048) and the first global bitonic stages, to 300k rows of window tables with every pair proposed several times."""
+    from same_amd import ops
+    from same_amd.merge import merge_window_matches_unique_ref
+
+    check_merge_dedup_golden(None)                      # None = the product's default: ops.merge_dedup on the GPU
+    g = load_golden("unpack_merge")
+    res = merge_window_matches_unique_ref(_merge_input())
+    assert np.array_equal(res[["window_id", "Aligned_Cell_Num_Old", "Ref_Cell_Num_Old"]].to_numpy(dtype=np.int64), g["merge_rows"])
+    assert np.array_equal(res["filtered_violation"].to_numpy().astype(np.uint8), g["merge_viol"])
+    rng = np.random.default_rng(9)
+    for n, n_pairs, n_win in ((0, 1, 1), (1, 1, 1), (2, 1, 1), (63, 10, 2), (64, 900, 5), (65, 4, 1), (2047, 50, 3), (2048, 2048, 7),
+                              (2049, 10, 1), (4096, 100, 9), (5000, 300, 12), (70000, 70000, 100), (300000, 40000, 400)):
+        v, w, a, r = random_dedup_tables(rng, n, n_pairs, n_win)
+        got = ops.merge_dedup(v, w, a, r)
+        assert got.dtype == np.int32 and np.array_equal(got, oracle.merge_dedup(v, w, a, r)), n
+    # all rows one pair; all rows distinct pairs; every row violating; window ids at the top of the int32 range
+    n = 3000
+    one = ops.merge_dedup(rng.random(n) < 0.5, rng.integers(0, 4, n), np.zeros(n, np.int32), np.zeros(n, np.int32))
+    assert len(one) == 1
+    distinct = ops.merge_dedup(np.ones(n, bool), np.full(n, 2 ** 31 - 1), np.arange(n), np.arange(n)[::-1].copy())
+    assert np.array_equal(distinct, np.arange(n))
+    from same_amd._lib import SameHipError
+    with pytest.raises(SameHipError):
+        ops.merge_dedup([False], [-1], [0], [0])
+    with pytest.raises(ValueError):
+        ops.merge_dedup([False, True], [0], [0], [0])

@@ -496,6 +496,35 @@ def metacell_case():
     np.savez_compressed(os.path.join(OUT, 'metacell.npz'), **out)
 
 
+def merge_dedup_case():
+    """merge_window_matches_unique_ref (src/helpers.py:692-815) on tables that show WHICH duplicate its de-duplication keeps
+    (:745-753): every (aligned, ref) pair is disjoint from every other, so the matching keeps them all, and each is proposed
+    by 1-6 windows with varying violation flags (some missing) and window ids, ties included; X carries the input row number,
+    so the output names the surviving row of every pair."""
+    rng = np.random.default_rng(77)
+    out = {}
+    for tag, n_pairs, n_win in (('a', 800, 16), ('b', 60, 3)):
+        reps = rng.integers(1, 7, n_pairs)
+        a = np.repeat(np.arange(n_pairs) * 3 + 11, reps)
+        perm = rng.permutation(len(a))
+        a = a[perm]
+        dfm = pd.DataFrame({'window_id': rng.integers(0, n_win, len(a)), 'Aligned_Cell_Num_Old': a, 'Ref_Cell_Num_Old': 5000 + 2 * a,
+                            'X': np.arange(len(a), dtype=float), 'Y': 0.0,
+                            'filtered_violation': (rng.random(len(a)) < 0.4).astype(object)})
+        dfm.loc[rng.choice(len(a), len(a) // 25, replace=False), 'filtered_violation'] = np.nan
+        cuts = np.sort(rng.choice(np.arange(1, len(a)), 4, replace=False))
+        lst = [part.copy() for part in np.split(dfm, cuts)]        # the caller hands over several tables; order = concatenation order
+        res = ref.helpers.merge_window_matches_unique_ref(lst)
+        out[f'{tag}_in'] = np.column_stack((dfm['window_id'], dfm['Aligned_Cell_Num_Old'], dfm['Ref_Cell_Num_Old'])).astype(np.int64)
+        out[f'{tag}_in_viol'] = dfm['filtered_violation'].astype(float).to_numpy()          # NaN = missing
+        out[f'{tag}_cuts'] = cuts.astype(np.int64)
+        out[f'{tag}_out_rows'] = res['X'].to_numpy().astype(np.int64)                      # input row of every kept pair, output order
+        out[f'{tag}_out'] = res[['window_id', 'Aligned_Cell_Num_Old', 'Ref_Cell_Num_Old']].to_numpy(dtype=np.int64)
+        out[f'{tag}_out_viol'] = res['filtered_violation'].to_numpy().astype(np.uint8)
+        print(f"[merge/dedup {tag}] {len(dfm)} rows, {n_pairs} pairs -> {len(res)} kept")
+    np.savez_compressed(os.path.join(OUT, 'merge_dedup.npz'), **out)
+
+
 def unpack_merge_case():
     """unpack_metacell_matches (src/metacell_utils.py:564-766) and merge_window_matches_unique_ref (src/helpers.py:692-815)."""
     out = {}
@@ -988,6 +1017,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'unpack':
         unpack_merge_case()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'mergededup':
+        merge_dedup_case()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'eval':
         eval_case()
         return
@@ -1022,6 +1054,7 @@ def main():
     metacell_case()
     # (8) SURVEY 8(f3, f4)
     unpack_merge_case()
+    merge_dedup_case()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith('.npz')}
     print(json.dumps(sizes, indent=1))
 
