@@ -98,6 +98,9 @@ class MetaCell:
         return out
 
 
+_WELL_KNOWN_ID_COLUMNS = ("Cell_Num", "Cell_Num_Old", "cell_id", "Cell_ID", "ID", "id")   # never averaged (src/metacell_utils.py:334)
+
+
 def _filter_valid(coords, triangles, r_max, min_angle_deg, ctx):
     """filter_triangles (src/metacell_utils.py:262-293) without the alpha shape: rows of `triangles` that are valid."""
     if len(triangles) == 0:
@@ -144,13 +147,16 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
             print("Warning: alphashape not available, skipping alpha shape filtering")
             use_alpha_shape = False
 
-    required = [x_col, y_col, cell_type_col, original_idx_col]
-    missing = [c for c in required if c not in aligned_df.columns]
+    # input contract of src/metacell_utils.py:296-309 (messages are part of it: callers match on them)
+    have = set(aligned_df.columns)
+    missing = [c for c in (x_col, y_col, cell_type_col, original_idx_col) if c not in have]
     if missing:
         raise ValueError(f"Input dataframe missing required columns: {missing}")
     aligned_df = aligned_df.copy()
-    if aligned_df[original_idx_col].duplicated().any():
-        dups = aligned_df.loc[aligned_df[original_idx_col].duplicated(), original_idx_col].head(5).tolist()
+    original_ids_by_pos = aligned_df[original_idx_col].to_numpy()
+    repeated = pd.Index(original_ids_by_pos).duplicated()          # every occurrence after the first
+    if repeated.any():
+        dups = original_ids_by_pos[repeated][:5].tolist()
         raise ValueError(f"'{original_idx_col}' must be unique per original cell. Found duplicates (examples): {dups}")
 
     # Qhull calls are the bulk of a collapse (1.14 of 1.35 s at 100k cells, one per iteration plus two).  Two of them repeat a
@@ -176,19 +182,14 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
         if have is not None and have[0].shape == points.shape and np.array_equal(have[0], points):
             return have[1].result() if hasattr(have[1], "result") else have[1]
         return Delaunay(points).simplices
-    original_ids_by_pos = aligned_df[original_idx_col].to_numpy()
-    if original_delaunay_pos.size == 0:
-        original_delaunay = np.array([], dtype=original_ids_by_pos.dtype).reshape(0, 3)
-    else:
-        original_delaunay = original_ids_by_pos[original_delaunay_pos.astype(int)]
+    # pre-collapse triangles in ORIGINAL-id space (:326-331); an empty list keeps the id dtype
+    original_delaunay = (original_ids_by_pos[original_delaunay_pos.astype(int)] if original_delaunay_pos.size
+                         else np.empty((0, 3), dtype=original_ids_by_pos.dtype))
 
-    id_columns = ["Cell_Num", "Cell_Num_Old", "cell_id", "Cell_ID", "ID", "id"]
-    id_cols_present = [col for col in aligned_df.columns if col in id_columns]
-    if original_idx_col not in id_cols_present:
-        id_cols_present.append(original_idx_col)
-    if metacell_idx_col in aligned_df.columns and metacell_idx_col not in id_cols_present:
-        id_cols_present.append(metacell_idx_col)
-    other_cols = [c for c in aligned_df.columns if c not in [x_col, y_col, cell_type_col] + id_cols_present]
+    # columns that are averaged over a metacell's members = everything that is neither a coordinate, the cell type, nor an
+    # id: the well-known id names plus the two the caller named (:333-340), as a set difference in frame order
+    not_averaged = {x_col, y_col, cell_type_col, original_idx_col, metacell_idx_col, *_WELL_KNOWN_ID_COLUMNS}
+    other_cols = [c for c in aligned_df.columns if c not in not_averaged]
 
     # every cell starts as a metacell of size 1 (:331-348); members are ORIGINAL ids
     metacell_df = pd.DataFrame({x_col: aligned_df[x_col].to_numpy(), y_col: aligned_df[y_col].to_numpy(),
@@ -242,8 +243,8 @@ def greedy_triangle_collapse(aligned_df, max_metacell_size=3, max_iterations=100
         last_made = None
         if len(next_coords) >= 4:
             ready = (next_coords, qhull_pool.pool().submit(next_coords))
-        for col in metacell_df.columns:
-            if col in [x_col, y_col, cell_type_col, "size", "members", metacell_idx_col] + id_cols_present:
+        for col in other_cols:                 # the averaged / carried columns, in frame order
+            if col in ("size", "members"):     # an input column of that name is the metacell's own bookkeeping from here on
                 continue
             if pd.api.types.is_numeric_dtype(metacell_df[col]):
                 merged[col] = _mean_over_members(aligned_df[col].to_numpy(dtype=np.float64), groups)   # true mean over original cells

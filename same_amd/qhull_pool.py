@@ -21,25 +21,33 @@ import threading
 
 import numpy as np
 
+_MAGIC = 0x51484C4C   # "QHLL": first word of every reply, so stray bytes on the pipe are noticed instead of read as a length
+
 _WORKER = r"""
-import struct, sys
+import os, struct, sys
+# the protocol owns the ORIGINAL stdout; anything else that prints (a Qhull or BLAS banner, a warnings hook) lands on stderr
+proto = os.fdopen(os.dup(1), "wb")
+os.dup2(2, 1)
+sys.stdout = sys.stderr
 import numpy as np
 from scipy.spatial import Delaunay
-inp, out = sys.stdin.buffer, sys.stdout.buffer
+inp = sys.stdin.buffer
 while True:
-    head = inp.read(8)
-    if len(head) < 8:
+    head = inp.read(16)
+    if len(head) < 16:
         break
-    (n,) = struct.unpack("<q", head)
+    seq, n = struct.unpack("<qq", head)
     if n < 0:
         break
     buf = inp.read(16 * n)
+    if len(buf) < 16 * n:
+        break
     try:
         s = np.ascontiguousarray(Delaunay(np.frombuffer(buf, np.float64).reshape(n, 2)).simplices, dtype=np.int32)
-        out.write(struct.pack("<q", len(s)) + s.tobytes())
+        proto.write(struct.pack("<iqq", 0x51484C4C, seq, len(s)) + s.tobytes())
     except Exception:
-        out.write(struct.pack("<q", -1))     # the caller repeats the call in-process to raise the same error
-    out.flush()
+        proto.write(struct.pack("<iqq", 0x51484C4C, seq, -1))     # the caller repeats the call in-process to raise the same error
+    proto.flush()
 """
 
 
@@ -50,8 +58,8 @@ def _delaunay_here(points):
 
 
 class _Ticket:
-    def __init__(self, pool, worker, points):
-        self.pool, self.worker, self.points, self._value = pool, worker, points, None
+    def __init__(self, pool, worker, points, seq=0):
+        self.pool, self.worker, self.points, self._value, self.seq = pool, worker, points, None, seq
 
     def result(self):
         """The (Tr, 3) int32 simplices -- blocks until the helper has answered."""
@@ -66,6 +74,7 @@ class QhullPool:
         self.procs = []
         self.pending = {}            # worker index -> ticket whose answer has not been read yet
         self.next = 0
+        self.seq = 0                 # request number, echoed by the helper: an answer is only taken for the request it names
         self.lock = threading.Lock()
 
     def _spawn(self):
@@ -94,34 +103,58 @@ class QhullPool:
                 self.next += 1
             if w in self.pending:                       # one request in flight per helper: read the old answer first
                 old = self.pending.pop(w)
-                old._value = self._read(w, old)
-            t = _Ticket(self, w, pts)
+                try:
+                    old._value = self._read(w, old)
+                except Exception:                        # Qhull refused the OLD request's points: that ticket raises on its own result()
+                    old.worker = None
+            self.seq += 1
+            t = _Ticket(self, w, pts, self.seq)
             if self.procs[w].poll() is not None:        # the helper has died since its last request: start another
                 self.procs[w] = self._spawn()
             try:
                 p = self.procs[w]
-                p.stdin.write(struct.pack("<q", len(pts)) + pts.tobytes())
+                p.stdin.write(struct.pack("<qq", t.seq, len(pts)) + pts.tobytes())
                 p.stdin.flush()
                 self.pending[w] = t
             except (OSError, ValueError):
                 t.worker = None                          # helper is gone: this one is computed in-process on result()
             return t
 
-    def _read(self, w, ticket):
+    def _retire(self, w):
+        """Stop helper w (its stream can no longer be trusted, or it is gone) and put a fresh one in its place."""
         p = self.procs[w]
         try:
-            head = p.stdout.read(8)
-            if len(head) == 8:
-                (n,) = struct.unpack("<q", head)
-                if n >= 0:
+            p.kill()
+            p.wait(timeout=5)
+        except (OSError, subprocess.TimeoutExpired):
+            pass
+        for f in (p.stdin, p.stdout):
+            try:
+                f.close()
+            except (OSError, ValueError):
+                pass
+        self.procs[w] = self._spawn()
+
+    def _read(self, w, ticket):
+        """The answer to `ticket` from helper w.  Anything but a well-formed reply to exactly this request -- wrong magic, another
+        request's number, an implausible count, a short read -- means the stream is out of step: the helper is replaced before it
+        is used again (a later request must never read leftover bytes as simplices) and the call is made here instead."""
+        p = self.procs[w]
+        n = None
+        try:
+            head = p.stdout.read(20)
+            if len(head) == 20:
+                magic, seq, n = struct.unpack("<iqq", head)
+                if magic == _MAGIC and seq == ticket.seq and 0 <= n <= 4 * len(ticket.points) + 16:   # a planar triangulation has < 2n triangles
                     raw = p.stdout.read(12 * n)
                     if len(raw) == 12 * n:
                         return np.frombuffer(raw, np.int32).reshape(n, 3).copy()
+                elif magic == _MAGIC and seq == ticket.seq and n == -1:
+                    return _delaunay_here(ticket.points)     # Qhull refused these points: the same call here raises the same error
         except OSError:
             pass
-        if p.poll() is not None:                         # died: replace it for later requests
-            self.procs[w] = self._spawn()
-        return _delaunay_here(ticket.points)             # error in the helper (or a dead helper): same call, here
+        self._retire(w)
+        return _delaunay_here(ticket.points)
 
     def _collect(self, ticket):
         if ticket.worker is None:
@@ -136,7 +169,7 @@ class QhullPool:
         with self.lock:
             for p in self.procs:
                 try:
-                    p.stdin.write(struct.pack("<q", -1))
+                    p.stdin.write(struct.pack("<qq", 0, -1))
                     p.stdin.flush()
                     p.stdin.close()
                 except (OSError, ValueError):

@@ -50,6 +50,50 @@ def test_a_dead_helper_is_replaced(pool):
     assert all(p.poll() is None for p in pool.procs)
 
 
+def test_a_reply_stream_out_of_step_retires_the_helper(pool):
+    """Stray bytes where a reply should be (wrong magic, another request's number, an implausible count): the answer is
+    computed in-process, the helper is REPLACED before it is used again, and later requests are right."""
+    import io
+    import struct
+    from same_amd import qhull_pool
+
+    pts = np.random.default_rng(4).uniform(0, 10, (300, 2))
+    want = Delaunay(pts).simplices
+    assert np.array_equal(pool.submit(pts).result(), want)
+    for junk in (b"Qhull banner: hello\n" * 3,                                            # text on the pipe
+                 struct.pack("<iqq", qhull_pool._MAGIC, 999_999, 5) + b"\0" * 60,           # an answer to some other request
+                 struct.pack("<iqq", qhull_pool._MAGIC, pool.seq + 1, 10 ** 9)):            # a count no triangulation of 300 points has
+        victim = pool.procs[0]
+        real = victim.stdout
+        victim.stdout = io.BytesIO(junk)
+        t = pool.submit(pts)
+        assert t.worker == 0
+        assert np.array_equal(t.result(), want)
+        assert pool.procs[0] is not victim and victim.poll() is not None      # retired, not reused
+        real.close()
+        assert np.array_equal(pool.submit(pts).result(), want)               # the replacement answers correctly
+
+
+def test_helper_output_on_stdout_does_not_reach_the_protocol():
+    """The worker keeps the protocol on a private copy of its stdout and points fd 1 at stderr: a library that prints there
+    cannot shift the framing."""
+    import struct
+    import subprocess
+    import sys
+    from same_amd import qhull_pool
+
+    noisy = qhull_pool._WORKER.replace("inp = sys.stdin.buffer", "inp = sys.stdin.buffer\nprint('banner on stdout')\nos.write(1, b'raw bytes on fd 1')")
+    p = subprocess.Popen([sys.executable, "-c", noisy], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    pts = np.random.default_rng(5).uniform(0, 10, (50, 2))
+    p.stdin.write(struct.pack("<qq", 7, len(pts)) + pts.tobytes() + struct.pack("<qq", 0, -1))
+    p.stdin.flush()
+    out, err = p.communicate(timeout=60)
+    magic, seq, n = struct.unpack("<iqq", out[:20])
+    assert magic == qhull_pool._MAGIC and seq == 7 and len(out) == 20 + 12 * n
+    assert np.array_equal(np.frombuffer(out[20:], np.int32).reshape(n, 3), Delaunay(pts).simplices)
+    assert b"banner on stdout" in err and b"raw bytes on fd 1" in err
+
+
 def test_no_helper_mode_and_default_size(monkeypatch):
     from same_amd import qhull_pool
 
