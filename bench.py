@@ -971,7 +971,179 @@ def run_rank(args):
 
 
 def run_cfg5(args, group, json_fd):
-    raise SystemExit("--workload cfg5 is not available in this build")
+    """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
+    round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
+    the per-window match tables exchanged ONCE over the host group and merged (src/helpers.py:692-815, de-duplication on the
+    GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
+    (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
+    One step = the whole plan once (every rank its share) + the exchange + the merge.  value = dense-equivalent cell pairs
+    (sum over windows of aligned x ref cells in the window) per second; `windows_per_s` per rank and the share of the step
+    spent outside libsame_hip calls (`host_glue_share`) come from the stage markers of same_amd/_trace.py."""
+    import numpy as np
+    import pandas as pd
+
+    import same_amd
+    from same_amd import _lib, _trace, ops, synth
+    from same_amd.merge import merge_window_matches_unique_ref
+    from same_amd.windows import assign_windows, window_plan
+
+    _trace.enable(True)
+    _lib.instrument()
+    local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
+    os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
+    n, T = int(args.cfg5_cells), 8
+    ref = synth.make_cells(n, T, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    r_df["Cell_Num_Old"], m_df["Cell_Num_Old"] = np.arange(len(r_df)), np.arange(len(m_df))
+    cols = synth.type_columns(T)
+    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
+    plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
+    mine = assign_windows(plan, group.world)[group.rank]
+    my_plan = [plan[q] for q in mine]
+    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)}")
+
+    def run_window(w, prep):
+        """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
+        a_df, rr_df = prep.aligned_df, prep.ref_df
+        ch, _un = same_amd.compute_mip_start_pairs(valid_pairs=prep.valid_pairs, costs=prep.costs_array, n_aligned=prep.n_aligned, n_ref=prep.n_ref,
+                                                   aligned_sizes=a_df["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1,
+                                                   init_method="greedy", verbose=False)
+        ai = np.array([c[0] for c in ch], dtype=np.int64)
+        ri = np.array([c[1] for c in ch], dtype=np.int64)
+        x = np.zeros(len(prep.valid_pairs))
+        x[[c[2] for c in ch]] = 1.0
+        rxy = rr_df[["X", "Y"]].to_numpy()
+        sw = same_amd.LazyOrientationSweep(prep.valid_pairs, prep.triangles_array, prep.signs_array, rxy, prep.n_aligned)
+        checked, viol, _ = sw.sweep(x)
+        sw.bound.close()
+        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms:
+        # the nested report dicts of the Python boundary are not built per window here
+        match = np.full(prep.n_aligned, -1, np.int32)
+        match[ai] = ri
+        axy = a_df[["X", "Y"]].to_numpy()
+        _edge, _tflag, pflag, counts = ops.xyorder_sweep(axy, rxy, prep.triangles_array, match)
+        _before, _after, _m3, flipped = ops.area_flip(axy, rxy, prep.triangles_array, match)
+        tab = pd.DataFrame({"Aligned_Cell_Num_Old": a_df["Cell_Num_Old"].to_numpy()[ai], "Ref_Cell_Num_Old": rr_df["Cell_Num_Old"].to_numpy()[ri],
+                            "X": axy[ai, 0], "Y": axy[ai, 1], "filtered_violation": pflag[ai].astype(bool)})
+        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
+        tab = tab[(tab["X"] >= tx0) & (tab["X"] < tx1) & (tab["Y"] >= ty0) & (tab["Y"] < ty1)].copy()
+        tab["window_id"] = w["window_id"]
+        return tab, {"pairs": len(prep.valid_pairs), "triangles": len(prep.triangles_array), "checked": int(checked), "flipped": len(viol),
+                     "xy_violations": int(counts[1]), "area_flips": int(np.count_nonzero(flipped))}
+
+    def one_pass(windows):
+        tabs, stats = [], []
+        for w, prep in same_amd.iter_prepared_windows(r_df, m_df, cols, windows, optim_params=op):
+            if isinstance(prep, Exception):       # a window whose prune leaves no pairs (src/same.py:1003)
+                continue
+            t, st = run_window(w, prep)
+            tabs.append(t)
+            stats.append(st)
+        return tabs, stats
+
+    def step():
+        tabs, stats = one_pass(my_plan)
+        every = group.allgather_object(tabs)                             # the ONE exchange: small frames, host channel
+        merged = merge_window_matches_unique_ref([t for part in every for t in part if len(t)])
+        return merged, stats
+
+    for _ in range(args.warmup):
+        one_pass(my_plan[: max(1, min(2, len(my_plan)))])                # scratch slots, Qhull helpers, first-launch costs
+    group.barrier()
+    _trace.reset()
+    t0 = time.perf_counter()
+    merged = stats = None
+    for _ in range(args.steps):
+        merged, stats = step()
+    group.barrier()
+    wall_here = time.perf_counter() - t0
+    dt = group.max(wall_here)
+    rep = _trace.report()
+    in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:"))
+    stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
+    lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
+    mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * args.steps / wall_here,
+                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / wall_here,
+                "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
+                "triangles": int(sum(s["triangles"] for s in stats))}
+    every = group.allgather_object(mine_rec)
+    # N=1: two windows through the oracle as the CPU baseline and as the parity check of what the GPU produced for them
+    cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
+    if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
+        from scipy.spatial import Delaunay
+
+        from oracle import same_oracle as orc
+
+        sample = [w for w in my_plan if w["n_mov"] > 1000][:2] or my_plan[:1]
+        c0 = time.perf_counter()
+        done_pairs = 0
+        for w in sample:
+            x0, x1, y0, y1 = w["box"]
+            rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
+            na, nr, pairs = orc.find_knn_within_radius(ms, rs, 25, 8)
+            pairs = np.asarray(pairs, dtype=np.int64)
+            axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
+            c32 = orc.pair_cost_arrays(na[cols].to_numpy(), nr[cols].to_numpy(), axy, rxy, pairs, 1.0, dtype=np.float32)
+            tri = np.asarray(orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
+                                                            min_angle_deg=15), dtype=np.int64).reshape(-1, 3)
+            signs = orc.source_signs(na, tri)
+            kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=c32.astype(np.float64), n_aligned=len(na), n_ref=len(nr),
+                      aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
+            och, _ = orc.compute_mip_start_pairs(**kw)
+            xo = np.zeros(len(pairs))
+            xo[[c[2] for c in och]] = 1.0
+            ochecked, oviol = orc.lazy_orientation_sweep(xo, pairs, tri, signs, rxy, len(na))
+            done_pairs += w["n_mov"] * w["n_ref"]
+            # the same window on the GPU, compared
+            prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
+            ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs) and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
+                  and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri) and list(prep.source_signs) == list(signs))
+            gch, _ = same_amd.compute_mip_start_pairs(**dict(kw, valid_pairs=prep.valid_pairs, costs=prep.costs))
+            sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
+            gchecked, gviol, _ = sw.sweep(xo)
+            sw.bound.close()
+            ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
+            if not ok:
+                raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
+        t_cpu = time.perf_counter() - c0
+        parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
+                  "equal the oracle bit-for-bit")
+        cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+               "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
+                         f"through oracle/same_oracle.{{c,py}} in {t_cpu:.1f} s, 1 thread; includes the GPU re-run of the same windows for the comparison",
+               "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on this box"}
+    if group.rank == 0:
+        total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
+        es, k = 4, 8
+        P, Tr = sum(r["pairs"] for r in every), sum(r["triangles"] for r in every)
+        touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)   # SURVEY 8d per-unit figures
+        lib_s = max(r["in_library_s"] for r in every) / args.steps
+        out = {"metric": baseline_metric(), "value": total_pairs * args.steps / dt, "unit": "cell-pairs/s", "n_gpus": group.world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
+                                      f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
+                                      "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
+                          "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no data-path collective; one host-channel exchange of the match tables"},
+               "windows_per_s": len(plan) * args.steps / dt,
+               "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
+                            "host_glue_share": [r["host_glue_share"] for r in every], "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
+               "host_glue_share": mine_rec["host_glue_share"],
+               "host_glue_share_means": "1 - (wall time inside libsame_hip calls) / (wall time of the timed loop), rank 0: Python / pandas / scipy glue, "
+                                        "waiting for the Qhull helpers and the table exchange included",
+               "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
+               "merged_matches": int(len(merged)),
+               "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (pair_cost_kernel<float> is the largest)",
+                            "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "algorithmic_bytes_per_step": touched,
+                            "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
+                                    "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by launch latency and host "
+                                    "glue, not by HBM -- see host_glue_share"},
+               "cpu_baseline": cpu, "parity_spot_check": parity}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    group.barrier()
+    group.close()
 
 
 def main():

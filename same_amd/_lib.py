@@ -148,6 +148,38 @@ def load():
     return _lib
 
 
+_instrumented = False
+
+
+def instrument():
+    """Account the wall time of every libsame_hip call to `_trace` under "lib:<entry point>" (host-buffer entry points are
+    synchronous, so this is device + copy + driver time; what is left of a stage's wall time is Python / pandas / scipy glue).
+    bench.py --workload cfg5 uses it for the host-glue share; off unless called."""
+    global _instrumented
+    import time
+
+    from . import _trace
+
+    L = load()
+    with _lib_lock:
+        if _instrumented:
+            return
+        for name in _PROTOTYPES:
+            if name in ("same_strerror", "same_last_error", "same_abi_version"):
+                continue
+            fn = getattr(L, name)
+
+            def timed(*a, _fn=fn, _key="lib:" + name):
+                t0 = time.perf_counter()
+                try:
+                    return _fn(*a)
+                finally:
+                    _trace.add(_key, time.perf_counter() - t0)
+
+            setattr(L, name, timed)     # instance attribute: shadows the ctypes function pointer for every later lookup
+        _instrumented = True
+
+
 def device_count():
     n = c_int(0)
     load().same_device_count(ctypes.byref(n))

@@ -61,6 +61,13 @@ def stage(name):
             _totals[name] = (n + 1, tot + dt)
 
 
+def add(name, seconds):
+    """Account `seconds` to `name` (used by _lib.instrument() for time spent inside libsame_hip calls)."""
+    with _lock:
+        n, tot = _totals.get(name, (0, 0.0))
+        _totals[name] = (n + 1, tot + seconds)
+
+
 def report():
     """{stage: (calls, seconds)} accumulated since the last reset()."""
     with _lock:

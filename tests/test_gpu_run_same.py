@@ -350,6 +350,38 @@ def test_bench_two_ranks_on_one_gpu_carry_the_diagnosis():
     assert out["per_rank"]["device_by_rank"] == [0, 0]
 
 
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_cfg5_windows_line(world):
+    """`bench.py --workload cfg5` (BASELINE cfg 5 at reduced size): whole windows dealt to the ranks, fp32 costs, all sweeps per
+    window, tables exchanged once and merged; the line reports windows/s per rank and the host-glue share, and at N=1 checks
+    two windows against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg5", "--cfg5-cells", "60000", "--steps", "1", "--warmup", "1", "--gpus", str(world)]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["metric"] == json.load(open(os.path.join(root, "BASELINE.json"), encoding="utf-8"))["metric"]
+    assert out["n_gpus"] == world and out["dtype"] == "f32" and out["value"] > 0 and out["config"]["workload"].startswith("cfg5: 60000-cell section")
+    pr = out["per_rank"]
+    assert len(pr["windows"]) == world and sum(pr["windows"]) >= 4 and all(v > 0 for v in pr["windows_per_s"])
+    assert all(0.0 <= v < 1.0 for v in pr["host_glue_share"]) and out["windows_per_s"] > 0 and out["merged_matches"] > 1000
+    assert any(k.startswith("prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    if world == 1:
+        assert out["cpu_baseline"]["kind"] == "port" and "equal the oracle bit-for-bit" in out["parity_spot_check"]
+    else:
+        assert out["cpu_baseline"] is None
+
+
 def test_bench_step_with_the_fixed_point_dense_build():
     """`bench.py --dense q32`: the step's dense build is the opt-in fixed-point kernel; the line says so (dtype, kernel name, note)
     and its own check -- twin-equal and within 1e-6 relative of the exact costs on every sampled pair -- passed."""
