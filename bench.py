@@ -1006,21 +1006,21 @@ def run_cfg5(args, group, json_fd):
     def run_window(w, prep):
         """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
         a_df, rr_df = prep.aligned_df, prep.ref_df
-        ch, _un = same_amd.compute_mip_start_pairs(valid_pairs=prep.valid_pairs, costs=prep.costs_array, n_aligned=prep.n_aligned, n_ref=prep.n_ref,
-                                                   aligned_sizes=a_df["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1,
-                                                   init_method="greedy", verbose=False)
-        ai = np.array([c[0] for c in ch], dtype=np.int64)
-        ri = np.array([c[1] for c in ch], dtype=np.int64)
-        x = np.zeros(len(prep.valid_pairs))
-        x[[c[2] for c in ch]] = 1.0
+        pairs = np.asarray(prep.valid_pairs, dtype=np.int32).reshape(-1, 2)
+        # greedy MIP start (src/init_helpers.py:104-133) in its flat device form: per-row minimum, rows that beat their
+        # no-match penalty, the scan's matching -> one pair index per aligned row
+        wants = ops.pair_rowmin(pairs, prep.costs_array, prep.n_aligned) < 100.0 * a_df["size"].to_numpy(dtype=float)
+        pair_of_row, _rounds = ops.greedy_match(pairs, prep.costs_array, prep.n_aligned, prep.n_ref, wants)
+        ai = np.flatnonzero(pair_of_row >= 0)
+        ri = pairs[pair_of_row[ai], 1].astype(np.int64)
         rxy = rr_df[["X", "Y"]].to_numpy()
-        sw = same_amd.LazyOrientationSweep(prep.valid_pairs, prep.triangles_array, prep.signs_array, rxy, prep.n_aligned)
-        checked, viol, _ = sw.sweep(x)
-        sw.bound.close()
-        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms:
-        # the nested report dicts of the Python boundary are not built per window here
         match = np.full(prep.n_aligned, -1, np.int32)
         match[ai] = ri
+        sw = ops.BoundSweep(prep.triangles_array, prep.signs_array, rxy, prep.n_aligned)      # the lazy-constraint body (src/same.py:645-669)
+        checked, viol = sw.sweep_match(match)
+        sw.close()
+        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms:
+        # the nested report dicts of the Python boundary are not built per window here
         axy = a_df[["X", "Y"]].to_numpy()
         _edge, _tflag, pflag, counts = ops.xyorder_sweep(axy, rxy, prep.triangles_array, match)
         _before, _after, _m3, flipped = ops.area_flip(axy, rxy, prep.triangles_array, match)
@@ -1044,8 +1044,9 @@ def run_cfg5(args, group, json_fd):
 
     def step():
         tabs, stats = one_pass(my_plan)
-        every = group.allgather_object(tabs)                             # the ONE exchange: small frames, host channel
-        merged = merge_window_matches_unique_ref([t for part in every for t in part if len(t)])
+        mine_tab = pd.concat(tabs, ignore_index=True) if tabs else pd.DataFrame()
+        every = group.allgather_object(mine_tab)                         # the ONE exchange: one frame per rank, host channel
+        merged = merge_window_matches_unique_ref([t for t in every if len(t)])
         return merged, stats
 
     for _ in range(args.warmup):

@@ -108,25 +108,28 @@ struct Timer {
         if (hipGetLastError() != hipSuccess) { rc = SAME_EIO; return 0.0; }
         return (double)passes * (double)n_chunks * (double)CHUNK / best * 1e-6;
     }
-    // GB/s of writing `span` bytes at a and `span` bytes at b at once, 4 GiB in all per launch; best of two after one untimed (the two levels are ~20 % apart, the readings within ~5 %)
-    double rate(char *a, char *b, uint64_t span) {
+    // GB/s of writing `span` bytes at a and `span` bytes at b at once, 4 GiB in all per launch.  `warm`: one untimed launch
+    // first (the first store into a freshly mapped chunk pays for its page tables); then `timed` launches, best of them
+    // (the two levels are ~20 % apart, the readings within ~5 %; noise only ever lowers a rate, and is_fast() reads again
+    // when a rate lands between the levels)
+    double rate(char *a, char *b, uint64_t span, bool warm = true, int timed = 1) {
         const unsigned passes = (unsigned)(2 * CHUNK / span);
         const unsigned per_pass = (unsigned)P_TILES * (unsigned)(span / 4 / P_ROW / P_RPB);
         const unsigned grid = 8u * per_pass * passes;
         float best = 1e30f;
-        for (int r = 0; r < 3; ++r) {
+        for (int r = warm ? -1 : 0; r < timed; ++r) {
             if (hipEventRecord(ev0, ctx->stream) != hipSuccess) { rc = SAME_EIO; return 0.0; }
             hipLaunchKernelGGL(spread_pair_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, span, per_pass);
             float ms = 0.f;
             if (hipEventRecord(ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ev1) != hipSuccess ||
                 hipEventElapsedTime(&ms, ev0, ev1) != hipSuccess) { rc = SAME_EIO; return 0.0; }
-            if (r && ms < best) best = ms;
+            if (r >= 0 && ms < best) best = ms;
         }
         if (hipGetLastError() != hipSuccess) { rc = SAME_EIO; return 0.0; }
         return 4.0 * (double)CHUNK / best * 1e-6;
     }
-    double halves(char *a) { return rate(a, a + CHUNK / 2, CHUNK / 2); }   // a chunk against itself: the same-region level
-    double pair(char *a, char *b) { return rate(a, b, CHUNK); }
+    double halves(char *a) { return rate(a, a + CHUNK / 2, CHUNK / 2, true, 1); }   // a new chunk against itself: the same-region level
+    double pair(char *a, char *b) { return rate(a, b, CHUNK, false, 1); }           // both chunks have been written by their halves() already
 };
 
 struct Chunk {
@@ -255,7 +258,7 @@ static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_
     auto is_fast = [&](double g, char *a, char *b, uint64_t span) {
         const double fast_above = slow * LEVEL_RATIO;
         const double first = g;
-        if (g < fast_above && g > slow * 1.04) g = std::max(g, tm.rate(a, b, span));
+        if (g < fast_above && g > slow * 1.04) g = std::max(g, tm.rate(a, b, span, false, 2));   // read again, best of two
         if (debug) fprintf(stderr, "[spread] %s rate %.0f%s vs level %.0f -> %s\n", span == CHUNK ? "pair" : "halves", first,
                            g != first ? (" (again: " + std::to_string((int)g) + ")").c_str() : "", slow, g >= fast_above ? "fast" : "slow");
         return g >= fast_above;

@@ -67,6 +67,10 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
     n_a, n_r = len(a_uniques), int(r_codes.max()) + 1 if len(r_codes) else 0
     graph = csr_matrix((np.ones(len(a_codes), np.int8), (a_codes, r_codes)), shape=(n_a, n_r))
     match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref index matched to each aligned node, -1 = none
-    row_of_edge = {(a, r): i for i, (a, r) in enumerate(zip(a_codes.tolist(), r_codes.tolist()))}
-    selected = [row_of_edge[(a, int(r))] for a, r in enumerate(match_r.tolist()) if r >= 0]   # aligned ids ascending (:799-808)
+    # the frame row of every matched (aligned, ref) edge, aligned ids ascending (:799-808).  Edges are unique after the
+    # de-duplication, so a sorted edge key finds the row without a Python dict over a table of 10^6 rows
+    a_sel = np.flatnonzero(match_r >= 0)
+    edge_key = a_codes.astype(np.int64) * max(n_r, 1) + r_codes
+    order = np.argsort(edge_key, kind="stable")
+    selected = order[np.searchsorted(edge_key[order], a_sel.astype(np.int64) * max(n_r, 1) + match_r[a_sel])]
     return merged_df.iloc[selected].copy().reset_index(drop=True)

@@ -283,6 +283,8 @@ class HostGroup:
         arrays and pandas frames (the per-window match tables), as JSON + .npy bytes -- no pickle, so nothing a peer sends
         can run code here.  The connections are loopback-only and admitted with the job's token, which sits in a 0600 file
         of a 0700 directory whose ownership every rank checks."""
+        if self.world == 1:
+            return [obj]
         return [_dec(json.loads(p.decode())) for p in self.allgather_bytes(json.dumps(_enc(obj)).encode())]
 
     def close(self):
