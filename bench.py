@@ -973,6 +973,7 @@ def run_rank(args):
 def run_cfg5(args, group, json_fd):
     """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
     round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
+    on the column pipeline (same_amd.windows.iter_window_arrays: no DataFrame per window),
     the per-window match tables exchanged ONCE over the host group and merged (src/helpers.py:692-815, de-duplication on the
     GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
     (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
@@ -985,7 +986,7 @@ def run_cfg5(args, group, json_fd):
     import same_amd
     from same_amd import _lib, _trace, ops, synth
     from same_amd.merge import merge_window_matches_unique_ref
-    from same_amd.windows import assign_windows, window_plan
+    from same_amd.windows import Section, assign_windows, iter_window_arrays, window_plan
 
     _trace.enable(True)
     _lib.instrument()
@@ -1003,50 +1004,53 @@ def run_cfg5(args, group, json_fd):
     my_plan = [plan[q] for q in mine]
     note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)}")
 
-    def run_window(w, prep):
+    ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
+    ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
+
+    def run_window(wa):
         """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
-        a_df, rr_df = prep.aligned_df, prep.ref_df
-        pairs = np.asarray(prep.valid_pairs, dtype=np.int32).reshape(-1, 2)
+        w, pairs = wa.window, wa.pairs.astype(np.int32)
         # greedy MIP start (src/init_helpers.py:104-133) in its flat device form: per-row minimum, rows that beat their
         # no-match penalty, the scan's matching -> one pair index per aligned row
-        wants = ops.pair_rowmin(pairs, prep.costs_array, prep.n_aligned) < 100.0 * a_df["size"].to_numpy(dtype=float)
-        pair_of_row, _rounds = ops.greedy_match(pairs, prep.costs_array, prep.n_aligned, prep.n_ref, wants)
+        wants = ops.pair_rowmin(pairs, wa.costs, wa.n_aligned) < 100.0 * wa.size.astype(float)
+        pair_of_row, _rounds = ops.greedy_match(pairs, wa.costs, wa.n_aligned, wa.n_ref, wants)
         ai = np.flatnonzero(pair_of_row >= 0)
         ri = pairs[pair_of_row[ai], 1].astype(np.int64)
-        rxy = rr_df[["X", "Y"]].to_numpy()
-        match = np.full(prep.n_aligned, -1, np.int32)
+        match = np.full(wa.n_aligned, -1, np.int32)
         match[ai] = ri
-        sw = ops.BoundSweep(prep.triangles_array, prep.signs_array, rxy, prep.n_aligned)      # the lazy-constraint body (src/same.py:645-669)
+        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned)      # the lazy-constraint body (src/same.py:645-669)
         checked, viol = sw.sweep_match(match)
         sw.close()
-        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms:
-        # the nested report dicts of the Python boundary are not built per window here
-        axy = a_df[["X", "Y"]].to_numpy()
-        _edge, _tflag, pflag, counts = ops.xyorder_sweep(axy, rxy, prep.triangles_array, match)
-        _before, _after, _m3, flipped = ops.area_flip(axy, rxy, prep.triangles_array, match)
-        tab = pd.DataFrame({"Aligned_Cell_Num_Old": a_df["Cell_Num_Old"].to_numpy()[ai], "Ref_Cell_Num_Old": rr_df["Cell_Num_Old"].to_numpy()[ri],
-                            "X": axy[ai, 0], "Y": axy[ai, 1], "filtered_violation": pflag[ai].astype(bool)})
+        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms
+        _edge, _tflag, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match)
+        _before, _after, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match)
+        x, y = wa.axy[ai, 0], wa.axy[ai, 1]
         tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
-        tab = tab[(tab["X"] >= tx0) & (tab["X"] < tx1) & (tab["Y"] >= ty0) & (tab["Y"] < ty1)].copy()
-        tab["window_id"] = w["window_id"]
-        return tab, {"pairs": len(prep.valid_pairs), "triangles": len(prep.triangles_array), "checked": int(checked), "flipped": len(viol),
+        c = np.flatnonzero((x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
+        tab = {"Aligned_Cell_Num_Old": mov_ids[wa.rows_m[ai[c]]], "Ref_Cell_Num_Old": ref_ids[wa.rows_r[ri[c]]], "X": x[c], "Y": y[c],
+               "filtered_violation": pflag[ai[c]].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
+        return tab, {"pairs": len(pairs), "triangles": len(wa.triangles), "checked": int(checked), "flipped": len(viol),
                      "xy_violations": int(counts[1]), "area_flips": int(np.count_nonzero(flipped))}
 
     def one_pass(windows):
         tabs, stats = [], []
-        for w, prep in same_amd.iter_prepared_windows(r_df, m_df, cols, windows, optim_params=op):
-            if isinstance(prep, Exception):       # a window whose prune leaves no pairs (src/same.py:1003)
+        for wa in iter_window_arrays(ref_sec, mov_sec, windows, radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
+                                     ignore_same_type_triangles=True, cost_dtype=np.float32):
+            if wa.error is not None:              # a window whose prune leaves no pairs (src/same.py:1003)
                 continue
-            t, st = run_window(w, prep)
+            with _trace.stage("incumbent + sweeps + table (bench step)"):
+                t, st = run_window(wa)
             tabs.append(t)
             stats.append(st)
         return tabs, stats
 
     def step():
         tabs, stats = one_pass(my_plan)
-        mine_tab = pd.concat(tabs, ignore_index=True) if tabs else pd.DataFrame()
-        every = group.allgather_object(mine_tab)                         # the ONE exchange: one frame per rank, host channel
-        merged = merge_window_matches_unique_ref([t for t in every if len(t)])
+        mine_tab = pd.DataFrame({k: np.concatenate([t[k] for t in tabs]) for k in tabs[0]}) if tabs else pd.DataFrame()
+        with _trace.stage("table exchange (host group)"):
+            every = group.allgather_object(mine_tab)                     # the ONE exchange: one frame per rank, host channel
+        with _trace.stage("merge (device de-duplication + host matching)"):
+            merged = merge_window_matches_unique_ref([t for t in every if len(t)])
         return merged, stats
 
     for _ in range(args.warmup):

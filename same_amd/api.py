@@ -622,51 +622,18 @@ def subset_data(df, x_min, x_max, y_min, y_max):
 
 class _WindowSubsetter:
     """subset_data for many boxes of one frame.  The reference evaluates four comparisons over the WHOLE frame for every
-    window (O(N * windows), src/same.py:521-526); here the rows are binned once into a uniform grid (counting sort by cell),
-    a window gathers the cells its box touches (one contiguous run per grid row) and only those rows are tested exactly.
-    The rows come back in frame order with their original labels, i.e. the frame `subset_data` returns (NaN / infinite
-    coordinates fall outside every box either way)."""
-
-    GRID = 256
+    window (O(N * windows), src/same.py:521-526); here the rows are binned once into a uniform grid (windows.GridRows), a
+    window gathers the cells its box touches and only those rows are tested exactly.  The rows come back in frame order with
+    their original labels, i.e. the frame `subset_data` returns (NaN / infinite coordinates fall outside every box either way)."""
 
     def __init__(self, df):
-        self.df = df
-        self.x = x = df["X"].to_numpy(dtype=np.float64)
-        self.y = y = df["Y"].to_numpy(dtype=np.float64)
-        finite = np.isfinite(x) & np.isfinite(y)
-        ok = None if finite.all() else np.flatnonzero(finite)
-        xo, yo = (x, y) if ok is None else (x[ok], y[ok])
-        self.nx = self.ny = 1
-        self.x0 = self.y0 = 0.0
-        self.inv = 1.0
-        if len(xo):
-            self.x0, self.y0 = float(xo.min()), float(yo.min())
-            extent = max(float(xo.max()) - self.x0, float(yo.max()) - self.y0)
-            if extent > 0.0:
-                self.inv = self.GRID / extent * (1.0 - 1e-12)
-                self.nx = self.ny = self.GRID
-        ix = ((xo - self.x0) * self.inv).astype(np.int32)
-        iy = ((yo - self.y0) * self.inv).astype(np.int32)
-        np.minimum(ix, self.nx - 1, out=ix)
-        np.minimum(iy, self.ny - 1, out=iy)
-        key = (iy * self.nx + ix).astype(np.uint16)     # GRID^2 cells fit 16 bits: numpy's stable sort of uint16 is a radix sort
-        order = np.argsort(key, kind="stable")
-        self.order = order if ok is None else ok[order]
-        self.starts = np.concatenate(([0], np.cumsum(np.bincount(key, minlength=self.nx * self.ny))))
+        from .windows import GridRows
 
-    def _cell(self, v, v0, n):
-        c = np.floor((v - v0) * self.inv)
-        return int(min(max(c, 0), n - 1)) if c == c else 0
+        self.df = df
+        self.grid = GridRows(df["X"].to_numpy(dtype=np.float64), df["Y"].to_numpy(dtype=np.float64))
 
     def subset(self, x_min, x_max, y_min, y_max):
-        ix0, ix1 = self._cell(x_min, self.x0, self.nx), self._cell(x_max, self.x0, self.nx)
-        iy0, iy1 = self._cell(y_min, self.y0, self.ny), self._cell(y_max, self.y0, self.ny)
-        st, od = self.starts, self.order
-        runs = [od[st[iy * self.nx + ix0]: st[iy * self.nx + ix1 + 1]] for iy in range(iy0, iy1 + 1)]
-        cand = np.concatenate(runs) if runs else od[:0]
-        xx, yy = self.x[cand], self.y[cand]
-        rows = np.sort(cand[(xx >= x_min) & (xx < x_max) & (yy >= y_min) & (yy < y_max)])
-        return self.df.iloc[rows]
+        return self.df.iloc[self.grid.rows(x_min, x_max, y_min, y_max)]
 
 
 def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None,

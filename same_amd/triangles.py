@@ -116,16 +116,18 @@ def classify_triangles(points, triangles, radius, min_angle_deg, type_id=None, c
 
 def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignore_same_type_triangles=False,
                                ensure_min_triangle_per_node=True, remove_unconstrained_nodes=False,
-                               min_angle_deg=15, verbose=True, ctx=None, _rows_as_array=False):
+                               min_angle_deg=15, verbose=True, ctx=None, _rows_as_array=False, _type_id=None):
     """Same signature and return shapes as src/helpers.py:233-395 (a list of kept triangle rows [+ set]).
     `_rows_as_array` (package-internal): hand back the (n, 3) array the list would be made of, so a caller that only
-    feeds it to kernels does not pay for 10^5 little row objects."""
+    feeds it to kernels does not pay for 10^5 little row objects.  `_type_id` (package-internal): integer codes of the
+    points' cell types (equal type <=> equal code) in place of `aligned_df["cell_type"]`, for callers without a frame."""
     points = np.asarray(points)
     tris = rows_array(triangles)
-    use_type = bool(ignore_same_type_triangles and aligned_df is not None)
+    use_type = bool(ignore_same_type_triangles and (aligned_df is not None or _type_id is not None))
     type_id = None
     if use_type:
-        type_id = pd.factorize(aligned_df["cell_type"].to_numpy(), use_na_sentinel=False)[0].astype(np.int32)
+        type_id = (np.ascontiguousarray(_type_id, dtype=np.int32) if _type_id is not None
+                   else pd.factorize(aligned_df["cell_type"].to_numpy(), use_na_sentinel=False)[0].astype(np.int32))
     cls, perim = classify_triangles(points, tris, radius, min_angle_deg, type_id, ctx=ctx)
 
     keep_idx = np.flatnonzero(cls == 0)

@@ -97,3 +97,162 @@ def assign_windows(plan, n_ranks):
     for pos, w in enumerate(order):
         shards[pos % n_ranks].append(w)
     return [sorted(s) for s in shards]
+
+
+class GridRows:
+    """Row indices of the points inside half-open boxes [x0, x1) x [y0, y1), for many boxes of one point set: the points are
+    binned once into a uniform grid (counting sort by cell), a box gathers the cells it touches (one contiguous run per grid
+    row) and only those points are tested exactly.  Indices come back ascending -- `np.flatnonzero` of the reference's four
+    comparisons (src/same.py:293-295); NaN / infinite coordinates fall outside every box either way."""
+
+    GRID = 256
+
+    def __init__(self, x, y):
+        self.x, self.y = x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        finite = np.isfinite(x) & np.isfinite(y)
+        ok = None if finite.all() else np.flatnonzero(finite)
+        xo, yo = (x, y) if ok is None else (x[ok], y[ok])
+        self.nx = self.ny = 1
+        self.x0 = self.y0 = 0.0
+        self.inv = 1.0
+        if len(xo):
+            self.x0, self.y0 = float(xo.min()), float(yo.min())
+            extent = max(float(xo.max()) - self.x0, float(yo.max()) - self.y0)
+            if extent > 0.0:
+                self.inv = self.GRID / extent * (1.0 - 1e-12)
+                self.nx = self.ny = self.GRID
+        ix = ((xo - self.x0) * self.inv).astype(np.int32)
+        iy = ((yo - self.y0) * self.inv).astype(np.int32)
+        np.minimum(ix, self.nx - 1, out=ix)
+        np.minimum(iy, self.ny - 1, out=iy)
+        key = (iy * self.nx + ix).astype(np.uint16)     # GRID^2 cells fit 16 bits: numpy's stable sort of uint16 is a radix sort
+        order = np.argsort(key, kind="stable")
+        self.order = order if ok is None else ok[order]
+        self.starts = np.concatenate(([0], np.cumsum(np.bincount(key, minlength=self.nx * self.ny))))
+
+    def _cell(self, v, v0, n):
+        c = np.floor((v - v0) * self.inv)
+        return int(min(max(c, 0), n - 1)) if c == c else 0
+
+    def rows(self, x_min, x_max, y_min, y_max):
+        ix0, ix1 = self._cell(x_min, self.x0, self.nx), self._cell(x_max, self.x0, self.nx)
+        iy0, iy1 = self._cell(y_min, self.y0, self.ny), self._cell(y_max, self.y0, self.ny)
+        st, od = self.starts, self.order
+        runs = [od[st[iy * self.nx + ix0]: st[iy * self.nx + ix1 + 1]] for iy in range(iy0, iy1 + 1)]
+        cand = np.concatenate(runs) if runs else od[:0]
+        xx, yy = self.x[cand], self.y[cand]
+        return np.sort(cand[(xx >= x_min) & (xx < x_max) & (yy >= y_min) & (yy < y_max)])
+
+
+class Section:
+    """One tissue section as columns (no DataFrame): what the window pipeline reads of it.
+    xy (n, 2) float64; types (n, T) float64, the commonCT columns in commonCT order; type_id (n,) int32 codes of the cell
+    type (equal type <=> equal code); size (n,) (integer dtype kept: it decides the dtype of the triangle weights)."""
+
+    def __init__(self, xy, types, type_id=None, size=None):
+        self.xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self.types = np.ascontiguousarray(types, dtype=np.float64).reshape(len(self.xy), -1)
+        self.type_id = None if type_id is None else np.ascontiguousarray(type_id, dtype=np.int32)
+        self.size = np.ones(len(self.xy), np.int64) if size is None else np.asarray(size)
+        self.grid = GridRows(self.xy[:, 0], self.xy[:, 1])
+
+    @classmethod
+    def from_frame(cls, df, commonCT):
+        import pandas as pd
+
+        type_id = pd.factorize(df["cell_type"].to_numpy(), use_na_sentinel=False)[0] if "cell_type" in df.columns else None
+        return cls(df[["X", "Y"]].to_numpy(dtype=np.float64), df[list(commonCT)].to_numpy(dtype=np.float64), type_id,
+                   df["size"].to_numpy() if "size" in df.columns else None)
+
+
+class WindowArrays:
+    """Pre-MIP artefacts of one window as flat arrays (what PreparedInputs holds, without the frames): `rows_m` / `rows_r` are
+    the section rows of the window's compacted aligned / reference cells, `pairs` (P, 2) int64 index into them, `costs` (P,)
+    float64 in pair order, `triangles` (Tr, 3) of compacted aligned rows in the reference's kept order, `weights`, `signs`."""
+
+    __slots__ = ("window", "rows_m", "rows_r", "pairs", "costs", "triangles", "weights", "signs", "axy", "rxy", "size", "error")
+
+    def __init__(self, window):
+        self.window = window
+        for name in self.__slots__[1:]:
+            setattr(self, name, None)
+
+    @property
+    def n_aligned(self):
+        return len(self.rows_m)
+
+    @property
+    def n_ref(self):
+        return len(self.rows_r)
+
+
+def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True,
+                       cost_dtype=np.float64, ctx=None):
+    """The pre-MIP path of every window of `plan` on COLUMNS (two `Section`s), in plan order: yields one `WindowArrays` per
+    window -- the same pairs, costs, kept triangles, weights and signs `api.iter_prepared_windows` computes from frames
+    (tests/test_gpu_run_same.py::test_window_arrays_equal_prepared_windows), without building a DataFrame per window.  The
+    frame pipeline spends ~90 % of a window in pandas `take`s that the reference's return types force at its boundary; a
+    caller that feeds the artefacts straight to kernels (bench.py --workload cfg5) does not need them.  Windows n+1..n+k are
+    subset, pruned and compacted ahead and triangulated by the Qhull helpers while window n runs, as in the frame pipeline.
+    A window whose prune leaves no pairs yields a WindowArrays whose `.error` is the ValueError run_same would raise."""
+    from . import qhull_pool
+    from ._trace import stage as marked
+    from .knn import pairs_from_padded
+    from .triangles import filter_triangles_by_radius
+
+    depth = qhull_pool.lookahead()
+    qhull_pool.warm(min(depth, len(plan)))
+    cost_dtype = np.dtype(cost_dtype)
+
+    def stage(w):
+        with marked("prune+compact"):
+            return prune(w)
+
+    def prune(w):
+        out = WindowArrays(w)
+        rows_r, rows_m = ref.grid.rows(*w["box"]), moving.grid.rows(*w["box"])
+        axy, rxy = moving.xy[rows_m], ref.xy[rows_r]
+        # the argument checks cKDTree makes for the reference are moot here: GridRows only returns finite points
+        r = float(radius)
+        if r != r or int(knn) <= 0 or len(rxy) == 0 or len(axy) == 0:
+            idx = np.full((len(axy), 1), -1, np.int32)
+        else:
+            idx, _, _ = ops.knn_prune(axy, rxy, abs(r), knn, want_d2=False, ctx=ctx)
+        kp = pairs_from_padded(idx)
+        if len(kp) == 0:
+            out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
+            return out, None
+        used_a = np.zeros(len(axy), bool)
+        used_a[kp[:, 0]] = True
+        used_r = np.zeros(len(rxy), bool)
+        used_r[kp[:, 1]] = True
+        ua, ur = np.flatnonzero(used_a), np.flatnonzero(used_r)            # compaction (src/utils.py:734-742)
+        out.pairs = np.column_stack(((np.cumsum(used_a) - 1)[kp[:, 0]], (np.cumsum(used_r) - 1)[kp[:, 1]])).astype(np.int64)
+        out.rows_m, out.rows_r = rows_m[ua], rows_r[ur]
+        out.axy, out.rxy = np.ascontiguousarray(axy[ua]), np.ascontiguousarray(rxy[ur])
+        return out, qhull_pool.pool().submit(out.axy)
+
+    def finish(out, ticket):
+        with marked("triangulate (wait for helper)"):
+            tris = ticket.result()
+        with marked("triangle filter"):
+            tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
+            out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
+                                                       min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
+        with marked("triangle weights + source signs"):
+            out.size = moving.size[out.rows_m]
+            sign, weight = ops.tri_sign_weight(out.axy, out.size.astype(np.float64), out.triangles, ctx=ctx)
+            out.weights = weight.astype(np.int64) if np.issubdtype(out.size.dtype, np.integer) else weight
+            out.signs = sign.astype(np.float64)
+        with marked("pair costs"):
+            out.costs = ops.pair_cost(moving.types[out.rows_m], ref.types[out.rows_r], out.axy, out.rxy, out.pairs, dist_ct_coeff,
+                                      dtype=cost_dtype, ctx=ctx).astype(np.float64, copy=False)
+        return out
+
+    ahead = {}
+    for q in range(len(plan)):
+        for nxt in range(q, min(q + 1 + depth, len(plan))):
+            if nxt not in ahead:
+                ahead[nxt] = stage(plan[nxt])
+        out, ticket = ahead.pop(q)
+        yield out if out.error is not None else finish(out, ticket)

@@ -350,6 +350,49 @@ def test_bench_two_ranks_on_one_gpu_carry_the_diagnosis():
     assert out["per_rank"]["device_by_rank"] == [0, 0]
 
 
+@pytest.mark.parametrize("cost_dtype", ["float64", "float32"])
+def test_window_arrays_equal_prepared_windows(cost_dtype):
+    """The column pipeline (windows.iter_window_arrays: no DataFrame per window; what bench.py --workload cfg5 runs) yields, for
+    every window of a plan -- thin edge strips, an empty window and integer / float size columns included -- exactly the
+    artefacts the frame pipeline (api.iter_prepared_windows, itself pinned against the reference's run_same) computes: the
+    same cells, pairs, costs, kept triangles in the same order, weights and signs."""
+    import same_amd
+    from same_amd import synth
+    from same_amd.windows import Section, iter_window_arrays, window_plan
+
+    T = 5
+    ref = synth.make_cells(40_000, T, seed=30)
+    mov = synth.make_jittered(ref, seed=31)
+    mov["xy"][:300] += 5000.0                                    # a far-away clump: windows whose prune finds nothing
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    m_df["size"] = np.where(np.arange(len(m_df)) % 3 == 0, 2, 1) if cost_dtype == "float32" else m_df["size"].astype(float) * 1.5
+    cols = synth.type_columns(T)
+    plan = window_plan(r_df[["X", "Y"]].to_numpy(), m_df[["X", "Y"]].to_numpy(), 700, 200, 10)
+    plan = plan[::2] + [dict(plan[0], box=(5000.0, 7100.0, 5000.0, 7100.0))]       # + a window over the clump: aligned cells, no reference cells
+    op = dict(radius=30, knn=6, min_angle_deg=12, dist_ct_coeff=1.5, hip_cost_dtype=cost_dtype)
+    frames = list(same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=op))
+    arrays = list(iter_window_arrays(Section.from_frame(r_df, cols), Section.from_frame(m_df, cols), plan, radius=30, knn=6,
+                                     dist_ct_coeff=1.5, min_angle_deg=12, ignore_same_type_triangles=True, cost_dtype=cost_dtype))
+    assert len(frames) == len(arrays) == len(plan) > 10
+    errors = 0
+    for (w, prep), wa in zip(frames, arrays):
+        assert wa.window is w
+        if isinstance(prep, Exception):
+            assert isinstance(wa.error, ValueError) and str(wa.error) == str(prep)
+            errors += 1
+            continue
+        assert wa.error is None
+        assert np.array_equal(m_df.index.to_numpy()[wa.rows_m], prep.aligned_df["__orig_idx"].to_numpy())
+        assert np.array_equal(r_df.index.to_numpy()[wa.rows_r], prep.ref_df["__orig_idx"].to_numpy())
+        assert np.array_equal(wa.pairs, np.asarray(prep.valid_pairs, dtype=np.int64).reshape(-1, 2))
+        assert np.array_equal(wa.costs, prep.costs_array) and wa.costs.dtype == np.float64
+        assert np.array_equal(wa.triangles, prep.triangles_array)
+        assert np.array_equal(wa.signs, prep.signs_array)
+        assert wa.weights.dtype == prep.weights_array.dtype and np.array_equal(wa.weights, prep.weights_array)
+        assert np.array_equal(wa.axy, prep.aligned_df[["X", "Y"]].to_numpy()) and np.array_equal(wa.rxy, prep.ref_df[["X", "Y"]].to_numpy())
+    assert errors >= 1
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_bench_cfg5_windows_line(world):
     """`bench.py --workload cfg5` (BASELINE cfg 5 at reduced size): whole windows dealt to the ranks, fp32 costs, all sweeps per
