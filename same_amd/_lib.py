@@ -314,16 +314,19 @@ class Context:
 
 
 _default_ctx = {}
+_n_devices = None
 _default_lock = threading.Lock()
 
 
 def default_context(device=None):
     """Process-wide context for `device` (default: $SAME_HIP_DEVICE or LOCAL_RANK or 0)."""
     if device is None:
+        global _n_devices
         device = int(os.environ.get("SAME_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        n = device_count()
-        if n > 0:
-            device %= n
+        if _n_devices is None or _n_devices <= 0:
+            _n_devices = device_count()      # asked once: hipGetDeviceCount costs ~0.15 ms and every op of a window resolves its context
+        if _n_devices > 0:
+            device %= _n_devices
     with _default_lock:
         ctx = _default_ctx.get(device)
         if ctx is None or not ctx.handle:

@@ -10,7 +10,7 @@ simplices are identical to an in-process call.
 Helpers are plain `python -c` children speaking a length-prefixed binary protocol over their pipes (no multiprocessing:
 nothing re-imports the caller's `__main__`, nothing is forked from a process that has initialised the GPU, and the
 helpers import numpy + scipy.spatial only -- they never touch the GPU).  `SAME_QHULL_WORKERS` sets their number
-(default: up to 4, at most half the cores; 0 = compute in-process, no helpers).
+(default: up to 8, at most half the cores; 0 = compute in-process, no helpers).
 """
 import atexit
 import os
@@ -79,7 +79,17 @@ class QhullPool:
 
     def _spawn(self):
         env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
-        return subprocess.Popen([sys.executable, "-c", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+        p = subprocess.Popen([sys.executable, "-c", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+        # a window's points are ~200 KB and its simplices ~250 KB; with the default 64 KiB pipes the submitting side blocks in
+        # write() until a busy helper gets round to reading, i.e. it waits for Qhull after all.  1 MiB is the unprivileged limit.
+        try:
+            import fcntl
+
+            for f in (p.stdin, p.stdout):
+                fcntl.fcntl(f.fileno(), getattr(fcntl, "F_SETPIPE_SZ", 1031), 1 << 20)
+        except (ImportError, OSError, ValueError):
+            pass
+        return p
 
     def submit(self, points):
         """Start Delaunay(points) in a helper; -> ticket with .result().  points: (n, 2) float64."""
@@ -190,7 +200,7 @@ def default_workers():
     v = os.environ.get("SAME_QHULL_WORKERS")
     if v is not None:
         return max(0, int(v))
-    return max(0, min(4, (os.cpu_count() or 1) // 2))
+    return max(0, min(8, (os.cpu_count() or 1) // 2))
 
 
 def warm(count=None):

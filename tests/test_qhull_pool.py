@@ -105,4 +105,4 @@ def test_no_helper_mode_and_default_size(monkeypatch):
     monkeypatch.setenv("SAME_QHULL_WORKERS", "0")
     assert qhull_pool.default_workers() == 0
     monkeypatch.delenv("SAME_QHULL_WORKERS")
-    assert 0 <= qhull_pool.default_workers() <= 4
+    assert 0 <= qhull_pool.default_workers() <= 8
