@@ -252,6 +252,30 @@ def test_bench_launches_its_own_ranks(world):
     assert len({r["pid"] for r in d["ranks"]}) == world            # fresh processes, one per rank
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_as_ranks_of_torch_distributed_run(world):
+    """The driver's N > 1 command, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- every process is a rank (RANK / LOCAL_RANK / WORLD_SIZE from the agent), the ranks
+    find each other through the directory derived from MASTER_PORT and the agent's pid (no SAME_RDV_DIR), pass its ownership
+    checks, and rank 0 prints the one line.  --dry-launch stops before any GPU work.  (torch is the LAUNCHER here, nothing more:
+    bench.py and the package import none of it.)"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+                        "--dry-launch"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["world"] == world and d["max_of_rank_plus_1"] == float(world) and all(r["id_ok"] for r in d["ranks"])
+    assert [r["rank"] for r in d["ranks"]] == list(range(world)) and len({r["pid"] for r in d["ranks"]}) == world
+
+
 def test_bench_launcher_reports_a_failed_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
     # without --dry-launch the ranks need a GPU: here every rank exits non-zero, and so must the launcher (no line)
