@@ -15,8 +15,13 @@ def _xy(df):
 
 def pairs_from_padded(idx, row_offset=0):
     """Row-major walk of the -1 padded lists: aligned i ascending, rank ascending within i."""
-    rows, cols = np.nonzero(idx >= 0)
-    return np.column_stack((rows.astype(np.int64) + int(row_offset), idx[rows, cols].astype(np.int64)))
+    # the lists are filled from the left, but nothing here relies on it: a boolean take walks the array in the same row-major
+    # order np.nonzero would, at a fraction of its cost
+    kept = idx >= 0
+    out = np.empty((int(np.count_nonzero(kept)), 2), np.int64)
+    out[:, 0] = np.repeat(np.arange(int(row_offset), int(row_offset) + len(idx), dtype=np.int64), kept.sum(axis=1))
+    out[:, 1] = idx[kept]
+    return out
 
 
 def compact_pairs(aligned_df, ref_df, knn_pairs):

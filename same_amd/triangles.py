@@ -136,7 +136,7 @@ def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignor
     has_kept[tris[keep_idx].reshape(-1)] = True
     any_valid = np.zeros(n_points, bool)
     any_valid[tris[(cls == 0) | (cls == 3)].reshape(-1)] = True
-    order = list(keep_idx)
+    order = keep_idx                          # triangle indices kept, in the order the reference's list has them
 
     if verbose:
         print("\nTriangle filtering summary:")
@@ -158,29 +158,27 @@ def filter_triangles_by_radius(points, triangles, radius, aligned_df=None, ignor
             o = np.lexsort((cand_t, perim[cand_t]))       # by perimeter, then input order
             v_sorted, t_sorted = cand_v[o], cand_t[o]
             first = np.unique(v_sorted, return_index=True)[1]
-            best_of = dict(zip(v_sorted[first].tolist(), t_sorted[first].tolist()))
+            best_t = np.full(n_points, -1, np.int64)                 # best same-type triangle of every vertex that has one
+            best_t[v_sorted[first]] = t_sorted[first]
             missing = np.flatnonzero(~has_kept & any_valid)
-            # the reference de-duplicates against every triangle kept so far (src/helpers.py:375-381); a candidate contains a
-            # node that no kept triangle contains, so it can only collide with a triangle added in this pass
-            added_set = set()
-            added = 0
-            for i in missing.tolist():
-                t = best_of.get(i)
-                if t is None:
-                    continue
-                key = tuple(tris[t].tolist())
-                if key not in added_set:
-                    order.append(t)
-                    added_set.add(key)
-                    added += 1
+            cand = best_t[missing]
+            cand = cand[cand >= 0]                                     # in ascending node order, as the reference walks them
+            # the reference de-duplicates by the triangle's vertex tuple against every triangle kept so far (src/helpers.py:375-381);
+            # a candidate contains a node that no kept triangle contains, so it can only collide with a triangle added in this
+            # pass: keep the first occurrence of every distinct vertex row, in walk order
+            if len(cand):
+                _, first_of_row = np.unique(tris[cand], axis=0, return_index=True)
+                cand = cand[np.sort(first_of_row)]
+            order = np.concatenate((keep_idx, cand))
+            added = len(cand)
             if verbose and added:
                 print(f"Added back {added} same-type triangles to ensure >=1 triangle per node")
                 print(f"Final triangles kept: {len(order)}")
 
     if _rows_as_array:
-        filtered = tris[np.asarray(order, dtype=np.int64)] if order else np.zeros((0, 3), dtype=tris.dtype)
+        filtered = tris[order] if len(order) else np.zeros((0, 3), dtype=tris.dtype)
     else:
-        filtered = RowList(tris[np.asarray(order, dtype=np.int64)]) if order else []   # a list of triangle rows, as the reference returns
+        filtered = RowList(tris[order]) if len(order) else []   # a list of triangle rows, as the reference returns
     if remove_unconstrained_nodes:
         return filtered, set(np.flatnonzero(~any_valid).tolist())
     return filtered
