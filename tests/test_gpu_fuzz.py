@@ -214,3 +214,23 @@ def test_fuzz_knn_index_and_block_sweeps(ops, oracle):
                 flags = dflag.download((Tr,), np.uint8)
                 L.same_sweep_unbind(sw)
             assert chk.value == och and np.array_equal(viol[: nv.value], oviol) and np.array_equal(flags, oflag), (case, Tr, world)
+
+
+def test_fuzz_merge_dedup(ops, oracle):
+    """The window-merge de-duplication (csrc/merge.hip) against the oracle on random tables: sizes that fall on either side of
+    the wave, of the 2 048-key LDS sort block and of the first global bitonic stages; few or many windows (long runs of equal
+    sort keys apart from the row index); pair codes drawn from tiny to sparse id spaces; all / none / some rows violating."""
+    for rnd in range(ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"merge soak round {rnd}", flush=True)
+        rng = np.random.default_rng(77 + 104729 * rnd)
+        for case in range(60):
+            n = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 2047, 2048, 2049, 4095, 4097, int(rng.integers(3, 9000)), int(rng.integers(9000, 40000))]))
+            n_win = int(rng.choice([1, 2, 7, 300, 2 ** 31 - 1]))
+            ids = int(rng.choice([1, 3, 50, 5000, 2 ** 31 - 1]))
+            viol = rng.random(n) < float(rng.choice([0.0, 0.3, 1.0]))
+            win = rng.integers(0, n_win, n, endpoint=(n_win < 2 ** 31 - 1)).astype(np.int32) if n_win > 1 else np.zeros(n, np.int32)
+            a = rng.integers(0, ids, n).astype(np.int32)
+            r = rng.integers(0, ids, n).astype(np.int32)
+            got = ops.merge_dedup(viol, win, a, r)
+            assert np.array_equal(got, oracle.merge_dedup(viol, win, a, r)), (rnd, case, n, n_win, ids)
