@@ -652,6 +652,29 @@ def run_rank(args):
                     "bench_kernel_ms": None if t_pT is None else t_pT * 1e3,
                     "what": "one hipMalloc of the same size in this process: its rate depends on which HBM regions the driver drew it from"}
                 plain.free()
+        # the pruned path on its own (SURVEY 8d "fused KNN + cost, no dense store": reported as cell-pairs/s): indexed prune + costs of the
+        # padded candidate lists for all rows of the block, HIP events on the tail stream
+        def tail_ms(call, reps=5):
+            out = []
+            for _ in range(reps + 1):
+                chk(L.same_timer_start(env.TH), "timer")
+                call()
+                ms = ctypes.c_float(0)
+                chk(L.same_timer_stop(env.TH, ctypes.byref(ms)), "timer")
+                out.append(ms.value)
+            return float(np.mean(out[1:])) * 1e-3
+
+        ctx.sync()
+        t_pc = tail_ms(prob.prune_and_costs)
+        t_sw = tail_ms(lambda: (prob.tri_maps(), prob.local_sweeps()))
+        pc_bytes = 8.0 * (T + 2) * (n_ref + rows) + 16.0 * k * rows
+        extras["pruned_path"] = {"ms": t_pc * 1e3, "cell_pairs_per_s": float(n_ref) * rows / t_pc, "algorithmic_bytes": pc_bytes,
+                                 "GBs": pc_bytes / t_pc / 1e9,
+                                 "what": f"same_knn_prune_indexed_dev (r={radius:g}, k={k}, caller-held grid index) + same_padded_cost_f64_dev for {rows} aligned rows "
+                                         f"against {n_ref} refs, alone on its stream: dense-equivalent pairs covered per second without materialising the matrix "
+                                         "(latency / gather-bound, no roofline fraction claimed)"}
+        extras["triangle_maps_and_sweeps"] = {"ms": t_sw * 1e3, "triangles": Tr, "triangles_per_s": Tr / t_sw,
+                                              "what": "classify + weights / signs + XY-order sweep + area flips + orientation sweep incl. its read-back, alone on its stream"}
         # operating point: loop the dense kernel alone for ~2 s while a side thread reads board power and shader clock
         tel = GpuTelemetry(ctx.pci_bus_id())
         if tel.available():
@@ -917,6 +940,9 @@ def run_rank(args):
                               f"(VALU busy {roof['valu_busy_frac']:.2f}): the bound of this kernel is fp64 issue under the board power cap, not HBM"))
             else:
                 msg.append("board power / clock could not be read from sysfs on this box")
+        for key in ("pruned_path", "triangle_maps_and_sweeps"):
+            if key in extras:
+                roof[key] = extras[key]
         if "sweep" in extras:
             roof["sweep"] = extras["sweep"]
             msg.append("sweep = same measurement at other type counts (the reference's datasets have T = 3, 5, 8)")

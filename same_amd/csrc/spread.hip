@@ -28,6 +28,7 @@
 #include <atomic>
 #include <mutex>
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 
 #include "common.h"
@@ -422,7 +423,14 @@ extern "C" int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dpt
         // the reason the spread path gave up stays readable after the plain allocation succeeded -- but only a reason of THIS
         // call: when the spread path was not attempted at all there is nothing to report
         const std::string why = tried ? ctx->err : std::string();
-        SAME_TRY(same_dev_alloc(ctx, bytes, out_dptr));
+        // a sibling rank on the same card may be holding look-ahead chunks of its own labelling for a second or two: an
+        // out-of-memory answer here is retried a few times before it is believed
+        int arc = same_dev_alloc(ctx, bytes, out_dptr);
+        for (int attempt = 0; attempt < 4 && arc == SAME_ENOMEM && n_need >= MIN_CHUNKS && bytes <= total_b; ++attempt) {   // never for a request the card cannot hold at all
+            std::this_thread::sleep_for(std::chrono::milliseconds(750));
+            arc = same_dev_alloc(ctx, bytes, out_dptr);
+        }
+        SAME_TRY(arc);
         ctx->err = why;
     }
     if (out_info) memcpy(out_info, info, sizeof info);

@@ -297,6 +297,7 @@ def test_bench_contract_line(force_comm):
             assert 0.0 < rf["valu_busy_frac"] <= 1.05 and rf["valu_floor_ms_at_held_clock"] > 0 and rf["held_clock_mhz"] > 500
         assert rf["measured_ceilings"]["device_copy_GBs"] > 0 and rf["frac_of_measured_copy_bw"] > 0
         assert "verified" in rf["output_buffer"]
+        assert rf["pruned_path"]["cell_pairs_per_s"] > out["value"] and rf["triangle_maps_and_sweeps"]["triangles_per_s"] > 0
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
         assert "equal the oracle bit-for-bit" in out["parity_spot_check"]

@@ -42,4 +42,15 @@ echo "== bench strong scaling cfg4 on one GPU (forced communicator: real collect
 tail -2 $out/bench_strong.err
 echo "== 2-rank launch rehearsal on the one GPU (RCCL refuses duplicate devices -> host transport)" && timeout -k 10 300 python3 bench.py --gpus 2 --workload cfg2 --no-cpu-baseline --steps 3 --warmup 1 > $out/bench_2rank.json 2> $out/bench_2rank.err || { tail -20 $out/bench_2rank.err; exit 1; }
 tail -2 $out/bench_2rank.err
+echo "== 3 ranks on the one GPU, tiny (uneven blocks; host transport)" && timeout -k 10 300 python3 bench.py --gpus 3 --workload tiny --no-cpu-baseline --steps 3 --warmup 1 > $out/bench_3rank.json 2> $out/bench_3rank.err || { tail -20 $out/bench_3rank.err; exit 1; }
+tail -1 $out/bench_3rank.err
+echo "== the driver's N>1 command form: bench.py as ranks of torch.distributed.run (2 ranks on the one GPU)" && timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --workload cfg2 --no-cpu-baseline --steps 3 --warmup 1 > $out/bench_torchrun_2rank.json 2> $out/bench_torchrun_2rank.err || { tail -20 $out/bench_torchrun_2rank.err; exit 1; }
+tail -1 $out/bench_torchrun_2rank.err
+echo "== cfg5 (1M cells, windows), 1 rank and 2 ranks on the one GPU" && timeout -k 10 300 python3 bench.py --workload cfg5 --steps 3 --warmup 1 > $out/bench_cfg5.json 2> $out/bench_cfg5.err || { tail -20 $out/bench_cfg5.err; exit 1; }
+timeout -k 10 300 python3 bench.py --workload cfg5 --steps 3 --warmup 1 --gpus 2 > $out/bench_cfg5_2rank.json 2> $out/bench_cfg5_2rank.err || { tail -20 $out/bench_cfg5_2rank.err; exit 1; }
+python3 - <<PY
+import json
+for f in ("bench_cfg5.json", "bench_cfg5_2rank.json"):
+    d = json.load(open("$out/" + f)); print(f, "%.1f windows/s, %.0f ms/step, host glue %.2f" % (d["windows_per_s"], d["ms_per_step"], d["host_glue_share"]))
+PY
 echo "== done"
