@@ -66,6 +66,8 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
     r_codes, _ = pd.factorize(merged_df[ref_col].values, sort=True)
     n_a, n_r = len(a_uniques), int(r_codes.max()) + 1 if len(r_codes) else 0
     graph = csr_matrix((np.ones(len(a_codes), np.int8), (a_codes, r_codes)), shape=(n_a, n_r))
+    graph.sort_indices()   # node numbers come from the sorted ids and every adjacency list is sorted: the matching chosen among equally
+                           # large ones depends on the ids alone, not on the order the window tables arrived in (1 rank or 8)
     match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref index matched to each aligned node, -1 = none
     # the frame row of every matched (aligned, ref) edge, aligned ids ascending (:799-808).  Edges are unique after the
     # de-duplication, so a sorted edge key finds the row without a Python dict over a table of 10^6 rows

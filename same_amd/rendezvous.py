@@ -19,7 +19,6 @@ The data path never goes through here on GPUs: pruned candidate lists and sweep 
 RCCL (csrc/comm.hip).  `allgather_array` exists for CPU tests and as a transport (never compute)
 fallback when the RCCL communicator cannot be created.
 """
-import base64
 import io
 import json
 import os
@@ -67,50 +66,53 @@ def _check_private(path, what, want_dir):
 
 # ---- small host objects, without pickle -------------------------------------------------------------------------------
 # What the ranks exchange (dicts of numbers and strings, lists, numpy arrays, the per-window match tables as pandas frames)
-# travels as JSON with numeric arrays as .npy bytes read back with allow_pickle=False: nothing a peer sends can name a
-# callable, so a channel that was somehow reached by someone else still cannot execute code in a rank.
-def _enc(o):
+# travels as a JSON skeleton plus a binary section: numeric arrays are appended as .npy bytes (read back with
+# allow_pickle=False) and the skeleton refers to them by position -- no base64, no megabyte strings inside JSON, and nothing
+# a peer sends can name a callable, so a channel that was somehow reached by someone else still cannot execute code in a rank.
+def _enc(o, blobs):
     import numpy as np
 
     if o is None or isinstance(o, (bool, int, float, str)):
         return o
     if isinstance(o, np.generic):
-        return _enc(o.item())
+        return _enc(o.item(), blobs)
     if isinstance(o, bytes):
-        return {"__b__": base64.b64encode(o).decode()}
+        blobs.append(o)
+        return {"__b__": len(blobs) - 1}
     if isinstance(o, np.ndarray):
         if o.dtype.kind in "biufc":
             buf = io.BytesIO()
             np.save(buf, np.ascontiguousarray(o), allow_pickle=False)
-            return {"__nd__": base64.b64encode(buf.getvalue()).decode()}
-        return {"__ndo__": [_enc(x) for x in o.reshape(-1).tolist()], "shape": list(o.shape), "dtype": o.dtype.str if o.dtype.kind in "US" else "O"}
+            blobs.append(buf.getvalue())
+            return {"__nd__": len(blobs) - 1}
+        return {"__ndo__": [_enc(x, blobs) for x in o.reshape(-1).tolist()], "shape": list(o.shape), "dtype": o.dtype.str if o.dtype.kind in "US" else "O"}
     if isinstance(o, tuple):
-        return {"__t__": [_enc(x) for x in o]}
+        return {"__t__": [_enc(x, blobs) for x in o]}
     if isinstance(o, (list, set, frozenset)):
-        return [_enc(x) for x in o] if isinstance(o, list) else {"__s__": [_enc(x) for x in sorted(o, key=repr)]}
+        return [_enc(x, blobs) for x in o] if isinstance(o, list) else {"__s__": [_enc(x, blobs) for x in sorted(o, key=repr)]}
     if isinstance(o, dict):
-        return {"__d__": [[_enc(k), _enc(v)] for k, v in o.items()]}
+        return {"__d__": [[_enc(k, blobs), _enc(v, blobs)] for k, v in o.items()]}
     try:
         import pandas as pd
     except ImportError:   # pragma: no cover
         pd = None
     if pd is not None and isinstance(o, pd.DataFrame):
-        return {"__df__": {"columns": [_enc(c) for c in o.columns], "data": [_enc(o[c].to_numpy()) for c in o.columns],
-                           "index": _enc(o.index.to_numpy())}}
+        return {"__df__": {"columns": [_enc(c, blobs) for c in o.columns], "data": [_enc(o[c].to_numpy(), blobs) for c in o.columns],
+                           "index": _enc(o.index.to_numpy(), blobs)}}
     raise TypeError(f"allgather_object cannot carry a {type(o).__name__} (numbers, strings, lists, dicts, numpy arrays and pandas frames only)")
 
 
-def _dec(o):
+def _dec(o, blobs):
     import numpy as np
 
     if isinstance(o, list):
-        return [_dec(x) for x in o]
+        return [_dec(x, blobs) for x in o]
     if not isinstance(o, dict):
         return o
     if "__nd__" in o:
-        return np.load(io.BytesIO(base64.b64decode(o["__nd__"])), allow_pickle=False)
+        return np.load(io.BytesIO(blobs[int(o["__nd__"])]), allow_pickle=False)
     if "__ndo__" in o:
-        vals = [_dec(x) for x in o["__ndo__"]]
+        vals = [_dec(x, blobs) for x in o["__ndo__"]]
         if o["dtype"] != "O":
             return np.array(vals, dtype=o["dtype"]).reshape(o["shape"])
         a = np.empty(len(vals), dtype=object)
@@ -118,23 +120,43 @@ def _dec(o):
             a[i] = v
         return a.reshape(o["shape"])
     if "__b__" in o:
-        return base64.b64decode(o["__b__"])
+        return bytes(blobs[int(o["__b__"])])
     if "__t__" in o:
-        return tuple(_dec(x) for x in o["__t__"])
+        return tuple(_dec(x, blobs) for x in o["__t__"])
     if "__s__" in o:
-        return set(_dec(x) for x in o["__s__"])
+        return set(_dec(x, blobs) for x in o["__s__"])
     if "__d__" in o:
-        return {_dec(k): _dec(v) for k, v in o["__d__"]}
+        return {_dec(k, blobs): _dec(v, blobs) for k, v in o["__d__"]}
     if "__df__" in o:
         import pandas as pd
 
         d = o["__df__"]
-        cols = [_dec(c) for c in d["columns"]]
-        idx = _dec(d["index"])
+        cols = [_dec(c, blobs) for c in d["columns"]]
+        idx = _dec(d["index"], blobs)
         # column by column, so every column keeps the dtype its array travelled with
-        return pd.DataFrame({i: pd.Series(_dec(a), index=idx) for i, a in enumerate(d["data"])}, index=idx).set_axis(cols, axis=1) \
+        return pd.DataFrame({i: pd.Series(_dec(a, blobs), index=idx) for i, a in enumerate(d["data"])}, index=idx).set_axis(cols, axis=1) \
             if cols else pd.DataFrame(index=idx)
     raise ValueError("malformed object frame from a peer")
+
+
+def pack_object(obj):
+    """obj -> bytes: u64 skeleton length, JSON skeleton, then for every binary part u64 length + bytes."""
+    blobs = []
+    head = json.dumps(_enc(obj, blobs)).encode()
+    return b"".join([struct.pack("<Q", len(head)), head] + [part for blob in blobs for part in (struct.pack("<Q", len(blob)), blob)])
+
+
+def unpack_object(payload):
+    view = memoryview(payload)
+    (n,) = struct.unpack_from("<Q", view, 0)
+    head, off, blobs = json.loads(bytes(view[8: 8 + n]).decode()), 8 + n, []
+    while off < len(view):
+        (m,) = struct.unpack_from("<Q", view, off)
+        if off + 8 + m > len(view):
+            raise ValueError("truncated object frame from a peer")
+        blobs.append(view[off + 8: off + 8 + m])
+        off += 8 + m
+    return _dec(head, blobs)
 
 
 def _recv_exact(sock, n):
@@ -280,12 +302,12 @@ class HostGroup:
 
     def allgather_object(self, obj):
         """Small host objects between this job's own ranks: numbers, strings, lists / tuples / sets / dicts of them, numpy
-        arrays and pandas frames (the per-window match tables), as JSON + .npy bytes -- no pickle, so nothing a peer sends
-        can run code here.  The connections are loopback-only and admitted with the job's token, which sits in a 0600 file
+        arrays and pandas frames (the per-window match tables), as a JSON skeleton + .npy bytes -- no pickle, so nothing a
+        peer sends can run code here.  The connections are loopback-only and admitted with the job's token, which sits in a 0600 file
         of a 0700 directory whose ownership every rank checks."""
         if self.world == 1:
             return [obj]
-        return [_dec(json.loads(p.decode())) for p in self.allgather_bytes(json.dumps(_enc(obj)).encode())]
+        return [unpack_object(p) for p in self.allgather_bytes(pack_object(obj))]
 
     def close(self):
         for s in list(self._peers.values()) + [self._hub, self._listener]:

@@ -175,14 +175,16 @@ def test_allgather_object_carries_frames_without_pickle(tmp_path):
                        "flag": np.array([True, False, True, True])}, index=[3, 5, 7, 9])
     obj = {"k": (1, 2.5, "s"), 3: [df, None, {1, 2}], "arr": np.arange(6, dtype=np.int32).reshape(2, 3), "empty": pd.DataFrame(),
            "raw": bytes(range(5)), "np": np.float32(0.25)}
-    wire = json.dumps(rdv._enc(obj))
-    assert "pickle" not in wire and "__reduce__" not in wire
-    back = rdv._dec(json.loads(wire))
+    wire = rdv.pack_object(obj)
+    assert b"pickle" not in wire and b"__reduce__" not in wire
+    back = rdv.unpack_object(wire)
     assert back["k"] == (1, 2.5, "s") and back[3][1] is None and back[3][2] == {1, 2} and back["raw"] == bytes(range(5)) and back["np"] == 0.25
     assert back["arr"].dtype == np.int32 and np.array_equal(back["arr"], obj["arr"]) and back["empty"].shape == (0, 0)
     pd.testing.assert_frame_equal(back[3][0], df)
     with pytest.raises(TypeError):
-        rdv._enc({"f": open})
+        rdv.pack_object({"f": open})
+    with pytest.raises(ValueError):
+        rdv.unpack_object(wire[:-5])                       # a truncated frame is refused, not half-read
     assert "import pickle" not in open(rdv.__file__).read()
     with rdv.HostGroup(0, 1) as g:
         assert g.allgather_object(obj)[0]["k"] == (1, 2.5, "s")

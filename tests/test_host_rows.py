@@ -208,6 +208,11 @@ def test_merge_window_matches_unique_ref(oracle):
     G.add_edges_from((f"a{a}", f"r{r}") for a, r in zip(df["Aligned_Cell_Num_Old"], df["Ref_Cell_Num_Old"]))
     want = len(nx.bipartite.hopcroft_karp_matching(G, top_nodes={n for n in G if n[0] == "a"})) // 2
     assert len(out) == want
+    # the matching chosen among equally large ones does not depend on the order the window tables arrive in (ranks deal windows)
+    shuffled = df.sample(frac=1.0, random_state=3).reset_index(drop=True)
+    out2 = merge_window_matches_unique_ref([shuffled.iloc[150:], shuffled.iloc[:150]])
+    key = ["Aligned_Cell_Num_Old", "Ref_Cell_Num_Old"]
+    assert out[key].to_numpy().tolist() == out2[key].to_numpy().tolist()
     # a duplicated (aligned, ref) pair keeps the non-violating row, then the smaller window id
     d = pd.DataFrame({"window_id": [3, 1, 2], "Aligned_Cell_Num_Old": [7, 7, 7], "Ref_Cell_Num_Old": [9, 9, 9], "X": 0.0, "Y": 0.0,
                       "filtered_violation": [False, True, False]})
