@@ -450,9 +450,7 @@ class Problem:
         L.same_sweep_unbind(self.sweep)
         L.same_knn_index_destroy(self.knn_index)
         if self.sharded is not None:
-            for b in vars(self.sharded).values():
-                if hasattr(b, "free"):
-                    b.free()
+            self.sharded.close()
         for b in self.bufs:
             b.free()
         if self.own_dense and not keep_dense:
@@ -1014,10 +1012,14 @@ def run_cfg5(args, group, json_fd):
     from same_amd.merge import merge_window_matches_unique_ref
     from same_amd.windows import Section, assign_windows, iter_window_arrays, window_plan
 
+    from same_amd.dist import allgather_table
+
     _trace.enable(True)
     _lib.instrument()
     local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
     os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
+    ctx = _lib.default_context()
+    comm, transport = make_comm(args, group, ctx)        # the table exchange is a device all-gather (RCCL; host transport if that fails)
     n, T = int(args.cfg5_cells), 8
     ref = synth.make_cells(n, T, seed=0)
     mov = synth.make_jittered(ref, seed=1)
@@ -1030,6 +1032,8 @@ def run_cfg5(args, group, json_fd):
     my_plan = [plan[q] for q in mine]
     note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)}")
 
+    TABLE_COLUMNS = (("Aligned_Cell_Num_Old", np.int64), ("Ref_Cell_Num_Old", np.int64), ("X", np.float64), ("Y", np.float64),
+                     ("filtered_violation", bool), ("window_id", np.int64))
     ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
     ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
 
@@ -1072,11 +1076,13 @@ def run_cfg5(args, group, json_fd):
 
     def step():
         tabs, stats = one_pass(my_plan)
-        mine_tab = pd.DataFrame({k: np.concatenate([t[k] for t in tabs]) for k in tabs[0]}) if tabs else pd.DataFrame()
-        with _trace.stage("table exchange (host group)"):
-            every = group.allgather_object(mine_tab)                     # the ONE exchange: one frame per rank, host channel
+        mine_tab = {c: (np.concatenate([t[c] for t in tabs]) if tabs else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
+        mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
+        with _trace.stage("table exchange (all-gather)"):
+            every = allgather_table(ctx, comm, group, mine_tab)          # the ONE exchange: one table per rank, a device all-gather
         with _trace.stage("merge (device de-duplication + host matching)"):
-            merged = merge_window_matches_unique_ref([t for t in every if len(t)])
+            frames = [pd.DataFrame(dict(t, filtered_violation=t["filtered_violation"].astype(bool))) for t in every if len(t["X"])]
+            merged = merge_window_matches_unique_ref(frames)
         return merged, stats
 
     for _ in range(args.warmup):
@@ -1099,6 +1105,7 @@ def run_cfg5(args, group, json_fd):
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
                 "triangles": int(sum(s["triangles"] for s in stats))}
     every = group.allgather_object(mine_rec)
+    rccl = comm_report(Env(args, group, ctx, ctx, comm, transport), np) if comm is not None else None
     # N=1: two windows through the oracle as the CPU baseline and as the parity check of what the GPU produced for them
     cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
     if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
@@ -1156,7 +1163,8 @@ def run_cfg5(args, group, json_fd):
                "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
                                       f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
                                       "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
-                          "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no data-path collective; one host-channel exchange of the match tables"},
+                          "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
+                                         "ranks' match tables per pass" + (f" ({transport})" if comm is not None else "")},
                "windows_per_s": len(plan) * args.steps / dt,
                "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
                             "host_glue_share": [r["host_glue_share"] for r in every], "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
@@ -1172,8 +1180,12 @@ def run_cfg5(args, group, json_fd):
                                     "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by launch latency and host "
                                     "glue, not by HBM -- see host_glue_share"},
                "cpu_baseline": cpu, "parity_spot_check": parity}
+        if rccl is not None:
+            out["rccl"] = rccl
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()
+    if comm is not None:
+        comm.close()
     group.close()
 
 

@@ -357,6 +357,15 @@ class ShardedSweeps:
                                          ctypes.byref(nviol)), "same_orient_from_flags_dev")
         return checked.value, self.viol[: nviol.value].copy()
 
+    def close(self):
+        """Free the device blocks this object allocated (the bound sweep, the operands and the communicator are the caller's)."""
+        for name in ("flag_l", "flag_g", "edge_l", "edge_g", "tflag_l", "tflag_g", "m3_l", "m3_g", "flip_l", "flip_g", "before_l", "before_g",
+                     "after_l", "after_g", "pflag", "counts"):
+            buf = getattr(self, name, None)
+            if buf is not None:
+                buf.free()
+                setattr(self, name, None)
+
     def download(self):
         """Complete outputs (any rank): dict of host arrays shaped like the single-GPU sweeps' outputs."""
         Tr = self.Tr
@@ -365,6 +374,50 @@ class ShardedSweeps:
                 "counts": self.counts.download((3,), np.uint64).astype(np.int64),
                 "before": self.before_g.download((Tr,), np.float64), "after": self.after_g.download((Tr,), np.float64),
                 "matched3": self.m3_g.download((Tr, 3), np.uint8), "flipped": self.flip_g.download((Tr,), np.uint8)}
+
+
+def allgather_table(ctx, comm, group, table):
+    """One exchange of per-rank tables (dict: column -> 1-D numeric array, all of one length, same columns / dtypes on every
+    rank) as a DEVICE collective: the columns are packed into one byte block per rank, padded to the longest, all-gathered with
+    `comm.allgather_dev` (RCCL over xGMI; `HostTransport` carries the same call where RCCL is not available) and unpacked.
+    -> list of tables in rank order, identical on every rank.  This is the exchange step of the window configuration
+    (BASELINE cfg 5): every rank's central-trimmed match table, once per pass."""
+    import struct
+
+    cols = list(table)
+    arrs = [np.ascontiguousarray(table[c]) for c in cols]
+    n = len(arrs[0]) if arrs else 0
+    if any(len(a) != n or a.ndim != 1 or a.dtype.kind not in "biuf" for a in arrs):
+        raise ValueError("allgather_table carries equal-length 1-D numeric columns only")
+    if comm is None:
+        return [dict(zip(cols, arrs))]
+    blob = struct.pack("<Q", n) + b"".join(a.tobytes() for a in arrs)
+    sizes = [struct.unpack("<Q", p)[0] for p in group.allgather_bytes(struct.pack("<Q", len(blob)))]
+    width = (max(sizes) + 255) & ~255
+    send, recv = ctx.alloc(width), ctx.alloc(width * group.world)
+    try:
+        padded = np.zeros(width, np.uint8)
+        padded[: len(blob)] = np.frombuffer(blob, np.uint8)
+        send.upload(padded)
+        comm.allgather_dev(send, recv, width)
+        ctx.sync()
+        got = recv.download((group.world, width), np.uint8)
+    finally:
+        send.free()
+        recv.free()
+    out = []
+    for r in range(group.world):
+        raw = got[r, : sizes[r]].tobytes()
+        (m,) = struct.unpack_from("<Q", raw, 0)
+        off, part = 8, {}
+        for c, a in zip(cols, arrs):
+            nb = m * a.dtype.itemsize
+            part[c] = np.frombuffer(raw, a.dtype, m, off).copy()
+            off += nb
+        if off != sizes[r]:
+            raise ValueError(f"table of rank {r} does not have the agreed columns")
+        out.append(part)
+    return out
 
 
 # ---- sliding windows over ranks -------------------------------------------------------------------------

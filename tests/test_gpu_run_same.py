@@ -394,6 +394,34 @@ def test_window_arrays_equal_prepared_windows(cost_dtype):
     assert errors >= 1
 
 
+def test_allgather_table_over_a_size_one_rccl_communicator():
+    """dist.allgather_table (the cfg 5 exchange: per-rank match tables as ONE device all-gather) through a real ncclAllGather on
+    a size-1 communicator: columns of different widths and an empty table come back bit for bit; ragged or non-numeric
+    columns are refused.  (Two ranks go through the same code over the host transport in test_bench_cfg5_windows_line[2].)"""
+    from same_amd import _lib
+    from same_amd.dist import RcclGroup, allgather_table
+    from same_amd.rendezvous import HostGroup
+
+    ctx = _lib.Context(0)
+    comm = RcclGroup(ctx, 1, 0, lambda b: b)
+    rng = np.random.default_rng(1)
+    try:
+        with HostGroup(0, 1) as group:
+            for n in (0, 1, 1000, 123_457):
+                t = {"a": rng.integers(-2 ** 62, 2 ** 62, n), "x": rng.random(n), "v": (rng.random(n) < 0.5).astype(np.uint8),
+                     "w": rng.integers(0, 300, n).astype(np.int32)}
+                (back,) = allgather_table(ctx, comm, group, t)
+                assert list(back) == list(t) and all(back[c].dtype == t[c].dtype and np.array_equal(back[c], t[c]) for c in t)
+            with pytest.raises(ValueError):
+                allgather_table(ctx, comm, group, {"a": np.arange(3), "b": np.arange(4)})
+            with pytest.raises(ValueError):
+                allgather_table(ctx, comm, group, {"a": np.array(["x", "y"])})
+            assert allgather_table(ctx, None, group, {"a": np.arange(3)})[0]["a"].tolist() == [0, 1, 2]
+    finally:
+        comm.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_bench_cfg5_windows_line(world):
     """`bench.py --workload cfg5` (BASELINE cfg 5 at reduced size): whole windows dealt to the ranks, fp32 costs, all sweeps per
