@@ -457,7 +457,7 @@ class Problem:
             self.dD.free()
 
 
-def make_comm(args, group, tctx):
+def make_comm(args, group, tctx, what="pruned lists"):
     """The communicator, BEFORE any spread allocation (spread.hip never reuses an address for a mapping, but it cannot speak
     for RCCL's own use of the virtual-memory calls).  -> (comm or None, transport text)."""
     from same_amd.dist import HostTransport, RcclGroup
@@ -492,9 +492,9 @@ def make_comm(args, group, tctx):
     if group.min(ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
         if comm is not None:
             comm.close()
-        return HostTransport(tctx, group), "HOST (loopback TCP) all-gather of pruned lists: RCCL init failed on this node"
+        return HostTransport(tctx, group), f"HOST (loopback TCP) all-gather of {what}: RCCL init failed on this node"
     v = comm.rccl_version()
-    return comm, f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100} all-gather of pruned lists"
+    return comm, f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100} all-gather of {what}"
 
 
 def comm_report(env, np):
@@ -1019,7 +1019,7 @@ def run_cfg5(args, group, json_fd):
     local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
     os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
     ctx = _lib.default_context()
-    comm, transport = make_comm(args, group, ctx)        # the table exchange is a device all-gather (RCCL; host transport if that fails)
+    comm, transport = make_comm(args, group, ctx, what="the ranks' match tables")   # a device all-gather (RCCL; host transport if that fails)
     n, T = int(args.cfg5_cells), 8
     ref = synth.make_cells(n, T, seed=0)
     mov = synth.make_jittered(ref, seed=1)
@@ -1164,7 +1164,7 @@ def run_cfg5(args, group, json_fd):
                                       f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
                                       "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
                           "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
-                                         "ranks' match tables per pass" + (f" ({transport})" if comm is not None else "")},
+                                         "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
                "windows_per_s": len(plan) * args.steps / dt,
                "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
                             "host_glue_share": [r["host_glue_share"] for r in every], "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
