@@ -143,6 +143,22 @@ class GridRows:
         xx, yy = self.x[cand], self.y[cand]
         return np.sort(cand[(xx >= x_min) & (xx < x_max) & (yy >= y_min) & (yy < y_max)])
 
+    def positions(self, x_min, x_max, y_min, y_max, xs, ys):
+        """As rows(), for data kept in GRID order: `xs`, `ys` are the coordinates permuted by `self.order`.  -> (rows ascending,
+        pos) with order[pos] == rows, so `column_in_grid_order[pos]` is the column's values for `rows`.  The candidates of a box
+        are a few contiguous runs of the grid-ordered arrays, so everything a window reads of a million-cell section comes from
+        ~1 MB of neighbouring memory instead of 10^4 cache-missing rows scattered over the whole array."""
+        ix0, ix1 = self._cell(x_min, self.x0, self.nx), self._cell(x_max, self.x0, self.nx)
+        iy0, iy1 = self._cell(y_min, self.y0, self.ny), self._cell(y_max, self.y0, self.ny)
+        st = self.starts
+        runs = [np.arange(st[iy * self.nx + ix0], st[iy * self.nx + ix1 + 1]) for iy in range(iy0, iy1 + 1)]
+        pos = np.concatenate(runs) if runs else np.zeros(0, np.int64)
+        xx, yy = xs[pos], ys[pos]
+        pos = pos[(xx >= x_min) & (xx < x_max) & (yy >= y_min) & (yy < y_max)]
+        rows = self.order[pos]
+        o = np.argsort(rows, kind="stable")
+        return rows[o], pos[o]
+
 
 class Section:
     """One tissue section as columns (no DataFrame): what the window pipeline reads of it.
@@ -155,6 +171,15 @@ class Section:
         self.type_id = None if type_id is None else np.ascontiguousarray(type_id, dtype=np.int32)
         self.size = np.ones(len(self.xy), np.int64) if size is None else np.asarray(size)
         self.grid = GridRows(self.xy[:, 0], self.xy[:, 1])
+        # the same columns once more in GRID order (GridRows.positions): what the window loop gathers from
+        od = self.grid.order
+        self.g_xy, self.g_types, self.g_size = np.ascontiguousarray(self.xy[od]), np.ascontiguousarray(self.types[od]), self.size[od]
+        self.g_x, self.g_y = np.ascontiguousarray(self.g_xy[:, 0]), np.ascontiguousarray(self.g_xy[:, 1])
+        self.g_type_id = None if self.type_id is None else self.type_id[od]
+
+    def window(self, box):
+        """-> (rows ascending, positions into the grid-ordered columns) of the section's points inside the half-open box."""
+        return self.grid.positions(*box, self.g_x, self.g_y)
 
     @classmethod
     def from_frame(cls, df, commonCT):
@@ -210,8 +235,8 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
 
     def prune(w):
         out = WindowArrays(w)
-        rows_r, rows_m = ref.grid.rows(*w["box"]), moving.grid.rows(*w["box"])
-        axy, rxy = moving.xy[rows_m], ref.xy[rows_r]
+        (rows_r, pos_r), (rows_m, pos_m) = ref.window(w["box"]), moving.window(w["box"])
+        axy, rxy = moving.g_xy[pos_m], ref.g_xy[pos_r]
         # the argument checks cKDTree makes for the reference are moot here: GridRows only returns finite points
         r = float(radius)
         if r != r or int(knn) <= 0 or len(rxy) == 0 or len(axy) == 0:
@@ -230,22 +255,23 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
         out.pairs = np.column_stack(((np.cumsum(used_a) - 1)[kp[:, 0]], (np.cumsum(used_r) - 1)[kp[:, 1]])).astype(np.int64)
         out.rows_m, out.rows_r = rows_m[ua], rows_r[ur]
         out.axy, out.rxy = np.ascontiguousarray(axy[ua]), np.ascontiguousarray(rxy[ur])
-        return out, qhull_pool.pool().submit(out.axy)
+        return out, (qhull_pool.pool().submit(out.axy), pos_m[ua], pos_r[ur])
 
-    def finish(out, ticket):
+    def finish(out, staged):
+        ticket, pos_m, pos_r = staged
         with marked("triangulate (wait for helper)"):
             tris = ticket.result()
         with marked("triangle filter"):
-            tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
+            tid = moving.g_type_id[pos_m] if (ignore_same_type_triangles and moving.g_type_id is not None) else None
             out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
                                                        min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
         with marked("triangle weights + source signs"):
-            out.size = moving.size[out.rows_m]
+            out.size = moving.g_size[pos_m]
             sign, weight = ops.tri_sign_weight(out.axy, out.size.astype(np.float64), out.triangles, ctx=ctx)
             out.weights = weight.astype(np.int64) if np.issubdtype(out.size.dtype, np.integer) else weight
             out.signs = sign.astype(np.float64)
         with marked("pair costs"):
-            out.costs = ops.pair_cost(moving.types[out.rows_m], ref.types[out.rows_r], out.axy, out.rxy, out.pairs, dist_ct_coeff,
+            out.costs = ops.pair_cost(moving.g_types[pos_m], ref.g_types[pos_r], out.axy, out.rxy, out.pairs, dist_ct_coeff,
                                       dtype=cost_dtype, ctx=ctx).astype(np.float64, copy=False)
         return out
 
@@ -254,5 +280,5 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
         for nxt in range(q, min(q + 1 + depth, len(plan))):
             if nxt not in ahead:
                 ahead[nxt] = stage(plan[nxt])
-        out, ticket = ahead.pop(q)
-        yield out if out.error is not None else finish(out, ticket)
+        out, staged = ahead.pop(q)
+        yield out if out.error is not None else finish(out, staged)

@@ -26,6 +26,8 @@ def test_grid_rows_equal_the_four_comparisons():
                 want = np.flatnonzero((pts[:, 0] >= x0) & (pts[:, 0] < x1) & (pts[:, 1] >= y0) & (pts[:, 1] < y1))
             got = g.rows(x0, x1, y0, y1)
             assert np.array_equal(got, want), (len(pts), x0, x1, y0, y1)
+            rows, pos = g.positions(x0, x1, y0, y1, pts[g.order, 0], pts[g.order, 1])     # the same query on grid-ordered storage
+            assert np.array_equal(rows, want) and np.array_equal(g.order[pos], rows)
 
 
 def test_section_from_frame_keeps_what_the_pipeline_reads():
@@ -37,5 +39,7 @@ def test_section_from_frame_keeps_what_the_pipeline_reads():
     assert s.xy.flags.c_contiguous and s.types.flags.c_contiguous and s.types.tolist() == [[9.0, 0.1], [8.0, 0.2], [7.0, 0.3]]
     assert s.type_id[0] == s.type_id[2] != s.type_id[1] and s.size.dtype == np.int32
     assert s.grid.rows(0, 2.5, 0, 10).tolist() == [0, 1]
+    rows, pos = s.window((0, 2.5, 0, 10))
+    assert rows.tolist() == [0, 1] and s.g_types[pos].tolist() == s.types[rows].tolist() and s.g_size[pos].tolist() == [1, 2]
     bare = Section.from_frame(df.drop(columns=["cell_type", "size"]), ["c1"])
     assert bare.type_id is None and bare.size.tolist() == [1, 1, 1] and np.issubdtype(bare.size.dtype, np.integer)
