@@ -671,7 +671,9 @@ def run_rank(args):
                                  "what": f"same_knn_prune_indexed_dev (r={radius:g}, k={k}, caller-held grid index) + same_padded_cost_f64_dev for {rows} aligned rows "
                                          f"against {n_ref} refs, alone on its stream: dense-equivalent pairs covered per second without materialising the matrix "
                                          "(latency / gather-bound, no roofline fraction claimed)"}
-        extras["triangle_maps_and_sweeps"] = {"ms": t_sw * 1e3, "triangles": Tr, "triangles_per_s": Tr / t_sw,
+        sw_bytes = Tr * (74 + (12 + 3 * 40 + 1) + (12 + 12 + 96 + 16 + 4) + (12 + 48 + 12 + 1 + 16) + (12 + 48 + 24 + 1 + 8)) + n_mov   # SURVEY 8d / DESIGN 5 per-unit figures
+        extras["triangle_maps_and_sweeps"] = {"ms": t_sw * 1e3, "triangles": Tr, "triangles_per_s": Tr / t_sw, "touched_bytes": sw_bytes,
+                                              "GBs": sw_bytes / t_sw / 1e9,
                                               "what": "classify + weights / signs + XY-order sweep + area flips + orientation sweep incl. its read-back, alone on its stream"}
         # operating point: loop the dense kernel alone for ~2 s while a side thread reads board power and shader clock
         tel = GpuTelemetry(ctx.pci_bus_id())
