@@ -675,18 +675,20 @@ def run_rank(args):
         extras["triangle_maps_and_sweeps"] = {"ms": t_sw * 1e3, "triangles": Tr, "triangles_per_s": Tr / t_sw, "touched_bytes": sw_bytes,
                                               "GBs": sw_bytes / t_sw / 1e9,
                                               "what": "classify + weights / signs + XY-order sweep + area flips + orientation sweep incl. its read-back, alone on its stream"}
-        # operating point: loop the dense kernel alone for ~2 s while a side thread reads board power and shader clock
+        # operating point: loop the dense kernel alone for a few seconds while a side thread reads board power and shader clock
         tel = GpuTelemetry(ctx.pci_bus_id())
         if tel.available():
             loop_ms = []
             tel.start()
-            t_end = time.perf_counter() + float(os.environ.get("SAME_BENCH_TELEMETRY_S", "2.0"))
+            # six seconds at the metric's size: long enough for steady-state means, and for an outside sampler with a 5 s period
+            # (the driver's gpu_busy probe) to see the card busy at least once; a second for the small test workloads
+            t_end = time.perf_counter() + float(os.environ.get("SAME_BENCH_TELEMETRY_S", "6.0" if float(n_ref) * rows >= 1e9 else "1.0"))
             while time.perf_counter() < t_end:
                 prob.dense_all(timed=loop_ms)
                 prob.dense_time(loop_ms)
             tele = tel.stop()
             tele["dense_ms_during_window"] = float(np.mean([m for m, _ in loop_ms]))
-            tele["what"] = f"dense kernel (T={T}, fp64) looped alone for the window; sysfs read every {tel.period * 1e3:.0f} ms by a side thread"
+            tele["what"] = f"dense kernel (T={T}, fp64) looped alone for the window ({tele.get('window_s', 0):.1f} s); sysfs read every {tel.period * 1e3:.0f} ms by a side thread"
         else:
             tele = {"available": False, "reason": f"no readable power/clock nodes under {tel.dev_dir}"}
         extras["telemetry"] = tele
