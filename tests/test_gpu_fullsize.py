@@ -280,3 +280,28 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
     # an unknown cost dtype is refused at the boundary
     with pytest.raises(ValueError):
         same_amd.prepare_same_inputs(rs, ms, cols, optim_params=dict(op, hip_cost_dtype="float16"), verbose=False)
+
+
+def test_merge_dedup_properties_at_cfg5_scale(env):
+    """The window-merge de-duplication at the size a 1M-cell section produces and beyond (2M rows, past the oracle-in-seconds
+    range used elsewhere), through properties that do not need the oracle: the survivors come out in stable (violation, window,
+    row) order; every (aligned, ref) pair survives exactly once; the survivor of a pair is its minimum in that order; running
+    the survivors through again changes nothing."""
+    _lib, ops, synth = env
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    a = rng.integers(0, 900_000, n).astype(np.int32)
+    r = (a + rng.integers(0, 2, n)).astype(np.int32)               # mostly the same ref per aligned cell: long duplicate runs
+    viol = rng.random(n) < 0.3
+    win = rng.integers(0, 144, n).astype(np.int32)
+    kept = ops.merge_dedup(viol, win, a, r)
+    order_key = (viol[kept].astype(np.int64) << 52) | (win[kept].astype(np.int64) << 32) | kept.astype(np.int64)
+    assert (np.diff(order_key) > 0).all()                                         # stable (violation, window, row) order
+    pair = a.astype(np.int64) << 32 | r.astype(np.int64)
+    assert len(np.unique(pair[kept])) == len(kept) == len(np.unique(pair))       # every pair exactly once
+    full_key = (viol.astype(np.int64) << 52) | (win.astype(np.int64) << 32) | np.arange(n, dtype=np.int64)
+    o = np.lexsort((full_key, pair))
+    first = o[np.r_[True, pair[o][1:] != pair[o][:-1]]]                           # minimum key of every pair
+    assert np.array_equal(np.sort(first), np.sort(kept.astype(np.int64)))
+    again = ops.merge_dedup(viol[kept], win[kept], a[kept], r[kept])
+    assert np.array_equal(again, np.arange(len(kept)))                            # idempotent
