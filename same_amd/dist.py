@@ -376,12 +376,32 @@ class ShardedSweeps:
                 "matched3": self.m3_g.download((Tr, 3), np.uint8), "flipped": self.flip_g.download((Tr,), np.uint8)}
 
 
+def _pack_table(cols, arrs, n):
+    import struct
+
+    return struct.pack("<Q", n) + b"".join(a.tobytes() for a in arrs)
+
+
+def _unpack_table(raw, cols, arrs, rank):
+    import struct
+
+    (m,) = struct.unpack_from("<Q", raw, 0)
+    off, part = 8, {}
+    for c, a in zip(cols, arrs):
+        part[c] = np.frombuffer(raw, a.dtype, m, off).copy()
+        off += m * a.dtype.itemsize
+    if off != len(raw):
+        raise ValueError(f"table of rank {rank} does not have the agreed columns")
+    return part
+
+
 def allgather_table(ctx, comm, group, table):
     """One exchange of per-rank tables (dict: column -> 1-D numeric array, all of one length, same columns / dtypes on every
     rank) as a DEVICE collective: the columns are packed into one byte block per rank, padded to the longest, all-gathered with
     `comm.allgather_dev` (RCCL over xGMI; `HostTransport` carries the same call where RCCL is not available) and unpacked.
     -> list of tables in rank order, identical on every rank.  This is the exchange step of the window configuration
-    (BASELINE cfg 5): every rank's central-trimmed match table, once per pass."""
+    (BASELINE cfg 5): every rank's central-trimmed match table, once per pass.  comm None: one rank, nothing to exchange;
+    ctx None (CPU tests): the same blocks through the host group's byte all-gather."""
     import struct
 
     cols = list(table)
@@ -389,9 +409,11 @@ def allgather_table(ctx, comm, group, table):
     n = len(arrs[0]) if arrs else 0
     if any(len(a) != n or a.ndim != 1 or a.dtype.kind not in "biuf" for a in arrs):
         raise ValueError("allgather_table carries equal-length 1-D numeric columns only")
-    if comm is None:
+    if comm is None and ctx is not None:
         return [dict(zip(cols, arrs))]
-    blob = struct.pack("<Q", n) + b"".join(a.tobytes() for a in arrs)
+    blob = _pack_table(cols, arrs, n)
+    if ctx is None:
+        return [_unpack_table(raw, cols, arrs, r) for r, raw in enumerate(group.allgather_bytes(blob))]
     sizes = [struct.unpack("<Q", p)[0] for p in group.allgather_bytes(struct.pack("<Q", len(blob)))]
     width = (max(sizes) + 255) & ~255
     send, recv = ctx.alloc(width), ctx.alloc(width * group.world)
@@ -405,19 +427,7 @@ def allgather_table(ctx, comm, group, table):
     finally:
         send.free()
         recv.free()
-    out = []
-    for r in range(group.world):
-        raw = got[r, : sizes[r]].tobytes()
-        (m,) = struct.unpack_from("<Q", raw, 0)
-        off, part = 8, {}
-        for c, a in zip(cols, arrs):
-            nb = m * a.dtype.itemsize
-            part[c] = np.frombuffer(raw, a.dtype, m, off).copy()
-            off += nb
-        if off != sizes[r]:
-            raise ValueError(f"table of rank {r} does not have the agreed columns")
-        out.append(part)
-    return out
+    return [_unpack_table(got[r, : sizes[r]].tobytes(), cols, arrs, r) for r in range(group.world)]
 
 
 # ---- sliding windows over ranks -------------------------------------------------------------------------

@@ -237,6 +237,35 @@ def test_rendezvous_rejects_strangers(tmp_path):
     assert res["got"] == [b"zero", b"one"] == got1
 
 
+def _table_worker(rank, world, rdv, out_dir):
+    _setup_paths()
+    from same_amd.dist import allgather_table
+    from same_amd.rendezvous import HostGroup
+
+    with HostGroup(rank, world, rdv_dir=rdv, timeout=120) as g:
+        rng = np.random.default_rng(100 + rank)
+        n = [0, 7, 1000, 33][rank % 4] + 100 * (rank == world - 1)           # ragged: an empty table and different lengths
+        mine = {"Aligned": rng.integers(0, 2 ** 62, n), "X": rng.random(n), "viol": (rng.random(n) < 0.5).astype(np.uint8),
+                "window_id": np.full(n, rank, np.int64)}
+        every = allgather_table(None, None, g, mine)                            # ctx None: the same blocks over the host group
+        ok = len(every) == world
+        for r, t in enumerate(every):
+            want_rng = np.random.default_rng(100 + r)
+            m = [0, 7, 1000, 33][r % 4] + 100 * (r == world - 1)
+            ok = ok and list(t) == list(mine) and np.array_equal(t["Aligned"], want_rng.integers(0, 2 ** 62, m)) and len(t["X"]) == m \
+                and (t["window_id"] == r).all() and t["viol"].dtype == np.uint8
+        g.barrier()
+    open(os.path.join(out_dir, f"t{rank}.txt"), "w").write(str(bool(ok)))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_allgather_table_blocks_over_the_host_group(tmp_path, world):
+    """The packing of dist.allgather_table (the cfg 5 exchange of the ranks' match tables) at several world sizes, ragged and empty
+    tables included -- on the GPU the same blocks travel by ncclAllGather (tests/test_gpu_run_same.py)."""
+    _run_ranks(_table_worker, world, str(tmp_path))
+    assert [(tmp_path / f"t{r}.txt").read_text() for r in range(world)] == ["True"] * world
+
+
 # ---------------------------------------------------------------------------------------------- bench.py launcher
 @pytest.mark.parametrize("world", [2, 8])
 def test_bench_launches_its_own_ranks(world):
