@@ -37,6 +37,26 @@ def _window_codes(window_id):
     return np.unique(w, return_inverse=True)[1].astype(np.int32)
 
 
+def _equality_codes(values):
+    """int32 codes with equal id <=> equal code, for the device de-duplication: the ids themselves when they are small
+    non-negative integers (cell numbers usually are), a hash factorisation otherwise (strings, huge or negative numbers, NaN)."""
+    v = np.asarray(values)
+    if v.dtype.kind in "iu" and (len(v) == 0 or (v.min() >= 0 and v.max() < 2 ** 31)):
+        return v.astype(np.int32)
+    return pd.factorize(v, use_na_sentinel=False)[0].astype(np.int32)
+
+
+def _node_numbers(values):
+    """Node numbers for the matching graph in the ORDER of the ids (the reference numbers its nodes through sorted(unique ids),
+    src/helpers.py:760-763) -> (numbers, node count).  Dense-ish non-negative integer ids are their own numbers (ids that do
+    not occur are isolated nodes); anything else is factorised with sorted uniques."""
+    v = np.asarray(values)
+    if v.dtype.kind in "iu" and len(v) and v.min() >= 0 and v.max() < 4 * len(v) + 1024:
+        return v.astype(np.int64), int(v.max()) + 1
+    codes, uniques = pd.factorize(v, sort=True)
+    return codes.astype(np.int64), len(uniques)
+
+
 def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _dedup=None):
     """src/helpers.py:692-815.  `_dedup(viol, window_id, aligned_code, ref_code) -> surviving row indices` defaults to the HIP
     kernel chain (`ops.merge_dedup`); the CPU tests pass the oracle's restatement of the same step."""
@@ -59,20 +79,17 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
 
         _dedup = ops.merge_dedup
     kept = _dedup(merged_df["filtered_violation"].to_numpy(), _window_codes(merged_df["window_id"].to_numpy()),
-                  pd.factorize(merged_df[aligned_col].values, use_na_sentinel=False)[0].astype(np.int32),
-                  pd.factorize(merged_df[ref_col].values, use_na_sentinel=False)[0].astype(np.int32))
+                  _equality_codes(merged_df[aligned_col].values), _equality_codes(merged_df[ref_col].values))
     merged_df = merged_df.iloc[np.asarray(kept, dtype=np.int64)]
-    a_codes, a_uniques = pd.factorize(merged_df[aligned_col].values, sort=True)
-    r_codes, _ = pd.factorize(merged_df[ref_col].values, sort=True)
-    n_a, n_r = len(a_uniques), int(r_codes.max()) + 1 if len(r_codes) else 0
-    graph = csr_matrix((np.ones(len(a_codes), np.int8), (a_codes, r_codes)), shape=(n_a, n_r))
+    (a_codes, n_a), (r_codes, n_r) = _node_numbers(merged_df[aligned_col].values), _node_numbers(merged_df[ref_col].values)
+    # every edge carries its frame row (+1: an explicit zero would be dropped), so the rows of the matched edges can be read off
+    # the matrix afterwards without a second sort or a Python dict over a table of 10^6 rows; edges are unique after the
+    # de-duplication, so nothing is summed
+    graph = csr_matrix((np.arange(1, len(a_codes) + 1, dtype=np.int64), (a_codes, r_codes)), shape=(n_a, n_r))
     graph.sort_indices()   # node numbers come from the sorted ids and every adjacency list is sorted: the matching chosen among equally
                            # large ones depends on the ids alone, not on the order the window tables arrived in (1 rank or 8)
-    match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref index matched to each aligned node, -1 = none
-    # the frame row of every matched (aligned, ref) edge, aligned ids ascending (:799-808).  Edges are unique after the
-    # de-duplication, so a sorted edge key finds the row without a Python dict over a table of 10^6 rows
-    a_sel = np.flatnonzero(match_r >= 0)
-    edge_key = a_codes.astype(np.int64) * max(n_r, 1) + r_codes
-    order = np.argsort(edge_key, kind="stable")
-    selected = order[np.searchsorted(edge_key[order], a_sel.astype(np.int64) * max(n_r, 1) + match_r[a_sel])]
+    match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref node matched to each aligned node, -1 = none (structure only)
+    node_of_edge = np.repeat(np.arange(n_a, dtype=np.int64), np.diff(graph.indptr))
+    matched_edge = match_r[node_of_edge] == graph.indices                 # CSR order = aligned ids ascending (:799-808)
+    selected = graph.data[matched_edge] - 1
     return merged_df.iloc[selected].copy().reset_index(drop=True)
