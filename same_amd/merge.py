@@ -80,8 +80,8 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
         _dedup = ops.merge_dedup
     kept = _dedup(merged_df["filtered_violation"].to_numpy(), _window_codes(merged_df["window_id"].to_numpy()),
                   _equality_codes(merged_df[aligned_col].values), _equality_codes(merged_df[ref_col].values))
-    merged_df = merged_df.iloc[np.asarray(kept, dtype=np.int64)]
-    (a_codes, n_a), (r_codes, n_r) = _node_numbers(merged_df[aligned_col].values), _node_numbers(merged_df[ref_col].values)
+    kept = np.asarray(kept, dtype=np.int64)     # rows of merged_df that survive, in the order the reference's frame has after :748-753
+    (a_codes, n_a), (r_codes, n_r) = _node_numbers(merged_df[aligned_col].values[kept]), _node_numbers(merged_df[ref_col].values[kept])
     # every edge carries its frame row (+1: an explicit zero would be dropped), so the rows of the matched edges can be read off
     # the matrix afterwards without a second sort or a Python dict over a table of 10^6 rows; edges are unique after the
     # de-duplication, so nothing is summed
@@ -91,5 +91,5 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
     match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref node matched to each aligned node, -1 = none (structure only)
     node_of_edge = np.repeat(np.arange(n_a, dtype=np.int64), np.diff(graph.indptr))
     matched_edge = match_r[node_of_edge] == graph.indices                 # CSR order = aligned ids ascending (:799-808)
-    selected = graph.data[matched_edge] - 1
-    return merged_df.iloc[selected].copy().reset_index(drop=True)
+    selected = graph.data[matched_edge] - 1                                # positions in `kept`
+    return merged_df.iloc[kept[selected]].reset_index(drop=True)          # ONE gather of the frame: the rows of the matched edges
