@@ -97,7 +97,9 @@ def dense_cost_q32(A, R, axy, rxy, w, row_begin=0, row_end=None, grid=None, rel_
     ld = (n_r + 1) & ~1
     with ctx.lock:
         dA, dR, dax, drx = ctx.to_device(A), ctx.to_device(R), ctx.to_device(axy), ctx.to_device(rxy)
-        dAq, dRq, dout = ctx.alloc(max(A.size, 1) * 4), ctx.alloc(max(R.size, 1) * 4), ctx.alloc_spread(rows * ld * 8)
+        # a plain block: the tile goes back over PCIe, which is what bounds this host-buffer form (HBM placement, same_dev_alloc_spread,
+        # only matters for blocks that stay resident -- callers of the _dev entry points choose it themselves)
+        dAq, dRq, dout = ctx.alloc(max(A.size, 1) * 4), ctx.alloc(max(R.size, 1) * 4), ctx.alloc(rows * ld * 8)
         ctx.check(ctx.lib.same_quantize_u32_dev(ctx.handle, dA.ptr, A.size, offset, scale, dAq.ptr), "same_quantize_u32_dev")
         ctx.check(ctx.lib.same_quantize_u32_dev(ctx.handle, dR.ptr, R.size, offset, scale, dRq.ptr), "same_quantize_u32_dev")
         ctx.check(ctx.lib.same_dense_cost_q32_dev(ctx.handle, dAq.ptr, dRq.ptr, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_r, int(row_begin),
