@@ -81,7 +81,7 @@ struct Timer {
     same_ctx *ctx;
     int rc = SAME_OK;
     // events of its own: the context's ev0 / ev1 belong to same_timer_start / stop, which a caller may have open around
-    // an allocation (ops.dense_cost_q32 allocates inside a region callers time)
+    // an allocation (a caller may well allocate its output block inside a region it is timing)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     explicit Timer(same_ctx *c) : ctx(c) {
         if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) rc = SAME_EIO;

@@ -149,7 +149,7 @@ def test_time_bound_stops_the_search_not_the_allocation(ctx, monkeypatch):
 
 def test_labelling_leaves_an_open_timer_alone(ctx):
     """The labelling stores are timed with events of their own: a same_timer_start .. same_timer_stop pair open around a spread
-    allocation measures what the caller enqueued, not a labelling store (ops.dense_cost_q32 allocates inside timed regions)."""
+    allocation measures what the caller enqueued, not a labelling store (callers do allocate output blocks inside regions they time)."""
     ms = ctypes.c_float(0)
     ctx.check(ctx.lib.same_timer_start(ctx.handle), "timer")
     b = ctx.alloc_spread(8 << 30)
