@@ -56,6 +56,10 @@ WORKLOADS = {
     "tiny": (4_000, 4_000, 20, 32, 25.0),
     "cfg5": None,              # sliding windows, see run_cfg5
 }
+# what the line carries at N > 1 on top of the N = 1 keys, so that the one 8-GPU run explains itself (checked before the line is written;
+# listed by --dry-launch so the CPU suite can hold the contract)
+N_GT1_KEYS = ("rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank")
+N_GT1_STRONG_KEYS = ("config", "scaling", "value", "ms_per_step", "dense_kernel_ms", "per_rank_dense_ms", "gather", "gather_hidden_ms", "parity_spot_check")
 STRONG_OF = {"dense100k": "cfg4"}   # the ONE-problem configuration embedded after a weak run of the key (else: the same shape)
 STRONG_CHUNK_BYTES = 40e9  # dense buffer of the strong mode (25k rows x 200k refs x 8 B)
 
@@ -556,8 +560,9 @@ def run_rank(args):
         mx = group.max(float(group.rank + 1))
         ranks = group.allgather_object({"rank": group.rank, "pid": os.getpid(), "id_ok": uid == bytes(range(128))})
         if group.rank == 0:
-            os.write(json_fd, (json.dumps({"dry_launch": True, "world": group.world, "max_of_rank_plus_1": mx,
-                                           "ranks": ranks}) + "\n").encode())
+            os.write(json_fd, (json.dumps({"dry_launch": True, "world": group.world, "max_of_rank_plus_1": mx, "ranks": ranks,
+                                           "line_keys_at_n_gt_1": list(N_GT1_KEYS) + ["strong_cfg4"],
+                                           "strong_record_keys": list(N_GT1_STRONG_KEYS)}) + "\n").encode())
         group.barrier()
         group.close()
         return
@@ -986,6 +991,12 @@ def run_rank(args):
             out["per_rank"] = per_rank
             if strong_rec is not None:
                 out["strong_cfg4" if STRONG_OF.get(args.workload) == "cfg4" else "strong_record"] = strong_rec
+                missing = [k for k in N_GT1_STRONG_KEYS if k not in strong_rec]
+                if missing:
+                    raise SystemExit(f"the embedded strong record lacks {missing}")
+            missing = [k for k in N_GT1_KEYS if out.get(k) is None and k != "gather_hidden_ms"]
+            if missing:
+                raise SystemExit(f"the N > 1 line lacks {missing}")
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
     if prob is not None:

@@ -281,6 +281,9 @@ def test_bench_launches_its_own_ranks(world):
     assert d["world"] == world and d["max_of_rank_plus_1"] == float(world)
     assert [r["rank"] for r in d["ranks"]] == list(range(world)) and all(r["id_ok"] for r in d["ranks"])
     assert len({r["pid"] for r in d["ranks"]}) == world            # fresh processes, one per rank
+    # the contract of the real N > 1 line (bench.py refuses to write a line that lacks one of these; the GPU suite checks their contents)
+    assert set(d["line_keys_at_n_gt_1"]) == {"rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank", "strong_cfg4"}
+    assert {"value", "ms_per_step", "gather", "gather_hidden_ms", "per_rank_dense_ms", "parity_spot_check"} <= set(d["strong_record_keys"])
 
 
 @pytest.mark.parametrize("world", [2, 8])
