@@ -1013,8 +1013,8 @@ def run_cfg5(args, group, json_fd):
     """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
     round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
     on the column pipeline (same_amd.windows.iter_window_arrays: no DataFrame per window),
-    the per-window match tables exchanged ONCE over the host group and merged (src/helpers.py:692-815, de-duplication on the
-    GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
+    every rank's central-trimmed match table exchanged in ONE device all-gather (dist.allgather_table) and merged
+    (src/helpers.py:692-815, de-duplication on the GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
     (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
     One step = the whole plan once (every rank its share) + the exchange + the merge.  value = dense-equivalent cell pairs
     (sum over windows of aligned x ref cells in the window) per second; `windows_per_s` per rank and the share of the step
@@ -1025,9 +1025,8 @@ def run_cfg5(args, group, json_fd):
     import same_amd
     from same_amd import _lib, _trace, ops, synth
     from same_amd.merge import merge_window_matches_unique_ref
-    from same_amd.windows import Section, assign_windows, iter_window_arrays, window_plan
-
     from same_amd.dist import allgather_table
+    from same_amd.windows import Section, assign_windows, iter_window_arrays, window_plan
 
     _trace.enable(True)
     _lib.instrument()
