@@ -76,6 +76,17 @@ int main(void) {
            mem_total / 1073741824.0, info[0] ? "spread" : "plain", D[0], NM - 1, NR - 1, D[(NM - 1) * ld + NR - 1]);
     void *blocks[] = {dA, dR, dax, drx, dD};
     for (int q = 0; q < 5; ++q) CHECK(same_dev_free(ctx, blocks[q]));
+    /* window merge, the de-duplication step (src/helpers.py:745-753): three windows propose matches; pair (aligned 4, ref 9) comes from
+     * windows 2, 0 and 1 -- the non-violating proposals win, then the smaller window id: row 3 survives, rows 0 and 5 do not */
+    const uint8_t mviol[6] = {0, 1, 0, 0, 1, 1};
+    const int32_t mwin[6] = {2, 0, 1, 0, 2, 1}, ma[6] = {4, 7, 5, 4, 6, 4}, mr[6] = {9, 8, 3, 9, 1, 9};
+    int32_t mrows[6];
+    int64_t mkept = 0;
+    CHECK(same_merge_dedup(ctx, mviol, mwin, ma, mr, 6, mrows, &mkept));
+    printf("merge de-duplication keeps %lld of 6 rows:", (long long)mkept);
+    for (int q = 0; q < mkept; ++q) printf(" %d", mrows[q]);
+    printf("\n");
+    if (mkept != 4 || mrows[0] != 3 || mrows[1] != 2 || mrows[2] != 1 || mrows[3] != 4) return 4;
     /* error convention: a bad index is reported, not dereferenced */
     int32_t bad[2] = {0, 99};
     int rc = same_pair_cost_f64(ctx, A, R, NM, NR, T, axy, rxy, bad, 1, 1.0, cost);

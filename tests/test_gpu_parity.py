@@ -882,7 +882,7 @@ def test_release_scratch_and_rebind(ops, oracle):
 
 
 def test_plain_c_abi_demo_runs(tmp_path):
-    """The C ABI from a plain C11 program: prune, pair costs, sign, bind, sweep, error code."""
+    """The C ABI from a plain C11 program: prune, pair costs, sign, bind, sweep, dense tile, window-merge de-duplication, error code."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "abi_demo"
@@ -892,6 +892,7 @@ def test_plain_c_abi_demo_runs(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "checked 4 triangles" in r.stdout and "bad pair -> -34" in r.stdout
+    assert "merge de-duplication keeps 4 of 6 rows: 3 2 1 4" in r.stdout
     assert sum(line.startswith("pair (") for line in r.stdout.splitlines()) >= 6
 
 
