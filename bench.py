@@ -165,10 +165,32 @@ def launch(args):
 # ======================================================================================================================
 # one rank
 # ======================================================================================================================
+_LAST_STAGE = ["start"]
+
+
 def note(group, msg):
     """Progress on stderr (rank 0): a cold box can spend minutes in imports / RCCL bootstrap, and stdout is reserved for the line."""
+    _LAST_STAGE[0] = msg
     if group.rank == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def arm_rank_watchdog(rank):
+    """A collective that never completes (a rank lost mid-run, a link that stops moving) has no timeout of its own: after
+    SAME_BENCH_RANK_TIMEOUT seconds (default 900) the rank says where it was and leaves with code 4, so that the launcher (ours or
+    torch.distributed.run) ends the job at once instead of at its own limit, with the GPUs still spinning."""
+    import threading
+
+    limit = float(os.environ.get("SAME_BENCH_RANK_TIMEOUT", "900"))
+
+    def fire():
+        print(f"[rank {rank}] still running after {limit:.0f} s; last stage: {_LAST_STAGE[0]!r}; giving up", file=sys.stderr, flush=True)
+        os._exit(4)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def baseline_metric():
@@ -552,6 +574,7 @@ def run_rank(args):
     if group.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={group.world}")
     local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
+    arm_rank_watchdog(group.rank)
     note(group, f"host group up: world {group.world} (rendezvous: loopback TCP, plain Python)")
 
     if args.dry_launch:   # control-plane check, no GPU: id broadcast, barrier, max -- what the real run does on the host side
@@ -593,6 +616,7 @@ def run_rank(args):
     mov, ref, tris, use_q32 = prob.mov, prob.ref, prob.tris, prob.use_q32
     note(group, f"inputs resident ({rows} of {n_mov} aligned x {n_ref} ref, {Tr} triangles); gather transport: {transport}")
 
+    note(group, f"warm-up ({args.warmup}) + timed loop ({args.steps} steps)")
     dt, dense_ms = prob.timed_loop(args.steps, args.warmup)
     note(group, f"{args.steps} steps in {dt:.3f} s")
 
@@ -601,6 +625,7 @@ def run_rank(args):
     if comm is not None:
         gather_steps = list(prob.gather_ms)
         steps_ng = max(1, min(args.steps, 5))
+        note(group, "second loop without the candidate-list gather")
         dt_ng, _ = prob.timed_loop(steps_ng, 1, gather=False)       # the same step without the candidate-list gather
         prob.gather_ms = gather_steps
         gather, gather_hidden_ms = gather_report(prob, dt, args.steps, dt_ng, steps_ng)
@@ -620,6 +645,8 @@ def run_rank(args):
     match = prob.dmatch.download((n_mov,), np.int32)
     extras = {}
     if group.rank == 0 and group.world == 1 and not args.no_extras and not strong:
+        note(group, "ceilings, telemetry window, T sweep (after the timed region)")
+
         def timed_ms(call, what, reps=5):
             out = []
             for _ in range(reps + 1):
