@@ -26,6 +26,7 @@ for f in ("pp_dpm_sclk", "pp_dpm_mclk", "gpu_busy_percent", "current_compute_par
     except Exception as e: print(f, "ERR", e)
 PY
 echo "== pytest -m gpu" && timeout -k 10 1000 python3 -m pytest tests -m gpu -q --durations=15 > $out/pytest_gpu.log 2>&1; rc=$?; tail -5 $out/pytest_gpu.log; [ $rc -eq 0 ] || exit $rc
+echo "== smoke" && timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
 echo "== bench (default)" && timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 tail -3 $out/bench.err
 echo "== bench forced communicator (size-1 RCCL), which librccl" && SAME_BENCH_FORCE_COMM=1 NCCL_DEBUG=VERSION timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extras --steps 5 > $out/bench_comm.json 2> $out/bench_comm.err || { tail -20 $out/bench_comm.err; exit 1; }
