@@ -590,6 +590,8 @@ def run_rank(args):
         group.close()
         return
 
+    from scipy.spatial import Delaunay
+
     from same_amd import _lib, synth
     from same_amd.telemetry import GpuTelemetry
 
@@ -707,6 +709,40 @@ def run_rank(args):
         extras["triangle_maps_and_sweeps"] = {"ms": t_sw * 1e3, "triangles": Tr, "triangles_per_s": Tr / t_sw, "touched_bytes": sw_bytes,
                                               "GBs": sw_bytes / t_sw / 1e9,
                                               "what": "classify + weights / signs + XY-order sweep + area flips + orientation sweep incl. its read-back, alone on its stream"}
+        # SURVEY 8d's second input variant: moving = refs + N(0, 2^2) jitter with 5 % of the rows dropped, matched by the greedy MIP
+        # start (src/init_helpers.py:104-133) -- a realistic matching, so the sweeps see few, local flips instead of the dense
+        # disorder of two independent sections.  Through the host-buffer entry points (PCIe included), one pass, untimed region.
+        from same_amd import ops as _ops
+
+        jm = synth.make_jittered(ref, seed=1)
+        jt = np.ascontiguousarray(Delaunay(jm["xy"]).simplices, dtype=np.int32)
+        j0 = time.perf_counter()
+        jidx, _, _ = _ops.knn_prune(jm["xy"], ref["xy"], radius, k, want_d2=False, ctx=tctx)
+        jr, jc = np.nonzero(jidx >= 0)
+        jpairs = np.column_stack((jr, jidx[jr, jc])).astype(np.int32)
+        jcost = _ops.pair_cost(jm["types"], ref["types"], jm["xy"], ref["xy"], jpairs, 1.0, ctx=tctx)
+        jwants = _ops.pair_rowmin(jpairs, jcost, len(jm["xy"]), ctx=tctx) < 100.0
+        jpor, jrounds = _ops.greedy_match(jpairs, jcost, len(jm["xy"]), n_ref, jwants, ctx=tctx)
+        j1 = time.perf_counter()
+        jmatch = np.full(len(jm["xy"]), -1, np.int32)
+        jai = np.flatnonzero(jpor >= 0)
+        jmatch[jai] = jpairs[jpor[jai], 1]
+        jsign, _ = _ops.tri_sign_weight(jm["xy"], jm["size"], jt, ctx=tctx)
+        jsw = _ops.BoundSweep(jt, jsign, ref["xy"], len(jm["xy"]), ctx=tctx)
+        j2 = time.perf_counter()
+        jchecked, jviol = jsw.sweep_match(jmatch)
+        j3 = time.perf_counter()
+        jsw.close()
+        _je, _jtf, jpf, jcounts = _ops.xyorder_sweep(jm["xy"], ref["xy"], jt, jmatch, ctx=tctx)
+        _jb, _ja, _jm3, jflip = _ops.area_flip(jm["xy"], ref["xy"], jt, jmatch, ctx=tctx)
+        j4 = time.perf_counter()
+        extras["realistic_matching"] = {
+            "what": f"moving = refs + N(0, 2^2) jitter, 5 % of rows dropped ({len(jm['xy'])} aligned cells, {len(jt)} triangles); prune (r={radius:g}, k={k}) + "
+                    "fp64 pair costs + greedy MIP start on the device, then the three sweeps under that matching; host-buffer entry points, one pass",
+            "pairs": int(len(jpairs)), "matched_rows": int(len(jai)), "greedy_rounds": int(jrounds), "prune_costs_start_ms": (j1 - j0) * 1e3,
+            "orientation_sweep_ms": (j3 - j2) * 1e3, "orientation_checked": int(jchecked), "orientation_flipped": int(len(jviol)),
+            "xyorder_and_area_ms": (j4 - j3) * 1e3, "xy_comparisons": int(jcounts[0]), "xy_violations": int(jcounts[1]),
+            "points_with_violations": int(np.count_nonzero(jpf)), "area_flips": int(np.count_nonzero(jflip))}
         # operating point: loop the dense kernel alone for a few seconds while a side thread reads board power and shader clock
         tel = GpuTelemetry(ctx.pci_bus_id())
         if tel.available():
@@ -974,7 +1010,7 @@ def run_rank(args):
                               f"(VALU busy {roof['valu_busy_frac']:.2f}): the bound of this kernel is fp64 issue under the board power cap, not HBM"))
             else:
                 msg.append("board power / clock could not be read from sysfs on this box")
-        for key in ("pruned_path", "triangle_maps_and_sweeps"):
+        for key in ("pruned_path", "triangle_maps_and_sweeps", "realistic_matching"):
             if key in extras:
                 roof[key] = extras[key]
         if "sweep" in extras:

@@ -298,6 +298,8 @@ def test_bench_contract_line(force_comm):
         assert rf["measured_ceilings"]["device_copy_GBs"] > 0 and rf["frac_of_measured_copy_bw"] > 0
         assert "verified" in rf["output_buffer"]
         assert rf["pruned_path"]["cell_pairs_per_s"] > out["value"] and rf["triangle_maps_and_sweeps"]["triangles_per_s"] > 0
+        rm = rf["realistic_matching"]        # jittered copy + greedy start: most rows matched, few flips among many checked triangles
+        assert rm["matched_rows"] > 0.8 * 0.9 * 4000 and rm["orientation_checked"] > 1000 and rm["orientation_flipped"] < 0.2 * rm["orientation_checked"]
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
         assert "equal the oracle bit-for-bit" in out["parity_spot_check"]
