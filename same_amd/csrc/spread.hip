@@ -172,7 +172,6 @@ void same_spread_release(same_spread_alloc &a) {
     a.va = nullptr;
 }
 
-// The virtual-memory path proper.  Leaves nothing behind on failure (every chunk given back).
 static double env_seconds(const char *name, double dflt) {
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
@@ -181,6 +180,7 @@ static double env_seconds(const char *name, double dflt) {
     return (end != v && x > 0.0) ? x : dflt;
 }
 
+// The virtual-memory path proper.  Leaves nothing behind on failure (every chunk given back).
 static int spread_build(same_ctx *ctx, size_t n_need, size_t budget, void **out_dptr, int64_t *info) {
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
