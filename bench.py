@@ -82,6 +82,7 @@ def parse():
                     help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
+    ap.add_argument("--cfg5-threads", type=int, default=2, help="--workload cfg5: worker threads (contexts) walking this rank's windows")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:
@@ -1114,23 +1115,23 @@ def run_cfg5(args, group, json_fd):
     ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
     ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
 
-    def run_window(wa):
+    def run_window(wa, wctx):
         """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
         w, pairs = wa.window, wa.pairs.astype(np.int32)
         # greedy MIP start (src/init_helpers.py:104-133) in its flat device form: per-row minimum, rows that beat their
         # no-match penalty, the scan's matching -> one pair index per aligned row
-        wants = ops.pair_rowmin(pairs, wa.costs, wa.n_aligned) < 100.0 * wa.size.astype(float)
-        pair_of_row, _rounds = ops.greedy_match(pairs, wa.costs, wa.n_aligned, wa.n_ref, wants)
+        wants = ops.pair_rowmin(pairs, wa.costs, wa.n_aligned, ctx=wctx) < 100.0 * wa.size.astype(float)
+        pair_of_row, _rounds = ops.greedy_match(pairs, wa.costs, wa.n_aligned, wa.n_ref, wants, ctx=wctx)
         ai = np.flatnonzero(pair_of_row >= 0)
         ri = pairs[pair_of_row[ai], 1].astype(np.int64)
         match = np.full(wa.n_aligned, -1, np.int32)
         match[ai] = ri
-        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned)      # the lazy-constraint body (src/same.py:645-669)
+        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned, ctx=wctx)      # the lazy-constraint body (src/same.py:645-669)
         checked, viol = sw.sweep_match(match)
         sw.close()
         # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms
-        _edge, _tflag, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match)
-        _before, _after, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match)
+        _edge, _tflag, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
+        _before, _after, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
         x, y = wa.axy[ai, 0], wa.axy[ai, 1]
         tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
         c = np.flatnonzero((x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
@@ -1139,17 +1140,43 @@ def run_cfg5(args, group, json_fd):
         return tab, {"pairs": len(pairs), "triangles": len(wa.triangles), "checked": int(checked), "flipped": len(viol),
                      "xy_violations": int(counts[1]), "area_flips": int(np.count_nonzero(flipped))}
 
-    def one_pass(windows):
-        tabs, stats = [], []
+    # The windows of a pass are independent and the host work per window (numpy index work, ~7 ms) dwarfs its kernels (~0.3 ms), so
+    # the rank walks its windows with --cfg5-threads workers, each with a context (= stream) of its own; numpy and the library calls
+    # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
+    n_workers = max(1, int(args.cfg5_threads))
+    worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
+
+    def walk(windows, wctx, out):
         for wa in iter_window_arrays(ref_sec, mov_sec, windows, radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
-                                     ignore_same_type_triangles=True, cost_dtype=np.float32):
+                                     ignore_same_type_triangles=True, cost_dtype=np.float32, ctx=wctx):
             if wa.error is not None:              # a window whose prune leaves no pairs (src/same.py:1003)
                 continue
             with _trace.stage("incumbent + sweeps + table (bench step)"):
-                t, st = run_window(wa)
-            tabs.append(t)
-            stats.append(st)
-        return tabs, stats
+                out.append((wa.window["window_id"], *run_window(wa, wctx)))
+
+    def one_pass(windows):
+        import threading
+
+        outs = [[] for _ in range(n_workers)]
+        if n_workers == 1:
+            walk(windows, ctx, outs[0])
+        else:
+            errors = []
+
+            def guarded(q):
+                try:
+                    walk(windows[q::n_workers], worker_ctx[q], outs[q])
+                except BaseException as e:   # noqa: BLE001 -- re-raised in the main thread below
+                    errors.append(e)
+
+            threads = [threading.Thread(target=guarded, args=(q,)) for q in range(n_workers)]
+            [t.start() for t in threads]
+            [t.join() for t in threads]
+            if errors:
+                raise errors[0]
+        pos = {w["window_id"]: q for q, w in enumerate(windows)}
+        done = sorted((r for part in outs for r in part), key=lambda r: pos[r[0]])
+        return [r[1] for r in done], [r[2] for r in done]
 
     def step():
         tabs, stats = one_pass(my_plan)
@@ -1178,7 +1205,7 @@ def run_cfg5(args, group, json_fd):
     stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
     lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * args.steps / wall_here,
-                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / wall_here,
+                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / (wall_here * n_workers), "threads": n_workers,
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
                 "triangles": int(sum(s["triangles"] for s in stats))}
     every = group.allgather_object(mine_rec)
@@ -1246,8 +1273,9 @@ def run_cfg5(args, group, json_fd):
                "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
                             "host_glue_share": [r["host_glue_share"] for r in every], "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
                "host_glue_share": mine_rec["host_glue_share"],
-               "host_glue_share_means": "1 - (wall time inside libsame_hip calls) / (wall time of the timed loop), rank 0: Python / pandas / scipy glue, "
-                                        "waiting for the Qhull helpers and the table exchange included",
+               "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
+                                        "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
+               "threads_per_rank": n_workers,
                "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
                "merged_matches": int(len(merged)),
                "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (pair_cost_kernel<float> is the largest)",
@@ -1261,6 +1289,8 @@ def run_cfg5(args, group, json_fd):
             out["rccl"] = rccl
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()
+    for c in worker_ctx[1:]:
+        c.close()
     if comm is not None:
         comm.close()
     group.close()
