@@ -82,7 +82,7 @@ def parse():
                     help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
-    ap.add_argument("--cfg5-threads", type=int, default=3, help="--workload cfg5: worker threads (contexts) walking this rank's windows")
+    ap.add_argument("--cfg5-threads", type=int, default=4, help="--workload cfg5: worker threads (contexts) walking this rank's windows")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:

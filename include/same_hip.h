@@ -42,7 +42,7 @@ extern "C" {
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
-#define SAME_ABI_VERSION 3
+#define SAME_ABI_VERSION 4
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
@@ -355,6 +355,48 @@ int same_eager_signs(same_ctx *ctx, const double *rxy, int64_t n_r, const int32_
  * half-open.  out_count[b] = rows inside; out_mask (may be NULL) [n_boxes][n]. */
 int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *boxes,
                       int64_t n_boxes, int64_t *out_count, uint8_t *out_mask);
+
+/* ---- a13 + the per-window pre-MIP path with the sections resident on the device -------------
+ * The reference's window loop (src/same.py:507-593) subsets both frames per window (:293-295) and runs the whole
+ * pre-MIP path on the subset.  A same_section is one section's columns uploaded once (XY, the commonCT type columns,
+ * cell sizes; cost_f32 != 0 keeps the cost operands as float, BASELINE cfg 5); a same_window is the device state of one
+ * window in flight (buffers grow on demand and are reused).  Two calls per window:
+ *   same_window_stage: rows of both sections inside box = {x0,x1,y0,y1} (half-open, ascending row order), radius / k
+ *     prune (src/utils.py:709-728), candidate costs (src/same.py:1180-1189), compaction of the aligned cells that have
+ *     candidates and of the pair list (src/utils.py:734-742).  out_counts[4] = {aligned rows in the box, reference rows
+ *     in the box, aligned rows kept, pairs}.  Reference cells are not renumbered: pair[1] / match index the window's
+ *     reference rows.  With no aligned or no reference row in the box nothing else is computed (kept = pairs = 0).
+ *   same_window_finish: the caller's kept Delaunay triangles of the kept aligned cells (src/same.py:1023, filtered as
+ *     :1040-1060) -> source signs / weights (:1128-1146), greedy MIP start with prefer = rowmin < no_match_penalty * size
+ *     (src/init_helpers.py:104-133), lazy-constraint body (:645-669), XY-order sweep (src/violationhelper.py:53-117), area
+ *     flips (:1362-1402).  out_match_row[kept] = SECTION row of the matched reference cell or -1, out_point_flag[kept] =
+ *     the XY-order sweep's per-cell flag, out_stats[8] = {orientation checked, flipped, XY comparisons, XY violations,
+ *     triangles with a violation, area flips, greedy rounds, matched cells}.
+ * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size. */
+typedef struct same_section same_section;
+typedef struct same_window same_window;
+enum {
+    SAME_WINDOW_ALIGNED_XY = 0,   /* double[kept][2]: XY of the kept aligned cells (the Delaunay input)            */
+    SAME_WINDOW_ALIGNED_ROWS = 1, /* int32[kept]: their section rows                                               */
+    SAME_WINDOW_ROWS_M = 2,       /* int32[aligned rows in the box]                                                */
+    SAME_WINDOW_ROWS_R = 3,       /* int32[reference rows in the box]                                              */
+    SAME_WINDOW_PAIRS = 4,        /* int32[pairs][2]: (kept aligned index, reference index in the window)         */
+    SAME_WINDOW_COSTS = 5,        /* double[pairs] (float costs widened)                                           */
+    SAME_WINDOW_KEPT = 6,         /* int32[kept]: index of each kept aligned cell among the box's aligned rows     */
+    SAME_WINDOW_SIGNS = 7,        /* int8[triangles]   (after same_window_finish)                                  */
+    SAME_WINDOW_WEIGHTS = 8,      /* double[triangles] (after same_window_finish)                                  */
+    SAME_WINDOW_MATCH = 9         /* int32[kept]: matched reference index in the window or -1 (after finish)       */
+};
+int same_section_create(same_ctx *ctx, const double *xy, const double *types, int T, const double *size,
+                        int64_t n, int cost_f32, same_section **out);
+void same_section_destroy(same_section *section);
+int same_window_create(same_ctx *ctx, same_window **out);
+void same_window_destroy(same_window *window);
+int same_window_stage(same_window *window, const same_section *moving, const same_section *ref,
+                      const double *box, double radius, int k, double dist_ct_coeff, int64_t *out_counts);
+int same_window_fetch(same_window *window, int what, void *out, int64_t bytes);
+int same_window_finish(same_window *window, const int32_t *tris, int64_t Tr, double no_match_penalty,
+                       int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats);
 
 /* ---- f3: window merge, the de-duplication step ------------------------------------------
  * Replaces src/helpers.py:745-753 (merged_df.sort_values(['filtered_violation', 'window_id'], kind='mergesort') then

@@ -21,7 +21,7 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
 SPREAD_INFO_LEN = 14                           # SAME_SPREAD_INFO_LEN
@@ -92,6 +92,13 @@ _PROTOTYPES = {
     "same_batched_assign": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "same_section_create": [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, ctypes.POINTER(c_vp)],
+    "same_section_destroy": [c_vp],
+    "same_window_create": [c_vp, ctypes.POINTER(c_vp)],
+    "same_window_destroy": [c_vp],
+    "same_window_stage": [c_vp, c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_vp],
+    "same_window_fetch": [c_vp, c_int, c_vp, c_i64],
+    "same_window_finish": [c_vp, c_vp, c_i64, c_dbl, c_vp, c_vp, c_vp],
     "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
     "same_comm_unique_id": [c_vp],
     "same_comm_init": [c_vp, c_int, c_int, c_vp],
@@ -142,6 +149,8 @@ def load():
             L.same_ctx_destroy.restype = None
             L.same_sweep_unbind.restype = None
             L.same_knn_index_destroy.restype = None
+            L.same_section_destroy.restype = None
+            L.same_window_destroy.restype = None
             if L.same_abi_version() != ABI_VERSION:
                 raise SameHipError(-22, "libsame_hip ABI version mismatch")
             _lib = L

@@ -124,3 +124,13 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Host-side index validation: a bad index must come back as SAME_ERANGE, never as a GPU fault.
 int check_index_range(same_ctx *ctx, const int32_t *idx, int64_t n, int64_t lo, int64_t hi, const char *what);
+
+// Device cores shared between the host-buffer entry points and the window pipeline (window.hip): every pointer is a device
+// pointer, the calls enqueue on ctx->stream (same_greedy_core reads one counter back per round).
+int same_pair_rowmin_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, int64_t n_m, double *dout);
+int same_compact_mask_core(same_ctx *ctx, const unsigned long long *dmask, int64_t n_words, int64_t n_items, int32_t *dout_idx,
+                           unsigned long long *dcounters);
+int same_orient_counts_core(same_ctx *ctx, const int32_t *dtris, int64_t Tr, const int8_t *dsign, const double *drxy,
+                            const int32_t *dmatch, uint8_t *dflag, unsigned long long *dmask, unsigned long long *dcnt);
+int same_greedy_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, int64_t n_m, int64_t n_r,
+                     const uint8_t *dprefer, int32_t *dmatch_pair, int *out_rounds);

@@ -298,6 +298,48 @@ __global__ __launch_bounds__(256) void batched_assign_kernel(
 
 }  // namespace
 
+// The greedy MIP start on device-resident pairs / costs / prefer flags: dmatch[n_m] = pair index per aligned row or -1.
+// Shared with the window pipeline (window.hip).  Scratch: SL_FLAG1, SL_FLAG2, SL_OUT0, SL_OUT1, SL_COUNTS and the pinned block;
+// one 8-byte read-back per round decides whether another round is needed.
+int same_greedy_core(same_ctx *ctx, const int32_t *dp, const double *dc, int64_t P, int64_t n_m, int64_t n_r, const uint8_t *dprefer,
+                     int32_t *dmatch, int *out_rounds) {
+    uint8_t *dalive, *durow, *ducol;
+    unsigned long long *drkey, *dckey, *dsel;
+    unsigned *dridx, *dcidx;
+    if (out_rounds) *out_rounds = 0;
+    if (n_m <= 0) return SAME_OK;
+    HIP_TRY(ctx, hipMemsetAsync(dmatch, 0xFF, (size_t)n_m * sizeof(int32_t), ctx->stream));
+    if (P <= 0) return SAME_OK;
+    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)P, &dalive));
+    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_m + n_r, &durow));
+    ducol = durow + n_m;
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_m + n_r, &drkey));
+    dckey = drkey + n_m;
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)n_m + n_r, &dridx));
+    dcidx = dridx + n_m;
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dsel));
+    HIP_TRY(ctx, hipMemsetAsync(durow, 0, (size_t)(n_m + n_r), ctx->stream));
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dprefer, dalive);
+    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
+    const int64_t nmax = n_m > n_r ? n_m : n_r;
+    int rounds = 0;
+    for (;; ++rounds) {
+        REQUIRE(ctx, rounds <= P + 1);  // each productive round removes at least one pair
+        HIP_TRY(ctx, hipMemsetAsync(dsel, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(greedy_reset_kernel, dim3(grid_for(nmax)), dim3(256), 0, ctx->stream, drkey, dridx, n_m, dckey, dcidx, n_r);
+        hipLaunchKernelGGL(greedy_min_key_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, durow, ducol, drkey, dckey);
+        hipLaunchKernelGGL(greedy_min_idx_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, drkey, dckey, dridx, dcidx);
+        hipLaunchKernelGGL(greedy_select_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dalive, dridx, dcidx, durow, ducol,
+                           dmatch, dsel);
+        HIP_TRY(ctx, hipGetLastError());
+        SAME_TRY(same_down(ctx, h, dsel, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (h[0] == 0) break;  // nothing alive: the smallest alive pair would always have been selected
+    }
+    if (out_rounds) *out_rounds = rounds;
+    return SAME_OK;
+}
+
 extern "C" {
 
 int same_greedy_match(same_ctx *ctx, const int32_t *pairs, const double *costs, int64_t P, int64_t n_m, int64_t n_r,
@@ -317,40 +359,13 @@ int same_greedy_match(same_ctx *ctx, const int32_t *pairs, const double *costs, 
         }
     int32_t *dp, *dmatch;
     double *dc;
-    uint8_t *dprefer, *dalive, *durow, *ducol;
-    unsigned long long *drkey, *dckey, *dsel;
-    unsigned *dridx, *dcidx;
+    uint8_t *dprefer;
     SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
     SAME_TRY(up_as(ctx, SL_X, costs, (size_t)P, &dc));
     SAME_TRY(up_as(ctx, SL_FLAG0, prefer, (size_t)n_m, &dprefer));
-    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)P, &dalive));
-    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_m + n_r, &durow));
-    ducol = durow + n_m;
-    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_m + n_r, &drkey));
-    dckey = drkey + n_m;
-    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)n_m + n_r, &dridx));
-    dcidx = dridx + n_m;
     SAME_TRY(slot_as(ctx, SL_MATCH, (size_t)n_m, &dmatch));
-    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dsel));
-    HIP_TRY(ctx, hipMemsetAsync(durow, 0, (size_t)(n_m + n_r), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dmatch, 0xFF, (size_t)n_m * sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(greedy_init_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dprefer, dalive);
-    unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
-    const int64_t nmax = n_m > n_r ? n_m : n_r;
     int rounds = 0;
-    for (;; ++rounds) {
-        REQUIRE(ctx, rounds <= P + 1);  // each productive round removes at least one pair
-        HIP_TRY(ctx, hipMemsetAsync(dsel, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(greedy_reset_kernel, dim3(grid_for(nmax)), dim3(256), 0, ctx->stream, drkey, dridx, n_m, dckey, dcidx, n_r);
-        hipLaunchKernelGGL(greedy_min_key_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, durow, ducol, drkey, dckey);
-        hipLaunchKernelGGL(greedy_min_idx_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, drkey, dckey, dridx, dcidx);
-        hipLaunchKernelGGL(greedy_select_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dalive, dridx, dcidx, durow, ducol,
-                           dmatch, dsel);
-        HIP_TRY(ctx, hipGetLastError());
-        SAME_TRY(same_down(ctx, h, dsel, sizeof(unsigned long long)));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (h[0] == 0) break;  // nothing alive: the smallest alive pair would always have been selected
-    }
+    SAME_TRY(same_greedy_core(ctx, dp, dc, P, n_m, n_r, dprefer, dmatch, &rounds));
     if (out_rounds) *out_rounds = rounds;
     SAME_TRY(same_down(ctx, out_match_pair, dmatch, (size_t)n_m * sizeof(int32_t)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

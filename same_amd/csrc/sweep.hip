@@ -351,7 +351,51 @@ int sweep_fill(same_sweep *s, const int32_t *tris, const int8_t *src_sign, const
     return SAME_OK;
 }
 
+// sum of the per-wave flipped masks -> counters[1] (the window pipeline wants the count, not the list)
+__global__ __launch_bounds__(256) void mask_count_kernel(const unsigned long long *__restrict__ mask, int64_t n_words,
+                                                          unsigned long long *__restrict__ counters) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = w < n_words ? __builtin_popcountll(mask[w]) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counters[1], (unsigned long long)c);
+}
+
 }  // namespace
+
+// ---- device cores shared with the window pipeline (window.hip); declared in common.h ----------------------------------
+// per-row minimum pair cost from device-resident pairs / costs into dout[n_m] (enqueue only; scratch: SL_MASK)
+int same_pair_rowmin_core(same_ctx *ctx, const int32_t *dp, const double *dc, int64_t P, int64_t n_m, double *dout) {
+    if (n_m <= 0) return SAME_OK;
+    unsigned long long *dk;
+    SAME_TRY(slot_as(ctx, SL_MASK, (size_t)n_m, &dk));
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, 0xFFF0000000000000ull /* key(+inf) */);
+    if (P) hipLaunchKernelGGL(rowmin_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dk);
+    hipLaunchKernelGGL(rowmin_decode_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, dout);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+// ascending indices of the set bits of dmask[n_words] (items < n_items) into dout_idx, their number into dcounters[1]
+int same_compact_mask_core(same_ctx *ctx, const unsigned long long *dmask, int64_t n_words, int64_t n_items, int32_t *dout_idx,
+                           unsigned long long *dcounters) {
+    hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, dmask, n_words, n_items, dout_idx, dcounters);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+// the lazy-constraint body (src/same.py:645-669) on device-resident arrays, counters only: dcnt[0] = checked, dcnt[1] = flipped.
+// dflag holds ceil(Tr/256)*256 bytes, dmask ceil(Tr/256)*4 words.
+int same_orient_counts_core(same_ctx *ctx, const int32_t *dtris, int64_t Tr, const int8_t *dsign, const double *drxy,
+                            const int32_t *dmatch, uint8_t *dflag, unsigned long long *dmask, unsigned long long *dcnt) {
+    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (Tr <= 0) return SAME_OK;
+    hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dtris, Tr, dsign, drxy, dmatch, dflag, dmask, dcnt);
+    const int64_t n_words = (int64_t)grid_for(Tr) * 4;
+    hipLaunchKernelGGL(mask_count_kernel, dim3(grid_for(n_words)), dim3(256), 0, ctx->stream, dmask, n_words, dcnt);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
 
 extern "C" {
 
@@ -468,15 +512,10 @@ int same_pair_rowmin(same_ctx *ctx, const int32_t *pairs, const double *costs, i
         if (pairs[2 * p] < 0 || pairs[2 * p] >= n_m) { ctx->err = "pair row out of range"; return SAME_ERANGE; }
     int32_t *dp;
     double *dc, *dout;
-    unsigned long long *dk;
     SAME_TRY(up_as(ctx, SL_PAIRS, pairs, (size_t)P * 2, &dp));
     SAME_TRY(up_as(ctx, SL_X, costs, (size_t)P, &dc));
-    SAME_TRY(slot_as(ctx, SL_MASK, (size_t)n_m, &dk));
     SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_m, &dout));
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, 0xFFF0000000000000ull /* key(+inf) */);
-    if (P) hipLaunchKernelGGL(rowmin_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dk);
-    hipLaunchKernelGGL(rowmin_decode_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, dout);
-    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_pair_rowmin_core(ctx, dp, dc, P, n_m, dout));
     SAME_TRY(same_down(ctx, out_min, dout, (size_t)n_m * sizeof(double)));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;

@@ -282,3 +282,189 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
                 ahead[nxt] = stage(plan[nxt])
         out, staged = ahead.pop(q)
         yield out if out.error is not None else finish(out, staged)
+
+
+# ---- the window path with the sections resident on the device (csrc/window.hip) -------------------------------------------
+
+_W_ALIGNED_XY, _W_ALIGNED_ROWS, _W_ROWS_M, _W_ROWS_R, _W_PAIRS, _W_COSTS, _W_KEPT, _W_SIGNS, _W_WEIGHTS, _W_MATCH = range(10)
+
+
+class DeviceSection:
+    """A `Section`'s XY, type columns and sizes uploaded once (same_section_create); every window reads them in place.
+    cost_dtype float32 keeps the cost operands as float (BASELINE cfg 5), float64 is the reference's arithmetic."""
+
+    def __init__(self, section, cost_dtype=np.float64, ctx=None):
+        import ctypes
+
+        self.ctx = ctx = ops._ctx(ctx)
+        self.section = section
+        self.cost_dtype = np.dtype(cost_dtype)
+        assert self.cost_dtype in (np.dtype(np.float64), np.dtype(np.float32))
+        size = np.ascontiguousarray(section.size, dtype=np.float64)
+        h = ctypes.c_void_p()
+        with ctx.lock:
+            rc = ctx.lib.same_section_create(ctx.handle, section.xy.ctypes.data, section.types.ctypes.data, section.types.shape[1],
+                                             size.ctypes.data, len(section.xy), int(self.cost_dtype == np.dtype(np.float32)), ctypes.byref(h))
+            if rc != 0 and h.value:
+                ctx.lib.same_section_destroy(h)
+            ctx.check(rc, "same_section_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:        # a context that is already gone took its device memory along
+            with self.ctx.lock:
+                self.ctx.lib.same_section_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceWindow:
+    """Device state of one window in flight (same_window): `stage` then `finish`, arrays of the state through `fetch`."""
+
+    def __init__(self, ctx=None):
+        import ctypes
+
+        self.ctx = ctx = ops._ctx(ctx)
+        h = ctypes.c_void_p()
+        with ctx.lock:
+            rc = ctx.lib.same_window_create(ctx.handle, ctypes.byref(h))
+            if rc != 0 and h.value:
+                ctx.lib.same_window_destroy(h)
+            ctx.check(rc, "same_window_create")
+        self.handle = h
+        self.counts = (0, 0, 0, 0)
+        self.n_triangles = 0
+
+    def stage(self, moving, ref, box, radius, knn, dist_ct_coeff):
+        """-> (aligned rows in the box, reference rows in the box, aligned rows kept, pairs)"""
+        box = np.ascontiguousarray(box, dtype=np.float64)
+        counts = np.zeros(4, np.int64)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_window_stage(self.handle, moving.handle, ref.handle, box.ctypes.data, float(radius), int(knn),
+                                                          float(dist_ct_coeff), counts.ctypes.data), "same_window_stage")
+        self.counts = tuple(int(c) for c in counts)
+        self.n_triangles = 0
+        return self.counts
+
+    def fetch(self, what):
+        n_m, n_r, kept, pairs = self.counts
+        dtype, shape = {_W_ALIGNED_XY: (np.float64, (kept, 2)), _W_ALIGNED_ROWS: (np.int32, (kept,)), _W_ROWS_M: (np.int32, (n_m,)),
+                        _W_ROWS_R: (np.int32, (n_r,)), _W_PAIRS: (np.int32, (pairs, 2)), _W_COSTS: (np.float64, (pairs,)),
+                        _W_KEPT: (np.int32, (kept,)), _W_SIGNS: (np.int8, (self.n_triangles,)),
+                        _W_WEIGHTS: (np.float64, (self.n_triangles,)), _W_MATCH: (np.int32, (kept,))}[what]
+        out = np.empty(shape, dtype)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_window_fetch(self.handle, int(what), out.ctypes.data, out.nbytes), "same_window_fetch")
+        return out
+
+    def finish(self, triangles, no_match_penalty):
+        """-> (section row of the matched reference cell per kept aligned cell or -1, XY-order flag per kept cell, stats dict)"""
+        tris = ops._tris(triangles)
+        kept = self.counts[2]
+        match_row, flag, stats = np.empty(kept, np.int32), np.empty(kept, np.uint8), np.zeros(8, np.int64)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_window_finish(self.handle, tris.ctypes.data, len(tris), float(no_match_penalty),
+                                                           match_row.ctypes.data, flag.ctypes.data, stats.ctypes.data), "same_window_finish")
+        self.n_triangles = len(tris)
+        names = ("checked", "flipped", "xy_comparisons", "xy_violations", "xy_triangles", "area_flips", "greedy_rounds", "matched")
+        return match_row, flag, dict(zip(names, (int(v) for v in stats)))
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            with self.ctx.lock:
+                self.ctx.lib.same_window_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceWindowResult:
+    """What one window of `iter_device_windows` leaves on the host: `rows_m` section rows of the kept aligned cells, `axy` their XY,
+    `triangles` the kept Delaunay triangles over them, `match_row` the section row of each cell's matched reference cell (-1 = none),
+    `point_flag` the XY-order sweep's per-cell flag, `stats` the sweeps' counters, `counts` (aligned in box, refs in box, kept, pairs);
+    `state` is the live DeviceWindow while the result is the newest one yielded (pairs, costs, signs ... through `state.fetch`)."""
+
+    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "match_row", "point_flag", "stats", "counts", "state")
+
+    def __init__(self, window):
+        self.window = window
+        for name in self.__slots__[1:]:
+            setattr(self, name, None)
+
+
+def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
+                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None):
+    """The window path of `iter_window_arrays` + the greedy incumbent and the three sweeps, with both sections resident on the
+    device (`dref`, `dmoving`: DeviceSections of `ref`, `moving`): per window the host only triangulates (Qhull helpers, windows
+    ahead as before), runs the same-type re-add pass of the triangle filter and receives the match.  Yields one
+    DeviceWindowResult per window in plan order; the numbers are those of the column pipeline
+    (tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline).  A window without pairs yields `.error`."""
+    from . import qhull_pool
+    from ._trace import stage as marked
+    from .triangles import filter_triangles_by_radius
+
+    ctx = ops._ctx(ctx)
+    depth = qhull_pool.lookahead()
+    qhull_pool.warm(min(depth, len(plan)))
+    free = [DeviceWindow(ctx) for _ in range(min(depth + 1, max(len(plan), 1)))]
+    r = float(radius)
+
+    def stage(w):
+        out = DeviceWindowResult(w)
+        with marked("subset + prune + costs + compaction (device)"):
+            state = None
+            if r == r and int(knn) > 0:
+                state = free.pop()
+                out.counts = state.stage(dmoving, dref, w["box"], abs(r), knn, dist_ct_coeff)
+            if state is None or out.counts[3] == 0:
+                if state is not None:
+                    free.append(state)
+                out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
+                return out, None
+            out.rows_m, out.axy = state.fetch(_W_ALIGNED_ROWS), state.fetch(_W_ALIGNED_XY)
+            return out, (state, qhull_pool.pool().submit(out.axy))
+
+    def finish(out, staged):
+        state, ticket = staged
+        with marked("triangulate (wait for helper)"):
+            tris = ticket.result()
+        with marked("triangle filter"):
+            tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
+            out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
+                                                       min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
+        with marked("signs + incumbent + sweeps (device)"):
+            out.match_row, out.point_flag, out.stats = state.finish(out.triangles, no_match_penalty)
+        out.state = state
+        return out
+
+    ahead, last = {}, None
+    try:
+        for q in range(len(plan)):
+            if last is not None:                      # the caller has moved on: the previous window's state goes back to the pool
+                free.append(last)
+                last = None
+            for nxt in range(q, min(q + 1 + depth, len(plan))):
+                if nxt not in ahead:
+                    ahead[nxt] = stage(plan[nxt])
+            out, staged = ahead.pop(q)
+            if out.error is None:
+                out = finish(out, staged)
+                last = out.state
+            yield out
+    finally:
+        for _o, staged in ahead.values():
+            if staged is not None:
+                free.append(staged[0])
+        if last is not None:
+            free.append(last)
+        for state in free:
+            state.close()

@@ -396,6 +396,69 @@ def test_window_arrays_equal_prepared_windows(cost_dtype):
     assert errors >= 1
 
 
+@pytest.mark.parametrize("cost_dtype", ["float64", "float32"])
+def test_device_windows_equal_the_column_pipeline(cost_dtype):
+    """The window path with both sections resident on the device (windows.iter_device_windows over csrc/window.hip: subsetting,
+    prune, costs, compaction, signs, greedy incumbent and the three sweeps in two calls per window) against the column pipeline
+    plus the host-buffer entry points -- every window of a plan, thin strips, a window without reference cells, integer and
+    float sizes: the same kept cells, pairs (reference cells compared by section row: the device path does not renumber them),
+    costs, triangles, signs, weights, match, per-cell flags and counters."""
+    from same_amd import ops, synth
+    from same_amd import windows as W
+
+    T = 5
+    ref = synth.make_cells(40_000, T, seed=30)
+    mov = synth.make_jittered(ref, seed=31)
+    mov["xy"][:300] += 5000.0
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    m_df["size"] = np.where(np.arange(len(m_df)) % 3 == 0, 2, 1) if cost_dtype == "float32" else m_df["size"].astype(float) * 1.5
+    cols = synth.type_columns(T)
+    plan = W.window_plan(r_df[["X", "Y"]].to_numpy(), m_df[["X", "Y"]].to_numpy(), 700, 200, 10)
+    plan = plan[::2] + [dict(plan[0], box=(5000.0, 7100.0, 5000.0, 7100.0))]
+    ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
+    dref, dmov = W.DeviceSection(ref_sec, cost_dtype), W.DeviceSection(mov_sec, cost_dtype)
+    kw = dict(radius=30, knn=6, dist_ct_coeff=1.5, min_angle_deg=12, ignore_same_type_triangles=True)
+    arrays = list(W.iter_window_arrays(ref_sec, mov_sec, plan, cost_dtype=cost_dtype, **kw))
+    penalty, errors, windows, n_matched, n_rows = 0.006, 0, 0, 0, 0   # a penalty some rows' best pair does not beat: `prefer` is not all ones
+    for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, **kw)):
+        assert dw.window is wa.window
+        if wa.error is not None:
+            assert isinstance(dw.error, ValueError) and str(dw.error) == str(wa.error)
+            errors += 1
+            continue
+        assert dw.error is None
+        st = dw.state
+        assert np.array_equal(dw.rows_m, wa.rows_m) and np.array_equal(dw.axy, wa.axy)
+        pairs, rows_r = st.fetch(W._W_PAIRS), st.fetch(W._W_ROWS_R)
+        assert dw.counts == (len(st.fetch(W._W_ROWS_M)), len(rows_r), len(wa.rows_m), len(wa.pairs))
+        assert np.array_equal(pairs[:, 0], wa.pairs[:, 0]) and np.array_equal(rows_r[pairs[:, 1]], wa.rows_r[wa.pairs[:, 1]])
+        assert np.array_equal(st.fetch(W._W_ROWS_M)[st.fetch(W._W_KEPT)], wa.rows_m)
+        assert np.array_equal(st.fetch(W._W_COSTS), wa.costs)
+        assert np.array_equal(dw.triangles, wa.triangles)
+        assert np.array_equal(st.fetch(W._W_SIGNS), wa.signs.astype(np.int8))
+        assert np.array_equal(st.fetch(W._W_WEIGHTS), np.asarray(wa.weights, dtype=np.float64))
+        # the incumbent and the sweeps through the host-buffer entry points on the column pipeline's arrays
+        p32 = wa.pairs.astype(np.int32)
+        wants = ops.pair_rowmin(p32, wa.costs, wa.n_aligned) < penalty * wa.size.astype(float)
+        pair_of_row, rounds = ops.greedy_match(p32, wa.costs, wa.n_aligned, wa.n_ref, wants)
+        match = np.where(pair_of_row >= 0, p32[np.maximum(pair_of_row, 0), 1], -1).astype(np.int32)
+        n_matched, n_rows = n_matched + int(np.count_nonzero(match >= 0)), n_rows + wa.n_aligned
+        assert np.array_equal(dw.match_row, np.where(match >= 0, wa.rows_r[np.maximum(match, 0)], -1))
+        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned)
+        checked, viol = sw.sweep_match(match)
+        sw.close()
+        _e, _t, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match)
+        _b, _a, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match)
+        assert np.array_equal(dw.point_flag, pflag)
+        assert dw.stats == dict(checked=int(checked), flipped=len(viol), xy_comparisons=int(counts[0]), xy_violations=int(counts[1]),
+                                xy_triangles=int(counts[2]), area_flips=int(np.count_nonzero(flipped)), greedy_rounds=int(rounds),
+                                matched=int(np.count_nonzero(match >= 0)))
+        windows += 1
+    assert errors >= 1 and windows > 10 and 0.2 * n_rows < n_matched < 0.95 * n_rows
+    dref.close()
+    dmov.close()
+
+
 def test_allgather_table_over_a_size_one_rccl_communicator():
     """dist.allgather_table (the cfg 5 exchange: per-rank match tables as ONE device all-gather) through a real ncclAllGather on
     a size-1 communicator: columns of different widths and an empty table come back bit for bit; ragged or non-numeric
