@@ -82,6 +82,9 @@ def parse():
                     help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
+    ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
+                    help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
+                         "and hands every kernel host buffers")
     ap.add_argument("--cfg5-threads", type=int, default=4, help="--workload cfg5: worker threads (contexts) walking this rank's windows")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
@@ -1076,7 +1079,8 @@ def run_rank(args):
 def run_cfg5(args, group, json_fd):
     """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
     round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
-    on the column pipeline (same_amd.windows.iter_window_arrays: no DataFrame per window),
+    with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates, runs the
+    filter's re-add pass and receives the match; --cfg5-pipeline columns is the host-buffer form it is tested against),
     every rank's central-trimmed match table exchanged in ONE device all-gather (dist.allgather_table) and merged
     (src/helpers.py:692-815, de-duplication on the GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
     (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
@@ -1090,7 +1094,8 @@ def run_cfg5(args, group, json_fd):
     from same_amd import _lib, _trace, ops, synth
     from same_amd.merge import merge_window_matches_unique_ref
     from same_amd.dist import allgather_table
-    from same_amd.windows import Section, assign_windows, iter_window_arrays, window_plan
+    from same_amd import windows as W
+    from same_amd.windows import DeviceSection, Section, assign_windows, iter_device_windows, iter_window_arrays, window_plan
 
     _trace.enable(True)
     _lib.instrument()
@@ -1114,6 +1119,22 @@ def run_cfg5(args, group, json_fd):
                      ("filtered_violation", bool), ("window_id", np.int64))
     ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
     ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
+    on_device = args.cfg5_pipeline == "device"
+    dref, dmov = (DeviceSection(ref_sec, np.float32, ctx), DeviceSection(mov_sec, np.float32, ctx)) if on_device else (None, None)
+    path_kw = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True)
+
+    def device_table(dw):
+        """the window's central match table from what iter_device_windows leaves on the host (section rows, XY, match, flags)"""
+        w = dw.window
+        ai = np.flatnonzero(dw.match_row >= 0)
+        x, y = dw.axy[ai, 0], dw.axy[ai, 1]
+        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
+        c = ai[(x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1)]
+        tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": dw.axy[c, 0], "Y": dw.axy[c, 1],
+               "filtered_violation": dw.point_flag[c].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
+        st = dw.stats
+        return tab, {"pairs": dw.counts[3], "triangles": len(dw.triangles), "checked": st["checked"], "flipped": st["flipped"],
+                     "xy_violations": st["xy_violations"], "area_flips": st["area_flips"]}
 
     def run_window(wa, wctx):
         """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
@@ -1147,8 +1168,13 @@ def run_cfg5(args, group, json_fd):
     worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
 
     def walk(windows, wctx, out):
-        for wa in iter_window_arrays(ref_sec, mov_sec, windows, radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
-                                     ignore_same_type_triangles=True, cost_dtype=np.float32, ctx=wctx):
+        if on_device:
+            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, windows, no_match_penalty=100.0, ctx=wctx, **path_kw):
+                if dw.error is None:
+                    with _trace.stage("table (bench step)"):
+                        out.append((dw.window["window_id"], *device_table(dw)))
+            return
+        for wa in iter_window_arrays(ref_sec, mov_sec, windows, cost_dtype=np.float32, ctx=wctx, **path_kw):
             if wa.error is not None:              # a window whose prune leaves no pairs (src/same.py:1003)
                 continue
             with _trace.stage("incumbent + sweeps + table (bench step)"):
@@ -1189,8 +1215,13 @@ def run_cfg5(args, group, json_fd):
             merged = merge_window_matches_unique_ref(frames)
         return merged, stats
 
+    from same_amd import qhull_pool as _qp
+
+    # warm-up: scratch slots, Qhull helpers, first-launch costs -- and, on the device path, every window state a worker keeps
+    # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
+    n_warm = (_qp.lookahead() + 1) * n_workers if on_device else 2
     for _ in range(args.warmup):
-        one_pass(my_plan[: max(1, min(2, len(my_plan)))])                # scratch slots, Qhull helpers, first-launch costs
+        one_pass(my_plan[: max(1, min(n_warm, len(my_plan)))])
     group.barrier()
     _trace.reset()
     t0 = time.perf_counter()
@@ -1246,11 +1277,22 @@ def run_cfg5(args, group, json_fd):
             gchecked, gviol, _ = sw.sweep(xo)
             sw.bound.close()
             ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
+            if ok and on_device:                 # and what the timed path itself computes for this window (csrc/window.hip)
+                nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
+                for hit in och:
+                    match_o[hit[0]] = nr_rows[hit[1]]
+                for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, **path_kw):
+                    dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
+                    ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
+                          and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])
+                          and np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), c32) and np.array_equal(dw.triangles, tri)
+                          and np.array_equal(dw.state.fetch(W._W_SIGNS), np.asarray(signs, dtype=np.int8))
+                          and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
             if not ok:
                 raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
         t_cpu = time.perf_counter() - c0
         parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
-                  "equal the oracle bit-for-bit")
+                  "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
         cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
                "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
                          f"through oracle/same_oracle.{{c,py}} in {t_cpu:.1f} s, 1 thread; includes the GPU re-run of the same windows for the comparison",
@@ -1267,6 +1309,9 @@ def run_cfg5(args, group, json_fd):
                "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
                                       f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
                                       "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
+                          "pipeline": ("device: both sections resident in HBM, two library calls per window (csrc/window.hip); the host triangulates (Qhull "
+                                       "helpers), runs the triangle filter's re-add pass and receives the match" if on_device
+                                       else "columns: subsetting, compaction and gathers on the host, every kernel through host buffers"),
                           "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
                                          "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
                "windows_per_s": len(plan) * args.steps / dt,
@@ -1278,7 +1323,7 @@ def run_cfg5(args, group, json_fd):
                "threads_per_rank": n_workers,
                "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
                "merged_matches": int(len(merged)),
-               "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (pair_cost_kernel<float> is the largest)",
+               "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (the padded / pair cost kernel is the largest)",
                             "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
                             "traffic": None, "algorithmic_bytes_per_step": touched,
                             "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
@@ -1289,6 +1334,9 @@ def run_cfg5(args, group, json_fd):
             out["rccl"] = rccl
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()
+    for sec in (dref, dmov):
+        if sec is not None:
+            sec.close()
     for c in worker_ctx[1:]:
         c.close()
     if comm is not None:

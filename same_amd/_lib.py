@@ -311,6 +311,8 @@ class Context:
         return ms.value
 
     def close(self):
+        for state in self.__dict__.pop("_device_windows", []):      # window states cached by windows.iter_device_windows
+            state.close()
         if self.handle:
             self.lib.same_ctx_destroy(self.handle)
             self.handle = None

@@ -415,7 +415,12 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     ctx = ops._ctx(ctx)
     depth = qhull_pool.lookahead()
     qhull_pool.warm(min(depth, len(plan)))
-    free = [DeviceWindow(ctx) for _ in range(min(depth + 1, max(len(plan), 1)))]
+    # window states (their device buffers, grown once) are kept with the context from one call to the next: a pass over a plan
+    # then makes no device allocation at all
+    cache = ctx.__dict__.setdefault("_device_windows", [])
+    want = min(depth + 1, max(len(plan), 1))
+    free = [cache.pop() for _ in range(min(want, len(cache)))]
+    free += [DeviceWindow(ctx) for _ in range(want - len(free))]
     r = float(radius)
 
     def stage(w):
@@ -466,5 +471,4 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
                 free.append(staged[0])
         if last is not None:
             free.append(last)
-        for state in free:
-            state.close()
+        cache.extend(free)

@@ -510,11 +510,20 @@ def test_bench_cfg5_windows_line(world):
     pr = out["per_rank"]
     assert len(pr["windows"]) == world and sum(pr["windows"]) >= 4 and all(v > 0 for v in pr["windows_per_s"])
     assert all(0.0 <= v < 1.0 for v in pr["host_glue_share"]) and out["windows_per_s"] > 0 and out["merged_matches"] > 1000
-    assert any(k.startswith("prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
+    assert out["config"]["pipeline"].startswith("device: both sections resident in HBM")
+    assert any(k.startswith("subset + prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
+    assert {"same_window_stage", "same_window_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     if world == 1:
         assert out["cpu_baseline"]["kind"] == "port" and "equal the oracle bit-for-bit" in out["parity_spot_check"]
+        assert "through the device-resident window path" in out["parity_spot_check"]
+        # the host-buffer form of the same step merges to the same table
+        res = subprocess.run(cmd + ["--cfg5-pipeline", "columns", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        col = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+        assert col["config"]["pipeline"].startswith("columns:") and col["merged_matches"] == out["merged_matches"]
+        assert any(k.startswith("prune") for k in col["stages_rank0"])
     else:
         assert out["cpu_baseline"] is None
 
