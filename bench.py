@@ -85,7 +85,8 @@ def parse():
     ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
                     help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
                          "and hands every kernel host buffers")
-    ap.add_argument("--cfg5-threads", type=int, default=4, help="--workload cfg5: worker threads (contexts) walking this rank's windows")
+    ap.add_argument("--cfg5-threads", type=int, default=None,
+                    help="--workload cfg5: worker threads (contexts) walking this rank's windows (default: 2 on the device pipeline, 4 on the column one)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:
@@ -1133,7 +1134,7 @@ def run_cfg5(args, group, json_fd):
         tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": dw.axy[c, 0], "Y": dw.axy[c, 1],
                "filtered_violation": dw.point_flag[c].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
         st = dw.stats
-        return tab, {"pairs": dw.counts[3], "triangles": len(dw.triangles), "checked": st["checked"], "flipped": st["flipped"],
+        return tab, {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
                      "xy_violations": st["xy_violations"], "area_flips": st["area_flips"]}
 
     def run_window(wa, wctx):
@@ -1164,7 +1165,7 @@ def run_cfg5(args, group, json_fd):
     # The windows of a pass are independent and the host work per window (numpy index work, ~7 ms) dwarfs its kernels (~0.3 ms), so
     # the rank walks its windows with --cfg5-threads workers, each with a context (= stream) of its own; numpy and the library calls
     # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
-    n_workers = max(1, int(args.cfg5_threads))
+    n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else (2 if on_device else 4)))
     worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
 
     def walk(windows, wctx, out):
@@ -1281,7 +1282,7 @@ def run_cfg5(args, group, json_fd):
                 nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
                 for hit in och:
                     match_o[hit[0]] = nr_rows[hit[1]]
-                for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, **path_kw):
+                for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, fetch_triangles=True, **path_kw):
                     dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
                     ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
                           and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])

@@ -372,6 +372,14 @@ int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *
  *     flips (:1362-1402).  out_match_row[kept] = SECTION row of the matched reference cell or -1, out_point_flag[kept] =
  *     the XY-order sweep's per-cell flag, out_stats[8] = {orientation checked, flipped, XY comparisons, XY violations,
  *     triangles with a violation, area flips, greedy rounds, matched cells}.
+ *   same_window_filter (optional, between the two): the Delaunay simplices of the kept aligned cells ->
+ *     filter_triangles_by_radius on the device (src/helpers.py:233-395: classes :300-330, the keep list, the same-type
+ *     triangles added back so that every node keeps one :331-340 / :365-389, in the reference's order); the section's
+ *     type_id codes play aligned_df["cell_type"].  out_counts[3] = {kept, added back, cosines within near_tol of
+ *     cos_thr}.  When the third is not zero nothing is left on the device: the caller re-decides those triangles with the
+ *     reference's literal arccos (same_amd/triangles.py) and passes its triangles to same_window_finish.  Otherwise
+ *     same_window_finish(window, NULL, -1, ...) continues with the triangles left on the device.  Simplices must be
+ *     distinct as vertex rows (Qhull's are): the re-add pass de-duplicates by triangle, the reference by vertex row.
  * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size. */
 typedef struct same_section same_section;
 typedef struct same_window same_window;
@@ -385,16 +393,20 @@ enum {
     SAME_WINDOW_KEPT = 6,         /* int32[kept]: index of each kept aligned cell among the box's aligned rows     */
     SAME_WINDOW_SIGNS = 7,        /* int8[triangles]   (after same_window_finish)                                  */
     SAME_WINDOW_WEIGHTS = 8,      /* double[triangles] (after same_window_finish)                                  */
-    SAME_WINDOW_MATCH = 9         /* int32[kept]: matched reference index in the window or -1 (after finish)       */
+    SAME_WINDOW_MATCH = 9,        /* int32[kept]: matched reference index in the window or -1 (after finish)       */
+    SAME_WINDOW_TRIANGLES = 10    /* int32[triangles][3]: the kept triangles (after same_window_filter / finish)   */
 };
 int same_section_create(same_ctx *ctx, const double *xy, const double *types, int T, const double *size,
-                        int64_t n, int cost_f32, same_section **out);
+                        const int32_t *type_id /* may be NULL */, int64_t n, int cost_f32, same_section **out);
 void same_section_destroy(same_section *section);
 int same_window_create(same_ctx *ctx, same_window **out);
 void same_window_destroy(same_window *window);
 int same_window_stage(same_window *window, const same_section *moving, const same_section *ref,
                       const double *box, double radius, int k, double dist_ct_coeff, int64_t *out_counts);
 int same_window_fetch(same_window *window, int what, void *out, int64_t bytes);
+int same_window_filter(same_window *window, const int32_t *simplices, int64_t n_simplices, double radius,
+                       int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
+                       int ensure_min_triangle_per_node, int64_t *out_counts);
 int same_window_finish(same_window *window, const int32_t *tris, int64_t Tr, double no_match_penalty,
                        int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats);
 

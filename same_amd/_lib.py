@@ -92,12 +92,13 @@ _PROTOTYPES = {
     "same_batched_assign": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp],
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
-    "same_section_create": [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, ctypes.POINTER(c_vp)],
+    "same_section_create": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, ctypes.POINTER(c_vp)],
     "same_section_destroy": [c_vp],
     "same_window_create": [c_vp, ctypes.POINTER(c_vp)],
     "same_window_destroy": [c_vp],
     "same_window_stage": [c_vp, c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_vp],
     "same_window_fetch": [c_vp, c_int, c_vp, c_i64],
+    "same_window_filter": [c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_vp],
     "same_window_finish": [c_vp, c_vp, c_i64, c_dbl, c_vp, c_vp, c_vp],
     "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
     "same_comm_unique_id": [c_vp],

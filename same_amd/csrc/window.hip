@@ -10,7 +10,11 @@
 //                       cost type (src/same.py:1180-1189), compaction of the aligned side and of the pair list
 //                       (src/utils.py:734-742).  Back to the host: four counts, and (same_window_fetch) the kept aligned rows
 //                       and their XY -- the input of the host's Delaunay call (src/same.py:1023).
-//   same_window_finish  kept triangles in; source signs / weights (src/same.py:1128-1146), per-row minimum and the greedy MIP
+//   same_window_filter  the Delaunay simplices in; triangle classes (src/helpers.py:300-330), the keep list and the same-type
+//                       triangles added back so that every node keeps one (src/helpers.py:331-340, :365-389) -- all on the
+//                       device, in the reference's order.  (A cosine within 8 ulp of the angle threshold is left to the host,
+//                       which re-decides it with the reference's literal arccos: the call then only reports it.)
+//   same_window_finish  kept triangles in (or the ones same_window_filter left on the device); source signs / weights (src/same.py:1128-1146), per-row minimum and the greedy MIP
 //                       start (src/init_helpers.py:104-133), the lazy-constraint body under that incumbent
 //                       (src/same.py:645-669), XY-order sweep (src/violationhelper.py:53-117), signed-area flips
 //                       (src/same.py:1362-1402).  Back to the host: the matched reference row per kept aligned cell, the
@@ -118,8 +122,9 @@ template <typename F>
 __global__ __launch_bounds__(256) void window_scatter_kernel(
     const int32_t *__restrict__ idx, const F *__restrict__ cost, const int32_t *__restrict__ cnt, int64_t n_m, int k,
     const int32_t *__restrict__ a_off, const int32_t *__restrict__ p_off, const int32_t *__restrict__ rows_m,
-    const double *__restrict__ axy_w, const double *__restrict__ size_w, int32_t *__restrict__ ua, int32_t *__restrict__ rows_ua,
-    double *__restrict__ axy_c, double *__restrict__ size_c, int32_t *__restrict__ pairs, double *__restrict__ cost64) {
+    const double *__restrict__ axy_w, const double *__restrict__ size_w, const int32_t *__restrict__ type_w, int32_t *__restrict__ ua,
+    int32_t *__restrict__ rows_ua, double *__restrict__ axy_c, double *__restrict__ size_c, int32_t *__restrict__ type_c,
+    int32_t *__restrict__ pairs, double *__restrict__ cost64) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_m || cnt[i] <= 0) return;
     const int32_t a = a_off[i];
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void window_scatter_kernel(
     axy_c[2 * (int64_t)a] = axy_w[2 * i];
     axy_c[2 * (int64_t)a + 1] = axy_w[2 * i + 1];
     size_c[a] = size_w[i];
+    if (type_w) type_c[a] = type_w[i];
     int64_t p = p_off[i];
     const int64_t p_end = p + cnt[i];              // the scan sized the list by cnt: never write past this row's share
     for (int q = 0; q < k && p < p_end; ++q) {
@@ -171,6 +177,84 @@ __global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *__restr
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(out, (unsigned long long)__builtin_popcountll(bal));
 }
 
+// ---- triangle filter (src/helpers.py:233-395) on the device ------------------------------------------------------------------
+// classes come from same_tri_classify_dev; this marks what the re-add pass needs: vertices with a kept triangle, vertices with
+// any valid (kept or same-type) triangle, the keep mask, and how many cosines sit within `tol` of the threshold
+__global__ __launch_bounds__(256) void filter_mark_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ maxcos,
+                                                           const int32_t *__restrict__ tris, int64_t Tr, int near_enabled, double thr,
+                                                           double tol, uint8_t *__restrict__ has_kept, uint8_t *__restrict__ any_valid,
+                                                           unsigned long long *__restrict__ keep_mask,
+                                                           unsigned long long *__restrict__ counters) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false, near = false;
+    if (t < Tr) {
+        const uint8_t c = cls[t];
+        keep = c == 0;
+        near = near_enabled && c != 1 && fabs(maxcos[t] - thr) <= tol;
+        if (c == 0 || c == 3) {
+            const int32_t a = tris[3 * t], b = tris[3 * t + 1], d = tris[3 * t + 2];
+            any_valid[a] = 1; any_valid[b] = 1; any_valid[d] = 1;
+            if (c == 0) { has_kept[a] = 1; has_kept[b] = 1; has_kept[d] = 1; }
+        }
+    }
+    const unsigned long long kb = __ballot(keep), nb = __ballot(near);
+    if ((threadIdx.x & 63) == 0) {
+        keep_mask[t >> 6] = kb;
+        if (nb) atomicAdd(&counters[2], (unsigned long long)__builtin_popcountll(nb));
+    }
+}
+
+// best same-type triangle of every vertex = smallest perimeter, first in input order on ties (src/helpers.py:334-340):
+// two passes of atomic minima, first over the perimeter's bit pattern (perimeters are >= 0: the order of the bits is theirs)
+__global__ __launch_bounds__(256) void filter_best_perim_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
+                                                                 const int32_t *__restrict__ tris, int64_t Tr,
+                                                                 unsigned long long *__restrict__ best_p) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tr || cls[t] != 3) return;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(perim[t]);
+    for (int q = 0; q < 3; ++q) atomicMin(&best_p[tris[3 * t + q]], key);
+}
+__global__ __launch_bounds__(256) void filter_best_tri_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
+                                                               const int32_t *__restrict__ tris, int64_t Tr,
+                                                               const unsigned long long *__restrict__ best_p, unsigned *__restrict__ best_t) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Tr || cls[t] != 3) return;
+    const unsigned long long key = (unsigned long long)__double_as_longlong(perim[t]);
+    for (int q = 0; q < 3; ++q) {
+        const int32_t v = tris[3 * t + q];
+        if (best_p[v] == key) atomicMin(&best_t[v], (unsigned)t);
+    }
+}
+// nodes without a kept triangle but with a valid one are walked in ascending order and bring their best triangle along unless an
+// earlier node already did (src/helpers.py:365-389): first_v[t] = the first node that asks for t ...
+__global__ __launch_bounds__(256) void filter_first_node_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
+                                                                 const unsigned *__restrict__ best_t, int64_t n, unsigned *__restrict__ first_v) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || has_kept[v] || !any_valid[v] || best_t[v] == ~0u) return;
+    atomicMin(&first_v[best_t[v]], (unsigned)v);
+}
+// ... and the nodes that are the first to ask, as a mask over the nodes (compacted in order afterwards)
+__global__ __launch_bounds__(256) void filter_owner_mask_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
+                                                                 const unsigned *__restrict__ best_t, const unsigned *__restrict__ first_v,
+                                                                 int64_t n, unsigned long long *__restrict__ mask) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool own = false;
+    if (v < n && !has_kept[v] && any_valid[v] && best_t[v] != ~0u) own = first_v[best_t[v]] == (unsigned)v;
+    const unsigned long long bal = __ballot(own);
+    if ((threadIdx.x & 63) == 0) mask[v >> 6] = bal;
+}
+// the kept triangles in the reference's order: class-0 triangles ascending, then the added-back ones in walk order
+__global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ keep_list, int64_t n_keep,
+                                                           const int32_t *__restrict__ owner_list, int64_t n_add,
+                                                           const unsigned *__restrict__ best_t, int32_t *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_keep + n_add) return;
+    const int64_t t = q < n_keep ? keep_list[q] : (int64_t)best_t[owner_list[q - n_keep]];
+    out[3 * q] = raw[3 * t];
+    out[3 * q + 1] = raw[3 * t + 1];
+    out[3 * q + 2] = raw[3 * t + 2];
+}
+
 }  // namespace
 
 struct same_section {
@@ -182,15 +266,17 @@ struct same_section {
     void *xy_c = nullptr;     // [n][2] in the cost type (== xy for fp64 costs)
     void *types_c = nullptr;  // [n][T] in the cost type
     double *size = nullptr;   // [n]
+    int32_t *type_id = nullptr;  // [n] codes of the cell type (equal type <=> equal code), or none
 };
 
 struct same_window {
     same_ctx *ctx = nullptr;
     const same_section *ref = nullptr;
-    int cost_f32 = 0, k = 0, staged = 0, finished = 0;
+    int cost_f32 = 0, k = 0, staged = 0, finished = 0, has_type = 0, filtered = 0;
     int64_t n_m = 0, n_r = 0, n_ua = 0, P = 0, Tr = 0;
     DevBuf mask, counts, rows_m, rows_r, axy_w, rxy_w, axyc_w, rxyc_w, A_w, R_w, size_w, idx, cnt, cost, a_off, p_off, ua, rows_ua,
         axy_c, size_c, pairs, cost64;
+    DevBuf type_w, type_c, raw, cls, perim, maxcos, kmask, has_kept, any_valid, best_p, best_t, first_v, nmask, nlist, klist;
     DevBuf tris, sign, weight, rowmin, prefer, pair_of_row, match, match_row, oflag, omask, edge, tflag, pflag, before, after, m3, flipped;
     void *host = nullptr;     // pinned staging for everything that comes back
     size_t host_bytes = 0;
@@ -262,8 +348,8 @@ void release(DevBuf &b) {
 
 extern "C" {
 
-int same_section_create(same_ctx *ctx, const double *xy, const double *types, int T, const double *size, int64_t n, int cost_f32,
-                        same_section **out) {
+int same_section_create(same_ctx *ctx, const double *xy, const double *types, int T, const double *size, const int32_t *type_id,
+                        int64_t n, int cost_f32, same_section **out) {
     REQUIRE(ctx, ctx && out);
     *out = nullptr;
     REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 31) - 256 && T >= 0 && T <= SAME_MAX_TYPES);
@@ -276,9 +362,11 @@ int same_section_create(same_ctx *ctx, const double *xy, const double *types, in
     const size_t nn = (size_t)std::max<int64_t>(n, 1), tt = (size_t)std::max(T, 1);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->xy), nn * 2 * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->size), nn * sizeof(double)));
+    if (type_id) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->type_id), nn * sizeof(int32_t)));
     if (n) {
         HIP_TRY(ctx, hipMemcpyAsync(s->xy, xy, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(s->size, size, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (type_id) HIP_TRY(ctx, hipMemcpyAsync(s->type_id, type_id, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     }
     if (!s->cost_f32) {
         s->xy_c = s->xy;
@@ -315,6 +403,7 @@ void same_section_destroy(same_section *s) {
     if (s->xy) (void)hipFree(s->xy);
     if (s->types_c) (void)hipFree(s->types_c);
     if (s->size) (void)hipFree(s->size);
+    if (s->type_id) (void)hipFree(s->type_id);
     delete s;
 }
 
@@ -337,7 +426,8 @@ void same_window_destroy(same_window *w) {
     (void)hipStreamSynchronize(w->ctx->stream);
     DevBuf *all[] = {&w->mask, &w->counts, &w->rows_m, &w->rows_r, &w->axy_w, &w->rxy_w, &w->axyc_w, &w->rxyc_w, &w->A_w, &w->R_w, &w->size_w,
                      &w->idx, &w->cnt, &w->cost, &w->a_off, &w->p_off, &w->ua, &w->rows_ua, &w->axy_c, &w->size_c, &w->pairs, &w->cost64,
-                     &w->tris, &w->sign, &w->weight, &w->rowmin, &w->prefer, &w->pair_of_row, &w->match, &w->match_row, &w->oflag, &w->omask,
+                     &w->type_w, &w->type_c, &w->raw, &w->cls, &w->perim, &w->maxcos, &w->kmask, &w->has_kept, &w->any_valid, &w->best_p,
+                     &w->best_t, &w->first_v, &w->nmask, &w->nlist, &w->klist, &w->tris, &w->sign, &w->weight, &w->rowmin, &w->prefer, &w->pair_of_row, &w->match, &w->match_row, &w->oflag, &w->omask,
                      &w->edge, &w->tflag, &w->pflag, &w->before, &w->after, &w->m3, &w->flipped};
     for (DevBuf *b : all) release(*b);
     if (w->host) (void)hipHostFree(w->host);
@@ -351,7 +441,8 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     REQUIRE(ctx, mov && ref && box && out_counts && mov->ctx->device == ctx->device && ref->ctx->device == ctx->device);
     REQUIRE(ctx, mov->T == ref->T && mov->cost_f32 == ref->cost_f32 && k >= 1 && k <= SAME_MAX_KNN && radius >= 0.0);
     SAME_TRY(same_use(ctx));
-    w->staged = w->finished = 0;
+    w->staged = w->finished = w->filtered = 0;
+    w->has_type = mov->type_id != nullptr;
     w->ref = ref;
     w->cost_f32 = mov->cost_f32;
     w->k = k;
@@ -370,6 +461,8 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     SAME_TRY(gather(ctx, mov->xy, 2 * sizeof(double), rm, n_m, w->axy_w));
     SAME_TRY(gather(ctx, ref->xy, 2 * sizeof(double), rr, n_r, w->rxy_w));
     SAME_TRY(gather(ctx, mov->size, sizeof(double), rm, n_m, w->size_w));
+    if (w->has_type) SAME_TRY(gather(ctx, mov->type_id, sizeof(int32_t), rm, n_m, w->type_w));
+    SAME_TRY(ensure(ctx, w->type_c, (size_t)n_m * sizeof(int32_t)));
     SAME_TRY(gather(ctx, mov->types_c, (size_t)T * cs, rm, n_m, w->A_w));
     SAME_TRY(gather(ctx, ref->types_c, (size_t)T * cs, rr, n_r, w->R_w));
     if (w->cost_f32) {
@@ -402,13 +495,13 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     if (w->cost_f32)
         hipLaunchKernelGGL(window_scatter_kernel<float>, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, as<int32_t>(w->idx), as<float>(w->cost),
                            as<int32_t>(w->cnt), n_m, k, as<int32_t>(w->a_off), as<int32_t>(w->p_off), rm, as<double>(w->axy_w),
-                           as<double>(w->size_w), as<int32_t>(w->ua), as<int32_t>(w->rows_ua), as<double>(w->axy_c), as<double>(w->size_c),
-                           as<int32_t>(w->pairs), as<double>(w->cost64));
+                           as<double>(w->size_w), w->has_type ? as<int32_t>(w->type_w) : nullptr, as<int32_t>(w->ua), as<int32_t>(w->rows_ua),
+                           as<double>(w->axy_c), as<double>(w->size_c), as<int32_t>(w->type_c), as<int32_t>(w->pairs), as<double>(w->cost64));
     else
         hipLaunchKernelGGL(window_scatter_kernel<double>, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, as<int32_t>(w->idx), as<double>(w->cost),
                            as<int32_t>(w->cnt), n_m, k, as<int32_t>(w->a_off), as<int32_t>(w->p_off), rm, as<double>(w->axy_w),
-                           as<double>(w->size_w), as<int32_t>(w->ua), as<int32_t>(w->rows_ua), as<double>(w->axy_c), as<double>(w->size_c),
-                           as<int32_t>(w->pairs), as<double>(w->cost64));
+                           as<double>(w->size_w), w->has_type ? as<int32_t>(w->type_w) : nullptr, as<int32_t>(w->ua), as<int32_t>(w->rows_ua),
+                           as<double>(w->axy_c), as<double>(w->size_c), as<int32_t>(w->type_c), as<int32_t>(w->pairs), as<double>(w->cost64));
     HIP_TRY(ctx, hipGetLastError());
     // one read-back: the two totals, then the kept aligned rows and their XY at the capacity n_m (n_ua <= n_m is not known yet)
     const size_t head = 64;
@@ -450,6 +543,7 @@ int same_window_fetch(same_window *w, int what, void *out, int64_t bytes) {
     case SAME_WINDOW_SIGNS: want = Tr; dev = w->sign.p; REQUIRE(ctx, w->finished); break;
     case SAME_WINDOW_WEIGHTS: want = Tr * 8; dev = w->weight.p; REQUIRE(ctx, w->finished); break;
     case SAME_WINDOW_MATCH: want = n_ua * 4; dev = w->match.p; REQUIRE(ctx, w->finished); break;
+    case SAME_WINDOW_TRIANGLES: want = Tr * 12; dev = w->tris.p; REQUIRE(ctx, w->finished || w->filtered); break;
     default: REQUIRE(ctx, !"unknown same_window_fetch selector");
     }
     REQUIRE(ctx, bytes == want);
@@ -463,16 +557,97 @@ int same_window_fetch(same_window *w, int what, void *out, int64_t bytes) {
     return SAME_OK;
 }
 
+int same_window_filter(same_window *w, const int32_t *simplices, int64_t n_simplices, double radius, int angle_enabled, double cos_thr,
+                       double near_tol, int ignore_same_type, int ensure_min_triangle_per_node, int64_t *out_counts) {
+    if (!w) return SAME_EINVAL;
+    same_ctx *ctx = w->ctx;
+    REQUIRE(ctx, w->staged == 2 && out_counts && n_simplices >= 0 && n_simplices < ((int64_t)1 << 31) - 512 && (n_simplices == 0 || simplices));
+    const int64_t n = w->n_ua, Tr = n_simplices;
+    for (int q = 0; q < 3; ++q) out_counts[q] = 0;
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, simplices, Tr * 3, 0, n, "triangles"));
+    w->filtered = w->finished = 0;
+    w->Tr = 0;
+    if (Tr == 0 || n == 0) { w->filtered = 1; return SAME_OK; }
+    const bool use_type = ignore_same_type && w->has_type;
+    const int64_t t_words = (int64_t)grid_for(Tr) * 4, n_words = (int64_t)grid_for(n) * 4;
+    SAME_TRY(ensure(ctx, w->raw, (size_t)Tr * 3 * sizeof(int32_t)));
+    SAME_TRY(ensure(ctx, w->tris, (size_t)Tr * 3 * sizeof(int32_t)));
+    SAME_TRY(ensure(ctx, w->cls, (size_t)Tr));
+    SAME_TRY(ensure(ctx, w->perim, (size_t)Tr * sizeof(double)));
+    SAME_TRY(ensure(ctx, w->maxcos, (size_t)Tr * sizeof(double)));
+    SAME_TRY(ensure(ctx, w->kmask, (size_t)t_words * sizeof(unsigned long long)));
+    SAME_TRY(ensure(ctx, w->klist, (size_t)Tr * sizeof(int32_t)));
+    SAME_TRY(ensure(ctx, w->first_v, (size_t)Tr * sizeof(unsigned)));
+    SAME_TRY(ensure(ctx, w->has_kept, (size_t)n));
+    SAME_TRY(ensure(ctx, w->any_valid, (size_t)n));
+    SAME_TRY(ensure(ctx, w->best_p, (size_t)n * sizeof(unsigned long long)));
+    SAME_TRY(ensure(ctx, w->best_t, (size_t)n * sizeof(unsigned)));
+    SAME_TRY(ensure(ctx, w->nmask, (size_t)n_words * sizeof(unsigned long long)));
+    SAME_TRY(ensure(ctx, w->nlist, (size_t)n * sizeof(int32_t)));
+    unsigned long long *dc = as<unsigned long long>(w->counts);   // [1] kept (class 0), [2] near the threshold, [5] added back
+    HIP_TRY(ctx, hipMemsetAsync(dc, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(w->raw.p, simplices, (size_t)Tr * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SAME_TRY(same_tri_classify_dev(ctx, as<double>(w->axy_c), as<int32_t>(w->raw), Tr, radius, angle_enabled, cos_thr,
+                                   use_type ? as<int32_t>(w->type_c) : nullptr, as<uint8_t>(w->cls), as<double>(w->perim), as<double>(w->maxcos)));
+    HIP_TRY(ctx, hipMemsetAsync(w->has_kept.p, 0, (size_t)n, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w->any_valid.p, 0, (size_t)n, ctx->stream));
+    const int near_enabled = angle_enabled && cos_thr == cos_thr && cos_thr - cos_thr == 0.0;       // a finite threshold
+    hipLaunchKernelGGL(filter_mark_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->cls), as<double>(w->maxcos),
+                       as<int32_t>(w->raw), Tr, near_enabled, cos_thr, near_tol, as<uint8_t>(w->has_kept), as<uint8_t>(w->any_valid),
+                       as<unsigned long long>(w->kmask), dc);
+    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(same_compact_mask_core(ctx, as<unsigned long long>(w->kmask), t_words, Tr, as<int32_t>(w->klist), dc));          // count -> dc[1]
+    const bool readd = use_type && ensure_min_triangle_per_node;
+    if (readd) {
+        HIP_TRY(ctx, hipMemsetAsync(w->best_p.p, 0xFF, (size_t)n * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(w->best_t.p, 0xFF, (size_t)n * sizeof(unsigned), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(w->first_v.p, 0xFF, (size_t)Tr * sizeof(unsigned), ctx->stream));
+        hipLaunchKernelGGL(filter_best_perim_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->cls), as<double>(w->perim),
+                           as<int32_t>(w->raw), Tr, as<unsigned long long>(w->best_p));
+        hipLaunchKernelGGL(filter_best_tri_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->cls), as<double>(w->perim),
+                           as<int32_t>(w->raw), Tr, as<unsigned long long>(w->best_p), as<unsigned>(w->best_t));
+        hipLaunchKernelGGL(filter_first_node_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, as<uint8_t>(w->has_kept),
+                           as<uint8_t>(w->any_valid), as<unsigned>(w->best_t), n, as<unsigned>(w->first_v));
+        hipLaunchKernelGGL(filter_owner_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, as<uint8_t>(w->has_kept),
+                           as<uint8_t>(w->any_valid), as<unsigned>(w->best_t), as<unsigned>(w->first_v), n, as<unsigned long long>(w->nmask));
+        HIP_TRY(ctx, hipGetLastError());
+        SAME_TRY(same_compact_mask_core(ctx, as<unsigned long long>(w->nmask), n_words, n, as<int32_t>(w->nlist), dc + 4));   // count -> dc[5]
+    }
+    unsigned long long *h = static_cast<unsigned long long *>(w->host);   // bytes [0, 64) of the staging block are scalars
+    HIP_TRY(ctx, hipMemcpyAsync(h, dc, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t n_keep = (int64_t)h[1], n_near = (int64_t)h[2], n_add = readd ? (int64_t)h[5] : 0;
+    out_counts[0] = n_keep;
+    out_counts[1] = n_add;
+    out_counts[2] = n_near;
+    if (n_near) return SAME_OK;                      // knife-edge cosines: the caller decides them as the reference does and passes the triangles in
+    if (n_keep + n_add) {
+        hipLaunchKernelGGL(filter_emit_kernel, dim3(grid_for(n_keep + n_add)), dim3(256), 0, ctx->stream, as<int32_t>(w->raw),
+                           as<int32_t>(w->klist), n_keep, as<int32_t>(w->nlist), n_add, as<unsigned>(w->best_t), as<int32_t>(w->tris));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    w->Tr = n_keep + n_add;
+    w->filtered = 1;
+    return SAME_OK;
+}
+
 int same_window_finish(same_window *w, const int32_t *tris, int64_t Tr, double no_match_penalty, int32_t *out_match_row,
                        uint8_t *out_point_flag, int64_t *out_stats) {
     if (!w) return SAME_EINVAL;
     same_ctx *ctx = w->ctx;
-    REQUIRE(ctx, w->staged == 2 && out_stats && Tr >= 0 && Tr < ((int64_t)1 << 31) - 512 && (Tr == 0 || tris));
+    const bool resident = tris == nullptr && Tr < 0;      // the triangles same_window_filter left on the device
+    REQUIRE(ctx, w->staged == 2 && out_stats);
+    if (resident) {
+        REQUIRE(ctx, w->filtered);
+        Tr = w->Tr;
+    }
+    REQUIRE(ctx, Tr >= 0 && Tr < ((int64_t)1 << 31) - 512 && (Tr == 0 || tris || resident));
     const int64_t n = w->n_ua, P = w->P;
     REQUIRE(ctx, n == 0 || (out_match_row && out_point_flag));
     for (int q = 0; q < 8; ++q) out_stats[q] = 0;
     SAME_TRY(same_use(ctx));
-    SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n, "triangles"));
+    if (!resident) SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n, "triangles"));
     w->Tr = Tr;
     w->finished = 0;
     if (n == 0) { w->finished = 1; return SAME_OK; }
@@ -498,7 +673,7 @@ int same_window_finish(same_window *w, const int32_t *tris, int64_t Tr, double n
     unsigned long long *dstats = dc + 8;
     HIP_TRY(ctx, hipMemsetAsync(dc, 0, 16 * sizeof(unsigned long long), ctx->stream));
     if (Tr) {
-        HIP_TRY(ctx, hipMemcpyAsync(w->tris.p, tris, (size_t)Tr * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (!resident) HIP_TRY(ctx, hipMemcpyAsync(w->tris.p, tris, (size_t)Tr * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         SAME_TRY(same_tri_sign_weight_dev(ctx, as<double>(w->axy_c), as<double>(w->size_c), as<int32_t>(w->tris), Tr, as<int8_t>(w->sign),
                                           as<double>(w->weight)));
     }

@@ -10,7 +10,7 @@ simplices are identical to an in-process call.
 Helpers are plain `python -c` children speaking a length-prefixed binary protocol over their pipes (no multiprocessing:
 nothing re-imports the caller's `__main__`, nothing is forked from a process that has initialised the GPU, and the
 helpers import numpy + scipy.spatial only -- they never touch the GPU).  `SAME_QHULL_WORKERS` sets their number
-(default: three quarters of the CPUs this process may use, at most 12; 0 = compute in-process, no helpers).
+(default: the CPUs this process may use less one, at most 16; 0 = compute in-process, no helpers).
 
 Placement matters more than the count: Qhull lives in the last-level cache, and eight helpers that the scheduler stacks on one
 CCD of an EPYC host triangulate a 13 000-point set in 45 ms each against 21 ms alone.  Helper i is therefore confined to the
@@ -261,7 +261,7 @@ def default_workers():
     v = os.environ.get("SAME_QHULL_WORKERS")
     if v is not None:
         return max(0, int(v))
-    return max(1, min(12, cpu_budget() * 3 // 4))
+    return max(1, min(16, cpu_budget() - 1))
 
 
 def warm(count=None):

@@ -286,7 +286,7 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
 
 # ---- the window path with the sections resident on the device (csrc/window.hip) -------------------------------------------
 
-_W_ALIGNED_XY, _W_ALIGNED_ROWS, _W_ROWS_M, _W_ROWS_R, _W_PAIRS, _W_COSTS, _W_KEPT, _W_SIGNS, _W_WEIGHTS, _W_MATCH = range(10)
+_W_ALIGNED_XY, _W_ALIGNED_ROWS, _W_ROWS_M, _W_ROWS_R, _W_PAIRS, _W_COSTS, _W_KEPT, _W_SIGNS, _W_WEIGHTS, _W_MATCH, _W_TRIANGLES = range(11)
 
 
 class DeviceSection:
@@ -301,10 +301,12 @@ class DeviceSection:
         self.cost_dtype = np.dtype(cost_dtype)
         assert self.cost_dtype in (np.dtype(np.float64), np.dtype(np.float32))
         size = np.ascontiguousarray(section.size, dtype=np.float64)
+        tid = None if section.type_id is None else np.ascontiguousarray(section.type_id, dtype=np.int32)
         h = ctypes.c_void_p()
         with ctx.lock:
             rc = ctx.lib.same_section_create(ctx.handle, section.xy.ctypes.data, section.types.ctypes.data, section.types.shape[1],
-                                             size.ctypes.data, len(section.xy), int(self.cost_dtype == np.dtype(np.float32)), ctypes.byref(h))
+                                             size.ctypes.data, None if tid is None else tid.ctypes.data, len(section.xy),
+                                             int(self.cost_dtype == np.dtype(np.float32)), ctypes.byref(h))
             if rc != 0 and h.value:
                 ctx.lib.same_section_destroy(h)
             ctx.check(rc, "same_section_create")
@@ -356,21 +358,38 @@ class DeviceWindow:
         dtype, shape = {_W_ALIGNED_XY: (np.float64, (kept, 2)), _W_ALIGNED_ROWS: (np.int32, (kept,)), _W_ROWS_M: (np.int32, (n_m,)),
                         _W_ROWS_R: (np.int32, (n_r,)), _W_PAIRS: (np.int32, (pairs, 2)), _W_COSTS: (np.float64, (pairs,)),
                         _W_KEPT: (np.int32, (kept,)), _W_SIGNS: (np.int8, (self.n_triangles,)),
-                        _W_WEIGHTS: (np.float64, (self.n_triangles,)), _W_MATCH: (np.int32, (kept,))}[what]
+                        _W_WEIGHTS: (np.float64, (self.n_triangles,)), _W_MATCH: (np.int32, (kept,)),
+                        _W_TRIANGLES: (np.int32, (self.n_triangles, 3))}[what]
         out = np.empty(shape, dtype)
         with self.ctx.lock:
             self.ctx.check(self.ctx.lib.same_window_fetch(self.handle, int(what), out.ctypes.data, out.nbytes), "same_window_fetch")
         return out
 
+    def filter(self, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node=True):
+        """filter_triangles_by_radius of the kept aligned cells' Delaunay simplices on the device.  -> (kept, added back, cosines
+        within near_tol of the threshold); when the last is not zero the caller filters on the host and passes finish() its triangles."""
+        tris = ops._tris(simplices)
+        counts = np.zeros(3, np.int64)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_window_filter(self.handle, tris.ctypes.data, len(tris), float(radius), int(angle_enabled), float(cos_thr),
+                                                           float(near_tol), int(bool(ignore_same_type)), int(bool(ensure_min_triangle_per_node)),
+                                                           counts.ctypes.data), "same_window_filter")
+        kept, added, near = (int(c) for c in counts)
+        self.n_triangles = 0 if near else kept + added
+        return kept, added, near
+
     def finish(self, triangles, no_match_penalty):
-        """-> (section row of the matched reference cell per kept aligned cell or -1, XY-order flag per kept cell, stats dict)"""
-        tris = ops._tris(triangles)
+        """-> (section row of the matched reference cell per kept aligned cell or -1, XY-order flag per kept cell, stats dict).
+        triangles None = the ones filter() left on the device."""
         kept = self.counts[2]
         match_row, flag, stats = np.empty(kept, np.int32), np.empty(kept, np.uint8), np.zeros(8, np.int64)
+        tris = None if triangles is None else ops._tris(triangles)
         with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_window_finish(self.handle, tris.ctypes.data, len(tris), float(no_match_penalty),
-                                                           match_row.ctypes.data, flag.ctypes.data, stats.ctypes.data), "same_window_finish")
-        self.n_triangles = len(tris)
+            self.ctx.check(self.ctx.lib.same_window_finish(self.handle, None if tris is None else tris.ctypes.data, -1 if tris is None else len(tris),
+                                                           float(no_match_penalty), match_row.ctypes.data, flag.ctypes.data, stats.ctypes.data),
+                           "same_window_finish")
+        if tris is not None:
+            self.n_triangles = len(tris)
         names = ("checked", "flipped", "xy_comparisons", "xy_violations", "xy_triangles", "area_flips", "greedy_rounds", "matched")
         return match_row, flag, dict(zip(names, (int(v) for v in stats)))
 
@@ -389,11 +408,11 @@ class DeviceWindow:
 
 class DeviceWindowResult:
     """What one window of `iter_device_windows` leaves on the host: `rows_m` section rows of the kept aligned cells, `axy` their XY,
-    `triangles` the kept Delaunay triangles over them, `match_row` the section row of each cell's matched reference cell (-1 = none),
+    `triangles` the kept Delaunay triangles over them (None unless asked for or filtered on the host; `n_triangles` always), `match_row` the section row of each cell's matched reference cell (-1 = none),
     `point_flag` the XY-order sweep's per-cell flag, `stats` the sweeps' counters, `counts` (aligned in box, refs in box, kept, pairs);
     `state` is the live DeviceWindow while the result is the newest one yielded (pairs, costs, signs ... through `state.fetch`)."""
 
-    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "match_row", "point_flag", "stats", "counts", "state")
+    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "n_triangles", "match_row", "point_flag", "stats", "counts", "state")
 
     def __init__(self, window):
         self.window = window
@@ -402,17 +421,20 @@ class DeviceWindowResult:
 
 
 def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
-                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None):
+                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False):
     """The window path of `iter_window_arrays` + the greedy incumbent and the three sweeps, with both sections resident on the
     device (`dref`, `dmoving`: DeviceSections of `ref`, `moving`): per window the host only triangulates (Qhull helpers, windows
-    ahead as before), runs the same-type re-add pass of the triangle filter and receives the match.  Yields one
+    ahead as before) and receives the match; the triangle filter runs on the device too, unless a cosine sits within 8 ulp of the
+    angle threshold (then the host re-decides it with the reference's literal expression, as triangles.classify_triangles does).  Yields one
     DeviceWindowResult per window in plan order; the numbers are those of the column pipeline
     (tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline).  A window without pairs yields `.error`."""
     from . import qhull_pool
     from ._trace import stage as marked
-    from .triangles import filter_triangles_by_radius
+    from .triangles import cos_threshold, filter_triangles_by_radius
 
     ctx = ops._ctx(ctx)
+    angle_enabled, cos_thr = cos_threshold(min_angle_deg)
+    near_tol = float(8 * np.spacing(abs(cos_thr))) if (angle_enabled and np.isfinite(cos_thr)) else 0.0
     depth = qhull_pool.lookahead()
     qhull_pool.warm(min(depth, len(plan)))
     # window states (their device buffers, grown once) are kept with the context from one call to the next: a pass over a plan
@@ -442,12 +464,18 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
         state, ticket = staged
         with marked("triangulate (wait for helper)"):
             tris = ticket.result()
-        with marked("triangle filter"):
-            tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
-            out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
-                                                       min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
+        with marked("triangle filter (device)"):
+            _kept, _added, near = state.filter(tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles)
+        if near:
+            with marked("triangle filter (host: a cosine at the threshold)"):
+                tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
+                out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
+                                                           min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
         with marked("signs + incumbent + sweeps (device)"):
             out.match_row, out.point_flag, out.stats = state.finish(out.triangles, no_match_penalty)
+        out.n_triangles = state.n_triangles
+        if fetch_triangles and out.triangles is None:
+            out.triangles = state.fetch(_W_TRIANGLES)
         out.state = state
         return out
 

@@ -420,7 +420,7 @@ def test_device_windows_equal_the_column_pipeline(cost_dtype):
     kw = dict(radius=30, knn=6, dist_ct_coeff=1.5, min_angle_deg=12, ignore_same_type_triangles=True)
     arrays = list(W.iter_window_arrays(ref_sec, mov_sec, plan, cost_dtype=cost_dtype, **kw))
     penalty, errors, windows, n_matched, n_rows = 0.006, 0, 0, 0, 0   # a penalty some rows' best pair does not beat: `prefer` is not all ones
-    for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, **kw)):
+    for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True, **kw)):
         assert dw.window is wa.window
         if wa.error is not None:
             assert isinstance(dw.error, ValueError) and str(dw.error) == str(wa.error)
@@ -455,6 +455,40 @@ def test_device_windows_equal_the_column_pipeline(cost_dtype):
                                 matched=int(np.count_nonzero(match >= 0)))
         windows += 1
     assert errors >= 1 and windows > 10 and 0.2 * n_rows < n_matched < 0.95 * n_rows
+    # other filter settings (no angle rule; same-type triangles kept), triangles only
+    for kw2 in (dict(kw, min_angle_deg=None), dict(kw, ignore_same_type_triangles=False), dict(kw, min_angle_deg=40, radius=18)):
+        some = plan[3:9]
+        for wa, dw in zip(W.iter_window_arrays(ref_sec, mov_sec, some, cost_dtype=cost_dtype, **kw2),
+                          W.iter_device_windows(ref_sec, mov_sec, dref, dmov, some, no_match_penalty=penalty, fetch_triangles=True, **kw2)):
+            assert (wa.error is None) == (dw.error is None)
+            if wa.error is None:
+                assert np.array_equal(dw.triangles, wa.triangles) and dw.n_triangles == len(wa.triangles)
+                assert np.array_equal(dw.state.fetch(W._W_SIGNS), wa.signs.astype(np.int8))
+    # a cosine "at" the threshold (forced here by a huge tolerance) is left to the host: nothing stays on the device for finish()
+    from scipy.spatial import Delaunay
+
+    from same_amd._lib import SameHipError
+    from same_amd.triangles import cos_threshold, filter_triangles_by_radius
+
+    st = W.DeviceWindow()
+    n_m, n_r, kept, n_pairs = st.stage(dmov, dref, plan[5]["box"], 30, 6, 1.5)
+    assert kept > 100 and n_pairs > kept
+    axy, rows = st.fetch(W._W_ALIGNED_XY), st.fetch(W._W_ALIGNED_ROWS)
+    simplices = Delaunay(axy).simplices
+    en, thr = cos_threshold(12)
+    k0, k1, near = st.filter(simplices, 30, en, thr, 4.0, True)
+    assert near > 0 and st.n_triangles == 0
+    with pytest.raises(SameHipError):
+        st.finish(None, penalty)
+    host = filter_triangles_by_radius(axy, simplices, 30, ignore_same_type_triangles=True, min_angle_deg=12, verbose=False, _rows_as_array=True,
+                                      _type_id=mov_sec.type_id[rows])
+    k0, k1, near = st.filter(simplices, 30, en, thr, 0.0, True)
+    assert near == 0 and k0 + k1 == len(host) and k1 > 0
+    a, b, c = st.finish(None, penalty)
+    assert np.array_equal(st.fetch(W._W_TRIANGLES), host)
+    a2, b2, c2 = st.finish(host, penalty)                  # the same triangles passed in from the host: the same answers
+    assert np.array_equal(a, a2) and np.array_equal(b, b2) and c == c2
+    st.close()
     dref.close()
     dmov.close()
 

@@ -3,7 +3,7 @@ Usage: python tools/cfg5_profile.py [cells]"""
 import cProfile, io, os, pstats, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
-sys.argv = ["bench.py", "--workload", "cfg5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--cfg5-threads", "1", "--cfg5-cells", sys.argv[1] if len(sys.argv) > 1 else "1000000"]
+sys.argv = ["bench.py", "--workload", "cfg5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--cfg5-threads", "1", "--cfg5-pipeline", os.environ.get("CFG5_PIPELINE", "device"), "--cfg5-cells", sys.argv[1] if len(sys.argv) > 1 else "1000000"]
 import bench
 pr = cProfile.Profile()
 pr.enable()

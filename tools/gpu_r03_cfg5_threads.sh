@@ -3,7 +3,7 @@
 set -o pipefail
 out=gpurun_out/${1:-r04m}; mkdir -p $out
 for t in ${2:-1 2 4}; do
-  timeout -k 10 200 python3 bench.py --workload cfg5 --cfg5-threads $t --steps 3 --warmup 1 --no-cpu-baseline > $out/cfg5_t$t.json 2>> $out/err.log || exit 1
+  timeout -k 10 200 python3 bench.py --workload cfg5 --cfg5-pipeline columns --cfg5-threads $t --steps 3 --warmup 1 --no-cpu-baseline > $out/cfg5_t$t.json 2>> $out/err.log || exit 1
   python3 - $out/cfg5_t$t.json $t <<'P'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
