@@ -234,3 +234,96 @@ def test_fuzz_merge_dedup(ops, oracle):
             r = rng.integers(0, ids, n).astype(np.int32)
             got = ops.merge_dedup(viol, win, a, r)
             assert np.array_equal(got, oracle.merge_dedup(viol, win, a, r)), (rnd, case, n, n_win, ids)
+
+
+def test_fuzz_device_windows(ops):
+    """The device-resident window path (csrc/window.hip) against the column pipeline + host-buffer entry points on random small
+    sections: ragged sizes, T from 0, k across both prune kernels' capacities, lattice / clustered / duplicate points, radii from
+    tiny to whole-section, fp32 and fp64 costs, integer and float sizes, boxes that are empty on one side, every filter setting."""
+    from scipy.spatial import QhullError
+    from window_check import check_window
+
+    from same_amd import windows as W
+
+    for rnd in range(ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"device window soak round {rnd}", flush=True)
+        rng = np.random.default_rng(77 + 104729 * rnd)
+        done = errors = 0
+        for case in range(36):
+            n_r, n_m = int(rng.integers(5, 2500)), int(rng.integers(5, 2500))
+            T, k = int(rng.choice([0, 1, 3, 8, 20, 33])), int(rng.choice([1, 2, 5, 8, 31, 64, 65, 130]))
+            side = float(rng.choice([50.0, 400.0]))
+            radius = float(rng.choice([0.5, 4.0, side / 8, side / 2, side * 2]))
+            mode_r, mode_m = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            rxy, mxy = _points(rng, n_r, side, mode_r), _points(rng, n_m, side, mode_m)
+            size = rng.integers(1, 4, n_m) if case % 2 else rng.uniform(0.5, 3.0, n_m)
+            ref_sec = W.Section(rxy, rng.gamma(0.3, 30.0, (n_r, T)), rng.integers(0, 3, n_r).astype(np.int32), None)
+            mov_sec = W.Section(mxy, rng.gamma(0.3, 30.0, (n_m, T)), rng.integers(0, 3, n_m).astype(np.int32) if case % 5 else None, size)
+            dt = "float32" if case % 3 else "float64"
+            dref, dmov = W.DeviceSection(ref_sec, dt), W.DeviceSection(mov_sec, dt)
+            cut = float(rng.uniform(0.2, 0.8)) * side
+            plan = [dict(box=(-1.0, side + 5.0, -1.0, side + 5.0)), dict(box=(-1.0, cut, -1.0, side + 5.0)),
+                    dict(box=(cut, side + 5.0, cut, side + 5.0)), dict(box=(side + 10.0, side + 20.0, 0.0, 1.0))]
+            kw = dict(radius=radius, knn=k, dist_ct_coeff=float(rng.choice([1.0, 0.3])), min_angle_deg=[15, None, 35][case % 3],
+                      ignore_same_type_triangles=bool(case % 4))
+            penalty = float(rng.choice([100.0, 5.0, 0.05]))
+            try:
+                arrays = list(W.iter_window_arrays(ref_sec, mov_sec, plan, cost_dtype=dt, **kw))
+            except (QhullError, ValueError):      # a window whose kept cells Qhull cannot triangulate (collinear / too few): both forms raise
+                with pytest.raises((QhullError, ValueError)):
+                    list(W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True, **kw))
+                errors += 1
+                continue
+            for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True, **kw)):
+                assert (wa.error is None) == (dw.error is None), (case, wa.window)
+                if wa.error is None:
+                    check_window(W, ops, wa, dw, penalty)
+                    done += 1
+            dref.close()
+            dmov.close()
+        assert done > 30, (done, errors)
+
+
+def test_device_window_argument_checks(ops):
+    """The window entry points refuse what they cannot run instead of running it: sections that do not belong together, a fetch of
+    the wrong size or before its producer, triangles out of range, finish without stage."""
+    from same_amd import windows as W
+    from same_amd._lib import SameHipError
+
+    rng = np.random.default_rng(5)
+    a = W.Section(rng.uniform(0, 100, (400, 2)), rng.random((400, 3)), rng.integers(0, 2, 400).astype(np.int32), None)
+    b = W.Section(rng.uniform(0, 100, (300, 2)), rng.random((300, 4)), None, None)          # another number of type columns
+    da, da32, db = W.DeviceSection(a, "float64"), W.DeviceSection(a, "float32"), W.DeviceSection(b, "float64")
+    st = W.DeviceWindow()
+    box = (0.0, 100.0, 0.0, 100.0)
+    with pytest.raises(SameHipError):
+        st.finish(np.zeros((1, 3), np.int32), 1.0)                  # nothing staged
+    for bad in ((da, db), (da, da32)):                             # T differs; cost types differ
+        with pytest.raises(SameHipError):
+            st.stage(bad[0], bad[1], box, 10.0, 4, 1.0)
+    with pytest.raises(SameHipError):
+        st.stage(da, da, box, -1.0, 4, 1.0)
+    with pytest.raises(SameHipError):
+        st.stage(da, da, box, 10.0, 0, 1.0)
+    assert st.stage(da, da, (200.0, 300.0, 0.0, 1.0), 10.0, 4, 1.0) == (0, 0, 0, 0)          # nobody in the box
+    assert len(st.fetch(W._W_ROWS_M)) == 0 and len(st.fetch(W._W_ALIGNED_XY)) == 0
+    n_m, n_r, kept, n_pairs = st.stage(da, da, box, 10.0, 4, 1.0)
+    assert n_m == n_r == kept == 400 and 400 <= n_pairs <= 1600
+    with pytest.raises(SameHipError):
+        st.fetch(W._W_SIGNS)                                         # before finish
+    with pytest.raises(SameHipError):
+        st.ctx.check(st.ctx.lib.same_window_fetch(st.handle, W._W_PAIRS, np.zeros(4, np.int32).ctypes.data, 16), "fetch")   # wrong size
+    with pytest.raises(SameHipError):
+        st.ctx.check(st.ctx.lib.same_window_fetch(st.handle, 99, np.zeros(4, np.int32).ctypes.data, 16), "fetch")            # unknown selector
+    with pytest.raises(SameHipError):
+        st.finish(np.array([[0, 1, 400]], np.int32), 1.0)            # vertex out of range: reported, not dereferenced
+    with pytest.raises(SameHipError):
+        st.filter(np.array([[0, 1, -1]], np.int32), 10.0, 1, 0.5, 0.0, True)
+    with pytest.raises(SameHipError):
+        st.finish(None, 1.0)                                         # no triangles were left on the device
+    row, flag, stats = st.finish(np.zeros((0, 3), np.int32), 1.0)    # no triangles at all: a match and empty sweeps
+    assert stats["checked"] == stats["xy_comparisons"] == stats["area_flips"] == 0 and stats["matched"] == np.count_nonzero(row >= 0) > 0
+    assert not flag.any()
+    for h in (st, da, da32, db):
+        h.close()

@@ -403,6 +403,8 @@ def test_device_windows_equal_the_column_pipeline(cost_dtype):
     plus the host-buffer entry points -- every window of a plan, thin strips, a window without reference cells, integer and
     float sizes: the same kept cells, pairs (reference cells compared by section row: the device path does not renumber them),
     costs, triangles, signs, weights, match, per-cell flags and counters."""
+    from window_check import check_window
+
     from same_amd import ops, synth
     from same_amd import windows as W
 
@@ -427,32 +429,7 @@ def test_device_windows_equal_the_column_pipeline(cost_dtype):
             errors += 1
             continue
         assert dw.error is None
-        st = dw.state
-        assert np.array_equal(dw.rows_m, wa.rows_m) and np.array_equal(dw.axy, wa.axy)
-        pairs, rows_r = st.fetch(W._W_PAIRS), st.fetch(W._W_ROWS_R)
-        assert dw.counts == (len(st.fetch(W._W_ROWS_M)), len(rows_r), len(wa.rows_m), len(wa.pairs))
-        assert np.array_equal(pairs[:, 0], wa.pairs[:, 0]) and np.array_equal(rows_r[pairs[:, 1]], wa.rows_r[wa.pairs[:, 1]])
-        assert np.array_equal(st.fetch(W._W_ROWS_M)[st.fetch(W._W_KEPT)], wa.rows_m)
-        assert np.array_equal(st.fetch(W._W_COSTS), wa.costs)
-        assert np.array_equal(dw.triangles, wa.triangles)
-        assert np.array_equal(st.fetch(W._W_SIGNS), wa.signs.astype(np.int8))
-        assert np.array_equal(st.fetch(W._W_WEIGHTS), np.asarray(wa.weights, dtype=np.float64))
-        # the incumbent and the sweeps through the host-buffer entry points on the column pipeline's arrays
-        p32 = wa.pairs.astype(np.int32)
-        wants = ops.pair_rowmin(p32, wa.costs, wa.n_aligned) < penalty * wa.size.astype(float)
-        pair_of_row, rounds = ops.greedy_match(p32, wa.costs, wa.n_aligned, wa.n_ref, wants)
-        match = np.where(pair_of_row >= 0, p32[np.maximum(pair_of_row, 0), 1], -1).astype(np.int32)
-        n_matched, n_rows = n_matched + int(np.count_nonzero(match >= 0)), n_rows + wa.n_aligned
-        assert np.array_equal(dw.match_row, np.where(match >= 0, wa.rows_r[np.maximum(match, 0)], -1))
-        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned)
-        checked, viol = sw.sweep_match(match)
-        sw.close()
-        _e, _t, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match)
-        _b, _a, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match)
-        assert np.array_equal(dw.point_flag, pflag)
-        assert dw.stats == dict(checked=int(checked), flipped=len(viol), xy_comparisons=int(counts[0]), xy_violations=int(counts[1]),
-                                xy_triangles=int(counts[2]), area_flips=int(np.count_nonzero(flipped)), greedy_rounds=int(rounds),
-                                matched=int(np.count_nonzero(match >= 0)))
+        n_matched, n_rows = n_matched + check_window(W, ops, wa, dw, penalty), n_rows + wa.n_aligned
         windows += 1
     assert errors >= 1 and windows > 10 and 0.2 * n_rows < n_matched < 0.95 * n_rows
     # other filter settings (no angle rule; same-type triangles kept), triangles only

@@ -106,3 +106,43 @@ def test_no_helper_mode_and_default_size(monkeypatch):
     assert qhull_pool.default_workers() == 0
     monkeypatch.delenv("SAME_QHULL_WORKERS")
     assert 0 <= qhull_pool.default_workers() <= 8
+
+
+def test_helpers_are_confined_to_one_cache_domain_each(monkeypatch):
+    """Placement (SAME_QHULL_PIN, on by default): helper i may only run on the CPUs of ONE last-level-cache domain, consecutive
+    helpers on different ones, the helpers of another local rank shifted; with a single domain, or switched off, nothing is
+    pinned.  The simplices do not depend on it."""
+    import os
+
+    from same_amd import qhull_pool
+
+    allowed = sorted(os.sched_getaffinity(0))
+    real = qhull_pool._l3_domains()
+    assert real == [] or sorted(c for d in real for c in d) == allowed          # a partition of what we may run on, or unknown
+    assert 1 <= qhull_pool.cpu_budget() <= len(allowed)
+    if len(allowed) < 2:
+        pytest.skip("one CPU: nothing to place")
+    halves = [allowed[: len(allowed) // 2], allowed[len(allowed) // 2:]]
+    monkeypatch.setattr(qhull_pool, "_l3_domains", lambda: halves)
+    pts = np.random.default_rng(3).uniform(0, 100, (500, 2))
+    want = Delaunay(pts).simplices
+    for local_rank, first in (("0", 0), ("1", 1)):
+        monkeypatch.setenv("LOCAL_RANK", local_rank)
+        p = qhull_pool.QhullPool(3)
+        try:
+            tickets = [p.submit(pts) for _ in range(3)]
+            assert all(np.array_equal(t.result(), want) for t in tickets)
+            got = [sorted(os.sched_getaffinity(proc.pid)) for proc in p.procs]
+            assert got == [halves[(first * 3 + i) % 2] for i in range(3)]
+        finally:
+            p.close()
+    monkeypatch.setenv("SAME_QHULL_PIN", "0")
+    p = qhull_pool.QhullPool(2)
+    try:
+        assert p.domains == [] and np.array_equal(p.submit(pts).result(), want)
+        assert sorted(os.sched_getaffinity(p.procs[0].pid)) == allowed
+    finally:
+        p.close()
+    monkeypatch.delenv("SAME_QHULL_PIN")
+    monkeypatch.setattr(qhull_pool, "_l3_domains", lambda: [allowed])
+    assert qhull_pool.QhullPool(2).domains == []                                   # one domain: nothing to choose
