@@ -222,6 +222,7 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
     op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
     big_last = [w for w in plan if w["n_mov"] > 5_000][-1]
     assert plan[0]["n_mov"] > 5_000 and plan[len(plan) // 2]["n_mov"] > 5_000 and plan[-1]["n_mov"] < 1_000   # + the thin edge strip
+    expect = []
     for w in (plan[0], plan[len(plan) // 2], big_last, plan[-1]):
         x0, x1, y0, y1 = w["box"]
         rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
@@ -277,6 +278,32 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
         assert np.array_equal(np.array([before[t] for t in range(len(tri))]), ob)
         assert np.array_equal(np.array([np.nan if after[t] is None else after[t] for t in range(len(tri))]), oa, equal_nan=True)
         assert flipped == np.flatnonzero(ofl).tolist()
+        expect.append(dict(window=w, rows_m=na["Cell_Num_Old"].to_numpy(), rows_r=nr["Cell_Num_Old"].to_numpy(), pairs=pairs, c32=c32, tri=tri,
+                           signs=np.asarray(prep.source_signs, dtype=np.int8), chosen=och, checked=ochecked, flipped=len(oviol),
+                           area_flips=int(np.count_nonzero(ofl)), xy=orep["violation_summary"]))
+    # the same four windows with both 1M-cell sections resident on the device (csrc/window.hip: what bench.py --workload cfg5 times)
+    from same_amd import windows as W
+
+    assert np.array_equal(r_df["Cell_Num_Old"].to_numpy(), np.arange(len(r_df))) and np.array_equal(m_df["Cell_Num_Old"].to_numpy(), np.arange(len(m_df)))
+    ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
+    dref, dmov = W.DeviceSection(ref_sec, "float32"), W.DeviceSection(mov_sec, "float32")
+    got = W.iter_device_windows(ref_sec, mov_sec, dref, dmov, [e["window"] for e in expect], radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
+                                ignore_same_type_triangles=True, no_match_penalty=100.0, fetch_triangles=True)
+    for e, dw in zip(expect, got):
+        assert dw.error is None and np.array_equal(dw.rows_m, e["rows_m"])
+        dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
+        assert np.array_equal(dp[:, 0], e["pairs"][:, 0]) and np.array_equal(rows_r[dp[:, 1]], e["rows_r"][e["pairs"][:, 1]])
+        assert np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), e["c32"])
+        assert np.array_equal(dw.triangles, e["tri"]) and np.array_equal(dw.state.fetch(W._W_SIGNS), e["signs"])
+        match_o = np.full(len(e["rows_m"]), -1, np.int64)
+        for i, j, _p in e["chosen"]:
+            match_o[i] = e["rows_r"][j]
+        assert np.array_equal(dw.match_row, match_o)
+        st = dw.stats
+        assert (st["checked"], st["flipped"], st["area_flips"], st["matched"]) == (e["checked"], e["flipped"], e["area_flips"], len(e["chosen"]))
+        assert st["xy_comparisons"] == e["xy"]["total_comparisons"] and st["xy_violations"] == e["xy"]["total_violations"]
+    dref.close()
+    dmov.close()
     # an unknown cost dtype is refused at the boundary
     with pytest.raises(ValueError):
         same_amd.prepare_same_inputs(rs, ms, cols, optim_params=dict(op, hip_cost_dtype="float16"), verbose=False)
