@@ -455,6 +455,7 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     out_counts[1] = n_r;
     w->staged = 1;
     if (n_m == 0 || n_r == 0) return SAME_OK;      // no pairs: the caller raises what run_same raises (src/same.py:1003)
+    REQUIRE(ctx, n_m * (int64_t)k < ((int64_t)1 << 31) - 1);   // pair offsets are 32-bit
     const int T = mov->T;
     const size_t cs = w->cost_f32 ? sizeof(float) : sizeof(double);
     const int32_t *rm = as<int32_t>(w->rows_m), *rr = as<int32_t>(w->rows_r);
