@@ -3,7 +3,7 @@
 // The column pipeline (same_amd/windows.py::iter_window_arrays) subsets, prunes, compacts and gathers on the host and hands
 // every kernel its operands through host buffers: at a million cells per section the window's ~10^4 rows are cache-missing
 // gathers from 64 MB columns, and that host work -- not the kernels -- bounds BASELINE cfg 5.  Here a section's columns are
-// uploaded once (same_section) and a window is two calls:
+// uploaded once (same_section) and a window is three calls:
 //
 //   same_window_stage   box test over the sections' rows + ordered compaction (= np.flatnonzero of src/same.py:293-295, rows
 //                       ascending), row gathers, radius / k prune (src/utils.py:709-728), costs of the candidate lists in the
@@ -14,11 +14,11 @@
 //                       triangles added back so that every node keeps one (src/helpers.py:331-340, :365-389) -- all on the
 //                       device, in the reference's order.  (A cosine within 8 ulp of the angle threshold is left to the host,
 //                       which re-decides it with the reference's literal arccos: the call then only reports it.)
-//   same_window_finish  kept triangles in (or the ones same_window_filter left on the device); source signs / weights (src/same.py:1128-1146), per-row minimum and the greedy MIP
-//                       start (src/init_helpers.py:104-133), the lazy-constraint body under that incumbent
-//                       (src/same.py:645-669), XY-order sweep (src/violationhelper.py:53-117), signed-area flips
-//                       (src/same.py:1362-1402).  Back to the host: the matched reference row per kept aligned cell, the
-//                       per-cell violation flag and eight counters.
+//   same_window_finish  kept triangles in (or the ones same_window_filter left on the device); source signs / weights
+//                       (src/same.py:1128-1146), per-row minimum and the greedy MIP start (src/init_helpers.py:104-133), the
+//                       lazy-constraint body under that incumbent (src/same.py:645-669), XY-order sweep
+//                       (src/violationhelper.py:53-117), signed-area flips (src/same.py:1362-1402).  Back to the host: the
+//                       matched reference row per kept aligned cell, the per-cell violation flag and eight counters.
 //
 // Reference cells are NOT renumbered (the reference drops unreferenced ones, src/utils.py:740-742): costs, the greedy rule and
 // the sweeps read coordinates and pair order only, which a monotone renumbering does not change; the match comes back as
@@ -271,7 +271,6 @@ struct same_section {
 
 struct same_window {
     same_ctx *ctx = nullptr;
-    const same_section *ref = nullptr;
     int cost_f32 = 0, k = 0, staged = 0, finished = 0, has_type = 0, filtered = 0;
     int64_t n_m = 0, n_r = 0, n_ua = 0, P = 0, Tr = 0;
     DevBuf mask, counts, rows_m, rows_r, axy_w, rxy_w, axyc_w, rxyc_w, A_w, R_w, size_w, idx, cnt, cost, a_off, p_off, ua, rows_ua,
@@ -382,7 +381,8 @@ int same_section_create(same_ctx *ctx, const double *xy, const double *types, in
                 HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * T * sizeof(double)));
                 hipError_t e = hipMemcpyAsync(tmp, types, (size_t)n * T * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
                 if (e == hipSuccess) {
-                    hipLaunchKernelGGL(to_float_kernel, dim3(grid_for(n * T)), dim3(256), 0, ctx->stream, tmp, n * T, static_cast<float *>(s->types_c));
+                    hipLaunchKernelGGL(to_float_kernel, dim3(grid_for(n * T)), dim3(256), 0, ctx->stream, tmp, n * T,
+                                       static_cast<float *>(s->types_c));
                     e = hipStreamSynchronize(ctx->stream);
                 }
                 (void)hipFree(tmp);
@@ -427,8 +427,9 @@ void same_window_destroy(same_window *w) {
     DevBuf *all[] = {&w->mask, &w->counts, &w->rows_m, &w->rows_r, &w->axy_w, &w->rxy_w, &w->axyc_w, &w->rxyc_w, &w->A_w, &w->R_w, &w->size_w,
                      &w->idx, &w->cnt, &w->cost, &w->a_off, &w->p_off, &w->ua, &w->rows_ua, &w->axy_c, &w->size_c, &w->pairs, &w->cost64,
                      &w->type_w, &w->type_c, &w->raw, &w->cls, &w->perim, &w->maxcos, &w->kmask, &w->has_kept, &w->any_valid, &w->best_p,
-                     &w->best_t, &w->first_v, &w->nmask, &w->nlist, &w->klist, &w->tris, &w->sign, &w->weight, &w->rowmin, &w->prefer, &w->pair_of_row, &w->match, &w->match_row, &w->oflag, &w->omask,
-                     &w->edge, &w->tflag, &w->pflag, &w->before, &w->after, &w->m3, &w->flipped};
+                     &w->best_t, &w->first_v, &w->nmask, &w->nlist, &w->klist, &w->tris, &w->sign, &w->weight, &w->rowmin, &w->prefer,
+                     &w->pair_of_row, &w->match, &w->match_row, &w->oflag, &w->omask, &w->edge, &w->tflag, &w->pflag, &w->before, &w->after,
+                     &w->m3, &w->flipped};
     for (DevBuf *b : all) release(*b);
     if (w->host) (void)hipHostFree(w->host);
     delete w;
@@ -443,7 +444,6 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     SAME_TRY(same_use(ctx));
     w->staged = w->finished = w->filtered = 0;
     w->has_type = mov->type_id != nullptr;
-    w->ref = ref;
     w->cost_f32 = mov->cost_f32;
     w->k = k;
     w->n_ua = w->P = w->Tr = 0;
