@@ -1322,6 +1322,10 @@ def run_cfg5(args, group, json_fd):
                "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
                                         "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
                "threads_per_rank": n_workers,
+               "qhull": {"helpers": _qp.pool().n, "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
+                         "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / args.steps,
+                         "what": "helper processes that run scipy.spatial.Delaunay for the windows ahead (a6 stays on the host); waiting = the worker "
+                                 "threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
                "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
                "merged_matches": int(len(merged)),
                "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (the padded / pair cost kernel is the largest)",

@@ -458,6 +458,7 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
                 out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
                 return out, None
             out.rows_m, out.axy = state.fetch(_W_ALIGNED_ROWS), state.fetch(_W_ALIGNED_XY)
+        with marked("triangulate (hand-over; waits for a free helper)"):
             return out, (state, qhull_pool.pool().submit(out.axy))
 
     def finish(out, staged):
