@@ -152,44 +152,84 @@ class QhullPool:
             pass
         return p
 
+    def _readable(self, workers):
+        """Those of `workers` whose answer (or end of file) has arrived.  Call with the lock held."""
+        import select
+
+        by_fd = {}
+        for w in workers:
+            try:
+                by_fd[self.procs[w].stdout.fileno()] = w
+            except (OSError, ValueError):
+                return [w]                                # its pipe is already closed: reading it will say so
+        if not by_fd:
+            return []
+        try:
+            ready = select.select(list(by_fd), [], [], 0)[0]
+        except (OSError, ValueError):
+            return list(workers)
+        return sorted(by_fd[fd] for fd in ready)
+
+    @staticmethod
+    def _wait(files, timeout):
+        """Sleep until one of the helpers' pipes has something to read (lock NOT held: other threads keep using the pool)."""
+        import select
+
+        try:
+            select.select([f.fileno() for f in files], [], [], timeout)
+        except (OSError, ValueError):                      # a pipe was closed under us (its helper was replaced): look again
+            pass
+
     def submit(self, points):
         """Start Delaunay(points) in a helper; -> ticket with .result().  points: (n, 2) float64."""
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
-        with self.lock:
-            if self.n <= 0:
-                return _Ticket(self, None, pts)
-            # a started helper with nothing in flight is preferred (a fresh one needs ~0.3 s to import scipy); a new helper
-            # is started only while every running one is busy; when all n are busy the next in turn is drained and reused
-            for q in range(len(self.procs)):            # a helper that died while idle is replaced where it stood
-                if q not in self.pending and self.procs[q].poll() is not None:
-                    self.procs[q] = self._spawn(q)
-            idle = [q for q in range(len(self.procs)) if q not in self.pending]
-            if idle:
-                w = idle[0]
-            elif len(self.procs) < self.n:
-                w = len(self.procs)
-                self.procs.append(self._spawn(w))
-            else:
-                w = self.next % self.n
-                self.next += 1
-            if w in self.pending:                       # one request in flight per helper: read the old answer first
-                old = self.pending.pop(w)
-                try:
-                    old._value = self._read(w, old)
-                except Exception:                        # Qhull refused the OLD request's points: that ticket raises on its own result()
-                    old.worker = None
-            self.seq += 1
-            t = _Ticket(self, w, pts, self.seq)
-            if self.procs[w].poll() is not None:        # the helper has died since its last request: start another
-                self.procs[w] = self._spawn(w)
+        while True:
+            with self.lock:
+                if self.n <= 0:
+                    return _Ticket(self, None, pts)
+                # a started helper with nothing in flight is preferred (a fresh one needs ~0.3 s to import scipy); a new helper is
+                # started only while every running one is busy; when all n are busy the first whose answer has ARRIVED is drained
+                # and reused -- nobody waits for Qhull while holding the lock, so the other threads' hand-overs and pick-ups go on
+                for q in range(len(self.procs)):            # a helper that died while idle is replaced where it stood
+                    if q not in self.pending and self.procs[q].poll() is not None:
+                        self.procs[q] = self._spawn(q)
+                idle = [q for q in range(len(self.procs)) if q not in self.pending]
+                w = None
+                if idle:
+                    w = idle[0]
+                elif len(self.procs) < self.n:
+                    w = len(self.procs)
+                    self.procs.append(self._spawn(w))
+                else:
+                    ready = self._readable(list(self.pending))
+                    if ready:
+                        w = min(ready, key=lambda q: (q - self.next) % self.n)       # in turn among the ready ones
+                        self.next = w + 1
+                if w is not None:
+                    return self._hand_over(w, pts)
+                busy = [self.procs[q].stdout for q in self.pending]
+            self._wait(busy, 0.25)
+
+    def _hand_over(self, w, pts):
+        """Give helper w the points (lock held).  Its previous answer, if still unread, has arrived and is read first."""
+        if w in self.pending:                           # one request in flight per helper
+            old = self.pending.pop(w)
             try:
-                p = self.procs[w]
-                p.stdin.write(struct.pack("<qq", t.seq, len(pts)) + pts.tobytes())
-                p.stdin.flush()
-                self.pending[w] = t
-            except (OSError, ValueError):
-                t.worker = None                          # helper is gone: this one is computed in-process on result()
-            return t
+                old._value = self._read(w, old)
+            except Exception:                            # Qhull refused the OLD request's points: that ticket raises on its own result()
+                old.worker = None
+        self.seq += 1
+        t = _Ticket(self, w, pts, self.seq)
+        if self.procs[w].poll() is not None:            # the helper has died since its last request: start another
+            self.procs[w] = self._spawn(w)
+        try:
+            p = self.procs[w]
+            p.stdin.write(struct.pack("<qq", t.seq, len(pts)) + pts.tobytes())
+            p.stdin.flush()
+            self.pending[w] = t
+        except (OSError, ValueError):
+            t.worker = None                              # helper is gone: this one is computed in-process on result()
+        return t
 
     def _retire(self, w):
         """Stop helper w (its stream can no longer be trusted, or it is gone) and put a fresh one in its place."""
@@ -230,10 +270,15 @@ class QhullPool:
     def _collect(self, ticket):
         if ticket.worker is None:
             return _delaunay_here(ticket.points)
-        with self.lock:
-            if self.pending.get(ticket.worker) is ticket:
-                del self.pending[ticket.worker]
-                return self._read(ticket.worker, ticket)
+        while True:
+            with self.lock:
+                if self.pending.get(ticket.worker) is not ticket:
+                    break                                  # a later hand-over to the same helper has read this answer already
+                if self._readable([ticket.worker]):
+                    del self.pending[ticket.worker]
+                    return self._read(ticket.worker, ticket)
+                f = self.procs[ticket.worker].stdout
+            self._wait([f], 0.25)                          # Qhull is still at it: wait without the lock
         return ticket._value if ticket._value is not None else _delaunay_here(ticket.points)
 
     def close(self):

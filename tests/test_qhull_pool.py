@@ -146,3 +146,56 @@ def test_helpers_are_confined_to_one_cache_domain_each(monkeypatch):
     monkeypatch.delenv("SAME_QHULL_PIN")
     monkeypatch.setattr(qhull_pool, "_l3_domains", lambda: [allowed])
     assert qhull_pool.QhullPool(2).domains == []                                   # one domain: nothing to choose
+
+
+def test_threads_share_the_pool_without_waiting_on_each_other():
+    """Several threads handing over and picking up through one pool (the window loop's worker threads): every ticket gets its own
+    simplices, whatever the interleaving; a thread blocked on Qhull does not hold the pool's lock (a thread whose answer is ready
+    gets it while another still waits)."""
+    import threading
+    import time
+
+    from same_amd.qhull_pool import QhullPool
+
+    pool = QhullPool(3)
+    rng = np.random.default_rng(9)
+    sets = [rng.uniform(0, 500, (int(n), 2)) for n in rng.integers(20, 4000, 40)]
+    want = [Delaunay(p).simplices for p in sets]
+    bad = []
+
+    def worker(q):
+        mine = list(range(q, len(sets), 4))
+        tickets = []
+        for j in mine:
+            tickets.append((j, pool.submit(sets[j])))
+            if len(tickets) > 2:
+                i, t = tickets.pop(0)
+                if not np.array_equal(t.result(), want[i]):
+                    bad.append(i)
+        for i, t in tickets:
+            if not np.array_equal(t.result(), want[i]):
+                bad.append(i)
+
+    threads = [threading.Thread(target=worker, args=(q,)) for q in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not bad
+    # the lock is free while a result is awaited: a big set in flight, its thread waiting, and a small one goes through meanwhile
+    big = rng.uniform(0, 1000, (150_000, 2))
+    slow = pool.submit(big)
+    box = {}
+    t0 = time.perf_counter()
+
+    def wait_for_it():
+        box["n"] = len(slow.result())
+        box["dt"] = time.perf_counter() - t0
+
+    waiter = threading.Thread(target=wait_for_it)
+    waiter.start()
+    time.sleep(0.02)                                       # the waiter is inside result() by now
+    small = pool.submit(sets[0])
+    assert np.array_equal(small.result(), want[0])
+    quick = time.perf_counter() - t0
+    waiter.join()
+    assert box["n"] > 100_000 and quick < 0.6 * box["dt"], (quick, box["dt"])
+    pool.close()
