@@ -82,6 +82,9 @@ def parse():
                     help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
+    ap.add_argument("--embed-cfg5", choices=("auto", "on", "off"), default="auto",
+                    help="after the timed loop, run BASELINE cfg 5 (`--workload cfg5`, same rank count) as a child job and embed its line as `cfg5` "
+                         "(auto: with the default workload only)")
     ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
                     help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
                          "and hands every kernel host buffers")
@@ -561,6 +564,45 @@ def gather_report(prob, dt_with, steps_with, dt_without, steps_without):
            "step_ms_with_gather": with_ms, "step_ms_without_gather": without_ms,
            "steps_without_gather": steps_without if dt_without is not None else 0}
     return out, (with_ms - without_ms if without_ms is not None else None)
+
+
+def embedded_cfg5(args, world):
+    """BASELINE cfg 5 as a sub-record of the line: `bench.py --workload cfg5 --gpus <world>` as a child job with ranks, contexts and
+    Qhull helpers of its own, while this job's ranks wait at their barrier with idle GPUs.  Never fatal: a child that fails or
+    outlives SAME_BENCH_CFG5_TIMEOUT (default 240 s) leaves an `error` entry instead of a record."""
+    import signal
+    import subprocess
+
+    limit_s = float(os.environ.get("SAME_BENCH_CFG5_TIMEOUT", "240"))
+    drop = {"RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+            "MASTER_ADDR", "MASTER_PORT", "SAME_RDV_DIR", "SAME_HIP_DEVICE", "SAME_TRACE"}
+    env = {k_: v for k_, v in os.environ.items() if k_ not in drop and not k_.startswith(("TORCHELASTIC_", "PET_"))}
+    env["SAME_BENCH_LAUNCH_TIMEOUT"] = env["SAME_BENCH_RANK_TIMEOUT"] = str(int(limit_s))   # the child's ranks also end by themselves
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg5", "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--cfg5-cells", str(args.cfg5_cells), "--cfg5-pipeline", args.cfg5_pipeline] + (["--no-cpu-baseline"] if world > 1 else [])
+    t0 = time.perf_counter()
+    try:
+        child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = child.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)           # the child's own ranks and helpers live in its session
+            child.communicate()
+            return {"error": f"no line after {limit_s:.0f} s", "command": " ".join(cmd[1:])}
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if child.returncode != 0 or not lines:
+            return {"error": f"exit code {child.returncode}: {se.strip()[-300:]}", "command": " ".join(cmd[1:])}
+        d = json.loads(lines[-1])
+    except Exception as e:  # noqa: BLE001 -- the sub-record must never cost the main line
+        return {"error": f"{type(e).__name__}: {e}", "command": " ".join(cmd[1:])}
+    keep = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "per_rank", "host_glue_share", "threads_per_rank",
+            "qhull", "merged_matches", "parity_spot_check", "rccl")
+    rec = {k_: d.get(k_) for k_ in keep if k_ in d}
+    rec["workload"], rec["pipeline"] = d["config"]["workload"], d["config"]["pipeline"]
+    rec["command"], rec["child_job_s"] = "python3 bench.py " + " ".join(cmd[2:]), time.perf_counter() - t0
+    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks, fp32 costs, all sweeps, tables exchanged once and merged) measured by a "
+                   "child job of the same rank count after this line's own timed region; windows_per_s is the whole job's")
+    return rec
 
 
 def run_rank(args):
@@ -1065,6 +1107,10 @@ def run_rank(args):
             missing = [k for k in N_GT1_KEYS if out.get(k) is None and k != "gather_hidden_ms"]
             if missing:
                 raise SystemExit(f"the N > 1 line lacks {missing}")
+        if args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and args.workload == "dense100k" and not strong and not args.no_extras):
+            note(group, "embedded cfg5 record: bench.py --workload cfg5 as a child job")
+            out["cfg5"] = embedded_cfg5(args, group.world)
+            note(group, "embedded cfg5 record: " + (f"{out['cfg5']['windows_per_s']:.0f} windows/s" if "windows_per_s" in out["cfg5"] else out["cfg5"].get("error", "?")))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
     if prob is not None:

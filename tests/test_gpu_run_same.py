@@ -540,6 +540,34 @@ def test_bench_cfg5_windows_line(world):
         assert out["cpu_baseline"] is None
 
 
+def test_bench_line_embeds_a_cfg5_record():
+    """The default line carries BASELINE cfg 5 as a sub-record measured by a child job (`--embed-cfg5`, automatic with the default
+    workload; forced here on the tiny one at a reduced section): windows/s, the pipeline, the Qhull record, the merged table's
+    size, and at one rank the child's own oracle check.  A child that cannot run leaves an error entry, not a broken line."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+           "--embed-cfg5", "on", "--cfg5-cells", "60000"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])["cfg5"]
+    assert "error" not in rec, rec
+    assert rec["n_gpus"] == 1 and rec["windows_per_s"] > 0 and rec["merged_matches"] > 1000 and rec["pipeline"].startswith("device:")
+    assert rec["workload"].startswith("cfg5: 60000-cell section") and rec["qhull"]["helpers"] >= 1 and rec["child_job_s"] > 0
+    assert "through the device-resident window path" in rec["parity_spot_check"]
+    res = subprocess.run(cmd, env=dict(env, SAME_BENCH_CFG5_TIMEOUT="0.05"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
+    assert out["value"] > 0 and "no line after" in out["cfg5"]["error"]
+
+
 def test_bench_step_with_the_fixed_point_dense_build():
     """`bench.py --dense q32`: the step's dense build is the opt-in fixed-point kernel; the line says so (dtype, kernel name, note)
     and its own check -- twin-equal and within 1e-6 relative of the exact costs on every sampled pair -- passed."""
