@@ -20,7 +20,9 @@ At N > 1 the same run then measures BASELINE cfg 4 as a second, embedded record 
   ranks own aligned-row blocks of it (dense build in 25k-row chunks through the resident buffer), all-gather the candidate
   lists, derive the common matching, and sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter
   all-reduce).  `--scaling strong --workload cfg4` runs that configuration as the main record instead.
-`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see run_cfg5.
+`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see run_cfg5;
+  the default line carries it as the sub-record `cfg5`, measured by a child job of the same rank count after the timed region
+  (embedded_cfg5; `--embed-cfg5 off` skips it).
 value = aligned-ref cell pairs covered per second by the whole job.
 
 `roofline` is for the dense kernel: algorithmic bytes s*N_r*rows + s*(T+2)*(N_r+rows) over its mean launch
