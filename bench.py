@@ -597,7 +597,7 @@ def embedded_cfg5(args, world):
         d = json.loads(lines[-1])
     except Exception as e:  # noqa: BLE001 -- the sub-record must never cost the main line
         return {"error": f"{type(e).__name__}: {e}", "command": " ".join(cmd[1:])}
-    keep = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "per_rank", "host_glue_share", "threads_per_rank",
+    keep = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "per_rank", "host_glue_share", "python_share", "threads_per_rank",
             "qhull", "merged_matches", "parity_spot_check", "rccl")
     rec = {k_: d.get(k_) for k_ in keep if k_ in d}
     rec["workload"], rec["pipeline"] = d["config"]["workload"], d["config"]["pipeline"]
@@ -1284,8 +1284,10 @@ def run_cfg5(args, group, json_fd):
     in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:"))
     stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
     lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
+    qhull_wait = sum(sec for name, (_c, sec) in rep.items() if name.startswith("triangulate"))
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * args.steps / wall_here,
                 "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / (wall_here * n_workers), "threads": n_workers,
+                "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / (wall_here * n_workers)),
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
                 "triangles": int(sum(s["triangles"] for s in stats))}
     every = group.allgather_object(mine_rec)
@@ -1365,10 +1367,15 @@ def run_cfg5(args, group, json_fd):
                                          "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
                "windows_per_s": len(plan) * args.steps / dt,
                "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
-                            "host_glue_share": [r["host_glue_share"] for r in every], "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
+                            "host_glue_share": [r["host_glue_share"] for r in every], "python_share": [r["python_share"] for r in every],
+                            "qhull_wait_s_per_step": [r["qhull_wait_s"] / args.steps for r in every],
+                            "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
                "host_glue_share": mine_rec["host_glue_share"],
                "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
                                         "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
+               "python_share": mine_rec["python_share"],
+               "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes of the "
+                                     "threads' time (the merge and the table exchange included)",
                "threads_per_rank": n_workers,
                "qhull": {"helpers": _qp.pool().n, "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
                          "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / args.steps,

@@ -525,6 +525,7 @@ def test_bench_cfg5_windows_line(world):
     assert any(k.startswith("subset + prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
     assert {"same_window_stage", "same_window_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
     assert out["qhull"]["helpers"] >= 1 and out["qhull"]["waiting_s_per_step_rank0"] >= 0 and out["qhull"]["cpu_budget"] >= 1
+    assert 0.0 <= out["python_share"] <= out["host_glue_share"] and len(pr["python_share"]) == world
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     if world == 1:
