@@ -21,8 +21,8 @@ At N > 1 the same run then measures BASELINE cfg 4 as a second, embedded record 
   lists, derive the common matching, and sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter
   all-reduce).  `--scaling strong --workload cfg4` runs that configuration as the main record instead.
 `--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see run_cfg5;
-  the default line carries it as the sub-record `cfg5`, measured by a child job of the same rank count after the timed region
-  (embedded_cfg5; `--embed-cfg5 off` skips it).
+  the default one-GPU line carries it as the sub-record `cfg5`, measured by a child job after the timed region (embedded_cfg5;
+  `--embed-cfg5 on` does the same at any rank count, `off` skips it).
 value = aligned-ref cell pairs covered per second by the whole job.
 
 `roofline` is for the dense kernel: algorithmic bytes s*N_r*rows + s*(T+2)*(N_r+rows) over its mean launch
@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
     ap.add_argument("--embed-cfg5", choices=("auto", "on", "off"), default="auto",
                     help="after the timed loop, run BASELINE cfg 5 (`--workload cfg5`, same rank count) as a child job and embed its line as `cfg5` "
-                         "(auto: with the default workload only)")
+                         "(auto: with the default workload at one rank only)")
     ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
                     help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
                          "and hands every kernel host buffers")
@@ -1109,7 +1109,10 @@ def run_rank(args):
             missing = [k for k in N_GT1_KEYS if out.get(k) is None and k != "gather_hidden_ms"]
             if missing:
                 raise SystemExit(f"the N > 1 line lacks {missing}")
-        if args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and args.workload == "dense100k" and not strong and not args.no_extras):
+        # auto: at one rank only -- the child job doubles the processes on every GPU while it runs, which a launcher's process limits
+        # at N > 1 may not allow; `--embed-cfg5 on` asks for it at any N (`bench.py --workload cfg5 --gpus N` is the same measurement)
+        if args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and args.workload == "dense100k" and group.world == 1 and not strong
+                                       and not args.no_extras):
             note(group, "embedded cfg5 record: bench.py --workload cfg5 as a child job")
             out["cfg5"] = embedded_cfg5(args, group.world)
             note(group, "embedded cfg5 record: " + (f"{out['cfg5']['windows_per_s']:.0f} windows/s" if "windows_per_s" in out["cfg5"] else out["cfg5"].get("error", "?")))
