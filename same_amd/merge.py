@@ -63,33 +63,40 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
     from scipy.sparse import csr_matrix
     from scipy.sparse.csgraph import maximum_bipartite_matching
 
+    from ._trace import stage as marked
+
     if not matches_list:
         return pd.DataFrame()
-    merged_df = pd.concat(matches_list, ignore_index=True)
-    aligned_col, ref_col = f"Aligned_{cell_id_col}", f"Ref_{cell_id_col}"
-    required = ["window_id", aligned_col, ref_col, "X", "Y", "filtered_violation"]
-    missing = [c for c in required if c not in merged_df.columns]
-    if missing:
-        raise ValueError(f"Missing required columns in matches: {missing}")
-    merged_df["filtered_violation"] = merged_df["filtered_violation"].fillna(True).astype(bool)
+    with marked("merge: concatenate the window tables"):
+        merged_df = pd.concat(matches_list, ignore_index=True)
+        aligned_col, ref_col = f"Aligned_{cell_id_col}", f"Ref_{cell_id_col}"
+        required = ["window_id", aligned_col, ref_col, "X", "Y", "filtered_violation"]
+        missing = [c for c in required if c not in merged_df.columns]
+        if missing:
+            raise ValueError(f"Missing required columns in matches: {missing}")
+        merged_df["filtered_violation"] = merged_df["filtered_violation"].fillna(True).astype(bool)
     # one row per (aligned, ref) pair: non-violating first, then the smaller window id, then the earlier row (:748-753);
     # the ids may be anything hashable, the device sees integer codes of them (equal id <=> equal code)
     if _dedup is None:
         from . import ops
 
         _dedup = ops.merge_dedup
-    kept = _dedup(merged_df["filtered_violation"].to_numpy(), _window_codes(merged_df["window_id"].to_numpy()),
-                  _equality_codes(merged_df[aligned_col].values), _equality_codes(merged_df[ref_col].values))
-    kept = np.asarray(kept, dtype=np.int64)     # rows of merged_df that survive, in the order the reference's frame has after :748-753
-    (a_codes, n_a), (r_codes, n_r) = _node_numbers(merged_df[aligned_col].values[kept]), _node_numbers(merged_df[ref_col].values[kept])
-    # every edge carries its frame row (+1: an explicit zero would be dropped), so the rows of the matched edges can be read off
-    # the matrix afterwards without a second sort or a Python dict over a table of 10^6 rows; edges are unique after the
-    # de-duplication, so nothing is summed
-    graph = csr_matrix((np.arange(1, len(a_codes) + 1, dtype=np.int64), (a_codes, r_codes)), shape=(n_a, n_r))
-    graph.sort_indices()   # node numbers come from the sorted ids and every adjacency list is sorted: the matching chosen among equally
-                           # large ones depends on the ids alone, not on the order the window tables arrived in (1 rank or 8)
-    match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref node matched to each aligned node, -1 = none (structure only)
-    node_of_edge = np.repeat(np.arange(n_a, dtype=np.int64), np.diff(graph.indptr))
-    matched_edge = match_r[node_of_edge] == graph.indices                 # CSR order = aligned ids ascending (:799-808)
-    selected = graph.data[matched_edge] - 1                                # positions in `kept`
-    return merged_df.iloc[kept[selected]].reset_index(drop=True)          # ONE gather of the frame: the rows of the matched edges
+    with marked("merge: de-duplication (codes + device)"):
+        kept = _dedup(merged_df["filtered_violation"].to_numpy(), _window_codes(merged_df["window_id"].to_numpy()),
+                      _equality_codes(merged_df[aligned_col].values), _equality_codes(merged_df[ref_col].values))
+        kept = np.asarray(kept, dtype=np.int64)     # rows of merged_df that survive, in the order the reference's frame has after :748-753
+    with marked("merge: graph of the surviving pairs"):
+        (a_codes, n_a), (r_codes, n_r) = _node_numbers(merged_df[aligned_col].values[kept]), _node_numbers(merged_df[ref_col].values[kept])
+        # every edge carries its frame row (+1: an explicit zero would be dropped), so the rows of the matched edges can be read off
+        # the matrix afterwards without a second sort or a Python dict over a table of 10^6 rows; edges are unique after the
+        # de-duplication, so nothing is summed
+        graph = csr_matrix((np.arange(1, len(a_codes) + 1, dtype=np.int64), (a_codes, r_codes)), shape=(n_a, n_r))
+        graph.sort_indices()   # node numbers come from the sorted ids and every adjacency list is sorted: the matching chosen among equally
+                               # large ones depends on the ids alone, not on the order the window tables arrived in (1 rank or 8)
+    with marked("merge: maximum matching"):
+        match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref node matched to each aligned node, -1 = none (structure only)
+    with marked("merge: rows of the matched pairs"):
+        node_of_edge = np.repeat(np.arange(n_a, dtype=np.int64), np.diff(graph.indptr))
+        matched_edge = match_r[node_of_edge] == graph.indices                 # CSR order = aligned ids ascending (:799-808)
+        selected = graph.data[matched_edge] - 1                                # positions in `kept`
+        return merged_df.iloc[kept[selected]].reset_index(drop=True)          # ONE gather of the frame: the rows of the matched edges
