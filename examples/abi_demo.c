@@ -1,5 +1,5 @@
 /* abi_demo.c -- the C ABI used from plain C (no Python, no C++): prune + pair costs + orientation sweep on a
- * tiny instance, printing the results.  Build (from the repo root):
+ * tiny instance, the dense tile, the window-merge de-duplication and the device-resident window path, printing the results.  Build (from the repo root):
  *   gcc -std=c11 -Iinclude examples/abi_demo.c -o /tmp/abi_demo -Lsame_amd -lsame_hip -Wl,-rpath,$PWD/same_amd -lm
  */
 #include <math.h>
@@ -87,6 +87,35 @@ int main(void) {
     for (int q = 0; q < mkept; ++q) printf(" %d", mrows[q]);
     printf("\n");
     if (mkept != 4 || mrows[0] != 3 || mrows[1] != 2 || mrows[2] != 1 || mrows[3] != 4) return 4;
+    /* the same instance as ONE window with both sections resident on the device (src/same.py:507-593 per window): subsetting, prune,
+     * costs and compaction in same_window_stage; the four triangles above play the Delaunay simplices of the kept aligned cells for
+     * same_window_filter (radius 30, no angle rule, no type rule); greedy MIP start and the three sweeps in same_window_finish */
+    double size[NM > NR ? NM : NR];
+    for (int i = 0; i < (NM > NR ? NM : NR); ++i) size[i] = 1.0;
+    same_section *smov = NULL, *sref = NULL;
+    same_window *win = NULL;
+    CHECK(same_section_create(ctx, axy, A, T, size, NULL, NM, 0, &smov));
+    CHECK(same_section_create(ctx, rxy, R, T, size, NULL, NR, 0, &sref));
+    CHECK(same_window_create(ctx, &win));
+    const double box[4] = {-100.0, 100.0, -100.0, 100.0};
+    int64_t wc[4], fc[3], st[8];
+    CHECK(same_window_stage(win, smov, sref, box, 12.0, K, 1.0, wc));
+    double wcost[NM * K];
+    CHECK(same_window_fetch(win, SAME_WINDOW_COSTS, wcost, wc[3] * (int64_t)sizeof(double)));
+    int same_costs = wc[3] == P;
+    for (int p = 0; same_costs && p < P; ++p) same_costs = wcost[p] == cost[p];
+    CHECK(same_window_filter(win, tris, 4, 30.0, 0, 0.0, 0.0, 0, 1, fc));
+    int32_t mrow[NM];
+    uint8_t pflag[NM];
+    CHECK(same_window_finish(win, NULL, -1, 100.0, mrow, pflag, st));
+    printf("window: %lld aligned, %lld ref, %lld kept, %lld pairs (costs %s the pair list's); %lld of 4 triangles kept; matched ref rows:",
+           (long long)wc[0], (long long)wc[1], (long long)wc[2], (long long)wc[3], same_costs ? "equal" : "DIFFER FROM", (long long)fc[0]);
+    for (int i = 0; i < wc[2]; ++i) printf(" %d", mrow[i]);
+    printf("; orientation checked %lld flipped %lld\n", (long long)st[0], (long long)st[1]);
+    same_window_destroy(win);
+    same_section_destroy(smov);
+    same_section_destroy(sref);
+    if (!same_costs || wc[0] != NM || wc[1] != NR) return 5;
     /* error convention: a bad index is reported, not dereferenced */
     int32_t bad[2] = {0, 99};
     int rc = same_pair_cost_f64(ctx, A, R, NM, NR, T, axy, rxy, bad, 1, 1.0, cost);

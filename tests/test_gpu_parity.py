@@ -893,6 +893,7 @@ def test_plain_c_abi_demo_runs(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "checked 4 triangles" in r.stdout and "bad pair -> -34" in r.stdout
     assert "merge de-duplication keeps 4 of 6 rows: 3 2 1 4" in r.stdout
+    assert "window: 6 aligned, 7 ref, 6 kept" in r.stdout and "(costs equal the pair list's); 4 of 4 triangles kept" in r.stdout
     assert sum(line.startswith("pair (") for line in r.stdout.splitlines()) >= 6
 
 
