@@ -502,7 +502,7 @@ def test_allgather_table_over_a_size_one_rccl_communicator():
 def test_bench_cfg5_windows_line(world):
     """`bench.py --workload cfg5` (BASELINE cfg 5 at reduced size): whole windows dealt to the ranks, fp32 costs, all sweeps per
     window, tables exchanged once and merged; the line reports windows/s per rank and the host-glue share, and at N=1 checks
-    two windows against the oracle."""
+    up to four windows against the oracle."""
     import json
     import os
     import subprocess
