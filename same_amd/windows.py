@@ -299,7 +299,8 @@ class DeviceSection:
         self.ctx = ctx = ops._ctx(ctx)
         self.section = section
         self.cost_dtype = np.dtype(cost_dtype)
-        assert self.cost_dtype in (np.dtype(np.float64), np.dtype(np.float32))
+        if self.cost_dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError(f"cost_dtype must be float64 or float32, not {self.cost_dtype}")
         size = np.ascontiguousarray(section.size, dtype=np.float64)
         tid = None if section.type_id is None else np.ascontiguousarray(section.type_id, dtype=np.int32)
         h = ctypes.c_void_p()
