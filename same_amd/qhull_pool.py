@@ -10,7 +10,9 @@ simplices are identical to an in-process call.
 Helpers are plain `python -c` children speaking a length-prefixed binary protocol over their pipes (no multiprocessing:
 nothing re-imports the caller's `__main__`, nothing is forked from a process that has initialised the GPU, and the
 helpers import numpy + scipy.spatial only -- they never touch the GPU).  `SAME_QHULL_WORKERS` sets their number
-(default: the CPUs this process may use less one, at most 16; 0 = compute in-process, no helpers).
+(default: one and a half times the CPUs this process may use, at most 24 -- a helper is idle while its points and simplices
+travel and until the next request reaches it, so a modest over-subscription keeps the cores busy: 576 -> 694 windows/s from 16 to
+24 helpers under a 16-CPU quota, profiles/r03_cfg5_device_pipeline.log; 0 = compute in-process, no helpers).
 
 Placement matters more than the count: Qhull lives in the last-level cache, and eight helpers that the scheduler stacks on one
 CCD of an EPYC host triangulate a 13 000-point set in 45 ms each against 21 ms alone.  Helper i is therefore confined to the
@@ -306,7 +308,8 @@ def default_workers():
     v = os.environ.get("SAME_QHULL_WORKERS")
     if v is not None:
         return max(0, int(v))
-    return max(1, min(16, cpu_budget() - 1))
+    b = cpu_budget()
+    return max(1, min(24, b + b // 2))
 
 
 def warm(count=None):
