@@ -105,7 +105,7 @@ def test_no_helper_mode_and_default_size(monkeypatch):
     monkeypatch.setenv("SAME_QHULL_WORKERS", "0")
     assert qhull_pool.default_workers() == 0
     monkeypatch.delenv("SAME_QHULL_WORKERS")
-    assert 0 <= qhull_pool.default_workers() <= 8
+    assert 1 <= qhull_pool.default_workers() <= 24 and qhull_pool.default_workers() <= 2 * qhull_pool.cpu_budget()
 
 
 def test_helpers_are_confined_to_one_cache_domain_each(monkeypatch):
