@@ -109,7 +109,7 @@ def launch(args):
     limit = float(os.environ.get("SAME_BENCH_LAUNCH_TIMEOUT", "1500"))
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), SAME_RDV_DIR=rdv,
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), SAME_RDV_DIR=rdv,
                    MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))   # if RCCL has something to complain about, keep it on stderr
         out = subprocess.PIPE if r == 0 else sys.stderr   # only rank 0 writes the line

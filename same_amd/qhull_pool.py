@@ -10,14 +10,18 @@ simplices are identical to an in-process call.
 Helpers are plain `python -c` children speaking a length-prefixed binary protocol over their pipes (no multiprocessing:
 nothing re-imports the caller's `__main__`, nothing is forked from a process that has initialised the GPU, and the
 helpers import numpy + scipy.spatial only -- they never touch the GPU).  `SAME_QHULL_WORKERS` sets their number
-(default: one and a half times the CPUs this process may use, at most 24 -- a helper is idle while its points and simplices
-travel and until the next request reaches it, so a modest over-subscription keeps the cores busy: 576 -> 694 windows/s from 16 to
-24 helpers under a 16-CPU quota, profiles/r03_cfg5_device_pipeline.log; 0 = compute in-process, no helpers).
+(default: one and a half times this process's SHARE of the CPUs it may use, at most 24 -- a helper is idle while its points and
+simplices travel and until the next request reaches it, so a modest over-subscription keeps the cores busy: 576 -> 694 windows/s
+from 16 to 24 helpers under a 16-CPU quota, profiles/r03_cfg5_device_pipeline.log; 0 = compute in-process, no helpers).  The share:
+the affinity mask and the cgroup quota are the same for every rank of a job on one host, so the budget is divided by the ranks that
+share it (`local_world()`: LOCAL_WORLD_SIZE, else WORLD_SIZE of a single-host rendezvous) -- eight ranks on a 16-CPU quota start 24
+helpers between them, not 192 (two ranks on one box ran 455 windows/s against 714 for one before the division).
 
 Placement matters more than the count: Qhull lives in the last-level cache, and eight helpers that the scheduler stacks on one
 CCD of an EPYC host triangulate a 13 000-point set in 45 ms each against 21 ms alone.  Helper i is therefore confined to the
-CPUs of ONE L3 domain, consecutive helpers (and the helpers of consecutive local ranks) to different ones: 7.3 -> 2.7 ms per
-set with eight helpers on the MI355X box's host (profiles/r03_qhull_scaling.log).  `SAME_QHULL_PIN=0` leaves placement to the
+CPUs of ONE L3 domain, consecutive helpers to different ones, and the local ranks of a job divide the host's domains between
+them (rank r of L takes the r-th of L equal runs of domains): 7.3 -> 2.7 ms per set with eight helpers on the MI355X box's host
+(profiles/r03_qhull_scaling.log).  `SAME_QHULL_PIN=0` leaves placement to the
 scheduler.
 """
 import atexit
@@ -117,6 +121,39 @@ def cpu_budget():
     return n
 
 
+def local_world():
+    """(ranks of this job that share this host's CPUs, this rank's index among them).  LOCAL_WORLD_SIZE / LOCAL_RANK when the launcher
+    sets them (torch.distributed.run, bench.launch); else WORLD_SIZE / RANK when the rendezvous is visibly on this host alone (a loopback
+    MASTER_ADDR, or bench.py's own rendezvous directory); else (1, 0).  SAME_LOCAL_WORLD overrides the count."""
+    def num(name):
+        try:
+            return int(os.environ[name])
+        except (KeyError, ValueError):
+            return None
+
+    n, r = num("SAME_LOCAL_WORLD"), num("LOCAL_RANK")
+    if n is None:
+        n = num("LOCAL_WORLD_SIZE")
+    if n is None and (os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1") or os.environ.get("SAME_RDV_DIR")):
+        n = num("WORLD_SIZE")
+        if r is None:
+            r = num("RANK")
+    n = max(1, n or 1)
+    return n, min(max(0, r or 0), n - 1)
+
+
+def _domain_share(domains, n_local, local_rank):
+    """The L3 domains local rank `local_rank` of `n_local` places its helpers in: an equal run of the list when there are at least as
+    many domains as ranks, otherwise the one domain the rank's position falls into (ranks then share it)."""
+    d = len(domains)
+    if d == 0 or n_local <= 1:
+        return list(domains)
+    if d >= n_local:
+        lo, hi = local_rank * d // n_local, (local_rank + 1) * d // n_local
+        return domains[lo:hi]
+    return [domains[local_rank * d // n_local]]
+
+
 class QhullPool:
     def __init__(self, workers, pin=None):
         self.n = int(workers)
@@ -125,12 +162,11 @@ class QhullPool:
         self.domains = _l3_domains() if pin else []
         if len(self.domains) < 2:
             self.domains = []                                          # one cache domain (or an unknown layout): nothing to choose
-        try:
-            self.first_domain = int(os.environ.get("LOCAL_RANK", "0")) * max(1, self.n)
-        except ValueError:
-            self.first_domain = 0
+        self.domains = _domain_share(self.domains, *local_world())     # this rank's part of the host
+        self.first_domain = 0
         self.procs = []
         self.pending = {}            # worker index -> ticket whose answer has not been read yet
+        self.writing = set()         # workers whose request is being written (outside the lock): busy, and not to be drained
         self.next = 0
         self.seq = 0                 # request number, echoed by the helper: an answer is only taken for the request it names
         self.lock = threading.Lock()
@@ -195,7 +231,7 @@ class QhullPool:
                 for q in range(len(self.procs)):            # a helper that died while idle is replaced where it stood
                     if q not in self.pending and self.procs[q].poll() is not None:
                         self.procs[q] = self._spawn(q)
-                idle = [q for q in range(len(self.procs)) if q not in self.pending]
+                idle = [q for q in range(len(self.procs)) if q not in self.pending and q not in self.writing]
                 w = None
                 if idle:
                     w = idle[0]
@@ -203,17 +239,33 @@ class QhullPool:
                     w = len(self.procs)
                     self.procs.append(self._spawn(w))
                 else:
-                    ready = self._readable(list(self.pending))
+                    ready = self._readable([q for q in self.pending if q not in self.writing])
                     if ready:
                         w = min(ready, key=lambda q: (q - self.next) % self.n)       # in turn among the ready ones
                         self.next = w + 1
                 if w is not None:
-                    return self._hand_over(w, pts)
-                busy = [self.procs[q].stdout for q in self.pending]
+                    t, p = self._claim(w, pts)
+                    break
+                busy = [self.procs[q].stdout for q in self.pending if q not in self.writing]
             self._wait(busy, 0.25)
+        # the ~200 KB of points go down the pipe WITHOUT the lock: a helper that is slow to read (or a pipe the kernel would not
+        # enlarge) then stalls this thread only, not every other thread's hand-overs and pick-ups
+        try:
+            p.stdin.write(struct.pack("<qq", t.seq, len(pts)) + pts.tobytes())
+            p.stdin.flush()
+            ok = True
+        except (OSError, ValueError):
+            ok = False
+        with self.lock:
+            self.writing.discard(w)
+            if not ok and self.pending.get(w) is t:
+                del self.pending[w]
+                t.worker = None                          # helper is gone: this one is computed in-process on result()
+        return t
 
-    def _hand_over(self, w, pts):
-        """Give helper w the points (lock held).  Its previous answer, if still unread, has arrived and is read first."""
+    def _claim(self, w, pts):
+        """Reserve helper w for these points (lock held); its previous answer, if still unread, has arrived and is read first.
+        -> (ticket, the helper process to write the request to once the lock is released)."""
         if w in self.pending:                           # one request in flight per helper
             old = self.pending.pop(w)
             try:
@@ -224,14 +276,9 @@ class QhullPool:
         t = _Ticket(self, w, pts, self.seq)
         if self.procs[w].poll() is not None:            # the helper has died since its last request: start another
             self.procs[w] = self._spawn(w)
-        try:
-            p = self.procs[w]
-            p.stdin.write(struct.pack("<qq", t.seq, len(pts)) + pts.tobytes())
-            p.stdin.flush()
-            self.pending[w] = t
-        except (OSError, ValueError):
-            t.worker = None                              # helper is gone: this one is computed in-process on result()
-        return t
+        self.pending[w] = t
+        self.writing.add(w)
+        return t, self.procs[w]
 
     def _retire(self, w):
         """Stop helper w (its stream can no longer be trusted, or it is gone) and put a fresh one in its place."""
@@ -297,7 +344,7 @@ class QhullPool:
                     p.wait(timeout=5)
                 except subprocess.TimeoutExpired:
                     p.kill()
-            self.procs, self.pending = [], {}
+            self.procs, self.pending, self.writing = [], {}, set()
 
 
 _pool = None
@@ -309,7 +356,7 @@ def default_workers():
     if v is not None:
         return max(0, int(v))
     b = cpu_budget()
-    return max(1, min(24, b + b // 2))
+    return max(1, min(24, (3 * b) // (2 * local_world()[0])))
 
 
 def warm(count=None):

@@ -108,6 +108,38 @@ def test_no_helper_mode_and_default_size(monkeypatch):
     assert 1 <= qhull_pool.default_workers() <= 24 and qhull_pool.default_workers() <= 2 * qhull_pool.cpu_budget()
 
 
+def test_the_cpu_budget_is_divided_by_the_ranks_on_the_host(monkeypatch):
+    """Every rank of a job sees the same affinity mask and cgroup quota, so the helper count is the rank's share of the budget:
+    world 8 on a 16-CPU budget starts at most 24 helpers in total (it was 8 x 24); the L3 domains are dealt the same way."""
+    from same_amd import qhull_pool
+
+    for var in ("SAME_QHULL_WORKERS", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "RANK", "SAME_LOCAL_WORLD", "SAME_RDV_DIR", "MASTER_ADDR"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(qhull_pool, "cpu_budget", lambda: 16)
+    assert qhull_pool.local_world() == (1, 0) and qhull_pool.default_workers() == 24
+    for world, per_rank in ((2, 12), (4, 6), (8, 3), (32, 1)):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(world))
+        assert qhull_pool.default_workers() == per_rank and world * per_rank <= max(24, world)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    # without LOCAL_WORLD_SIZE: WORLD_SIZE counts only when the rendezvous is visibly on this host
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "5")
+    assert qhull_pool.local_world() == (1, 0)                                   # could be eight hosts
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    assert qhull_pool.local_world() == (8, 5) and qhull_pool.default_workers() == 3
+    monkeypatch.setenv("MASTER_ADDR", "10.0.0.7")
+    monkeypatch.setenv("SAME_RDV_DIR", "/tmp/x")                                # bench.py's own launcher: one host by construction
+    assert qhull_pool.local_world() == (8, 5)
+    monkeypatch.setenv("SAME_LOCAL_WORLD", "2")                                 # explicit override
+    assert qhull_pool.local_world()[0] == 2 and qhull_pool.default_workers() == 12
+    monkeypatch.setenv("SAME_QHULL_WORKERS", "7")                               # the explicit count is per process, not divided
+    assert qhull_pool.default_workers() == 7
+    doms = [[c] for c in range(8)]
+    assert [qhull_pool._domain_share(doms, 4, r) for r in range(4)] == [[[0], [1]], [[2], [3]], [[4], [5]], [[6], [7]]]
+    assert [qhull_pool._domain_share(doms[:2], 4, r) for r in range(4)] == [[[0]], [[0]], [[1]], [[1]]]
+    assert qhull_pool._domain_share(doms, 1, 0) == doms and qhull_pool._domain_share([], 8, 3) == []
+
+
 def test_helpers_are_confined_to_one_cache_domain_each(monkeypatch):
     """Placement (SAME_QHULL_PIN, on by default): helper i may only run on the CPUs of ONE last-level-cache domain, consecutive
     helpers on different ones, the helpers of another local rank shifted; with a single domain, or switched off, nothing is
@@ -126,16 +158,27 @@ def test_helpers_are_confined_to_one_cache_domain_each(monkeypatch):
     monkeypatch.setattr(qhull_pool, "_l3_domains", lambda: halves)
     pts = np.random.default_rng(3).uniform(0, 100, (500, 2))
     want = Delaunay(pts).simplices
-    for local_rank, first in (("0", 0), ("1", 1)):
-        monkeypatch.setenv("LOCAL_RANK", local_rank)
+    for var in ("LOCAL_RANK", "LOCAL_WORLD_SIZE", "WORLD_SIZE", "RANK", "SAME_LOCAL_WORLD", "SAME_RDV_DIR"):
+        monkeypatch.delenv(var, raising=False)
+    p = qhull_pool.QhullPool(3)                      # one rank on the host: its helpers alternate over both domains
+    try:
+        tickets = [p.submit(pts) for _ in range(3)]
+        assert all(np.array_equal(t.result(), want) for t in tickets)
+        assert [sorted(os.sched_getaffinity(proc.pid)) for proc in p.procs] == [halves[i % 2] for i in range(3)]
+    finally:
+        p.close()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")     # two ranks on the host: each keeps its helpers in its own half
+    for local_rank in (0, 1):
+        monkeypatch.setenv("LOCAL_RANK", str(local_rank))
         p = qhull_pool.QhullPool(3)
         try:
             tickets = [p.submit(pts) for _ in range(3)]
             assert all(np.array_equal(t.result(), want) for t in tickets)
-            got = [sorted(os.sched_getaffinity(proc.pid)) for proc in p.procs]
-            assert got == [halves[(first * 3 + i) % 2] for i in range(3)]
+            assert [sorted(os.sched_getaffinity(proc.pid)) for proc in p.procs] == [halves[local_rank]] * 3
         finally:
             p.close()
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.delenv("LOCAL_RANK")
     monkeypatch.setenv("SAME_QHULL_PIN", "0")
     p = qhull_pool.QhullPool(2)
     try:

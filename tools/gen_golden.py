@@ -34,7 +34,7 @@ _spec = importlib.util.spec_from_file_location("same_synth", os.path.join(ROOT, 
 synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("SAME_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # the test that re-generates into a scratch directory sets it
 if len(sys.argv) > 1 and sys.argv[1] in ("eager", "runsame", "tiler", "tongue", "heart", "sweep"):
     # solver-facing fixtures: the reference's model builders / run_same talk to the recording solver double of the tests
     # (gurobipy itself is proprietary and absent), installed as `gurobipy` BEFORE the reference modules bind its names
@@ -629,7 +629,7 @@ def run_same_mock_case():
     import tempfile
 
     out = {}
-    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    work = tempfile.mkdtemp(prefix='same_golden_')
     cwd = os.getcwd()
     os.chdir(work)                                           # run_same writes gurobi_logs/ and matching_model.lp into the cwd
     try:
@@ -786,7 +786,7 @@ def window_tiler_case():
         [1000, 900, 350.5, 10, 90, 45, 35, 1],
     ], dtype=float)
     out = {'cfgs': cfgs}
-    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    work = tempfile.mkdtemp(prefix='same_golden_')
     calls = []
 
     def recorder(aligned_df, ref_df, commonCT, optim_params, gurobi_params, outprefix, aligned_delaunay, aligned_delaunay_vertex_col,
@@ -856,7 +856,7 @@ def tongue_case():
     out = {}
     out.update(rec.record_frame('prot', raw_a))
     out.update(rec.record_frame('mer', raw_r))
-    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    work = tempfile.mkdtemp(prefix='same_golden_')
     cwd = os.getcwd()
     os.chdir(work)
     try:
@@ -916,7 +916,7 @@ def heart_case():
     out = {}
     out.update(rec.record_frame('query', raw_a))
     out.update(rec.record_frame('ref', raw_r))
-    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    work = tempfile.mkdtemp(prefix='same_golden_')
     cwd = os.getcwd()
     os.chdir(work)
     try:
@@ -964,7 +964,7 @@ def run_same_sweep_case(n_cfg=16):
     import tempfile
 
     out = {'n_cfg': np.array([n_cfg])}
-    work = tempfile.mkdtemp(dir=os.path.join(ROOT, 'gpurun_out'))
+    work = tempfile.mkdtemp(prefix='same_golden_')
     cwd = os.getcwd()
     os.chdir(work)
     try:
