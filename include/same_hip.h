@@ -42,7 +42,7 @@ extern "C" {
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
-#define SAME_ABI_VERSION 4
+#define SAME_ABI_VERSION 5
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
@@ -61,6 +61,13 @@ const char *same_last_error(same_ctx *ctx);
 int same_ctx_info(same_ctx *ctx, char *name, size_t name_len, int *cu_count, int64_t *hbm_bytes);
 /* "domain:bus:device.function" of the context's GPU (names its sysfs directory: power / clock telemetry) */
 int same_ctx_pci_bus_id(same_ctx *ctx, char *out, size_t out_len);
+/* What the library itself has asked of the HIP runtime on this context since it was created, for the entry points that count
+ * (the window path, the greedy start): kernel launches, hipMemsetAsync fills, hipMemcpyAsync copies, stream waits, and the
+ * device-to-host reads the greedy rounds made.  The difference of two reads around a call is that call's cost in runtime calls --
+ * the number a rocprof trace shows, available to a test (tests/test_gpu_run_same.py holds launches / fills / copies / waits per
+ * window).  which = SAME_STAT_*. */
+enum { SAME_STAT_LAUNCHES = 0, SAME_STAT_FILLS = 1, SAME_STAT_COPIES = 2, SAME_STAT_WAITS = 3, SAME_STAT_GREEDY_READBACKS = 4, SAME_STAT_COUNT = 5 };
+int same_ctx_stat(same_ctx *ctx, int which, int64_t *out);
 
 /* ---- device memory + timing (for resident operands and in-library kernel timing) ------ */
 int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr);
@@ -357,15 +364,22 @@ int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *
                       int64_t n_boxes, int64_t *out_count, uint8_t *out_mask);
 
 /* ---- a13 + the per-window pre-MIP path with the sections resident on the device -------------
- * The reference's window loop (src/same.py:507-593) subsets both frames per window (:293-295) and runs the whole
- * pre-MIP path on the subset.  A same_section is one section's columns uploaded once (XY, the commonCT type columns,
- * cell sizes; cost_f32 != 0 keeps the cost operands as float, BASELINE cfg 5); a same_window is the device state of one
- * window in flight (buffers grow on demand and are reused).  Two calls per window:
- *   same_window_stage: rows of both sections inside box = {x0,x1,y0,y1} (half-open, ascending row order), radius / k
+ * The reference's window loop (src/same.py:507-593) subsets both frames per window (:293-295: one boolean mask over the
+ * whole frame per window) and runs the whole pre-MIP path on the subset.  Here:
+ *   same_section      one section's columns uploaded once (XY, the commonCT type columns, cell sizes; cost_f32 != 0 keeps the
+ *                     cost operands as float, BASELINE cfg 5), its rows binned ONCE into a grid of cells (rows sorted by cell,
+ *                     ascending inside a cell).  same_section_bin(section, x0, y0, cell_w, cell_h) re-bins it on the caller's
+ *                     grid: with the window grid's origin (int(x_min), int(y_min)) and cell = gcd(window step, window size)
+ *                     every window box of src/same.py:481-488 / :527-542 is a union of cells and its rows need no test at all;
+ *                     other boxes test the rows of the cells they cut.  A box covering more than 64 cells falls back to one
+ *                     mask over the section.  Call it before windows use the section (not concurrently with them).  Sections
+ *                     may be shared by the windows of several contexts of one device.
+ *   same_window       the device state of one window in flight (buffers grow on demand and are reused).
+ *   same_window_stage rows of both sections inside box = {x0,x1,y0,y1} (half-open, ascending row order), radius / k
  *     prune (src/utils.py:709-728), candidate costs (src/same.py:1180-1189), compaction of the aligned cells that have
  *     candidates and of the pair list (src/utils.py:734-742).  out_counts[4] = {aligned rows in the box, reference rows
  *     in the box, aligned rows kept, pairs}.  Reference cells are not renumbered: pair[1] / match index the window's
- *     reference rows.  With no aligned or no reference row in the box nothing else is computed (kept = pairs = 0).
+ *     reference rows.  One fill, at most five launches, one copy back, one wait; reads O(rows of the covered cells).
  *   same_window_finish: the caller's kept Delaunay triangles of the kept aligned cells (src/same.py:1023, filtered as
  *     :1040-1060) -> source signs / weights (:1128-1146), greedy MIP start with prefer = rowmin < no_match_penalty * size
  *     (src/init_helpers.py:104-133), lazy-constraint body (:645-669), XY-order sweep (src/violationhelper.py:53-117), area
@@ -380,6 +394,9 @@ int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *
  *     reference's literal arccos (same_amd/triangles.py) and passes its triangles to same_window_finish.  Otherwise
  *     same_window_finish(window, NULL, -1, ...) continues with the triangles left on the device.  Simplices must be
  *     distinct as vertex rows (Qhull's are): the re-add pass de-duplicates by triangle, the reference by vertex row.
+ *   same_window_filter_finish = same_window_filter then same_window_finish(window, NULL, -1, ...) without a host round trip
+ *     between them (one wait instead of two); out_counts as the filter's, the rest as the finish call's.  When
+ *     out_counts[2] != 0 the other outputs mean nothing and the caller proceeds as after same_window_filter.
  * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size. */
 typedef struct same_section same_section;
 typedef struct same_window same_window;
@@ -398,6 +415,7 @@ enum {
 };
 int same_section_create(same_ctx *ctx, const double *xy, const double *types, int T, const double *size,
                         const int32_t *type_id /* may be NULL */, int64_t n, int cost_f32, same_section **out);
+int same_section_bin(same_section *section, double x0, double y0, double cell_w, double cell_h);
 void same_section_destroy(same_section *section);
 int same_window_create(same_ctx *ctx, same_window **out);
 void same_window_destroy(same_window *window);
@@ -409,6 +427,10 @@ int same_window_filter(same_window *window, const int32_t *simplices, int64_t n_
                        int ensure_min_triangle_per_node, int64_t *out_counts);
 int same_window_finish(same_window *window, const int32_t *tris, int64_t Tr, double no_match_penalty,
                        int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats);
+int same_window_filter_finish(same_window *window, const int32_t *simplices, int64_t n_simplices, double radius,
+                              int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
+                              int ensure_min_triangle_per_node, double no_match_penalty, int32_t *out_match_row,
+                              uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts);
 
 /* ---- f3: window merge, the de-duplication step ------------------------------------------
  * Replaces src/helpers.py:745-753 (merged_df.sort_values(['filtered_violation', 'window_id'], kind='mergesort') then

@@ -21,7 +21,7 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
 SPREAD_INFO_LEN = 14                           # SAME_SPREAD_INFO_LEN
@@ -39,6 +39,7 @@ _PROTOTYPES = {
     "same_last_error": [c_vp],
     "same_ctx_info": [c_vp, ctypes.c_char_p, c_sz, ctypes.POINTER(c_int), ctypes.POINTER(c_i64)],
     "same_ctx_pci_bus_id": [c_vp, ctypes.c_char_p, c_sz],
+    "same_ctx_stat": [c_vp, c_int, ctypes.POINTER(c_i64)],
     "same_dev_alloc": [c_vp, c_sz, ctypes.POINTER(c_vp)],
     "same_dev_free": [c_vp, c_vp],
     "same_dev_alloc_spread": [c_vp, c_sz, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64)],
@@ -93,6 +94,7 @@ _PROTOTYPES = {
     "same_eager_signs": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_vp],
     "same_window_count": [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "same_section_create": [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, ctypes.POINTER(c_vp)],
+    "same_section_bin": [c_vp, c_dbl, c_dbl, c_dbl, c_dbl],
     "same_section_destroy": [c_vp],
     "same_window_create": [c_vp, ctypes.POINTER(c_vp)],
     "same_window_destroy": [c_vp],
@@ -100,6 +102,7 @@ _PROTOTYPES = {
     "same_window_fetch": [c_vp, c_int, c_vp, c_i64],
     "same_window_filter": [c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_vp],
     "same_window_finish": [c_vp, c_vp, c_i64, c_dbl, c_vp, c_vp, c_vp],
+    "same_window_filter_finish": [c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
     "same_comm_unique_id": [c_vp],
     "same_comm_init": [c_vp, c_int, c_int, c_vp],
@@ -275,6 +278,17 @@ class Context:
         buf = ctypes.create_string_buffer(64)
         self.check(self.lib.same_ctx_pci_bus_id(self.handle, buf, 64), "same_ctx_pci_bus_id")
         return buf.value.decode().lower()
+
+    STAT_NAMES = ("launches", "fills", "copies", "waits", "greedy_readbacks")       # SAME_STAT_*
+
+    def stats(self):
+        """What the library has asked of the HIP runtime on this context so far, for the entry points that count (the window path,
+        the greedy start): {'launches', 'fills', 'copies', 'waits', 'greedy_readbacks'} (same_ctx_stat)."""
+        out, v = {}, c_i64(0)
+        for which, name in enumerate(self.STAT_NAMES):
+            self.check(self.lib.same_ctx_stat(self.handle, which, ctypes.byref(v)), "same_ctx_stat")
+            out[name] = v.value
+        return out
 
     def mem_info(self):
         """(free bytes, total bytes) of the card right now."""

@@ -48,7 +48,31 @@ struct same_ctx {
     ncclComm *comm = nullptr;
     int nranks = 1, rank = 0;
     std::vector<same_spread_alloc> spread;
+    int64_t stats[SAME_STAT_COUNT] = {};   // what the library itself asked of the runtime on this context (same_ctx_stat)
 };
+
+// every kernel launch / fill / copy / wait of the window path and of the cores it shares goes through these, so that the
+// per-window counts a profile shows can also be read from the library (same_ctx_stat) and held by a test
+#define SAME_LAUNCH(ctx, kernel, grid, block, lds, ...)                                  \
+    do {                                                                                 \
+        ++(ctx)->stats[SAME_STAT_LAUNCHES];                                              \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);        \
+    } while (0)
+#define SAME_FILL(ctx, ptr, value, bytes)                                                \
+    do {                                                                                 \
+        ++(ctx)->stats[SAME_STAT_FILLS];                                                 \
+        HIP_TRY((ctx), hipMemsetAsync((ptr), (value), (bytes), (ctx)->stream));          \
+    } while (0)
+#define SAME_COPY(ctx, dst, src, bytes, kind)                                            \
+    do {                                                                                 \
+        ++(ctx)->stats[SAME_STAT_COPIES];                                                \
+        HIP_TRY((ctx), hipMemcpyAsync((dst), (src), (bytes), (kind), (ctx)->stream));    \
+    } while (0)
+#define SAME_WAIT(ctx)                                                                   \
+    do {                                                                                 \
+        ++(ctx)->stats[SAME_STAT_WAITS];                                                 \
+        HIP_TRY((ctx), hipStreamSynchronize((ctx)->stream));                             \
+    } while (0)
 
 // Resident state of the lazy-constraint orientation sweep (same_sweep_bind): its own device blocks, so
 // several sweeps can live on one context and none can be run against another's shapes.
@@ -134,3 +158,27 @@ int same_orient_counts_core(same_ctx *ctx, const int32_t *dtris, int64_t Tr, con
                             const int32_t *dmatch, uint8_t *dflag, unsigned long long *dmask, unsigned long long *dcnt);
 int same_greedy_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, int64_t n_m, int64_t n_r,
                      const uint8_t *dprefer, int32_t *dmatch_pair, int *out_rounds);
+
+// State of the greedy rule between rounds (match.hip): all of it zero before round 0 except `alive`.
+constexpr int SAME_GREEDY_BATCH_MAX = 64;
+struct same_greedy_state {
+    uint8_t *alive = nullptr;                       // [P] pair still in play
+    uint8_t *used = nullptr;                        // [n_m + n_r] end point taken: rows, then columns
+    unsigned long long *key[2] = {nullptr, nullptr};   // [n_m + n_r] each: inverted minimum cost key per end point, alternating sets
+    unsigned *idx[2] = {nullptr, nullptr};          // [n_m + n_r] each: inverted pair index among equal minima
+    unsigned long long *sel = nullptr;              // [rounds of one batch] pairs selected per round
+};
+int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, const unsigned long long *dP,
+                            int64_t n_m, int64_t n_r, const same_greedy_state &st, int32_t *dmatch_pair, int first, int count);
+
+// ascending sort of n_pad (a power of two >= 2048) 64-bit keys in place (merge.hip)
+int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad);
+
+// the window path's prune and candidate-list costs on row lists of the sections (knn.hip, cost.hip)
+struct same_knn_index;
+int same_knn_window_core(same_ctx *ctx, const same_knn_index *ix, const double *dmov_xy, const int32_t *drows_m,
+                         const unsigned long long *dn_m, int64_t cap_m, const int32_t *drows_r, const unsigned long long *dn_r,
+                         const double *box, int k, int32_t *didx, int32_t *dcnt);
+int same_padded_cost_window_core(same_ctx *ctx, int cost_f32, const void *dA, const void *dR, int T, const void *daxy_c, const void *drxy_c,
+                                 const int32_t *drows, const unsigned long long *dn, int64_t cap, int k, const int32_t *didx, double w,
+                                 void *dout_cost);

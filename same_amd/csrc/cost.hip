@@ -413,17 +413,25 @@ __global__ __launch_bounds__(256) void pair_cost_kernel(
     out[p] = w * s + dcoef * dc;
 }
 
+// Window form (csrc/window.hip): list row q / k is row arows[q / k] of A / axy (the moving SECTION's arrays), the number of list
+// rows lives on the device and the launch is sized by an upper bound.
+struct WinCost {
+    const int32_t *arows;
+    const unsigned long long *n_a;
+};
+
 // Costs of padded candidate lists idx[(i-row_begin)*k + q] (-1 = empty -> +inf).
-template <typename F>
+template <typename F, bool WIN = false>
 __global__ __launch_bounds__(256) void padded_cost_kernel(
     const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
-    F w, F dcoef, F *__restrict__ out) {
+    F w, F dcoef, F *__restrict__ out, WinCost win) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (WIN) n_slots = (int64_t)*win.n_a * k;
     if (q >= n_slots) return;
     const int64_t j = idx[q];
     if (j < 0) { out[q] = inf_of<F>(); return; }
-    const int64_t i = row_begin + q / k;
+    const int64_t i = WIN ? (int64_t)win.arows[q / k] : row_begin + q / k;
     const F *a = A + i * T, *r = R + j * T;
     F s = F(0);
     for (int t = 0; t < T; ++t) s = s + absf<F>(a[t] - r[t]);
@@ -435,12 +443,13 @@ __global__ __launch_bounds__(256) void padded_cost_kernel(
 // load instruction touch 64 different cache lines; here the wave first copies its 64 rows into LDS with lanes running
 // along the rows (each load instruction covers ~3 rows = a handful of lines), then every lane walks its row in LDS in the
 // reference's left-to-right order.  Row pitch in LDS is T|1 elements (odd: 2-way bank aliasing at worst).
-template <typename F>
+template <typename F, bool WIN = false>
 __global__ void padded_cost_lds_kernel(
     const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
-    F w, F dcoef, F *__restrict__ out) {
+    F w, F dcoef, F *__restrict__ out, WinCost win) {
     extern __shared__ double lds_raw[];
+    if constexpr (WIN) n_slots = (int64_t)*win.n_a * k;
     F *lds = reinterpret_cast<F *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int P = T | 1;
@@ -466,7 +475,7 @@ __global__ void padded_cost_lds_kernel(
     __builtin_amdgcn_wave_barrier();
     if (q >= n_slots) return;
     if (j < 0) { out[q] = inf_of<F>(); return; }
-    const int64_t i = row_begin + q / k;
+    const int64_t i = WIN ? (int64_t)win.arows[q / k] : row_begin + q / k;
     const F *a = A + i * T;
     const F *r = rows + lane * P;
     F s = F(0);
@@ -626,28 +635,29 @@ int pair_cost_host(same_ctx *ctx, const F *A, const F *R, int64_t n_m, int64_t n
     return SAME_OK;
 }
 
-template <typename F>
+template <typename F, bool WIN = false>
 int padded_cost_dev(same_ctx *ctx, const F *dA, const F *dR, int T, const F *daxy, const F *drxy, int64_t row_begin,
-                    int64_t row_end, int k, const int32_t *didx, F w, F *dout_cost) {
+                    int64_t row_end, int k, const int32_t *didx, F w, F *dout_cost, WinCost win = WinCost{}) {
     REQUIRE(ctx, ctx && daxy && drxy && didx && dout_cost && (T == 0 || (dA && dR)));
     REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && k >= 1 && row_begin >= 0 && row_end >= row_begin);
     SAME_TRY(same_use(ctx));
-    const int64_t n_slots = (row_end - row_begin) * k;
+    const int64_t n_slots = (row_end - row_begin) * k;   // WIN: the upper bound the launch is sized by
     if (n_slots == 0) return SAME_OK;
     size_t per_wave = (size_t)64 * (T | 1) * sizeof(F) + 64 * sizeof(int);
     per_wave = (per_wave + 7) & ~size_t(7);
     int waves = (int)std::min<size_t>(4, (size_t)65536 / per_wave);
     if (T >= 2 && waves >= 1 && n_slots >= 64 * 64) {   // LDS-staged rows; tiny inputs and very wide rows: one lane gathers its row
         // the per-wave index list sits after ALL waves' row blocks: keep it 4-byte aligned for float rows of odd pitch
-        hipLaunchKernelGGL(padded_cost_lds_kernel<F>, dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
-                           ctx->stream, dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost);
+        SAME_LAUNCH(ctx, (padded_cost_lds_kernel<F, WIN>), dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
+                           dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost, win);
     } else {
-        hipLaunchKernelGGL(padded_cost_kernel<F>, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, ctx->stream, dA, dR, T,
-                           daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost);
+        SAME_LAUNCH(ctx, (padded_cost_kernel<F, WIN>), dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, dA, dR, T,
+                           daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost, win);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
+
 
 template <int T>
 int launch_q32_T(same_ctx *ctx, const uint32_t *Aq, const uint32_t *Rq, const double *A, const double *R, const double *axy,
@@ -668,6 +678,19 @@ int launch_q32_T(same_ctx *ctx, const uint32_t *Aq, const uint32_t *Rq, const do
 }
 
 }  // namespace
+
+// The window path's candidate-list costs (csrc/window.hip; declared in common.h): lists of rows drows[0, *dn) of the moving
+// section, candidates = reference SECTION rows; cap = the upper bound on *dn the launch is sized by.  Enqueue only.
+int same_padded_cost_window_core(same_ctx *ctx, int cost_f32, const void *dA, const void *dR, int T, const void *daxy_c, const void *drxy_c,
+                                 const int32_t *drows, const unsigned long long *dn, int64_t cap, int k, const int32_t *didx, double w,
+                                 void *dout_cost) {
+    const WinCost win{drows, dn};
+    if (cost_f32)
+        return padded_cost_dev<float, true>(ctx, static_cast<const float *>(dA), static_cast<const float *>(dR), T, static_cast<const float *>(daxy_c),
+                                            static_cast<const float *>(drxy_c), 0, cap, k, didx, (float)w, static_cast<float *>(dout_cost), win);
+    return padded_cost_dev<double, true>(ctx, static_cast<const double *>(dA), static_cast<const double *>(dR), T, static_cast<const double *>(daxy_c),
+                                         static_cast<const double *>(drxy_c), 0, cap, k, didx, w, static_cast<double *>(dout_cost), win);
+}
 
 extern "C" {
 

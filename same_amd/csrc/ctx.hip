@@ -102,6 +102,12 @@ int same_ctx_pci_bus_id(same_ctx *ctx, char *out, size_t out_len) {
     return SAME_OK;
 }
 
+int same_ctx_stat(same_ctx *ctx, int which, int64_t *out) {
+    REQUIRE(ctx, ctx && out && which >= 0 && which < SAME_STAT_COUNT);
+    *out = ctx->stats[which];
+    return SAME_OK;
+}
+
 int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr) {
     REQUIRE(ctx, ctx && out_dptr);
     SAME_TRY(same_use(ctx));

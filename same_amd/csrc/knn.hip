@@ -66,14 +66,28 @@ __device__ __forceinline__ int prune_in_place(RowList<CAP> &L, int m, int k, int
     return m < k ? m : k;
 }
 
-template <int KNN_CAP, int KNN_RW>
+// Window form (WIN, csrc/window.hip): the aligned rows and the reference cells are ROW LISTS into their sections' arrays
+// (win.arows / win.rrows, ascending section rows), their lengths live on the device (win.n_a / win.n_r: the launch is sized by
+// an upper bound), and the candidate written is the reference cell's SECTION row -- ranking by (d2, section row) is the ranking
+// by (d2, index in the window), the lists being ascending.
+struct WinRows {
+    const int32_t *arows, *rrows;
+    const unsigned long long *n_a, *n_r;
+    double bx0, bx1, by0, by1;   // the window's box (grid form: a reference cell outside it is not a candidate)
+};
+
+template <int KNN_CAP, int KNN_RW, bool WIN = false>
 __global__ __launch_bounds__(64 * KNN_WAVES) void knn_prune_kernel(
     const double *__restrict__ axy, const double *__restrict__ rxy, int64_t n_r, int64_t row_begin,
     int64_t row_end, double r2, int k, int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
-    int32_t *__restrict__ out_cnt) {
+    int32_t *__restrict__ out_cnt, WinRows win) {
     __shared__ RowList<KNN_CAP> lists[KNN_WAVES * KNN_RW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (WIN) {
+        row_end = (int64_t)*win.n_a;
+        n_r = (int64_t)*win.n_r;
+    }
     const int64_t row0 = row_begin + ((int64_t)blockIdx.x * KNN_WAVES + wave) * KNN_RW;
     if (row0 >= row_end) return;
     RowList<KNN_CAP> *L = lists + wave * KNN_RW;
@@ -82,7 +96,8 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_prune_kernel(
     int cnt[KNN_RW];
 #pragma unroll
     for (int r = 0; r < KNN_RW; ++r) {
-        const int64_t i = (row0 + r < row_end) ? row0 + r : row_end - 1;  // tail rows repeat the last one
+        int64_t i = (row0 + r < row_end) ? row0 + r : row_end - 1;  // tail rows repeat the last one
+        if constexpr (WIN) i = win.arows[i];
         ax[r] = axy[2 * i];
         ay[r] = axy[2 * i + 1];
         cnt[r] = 0;
@@ -90,8 +105,9 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_prune_kernel(
 
     typedef double double2_t __attribute__((ext_vector_type(2)));
     for (int64_t base = 0; base < n_r; base += 64) {
-        const int64_t j = base + lane;
+        int64_t j = base + lane;
         const bool valid = j < n_r;
+        if constexpr (WIN) j = win.rrows[valid ? j : n_r - 1];
         const double2_t p = *reinterpret_cast<const double2_t *>(rxy + 2 * (valid ? j : n_r - 1));
 #pragma unroll
         for (int r = 0; r < KNN_RW; ++r) {
@@ -229,18 +245,20 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const double *__restr
     sidx[pos] = (int32_t)j;
 }
 
-template <int KNN_CAP>
+template <int KNN_CAP, bool WIN = false>
 __global__ __launch_bounds__(64 * KNN_WAVES) void knn_grid_kernel(
     const double *__restrict__ axy, const double *__restrict__ sxy, const int32_t *__restrict__ sidx,
     const unsigned *__restrict__ start, GridDesc g, int64_t row_begin, int64_t row_end, double r2, int k,
-    int32_t *__restrict__ out_idx, double *__restrict__ out_d2, int32_t *__restrict__ out_cnt) {
+    int32_t *__restrict__ out_idx, double *__restrict__ out_d2, int32_t *__restrict__ out_cnt, WinRows win) {
     __shared__ RowList<KNN_CAP> lists[KNN_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (WIN) row_end = (int64_t)*win.n_a;
     const int64_t i = row_begin + (int64_t)blockIdx.x * KNN_WAVES + wave;
     if (i >= row_end) return;
     RowList<KNN_CAP> &L = lists[wave];
-    const double ax = axy[2 * i], ay = axy[2 * i + 1];
+    const int64_t arow = WIN ? (int64_t)win.arows[i] : i;
+    const double ax = axy[2 * arow], ay = axy[2 * arow + 1];
     // unclamped cell of the aligned point; neighbours clipped to the grid
     const double fcx = __builtin_floor((ax - g.x0) * g.inv_cell), fcy = __builtin_floor((ay - g.y0) * g.inv_cell);
     int cnt = 0;
@@ -269,7 +287,8 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_grid_kernel(
             const int32_t j = sidx[pos];
             const double dx = p.x - ax, dy = p.y - ay;
             const double d2 = dx * dx + dy * dy;
-            const bool in = valid && d2 <= r2;
+            bool in = valid && d2 <= r2;
+            if constexpr (WIN) in = in && p.x >= win.bx0 && p.x < win.bx1 && p.y >= win.by0 && p.y < win.by1;   // src/same.py:293-295
             const unsigned long long mask = __ballot(in);
             if (mask) {
                 const int m = __builtin_popcountll(mask);
@@ -366,10 +385,10 @@ int grid_query(same_ctx *ctx, const double *daxy, const GridDesc &g, const unsig
     REQUIRE(ctx, ceil_div(rows, KNN_WAVES) < (int64_t)1 << 31);
     if (k <= KNN_CAP_SMALL - 64)
         hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_SMALL>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
+                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
     else
         hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_LARGE>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt);
+                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -401,10 +420,10 @@ int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int6
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
     if (small)
         hipLaunchKernelGGL((knn_prune_kernel<KNN_CAP_SMALL, KNN_RW_SMALL>), dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt);
+                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
     else
         hipLaunchKernelGGL((knn_prune_kernel<KNN_CAP_LARGE, KNN_RW_LARGE>), dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt);
+                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -429,7 +448,8 @@ int launch_knn(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_
 // Caller-held index of one reference set for one radius: the grid (or the decision that brute force is the
 // better plan) is made once; prunes against it neither rebuild anything nor synchronise with the host.
 struct same_knn_index {
-    same_ctx *ctx = nullptr;
+    same_ctx *ctx = nullptr;       // the context that built it (not used after the build: an index may outlive it)
+    int device = -1;
     const double *drxy = nullptr;  // the caller's device array (not owned; must stay valid and unchanged)
     int64_t n_r = 0;
     double radius = 0.0;
@@ -440,6 +460,39 @@ struct same_knn_index {
     int32_t *sidx = nullptr;
 };
 
+// The window path's prune (csrc/window.hip; declared in common.h): `ix` indexes the reference SECTION (all of its rows, built
+// once per radius); aligned rows are drows_m[0, *dn_m) of the moving section's XY, candidates the reference rows inside `box`
+// (grid form: box test on the swept cells; brute form: the window's own ascending list drows_r[0, *dn_r)).  didx[cap_m][k] gets
+// section rows (-1 padded), dcnt[cap_m] the list lengths; rows past *dn_m are not written.  Enqueue only.
+int same_knn_window_core(same_ctx *ctx, const same_knn_index *ix, const double *dmov_xy, const int32_t *drows_m,
+                         const unsigned long long *dn_m, int64_t cap_m, const int32_t *drows_r, const unsigned long long *dn_r,
+                         const double *box, int k, int32_t *didx, int32_t *dcnt) {
+    REQUIRE(ctx, ix && ix->device == ctx->device && k >= 1 && k <= SAME_MAX_KNN && cap_m >= 0);
+    if (cap_m == 0) return SAME_OK;
+    const WinRows win{drows_m, drows_r, dn_m, dn_r, box[0], box[1], box[2], box[3]};
+    const bool small = k <= KNN_CAP_SMALL - 64;
+    const double r2 = ix->radius * ix->radius;
+    if (ix->grid) {
+        const unsigned blocks = (unsigned)ceil_div(cap_m, KNN_WAVES);
+        if (small)
+            SAME_LAUNCH(ctx, (knn_grid_kernel<KNN_CAP_SMALL, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0, dmov_xy, ix->sxy,
+                               ix->sidx, ix->hist, ix->g, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+        else
+            SAME_LAUNCH(ctx, (knn_grid_kernel<KNN_CAP_LARGE, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0, dmov_xy, ix->sxy,
+                               ix->sidx, ix->hist, ix->g, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+    } else {
+        const unsigned blocks = (unsigned)ceil_div(cap_m, KNN_WAVES * (small ? KNN_RW_SMALL : KNN_RW_LARGE));
+        if (small)
+            SAME_LAUNCH(ctx, (knn_prune_kernel<KNN_CAP_SMALL, KNN_RW_SMALL, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0,
+                               dmov_xy, ix->drxy, (int64_t)0, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+        else
+            SAME_LAUNCH(ctx, (knn_prune_kernel<KNN_CAP_LARGE, KNN_RW_LARGE, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0,
+                               dmov_xy, ix->drxy, (int64_t)0, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
 extern "C" {
 
 int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double radius, same_knn_index **out) {
@@ -449,7 +502,7 @@ int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double 
     SAME_TRY(same_use(ctx));
     same_knn_index *ix = new (std::nothrow) same_knn_index();
     if (!ix) return SAME_ENOMEM;
-    ix->ctx = ctx; ix->drxy = drxy; ix->n_r = n_r; ix->radius = radius;
+    ix->ctx = ctx; ix->device = ctx->device; ix->drxy = drxy; ix->n_r = n_r; ix->radius = radius;
     const char *mode = getenv("SAME_KNN_MODE");
     bool want_grid = n_r >= 2048 && std::isfinite(radius);
     if (mode && mode[0] == 'b') want_grid = false;
@@ -479,8 +532,7 @@ int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double 
 
 void same_knn_index_destroy(same_knn_index *ix) {
     if (!ix) return;
-    (void)hipSetDevice(ix->ctx->device);
-    (void)hipStreamSynchronize(ix->ctx->stream);
+    (void)hipSetDevice(ix->device);        // hipFree waits for the device's outstanding work itself
     if (ix->hist) (void)hipFree(ix->hist);
     if (ix->sxy) (void)hipFree(ix->sxy);
     if (ix->sidx) (void)hipFree(ix->sidx);
@@ -489,7 +541,7 @@ void same_knn_index_destroy(same_knn_index *ix) {
 
 int same_knn_prune_indexed_dev(same_ctx *ctx, const same_knn_index *ix, const double *daxy, int64_t row_begin,
                                int64_t row_end, int k, int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt) {
-    REQUIRE(ctx, ctx && ix && ix->ctx == ctx && daxy && dout_idx && dout_cnt);
+    REQUIRE(ctx, ctx && ix && ix->device == ctx->device && daxy && dout_idx && dout_cnt);
     REQUIRE(ctx, row_begin >= 0 && row_end >= row_begin && k >= 1 && k <= SAME_MAX_KNN);
     SAME_TRY(same_use(ctx));
     if (row_end == row_begin) return SAME_OK;

@@ -27,55 +27,58 @@ __global__ __launch_bounds__(256) void greedy_init_kernel(const int32_t *__restr
     if (p < P) alive[p] = prefer[pairs[2 * p]];  // rows that prefer "unmatched" never enter (init_helpers.py:122,128)
 }
 
-__global__ __launch_bounds__(256) void greedy_reset_kernel(unsigned long long *__restrict__ rkey, unsigned *__restrict__ ridx,
-                                                            int64_t n_m, unsigned long long *__restrict__ ckey,
-                                                            unsigned *__restrict__ cidx, int64_t n_r) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n_m) { rkey[q] = ~0ull; ridx[q] = ~0u; }
-    if (q < n_r) { ckey[q] = ~0ull; cidx[q] = ~0u; }
+// One round = three maps over the pairs.  The per-endpoint minima are kept INVERTED (atomicMax of ~key, ~pair index) so that an
+// all-zero word means "nothing yet": the state starts from one memset, and the select map of round r clears the set round r + 1
+// uses (two sets, alternating), so a round is three launches and no fill.  `key` / `idx` hold rows [0, n_m) then columns
+// [n_m, n_m + n_r); dP (if not null) is the pair count on the device, P then only the bound the launch was sized by.
+__device__ __forceinline__ unsigned long long inv_key(double c) {
+    const unsigned long long k = ~cost_key(c);
+    return k ? k : 1ull;   // ~key == 0 only for one NaN payload: keep 0 for "nothing yet"
 }
 
 __global__ __launch_bounds__(256) void greedy_min_key_kernel(
-    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, uint8_t *__restrict__ alive,
-    const uint8_t *__restrict__ used_row, const uint8_t *__restrict__ used_col, unsigned long long *__restrict__ rkey,
-    unsigned long long *__restrict__ ckey) {
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m, unsigned long long *__restrict__ key) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dP) P = (int64_t)*dP;
     if (p >= P || !alive[p]) return;
     const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
-    if (used_row[i] || used_col[j]) { alive[p] = 0; return; }
-    const unsigned long long k = cost_key(costs[p]);
-    atomicMin(&rkey[i], k);
-    atomicMin(&ckey[j], k);
+    if (used[i] || used[n_m + j]) { alive[p] = 0; return; }
+    const unsigned long long k = inv_key(costs[p]);
+    atomicMax(&key[i], k);
+    atomicMax(&key[n_m + j], k);
 }
 
 __global__ __launch_bounds__(256) void greedy_min_idx_kernel(
-    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const uint8_t *__restrict__ alive,
-    const unsigned long long *__restrict__ rkey, const unsigned long long *__restrict__ ckey, unsigned *__restrict__ ridx,
-    unsigned *__restrict__ cidx) {
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    const uint8_t *__restrict__ alive, int64_t n_m, const unsigned long long *__restrict__ key, unsigned *__restrict__ idx) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dP) P = (int64_t)*dP;
     if (p >= P || !alive[p]) return;
     const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
-    const unsigned long long k = cost_key(costs[p]);
-    if (k == rkey[i]) atomicMin(&ridx[i], (unsigned)p);
-    if (k == ckey[j]) atomicMin(&cidx[j], (unsigned)p);
+    const unsigned long long k = inv_key(costs[p]);
+    if (k == key[i]) atomicMax(&idx[i], ~(unsigned)p);
+    if (k == key[n_m + j]) atomicMax(&idx[n_m + j], ~(unsigned)p);
 }
 
 __global__ __launch_bounds__(256) void greedy_select_kernel(
-    const int32_t *__restrict__ pairs, int64_t P, uint8_t *__restrict__ alive, const unsigned *__restrict__ ridx,
-    const unsigned *__restrict__ cidx, uint8_t *__restrict__ used_row, uint8_t *__restrict__ used_col,
-    int32_t *__restrict__ match_pair, unsigned long long *__restrict__ n_selected) {
+    const int32_t *__restrict__ pairs, int64_t P, const unsigned long long *__restrict__ dP, uint8_t *__restrict__ alive,
+    int64_t n_m, int64_t n_ends, const unsigned *__restrict__ idx, uint8_t *__restrict__ used, int32_t *__restrict__ match_pair,
+    unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key, unsigned *__restrict__ next_idx) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dP) P = (int64_t)*dP;
     bool sel = false;
     if (p < P && alive[p]) {
         const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
-        if (ridx[i] == (unsigned)p && cidx[j] == (unsigned)p) {
+        if (idx[i] == ~(unsigned)p && idx[n_m + j] == ~(unsigned)p) {
             sel = true;
             alive[p] = 0;
-            used_row[i] = 1;
-            used_col[j] = 1;
+            used[i] = 1;
+            used[n_m + j] = 1;
             match_pair[i] = (int32_t)p;
         }
     }
+    if (p < n_ends) { next_key[p] = 0ull; next_idx[p] = 0u; }   // the other set: nobody reads it in this round
     const unsigned long long bal = __ballot(sel);
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_selected, (unsigned long long)__builtin_popcountll(bal));
 }
@@ -298,43 +301,63 @@ __global__ __launch_bounds__(256) void batched_assign_kernel(
 
 }  // namespace
 
+// Rounds [first, first + count) of the greedy rule on device-resident state (declared in common.h; shared with window.hip).
+// st.used / st.key[] / st.idx[] / st.sel zero before round 0 (one memset); st.alive = the rows' "prefers a match" flag per
+// pair; dmatch_pair = -1.  Round r adds the number of pairs it selected to st.sel[r - first].  Enqueue only: 3 launches a round.
+int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dp, const double *dc, int64_t P, const unsigned long long *dP, int64_t n_m,
+                            int64_t n_r, const same_greedy_state &st, int32_t *dmatch_pair, int first, int count) {
+    const int64_t n_ends = n_m + n_r;
+    const unsigned gp = grid_for(P), gs = grid_for(P > n_ends ? P : n_ends);
+    for (int r = first; r < first + count; ++r) {
+        const int s = r & 1;
+        SAME_LAUNCH(ctx, greedy_min_key_kernel, dim3(gp), dim3(256), 0, dp, dc, P, dP, st.alive, st.used, n_m, st.key[s]);
+        SAME_LAUNCH(ctx, greedy_min_idx_kernel, dim3(gp), dim3(256), 0, dp, dc, P, dP, st.alive, n_m, st.key[s], st.idx[s]);
+        SAME_LAUNCH(ctx, greedy_select_kernel, dim3(gs), dim3(256), 0, dp, P, dP, st.alive, n_m, n_ends, st.idx[s], st.used, dmatch_pair,
+                    st.sel + (r - first), st.key[s ^ 1], st.idx[s ^ 1]);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
 // The greedy MIP start on device-resident pairs / costs / prefer flags: dmatch[n_m] = pair index per aligned row or -1.
-// Shared with the window pipeline (window.hip).  Scratch: SL_FLAG1, SL_FLAG2, SL_OUT0, SL_OUT1, SL_COUNTS and the pinned block;
-// one 8-byte read-back per round decides whether another round is needed.
+// Scratch: SL_FLAG1, SL_FLAG2, SL_OUT0, SL_OUT1, SL_COUNTS and the pinned block.  A round in which nothing is alive is a no-op, so
+// rounds are enqueued in batches (4, 4, 8, 16, ... 64) and the per-round selection counts of a batch come back in ONE read: the
+// host waits for the device once per batch, not once per round (a monotone cost chain needs a round per pair).
 int same_greedy_core(same_ctx *ctx, const int32_t *dp, const double *dc, int64_t P, int64_t n_m, int64_t n_r, const uint8_t *dprefer,
                      int32_t *dmatch, int *out_rounds) {
-    uint8_t *dalive, *durow, *ducol;
-    unsigned long long *drkey, *dckey, *dsel;
-    unsigned *dridx, *dcidx;
     if (out_rounds) *out_rounds = 0;
     if (n_m <= 0) return SAME_OK;
     HIP_TRY(ctx, hipMemsetAsync(dmatch, 0xFF, (size_t)n_m * sizeof(int32_t), ctx->stream));
     if (P <= 0) return SAME_OK;
-    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)P, &dalive));
-    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_m + n_r, &durow));
-    ducol = durow + n_m;
-    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)n_m + n_r, &drkey));
-    dckey = drkey + n_m;
-    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)n_m + n_r, &dridx));
-    dcidx = dridx + n_m;
-    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)4, &dsel));
-    HIP_TRY(ctx, hipMemsetAsync(durow, 0, (size_t)(n_m + n_r), ctx->stream));
-    hipLaunchKernelGGL(greedy_init_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dprefer, dalive);
+    const int64_t n_ends = n_m + n_r;
+    same_greedy_state st;
+    unsigned long long *keys;
+    unsigned *idxs;
+    SAME_TRY(slot_as(ctx, SL_FLAG1, (size_t)P, &st.alive));
+    SAME_TRY(slot_as(ctx, SL_FLAG2, (size_t)n_ends, &st.used));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)2 * n_ends, &keys));
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)2 * n_ends, &idxs));
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)SAME_GREEDY_BATCH_MAX, &st.sel));
+    st.key[0] = keys; st.key[1] = keys + n_ends;
+    st.idx[0] = idxs; st.idx[1] = idxs + n_ends;
+    HIP_TRY(ctx, hipMemsetAsync(st.used, 0, (size_t)n_ends, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(keys, 0, (size_t)2 * n_ends * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(idxs, 0, (size_t)2 * n_ends * sizeof(unsigned), ctx->stream));
+    SAME_LAUNCH(ctx, greedy_init_kernel, dim3(grid_for(P)), dim3(256), 0, dp, P, dprefer, st.alive);
     unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
-    const int64_t nmax = n_m > n_r ? n_m : n_r;
-    int rounds = 0;
-    for (;; ++rounds) {
+    int rounds = 0, batch = 4;
+    for (int n_batch = 0;; ++n_batch) {
         REQUIRE(ctx, rounds <= P + 1);  // each productive round removes at least one pair
-        HIP_TRY(ctx, hipMemsetAsync(dsel, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(greedy_reset_kernel, dim3(grid_for(nmax)), dim3(256), 0, ctx->stream, drkey, dridx, n_m, dckey, dcidx, n_r);
-        hipLaunchKernelGGL(greedy_min_key_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, durow, ducol, drkey, dckey);
-        hipLaunchKernelGGL(greedy_min_idx_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dalive, drkey, dckey, dridx, dcidx);
-        hipLaunchKernelGGL(greedy_select_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, P, dalive, dridx, dcidx, durow, ducol,
-                           dmatch, dsel);
-        HIP_TRY(ctx, hipGetLastError());
-        SAME_TRY(same_down(ctx, h, dsel, sizeof(unsigned long long)));
+        HIP_TRY(ctx, hipMemsetAsync(st.sel, 0, (size_t)batch * sizeof(unsigned long long), ctx->stream));
+        SAME_TRY(same_greedy_rounds_core(ctx, dp, dc, P, nullptr, n_m, n_r, st, dmatch, rounds, batch));
+        SAME_TRY(same_down(ctx, h, st.sel, (size_t)batch * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (h[0] == 0) break;  // nothing alive: the smallest alive pair would always have been selected
+        ++ctx->stats[SAME_STAT_GREEDY_READBACKS];
+        int q = 0;
+        while (q < batch && h[q] != 0) ++q;   // the first round that selected nothing: nothing was alive any more
+        rounds += q;
+        if (q < batch) break;
+        if (n_batch >= 1 && batch < SAME_GREEDY_BATCH_MAX) batch *= 2;
     }
     if (out_rounds) *out_rounds = rounds;
     return SAME_OK;

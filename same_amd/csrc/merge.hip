@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void merge_scatter_kernel(const unsigned long 
 
 }  // namespace
 
+// Ascending sort of n_pad 64-bit keys on the device (n_pad a power of two >= 2048; pad with ~0).  Enqueue only.  Shared with the
+// section index of the window path (window.hip), declared in common.h.
+int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad) {
+    REQUIRE(ctx, n_pad >= SORT_BLOCK && (n_pad & (n_pad - 1)) == 0);
+    hipLaunchKernelGGL(bitonic_lds_head_kernel, dim3((unsigned)(n_pad / SORT_BLOCK)), dim3(1024), 0, ctx->stream, dkey);
+    for (int64_t k = 2 * SORT_BLOCK; k <= n_pad; k <<= 1) {
+        for (int64_t j = k >> 1; j >= SORT_BLOCK; j >>= 1)
+            hipLaunchKernelGGL(bitonic_global_kernel, dim3((unsigned)ceil_div(n_pad / 2, 256)), dim3(256), 0, ctx->stream, dkey, n_pad, j, k);
+        hipLaunchKernelGGL(bitonic_lds_kernel, dim3((unsigned)(n_pad / SORT_BLOCK)), dim3(1024), 0, ctx->stream, dkey, k, SORT_BLOCK / 2);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
 extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_t *window_id, const int32_t *aligned_code,
                                 const int32_t *ref_code, int64_t n, int32_t *out_rows, int64_t *out_n) {
     REQUIRE(ctx, ctx && out_n && n >= 0 && n < ((int64_t)1 << 27));
@@ -195,12 +209,7 @@ extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_
     HIP_TRY(ctx, hipMemsetAsync(dtkey, 0xFF, (size_t)slots * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dtfirst, 0xFF, (size_t)slots * 4, ctx->stream));
     hipLaunchKernelGGL(merge_key_kernel, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, ctx->stream, dviol, dwin, n, n_pad, dkey);
-    hipLaunchKernelGGL(bitonic_lds_head_kernel, dim3((unsigned)(n_pad / SORT_BLOCK)), dim3(1024), 0, ctx->stream, dkey);
-    for (int64_t k = 2 * SORT_BLOCK; k <= n_pad; k <<= 1) {
-        for (int64_t j = k >> 1; j >= SORT_BLOCK; j >>= 1)
-            hipLaunchKernelGGL(bitonic_global_kernel, dim3((unsigned)ceil_div(n_pad / 2, 256)), dim3(256), 0, ctx->stream, dkey, n_pad, j, k);
-        hipLaunchKernelGGL(bitonic_lds_kernel, dim3((unsigned)(n_pad / SORT_BLOCK)), dim3(1024), 0, ctx->stream, dkey, k, SORT_BLOCK / 2);
-    }
+    SAME_TRY(same_sort_u64_core(ctx, dkey, n_pad));
     const unsigned grid = (unsigned)ceil_div(n, 256);
     hipLaunchKernelGGL(merge_first_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1);
     hipLaunchKernelGGL(merge_keep_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1, dmask, dwave);

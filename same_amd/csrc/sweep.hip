@@ -14,17 +14,11 @@
 #include <utility>
 
 #include "common.h"
+#include "devmath.h"
 
 namespace {
 
-typedef double double2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2_t ld2(const double *xy, int64_t i) {
-    return *reinterpret_cast<const double2_t *>(xy + 2 * i);
-}
-__device__ __forceinline__ int8_t orient_sign(double2_t a, double2_t b, double2_t c) {
-    const double v = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);  // src/same.py:658
-    return (int8_t)((v > 0.0) - (v < 0.0));
-}
+using namespace devmath;   // ld2, orient_sign, orient_flag, xyorder_edge, order_key: one definition (devmath.h)
 
 // ---- matching from x: last pair (highest pair index) with x > 0.5 wins per aligned row -----
 __global__ __launch_bounds__(256) void match_init_kernel(int32_t *__restrict__ pidx, int64_t n_m) {
@@ -53,11 +47,9 @@ __global__ __launch_bounds__(256) void orient_flag_kernel(
     if (t < Tr) {
         const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
         const int32_t ja = match[a], jb = match[b], jc = match[c];
-        if (ja >= 0 && jb >= 0 && jc >= 0) {                       // src/same.py:649-650
-            const int8_t rs = orient_sign(ld2(rxy, ja), ld2(rxy, jb), ld2(rxy, jc));
-            const int8_t ss = src_sign[t];
-            if (ss != 0 && rs != 0) f = (ss != rs) ? 2 : 1;        // src/same.py:663-669
-        }
+        const bool all3 = ja >= 0 && jb >= 0 && jc >= 0;           // src/same.py:649-650
+        const double2_t z = {0.0, 0.0};
+        f = orient_flag(src_sign[t], all3, all3 ? ld2(rxy, ja) : z, all3 ? ld2(rxy, jb) : z, all3 ? ld2(rxy, jc) : z);   // :658-669
         flag[t] = f;
     }
     const unsigned long long checked = __ballot(f != 0);
@@ -159,10 +151,9 @@ __global__ __launch_bounds__(256) void xyorder_kernel(
             if (m[p] >= 0 && m[q] >= 0) {  // both matched (implies >= 2 matched vertices, violationhelper.py:58-60)
                 f = 1;
                 ++ncmp;
-                const bool ox = a[p].x < a[q].x, oy = a[p].y < a[q].y;  // violationhelper.py:68-69
-                const bool mx = r[p].x < r[q].x, my = r[p].y < r[q].y;  // :74-75
-                if (ox != mx) { f |= 2; ++nviol; }
-                if (oy != my) { f |= 4; ++nviol; }
+                const uint8_t e2 = xyorder_edge(a[p], a[q], r[p], r[q]);   // violationhelper.py:68-75
+                f |= e2;
+                nviol += ((e2 >> 1) & 1) + ((e2 >> 2) & 1);
                 if (f & 6) { tv = 1; point_flag[v[p]] = 1; point_flag[v[q]] = 1; }  // benign: every writer stores 1
             }
             edge_flags[3 * t + e] = f;
@@ -191,14 +182,6 @@ __global__ __launch_bounds__(256) void xyorder_kernel(
 }
 
 // ---- a5 helpers -----------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long order_key(double v) {  // monotone u64 key of a double
-    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_to_double(unsigned long long k) {
-    const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
-    return __longlong_as_double((long long)u);
-}
 __global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *__restrict__ p, int64_t n, unsigned long long v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

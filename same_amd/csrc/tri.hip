@@ -5,28 +5,11 @@
 // fused multiply-add (OpenBLAS ddot behind 1-D np.linalg.norm / np.dot, see
 // oracle/same_oracle.c) use __builtin_fma explicitly.
 #include "common.h"
+#include "devmath.h"
 
 namespace {
 
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ double2_t ld2(const double *xy, int64_t i) {
-    return *reinterpret_cast<const double2_t *>(xy + 2 * i);
-}
-
-// src/helpers.py:305-307 -- np.linalg.norm of a 2-vector = sqrt(ddot(v, v))
-__device__ __forceinline__ double norm2(double x, double y) { return __builtin_sqrt(__builtin_fma(y, y, x * x)); }
-
-// src/helpers.py:278-288 -- clipped cosine of the corner at p2; 2.0 encodes the "angle 0" early return
-__device__ __forceinline__ double corner_cos(double2_t p1, double2_t p2, double2_t p3) {
-    const double v1x = p1.x - p2.x, v1y = p1.y - p2.y, v2x = p3.x - p2.x, v2y = p3.y - p2.y;
-    const double n1 = norm2(v1x, v1y), n2 = norm2(v2x, v2y);
-    if (n1 == 0.0 || n2 == 0.0) return 2.0;
-    double c = __builtin_fma(v1y, v2y, v1x * v2x) / (n1 * n2);
-    c = c < -1.0 ? -1.0 : c;
-    c = c > 1.0 ? 1.0 : c;
-    return c;
-}
+using namespace devmath;   // ld2, norm2, corner_cos, classify_triangle, orient_sign, signed_area: one definition (devmath.h)
 
 __global__ __launch_bounds__(256) void tri_classify_kernel(
     const double *__restrict__ xy, const int32_t *__restrict__ tris, int64_t Tr, double radius,
@@ -35,28 +18,11 @@ __global__ __launch_bounds__(256) void tri_classify_kernel(
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Tr) return;
     const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
-    const double2_t p1 = ld2(xy, a), p2 = ld2(xy, b), p3 = ld2(xy, c);
-    const double s1 = norm2(p2.x - p1.x, p2.y - p1.y);
-    const double s2 = norm2(p3.x - p2.x, p3.y - p2.y);
-    const double s3 = norm2(p1.x - p3.x, p1.y - p3.y);
-    double mx = s1 > s2 ? s1 : s2;
-    mx = mx > s3 ? mx : s3;
-    const double c1 = corner_cos(p2, p1, p3), c2 = corner_cos(p1, p2, p3), c3 = corner_cos(p1, p3, p2);
-    double mc = c1 > c2 ? c1 : c2;
-    mc = mc > c3 ? mc : c3;
-    uint8_t cls = 0;
-    if (mx >= radius) cls = 1;                                    // src/helpers.py:310
-    else if (angle_enabled && mc >= cos_thr) cls = 2;             // src/helpers.py:319
-    else if (type_id && type_id[a] == type_id[b] && type_id[b] == type_id[c]) cls = 3;  // :328-330
-    out_class[t] = cls;
-    out_perim[t] = s1 + s2 + s3;                                  // src/helpers.py:334
-    out_maxcos[t] = mc;
-}
-
-// src/same.py:1146, :658
-__device__ __forceinline__ int8_t orient_sign(double2_t a, double2_t b, double2_t c) {
-    const double v = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
-    return (int8_t)((v > 0.0) - (v < 0.0));
+    const TriClass r = classify_triangle(ld2(xy, a), ld2(xy, b), ld2(xy, c), radius, angle_enabled, cos_thr,
+                                         type_id && type_id[a] == type_id[b] && type_id[b] == type_id[c]);
+    out_class[t] = r.cls;
+    out_perim[t] = r.perim;
+    out_maxcos[t] = r.maxcos;
 }
 
 __global__ __launch_bounds__(256) void tri_sign_weight_kernel(
@@ -67,11 +33,6 @@ __global__ __launch_bounds__(256) void tri_sign_weight_kernel(
     const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
     out_sign[t] = orient_sign(ld2(xy, a), ld2(xy, b), ld2(xy, c));
     if (out_weight) out_weight[t] = size[a] + size[b] + size[c];  // src/same.py:1131-1133
-}
-
-// src/helpers.py:73-77
-__device__ __forceinline__ double signed_area(double2_t p1, double2_t p2, double2_t p3) {
-    return 0.5 * (p1.x * (p2.y - p3.y) + p2.x * (p3.y - p1.y) + p3.x * (p1.y - p2.y));
 }
 
 __global__ __launch_bounds__(256) void area_flip_kernel(

@@ -1,15 +1,15 @@
 // window.hip -- one window of the sliding-window path (src/same.py:507-593) with both sections RESIDENT on the device.
 //
-// The column pipeline (same_amd/windows.py::iter_window_arrays) subsets, prunes, compacts and gathers on the host and hands
-// every kernel its operands through host buffers: at a million cells per section the window's ~10^4 rows are cache-missing
-// gathers from 64 MB columns, and that host work -- not the kernels -- bounds BASELINE cfg 5.  Here a section's columns are
-// uploaded once (same_section) and a window is three calls:
+// A section's columns are uploaded once (same_section) and its rows are binned once into a grid of cells
+// (same_section_bin: rows sorted by cell, ascending inside a cell) -- SURVEY a13's "one-pass bin".  A window is then
 //
-//   same_window_stage   box test over the sections' rows + ordered compaction (= np.flatnonzero of src/same.py:293-295, rows
-//                       ascending), row gathers, radius / k prune (src/utils.py:709-728), costs of the candidate lists in the
-//                       cost type (src/same.py:1180-1189), compaction of the aligned side and of the pair list
-//                       (src/utils.py:734-742).  Back to the host: four counts, and (same_window_fetch) the kept aligned rows
-//                       and their XY -- the input of the host's Delaunay call (src/same.py:1023).
+//   same_window_stage   the rows of both sections inside the box, ascending (= np.flatnonzero of src/same.py:293-295), built from
+//                       the few cells the box covers: a row's place in the list is the number of smaller rows in those cells
+//                       (one binary search per cell), so the call reads O(window) rows whatever the section's size; radius / k
+//                       prune against the reference SECTION's grid index (src/utils.py:709-728; candidates outside the box are
+//                       not candidates), costs of the candidate lists in the cost type (src/same.py:1180-1189), compaction of the
+//                       aligned side and of the pair list (src/utils.py:734-742).  Back to the host in ONE copy: four counts, the
+//                       kept aligned rows and their XY -- the input of the host's Delaunay call (src/same.py:1023).
 //   same_window_filter  the Delaunay simplices in; triangle classes (src/helpers.py:300-330), the keep list and the same-type
 //                       triangles added back so that every node keeps one (src/helpers.py:331-340, :365-389) -- all on the
 //                       device, in the reference's order.  (A cosine within 8 ulp of the angle threshold is left to the host,
@@ -17,21 +17,42 @@
 //   same_window_finish  kept triangles in (or the ones same_window_filter left on the device); source signs / weights
 //                       (src/same.py:1128-1146), per-row minimum and the greedy MIP start (src/init_helpers.py:104-133), the
 //                       lazy-constraint body under that incumbent (src/same.py:645-669), XY-order sweep
-//                       (src/violationhelper.py:53-117), signed-area flips (src/same.py:1362-1402).  Back to the host: the
-//                       matched reference row per kept aligned cell, the per-cell violation flag and eight counters.
+//                       (src/violationhelper.py:53-117), signed-area flips (src/same.py:1362-1402).  Back to the host in ONE copy:
+//                       the matched reference row per kept aligned cell, the per-cell violation flag and eight counters.
+//   same_window_filter_finish = the last two with no host round trip between them.
 //
-// Reference cells are NOT renumbered (the reference drops unreferenced ones, src/utils.py:740-742): costs, the greedy rule and
-// the sweeps read coordinates and pair order only, which a monotone renumbering does not change; the match comes back as
-// section rows.  Everything reuses the kernels of the other translation units through their _dev entry points / cores, so
-// a window's numbers are those of the column pipeline bit for bit (tests/test_gpu_run_same.py::test_device_windows_*).
+// Nothing a call computes is sized by a number the host has to wait for: lists are allocated for the candidates of the covered
+// cells (known from the host's copy of the cell offsets), their true lengths stay in a counter block on the device and every
+// kernel reads them there.  A call is one fill (its counters and scan words), its launches, one copy back, ONE wait:
+// same_ctx_stat counts them, tests/test_gpu_run_same.py holds the per-window totals.  Ordered compactions are single launches
+// over many blocks (scan.h).
+//
+// Reference cells keep their SECTION rows through prune, costs and sweeps; the window's own numbering (position in the ascending
+// list of reference rows in the box -- what the reference's frames would index before src/utils.py:740-742 drops the unreferenced)
+// is only looked up for the pair list handed out and for the greedy rule's per-column state.  A window's numbers are those of
+// the column pipeline bit for bit (tests/test_gpu_run_same.py::test_device_windows_*).
 #include <algorithm>
+#include <cmath>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "common.h"
+#include "devmath.h"
+#include "scan.h"
+
+struct same_knn_index;
+extern "C" int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double radius, same_knn_index **out);
+extern "C" void same_knn_index_destroy(same_knn_index *ix);
 
 namespace {
 
-typedef double double2_t __attribute__((ext_vector_type(2)));
+using namespace devmath;
+using scan::Pair;
+
+constexpr int MAX_RUN_CELLS = 64;        // cells of a section's grid one window may cover on the cell-run path
+constexpr int64_t MAX_GRID_CELLS = (int64_t)1 << 22;
+constexpr unsigned OUTSIDE = 0x80000000u;   // flag on a candidate row that fails the box test
 
 struct DevBuf {
     void *p = nullptr;
@@ -40,7 +61,7 @@ struct DevBuf {
 
 int ensure(same_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.bytes && b.p) return SAME_OK;
-    const size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
     if (b.p) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipFree(b.p));
@@ -51,32 +72,100 @@ int ensure(same_ctx *ctx, DevBuf &b, size_t bytes) {
     b.bytes = want;
     return SAME_OK;
 }
-template <typename T>
-inline T *as(const DevBuf &b) { return static_cast<T *>(b.p); }
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// carve a buffer: offsets are multiples of 256 bytes
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~size_t(255);
+        return at;
+    }
+};
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
 
-// rows inside the half-open box, one bit per row (src/same.py:293-295; NaN coordinates fail every comparison)
-__global__ __launch_bounds__(256) void box_mask_kernel(const double *__restrict__ xy, int64_t n, double x0, double x1, double y0,
-                                                        double y1, unsigned long long *__restrict__ mask) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool in = false;
-    if (i < n) {
-        const double2_t p = *reinterpret_cast<const double2_t *>(xy + 2 * i);
-        in = p.x >= x0 && p.x < x1 && p.y >= y0 && p.y < y1;
-    }
-    const unsigned long long bal = __ballot(in);
-    if ((threadIdx.x & 63) == 0) mask[i >> 6] = bal;
+// ---- the section's grid of cells -------------------------------------------------------------------------------------------
+// cell (cx, cy) = [x0 + cx*cw, x0 + (cx+1)*cw) x [y0 + cy*ch, y0 + (cy+1)*ch): a row belongs to the cell whose edges -- these
+// very doubles -- bracket it under the comparisons of src/same.py:293-295, so a box whose edges are cell edges needs no test.
+struct BinGrid {
+    double x0 = 0.0, y0 = 0.0, cw = 1.0, ch = 1.0;
+    int nx = 1, ny = 1;
+};
+__host__ __device__ inline double cell_edge(double origin, double width, int c) { return origin + (double)c * width; }
+
+__device__ __forceinline__ int cell_of(double v, double origin, double width, int n) {
+    const double f = __builtin_floor((v - origin) / width);
+    int c = f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f);
+    while (c > 0 && v < cell_edge(origin, width, c)) --c;             // the quotient may round across an edge: the edges decide
+    while (c < n - 1 && v >= cell_edge(origin, width, c + 1)) ++c;
+    return c;
 }
 
-// dst[q][0..words) = src[pos[q]][0..words): rows of 4-byte words (XY pairs, type rows, sizes)
-__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t *__restrict__ src, int words, const int32_t *__restrict__ pos,
-                                                           int64_t n, uint32_t *__restrict__ dst) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * words) return;
-    const int64_t q = e / words;
-    const int w = (int)(e - q * words);
-    dst[e] = src[(int64_t)pos[q] * words + w];
+// sort key of a row: cell << 32 | row (rows ascending inside a cell); rows with a NaN / infinite coordinate sort behind every cell
+__global__ __launch_bounds__(256) void bin_key_kernel(const double *__restrict__ xy, int64_t n, int64_t n_pad, BinGrid g,
+                                                       unsigned long long *__restrict__ key) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    unsigned long long k = ~0ull;
+    if (i < n) {
+        const double2_t p = ld2(xy, i);
+        if (p.x - p.x == 0.0 && p.y - p.y == 0.0) {
+            const int cx = cell_of(p.x, g.x0, g.cw, g.nx), cy = cell_of(p.y, g.y0, g.ch, g.ny);
+            k = ((unsigned long long)((unsigned)cy * (unsigned)g.nx + (unsigned)cx) << 32) | (unsigned long long)i;
+        } else {
+            k = 0xFFFFFFFF00000000ull | (unsigned long long)i;
+        }
+    }
+    key[i] = k;
+}
+__global__ __launch_bounds__(256) void bin_order_kernel(const unsigned long long *__restrict__ key, int64_t n, int32_t *__restrict__ order) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) order[q] = (int32_t)(uint32_t)key[q];
+}
+// starts[c] = first sorted position of a row of cell >= c, c = 0 .. cells (starts[cells] = rows with finite coordinates)
+__global__ __launch_bounds__(256) void bin_starts_kernel(const unsigned long long *__restrict__ key, int64_t n, int64_t cells,
+                                                          unsigned *__restrict__ starts) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > cells) return;
+    const unsigned long long want = (unsigned long long)c << 32;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (key[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    starts[c] = (unsigned)lo;
+}
+// bounding box of the finite points: keys of {min x, min y} by atomicMin, {max x, max y} by atomicMax
+__global__ __launch_bounds__(256) void bin_bbox_kernel(const double *__restrict__ xy, int64_t n, unsigned long long *__restrict__ bbox) {
+    unsigned long long kx0 = ~0ull, ky0 = ~0ull, kx1 = 0ull, ky1 = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2_t p = ld2(xy, i);
+        if (p.x - p.x == 0.0 && p.y - p.y == 0.0) {
+            const unsigned long long kx = order_key(p.x), ky = order_key(p.y);
+            kx0 = kx < kx0 ? kx : kx0; ky0 = ky < ky0 ? ky : ky0; kx1 = kx > kx1 ? kx : kx1; ky1 = ky > ky1 ? ky : ky1;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kx0, off, 64), b = __shfl_xor(ky0, off, 64), c = __shfl_xor(kx1, off, 64),
+                                 d = __shfl_xor(ky1, off, 64);
+        kx0 = a < kx0 ? a : kx0; ky0 = b < ky0 ? b : ky0; kx1 = c > kx1 ? c : kx1; ky1 = d > ky1 ? d : ky1;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&bbox[0], kx0); atomicMin(&bbox[1], ky0); atomicMax(&bbox[2], kx1); atomicMax(&bbox[3], ky1);
+    }
+}
+double host_key_to_double(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    double d;
+    memcpy(&d, &u, sizeof d);
+    return d;
 }
 
 __global__ __launch_bounds__(256) void to_float_kernel(const double *__restrict__ src, int64_t n, float *__restrict__ dst) {
@@ -84,175 +173,382 @@ __global__ __launch_bounds__(256) void to_float_kernel(const double *__restrict_
     if (i < n) dst[i] = (float)src[i];          // round to nearest even, as numpy's astype(float32)
 }
 
-// one block: exclusive scans of (cnt > 0) and cnt over the window's aligned rows; totals -> counts[2] = kept rows, counts[3] = pairs
-__global__ __launch_bounds__(1024) void window_scan_kernel(const int32_t *__restrict__ cnt, int64_t n, int32_t *__restrict__ a_off,
-                                                            int32_t *__restrict__ p_off, unsigned long long *__restrict__ counts) {
-    __shared__ int wave_a[16], wave_p[16];
-    __shared__ long long carry_a, carry_p;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry_a = 0; carry_p = 0; }
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + tid;
-        const int c = i < n ? cnt[i] : 0;
-        const int u = c > 0;
-        int ia = u, ip = c;
+// ---- rows of a section inside a box, from the cells the box covers ---------------------------------------------------------
+struct RunDesc {               // one section's share of a window
+    const int32_t *order;      // the section's rows by cell
+    const unsigned *starts;    // cell offsets into `order`
+    const double *xy;          // section XY (box test of the candidates)
+    int nx, cx0, ncx, cy0, ncy;   // covered cells: [cx0, cx0 + ncx) x [cy0, cy0 + ncy), ncx * ncy <= MAX_RUN_CELLS
+    int n_cand;                // rows in those cells (the host knows the cell offsets)
+    int aligned;               // the box is a union of cells: every candidate is inside
+    uint32_t *merged;          // out: the candidates ascending by row (| OUTSIDE where the box test fails)
+    unsigned long long *count; // out, aligned only: n_cand
+};
+
+// One thread per candidate: its place in the ascending list = the number of candidates with a smaller row = the sum over the
+// covered cells of a lower bound in that cell's (ascending) run.  No sort, no scan; rows in different cells are distinct.
+__global__ __launch_bounds__(256) void window_rows_kernel(RunDesc dm, RunDesc dr, unsigned blocks_m, double bx0, double bx1, double by0,
+                                                           double by1) {
+    __shared__ unsigned lo[MAX_RUN_CELLS], hi[MAX_RUN_CELLS], pref[MAX_RUN_CELLS + 1];
+    const bool second = blockIdx.x >= blocks_m;
+    const RunDesc &d = second ? dr : dm;
+    const int nc = d.ncx * d.ncy;
+    if (threadIdx.x < 64) {     // one wave: the cells' runs and the prefix of their lengths
+        const int c = threadIdx.x;
+        unsigned a = 0, b = 0;
+        if (c < nc) {
+            const int64_t cell = (int64_t)(d.cy0 + c / d.ncx) * d.nx + (d.cx0 + c % d.ncx);
+            a = d.starts[cell];
+            b = d.starts[cell + 1];
+        }
+        unsigned incl = b - a;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int va = __shfl_up(ia, off, 64), vp = __shfl_up(ip, off, 64);
-            if (lane >= off) { ia += va; ip += vp; }
+            const unsigned v = __shfl_up(incl, off, 64);
+            if (c >= off) incl += v;
         }
-        if (lane == 63) { wave_a[wave] = ia; wave_p[wave] = ip; }
-        __syncthreads();
-        int oa = 0, op = 0;
-        for (int q = 0; q < wave; ++q) { oa += wave_a[q]; op += wave_p[q]; }
-        if (i < n) {
-            a_off[i] = (int32_t)(carry_a + oa + ia - u);
-            p_off[i] = (int32_t)(carry_p + op + ip - c);
-        }
-        __syncthreads();
-        if (tid == 1023) { carry_a += oa + ia; carry_p += op + ip; }
-        __syncthreads();
+        lo[c] = a;
+        hi[c] = b;
+        pref[c + 1] = incl;
+        if (c == 0) pref[0] = 0;
     }
-    if (tid == 0) { counts[2] = (unsigned long long)carry_a; counts[3] = (unsigned long long)carry_p; }
-}
-
-// compaction of the aligned side and of the pair list (src/utils.py:734-742): one lane per aligned row with candidates
-template <typename F>
-__global__ __launch_bounds__(256) void window_scatter_kernel(
-    const int32_t *__restrict__ idx, const F *__restrict__ cost, const int32_t *__restrict__ cnt, int64_t n_m, int k,
-    const int32_t *__restrict__ a_off, const int32_t *__restrict__ p_off, const int32_t *__restrict__ rows_m,
-    const double *__restrict__ axy_w, const double *__restrict__ size_w, const int32_t *__restrict__ type_w, int32_t *__restrict__ ua,
-    int32_t *__restrict__ rows_ua, double *__restrict__ axy_c, double *__restrict__ size_c, int32_t *__restrict__ type_c,
-    int32_t *__restrict__ pairs, double *__restrict__ cost64) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_m || cnt[i] <= 0) return;
-    const int32_t a = a_off[i];
-    ua[a] = (int32_t)i;
-    rows_ua[a] = rows_m[i];
-    axy_c[2 * (int64_t)a] = axy_w[2 * i];
-    axy_c[2 * (int64_t)a + 1] = axy_w[2 * i + 1];
-    size_c[a] = size_w[i];
-    if (type_w) type_c[a] = type_w[i];
-    int64_t p = p_off[i];
-    const int64_t p_end = p + cnt[i];              // the scan sized the list by cnt: never write past this row's share
-    for (int q = 0; q < k && p < p_end; ++q) {
-        const int32_t j = idx[i * k + q];
-        if (j >= 0) {
-            pairs[2 * p] = a;
-            pairs[2 * p + 1] = j;
-            cost64[p] = (double)cost[i * k + q];
-            ++p;
-        }
+    __syncthreads();
+    const int64_t q = (int64_t)(blockIdx.x - (second ? blocks_m : 0)) * blockDim.x + threadIdx.x;
+    if (q == 0 && d.aligned) *d.count = (unsigned long long)d.n_cand;
+    if (q >= d.n_cand) return;
+    int c0 = 0, c1 = nc;        // the cell of candidate q: pref[c] <= q < pref[c + 1]
+    while (c1 - c0 > 1) {
+        const int mid = (c0 + c1) >> 1;
+        if (pref[mid] <= (unsigned)q) c0 = mid; else c1 = mid;
     }
+    const unsigned at = lo[c0] + ((unsigned)q - pref[c0]);
+    const int32_t row = d.order[at];
+    unsigned rank = at - lo[c0];
+    for (int c = 0; c < nc; ++c) {
+        if (c == c0) continue;
+        unsigned a = lo[c], b = hi[c];
+        const unsigned base = a;
+        while (a < b) {
+            const unsigned mid = (a + b) >> 1;
+            if (d.order[mid] < row) a = mid + 1; else b = mid;
+        }
+        rank += a - base;
+    }
+    uint32_t out = (uint32_t)row;
+    if (!d.aligned) {
+        const double2_t p = ld2(d.xy, row);
+        if (!(p.x >= bx0 && p.x < bx1 && p.y >= by0 && p.y < by1)) out |= OUTSIDE;   // src/same.py:293-295
+    }
+    d.merged[rank] = out;
 }
 
-// rows whose best pair beats their no-match penalty (src/init_helpers.py:118-122)
-__global__ __launch_bounds__(256) void prefer_kernel(const double *__restrict__ rowmin, const double *__restrict__ size, int64_t n,
-                                                      double penalty, uint8_t *__restrict__ prefer) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) prefer[i] = rowmin[i] < penalty * size[i];
+// the candidates that passed the box test, in order (only for boxes that cut through cells); blocks [0, blocks_m) = moving
+struct RowsCompact {
+    const uint32_t *merged;
+    int n_cand;
+    int32_t *rows;
+    unsigned long long *status, *count;
+};
+__global__ __launch_bounds__(scan::NT) void rows_compact_kernel(RowsCompact cm, RowsCompact cr, unsigned blocks_m) {
+    __shared__ scan::Shared sh;
+    const bool second = blockIdx.x >= blocks_m;
+    const RowsCompact &c = second ? cr : cm;
+    const int b = (int)(blockIdx.x - (second ? blocks_m : 0));
+    const int nb = (int)(second ? gridDim.x - blocks_m : blocks_m);
+    auto val = [&](int64_t i) { return Pair{i < c.n_cand && !(c.merged[i] & OUTSIDE) ? 1u : 0u, 0u}; };
+    Pair through;
+    const Pair off = scan::exclusive(c.status, b, val, sh, &through);
+    const int64_t i = (int64_t)b * scan::NT + threadIdx.x;
+    if (i < c.n_cand && !(c.merged[i] & OUTSIDE)) c.rows[off.a] = (int32_t)c.merged[i];
+    if (b == nb - 1 && threadIdx.x == 0) *c.count = through.a;
 }
 
-// pair per row -> matched reference (window numbering, for the sweeps) and its section row (for the caller)
-__global__ __launch_bounds__(256) void match_rows_kernel(const int32_t *__restrict__ pair_of_row, const int32_t *__restrict__ pairs,
-                                                          const int32_t *__restrict__ rows_r, int64_t n, int32_t *__restrict__ match,
-                                                          int32_t *__restrict__ match_row, unsigned long long *__restrict__ stats) {
+// ---- the rows of a section inside a box without the grid (a box over more than MAX_RUN_CELLS cells) ------------------------
+__global__ __launch_bounds__(256) void box_mask_kernel(const double *__restrict__ xy, int64_t n, double x0, double x1, double y0,
+                                                        double y1, unsigned long long *__restrict__ mask) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool m = false;
+    bool in = false;
     if (i < n) {
-        const int32_t p = pair_of_row[i];
-        const int32_t j = p >= 0 ? pairs[2 * (int64_t)p + 1] : -1;
-        match[i] = j;
-        match_row[i] = j >= 0 ? rows_r[j] : -1;
-        m = j >= 0;
+        const double2_t p = ld2(xy, i);
+        in = p.x >= x0 && p.x < x1 && p.y >= y0 && p.y < y1;
     }
-    const unsigned long long bal = __ballot(m);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&stats[7], (unsigned long long)__builtin_popcountll(bal));
+    const unsigned long long bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0) mask[i >> 6] = bal;
+}
+__global__ __launch_bounds__(scan::NT) void mask_compact_kernel(const unsigned long long *__restrict__ mask, int64_t n_words,
+                                                                 unsigned long long *__restrict__ status, int32_t *__restrict__ rows,
+                                                                 unsigned long long *__restrict__ count) {
+    __shared__ scan::Shared sh;
+    auto val = [&](int64_t w) { return Pair{w < n_words ? (unsigned)__builtin_popcountll(mask[w]) : 0u, 0u}; };
+    Pair through;
+    const Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const int64_t w = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    if (w < n_words) {
+        unsigned long long bits = mask[w];
+        unsigned pos = off.a;
+        while (bits) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            rows[pos++] = (int32_t)(w * 64 + b);
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count = through.a;
 }
 
-__global__ __launch_bounds__(256) void count_flags_kernel(const uint8_t *__restrict__ flag, int64_t n, unsigned long long *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long bal = __ballot(i < n && flag[i] != 0);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(out, (unsigned long long)__builtin_popcountll(bal));
+// ---- compaction of the aligned side and of the pair list (src/utils.py:734-742): scan + scatter in one launch ---------------
+// counts: [0] aligned rows in the box, [1] reference rows in the box, [2] aligned rows kept, [3] pairs
+struct ScatterArgs {
+    const int32_t *idx;        // [cap][k] reference SECTION rows, -1 padded
+    const void *cost;          // [cap][k] in the cost type
+    const int32_t *cnt;        // [cap]
+    const int32_t *rows_m, *rows_r;
+    const double *mov_xy, *mov_size;
+    const int32_t *mov_type;   // or null
+    unsigned long long *status, *counts;
+    int32_t *ua, *rows_ua, *type_c, *prow, *pairs, *jsec;
+    double *axy_c, *size_c, *cost64;
+    int k;
+};
+template <typename F>
+__global__ __launch_bounds__(scan::NT) void window_scatter_kernel(ScatterArgs s) {
+    __shared__ scan::Shared sh;
+    const int64_t n_m = (int64_t)s.counts[0], n_r = (int64_t)s.counts[1];
+    auto val = [&](int64_t i) {
+        const int c = i < n_m ? s.cnt[i] : 0;
+        return Pair{c > 0 ? 1u : 0u, c > 0 ? (unsigned)c : 0u};
+    };
+    Pair through;
+    const Pair off = scan::exclusive(s.status, (int)blockIdx.x, val, sh, &through);
+    const int64_t i = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    const int c = i < n_m ? s.cnt[i] : 0;
+    if (c > 0) {
+        const int32_t a = (int32_t)off.a, row = s.rows_m[i];
+        s.ua[a] = (int32_t)i;
+        s.rows_ua[a] = row;
+        const double2_t p = ld2(s.mov_xy, row);
+        s.axy_c[2 * (int64_t)a] = p.x;
+        s.axy_c[2 * (int64_t)a + 1] = p.y;
+        s.size_c[a] = s.mov_size[row];
+        s.type_c[a] = s.mov_type ? s.mov_type[row] : 0;
+        s.prow[a] = (int32_t)off.p;
+        int64_t pp = off.p;
+        const int64_t p_end = pp + c;                // the scan sized the list by cnt: never write past this row's share
+        const F *cost = static_cast<const F *>(s.cost);
+        for (int q = 0; q < s.k && pp < p_end; ++q) {
+            const int32_t j = s.idx[i * s.k + q];
+            if (j >= 0) {
+                int64_t lo = 0, hi = n_r;            // the reference cell's number in the window: its place in the ascending row list
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (s.rows_r[mid] < j) lo = mid + 1; else hi = mid;
+                }
+                s.pairs[2 * pp] = a;
+                s.pairs[2 * pp + 1] = (int32_t)lo;
+                s.jsec[pp] = j;
+                s.cost64[pp] = (double)cost[i * s.k + q];
+                ++pp;
+            }
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        s.counts[2] = through.a;
+        s.counts[3] = through.p;
+        s.prow[through.a] = (int32_t)through.p;
+    }
 }
 
 // ---- triangle filter (src/helpers.py:233-395) on the device ------------------------------------------------------------------
-// classes come from same_tri_classify_dev; this marks what the re-add pass needs: vertices with a kept triangle, vertices with
-// any valid (kept or same-type) triangle, the keep mask, and how many cosines sit within `tol` of the threshold
-__global__ __launch_bounds__(256) void filter_mark_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ maxcos,
-                                                           const int32_t *__restrict__ tris, int64_t Tr, int near_enabled, double thr,
-                                                           double tol, uint8_t *__restrict__ has_kept, uint8_t *__restrict__ any_valid,
-                                                           unsigned long long *__restrict__ keep_mask,
-                                                           unsigned long long *__restrict__ counters) {
+// counters of the filter: [0] kept (class 0), [1] added back, [2] cosines within `tol` of the threshold, [3] triangles left
+enum { FC_KEEP = 0, FC_ADD = 1, FC_NEAR = 2, FC_TR = 3 };
+
+// classes; vertices with a kept triangle, vertices with any valid (kept or same-type) triangle; knife-edge cosines
+__global__ __launch_bounds__(256) void filter_classify_kernel(const double *__restrict__ xy, const int32_t *__restrict__ tris, int64_t Tr,
+                                                               double radius, int angle_enabled, double cos_thr, const int32_t *__restrict__ type_id,
+                                                               int near_enabled, double tol, uint8_t *__restrict__ cls,
+                                                               double *__restrict__ perim, uint8_t *__restrict__ has_kept,
+                                                               uint8_t *__restrict__ any_valid, unsigned long long *__restrict__ counters) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool keep = false, near = false;
+    bool near = false;
     if (t < Tr) {
-        const uint8_t c = cls[t];
-        keep = c == 0;
-        near = near_enabled && c != 1 && fabs(maxcos[t] - thr) <= tol;
-        if (c == 0 || c == 3) {
-            const int32_t a = tris[3 * t], b = tris[3 * t + 1], d = tris[3 * t + 2];
+        const int32_t a = tris[3 * t], b = tris[3 * t + 1], d = tris[3 * t + 2];
+        const TriClass r = classify_triangle(ld2(xy, a), ld2(xy, b), ld2(xy, d), radius, angle_enabled, cos_thr,
+                                             type_id && type_id[a] == type_id[b] && type_id[b] == type_id[d]);
+        cls[t] = r.cls;
+        perim[t] = r.perim;
+        near = near_enabled && r.cls != 1 && fabs(r.maxcos - cos_thr) <= tol;
+        if (r.cls == 0 || r.cls == 3) {
             any_valid[a] = 1; any_valid[b] = 1; any_valid[d] = 1;
-            if (c == 0) { has_kept[a] = 1; has_kept[b] = 1; has_kept[d] = 1; }
+            if (r.cls == 0) { has_kept[a] = 1; has_kept[b] = 1; has_kept[d] = 1; }
         }
     }
-    const unsigned long long kb = __ballot(keep), nb = __ballot(near);
-    if ((threadIdx.x & 63) == 0) {
-        keep_mask[t >> 6] = kb;
-        if (nb) atomicAdd(&counters[2], (unsigned long long)__builtin_popcountll(nb));
-    }
+    const unsigned long long nb = __ballot(near);
+    if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&counters[FC_NEAR], (unsigned long long)__builtin_popcountll(nb));
 }
-
-// best same-type triangle of every vertex = smallest perimeter, first in input order on ties (src/helpers.py:334-340):
-// two passes of atomic minima, first over the perimeter's bit pattern (perimeters are >= 0: the order of the bits is theirs)
+__global__ __launch_bounds__(scan::NT) void filter_keep_kernel(const uint8_t *__restrict__ cls, int64_t Tr, unsigned long long *__restrict__ status,
+                                                                int32_t *__restrict__ keep_list, unsigned long long *__restrict__ counters) {
+    __shared__ scan::Shared sh;
+    auto val = [&](int64_t t) { return Pair{t < Tr && cls[t] == 0 ? 1u : 0u, 0u}; };
+    Pair through;
+    const Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const int64_t t = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    if (t < Tr && cls[t] == 0) keep_list[off.a] = (int32_t)t;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters[FC_KEEP] = through.a;
+}
+// best same-type triangle of every vertex = smallest perimeter, first in input order on ties (src/helpers.py:334-340): two passes
+// of atomic maxima over INVERTED keys (zero = none yet, so one fill prepares them): the perimeter's bit pattern (perimeters are
+// >= 0: the order of the bits is theirs), then the triangle index among equal perimeters
 __global__ __launch_bounds__(256) void filter_best_perim_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
                                                                  const int32_t *__restrict__ tris, int64_t Tr,
                                                                  unsigned long long *__restrict__ best_p) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Tr || cls[t] != 3) return;
-    const unsigned long long key = (unsigned long long)__double_as_longlong(perim[t]);
-    for (int q = 0; q < 3; ++q) atomicMin(&best_p[tris[3 * t + q]], key);
+    const unsigned long long key = ~(unsigned long long)__double_as_longlong(perim[t]);
+    for (int q = 0; q < 3; ++q) atomicMax(&best_p[tris[3 * t + q]], key);
 }
 __global__ __launch_bounds__(256) void filter_best_tri_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
                                                                const int32_t *__restrict__ tris, int64_t Tr,
                                                                const unsigned long long *__restrict__ best_p, unsigned *__restrict__ best_t) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Tr || cls[t] != 3) return;
-    const unsigned long long key = (unsigned long long)__double_as_longlong(perim[t]);
+    const unsigned long long key = ~(unsigned long long)__double_as_longlong(perim[t]);
     for (int q = 0; q < 3; ++q) {
         const int32_t v = tris[3 * t + q];
-        if (best_p[v] == key) atomicMin(&best_t[v], (unsigned)t);
+        if (best_p[v] == key) atomicMax(&best_t[v], ~(unsigned)t);
     }
 }
 // nodes without a kept triangle but with a valid one are walked in ascending order and bring their best triangle along unless an
-// earlier node already did (src/helpers.py:365-389): first_v[t] = the first node that asks for t ...
+// earlier node already did (src/helpers.py:365-389): first_v[t] = the first node that asks for t (inverted, zero = nobody) ...
+__device__ __forceinline__ bool asks(const uint8_t *has_kept, const uint8_t *any_valid, const unsigned *best_t, int64_t v) {
+    return !has_kept[v] && any_valid[v] && best_t[v] != 0u;
+}
 __global__ __launch_bounds__(256) void filter_first_node_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
                                                                  const unsigned *__restrict__ best_t, int64_t n, unsigned *__restrict__ first_v) {
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || has_kept[v] || !any_valid[v] || best_t[v] == ~0u) return;
-    atomicMin(&first_v[best_t[v]], (unsigned)v);
+    if (v >= n || !asks(has_kept, any_valid, best_t, v)) return;
+    atomicMax(&first_v[~best_t[v]], ~(unsigned)v);
 }
-// ... and the nodes that are the first to ask, as a mask over the nodes (compacted in order afterwards)
-__global__ __launch_bounds__(256) void filter_owner_mask_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
-                                                                 const unsigned *__restrict__ best_t, const unsigned *__restrict__ first_v,
-                                                                 int64_t n, unsigned long long *__restrict__ mask) {
-    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool own = false;
-    if (v < n && !has_kept[v] && any_valid[v] && best_t[v] != ~0u) own = first_v[best_t[v]] == (unsigned)v;
-    const unsigned long long bal = __ballot(own);
-    if ((threadIdx.x & 63) == 0) mask[v >> 6] = bal;
+// ... and the nodes that are the first to ask, compacted in order
+__global__ __launch_bounds__(scan::NT) void filter_owner_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
+                                                                 const unsigned *__restrict__ best_t, const unsigned *__restrict__ first_v, int64_t n,
+                                                                 unsigned long long *__restrict__ status, int32_t *__restrict__ owner_list,
+                                                                 unsigned long long *__restrict__ counters) {
+    __shared__ scan::Shared sh;
+    auto own = [&](int64_t v) { return v < n && asks(has_kept, any_valid, best_t, v) && first_v[~best_t[v]] == ~(unsigned)v; };
+    auto val = [&](int64_t v) { return Pair{own(v) ? 1u : 0u, 0u}; };
+    Pair through;
+    const Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const int64_t v = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    if (own(v)) owner_list[off.a] = (int32_t)v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters[FC_ADD] = through.a;
 }
 // the kept triangles in the reference's order: class-0 triangles ascending, then the added-back ones in walk order
-__global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ keep_list, int64_t n_keep,
-                                                           const int32_t *__restrict__ owner_list, int64_t n_add,
-                                                           const unsigned *__restrict__ best_t, int32_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ keep_list,
+                                                           const int32_t *__restrict__ owner_list, const unsigned *__restrict__ best_t,
+                                                           unsigned long long *__restrict__ counters, int32_t *__restrict__ out) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_keep = (int64_t)counters[FC_KEEP], n_add = (int64_t)counters[FC_ADD];
+    if (q == 0) counters[FC_TR] = (unsigned long long)(n_keep + n_add);
     if (q >= n_keep + n_add) return;
-    const int64_t t = q < n_keep ? keep_list[q] : (int64_t)best_t[owner_list[q - n_keep]];
+    const int64_t t = q < n_keep ? keep_list[q] : (int64_t)~best_t[owner_list[q - n_keep]];
     out[3 * q] = raw[3 * t];
     out[3 * q + 1] = raw[3 * t + 1];
     out[3 * q + 2] = raw[3 * t + 2];
+}
+
+// ---- incumbent and sweeps ---------------------------------------------------------------------------------------------------
+// counters of the finish call: [0] orientation checked, [1] flipped, [2] XY comparisons, [3] XY violations, [4] triangles with
+// one, [5] area flips, [6] (host) greedy rounds, [7] matched aligned cells
+enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7 };
+
+// per kept aligned row: minimum pair cost (src/init_helpers.py:118-122; its pairs are a contiguous run of the pair list), whether
+// it beats the no-match penalty, the row's pairs enter the greedy rule or not, no match yet
+__global__ __launch_bounds__(256) void row_prefer_kernel(const int32_t *__restrict__ prow, const double *__restrict__ cost64,
+                                                          const double *__restrict__ size_c, const unsigned long long *__restrict__ dn,
+                                                          double penalty, uint8_t *__restrict__ alive, int32_t *__restrict__ match_pair) {
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= (int64_t)*dn) return;
+    const int32_t lo = prow[a], hi = prow[a + 1];
+    double best = __builtin_inf();
+    for (int32_t p = lo; p < hi; ++p) {
+        const double c = cost64[p];
+        if (c < best) best = c;
+    }
+    const uint8_t prefer = best < penalty * size_c[a];
+    for (int32_t p = lo; p < hi; ++p) alive[p] = prefer;
+    match_pair[a] = -1;
+}
+// pair per row -> matched reference cell: its number in the window (handed out), its section row (the sweeps and the caller)
+__global__ __launch_bounds__(256) void match_rows_kernel(const int32_t *__restrict__ match_pair, const int32_t *__restrict__ pairs,
+                                                          const int32_t *__restrict__ jsec, const unsigned long long *__restrict__ dn,
+                                                          int32_t *__restrict__ match_loc, int32_t *__restrict__ match_row,
+                                                          uint8_t *__restrict__ pflag, unsigned long long *__restrict__ counters) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool m = false;
+    if (i < (int64_t)*dn) {
+        const int32_t p = match_pair[i];
+        match_loc[i] = p >= 0 ? pairs[2 * (int64_t)p + 1] : -1;
+        match_row[i] = p >= 0 ? jsec[p] : -1;
+        pflag[i] = 0;
+        m = p >= 0;
+    }
+    const unsigned long long bal = __ballot(m);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counters[SC_MATCHED], (unsigned long long)__builtin_popcountll(bal));
+}
+// one pass over the kept triangles: source sign and weight (src/same.py:1128-1146), the lazy-constraint body under the incumbent
+// (:645-669), the XY-order sweep (src/violationhelper.py:53-117), the signed-area flip (src/same.py:1362-1402; helpers.py:73-77)
+__global__ __launch_bounds__(256) void window_sweeps_kernel(const int32_t *__restrict__ tris, int64_t Tr, const unsigned long long *__restrict__ dTr,
+                                                             const double *__restrict__ axy, const double *__restrict__ size_c,
+                                                             const double *__restrict__ ref_xy, const int32_t *__restrict__ match_row,
+                                                             int8_t *__restrict__ sign, double *__restrict__ weight, uint8_t *__restrict__ pflag,
+                                                             unsigned long long *__restrict__ counters) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dTr) Tr = (int64_t)*dTr;
+    int checked = 0, flipped = 0, ncmp = 0, nviol = 0, tv = 0, aflip = 0;
+    if (t < Tr) {
+        const int32_t v[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
+        const int32_t m[3] = {match_row[v[0]], match_row[v[1]], match_row[v[2]]};
+        double2_t a[3], r[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            a[q] = ld2(axy, v[q]);
+            r[q] = m[q] >= 0 ? ld2(ref_xy, m[q]) : double2_t{0.0, 0.0};
+        }
+        const int8_t ss = orient_sign(a[0], a[1], a[2]);
+        sign[t] = ss;
+        weight[t] = size_c[v[0]] + size_c[v[1]] + size_c[v[2]];            // src/same.py:1131-1133
+        const bool all3 = m[0] >= 0 && m[1] >= 0 && m[2] >= 0;
+        const uint8_t f = orient_flag(ss, all3, r[0], r[1], r[2]);
+        checked = f != 0;
+        flipped = f == 2;
+        const int E[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int p = E[e][0], q = E[e][1];
+            if (m[p] >= 0 && m[q] >= 0) {  // both matched (implies >= 2 matched vertices, violationhelper.py:58-60)
+                ++ncmp;
+                const uint8_t e2 = xyorder_edge(a[p], a[q], r[p], r[q]);
+                nviol += ((e2 >> 1) & 1) + ((e2 >> 2) & 1);
+                if (e2) { tv = 1; pflag[v[p]] = 1; pflag[v[q]] = 1; }  // benign: every writer stores 1
+            }
+        }
+        if (all3) {
+            const double bf = signed_area(a[0], a[1], a[2]), af = signed_area(r[0], r[1], r[2]);
+            aflip = bf * af < 0.0;                                         // src/same.py:1401
+        }
+    }
+    int vals[6] = {checked, flipped, ncmp, nviol, tv, aflip};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vals[q] += __shfl_down(vals[q], off, 64);
+    __shared__ int part[4][6];
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < 6; ++q) part[threadIdx.x >> 6][q] = vals[q];
+    __syncthreads();
+    if (threadIdx.x < 6) {      // one atomic per block per counter (integer sums: order-independent)
+        const int s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (s) atomicAdd(&counters[threadIdx.x], (unsigned long long)s);
+    }
 }
 
 }  // namespace
@@ -267,18 +563,38 @@ struct same_section {
     void *types_c = nullptr;  // [n][T] in the cost type
     double *size = nullptr;   // [n]
     int32_t *type_id = nullptr;  // [n] codes of the cell type (equal type <=> equal code), or none
+    // the grid of cells (same_section_bin)
+    BinGrid grid;
+    int32_t *order = nullptr;        // [n_binned] rows by cell, ascending inside a cell
+    unsigned *starts = nullptr;      // [cells + 1] on the device ...
+    std::vector<unsigned> h_starts;  // ... and on the host: a window's candidate count is known without asking the device
+    int64_t n_binned = 0;
+    // prune indices of this section as the REFERENCE side, one per radius used (built on first use, under the lock: sections are
+    // shared by the worker threads' contexts)
+    std::mutex lock;
+    std::vector<std::pair<double, same_knn_index *>> knn;
 };
 
 struct same_window {
     same_ctx *ctx = nullptr;
+    const same_section *mov = nullptr, *ref = nullptr;
     int cost_f32 = 0, k = 0, staged = 0, finished = 0, has_type = 0, filtered = 0;
+    int64_t cap_m = 0, cap_r = 0;                   // candidates of the covered cells: what the lists are sized for
     int64_t n_m = 0, n_r = 0, n_ua = 0, P = 0, Tr = 0;
-    DevBuf mask, counts, rows_m, rows_r, axy_w, rxy_w, axyc_w, rxyc_w, A_w, R_w, size_w, idx, cnt, cost, a_off, p_off, ua, rows_ua,
-        axy_c, size_c, pairs, cost64;
-    DevBuf type_w, type_c, raw, cls, perim, maxcos, kmask, has_kept, any_valid, best_p, best_t, first_v, nmask, nlist, klist;
-    DevBuf tris, sign, weight, rowmin, prefer, pair_of_row, match, match_row, oflag, omask, edge, tflag, pflag, before, after, m3, flipped;
+    DevBuf stage, filter, finish, tris, big_mask, full_m, full_r;
+    // stage block
+    unsigned long long *counts = nullptr;           // [8], first words of the block the stage call copies back
+    int32_t *rows_m = nullptr, *rows_r = nullptr, *idx = nullptr, *cnt = nullptr, *ua = nullptr, *rows_ua = nullptr, *type_c = nullptr,
+            *prow = nullptr, *pairs = nullptr, *jsec = nullptr;
+    double *axy_c = nullptr, *size_c = nullptr, *cost64 = nullptr;
+    // finish block
+    int8_t *sign = nullptr;
+    double *weight = nullptr;
+    int32_t *match_loc = nullptr;
     void *host = nullptr;     // pinned staging for everything that comes back
     size_t host_bytes = 0;
+    size_t host_finish_off = 0;   // the pinned block: [stage call's copy | finish call's copy | the filter's counters]
+    size_t host_filter_off = 0;
 };
 
 namespace {
@@ -298,49 +614,179 @@ int ensure_host(same_window *w, size_t bytes) {
     return SAME_OK;
 }
 
-// Layout of the pinned staging block: [0, 64) scalars; the stage call's results (kept aligned XY, then their section rows, at the
-// capacity n_m) from byte 64; the finish call's results behind them.  Sized once per window by the stage call.
-inline size_t finish_off(int64_t n_m) { return (64 + (size_t)n_m * (sizeof(int32_t) + 2 * sizeof(double)) + 127) & ~size_t(63); }
-inline size_t host_need(int64_t n_m) { return finish_off(n_m) + 128 + (size_t)n_m * 5 + 64; }
+// the prune index of `ref` for this radius (built once, with the caller's context)
+int knn_index_for(same_ctx *ctx, const same_section *ref, double radius, const same_knn_index **out) {
+    same_section *s = const_cast<same_section *>(ref);
+    std::lock_guard<std::mutex> hold(s->lock);
+    for (const auto &e : s->knn)
+        if (e.first == radius) { *out = e.second; return SAME_OK; }
+    REQUIRE(ctx, s->knn.size() < 16);      // one index per radius a section is pruned with: a handful, not a stream of them
+    same_knn_index *ix = nullptr;
+    SAME_TRY(same_knn_index_build(ctx, s->xy, s->n, radius, &ix));
+    s->knn.emplace_back(radius, ix);
+    *out = ix;
+    return SAME_OK;
+}
 
-// rows of `sec` inside the box, ascending, into dst (sized for them); their number into *out_n.  One read-back.
-int subset_rows(same_window *w, const same_section *sec, const double *box, DevBuf &dst, int64_t *out_n) {
+// covered cells of `box` in the section's grid, and whether the box is exactly their union
+struct Cover {
+    int cx0 = 0, ncx = 0, cy0 = 0, ncy = 0;
+    int64_t n_cand = 0;
+    bool aligned = false, use_runs = false;
+};
+int host_cell(double v, double origin, double width, int n) {      // cell_of on the host (the same expressions)
+    const double f = std::floor((v - origin) / width);
+    int c = f < 0.0 ? 0 : (f >= (double)n ? n - 1 : (int)f);
+    while (c > 0 && v < cell_edge(origin, width, c)) --c;
+    while (c < n - 1 && v >= cell_edge(origin, width, c + 1)) ++c;
+    return c;
+}
+Cover cover_of(const same_section *s, const double *box) {
+    Cover c;
+    c.use_runs = true;
+    if (s->n_binned == 0) return c;                                                       // no row with finite coordinates: nothing is inside any box
+    const BinGrid &g = s->grid;
+    const double x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3];
+    if (!(x0 < x1) || !(y0 < y1)) return c;                                               // empty (or NaN) box
+    const double gx1 = cell_edge(g.x0, g.cw, g.nx), gy1 = cell_edge(g.y0, g.ch, g.ny);
+    if (!(x1 > g.x0) || !(x0 < gx1) || !(y1 > g.y0) || !(y0 < gy1)) return c;             // beside the grid
+    // first cell whose upper edge is above the box's lower edge; last cell whose lower edge is below the box's upper edge
+    const int cx0 = x0 <= g.x0 ? 0 : host_cell(x0, g.x0, g.cw, g.nx), cy0 = y0 <= g.y0 ? 0 : host_cell(y0, g.y0, g.ch, g.ny);
+    int cx1 = x1 >= gx1 ? g.nx - 1 : host_cell(x1, g.x0, g.cw, g.nx), cy1 = y1 >= gy1 ? g.ny - 1 : host_cell(y1, g.y0, g.ch, g.ny);
+    if (cx1 > cx0 && cell_edge(g.x0, g.cw, cx1) >= x1) --cx1;      // x1 is exclusive: a cell that starts at x1 holds nothing of the box
+    if (cy1 > cy0 && cell_edge(g.y0, g.ch, cy1) >= y1) --cy1;
+    c.cx0 = cx0; c.ncx = cx1 - cx0 + 1; c.cy0 = cy0; c.ncy = cy1 - cy0 + 1;
+    c.use_runs = (int64_t)c.ncx * c.ncy <= MAX_RUN_CELLS;
+    // every row of the covered cells is inside the box iff the box reaches (at least) the cells' outer edges
+    c.aligned = x0 <= cell_edge(g.x0, g.cw, cx0) && x1 >= cell_edge(g.x0, g.cw, cx1 + 1) && y0 <= cell_edge(g.y0, g.ch, cy0) &&
+                y1 >= cell_edge(g.y0, g.ch, cy1 + 1);
+    for (int cy = cy0; cy <= cy1; ++cy)
+        c.n_cand += (int64_t)s->h_starts[(size_t)cy * g.nx + cx1 + 1] - (int64_t)s->h_starts[(size_t)cy * g.nx + cx0];
+    return c;
+}
+
+// rows of `sec` inside the box through a mask over ALL its rows (boxes that cover more cells than the run path takes): ascending
+// into dst (sized for the section), their number into *out_n.  A wait of its own: this is not the window loop's path.
+int subset_rows_full(same_window *w, const same_section *sec, const double *box, DevBuf &dst, int64_t *out_n) {
     same_ctx *ctx = w->ctx;
     *out_n = 0;
-    if (sec->n == 0) return ensure(ctx, dst, 4);
+    if (sec->n == 0) return SAME_OK;
     const int64_t n_words = (int64_t)grid_for(sec->n) * 4;
-    SAME_TRY(ensure(ctx, w->mask, (size_t)n_words * sizeof(unsigned long long)));
-    int32_t *scratch;
-    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)sec->n, &scratch));
-    unsigned long long *dc = as<unsigned long long>(w->counts);
-    hipLaunchKernelGGL(box_mask_kernel, dim3(grid_for(sec->n)), dim3(256), 0, ctx->stream, sec->xy, sec->n, box[0], box[1], box[2], box[3],
-                       as<unsigned long long>(w->mask));
+    Carver cv;
+    const size_t o_status = cv.take(scan::status_bytes(n_words)), o_count = cv.take(16);
+    const size_t zero_bytes = cv.off;
+    const size_t o_mask = cv.take((size_t)n_words * 8);
+    SAME_TRY(ensure(ctx, w->big_mask, cv.off));
+    char *base = static_cast<char *>(w->big_mask.p);
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(base + o_status), *dcount = reinterpret_cast<unsigned long long *>(base + o_count),
+                       *mask = reinterpret_cast<unsigned long long *>(base + o_mask);
+    SAME_TRY(ensure(ctx, dst, (size_t)sec->n * sizeof(int32_t)));
+    SAME_FILL(ctx, base, 0, zero_bytes);
+    SAME_LAUNCH(ctx, box_mask_kernel, dim3(grid_for(sec->n)), dim3(256), 0, sec->xy, sec->n, box[0], box[1], box[2], box[3], mask);
+    SAME_LAUNCH(ctx, mask_compact_kernel, dim3(scan::blocks_for(n_words)), dim3(scan::NT), 0, mask, n_words, status,
+                static_cast<int32_t *>(dst.p), dcount);
     HIP_TRY(ctx, hipGetLastError());
-    SAME_TRY(same_compact_mask_core(ctx, as<unsigned long long>(w->mask), n_words, sec->n, scratch, dc));
     unsigned long long *h = static_cast<unsigned long long *>(w->host);
-    HIP_TRY(ctx, hipMemcpyAsync(h, dc + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t n = (int64_t)h[0];
-    SAME_TRY(ensure(ctx, dst, (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
-    if (n) HIP_TRY(ctx, hipMemcpyAsync(dst.p, scratch, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    *out_n = n;
+    SAME_COPY(ctx, h, dcount, sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    SAME_WAIT(ctx);
+    *out_n = (int64_t)h[0];
     return SAME_OK;
 }
 
-int gather(same_ctx *ctx, const void *src, size_t row_bytes, const int32_t *pos, int64_t n, DevBuf &dst) {
-    SAME_TRY(ensure(ctx, dst, std::max<size_t>((size_t)n * row_bytes, 16)));
-    if (n == 0 || row_bytes == 0) return SAME_OK;
-    const int words = (int)(row_bytes / 4);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * words)), dim3(256), 0, ctx->stream, static_cast<const uint32_t *>(src), words, pos,
-                       n, as<uint32_t>(dst));
-    HIP_TRY(ctx, hipGetLastError());
-    return SAME_OK;
-}
+__global__ void set_count_kernel(unsigned long long *p, unsigned long long v) { *p = v; }
 
-void release(DevBuf &b) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
+int bin_section(same_ctx *ctx, same_section *s, double x0, double y0, double cw, double ch, bool default_grid) {
+    // a binned section is replaced as a whole: the old index goes when the new one stands
+    const int64_t n = s->n;
+    BinGrid g;
+    std::vector<unsigned> h_starts;
+    int32_t *order = nullptr;
+    unsigned *starts = nullptr;
+    int64_t n_binned = 0;
+    if (n > 0) {
+        // bounding box of the rows with finite coordinates
+        unsigned long long *dbbox = nullptr, hb[4] = {~0ull, ~0ull, 0ull, 0ull};
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dbbox), sizeof hb));
+        hipError_t e = hipMemcpyAsync(dbbox, hb, sizeof hb, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bin_bbox_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 256)), dim3(256), 0, ctx->stream, s->xy, n, dbbox);
+            e = hipMemcpyAsync(hb, dbbox, sizeof hb, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(dbbox);
+        if (e != hipSuccess) return same_fail(ctx, SAME_EIO, "section bounding box", e);
+        const bool any = hb[0] != ~0ull;
+        if (any) {
+            const double mx0 = host_key_to_double(hb[0]), my0 = host_key_to_double(hb[1]), mx1 = host_key_to_double(hb[2]),
+                         my1 = host_key_to_double(hb[3]);
+            if (default_grid) {      // about 512 rows a cell, at most 128 x 128 cells, anchored at the lower corner
+                const double side = std::sqrt((double)n / 512.0);
+                const int want = (int)std::min(128.0, std::max(1.0, std::floor(side)));
+                x0 = mx0; y0 = my0;
+                cw = (mx1 - mx0) / want; ch = (my1 - my0) / want;
+                if (!(cw > 0.0) || !std::isfinite(cw)) cw = 1.0;
+                if (!(ch > 0.0) || !std::isfinite(ch)) ch = 1.0;
+            }
+            // whole cells from the caller's origin down to the lowest row and up past the highest
+            auto fit = [](double origin, double width, double lo, double hi, double *o_out, int *n_out) -> bool {
+                double shift = origin > lo ? std::ceil((origin - lo) / width) : 0.0;
+                if (!(shift < 1e9)) return false;
+                double o = origin - shift * width;
+                while (o > lo) { shift += 1.0; o = origin - shift * width; }
+                double cells = std::floor((hi - o) / width) + 1.0;
+                if (!(cells < 1e9)) return false;
+                int nn = (int)std::max(1.0, cells);
+                while (!(cell_edge(o, width, nn) > hi)) {
+                    if (nn >= (1 << 30)) return false;
+                    ++nn;
+                }
+                *o_out = o;
+                *n_out = nn;
+                return true;
+            };
+            REQUIRE(ctx, fit(x0, cw, mx0, mx1, &g.x0, &g.nx) && fit(y0, ch, my0, my1, &g.y0, &g.ny));
+            g.cw = cw;
+            g.ch = ch;
+            REQUIRE(ctx, (int64_t)g.nx * g.ny <= MAX_GRID_CELLS);
+        }
+        const int64_t cells = (int64_t)g.nx * g.ny;
+        int64_t n_pad = 2048;
+        while (n_pad < n) n_pad <<= 1;
+        unsigned long long *key = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&key), (size_t)n_pad * 8));
+        int rc = SAME_OK;
+        e = hipMalloc(reinterpret_cast<void **>(&order), (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&starts), (size_t)(cells + 1) * sizeof(unsigned));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bin_key_kernel, dim3(grid_for(n_pad)), dim3(256), 0, ctx->stream, s->xy, n, n_pad, g, key);
+            rc = same_sort_u64_core(ctx, key, n_pad);
+            if (rc == SAME_OK) {
+                hipLaunchKernelGGL(bin_order_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, key, n, order);
+                hipLaunchKernelGGL(bin_starts_kernel, dim3(grid_for(cells + 1)), dim3(256), 0, ctx->stream, key, n, cells, starts);
+                h_starts.resize((size_t)cells + 1);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(h_starts.data(), starts, (size_t)(cells + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            }
+        }
+        (void)hipFree(key);
+        if (e != hipSuccess || rc != SAME_OK) {
+            if (order) (void)hipFree(order);
+            if (starts) (void)hipFree(starts);
+            return rc != SAME_OK ? rc : same_fail(ctx, e == hipErrorOutOfMemory ? SAME_ENOMEM : SAME_EIO, "section grid", e);
+        }
+        n_binned = (int64_t)h_starts[(size_t)cells];
+    } else {
+        h_starts.assign(2, 0u);
+    }
+    if (s->order) (void)hipFree(s->order);
+    if (s->starts) (void)hipFree(s->starts);
+    s->grid = g;
+    s->order = order;
+    s->starts = starts;
+    s->h_starts.swap(h_starts);
+    s->n_binned = n_binned;
+    return SAME_OK;
 }
 
 }  // namespace
@@ -392,18 +838,29 @@ int same_section_create(same_ctx *ctx, const double *xy, const double *types, in
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return SAME_OK;
+    return bin_section(ctx, s, 0.0, 0.0, 0.0, 0.0, true);     // a grid of its own until the caller names the windows' (same_section_bin)
+}
+
+int same_section_bin(same_section *s, double x0, double y0, double cell_w, double cell_h) {
+    if (!s) return SAME_EINVAL;
+    same_ctx *ctx = s->ctx;
+    REQUIRE(ctx, std::isfinite(x0) && std::isfinite(y0) && cell_w > 0.0 && cell_h > 0.0 && std::isfinite(cell_w) && std::isfinite(cell_h));
+    SAME_TRY(same_use(ctx));
+    return bin_section(ctx, s, x0, y0, cell_w, cell_h, false);
 }
 
 void same_section_destroy(same_section *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
+    (void)hipDeviceSynchronize();                 // windows of other contexts may still be reading the section
+    for (auto &e : s->knn) same_knn_index_destroy(e.second);
     if (s->xy_c && s->xy_c != s->xy) (void)hipFree(s->xy_c);
     if (s->xy) (void)hipFree(s->xy);
     if (s->types_c) (void)hipFree(s->types_c);
     if (s->size) (void)hipFree(s->size);
     if (s->type_id) (void)hipFree(s->type_id);
+    if (s->order) (void)hipFree(s->order);
+    if (s->starts) (void)hipFree(s->starts);
     delete s;
 }
 
@@ -415,7 +872,6 @@ int same_window_create(same_ctx *ctx, same_window **out) {
     if (!w) return SAME_ENOMEM;
     w->ctx = ctx;
     *out = w;
-    SAME_TRY(ensure(ctx, w->counts, 16 * sizeof(unsigned long long)));
     SAME_TRY(ensure_host(w, 1 << 16));
     return SAME_OK;
 }
@@ -424,13 +880,7 @@ void same_window_destroy(same_window *w) {
     if (!w) return;
     (void)hipSetDevice(w->ctx->device);
     (void)hipStreamSynchronize(w->ctx->stream);
-    DevBuf *all[] = {&w->mask, &w->counts, &w->rows_m, &w->rows_r, &w->axy_w, &w->rxy_w, &w->axyc_w, &w->rxyc_w, &w->A_w, &w->R_w, &w->size_w,
-                     &w->idx, &w->cnt, &w->cost, &w->a_off, &w->p_off, &w->ua, &w->rows_ua, &w->axy_c, &w->size_c, &w->pairs, &w->cost64,
-                     &w->type_w, &w->type_c, &w->raw, &w->cls, &w->perim, &w->maxcos, &w->kmask, &w->has_kept, &w->any_valid, &w->best_p,
-                     &w->best_t, &w->first_v, &w->nmask, &w->nlist, &w->klist, &w->tris, &w->sign, &w->weight, &w->rowmin, &w->prefer,
-                     &w->pair_of_row, &w->match, &w->match_row, &w->oflag, &w->omask, &w->edge, &w->tflag, &w->pflag, &w->before, &w->after,
-                     &w->m3, &w->flipped};
-    for (DevBuf *b : all) release(*b);
+    for (DevBuf *b : {&w->stage, &w->filter, &w->finish, &w->tris, &w->big_mask, &w->full_m, &w->full_r}) release(*b);
     if (w->host) (void)hipHostFree(w->host);
     delete w;
 }
@@ -443,82 +893,127 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     REQUIRE(ctx, mov->T == ref->T && mov->cost_f32 == ref->cost_f32 && k >= 1 && k <= SAME_MAX_KNN && radius >= 0.0);
     SAME_TRY(same_use(ctx));
     w->staged = w->finished = w->filtered = 0;
+    w->mov = mov;
+    w->ref = ref;
     w->has_type = mov->type_id != nullptr;
     w->cost_f32 = mov->cost_f32;
     w->k = k;
-    w->n_ua = w->P = w->Tr = 0;
+    w->n_m = w->n_r = w->n_ua = w->P = w->Tr = 0;
     for (int q = 0; q < 4; ++q) out_counts[q] = 0;
-    SAME_TRY(subset_rows(w, mov, box, w->rows_m, &w->n_m));
-    SAME_TRY(subset_rows(w, ref, box, w->rows_r, &w->n_r));
-    const int64_t n_m = w->n_m, n_r = w->n_r;
-    out_counts[0] = n_m;
-    out_counts[1] = n_r;
-    w->staged = 1;
-    if (n_m == 0 || n_r == 0) return SAME_OK;      // no pairs: the caller raises what run_same raises (src/same.py:1003)
-    REQUIRE(ctx, n_m * (int64_t)k < ((int64_t)1 << 31) - 1);   // pair offsets are 32-bit
+    const same_knn_index *ix = nullptr;
+    SAME_TRY(knn_index_for(ctx, ref, radius, &ix));
+
+    // the candidates: rows of the cells the box covers (their number is known here), or a mask over the whole section
+    Cover cm = cover_of(mov, box), cr = cover_of(ref, box);
+    int64_t cap_m = cm.n_cand, cap_r = cr.n_cand;
+    if (!cm.use_runs) SAME_TRY(subset_rows_full(w, mov, box, w->full_m, &cap_m));     // rare: a box over more than MAX_RUN_CELLS cells
+    if (!cr.use_runs) SAME_TRY(subset_rows_full(w, ref, box, w->full_r, &cap_r));
+    REQUIRE(ctx, cap_m * (int64_t)k < ((int64_t)1 << 31) - 1 && cap_r < ((int64_t)1 << 31) - 1);   // offsets and scan totals are 31-bit
+    w->cap_m = cap_m;
+    w->cap_r = cap_r;
     const int T = mov->T;
     const size_t cs = w->cost_f32 ? sizeof(float) : sizeof(double);
-    const int32_t *rm = as<int32_t>(w->rows_m), *rr = as<int32_t>(w->rows_r);
-    SAME_TRY(gather(ctx, mov->xy, 2 * sizeof(double), rm, n_m, w->axy_w));
-    SAME_TRY(gather(ctx, ref->xy, 2 * sizeof(double), rr, n_r, w->rxy_w));
-    SAME_TRY(gather(ctx, mov->size, sizeof(double), rm, n_m, w->size_w));
-    if (w->has_type) SAME_TRY(gather(ctx, mov->type_id, sizeof(int32_t), rm, n_m, w->type_w));
-    SAME_TRY(ensure(ctx, w->type_c, (size_t)n_m * sizeof(int32_t)));
-    SAME_TRY(gather(ctx, mov->types_c, (size_t)T * cs, rm, n_m, w->A_w));
-    SAME_TRY(gather(ctx, ref->types_c, (size_t)T * cs, rr, n_r, w->R_w));
-    if (w->cost_f32) {
-        SAME_TRY(gather(ctx, mov->xy_c, 2 * cs, rm, n_m, w->axyc_w));
-        SAME_TRY(gather(ctx, ref->xy_c, 2 * cs, rr, n_r, w->rxyc_w));
+    const size_t slots = (size_t)cap_m * k, cm1 = (size_t)cap_m + 1;
+    const bool compact_m = cm.use_runs && !cm.aligned && cap_m > 0, compact_r = cr.use_runs && !cr.aligned && cap_r > 0;
+    // layout: [scan words | counts | kept XY | kept rows] (zeroed up to the counts; copied back from the counts on) | the rest
+    Carver cv;
+    const size_t st_scatter = scan::status_bytes(cap_m), st_cm = scan::status_bytes(cap_m), st_cr = scan::status_bytes(cap_r);
+    const size_t o_st_scatter = cv.take(st_scatter), o_st_cm = cv.take(st_cm), o_st_cr = cv.take(st_cr);
+    const size_t o_counts = cv.off;
+    cv.off += 64;
+    const size_t o_axy_c = cv.off;
+    cv.off += (size_t)cap_m * 2 * sizeof(double);
+    const size_t o_rows_ua = cv.off;
+    cv.off += (size_t)cap_m * sizeof(int32_t);
+    const size_t back_bytes = cv.off - o_counts;
+    cv.off = (cv.off + 255) & ~size_t(255);
+    const size_t o_merged_m = cv.take((size_t)cap_m * 4), o_merged_r = cv.take((size_t)cap_r * 4);
+    const size_t o_rows_m = cv.take((size_t)cap_m * 4), o_rows_r = cv.take((size_t)cap_r * 4);
+    const size_t o_idx = cv.take(slots * 4), o_cnt = cv.take((size_t)cap_m * 4), o_cost = cv.take(slots * cs);
+    const size_t o_ua = cv.take((size_t)cap_m * 4), o_type_c = cv.take((size_t)cap_m * 4), o_size_c = cv.take((size_t)cap_m * 8);
+    const size_t o_prow = cv.take(cm1 * 4), o_pairs = cv.take(slots * 8), o_jsec = cv.take(slots * 4), o_cost64 = cv.take(slots * 8);
+    SAME_TRY(ensure(ctx, w->stage, cv.off));
+    // everything the three calls of this window copy back fits the pinned block from now on (it must not move between them)
+    w->host_finish_off = (back_bytes + 255) & ~size_t(255);
+    w->host_filter_off = w->host_finish_off + ((SAME_GREEDY_BATCH_MAX * 8 + 64 + (size_t)cap_m * 5 + 64 + 255) & ~size_t(255));
+    SAME_TRY(ensure_host(w, w->host_filter_off + 256));
+    char *base = static_cast<char *>(w->stage.p);
+    auto at = [&](size_t off) { return base + off; };
+    w->counts = reinterpret_cast<unsigned long long *>(at(o_counts));
+    w->axy_c = reinterpret_cast<double *>(at(o_axy_c));
+    w->rows_ua = reinterpret_cast<int32_t *>(at(o_rows_ua));
+    uint32_t *merged_m = reinterpret_cast<uint32_t *>(at(o_merged_m)), *merged_r = reinterpret_cast<uint32_t *>(at(o_merged_r));
+    // aligned boxes: the merged list IS the row list; whole-section path: its own list is copied in
+    w->rows_m = reinterpret_cast<int32_t *>(compact_m || !cm.use_runs ? at(o_rows_m) : at(o_merged_m));
+    w->rows_r = reinterpret_cast<int32_t *>(compact_r || !cr.use_runs ? at(o_rows_r) : at(o_merged_r));
+    w->idx = reinterpret_cast<int32_t *>(at(o_idx));
+    w->cnt = reinterpret_cast<int32_t *>(at(o_cnt));
+    void *cost = at(o_cost);
+    w->ua = reinterpret_cast<int32_t *>(at(o_ua));
+    w->type_c = reinterpret_cast<int32_t *>(at(o_type_c));
+    w->size_c = reinterpret_cast<double *>(at(o_size_c));
+    w->prow = reinterpret_cast<int32_t *>(at(o_prow));
+    w->pairs = reinterpret_cast<int32_t *>(at(o_pairs));
+    w->jsec = reinterpret_cast<int32_t *>(at(o_jsec));
+    w->cost64 = reinterpret_cast<double *>(at(o_cost64));
+    unsigned long long *dc = w->counts;
+
+    SAME_FILL(ctx, base, 0, o_counts + 64);       // scan words + counts: ONE fill
+    if (!cm.use_runs && cap_m) {                  // the whole-section path's list and count take their places
+        SAME_COPY(ctx, w->rows_m, w->full_m.p, (size_t)cap_m * 4, hipMemcpyDeviceToDevice);
+        SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, dc, (unsigned long long)cap_m);
     }
-    const size_t slots = (size_t)n_m * k;
-    SAME_TRY(ensure(ctx, w->idx, slots * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->cnt, (size_t)n_m * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->cost, slots * cs));
-    SAME_TRY(same_knn_prune_dev(ctx, as<double>(w->axy_w), as<double>(w->rxy_w), n_r, 0, n_m, radius, k, as<int32_t>(w->idx), nullptr,
-                                as<int32_t>(w->cnt)));
-    if (w->cost_f32)
-        SAME_TRY(same_padded_cost_f32_dev(ctx, as<float>(w->A_w), as<float>(w->R_w), T, as<float>(w->axyc_w), as<float>(w->rxyc_w), 0, n_m, k,
-                                          as<int32_t>(w->idx), (float)dist_ct_coeff, as<float>(w->cost)));
-    else
-        SAME_TRY(same_padded_cost_f64_dev(ctx, as<double>(w->A_w), as<double>(w->R_w), T, as<double>(w->axy_w), as<double>(w->rxy_w), 0, n_m, k,
-                                          as<int32_t>(w->idx), dist_ct_coeff, as<double>(w->cost)));
-    SAME_TRY(ensure(ctx, w->a_off, (size_t)n_m * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->p_off, (size_t)n_m * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->ua, (size_t)n_m * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->rows_ua, (size_t)n_m * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->axy_c, (size_t)n_m * 2 * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->size_c, (size_t)n_m * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->pairs, slots * 2 * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->cost64, slots * sizeof(double)));
-    unsigned long long *dc = as<unsigned long long>(w->counts);
-    hipLaunchKernelGGL(window_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, as<int32_t>(w->cnt), n_m, as<int32_t>(w->a_off),
-                       as<int32_t>(w->p_off), dc);
-    if (w->cost_f32)
-        hipLaunchKernelGGL(window_scatter_kernel<float>, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, as<int32_t>(w->idx), as<float>(w->cost),
-                           as<int32_t>(w->cnt), n_m, k, as<int32_t>(w->a_off), as<int32_t>(w->p_off), rm, as<double>(w->axy_w),
-                           as<double>(w->size_w), w->has_type ? as<int32_t>(w->type_w) : nullptr, as<int32_t>(w->ua), as<int32_t>(w->rows_ua),
-                           as<double>(w->axy_c), as<double>(w->size_c), as<int32_t>(w->type_c), as<int32_t>(w->pairs), as<double>(w->cost64));
-    else
-        hipLaunchKernelGGL(window_scatter_kernel<double>, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, as<int32_t>(w->idx), as<double>(w->cost),
-                           as<int32_t>(w->cnt), n_m, k, as<int32_t>(w->a_off), as<int32_t>(w->p_off), rm, as<double>(w->axy_w),
-                           as<double>(w->size_w), w->has_type ? as<int32_t>(w->type_w) : nullptr, as<int32_t>(w->ua), as<int32_t>(w->rows_ua),
-                           as<double>(w->axy_c), as<double>(w->size_c), as<int32_t>(w->type_c), as<int32_t>(w->pairs), as<double>(w->cost64));
+    if (!cr.use_runs && cap_r) {
+        SAME_COPY(ctx, w->rows_r, w->full_r.p, (size_t)cap_r * 4, hipMemcpyDeviceToDevice);
+        SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, dc + 1, (unsigned long long)cap_r);
+    }
+    {
+        RunDesc dm{}, dr{};
+        unsigned bm = 0, br = 0;
+        if (cm.use_runs && cap_m) {
+            dm = RunDesc{mov->order, mov->starts, mov->xy, mov->grid.nx, cm.cx0, cm.ncx, cm.cy0, cm.ncy, (int)cap_m, cm.aligned ? 1 : 0, merged_m, dc};
+            bm = grid_for(cap_m);
+        }
+        if (cr.use_runs && cap_r) {
+            dr = RunDesc{ref->order, ref->starts, ref->xy, ref->grid.nx, cr.cx0, cr.ncx, cr.cy0, cr.ncy, (int)cap_r, cr.aligned ? 1 : 0, merged_r, dc + 1};
+            br = grid_for(cap_r);
+        }
+        if (bm + br) SAME_LAUNCH(ctx, window_rows_kernel, dim3(bm + br), dim3(256), 0, dm, dr, bm, box[0], box[1], box[2], box[3]);
+        if (compact_m || compact_r) {
+            const RowsCompact c_m{merged_m, compact_m ? (int)cap_m : 0, w->rows_m, reinterpret_cast<unsigned long long *>(at(o_st_cm)), dc};
+            const RowsCompact c_r{merged_r, compact_r ? (int)cap_r : 0, w->rows_r, reinterpret_cast<unsigned long long *>(at(o_st_cr)), dc + 1};
+            const unsigned b_m = compact_m ? scan::blocks_for(cap_m) : 0, b_r = compact_r ? scan::blocks_for(cap_r) : 0;
+            SAME_LAUNCH(ctx, rows_compact_kernel, dim3(b_m + b_r), dim3(scan::NT), 0, c_m, c_r, b_m);
+        }
+    }
+    if (cap_m) {
+        SAME_TRY(same_knn_window_core(ctx, ix, mov->xy, w->rows_m, dc, cap_m, w->rows_r, dc + 1, box, k, w->idx, w->cnt));
+        SAME_TRY(same_padded_cost_window_core(ctx, w->cost_f32, mov->types_c, ref->types_c, T, mov->xy_c, ref->xy_c, w->rows_m, dc, cap_m, k,
+                                              w->idx, dist_ct_coeff, cost));
+        const ScatterArgs sa{w->idx, cost, w->cnt, w->rows_m, w->rows_r, mov->xy, mov->size, mov->type_id,
+                             reinterpret_cast<unsigned long long *>(at(o_st_scatter)), dc, w->ua, w->rows_ua, w->type_c, w->prow, w->pairs, w->jsec,
+                             w->axy_c, w->size_c, w->cost64, k};
+        if (w->cost_f32)
+            SAME_LAUNCH(ctx, window_scatter_kernel<float>, dim3(scan::blocks_for(cap_m)), dim3(scan::NT), 0, sa);
+        else
+            SAME_LAUNCH(ctx, window_scatter_kernel<double>, dim3(scan::blocks_for(cap_m)), dim3(scan::NT), 0, sa);
+    }
     HIP_TRY(ctx, hipGetLastError());
-    // one read-back: the two totals, then the kept aligned rows and their XY at the capacity n_m (n_ua <= n_m is not known yet)
-    const size_t head = 64;
-    SAME_TRY(ensure_host(w, host_need(n_m)));
-    char *h = static_cast<char *>(w->host);
-    HIP_TRY(ctx, hipMemcpyAsync(h, dc + 2, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(h + head, w->axy_c.p, (size_t)n_m * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(h + head + (size_t)n_m * 2 * sizeof(double), w->rows_ua.p, (size_t)n_m * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long *tot = reinterpret_cast<const unsigned long long *>(h);
-    w->n_ua = (int64_t)tot[0];
-    w->P = (int64_t)tot[1];
+    // ONE copy back: the four counts, then the kept aligned rows' XY and section rows at the capacity cap_m
+    char *hb = static_cast<char *>(w->host);
+    SAME_COPY(ctx, hb, dc, back_bytes, hipMemcpyDeviceToHost);
+    SAME_WAIT(ctx);
+    const unsigned long long *tot = reinterpret_cast<const unsigned long long *>(hb);
+    w->n_m = (int64_t)tot[0];
+    w->n_r = (int64_t)tot[1];
+    w->n_ua = (int64_t)tot[2];
+    w->P = (int64_t)tot[3];
+    REQUIRE(ctx, w->n_m <= cap_m && w->n_r <= cap_r && w->n_ua <= w->n_m && w->P <= (int64_t)slots);
+    out_counts[0] = w->n_m;
+    out_counts[1] = w->n_r;
     out_counts[2] = w->n_ua;
     out_counts[3] = w->P;
-    w->staged = 2;
+    w->staged = (w->n_m && w->n_r) ? 2 : 1;      // no pairs possible: the caller raises what run_same raises (src/same.py:1003)
     return SAME_OK;
 }
 
@@ -535,21 +1030,21 @@ int same_window_fetch(same_window *w, int what, void *out, int64_t bytes) {
     const bool full = w->staged == 2;
     switch (what) {
     case SAME_WINDOW_ALIGNED_XY: want = n_ua * 16; host = h + 64; REQUIRE(ctx, full || n_ua == 0); break;
-    case SAME_WINDOW_ALIGNED_ROWS: want = n_ua * 4; host = h + 64 + (size_t)n_m * 16; REQUIRE(ctx, full || n_ua == 0); break;
-    case SAME_WINDOW_ROWS_M: want = n_m * 4; dev = w->rows_m.p; break;
-    case SAME_WINDOW_ROWS_R: want = n_r * 4; dev = w->rows_r.p; break;
-    case SAME_WINDOW_PAIRS: want = P * 8; dev = w->pairs.p; break;
-    case SAME_WINDOW_COSTS: want = P * 8; dev = w->cost64.p; break;
-    case SAME_WINDOW_KEPT: want = n_ua * 4; dev = w->ua.p; break;
-    case SAME_WINDOW_SIGNS: want = Tr; dev = w->sign.p; REQUIRE(ctx, w->finished); break;
-    case SAME_WINDOW_WEIGHTS: want = Tr * 8; dev = w->weight.p; REQUIRE(ctx, w->finished); break;
-    case SAME_WINDOW_MATCH: want = n_ua * 4; dev = w->match.p; REQUIRE(ctx, w->finished); break;
+    case SAME_WINDOW_ALIGNED_ROWS: want = n_ua * 4; host = h + 64 + (size_t)w->cap_m * 16; REQUIRE(ctx, full || n_ua == 0); break;
+    case SAME_WINDOW_ROWS_M: want = n_m * 4; dev = w->rows_m; break;
+    case SAME_WINDOW_ROWS_R: want = n_r * 4; dev = w->rows_r; break;
+    case SAME_WINDOW_PAIRS: want = P * 8; dev = w->pairs; break;
+    case SAME_WINDOW_COSTS: want = P * 8; dev = w->cost64; break;
+    case SAME_WINDOW_KEPT: want = n_ua * 4; dev = w->ua; break;
+    case SAME_WINDOW_SIGNS: want = Tr; dev = w->sign; REQUIRE(ctx, w->finished); break;
+    case SAME_WINDOW_WEIGHTS: want = Tr * 8; dev = w->weight; REQUIRE(ctx, w->finished); break;
+    case SAME_WINDOW_MATCH: want = n_ua * 4; dev = w->match_loc; REQUIRE(ctx, w->finished); break;
     case SAME_WINDOW_TRIANGLES: want = Tr * 12; dev = w->tris.p; REQUIRE(ctx, w->finished || w->filtered); break;
     default: REQUIRE(ctx, !"unknown same_window_fetch selector");
     }
     REQUIRE(ctx, bytes == want);
     if (want == 0) return SAME_OK;
-    if (host) {                                   // already on the host since the stage call's own read-back
+    if (host) {                                   // already on the host since the stage call's own copy
         memcpy(out, host, (size_t)want);
         return SAME_OK;
     }
@@ -557,6 +1052,188 @@ int same_window_fetch(same_window *w, int what, void *out, int64_t bytes) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// ---- the filter and the finish as enqueue-only halves + their read-backs, so that the two calls can also run as one ----------
+struct FilterPlan {
+    unsigned long long *counters = nullptr;   // [4] FC_*
+    bool readd = false;
+};
+
+int enqueue_filter(same_window *w, const int32_t *simplices, int64_t Tr, double radius, int angle_enabled, double cos_thr, double near_tol,
+                   int ignore_same_type, int ensure_min_triangle_per_node, FilterPlan *plan) {
+    same_ctx *ctx = w->ctx;
+    const int64_t n = w->n_ua;
+    const bool use_type = ignore_same_type && w->has_type;
+    plan->readd = use_type && ensure_min_triangle_per_node;
+    Carver cv;   // zeroed head: scan words, counters, vertex marks, inverted minima
+    const size_t st_keep = scan::status_bytes(Tr), st_own = scan::status_bytes(n);
+    const size_t o_st_keep = cv.take(st_keep), o_st_own = cv.take(st_own), o_counters = cv.take(64), o_has_kept = cv.take((size_t)n),
+                 o_any_valid = cv.take((size_t)n), o_best_p = cv.take((size_t)n * 8), o_best_t = cv.take((size_t)n * 4),
+                 o_first_v = cv.take((size_t)Tr * 4);
+    const size_t zero_bytes = cv.off;
+    const size_t o_raw = cv.take((size_t)Tr * 12), o_cls = cv.take((size_t)Tr), o_perim = cv.take((size_t)Tr * 8), o_klist = cv.take((size_t)Tr * 4),
+                 o_nlist = cv.take((size_t)n * 4);
+    SAME_TRY(ensure(ctx, w->filter, cv.off));
+    SAME_TRY(ensure(ctx, w->tris, (size_t)std::max<int64_t>(Tr, 1) * 12));
+    char *base = static_cast<char *>(w->filter.p);
+    auto at = [&](size_t off) { return base + off; };
+    unsigned long long *dc = reinterpret_cast<unsigned long long *>(at(o_counters));
+    plan->counters = dc;
+    uint8_t *has_kept = reinterpret_cast<uint8_t *>(at(o_has_kept)), *any_valid = reinterpret_cast<uint8_t *>(at(o_any_valid));
+    unsigned long long *best_p = reinterpret_cast<unsigned long long *>(at(o_best_p));
+    unsigned *best_t = reinterpret_cast<unsigned *>(at(o_best_t)), *first_v = reinterpret_cast<unsigned *>(at(o_first_v));
+    int32_t *raw = reinterpret_cast<int32_t *>(at(o_raw)), *klist = reinterpret_cast<int32_t *>(at(o_klist)), *nlist = reinterpret_cast<int32_t *>(at(o_nlist));
+    uint8_t *cls = reinterpret_cast<uint8_t *>(at(o_cls));
+    double *perim = reinterpret_cast<double *>(at(o_perim));
+    SAME_FILL(ctx, base, 0, zero_bytes);
+    SAME_COPY(ctx, raw, simplices, (size_t)Tr * 12, hipMemcpyHostToDevice);
+    const int near_enabled = angle_enabled && cos_thr == cos_thr && cos_thr - cos_thr == 0.0;       // a finite threshold
+    SAME_LAUNCH(ctx, filter_classify_kernel, dim3(grid_for(Tr)), dim3(256), 0, w->axy_c, raw, Tr, radius, angle_enabled, cos_thr,
+                use_type ? w->type_c : nullptr, near_enabled, near_tol, cls, perim, has_kept, any_valid, dc);
+    SAME_LAUNCH(ctx, filter_keep_kernel, dim3(scan::blocks_for(Tr)), dim3(scan::NT), 0, cls, Tr, reinterpret_cast<unsigned long long *>(at(o_st_keep)),
+                klist, dc);
+    if (plan->readd) {
+        SAME_LAUNCH(ctx, filter_best_perim_kernel, dim3(grid_for(Tr)), dim3(256), 0, cls, perim, raw, Tr, best_p);
+        SAME_LAUNCH(ctx, filter_best_tri_kernel, dim3(grid_for(Tr)), dim3(256), 0, cls, perim, raw, Tr, best_p, best_t);
+        SAME_LAUNCH(ctx, filter_first_node_kernel, dim3(grid_for(n)), dim3(256), 0, has_kept, any_valid, best_t, n, first_v);
+        SAME_LAUNCH(ctx, filter_owner_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, has_kept, any_valid, best_t, first_v, n,
+                    reinterpret_cast<unsigned long long *>(at(o_st_own)), nlist, dc);
+    }
+    SAME_LAUNCH(ctx, filter_emit_kernel, dim3(grid_for(Tr)), dim3(256), 0, raw, klist, nlist, best_t, dc, static_cast<int32_t *>(w->tris.p));
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+struct FinishPlan {
+    unsigned long long *zero = nullptr;       // head of the finish buffer: [sel | counters | point flags (padded) | matched rows]
+    size_t zero_bytes = 0, back_off = 0, back_bytes = 0, o_counters = 0, o_pflag = 0, o_match_row = 0;
+    same_greedy_state gs;
+    int32_t *match_pair = nullptr, *match_row = nullptr;
+    uint8_t *pflag = nullptr;
+    unsigned long long *counters = nullptr;
+    int64_t cap_tr = 0;
+    const unsigned long long *dTr = nullptr;
+};
+
+int enqueue_tail(same_window *w, FinishPlan *p) {
+    same_ctx *ctx = w->ctx;
+    const int64_t n = w->n_ua;
+    SAME_LAUNCH(ctx, match_rows_kernel, dim3(grid_for(n)), dim3(256), 0, p->match_pair, w->pairs, w->jsec, w->counts + 2, w->match_loc, p->match_row,
+                p->pflag, p->counters);
+    if (p->cap_tr)
+        SAME_LAUNCH(ctx, window_sweeps_kernel, dim3(grid_for(p->cap_tr)), dim3(256), 0, static_cast<const int32_t *>(w->tris.p), p->cap_tr, p->dTr,
+                    w->axy_c, w->size_c, w->ref->xy, p->match_row, w->sign, w->weight, p->pflag, p->counters);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+// cap_tr: the number of triangles, or (dTr != null) the bound the launch is sized by with the number itself on the device
+int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, const unsigned long long *dTr, double no_match_penalty, FinishPlan *p) {
+    same_ctx *ctx = w->ctx;
+    const int64_t n = w->n_ua, P = w->P, n_ends = n + w->n_r;
+    Carver cv;
+    const size_t o_used = cv.take((size_t)n_ends), o_key = cv.take((size_t)n_ends * 16), o_idx = cv.take((size_t)n_ends * 8);
+    const size_t o_sel = cv.take(SAME_GREEDY_BATCH_MAX * 8);
+    const size_t o_counters = cv.off;
+    cv.off += 64;
+    const size_t o_pflag = cv.off;
+    cv.off += ((size_t)n + 7) & ~size_t(7);
+    const size_t zero_bytes = (cv.off + 15) & ~size_t(15);
+    cv.off = zero_bytes;
+    const size_t o_match_row = cv.off;
+    cv.off += (size_t)n * 4;
+    const size_t back_end = cv.off;
+    cv.off = (cv.off + 255) & ~size_t(255);
+    const size_t tt = (size_t)std::max<int64_t>(cap_tr, 1);
+    const size_t o_alive = cv.take((size_t)std::max<int64_t>(P, 1)), o_match_pair = cv.take((size_t)n * 4), o_match_loc = cv.take((size_t)n * 4),
+                 o_sign = cv.take(tt), o_weight = cv.take(tt * 8);
+    SAME_TRY(ensure(ctx, w->finish, cv.off));
+    SAME_TRY(ensure(ctx, w->tris, tt * 12));
+    char *base = static_cast<char *>(w->finish.p);
+    auto at = [&](size_t off) { return base + off; };
+    p->zero = reinterpret_cast<unsigned long long *>(base);
+    p->zero_bytes = zero_bytes;
+    p->back_off = o_sel;
+    p->back_bytes = back_end - o_sel;
+    p->o_counters = o_counters - o_sel;
+    p->o_pflag = o_pflag - o_sel;
+    p->o_match_row = o_match_row - o_sel;
+    p->gs.alive = reinterpret_cast<uint8_t *>(at(o_alive));
+    p->gs.used = reinterpret_cast<uint8_t *>(at(o_used));
+    p->gs.key[0] = reinterpret_cast<unsigned long long *>(at(o_key));
+    p->gs.key[1] = p->gs.key[0] + n_ends;
+    p->gs.idx[0] = reinterpret_cast<unsigned *>(at(o_idx));
+    p->gs.idx[1] = p->gs.idx[0] + n_ends;
+    p->gs.sel = reinterpret_cast<unsigned long long *>(at(o_sel));
+    p->counters = reinterpret_cast<unsigned long long *>(at(o_counters));
+    p->pflag = reinterpret_cast<uint8_t *>(at(o_pflag));
+    p->match_row = reinterpret_cast<int32_t *>(at(o_match_row));
+    p->match_pair = reinterpret_cast<int32_t *>(at(o_match_pair));
+    w->match_loc = reinterpret_cast<int32_t *>(at(o_match_loc));
+    w->sign = reinterpret_cast<int8_t *>(at(o_sign));
+    w->weight = reinterpret_cast<double *>(at(o_weight));
+    p->cap_tr = cap_tr;
+    p->dTr = dTr;
+    REQUIRE(ctx, w->host_finish_off + p->back_bytes <= w->host_filter_off);   // sized by the stage call
+    SAME_FILL(ctx, base, 0, zero_bytes);
+    if (host_tris && cap_tr) SAME_COPY(ctx, w->tris.p, host_tris, (size_t)cap_tr * 12, hipMemcpyHostToDevice);
+    // greedy MIP start: per-row minimum, rows that beat their penalty, the scan's matching (one pair per aligned row)
+    SAME_LAUNCH(ctx, row_prefer_kernel, dim3(grid_for(n)), dim3(256), 0, w->prow, w->cost64, w->size_c, w->counts + 2, no_match_penalty, p->gs.alive,
+                p->match_pair);
+    if (P) SAME_TRY(same_greedy_rounds_core(ctx, w->pairs, w->cost64, P, nullptr, n, w->n_r, p->gs, p->match_pair, 0, 4));
+    return enqueue_tail(w, p);
+}
+
+// the finish call's answers: one copy, one wait; more greedy rounds (and the tail again) when four did not settle the matching
+int collect_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats) {
+    same_ctx *ctx = w->ctx;
+    const int64_t n = w->n_ua, P = w->P;
+    char *h = static_cast<char *>(w->host) + w->host_finish_off;
+    const char *dsel = reinterpret_cast<const char *>(p->gs.sel);
+    SAME_COPY(ctx, h, dsel, p->back_bytes, hipMemcpyDeviceToHost);
+    SAME_WAIT(ctx);
+    const unsigned long long *sel = reinterpret_cast<const unsigned long long *>(h);
+    int rounds = 0;
+    if (P) {
+        int q = 0;
+        while (q < 4 && sel[q] != 0) ++q;
+        rounds = q;
+        if (q == 4) {             // a long chain of pre-empting pairs: keep going in growing batches, then redo the tail
+            int batch = 4;
+            for (;;) {
+                REQUIRE(ctx, rounds <= P + 1);
+                SAME_FILL(ctx, p->gs.sel, 0, (size_t)batch * 8);
+                SAME_TRY(same_greedy_rounds_core(ctx, w->pairs, w->cost64, P, nullptr, n, w->n_r, p->gs, p->match_pair, rounds, batch));
+                SAME_COPY(ctx, h, dsel, (size_t)batch * 8, hipMemcpyDeviceToHost);
+                SAME_WAIT(ctx);
+                ++ctx->stats[SAME_STAT_GREEDY_READBACKS];
+                q = 0;
+                while (q < batch && sel[q] != 0) ++q;
+                rounds += q;
+                if (q < batch) break;
+                if (batch < SAME_GREEDY_BATCH_MAX) batch *= 2;
+            }
+            SAME_FILL(ctx, p->counters, 0, 64);
+            SAME_TRY(enqueue_tail(w, p));
+            SAME_COPY(ctx, h, dsel, p->back_bytes, hipMemcpyDeviceToHost);
+            SAME_WAIT(ctx);
+        }
+    }
+    const unsigned long long *c = reinterpret_cast<const unsigned long long *>(h + p->o_counters);
+    for (int q = 0; q < 8; ++q) out_stats[q] = (int64_t)c[q];
+    out_stats[SC_ROUNDS] = rounds;
+    memcpy(out_match_row, h + p->o_match_row, (size_t)n * sizeof(int32_t));
+    memcpy(out_point_flag, h + p->o_pflag, (size_t)n);
+    return SAME_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int same_window_filter(same_window *w, const int32_t *simplices, int64_t n_simplices, double radius, int angle_enabled, double cos_thr,
                        double near_tol, int ignore_same_type, int ensure_min_triangle_per_node, int64_t *out_counts) {
@@ -570,64 +1247,16 @@ int same_window_filter(same_window *w, const int32_t *simplices, int64_t n_simpl
     w->filtered = w->finished = 0;
     w->Tr = 0;
     if (Tr == 0 || n == 0) { w->filtered = 1; return SAME_OK; }
-    const bool use_type = ignore_same_type && w->has_type;
-    const int64_t t_words = (int64_t)grid_for(Tr) * 4, n_words = (int64_t)grid_for(n) * 4;
-    SAME_TRY(ensure(ctx, w->raw, (size_t)Tr * 3 * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->tris, (size_t)Tr * 3 * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->cls, (size_t)Tr));
-    SAME_TRY(ensure(ctx, w->perim, (size_t)Tr * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->maxcos, (size_t)Tr * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->kmask, (size_t)t_words * sizeof(unsigned long long)));
-    SAME_TRY(ensure(ctx, w->klist, (size_t)Tr * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->first_v, (size_t)Tr * sizeof(unsigned)));
-    SAME_TRY(ensure(ctx, w->has_kept, (size_t)n));
-    SAME_TRY(ensure(ctx, w->any_valid, (size_t)n));
-    SAME_TRY(ensure(ctx, w->best_p, (size_t)n * sizeof(unsigned long long)));
-    SAME_TRY(ensure(ctx, w->best_t, (size_t)n * sizeof(unsigned)));
-    SAME_TRY(ensure(ctx, w->nmask, (size_t)n_words * sizeof(unsigned long long)));
-    SAME_TRY(ensure(ctx, w->nlist, (size_t)n * sizeof(int32_t)));
-    unsigned long long *dc = as<unsigned long long>(w->counts);   // [1] kept (class 0), [2] near the threshold, [5] added back
-    HIP_TRY(ctx, hipMemsetAsync(dc, 0, 8 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(w->raw.p, simplices, (size_t)Tr * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    SAME_TRY(same_tri_classify_dev(ctx, as<double>(w->axy_c), as<int32_t>(w->raw), Tr, radius, angle_enabled, cos_thr,
-                                   use_type ? as<int32_t>(w->type_c) : nullptr, as<uint8_t>(w->cls), as<double>(w->perim), as<double>(w->maxcos)));
-    HIP_TRY(ctx, hipMemsetAsync(w->has_kept.p, 0, (size_t)n, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(w->any_valid.p, 0, (size_t)n, ctx->stream));
-    const int near_enabled = angle_enabled && cos_thr == cos_thr && cos_thr - cos_thr == 0.0;       // a finite threshold
-    hipLaunchKernelGGL(filter_mark_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->cls), as<double>(w->maxcos),
-                       as<int32_t>(w->raw), Tr, near_enabled, cos_thr, near_tol, as<uint8_t>(w->has_kept), as<uint8_t>(w->any_valid),
-                       as<unsigned long long>(w->kmask), dc);
-    HIP_TRY(ctx, hipGetLastError());
-    SAME_TRY(same_compact_mask_core(ctx, as<unsigned long long>(w->kmask), t_words, Tr, as<int32_t>(w->klist), dc));          // count -> dc[1]
-    const bool readd = use_type && ensure_min_triangle_per_node;
-    if (readd) {
-        HIP_TRY(ctx, hipMemsetAsync(w->best_p.p, 0xFF, (size_t)n * sizeof(unsigned long long), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(w->best_t.p, 0xFF, (size_t)n * sizeof(unsigned), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(w->first_v.p, 0xFF, (size_t)Tr * sizeof(unsigned), ctx->stream));
-        hipLaunchKernelGGL(filter_best_perim_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->cls), as<double>(w->perim),
-                           as<int32_t>(w->raw), Tr, as<unsigned long long>(w->best_p));
-        hipLaunchKernelGGL(filter_best_tri_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->cls), as<double>(w->perim),
-                           as<int32_t>(w->raw), Tr, as<unsigned long long>(w->best_p), as<unsigned>(w->best_t));
-        hipLaunchKernelGGL(filter_first_node_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, as<uint8_t>(w->has_kept),
-                           as<uint8_t>(w->any_valid), as<unsigned>(w->best_t), n, as<unsigned>(w->first_v));
-        hipLaunchKernelGGL(filter_owner_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, as<uint8_t>(w->has_kept),
-                           as<uint8_t>(w->any_valid), as<unsigned>(w->best_t), as<unsigned>(w->first_v), n, as<unsigned long long>(w->nmask));
-        HIP_TRY(ctx, hipGetLastError());
-        SAME_TRY(same_compact_mask_core(ctx, as<unsigned long long>(w->nmask), n_words, n, as<int32_t>(w->nlist), dc + 4));   // count -> dc[5]
-    }
-    unsigned long long *h = static_cast<unsigned long long *>(w->host);   // bytes [0, 64) of the staging block are scalars
-    HIP_TRY(ctx, hipMemcpyAsync(h, dc, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const int64_t n_keep = (int64_t)h[1], n_near = (int64_t)h[2], n_add = readd ? (int64_t)h[5] : 0;
+    FilterPlan plan;
+    SAME_TRY(enqueue_filter(w, simplices, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &plan));
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
+    SAME_COPY(ctx, h, plan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    SAME_WAIT(ctx);
+    const int64_t n_keep = (int64_t)h[FC_KEEP], n_near = (int64_t)h[FC_NEAR], n_add = plan.readd ? (int64_t)h[FC_ADD] : 0;
     out_counts[0] = n_keep;
     out_counts[1] = n_add;
     out_counts[2] = n_near;
     if (n_near) return SAME_OK;                      // knife-edge cosines: the caller decides them as the reference does and passes the triangles in
-    if (n_keep + n_add) {
-        hipLaunchKernelGGL(filter_emit_kernel, dim3(grid_for(n_keep + n_add)), dim3(256), 0, ctx->stream, as<int32_t>(w->raw),
-                           as<int32_t>(w->klist), n_keep, as<int32_t>(w->nlist), n_add, as<unsigned>(w->best_t), as<int32_t>(w->tris));
-        HIP_TRY(ctx, hipGetLastError());
-    }
     w->Tr = n_keep + n_add;
     w->filtered = 1;
     return SAME_OK;
@@ -644,7 +1273,7 @@ int same_window_finish(same_window *w, const int32_t *tris, int64_t Tr, double n
         Tr = w->Tr;
     }
     REQUIRE(ctx, Tr >= 0 && Tr < ((int64_t)1 << 31) - 512 && (Tr == 0 || tris || resident));
-    const int64_t n = w->n_ua, P = w->P;
+    const int64_t n = w->n_ua;
     REQUIRE(ctx, n == 0 || (out_match_row && out_point_flag));
     for (int q = 0; q < 8; ++q) out_stats[q] = 0;
     SAME_TRY(same_use(ctx));
@@ -652,72 +1281,52 @@ int same_window_finish(same_window *w, const int32_t *tris, int64_t Tr, double n
     w->Tr = Tr;
     w->finished = 0;
     if (n == 0) { w->finished = 1; return SAME_OK; }
-    const size_t tt = (size_t)std::max<int64_t>(Tr, 1), padded = (size_t)grid_for(Tr) * 256;
-    SAME_TRY(ensure(ctx, w->tris, tt * 3 * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->sign, tt));
-    SAME_TRY(ensure(ctx, w->weight, tt * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->rowmin, (size_t)n * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->prefer, (size_t)n));
-    SAME_TRY(ensure(ctx, w->pair_of_row, (size_t)n * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->match, (size_t)n * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->match_row, (size_t)n * sizeof(int32_t)));
-    SAME_TRY(ensure(ctx, w->oflag, padded + 256));
-    SAME_TRY(ensure(ctx, w->omask, ((size_t)grid_for(Tr) * 4 + 4) * sizeof(unsigned long long)));
-    SAME_TRY(ensure(ctx, w->edge, tt * 3));
-    SAME_TRY(ensure(ctx, w->tflag, tt));
-    SAME_TRY(ensure(ctx, w->pflag, (size_t)n));
-    SAME_TRY(ensure(ctx, w->before, tt * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->after, tt * sizeof(double)));
-    SAME_TRY(ensure(ctx, w->m3, tt * 3));
-    SAME_TRY(ensure(ctx, w->flipped, tt));
-    unsigned long long *dc = as<unsigned long long>(w->counts);      // [0..1] orientation, [4..6] XY-order, [8..15] the stats block
-    unsigned long long *dstats = dc + 8;
-    HIP_TRY(ctx, hipMemsetAsync(dc, 0, 16 * sizeof(unsigned long long), ctx->stream));
-    if (Tr) {
-        if (!resident) HIP_TRY(ctx, hipMemcpyAsync(w->tris.p, tris, (size_t)Tr * 3 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        SAME_TRY(same_tri_sign_weight_dev(ctx, as<double>(w->axy_c), as<double>(w->size_c), as<int32_t>(w->tris), Tr, as<int8_t>(w->sign),
-                                          as<double>(w->weight)));
-    }
-    // greedy MIP start: per-row minimum, rows that beat their penalty, the scan's matching (one pair per aligned row)
-    SAME_TRY(same_pair_rowmin_core(ctx, as<int32_t>(w->pairs), as<double>(w->cost64), P, n, as<double>(w->rowmin)));
-    hipLaunchKernelGGL(prefer_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, as<double>(w->rowmin), as<double>(w->size_c), n,
-                       no_match_penalty, as<uint8_t>(w->prefer));
-    HIP_TRY(ctx, hipGetLastError());
-    int rounds = 0;
-    SAME_TRY(same_greedy_core(ctx, as<int32_t>(w->pairs), as<double>(w->cost64), P, n, w->n_r, as<uint8_t>(w->prefer),
-                              as<int32_t>(w->pair_of_row), &rounds));
-    hipLaunchKernelGGL(match_rows_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, as<int32_t>(w->pair_of_row), as<int32_t>(w->pairs),
-                       as<int32_t>(w->rows_r), n, as<int32_t>(w->match), as<int32_t>(w->match_row), dstats);
-    HIP_TRY(ctx, hipGetLastError());
-    // the three sweeps under that incumbent
-    SAME_TRY(same_orient_counts_core(ctx, as<int32_t>(w->tris), Tr, as<int8_t>(w->sign), as<double>(w->rxy_w), as<int32_t>(w->match),
-                                     as<uint8_t>(w->oflag), as<unsigned long long>(w->omask), dc));
-    SAME_TRY(same_xyorder_sweep_dev(ctx, as<double>(w->axy_c), n, as<double>(w->rxy_w), as<int32_t>(w->tris), Tr, as<int32_t>(w->match),
-                                    as<uint8_t>(w->edge), as<uint8_t>(w->tflag), as<uint8_t>(w->pflag), reinterpret_cast<uint64_t *>(dc + 4)));
-    if (Tr) {
-        SAME_TRY(same_area_flip_dev(ctx, as<double>(w->axy_c), as<double>(w->rxy_w), as<int32_t>(w->tris), Tr, as<int32_t>(w->match),
-                                    as<double>(w->before), as<double>(w->after), as<uint8_t>(w->m3), as<uint8_t>(w->flipped)));
-        hipLaunchKernelGGL(count_flags_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, as<uint8_t>(w->flipped), Tr, dstats + 5);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    const size_t head = 128;
-    char *h = static_cast<char *>(w->host) + finish_off(w->n_m);     // behind the stage call's results, which stay valid
-    HIP_TRY(ctx, hipMemcpyAsync(h, dc, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(h + head, w->match_row.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(h + head + (size_t)n * sizeof(int32_t), w->pflag.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned long long *c = reinterpret_cast<const unsigned long long *>(h);
-    out_stats[0] = (int64_t)c[0];        // orientation: triangles checked
-    out_stats[1] = (int64_t)c[1];        //              flipped
-    out_stats[2] = (int64_t)c[4];        // XY-order: comparisons
-    out_stats[3] = (int64_t)c[5];        //           violations
-    out_stats[4] = (int64_t)c[6];        //           triangles with a violation
-    out_stats[5] = (int64_t)c[8 + 5];    // area flips
-    out_stats[6] = rounds;               // rounds of the greedy rule
-    out_stats[7] = (int64_t)c[8 + 7];    // matched aligned cells
-    memcpy(out_match_row, h + head, (size_t)n * sizeof(int32_t));
-    memcpy(out_point_flag, h + head + (size_t)n * sizeof(int32_t), (size_t)n);
+    FinishPlan plan;
+    SAME_TRY(enqueue_finish(w, resident ? nullptr : tris, Tr, nullptr, no_match_penalty, &plan));
+    SAME_TRY(collect_finish(w, &plan, out_match_row, out_point_flag, out_stats));
     w->finished = 1;
+    return SAME_OK;
+}
+
+int same_window_filter_finish(same_window *w, const int32_t *simplices, int64_t n_simplices, double radius, int angle_enabled, double cos_thr,
+                              double near_tol, int ignore_same_type, int ensure_min_triangle_per_node, double no_match_penalty,
+                              int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts) {
+    if (!w) return SAME_EINVAL;
+    same_ctx *ctx = w->ctx;
+    REQUIRE(ctx, w->staged == 2 && out_counts && out_stats && n_simplices >= 0 && n_simplices < ((int64_t)1 << 31) - 512 &&
+                     (n_simplices == 0 || simplices));
+    const int64_t n = w->n_ua, Tr = n_simplices;
+    REQUIRE(ctx, n == 0 || (out_match_row && out_point_flag));
+    for (int q = 0; q < 3; ++q) out_counts[q] = 0;
+    for (int q = 0; q < 8; ++q) out_stats[q] = 0;
+    SAME_TRY(same_use(ctx));
+    SAME_TRY(check_index_range(ctx, simplices, Tr * 3, 0, n, "triangles"));
+    w->filtered = w->finished = 0;
+    w->Tr = 0;
+    if (n == 0) { w->filtered = w->finished = 1; return SAME_OK; }
+    FilterPlan fplan;
+    FinishPlan plan;
+    if (Tr) {
+        SAME_TRY(enqueue_filter(w, simplices, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &fplan));
+        SAME_TRY(enqueue_finish(w, nullptr, Tr, fplan.counters + FC_TR, no_match_penalty, &plan));
+        // the filter's counters come back beside the finish call's block: one copy from each buffer, ONE wait
+        unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
+        SAME_COPY(ctx, hf, fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        SAME_TRY(collect_finish(w, &plan, out_match_row, out_point_flag, out_stats));
+        const int64_t n_keep = (int64_t)hf[FC_KEEP], n_near = (int64_t)hf[FC_NEAR], n_add = fplan.readd ? (int64_t)hf[FC_ADD] : 0;
+        out_counts[0] = n_keep;
+        out_counts[1] = n_add;
+        out_counts[2] = n_near;
+        if (n_near) {             // the caller filters on the host and calls same_window_finish with its triangles: nothing here counts
+            for (int q = 0; q < 8; ++q) out_stats[q] = 0;
+            return SAME_OK;
+        }
+        w->Tr = n_keep + n_add;
+    } else {
+        SAME_TRY(enqueue_finish(w, nullptr, 0, nullptr, no_match_penalty, &plan));
+        SAME_TRY(collect_finish(w, &plan, out_match_row, out_point_flag, out_stats));
+    }
+    w->filtered = w->finished = 1;
     return SAME_OK;
 }
 

@@ -289,9 +289,22 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
 _W_ALIGNED_XY, _W_ALIGNED_ROWS, _W_ROWS_M, _W_ROWS_R, _W_PAIRS, _W_COSTS, _W_KEPT, _W_SIGNS, _W_WEIGHTS, _W_MATCH, _W_TRIANGLES = range(11)
 
 
+def window_cell_grid(plan_or_grid, window_size, overlap):
+    """(x0, y0, cell) of the grid on which every box of a window plan is a union of cells: the plan's boxes start at the grid
+    origins int(x_min) + i * step and end window_size later (merged ones at a later origin + window_size: src/same.py:481-488,
+    :527-542), so with cell = gcd(step, window_size) all their edges are cell edges.  `plan_or_grid` = (xs, ys) of window_grid."""
+    import math
+
+    xs, ys = plan_or_grid
+    step = int(window_size) - int(overlap)
+    return float(xs[0]), float(ys[0]), float(math.gcd(step, int(window_size)))
+
+
 class DeviceSection:
-    """A `Section`'s XY, type columns and sizes uploaded once (same_section_create); every window reads them in place.
-    cost_dtype float32 keeps the cost operands as float (BASELINE cfg 5), float64 is the reference's arithmetic."""
+    """A `Section`'s XY, type columns and sizes uploaded once (same_section_create) and binned into a grid of cells; every window
+    reads them in place.  cost_dtype float32 keeps the cost operands as float (BASELINE cfg 5), float64 is the reference's
+    arithmetic.  `bin(x0, y0, cell)` re-bins the rows on the window grid (window_cell_grid), on which a window's rows are
+    whole cells: do it once, before the windows run."""
 
     def __init__(self, section, cost_dtype=np.float64, ctx=None):
         import ctypes
@@ -312,6 +325,12 @@ class DeviceSection:
                 ctx.lib.same_section_destroy(h)
             ctx.check(rc, "same_section_create")
         self.handle = h
+
+    def bin(self, x0, y0, cell_w, cell_h=None):
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_section_bin(self.handle, float(x0), float(y0), float(cell_w), float(cell_w if cell_h is None else cell_h)),
+                           "same_section_bin")
+        return self
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:        # a context that is already gone took its device memory along
@@ -379,6 +398,26 @@ class DeviceWindow:
         self.n_triangles = 0 if near else kept + added
         return kept, added, near
 
+    STAT_NAMES = ("checked", "flipped", "xy_comparisons", "xy_violations", "xy_triangles", "area_flips", "greedy_rounds", "matched")
+
+    def filter_finish(self, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, no_match_penalty, ensure_min_triangle_per_node=True):
+        """filter() then finish(None) in one call, with no wait between them.  -> (kept, added back, near, match_row, flag, stats);
+        with near != 0 the last three are None and the caller filters on the host and calls finish() with its triangles."""
+        tris = ops._tris(simplices)
+        kept_rows = self.counts[2]
+        counts, stats = np.zeros(3, np.int64), np.zeros(8, np.int64)
+        match_row, flag = np.empty(kept_rows, np.int32), np.empty(kept_rows, np.uint8)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_window_filter_finish(self.handle, tris.ctypes.data, len(tris), float(radius), int(angle_enabled),
+                                                                  float(cos_thr), float(near_tol), int(bool(ignore_same_type)),
+                                                                  int(bool(ensure_min_triangle_per_node)), float(no_match_penalty), match_row.ctypes.data,
+                                                                  flag.ctypes.data, stats.ctypes.data, counts.ctypes.data), "same_window_filter_finish")
+        kept, added, near = (int(c) for c in counts)
+        self.n_triangles = 0 if near else kept + added
+        if near:
+            return kept, added, near, None, None, None
+        return kept, added, near, match_row, flag, dict(zip(self.STAT_NAMES, (int(v) for v in stats)))
+
     def finish(self, triangles, no_match_penalty):
         """-> (section row of the matched reference cell per kept aligned cell or -1, XY-order flag per kept cell, stats dict).
         triangles None = the ones filter() left on the device."""
@@ -391,8 +430,7 @@ class DeviceWindow:
                            "same_window_finish")
         if tris is not None:
             self.n_triangles = len(tris)
-        names = ("checked", "flipped", "xy_comparisons", "xy_violations", "xy_triangles", "area_flips", "greedy_rounds", "matched")
-        return match_row, flag, dict(zip(names, (int(v) for v in stats)))
+        return match_row, flag, dict(zip(self.STAT_NAMES, (int(v) for v in stats)))
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:
@@ -452,29 +490,39 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
             state = None
             if r == r and int(knn) > 0:
                 state = free.pop()
-                out.counts = state.stage(dmoving, dref, w["box"], abs(r), knn, dist_ct_coeff)
+                try:
+                    out.counts = state.stage(dmoving, dref, w["box"], abs(r), knn, dist_ct_coeff)
+                    if out.counts[3]:
+                        out.rows_m, out.axy = state.fetch(_W_ALIGNED_ROWS), state.fetch(_W_ALIGNED_XY)
+                except BaseException:
+                    free.append(state)                # a refused window (SAME_EINVAL ...) must not take its state out of the pool
+                    raise
             if state is None or out.counts[3] == 0:
                 if state is not None:
                     free.append(state)
                 out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
                 return out, None
-            out.rows_m, out.axy = state.fetch(_W_ALIGNED_ROWS), state.fetch(_W_ALIGNED_XY)
         with marked("triangulate (hand-over; waits for a free helper)"):
-            return out, (state, qhull_pool.pool().submit(out.axy))
+            try:
+                return out, (state, qhull_pool.pool().submit(out.axy))
+            except BaseException:
+                free.append(state)
+                raise
 
     def finish(out, staged):
         state, ticket = staged
         with marked("triangulate (wait for helper)"):
             tris = ticket.result()
-        with marked("triangle filter (device)"):
-            _kept, _added, near = state.filter(tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles)
+        with marked("filter + signs + incumbent + sweeps (device)"):
+            _kept, _added, near, out.match_row, out.point_flag, out.stats = state.filter_finish(
+                tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles, no_match_penalty)
         if near:
             with marked("triangle filter (host: a cosine at the threshold)"):
                 tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
                 out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
                                                            min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
-        with marked("signs + incumbent + sweeps (device)"):
-            out.match_row, out.point_flag, out.stats = state.finish(out.triangles, no_match_penalty)
+            with marked("signs + incumbent + sweeps (device)"):
+                out.match_row, out.point_flag, out.stats = state.finish(out.triangles, no_match_penalty)
         out.n_triangles = state.n_triangles
         if fetch_triangles and out.triangles is None:
             out.triangles = state.fetch(_W_TRIANGLES)

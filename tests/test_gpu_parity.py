@@ -751,6 +751,37 @@ def test_greedy_match_equals_sequential_scan(ops, oracle):
     assert (mp == -1).all()
 
 
+def test_greedy_chain_is_resolved_in_batches(ops, oracle):
+    """A monotone chain -- pair (i, i) costs 2i, pair (i + 1, i) costs 2i + 1 -- lets the parallel rule select exactly ONE pair a
+    round (every (i, i) is pre-empted at its row by (i, i - 1) until that one dies): 5 000 rounds for 9 999 pairs.  The result is
+    still the reference's scan (src/init_helpers.py:109-133), and the host reads the device once per BATCH of rounds, not once
+    per round: read-backs <= rounds / 4."""
+    import same_amd
+    from same_amd import _lib
+
+    n = 5000
+    pairs = np.empty((2 * n - 1, 2), np.int32)
+    pairs[0::2] = np.column_stack((np.arange(n), np.arange(n)))
+    pairs[1::2] = np.column_stack((np.arange(1, n), np.arange(n - 1)))
+    costs = np.arange(2 * n - 1, dtype=np.float64)
+    ctx = _lib.default_context()
+    before = ctx.stats()
+    mp, rounds = ops.greedy_match(pairs, costs, n, n, np.ones(n, np.uint8))
+    after = ctx.stats()
+    assert np.array_equal(mp, 2 * np.arange(n)) and rounds == n
+    readbacks = after["greedy_readbacks"] - before["greedy_readbacks"]
+    assert 1 <= readbacks <= rounds // 4, (readbacks, rounds)
+    kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=list(costs), n_aligned=n, n_ref=n, aligned_sizes=np.ones(n),
+              no_match_penalty=1e9, max_matches=1, init_method="greedy", verbose=False)
+    assert same_amd.compute_mip_start_pairs(**kw) == oracle.compute_mip_start_pairs(**kw)
+    # the usual case -- a few rounds -- is ONE read-back
+    rng = np.random.default_rng(3)
+    pi, pj = np.repeat(np.arange(2000), 8), rng.integers(0, 2000, 16000)
+    before = ctx.stats()
+    mp, rounds = ops.greedy_match(np.column_stack((pi, pj)).astype(np.int32), rng.gamma(2.0, 20.0, 16000), 2000, 2000, np.ones(2000, np.uint8))
+    assert rounds <= 3 and ctx.stats()["greedy_readbacks"] - before["greedy_readbacks"] == 1 or rounds > 3
+
+
 # ------------------------------------------------------------------------------------------ SURVEY 8(f2)
 @pytest.mark.parametrize("which", ["s3", "s6", "s9", "s1", "seeded"])
 def test_greedy_triangle_collapse_golden(hip, which):

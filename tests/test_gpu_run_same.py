@@ -994,3 +994,88 @@ def test_sharded_sliding_windows_equal_reference(tmp_path, world):
         got = np.load(tmp_path / f"rank{rank}.npz")
         rec.assert_same_record({k[4:]: got[k] for k in got.files}, g, prefix="sw/res_")
         assert (tmp_path / "sw" / f"rank{rank}" / "matchedDF.csv").exists()
+
+
+def test_window_rows_do_not_depend_on_the_section_grid():
+    """same_window_stage builds a window's row lists from the cells of the section's grid the box covers.  Whatever the grid -- the
+    default one, the window grid (every box a union of cells: no test at all), a grid the boxes cut through (exact box test on the
+    candidates), cells so small that a box covers more than 64 of them (one mask over the section) -- the rows, pairs and costs
+    are the same, and they are np.flatnonzero of the reference's four comparisons (src/same.py:293-295)."""
+    from same_amd import synth
+    from same_amd import windows as W
+
+    T = 4
+    ref = synth.make_cells(60_000, T, seed=50)
+    mov = synth.make_jittered(ref, seed=51)
+    mov["xy"][7] = (np.nan, 3.0)                       # a row no box holds
+    ref["xy"][11] = (np.inf, 3.0)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    cols = synth.type_columns(T)
+    rxy, mxy = r_df[["X", "Y"]].to_numpy(), m_df[["X", "Y"]].to_numpy()
+    ok_r, ok_m = np.isfinite(rxy).all(axis=1), np.isfinite(mxy).all(axis=1)
+    xs, ys, _ = W.window_grid(rxy[ok_r], mxy[ok_m], 600, 150)
+    plan = W.window_plan(rxy[ok_r], mxy[ok_m], 600, 150, 10)
+    boxes = [w["box"] for w in plan[::5]] + [(101.5, 640.25, 333.0, 1200.0), (-50.0, 90.0, -50.0, 4000.0), (0.0, 1e9, 0.0, 1e9), (5.0, 5.0, 0.0, 9.0)]
+    ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
+    x0, y0, cell = W.window_cell_grid((xs, ys), 600, 150)
+    assert cell == 150.0
+    grids = {"default": None, "window grid": (x0, y0, cell), "offset grid": (x0 + 37.25, y0 - 11.5, 211.0), "tiny cells": (x0, y0, 25.0)}
+    got = {}
+    for name, g in grids.items():
+        dref, dmov = W.DeviceSection(ref_sec, "float32"), W.DeviceSection(mov_sec, "float32")
+        if g is not None:
+            dref.bin(*g)
+            dmov.bin(*g)
+        st = W.DeviceWindow()
+        out = []
+        for box in boxes:
+            counts = st.stage(dmov, dref, box, 25, 8, 1.0)
+            out.append((counts, st.fetch(W._W_ROWS_M), st.fetch(W._W_ROWS_R), st.fetch(W._W_PAIRS), st.fetch(W._W_COSTS), st.fetch(W._W_ALIGNED_ROWS)))
+        got[name] = out
+        st.close()
+        dref.close()
+        dmov.close()
+    for q, box in enumerate(boxes):
+        x0_, x1_, y0_, y1_ = box
+        want_m = np.flatnonzero((mxy[:, 0] >= x0_) & (mxy[:, 0] < x1_) & (mxy[:, 1] >= y0_) & (mxy[:, 1] < y1_))
+        want_r = np.flatnonzero((rxy[:, 0] >= x0_) & (rxy[:, 0] < x1_) & (rxy[:, 1] >= y0_) & (rxy[:, 1] < y1_))
+        base = got["default"][q]
+        assert np.array_equal(base[1], want_m) and np.array_equal(base[2], want_r) and base[0][:2] == (len(want_m), len(want_r)), box
+        for name in grids:
+            for a, b in zip(got[name][q], base):
+                assert np.array_equal(a, b), (name, box)
+    assert sum(len(o[3]) for o in got["default"]) > 10_000
+
+
+def test_window_calls_stay_within_their_launch_budget():
+    """What a window costs in runtime calls, counted by the library itself (same_ctx_stat): with the sections binned on the window
+    grid a window is three fills (one per call's counters), at most 30 kernel launches, four copies and two waits (stage;
+    filter + finish as one call) -- round 3 needed ~80 launches, ~24 fills, ~13 copies and 5-6 waits."""
+    from same_amd import _lib, synth
+    from same_amd import windows as W
+
+    T = 8
+    ref = synth.make_cells(150_000, T, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    cols = synth.type_columns(T)
+    xs, ys, _ = W.window_grid(ref["xy"], mov["xy"], 1200, 300)
+    plan = W.window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
+    ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
+    dref, dmov = W.DeviceSection(ref_sec, "float32"), W.DeviceSection(mov_sec, "float32")
+    grid = W.window_cell_grid((xs, ys), 1200, 300)
+    dref.bin(*grid)
+    dmov.bin(*grid)
+    ctx = _lib.default_context()
+    kw = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0)
+    list(W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan[:3], **kw))          # buffers, helpers, the prune index
+    before = ctx.stats()
+    done = [dw for dw in W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, **kw) if dw.error is None]
+    after = ctx.stats()
+    per = {k: (after[k] - before[k]) / len(done) for k in after}
+    rounds = [dw.stats["greedy_rounds"] for dw in done]
+    print("per window:", per, "greedy rounds min/mean/max:", min(rounds), sum(rounds) / len(rounds), max(rounds))
+    assert len(done) >= 9 and sum(dw.counts[3] for dw in done) > 100_000
+    assert per["launches"] <= 30 and per["fills"] <= 4 and per["copies"] <= 4 and per["waits"] <= 3, per
+    dref.close()
+    dmov.close()
