@@ -20,9 +20,9 @@ At N > 1 the same run then measures BASELINE cfg 4 as a second, embedded record 
   ranks own aligned-row blocks of it (dense build in 25k-row chunks through the resident buffer), all-gather the candidate
   lists, derive the common matching, and sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter
   all-reduce).  `--scaling strong --workload cfg4` runs that configuration as the main record instead.
-`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see run_cfg5;
-  the default one-GPU line carries it as the sub-record `cfg5`, measured by a child job after the timed region (embedded_cfg5;
-  `--embed-cfg5 on` does the same at any rank count, `off` skips it).
+`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see same_amd/bench_cfg5.py;
+  every line of the default workload -- at 1 rank or N -- carries it as the sub-record `cfg5`, measured in the same job after the
+  timed region (on its ranks, contexts and communicator; `--embed-cfg5 off` skips it).
 value = aligned-ref cell pairs covered per second by the whole job.
 
 `roofline` is for the dense kernel: algorithmic bytes s*N_r*rows + s*(T+2)*(N_r+rows) over its mean launch
@@ -46,7 +46,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+from same_amd.bench_common import HBM_PEAK_GBS, Env, arm_rank_watchdog, baseline_metric, comm_report, make_comm, note, stats3  # noqa: E402  (no GPU, no torch)
 FP64_ISSUE_PEAK_T = 39.3   # T lane-instructions/s: the 78.6 TFLOP/s fp64 vector spec counts an FMA as two
 SIMDS, FP64_LANES_PER_CLK = 1024, 16   # 256 CUs x 4 SIMDs; a wave64 fp64 instruction occupies its SIMD for 4 cycles
 
@@ -60,7 +60,7 @@ WORKLOADS = {
 }
 # what the line carries at N > 1 on top of the N = 1 keys, so that the one 8-GPU run explains itself (checked before the line is written;
 # listed by --dry-launch so the CPU suite can hold the contract)
-N_GT1_KEYS = ("rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank")
+N_GT1_KEYS = ("rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank", "cfg5")
 N_GT1_STRONG_KEYS = ("config", "scaling", "value", "ms_per_step", "dense_kernel_ms", "per_rank_dense_ms", "gather", "gather_hidden_ms", "parity_spot_check")
 STRONG_OF = {"dense100k": "cfg4"}   # the ONE-problem configuration embedded after a weak run of the key (else: the same shape)
 STRONG_CHUNK_BYTES = 40e9  # dense buffer of the strong mode (25k rows x 200k refs x 8 B)
@@ -85,8 +85,8 @@ def parse():
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
     ap.add_argument("--embed-cfg5", choices=("auto", "on", "off"), default="auto",
-                    help="after the timed loop, run BASELINE cfg 5 (`--workload cfg5`, same rank count) as a child job and embed its line as `cfg5` "
-                         "(auto: with the default workload at one rank only)")
+                    help="after the timed loop, run BASELINE cfg 5 (the step of `--workload cfg5`) on this job's ranks and embed its numbers as `cfg5` "
+                         "(auto: with the default workload, at any rank count)")
     ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
                     help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
                          "and hands every kernel host buffers")
@@ -100,117 +100,8 @@ def parse():
 
 
 # ======================================================================================================================
-# launcher: the parent of `python3 bench.py --gpus N`
-# ======================================================================================================================
-def launch(args):
-    """Spawn N rank processes (fresh children: nothing here has touched the GPU), relay rank 0's JSON line."""
-    n = args.gpus
-    rdv = tempfile.mkdtemp(prefix="same_bench_rdv_")
-    limit = float(os.environ.get("SAME_BENCH_LAUNCH_TIMEOUT", "1500"))
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), SAME_RDV_DIR=rdv,
-                   MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-                   NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))   # if RCCL has something to complain about, keep it on stderr
-        out = subprocess.PIPE if r == 0 else sys.stderr   # only rank 0 writes the line
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    deadline = time.monotonic() + limit
-    rc, line = 0, None
-    try:
-        import selectors
-
-        sel = selectors.DefaultSelector()
-        sel.register(procs[0].stdout, selectors.EVENT_READ)
-        buf, open_out = b"", True
-        while True:
-            if open_out:
-                for _key, _ in sel.select(timeout=0.2):
-                    chunk = os.read(procs[0].stdout.fileno(), 65536)
-                    if chunk:
-                        buf += chunk
-                    else:
-                        open_out = False
-                        sel.unregister(procs[0].stdout)
-            else:
-                time.sleep(0.1)
-            codes = [p.poll() for p in procs]
-            bad = [c for c in codes if c not in (None, 0)]
-            if bad:
-                rc = bad[0] if bad[0] > 0 else 1
-                print(f"[bench launcher] a rank exited with {bad[0]}; stopping the others", file=sys.stderr)
-                break
-            if all(c == 0 for c in codes) and not open_out:
-                break
-            if time.monotonic() > deadline:
-                rc = 124
-                print(f"[bench launcher] ranks still running after {limit:.0f} s; stopping them", file=sys.stderr)
-                break
-        for ln in buf.decode(errors="replace").splitlines():
-            if ln.startswith("{") and ln.rstrip().endswith("}"):
-                line = ln
-    finally:
-        for p in procs:      # exactly the PIDs started above
-            if p.poll() is None:
-                p.terminate()
-        for p in procs:
-            try:
-                p.wait(timeout=10)
-            except subprocess.TimeoutExpired:
-                p.kill()
-        try:
-            for f in os.listdir(rdv):
-                os.remove(os.path.join(rdv, f))
-            os.rmdir(rdv)
-        except OSError:
-            pass
-    if rc == 0 and line is None:
-        print("[bench launcher] rank 0 finished without a JSON line", file=sys.stderr)
-        rc = 1
-    if line is not None and rc == 0:
-        sys.stdout.write(line + "\n")
-        sys.stdout.flush()
-    return rc
-
-
-# ======================================================================================================================
 # one rank
 # ======================================================================================================================
-_LAST_STAGE = ["start"]
-
-
-def note(group, msg):
-    """Progress on stderr (rank 0): a cold box can spend minutes in imports / RCCL bootstrap, and stdout is reserved for the line."""
-    _LAST_STAGE[0] = msg
-    if group.rank == 0:
-        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
-
-def arm_rank_watchdog(rank):
-    """A collective that never completes (a rank lost mid-run, a link that stops moving) has no timeout of its own: after
-    SAME_BENCH_RANK_TIMEOUT seconds (default 900) the rank says where it was and leaves with code 4, so that the launcher (ours or
-    torch.distributed.run) ends the job at once instead of at its own limit, with the GPUs still spinning."""
-    import threading
-
-    limit = float(os.environ.get("SAME_BENCH_RANK_TIMEOUT", "900"))
-
-    def fire():
-        print(f"[rank {rank}] still running after {limit:.0f} s; last stage: {_LAST_STAGE[0]!r}; giving up", file=sys.stderr, flush=True)
-        os._exit(4)
-
-    t = threading.Timer(limit, fire)
-    t.daemon = True
-    t.start()
-    return t
-
-
-def baseline_metric():
-    """The metric string of BASELINE.json, verbatim (the file ships with the repo)."""
-    try:
-        return json.load(open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8"))["metric"]
-    except Exception:
-        return "cell-pairs/sec on 100k×100k cost build + edge-cross sweep; % HBM roofline"
-
-
 def dense_kernel_label(dtype, T):
     """The kernel csrc/cost.hip dispatches to for this dtype and type count."""
     name = "double" if dtype == "f64" else "float"
@@ -220,20 +111,6 @@ def dense_kernel_label(dtype, T):
     if T * cpl * (2 if dtype == "f64" else 1) > 160:
         cpl = 1
     return f"dense_cost_kernel<{name},{T},{cpl}>"
-
-
-def stats3(values):
-    """[min, mean, max] of a list of numbers."""
-    v = [float(x) for x in values]
-    return [min(v), sum(v) / len(v), max(v)] if v else None
-
-
-class Env:
-    """What every problem of this rank shares: the host group, the two contexts, the communicator."""
-
-    def __init__(self, args, group, ctx, tctx, comm, transport):
-        self.args, self.group, self.ctx, self.tctx, self.comm, self.transport = args, group, ctx, tctx, comm, transport
-        self.L, self.H, self.TH, self.chk = ctx.lib, ctx.handle, tctx.handle, ctx.check
 
 
 class Problem:
@@ -493,64 +370,6 @@ class Problem:
             self.dD.free()
 
 
-def make_comm(args, group, tctx, what="pruned lists"):
-    """The communicator, BEFORE any spread allocation (spread.hip never reuses an address for a mapping, but it cannot speak
-    for RCCL's own use of the virtual-memory calls).  -> (comm or None, transport text)."""
-    from same_amd.dist import HostTransport, RcclGroup
-
-    if not (group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM")):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
-        return None, "none (single rank)"
-    comm = None
-    try:
-        if os.environ.get("SAME_BENCH_FAIL_RCCL"):
-            raise RuntimeError("forced by SAME_BENCH_FAIL_RCCL (test switch)")
-        # ncclCommInitRank is a collective without a timeout: if it never returns (a rank lost, a bootstrap interface that
-        # does not route) say so and leave, so the launcher stops the job at once instead of at its own limit
-        import threading
-
-        limit_s = float(os.environ.get("SAME_BENCH_RCCL_TIMEOUT", "300"))
-
-        def stuck():
-            print(f"[rank {group.rank}] RCCL communicator init has not returned after {limit_s:.0f} s; giving up", file=sys.stderr, flush=True)
-            os._exit(3)
-
-        watchdog = threading.Timer(limit_s, stuck)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            comm = RcclGroup(tctx, group.world, group.rank, lambda b: group.bcast_bytes(b or b""))
-        finally:
-            watchdog.cancel()
-        ok_here = 1.0
-    except Exception as e:  # TRANSPORT fallback only (compute stays on the GPU): reported in the JSON line
-        print(f"[rank {group.rank}] RCCL communicator init failed ({e}); gathering through the host group instead", file=sys.stderr)
-        ok_here = 0.0
-    if group.min(ok_here) < 1.0:  # any rank failed -> every rank uses the host transport
-        if comm is not None:
-            comm.close()
-        return HostTransport(tctx, group), f"HOST (loopback TCP) all-gather of {what}: RCCL init failed on this node"
-    v = comm.rccl_version()
-    return comm, f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100} all-gather of {what}"
-
-
-def comm_report(env, np):
-    """`rccl`: what every rank's communicator says about itself -- the size and rank from ncclCommCount / ncclCommUserRank."""
-    me = dict(env.comm.info(), host_rank=env.group.rank, local_rank=int(os.environ.get("LOCAL_RANK", str(env.group.rank))),
-              hip_device=env.tctx.device, kind="rccl" if not env.comm.synchronous else "host")
-    every = env.group.allgather_object(me)
-    if env.group.rank != 0:
-        return None
-    v = me["version"]
-    return {"kind": me["kind"], "nranks": me["nranks"], "rank": me["rank"], "device": me["device"],
-            "version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None,
-            "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the live communicator" if me["kind"] == "rccl"
-                      else "host transport (no RCCL communicator): the host group's world and rank",
-            "every_rank": [[r["host_rank"], r["rank"], r["nranks"], r["device"]] for r in every],
-            "every_rank_columns": ["host rank", "communicator rank", "communicator size", "device"],
-            "consistent": all(r["nranks"] == env.group.world and r["rank"] == r["host_rank"] for r in every),
-            "distinct_devices": len({r["device"] for r in every})}
-
-
 def gather_report(prob, dt_with, steps_with, dt_without, steps_without):
     """`gather`: the candidate-list all-gather by itself (events on its stream) and what it costs the step."""
     env = prob.env
@@ -566,45 +385,6 @@ def gather_report(prob, dt_with, steps_with, dt_without, steps_without):
            "step_ms_with_gather": with_ms, "step_ms_without_gather": without_ms,
            "steps_without_gather": steps_without if dt_without is not None else 0}
     return out, (with_ms - without_ms if without_ms is not None else None)
-
-
-def embedded_cfg5(args, world):
-    """BASELINE cfg 5 as a sub-record of the line: `bench.py --workload cfg5 --gpus <world>` as a child job with ranks, contexts and
-    Qhull helpers of its own, while this job's ranks wait at their barrier with idle GPUs.  Never fatal: a child that fails or
-    outlives SAME_BENCH_CFG5_TIMEOUT (default 240 s) leaves an `error` entry instead of a record."""
-    import signal
-    import subprocess
-
-    limit_s = float(os.environ.get("SAME_BENCH_CFG5_TIMEOUT", "240"))
-    drop = {"RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
-            "MASTER_ADDR", "MASTER_PORT", "SAME_RDV_DIR", "SAME_HIP_DEVICE", "SAME_TRACE"}
-    env = {k_: v for k_, v in os.environ.items() if k_ not in drop and not k_.startswith(("TORCHELASTIC_", "PET_"))}
-    env["SAME_BENCH_LAUNCH_TIMEOUT"] = env["SAME_BENCH_RANK_TIMEOUT"] = str(int(limit_s))   # the child's ranks also end by themselves
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg5", "--gpus", str(world), "--steps", "3", "--warmup", "1",
-           "--cfg5-cells", str(args.cfg5_cells), "--cfg5-pipeline", args.cfg5_pipeline] + (["--no-cpu-baseline"] if world > 1 else [])
-    t0 = time.perf_counter()
-    try:
-        child = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-        try:
-            so, se = child.communicate(timeout=limit_s)
-        except subprocess.TimeoutExpired:
-            os.killpg(child.pid, signal.SIGKILL)           # the child's own ranks and helpers live in its session
-            child.communicate()
-            return {"error": f"no line after {limit_s:.0f} s", "command": " ".join(cmd[1:])}
-        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
-        if child.returncode != 0 or not lines:
-            return {"error": f"exit code {child.returncode}: {se.strip()[-300:]}", "command": " ".join(cmd[1:])}
-        d = json.loads(lines[-1])
-    except Exception as e:  # noqa: BLE001 -- the sub-record must never cost the main line
-        return {"error": f"{type(e).__name__}: {e}", "command": " ".join(cmd[1:])}
-    keep = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "per_rank", "host_glue_share", "python_share", "threads_per_rank",
-            "qhull", "merged_matches", "parity_spot_check", "rccl")
-    rec = {k_: d.get(k_) for k_ in keep if k_ in d}
-    rec["workload"], rec["pipeline"] = d["config"]["workload"], d["config"]["pipeline"]
-    rec["command"], rec["child_job_s"] = "python3 bench.py " + " ".join(cmd[2:]), time.perf_counter() - t0
-    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks, fp32 costs, all sweeps, tables exchanged once and merged) measured by a "
-                   "child job of the same rank count after this line's own timed region; windows_per_s is the whole job's")
-    return rec
 
 
 def run_rank(args):
@@ -630,7 +410,10 @@ def run_rank(args):
         uid = group.bcast_bytes(bytes(range(128)) if group.rank == 0 else b"")
         group.barrier()
         mx = group.max(float(group.rank + 1))
-        ranks = group.allgather_object({"rank": group.rank, "pid": os.getpid(), "id_ok": uid == bytes(range(128))})
+        from same_amd import qhull_pool
+
+        ranks = group.allgather_object({"rank": group.rank, "pid": os.getpid(), "id_ok": uid == bytes(range(128)),
+                                        "local_world": qhull_pool.local_world()[0], "qhull_helpers": qhull_pool.default_workers()})
         if group.rank == 0:
             os.write(json_fd, (json.dumps({"dry_launch": True, "world": group.world, "max_of_rank_plus_1": mx, "ranks": ranks,
                                            "line_keys_at_n_gt_1": list(N_GT1_KEYS) + ["strong_cfg4"],
@@ -647,7 +430,7 @@ def run_rank(args):
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libsame_hip has no CPU fallback")
     if args.workload == "cfg5":
-        return run_cfg5(args, group, json_fd)
+        return run_cfg5_workload(args, group, json_fd, local_rank)
     strong = args.scaling == "strong"
     ctx = _lib.Context(local_rank % _lib.device_count())          # the dense build's context (one context = one stream)
     L, H, chk = ctx.lib, ctx.handle, ctx.check
@@ -975,6 +758,24 @@ def run_rank(args):
         sp.close(keep_dense=True)
         prob = None
 
+    # ---- BASELINE cfg 5 as an embedded record, IN THIS JOB (its ranks, their contexts, the communicator): the same at 1 rank or 8 ----
+    cfg5_rec = None
+    want_cfg5 = args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and args.workload == "dense100k" and not strong and not args.no_extras)
+    if want_cfg5:
+        from same_amd import bench_cfg5
+
+        note(group, "embedded cfg5 record: the window configuration on this job's ranks")
+        try:
+            line5 = bench_cfg5.run(args, group, tctx, comm, transport.replace(" (overlapped on a second stream)", "").replace("pruned lists", "the ranks' match tables"),
+                                   3, 1, cpu_baseline=group.world == 1)   # one rank: four windows through the oracle, as parity check and CPU figure
+            cfg5_rec = bench_cfg5.record(line5) if group.rank == 0 else None
+        except SystemExit:
+            raise                                     # a parity failure inside the record is a failure of the line
+        except Exception as e:  # noqa: BLE001 -- anything else costs the sub-record, never the main line; every rank raises alike or none does
+            cfg5_rec = {"error": f"{type(e).__name__}: {e}"}
+        if group.rank == 0:
+            note(group, "embedded cfg5 record: " + (f"{cfg5_rec['windows_per_s']:.0f} windows/s" if "windows_per_s" in cfg5_rec else cfg5_rec.get("error", "?")))
+
     if group.rank == 0:
         total_rows = n_mov if strong else rows * group.world
         pairs_per_step = float(n_ref) * total_rows
@@ -1112,16 +913,13 @@ def run_rank(args):
                 missing = [k for k in N_GT1_STRONG_KEYS if k not in strong_rec]
                 if missing:
                     raise SystemExit(f"the embedded strong record lacks {missing}")
-            missing = [k for k in N_GT1_KEYS if out.get(k) is None and k != "gather_hidden_ms"]
+            missing = [k for k in N_GT1_KEYS if out.get(k) is None and k not in ("gather_hidden_ms", "cfg5")]   # cfg5 joins below
             if missing:
                 raise SystemExit(f"the N > 1 line lacks {missing}")
-        # auto: at one rank only -- the child job doubles the processes on every GPU while it runs, which a launcher's process limits
-        # at N > 1 may not allow; `--embed-cfg5 on` asks for it at any N (`bench.py --workload cfg5 --gpus N` is the same measurement)
-        if args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and args.workload == "dense100k" and group.world == 1 and not strong
-                                       and not args.no_extras):
-            note(group, "embedded cfg5 record: bench.py --workload cfg5 as a child job")
-            out["cfg5"] = embedded_cfg5(args, group.world)
-            note(group, "embedded cfg5 record: " + (f"{out['cfg5']['windows_per_s']:.0f} windows/s" if "windows_per_s" in out["cfg5"] else out["cfg5"].get("error", "?")))
+        if want_cfg5:
+            out["cfg5"] = cfg5_rec
+            if group.world > 1 and (cfg5_rec is None or "windows_per_s" not in cfg5_rec) and args.embed_cfg5 != "off":
+                raise SystemExit(f"the N > 1 line lacks its cfg5 record: {cfg5_rec}")
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
     if prob is not None:
@@ -1134,281 +932,17 @@ def run_rank(args):
     group.close()
 
 
-def run_cfg5(args, group, json_fd):
-    """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
-    round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
-    with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates, runs the
-    filter's re-add pass and receives the match; --cfg5-pipeline columns is the host-buffer form it is tested against),
-    every rank's central-trimmed match table exchanged in ONE device all-gather (dist.allgather_table) and merged
-    (src/helpers.py:692-815, de-duplication on the GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
-    (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
-    One step = the whole plan once (every rank its share) + the exchange + the merge.  value = dense-equivalent cell pairs
-    (sum over windows of aligned x ref cells in the window) per second; `windows_per_s` per rank and the share of the step
-    spent outside libsame_hip calls (`host_glue_share`) come from the stage markers of same_amd/_trace.py."""
-    import numpy as np
-    import pandas as pd
+def run_cfg5_workload(args, group, json_fd, local_rank):
+    """`--workload cfg5`: the window configuration as the line itself (same_amd/bench_cfg5.py)."""
+    from same_amd import _lib, bench_cfg5
 
-    import same_amd
-    from same_amd import _lib, _trace, ops, synth
-    from same_amd.merge import merge_window_matches_unique_ref
-    from same_amd.dist import allgather_table
-    from same_amd import windows as W
-    from same_amd.windows import DeviceSection, Section, assign_windows, iter_device_windows, iter_window_arrays, window_plan
-
-    _trace.enable(True)
-    _lib.instrument()
-    local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
     os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
     ctx = _lib.default_context()
     comm, transport = make_comm(args, group, ctx, what="the ranks' match tables")   # a device all-gather (RCCL; host transport if that fails)
-    n, T = int(args.cfg5_cells), 8
-    ref = synth.make_cells(n, T, seed=0)
-    mov = synth.make_jittered(ref, seed=1)
-    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
-    r_df["Cell_Num_Old"], m_df["Cell_Num_Old"] = np.arange(len(r_df)), np.arange(len(m_df))
-    cols = synth.type_columns(T)
-    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
-    plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
-    mine = assign_windows(plan, group.world)[group.rank]
-    my_plan = [plan[q] for q in mine]
-    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)}")
-
-    TABLE_COLUMNS = (("Aligned_Cell_Num_Old", np.int64), ("Ref_Cell_Num_Old", np.int64), ("X", np.float64), ("Y", np.float64),
-                     ("filtered_violation", bool), ("window_id", np.int64))
-    ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
-    ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
-    on_device = args.cfg5_pipeline == "device"
-    dref, dmov = (DeviceSection(ref_sec, np.float32, ctx), DeviceSection(mov_sec, np.float32, ctx)) if on_device else (None, None)
-    path_kw = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True)
-
-    def device_table(dw):
-        """the window's central match table from what iter_device_windows leaves on the host (section rows, XY, match, flags)"""
-        w = dw.window
-        ai = np.flatnonzero(dw.match_row >= 0)
-        x, y = dw.axy[ai, 0], dw.axy[ai, 1]
-        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
-        c = ai[(x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1)]
-        tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": dw.axy[c, 0], "Y": dw.axy[c, 1],
-               "filtered_violation": dw.point_flag[c].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
-        st = dw.stats
-        return tab, {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
-                     "xy_violations": st["xy_violations"], "area_flips": st["area_flips"]}
-
-    def run_window(wa, wctx):
-        """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
-        w, pairs = wa.window, wa.pairs.astype(np.int32)
-        # greedy MIP start (src/init_helpers.py:104-133) in its flat device form: per-row minimum, rows that beat their
-        # no-match penalty, the scan's matching -> one pair index per aligned row
-        wants = ops.pair_rowmin(pairs, wa.costs, wa.n_aligned, ctx=wctx) < 100.0 * wa.size.astype(float)
-        pair_of_row, _rounds = ops.greedy_match(pairs, wa.costs, wa.n_aligned, wa.n_ref, wants, ctx=wctx)
-        ai = np.flatnonzero(pair_of_row >= 0)
-        ri = pairs[pair_of_row[ai], 1].astype(np.int64)
-        match = np.full(wa.n_aligned, -1, np.int32)
-        match[ai] = ri
-        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned, ctx=wctx)      # the lazy-constraint body (src/same.py:645-669)
-        checked, viol = sw.sweep_match(match)
-        sw.close()
-        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms
-        _edge, _tflag, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
-        _before, _after, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
-        x, y = wa.axy[ai, 0], wa.axy[ai, 1]
-        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
-        c = np.flatnonzero((x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
-        tab = {"Aligned_Cell_Num_Old": mov_ids[wa.rows_m[ai[c]]], "Ref_Cell_Num_Old": ref_ids[wa.rows_r[ri[c]]], "X": x[c], "Y": y[c],
-               "filtered_violation": pflag[ai[c]].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
-        return tab, {"pairs": len(pairs), "triangles": len(wa.triangles), "checked": int(checked), "flipped": len(viol),
-                     "xy_violations": int(counts[1]), "area_flips": int(np.count_nonzero(flipped))}
-
-    # The windows of a pass are independent and the host work per window (numpy index work, ~7 ms) dwarfs its kernels (~0.3 ms), so
-    # the rank walks its windows with --cfg5-threads workers, each with a context (= stream) of its own; numpy and the library calls
-    # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
-    n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else (2 if on_device else 4)))
-    worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
-
-    def walk(windows, wctx, out):
-        if on_device:
-            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, windows, no_match_penalty=100.0, ctx=wctx, **path_kw):
-                if dw.error is None:
-                    with _trace.stage("table (bench step)"):
-                        out.append((dw.window["window_id"], *device_table(dw)))
-            return
-        for wa in iter_window_arrays(ref_sec, mov_sec, windows, cost_dtype=np.float32, ctx=wctx, **path_kw):
-            if wa.error is not None:              # a window whose prune leaves no pairs (src/same.py:1003)
-                continue
-            with _trace.stage("incumbent + sweeps + table (bench step)"):
-                out.append((wa.window["window_id"], *run_window(wa, wctx)))
-
-    def one_pass(windows):
-        import threading
-
-        outs = [[] for _ in range(n_workers)]
-        if n_workers == 1:
-            walk(windows, ctx, outs[0])
-        else:
-            errors = []
-
-            def guarded(q):
-                try:
-                    walk(windows[q::n_workers], worker_ctx[q], outs[q])
-                except BaseException as e:   # noqa: BLE001 -- re-raised in the main thread below
-                    errors.append(e)
-
-            threads = [threading.Thread(target=guarded, args=(q,)) for q in range(n_workers)]
-            [t.start() for t in threads]
-            [t.join() for t in threads]
-            if errors:
-                raise errors[0]
-        pos = {w["window_id"]: q for q, w in enumerate(windows)}
-        done = sorted((r for part in outs for r in part), key=lambda r: pos[r[0]])
-        return [r[1] for r in done], [r[2] for r in done]
-
-    def step():
-        tabs, stats = one_pass(my_plan)
-        mine_tab = {c: (np.concatenate([t[c] for t in tabs]) if tabs else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
-        mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
-        with _trace.stage("table exchange (all-gather)"):
-            every = allgather_table(ctx, comm, group, mine_tab)          # the ONE exchange: one table per rank, a device all-gather
-        with _trace.stage("merge (device de-duplication + host matching)"):
-            frames = [pd.DataFrame(dict(t, filtered_violation=t["filtered_violation"].astype(bool))) for t in every if len(t["X"])]
-            merged = merge_window_matches_unique_ref(frames)
-        return merged, stats
-
-    from same_amd import qhull_pool as _qp
-
-    # warm-up: scratch slots, Qhull helpers, first-launch costs -- and, on the device path, every window state a worker keeps
-    # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
-    n_warm = (_qp.lookahead() + 1) * n_workers if on_device else 2
-    for _ in range(args.warmup):
-        one_pass(my_plan[: max(1, min(n_warm, len(my_plan)))])
-    group.barrier()
-    _trace.reset()
-    t0 = time.perf_counter()
-    merged = stats = None
-    for _ in range(args.steps):
-        merged, stats = step()
-    group.barrier()
-    wall_here = time.perf_counter() - t0
-    dt = group.max(wall_here)
-    rep = _trace.report()
-    in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:"))
-    stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
-    lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
-    qhull_wait = sum(sec for name, (_c, sec) in rep.items() if name.startswith("triangulate"))
-    mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * args.steps / wall_here,
-                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / (wall_here * n_workers), "threads": n_workers,
-                "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / (wall_here * n_workers)),
-                "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
-                "triangles": int(sum(s["triangles"] for s in stats))}
-    every = group.allgather_object(mine_rec)
-    rccl = comm_report(Env(args, group, ctx, ctx, comm, transport), np) if comm is not None else None
-    # N=1: four windows through the oracle as the CPU baseline and as the parity check of what the GPU produced for them
-    cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
-    if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
-        from scipy.spatial import Delaunay
-
-        from oracle import same_oracle as orc
-
-        sample = [w for w in my_plan if w["n_mov"] > 1000][:4] or my_plan[:1]
-        t_cpu, done_pairs = 0.0, 0
-        for w in sample:
-            c0 = time.perf_counter()                 # the oracle's part of this window only: the GPU re-runs below are not the CPU's time
-            x0, x1, y0, y1 = w["box"]
-            rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
-            na, nr, pairs = orc.find_knn_within_radius(ms, rs, 25, 8)
-            pairs = np.asarray(pairs, dtype=np.int64)
-            axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
-            c32 = orc.pair_cost_arrays(na[cols].to_numpy(), nr[cols].to_numpy(), axy, rxy, pairs, 1.0, dtype=np.float32)
-            tri = np.asarray(orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
-                                                            min_angle_deg=15), dtype=np.int64).reshape(-1, 3)
-            signs = orc.source_signs(na, tri)
-            kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=c32.astype(np.float64), n_aligned=len(na), n_ref=len(nr),
-                      aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
-            och, _ = orc.compute_mip_start_pairs(**kw)
-            xo = np.zeros(len(pairs))
-            xo[[c[2] for c in och]] = 1.0
-            ochecked, oviol = orc.lazy_orientation_sweep(xo, pairs, tri, signs, rxy, len(na))
-            done_pairs += w["n_mov"] * w["n_ref"]
-            t_cpu += time.perf_counter() - c0
-            # the same window on the GPU, compared
-            prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
-            ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs) and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
-                  and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri) and list(prep.source_signs) == list(signs))
-            gch, _ = same_amd.compute_mip_start_pairs(**dict(kw, valid_pairs=prep.valid_pairs, costs=prep.costs))
-            sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
-            gchecked, gviol, _ = sw.sweep(xo)
-            sw.bound.close()
-            ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
-            if ok and on_device:                 # and what the timed path itself computes for this window (csrc/window.hip)
-                nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
-                for hit in och:
-                    match_o[hit[0]] = nr_rows[hit[1]]
-                for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, fetch_triangles=True, **path_kw):
-                    dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
-                    ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
-                          and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])
-                          and np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), c32) and np.array_equal(dw.triangles, tri)
-                          and np.array_equal(dw.state.fetch(W._W_SIGNS), np.asarray(signs, dtype=np.int8))
-                          and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
-            if not ok:
-                raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
-        parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
-                  "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
-        cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
-               "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
-                         f"through oracle/same_oracle.{{c,py}} in {t_cpu:.2f} s, 1 thread (frame subsetting included; the GPU re-runs of the same windows for the "
-                         "comparison are not in this time)",
-               "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on this box"}
+    out = bench_cfg5.run(args, group, ctx, comm, transport, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline)
     if group.rank == 0:
-        total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
-        es, k = 4, 8
-        P, Tr = sum(r["pairs"] for r in every), sum(r["triangles"] for r in every)
-        touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)   # SURVEY 8d per-unit figures
-        lib_s = max(r["in_library_s"] for r in every) / args.steps
-        out = {"metric": baseline_metric(), "value": total_pairs * args.steps / dt, "unit": "cell-pairs/s", "n_gpus": group.world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
-                                      f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
-                                      "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
-                          "pipeline": ("device: both sections resident in HBM, two library calls per window (csrc/window.hip); the host triangulates (Qhull "
-                                       "helpers), runs the triangle filter's re-add pass and receives the match" if on_device
-                                       else "columns: subsetting, compaction and gathers on the host, every kernel through host buffers"),
-                          "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
-                                         "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
-               "windows_per_s": len(plan) * args.steps / dt,
-               "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
-                            "host_glue_share": [r["host_glue_share"] for r in every], "python_share": [r["python_share"] for r in every],
-                            "qhull_wait_s_per_step": [r["qhull_wait_s"] / args.steps for r in every],
-                            "in_library_s_per_step": [r["in_library_s"] / args.steps for r in every]},
-               "host_glue_share": mine_rec["host_glue_share"],
-               "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
-                                        "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
-               "python_share": mine_rec["python_share"],
-               "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes of the "
-                                     "threads' time (the merge and the table exchange included)",
-               "threads_per_rank": n_workers,
-               "qhull": {"helpers": _qp.pool().n, "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
-                         "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / args.steps,
-                         "what": "helper processes that run scipy.spatial.Delaunay for the windows ahead (a6 stays on the host); waiting = the worker "
-                                 "threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
-               "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
-               "merged_matches": int(len(merged)),
-               "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (the padded / pair cost kernel is the largest)",
-                            "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "algorithmic_bytes_per_step": touched,
-                            "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
-                                    "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by launch latency and host "
-                                    "glue, not by HBM -- see host_glue_share"},
-               "cpu_baseline": cpu, "parity_spot_check": parity}
-        if rccl is not None:
-            out["rccl"] = rccl
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()
-    for sec in (dref, dmov):
-        if sec is not None:
-            sec.close()
-    for c in worker_ctx[1:]:
-        c.close()
     if comm is not None:
         comm.close()
     group.close()
@@ -1417,7 +951,9 @@ def run_cfg5(args, group, json_fd):
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(launch(args))
+        from same_amd.bench_launch import launch
+
+        sys.exit(launch(args, __file__))
     run_rank(args)
 
 

@@ -476,9 +476,10 @@ int same_comm_group_end(same_ctx *ctx);
 int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version);
 /* ncclCommCuDevice of the communicator (-1 = none) */
 int same_comm_device(same_ctx *ctx, int *out_device);
-/* Device time (HIP events on the stream they ran on) of the all-gathers issued since the last same_comm_wait -- the
- * overlapped ones, or the in-stream ones issued outside a group -- and the bytes this rank sent in them (may be NULL);
- * waits for the last of them.  0 ms if none. */
+/* Device time (HIP events on the stream they ran on) of the all-gathers issued since the last same_comm_wait or the last
+ * call of this function, whichever came later -- the overlapped ones, or the in-stream ones issued outside a group -- and the
+ * bytes this rank sent in them (may be NULL); waits for the last of them.  0 ms if none.  Reading closes the batch: the next
+ * gather starts a new one (a caller that only uses the in-stream form never needs same_comm_wait). */
 int same_comm_gather_time(same_ctx *ctx, float *out_ms, int64_t *out_send_bytes);
 
 #ifdef __cplusplus

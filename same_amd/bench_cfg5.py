@@ -1,0 +1,324 @@
+"""BASELINE cfg 5 as a bench step (bench.py --workload cfg5, and the `cfg5` record every bench line embeds): the reference's window
+loop src/same.py:507-593 with whole windows dealt to the ranks.  Runs on the caller's host group, context and communicator -- no
+process of its own -- so the same code measures one rank or eight."""
+import os
+import time
+
+from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
+
+RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "per_rank", "host_glue_share", "python_share",
+               "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl")
+
+
+def record(line):
+    """The sub-record a bench line of another workload carries as `cfg5`: the cfg 5 line's own numbers, without its prose."""
+    rec = {k_: line.get(k_) for k_ in RECORD_KEYS if k_ in line}
+    rec["workload"], rec["pipeline"] = line["config"]["workload"], line["config"]["pipeline"]
+    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks, fp32 costs, all sweeps, tables exchanged once and merged) measured in "
+                   "this job, on its ranks, contexts and communicator, after this line's own timed region; windows_per_s is the whole job's")
+    return rec
+
+
+def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline):
+    """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
+    round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
+    with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates, runs the
+    filter's re-add pass and receives the match; --cfg5-pipeline columns is the host-buffer form it is tested against),
+    every rank's central-trimmed match table exchanged in ONE device all-gather (dist.allgather_table) and merged
+    (src/helpers.py:692-815, de-duplication on the GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
+    (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
+    `ctx` is the context the communicator lives on (the exchange runs on its stream); worker threads get contexts of their own.
+    One step = the whole plan once (every rank its share) + the exchange + the merge (on rank 0, which owns the result).
+    -> the line as a dict on rank 0, None elsewhere; nothing is closed here.  value = dense-equivalent cell pairs
+    (sum over windows of aligned x ref cells in the window) per second; `windows_per_s` per rank and the share of the step
+    spent outside libsame_hip calls (`host_glue_share`) come from the stage markers of same_amd/_trace.py."""
+    import numpy as np
+    import pandas as pd
+
+    import same_amd
+    from same_amd import _lib, _trace, ops, synth
+    from same_amd.merge import merge_window_matches_unique_ref
+    from same_amd.dist import allgather_table, last_table_gather
+    from same_amd import windows as W
+    from same_amd.windows import DeviceSection, Section, assign_windows, iter_device_windows, iter_window_arrays, window_plan
+
+    _trace.enable(True)
+    _lib.instrument()
+    n, T = int(args.cfg5_cells), 8
+    ref = synth.make_cells(n, T, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    r_df["Cell_Num_Old"], m_df["Cell_Num_Old"] = np.arange(len(r_df)), np.arange(len(m_df))
+    cols = synth.type_columns(T)
+    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
+    plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
+    mine = assign_windows(plan, group.world)[group.rank]
+    my_plan = [plan[q] for q in mine]
+    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)}")
+
+    TABLE_COLUMNS = (("Aligned_Cell_Num_Old", np.int64), ("Ref_Cell_Num_Old", np.int64), ("X", np.float64), ("Y", np.float64),
+                     ("filtered_violation", bool), ("window_id", np.int64))
+    ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
+    ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
+    on_device = args.cfg5_pipeline == "device"
+    dref, dmov = (DeviceSection(ref_sec, np.float32, ctx), DeviceSection(mov_sec, np.float32, ctx)) if on_device else (None, None)
+    if on_device:       # the rows of both sections binned ONCE on the window grid: every window box is then a union of cells
+        xs, ys, _ = W.window_grid(ref["xy"], mov["xy"], 1200, 300)
+        cell_grid = W.window_cell_grid((xs, ys), 1200, 300)
+        dref.bin(*cell_grid)
+        dmov.bin(*cell_grid)
+    path_kw = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True)
+
+    def device_table(dw):
+        """the window's central match table from what iter_device_windows leaves on the host (section rows, XY, match, flags)"""
+        w = dw.window
+        ai = np.flatnonzero(dw.match_row >= 0)
+        x, y = dw.axy[ai, 0], dw.axy[ai, 1]
+        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
+        c = ai[(x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1)]
+        tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": dw.axy[c, 0], "Y": dw.axy[c, 1],
+               "filtered_violation": dw.point_flag[c].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
+        st = dw.stats
+        return tab, {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
+                     "xy_violations": st["xy_violations"], "area_flips": st["area_flips"]}
+
+    def run_window(wa, wctx):
+        """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
+        w, pairs = wa.window, wa.pairs.astype(np.int32)
+        # greedy MIP start (src/init_helpers.py:104-133) in its flat device form: per-row minimum, rows that beat their
+        # no-match penalty, the scan's matching -> one pair index per aligned row
+        wants = ops.pair_rowmin(pairs, wa.costs, wa.n_aligned, ctx=wctx) < 100.0 * wa.size.astype(float)
+        pair_of_row, _rounds = ops.greedy_match(pairs, wa.costs, wa.n_aligned, wa.n_ref, wants, ctx=wctx)
+        ai = np.flatnonzero(pair_of_row >= 0)
+        ri = pairs[pair_of_row[ai], 1].astype(np.int64)
+        match = np.full(wa.n_aligned, -1, np.int32)
+        match[ai] = ri
+        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned, ctx=wctx)      # the lazy-constraint body (src/same.py:645-669)
+        checked, viol = sw.sweep_match(match)
+        sw.close()
+        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms
+        _edge, _tflag, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
+        _before, _after, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
+        x, y = wa.axy[ai, 0], wa.axy[ai, 1]
+        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
+        c = np.flatnonzero((x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
+        tab = {"Aligned_Cell_Num_Old": mov_ids[wa.rows_m[ai[c]]], "Ref_Cell_Num_Old": ref_ids[wa.rows_r[ri[c]]], "X": x[c], "Y": y[c],
+               "filtered_violation": pflag[ai[c]].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
+        return tab, {"pairs": len(pairs), "triangles": len(wa.triangles), "checked": int(checked), "flipped": len(viol),
+                     "xy_violations": int(counts[1]), "area_flips": int(np.count_nonzero(flipped))}
+
+    # The windows of a pass are independent and the host work per window (numpy index work, ~7 ms) dwarfs its kernels (~0.3 ms), so
+    # the rank walks its windows with --cfg5-threads workers, each with a context (= stream) of its own; numpy and the library calls
+    # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
+    n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else (2 if on_device else 4)))
+    worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
+
+    def walk(windows, wctx, out):
+        if on_device:
+            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, windows, no_match_penalty=100.0, ctx=wctx, **path_kw):
+                if dw.error is None:
+                    with _trace.stage("table (bench step)"):
+                        out.append((dw.window["window_id"], *device_table(dw)))
+            return
+        for wa in iter_window_arrays(ref_sec, mov_sec, windows, cost_dtype=np.float32, ctx=wctx, **path_kw):
+            if wa.error is not None:              # a window whose prune leaves no pairs (src/same.py:1003)
+                continue
+            with _trace.stage("incumbent + sweeps + table (bench step)"):
+                out.append((wa.window["window_id"], *run_window(wa, wctx)))
+
+    def one_pass(windows):
+        import threading
+
+        outs = [[] for _ in range(n_workers)]
+        if n_workers == 1:
+            walk(windows, ctx, outs[0])
+        else:
+            errors = []
+
+            def guarded(q):
+                try:
+                    walk(windows[q::n_workers], worker_ctx[q], outs[q])
+                except BaseException as e:   # noqa: BLE001 -- re-raised in the main thread below
+                    errors.append(e)
+
+            threads = [threading.Thread(target=guarded, args=(q,)) for q in range(n_workers)]
+            [t.start() for t in threads]
+            [t.join() for t in threads]
+            if errors:
+                raise errors[0]
+        pos = {w["window_id"]: q for q, w in enumerate(windows)}
+        done = sorted((r for part in outs for r in part), key=lambda r: pos[r[0]])
+        return [r[1] for r in done], [r[2] for r in done]
+
+    def step():
+        tabs, stats = one_pass(my_plan)
+        mine_tab = {c: (np.concatenate([t[c] for t in tabs]) if tabs else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
+        mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
+        with _trace.stage("table exchange (all-gather)"):
+            every = allgather_table(ctx, comm, group, mine_tab)          # the ONE exchange: one table per rank, a device all-gather
+            if comm is not None:
+                ms, nbytes = last_table_gather()
+                exchange_ms.append(ms)
+                exchange_bytes[0] = nbytes
+        merged = None
+        if group.rank == 0:                                              # the merged table is the job's result: rank 0 holds it
+            with _trace.stage("merge (device de-duplication + host matching)"):
+                frames = [pd.DataFrame(dict(t, filtered_violation=t["filtered_violation"].astype(bool))) for t in every if len(t["X"])]
+                merged = merge_window_matches_unique_ref(frames)
+        return merged, stats
+
+    from same_amd import qhull_pool as _qp
+
+    exchange_ms, exchange_bytes = [], [0]
+
+    # warm-up: scratch slots, Qhull helpers, first-launch costs -- and, on the device path, every window state a worker keeps
+    # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
+    n_warm = (_qp.lookahead() + 1) * n_workers if on_device else 2
+    for _ in range(warmup):
+        one_pass(my_plan[: max(1, min(n_warm, len(my_plan)))])
+    group.barrier()
+    _trace.reset()
+    calls0 = [c.stats() for c in worker_ctx]
+    t0 = time.perf_counter()
+    merged = stats = None
+    for _ in range(steps):
+        merged, stats = step()
+    group.barrier()
+    wall_here = time.perf_counter() - t0
+    calls1 = [c.stats() for c in worker_ctx]
+    n_done = max(1, len(stats) * steps)
+    calls_per_window = {k_: sum(b[k_] - a[k_] for a, b in zip(calls0, calls1)) / n_done for k_ in calls1[0]}
+    dt = group.max(wall_here)
+    rep = _trace.report()
+    in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:"))
+    stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
+    lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
+    qhull_wait = sum(sec for name, (_c, sec) in rep.items() if name.startswith("triangulate"))
+    mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * steps / wall_here,
+                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / (wall_here * n_workers), "threads": n_workers,
+                "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / (wall_here * n_workers)),
+                "runtime_calls_per_window": calls_per_window, "table_allgather_ms": (sum(exchange_ms) / len(exchange_ms)) if exchange_ms else None,
+                "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
+                "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
+                "triangles": int(sum(s["triangles"] for s in stats))}
+    every = group.allgather_object(mine_rec)
+    rccl = comm_report(Env(args, group, ctx, ctx, comm, transport), np) if comm is not None else None
+    # N=1: four windows through the oracle as the CPU baseline and as the parity check of what the GPU produced for them
+    cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
+    if group.rank == 0 and group.world == 1 and cpu_baseline:
+        from scipy.spatial import Delaunay
+
+        from oracle import same_oracle as orc
+
+        sample = [w for w in my_plan if w["n_mov"] > 1000][:4] or my_plan[:1]
+        t_cpu, done_pairs = 0.0, 0
+        for w in sample:
+            c0 = time.perf_counter()                 # the oracle's part of this window only: the GPU re-runs below are not the CPU's time
+            x0, x1, y0, y1 = w["box"]
+            rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
+            na, nr, pairs = orc.find_knn_within_radius(ms, rs, 25, 8)
+            pairs = np.asarray(pairs, dtype=np.int64)
+            axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
+            c32 = orc.pair_cost_arrays(na[cols].to_numpy(), nr[cols].to_numpy(), axy, rxy, pairs, 1.0, dtype=np.float32)
+            tri = np.asarray(orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
+                                                            min_angle_deg=15), dtype=np.int64).reshape(-1, 3)
+            signs = orc.source_signs(na, tri)
+            kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=c32.astype(np.float64), n_aligned=len(na), n_ref=len(nr),
+                      aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
+            och, _ = orc.compute_mip_start_pairs(**kw)
+            xo = np.zeros(len(pairs))
+            xo[[c[2] for c in och]] = 1.0
+            ochecked, oviol = orc.lazy_orientation_sweep(xo, pairs, tri, signs, rxy, len(na))
+            done_pairs += w["n_mov"] * w["n_ref"]
+            t_cpu += time.perf_counter() - c0
+            # the same window on the GPU, compared
+            prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
+            ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs) and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
+                  and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri) and list(prep.source_signs) == list(signs))
+            gch, _ = same_amd.compute_mip_start_pairs(**dict(kw, valid_pairs=prep.valid_pairs, costs=prep.costs))
+            sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
+            gchecked, gviol, _ = sw.sweep(xo)
+            sw.bound.close()
+            ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
+            if ok and on_device:                 # and what the timed path itself computes for this window (csrc/window.hip)
+                nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
+                for hit in och:
+                    match_o[hit[0]] = nr_rows[hit[1]]
+                for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, fetch_triangles=True, **path_kw):
+                    dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
+                    ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
+                          and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])
+                          and np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), c32) and np.array_equal(dw.triangles, tri)
+                          and np.array_equal(dw.state.fetch(W._W_SIGNS), np.asarray(signs, dtype=np.int8))
+                          and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
+            if not ok:
+                raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
+        parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
+                  "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
+        cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+               "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
+                         f"through oracle/same_oracle.{{c,py}} in {t_cpu:.2f} s, 1 thread (frame subsetting included; the GPU re-runs of the same windows for the "
+                         "comparison are not in this time)",
+               "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on this box"}
+    out = None
+    if group.rank == 0:
+        total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
+        es, k = 4, 8
+        P, Tr = sum(r["pairs"] for r in every), sum(r["triangles"] for r in every)
+        touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)   # SURVEY 8d per-unit figures
+        lib_s = max(r["in_library_s"] for r in every) / steps
+        out = {"metric": baseline_metric(), "value": total_pairs * steps / dt, "unit": "cell-pairs/s", "n_gpus": group.world,
+               "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
+                                      f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
+                                      "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
+                          "pipeline": ("device: both sections resident in HBM, two library calls per window (csrc/window.hip); the host triangulates (Qhull "
+                                       "helpers), runs the triangle filter's re-add pass and receives the match" if on_device
+                                       else "columns: subsetting, compaction and gathers on the host, every kernel through host buffers"),
+                          "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
+                                         "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
+               "windows_per_s": len(plan) * steps / dt,
+               "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
+                            "host_glue_share": [r["host_glue_share"] for r in every], "python_share": [r["python_share"] for r in every],
+                            "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
+                            "in_library_s_per_step": [r["in_library_s"] / steps for r in every],
+                            "table_allgather_ms": [r["table_allgather_ms"] for r in every], "qhull_helpers": [r["qhull_helpers"] for r in every],
+                            "qhull_l3_domains": [r["qhull_domains"] for r in every]},
+               "host_glue_share": mine_rec["host_glue_share"],
+               "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
+                                        "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
+               "python_share": mine_rec["python_share"],
+               "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes of the "
+                                     "threads' time (the merge and the table exchange included)",
+               "threads_per_rank": n_workers,
+               "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
+               "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued per window on rank 0, "
+                                                 "counted by the library itself (same_ctx_stat) over the timed passes; the merge's de-duplication included",
+               "table_allgather": None if comm is None else {
+                   "ms": mine_rec["table_allgather_ms"], "bytes_per_rank": int(exchange_bytes[0]), "bytes_total": int(exchange_bytes[0]) * group.world,
+                   "timed_with": ("HIP events on the stream the all-gather ran on (same_comm_gather_time), rank 0" if not comm.synchronous
+                                  else "host wall time of the host-transport exchange (no RCCL communicator), rank 0")},
+               "qhull": {"helpers": _qp.pool().n, "helpers_all_ranks": sum(r["qhull_helpers"] for r in every), "ranks_on_this_host": every[0]["local_world"],
+                         "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
+                         "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / steps,
+                         "what": "helper processes that run scipy.spatial.Delaunay for the windows ahead (a6 stays on the host); waiting = the worker "
+                                 "threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
+               "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
+               "merged_matches": int(len(merged)),
+               "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (the padded / pair cost kernel is the largest)",
+                            "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "algorithmic_bytes_per_step": touched,
+                            "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
+                                    "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by launch latency and host "
+                                    "glue, not by HBM -- see host_glue_share"},
+               "cpu_baseline": cpu, "parity_spot_check": parity}
+        if rccl is not None:
+            out["rccl"] = rccl
+    group.barrier()
+    for sec in (dref, dmov):
+        if sec is not None:
+            sec.close()
+    for c in worker_ctx[1:]:
+        c.close()
+    return out if group.rank == 0 else None

@@ -166,7 +166,7 @@ int same_comm_wait(same_ctx *ctx) {
     return SAME_OK;
 }
 
-// Device time of the overlapped gathers issued since the last same_comm_wait: from the moment the communication stream
+// Device time of the gathers issued since the last same_comm_wait (or the last call of this function): from the moment the communication stream
 // was released by the producer (its first gather could start) to the end of its last gather, HIP events on that stream.
 // Blocks the host until that last gather has finished.
 int same_comm_gather_time(same_ctx *ctx, float *out_ms, int64_t *out_send_bytes) {
@@ -177,6 +177,8 @@ int same_comm_gather_time(same_ctx *ctx, float *out_ms, int64_t *out_send_bytes)
     if (!ctx->gather_stamped) return SAME_OK;   // no gather issued yet
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_gathered));
     HIP_TRY(ctx, hipEventElapsedTime(out_ms, ctx->ev_gather0, ctx->ev_gathered));
+    ctx->gather_open = false;   // a read closes the batch too: callers of the in-stream form alone never call same_comm_wait, and
+                                // their next gather must not be timed from the first one ever issued
     return SAME_OK;
 }
 

@@ -541,7 +541,7 @@ void same_knn_index_destroy(same_knn_index *ix) {
 
 int same_knn_prune_indexed_dev(same_ctx *ctx, const same_knn_index *ix, const double *daxy, int64_t row_begin,
                                int64_t row_end, int k, int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt) {
-    REQUIRE(ctx, ctx && ix && ix->device == ctx->device && daxy && dout_idx && dout_cnt);
+    REQUIRE(ctx, ctx && ix && ix->ctx == ctx && daxy && dout_idx && dout_cnt);   // the public form: the index of this very context
     REQUIRE(ctx, row_begin >= 0 && row_end >= row_begin && k >= 1 && k <= SAME_MAX_KNN);
     SAME_TRY(same_use(ctx));
     if (row_end == row_begin) return SAME_OK;

@@ -395,6 +395,15 @@ def _unpack_table(raw, cols, arrs, rank):
     return part
 
 
+_last_table_gather = [0.0, 0]    # (ms on the gather's stream or host wall ms, bytes this rank sent) of the latest allgather_table
+
+
+def last_table_gather():
+    """(ms, bytes sent by this rank) of the latest allgather_table's collective: HIP events on its stream (RCCL), host wall time
+    (host transport)."""
+    return tuple(_last_table_gather)
+
+
 def allgather_table(ctx, comm, group, table):
     """One exchange of per-rank tables (dict: column -> 1-D numeric array, all of one length, same columns / dtypes on every
     rank) as a DEVICE collective: the columns are packed into one byte block per rank, padded to the longest, all-gathered with
@@ -414,6 +423,13 @@ def allgather_table(ctx, comm, group, table):
     blob = _pack_table(cols, arrs, n)
     if ctx is None:
         return [_unpack_table(raw, cols, arrs, r) for r, raw in enumerate(group.allgather_bytes(blob))]
+    if getattr(comm, "synchronous", False):     # host transport (no RCCL communicator): the block is host bytes already -- no device round trip
+        import time
+
+        t0 = time.perf_counter()
+        parts = group.allgather_bytes(blob)
+        _last_table_gather[:] = ((time.perf_counter() - t0) * 1e3, len(blob))
+        return [_unpack_table(raw, cols, arrs, r) for r, raw in enumerate(parts)]
     sizes = [struct.unpack("<Q", p)[0] for p in group.allgather_bytes(struct.pack("<Q", len(blob)))]
     width = (max(sizes) + 255) & ~255
     send, recv = ctx.alloc(width), ctx.alloc(width * group.world)
@@ -421,9 +437,11 @@ def allgather_table(ctx, comm, group, table):
         padded = np.zeros(width, np.uint8)
         padded[: len(blob)] = np.frombuffer(blob, np.uint8)
         send.upload(padded)
+        comm.wait()                                # a fresh timing batch: gather_time() below is this exchange alone
         comm.allgather_dev(send, recv, width)
         ctx.sync()
         got = recv.download((group.world, width), np.uint8)
+        _last_table_gather[:] = comm.gather_time()
     finally:
         send.free()
         recv.free()

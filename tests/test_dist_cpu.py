@@ -282,7 +282,9 @@ def test_bench_launches_its_own_ranks(world):
     assert [r["rank"] for r in d["ranks"]] == list(range(world)) and all(r["id_ok"] for r in d["ranks"])
     assert len({r["pid"] for r in d["ranks"]}) == world            # fresh processes, one per rank
     # the contract of the real N > 1 line (bench.py refuses to write a line that lacks one of these; the GPU suite checks their contents)
-    assert set(d["line_keys_at_n_gt_1"]) == {"rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank", "strong_cfg4"}
+    assert set(d["line_keys_at_n_gt_1"]) == {"rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank", "strong_cfg4", "cfg5"}
+    # every rank was told how many share the host: the Qhull helper budget is divided by it (same_amd/qhull_pool.py)
+    assert [r["local_world"] for r in d["ranks"]] == [world] * world and sum(r["qhull_helpers"] for r in d["ranks"]) <= max(24, world)
     assert {"value", "ms_per_step", "gather", "gather_hidden_ms", "per_rank_dense_ms", "parity_spot_check"} <= set(d["strong_record_keys"])
 
 
@@ -319,8 +321,9 @@ def test_bench_launcher_reports_a_failed_rank():
 
 
 def test_bench_is_torch_free():
-    src = open(os.path.join(ROOT, "bench.py")).read() + open(os.path.join(ROOT, "same_amd", "dist.py")).read() + \
-        open(os.path.join(ROOT, "same_amd", "rendezvous.py")).read()
+    src = "".join(open(os.path.join(ROOT, *parts)).read() for parts in (("bench.py",), ("same_amd", "dist.py"), ("same_amd", "rendezvous.py"),
+                                                                        ("same_amd", "bench_common.py"), ("same_amd", "bench_launch.py"),
+                                                                        ("same_amd", "bench_cfg5.py"), ("same_amd", "qhull_pool.py")))
     assert "import torch" not in src and "from torch" not in src
 
 

@@ -523,7 +523,7 @@ def test_bench_cfg5_windows_line(world):
     assert all(0.0 <= v < 1.0 for v in pr["host_glue_share"]) and out["windows_per_s"] > 0 and out["merged_matches"] > 1000
     assert out["config"]["pipeline"].startswith("device: both sections resident in HBM")
     assert any(k.startswith("subset + prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
-    assert {"same_window_stage", "same_window_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
+    assert {"same_window_stage", "same_window_filter_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
     assert out["qhull"]["helpers"] >= 0 and out["qhull"]["waiting_s_per_step_rank0"] >= 0 and out["qhull"]["cpu_budget"] >= 1
     assert 0.0 <= out["python_share"] <= out["host_glue_share"] and len(pr["python_share"]) == world
     rf = out["roofline"]
@@ -541,32 +541,38 @@ def test_bench_cfg5_windows_line(world):
         assert out["cpu_baseline"] is None
 
 
-def test_bench_line_embeds_a_cfg5_record():
-    """The default line carries BASELINE cfg 5 as a sub-record measured by a child job (`--embed-cfg5`, automatic with the default
-    workload; forced here on the tiny one at a reduced section): windows/s, the pipeline, the Qhull record, the merged table's
-    size, and at one rank the child's own oracle check.  A child that cannot run leaves an error entry, not a broken line."""
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_line_embeds_a_cfg5_record(world):
+    """Every line of the default workload carries BASELINE cfg 5 as a sub-record measured IN THE SAME JOB -- its ranks, their
+    contexts, the communicator; no child process -- at one rank or N (`--embed-cfg5`, automatic with the default workload; forced
+    here on the tiny one at a reduced section): windows/s per rank, the pipeline, the Qhull record with the helper budget divided
+    by the ranks on the host, the table all-gather's time, the merged table's size, and at one rank the oracle check of four windows."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SAME_RDV_DIR", "SAME_QHULL_WORKERS")}
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
-           "--embed-cfg5", "on", "--cfg5-cells", "60000"]
+           "--no-strong-record", "--embed-cfg5", "on", "--cfg5-cells", "60000", "--gpus", str(world)]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     rec = json.loads(lines[0])["cfg5"]
     assert "error" not in rec, rec
-    assert rec["n_gpus"] == 1 and rec["windows_per_s"] > 0 and rec["merged_matches"] > 1000 and rec["pipeline"].startswith("device:")
-    assert rec["workload"].startswith("cfg5: 60000-cell section") and rec["qhull"]["helpers"] >= 0 and rec["child_job_s"] > 0
-    assert "through the device-resident window path" in rec["parity_spot_check"]
-    res = subprocess.run(cmd, env=dict(env, SAME_BENCH_CFG5_TIMEOUT="0.05"), cwd=root, capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0, res.stderr[-3000:]
-    out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
-    assert out["value"] > 0 and "no line after" in out["cfg5"]["error"]
+    assert rec["n_gpus"] == world and rec["windows_per_s"] > 0 and rec["merged_matches"] > 1000 and rec["pipeline"].startswith("device:")
+    assert rec["workload"].startswith("cfg5: 60000-cell section")
+    pr = rec["per_rank"]
+    assert len(pr["windows"]) == len(pr["windows_per_s"]) == len(pr["qhull_helpers"]) == world and sum(pr["windows"]) >= 4
+    assert rec["qhull"]["ranks_on_this_host"] == world and rec["qhull"]["helpers_all_ranks"] == sum(pr["qhull_helpers"]) <= max(24, world)
+    calls = rec["runtime_calls_per_window"]
+    assert calls["launches"] <= 30 and calls["fills"] <= 4 and calls["copies"] <= 4 and calls["waits"] <= 3
+    if world == 1:
+        assert "through the device-resident window path" in rec["parity_spot_check"] and rec["table_allgather"] is None
+    else:
+        assert rec["table_allgather"]["ms"] > 0 and rec["table_allgather"]["bytes_per_rank"] > 0 and len(pr["table_allgather_ms"]) == world
 
 
 def test_bench_step_with_the_fixed_point_dense_build():
