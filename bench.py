@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
     ap.add_argument("--embed-cfg5", choices=("auto", "on", "off"), default="auto",
                     help="after the timed loop, run BASELINE cfg 5 (the step of `--workload cfg5`) on this job's ranks and embed its numbers as `cfg5` "
-                         "(auto: with the default workload, at any rank count)")
+                         "(auto: with the default workload at any rank count, and with cfg2 / cfg4 at N > 1)")
     ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
                     help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
                          "and hands every kernel host buffers")
@@ -760,7 +760,9 @@ def run_rank(args):
 
     # ---- BASELINE cfg 5 as an embedded record, IN THIS JOB (its ranks, their contexts, the communicator): the same at 1 rank or 8 ----
     cfg5_rec = None
-    want_cfg5 = args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and args.workload == "dense100k" and not strong and not args.no_extras)
+    # auto: the default workload at any rank count, and every full-size workload at N > 1 (`tiny` is the test suite's: it asks with "on")
+    want_cfg5 = args.embed_cfg5 == "on" or (args.embed_cfg5 == "auto" and not strong and not args.no_extras
+                                            and (args.workload == "dense100k" or (group.world > 1 and args.workload != "tiny")))
     if want_cfg5:
         from same_amd import bench_cfg5
 

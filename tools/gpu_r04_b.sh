@@ -19,6 +19,8 @@ P
 }
 run 1m
 run 1m_2rank --gpus 2 --no-cpu-baseline
+timeout -k 10 400 python3 bench.py --gpus 2 --workload cfg2 --no-cpu-baseline --steps 3 --warmup 1 > $out/bench_2rank_cfg2.json 2> $out/bench_2rank_cfg2.err || { tail -20 $out/bench_2rank_cfg2.err; exit 1; }
+python3 -c "import json;d=json.loads(open(\"$out/bench_2rank_cfg2.json\").read().strip().splitlines()[-1]);c=d[\"cfg5\"];print(\"2 ranks cfg2 line: cfg5 record\", c.get(\"windows_per_s\"), c.get(\"per_rank\",{}).get(\"windows_per_s\"), c.get(\"table_allgather\"), c.get(\"qhull\"))"
 run 4m --cfg5-cells 4000000 --no-cpu-baseline
 run 1m_t1 --cfg5-threads 1 --no-cpu-baseline
 run 1m_t3 --cfg5-threads 3 --no-cpu-baseline
