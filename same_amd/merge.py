@@ -34,7 +34,10 @@ def _window_codes(window_id):
     w = np.asarray(window_id)
     if w.dtype.kind in "iu" and (len(w) == 0 or (w.min() >= 0 and w.max() < 2 ** 31)):
         return w.astype(np.int32)
-    return np.unique(w, return_inverse=True)[1].astype(np.int32)
+    # ranks in sorted order; missing ids (None / NaN in an object or float column) go last, where the reference's sort_values
+    # (na_position='last', src/helpers.py:748) puts them
+    codes, uniques = pd.factorize(w, sort=True)
+    return np.where(codes < 0, len(uniques), codes).astype(np.int32)
 
 
 def _equality_codes(values):
@@ -80,7 +83,7 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
     if _dedup is None:
         from . import ops
 
-        _dedup = ops.merge_dedup
+        _dedup = ops.merge_dedup      # the device step; there is no host substitute in the product (a missing GPU raises SameHipError)
     with marked("merge: de-duplication (codes + device)"):
         kept = _dedup(merged_df["filtered_violation"].to_numpy(), _window_codes(merged_df["window_id"].to_numpy()),
                       _equality_codes(merged_df[aligned_col].values), _equality_codes(merged_df[ref_col].values))

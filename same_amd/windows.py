@@ -550,3 +550,6 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
         if last is not None:
             free.append(last)
         cache.extend(free)
+        for extra in cache[want:]:            # a context keeps what one pass needs, not every state it ever had
+            extra.close()
+        del cache[want:]

@@ -6,7 +6,10 @@ root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p $out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-echo "== valu issue probe" && timeout -k 10 120 tools/probes/valu_issue > $out/valu_issue.log 2>&1; cat $out/valu_issue.log
+echo "== valu issue probe"
+[ -x tools/probes/valu_issue ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/probes/valu_issue tools/probes/valu_issue.hip || { echo "cannot build tools/probes/valu_issue"; exit 1; }
+timeout -k 10 120 tools/probes/valu_issue > $out/valu_issue.log 2>&1 || { cat $out/valu_issue.log; exit 1; }
+cat $out/valu_issue.log
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 60 rocprofv3 -L > $out/counters_avail.txt 2>&1 || true
 pass() {  # name, dtype, counters...

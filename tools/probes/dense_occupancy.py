@@ -1,10 +1,15 @@
 """Probe: one dense build (dtype, T) looped alone for ~2.5 s at whatever occupancy SAME_DENSE_LDS_PAD leaves it, with board
 power / shader clock sampled from sysfs -- is the kernel bound by VALU issue (time grows as waves per SIMD shrink) or by
 the board power cap (the clock rises as the VALU idles, time stays)?
-Usage: SAME_DENSE_LDS_PAD=<bytes> python tools/probes/dense_occupancy.py f32|f64 T [n]"""
+Usage: SAME_DENSE_LDS_PAD=<bytes> python tools/probes/dense_occupancy.py f32|f64 T [n]
+HISTORICAL: csrc/cost.hip had the SAME_DENSE_LDS_PAD switch only up to commit 2b8b3b4 (where profiles/r03_dense_occupancy.log was
+taken); against a later library every setting measures the same kernel, so the probe refuses to run there."""
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if b"SAME_DENSE_LDS_PAD" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "same_amd",
+                                                  "libsame_hip.so"), "rb").read():
+    sys.exit("this libsame_hip.so has no SAME_DENSE_LDS_PAD switch (removed after commit 2b8b3b4): the sweep would label one kernel four ways")
 from same_amd import _lib, synth
 from same_amd.telemetry import GpuTelemetry
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL: the occupancy sweep below drives the SAME_DENSE_LDS_PAD switch, which csrc/cost.hip had only up to commit 2b8b3b4;
+# at HEAD every leg runs the same kernel.  Check that commit out to repeat profiles/r03_dense_occupancy.log.
 # Round-3 visit B: occupancy sweep of the fp32 / fp64 T=20 dense kernels with power + clock telemetry.
 set -o pipefail
 tag=${1:-r03b}
