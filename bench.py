@@ -769,7 +769,7 @@ def run_rank(args):
         note(group, "embedded cfg5 record: the window configuration on this job's ranks")
         try:
             line5 = bench_cfg5.run(args, group, tctx, comm, transport.replace(" (overlapped on a second stream)", "").replace("pruned lists", "the ranks' match tables"),
-                                   3, 1, cpu_baseline=group.world == 1)   # one rank: four windows through the oracle, as parity check and CPU figure
+                                   3, 1, cpu_baseline=cfg5_oracle_leg)   # used at one rank: four windows through the oracle, as parity check and CPU figure
             cfg5_rec = bench_cfg5.record(line5) if group.rank == 0 else None
         except SystemExit:
             raise                                     # a parity failure inside the record is a failure of the line
@@ -934,6 +934,75 @@ def run_rank(args):
     group.close()
 
 
+def cfg5_oracle_leg(st):
+    """The cpu_baseline leg of the cfg 5 step (same_amd/bench_cfg5.py calls it on rank 0 at one rank): four windows through the CPU
+    oracle -- timed: that is `cpu_baseline` -- and the same windows on the GPU, through prepare_same_inputs and through the timed
+    device-resident path, compared bit for bit.  Lives here because only bench.py's cpu_baseline leg may import the oracle."""
+    import numpy as np
+
+    import same_amd
+    from same_amd import windows as W
+    from same_amd.windows import iter_device_windows
+
+    plan, my_plan, r_df, m_df, cols, op = st["plan"], st["my_plan"], st["r_df"], st["m_df"], st["cols"], st["op"]
+    ref_sec, mov_sec, dref, dmov, path_kw, ctx, on_device = st["ref_sec"], st["mov_sec"], st["dref"], st["dmov"], st["path_kw"], st["ctx"], st["on_device"]
+    from scipy.spatial import Delaunay
+
+    from oracle import same_oracle as orc
+
+    sample = [w for w in my_plan if w["n_mov"] > 1000][:4] or my_plan[:1]
+    t_cpu, done_pairs = 0.0, 0
+    for w in sample:
+        c0 = time.perf_counter()                 # the oracle's part of this window only: the GPU re-runs below are not the CPU's time
+        x0, x1, y0, y1 = w["box"]
+        rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
+        na, nr, pairs = orc.find_knn_within_radius(ms, rs, 25, 8)
+        pairs = np.asarray(pairs, dtype=np.int64)
+        axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
+        c32 = orc.pair_cost_arrays(na[cols].to_numpy(), nr[cols].to_numpy(), axy, rxy, pairs, 1.0, dtype=np.float32)
+        tri = np.asarray(orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
+                                                        min_angle_deg=15), dtype=np.int64).reshape(-1, 3)
+        signs = orc.source_signs(na, tri)
+        kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=c32.astype(np.float64), n_aligned=len(na), n_ref=len(nr),
+                  aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
+        och, _ = orc.compute_mip_start_pairs(**kw)
+        xo = np.zeros(len(pairs))
+        xo[[c[2] for c in och]] = 1.0
+        ochecked, oviol = orc.lazy_orientation_sweep(xo, pairs, tri, signs, rxy, len(na))
+        done_pairs += w["n_mov"] * w["n_ref"]
+        t_cpu += time.perf_counter() - c0
+        # the same window on the GPU, compared
+        prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
+        ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs) and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
+              and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri) and list(prep.source_signs) == list(signs))
+        gch, _ = same_amd.compute_mip_start_pairs(**dict(kw, valid_pairs=prep.valid_pairs, costs=prep.costs))
+        sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
+        gchecked, gviol, _ = sw.sweep(xo)
+        sw.bound.close()
+        ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
+        if ok and on_device:                 # and what the timed path itself computes for this window (csrc/window.hip)
+            nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
+            for hit in och:
+                match_o[hit[0]] = nr_rows[hit[1]]
+            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, fetch_triangles=True, **path_kw):
+                dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
+                ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
+                      and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])
+                      and np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), c32) and np.array_equal(dw.triangles, tri)
+                      and np.array_equal(dw.state.fetch(W._W_SIGNS), np.asarray(signs, dtype=np.int8))
+                      and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
+        if not ok:
+            raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
+    parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
+              "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
+    cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+           "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
+                     f"through oracle/same_oracle.{{c,py}} in {t_cpu:.2f} s, 1 thread (frame subsetting included; the GPU re-runs of the same windows for the "
+                     "comparison are not in this time)",
+           "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on this box"}
+    return cpu, parity
+
+
 def run_cfg5_workload(args, group, json_fd, local_rank):
     """`--workload cfg5`: the window configuration as the line itself (same_amd/bench_cfg5.py)."""
     from same_amd import _lib, bench_cfg5
@@ -941,7 +1010,7 @@ def run_cfg5_workload(args, group, json_fd, local_rank):
     os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
     ctx = _lib.default_context()
     comm, transport = make_comm(args, group, ctx, what="the ranks' match tables")   # a device all-gather (RCCL; host transport if that fails)
-    out = bench_cfg5.run(args, group, ctx, comm, transport, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline)
+    out = bench_cfg5.run(args, group, ctx, comm, transport, args.steps, args.warmup, cpu_baseline=None if args.no_cpu_baseline else cfg5_oracle_leg)
     if group.rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()

@@ -49,6 +49,22 @@ extern "C" {
 typedef struct same_ctx same_ctx;
 typedef struct same_sweep same_sweep; /* resident state of one lazy-constraint sweep (same_sweep_bind) */
 
+/* ---- index of this header ------------------------------------------------------------------------------------------------------
+ * part 0  context, device memory, timers, runtime-call counters      same_ctx_*, same_dev_*, same_h2d / d2h / d2d, same_timer_*, same_ctx_stat
+ * part 1  HOST-BUFFER entry points (caller's arrays in and out; one   same_pair_cost_*, same_dense_cost_f64 / f32, same_knn_prune, same_tri_*, same_sweep_* /
+ *         call = upload, kernels, download, wait)                     same_orient_sweep*, same_xyorder_sweep, same_area_flip, same_pair_rowmin,
+ *                                                                     same_assign_matrix, same_greedy_*, same_tri_flip_stats, same_collapse_candidates,
+ *                                                                     same_batched_assign, same_eager_signs, same_window_count, same_merge_dedup
+ * part 2  DEVICE-RESIDENT forms (operands already in HBM; enqueue     same_dense_cost_*_dev, same_quantize_u32_dev, same_dense_cost_q32_dev, same_knn_prune_dev,
+ *         only unless noted)                                          same_knn_index_*, same_knn_prune_indexed_dev, same_padded_cost_*_dev, same_tri_*_dev,
+ *                                                                     same_area_flip_dev, same_xyorder_sweep_dev, same_orient_*_dev, same_first_candidate_dev
+ * part 3  WINDOW path, sections resident (BASELINE cfg 5)             same_section_*, same_window_*
+ * part 4  COMM: RCCL collectives between the ranks' contexts          same_comm_*, same_allgather_dev*, same_allreduce_dev
+ * Every declaration cites the reference lines it replaces (file:line into the reference tree). */
+
+/* ======================================================================================================================
+ * part 0 -- context, device memory, timers
+ * ====================================================================================================================== */
 /* ---- context ------------------------------------------------------------------------- */
 int same_abi_version(void);
 int same_device_count(int *out_count);
@@ -113,6 +129,9 @@ int same_timer_stop(same_ctx *ctx, float *out_ms); /* records, synchronises, ret
 int same_timer_mark(same_ctx *ctx);
 int same_timer_read(same_ctx *ctx, float *out_ms);
 
+/* ======================================================================================================================
+ * part 1 -- HOST-BUFFER entry points: the caller's (NumPy) arrays in and out; synchronous
+ * ====================================================================================================================== */
 /* ---- a4: pair costs -------------------------------------------------------------------
  * Replaces the loop at src/same.py:1180-1189:
  *   c[p] = w * sum_t |A[i,t]-R[j,t]|  +  (w*0.001) * (|ax-rx| + |ay-ry|),  (i,j) = pairs[p]
@@ -131,42 +150,13 @@ int same_pair_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_
  * The same expression for every (i, j), i in [row_begin,row_end), j in [0,n_r):
  *   out[(i-row_begin)*ld + j].  Generalises the only dense matrix of the reference
  * (src/init_helpers.py:151-155) to the metric of BASELINE.json (100k x 100k).
- * _dev: all pointers are device pointers; A/R/axy/rxy hold the full arrays. */
-int same_dense_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
-                            const double *daxy, const double *drxy, int64_t n_r,
-                            int64_t row_begin, int64_t row_end, double w, double *dout, int64_t ld);
-int same_dense_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T,
-                            const float *daxy, const float *drxy, int64_t n_r, int64_t row_begin,
-                            int64_t row_end, float w, float *dout, int64_t ld);
-/* host-buffer forms (copy in, build, copy out) */
+ * The device-resident forms (same_dense_cost_*_dev, part 2) are what large operands use: this form copies in, builds, copies out. */
 int same_dense_cost_f64(same_ctx *ctx, const double *A, const double *R, int64_t n_m, int64_t n_r,
                         int T, const double *axy, const double *rxy, int64_t row_begin,
                         int64_t row_end, double w, double *out, int64_t ld);
 int same_dense_cost_f32(same_ctx *ctx, const float *A, const float *R, int64_t n_m, int64_t n_r,
                         int T, const float *axy, const float *rxy, int64_t row_begin,
                         int64_t row_end, float w, float *out, int64_t ld);
-
-/* ---- opt-in fixed-point dense build ---------------------------------------------------------
- * NOT the reference's arithmetic and never a default: the type values are put on a common 32-bit
- * fixed-point grid q(v) = rint((v - offset) * scale), the type sum becomes an exact integer sum of
- * absolute differences (one v_sad_u32 per element instead of two fp64 adds), the rest of the expression
- * is unchanged fp64:  out = w * (double(S_q) * inv_scale) + (w*0.001) * (|ax-rx| + |ay-ry|).
- * Against same_dense_cost_f64_dev: |S_q * inv_scale - S| <= T * inv_scale.  With rel_tol > 0 every type
- * sum of fewer than T / rel_tol + T grid steps (near-identical cells) is recomputed from the fp64
- * matrices dA / dR with the reference's own expression, so EVERY output is within rel_tol (relative) of
- * the fp64 build's -- rel_tol = 1e-6 is BASELINE.json's tolerance for fp64 costs; rel_tol = 0 keeps the
- * pure grid result (dA / dR may then be NULL).  The caller chooses offset / scale so that every
- * row-pair sum fits 32 bits (same_amd.ops.quantize_types); the row pitch ld must be even and columns
- * [n_r, ld) are written too (padding owned by the caller).  T <= SAME_Q32_MAX_TYPES.  Meant for the
- * dense matrix of the Hungarian MIP-start heuristic (src/init_helpers.py:151-155) and as the roofline
- * control of DESIGN.md 5.1 (the same 80 GB of stores without the fp64 adds). */
-#define SAME_Q32_MAX_TYPES 32
-int same_quantize_u32_dev(same_ctx *ctx, const double *dsrc, int64_t n, double offset, double scale,
-                          uint32_t *ddst);
-int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, const double *dA,
-                            const double *dR, int T, const double *daxy, const double *drxy, int64_t n_r,
-                            int64_t row_begin, int64_t row_end, double w, double inv_scale,
-                            double rel_tol, double *dout, int64_t ld);
 
 /* ---- a2: KNN prune within a radius ----------------------------------------------------
  * Replaces the per-row body of utils.find_knn_within_radius (src/utils.py:720-728):
@@ -178,33 +168,6 @@ int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *
 int same_knn_prune(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy, int64_t n_r,
                    int64_t row_begin, int64_t row_end, double radius, int k, int32_t *out_idx,
                    double *out_d2, int32_t *out_cnt);
-int same_knn_prune_dev(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r,
-                       int64_t row_begin, int64_t row_end, double radius, int k,
-                       int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt);
-/* Caller-held index of one reference set for one radius.  same_knn_prune_dev rebuilds the uniform grid
- * of the references (a counting sort) and reads their bounding box back on every call; when the same
- * references are pruned against repeatedly -- windows that share a reference section, the row blocks of
- * a sharded build, a benchmark step -- build the index once: same_knn_prune_indexed_dev then only
- * enqueues the query kernel (no rebuild, no host synchronisation) and returns bit-identical lists.
- * drxy is the caller's device array: it is not copied for the brute-force plan (small or degenerate
- * sets), so it must stay valid and unchanged until same_knn_index_destroy. */
-typedef struct same_knn_index same_knn_index;
-int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double radius,
-                         same_knn_index **out);
-void same_knn_index_destroy(same_knn_index *index);
-int same_knn_prune_indexed_dev(same_ctx *ctx, const same_knn_index *index, const double *daxy,
-                               int64_t row_begin, int64_t row_end, int k, int32_t *dout_idx,
-                               double *dout_d2, int32_t *dout_cnt);
-/* costs of the padded candidate lists (a2 + a4 fused for the sharded path, SURVEY 8e):
- * out_cost[(i-row_begin)*k + q] = pair cost of (i, idx[..]) or +inf where idx == -1. */
-int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
-                             const double *daxy, const double *drxy, int64_t row_begin,
-                             int64_t row_end, int k, const int32_t *didx, double w,
-                             double *dout_cost);
-int same_padded_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T,
-                             const float *daxy, const float *drxy, int64_t row_begin,
-                             int64_t row_end, int k, const int32_t *didx, float w,
-                             float *dout_cost);
 
 /* ---- a7: triangle classes -------------------------------------------------------------
  * Replaces the per-triangle decisions of helpers.filter_triangles_by_radius
@@ -263,38 +226,6 @@ int same_xyorder_sweep(same_ctx *ctx, const double *axy, int64_t n_m, const doub
 int same_area_flip(same_ctx *ctx, const double *axy, int64_t n_m, const double *rxy, int64_t n_r,
                    const int32_t *tris, int64_t Tr, const int32_t *match, double *out_before,
                    double *out_after, uint8_t *out_matched3, uint8_t *out_flipped);
-
-/* ---- device-resident forms of the triangle kernels and sweeps -------------------------
- * Same semantics as the host-buffer entry points above; every pointer is a device pointer
- * and the call only enqueues on the context's stream.  Index ranges are the caller's
- * responsibility here (the host-buffer forms validate them).  dcounts = 3 x uint64. */
-int same_tri_classify_dev(same_ctx *ctx, const double *dxy, const int32_t *dtris, int64_t Tr,
-                          double radius, int angle_enabled, double cos_thr, const int32_t *dtype_id,
-                          uint8_t *dout_class, double *dout_perim, double *dout_maxcos);
-int same_tri_sign_weight_dev(same_ctx *ctx, const double *dxy, const double *dsize,
-                             const int32_t *dtris, int64_t Tr, int8_t *dout_sign, double *dout_weight);
-int same_area_flip_dev(same_ctx *ctx, const double *daxy, const double *drxy, const int32_t *dtris,
-                       int64_t Tr, const int32_t *dmatch, double *dout_before, double *dout_after,
-                       uint8_t *dout_matched3, uint8_t *dout_flipped);
-int same_xyorder_sweep_dev(same_ctx *ctx, const double *daxy, int64_t n_m, const double *drxy,
-                           const int32_t *dtris, int64_t Tr, const int32_t *dmatch,
-                           uint8_t *dedge_flags, uint8_t *dtri_flag, uint8_t *dpoint_flag,
-                           uint64_t *dcounts);
-int same_orient_sweep_dev(same_sweep *sweep, const int32_t *dmatch, int64_t *out_checked,
-                          int32_t *out_viol_idx, int64_t *out_nviol);
-/* Triangle-block forms for the sweep sharded over GPUs (SURVEY 8e; the loops being sharded are
- * src/same.py:645-669 and src/violationhelper.py:53-117).  same_orient_flags_dev writes the flags of
- * triangles [t_begin, t_end) at their absolute positions dflag[t] (t_begin a multiple of 64) and only
- * enqueues; after the blocks of all ranks have been all-gathered into one flag array,
- * same_orient_from_flags_dev produces what same_orient_sweep produces: checked count and the ascending
- * list of flipped triangles (src/same.py:687-703 relies on that order).  The XY-order and area sweeps
- * shard by calling their _dev forms on offset pointers (dtris + 3*t_begin, outputs + t_begin). */
-int same_orient_flags_dev(same_sweep *sweep, const int32_t *dmatch, int64_t t_begin, int64_t t_end,
-                          uint8_t *dflag);
-int same_orient_from_flags_dev(same_sweep *sweep, const uint8_t *dflag, int64_t *out_checked,
-                               int32_t *out_viol_idx, int64_t *out_nviol);
-/* dmatch[i] = didx[i*k]: the nearest candidate of every row of a padded candidate list (-1 = none). */
-int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, int k, int32_t *dmatch);
 
 /* ---- a5: MIP-start helpers ------------------------------------------------------------
  * Per-row minimum pair cost (src/init_helpers.py:118-122; +inf for rows without pairs) and
@@ -363,6 +294,115 @@ int same_eager_signs(same_ctx *ctx, const double *rxy, int64_t n_r, const int32_
 int same_window_count(same_ctx *ctx, const double *xy, int64_t n, const double *boxes,
                       int64_t n_boxes, int64_t *out_count, uint8_t *out_mask);
 
+/* ---- f3: window merge, the de-duplication step ------------------------------------------
+ * Replaces src/helpers.py:745-753 (merged_df.sort_values(['filtered_violation', 'window_id'], kind='mergesort') then
+ * drop_duplicates([aligned, ref], keep='first')): rows i = 0..n-1 of the concatenated per-window match tables carry a
+ * violation flag, a window id and integer codes of their aligned / ref ids (equal ids <=> equal codes; any
+ * non-negative int32).  out_rows receives the indices of the rows that survive, in the order the reference's frame has
+ * after those two calls (stable by violation, then window id; first row of every pair); *out_n their number.
+ * The maximum-cardinality matching that follows (:755-815) is sequential and stays with the caller. */
+int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_t *window_id, const int32_t *aligned_code,
+                     const int32_t *ref_code, int64_t n, int32_t *out_rows, int64_t *out_n);
+
+/* ======================================================================================================================
+ * part 2 -- DEVICE-RESIDENT forms: every pointer is a device pointer of the context's GPU; calls enqueue on the context's stream
+ * ====================================================================================================================== */
+/* ---- dense cost tile builder, operands resident (the roofline kernel of the bench; expression and indexing as
+ * same_dense_cost_f64 in part 1): all pointers are device pointers; dA / dR / daxy / drxy hold the full arrays. */
+int same_dense_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
+                            const double *daxy, const double *drxy, int64_t n_r,
+                            int64_t row_begin, int64_t row_end, double w, double *dout, int64_t ld);
+int same_dense_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T,
+                            const float *daxy, const float *drxy, int64_t n_r, int64_t row_begin,
+                            int64_t row_end, float w, float *dout, int64_t ld);
+
+/* ---- opt-in fixed-point dense build ---------------------------------------------------------
+ * NOT the reference's arithmetic and never a default: the type values are put on a common 32-bit
+ * fixed-point grid q(v) = rint((v - offset) * scale), the type sum becomes an exact integer sum of
+ * absolute differences (one v_sad_u32 per element instead of two fp64 adds), the rest of the expression
+ * is unchanged fp64:  out = w * (double(S_q) * inv_scale) + (w*0.001) * (|ax-rx| + |ay-ry|).
+ * Against same_dense_cost_f64_dev: |S_q * inv_scale - S| <= T * inv_scale.  With rel_tol > 0 every type
+ * sum of fewer than T / rel_tol + T grid steps (near-identical cells) is recomputed from the fp64
+ * matrices dA / dR with the reference's own expression, so EVERY output is within rel_tol (relative) of
+ * the fp64 build's -- rel_tol = 1e-6 is BASELINE.json's tolerance for fp64 costs; rel_tol = 0 keeps the
+ * pure grid result (dA / dR may then be NULL).  The caller chooses offset / scale so that every
+ * row-pair sum fits 32 bits (same_amd.ops.quantize_types); the row pitch ld must be even and columns
+ * [n_r, ld) are written too (padding owned by the caller).  T <= SAME_Q32_MAX_TYPES.  Meant for the
+ * dense matrix of the Hungarian MIP-start heuristic (src/init_helpers.py:151-155) and as the roofline
+ * control of DESIGN.md 5.1 (the same 80 GB of stores without the fp64 adds). */
+#define SAME_Q32_MAX_TYPES 32
+int same_quantize_u32_dev(same_ctx *ctx, const double *dsrc, int64_t n, double offset, double scale,
+                          uint32_t *ddst);
+int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, const double *dA,
+                            const double *dR, int T, const double *daxy, const double *drxy, int64_t n_r,
+                            int64_t row_begin, int64_t row_end, double w, double inv_scale,
+                            double rel_tol, double *dout, int64_t ld);
+
+/* ---- a2 on resident operands: the prune of same_knn_prune (part 1) with device pointers, the caller-held index, the costs of
+ * the padded candidate lists */
+int same_knn_prune_dev(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r,
+                       int64_t row_begin, int64_t row_end, double radius, int k,
+                       int32_t *dout_idx, double *dout_d2, int32_t *dout_cnt);
+/* Caller-held index of one reference set for one radius.  same_knn_prune_dev rebuilds the uniform grid
+ * of the references (a counting sort) and reads their bounding box back on every call; when the same
+ * references are pruned against repeatedly -- windows that share a reference section, the row blocks of
+ * a sharded build, a benchmark step -- build the index once: same_knn_prune_indexed_dev then only
+ * enqueues the query kernel (no rebuild, no host synchronisation) and returns bit-identical lists.
+ * drxy is the caller's device array: it is not copied for the brute-force plan (small or degenerate
+ * sets), so it must stay valid and unchanged until same_knn_index_destroy. */
+typedef struct same_knn_index same_knn_index;
+int same_knn_index_build(same_ctx *ctx, const double *drxy, int64_t n_r, double radius,
+                         same_knn_index **out);
+void same_knn_index_destroy(same_knn_index *index);
+int same_knn_prune_indexed_dev(same_ctx *ctx, const same_knn_index *index, const double *daxy,
+                               int64_t row_begin, int64_t row_end, int k, int32_t *dout_idx,
+                               double *dout_d2, int32_t *dout_cnt);
+/* costs of the padded candidate lists (a2 + a4 fused for the sharded path, SURVEY 8e):
+ * out_cost[(i-row_begin)*k + q] = pair cost of (i, idx[..]) or +inf where idx == -1. */
+int same_padded_cost_f64_dev(same_ctx *ctx, const double *dA, const double *dR, int T,
+                             const double *daxy, const double *drxy, int64_t row_begin,
+                             int64_t row_end, int k, const int32_t *didx, double w,
+                             double *dout_cost);
+int same_padded_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int T,
+                             const float *daxy, const float *drxy, int64_t row_begin,
+                             int64_t row_end, int k, const int32_t *didx, float w,
+                             float *dout_cost);
+
+/* ---- device-resident forms of the triangle kernels and sweeps -------------------------
+ * Same semantics as the host-buffer entry points above; every pointer is a device pointer
+ * and the call only enqueues on the context's stream.  Index ranges are the caller's
+ * responsibility here (the host-buffer forms validate them).  dcounts = 3 x uint64. */
+int same_tri_classify_dev(same_ctx *ctx, const double *dxy, const int32_t *dtris, int64_t Tr,
+                          double radius, int angle_enabled, double cos_thr, const int32_t *dtype_id,
+                          uint8_t *dout_class, double *dout_perim, double *dout_maxcos);
+int same_tri_sign_weight_dev(same_ctx *ctx, const double *dxy, const double *dsize,
+                             const int32_t *dtris, int64_t Tr, int8_t *dout_sign, double *dout_weight);
+int same_area_flip_dev(same_ctx *ctx, const double *daxy, const double *drxy, const int32_t *dtris,
+                       int64_t Tr, const int32_t *dmatch, double *dout_before, double *dout_after,
+                       uint8_t *dout_matched3, uint8_t *dout_flipped);
+int same_xyorder_sweep_dev(same_ctx *ctx, const double *daxy, int64_t n_m, const double *drxy,
+                           const int32_t *dtris, int64_t Tr, const int32_t *dmatch,
+                           uint8_t *dedge_flags, uint8_t *dtri_flag, uint8_t *dpoint_flag,
+                           uint64_t *dcounts);
+int same_orient_sweep_dev(same_sweep *sweep, const int32_t *dmatch, int64_t *out_checked,
+                          int32_t *out_viol_idx, int64_t *out_nviol);
+/* Triangle-block forms for the sweep sharded over GPUs (SURVEY 8e; the loops being sharded are
+ * src/same.py:645-669 and src/violationhelper.py:53-117).  same_orient_flags_dev writes the flags of
+ * triangles [t_begin, t_end) at their absolute positions dflag[t] (t_begin a multiple of 64) and only
+ * enqueues; after the blocks of all ranks have been all-gathered into one flag array,
+ * same_orient_from_flags_dev produces what same_orient_sweep produces: checked count and the ascending
+ * list of flipped triangles (src/same.py:687-703 relies on that order).  The XY-order and area sweeps
+ * shard by calling their _dev forms on offset pointers (dtris + 3*t_begin, outputs + t_begin). */
+int same_orient_flags_dev(same_sweep *sweep, const int32_t *dmatch, int64_t t_begin, int64_t t_end,
+                          uint8_t *dflag);
+int same_orient_from_flags_dev(same_sweep *sweep, const uint8_t *dflag, int64_t *out_checked,
+                               int32_t *out_viol_idx, int64_t *out_nviol);
+/* dmatch[i] = didx[i*k]: the nearest candidate of every row of a padded candidate list (-1 = none). */
+int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, int k, int32_t *dmatch);
+
+/* ======================================================================================================================
+ * part 3 -- WINDOW path: both sections resident on the device, one window = two or three calls
+ * ====================================================================================================================== */
 /* ---- a13 + the per-window pre-MIP path with the sections resident on the device -------------
  * The reference's window loop (src/same.py:507-593) subsets both frames per window (:293-295: one boolean mask over the
  * whole frame per window) and runs the whole pre-MIP path on the subset.  Here:
@@ -432,16 +472,9 @@ int same_window_filter_finish(same_window *window, const int32_t *simplices, int
                               int ensure_min_triangle_per_node, double no_match_penalty, int32_t *out_match_row,
                               uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts);
 
-/* ---- f3: window merge, the de-duplication step ------------------------------------------
- * Replaces src/helpers.py:745-753 (merged_df.sort_values(['filtered_violation', 'window_id'], kind='mergesort') then
- * drop_duplicates([aligned, ref], keep='first')): rows i = 0..n-1 of the concatenated per-window match tables carry a
- * violation flag, a window id and integer codes of their aligned / ref ids (equal ids <=> equal codes; any
- * non-negative int32).  out_rows receives the indices of the rows that survive, in the order the reference's frame has
- * after those two calls (stable by violation, then window id; first row of every pair); *out_n their number.
- * The maximum-cardinality matching that follows (:755-815) is sequential and stays with the caller. */
-int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_t *window_id, const int32_t *aligned_code,
-                     const int32_t *ref_code, int64_t n, int32_t *out_rows, int64_t *out_n);
-
+/* ======================================================================================================================
+ * part 4 -- COMM: one communicator per context, RCCL over xGMI
+ * ====================================================================================================================== */
 /* ---- multi-GPU: RCCL all-gather of the pruned candidate lists -------------
  * One process per GPU.  Rank 0 calls same_comm_unique_id and hands the 128 bytes to the
  * other ranks by any host channel; all ranks then call same_comm_init.  same_allgather_dev

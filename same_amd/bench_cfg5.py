@@ -19,7 +19,7 @@ def record(line):
     return rec
 
 
-def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline):
+def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
     round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
     with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates, runs the
@@ -29,6 +29,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline):
     (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
     `ctx` is the context the communicator lives on (the exchange runs on its stream); worker threads get contexts of their own.
     One step = the whole plan once (every rank its share) + the exchange + the merge (on rank 0, which owns the result).
+    cpu_baseline: None, or the caller's function (state dict) -> (cpu_baseline record, parity text) run on rank 0 at world 1.
     -> the line as a dict on rank 0, None elsewhere; nothing is closed here.  value = dense-equivalent cell pairs
     (sum over windows of aligned x ref cells in the window) per second; `windows_per_s` per rank and the share of the step
     spent outside libsame_hip calls (`host_glue_share`) come from the stage markers of same_amd/_trace.py."""
@@ -203,63 +204,12 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline):
                 "triangles": int(sum(s["triangles"] for s in stats))}
     every = group.allgather_object(mine_rec)
     rccl = comm_report(Env(args, group, ctx, ctx, comm, transport), np) if comm is not None else None
-    # N=1: four windows through the oracle as the CPU baseline and as the parity check of what the GPU produced for them
+    # N=1: the caller's oracle leg (bench.py: four windows through the CPU oracle, as the CPU baseline and as the parity check of what the
+    # GPU produced for them -- the package itself never imports the oracle)
     cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
-    if group.rank == 0 and group.world == 1 and cpu_baseline:
-        from scipy.spatial import Delaunay
-
-        from oracle import same_oracle as orc
-
-        sample = [w for w in my_plan if w["n_mov"] > 1000][:4] or my_plan[:1]
-        t_cpu, done_pairs = 0.0, 0
-        for w in sample:
-            c0 = time.perf_counter()                 # the oracle's part of this window only: the GPU re-runs below are not the CPU's time
-            x0, x1, y0, y1 = w["box"]
-            rs, ms = same_amd.subset_data(r_df, x0, x1, y0, y1), same_amd.subset_data(m_df, x0, x1, y0, y1)
-            na, nr, pairs = orc.find_knn_within_radius(ms, rs, 25, 8)
-            pairs = np.asarray(pairs, dtype=np.int64)
-            axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
-            c32 = orc.pair_cost_arrays(na[cols].to_numpy(), nr[cols].to_numpy(), axy, rxy, pairs, 1.0, dtype=np.float32)
-            tri = np.asarray(orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
-                                                            min_angle_deg=15), dtype=np.int64).reshape(-1, 3)
-            signs = orc.source_signs(na, tri)
-            kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=c32.astype(np.float64), n_aligned=len(na), n_ref=len(nr),
-                      aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
-            och, _ = orc.compute_mip_start_pairs(**kw)
-            xo = np.zeros(len(pairs))
-            xo[[c[2] for c in och]] = 1.0
-            ochecked, oviol = orc.lazy_orientation_sweep(xo, pairs, tri, signs, rxy, len(na))
-            done_pairs += w["n_mov"] * w["n_ref"]
-            t_cpu += time.perf_counter() - c0
-            # the same window on the GPU, compared
-            prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
-            ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs) and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
-                  and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri) and list(prep.source_signs) == list(signs))
-            gch, _ = same_amd.compute_mip_start_pairs(**dict(kw, valid_pairs=prep.valid_pairs, costs=prep.costs))
-            sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
-            gchecked, gviol, _ = sw.sweep(xo)
-            sw.bound.close()
-            ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
-            if ok and on_device:                 # and what the timed path itself computes for this window (csrc/window.hip)
-                nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
-                for hit in och:
-                    match_o[hit[0]] = nr_rows[hit[1]]
-                for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, fetch_triangles=True, **path_kw):
-                    dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
-                    ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
-                          and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])
-                          and np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), c32) and np.array_equal(dw.triangles, tri)
-                          and np.array_equal(dw.state.fetch(W._W_SIGNS), np.asarray(signs, dtype=np.int8))
-                          and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
-            if not ok:
-                raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
-        parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
-                  "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
-        cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
-               "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
-                         f"through oracle/same_oracle.{{c,py}} in {t_cpu:.2f} s, 1 thread (frame subsetting included; the GPU re-runs of the same windows for the "
-                         "comparison are not in this time)",
-               "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on this box"}
+    if group.rank == 0 and group.world == 1 and cpu_baseline is not None:
+        cpu, parity = cpu_baseline(dict(plan=plan, my_plan=my_plan, r_df=r_df, m_df=m_df, cols=cols, op=op, ref_sec=ref_sec, mov_sec=mov_sec,
+                                        dref=dref, dmov=dmov, path_kw=path_kw, ctx=ctx, on_device=on_device))
     out = None
     if group.rank == 0:
         total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))

@@ -224,6 +224,21 @@ def test_merge_window_matches_unique_ref(oracle):
     assert len(got) == 2 and set(got["Ref_Cell_Num_Old"]) == {"r9", "r1"}
 
 
+def test_window_codes_follow_sort_values_for_any_column():
+    """The device de-duplication sees window ids as int32 ranks in THEIR order: small non-negative integers as they are, anything
+    else ranked -- and a missing id (None / NaN) last, where the reference's sort_values puts it (src/helpers.py:748)."""
+    import pandas as pd
+
+    from same_amd.merge import _window_codes
+
+    assert np.array_equal(_window_codes(np.array([3, 0, 7])), [3, 0, 7])
+    assert np.array_equal(_window_codes(np.array([3, -2, 2 ** 40])), [1, 0, 2])
+    for col in (np.array(["w10", None, "w2", "w10"], dtype=object), np.array([2.5, np.nan, -1.0, 2.5])):
+        codes = _window_codes(col)
+        order = pd.DataFrame({"w": col}).sort_values("w", kind="mergesort").index.to_numpy()
+        assert np.array_equal(np.argsort(codes, kind="stable"), order) and codes[0] == codes[3]
+
+
 def test_priority_filter_closed_form_equals_the_reference_walk():
     """knn_utils.find_knn_with_cell_type_priority's pair filter (src/knn_utils.py:28-65) is written in the reference as a walk over
     the aligned rows carrying a set of claimed references; same_amd.knn.priority_filter is its closed form.  Pinned against the
