@@ -112,6 +112,25 @@ int main(void) {
            (long long)wc[0], (long long)wc[1], (long long)wc[2], (long long)wc[3], same_costs ? "equal" : "DIFFER FROM", (long long)fc[0]);
     for (int i = 0; i < wc[2]; ++i) printf(" %d", mrow[i]);
     printf("; orientation checked %lld flipped %lld\n", (long long)st[0], (long long)st[1]);
+    /* the same window once more with the sections re-binned on a 50-unit grid from (-100, -100) -- the box is then a union of cells and no
+     * row is tested -- and the filter and the finish as ONE call; the runtime calls the library issued for it are read from its counters */
+    CHECK(same_section_bin(smov, -100.0, -100.0, 50.0, 50.0));
+    CHECK(same_section_bin(sref, -100.0, -100.0, 50.0, 50.0));
+    int64_t c0[4], c1[4], wc2[4], fc2[3], st2[8];
+    int32_t mrow2[NM];
+    uint8_t pflag2[NM];
+    for (int q = 0; q < 4; ++q) CHECK(same_ctx_stat(ctx, q, &c0[q]));
+    CHECK(same_window_stage(win, smov, sref, box, 12.0, K, 1.0, wc2));
+    CHECK(same_window_filter_finish(win, tris, 4, 30.0, 0, 0.0, 0.0, 0, 1, 100.0, mrow2, pflag2, st2, fc2));
+    for (int q = 0; q < 4; ++q) CHECK(same_ctx_stat(ctx, q, &c1[q]));
+    int same_window = fc2[0] == fc[0] && fc2[1] == fc[1];
+    for (int q = 0; q < 4; ++q) same_window = same_window && wc2[q] == wc[q];
+    for (int q = 0; q < 8; ++q) same_window = same_window && st2[q] == st[q];
+    for (int i = 0; i < wc[2]; ++i) same_window = same_window && mrow2[i] == mrow[i] && pflag2[i] == pflag[i];
+    printf("window again (binned sections, filter + finish as one call): %s; %lld launches, %lld fills, %lld copies, %lld waits\n",
+           same_window ? "the same answers" : "DIFFERENT ANSWERS", (long long)(c1[0] - c0[0]), (long long)(c1[1] - c0[1]),
+           (long long)(c1[2] - c0[2]), (long long)(c1[3] - c0[3]));
+    if (!same_window || c1[0] - c0[0] > 30 || c1[3] - c0[3] > 2) return 6;
     same_window_destroy(win);
     same_section_destroy(smov);
     same_section_destroy(sref);
