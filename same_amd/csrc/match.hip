@@ -482,19 +482,29 @@ int same_greedy_disjoint(same_ctx *ctx, const int32_t *items, const double *keys
     HIP_TRY(ctx, hipMemsetAsync(dalive, 1, (size_t)M, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dsel, 0, (size_t)M, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dused, 0, (size_t)n_nodes, ctx->stream));
+    // rounds in batches (4, 4, 8 ... 64) with one read of the per-round selection counts per batch, as same_greedy_core does: a
+    // round in which nothing is alive is a no-op, so overshooting costs launches, never results
     unsigned long long *h = static_cast<unsigned long long *>(ctx->pinned);
-    int rounds = 0;
-    for (;; ++rounds) {
+    int rounds = 0, batch = 4;
+    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)SAME_GREEDY_BATCH_MAX, &dcount));
+    for (int n_batch = 0;; ++n_batch) {
         REQUIRE(ctx, rounds <= M + 1);
-        HIP_TRY(ctx, hipMemsetAsync(dcount, 0, sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(disjoint_reset_kernel, dim3(grid_for(n_nodes)), dim3(256), 0, ctx->stream, dvkey, dvidx, n_nodes);
-        hipLaunchKernelGGL(disjoint_min_key_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, dkeys, M, dalive, dused, dvkey);
-        hipLaunchKernelGGL(disjoint_min_idx_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, dkeys, M, dalive, dvkey, dvidx);
-        hipLaunchKernelGGL(disjoint_select_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, M, dalive, dvidx, dused, dsel, dcount);
+        HIP_TRY(ctx, hipMemsetAsync(dcount, 0, (size_t)batch * sizeof(unsigned long long), ctx->stream));
+        for (int q = 0; q < batch; ++q) {
+            hipLaunchKernelGGL(disjoint_reset_kernel, dim3(grid_for(n_nodes)), dim3(256), 0, ctx->stream, dvkey, dvidx, n_nodes);
+            hipLaunchKernelGGL(disjoint_min_key_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, dkeys, M, dalive, dused, dvkey);
+            hipLaunchKernelGGL(disjoint_min_idx_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, dkeys, M, dalive, dvkey, dvidx);
+            hipLaunchKernelGGL(disjoint_select_kernel, dim3(grid_for(M)), dim3(256), 0, ctx->stream, ditems, M, dalive, dvidx, dused, dsel, dcount + q);
+        }
         HIP_TRY(ctx, hipGetLastError());
-        SAME_TRY(same_down(ctx, h, dcount, sizeof(unsigned long long)));
+        SAME_TRY(same_down(ctx, h, dcount, (size_t)batch * sizeof(unsigned long long)));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (h[0] == 0) break;
+        ++ctx->stats[SAME_STAT_GREEDY_READBACKS];
+        int q = 0;
+        while (q < batch && h[q] != 0) ++q;
+        rounds += q;
+        if (q < batch) break;
+        if (n_batch >= 1 && batch < SAME_GREEDY_BATCH_MAX) batch *= 2;
     }
     if (out_rounds) *out_rounds = rounds;
     SAME_TRY(same_down(ctx, out_selected, dsel, (size_t)M));

@@ -309,6 +309,57 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
         same_amd.prepare_same_inputs(rs, ms, cols, optim_params=dict(op, hip_cost_dtype="float16"), verbose=False)
 
 
+def test_window_stage_with_thousands_of_scan_blocks(env):
+    """The single-launch scans of the window path (csrc/scan.h) well past one look-back window of 64 blocks: ONE box over a whole
+    1.2M-row section, (a) on a grid of 7 x 7 cells -- the cell-run path with 1.2M candidates: 4 700 blocks in the scatter's scan --, (b) on
+    25-unit cells -- the box covers far more than 64 cells: the mask over the section, 74 blocks in its compaction -- and (c) a box
+    that cuts through the cells (flagged candidates compacted by a 2 300-block scan).  Rows = np.flatnonzero of the box test; kept rows,
+    pairs and their order = the host-buffer prune's padded lists (src/utils.py:709-742); nothing depends on the grid."""
+    import same_amd  # noqa: F401
+    from same_amd import ops, synth
+    from same_amd import windows as W
+    from same_amd.knn import pairs_from_padded
+
+    n, T, k, r = 1_200_000, 2, 4, 10.0
+    ref = synth.make_cells(n, T, seed=70)
+    mov = synth.make_cells(n, T, seed=71)
+    side = float(max(ref["xy"].max(), mov["xy"].max())) + 1.0
+    ref_sec, mov_sec = W.Section(ref["xy"], ref["types"], None, None), W.Section(mov["xy"], mov["types"], None, None)
+    idx, _, cnt = ops.knn_prune(mov["xy"], ref["xy"], r, k, want_d2=False)
+    want_pairs = pairs_from_padded(idx)
+    kept = np.flatnonzero(cnt > 0)
+    assert len(want_pairs) > 2_000_000 and 0.5 * n < len(kept) < n
+    half = (0.0, side / 2 + 3.3, -5.0, side + 5.0)
+    in_m = np.flatnonzero((mov["xy"][:, 0] >= half[0]) & (mov["xy"][:, 0] < half[1]))
+    in_r = np.flatnonzero((ref["xy"][:, 0] >= half[0]) & (ref["xy"][:, 0] < half[1]))
+    st = W.DeviceWindow()
+    for name, cell in (("7 x 7 cells", side / 7.0 + 1e-6), ("25-unit cells", 25.0)):
+        dref, dmov = W.DeviceSection(ref_sec, "float64"), W.DeviceSection(mov_sec, "float64")
+        dref.bin(0.0, 0.0, cell)
+        dmov.bin(0.0, 0.0, cell)
+        n_m, n_r, n_kept, n_pairs = st.stage(dmov, dref, (-1.0, side + 1.0, -1.0, side + 1.0), r, k, 1.0)
+        assert (n_m, n_r, n_kept, n_pairs) == (n, n, len(kept), len(want_pairs)), name
+        assert np.array_equal(st.fetch(W._W_ROWS_M), np.arange(n)) and np.array_equal(st.fetch(W._W_ALIGNED_ROWS), kept), name
+        got = st.fetch(W._W_PAIRS)
+        assert np.array_equal(kept[got[:, 0]], want_pairs[:, 0]) and np.array_equal(got[:, 1], want_pairs[:, 1]), name   # all refs in the box: window number = row
+        # half the section: the box cuts through a column of cells (7 x 7) / covers too many cells (25-unit)
+        n_m, n_r, _nk, _np = st.stage(dmov, dref, half, r, k, 1.0)
+        assert (n_m, n_r) == (len(in_m), len(in_r)) and np.array_equal(st.fetch(W._W_ROWS_M), in_m) and np.array_equal(st.fetch(W._W_ROWS_R), in_r), name
+        gp, rows_r, rows_ua = st.fetch(W._W_PAIRS), st.fetch(W._W_ROWS_R), st.fetch(W._W_ALIGNED_ROWS)
+        sel = np.isin(want_pairs[:, 0], in_m)          # pairs of aligned rows in the box whose reference cell is in the box as well ...
+        # ... as long as no in-box row loses a nearer out-of-box candidate to the k limit: compare rows whose whole list is inside
+        full = np.ones(n, bool)
+        outside = np.ones(n, bool)
+        outside[in_r] = False
+        bad_rows = np.unique(want_pairs[outside[want_pairs[:, 1]], 0])
+        full[bad_rows] = False
+        keep_rows = full[rows_ua[gp[:, 0]]]
+        assert np.array_equal(np.column_stack((rows_ua[gp[:, 0]], rows_r[gp[:, 1]]))[keep_rows], want_pairs[sel & full[want_pairs[:, 0]]]), name
+        dref.close()
+        dmov.close()
+    st.close()
+
+
 def test_merge_dedup_properties_at_cfg5_scale(env):
     """The window-merge de-duplication at the size a 1M-cell section produces and beyond (2M rows, past the oracle-in-seconds
     range used elsewhere), through properties that do not need the oracle: the survivors come out in stable (violation, window,
