@@ -224,15 +224,39 @@ __global__ __launch_bounds__(256) void window_rows_kernel(RunDesc dm, RunDesc dr
     const unsigned at = lo[c0] + ((unsigned)q - pref[c0]);
     const int32_t row = d.order[at];
     unsigned rank = at - lo[c0];
-    for (int c = 0; c < nc; ++c) {
-        if (c == c0) continue;
-        unsigned a = lo[c], b = hi[c];
-        const unsigned base = a;
-        while (a < b) {
-            const unsigned mid = (a + b) >> 1;
-            if (d.order[mid] < row) a = mid + 1; else b = mid;
+    // lower bounds in the other cells' runs, eight runs in lock step: the eight loads of a step are independent, so a step costs one
+    // memory latency instead of eight (the searches are latency-bound: ~10 dependent loads each)
+    constexpr int G = 8;
+    for (int cb = 0; cb < nc; cb += G) {
+        unsigned a[G], n[G];
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int c = cb + g;
+            const bool live = c < nc && c != c0;
+            a[g] = live ? lo[c] : 0u;
+            n[g] = live ? hi[c] - lo[c] : 0u;
+            any = any || n[g] != 0u;
         }
-        rank += a - base;
+        while (any) {
+            int32_t v[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) v[g] = n[g] ? d.order[a[g] + (n[g] >> 1)] : 0;
+            any = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (n[g]) {
+                    const unsigned half = n[g] >> 1;
+                    if (v[g] < row) { a[g] += half + 1; n[g] -= half + 1; } else n[g] = half;
+                    any = any || n[g] != 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int c = cb + g;
+            if (c < nc && c != c0) rank += a[g] - lo[c];
+        }
     }
     uint32_t out = (uint32_t)row;
     if (!d.aligned) {
@@ -334,19 +358,43 @@ __global__ __launch_bounds__(scan::NT) void window_scatter_kernel(ScatterArgs s)
         int64_t pp = off.p;
         const int64_t p_end = pp + c;                // the scan sized the list by cnt: never write past this row's share
         const F *cost = static_cast<const F *>(s.cost);
-        for (int q = 0; q < s.k && pp < p_end; ++q) {
-            const int32_t j = s.idx[i * s.k + q];
-            if (j >= 0) {
-                int64_t lo = 0, hi = n_r;            // the reference cell's number in the window: its place in the ascending row list
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (s.rows_r[mid] < j) lo = mid + 1; else hi = mid;
+        // a reference cell's number in the window = its place in the ascending row list: lower bounds for eight candidates in lock
+        // step (independent loads per step), then the pairs in list order
+        constexpr int G = 8;
+        for (int qb = 0; qb < s.k && pp < p_end; qb += G) {
+            int32_t j[G];
+            unsigned lb[G], n[G];
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                j[g] = qb + g < s.k ? s.idx[i * s.k + qb + g] : -1;
+                lb[g] = 0u;
+                n[g] = j[g] >= 0 ? (unsigned)n_r : 0u;
+                any = any || n[g] != 0u;
+            }
+            while (any) {
+                int32_t v[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) v[g] = n[g] ? s.rows_r[lb[g] + (n[g] >> 1)] : 0;
+                any = false;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (n[g]) {
+                        const unsigned half = n[g] >> 1;
+                        if (v[g] < j[g]) { lb[g] += half + 1; n[g] -= half + 1; } else n[g] = half;
+                        any = any || n[g] != 0u;
+                    }
                 }
-                s.pairs[2 * pp] = a;
-                s.pairs[2 * pp + 1] = (int32_t)lo;
-                s.jsec[pp] = j;
-                s.cost64[pp] = (double)cost[i * s.k + q];
-                ++pp;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (j[g] >= 0 && pp < p_end) {
+                    s.pairs[2 * pp] = a;
+                    s.pairs[2 * pp + 1] = (int32_t)lb[g];
+                    s.jsec[pp] = j[g];
+                    s.cost64[pp] = (double)cost[i * s.k + qb + g];
+                    ++pp;
+                }
             }
         }
     }
@@ -366,7 +414,8 @@ __global__ __launch_bounds__(256) void filter_classify_kernel(const double *__re
                                                                double radius, int angle_enabled, double cos_thr, const int32_t *__restrict__ type_id,
                                                                int near_enabled, double tol, uint8_t *__restrict__ cls,
                                                                double *__restrict__ perim, uint8_t *__restrict__ has_kept,
-                                                               uint8_t *__restrict__ any_valid, unsigned long long *__restrict__ counters) {
+                                                               uint8_t *__restrict__ any_valid, unsigned long long *__restrict__ best_p,
+                                                               unsigned long long *__restrict__ counters) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool near = false;
     if (t < Tr) {
@@ -380,41 +429,39 @@ __global__ __launch_bounds__(256) void filter_classify_kernel(const double *__re
             any_valid[a] = 1; any_valid[b] = 1; any_valid[d] = 1;
             if (r.cls == 0) { has_kept[a] = 1; has_kept[b] = 1; has_kept[d] = 1; }
         }
+        // best same-type triangle of every vertex, first pass (src/helpers.py:334-340): the smallest perimeter, as an atomic maximum
+        // over the INVERTED bit pattern (perimeters are >= 0: the order of the bits is theirs; zero = none yet, one fill prepares it)
+        if (best_p && r.cls == 3) {
+            const unsigned long long key = ~(unsigned long long)__double_as_longlong(r.perim);
+            atomicMax(&best_p[a], key); atomicMax(&best_p[b], key); atomicMax(&best_p[d], key);
+        }
     }
     const unsigned long long nb = __ballot(near);
     if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&counters[FC_NEAR], (unsigned long long)__builtin_popcountll(nb));
 }
-__global__ __launch_bounds__(scan::NT) void filter_keep_kernel(const uint8_t *__restrict__ cls, int64_t Tr, unsigned long long *__restrict__ status,
-                                                                int32_t *__restrict__ keep_list, unsigned long long *__restrict__ counters) {
+// the kept (class 0) triangles in order; and, second pass of the best same-type triangle: the first triangle in input order among
+// a vertex's equal smallest perimeters (an atomic maximum of the inverted triangle index)
+__global__ __launch_bounds__(scan::NT) void filter_keep_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
+                                                                const int32_t *__restrict__ tris, int64_t Tr, unsigned long long *__restrict__ status,
+                                                                int32_t *__restrict__ keep_list, const unsigned long long *__restrict__ best_p,
+                                                                unsigned *__restrict__ best_t, unsigned long long *__restrict__ counters) {
     __shared__ scan::Shared sh;
     auto val = [&](int64_t t) { return Pair{t < Tr && cls[t] == 0 ? 1u : 0u, 0u}; };
     Pair through;
     const Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
     const int64_t t = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
-    if (t < Tr && cls[t] == 0) keep_list[off.a] = (int32_t)t;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters[FC_KEEP] = through.a;
-}
-// best same-type triangle of every vertex = smallest perimeter, first in input order on ties (src/helpers.py:334-340): two passes
-// of atomic maxima over INVERTED keys (zero = none yet, so one fill prepares them): the perimeter's bit pattern (perimeters are
-// >= 0: the order of the bits is theirs), then the triangle index among equal perimeters
-__global__ __launch_bounds__(256) void filter_best_perim_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
-                                                                 const int32_t *__restrict__ tris, int64_t Tr,
-                                                                 unsigned long long *__restrict__ best_p) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Tr || cls[t] != 3) return;
-    const unsigned long long key = ~(unsigned long long)__double_as_longlong(perim[t]);
-    for (int q = 0; q < 3; ++q) atomicMax(&best_p[tris[3 * t + q]], key);
-}
-__global__ __launch_bounds__(256) void filter_best_tri_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
-                                                               const int32_t *__restrict__ tris, int64_t Tr,
-                                                               const unsigned long long *__restrict__ best_p, unsigned *__restrict__ best_t) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Tr || cls[t] != 3) return;
-    const unsigned long long key = ~(unsigned long long)__double_as_longlong(perim[t]);
-    for (int q = 0; q < 3; ++q) {
-        const int32_t v = tris[3 * t + q];
-        if (best_p[v] == key) atomicMax(&best_t[v], ~(unsigned)t);
+    if (t < Tr) {
+        const uint8_t c = cls[t];
+        if (c == 0) keep_list[off.a] = (int32_t)t;
+        if (best_p && c == 3) {
+            const unsigned long long key = ~(unsigned long long)__double_as_longlong(perim[t]);
+            for (int q = 0; q < 3; ++q) {
+                const int32_t v = tris[3 * t + q];
+                if (best_p[v] == key) atomicMax(&best_t[v], ~(unsigned)t);
+            }
+        }
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters[FC_KEEP] = through.a;
 }
 // nodes without a kept triangle but with a valid one are walked in ascending order and bring their best triangle along unless an
 // earlier node already did (src/helpers.py:365-389): first_v[t] = the first node that asks for t (inverted, zero = nobody) ...
@@ -457,8 +504,9 @@ __global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restr
 
 // ---- incumbent and sweeps ---------------------------------------------------------------------------------------------------
 // counters of the finish call: [0] orientation checked, [1] flipped, [2] XY comparisons, [3] XY violations, [4] triangles with
-// one, [5] area flips, [6] (host) greedy rounds, [7] matched aligned cells
-enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7 };
+// one, [5] area flips, [6] (host) greedy rounds, [7] matched aligned cells, [8] pairs the greedy rule could still take
+enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7, SC_REMAINING = 8, SC_COUNT = 16 };
+constexpr int WINDOW_GREEDY_ROUNDS = 3;   // rounds enqueued before the first look (cfg 5: 1-3 productive rounds per window)
 
 // per kept aligned row: minimum pair cost (src/init_helpers.py:118-122; its pairs are a contiguous run of the pair list), whether
 // it beats the no-match penalty, the row's pairs enter the greedy rule or not, no match yet
@@ -477,22 +525,31 @@ __global__ __launch_bounds__(256) void row_prefer_kernel(const int32_t *__restri
     for (int32_t p = lo; p < hi; ++p) alive[p] = prefer;
     match_pair[a] = -1;
 }
-// pair per row -> matched reference cell: its number in the window (handed out), its section row (the sweeps and the caller)
+// pair per row -> matched reference cell: its number in the window (handed out), its section row (the sweeps and the caller); and
+// whether the greedy rule is finished: a pair still alive whose end points are both free would be taken by a further round
 __global__ __launch_bounds__(256) void match_rows_kernel(const int32_t *__restrict__ match_pair, const int32_t *__restrict__ pairs,
-                                                          const int32_t *__restrict__ jsec, const unsigned long long *__restrict__ dn,
-                                                          int32_t *__restrict__ match_loc, int32_t *__restrict__ match_row,
-                                                          uint8_t *__restrict__ pflag, unsigned long long *__restrict__ counters) {
+                                                          const int32_t *__restrict__ jsec, const int32_t *__restrict__ prow,
+                                                          const uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_rows,
+                                                          const unsigned long long *__restrict__ dn, int32_t *__restrict__ match_loc,
+                                                          int32_t *__restrict__ match_row, uint8_t *__restrict__ pflag,
+                                                          unsigned long long *__restrict__ counters) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool m = false;
+    int open = 0;
     if (i < (int64_t)*dn) {
         const int32_t p = match_pair[i];
         match_loc[i] = p >= 0 ? pairs[2 * (int64_t)p + 1] : -1;
         match_row[i] = p >= 0 ? jsec[p] : -1;
         pflag[i] = 0;
         m = p >= 0;
+        if (!m && !used[i])
+            for (int32_t q = prow[i]; q < prow[i + 1]; ++q) open += alive[q] && !used[n_rows + pairs[2 * (int64_t)q + 1]];
     }
-    const unsigned long long bal = __ballot(m);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counters[SC_MATCHED], (unsigned long long)__builtin_popcountll(bal));
+    const unsigned long long bal = __ballot(m), ob = __ballot(open != 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (bal) atomicAdd(&counters[SC_MATCHED], (unsigned long long)__builtin_popcountll(bal));
+        if (ob) atomicAdd(&counters[SC_REMAINING], (unsigned long long)__builtin_popcountll(ob));
+    }
 }
 // one pass over the kept triangles: source sign and weight (src/same.py:1128-1146), the lazy-constraint body under the incumbent
 // (:645-669), the XY-order sweep (src/violationhelper.py:53-117), the signed-area flip (src/same.py:1362-1402; helpers.py:73-77)
@@ -935,7 +992,7 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     SAME_TRY(ensure(ctx, w->stage, cv.off));
     // everything the three calls of this window copy back fits the pinned block from now on (it must not move between them)
     w->host_finish_off = (back_bytes + 255) & ~size_t(255);
-    w->host_filter_off = w->host_finish_off + ((SAME_GREEDY_BATCH_MAX * 8 + 64 + (size_t)cap_m * 5 + 64 + 255) & ~size_t(255));
+    w->host_filter_off = w->host_finish_off + ((SAME_GREEDY_BATCH_MAX * 8 + 128 + (size_t)cap_m * 5 + 64 + 255) & ~size_t(255));
     SAME_TRY(ensure_host(w, w->host_filter_off + 256));
     char *base = static_cast<char *>(w->stage.p);
     auto at = [&](size_t off) { return base + off; };
@@ -1093,12 +1150,10 @@ int enqueue_filter(same_window *w, const int32_t *simplices, int64_t Tr, double 
     SAME_COPY(ctx, raw, simplices, (size_t)Tr * 12, hipMemcpyHostToDevice);
     const int near_enabled = angle_enabled && cos_thr == cos_thr && cos_thr - cos_thr == 0.0;       // a finite threshold
     SAME_LAUNCH(ctx, filter_classify_kernel, dim3(grid_for(Tr)), dim3(256), 0, w->axy_c, raw, Tr, radius, angle_enabled, cos_thr,
-                use_type ? w->type_c : nullptr, near_enabled, near_tol, cls, perim, has_kept, any_valid, dc);
-    SAME_LAUNCH(ctx, filter_keep_kernel, dim3(scan::blocks_for(Tr)), dim3(scan::NT), 0, cls, Tr, reinterpret_cast<unsigned long long *>(at(o_st_keep)),
-                klist, dc);
+                use_type ? w->type_c : nullptr, near_enabled, near_tol, cls, perim, has_kept, any_valid, plan->readd ? best_p : nullptr, dc);
+    SAME_LAUNCH(ctx, filter_keep_kernel, dim3(scan::blocks_for(Tr)), dim3(scan::NT), 0, cls, perim, raw, Tr,
+                reinterpret_cast<unsigned long long *>(at(o_st_keep)), klist, plan->readd ? best_p : nullptr, best_t, dc);
     if (plan->readd) {
-        SAME_LAUNCH(ctx, filter_best_perim_kernel, dim3(grid_for(Tr)), dim3(256), 0, cls, perim, raw, Tr, best_p);
-        SAME_LAUNCH(ctx, filter_best_tri_kernel, dim3(grid_for(Tr)), dim3(256), 0, cls, perim, raw, Tr, best_p, best_t);
         SAME_LAUNCH(ctx, filter_first_node_kernel, dim3(grid_for(n)), dim3(256), 0, has_kept, any_valid, best_t, n, first_v);
         SAME_LAUNCH(ctx, filter_owner_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, has_kept, any_valid, best_t, first_v, n,
                     reinterpret_cast<unsigned long long *>(at(o_st_own)), nlist, dc);
@@ -1122,8 +1177,8 @@ struct FinishPlan {
 int enqueue_tail(same_window *w, FinishPlan *p) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua;
-    SAME_LAUNCH(ctx, match_rows_kernel, dim3(grid_for(n)), dim3(256), 0, p->match_pair, w->pairs, w->jsec, w->counts + 2, w->match_loc, p->match_row,
-                p->pflag, p->counters);
+    SAME_LAUNCH(ctx, match_rows_kernel, dim3(grid_for(n)), dim3(256), 0, p->match_pair, w->pairs, w->jsec, w->prow, p->gs.alive, p->gs.used, n,
+                w->counts + 2, w->match_loc, p->match_row, p->pflag, p->counters);
     if (p->cap_tr)
         SAME_LAUNCH(ctx, window_sweeps_kernel, dim3(grid_for(p->cap_tr)), dim3(256), 0, static_cast<const int32_t *>(w->tris.p), p->cap_tr, p->dTr,
                     w->axy_c, w->size_c, w->ref->xy, p->match_row, w->sign, w->weight, p->pflag, p->counters);
@@ -1139,7 +1194,7 @@ int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     const size_t o_used = cv.take((size_t)n_ends), o_key = cv.take((size_t)n_ends * 16), o_idx = cv.take((size_t)n_ends * 8);
     const size_t o_sel = cv.take(SAME_GREEDY_BATCH_MAX * 8);
     const size_t o_counters = cv.off;
-    cv.off += 64;
+    cv.off += SC_COUNT * 8;
     const size_t o_pflag = cv.off;
     cv.off += ((size_t)n + 7) & ~size_t(7);
     const size_t zero_bytes = (cv.off + 15) & ~size_t(15);
@@ -1184,7 +1239,7 @@ int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     // greedy MIP start: per-row minimum, rows that beat their penalty, the scan's matching (one pair per aligned row)
     SAME_LAUNCH(ctx, row_prefer_kernel, dim3(grid_for(n)), dim3(256), 0, w->prow, w->cost64, w->size_c, w->counts + 2, no_match_penalty, p->gs.alive,
                 p->match_pair);
-    if (P) SAME_TRY(same_greedy_rounds_core(ctx, w->pairs, w->cost64, P, nullptr, n, w->n_r, p->gs, p->match_pair, 0, 4));
+    if (P) SAME_TRY(same_greedy_rounds_core(ctx, w->pairs, w->cost64, P, nullptr, n, w->n_r, p->gs, p->match_pair, 0, WINDOW_GREEDY_ROUNDS));
     return enqueue_tail(w, p);
 }
 
@@ -1197,12 +1252,15 @@ int collect_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_
     SAME_COPY(ctx, h, dsel, p->back_bytes, hipMemcpyDeviceToHost);
     SAME_WAIT(ctx);
     const unsigned long long *sel = reinterpret_cast<const unsigned long long *>(h);
+    const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(h + p->o_counters);
     int rounds = 0;
     if (P) {
         int q = 0;
-        while (q < 4 && sel[q] != 0) ++q;
+        while (q < WINDOW_GREEDY_ROUNDS && sel[q] != 0) ++q;
         rounds = q;
-        if (q == 4) {             // a long chain of pre-empting pairs: keep going in growing batches, then redo the tail
+        // every enqueued round took something AND a pair could still be taken (counted by match_rows_kernel): a long chain of pre-empting
+        // pairs -- keep going in growing batches (one read per batch), then redo the tail
+        if (q == WINDOW_GREEDY_ROUNDS && cnt[SC_REMAINING] != 0) {
             int batch = 4;
             for (;;) {
                 REQUIRE(ctx, rounds <= P + 1);
@@ -1217,14 +1275,13 @@ int collect_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_
                 if (q < batch) break;
                 if (batch < SAME_GREEDY_BATCH_MAX) batch *= 2;
             }
-            SAME_FILL(ctx, p->counters, 0, 64);
+            SAME_FILL(ctx, p->counters, 0, SC_COUNT * 8);
             SAME_TRY(enqueue_tail(w, p));
             SAME_COPY(ctx, h, dsel, p->back_bytes, hipMemcpyDeviceToHost);
             SAME_WAIT(ctx);
         }
     }
-    const unsigned long long *c = reinterpret_cast<const unsigned long long *>(h + p->o_counters);
-    for (int q = 0; q < 8; ++q) out_stats[q] = (int64_t)c[q];
+    for (int q = 0; q < 8; ++q) out_stats[q] = (int64_t)cnt[q];
     out_stats[SC_ROUNDS] = rounds;
     memcpy(out_match_row, h + p->o_match_row, (size_t)n * sizeof(int32_t));
     memcpy(out_point_flag, h + p->o_pflag, (size_t)n);

@@ -249,7 +249,7 @@ def test_fuzz_device_windows(ops):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"device window soak round {rnd}", flush=True)
         rng = np.random.default_rng(77 + 104729 * rnd)
-        done = errors = 0
+        done = errors = max_rounds = 0
         for case in range(36):
             n_r, n_m = int(rng.integers(5, 2500)), int(rng.integers(5, 2500))
             T, k = int(rng.choice([0, 1, 3, 8, 20, 33])), int(rng.choice([1, 2, 5, 8, 31, 64, 65, 130]))
@@ -280,9 +280,11 @@ def test_fuzz_device_windows(ops):
                 if wa.error is None:
                     check_window(W, ops, wa, dw, penalty)
                     done += 1
+                    max_rounds = max(max_rounds, dw.stats["greedy_rounds"])
             dref.close()
             dmov.close()
         assert done > 30, (done, errors)
+        assert max_rounds > 3, max_rounds     # some window needs more greedy rounds than the finish call enqueues up front: the "keep going" path ran
 
 
 def test_device_window_argument_checks(ops):
