@@ -79,8 +79,14 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(
         }
     }
     if (p < n_ends) { next_key[p] = 0ull; next_idx[p] = 0u; }   // the other set: nobody reads it in this round
-    const unsigned long long bal = __ballot(sel);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_selected, (unsigned long long)__builtin_popcountll(bal));
+    // only "did this round take anything" is ever asked: one plain store per block that took something (a same-address atomicAdd
+    // per wave serialised ~1 800 atomics at one L2 line and was most of this kernel's time)
+    __shared__ int any_sel;
+    if (threadIdx.x == 0) any_sel = 0;
+    __syncthreads();
+    if (__ballot(sel) && (threadIdx.x & 63) == 0) any_sel = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && any_sel) *n_selected = 1ull;
 }
 
 // ---- node-local flip statistics (src/eval_utils.py:66-223) -------------------------------------
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(256) void batched_assign_kernel(
 
 // Rounds [first, first + count) of the greedy rule on device-resident state (declared in common.h; shared with window.hip).
 // st.used / st.key[] / st.idx[] / st.sel zero before round 0 (one memset); st.alive = the rows' "prefers a match" flag per
-// pair; dmatch_pair = -1.  Round r adds the number of pairs it selected to st.sel[r - first].  Enqueue only: 3 launches a round.
+// pair; dmatch_pair = -1.  Round r sets st.sel[r - first] to 1 if it selected a pair (it stays 0 otherwise).  Enqueue only: 3 launches a round.
 int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dp, const double *dc, int64_t P, const unsigned long long *dP, int64_t n_m,
                             int64_t n_r, const same_greedy_state &st, int32_t *dmatch_pair, int first, int count) {
     const int64_t n_ends = n_m + n_r;

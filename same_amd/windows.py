@@ -167,7 +167,8 @@ class Section:
 
     def __init__(self, xy, types, type_id=None, size=None):
         self.xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
-        self.types = np.ascontiguousarray(types, dtype=np.float64).reshape(len(self.xy), -1)
+        t = np.ascontiguousarray(types, dtype=np.float64)
+        self.types = t if (t.ndim == 2 and len(t) == len(self.xy)) else t.reshape(len(self.xy), -1)      # (0, T) stays (0, T)
         self.type_id = None if type_id is None else np.ascontiguousarray(type_id, dtype=np.int32)
         self.size = np.ones(len(self.xy), np.int64) if size is None else np.asarray(size)
         self.grid = GridRows(self.xy[:, 0], self.xy[:, 1])

@@ -1053,9 +1053,48 @@ def test_window_rows_do_not_depend_on_the_section_grid():
     assert sum(len(o[3]) for o in got["default"]) > 10_000
 
 
+def test_window_rows_when_points_sit_on_cell_and_box_edges():
+    """A row belongs to the grid cell whose edges -- the very doubles x0 + c * cell -- bracket it under the reference's comparisons
+    (>= lower, < upper, src/same.py:293-295), so a box on cell edges needs no test.  Lattice points ON the edges, with an edge that is
+    not a binary fraction (0.1 * c), origins off the lattice, boxes on and off the edges, degenerate boxes: always np.flatnonzero."""
+    from same_amd import windows as W
+    from same_amd._lib import SameHipError
+
+    g = np.arange(60, dtype=np.float64)
+    for scale in (1.0, 0.1, 7.0 / 3.0):
+        pts = np.array([(x * scale, y * scale) for y in g for x in g])                 # 3 600 lattice points, many exactly on cell edges
+        sec = W.Section(pts, np.ones((len(pts), 2)), None, None)
+        edges = [0.0, 3 * scale, 10 * scale, 20 * scale, 30 * scale, 0.30000000000000004, 59 * scale, 60 * scale, 12.5 * scale, -4.0, 1e9]
+        boxes = [(a, b, c, d) for a in edges[:6] for b in edges[3:] for (c, d) in ((0.0, 60 * scale), (10 * scale, 30 * scale), (12.5 * scale, 12.5 * scale))]
+        boxes += [(5.0, 5.0, 0.0, 9.0), (9.0, 5.0, 0.0, 9.0), (float("nan"), 5.0, 0.0, 9.0), (-1e300, 1e300, -1e300, 1e300)]
+        st = W.DeviceWindow()
+        for origin, cell in (((0.0, 0.0), 10 * scale), ((0.0, 0.0), scale), ((-3.7, 1.3), 4.9 * scale), ((30 * scale, 30 * scale), 10 * scale)):
+            dsec = W.DeviceSection(sec, "float64").bin(origin[0], origin[1], cell)
+            for box in boxes:
+                x0, x1, y0, y1 = box
+                want = np.flatnonzero((pts[:, 0] >= x0) & (pts[:, 0] < x1) & (pts[:, 1] >= y0) & (pts[:, 1] < y1))
+                n_m, n_r, _k, _p = st.stage(dsec, dsec, box, scale, 2, 1.0)
+                assert n_m == n_r == len(want), (scale, origin, cell, box)
+                assert np.array_equal(st.fetch(W._W_ROWS_M), want) and np.array_equal(st.fetch(W._W_ROWS_R), want), (scale, origin, cell, box)
+            dsec.close()
+        st.close()
+    # a section without a usable row, and grids the library refuses
+    empty = W.DeviceSection(W.Section(np.zeros((0, 2)), np.zeros((0, 1)), None, None), "float64")
+    nans = W.DeviceSection(W.Section(np.full((5, 2), np.nan), np.ones((5, 1)), None, None), "float64").bin(0.0, 0.0, 1.0)
+    st = W.DeviceWindow()
+    assert st.stage(empty, nans, (0.0, 1.0, 0.0, 1.0), 1.0, 1, 1.0) == (0, 0, 0, 0) and st.stage(nans, empty, (-1e9, 1e9, -1e9, 1e9), 1.0, 1, 1.0) == (0, 0, 0, 0)
+    some = W.DeviceSection(W.Section(np.array([[0.0, 0.0], [1e6, 1e6]]), np.ones((2, 1)), None, None), "float64")
+    for bad in ((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (float("nan"), 0.0, 1.0), (0.0, float("inf"), 1.0), (0.0, 0.0, 1e-3)):   # the last: 10^18 cells
+        with pytest.raises(SameHipError):
+            some.bin(*bad)
+    assert st.stage(some, some, (0.0, 2e6, 0.0, 2e6), 1.0, 1, 1.0)[:2] == (2, 2)       # a refused grid leaves the old one in place
+    for h in (st, empty, nans, some):
+        h.close()
+
+
 def test_window_calls_stay_within_their_launch_budget():
     """What a window costs in runtime calls, counted by the library itself (same_ctx_stat): with the sections binned on the window
-    grid a window is three fills (one per call's counters), at most 30 kernel launches, four copies and two waits (stage;
+    grid a window is three fills (one per call's counters), 21 kernel launches (the budget: 30), four copies and two waits (stage;
     filter + finish as one call) -- round 3 needed ~80 launches, ~24 fills, ~13 copies and 5-6 waits."""
     from same_amd import _lib, synth
     from same_amd import windows as W
