@@ -6,7 +6,8 @@ import time
 
 from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 
-RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "per_rank", "host_glue_share", "python_share",
+RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "windows_per_s_triangulations_given", "per_rank",
+               "host_glue_share", "python_share",
                "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl")
 
 
@@ -114,9 +115,11 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else (2 if on_device else 4)))
     worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
 
+    tri_cache = [None]        # set for the diagnostic pass after the timed loop (triangulations remembered: Qhull out of the picture)
+
     def walk(windows, wctx, out):
         if on_device:
-            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, windows, no_match_penalty=100.0, ctx=wctx, **path_kw):
+            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, windows, no_match_penalty=100.0, ctx=wctx, triangulator=tri_cache[0], **path_kw):
                 if dw.error is None:
                     with _trace.stage("table (bench step)"):
                         out.append((dw.window["window_id"], *device_table(dw)))
@@ -195,9 +198,23 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
     lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
     qhull_wait = sum(sec for name, (_c, sec) in rep.items() if name.startswith("triangulate"))
+    # DIAGNOSTIC, outside the timed region and never part of `value`: the same pass with every window's triangulation remembered from a
+    # first pass -- what the library calls + the Python glue cost once Qhull is out of the picture, i.e. the rate a host with enough
+    # CPU per rank could approach (on this box the timed pass is bound by its 16 CPUs' worth of Qhull)
+    no_qhull = None
+    if on_device:
+        tri_cache[0] = W.TriangulationCache()
+        one_pass(my_plan)                                  # fills the cache
+        group.barrier()
+        tq = time.perf_counter()
+        for _ in range(2):
+            one_pass(my_plan)
+        no_qhull = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
+        tri_cache[0] = None
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * steps / wall_here,
                 "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / (wall_here * n_workers), "threads": n_workers,
                 "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / (wall_here * n_workers)),
+                "windows_per_s_triangulations_given": no_qhull,
                 "runtime_calls_per_window": calls_per_window, "table_allgather_ms": (sum(exchange_ms) / len(exchange_ms)) if exchange_ms else None,
                 "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
@@ -234,6 +251,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                             "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
                             "in_library_s_per_step": [r["in_library_s"] / steps for r in every],
                             "table_allgather_ms": [r["table_allgather_ms"] for r in every], "qhull_helpers": [r["qhull_helpers"] for r in every],
+                            "windows_per_s_triangulations_given": [r["windows_per_s_triangulations_given"] for r in every],
                             "qhull_l3_domains": [r["qhull_domains"] for r in every]},
                "host_glue_share": mine_rec["host_glue_share"],
                "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
@@ -242,6 +260,10 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes of the "
                                      "threads' time (the merge and the table exchange included)",
                "threads_per_rank": n_workers,
+               "windows_per_s_triangulations_given": None if no_qhull is None else sum(r["windows_per_s_triangulations_given"] or 0.0 for r in every),
+               "windows_per_s_triangulations_given_means": "DIAGNOSTIC, not a throughput: the rate of two extra passes (windows only: no exchange, no merge) "
+                                                           "in which every window's Delaunay simplices are remembered from an earlier pass, summed over "
+                                                           "the ranks -- what the library calls and the Python glue allow once Qhull is out of the picture",
                "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
                "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued per window on rank 0, "
                                                  "counted by the library itself (same_ctx_stat) over the timed passes; the merge's de-duplication included",

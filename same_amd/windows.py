@@ -460,14 +460,46 @@ class DeviceWindowResult:
             setattr(self, name, None)
 
 
+class TriangulationCache:
+    """Delaunay simplices remembered per window (a DIAGNOSTIC: bench.py's "what would a pass cost if the triangulations were free").
+    `submit(points, key)` hands back the simplices of `key` when it has seen the window before, else asks the helper pool and keeps
+    the answer; the simplices are the pool's, i.e. scipy's, either way."""
+
+    class _Ready:
+        def __init__(self, value):
+            self._value = value
+
+        def result(self):
+            return self._value
+
+    class _Pending:
+        def __init__(self, cache, key, ticket):
+            self.cache, self.key, self.ticket = cache, key, ticket
+
+        def result(self):
+            v = self.cache.known[self.key] = self.ticket.result()
+            return v
+
+    def __init__(self):
+        self.known = {}
+
+    def submit(self, points, key=None):
+        from . import qhull_pool
+
+        if key in self.known:
+            return self._Ready(self.known[key])
+        return self._Pending(self, key, qhull_pool.pool().submit(points))
+
+
 def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
-                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False):
+                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False, triangulator=None):
     """The window path of `iter_window_arrays` + the greedy incumbent and the three sweeps, with both sections resident on the
     device (`dref`, `dmoving`: DeviceSections of `ref`, `moving`): per window the host only triangulates (Qhull helpers, windows
     ahead as before) and receives the match; the triangle filter runs on the device too, unless a cosine sits within 8 ulp of the
     angle threshold (then the host re-decides it with the reference's literal expression, as triangles.classify_triangles does).  Yields one
     DeviceWindowResult per window in plan order; the numbers are those of the column pipeline
-    (tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline).  A window without pairs yields `.error`."""
+    (tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline).  A window without pairs yields `.error`.
+    `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`."""
     from . import qhull_pool
     from ._trace import stage as marked
     from .triangles import cos_threshold, filter_triangles_by_radius
@@ -505,7 +537,8 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
                 return out, None
         with marked("triangulate (hand-over; waits for a free helper)"):
             try:
-                return out, (state, qhull_pool.pool().submit(out.axy))
+                return out, (state, qhull_pool.pool().submit(out.axy) if triangulator is None
+                             else triangulator.submit(out.axy, key=w.get("window_id")))
             except BaseException:
                 free.append(state)
                 raise

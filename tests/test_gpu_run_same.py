@@ -524,6 +524,8 @@ def test_bench_cfg5_windows_line(world):
     assert out["config"]["pipeline"].startswith("device: both sections resident in HBM")
     assert any(k.startswith("subset + prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
     assert {"same_window_stage", "same_window_filter_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
+    # the diagnostic pass with the triangulations remembered (not a throughput; it says what is left once Qhull is out of the picture)
+    assert out["windows_per_s_triangulations_given"] > 0 and len(pr["windows_per_s_triangulations_given"]) == world
     assert out["qhull"]["helpers"] >= 0 and out["qhull"]["waiting_s_per_step_rank0"] >= 0 and out["qhull"]["cpu_budget"] >= 1
     assert 0.0 <= out["python_share"] <= out["host_glue_share"] and len(pr["python_share"]) == world
     rf = out["roofline"]

@@ -14,7 +14,7 @@ run() {   # tag, args...
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(f"{sys.argv[2]}: {d['windows_per_s']:.1f} windows/s, {d['ms_per_step']:.0f} ms/step, host glue {d['host_glue_share']:.3f}, in library {d['per_rank']['in_library_s_per_step']} s/step, "
-      f"qhull wait {d['per_rank']['qhull_wait_s_per_step']}, helpers {d['per_rank']['qhull_helpers']}, exchange {d.get('table_allgather')}, calls {d.get('runtime_calls_per_window')}")
+      f"qhull wait {d['per_rank']['qhull_wait_s_per_step']}, helpers {d['per_rank']['qhull_helpers']}, exchange {d.get('table_allgather')}, calls {d.get('runtime_calls_per_window')}, triangulations given: {d.get('windows_per_s_triangulations_given')}")
 P
 }
 run 1m --no-cpu-baseline
