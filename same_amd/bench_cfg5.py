@@ -154,8 +154,21 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
         done = sorted((r for part in outs for r in part), key=lambda r: pos[r[0]])
         return [r[1] for r in done], [r[2] for r in done]
 
+    def all_ranks(fn, *a):
+        """fn(*a) on this rank; if ANY rank raised, every rank raises (so that no rank walks into a collective the others never reach)."""
+        err, out = None, None
+        try:
+            out = fn(*a)
+        except Exception as e:  # noqa: BLE001 -- re-raised below, on every rank
+            err = e
+        if group.world > 1 and group.min(0.0 if err is not None else 1.0) < 1.0:
+            raise RuntimeError(f"cfg5: a rank failed in its window pass ({type(err).__name__ if err else 'another rank'}: {err})")
+        if err is not None:
+            raise err
+        return out
+
     def step():
-        tabs, stats = one_pass(my_plan)
+        tabs, stats = all_ranks(one_pass, my_plan)
         mine_tab = {c: (np.concatenate([t[c] for t in tabs]) if tabs else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
         mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
         with _trace.stage("table exchange (all-gather)"):
@@ -179,7 +192,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
     n_warm = (_qp.lookahead() + 1) * n_workers if on_device else 2
     for _ in range(warmup):
-        one_pass(my_plan[: max(1, min(n_warm, len(my_plan)))])
+        all_ranks(one_pass, my_plan[: max(1, min(n_warm, len(my_plan)))])
     group.barrier()
     _trace.reset()
     calls0 = [c.stats() for c in worker_ctx]
@@ -204,11 +217,11 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     no_qhull = None
     if on_device:
         tri_cache[0] = W.TriangulationCache()
-        one_pass(my_plan)                                  # fills the cache
+        all_ranks(one_pass, my_plan)                       # fills the cache
         group.barrier()
         tq = time.perf_counter()
         for _ in range(2):
-            one_pass(my_plan)
+            all_ranks(one_pass, my_plan)
         no_qhull = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
         tri_cache[0] = None
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * steps / wall_here,
