@@ -3,7 +3,7 @@
 set -o pipefail
 tag=${1:-r04d}
 out=gpurun_out/$tag; mkdir -p $out
-echo "== (suite ran in the previous call of this visit)"
+echo "== pytest -m gpu" && timeout -k 10 1100 python3 -m pytest tests -m gpu -q --durations=8 > $out/pytest_gpu.log 2>&1; rc=$?; tail -4 $out/pytest_gpu.log; [ $rc -eq 0 ] || { grep -n "Error\|FAILED" $out/pytest_gpu.log | head -20; exit $rc; }
 echo "== smoke" && timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
 echo "== bench (default)" && SECONDS=0; timeout -k 10 900 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -30 $out/bench.err; exit 1; }
 echo "bench wall $SECONDS s"; grep "^\[bench" $out/bench.err | tail -12
