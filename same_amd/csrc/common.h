@@ -85,8 +85,10 @@ struct same_sweep {
     int32_t *pairs = nullptr;     // [P][2]
     int32_t *match = nullptr, *pidx = nullptr;  // [n_m]
     uint8_t *flag = nullptr;      // [Tr rounded up to 256]
-    // one block: cnt[2] = {checked, flipped}, then viol[Tr] -- so the counters and the head of the ascending flipped list
-    // come back in ONE device-to-host copy
+    // one block: scan words | cnt[2] = {checked, flipped} | viol[Tr] -- the words and counters are zeroed by one fill, the counters and
+    // the head of the ascending flipped list come back in ONE device-to-host copy
+    unsigned long long *scan_base = nullptr;
+    size_t scan_zero_bytes = 0;
     unsigned long long *cnt = nullptr;
     int32_t *viol = nullptr;      // = (int32_t *)(cnt + 2)
     unsigned long long *mask = nullptr;
@@ -152,10 +154,6 @@ int check_index_range(same_ctx *ctx, const int32_t *idx, int64_t n, int64_t lo, 
 // Device cores shared between the host-buffer entry points and the window pipeline (window.hip): every pointer is a device
 // pointer, the calls enqueue on ctx->stream (same_greedy_core reads one counter back per round).
 int same_pair_rowmin_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, int64_t n_m, double *dout);
-int same_compact_mask_core(same_ctx *ctx, const unsigned long long *dmask, int64_t n_words, int64_t n_items, int32_t *dout_idx,
-                           unsigned long long *dcounters);
-int same_orient_counts_core(same_ctx *ctx, const int32_t *dtris, int64_t Tr, const int8_t *dsign, const double *drxy,
-                            const int32_t *dmatch, uint8_t *dflag, unsigned long long *dmask, unsigned long long *dcnt);
 int same_greedy_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, int64_t n_m, int64_t n_r,
                      const uint8_t *dprefer, int32_t *dmatch_pair, int *out_rounds);
 

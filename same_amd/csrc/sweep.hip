@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "devmath.h"
+#include "scan.h"
 
 namespace {
 
@@ -125,6 +126,43 @@ __global__ __launch_bounds__(1024) void compact_mask_kernel(const unsigned long 
         __syncthreads();
     }
     if (tid == 0) counters[1] = (unsigned long long)carry_s;
+}
+
+// The per-incumbent sweep in ONE launch: flag per triangle, the checked counter, and the flipped triangles as an ascending list
+// through the multi-block look-back scan of scan.h (no second launch for the compaction, no single-block scan).
+// counters[0] = checked, counters[1] = flipped.
+__global__ __launch_bounds__(scan::NT) void orient_sweep_kernel(
+    const int32_t *__restrict__ tris, int64_t Tr, const int8_t *__restrict__ src_sign, const double *__restrict__ rxy,
+    const int32_t *__restrict__ match, uint8_t *__restrict__ flag, unsigned long long *__restrict__ status, int32_t *__restrict__ viol,
+    unsigned long long *__restrict__ counters) {
+    __shared__ scan::Shared sh;
+    __shared__ int wave_checked[scan::NT / 64];
+    auto flag_of = [&](int64_t t) -> uint8_t {
+        if (t >= Tr) return 0;
+        const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+        const int32_t ja = match[a], jb = match[b], jc = match[c];
+        const bool all3 = ja >= 0 && jb >= 0 && jc >= 0;           // src/same.py:649-650
+        const double2_t z = {0.0, 0.0};
+        return orient_flag(src_sign[t], all3, all3 ? ld2(rxy, ja) : z, all3 ? ld2(rxy, jb) : z, all3 ? ld2(rxy, jc) : z);   // :658-669
+    };
+    const int64_t t = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    const uint8_t f = flag_of(t);
+    if (t < Tr) flag[t] = f;
+    // the scan's element function must be able to produce ANY block's counters (a predecessor that has not published is recomputed,
+    // never waited for): the own element comes from the register, everything else from the inputs
+    auto val = [&](int64_t i) { return scan::Pair{(i == t ? f : flag_of(i)) == 2 ? 1u : 0u, 0u}; };
+    scan::Pair through;
+    const scan::Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    if (f == 2) viol[off.a] = (int32_t)t;
+    const unsigned long long checked = __ballot(f != 0);
+    if ((threadIdx.x & 63) == 0) wave_checked[threadIdx.x >> 6] = __builtin_popcountll(checked);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per block (integer sum: order-independent)
+        int c = 0;
+        for (int q = 0; q < scan::NT / 64; ++q) c += wave_checked[q];
+        if (c) atomicAdd(&counters[0], (unsigned long long)c);
+        if (blockIdx.x == gridDim.x - 1) counters[1] = through.a;
+    }
 }
 
 // ---- XY-order sweep ------------------------------------------------------------------------
@@ -293,19 +331,21 @@ int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, in
 }
 
 // The per-incumbent sweep from the handle's own match block is the launch-bound inner loop of the path (the solver calls it
-// for every incumbent): four stream operations -- counter memset, flag kernel, compaction, one read-back.  Replaying them as
-// one captured hipGraph was measured SLOWER on this ROCm (69 us against 61 us per call at 95k triangles,
-// profiles/r02_sweep_latency.log: hipGraphLaunch costs more than four enqueues), so the plain launches are the only form.
+// for every incumbent): three stream operations -- one fill (scan words + counters), ONE kernel (flags, counters, ordered list),
+// one read-back.  Replaying the round-2 form (four operations) as one captured hipGraph was measured SLOWER on this ROCm (69 us
+// against 61 us per call at 95k triangles, profiles/r02_sweep_latency.log), so plain launches are the only form.
 int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol,
                uint8_t *out_flag) {
     same_ctx *ctx = s->ctx;
     *out_checked = 0;
     *out_nviol = 0;
     if (s->Tr == 0) return SAME_OK;
-    HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    SAME_TRY(launch_orient_flags(s, dmatch, 0, s->Tr, s->flag, s->mask, s->cnt));
+    HIP_TRY(ctx, hipMemsetAsync(s->scan_base, 0, s->scan_zero_bytes, ctx->stream));     // the scan's words + the two counters: one fill
+    hipLaunchKernelGGL(orient_sweep_kernel, dim3(scan::blocks_for(s->Tr)), dim3(scan::NT), 0, ctx->stream, s->tris, s->Tr, s->sign, s->rxy, dmatch,
+                       s->flag, s->scan_base, s->viol, s->cnt);
+    HIP_TRY(ctx, hipGetLastError());
     if (out_flag) SAME_TRY(same_down(ctx, out_flag, s->flag, (size_t)s->Tr));
-    return compact_from_flags(s, s->flag, true, out_checked, out_viol_idx, out_nviol);
+    return read_back(s, out_checked, out_viol_idx, out_nviol);
 }
 
 template <typename T>
@@ -327,21 +367,16 @@ int sweep_fill(same_sweep *s, const int32_t *tris, const int8_t *src_sign, const
     SAME_TRY(sweep_block<int32_t>(ctx, &s->pidx, (size_t)s->n_m, nullptr));
     SAME_TRY(sweep_block<uint8_t>(ctx, &s->flag, (size_t)ceil_div(s->Tr, 256) * 256 + 256, nullptr));
     SAME_TRY(sweep_block<unsigned long long>(ctx, &s->mask, (size_t)ceil_div(s->Tr, 256) * 4 + 4, nullptr));
-    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->cnt, 2 + (size_t)(s->Tr + 1) / 2 + 2, nullptr));   // counters, then the list
+    // one block: [scan words of orient_sweep_kernel | cnt[2] | the flipped list] -- the words and the counters are zeroed by one fill,
+    // the counters and the head of the list come back in one copy
+    const size_t words = scan::status_bytes(s->Tr) / 8;
+    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->scan_base, words + 2 + (size_t)(s->Tr + 1) / 2 + 2, nullptr));
+    s->scan_zero_bytes = (words + 2) * sizeof(unsigned long long);
+    s->cnt = s->scan_base + words;
     s->viol = reinterpret_cast<int32_t *>(s->cnt + 2);
     SAME_TRY(sweep_block<double>(ctx, &s->x, (size_t)s->P, nullptr));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SAME_OK;
-}
-
-// sum of the per-wave flipped masks -> counters[1] (the window pipeline wants the count, not the list)
-__global__ __launch_bounds__(256) void mask_count_kernel(const unsigned long long *__restrict__ mask, int64_t n_words,
-                                                          unsigned long long *__restrict__ counters) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int c = w < n_words ? __builtin_popcountll(mask[w]) : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counters[1], (unsigned long long)c);
 }
 
 }  // namespace
@@ -355,27 +390,6 @@ int same_pair_rowmin_core(same_ctx *ctx, const int32_t *dp, const double *dc, in
     hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, 0xFFF0000000000000ull /* key(+inf) */);
     if (P) hipLaunchKernelGGL(rowmin_kernel, dim3(grid_for(P)), dim3(256), 0, ctx->stream, dp, dc, P, dk);
     hipLaunchKernelGGL(rowmin_decode_kernel, dim3(grid_for(n_m)), dim3(256), 0, ctx->stream, dk, n_m, dout);
-    HIP_TRY(ctx, hipGetLastError());
-    return SAME_OK;
-}
-
-// ascending indices of the set bits of dmask[n_words] (items < n_items) into dout_idx, their number into dcounters[1]
-int same_compact_mask_core(same_ctx *ctx, const unsigned long long *dmask, int64_t n_words, int64_t n_items, int32_t *dout_idx,
-                           unsigned long long *dcounters) {
-    hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, dmask, n_words, n_items, dout_idx, dcounters);
-    HIP_TRY(ctx, hipGetLastError());
-    return SAME_OK;
-}
-
-// the lazy-constraint body (src/same.py:645-669) on device-resident arrays, counters only: dcnt[0] = checked, dcnt[1] = flipped.
-// dflag holds ceil(Tr/256)*256 bytes, dmask ceil(Tr/256)*4 words.
-int same_orient_counts_core(same_ctx *ctx, const int32_t *dtris, int64_t Tr, const int8_t *dsign, const double *drxy,
-                            const int32_t *dmatch, uint8_t *dflag, unsigned long long *dmask, unsigned long long *dcnt) {
-    HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    if (Tr <= 0) return SAME_OK;
-    hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dtris, Tr, dsign, drxy, dmatch, dflag, dmask, dcnt);
-    const int64_t n_words = (int64_t)grid_for(Tr) * 4;
-    hipLaunchKernelGGL(mask_count_kernel, dim3(grid_for(n_words)), dim3(256), 0, ctx->stream, dmask, n_words, dcnt);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -409,7 +423,7 @@ void same_sweep_unbind(same_sweep *s) {
     same_ctx *ctx = s->ctx;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->mask, s->cnt, s->x};   // viol lives in cnt's block
+    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->mask, s->scan_base, s->x};   // viol lives in cnt's block
     for (void *b : blocks)
         if (b) (void)hipFree(b);
     delete s;
