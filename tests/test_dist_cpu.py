@@ -323,7 +323,7 @@ def test_bench_launcher_reports_a_failed_rank():
 def test_bench_is_torch_free():
     src = "".join(open(os.path.join(ROOT, *parts)).read() for parts in (("bench.py",), ("same_amd", "dist.py"), ("same_amd", "rendezvous.py"),
                                                                         ("same_amd", "bench_common.py"), ("same_amd", "bench_launch.py"),
-                                                                        ("same_amd", "bench_cfg5.py"), ("same_amd", "qhull_pool.py")))
+                                                                        ("same_amd", "bench_cfg5.py"), ("same_amd", "bench_problem.py"), ("same_amd", "qhull_pool.py")))
     assert "import torch" not in src and "from torch" not in src
 
 
