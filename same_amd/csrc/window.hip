@@ -1243,7 +1243,7 @@ int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     return enqueue_tail(w, p);
 }
 
-// the finish call's answers: one copy, one wait; more greedy rounds (and the tail again) when four did not settle the matching
+// the finish call's answers: one copy, one wait; more greedy rounds (and the tail again) when the rounds enqueued up front did not settle the matching
 int collect_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua, P = w->P;
