@@ -112,7 +112,11 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # The windows of a pass are independent and the host work per window (numpy index work, ~7 ms) dwarfs its kernels (~0.3 ms), so
     # the rank walks its windows with --cfg5-threads workers, each with a context (= stream) of its own; numpy and the library calls
     # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
-    n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else (2 if on_device else 4)))
+    from same_amd import qhull_pool as _share
+
+    cpu_share = _share.cpu_budget() / _share.local_world()[0]          # this rank's part of the host's CPUs
+    default_threads = (2 if cpu_share >= 8 else 1) if on_device else 4  # a second Python thread only pays where there are CPUs to feed it
+    n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else default_threads))
     worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
 
     tri_cache = [None]        # set for the diagnostic pass after the timed loop (triangulations remembered: Qhull out of the picture)
