@@ -23,8 +23,8 @@ def record(line):
 def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
     round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
-    with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates, runs the
-    filter's re-add pass and receives the match; --cfg5-pipeline columns is the host-buffer form it is tested against),
+    with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates and receives
+    the match; --cfg5-pipeline columns is the host-buffer form it is tested against),
     every rank's central-trimmed match table exchanged in ONE device all-gather (dist.allgather_table) and merged
     (src/helpers.py:692-815, de-duplication on the GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
     (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
@@ -257,8 +257,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
                                       f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
                                       "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
-                          "pipeline": ("device: both sections resident in HBM, two library calls per window (csrc/window.hip); the host triangulates (Qhull "
-                                       "helpers), runs the triangle filter's re-add pass and receives the match" if on_device
+                          "pipeline": ("device: both sections resident in HBM and binned on the window grid, two library calls per window (csrc/window.hip); the "
+                                       "host triangulates (Qhull helpers) and receives the match" if on_device
                                        else "columns: subsetting, compaction and gathers on the host, every kernel through host buffers"),
                           "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
                                          "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
