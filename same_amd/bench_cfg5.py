@@ -74,11 +74,10 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     def device_table(dw):
         """the window's central match table from what iter_device_windows leaves on the host (section rows, XY, match, flags)"""
         w = dw.window
-        ai = np.flatnonzero(dw.match_row >= 0)
-        x, y = dw.axy[ai, 0], dw.axy[ai, 1]
-        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
-        c = ai[(x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1)]
-        tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": dw.axy[c, 0], "Y": dw.axy[c, 1],
+        x, y = dw.axy[:, 0], dw.axy[:, 1]
+        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581), matched cells only
+        c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
+        tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": x[c], "Y": y[c],
                "filtered_violation": dw.point_flag[c].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
         st = dw.stats
         return tab, {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
