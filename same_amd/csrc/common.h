@@ -164,7 +164,8 @@ struct same_greedy_state {
     uint8_t *used = nullptr;                        // [n_m + n_r] end point taken: rows, then columns
     unsigned long long *key[2] = {nullptr, nullptr};   // [n_m + n_r] each: inverted minimum cost key per end point, alternating sets
     unsigned *idx[2] = {nullptr, nullptr};          // [n_m + n_r] each: inverted pair index among equal minima
-    unsigned long long *sel = nullptr;              // [rounds of one batch] pairs selected per round
+    unsigned long long *sel = nullptr;              // [rounds of one batch] 1 = the round selected a pair
+    bool float_costs = false;                       // every cost is exactly a float: (cost, pair index) packs into one word, 2 launches a round
 };
 int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, const unsigned long long *dP,
                             int64_t n_m, int64_t n_r, const same_greedy_state &st, int32_t *dmatch_pair, int first, int count);

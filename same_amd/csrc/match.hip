@@ -89,6 +89,53 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(
     if (threadIdx.x == 0 && any_sel) *n_selected = 1ull;
 }
 
+// Rounds for costs that are exactly floats (the fp32-cost windows, cost64 = (double)float): (cost, pair index) fits ONE 64-bit word
+// -- float key in the high half, inverted pair index in the low half -- so a single atomicMax per end point finds the minimum cost
+// AND the first pair among equal costs: a round is two launches instead of three.  Same order, same matching as the generic rounds.
+__device__ __forceinline__ unsigned long long packed_key(double c, int64_t p) {
+    const unsigned u = __float_as_uint((float)c);
+    const unsigned k = (u >> 31) ? ~u : (u | 0x80000000u);      // monotone key of the float
+    return ((unsigned long long)(~k) << 32) | (unsigned long long)(~(unsigned)p);   // larger word = smaller (cost, index); never 0: p < 2^32 - 1
+}
+__global__ __launch_bounds__(256) void greedy_min_packed_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m, unsigned long long *__restrict__ key) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dP) P = (int64_t)*dP;
+    if (p >= P || !alive[p]) return;
+    const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+    if (used[i] || used[n_m + j]) { alive[p] = 0; return; }
+    const unsigned long long k = packed_key(costs[p], p);
+    atomicMax(&key[i], k);
+    atomicMax(&key[n_m + j], k);
+}
+__global__ __launch_bounds__(256) void greedy_select_packed_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    uint8_t *__restrict__ alive, int64_t n_m, int64_t n_ends, const unsigned long long *__restrict__ key, uint8_t *__restrict__ used,
+    int32_t *__restrict__ match_pair, unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dP) P = (int64_t)*dP;
+    bool sel = false;
+    if (p < P && alive[p]) {
+        const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
+        const unsigned long long k = packed_key(costs[p], p);
+        if (key[i] == k && key[n_m + j] == k) {
+            sel = true;
+            alive[p] = 0;
+            used[i] = 1;
+            used[n_m + j] = 1;
+            match_pair[i] = (int32_t)p;
+        }
+    }
+    if (p < n_ends) next_key[p] = 0ull;
+    __shared__ int any_sel;
+    if (threadIdx.x == 0) any_sel = 0;
+    __syncthreads();
+    if (__ballot(sel) && (threadIdx.x & 63) == 0) any_sel = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && any_sel) *n_selected = 1ull;
+}
+
 // ---- node-local flip statistics (src/eval_utils.py:66-223) -------------------------------------
 typedef double double2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2_t ld2(const double *xy, int64_t i) { return *reinterpret_cast<const double2_t *>(xy + 2 * i); }
@@ -309,13 +356,20 @@ __global__ __launch_bounds__(256) void batched_assign_kernel(
 
 // Rounds [first, first + count) of the greedy rule on device-resident state (declared in common.h; shared with window.hip).
 // st.used / st.key[] / st.idx[] / st.sel zero before round 0 (one memset); st.alive = the rows' "prefers a match" flag per
-// pair; dmatch_pair = -1.  Round r sets st.sel[r - first] to 1 if it selected a pair (it stays 0 otherwise).  Enqueue only: 3 launches a round.
+// pair; dmatch_pair = -1.  Round r sets st.sel[r - first] to 1 if it selected a pair (it stays 0 otherwise).  Enqueue only: 3 launches a
+// round, 2 when st.float_costs says every cost is exactly a float (then P < 2^32 - 1 and st.idx is not used).
 int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dp, const double *dc, int64_t P, const unsigned long long *dP, int64_t n_m,
                             int64_t n_r, const same_greedy_state &st, int32_t *dmatch_pair, int first, int count) {
     const int64_t n_ends = n_m + n_r;
     const unsigned gp = grid_for(P), gs = grid_for(P > n_ends ? P : n_ends);
     for (int r = first; r < first + count; ++r) {
         const int s = r & 1;
+        if (st.float_costs) {      // (cost, index) in one word: two launches a round
+            SAME_LAUNCH(ctx, greedy_min_packed_kernel, dim3(gp), dim3(256), 0, dp, dc, P, dP, st.alive, st.used, n_m, st.key[s]);
+            SAME_LAUNCH(ctx, greedy_select_packed_kernel, dim3(gs), dim3(256), 0, dp, dc, P, dP, st.alive, n_m, n_ends, st.key[s], st.used,
+                        dmatch_pair, st.sel + (r - first), st.key[s ^ 1]);
+            continue;
+        }
         SAME_LAUNCH(ctx, greedy_min_key_kernel, dim3(gp), dim3(256), 0, dp, dc, P, dP, st.alive, st.used, n_m, st.key[s]);
         SAME_LAUNCH(ctx, greedy_min_idx_kernel, dim3(gp), dim3(256), 0, dp, dc, P, dP, st.alive, n_m, st.key[s], st.idx[s]);
         SAME_LAUNCH(ctx, greedy_select_kernel, dim3(gs), dim3(256), 0, dp, P, dP, st.alive, n_m, n_ends, st.idx[s], st.used, dmatch_pair,

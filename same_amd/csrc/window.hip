@@ -1224,6 +1224,7 @@ int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     p->gs.idx[0] = reinterpret_cast<unsigned *>(at(o_idx));
     p->gs.idx[1] = p->gs.idx[0] + n_ends;
     p->gs.sel = reinterpret_cast<unsigned long long *>(at(o_sel));
+    p->gs.float_costs = w->cost_f32 != 0;          // cost64 = (double)float there: the two-launch rounds
     p->counters = reinterpret_cast<unsigned long long *>(at(o_counters));
     p->pflag = reinterpret_cast<uint8_t *>(at(o_pflag));
     p->match_row = reinterpret_cast<int32_t *>(at(o_match_row));
