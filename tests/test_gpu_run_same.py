@@ -1096,7 +1096,7 @@ def test_window_rows_when_points_sit_on_cell_and_box_edges():
 
 def test_window_calls_stay_within_their_launch_budget():
     """What a window costs in runtime calls, counted by the library itself (same_ctx_stat): with the sections binned on the window
-    grid a window is three fills (one per call's counters), 21 kernel launches (the budget: 30), four copies and two waits (stage;
+    grid a window is three fills (one per call's counters), 18 kernel launches with fp32 costs (the budget: 30), four copies and two waits (stage;
     filter + finish as one call) -- round 3 needed ~80 launches, ~24 fills, ~13 copies and 5-6 waits."""
     from same_amd import _lib, synth
     from same_amd import windows as W
