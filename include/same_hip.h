@@ -388,7 +388,7 @@ int same_orient_sweep_dev(same_sweep *sweep, const int32_t *dmatch, int64_t *out
                           int32_t *out_viol_idx, int64_t *out_nviol);
 /* Triangle-block forms for the sweep sharded over GPUs (the loops being sharded are
  * src/same.py:645-669 and src/violationhelper.py:53-117).  same_orient_flags_dev writes the flags of
- * triangles [t_begin, t_end) at their absolute positions dflag[t] (t_begin a multiple of 64) and only
+ * triangles [t_begin, t_end) at their absolute positions dflag[t] (any block boundaries) and only
  * enqueues; after the blocks of all ranks have been all-gathered into one flag array,
  * same_orient_from_flags_dev produces what same_orient_sweep produces: checked count and the ascending
  * list of flipped triangles (src/same.py:687-703 relies on that order).  The XY-order and area sweeps

@@ -91,7 +91,6 @@ struct same_sweep {
     size_t scan_zero_bytes = 0;
     unsigned long long *cnt = nullptr;
     int32_t *viol = nullptr;      // = (int32_t *)(cnt + 2)
-    unsigned long long *mask = nullptr;
     double *x = nullptr;          // [P]
 };
 

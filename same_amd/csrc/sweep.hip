@@ -38,48 +38,39 @@ __global__ __launch_bounds__(256) void match_resolve_kernel(const int32_t *__res
 }
 
 // ---- orientation sweep -------------------------------------------------------------------
-// counters[0] = checked, counters[1] = flipped (filled by the compaction kernel)
+// flags of a block of triangles (the sharded sweep's per-rank share): 0 not checked, 1 checked, 2 checked and flipped
 __global__ __launch_bounds__(256) void orient_flag_kernel(
     const int32_t *__restrict__ tris, int64_t Tr, const int8_t *__restrict__ src_sign, const double *__restrict__ rxy,
-    const int32_t *__restrict__ match, uint8_t *__restrict__ flag, unsigned long long *__restrict__ viol_mask,
-    unsigned long long *__restrict__ counters) {
+    const int32_t *__restrict__ match, uint8_t *__restrict__ flag) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint8_t f = 0;
-    if (t < Tr) {
-        const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
-        const int32_t ja = match[a], jb = match[b], jc = match[c];
-        const bool all3 = ja >= 0 && jb >= 0 && jc >= 0;           // src/same.py:649-650
-        const double2_t z = {0.0, 0.0};
-        f = orient_flag(src_sign[t], all3, all3 ? ld2(rxy, ja) : z, all3 ? ld2(rxy, jb) : z, all3 ? ld2(rxy, jc) : z);   // :658-669
-        flag[t] = f;
-    }
-    const unsigned long long checked = __ballot(f != 0);
-    const unsigned long long flipped = __ballot(f == 2);
-    __shared__ int wave_checked[4];
-    const int wave_in_block = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-        viol_mask[w] = flipped;
-        wave_checked[wave_in_block] = __builtin_popcountll(checked);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // one atomic per block, not per wave (integer sum: order-independent)
-        const int c = wave_checked[0] + wave_checked[1] + wave_checked[2] + wave_checked[3];
-        if (c) atomicAdd(&counters[0], (unsigned long long)c);
-    }
+    if (t >= Tr) return;
+    const int32_t a = tris[3 * t], b = tris[3 * t + 1], c = tris[3 * t + 2];
+    const int32_t ja = match[a], jb = match[b], jc = match[c];
+    const bool all3 = ja >= 0 && jb >= 0 && jc >= 0;           // src/same.py:649-650
+    const double2_t z = {0.0, 0.0};
+    flag[t] = orient_flag(src_sign[t], all3, all3 ? ld2(rxy, ja) : z, all3 ? ld2(rxy, jb) : z, all3 ? ld2(rxy, jc) : z);   // :658-669
 }
 
-// per-wave flipped masks + checked count from a complete flag array (sharded sweep: the flags were all-gathered)
-__global__ __launch_bounds__(256) void flag_mask_kernel(const uint8_t *__restrict__ flag, int64_t Tr,
-                                                         unsigned long long *__restrict__ viol_mask,
-                                                         unsigned long long *__restrict__ counters) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// checked counter and the ascending list of flipped triangles from a COMPLETE flag array (the all-gathered flags of a sharded
+// sweep), one launch: multi-block look-back scan (scan.h).  counters[0] = checked, counters[1] = flipped.
+__global__ __launch_bounds__(scan::NT) void flags_compact_kernel(const uint8_t *__restrict__ flag, int64_t Tr, unsigned long long *__restrict__ status,
+                                                                  int32_t *__restrict__ viol, unsigned long long *__restrict__ counters) {
+    __shared__ scan::Shared sh;
+    __shared__ int wave_checked[scan::NT / 64];
+    auto val = [&](int64_t i) { return scan::Pair{i < Tr && flag[i] == 2 ? 1u : 0u, 0u}; };
+    scan::Pair through;
+    const scan::Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const int64_t t = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
     const uint8_t f = t < Tr ? flag[t] : 0;
+    if (f == 2) viol[off.a] = (int32_t)t;
     const unsigned long long checked = __ballot(f != 0);
-    const unsigned long long flipped = __ballot(f == 2);
-    if ((threadIdx.x & 63) == 0) {
-        viol_mask[t >> 6] = flipped;
-        if (checked) atomicAdd(&counters[0], (unsigned long long)__builtin_popcountll(checked));
+    if ((threadIdx.x & 63) == 0) wave_checked[threadIdx.x >> 6] = __builtin_popcountll(checked);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int q = 0; q < scan::NT / 64; ++q) c += wave_checked[q];
+        if (c) atomicAdd(&counters[0], (unsigned long long)c);
+        if (blockIdx.x == gridDim.x - 1) counters[1] = through.a;
     }
 }
 
@@ -88,44 +79,6 @@ __global__ __launch_bounds__(256) void first_candidate_kernel(const int32_t *__r
                                                                int32_t *__restrict__ match) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < rows) match[i] = idx[i * k];
-}
-
-// one block: exclusive scan of popcount(mask[w]) in chunks of 1024 words, then expand bits
-__global__ __launch_bounds__(1024) void compact_mask_kernel(const unsigned long long *__restrict__ mask, int64_t n_words,
-                                                             int64_t n_items, int32_t *__restrict__ out_idx,
-                                                             unsigned long long *__restrict__ counters) {
-    __shared__ int wave_sum[16];
-    __shared__ long long carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n_words; base += 1024) {
-        const int64_t w = base + tid;
-        const unsigned long long m = w < n_words ? mask[w] : 0ull;
-        const int c = __builtin_popcountll(m);
-        int incl = c;  // inclusive scan within the wave
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        int wave_off = 0;
-        for (int q = 0; q < wave; ++q) wave_off += wave_sum[q];
-        long long pos = carry_s + wave_off + (incl - c);
-        unsigned long long bits = m;
-        while (bits) {
-            const int b = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const int64_t item = w * 64 + b;
-            if (item < n_items) out_idx[pos++] = (int32_t)item;
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s += wave_off + incl;
-        __syncthreads();
-    }
-    if (tid == 0) counters[1] = (unsigned long long)carry_s;
 }
 
 // The per-incumbent sweep in ONE launch: flag per triangle, the checked counter, and the flipped triangles as an ascending list
@@ -274,15 +227,13 @@ __global__ __launch_bounds__(256) void window_count_kernel(const double *__restr
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n > 0 ? n : 1, 256); }
 
-// flags of triangles [t_begin, t_end) of a bound sweep, written at their absolute positions in dflag; the
-// per-wave flipped masks and the checked counter are only produced when the block is the whole list
-int launch_orient_flags(same_sweep *s, const int32_t *dmatch, int64_t t_begin, int64_t t_end, uint8_t *dflag,
-                        unsigned long long *dmask, unsigned long long *dcnt) {
+// flags of triangles [t_begin, t_end) of a bound sweep, written at their absolute positions in dflag
+int launch_orient_flags(same_sweep *s, const int32_t *dmatch, int64_t t_begin, int64_t t_end, uint8_t *dflag) {
     same_ctx *ctx = s->ctx;
     const int64_t n = t_end - t_begin;
     if (n <= 0) return SAME_OK;
     hipLaunchKernelGGL(orient_flag_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, s->tris + 3 * t_begin, n,
-                       s->sign + t_begin, s->rxy, dmatch, dflag + t_begin, dmask, dcnt);
+                       s->sign + t_begin, s->rxy, dmatch, dflag + t_begin);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -314,18 +265,11 @@ int read_back(same_sweep *s, int64_t *out_checked, int32_t *out_viol_idx, int64_
     return SAME_OK;
 }
 
-// ascending list of flipped triangles + counters from a complete flag array (the single-GPU sweep's own flags,
-// or the all-gathered flags of a triangle-block sharded sweep)
-int compact_from_flags(same_sweep *s, const uint8_t *dflag, bool masks_ready, int64_t *out_checked, int32_t *out_viol_idx,
-                       int64_t *out_nviol) {
+// ascending list of flipped triangles + counters from a complete flag array (the all-gathered flags of a triangle-block sharded sweep)
+int compact_from_flags(same_sweep *s, const uint8_t *dflag, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol) {
     same_ctx *ctx = s->ctx;
-    const int64_t Tr = s->Tr, n_words = ceil_div(Tr, 64);
-    if (!masks_ready) {
-        HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(flag_mask_kernel, dim3(grid_for(Tr)), dim3(256), 0, ctx->stream, dflag, Tr, s->mask, s->cnt);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    hipLaunchKernelGGL(compact_mask_kernel, dim3(1), dim3(1024), 0, ctx->stream, s->mask, n_words, Tr, s->viol, s->cnt);
+    HIP_TRY(ctx, hipMemsetAsync(s->scan_base, 0, s->scan_zero_bytes, ctx->stream));
+    hipLaunchKernelGGL(flags_compact_kernel, dim3(scan::blocks_for(s->Tr)), dim3(scan::NT), 0, ctx->stream, dflag, s->Tr, s->scan_base, s->viol, s->cnt);
     HIP_TRY(ctx, hipGetLastError());
     return read_back(s, out_checked, out_viol_idx, out_nviol);
 }
@@ -366,7 +310,6 @@ int sweep_fill(same_sweep *s, const int32_t *tris, const int8_t *src_sign, const
     SAME_TRY(sweep_block<int32_t>(ctx, &s->match, (size_t)s->n_m, nullptr));
     SAME_TRY(sweep_block<int32_t>(ctx, &s->pidx, (size_t)s->n_m, nullptr));
     SAME_TRY(sweep_block<uint8_t>(ctx, &s->flag, (size_t)ceil_div(s->Tr, 256) * 256 + 256, nullptr));
-    SAME_TRY(sweep_block<unsigned long long>(ctx, &s->mask, (size_t)ceil_div(s->Tr, 256) * 4 + 4, nullptr));
     // one block: [scan words of orient_sweep_kernel | cnt[2] | the flipped list] -- the words and the counters are zeroed by one fill,
     // the counters and the head of the list come back in one copy
     const size_t words = scan::status_bytes(s->Tr) / 8;
@@ -423,7 +366,7 @@ void same_sweep_unbind(same_sweep *s) {
     same_ctx *ctx = s->ctx;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->mask, s->scan_base, s->x};   // viol lives in cnt's block
+    void *blocks[] = {s->tris, s->sign, s->rxy, s->pairs, s->match, s->pidx, s->flag, s->scan_base, s->x};   // viol lives in cnt's block
     for (void *b : blocks)
         if (b) (void)hipFree(b);
     delete s;
@@ -623,10 +566,8 @@ int same_orient_flags_dev(same_sweep *s, const int32_t *dmatch, int64_t t_begin,
     if (!s) return SAME_EINVAL;
     same_ctx *ctx = s->ctx;
     REQUIRE(ctx, t_begin >= 0 && t_begin <= t_end && t_end <= s->Tr && (t_begin == t_end || (dmatch && dflag)));
-    REQUIRE(ctx, t_begin == t_end || t_begin % 64 == 0);  // whole waves: a block's per-wave masks must not straddle its start
     SAME_TRY(same_use(ctx));
-    HIP_TRY(ctx, hipMemsetAsync(s->cnt, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    return launch_orient_flags(s, dmatch, t_begin, t_end, dflag, s->mask + t_begin / 64, s->cnt);
+    return launch_orient_flags(s, dmatch, t_begin, t_end, dflag);
 }
 
 int same_orient_from_flags_dev(same_sweep *s, const uint8_t *dflag, int64_t *out_checked, int32_t *out_viol_idx,
@@ -637,7 +578,7 @@ int same_orient_from_flags_dev(same_sweep *s, const uint8_t *dflag, int64_t *out
     *out_checked = 0;
     *out_nviol = 0;
     if (s->Tr == 0) return SAME_OK;
-    return compact_from_flags(s, dflag, false, out_checked, out_viol_idx, out_nviol);
+    return compact_from_flags(s, dflag, out_checked, out_viol_idx, out_nviol);
 }
 
 int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, int k, int32_t *dmatch) {

@@ -526,7 +526,12 @@ def test_sharded_sweeps_rccl_single_rank_and_block_forms(ops, oracle):
         ctx.check(L.same_orient_from_flags_dev(sweep, dflag.ptr, ctypes.byref(chk), viol.ctypes.data, ctypes.byref(nv)), "from_flags")
         assert chk.value == want_checked and np.array_equal(viol[: nv.value], want_viol)
         assert np.array_equal(dflag.download((Tr,), np.uint8), want_flag)
-    assert L.same_orient_flags_dev(sweep, dmatch.ptr, 10, 300, dflag.ptr) == -22      # block start must be a multiple of 64
+    # blocks need not start on a wave: ragged blocks give the same flags and list
+    ctx.check(L.same_dev_memset(H, dflag.ptr, 0, dflag.nbytes), "memset")
+    for t0, t1 in ((0, 10), (10, 301), (301, Tr)):
+        ctx.check(L.same_orient_flags_dev(sweep, dmatch.ptr, t0, t1, dflag.ptr), "flags")
+    ctx.check(L.same_orient_from_flags_dev(sweep, dflag.ptr, ctypes.byref(chk), viol.ctypes.data, ctypes.byref(nv)), "from_flags")
+    assert chk.value == want_checked and np.array_equal(viol[: nv.value], want_viol) and np.array_equal(dflag.download((Tr,), np.uint8), want_flag)
     assert L.same_orient_flags_dev(sweep, dmatch.ptr, 0, Tr + 1, dflag.ptr) == -22
     # first candidate of a padded list
     didx = ctx.to_device(idx)
