@@ -18,7 +18,7 @@ enum Slot {
     SL_A = 0, SL_R, SL_AXY, SL_RXY, SL_PAIRS, SL_OUT0, SL_OUT1, SL_OUT2, SL_TRIS, SL_MATCH,
     SL_SIGN, SL_SIZE, SL_TYPE, SL_FLAG0, SL_FLAG1, SL_FLAG2, SL_COUNTS, SL_X, SL_MASK,
     // uniform-grid index of the reference cells built per call by the un-indexed prune entry points (knn.hip)
-    SL_K_HIST, SL_K_RANK, SL_K_SXY, SL_K_SIDX, SL_K_BBOX,
+    SL_K_HIST, SL_K_RANK, SL_K_SXY, SL_K_SIDX, SL_K_BBOX, SL_K_START,
     SL_COUNT
 };
 

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "scan.h"
 
 namespace {
 
@@ -204,32 +205,16 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const double *__restric
     rank[j] = atomicAdd(&hist[(int64_t)cy * g.gx + cx], 1u);
 }
 
-// in-place exclusive scan of hist[0..n] (n+1 entries; hist[n] receives the total), one block
-__global__ __launch_bounds__(1024) void grid_scan_kernel(unsigned *__restrict__ hist, int64_t n) {
-    __shared__ unsigned wave_sum[16];
-    __shared__ unsigned carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t q = base + tid;
-        const unsigned c = q < n ? hist[q] : 0u;
-        unsigned incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        unsigned wave_off = 0;
-        for (int w = 0; w < wave; ++w) wave_off += wave_sum[w];
-        if (q < n) hist[q] = carry_s + wave_off + (incl - c);
-        __syncthreads();
-        if (tid == 1023) carry_s += wave_off + incl;
-        __syncthreads();
-    }
-    if (tid == 0) hist[n] = carry_s;
+// start[0..n] = exclusive scan of the cell counts (start[n] = their total): one launch over many blocks (scan.h)
+__global__ __launch_bounds__(scan::NT) void grid_scan_kernel(const unsigned *__restrict__ count, int64_t n, unsigned long long *__restrict__ status,
+                                                              unsigned *__restrict__ start) {
+    __shared__ scan::Shared sh;
+    auto val = [&](int64_t q) { return scan::Pair{q < n ? count[q] : 0u, 0u}; };
+    scan::Pair through;
+    const scan::Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const int64_t q = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    if (q < n) start[q] = off.a;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) start[n] = through.a;
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const double *__restrict__ rxy, int64_t n_r, GridDesc g,
@@ -365,14 +350,20 @@ int grid_geometry(same_ctx *ctx, const double *drxy, int64_t n_r, double radius,
     return SAME_OK;
 }
 
-// counting sort of the references by cell: start[cells+1] (exclusive scan), sorted XY and original indices
-int grid_fill(same_ctx *ctx, const double *drxy, int64_t n_r, const GridDesc &g, unsigned *dhist, unsigned *drank, double *dsxy,
+// counting sort of the references by cell: start[cells+1] (exclusive scan of the counts), sorted XY and original indices
+int grid_fill(same_ctx *ctx, const double *drxy, int64_t n_r, const GridDesc &g, unsigned *dstart, unsigned *drank, double *dsxy,
               int32_t *dsidx) {
     const int64_t cells = (int64_t)g.gx * g.gy;
-    HIP_TRY(ctx, hipMemsetAsync(dhist, 0, (size_t)(cells + 1) * sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dhist, cells);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dhist, drank,
+    // scratch: [scan words | counts per cell], zeroed by one fill
+    const size_t st_bytes = scan::status_bytes(cells);
+    unsigned char *scratch;
+    SAME_TRY(slot_as(ctx, SL_K_HIST, st_bytes + (size_t)cells * sizeof(unsigned), &scratch));
+    unsigned long long *dstatus = reinterpret_cast<unsigned long long *>(scratch);
+    unsigned *dcount = reinterpret_cast<unsigned *>(scratch + st_bytes);
+    HIP_TRY(ctx, hipMemsetAsync(scratch, 0, st_bytes + (size_t)cells * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dcount, drank);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(scan::blocks_for(cells)), dim3(scan::NT), 0, ctx->stream, dcount, cells, dstatus, dstart);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dstart, drank,
                        dsxy, dsidx);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
@@ -403,7 +394,7 @@ int launch_knn_grid(same_ctx *ctx, const double *daxy, const double *drxy, int64
     unsigned *dhist, *drank;
     double *dsxy;
     int32_t *dsidx;
-    SAME_TRY(slot_as(ctx, SL_K_HIST, (size_t)cells + 1, &dhist));
+    SAME_TRY(slot_as(ctx, SL_K_START, (size_t)cells + 1, &dhist));
     SAME_TRY(slot_as(ctx, SL_K_RANK, (size_t)n_r, &drank));
     SAME_TRY(slot_as(ctx, SL_K_SXY, (size_t)n_r * 2, &dsxy));
     SAME_TRY(slot_as(ctx, SL_K_SIDX, (size_t)n_r, &dsidx));

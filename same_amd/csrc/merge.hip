@@ -14,11 +14,12 @@
 //      pass each, all smaller strides of a stage inside LDS (2048 keys per workgroup)
 //   3. first[pair] = min over sorted positions s of rows with that pair: open-addressing table keyed by
 //      aligned_code << 32 | ref_code, 64-bit CAS to claim a slot, atomicMin on the position
-//   4. keep[s] = (s == first[pair of row at s]); ballot + popcount per wave, one scan over the wave counts,
-//      ordered scatter of the surviving ROW INDICES -> out_rows, in the reference's post-drop_duplicates order.
+//   4. keep[s] = (s == first[pair of row at s]); ordered compaction of the surviving ROW INDICES -> out_rows (one launch:
+//      multi-block look-back scan, scan.h), in the reference's post-drop_duplicates order.
 #include <algorithm>
 
 #include "common.h"
+#include "scan.h"
 
 namespace {
 
@@ -109,53 +110,27 @@ __global__ __launch_bounds__(256) void merge_first_kernel(const unsigned long lo
     atomicMin(&tfirst[pair_slot(tkey, mask, pair)], (unsigned int)s);
 }
 
-// keep flag per sorted position + the number kept in every wave of 64 positions
-__global__ __launch_bounds__(256) void merge_keep_kernel(const unsigned long long *__restrict__ key, int64_t n, const int32_t *__restrict__ a_code,
-                                                           const int32_t *__restrict__ r_code, unsigned long long *__restrict__ tkey,
-                                                           const unsigned int *__restrict__ tfirst, int64_t mask,
-                                                           unsigned long long *__restrict__ keep_mask, unsigned int *__restrict__ wave_count) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool keep = false;
-    if (s < n) {
-        const uint32_t row = (uint32_t)key[s];
+// keep[s] = (s is the first sorted position of its pair); the surviving ROW INDICES in sorted order, their number: one launch over
+// many blocks (look-back scan, scan.h; a block that has to recompute a predecessor's count probes the finished table again)
+__global__ __launch_bounds__(scan::NT) void merge_compact_kernel(const unsigned long long *__restrict__ key, int64_t n, const int32_t *__restrict__ a_code,
+                                                                  const int32_t *__restrict__ r_code, unsigned long long *__restrict__ tkey,
+                                                                  const unsigned int *__restrict__ tfirst, int64_t mask,
+                                                                  unsigned long long *__restrict__ status, int32_t *__restrict__ out_rows,
+                                                                  unsigned long long *__restrict__ out_total) {
+    __shared__ scan::Shared sh;
+    auto keep_of = [&](int64_t q) -> bool {
+        if (q >= n) return false;
+        const uint32_t row = (uint32_t)key[q];
         const unsigned long long pair = ((unsigned long long)(uint32_t)a_code[row] << 32) | (uint32_t)r_code[row];
-        keep = tfirst[pair_slot(tkey, mask, pair)] == (unsigned int)s;
-    }
-    const unsigned long long m = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && s < n) {   // lane 0 beyond n: the whole wave is
-        const int64_t w = s >> 6;
-        keep_mask[w] = m;
-        wave_count[w] = (unsigned int)__popcll(m);
-    }
-}
-
-// exclusive scan of the wave counts by ONE workgroup (tables here have at most a few thousand waves), total -> *out_total
-__global__ __launch_bounds__(1024) void merge_scan_kernel(unsigned int *__restrict__ wave_count, int64_t n_waves, unsigned long long *__restrict__ out_total) {
-    __shared__ unsigned int part[1024];
-    const int64_t per = (n_waves + 1023) / 1024, b = (int64_t)threadIdx.x * per, e = b + per < n_waves ? b + per : n_waves;
-    unsigned int sum = 0;
-    for (int64_t w = b; w < e; ++w) sum += wave_count[w];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partial sums
-        const unsigned int v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    unsigned int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (int64_t w = b; w < e; ++w) { const unsigned int c = wave_count[w]; wave_count[w] = run; run += c; }
-    if (threadIdx.x == 1023) *out_total = part[1023];
-}
-
-__global__ __launch_bounds__(256) void merge_scatter_kernel(const unsigned long long *__restrict__ key, int64_t n,
-                                                              const unsigned long long *__restrict__ keep_mask,
-                                                              const unsigned int *__restrict__ wave_start, int32_t *__restrict__ out_rows) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const unsigned long long m = keep_mask[s >> 6];
-    const int lane = (int)(s & 63);
-    if ((m >> lane) & 1ull) out_rows[wave_start[s >> 6] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)(uint32_t)key[s];
+        return tfirst[pair_slot(tkey, mask, pair)] == (unsigned int)q;
+    };
+    const int64_t s0 = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    const bool keep = keep_of(s0);
+    auto val = [&](int64_t q) { return scan::Pair{(q == s0 ? keep : keep_of(q)) ? 1u : 0u, 0u}; };
+    scan::Pair through;
+    const scan::Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    if (keep) out_rows[off.a] = (int32_t)(uint32_t)key[s0];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_total = through.a;
 }
 
 }  // namespace
@@ -190,11 +165,11 @@ extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_
     while (n_pad < n) n_pad <<= 1;
     int64_t slots = 2;
     while (slots < 2 * n) slots <<= 1;
-    const int64_t n_waves = ceil_div(n, 64);
     uint8_t *dviol;
     int32_t *dwin, *da, *dr, *dout;
-    unsigned long long *dkey, *dtkey, *dmask, *dtotal;
-    unsigned int *dtfirst, *dwave;
+    unsigned long long *dkey, *dtkey, *dstatus, *dtotal;
+    unsigned int *dtfirst;
+    const size_t st_words = scan::status_bytes(n) / 8;
     SAME_TRY(up_as(ctx, SL_FLAG0, viol, (size_t)n, &dviol));
     SAME_TRY(up_as(ctx, SL_PAIRS, window_id, (size_t)n, &dwin));
     SAME_TRY(up_as(ctx, SL_MATCH, aligned_code, (size_t)n, &da));
@@ -202,19 +177,18 @@ extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_
     SAME_TRY(slot_as(ctx, SL_X, (size_t)n_pad, &dkey));
     SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)slots, &dtkey));
     SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)slots, &dtfirst));
-    SAME_TRY(slot_as(ctx, SL_MASK, (size_t)n_waves + 1, &dmask));
-    SAME_TRY(slot_as(ctx, SL_COUNTS, (size_t)n_waves + 4, &dwave));
+    SAME_TRY(slot_as(ctx, SL_MASK, st_words + 2, &dstatus));      // the scan's words, then the total
     SAME_TRY(slot_as(ctx, SL_OUT2, (size_t)n, &dout));
-    dtotal = dmask + n_waves;
+    dtotal = dstatus + st_words;
     HIP_TRY(ctx, hipMemsetAsync(dtkey, 0xFF, (size_t)slots * 8, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(dtfirst, 0xFF, (size_t)slots * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(dstatus, 0, (st_words + 2) * 8, ctx->stream));
     hipLaunchKernelGGL(merge_key_kernel, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, ctx->stream, dviol, dwin, n, n_pad, dkey);
     SAME_TRY(same_sort_u64_core(ctx, dkey, n_pad));
     const unsigned grid = (unsigned)ceil_div(n, 256);
     hipLaunchKernelGGL(merge_first_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1);
-    hipLaunchKernelGGL(merge_keep_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1, dmask, dwave);
-    hipLaunchKernelGGL(merge_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dwave, n_waves, dtotal);
-    hipLaunchKernelGGL(merge_scatter_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, dmask, dwave, dout);
+    hipLaunchKernelGGL(merge_compact_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1,
+                       dstatus, dout, dtotal);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long total = 0;
     SAME_TRY(same_down(ctx, &total, dtotal, sizeof total));
