@@ -362,7 +362,7 @@ int grid_fill(same_ctx *ctx, const double *drxy, int64_t n_r, const GridDesc &g,
     unsigned *dcount = reinterpret_cast<unsigned *>(scratch + st_bytes);
     HIP_TRY(ctx, hipMemsetAsync(scratch, 0, st_bytes + (size_t)cells * sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL(grid_count_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dcount, drank);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(scan::blocks_for(cells)), dim3(scan::NT), 0, ctx->stream, dcount, cells, dstatus, dstart);
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(scan::blocks_for(cells)), dim3(scan::NT), 0, ctx->stream, dcount, cells, scan::arg(dstatus), dstart);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3((unsigned)ceil_div(n_r, 256)), dim3(256), 0, ctx->stream, drxy, n_r, g, dstart, drank,
                        dsxy, dsidx);
     HIP_TRY(ctx, hipGetLastError());

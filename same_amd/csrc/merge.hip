@@ -188,7 +188,7 @@ extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_
     const unsigned grid = (unsigned)ceil_div(n, 256);
     hipLaunchKernelGGL(merge_first_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1);
     hipLaunchKernelGGL(merge_compact_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1,
-                       dstatus, dout, dtotal);
+                       scan::arg(dstatus), dout, dtotal);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long total = 0;
     SAME_TRY(same_down(ctx, &total, dtotal, sizeof total));

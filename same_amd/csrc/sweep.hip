@@ -269,7 +269,7 @@ int read_back(same_sweep *s, int64_t *out_checked, int32_t *out_viol_idx, int64_
 int compact_from_flags(same_sweep *s, const uint8_t *dflag, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol) {
     same_ctx *ctx = s->ctx;
     HIP_TRY(ctx, hipMemsetAsync(s->scan_base, 0, s->scan_zero_bytes, ctx->stream));
-    hipLaunchKernelGGL(flags_compact_kernel, dim3(scan::blocks_for(s->Tr)), dim3(scan::NT), 0, ctx->stream, dflag, s->Tr, s->scan_base, s->viol, s->cnt);
+    hipLaunchKernelGGL(flags_compact_kernel, dim3(scan::blocks_for(s->Tr)), dim3(scan::NT), 0, ctx->stream, dflag, s->Tr, scan::arg(s->scan_base), s->viol, s->cnt);
     HIP_TRY(ctx, hipGetLastError());
     return read_back(s, out_checked, out_viol_idx, out_nviol);
 }
@@ -286,7 +286,7 @@ int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32
     if (s->Tr == 0) return SAME_OK;
     HIP_TRY(ctx, hipMemsetAsync(s->scan_base, 0, s->scan_zero_bytes, ctx->stream));     // the scan's words + the two counters: one fill
     hipLaunchKernelGGL(orient_sweep_kernel, dim3(scan::blocks_for(s->Tr)), dim3(scan::NT), 0, ctx->stream, s->tris, s->Tr, s->sign, s->rxy, dmatch,
-                       s->flag, s->scan_base, s->viol, s->cnt);
+                       s->flag, scan::arg(s->scan_base), s->viol, s->cnt);
     HIP_TRY(ctx, hipGetLastError());
     if (out_flag) SAME_TRY(same_down(ctx, out_flag, s->flag, (size_t)s->Tr));
     return read_back(s, out_checked, out_viol_idx, out_nviol);

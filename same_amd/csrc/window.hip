@@ -740,7 +740,7 @@ int subset_rows_full(same_window *w, const same_section *sec, const double *box,
     SAME_TRY(ensure(ctx, dst, (size_t)sec->n * sizeof(int32_t)));
     SAME_FILL(ctx, base, 0, zero_bytes);
     SAME_LAUNCH(ctx, box_mask_kernel, dim3(grid_for(sec->n)), dim3(256), 0, sec->xy, sec->n, box[0], box[1], box[2], box[3], mask);
-    SAME_LAUNCH(ctx, mask_compact_kernel, dim3(scan::blocks_for(n_words)), dim3(scan::NT), 0, mask, n_words, status,
+    SAME_LAUNCH(ctx, mask_compact_kernel, dim3(scan::blocks_for(n_words)), dim3(scan::NT), 0, mask, n_words, scan::arg(status),
                 static_cast<int32_t *>(dst.p), dcount);
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long *h = static_cast<unsigned long long *>(w->host);
@@ -1037,8 +1037,8 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
         }
         if (bm + br) SAME_LAUNCH(ctx, window_rows_kernel, dim3(bm + br), dim3(256), 0, dm, dr, bm, box[0], box[1], box[2], box[3]);
         if (compact_m || compact_r) {
-            const RowsCompact c_m{merged_m, compact_m ? (int)cap_m : 0, w->rows_m, reinterpret_cast<unsigned long long *>(at(o_st_cm)), dc};
-            const RowsCompact c_r{merged_r, compact_r ? (int)cap_r : 0, w->rows_r, reinterpret_cast<unsigned long long *>(at(o_st_cr)), dc + 1};
+            const RowsCompact c_m{merged_m, compact_m ? (int)cap_m : 0, w->rows_m, scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_cm))), dc};
+            const RowsCompact c_r{merged_r, compact_r ? (int)cap_r : 0, w->rows_r, scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_cr))), dc + 1};
             const unsigned b_m = compact_m ? scan::blocks_for(cap_m) : 0, b_r = compact_r ? scan::blocks_for(cap_r) : 0;
             SAME_LAUNCH(ctx, rows_compact_kernel, dim3(b_m + b_r), dim3(scan::NT), 0, c_m, c_r, b_m);
         }
@@ -1048,7 +1048,7 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
         SAME_TRY(same_padded_cost_window_core(ctx, w->cost_f32, mov->types_c, ref->types_c, T, mov->xy_c, ref->xy_c, w->rows_m, dc, cap_m, k,
                                               w->idx, dist_ct_coeff, cost));
         const ScatterArgs sa{w->idx, cost, w->cnt, w->rows_m, w->rows_r, mov->xy, mov->size, mov->type_id,
-                             reinterpret_cast<unsigned long long *>(at(o_st_scatter)), dc, w->ua, w->rows_ua, w->type_c, w->prow, w->pairs, w->jsec,
+                             scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_scatter))), dc, w->ua, w->rows_ua, w->type_c, w->prow, w->pairs, w->jsec,
                              w->axy_c, w->size_c, w->cost64, k};
         if (w->cost_f32)
             SAME_LAUNCH(ctx, window_scatter_kernel<float>, dim3(scan::blocks_for(cap_m)), dim3(scan::NT), 0, sa);
@@ -1152,11 +1152,11 @@ int enqueue_filter(same_window *w, const int32_t *simplices, int64_t Tr, double 
     SAME_LAUNCH(ctx, filter_classify_kernel, dim3(grid_for(Tr)), dim3(256), 0, w->axy_c, raw, Tr, radius, angle_enabled, cos_thr,
                 use_type ? w->type_c : nullptr, near_enabled, near_tol, cls, perim, has_kept, any_valid, plan->readd ? best_p : nullptr, dc);
     SAME_LAUNCH(ctx, filter_keep_kernel, dim3(scan::blocks_for(Tr)), dim3(scan::NT), 0, cls, perim, raw, Tr,
-                reinterpret_cast<unsigned long long *>(at(o_st_keep)), klist, plan->readd ? best_p : nullptr, best_t, dc);
+                scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_keep))), klist, plan->readd ? best_p : nullptr, best_t, dc);
     if (plan->readd) {
         SAME_LAUNCH(ctx, filter_first_node_kernel, dim3(grid_for(n)), dim3(256), 0, has_kept, any_valid, best_t, n, first_v);
         SAME_LAUNCH(ctx, filter_owner_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, has_kept, any_valid, best_t, first_v, n,
-                    reinterpret_cast<unsigned long long *>(at(o_st_own)), nlist, dc);
+                    scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_own))), nlist, dc);
     }
     SAME_LAUNCH(ctx, filter_emit_kernel, dim3(grid_for(Tr)), dim3(256), 0, raw, klist, nlist, best_t, dc, static_cast<int32_t *>(w->tris.p));
     HIP_TRY(ctx, hipGetLastError());

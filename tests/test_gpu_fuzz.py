@@ -329,3 +329,23 @@ def test_device_window_argument_checks(ops):
     assert not flag.any()
     for h in (st, da, da32, db):
         h.close()
+
+
+def test_scans_hold_when_no_block_ever_sees_a_predecessor():
+    """csrc/scan.h never waits: a block that finds a predecessor's word unpublished recomputes that block's counters from the input.
+    In a normal run that path is rare and timing-dependent, so here it carries everything: SAME_SCAN_FORCE_RECOMPUTE=1 makes every
+    look-back treat every predecessor as unpublished.  The window path, the merge, the prune index and the sweeps must not notice."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAME_SCAN_FORCE_RECOMPUTE="1", SAME_FUZZ_ROUNDS="1")
+    sel = ["tests/test_gpu_fuzz.py::test_fuzz_device_windows", "tests/test_gpu_fuzz.py::test_fuzz_knn_and_costs",
+           "tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline",
+           "tests/test_gpu_run_same.py::test_window_rows_do_not_depend_on_the_section_grid",
+           "tests/test_gpu_parity.py::test_sharded_sweeps_rccl_single_rank_and_block_forms", "tests/test_host_rows.py::test_merge_dedup_on_device"]
+    res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "not scans_hold"] + sel, cwd=root, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert " passed" in res.stdout
