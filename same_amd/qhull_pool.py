@@ -251,7 +251,8 @@ class QhullPool:
         # the ~200 KB of points go down the pipe WITHOUT the lock: a helper that is slow to read (or a pipe the kernel would not
         # enlarge) then stalls this thread only, not every other thread's hand-overs and pick-ups
         try:
-            p.stdin.write(struct.pack("<qq", t.seq, len(pts)) + pts.tobytes())
+            p.stdin.write(struct.pack("<qq", t.seq, len(pts)))
+            p.stdin.write(memoryview(pts).cast("B"))      # the array's own bytes: no tobytes() copy, no concatenation
             p.stdin.flush()
             ok = True
         except (OSError, ValueError):
