@@ -252,7 +252,8 @@ class QhullPool:
         # enlarge) then stalls this thread only, not every other thread's hand-overs and pick-ups
         try:
             p.stdin.write(struct.pack("<qq", t.seq, len(pts)))
-            p.stdin.write(memoryview(pts).cast("B"))      # the array's own bytes: no tobytes() copy, no concatenation
+            if len(pts):
+                p.stdin.write(memoryview(pts).cast("B"))  # the array's own bytes: no tobytes() copy, no concatenation
             p.stdin.flush()
             ok = True
         except (OSError, ValueError):
