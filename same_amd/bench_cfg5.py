@@ -6,7 +6,8 @@ import time
 
 from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 
-RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "windows_per_s_triangulations_given", "per_rank",
+RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s", "aligned_cells_per_window",
+               "windows_per_s_triangulations_given", "per_rank",
                "host_glue_share", "python_share",
                "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl")
 
@@ -262,6 +263,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                           "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
                                          "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
                "windows_per_s": len(plan) * steps / dt,
+               "aligned_cells_per_s": float(sum(w["n_mov"] for w in plan)) * steps / dt,
+               "aligned_cells_per_window": float(np.mean([w["n_mov"] for w in plan])),
                "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
                             "host_glue_share": [r["host_glue_share"] for r in every], "python_share": [r["python_share"] for r in every],
                             "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
