@@ -293,12 +293,16 @@ _W_ALIGNED_XY, _W_ALIGNED_ROWS, _W_ROWS_M, _W_ROWS_R, _W_PAIRS, _W_COSTS, _W_KEP
 def window_cell_grid(plan_or_grid, window_size, overlap):
     """(x0, y0, cell) of the grid on which every box of a window plan is a union of cells: the plan's boxes start at the grid
     origins int(x_min) + i * step and end window_size later (merged ones at a later origin + window_size: src/same.py:481-488,
-    :527-542), so with cell = gcd(step, window_size) all their edges are cell edges.  `plan_or_grid` = (xs, ys) of window_grid."""
+    :527-542), so with cell = gcd(step, window_size) all their edges are cell edges (window sizes whose gcd with the step is small get
+    quarter-window cells instead: correct for any box, only no longer test-free).  `plan_or_grid` = (xs, ys) of window_grid."""
     import math
 
     xs, ys = plan_or_grid
     step = int(window_size) - int(overlap)
-    return float(xs[0]), float(ys[0]), float(math.gcd(step, int(window_size)))
+    cell = float(math.gcd(step, int(window_size)))
+    if window_size / cell > 5:          # a window of more than ~5 x 5 such cells (8 x 8 once merged) would leave the cell-run path (<= 64 cells):
+        cell = window_size / 4.0        # quarter windows instead -- boxes then cut through cells and their candidates are tested, still O(window)
+    return float(xs[0]), float(ys[0]), cell
 
 
 class DeviceSection:

@@ -1027,7 +1027,8 @@ def test_window_rows_do_not_depend_on_the_section_grid():
     ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
     x0, y0, cell = W.window_cell_grid((xs, ys), 600, 150)
     assert cell == 150.0
-    grids = {"default": None, "window grid": (x0, y0, cell), "offset grid": (x0 + 37.25, y0 - 11.5, 211.0), "tiny cells": (x0, y0, 25.0)}
+    grids = {"default": None, "window grid": (x0, y0, cell), "offset grid": (x0 + 37.25, y0 - 11.5, 211.0), "tiny cells": (x0, y0, 25.0),
+             "quarter windows of an odd size": W.window_cell_grid((xs, ys), 601, 150)}
     got = {}
     for name, g in grids.items():
         dref, dmov = W.DeviceSection(ref_sec, "float32"), W.DeviceSection(mov_sec, "float32")

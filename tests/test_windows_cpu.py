@@ -43,3 +43,14 @@ def test_section_from_frame_keeps_what_the_pipeline_reads():
     assert rows.tolist() == [0, 1] and s.g_types[pos].tolist() == s.types[rows].tolist() and s.g_size[pos].tolist() == [1, 2]
     bare = Section.from_frame(df.drop(columns=["cell_type", "size"]), ["c1"])
     assert bare.type_id is None and bare.size.tolist() == [1, 1, 1] and np.issubdtype(bare.size.dtype, np.integer)
+
+
+def test_window_cell_grid_sizes():
+    """The grid the device sections are binned on: gcd(step, window) cells when a window is at most 5 x 5 of them (every box of the plan a
+    union of cells), quarter windows otherwise."""
+    from same_amd.windows import window_cell_grid
+
+    assert window_cell_grid(([7, 907], [3, 903]), 1200, 300) == (7.0, 3.0, 300.0)
+    assert window_cell_grid(([0], [0]), 1000, 250) == (0.0, 0.0, 250.0)
+    assert window_cell_grid(([0], [0]), 1001, 250) == (0.0, 0.0, 1001 / 4.0)       # gcd 1
+    assert window_cell_grid(([0], [0]), 700, 200) == (0.0, 0.0, 700 / 4.0)        # gcd 100: 7 x 7 cells a window
