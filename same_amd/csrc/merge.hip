@@ -151,7 +151,7 @@ int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad) {
 
 extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_t *window_id, const int32_t *aligned_code,
                                 const int32_t *ref_code, int64_t n, int32_t *out_rows, int64_t *out_n) {
-    REQUIRE(ctx, ctx && out_n && n >= 0 && n < ((int64_t)1 << 27));
+    REQUIRE(ctx, ctx && out_n && n >= 0 && n < ((int64_t)1 << 30));   // row indices and sorted positions are 32-bit, scan totals 31-bit; 2^30 rows need ~45 GB of scratch
     *out_n = 0;
     if (n == 0) return SAME_OK;
     REQUIRE(ctx, viol && window_id && aligned_code && ref_code && out_rows);
