@@ -490,6 +490,8 @@ class TriangulationCache:
     def submit(self, points, key=None):
         from . import qhull_pool
 
+        if key is None:                                   # a window without an id cannot be remembered
+            return qhull_pool.pool().submit(points)
         if key in self.known:
             return self._Ready(self.known[key])
         return self._Pending(self, key, qhull_pool.pool().submit(points))
