@@ -242,3 +242,26 @@ def test_threads_share_the_pool_without_waiting_on_each_other():
     waiter.join()
     assert box["n"] > 100_000 and quick < 0.6 * box["dt"], (quick, box["dt"])
     pool.close()
+
+
+def test_triangulation_cache_remembers_windows_by_id(monkeypatch):
+    """windows.TriangulationCache (bench.py's diagnostic pass): the first request of a window goes to the helper pool and its answer is
+    kept; the second is answered from memory; a window without an id is never remembered.  The simplices are scipy's either way."""
+    monkeypatch.setenv("SAME_QHULL_WORKERS", "1")
+    from same_amd import qhull_pool
+    from same_amd.windows import TriangulationCache
+
+    monkeypatch.setattr(qhull_pool, "_pool", None)
+    try:
+        rng = np.random.default_rng(11)
+        a, b = rng.uniform(0, 50, (300, 2)), rng.uniform(0, 50, (200, 2))
+        cache = TriangulationCache()
+        first = cache.submit(a, key=7)
+        assert 7 not in cache.known and np.array_equal(first.result(), Delaunay(a).simplices) and 7 in cache.known
+        again = cache.submit(b, key=7)                  # the id decides, not the points: the remembered answer comes back
+        assert np.array_equal(again.result(), Delaunay(a).simplices)
+        assert np.array_equal(cache.submit(b, key=None).result(), Delaunay(b).simplices) and list(cache.known) == [7]
+    finally:
+        if qhull_pool._pool is not None:
+            qhull_pool._pool.close()
+        monkeypatch.setattr(qhull_pool, "_pool", None)
