@@ -818,6 +818,41 @@ def test_window_tiler_equals_reference_loop():
                 assert not os.path.exists(csv)
 
 
+def test_device_window_rows_equal_the_reference_loops_frames():
+    """a13 on the device against the REFERENCE's own loop: for the ten seeded layouts of tests/golden/window_tiler.npz (merges of
+    under-populated windows included) the rows same_window_stage finds for every window of the plan -- sections binned on the window
+    grid -- are the cells of the frames the reference's sliding_window_matching handed its run_same, call by call, in order."""
+    from run_same_record import tiler_inputs
+
+    from same_amd import windows as W
+
+    g = load_golden("window_tiler")
+    st = W.DeviceWindow()
+    windows = 0
+    for q, cfg in enumerate(g["cfgs"]):
+        r_df, m_df = tiler_inputs(cfg)
+        ws, ov, mc = int(cfg[4]), int(cfg[5]), int(cfg[6])
+        rxy, mxy = r_df[["X", "Y"]].to_numpy(), m_df[["X", "Y"]].to_numpy()
+        plan = W.window_plan(rxy, mxy, ws, ov, mc)
+        xs, ys, _ = W.window_grid(rxy, mxy, ws, ov)
+        grid = W.window_cell_grid((xs, ys), ws, ov)
+        dref = W.DeviceSection(W.Section(rxy, np.ones((len(rxy), 1)), None, None), "float64").bin(*grid)
+        dmov = W.DeviceSection(W.Section(mxy, np.ones((len(mxy), 1)), None, None), "float64").bin(*grid)
+        a_off, r_off = g[f"c{q}/plain/a_off"], g[f"c{q}/plain/r_off"]
+        assert len(plan) == len(a_off) - 1, q
+        r_ids, m_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
+        for c, w in enumerate(plan):
+            n_m, n_r, _kept, _pairs = st.stage(dmov, dref, w["box"], 1.0, 1, 1.0)
+            assert np.array_equal(m_ids[st.fetch(W._W_ROWS_M)], g[f"c{q}/plain/a_ids"][a_off[c]:a_off[c + 1]]), (q, c)
+            assert np.array_equal(r_ids[st.fetch(W._W_ROWS_R)], g[f"c{q}/plain/r_ids"][r_off[c]:r_off[c + 1]]), (q, c)
+            assert (n_m, n_r) == (w["n_mov"], w["n_ref"])
+            windows += 1
+        dref.close()
+        dmov.close()
+    st.close()
+    assert windows > 60
+
+
 @pytest.mark.parametrize("ms", [1, 3])
 def test_real_tongue_flow_equals_reference(gp, ms, tmp_path, monkeypatch):
     """Real data (examples/tongue: 4 671 protein cells with UUID string ids against 3 608 RNA cells with 64-bit integer ids,
