@@ -687,6 +687,50 @@ def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res3).items()}, g, prefix="sw_infer/res_")
 
 
+def test_device_window_flow_equals_the_reference_window_loop():
+    """The device-resident window path END TO END against the reference's own sliding_window_matching (tests/golden/run_same_mock.npz,
+    `sw` and `sw_infer`: run there with the recording solver double, which takes the greedy MIP start as the incumbent): per window
+    stage -> Qhull -> filter -> greedy incumbent on the device, matched cells inside the central trim -- the (aligned id, reference id,
+    window id) rows, their order, the matched reference's coordinates and both XY columns equal the reference's result table."""
+    from same_amd import synth
+    from same_amd import windows as W
+
+    g = load_golden("run_same_mock")
+    cells = synth.make_cells(1500, 3, seed=51)
+    r_big = synth.to_frame(cells)
+    m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
+    m_big = m_big[~((m_big["X"] < 120) & (m_big["Y"] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
+    cols = synth.type_columns(3)
+    for prefix, ws, ov in (("sw", 150, 40), ("sw_infer", 220, 60)):
+        rxy, mxy = r_big[["X", "Y"]].to_numpy(), m_big[["X", "Y"]].to_numpy()
+        plan = W.window_plan(rxy, mxy, ws, ov, 60)
+        xs, ys, _ = W.window_grid(rxy, mxy, ws, ov)
+        ref_sec, mov_sec = W.Section.from_frame(r_big, cols), W.Section.from_frame(m_big, cols)
+        grid = W.window_cell_grid((xs, ys), ws, ov)
+        dref, dmov = W.DeviceSection(ref_sec, "float64").bin(*grid), W.DeviceSection(mov_sec, "float64").bin(*grid)
+        rows = {k: [] for k in ("a", "r", "x", "y", "rx", "ry", "w")}
+        for dw in W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, radius=20, knn=4, dist_ct_coeff=1.0, min_angle_deg=15,
+                                        ignore_same_type_triangles=True, no_match_penalty=100.0):
+            if dw.error is not None:
+                continue
+            x, y = dw.axy[:, 0], dw.axy[:, 1]
+            tx0, tx1, ty0, ty1 = dw.window["trim"]                        # src/same.py:565-582
+            c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
+            rows["a"].append(dw.rows_m[c]); rows["r"].append(dw.match_row[c]); rows["x"].append(x[c]); rows["y"].append(y[c])
+            rows["rx"].append(rxy[dw.match_row[c], 0]); rows["ry"].append(rxy[dw.match_row[c], 1])
+            rows["w"].append(np.full(len(c), dw.window["window_id"], np.int64))
+        got = {k: np.concatenate(v) for k, v in rows.items()}
+        want_a, want_r = g[f"{prefix}/res__Aligned_Cell_Num_Old"], g[f"{prefix}/res__Ref_Cell_Num_Old"]
+        a_ids, r_ids = m_big["Cell_Num_Old"].to_numpy(), r_big["Cell_Num_Old"].to_numpy()
+        assert np.array_equal(a_ids[got["a"]], want_a) and np.array_equal(r_ids[got["r"]], want_r), prefix
+        assert np.array_equal(got["w"], g[f"{prefix}/res__window_id"]), prefix
+        assert np.array_equal(got["x"], g[f"{prefix}/res__X"]) and np.array_equal(got["y"], g[f"{prefix}/res__Y"]), prefix
+        assert np.array_equal(got["rx"], g[f"{prefix}/res__ref_X"]) and np.array_equal(got["ry"], g[f"{prefix}/res__ref_Y"]), prefix
+        assert len(want_a) > 500
+        dref.close()
+        dmov.close()
+
+
 def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     """collapse both sections -> run_same on a MetaCell object -> unpack with per-match assignments -> windows over MetaCell
     objects: the reference's own pipeline, run there through the solver double, reproduced array for array."""
