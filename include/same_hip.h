@@ -414,7 +414,8 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *                     other boxes test the rows of the cells they cut.  A box covering more than 64 cells falls back to one
  *                     mask over the section.  Call it before windows use the section (not concurrently with them).  Sections
  *                     may be shared by the windows of several contexts of one device.
- *   same_window       the device state of one window in flight (buffers grow on demand and are reused).
+ *   same_window       the device state of one window in flight (buffers grow on demand and are reused).  It reads the two sections it was
+ *                     staged on until its finish call returns: destroy windows (or stage them elsewhere) before their sections.
  *   same_window_stage rows of both sections inside box = {x0,x1,y0,y1} (half-open, ascending row order), radius / k
  *     prune (src/utils.py:709-728), candidate costs (src/same.py:1180-1189), compaction of the aligned cells that have
  *     candidates and of the pair list (src/utils.py:734-742).  out_counts[4] = {aligned rows in the box, reference rows
