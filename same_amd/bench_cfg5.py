@@ -8,7 +8,7 @@ from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 
 RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s", "aligned_cells_per_window",
                "windows_per_s_triangulations_given", "per_rank",
-               "host_glue_share", "python_share",
+               "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step",
                "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl")
 
 
@@ -171,8 +171,12 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
             raise err
         return out
 
+    pass_seconds = [0.0]      # wall time of the window passes inside the timed loop (the threads' capacity is this x threads + the serial rest)
+
     def step():
+        t_pass = time.perf_counter()
         tabs, stats = all_ranks(one_pass, my_plan)
+        pass_seconds[0] += time.perf_counter() - t_pass
         mine_tab = {c: (np.concatenate([t[c] for t in tabs]) if tabs else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
         mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
         with _trace.stage("table exchange (all-gather)"):
@@ -228,9 +232,12 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
             all_ranks(one_pass, my_plan)
         no_qhull = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
         tri_cache[0] = None
+    # what the threads could have used: every worker for the window passes, one thread for the exchange + merge behind them
+    thread_seconds = max(pass_seconds[0] * n_workers + (wall_here - pass_seconds[0]), 1e-9)
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * steps / wall_here,
-                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / (wall_here * n_workers), "threads": n_workers,
-                "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / (wall_here * n_workers)),
+                "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / thread_seconds, "threads": n_workers,
+                "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / thread_seconds),
+                "qhull_wait_share": qhull_wait / thread_seconds, "serial_tail_s_per_step": (wall_here - pass_seconds[0]) / steps,
                 "windows_per_s_triangulations_given": no_qhull,
                 "runtime_calls_per_window": calls_per_window, "table_allgather_ms": (sum(exchange_ms) / len(exchange_ms)) if exchange_ms else None,
                 "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
@@ -273,9 +280,14 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                             "windows_per_s_triangulations_given": [r["windows_per_s_triangulations_given"] for r in every],
                             "qhull_l3_domains": [r["qhull_domains"] for r in every]},
                "host_glue_share": mine_rec["host_glue_share"],
-               "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the timed loop x threads), "
+               "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the window passes x threads + "
+                                        "wall time of the exchange and merge behind them, which one thread runs), "
                                         "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
                "python_share": mine_rec["python_share"],
+               "qhull_wait_share": mine_rec["qhull_wait_share"],
+               "qhull_wait_share_means": "the worker threads' waits for the Qhull helpers (hand-over when all are busy + collecting answers) over the same "
+                                         "capacity: host_glue_share = qhull_wait_share + python_share",
+               "serial_tail_s_per_step": mine_rec["serial_tail_s_per_step"],
                "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes of the "
                                      "threads' time (the merge and the table exchange included)",
                "threads_per_rank": n_workers,
