@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void dense_cost_kernel(
 // (one 64-byte run) and every row of the chunk consumes them, the row's own 8 values arriving as one wave-uniform scalar
 // load.  Per element that is still the two fp64 adds of the reference's left-to-right sum (the running sum is carried
 // across pieces, so the order of additions is unchanged) plus 1/32 of a vector load; stores are 8 B per lane, contiguous
-// across the wave.  Measured at 50k x 50k fp64 (profiles/r02_dense_generic_kernel.log): T=49 17.7 ms, T=64 22.8 ms,
+// across the wave.  Measured at 50k x 50k fp64 (profiles/archive/r02_dense_generic_kernel.log): T=49 17.7 ms, T=64 22.8 ms,
 // T=128 44.0 ms, i.e. ~14.5 T fp64 lane-instructions/s -- half the column-resident kernel's rate (one 64-byte scalar
 // load per 16 VALU instructions), against 497 / 616 / 1317 ms for the one-column-per-lane, load-per-element form it
 // replaces.  It also beats the column-resident kernel at fp64 T=48 (17.6 vs 20.6 ms, where that kernel is down to one
@@ -525,7 +525,7 @@ int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F 
     const int64_t rows = re - rb;
     // Store-bound shapes want every XCD to stream whole output rows (MAP_XCD_ROWS: 11.4 ms at 100k x 100k vs 14.1 ms for
     // MAP_XCD_TILES); once fp64 issue under the power cap is the limit (T >= 16, equal times) MAP_XCD_TILES keeps each XCD's
-    // share of R in its own L2 (profiles/r01_dense_map_fetch.md).
+    // share of R in its own L2 (profiles/archive/r01_dense_map_fetch.md).
     const int map = forced_map() >= 0 ? forced_map() : ((sizeof(F) == 8 && T >= 16) ? MAP_XCD_TILES : MAP_XCD_ROWS);
     // vector stores need whole CPL-groups: n_store (a multiple of CPL, n_r <= n_store <= ld) says how many
     // columns may be written; without such padding the scalar-store variant is used
@@ -536,7 +536,7 @@ int launch_dense_T(same_ctx *ctx, const F *A, const F *R, const F *axy, const F 
             const int col_tiles = (int)ceil_div(n_store, 256 * CPL);
             // enough row chunks to fill the chip several times over, long enough to amortise the column prologue: 256 rows per
             // block measured best at 100k x 100k (store-bound T<=12: 6.4-6.9 TB/s vs 5.9 at 64 or 512; T=20: equal) --
-            // profiles/r01_dense_probe_rpb.log
+            // profiles/archive/r01_dense_probe_rpb.log
             int rows_per_block = 256;
             while (rows_per_block > 32 && ceil_div(rows, rows_per_block) * col_tiles < 4096) rows_per_block /= 2;
             if (rows_per_block > rows) rows_per_block = (int)rows;   // fewer rows than one chunk: one chunk of exactly these rows
@@ -556,7 +556,7 @@ int launch_dense(same_ctx *ctx, const F *A, const F *R, int T, const F *axy, con
     SAME_TRY(same_use(ctx));
     if (n_r == 0 || re == rb) return SAME_OK;
     // above this many type columns the row-blocked kernel takes over from the column-resident one (measured crossover:
-    // profiles/r02_dense_generic_kernel.log)
+    // profiles/archive/r02_dense_generic_kernel.log)
     constexpr int rowblock_min_T = sizeof(F) == 8 ? 48 : 49;
     if (T < rowblock_min_T)
     switch (T) {

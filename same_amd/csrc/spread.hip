@@ -1,6 +1,6 @@
 // spread.hip -- HBM-region-aware allocation for the large streaming outputs of libsame_hip (the dense cost matrix).
 //
-// Measured on MI355X (profiles/r02_hbm_regions.md): the card's 288 GiB are three physical regions of 96 GiB, and a
+// Measured on MI355X (profiles/archive/r02_hbm_regions.md): the card's 288 GiB are three physical regions of 96 GiB, and a
 // streaming store confined to ONE region runs at ~5.5-5.8 TB/s while the same store spread over two or three regions runs
 // at ~7.0 TB/s.  hipMalloc hands an 80 GB buffer out of whatever regions its free lists hold, so the store time of the
 // 100k x 100k build moved between 11.4 and 14.4 ms from one allocation to the next (what round 1 read as a per-box
@@ -14,7 +14,7 @@
 // the driver.
 //
 // Two behaviours of this ROCm's virtual-memory calls shape the code (tools/probes/vmm_{remap,release,protocol}.hip,
-// profiles/r02_hbm_vmm_*.log):
+// profiles/archive/r02_hbm_vmm_*.log):
 //  * memory taken with hipMemCreate only returns to the card when the ADDRESS RANGE it was mapped in is handed back with
 //    hipMemAddressFree -- hipMemUnmap + hipMemRelease alone leave it charged;
 //  * an address that carried chunk X keeps reaching X after hipMemUnmap + hipMemMap of another chunk there for as long as
@@ -41,7 +41,7 @@ constexpr int MAX_REGIONS = 3;
 constexpr int MIXED = MAX_REGIONS;       // label of a chunk whose own two halves already run at the fast level (it straddles)
 constexpr size_t MIN_CHUNKS = 6;         // below this a plain allocation: nothing to spread
 constexpr double LEVEL_RATIO = 1.12;     // a rate above this multiple of the same-region level is the fast level (measured: same
-                                         // region 0.95-1.08x of the level, other region 1.18-1.27x: profiles/r02_spread_levels.log)
+                                         // region 0.95-1.08x of the level, other region 1.18-1.27x: profiles/archive/r02_spread_levels.log)
 constexpr size_t MAX_SHARE_PERMILLE = 500;   // chosen chunks: no region above half (4+4 over two regions runs within 2 % of 3+3+2)
 constexpr uintptr_t VA_FIRST = uintptr_t(0x100000000000);   // 16 TiB: far below where mmap / hipMalloc hand out addresses
 constexpr uintptr_t VA_LAST = uintptr_t(0x400000000000);    // 64 TiB: 48 TiB of never-reused addresses for this process

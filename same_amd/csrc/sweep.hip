@@ -277,7 +277,7 @@ int compact_from_flags(same_sweep *s, const uint8_t *dflag, int64_t *out_checked
 // The per-incumbent sweep from the handle's own match block is the launch-bound inner loop of the path (the solver calls it
 // for every incumbent): three stream operations -- one fill (scan words + counters), ONE kernel (flags, counters, ordered list),
 // one read-back.  Replaying the round-2 form (four operations) as one captured hipGraph was measured SLOWER on this ROCm (69 us
-// against 61 us per call at 95k triangles, profiles/r02_sweep_latency.log), so plain launches are the only form.
+// against 61 us per call at 95k triangles, profiles/archive/r02_sweep_latency.log), so plain launches are the only form.
 int run_orient(same_sweep *s, const int32_t *dmatch, int64_t *out_checked, int32_t *out_viol_idx, int64_t *out_nviol,
                uint8_t *out_flag) {
     same_ctx *ctx = s->ctx;
