@@ -114,7 +114,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
     from same_amd import qhull_pool as _share
 
-    cpu_share = _share.cpu_budget() / _share.local_world()[0]          # this rank's part of the host's CPUs
+    cpu_share = _share.cpu_budget() / _share.cpu_sharers()[0]          # this rank's part of the CPUs it may use
     default_threads = (2 if cpu_share >= 8 else 1) if on_device else 4  # a second Python thread only pays where there are CPUs to feed it
     n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else default_threads))
     worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]

@@ -15,6 +15,7 @@ WORKLOADS = {
 }
 STRONG_OF = {"dense100k": "cfg4"}   # the ONE-problem configuration embedded after a weak run of the key (else: the same shape)
 STRONG_CHUNK_BYTES = 40e9  # dense buffer of the strong mode (25k rows x 200k refs x 8 B)
+SPREAD_MAX_T = 12          # --spread auto: type counts up to this are bound by the store stream (placement over the HBM regions pays)
 
 
 def dense_kernel_label(dtype, T):
@@ -76,12 +77,16 @@ class Problem:
         self.ld = ld = (n_ref + 1) & ~1
         self.chunk_rows = max(1, min(max(rows, 1), int(STRONG_CHUNK_BYTES // (ld * 8)))) if strong else rows
         need = max(self.chunk_rows, 1) * ld * 8
+        self.spread = False
         if dense_buf is not None and dense_buf.nbytes >= need:
             self.dD, self.own_dense = dense_buf, False      # the resident block of the run's main problem, reused
         else:
-            # the dense cost block (80 GB at dense100k), laid over the card's three HBM regions: a streaming store confined to
-            # one region runs ~20 % below one spread over them, and a plain hipMalloc lands wherever the free lists point
-            self.dD, self.own_dense = ctx.alloc_spread(need), True
+            # the dense cost block (80 GB at dense100k).  A streaming store confined to one of the card's three HBM regions runs ~20 %
+            # below one spread over them, so STORE-BOUND shapes (T <= SPREAD_MAX_T) take the block from same_dev_alloc_spread; where fp64
+            # issue binds (the T = 20 headline: 16.88 ms plain against 17.04 ms spread) a plain hipMalloc is as fast, starts 0.4 s and
+            # 404 probe launches sooner and does not depend on timed stores while other ranks start beside this one
+            self.spread = args.spread == "on" or (args.spread == "auto" and T <= SPREAD_MAX_T)
+            self.dD, self.own_dense = (ctx.alloc_spread(need) if self.spread else ctx.alloc(need)), True
         ta = lambda n: keep(tctx.alloc(n))
         self.didx, self.dcost, self.dcnt = ta(block * k * 4), ta(block * k * 8), ta(max(block, 1) * 4)
         chk(L.same_dev_memset(TH, self.didx.ptr, 0xFF, self.didx.nbytes), "memset")   # rows past a short last block stay -1
@@ -270,6 +275,17 @@ class Problem:
         arith = ("fixed-point (2^-%d grid, every output within 1e-6 relative of the fp64 one) " % self.q_l2) if self.use_q32 else "fp64 "
         return (f"{self.name}: {shape}, T={self.T} type cols, {arith}dense L1 cost + r={self.radius:g}/k={self.k} KNN prune + pair costs + "
                 f"{self.Tr} Delaunay triangles classify/sign + orientation / XY-order / area-flip sweeps")
+
+    def respread(self):
+        """Replace a plain cost block of this problem by one laid over the HBM regions (the store-bound entries of the T sweep are
+        measured on such a block); the contents are lost.  No-op when the block is spread already or is not this problem's own."""
+        if self.spread or not self.own_dense:
+            return self.dD
+        self.env.ctx.sync()
+        nbytes = self.dD.nbytes
+        self.dD.free()
+        self.dD, self.spread = self.env.ctx.alloc_spread(nbytes), True
+        return self.dD
 
     def close(self, keep_dense=False):
         L = self.env.L

@@ -35,6 +35,8 @@
 #include <cmath>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -629,7 +631,10 @@ struct same_section {
     // prune indices of this section as the REFERENCE side, one per radius used (built on first use, under the lock: sections are
     // shared by the worker threads' contexts)
     std::mutex lock;
-    std::vector<std::pair<double, same_knn_index *>> knn;
+    std::vector<std::pair<double, same_knn_index *>> knn;   // most recently used first; at most MAX_KNN_INDICES (the oldest is dropped)
+    // grid, order, starts, h_starts: read (shared) by every stage call from cover_of() until its kernels are enqueued, replaced
+    // (exclusive, after a device-wide wait: kernels enqueued earlier may still be reading the old arrays) by same_section_bin
+    std::shared_mutex grid_lock;
 };
 
 struct same_window {
@@ -675,12 +680,23 @@ int ensure_host(same_window *w, size_t bytes) {
 int knn_index_for(same_ctx *ctx, const same_section *ref, double radius, const same_knn_index **out) {
     same_section *s = const_cast<same_section *>(ref);
     std::lock_guard<std::mutex> hold(s->lock);
-    for (const auto &e : s->knn)
-        if (e.first == radius) { *out = e.second; return SAME_OK; }
-    REQUIRE(ctx, s->knn.size() < 16);      // one index per radius a section is pruned with: a handful, not a stream of them
+    for (size_t q = 0; q < s->knn.size(); ++q)
+        if (s->knn[q].first == radius) {
+            if (q) std::rotate(s->knn.begin(), s->knn.begin() + q, s->knn.begin() + q + 1);     // most recently used first
+            *out = s->knn.front().second;
+            return SAME_OK;
+        }
+    // one index per radius a section is pruned with: a handful in a run, a stream of them in a parameter search over one long-lived
+    // section -- the least recently used one goes when the table is full (each holds a sorted copy of the section's XY and rows)
+    constexpr size_t MAX_KNN_INDICES = 16;
+    if (s->knn.size() >= MAX_KNN_INDICES) {
+        HIP_TRY(ctx, hipDeviceSynchronize());       // windows of other contexts may have kernels in flight that read it
+        same_knn_index_destroy(s->knn.back().second);
+        s->knn.pop_back();
+    }
     same_knn_index *ix = nullptr;
     SAME_TRY(same_knn_index_build(ctx, s->xy, s->n, radius, &ix));
-    s->knn.emplace_back(radius, ix);
+    s->knn.insert(s->knn.begin(), std::make_pair(radius, ix));
     *out = ix;
     return SAME_OK;
 }
@@ -836,6 +852,9 @@ int bin_section(same_ctx *ctx, same_section *s, double x0, double y0, double cw,
     } else {
         h_starts.assign(2, 0u);
     }
+    // the swap: no stage call is between cover_of() and its last enqueue (exclusive lock), and what was enqueued before has finished
+    std::unique_lock<std::shared_mutex> swap_hold(s->grid_lock);
+    if (s->order || s->starts) (void)hipDeviceSynchronize();
     if (s->order) (void)hipFree(s->order);
     if (s->starts) (void)hipFree(s->starts);
     s->grid = g;
@@ -959,6 +978,9 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     for (int q = 0; q < 4; ++q) out_counts[q] = 0;
     const same_knn_index *ix = nullptr;
     SAME_TRY(knn_index_for(ctx, ref, radius, &ix));
+    // both sections' grids stay as they are until this call's kernels are enqueued (same_section_bin waits for this, then for the device)
+    std::shared_lock<std::shared_mutex> grid_m(const_cast<same_section *>(mov)->grid_lock), grid_r;
+    if (ref != mov) grid_r = std::shared_lock<std::shared_mutex>(const_cast<same_section *>(ref)->grid_lock);
 
     // the candidates: rows of the cells the box covers (their number is known here), or a mask over the whole section
     Cover cm = cover_of(mov, box), cr = cover_of(ref, box);

@@ -13,8 +13,9 @@ helpers import numpy + scipy.spatial only -- they never touch the GPU).  `SAME_Q
 (default: one and a half times this process's SHARE of the CPUs it may use, at most 24 -- a helper is idle while its points and
 simplices travel and until the next request reaches it, so a modest over-subscription keeps the cores busy: 576 -> 694 windows/s
 from 16 to 24 helpers under a 16-CPU quota, profiles/r03_cfg5_device_pipeline.log; 0 = compute in-process, no helpers).  The share:
-the affinity mask and the cgroup quota are the same for every rank of a job on one host, so the budget is divided by the ranks that
-share it (`local_world()`: LOCAL_WORLD_SIZE, else WORLD_SIZE of a single-host rendezvous) -- eight ranks on a 16-CPU quota start 24
+ranks launched plainly see the same affinity mask and cgroup quota, so the budget is divided by the ranks that share it
+(`cpu_sharers()`: `local_world()` = LOCAL_WORLD_SIZE, else WORLD_SIZE of a single-host rendezvous -- unless the mask is already a
+1 / L slice of the host, i.e. the launcher bound every rank to CPUs of its own) -- eight ranks on a 16-CPU quota start 24
 helpers between them, not 192 (two ranks on one box ran 455 windows/s against 714 for one before the division).
 
 Placement matters more than the count: Qhull lives in the last-level cache, and eight helpers that the scheduler stacks on one
@@ -142,6 +143,32 @@ def local_world():
     return n, min(max(0, r or 0), n - 1)
 
 
+def cpu_sharers():
+    """(ranks of this job that share the CPUs of `cpu_budget()`, this rank's index among them).  Ranks launched plainly all see the same
+    affinity mask and cgroup quota, and the budget is divided between the `local_world()` of them.  A BOUND launch (slurm --cpu-bind,
+    numactl, one cpuset per rank) hands every rank a mask of its own: `cpu_budget()` is then already this rank's share and dividing it
+    again would leave 1 / L of the helpers (3 instead of 24 at eight ranks).  The two are told apart by the mask itself: one no larger
+    than the rank's 1 / L part of the host's CPUs is taken to be the rank's own.  SAME_CPU_SHARERS overrides the count."""
+    n, r = local_world()
+    v = os.environ.get("SAME_CPU_SHARERS")
+    if v is not None:
+        try:
+            n = max(1, int(v))
+            return n, min(r, n - 1)
+        except ValueError:
+            pass
+    if n <= 1:
+        return 1, 0
+    try:
+        mask = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return n, r
+    host = os.cpu_count() or mask
+    if mask * n <= host:
+        return 1, 0
+    return n, r
+
+
 def _domain_share(domains, n_local, local_rank):
     """The L3 domains local rank `local_rank` of `n_local` places its helpers in: an equal run of the list when there are at least as
     many domains as ranks, otherwise the one domain the rank's position falls into (ranks then share it)."""
@@ -162,7 +189,7 @@ class QhullPool:
         self.domains = _l3_domains() if pin else []
         if len(self.domains) < 2:
             self.domains = []                                          # one cache domain (or an unknown layout): nothing to choose
-        self.domains = _domain_share(self.domains, *local_world())     # this rank's part of the host
+        self.domains = _domain_share(self.domains, *cpu_sharers())     # this rank's part of the CPUs it shares with other local ranks
         self.first_domain = 0
         self.procs = []
         self.pending = {}            # worker index -> ticket whose answer has not been read yet
@@ -358,7 +385,7 @@ def default_workers():
     if v is not None:
         return max(0, int(v))
     b = cpu_budget()
-    return max(1, min(24, (3 * b) // (2 * local_world()[0])))
+    return max(1, min(24, (3 * b) // (2 * cpu_sharers()[0])))
 
 
 def warm(count=None):

@@ -487,14 +487,22 @@ class TriangulationCache:
     def __init__(self):
         self.known = {}
 
+    @staticmethod
+    def _tag(points, key):
+        """What an entry is remembered under: the window's id AND its points (count + a checksum of the coordinates' bits), so that a
+        cache reused with another plan or section whose windows reuse ids asks the pool again instead of answering with stale simplices."""
+        p = np.ascontiguousarray(points, dtype=np.float64)
+        return key, len(p), int(np.bitwise_xor.reduce(p.view(np.uint64).ravel())) if len(p) else 0
+
     def submit(self, points, key=None):
         from . import qhull_pool
 
         if key is None:                                   # a window without an id cannot be remembered
             return qhull_pool.pool().submit(points)
-        if key in self.known:
-            return self._Ready(self.known[key])
-        return self._Pending(self, key, qhull_pool.pool().submit(points))
+        tag = self._tag(points, key)
+        if tag in self.known:
+            return self._Ready(self.known[tag])
+        return self._Pending(self, tag, qhull_pool.pool().submit(points))
 
 
 def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,

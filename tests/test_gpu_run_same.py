@@ -296,7 +296,8 @@ def test_bench_contract_line(force_comm):
         if rf["telemetry"].get("available") and rf["telemetry"].get("sclk_steady"):
             assert 0.0 < rf["valu_busy_frac"] <= 1.05 and rf["valu_floor_ms_at_held_clock"] > 0 and rf["held_clock_mhz"] > 500
         assert rf["measured_ceilings"]["device_copy_GBs"] > 0 and rf["frac_of_measured_copy_bw"] > 0
-        assert "verified" in rf["output_buffer"]
+        assert rf["output_buffer"]["spread"] is False       # T = 20 is bound by fp64 issue: the timed loop stores into a plain block (--spread auto)
+        assert all("output_buffer" in e for e in rf["sweep"] if not e.get("opt_in"))
         assert rf["pruned_path"]["cell_pairs_per_s"] > out["value"] and rf["triangle_maps_and_sweeps"]["triangles_per_s"] > 0
         rm = rf["realistic_matching"]        # jittered copy + greedy start: most rows matched, few flips among many checked triangles
         assert rm["matched_rows"] > 0.8 * 0.9 * 4000 and rm["orientation_checked"] > 1000 and rm["orientation_flipped"] < 0.2 * rm["orientation_checked"]

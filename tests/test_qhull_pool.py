@@ -134,6 +134,18 @@ def test_the_cpu_budget_is_divided_by_the_ranks_on_the_host(monkeypatch):
     assert qhull_pool.local_world()[0] == 2 and qhull_pool.default_workers() == 12
     monkeypatch.setenv("SAME_QHULL_WORKERS", "7")                               # the explicit count is per process, not divided
     assert qhull_pool.default_workers() == 7
+    monkeypatch.delenv("SAME_QHULL_WORKERS")
+    # a bound launch (slurm --cpu-bind, numactl, per-rank cpusets): the mask is already the rank's own 1 / L slice -> not divided again
+    import os
+    monkeypatch.setenv("SAME_LOCAL_WORLD", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(os, "cpu_count", lambda: 128)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)))
+    assert qhull_pool.cpu_sharers() == (1, 0) and qhull_pool.default_workers() == 24
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))   # every rank sees the whole host: shared
+    assert qhull_pool.cpu_sharers() == (8, 5) and qhull_pool.default_workers() == 3
+    monkeypatch.setenv("SAME_CPU_SHARERS", "2")
+    assert qhull_pool.cpu_sharers() == (2, 1) and qhull_pool.default_workers() == 12
     doms = [[c] for c in range(8)]
     assert [qhull_pool._domain_share(doms, 4, r) for r in range(4)] == [[[0], [1]], [[2], [3]], [[4], [5]], [[6], [7]]]
     assert [qhull_pool._domain_share(doms[:2], 4, r) for r in range(4)] == [[[0]], [[0]], [[1]], [[1]]]
