@@ -425,7 +425,8 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *     :1040-1060) -> source signs / weights (:1128-1146), greedy MIP start with prefer = rowmin < no_match_penalty * size
  *     (src/init_helpers.py:104-133), lazy-constraint body (:645-669), XY-order sweep (src/violationhelper.py:53-117), area
  *     flips (:1362-1402).  out_match_row[kept] = SECTION row of the matched reference cell or -1, out_point_flag[kept] =
- *     the XY-order sweep's per-cell flag, out_stats[8] = {orientation checked, flipped, XY comparisons, XY violations,
+ *     per-cell flag byte: bit 0 the XY-order sweep flags the cell (src/violationhelper.py:100-104), bit 1 the cell is a vertex of a
+ *     triangle whose signed area flips (src/same.py:1464-1469), out_stats[8] = {orientation checked, flipped, XY comparisons, XY violations,
  *     triangles with a violation, area flips, greedy rounds, matched cells}.
  *   same_window_filter (optional, between the two): the Delaunay simplices of the kept aligned cells ->
  *     filter_triangles_by_radius on the device (src/helpers.py:233-395: classes :300-330, the keep list, the same-type

@@ -16,7 +16,8 @@ from .triangles import (filter_triangles_by_radius, precompute_triangle_info, pr
 from .sweeps import (LazyOrientationSweep, verify_spatial_preservation, print_violation_report,  # noqa: F401
                      triangle_area_flips)
 from .init_helpers import compute_mip_start_pairs, apply_mip_start  # noqa: F401
-from .api import iter_prepared_windows, prepare_same_inputs, run_same, sliding_window_matching, subset_data  # noqa: F401
+from .api import iter_prepared_windows, prepare_same_inputs, resident_frames, run_same, sliding_window_matching, subset_data  # noqa: F401
+from .incumbent import sliding_window_incumbent  # noqa: F401
 from .windows import window_plan  # noqa: F401
 from .metacell_utils import MetaCell, greedy_triangle_collapse, unpack_metacell_matches  # noqa: F401
 from .merge import merge_window_matches_unique_ref, load_matching_results  # noqa: F401
@@ -24,7 +25,7 @@ from .eval_utils import check_triangle_violations  # noqa: F401
 
 __version__ = "0.1.0"
 __all__ = [
-    "init_gurobi_params", "init_optim_params", "sliding_window_matching", "run_same", "prepare_same_inputs",
+    "init_gurobi_params", "init_optim_params", "sliding_window_matching", "sliding_window_incumbent", "run_same", "prepare_same_inputs",
     "find_knn_within_radius", "find_knn_with_cell_type_priority", "pair_costs", "dense_cost_matrix",
     "filter_triangles_by_radius", "precompute_triangle_info", "triangle_weights_and_signs",
     "LazyOrientationSweep", "verify_spatial_preservation", "print_violation_report", "triangle_area_flips",

@@ -553,6 +553,12 @@ __global__ __launch_bounds__(256) void match_rows_kernel(const int32_t *__restri
         if (ob) atomicAdd(&counters[SC_REMAINING], (unsigned long long)__builtin_popcountll(ob));
     }
 }
+// per-cell flag byte: bit 0 = the XY-order sweep flags the cell (src/violationhelper.py:100-104), bit 1 = the cell is a vertex of a
+// triangle whose signed area flips (src/same.py:1464-1469).  Two kinds of writers share a byte, so they OR into its 32-bit word
+// (the array is word-aligned and padded to whole words by its carver; flagged cells are the exception, not the rule).
+__device__ __forceinline__ void cell_flag_or(uint8_t *flags, int32_t i, unsigned bit) {
+    atomicOr(reinterpret_cast<unsigned *>(flags) + (i >> 2), bit << (8 * (i & 3)));
+}
 // one pass over the kept triangles: source sign and weight (src/same.py:1128-1146), the lazy-constraint body under the incumbent
 // (:645-669), the XY-order sweep (src/violationhelper.py:53-117), the signed-area flip (src/same.py:1362-1402; helpers.py:73-77)
 __global__ __launch_bounds__(256) void window_sweeps_kernel(const int32_t *__restrict__ tris, int64_t Tr, const unsigned long long *__restrict__ dTr,
@@ -587,12 +593,14 @@ __global__ __launch_bounds__(256) void window_sweeps_kernel(const int32_t *__res
                 ++ncmp;
                 const uint8_t e2 = xyorder_edge(a[p], a[q], r[p], r[q]);
                 nviol += ((e2 >> 1) & 1) + ((e2 >> 2) & 1);
-                if (e2) { tv = 1; pflag[v[p]] = 1; pflag[v[q]] = 1; }  // benign: every writer stores 1
+                if (e2) { tv = 1; cell_flag_or(pflag, v[p], 1u); cell_flag_or(pflag, v[q], 1u); }
             }
         }
         if (all3) {
             const double bf = signed_area(a[0], a[1], a[2]), af = signed_area(r[0], r[1], r[2]);
             aflip = bf * af < 0.0;                                         // src/same.py:1401
+            if (aflip)
+                for (int q = 0; q < 3; ++q) cell_flag_or(pflag, v[q], 2u);
         }
     }
     int vals[6] = {checked, flipped, ncmp, nviol, tv, aflip};

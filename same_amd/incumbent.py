@@ -1,0 +1,264 @@
+"""The window loop without a solver: sliding_window_matching (src/same.py:297-595) with every window's solution taken to be the greedy
+MIP start (src/init_helpers.py:104-133) -- the incumbent the reference itself hands Gurobi first -- swept by the lazy-constraint body
+(src/same.py:645-669), the XY-order sweep (src/violationhelper.py:53-117) and the area flips (src/same.py:1362-1402), and trimmed
+to each window's central region (src/same.py:565-582).  It is the product function for hosts without a Gurobi licence, the first stage
+of a two-stage run (the table is what `merge_window_matches_unique_ref` takes) and what `bench.py --workload cfg5` times.
+
+Same arguments as `sliding_window_matching`; the result has its columns wherever they are defined without a solver:
+
+    aligned_idx [ref_idx] <commonCT...> X Y ref_X ref_Y size ref_size Ref_<cell_id_col> Aligned_<cell_id_col> time_limit_reached
+    triangle_violation filtered_violation run_time window_id
+
+* `triangle_violation`: the cell is a vertex of a triangle whose signed area flips under the matching (as src/same.py:1464-1469).
+* `filtered_violation`: the reference intersects the XY-order sweep's points with the triangles the SOLVER penalised
+  (src/same.py:1411-1432); without a solver there are no penalties, and the column carries the sweep's own per-cell flag -- the
+  ranking key the window merge sorts by (src/helpers.py:745-753) keeps its meaning: unflagged proposals of a pair win.
+* `ref_idx` (index in the window's compacted reference frame) needs the window's pair list on the host and is only made on request
+  (`window_local_indices=True`); `aligned_idx` is free.  `run_time` is 0.0, `time_limit_reached` False.
+
+Two routes produce the same table (tests/test_gpu_run_same.py::test_incumbent_table_routes_agree):
+  device   both frames resident on the GPU, two library calls per window, the incumbent and the sweeps computed where the pairs are
+           (csrc/window.hip); the host triangulates, receives (match, flags) per window and gathers the table's columns ONCE at the
+           end.  Windows are walked by `workers` threads with a context each.
+  general  every window becomes a `PreparedInputs` (either pipeline of same_amd.api) and the incumbent + sweeps run through the
+           host-buffer entry points: caller-supplied triangulations (MetaCell inputs), the cell-type-priority filter, inputs the
+           sections cannot hold.
+"""
+import os
+import threading
+
+import numpy as np
+import pandas as pd
+
+from . import ops
+from ._trace import stage
+from .api import (_DeviceFrames, _WindowJob, _WindowSubsetter, _prepared_from_device, _stage_prune, _staged_from_device, prepare_same_inputs,
+                  window_pipeline)
+
+STAT_KEYS = ("pairs", "triangles", "checked", "flipped", "xy_violations", "area_flips", "matched")
+
+
+def _default_workers():
+    from . import qhull_pool
+
+    share = qhull_pool.cpu_budget() / qhull_pool.cpu_sharers()[0]
+    return 2 if share >= 8 else 1       # a second Python thread only pays where there are CPUs to feed it
+
+
+class _Chunks:
+    """The device route's per-window pieces: section rows of the matched cells inside the central trim, in window order."""
+
+    COLS = ("pos", "window_id", "rows_a", "rows_r", "aligned_idx", "ref_idx", "xy_flag", "flip_flag")
+
+    def __init__(self):
+        self.parts = []
+
+    def add(self, pos, w, dw, ref_idx=None):
+        x, y = dw.axy[:, 0], dw.axy[:, 1]
+        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:565-582), matched cells only
+        c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
+        self.parts.append((pos, w["window_id"], dw.rows_m[c], dw.match_row[c], c, None if ref_idx is None else ref_idx[c],
+                           dw.point_flag[c].astype(bool), dw.flip_flag[c].astype(bool)))
+
+    def table(self, job, with_ref_idx):
+        """One gather per column over all windows' rows: the frame sliding_window_matching would have concatenated."""
+        parts = sorted(self.parts, key=lambda p: p[0])
+        if not parts or not sum(len(p[2]) for p in parts):
+            return pd.DataFrame()
+        cat = lambda q, dt=None: np.concatenate([p[q] for p in parts]) if dt is None else np.concatenate([p[q] for p in parts]).astype(dt)
+        ra, rr = cat(2).astype(np.int64), cat(3).astype(np.int64)
+        ref, mov, cid = job.ref, job.moving, job.optim_params["cell_id_col"]
+        out = {"aligned_idx": cat(4, np.int64)}
+        if with_ref_idx:
+            out["ref_idx"] = cat(5, np.int64)
+        for ct in list(job.commonCT) + ["X", "Y"]:
+            out[ct] = mov[ct].to_numpy()[ra]
+        for ct in ("X", "Y"):
+            out[f"ref_{ct}"] = ref[ct].to_numpy()[rr]
+        out["size"] = mov["size"].to_numpy()[ra] if "size" in mov.columns else np.ones(len(ra), np.int64)
+        out["ref_size"] = ref["size"].to_numpy()[rr] if "size" in ref.columns else np.ones(len(rr), np.int64)
+        out[f"Ref_{cid}"] = ref[cid].to_numpy()[rr]
+        out[f"Aligned_{cid}"] = mov[cid].to_numpy()[ra]
+        out["time_limit_reached"] = np.zeros(len(ra), bool)
+        out["triangle_violation"] = cat(7)
+        out["filtered_violation"] = cat(6)
+        out["run_time"] = np.zeros(len(ra))
+        out["window_id"] = np.concatenate([np.full(len(p[2]), p[1], np.int64) for p in parts])
+        if job.mine is not None:
+            out["__plan_pos"] = np.concatenate([np.full(len(p[2]), p[0], np.int64) for p in parts])
+        return pd.DataFrame(out)
+
+
+def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None):
+    """(match table of ONE window as run_same's post-solve builds it, stats) from its pre-MIP artefacts, through the host-buffer entry
+    points: greedy start -> matching -> lazy-constraint body, XY-order sweep, area flips.  The general route of this module."""
+    op = prep.optim_params
+    pairs = np.ascontiguousarray(np.asarray(prep.valid_pairs, dtype=np.int64).reshape(-1, 2), dtype=np.int32)
+    costs, n_a, n_r = prep.costs_array, prep.n_aligned, prep.n_ref
+    a_df, r_df, tris = prep.aligned_df, prep.ref_df, prep.triangles_array
+    size = a_df["size"].to_numpy(dtype=np.float64)
+    wants = ops.pair_rowmin(pairs, costs, n_a, ctx=ctx) < float(op["no_match_penalty"]) * size       # src/init_helpers.py:104,118-122
+    pair_of_row, _rounds = ops.greedy_match(pairs, costs, n_a, n_r, wants, ctx=ctx)
+    ai = np.flatnonzero(pair_of_row >= 0)
+    ri = pairs[pair_of_row[ai], 1].astype(np.int64)
+    match = np.full(n_a, -1, np.int32)
+    match[ai] = ri
+    axy, rxy = a_df[["X", "Y"]].to_numpy(dtype=np.float64), r_df[["X", "Y"]].to_numpy(dtype=np.float64)
+    t32 = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    sw = ops.BoundSweep(t32, prep.signs_array.astype(np.int8), rxy, n_a, ctx=ctx)
+    try:
+        checked, viol = sw.sweep_match(match)
+    finally:
+        sw.close()
+    _edge, _tflag, pflag, counts = ops.xyorder_sweep(axy, rxy, t32, match, ctx=ctx)
+    _before, _after, _m3, flipped = ops.area_flip(axy, rxy, t32, match, ctx=ctx)
+    flip_node = np.zeros(n_a, bool)
+    if len(t32):
+        flip_node[t32[flipped.astype(bool)].reshape(-1)] = True
+    cid = op["cell_id_col"]
+    out = {"aligned_idx": ai.astype(np.int64)}
+    if with_ref_idx:
+        out["ref_idx"] = ri
+    for ct in list(commonCT) + ["X", "Y"]:
+        out[ct] = a_df[ct].to_numpy()[ai]
+    for ct in ("X", "Y"):
+        out[f"ref_{ct}"] = r_df[ct].to_numpy()[ri]
+    out["size"] = a_df["size"].to_numpy()[ai]
+    out["ref_size"] = r_df["size"].to_numpy()[ri]
+    out[f"Ref_{cid}"] = r_df[cid].to_numpy()[ri]
+    out[f"Aligned_{cid}"] = a_df[cid].to_numpy()[ai]
+    out["time_limit_reached"] = np.zeros(len(ai), bool)
+    out["triangle_violation"] = flip_node[ai]
+    out["filtered_violation"] = pflag[ai].astype(bool)
+    out["run_time"] = np.zeros(len(ai))
+    stats = {"pairs": len(pairs), "triangles": len(t32), "checked": int(checked), "flipped": len(viol), "xy_violations": int(counts[1]),
+             "area_flips": int(np.count_nonzero(flipped)), "matched": len(ai)}
+    return pd.DataFrame(out), stats
+
+
+def _device_ref_idx(dw):
+    """index of every kept aligned cell's matched reference in the window's COMPACTED reference frame (src/utils.py:734-742), -1 = none"""
+    from .windows import _W_MATCH, _W_PAIRS, _W_ROWS_R
+
+    st = dw.state
+    pairs, n_box = st.fetch(_W_PAIRS), len(st.fetch(_W_ROWS_R))
+    used = np.zeros(n_box, bool)
+    used[pairs[:, 1]] = True
+    m = st.fetch(_W_MATCH)
+    return np.where(m >= 0, (np.cumsum(used) - 1)[np.maximum(m, 0)], -1)
+
+
+def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None, moving_delaunay_vertex_col=None,
+                             optim_params=None, gurobi_params=None, ignore_precomputed_triangulation=False, *, workers=None,
+                             window_local_indices=False, return_stats=False, triangulator=None, ctx=None, _shard=None, _pipeline=None,
+                             _route=None):
+    """See the module text.  -> DataFrame (with return_stats: (DataFrame, [per-window stats dict in plan order])).
+    workers: threads walking this process's windows on the device route (default: 2 where the process has >= 8 CPUs, else 1).
+    A window whose prune leaves no pairs raises the ValueError run_same raises for it (src/same.py:1003), as the reference's loop does.
+    `triangulator`: see windows.iter_device_windows.  `_route` = 'device' | 'general' (testing: forces a route)."""
+    job = _WindowJob(ref, moving, commonCT, outprefix, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
+                     ignore_precomputed_triangulation, _shard)
+    frames, own = job.device_frames(_pipeline, ctx=ctx)
+    fast = frames is not None and not job.caller_triangulation and not job.optim_params["ignore_knn_if_matched"]
+    if _route is not None:
+        if _route == "device" and not fast:
+            raise ValueError("the device route does not apply to these inputs")
+        fast = _route == "device"
+    stats = {}
+    try:
+        if fast:
+            table = _device_route(job, frames, workers, window_local_indices, triangulator, stats)
+        else:
+            table = _general_route(job, frames, window_local_indices, stats, ctx)
+    finally:
+        if own:
+            frames.close()
+    if job.output_file and len(table):
+        table.to_csv(job.output_file, index=False)
+    return (table, [stats[pos] for pos in sorted(stats)]) if return_stats else table
+
+
+def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
+    from . import _lib
+
+    n_workers = max(1, int(workers if workers is not None else _default_workers()))
+    n_workers = min(n_workers, max(1, len(job.todo)))
+    contexts = [frames.ctx] + [_lib.Context(frames.ctx.device) for _ in range(n_workers - 1)]
+    chunks = [_Chunks() for _ in range(n_workers)]
+    lock = threading.Lock()
+
+    def walk(q):
+        mine = job.todo[q::n_workers]
+        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator)):
+            if dw.error is not None:
+                raise dw.error
+            with stage("table rows (central trim)"):
+                chunks[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
+                st = dw.stats
+                rec = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
+                       "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
+            with lock:
+                stats[pos] = rec
+
+    try:
+        if n_workers == 1:
+            walk(0)
+        else:
+            errors = []
+
+            def guarded(q):
+                try:
+                    walk(q)
+                except BaseException as e:   # noqa: BLE001 -- re-raised in the calling thread below
+                    errors.append(e)
+
+            threads = [threading.Thread(target=guarded, args=(q,), name=f"same-windows-{q}") for q in range(n_workers)]
+            [t.start() for t in threads]
+            [t.join() for t in threads]
+            if errors:
+                raise errors[0]
+    finally:
+        for c in contexts[1:]:
+            c.close()
+    with stage("table columns (one gather over all windows)"):
+        merged = _Chunks()
+        for ch in chunks:
+            merged.parts.extend(ch.parts)
+        table = merged.table(job, with_ref_idx)
+    if job.all_matches:                      # rows of windows finished by an earlier run (resume)
+        table = pd.concat(job.all_matches + ([table] if len(table) else []), ignore_index=True)
+    return table
+
+
+def _general_route(job, frames, with_ref_idx, stats, ctx):
+    commonCT, op, gp = job.commonCT, job.optim_params, job.gurobi_params
+
+    def prepared():
+        if frames is not None:
+            plan = [w for _pos, w in job.todo]
+            for (pos, w), dw in zip(job.todo, frames.windows(plan, triangulate=not job.caller_triangulation, ctx=ctx, fetch_triangles=True)):
+                if dw.error is not None:
+                    raise dw.error
+                if job.caller_triangulation:
+                    st = _staged_from_device(dw, frames, commonCT, op, gp, job.moving_delaunay, job.vertex_col, verbose=False)
+                    yield pos, w, prepare_same_inputs(None, None, commonCT, verbose=False, ctx=ctx, _staged=st)
+                else:
+                    yield pos, w, _prepared_from_device(dw, frames, op, gp, verbose=False, vertex_col=job.vertex_col)
+            return
+        ref_rows, moving_rows = _WindowSubsetter(job.ref), _WindowSubsetter(job.moving)
+        for pos, w in job.todo:
+            st = _stage_prune(ref_rows.subset(*w["box"]), moving_rows.subset(*w["box"]), commonCT, job.moving_delaunay, job.vertex_col, op, gp,
+                              job.ignore_pre, False, ctx, prefetch=False, fresh_frames=True)
+            yield pos, w, prepare_same_inputs(None, None, commonCT, verbose=False, ctx=ctx, _staged=st)
+
+    keep_csv, job.outprefix = job.outprefix, None        # the table is written once, by the caller of this route
+    try:
+        for pos, w, prep in prepared():
+            if len(prep.valid_pairs) == 0:               # every node unconstrained under the caller's triangulation: nothing to match
+                continue
+            with stage("incumbent + sweeps + table (general route)"):
+                window_matches, stats[pos] = incumbent_of_prepared(prep, commonCT, with_ref_idx, ctx=ctx)
+            job.collect(pos, w, window_matches)
+    finally:
+        job.outprefix = keep_csv
+    return job.result()

@@ -163,7 +163,9 @@ class GridRows:
 class Section:
     """One tissue section as columns (no DataFrame): what the window pipeline reads of it.
     xy (n, 2) float64; types (n, T) float64, the commonCT columns in commonCT order; type_id (n,) int32 codes of the cell
-    type (equal type <=> equal code); size (n,) (integer dtype kept: it decides the dtype of the triangle weights)."""
+    type (equal type <=> equal code); size (n,) (integer dtype kept: it decides the dtype of the triangle weights).
+    The host-side grid and the grid-ordered copies of the columns (`grid`, `g_*`) are what the COLUMN pipeline subsets with; they are
+    built on first use, so a section that only feeds a DeviceSection never pays for them."""
 
     def __init__(self, xy, types, type_id=None, size=None):
         self.xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
@@ -171,12 +173,25 @@ class Section:
         self.types = t if (t.ndim == 2 and len(t) == len(self.xy)) else t.reshape(len(self.xy), -1)      # (0, T) stays (0, T)
         self.type_id = None if type_id is None else np.ascontiguousarray(type_id, dtype=np.int32)
         self.size = np.ones(len(self.xy), np.int64) if size is None else np.asarray(size)
-        self.grid = GridRows(self.xy[:, 0], self.xy[:, 1])
-        # the same columns once more in GRID order (GridRows.positions): what the window loop gathers from
-        od = self.grid.order
-        self.g_xy, self.g_types, self.g_size = np.ascontiguousarray(self.xy[od]), np.ascontiguousarray(self.types[od]), self.size[od]
-        self.g_x, self.g_y = np.ascontiguousarray(self.g_xy[:, 0]), np.ascontiguousarray(self.g_xy[:, 1])
-        self.g_type_id = None if self.type_id is None else self.type_id[od]
+        self._host = None
+
+    def _host_grid(self):
+        if self._host is None:
+            grid = GridRows(self.xy[:, 0], self.xy[:, 1])
+            od = grid.order     # the same columns once more in GRID order (GridRows.positions): what the window loop gathers from
+            g_xy = np.ascontiguousarray(self.xy[od])
+            self._host = {"grid": grid, "g_xy": g_xy, "g_types": np.ascontiguousarray(self.types[od]), "g_size": self.size[od],
+                          "g_x": np.ascontiguousarray(g_xy[:, 0]), "g_y": np.ascontiguousarray(g_xy[:, 1]),
+                          "g_type_id": None if self.type_id is None else self.type_id[od]}
+        return self._host
+
+    grid = property(lambda self: self._host_grid()["grid"])
+    g_xy = property(lambda self: self._host_grid()["g_xy"])
+    g_types = property(lambda self: self._host_grid()["g_types"])
+    g_size = property(lambda self: self._host_grid()["g_size"])
+    g_x = property(lambda self: self._host_grid()["g_x"])
+    g_y = property(lambda self: self._host_grid()["g_y"])
+    g_type_id = property(lambda self: self._host_grid()["g_type_id"])
 
     def window(self, box):
         """-> (rows ascending, positions into the grid-ordered columns) of the section's points inside the half-open box."""
@@ -424,8 +439,8 @@ class DeviceWindow:
         return kept, added, near, match_row, flag, dict(zip(self.STAT_NAMES, (int(v) for v in stats)))
 
     def finish(self, triangles, no_match_penalty):
-        """-> (section row of the matched reference cell per kept aligned cell or -1, XY-order flag per kept cell, stats dict).
-        triangles None = the ones filter() left on the device."""
+        """-> (section row of the matched reference cell per kept aligned cell or -1, flag byte per kept cell: bit 0 = XY-order sweep,
+        bit 1 = vertex of an area-flipped triangle; stats dict).  triangles None = the ones filter() left on the device."""
         kept = self.counts[2]
         match_row, flag, stats = np.empty(kept, np.int32), np.empty(kept, np.uint8), np.zeros(8, np.int64)
         tris = None if triangles is None else ops._tris(triangles)
@@ -453,10 +468,10 @@ class DeviceWindow:
 class DeviceWindowResult:
     """What one window of `iter_device_windows` leaves on the host: `rows_m` section rows of the kept aligned cells, `axy` their XY,
     `triangles` the kept Delaunay triangles over them (None unless asked for or filtered on the host; `n_triangles` always), `match_row` the section row of each cell's matched reference cell (-1 = none),
-    `point_flag` the XY-order sweep's per-cell flag, `stats` the sweeps' counters, `counts` (aligned in box, refs in box, kept, pairs);
+    `point_flag` the XY-order sweep's per-cell flag, `flip_flag` 1 for the vertices of triangles whose signed area flips, `stats` the sweeps' counters, `counts` (aligned in box, refs in box, kept, pairs);
     `state` is the live DeviceWindow while the result is the newest one yielded (pairs, costs, signs ... through `state.fetch`)."""
 
-    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "n_triangles", "match_row", "point_flag", "stats", "counts", "state")
+    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "n_triangles", "match_row", "point_flag", "flip_flag", "stats", "counts", "state")
 
     def __init__(self, window):
         self.window = window
@@ -506,14 +521,17 @@ class TriangulationCache:
 
 
 def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
-                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False, triangulator=None):
+                        ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False, triangulator=None,
+                        triangulate=True):
     """The window path of `iter_window_arrays` + the greedy incumbent and the three sweeps, with both sections resident on the
     device (`dref`, `dmoving`: DeviceSections of `ref`, `moving`): per window the host only triangulates (Qhull helpers, windows
     ahead as before) and receives the match; the triangle filter runs on the device too, unless a cosine sits within 8 ulp of the
     angle threshold (then the host re-decides it with the reference's literal expression, as triangles.classify_triangles does).  Yields one
     DeviceWindowResult per window in plan order; the numbers are those of the column pipeline
     (tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline).  A window without pairs yields `.error`.
-    `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`."""
+    `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`.
+    `triangulate=False` stops after the stage call (rows, prune, costs, compaction): the caller brings its own triangles
+    (api.sliding_window_matching with a caller's triangulation) and reads pairs / costs through `state.fetch`."""
     from . import qhull_pool
     from ._trace import stage as marked
     from .triangles import cos_threshold, filter_triangles_by_radius
@@ -549,6 +567,8 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
                     free.append(state)
                 out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
                 return out, None
+        if not triangulate:
+            return out, (state, None)
         with marked("triangulate (hand-over; waits for a free helper)"):
             try:
                 return out, (state, qhull_pool.pool().submit(out.axy) if triangulator is None
@@ -559,10 +579,13 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
 
     def finish(out, staged):
         state, ticket = staged
+        if ticket is None:
+            out.state, out.n_triangles = state, 0
+            return out
         with marked("triangulate (wait for helper)"):
             tris = ticket.result()
         with marked("filter + signs + incumbent + sweeps (device)"):
-            _kept, _added, near, out.match_row, out.point_flag, out.stats = state.filter_finish(
+            _kept, _added, near, out.match_row, cell_flags, out.stats = state.filter_finish(
                 tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles, no_match_penalty)
         if near:
             with marked("triangle filter (host: a cosine at the threshold)"):
@@ -570,7 +593,8 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
                 out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
                                                            min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
             with marked("signs + incumbent + sweeps (device)"):
-                out.match_row, out.point_flag, out.stats = state.finish(out.triangles, no_match_penalty)
+                out.match_row, cell_flags, out.stats = state.finish(out.triangles, no_match_penalty)
+        out.point_flag, out.flip_flag = cell_flags & 1, (cell_flags >> 1) & 1        # the library packs both per-cell flags into one byte
         out.n_triangles = state.n_triangles
         if fetch_triangles and out.triangles is None:
             out.triangles = state.fetch(_W_TRIANGLES)

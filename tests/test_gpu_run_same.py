@@ -354,8 +354,9 @@ def test_bench_two_ranks_on_one_gpu_carry_the_diagnosis():
     assert out["per_rank"]["device_by_rank"] == [0, 0]
 
 
+@pytest.mark.parametrize("pipeline", ["device", "frames"])
 @pytest.mark.parametrize("cost_dtype", ["float64", "float32"])
-def test_window_arrays_equal_prepared_windows(cost_dtype):
+def test_window_arrays_equal_prepared_windows(cost_dtype, pipeline):
     """The column pipeline (windows.iter_window_arrays: no DataFrame per window; what bench.py --workload cfg5 runs) yields, for
     every window of a plan -- thin edge strips, an empty window and integer / float size columns included -- exactly the
     artefacts the frame pipeline (api.iter_prepared_windows, itself pinned against the reference's run_same) computes: the
@@ -374,7 +375,7 @@ def test_window_arrays_equal_prepared_windows(cost_dtype):
     plan = window_plan(r_df[["X", "Y"]].to_numpy(), m_df[["X", "Y"]].to_numpy(), 700, 200, 10)
     plan = plan[::2] + [dict(plan[0], box=(5000.0, 7100.0, 5000.0, 7100.0))]       # + a window over the clump: aligned cells, no reference cells
     op = dict(radius=30, knn=6, min_angle_deg=12, dist_ct_coeff=1.5, hip_cost_dtype=cost_dtype)
-    frames = list(same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=op))
+    frames = list(same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=op, pipeline=pipeline))
     arrays = list(iter_window_arrays(Section.from_frame(r_df, cols), Section.from_frame(m_df, cols), plan, radius=30, knn=6,
                                      dist_ct_coeff=1.5, min_angle_deg=12, ignore_same_type_triangles=True, cost_dtype=cost_dtype))
     assert len(frames) == len(arrays) == len(plan) > 10
@@ -660,7 +661,10 @@ def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
         assert len(la) == len(var_out["no_match_vars"]) and len(lr) == len(var_out["penalty_vars"])
 
 
-def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
+@pytest.mark.parametrize("pipeline", ["device", "frames"])
+def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch, pipeline):
+    """sliding_window_matching against the reference's own (recording solver double on both sides), on the default pipeline -- both
+    frames resident on the device for the whole loop, a window's frames made from the device's row lists -- and on the host-frame one."""
     import os
     import pandas as pd
     import run_same_record as rec
@@ -668,6 +672,8 @@ def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
     from same_amd import synth
 
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SAME_WINDOW_PIPELINE", pipeline)
+    assert same_amd.api.window_pipeline() == pipeline
     g = load_golden("run_same_mock")
     cells = synth.make_cells(1500, 3, seed=51)
     r_big = synth.to_frame(cells)
@@ -688,48 +694,91 @@ def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch):
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res3).items()}, g, prefix="sw_infer/res_")
 
 
-def test_device_window_flow_equals_the_reference_window_loop():
-    """The device-resident window path END TO END against the reference's own sliding_window_matching (tests/golden/run_same_mock.npz,
-    `sw` and `sw_infer`: run there with the recording solver double, which takes the greedy MIP start as the incumbent): per window
-    stage -> Qhull -> filter -> greedy incumbent on the device, matched cells inside the central trim -- the (aligned id, reference id,
-    window id) rows, their order, the matched reference's coordinates and both XY columns equal the reference's result table."""
+def _sw_inputs():
     from same_amd import synth
-    from same_amd import windows as W
 
-    g = load_golden("run_same_mock")
     cells = synth.make_cells(1500, 3, seed=51)
     r_big = synth.to_frame(cells)
     m_big = synth.to_frame(synth.make_jittered(cells, seed=52))
     m_big = m_big[~((m_big["X"] < 120) & (m_big["Y"] < 170) & (np.arange(len(m_big)) % 4 != 0))].reset_index(drop=True)
-    cols = synth.type_columns(3)
-    for prefix, ws, ov in (("sw", 150, 40), ("sw_infer", 220, 60)):
-        rxy, mxy = r_big[["X", "Y"]].to_numpy(), m_big[["X", "Y"]].to_numpy()
-        plan = W.window_plan(rxy, mxy, ws, ov, 60)
-        xs, ys, _ = W.window_grid(rxy, mxy, ws, ov)
-        ref_sec, mov_sec = W.Section.from_frame(r_big, cols), W.Section.from_frame(m_big, cols)
-        grid = W.window_cell_grid((xs, ys), ws, ov)
-        dref, dmov = W.DeviceSection(ref_sec, "float64").bin(*grid), W.DeviceSection(mov_sec, "float64").bin(*grid)
-        rows = {k: [] for k in ("a", "r", "x", "y", "rx", "ry", "w")}
-        for dw in W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, radius=20, knn=4, dist_ct_coeff=1.0, min_angle_deg=15,
-                                        ignore_same_type_triangles=True, no_match_penalty=100.0):
-            if dw.error is not None:
-                continue
-            x, y = dw.axy[:, 0], dw.axy[:, 1]
-            tx0, tx1, ty0, ty1 = dw.window["trim"]                        # src/same.py:565-582
-            c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
-            rows["a"].append(dw.rows_m[c]); rows["r"].append(dw.match_row[c]); rows["x"].append(x[c]); rows["y"].append(y[c])
-            rows["rx"].append(rxy[dw.match_row[c], 0]); rows["ry"].append(rxy[dw.match_row[c], 1])
-            rows["w"].append(np.full(len(c), dw.window["window_id"], np.int64))
-        got = {k: np.concatenate(v) for k, v in rows.items()}
-        want_a, want_r = g[f"{prefix}/res__Aligned_Cell_Num_Old"], g[f"{prefix}/res__Ref_Cell_Num_Old"]
-        a_ids, r_ids = m_big["Cell_Num_Old"].to_numpy(), r_big["Cell_Num_Old"].to_numpy()
-        assert np.array_equal(a_ids[got["a"]], want_a) and np.array_equal(r_ids[got["r"]], want_r), prefix
-        assert np.array_equal(got["w"], g[f"{prefix}/res__window_id"]), prefix
-        assert np.array_equal(got["x"], g[f"{prefix}/res__X"]) and np.array_equal(got["y"], g[f"{prefix}/res__Y"]), prefix
-        assert np.array_equal(got["rx"], g[f"{prefix}/res__ref_X"]) and np.array_equal(got["ry"], g[f"{prefix}/res__ref_Y"]), prefix
-        assert len(want_a) > 500
-        dref.close()
-        dmov.close()
+    return r_big, m_big, synth.type_columns(3)
+
+
+def _assert_incumbent_equals_golden(res, g, prefix, with_ref_idx=True):
+    """Every column of the reference's result table that is defined without a solver, and the column order.  `filtered_violation`
+    is the XY-order flag here and the flag intersected with the solver's penalised triangles there; `run_time` is the double's."""
+    want_cols = [str(c) for c in g[f"{prefix}/res_columns"]]
+    assert list(res.columns) == [c for c in want_cols if with_ref_idx or c != "ref_idx"], prefix
+    for c in want_cols:
+        if c in ("filtered_violation", "run_time") or (c == "ref_idx" and not with_ref_idx):
+            continue
+        want, got = g[f"{prefix}/res__{c}"], res[c].to_numpy()
+        assert np.array_equal(got.astype(want.dtype) if want.dtype.kind in "fiub" else got.astype(str), want), (prefix, c)
+    assert len(res) > 500
+
+
+@pytest.mark.parametrize("route,pipeline", [("device", "device"), ("general", "device"), ("general", "frames")])
+def test_incumbent_table_equals_the_reference_window_loop(route, pipeline, tmp_path):
+    """The solver-free product function END TO END against the reference's own sliding_window_matching (tests/golden/run_same_mock.npz,
+    `sw` and `sw_infer`: run there with the recording solver double, which takes the greedy MIP start as the incumbent): per window
+    stage -> Qhull -> filter -> greedy incumbent -> sweeps, matched cells inside the central trim -- every column of the reference's
+    result table that does not need a solver, row for row, through the device route (two library calls per window, one gather at the
+    end) and through the general route on either pipeline."""
+    import same_amd
+
+    g = load_golden("run_same_mock")
+    r_big, m_big, cols = _sw_inputs()
+    for prefix, ws, ov, ct in (("sw", 150, 40, cols), ("sw_infer", 220, 60, None)):
+        op = dict(radius=20, knn=4, window_size=ws, overlap=ov, min_cells_per_window=60)
+        res, stats = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), commonCT=ct, optim_params=dict(op), window_local_indices=True,
+                                                       return_stats=True, _route=route, _pipeline=pipeline)
+        _assert_incumbent_equals_golden(res, g, prefix)
+        assert len(stats) == res["window_id"].nunique() and all(s["pairs"] > 0 and s["triangles"] > 0 for s in stats)
+    if route == "device":
+        # without the window-local reference index (the default: no pair list comes back), with two worker threads, into a directory
+        res2 = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), optim_params=dict(op), workers=2, outprefix=str(tmp_path / "inc"))
+        assert "ref_idx" not in res2.columns and res2.equals(res.drop(columns=["ref_idx"]))
+        assert len(pd.read_csv(tmp_path / "inc" / "matchedDF.csv")) == len(res2)
+        # a second call finds every window in the file and runs none
+        res3 = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), optim_params=dict(op), outprefix=str(tmp_path / "inc"))
+        assert len(res3) == len(res2)
+
+
+def test_incumbent_table_routes_agree():
+    """The two routes of same_amd.incumbent on a plan with thin edge strips, fp32 costs, integer sizes and a penalty some rows do not beat:
+    the same table, bit for bit; the cell-type-priority filter (general route only) runs on both pipelines alike; a window whose prune
+    finds nothing raises run_same's ValueError on every route."""
+    import same_amd
+    from same_amd import synth
+
+    ref = synth.make_cells(30_000, 5, seed=30)
+    mov = synth.make_jittered(ref, seed=31)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    m_df["size"] = np.where(np.arange(len(m_df)) % 3 == 0, 2, 1)
+    op = dict(radius=30, knn=6, min_angle_deg=12, dist_ct_coeff=1.5, hip_cost_dtype="float32", window_size=700, overlap=200, no_match_penalty=0.006,
+              min_cells_per_window=10)
+    cols = synth.type_columns(5)
+    fast = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), window_local_indices=True, _route="device")
+    for pipeline in ("device", "frames"):
+        slow = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), window_local_indices=True, _route="general",
+                                                 _pipeline=pipeline)
+        assert list(fast.columns) == list(slow.columns) and len(fast) == len(slow) > 5000
+        for c in fast.columns:
+            assert np.array_equal(fast[c].to_numpy(), slow[c].to_numpy()), (pipeline, c)
+    assert 0.2 * len(m_df) < fast["Aligned_Cell_Num_Old"].nunique() < 0.98 * len(m_df) and fast["triangle_violation"].any() and fast["filtered_violation"].any()
+    pri = [same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op, ignore_knn_if_matched=True), _pipeline=p)
+           for p in ("device", "frames")]
+    assert pri[0].equals(pri[1]) and len(pri[0]) > 5000 and not pri[0].equals(fast.drop(columns=["ref_idx"]))
+    # a clump of aligned cells and a clump of reference cells that share a window 50 000 units away, farther apart than the radius
+    rng = np.random.default_rng(5)
+    far = m_df.copy()
+    far.loc[far.index[:300], ["X", "Y"]] = 50_000.0 + rng.uniform(0, 300, (300, 2))
+    near_refs = r_df.iloc[:12].copy()
+    near_refs[["X", "Y"]] = 50_500.0 + rng.uniform(0, 50, (12, 2))
+    r_far = pd.concat([r_df, near_refs], ignore_index=True)
+    for kw in (dict(_route="device"), dict(_route="general", _pipeline="frames")):
+        with pytest.raises(ValueError, match="No valid_pairs after KNN filtering"):
+            same_amd.sliding_window_incumbent(r_far, far, commonCT=cols, optim_params=dict(op), **kw)
 
 
 def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
@@ -771,6 +820,15 @@ def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     res = same_amd.sliding_window_matching(mc_r, mc_a, commonCT=synth.type_columns(3),
                                            optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix="sw_metacell/res_")
+    # the solver-free product function on the same MetaCell objects (caller's triangulation -> its general route): the reference's table
+    inc = same_amd.sliding_window_incumbent(mc_r, mc_a, commonCT=synth.type_columns(3), window_local_indices=True,
+                                            optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
+    want_cols = [str(c) for c in g["sw_metacell/res_columns"]]
+    assert [c for c in inc.columns] == [c for c in want_cols if c in inc.columns] and set(want_cols) - set(inc.columns) <= {"members"}
+    for c in inc.columns:
+        if c not in ("filtered_violation", "run_time"):
+            want, got = g[f"sw_metacell/res__{c}"], inc[c].to_numpy()
+            assert np.array_equal(got.astype(want.dtype) if want.dtype.kind in "fiub" else got.astype(str), want), c
 
 
 def test_shipped_example_flow_equals_reference(gp, tmp_path, monkeypatch):
@@ -1176,9 +1234,12 @@ def test_window_rows_when_points_sit_on_cell_and_box_edges():
 
 
 def test_window_calls_stay_within_their_launch_budget():
-    """What a window costs in runtime calls, counted by the library itself (same_ctx_stat): with the sections binned on the window
-    grid a window is three fills (one per call's counters), 18 kernel launches with fp32 costs (the budget: 30), four copies and two waits (stage;
-    filter + finish as one call) -- round 3 needed ~80 launches, ~24 fills, ~13 copies and 5-6 waits."""
+    """What a window costs in runtime calls, counted by the library itself (same_ctx_stat), ENTERED THROUGH THE PRODUCT FUNCTIONS: with the
+    sections binned on the window grid a window of sliding_window_incumbent is three fills (one per call's counters), 18 kernel launches with
+    fp32 costs (the budget: 30), four copies and two waits (stage; filter + finish as one call) -- round 3 needed ~80 launches, ~24 fills,
+    ~13 copies and 5-6 waits.  iter_prepared_windows (what sliding_window_matching hands its run_same body) adds the seven arrays it
+    fetches for the solver: pairs, reference rows, costs, triangles, signs, weights."""
+    import same_amd
     from same_amd import _lib, synth
     from same_amd import windows as W
 
@@ -1187,23 +1248,22 @@ def test_window_calls_stay_within_their_launch_budget():
     mov = synth.make_jittered(ref, seed=1)
     r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
     cols = synth.type_columns(T)
-    xs, ys, _ = W.window_grid(ref["xy"], mov["xy"], 1200, 300)
+    op = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0, hip_cost_dtype="float32",
+              window_size=1200, overlap=300, min_cells_per_window=10)
     plan = W.window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
-    ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
-    dref, dmov = W.DeviceSection(ref_sec, "float32"), W.DeviceSection(mov_sec, "float32")
-    grid = W.window_cell_grid((xs, ys), 1200, 300)
-    dref.bin(*grid)
-    dmov.bin(*grid)
     ctx = _lib.default_context()
-    kw = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0)
-    list(W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan[:3], **kw))          # buffers, helpers, the prune index
+    same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), workers=1)          # buffers, helpers, the prune index
     before = ctx.stats()
-    done = [dw for dw in W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, **kw) if dw.error is None]
+    res, stats = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), workers=1, return_stats=True)
     after = ctx.stats()
-    per = {k: (after[k] - before[k]) / len(done) for k in after}
-    rounds = [dw.stats["greedy_rounds"] for dw in done]
-    print("per window:", per, "greedy rounds min/mean/max:", min(rounds), sum(rounds) / len(rounds), max(rounds))
-    assert len(done) >= 9 and sum(dw.counts[3] for dw in done) > 100_000
+    # the two section uploads + binnings of the call are part of the count: a handful of launches and copies per JOB, spread over its windows
+    per = {k: (after[k] - before[k]) / len(stats) for k in after}
+    print("per window (sliding_window_incumbent):", per)
+    assert len(stats) == len(plan) >= 9 and sum(s["pairs"] for s in stats) > 100_000 and len(res) > 50_000
     assert per["launches"] <= 30 and per["fills"] <= 4 and per["copies"] <= 4 and per["waits"] <= 3, per
-    dref.close()
-    dmov.close()
+    before = ctx.stats()
+    preps = [p for _w, p in same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=dict(op)) if not isinstance(p, Exception)]
+    after = ctx.stats()
+    per = {k: (after[k] - before[k]) / len(preps) for k in after}
+    print("per window (iter_prepared_windows):", per)
+    assert len(preps) == len(stats) and per["launches"] <= 30 and per["fills"] <= 4 and per["copies"] <= 12 and per["waits"] <= 11, per
