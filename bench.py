@@ -83,9 +83,10 @@ def parse():
     ap.add_argument("--embed-cfg5", choices=("auto", "on", "off"), default="auto",
                     help="after the timed loop, run BASELINE cfg 5 (the step of `--workload cfg5`) on this job's ranks and embed its numbers as `cfg5` "
                          "(auto: with the default workload at any rank count, and with cfg2 / cfg4 at N > 1)")
-    ap.add_argument("--cfg5-pipeline", choices=("device", "columns"), default="device",
-                    help="--workload cfg5: 'device' keeps both sections resident on the GPU (two library calls per window), 'columns' subsets on the host "
-                         "and hands every kernel host buffers")
+    ap.add_argument("--cfg5-pipeline", choices=("device", "frames"), default="device",
+                    help="--workload cfg5: both run the product function same_amd.sliding_window_incumbent; 'device' on frames resident on the GPU "
+                         "(two library calls per window), 'frames' through its general route on host frames (every window's frames cut on the "
+                         "host, every kernel through host buffers: the pipeline of rounds 1-3, kept measurable)")
     ap.add_argument("--cfg5-threads", type=int, default=None,
                     help="--workload cfg5: worker threads (contexts) walking this rank's windows (default: 2 on the device pipeline, 4 on the column one)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
@@ -662,17 +663,14 @@ def cfg5_oracle_leg(st):
     import numpy as np
 
     import same_amd
-    from same_amd import windows as W
-    from same_amd.windows import iter_device_windows
 
-    plan, my_plan, r_df, m_df, cols, op = st["plan"], st["my_plan"], st["r_df"], st["m_df"], st["cols"], st["op"]
-    ref_sec, mov_sec, dref, dmov, path_kw, ctx, on_device = st["ref_sec"], st["mov_sec"], st["dref"], st["dmov"], st["path_kw"], st["ctx"], st["on_device"]
+    plan, my_plan, r_df, m_df, cols, op, on_device = st["plan"], st["my_plan"], st["r_df"], st["m_df"], st["cols"], st["op"], st["on_device"]
     from scipy.spatial import Delaunay
 
     from oracle import same_oracle as orc
 
     sample = [w for w in my_plan if w["n_mov"] > 1000][:4] or my_plan[:1]
-    t_cpu, done_pairs = 0.0, 0
+    t_cpu, done_pairs, checks = 0.0, 0, []
     for w in sample:
         c0 = time.perf_counter()                 # the oracle's part of this window only: the GPU re-runs below are not the CPU's time
         x0, x1, y0, y1 = w["box"]
@@ -701,19 +699,25 @@ def cfg5_oracle_leg(st):
         gchecked, gviol, _ = sw.sweep(xo)
         sw.bound.close()
         ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
-        if ok and on_device:                 # and what the timed path itself computes for this window (csrc/window.hip)
+        checks.append((w, na, nr, pairs, c32, tri, signs, och, ochecked, oviol))
+        if not ok:
+            raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
+    if on_device:       # and what the timed path itself computes for these windows (csrc/window.hip), as the API hands it on
+        got = [p for _w, p in same_amd.iter_prepared_windows(r_df, m_df, cols, [c[0] for c in checks], optim_params=op, pipeline="device")]
+        for (w, na, nr, pairs, c32, tri, signs, och, ochecked, oviol), prep in zip(checks, got):
             nr_rows, match_o = nr["Cell_Num_Old"].to_numpy(), np.full(len(na), -1, np.int64)
             for hit in och:
                 match_o[hit[0]] = nr_rows[hit[1]]
-            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, [w], no_match_penalty=100.0, ctx=ctx, fetch_triangles=True, **path_kw):
-                dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
-                ok = (dw.error is None and np.array_equal(dw.rows_m, na["Cell_Num_Old"].to_numpy()) and np.array_equal(dp[:, 0], pairs[:, 0])
-                      and np.array_equal(rows_r[dp[:, 1]], nr_rows[pairs[:, 1]])
-                      and np.array_equal(dw.state.fetch(W._W_COSTS).astype(np.float32), c32) and np.array_equal(dw.triangles, tri)
-                      and np.array_equal(dw.state.fetch(W._W_SIGNS), np.asarray(signs, dtype=np.int8))
-                      and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
-        if not ok:
-            raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
+            if isinstance(prep, Exception):
+                raise SystemExit(f"cfg5: the device-resident path refused a window the oracle ran: {prep}")
+            dw = prep.device
+            ok = (np.array_equal(prep.rows_m, na["Cell_Num_Old"].to_numpy())
+                  and np.array_equal(prep.rows_r, nr_rows) and np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs)
+                  and np.array_equal(prep.costs_array.astype(np.float32), c32) and np.array_equal(prep.triangles_array, tri)
+                  and np.array_equal(prep.signs_array, np.asarray(signs, dtype=np.float64))
+                  and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
+            if not ok:
+                raise SystemExit("cfg5 window outputs of the device-resident path differ from the oracle: refusing to report a number")
     parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
               "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
     cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),

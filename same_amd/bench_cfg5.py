@@ -9,7 +9,8 @@ from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s", "aligned_cells_per_window",
                "windows_per_s_triangulations_given", "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step",
-               "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl")
+               "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl",
+               "product_function", "api_path_windows_per_s", "api_path")
 
 
 def record(line):
@@ -23,27 +24,31 @@ def record(line):
 
 def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     """BASELINE cfg 5: a section of --cfg5-cells cells tiled into overlapping windows (src/same.py:481-488), the windows dealt
-    round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps,
-    with both sections resident on the device (same_amd.windows.iter_device_windows over csrc/window.hip: the host triangulates and receives
-    the match; --cfg5-pipeline columns is the host-buffer form it is tested against),
-    every rank's central-trimmed match table exchanged in ONE device all-gather (dist.allgather_table) and merged
-    (src/helpers.py:692-815, de-duplication on the GPU).  There is no solver on the GPU box: the incumbent whose violations are swept is the greedy MIP start
-    (src/init_helpers.py:109-133), which is what the reference hands Gurobi as its first incumbent.
+    round-robin (heaviest first) to the ranks, every window through the whole pre-MIP path with fp32 costs and all three sweeps --
+    by the PRODUCT function `same_amd.sliding_window_incumbent` (the reference's sliding_window_matching signature with the greedy MIP
+    start, src/init_helpers.py:109-133, as each window's solution: there is no solver on the GPU box, and that start is what the
+    reference hands Gurobi as its first incumbent).  --cfg5-pipeline device: both frames resident on the device (`resident_frames`,
+    uploaded and binned before the timed region, as ④ of the bench contract has inputs resident), two library calls per window
+    (csrc/window.hip), the host triangulates; --cfg5-pipeline frames: the function's general route on host frames, every kernel through
+    host buffers (the pipeline of rounds 1-3).  Every rank's central-trimmed match table is exchanged in ONE device all-gather
+    (dist.allgather_table) and merged (src/helpers.py:692-815, de-duplication on the GPU).
     `ctx` is the context the communicator lives on (the exchange runs on its stream); worker threads get contexts of their own.
     One step = the whole plan once (every rank its share) + the exchange + the merge (on rank 0, which owns the result).
     cpu_baseline: None, or the caller's function (state dict) -> (cpu_baseline record, parity text) run on rank 0 at world 1.
     -> the line as a dict on rank 0, None elsewhere; nothing is closed here.  value = dense-equivalent cell pairs
     (sum over windows of aligned x ref cells in the window) per second; `windows_per_s` per rank and the share of the step
-    spent outside libsame_hip calls (`host_glue_share`) come from the stage markers of same_amd/_trace.py."""
+    spent outside libsame_hip calls (`host_glue_share`) come from the stage markers of same_amd/_trace.py.  After the timed region
+    rank 0 also times the reference's OWN signature (`api_path`): sliding_window_matching with a stand-in for the solver half."""
     import numpy as np
     import pandas as pd
 
     import same_amd
-    from same_amd import _lib, _trace, ops, synth
+    from same_amd import _lib, _trace, synth
+    from same_amd.incumbent import incumbent_of_prepared
     from same_amd.merge import merge_window_matches_unique_ref
     from same_amd.dist import allgather_table, last_table_gather
     from same_amd import windows as W
-    from same_amd.windows import DeviceSection, Section, assign_windows, iter_device_windows, iter_window_arrays, window_plan
+    from same_amd.windows import assign_windows, window_plan
 
     _trace.enable(True)
     _lib.instrument()
@@ -53,7 +58,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
     r_df["Cell_Num_Old"], m_df["Cell_Num_Old"] = np.arange(len(r_df)), np.arange(len(m_df))
     cols = synth.type_columns(T)
-    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32")
+    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32", window_size=1200, overlap=300, min_cells_per_window=10)
     plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
     mine = assign_windows(plan, group.world)[group.rank]
     my_plan = [plan[q] for q in mine]
@@ -61,102 +66,25 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
 
     TABLE_COLUMNS = (("Aligned_Cell_Num_Old", np.int64), ("Ref_Cell_Num_Old", np.int64), ("X", np.float64), ("Y", np.float64),
                      ("filtered_violation", bool), ("window_id", np.int64))
-    ref_sec, mov_sec = Section.from_frame(r_df, cols), Section.from_frame(m_df, cols)
-    ref_ids, mov_ids = r_df["Cell_Num_Old"].to_numpy(), m_df["Cell_Num_Old"].to_numpy()
     on_device = args.cfg5_pipeline == "device"
-    dref, dmov = (DeviceSection(ref_sec, np.float32, ctx), DeviceSection(mov_sec, np.float32, ctx)) if on_device else (None, None)
-    if on_device:       # the rows of both sections binned ONCE on the window grid: every window box is then a union of cells
-        xs, ys, _ = W.window_grid(ref["xy"], mov["xy"], 1200, 300)
-        cell_grid = W.window_cell_grid((xs, ys), 1200, 300)
-        dref.bin(*cell_grid)
-        dmov.bin(*cell_grid)
-    path_kw = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True)
+    # device pipeline: the two frames go to the device ONCE, before the timed region (inputs resident, as the bench contract asks), and
+    # every step's call names them; frames pipeline: the frames themselves
+    resident = same_amd.resident_frames(r_df, m_df, ctx=ctx) if on_device else None
+    frame_args = (resident, resident) if on_device else (r_df, m_df)
+    shard = (group.rank, group.world) if group.world > 1 else None
 
-    def device_table(dw):
-        """the window's central match table from what iter_device_windows leaves on the host (section rows, XY, match, flags)"""
-        w = dw.window
-        x, y = dw.axy[:, 0], dw.axy[:, 1]
-        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581), matched cells only
-        c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
-        tab = {"Aligned_Cell_Num_Old": mov_ids[dw.rows_m[c]], "Ref_Cell_Num_Old": ref_ids[dw.match_row[c]], "X": x[c], "Y": y[c],
-               "filtered_violation": dw.point_flag[c].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
-        st = dw.stats
-        return tab, {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
-                     "xy_violations": st["xy_violations"], "area_flips": st["area_flips"]}
-
-    def run_window(wa, wctx):
-        """greedy incumbent -> orientation sweep (lazy-constraint body), XY-order sweep, area flips -> the window's central match table"""
-        w, pairs = wa.window, wa.pairs.astype(np.int32)
-        # greedy MIP start (src/init_helpers.py:104-133) in its flat device form: per-row minimum, rows that beat their
-        # no-match penalty, the scan's matching -> one pair index per aligned row
-        wants = ops.pair_rowmin(pairs, wa.costs, wa.n_aligned, ctx=wctx) < 100.0 * wa.size.astype(float)
-        pair_of_row, _rounds = ops.greedy_match(pairs, wa.costs, wa.n_aligned, wa.n_ref, wants, ctx=wctx)
-        ai = np.flatnonzero(pair_of_row >= 0)
-        ri = pairs[pair_of_row[ai], 1].astype(np.int64)
-        match = np.full(wa.n_aligned, -1, np.int32)
-        match[ai] = ri
-        sw = ops.BoundSweep(wa.triangles, wa.signs, wa.rxy, wa.n_aligned, ctx=wctx)      # the lazy-constraint body (src/same.py:645-669)
-        checked, viol = sw.sweep_match(match)
-        sw.close()
-        # XY-order sweep (src/violationhelper.py:53-117) and signed-area flips (src/same.py:1362-1402) in their flat device forms
-        _edge, _tflag, pflag, counts = ops.xyorder_sweep(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
-        _before, _after, _m3, flipped = ops.area_flip(wa.axy, wa.rxy, wa.triangles, match, ctx=wctx)
-        x, y = wa.axy[ai, 0], wa.axy[ai, 1]
-        tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:566-581)
-        c = np.flatnonzero((x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
-        tab = {"Aligned_Cell_Num_Old": mov_ids[wa.rows_m[ai[c]]], "Ref_Cell_Num_Old": ref_ids[wa.rows_r[ri[c]]], "X": x[c], "Y": y[c],
-               "filtered_violation": pflag[ai[c]].astype(bool), "window_id": np.full(len(c), w["window_id"], np.int64)}
-        return tab, {"pairs": len(pairs), "triangles": len(wa.triangles), "checked": int(checked), "flipped": len(viol),
-                     "xy_violations": int(counts[1]), "area_flips": int(np.count_nonzero(flipped))}
-
-    # The windows of a pass are independent and the host work per window (numpy index work, ~7 ms) dwarfs its kernels (~0.3 ms), so
-    # the rank walks its windows with --cfg5-threads workers, each with a context (= stream) of its own; numpy and the library calls
-    # release the interpreter lock.  Results are put back into plan order, so the tables do not depend on the thread count.
     from same_amd import qhull_pool as _share
 
     cpu_share = _share.cpu_budget() / _share.cpu_sharers()[0]          # this rank's part of the CPUs it may use
-    default_threads = (2 if cpu_share >= 8 else 1) if on_device else 4  # a second Python thread only pays where there are CPUs to feed it
+    default_threads = (2 if cpu_share >= 8 else 1) if on_device else 1  # a second Python thread only pays where there are CPUs to feed it
     n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else default_threads))
-    worker_ctx = [ctx] + [_lib.Context(ctx.device) for _ in range(n_workers - 1)]
-
     tri_cache = [None]        # set for the diagnostic pass after the timed loop (triangulations remembered: Qhull out of the picture)
+    worker_ctx = [ctx]        # the product function makes (and closes) the other workers' contexts itself; their calls are summed by _lib.instrument
 
-    def walk(windows, wctx, out):
-        if on_device:
-            for dw in iter_device_windows(ref_sec, mov_sec, dref, dmov, windows, no_match_penalty=100.0, ctx=wctx, triangulator=tri_cache[0], **path_kw):
-                if dw.error is None:
-                    with _trace.stage("table (bench step)"):
-                        out.append((dw.window["window_id"], *device_table(dw)))
-            return
-        for wa in iter_window_arrays(ref_sec, mov_sec, windows, cost_dtype=np.float32, ctx=wctx, **path_kw):
-            if wa.error is not None:              # a window whose prune leaves no pairs (src/same.py:1003)
-                continue
-            with _trace.stage("incumbent + sweeps + table (bench step)"):
-                out.append((wa.window["window_id"], *run_window(wa, wctx)))
-
-    def one_pass(windows):
-        import threading
-
-        outs = [[] for _ in range(n_workers)]
-        if n_workers == 1:
-            walk(windows, ctx, outs[0])
-        else:
-            errors = []
-
-            def guarded(q):
-                try:
-                    walk(windows[q::n_workers], worker_ctx[q], outs[q])
-                except BaseException as e:   # noqa: BLE001 -- re-raised in the main thread below
-                    errors.append(e)
-
-            threads = [threading.Thread(target=guarded, args=(q,)) for q in range(n_workers)]
-            [t.start() for t in threads]
-            [t.join() for t in threads]
-            if errors:
-                raise errors[0]
-        pos = {w["window_id"]: q for q, w in enumerate(windows)}
-        done = sorted((r for part in outs for r in part), key=lambda r: pos[r[0]])
-        return [r[1] for r in done], [r[2] for r in done]
+    def one_pass(_windows=None):
+        """this rank's share of the plan through the product function -> (its table as a frame, per-window stats)"""
+        kw = dict(workers=n_workers, triangulator=tri_cache[0]) if on_device else dict(_route="general", _pipeline="frames")
+        return same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), return_stats=True, ctx=ctx, _shard=shard, **kw)
 
     def all_ranks(fn, *a):
         """fn(*a) on this rank; if ANY rank raised, every rank raises (so that no rank walks into a collective the others never reach)."""
@@ -175,9 +103,9 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
 
     def step():
         t_pass = time.perf_counter()
-        tabs, stats = all_ranks(one_pass, my_plan)
+        tab, stats = all_ranks(one_pass, my_plan)
         pass_seconds[0] += time.perf_counter() - t_pass
-        mine_tab = {c: (np.concatenate([t[c] for t in tabs]) if tabs else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
+        mine_tab = {c: (tab[c].to_numpy().astype(dt) if len(tab) else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
         mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
         with _trace.stage("table exchange (all-gather)"):
             every = allgather_table(ctx, comm, group, mine_tab)          # the ONE exchange: one table per rank, a device all-gather
@@ -198,9 +126,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
 
     # warm-up: scratch slots, Qhull helpers, first-launch costs -- and, on the device path, every window state a worker keeps
     # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
-    n_warm = (_qp.lookahead() + 1) * n_workers if on_device else 2
-    for _ in range(warmup):
-        all_ranks(one_pass, my_plan[: max(1, min(n_warm, len(my_plan)))])
+    for _ in range(min(warmup, 1)):     # one whole pass: the sections go up and are binned, the plan and the type sets are remembered,
+        all_ranks(one_pass, my_plan)    # every window state a worker keeps in flight gets its buffers (they stay with the contexts)
     group.barrier()
     _trace.reset()
     calls0 = [c.stats() for c in worker_ctx]
@@ -211,7 +138,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     group.barrier()
     wall_here = time.perf_counter() - t0
     calls1 = [c.stats() for c in worker_ctx]
-    n_done = max(1, len(stats) * steps)
+    # the calls counted are those of `ctx`: worker 0's windows (every n_workers-th of this rank's share) + the merge's de-duplication
+    n_done = max(1, -(-len(stats) // n_workers) * steps)
     calls_per_window = {k_: sum(b[k_] - a[k_] for a, b in zip(calls0, calls1)) / n_done for k_ in calls1[0]}
     dt = group.max(wall_here)
     rep = _trace.report()
@@ -249,8 +177,15 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # GPU produced for them -- the package itself never imports the oracle)
     cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
     if group.rank == 0 and group.world == 1 and cpu_baseline is not None:
-        cpu, parity = cpu_baseline(dict(plan=plan, my_plan=my_plan, r_df=r_df, m_df=m_df, cols=cols, op=op, ref_sec=ref_sec, mov_sec=mov_sec,
-                                        dref=dref, dmov=dmov, path_kw=path_kw, ctx=ctx, on_device=on_device))
+        cpu, parity = cpu_baseline(dict(plan=plan, my_plan=my_plan, r_df=r_df, m_df=m_df, cols=cols, op=op, ctx=ctx, on_device=on_device))
+    # THE REFERENCE'S OWN SIGNATURE, timed (rank 0, after the timed region, never part of `value`): sliding_window_matching on this job's frames
+    #   (a) with `incumbent_of_prepared` standing in for the solver half of run_same -- the signature, the window loop, the pre-MIP path on
+    #       the device, PreparedInputs (7 arrays fetched per window), a frame per window, the central trim: everything but Gurobi's side;
+    #   (b) on a few windows with a do-nothing `gurobipy` in place (bench_solver_double): run_same's own model assembly, MIP start, lazy
+    #       callback and post-solve tables in Python -- what a licensed run pays per window on top of (a) before the solver does anything.
+    api_path = None
+    if group.rank == 0 and not getattr(args, "no_extras", False):
+        api_path = _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, cols, op, plan, on_device, _trace)
     out = None
     if group.rank == 0:
         total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
@@ -264,9 +199,11 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
                                       f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
                                       "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
-                          "pipeline": ("device: both sections resident in HBM and binned on the window grid, two library calls per window (csrc/window.hip); the "
-                                       "host triangulates (Qhull helpers) and receives the match" if on_device
-                                       else "columns: subsetting, compaction and gathers on the host, every kernel through host buffers"),
+                          "pipeline": ("device: same_amd.sliding_window_incumbent on resident frames -- both sections in HBM, binned on the window grid, "
+                                       "two library calls per window (csrc/window.hip); the host triangulates (Qhull helpers) and receives the match; the "
+                                       "table's columns are gathered once per pass" if on_device
+                                       else "frames: same_amd.sliding_window_incumbent, general route on host frames -- every window's frames cut on the "
+                                            "host, every kernel through host buffers, a DataFrame per window"),
                           "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
                                          "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
                "windows_per_s": len(plan) * steps / dt,
@@ -315,13 +252,58 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                             "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
                                     "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by launch latency and host "
                                     "glue, not by HBM -- see host_glue_share"},
+               "product_function": "same_amd.sliding_window_incumbent (sliding_window_matching's arguments; the greedy MIP start as every window's "
+                                   "solution) -- the timed step IS a call of it per rank" + (", on frames made resident before the timed region" if on_device else ""),
+               "api_path_windows_per_s": None if api_path is None else api_path["api_path_windows_per_s"], "api_path": api_path,
                "cpu_baseline": cpu, "parity_spot_check": parity}
         if rccl is not None:
             out["rccl"] = rccl
     group.barrier()
-    for sec in (dref, dmov):
-        if sec is not None:
-            sec.close()
-    for c in worker_ctx[1:]:
-        c.close()
+    if resident is not None:
+        resident.close()
     return out if group.rank == 0 else None
+
+
+def _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, cols, op, plan, on_device, _trace):
+    import numpy as np
+
+    from . import bench_solver_double
+
+    pipeline = "device" if on_device else "frames"
+    t0 = time.perf_counter()
+    res = same_amd.sliding_window_matching(*frame_args, commonCT=cols, optim_params=dict(op), _pipeline=pipeline,
+                                           _solve=lambda prep, _outprefix: (incumbent_of_prepared(prep, cols, True)[0], {}))
+    t_a = time.perf_counter() - t0
+    # (b): a corner of the section holding a handful of windows, so that the default run stays within minutes
+    xs = sorted({w["box"][0] for w in plan})
+    ys = sorted({w["box"][2] for w in plan})
+    x_hi, y_hi = plan[0]["box"][1] + (xs[1] - xs[0] if len(xs) > 1 else 0.0), plan[0]["box"][3] + (ys[1] - ys[0] if len(ys) > 1 else 0.0)
+    corner = lambda df: df[(df["X"] < x_hi) & (df["Y"] < y_hi)].reset_index(drop=True)
+    r_c, m_c = corner(r_df), corner(m_df)
+    bench_solver_double.install()
+    _trace.reset()
+    cwd = os.getcwd()
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as work:      # run_same writes matching_model.lp into the working directory
+            os.chdir(work)
+            t0 = time.perf_counter()
+            res_b = same_amd.sliding_window_matching(r_c, m_c, commonCT=cols, optim_params=dict(op), gurobi_params=dict(init_method="greedy"),
+                                                     _pipeline=pipeline)
+            t_b = time.perf_counter() - t0
+    finally:
+        os.chdir(cwd)
+        bench_solver_double.uninstall()
+    n_b = max(1, int(res_b["window_id"].nunique()) if len(res_b) else 1)
+    rep = {name: sec for name, (_c, sec) in _trace.report().items() if not name.startswith("lib:")}
+    solver_side = sum(sec for name, sec in rep.items() if name in ("MIP start", "solve (incl. lazy sweeps)", "post-solve sweeps + tables"))
+    return {"what": "sliding_window_matching (the reference's signature, src/same.py:297-307) on this job's frames, after the timed region, rank 0, one "
+                    "thread: (a) all windows with the greedy incumbent standing in for the solver half of run_same; (b) the windows of one corner of "
+                    "the section with a do-nothing gurobipy double: run_same's own Python around the solver",
+            "pipeline": pipeline, "windows": len(plan), "seconds": t_a, "api_path_windows_per_s": len(plan) / t_a, "matches": int(len(res)),
+            "with_solver_double": {"windows": n_b, "cells": [int(len(m_c)), int(len(r_c))], "seconds_per_window": t_b / n_b, "windows_per_s": n_b / t_b,
+                                   "solver_side_python_s_per_window": solver_side / n_b,
+                                   "solver_side_means": "MIP start + optimize() of the double incl. one lazy callback + post-solve tables (stage "
+                                                        "markers of same_amd/_trace.py); the rest is model assembly (one Python object per pair, "
+                                                        "constraint and triangle) and the pre-MIP path",
+                                   "matches": int(len(res_b))}}

@@ -24,7 +24,6 @@ Two routes produce the same table (tests/test_gpu_run_same.py::test_incumbent_ta
            host-buffer entry points: caller-supplied triangulations (MetaCell inputs), the cell-type-priority filter, inputs the
            sections cannot hold.
 """
-import os
 import threading
 
 import numpy as np
@@ -32,8 +31,7 @@ import pandas as pd
 
 from . import ops
 from ._trace import stage
-from .api import (_DeviceFrames, _WindowJob, _WindowSubsetter, _prepared_from_device, _stage_prune, _staged_from_device, prepare_same_inputs,
-                  window_pipeline)
+from .api import _WindowJob, _WindowSubsetter, _prepared_from_device, _stage_prune, _staged_from_device, prepare_same_inputs
 
 STAT_KEYS = ("pairs", "triangles", "checked", "flipped", "xy_violations", "area_flips", "matched")
 

@@ -523,7 +523,8 @@ def test_bench_cfg5_windows_line(world):
     pr = out["per_rank"]
     assert len(pr["windows"]) == world and sum(pr["windows"]) >= 4 and all(v > 0 for v in pr["windows_per_s"])
     assert all(0.0 <= v < 1.0 for v in pr["host_glue_share"]) and out["windows_per_s"] > 0 and out["merged_matches"] > 1000
-    assert out["config"]["pipeline"].startswith("device: both sections resident in HBM")
+    assert out["config"]["pipeline"].startswith("device: same_amd.sliding_window_incumbent on resident frames")
+    assert out["product_function"].startswith("same_amd.sliding_window_incumbent")
     assert any(k.startswith("subset + prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
     assert {"same_window_stage", "same_window_filter_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
     # the diagnostic pass with the triangulations remembered (not a throughput; it says what is left once Qhull is out of the picture)
@@ -535,12 +536,17 @@ def test_bench_cfg5_windows_line(world):
     if world == 1:
         assert out["cpu_baseline"]["kind"] == "port" and "equal the oracle bit-for-bit" in out["parity_spot_check"]
         assert "through the device-resident window path" in out["parity_spot_check"]
-        # the host-buffer form of the same step merges to the same table
-        res = subprocess.run(cmd + ["--cfg5-pipeline", "columns", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        # the reference's own signature, timed in the same run: all windows with the incumbent standing in for the solver half, a corner
+        # of the section with a do-nothing gurobipy (run_same's own Python around the solver)
+        ap = out["api_path"]
+        assert out["api_path_windows_per_s"] == ap["api_path_windows_per_s"] > 0 and ap["pipeline"] == "device" and ap["matches"] > 1000
+        assert ap["with_solver_double"]["windows"] >= 1 and ap["with_solver_double"]["seconds_per_window"] > ap["with_solver_double"]["solver_side_python_s_per_window"] > 0
+        # the same function's general route on host frames merges to the same table
+        res = subprocess.run(cmd + ["--cfg5-pipeline", "frames", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
         assert res.returncode == 0, res.stderr[-3000:]
         col = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
-        assert col["config"]["pipeline"].startswith("columns:") and col["merged_matches"] == out["merged_matches"]
-        assert any(k.startswith("prune") for k in col["stages_rank0"])
+        assert col["config"]["pipeline"].startswith("frames:") and col["merged_matches"] == out["merged_matches"]
+        assert any(k.startswith("prune") for k in col["stages_rank0"]) and col["api_path"]["pipeline"] == "frames"
     else:
         assert out["cpu_baseline"] is None
 
