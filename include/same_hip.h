@@ -42,7 +42,7 @@ extern "C" {
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
-#define SAME_ABI_VERSION 5
+#define SAME_ABI_VERSION 6
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
@@ -401,7 +401,7 @@ int same_orient_from_flags_dev(same_sweep *sweep, const uint8_t *dflag, int64_t 
 int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, int k, int32_t *dmatch);
 
 /* ======================================================================================================================
- * part 3 -- WINDOW path: both sections resident on the device, one window = two or three calls
+ * part 3 -- WINDOW path: both sections resident on the device, a batch of windows = two calls
  * ====================================================================================================================== */
 /* ---- a13 + the per-window pre-MIP path with the sections resident on the device -------------
  * The reference's window loop (src/same.py:507-593) subsets both frames per window (:293-295: one boolean mask over the
@@ -412,34 +412,42 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *                     grid: with the window grid's origin (int(x_min), int(y_min)) and cell = gcd(window step, window size)
  *                     every window box of src/same.py:481-488 / :527-542 is a union of cells and its rows need no test at all;
  *                     other boxes test the rows of the cells they cut.  A box covering more than 64 cells falls back to one
- *                     mask over the section.  Call it before windows use the section (not concurrently with them).  Sections
+ *                     mask over the section.  It waits for stage calls in flight on the section and for the device before it replaces the
+ *                     grid (a lock per section); still, re-bin between passes, not between the two calls of a window.  Sections
  *                     may be shared by the windows of several contexts of one device.
  *   same_window       the device state of one window in flight (buffers grow on demand and are reused).  It reads the two sections it was
  *                     staged on until its finish call returns: destroy windows (or stage them elsewhere) before their sections.
- *   same_window_stage rows of both sections inside box = {x0,x1,y0,y1} (half-open, ascending row order), radius / k
- *     prune (src/utils.py:709-728), candidate costs (src/same.py:1180-1189), compaction of the aligned cells that have
- *     candidates and of the pair list (src/utils.py:734-742).  out_counts[4] = {aligned rows in the box, reference rows
- *     in the box, aligned rows kept, pairs}.  Reference cells are not renumbered: pair[1] / match index the window's
- *     reference rows.  One fill, at most five launches, one copy back, one wait; reads O(rows of the covered cells).
- *   same_window_finish: the caller's kept Delaunay triangles of the kept aligned cells (src/same.py:1023, filtered as
- *     :1040-1060) -> source signs / weights (:1128-1146), greedy MIP start with prefer = rowmin < no_match_penalty * size
- *     (src/init_helpers.py:104-133), lazy-constraint body (:645-669), XY-order sweep (src/violationhelper.py:53-117), area
- *     flips (:1362-1402).  out_match_row[kept] = SECTION row of the matched reference cell or -1, out_point_flag[kept] =
- *     per-cell flag byte: bit 0 the XY-order sweep flags the cell (src/violationhelper.py:100-104), bit 1 the cell is a vertex of a
- *     triangle whose signed area flips (src/same.py:1464-1469), out_stats[8] = {orientation checked, flipped, XY comparisons, XY violations,
- *     triangles with a violation, area flips, greedy rounds, matched cells}.
- *   same_window_filter (optional, between the two): the Delaunay simplices of the kept aligned cells ->
- *     filter_triangles_by_radius on the device (src/helpers.py:233-395: classes :300-330, the keep list, the same-type
- *     triangles added back so that every node keeps one :331-340 / :365-389, in the reference's order); the section's
- *     type_id codes play aligned_df["cell_type"].  out_counts[3] = {kept, added back, cosines within near_tol of
- *     cos_thr}.  When the third is not zero nothing is left on the device: the caller re-decides those triangles with the
- *     reference's literal arccos (same_amd/triangles.py) and passes its triangles to same_window_finish.  Otherwise
- *     same_window_finish(window, NULL, -1, ...) continues with the triangles left on the device.  Simplices must be
- *     distinct as vertex rows (Qhull's are): the re-add pass de-duplicates by triangle, the reference by vertex row.
- *   same_window_filter_finish = same_window_filter then same_window_finish(window, NULL, -1, ...) without a host round trip
- *     between them (one wait instead of two); out_counts as the filter's, the rest as the finish call's.  When
- *     out_counts[2] != 0 the other outputs mean nothing and the caller proceeds as after same_window_filter.
- * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size. */
+ *   same_window_stage: for each of n_windows windows (window i takes boxes[4 i .. 4 i + 3] = {x0,x1,y0,y1}, half-open): the rows of both
+ *     sections inside the box (ascending row order), radius / k prune (src/utils.py:709-728), candidate costs (src/same.py:1180-1189),
+ *     compaction of the aligned cells that have candidates and of the pair list (src/utils.py:734-742).  out_counts[4 i ..] = {aligned
+ *     rows in the box, reference rows in the box, aligned rows kept, pairs}.  Reference cells are not renumbered: pair[1] / match index
+ *     the window's reference rows.  Per window one fill, at most five launches and one copy back, reading O(rows of the covered cells);
+ *     ONE wait for the whole batch -- the device works on window i while the host enqueues window i + 1.  The windows of a batch
+ *     belong to one context and are distinct; n_windows <= SAME_WINDOW_BATCH_MAX.  If any window is refused nothing of the batch counts.
+ *   same_window_filter_finish: for each window of the batch, the Delaunay simplices of its kept aligned cells (window i:
+ *     simplices[3 simplex_offsets[i] .. 3 simplex_offsets[i+1]), offsets[0] = 0) ->
+ *     - filter_triangles_by_radius on the device (src/helpers.py:233-395: classes :300-330, the keep list, the same-type triangles
+ *       added back so that every node keeps one :331-340 / :365-389, in the reference's order); the section's type_id codes play
+ *       aligned_df["cell_type"].  Simplices must be distinct as vertex rows (Qhull's are): the re-add pass de-duplicates by triangle,
+ *       the reference by vertex row.  prefiltered != 0 skips this step: the rows passed ARE the kept triangles, in the reference's
+ *       order (a caller's own triangulation; the knife-edge fallback below), and the filter arguments are ignored;
+ *     - source signs / weights (src/same.py:1128-1146), greedy MIP start with prefer = rowmin < no_match_penalty * size
+ *       (src/init_helpers.py:104-133), lazy-constraint body (src/same.py:645-669), XY-order sweep (src/violationhelper.py:53-117),
+ *       area flips (src/same.py:1362-1402).
+ *     Outputs are laid end to end in window order: out_match_row / out_point_flag hold kept[0] + kept[1] + ... entries (kept = the
+ *     stage call's out_counts[4 i + 2]); out_match_row = SECTION row of the matched reference cell or -1; out_point_flag = per-cell
+ *     flag byte: bit 0 the XY-order sweep flags the cell (src/violationhelper.py:100-104), bit 1 the cell is a vertex of a triangle
+ *     whose signed area flips (src/same.py:1464-1469); out_stats[8 i ..] = {orientation checked, flipped, XY comparisons, XY
+ *     violations, triangles with a violation, area flips, greedy rounds, matched cells}; out_counts[3 i ..] = {kept, added back,
+ *     cosines within near_tol of cos_thr} (prefiltered: {n, 0, 0}).  When a window's third count is not zero nothing of that window
+ *     counts (its slices of the outputs mean nothing, no triangles are left on the device): the caller re-decides its triangles with
+ *     the reference's literal arccos (same_amd/triangles.py) and calls again for that window with prefiltered = 1.  Per window two
+ *     fills, 14 launches (17 with fp64 costs) and three copies; ONE wait for the batch (more greedy rounds, in batches with a wait
+ *     each, only for a window in which a pair could still be taken after the rounds enqueued up front).
+ * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size.
+ * (ABI 6: same_window_stage / same_window_filter_finish take batches; same_window_filter and same_window_finish of ABI 5 are gone --
+ * the former is the latter's first half, the latter is prefiltered = 1.) */
+#define SAME_WINDOW_BATCH_MAX 64
 typedef struct same_section same_section;
 typedef struct same_window same_window;
 enum {
@@ -461,16 +469,11 @@ int same_section_bin(same_section *section, double x0, double y0, double cell_w,
 void same_section_destroy(same_section *section);
 int same_window_create(same_ctx *ctx, same_window **out);
 void same_window_destroy(same_window *window);
-int same_window_stage(same_window *window, const same_section *moving, const same_section *ref,
-                      const double *box, double radius, int k, double dist_ct_coeff, int64_t *out_counts);
+int same_window_stage(same_window *const *windows, int n_windows, const same_section *moving, const same_section *ref,
+                      const double *boxes, double radius, int k, double dist_ct_coeff, int64_t *out_counts);
 int same_window_fetch(same_window *window, int what, void *out, int64_t bytes);
-int same_window_filter(same_window *window, const int32_t *simplices, int64_t n_simplices, double radius,
-                       int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
-                       int ensure_min_triangle_per_node, int64_t *out_counts);
-int same_window_finish(same_window *window, const int32_t *tris, int64_t Tr, double no_match_penalty,
-                       int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats);
-int same_window_filter_finish(same_window *window, const int32_t *simplices, int64_t n_simplices, double radius,
-                              int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
+int same_window_filter_finish(same_window *const *windows, int n_windows, const int32_t *simplices, const int64_t *simplex_offsets,
+                              int prefiltered, double radius, int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
                               int ensure_min_triangle_per_node, double no_match_penalty, int32_t *out_match_row,
                               uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts);
 

@@ -21,7 +21,7 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
 SPREAD_INFO_LEN = 14                           # SAME_SPREAD_INFO_LEN
@@ -98,11 +98,9 @@ _PROTOTYPES = {
     "same_section_destroy": [c_vp],
     "same_window_create": [c_vp, ctypes.POINTER(c_vp)],
     "same_window_destroy": [c_vp],
-    "same_window_stage": [c_vp, c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_vp],
+    "same_window_stage": [c_vp, c_int, c_vp, c_vp, c_vp, c_dbl, c_int, c_dbl, c_vp],
     "same_window_fetch": [c_vp, c_int, c_vp, c_i64],
-    "same_window_filter": [c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_vp],
-    "same_window_finish": [c_vp, c_vp, c_i64, c_dbl, c_vp, c_vp, c_vp],
-    "same_window_filter_finish": [c_vp, c_vp, c_i64, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
+    "same_window_filter_finish": [c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
     "same_comm_unique_id": [c_vp],
     "same_comm_init": [c_vp, c_int, c_int, c_vp],

@@ -969,13 +969,18 @@ void same_window_destroy(same_window *w) {
     delete w;
 }
 
-int same_window_stage(same_window *w, const same_section *mov, const same_section *ref, const double *box, double radius, int k,
-                      double dist_ct_coeff, int64_t *out_counts) {
-    if (!w) return SAME_EINVAL;
+}  // extern "C"
+
+namespace {
+
+struct StagePlan {
+    size_t back_bytes = 0, slots = 0;
+};
+
+// everything of one window's stage call up to and including its copy back (no wait): the caller holds the sections' grid locks
+int enqueue_stage(same_window *w, const same_section *mov, const same_section *ref, const double *box, int k, double dist_ct_coeff,
+                  const same_knn_index *ix, StagePlan *sp) {
     same_ctx *ctx = w->ctx;
-    REQUIRE(ctx, mov && ref && box && out_counts && mov->ctx->device == ctx->device && ref->ctx->device == ctx->device);
-    REQUIRE(ctx, mov->T == ref->T && mov->cost_f32 == ref->cost_f32 && k >= 1 && k <= SAME_MAX_KNN && radius >= 0.0);
-    SAME_TRY(same_use(ctx));
     w->staged = w->finished = w->filtered = 0;
     w->mov = mov;
     w->ref = ref;
@@ -983,13 +988,6 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     w->cost_f32 = mov->cost_f32;
     w->k = k;
     w->n_m = w->n_r = w->n_ua = w->P = w->Tr = 0;
-    for (int q = 0; q < 4; ++q) out_counts[q] = 0;
-    const same_knn_index *ix = nullptr;
-    SAME_TRY(knn_index_for(ctx, ref, radius, &ix));
-    // both sections' grids stay as they are until this call's kernels are enqueued (same_section_bin waits for this, then for the device)
-    std::shared_lock<std::shared_mutex> grid_m(const_cast<same_section *>(mov)->grid_lock), grid_r;
-    if (ref != mov) grid_r = std::shared_lock<std::shared_mutex>(const_cast<same_section *>(ref)->grid_lock);
-
     // the candidates: rows of the cells the box covers (their number is known here), or a mask over the whole section
     Cover cm = cover_of(mov, box), cr = cover_of(ref, box);
     int64_t cap_m = cm.n_cand, cap_r = cr.n_cand;
@@ -1087,20 +1085,73 @@ int same_window_stage(same_window *w, const same_section *mov, const same_sectio
     }
     HIP_TRY(ctx, hipGetLastError());
     // ONE copy back: the four counts, then the kept aligned rows' XY and section rows at the capacity cap_m
-    char *hb = static_cast<char *>(w->host);
-    SAME_COPY(ctx, hb, dc, back_bytes, hipMemcpyDeviceToHost);
-    SAME_WAIT(ctx);
-    const unsigned long long *tot = reinterpret_cast<const unsigned long long *>(hb);
+    SAME_COPY(ctx, w->host, dc, back_bytes, hipMemcpyDeviceToHost);
+    sp->back_bytes = back_bytes;
+    sp->slots = slots;
+    return SAME_OK;
+}
+
+// after the wait: the counts the copy brought back
+int collect_stage(same_window *w, const StagePlan &sp, int64_t *out_counts) {
+    same_ctx *ctx = w->ctx;
+    const unsigned long long *tot = reinterpret_cast<const unsigned long long *>(w->host);
     w->n_m = (int64_t)tot[0];
     w->n_r = (int64_t)tot[1];
     w->n_ua = (int64_t)tot[2];
     w->P = (int64_t)tot[3];
-    REQUIRE(ctx, w->n_m <= cap_m && w->n_r <= cap_r && w->n_ua <= w->n_m && w->P <= (int64_t)slots);
+    REQUIRE(ctx, w->n_m <= w->cap_m && w->n_r <= w->cap_r && w->n_ua <= w->n_m && w->P <= (int64_t)sp.slots);
     out_counts[0] = w->n_m;
     out_counts[1] = w->n_r;
     out_counts[2] = w->n_ua;
     out_counts[3] = w->P;
     w->staged = (w->n_m && w->n_r) ? 2 : 1;      // no pairs possible: the caller raises what run_same raises (src/same.py:1003)
+    return SAME_OK;
+}
+
+// a batch call's windows: one context, no window twice
+int check_batch(same_window *const *windows, int n_windows, same_ctx **out_ctx) {
+    if (!windows || n_windows < 1 || !windows[0]) return SAME_EINVAL;
+    same_ctx *ctx = windows[0]->ctx;
+    REQUIRE(ctx, n_windows <= SAME_WINDOW_BATCH_MAX);
+    for (int i = 0; i < n_windows; ++i) {
+        REQUIRE(ctx, windows[i] && windows[i]->ctx == ctx);
+        for (int j = 0; j < i; ++j) REQUIRE(ctx, windows[j] != windows[i]);
+    }
+    *out_ctx = ctx;
+    return SAME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int same_window_stage(same_window *const *windows, int n_windows, const same_section *mov, const same_section *ref, const double *boxes,
+                      double radius, int k, double dist_ct_coeff, int64_t *out_counts) {
+    same_ctx *ctx = nullptr;
+    SAME_TRY(check_batch(windows, n_windows, &ctx));
+    REQUIRE(ctx, mov && ref && boxes && out_counts && mov->ctx->device == ctx->device && ref->ctx->device == ctx->device);
+    REQUIRE(ctx, mov->T == ref->T && mov->cost_f32 == ref->cost_f32 && k >= 1 && k <= SAME_MAX_KNN && radius >= 0.0);
+    SAME_TRY(same_use(ctx));
+    for (int i = 0; i < 4 * n_windows; ++i) out_counts[i] = 0;
+    for (int i = 0; i < n_windows; ++i) windows[i]->staged = windows[i]->finished = windows[i]->filtered = 0;
+    const same_knn_index *ix = nullptr;
+    SAME_TRY(knn_index_for(ctx, ref, radius, &ix));
+    // both sections' grids stay as they are until this call's kernels are enqueued (same_section_bin waits for this, then for the device)
+    std::shared_lock<std::shared_mutex> grid_m(const_cast<same_section *>(mov)->grid_lock), grid_r;
+    if (ref != mov) grid_r = std::shared_lock<std::shared_mutex>(const_cast<same_section *>(ref)->grid_lock);
+    // every window's fill, launches and copy back go into the stream one after the other; ONE wait for the batch -- the device works
+    // on window i while the host enqueues window i + 1
+    std::vector<StagePlan> plans((size_t)n_windows);
+    int rc = SAME_OK;
+    for (int i = 0; i < n_windows && rc == SAME_OK; ++i)
+        rc = enqueue_stage(windows[i], mov, ref, boxes + 4 * i, k, dist_ct_coeff, ix, &plans[(size_t)i]);
+    if (rc != SAME_OK) {                          // nothing of a failed batch counts; what was enqueued is waited for before returning
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int i = 0; i < n_windows; ++i) windows[i]->staged = 0;
+        return rc;
+    }
+    SAME_WAIT(ctx);
+    for (int i = 0; i < n_windows; ++i) SAME_TRY(collect_stage(windows[i], plans[(size_t)i], out_counts + 4 * i));
     return SAME_OK;
 }
 
@@ -1274,14 +1325,19 @@ int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     return enqueue_tail(w, p);
 }
 
-// the finish call's answers: one copy, one wait; more greedy rounds (and the tail again) when the rounds enqueued up front did not settle the matching
-int collect_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats) {
+// the finish call's answers: one copy (enqueue_finish_copy), a wait the CALLER makes (one for a whole batch of windows), then
+// read_finish: more greedy rounds (and the tail again) when the rounds enqueued up front did not settle the matching
+int enqueue_finish_copy(same_window *w, FinishPlan *p) {
+    same_ctx *ctx = w->ctx;
+    SAME_COPY(ctx, static_cast<char *>(w->host) + w->host_finish_off, reinterpret_cast<const char *>(p->gs.sel), p->back_bytes, hipMemcpyDeviceToHost);
+    return SAME_OK;
+}
+
+int read_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua, P = w->P;
     char *h = static_cast<char *>(w->host) + w->host_finish_off;
     const char *dsel = reinterpret_cast<const char *>(p->gs.sel);
-    SAME_COPY(ctx, h, dsel, p->back_bytes, hipMemcpyDeviceToHost);
-    SAME_WAIT(ctx);
     const unsigned long long *sel = reinterpret_cast<const unsigned long long *>(h);
     const unsigned long long *cnt = reinterpret_cast<const unsigned long long *>(h + p->o_counters);
     int rounds = 0;
@@ -1323,98 +1379,92 @@ int collect_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_
 
 extern "C" {
 
-int same_window_filter(same_window *w, const int32_t *simplices, int64_t n_simplices, double radius, int angle_enabled, double cos_thr,
-                       double near_tol, int ignore_same_type, int ensure_min_triangle_per_node, int64_t *out_counts) {
-    if (!w) return SAME_EINVAL;
-    same_ctx *ctx = w->ctx;
-    REQUIRE(ctx, w->staged == 2 && out_counts && n_simplices >= 0 && n_simplices < ((int64_t)1 << 31) - 512 && (n_simplices == 0 || simplices));
-    const int64_t n = w->n_ua, Tr = n_simplices;
-    for (int q = 0; q < 3; ++q) out_counts[q] = 0;
-    SAME_TRY(same_use(ctx));
-    SAME_TRY(check_index_range(ctx, simplices, Tr * 3, 0, n, "triangles"));
-    w->filtered = w->finished = 0;
-    w->Tr = 0;
-    if (Tr == 0 || n == 0) { w->filtered = 1; return SAME_OK; }
-    FilterPlan plan;
-    SAME_TRY(enqueue_filter(w, simplices, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &plan));
-    unsigned long long *h = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
-    SAME_COPY(ctx, h, plan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    SAME_WAIT(ctx);
-    const int64_t n_keep = (int64_t)h[FC_KEEP], n_near = (int64_t)h[FC_NEAR], n_add = plan.readd ? (int64_t)h[FC_ADD] : 0;
-    out_counts[0] = n_keep;
-    out_counts[1] = n_add;
-    out_counts[2] = n_near;
-    if (n_near) return SAME_OK;                      // knife-edge cosines: the caller decides them as the reference does and passes the triangles in
-    w->Tr = n_keep + n_add;
-    w->filtered = 1;
-    return SAME_OK;
-}
-
-int same_window_finish(same_window *w, const int32_t *tris, int64_t Tr, double no_match_penalty, int32_t *out_match_row,
-                       uint8_t *out_point_flag, int64_t *out_stats) {
-    if (!w) return SAME_EINVAL;
-    same_ctx *ctx = w->ctx;
-    const bool resident = tris == nullptr && Tr < 0;      // the triangles same_window_filter left on the device
-    REQUIRE(ctx, w->staged == 2 && out_stats);
-    if (resident) {
-        REQUIRE(ctx, w->filtered);
-        Tr = w->Tr;
+int same_window_filter_finish(same_window *const *windows, int n_windows, const int32_t *simplices, const int64_t *simplex_offsets, int prefiltered,
+                              double radius, int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
+                              int ensure_min_triangle_per_node, double no_match_penalty, int32_t *out_match_row, uint8_t *out_point_flag,
+                              int64_t *out_stats, int64_t *out_counts) {
+    same_ctx *ctx = nullptr;
+    SAME_TRY(check_batch(windows, n_windows, &ctx));
+    REQUIRE(ctx, simplex_offsets && out_counts && out_stats && simplex_offsets[0] == 0);
+    int64_t n_cells = 0;
+    for (int i = 0; i < n_windows; ++i) {
+        const int64_t Tr = simplex_offsets[i + 1] - simplex_offsets[i];
+        REQUIRE(ctx, windows[i]->staged == 2 && Tr >= 0 && Tr < ((int64_t)1 << 31) - 512);
+        n_cells += windows[i]->n_ua;
     }
-    REQUIRE(ctx, Tr >= 0 && Tr < ((int64_t)1 << 31) - 512 && (Tr == 0 || tris || resident));
-    const int64_t n = w->n_ua;
-    REQUIRE(ctx, n == 0 || (out_match_row && out_point_flag));
-    for (int q = 0; q < 8; ++q) out_stats[q] = 0;
+    REQUIRE(ctx, (simplex_offsets[n_windows] == 0 || simplices) && (n_cells == 0 || (out_match_row && out_point_flag)));
+    for (int q = 0; q < 3 * n_windows; ++q) out_counts[q] = 0;
+    for (int q = 0; q < 8 * n_windows; ++q) out_stats[q] = 0;
     SAME_TRY(same_use(ctx));
-    if (!resident) SAME_TRY(check_index_range(ctx, tris, Tr * 3, 0, n, "triangles"));
-    w->Tr = Tr;
-    w->finished = 0;
-    if (n == 0) { w->finished = 1; return SAME_OK; }
-    FinishPlan plan;
-    SAME_TRY(enqueue_finish(w, resident ? nullptr : tris, Tr, nullptr, no_match_penalty, &plan));
-    SAME_TRY(collect_finish(w, &plan, out_match_row, out_point_flag, out_stats));
-    w->finished = 1;
-    return SAME_OK;
-}
-
-int same_window_filter_finish(same_window *w, const int32_t *simplices, int64_t n_simplices, double radius, int angle_enabled, double cos_thr,
-                              double near_tol, int ignore_same_type, int ensure_min_triangle_per_node, double no_match_penalty,
-                              int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts) {
-    if (!w) return SAME_EINVAL;
-    same_ctx *ctx = w->ctx;
-    REQUIRE(ctx, w->staged == 2 && out_counts && out_stats && n_simplices >= 0 && n_simplices < ((int64_t)1 << 31) - 512 &&
-                     (n_simplices == 0 || simplices));
-    const int64_t n = w->n_ua, Tr = n_simplices;
-    REQUIRE(ctx, n == 0 || (out_match_row && out_point_flag));
-    for (int q = 0; q < 3; ++q) out_counts[q] = 0;
-    for (int q = 0; q < 8; ++q) out_stats[q] = 0;
-    SAME_TRY(same_use(ctx));
-    SAME_TRY(check_index_range(ctx, simplices, Tr * 3, 0, n, "triangles"));
-    w->filtered = w->finished = 0;
-    w->Tr = 0;
-    if (n == 0) { w->filtered = w->finished = 1; return SAME_OK; }
-    FilterPlan fplan;
-    FinishPlan plan;
-    if (Tr) {
-        SAME_TRY(enqueue_filter(w, simplices, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &fplan));
-        SAME_TRY(enqueue_finish(w, nullptr, Tr, fplan.counters + FC_TR, no_match_penalty, &plan));
-        // the filter's counters come back beside the finish call's block: one copy from each buffer, ONE wait
-        unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
-        SAME_COPY(ctx, hf, fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        SAME_TRY(collect_finish(w, &plan, out_match_row, out_point_flag, out_stats));
-        const int64_t n_keep = (int64_t)hf[FC_KEEP], n_near = (int64_t)hf[FC_NEAR], n_add = fplan.readd ? (int64_t)hf[FC_ADD] : 0;
-        out_counts[0] = n_keep;
-        out_counts[1] = n_add;
-        out_counts[2] = n_near;
-        if (n_near) {             // the caller filters on the host and calls same_window_finish with its triangles: nothing here counts
-            for (int q = 0; q < 8; ++q) out_stats[q] = 0;
-            return SAME_OK;
+    for (int i = 0; i < n_windows; ++i)
+        SAME_TRY(check_index_range(ctx, simplices + 3 * simplex_offsets[i], (simplex_offsets[i + 1] - simplex_offsets[i]) * 3, 0, windows[i]->n_ua,
+                                   "triangles"));
+    struct Item {
+        FilterPlan fplan;
+        FinishPlan plan;
+        bool filtered = false, enqueued = false;
+    };
+    std::vector<Item> items((size_t)n_windows);
+    // every window's filter + finish + copies go into the stream back to back; ONE wait for the batch
+    int rc = SAME_OK;
+    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
+        same_window *w = windows[i];
+        Item &it = items[(size_t)i];
+        const int32_t *tri = simplices + 3 * simplex_offsets[i];
+        const int64_t Tr = simplex_offsets[i + 1] - simplex_offsets[i];
+        w->filtered = w->finished = 0;
+        w->Tr = 0;
+        if (w->n_ua == 0) continue;
+        if (Tr && !prefiltered) {
+            rc = enqueue_filter(w, tri, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &it.fplan);
+            if (rc == SAME_OK) rc = enqueue_finish(w, nullptr, Tr, it.fplan.counters + FC_TR, no_match_penalty, &it.plan);
+            if (rc == SAME_OK) {       // the filter's counters come back beside the finish call's block: one copy from each buffer
+                unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
+                hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+                ++ctx->stats[SAME_STAT_COPIES];
+                if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "filter counters", e);
+            }
+            it.filtered = true;
+        } else {
+            rc = enqueue_finish(w, Tr ? tri : nullptr, Tr, nullptr, no_match_penalty, &it.plan);     // the caller's kept triangles (or none)
         }
-        w->Tr = n_keep + n_add;
-    } else {
-        SAME_TRY(enqueue_finish(w, nullptr, 0, nullptr, no_match_penalty, &plan));
-        SAME_TRY(collect_finish(w, &plan, out_match_row, out_point_flag, out_stats));
+        if (rc == SAME_OK) rc = enqueue_finish_copy(w, &it.plan);
+        it.enqueued = rc == SAME_OK;
     }
-    w->filtered = w->finished = 1;
+    if (rc != SAME_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    SAME_WAIT(ctx);
+    int64_t cell0 = 0;
+    for (int i = 0; i < n_windows; ++i) {
+        same_window *w = windows[i];
+        Item &it = items[(size_t)i];
+        const int64_t Tr = simplex_offsets[i + 1] - simplex_offsets[i];
+        int64_t *counts = out_counts + 3 * i, *stats = out_stats + 8 * i;
+        if (!it.enqueued) {                 // no kept aligned cell: nothing to match, nothing to sweep
+            w->filtered = w->finished = 1;
+            continue;
+        }
+        SAME_TRY(read_finish(w, &it.plan, out_match_row + cell0, out_point_flag + cell0, stats));
+        cell0 += w->n_ua;
+        if (it.filtered) {
+            const unsigned long long *hf = reinterpret_cast<const unsigned long long *>(static_cast<const char *>(w->host) + w->host_filter_off);
+            const int64_t n_keep = (int64_t)hf[FC_KEEP], n_near = (int64_t)hf[FC_NEAR], n_add = it.fplan.readd ? (int64_t)hf[FC_ADD] : 0;
+            counts[0] = n_keep;
+            counts[1] = n_add;
+            counts[2] = n_near;
+            if (n_near) {             // the caller filters this window on the host and calls again with prefiltered = 1: nothing here counts
+                for (int q = 0; q < 8; ++q) stats[q] = 0;
+                continue;
+            }
+            w->Tr = n_keep + n_add;
+        } else {
+            counts[0] = Tr;
+            w->Tr = Tr;
+        }
+        w->filtered = w->finished = 1;
+    }
     return SAME_OK;
 }
 

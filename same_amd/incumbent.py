@@ -58,21 +58,36 @@ class _Chunks:
         self.parts.append((pos, w["window_id"], dw.rows_m[c], dw.match_row[c], c, None if ref_idx is None else ref_idx[c],
                            dw.point_flag[c].astype(bool), dw.flip_flag[c].astype(bool)))
 
-    def table(self, job, with_ref_idx):
-        """One gather per column over all windows' rows: the frame sliding_window_matching would have concatenated."""
+    def table(self, job, with_ref_idx, sections=None):
+        """One gather per column over all windows' rows: the frame sliding_window_matching would have concatenated.  `sections` = (ref,
+        moving) `windows.Section`s of the frames: where the frame's own columns are float64 (the usual case) the type columns and the
+        coordinates are gathered from their row-major copies -- one pass of 8 (T + 2) bytes per row instead of one cache-missing pass per column."""
         parts = sorted(self.parts, key=lambda p: p[0])
         if not parts or not sum(len(p[2]) for p in parts):
             return pd.DataFrame()
         cat = lambda q, dt=None: np.concatenate([p[q] for p in parts]) if dt is None else np.concatenate([p[q] for p in parts]).astype(dt)
         ra, rr = cat(2).astype(np.int64), cat(3).astype(np.int64)
         ref, mov, cid = job.ref, job.moving, job.optim_params["cell_id_col"]
+        cts = list(job.commonCT)
+        f64 = np.dtype(np.float64)
         out = {"aligned_idx": cat(4, np.int64)}
         if with_ref_idx:
             out["ref_idx"] = cat(5, np.int64)
-        for ct in list(job.commonCT) + ["X", "Y"]:
-            out[ct] = mov[ct].to_numpy()[ra]
-        for ct in ("X", "Y"):
-            out[f"ref_{ct}"] = ref[ct].to_numpy()[rr]
+        if sections is not None and all(mov[c].dtype == f64 for c in cts) and len(set(cts)) == len(cts):
+            block = sections[1].types[ra]                      # (rows, T): the commonCT columns in commonCT order
+            for q, ct in enumerate(cts):
+                out[ct] = block[:, q]
+        else:
+            for ct in cts:
+                out[ct] = mov[ct].to_numpy()[ra]
+        if sections is not None and mov["X"].dtype == f64 and mov["Y"].dtype == f64 and ref["X"].dtype == f64 and ref["Y"].dtype == f64:
+            axy, rxy = sections[1].xy[ra], sections[0].xy[rr]
+            out["X"], out["Y"], out["ref_X"], out["ref_Y"] = axy[:, 0], axy[:, 1], rxy[:, 0], rxy[:, 1]
+        else:
+            for ct in ("X", "Y"):
+                out[ct] = mov[ct].to_numpy()[ra]
+            for ct in ("X", "Y"):
+                out[f"ref_{ct}"] = ref[ct].to_numpy()[rr]
         out["size"] = mov["size"].to_numpy()[ra] if "size" in mov.columns else np.ones(len(ra), np.int64)
         out["ref_size"] = ref["size"].to_numpy()[rr] if "size" in ref.columns else np.ones(len(rr), np.int64)
         out[f"Ref_{cid}"] = ref[cid].to_numpy()[rr]
@@ -84,13 +99,18 @@ class _Chunks:
         out["window_id"] = np.concatenate([np.full(len(p[2]), p[1], np.int64) for p in parts])
         if job.mine is not None:
             out["__plan_pos"] = np.concatenate([np.full(len(p[2]), p[0], np.int64) for p in parts])
-        return pd.DataFrame(out)
+        return pd.DataFrame(out, copy=False)       # the arrays were made for this frame: no second copy into consolidated blocks
 
 
-def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None):
+def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None, use_device=True):
     """(match table of ONE window as run_same's post-solve builds it, stats) from its pre-MIP artefacts, through the host-buffer entry
-    points: greedy start -> matching -> lazy-constraint body, XY-order sweep, area flips.  The general route of this module."""
+    points: greedy start -> matching -> lazy-constraint body, XY-order sweep, area flips.  The general route of this module.
+    use_device: a PreparedInputs made by the device-resident window path with its pair list untouched carries the incumbent and the
+    sweeps already (computed where the pairs are, by same_window_filter_finish): take them instead of computing them again."""
     op = prep.optim_params
+    dw = getattr(prep, "device", None)
+    if use_device and dw is not None and dw.match_row is not None and isinstance(prep.valid_pairs, np.ndarray):
+        return _table_of_device_window(prep, dw, commonCT, with_ref_idx)
     pairs = np.ascontiguousarray(np.asarray(prep.valid_pairs, dtype=np.int64).reshape(-1, 2), dtype=np.int32)
     costs, n_a, n_r = prep.costs_array, prep.n_aligned, prep.n_ref
     a_df, r_df, tris = prep.aligned_df, prep.ref_df, prep.triangles_array
@@ -113,10 +133,17 @@ def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None):
     flip_node = np.zeros(n_a, bool)
     if len(t32):
         flip_node[t32[flipped.astype(bool)].reshape(-1)] = True
-    cid = op["cell_id_col"]
+    stats = {"pairs": len(pairs), "triangles": len(t32), "checked": int(checked), "flipped": len(viol), "xy_violations": int(counts[1]),
+             "area_flips": int(np.count_nonzero(flipped)), "matched": len(ai)}
+    return _window_table(prep, commonCT, ai, ri, flip_node, pflag, with_ref_idx), stats
+
+
+def _window_table(prep, commonCT, ai, ri, flip_node, pflag, with_ref_idx):
+    """run_same's post-solve match table (src/same.py:1264-1278, :1464-1470) for matched aligned rows `ai` -> reference rows `ri`"""
+    a_df, r_df, cid = prep.aligned_df, prep.ref_df, prep.optim_params["cell_id_col"]
     out = {"aligned_idx": ai.astype(np.int64)}
     if with_ref_idx:
-        out["ref_idx"] = ri
+        out["ref_idx"] = ri.astype(np.int64)
     for ct in list(commonCT) + ["X", "Y"]:
         out[ct] = a_df[ct].to_numpy()[ai]
     for ct in ("X", "Y"):
@@ -126,12 +153,20 @@ def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None):
     out[f"Ref_{cid}"] = r_df[cid].to_numpy()[ri]
     out[f"Aligned_{cid}"] = a_df[cid].to_numpy()[ai]
     out["time_limit_reached"] = np.zeros(len(ai), bool)
-    out["triangle_violation"] = flip_node[ai]
+    out["triangle_violation"] = flip_node[ai].astype(bool)
     out["filtered_violation"] = pflag[ai].astype(bool)
     out["run_time"] = np.zeros(len(ai))
-    stats = {"pairs": len(pairs), "triangles": len(t32), "checked": int(checked), "flipped": len(viol), "xy_violations": int(counts[1]),
-             "area_flips": int(np.count_nonzero(flipped)), "matched": len(ai)}
-    return pd.DataFrame(out), stats
+    return pd.DataFrame(out)
+
+
+def _table_of_device_window(prep, dw, commonCT, with_ref_idx):
+    ai = np.flatnonzero(dw.match_row >= 0)
+    # rows_r (ascending section rows of the compacted reference frame) -> the compacted index of every matched reference cell
+    ri = np.searchsorted(prep.rows_r, dw.match_row[ai])
+    st = dw.stats
+    stats = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
+             "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
+    return _window_table(prep, commonCT, ai, ri, dw.flip_flag, dw.point_flag, with_ref_idx), stats
 
 
 def _device_ref_idx(dw):
@@ -222,7 +257,7 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
         merged = _Chunks()
         for ch in chunks:
             merged.parts.extend(ch.parts)
-        table = merged.table(job, with_ref_idx)
+        table = merged.table(job, with_ref_idx, (frames.ref_sec, frames.mov_sec))
     if job.all_matches:                      # rows of windows finished by an earlier run (resume)
         table = pd.concat(job.all_matches + ([table] if len(table) else []), ignore_index=True)
     return table
@@ -243,11 +278,19 @@ def _general_route(job, frames, with_ref_idx, stats, ctx):
                 else:
                     yield pos, w, _prepared_from_device(dw, frames, op, gp, verbose=False, vertex_col=job.vertex_col)
             return
+        from . import qhull_pool
+
         ref_rows, moving_rows = _WindowSubsetter(job.ref), _WindowSubsetter(job.moving)
-        for pos, w in job.todo:
-            st = _stage_prune(ref_rows.subset(*w["box"]), moving_rows.subset(*w["box"]), commonCT, job.moving_delaunay, job.vertex_col, op, gp,
-                              job.ignore_pre, False, ctx, prefetch=False, fresh_frames=True)
-            yield pos, w, prepare_same_inputs(None, None, commonCT, verbose=False, ctx=ctx, _staged=st)
+        depth = qhull_pool.lookahead()               # windows cut, pruned and handed to the Qhull helpers ahead of the one being finished
+        qhull_pool.warm(min(depth, len(job.todo)))
+        ahead = {}
+        for q, (pos, w) in enumerate(job.todo):
+            for nxt in range(q, min(q + 1 + depth, len(job.todo))):
+                if nxt not in ahead:
+                    box = job.todo[nxt][1]["box"]
+                    ahead[nxt] = _stage_prune(ref_rows.subset(*box), moving_rows.subset(*box), commonCT, job.moving_delaunay, job.vertex_col, op, gp,
+                                              job.ignore_pre, False, ctx, prefetch=True, fresh_frames=True)
+            yield pos, w, prepare_same_inputs(None, None, commonCT, verbose=False, ctx=ctx, _staged=ahead.pop(q))
 
     keep_csv, job.outprefix = job.outprefix, None        # the table is written once, by the caller of this route
     try:
@@ -255,7 +298,7 @@ def _general_route(job, frames, with_ref_idx, stats, ctx):
             if len(prep.valid_pairs) == 0:               # every node unconstrained under the caller's triangulation: nothing to match
                 continue
             with stage("incumbent + sweeps + table (general route)"):
-                window_matches, stats[pos] = incumbent_of_prepared(prep, commonCT, with_ref_idx, ctx=ctx)
+                window_matches, stats[pos] = incumbent_of_prepared(prep, commonCT, with_ref_idx, ctx=ctx, use_device=False)
             job.collect(pos, w, window_matches)
     finally:
         job.outprefix = keep_csv

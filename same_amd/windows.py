@@ -366,7 +366,8 @@ class DeviceSection:
 
 
 class DeviceWindow:
-    """Device state of one window in flight (same_window): `stage` then `finish`, arrays of the state through `fetch`."""
+    """Device state of one window in flight (same_window): `stage` then `filter_finish` (or `finish` with triangles filtered by the
+    caller), arrays of the state through `fetch`.  `stage_windows` / `filter_finish_windows` run a BATCH of windows per library call."""
 
     def __init__(self, ctx=None):
         import ctypes
@@ -384,14 +385,7 @@ class DeviceWindow:
 
     def stage(self, moving, ref, box, radius, knn, dist_ct_coeff):
         """-> (aligned rows in the box, reference rows in the box, aligned rows kept, pairs)"""
-        box = np.ascontiguousarray(box, dtype=np.float64)
-        counts = np.zeros(4, np.int64)
-        with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_window_stage(self.handle, moving.handle, ref.handle, box.ctypes.data, float(radius), int(knn),
-                                                          float(dist_ct_coeff), counts.ctypes.data), "same_window_stage")
-        self.counts = tuple(int(c) for c in counts)
-        self.n_triangles = 0
-        return self.counts
+        return stage_windows([self], moving, ref, [box], radius, knn, dist_ct_coeff)[0]
 
     def fetch(self, what):
         n_m, n_r, kept, pairs = self.counts
@@ -405,52 +399,19 @@ class DeviceWindow:
             self.ctx.check(self.ctx.lib.same_window_fetch(self.handle, int(what), out.ctypes.data, out.nbytes), "same_window_fetch")
         return out
 
-    def filter(self, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node=True):
-        """filter_triangles_by_radius of the kept aligned cells' Delaunay simplices on the device.  -> (kept, added back, cosines
-        within near_tol of the threshold); when the last is not zero the caller filters on the host and passes finish() its triangles."""
-        tris = ops._tris(simplices)
-        counts = np.zeros(3, np.int64)
-        with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_window_filter(self.handle, tris.ctypes.data, len(tris), float(radius), int(angle_enabled), float(cos_thr),
-                                                           float(near_tol), int(bool(ignore_same_type)), int(bool(ensure_min_triangle_per_node)),
-                                                           counts.ctypes.data), "same_window_filter")
-        kept, added, near = (int(c) for c in counts)
-        self.n_triangles = 0 if near else kept + added
-        return kept, added, near
-
     STAT_NAMES = ("checked", "flipped", "xy_comparisons", "xy_violations", "xy_triangles", "area_flips", "greedy_rounds", "matched")
 
     def filter_finish(self, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, no_match_penalty, ensure_min_triangle_per_node=True):
-        """filter() then finish(None) in one call, with no wait between them.  -> (kept, added back, near, match_row, flag, stats);
-        with near != 0 the last three are None and the caller filters on the host and calls finish() with its triangles."""
-        tris = ops._tris(simplices)
-        kept_rows = self.counts[2]
-        counts, stats = np.zeros(3, np.int64), np.zeros(8, np.int64)
-        match_row, flag = np.empty(kept_rows, np.int32), np.empty(kept_rows, np.uint8)
-        with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_window_filter_finish(self.handle, tris.ctypes.data, len(tris), float(radius), int(angle_enabled),
-                                                                  float(cos_thr), float(near_tol), int(bool(ignore_same_type)),
-                                                                  int(bool(ensure_min_triangle_per_node)), float(no_match_penalty), match_row.ctypes.data,
-                                                                  flag.ctypes.data, stats.ctypes.data, counts.ctypes.data), "same_window_filter_finish")
-        kept, added, near = (int(c) for c in counts)
-        self.n_triangles = 0 if near else kept + added
-        if near:
-            return kept, added, near, None, None, None
-        return kept, added, near, match_row, flag, dict(zip(self.STAT_NAMES, (int(v) for v in stats)))
+        """filter_triangles_by_radius of the kept aligned cells' Delaunay simplices, then signs, weights, the greedy incumbent and the three
+        sweeps, in one call.  -> (kept, added back, near, match_row, flag, stats); with near != 0 (cosines within near_tol of the
+        threshold) the last three are None and the caller filters on the host and calls finish() with its triangles."""
+        return filter_finish_windows([self], [simplices], radius, angle_enabled, cos_thr, near_tol, ignore_same_type, no_match_penalty,
+                                     ensure_min_triangle_per_node)[0]
 
     def finish(self, triangles, no_match_penalty):
-        """-> (section row of the matched reference cell per kept aligned cell or -1, flag byte per kept cell: bit 0 = XY-order sweep,
-        bit 1 = vertex of an area-flipped triangle; stats dict).  triangles None = the ones filter() left on the device."""
-        kept = self.counts[2]
-        match_row, flag, stats = np.empty(kept, np.int32), np.empty(kept, np.uint8), np.zeros(8, np.int64)
-        tris = None if triangles is None else ops._tris(triangles)
-        with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_window_finish(self.handle, None if tris is None else tris.ctypes.data, -1 if tris is None else len(tris),
-                                                           float(no_match_penalty), match_row.ctypes.data, flag.ctypes.data, stats.ctypes.data),
-                           "same_window_finish")
-        if tris is not None:
-            self.n_triangles = len(tris)
-        return match_row, flag, dict(zip(self.STAT_NAMES, (int(v) for v in stats)))
+        """The same with triangles the CALLER filtered (kept ones, in the reference's order).  -> (section row of the matched reference cell per
+        kept aligned cell or -1, flag byte per kept cell: bit 0 = XY-order sweep, bit 1 = vertex of an area-flipped triangle; stats dict)."""
+        return filter_finish_windows([self], [triangles], 0.0, 0, 0.0, 0.0, False, no_match_penalty, True, prefiltered=True)[0][3:]
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:
@@ -463,6 +424,59 @@ class DeviceWindow:
             self.close()
         except Exception:
             pass
+
+
+WINDOW_BATCH_MAX = 64      # SAME_WINDOW_BATCH_MAX
+
+
+def _handles(states):
+    import ctypes
+
+    return (ctypes.c_void_p * len(states))(*[s.handle.value for s in states])
+
+
+def stage_windows(states, moving, ref, boxes, radius, knn, dist_ct_coeff):
+    """same_window_stage for a batch of windows of one context (one wait for all of them).  -> [counts per window]"""
+    ctx, n = states[0].ctx, len(states)
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(n, 4)
+    counts = np.zeros((n, 4), np.int64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_window_stage(_handles(states), n, moving.handle, ref.handle, boxes.ctypes.data, float(radius), int(knn),
+                                            float(dist_ct_coeff), counts.ctypes.data), "same_window_stage")
+    for s, c in zip(states, counts.tolist()):
+        s.counts, s.n_triangles = tuple(c), 0
+    return [s.counts for s in states]
+
+
+def filter_finish_windows(states, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, no_match_penalty,
+                          ensure_min_triangle_per_node=True, prefiltered=False):
+    """same_window_filter_finish for a batch (one wait for all of them): `simplices[i]` are window i's Delaunay simplices, or with
+    `prefiltered` its kept triangles.  -> [(kept, added back, near, match_row, flag byte, stats dict) per window]; a window with near != 0
+    has None for the last three."""
+    ctx, n = states[0].ctx, len(states)
+    tris = [ops._tris(t) for t in simplices]
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum([len(t) for t in tris], out=offsets[1:])
+    flat = tris[0] if n == 1 else np.concatenate(tris)
+    kept_cells = [s.counts[2] for s in states]
+    cell_off = np.concatenate(([0], np.cumsum(kept_cells))).astype(np.int64)
+    match_row, flag = np.empty(int(cell_off[-1]), np.int32), np.empty(int(cell_off[-1]), np.uint8)
+    stats, counts = np.zeros((n, 8), np.int64), np.zeros((n, 3), np.int64)
+    with ctx.lock:
+        ctx.check(ctx.lib.same_window_filter_finish(_handles(states), n, flat.ctypes.data, offsets.ctypes.data, int(bool(prefiltered)), float(radius),
+                                                    int(angle_enabled), float(cos_thr), float(near_tol), int(bool(ignore_same_type)),
+                                                    int(bool(ensure_min_triangle_per_node)), float(no_match_penalty), match_row.ctypes.data,
+                                                    flag.ctypes.data, stats.ctypes.data, counts.ctypes.data), "same_window_filter_finish")
+    out = []
+    for i, s in enumerate(states):
+        kept, added, near = (int(c) for c in counts[i])
+        s.n_triangles = 0 if near else kept + added
+        if near:
+            out.append((kept, added, near, None, None, None))
+        else:
+            a, b = int(cell_off[i]), int(cell_off[i + 1])
+            out.append((kept, added, near, match_row[a:b], flag[a:b], dict(zip(DeviceWindow.STAT_NAMES, stats[i].tolist()))))
+    return out
 
 
 class DeviceWindowResult:
@@ -522,16 +536,22 @@ class TriangulationCache:
 
 def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
                         ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False, triangulator=None,
-                        triangulate=True):
+                        triangulate=True, batch=None):
     """The window path of `iter_window_arrays` + the greedy incumbent and the three sweeps, with both sections resident on the
     device (`dref`, `dmoving`: DeviceSections of `ref`, `moving`): per window the host only triangulates (Qhull helpers, windows
     ahead as before) and receives the match; the triangle filter runs on the device too, unless a cosine sits within 8 ulp of the
     angle threshold (then the host re-decides it with the reference's literal expression, as triangles.classify_triangles does).  Yields one
     DeviceWindowResult per window in plan order; the numbers are those of the column pipeline
     (tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline).  A window without pairs yields `.error`.
+    Windows go to the library in BATCHES of `batch` (default $SAME_WINDOW_BATCH, else 8): one stage call, and later one filter + finish
+    call, for up to that many windows -- one wait per call instead of one per window, and the device works on one window while the host
+    enqueues the next.  The states of a batch stay live (`result.state`) until the generator is asked for the first window of the next.
     `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`.
     `triangulate=False` stops after the stage call (rows, prune, costs, compaction): the caller brings its own triangles
     (api.sliding_window_matching with a caller's triangulation) and reads pairs / costs through `state.fetch`."""
+    import os
+    from collections import deque
+
     from . import qhull_pool
     from ._trace import stage as marked
     from .triangles import cos_threshold, filter_triangles_by_radius
@@ -541,86 +561,99 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     near_tol = float(8 * np.spacing(abs(cos_thr))) if (angle_enabled and np.isfinite(cos_thr)) else 0.0
     depth = qhull_pool.lookahead()
     qhull_pool.warm(min(depth, len(plan)))
+    B = max(1, min(int(batch if batch is not None else os.environ.get("SAME_WINDOW_BATCH", "8")), WINDOW_BATCH_MAX, max(len(plan), 1)))
+    ahead_max = max(depth, B)                 # windows staged and not yet finished: about one per helper
     # window states (their device buffers, grown once) are kept with the context from one call to the next: a pass over a plan
-    # then makes no device allocation at all
+    # then makes no device allocation at all.  In use at once: the windows ahead + the batch being staged + the batch last yielded
     cache = ctx.__dict__.setdefault("_device_windows", [])
-    want = min(depth + 1, max(len(plan), 1))
+    want = min(ahead_max + 2 * B, max(len(plan), 1) + B)
     free = [cache.pop() for _ in range(min(want, len(cache)))]
-    free += [DeviceWindow(ctx) for _ in range(want - len(free))]
     r = float(radius)
+    prune_possible = r == r and int(knn) > 0
 
-    def stage(w):
-        out = DeviceWindowResult(w)
-        with marked("subset + prune + costs + compaction (device)"):
-            state = None
-            if r == r and int(knn) > 0:
-                state = free.pop()
-                try:
-                    out.counts = state.stage(dmoving, dref, w["box"], abs(r), knn, dist_ct_coeff)
-                    if out.counts[3]:
-                        out.rows_m, out.axy = state.fetch(_W_ALIGNED_ROWS), state.fetch(_W_ALIGNED_XY)
-                except BaseException:
-                    free.append(state)                # a refused window (SAME_EINVAL ...) must not take its state out of the pool
-                    raise
-            if state is None or out.counts[3] == 0:
-                if state is not None:
-                    free.append(state)
+    def take_state():
+        return free.pop() if free else DeviceWindow(ctx)
+
+    def stage_batch(windows):
+        """-> [(result, state or None, ticket or None)] for `windows`, staged by ONE library call"""
+        outs = [DeviceWindowResult(w) for w in windows]
+        if not prune_possible:
+            for out in outs:
                 out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
-                return out, None
-        if not triangulate:
-            return out, (state, None)
-        with marked("triangulate (hand-over; waits for a free helper)"):
-            try:
-                return out, (state, qhull_pool.pool().submit(out.axy) if triangulator is None
-                             else triangulator.submit(out.axy, key=w.get("window_id")))
-            except BaseException:
+            return [(out, None, None) for out in outs]
+        states = [take_state() for _ in windows]
+        try:
+            with marked("subset + prune + costs + compaction (device)"):
+                counts = stage_windows(states, dmoving, dref, [w["box"] for w in windows], abs(r), knn, dist_ct_coeff)
+        except BaseException:
+            free.extend(states)                       # a refused batch (SAME_EINVAL ...) must not take its states out of the pool
+            raise
+        staged = []
+        for q, (out, state) in enumerate(zip(outs, states)):
+            out.counts = counts[q]
+            if out.counts[3] == 0:
                 free.append(state)
+                out.error = ValueError("No valid_pairs after KNN filtering. Increase radius and/or knn.")
+                staged.append((out, None, None))
+                continue
+            ticket = None
+            try:
+                out.rows_m, out.axy = state.fetch(_W_ALIGNED_ROWS), state.fetch(_W_ALIGNED_XY)
+                if triangulate:
+                    with marked("triangulate (hand-over; waits for a free helper)"):
+                        ticket = (qhull_pool.pool().submit(out.axy) if triangulator is None
+                                  else triangulator.submit(out.axy, key=out.window.get("window_id")))
+            except BaseException:
+                free.extend(st for st in states[q:])
+                free.extend(st for _o, st, _t in staged if st is not None)
                 raise
+            staged.append((out, state, ticket))
+        return staged
 
-    def finish(out, staged):
-        state, ticket = staged
-        if ticket is None:
+    def finish_batch(group):
+        """filter + signs + incumbent + sweeps of the staged windows of `group`, by ONE library call (+ one per window whose filter met a
+        cosine at the threshold)"""
+        todo = [(out, state, ticket) for out, state, ticket in group if state is not None]
+        for out, state, _t in todo:
             out.state, out.n_triangles = state, 0
-            return out
+        if not triangulate or not todo:
+            return
         with marked("triangulate (wait for helper)"):
-            tris = ticket.result()
+            tris = [ticket.result() for _o, _s, ticket in todo]
         with marked("filter + signs + incumbent + sweeps (device)"):
-            _kept, _added, near, out.match_row, cell_flags, out.stats = state.filter_finish(
-                tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles, no_match_penalty)
-        if near:
-            with marked("triangle filter (host: a cosine at the threshold)"):
-                tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
-                out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
-                                                           min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
-            with marked("signs + incumbent + sweeps (device)"):
-                out.match_row, cell_flags, out.stats = state.finish(out.triangles, no_match_penalty)
-        out.point_flag, out.flip_flag = cell_flags & 1, (cell_flags >> 1) & 1        # the library packs both per-cell flags into one byte
-        out.n_triangles = state.n_triangles
-        if fetch_triangles and out.triangles is None:
-            out.triangles = state.fetch(_W_TRIANGLES)
-        out.state = state
-        return out
+            res = filter_finish_windows([st for _o, st, _t in todo], tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles,
+                                        no_match_penalty)
+        for (out, state, _t), simplices, (_kept, _added, near, match_row, cell_flags, stats) in zip(todo, tris, res):
+            if near:
+                with marked("triangle filter (host: a cosine at the threshold)"):
+                    tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
+                    out.triangles = filter_triangles_by_radius(out.axy, simplices, radius, ignore_same_type_triangles=ignore_same_type_triangles,
+                                                               min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
+                with marked("signs + incumbent + sweeps (device)"):
+                    match_row, cell_flags, stats = state.finish(out.triangles, no_match_penalty)
+            out.match_row, out.stats = match_row, stats
+            out.point_flag, out.flip_flag = cell_flags & 1, (cell_flags >> 1) & 1        # the library packs both per-cell flags into one byte
+            out.n_triangles = state.n_triangles
+            if fetch_triangles and out.triangles is None:
+                out.triangles = state.fetch(_W_TRIANGLES)
 
-    ahead, last = {}, None
+    pending, live, nxt = deque(), [], 0
     try:
-        for q in range(len(plan)):
-            if last is not None:                      # the caller has moved on: the previous window's state goes back to the pool
-                free.append(last)
-                last = None
-            for nxt in range(q, min(q + 1 + depth, len(plan))):
-                if nxt not in ahead:
-                    ahead[nxt] = stage(plan[nxt])
-            out, staged = ahead.pop(q)
-            if out.error is None:
-                out = finish(out, staged)
-                last = out.state
-            yield out
+        while nxt < len(plan) or pending:
+            while nxt < len(plan) and (not pending or len(pending) + min(B, len(plan) - nxt) <= ahead_max):
+                windows = plan[nxt:nxt + B]
+                nxt += len(windows)
+                pending.extend(stage_batch(windows))
+            free.extend(live)                     # the caller has moved on: the previous batch's states go back to the pool
+            live = []
+            group = [pending.popleft() for _ in range(min(B, len(pending)))]
+            live = [state for _o, state, _t in group if state is not None]
+            finish_batch(group)
+            for out, _state, _ticket in group:
+                yield out
     finally:
-        for _o, staged in ahead.values():
-            if staged is not None:
-                free.append(staged[0])
-        if last is not None:
-            free.append(last)
+        free.extend(state for _o, state, _t in pending if state is not None)
+        free.extend(live)
         cache.extend(free)
         for extra in cache[want:]:            # a context keeps what one pass needs, not every state it ever had
             extra.close()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in same_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared, "ctypes prototypes and header drifted apart"
-    assert lib.same_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.same_abi_version() == _lib.ABI_VERSION == 6
     assert b"range" in lib.same_strerror(-34)
 
 

@@ -321,9 +321,30 @@ def test_device_window_argument_checks(ops):
     with pytest.raises(SameHipError):
         st.finish(np.array([[0, 1, 400]], np.int32), 1.0)            # vertex out of range: reported, not dereferenced
     with pytest.raises(SameHipError):
-        st.filter(np.array([[0, 1, -1]], np.int32), 10.0, 1, 0.5, 0.0, True)
-    with pytest.raises(SameHipError):
-        st.finish(None, 1.0)                                         # no triangles were left on the device
+        st.filter_finish(np.array([[0, 1, -1]], np.int32), 10.0, 1, 0.5, 0.0, True, 1.0)
+    # batches: a window twice, windows of two contexts, more windows than SAME_WINDOW_BATCH_MAX
+    from same_amd import _lib
+    st2, other = W.DeviceWindow(), _lib.Context(st.ctx.device)
+    st3 = W.DeviceWindow(other)
+    for bad in ([st, st], [st, st3], [st] * (W.WINDOW_BATCH_MAX + 1)):
+        with pytest.raises(SameHipError):
+            W.stage_windows(bad, da, da, [box] * len(bad), 10.0, 4, 1.0)
+    # ... and a batch of two gives what two single calls give (the first window of the batch is the one staged above)
+    half = (0.0, 50.0, 0.0, 100.0)
+    assert W.stage_windows([st, st2], da, da, [box, half], 10.0, 4, 1.0) == [(n_m, n_r, kept, n_pairs), st2.stage(da, da, half, 10.0, 4, 1.0)]
+    from scipy.spatial import Delaunay
+    tri = [Delaunay(s_.fetch(W._W_ALIGNED_XY)).simplices for s_ in (st, st2)]
+    both = W.filter_finish_windows([st, st2], tri, 10.0, 1, 0.9, 0.0, True, 1.0)
+    for s_, t_, got in zip((st, st2), tri, both):
+        one = s_.filter_finish(t_, 10.0, 1, 0.9, 0.0, True, 1.0)
+        assert got[:3] == one[:3] and np.array_equal(got[3], one[3]) and np.array_equal(got[4], one[4]) and got[5] == one[5]
+        kept_tris = s_.fetch(W._W_TRIANGLES)
+        again = s_.finish(kept_tris, 1.0)               # the kept triangles handed back as the caller's own: the same match and sweeps
+        assert np.array_equal(again[0], one[3]) and np.array_equal(again[1], one[4]) and again[2] == one[5]
+    st2.close()
+    st3.close()
+    other.close()
+    st.stage(da, da, box, 10.0, 4, 1.0)
     row, flag, stats = st.finish(np.zeros((0, 3), np.int32), 1.0)    # no triangles at all: a match and empty sweeps
     assert stats["checked"] == stats["xy_comparisons"] == stats["area_flips"] == 0 and stats["matched"] == np.count_nonzero(row >= 0) > 0
     assert not flag.any()
