@@ -682,6 +682,7 @@ class _DeviceFrames:
         self.ctx = ops._ctx(ctx)
         self.ref_sec, self.mov_sec = Section.from_frame(ref, self.commonCT), Section.from_frame(moving, self.commonCT)
         self.dref = self.dmov = None
+        self._worker_ctx = []            # contexts (= streams) of the worker threads beyond the first, kept with their window states
         with stage("sections to the device + binning on the window grid"):
             self.dref = DeviceSection(self.ref_sec, self.cost_dtype, self.ctx)
             self.dmov = DeviceSection(self.mov_sec, self.cost_dtype, self.ctx)
@@ -731,7 +732,19 @@ class _DeviceFrames:
         state.stage(self.dmov, self.dref, box, 1.0, 1, 1.0)
         return state.fetch(_W_ROWS_M), state.fetch(_W_ROWS_R)
 
+    def worker_contexts(self, n):
+        """n contexts on the sections' device for n worker threads: this object's own first, then extra ones that live (with the window
+        states they have grown) until close()."""
+        from . import _lib
+
+        while len(self._worker_ctx) < n - 1:
+            self._worker_ctx.append(_lib.Context(self.ctx.device))
+        return [self.ctx] + self._worker_ctx[:n - 1]
+
     def close(self):
+        for c in self._worker_ctx:
+            c.close()
+        self._worker_ctx = []
         for sec in (self.dref, self.dmov):
             if sec is not None:
                 sec.close()

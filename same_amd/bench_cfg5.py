@@ -138,8 +138,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     group.barrier()
     wall_here = time.perf_counter() - t0
     calls1 = [c.stats() for c in worker_ctx]
-    # the calls counted are those of `ctx`: worker 0's windows (every n_workers-th of this rank's share) + the merge's de-duplication
-    n_done = max(1, -(-len(stats) // n_workers) * steps)
+    # the calls counted are those of `ctx`: worker 0's windows (the first of n_workers contiguous runs of this rank's share) + the merge's de-duplication
+    n_done = max(1, (len(stats) // n_workers) * steps)
     calls_per_window = {k_: sum(b[k_] - a[k_] for a, b in zip(calls0, calls1)) / n_done for k_ in calls1[0]}
     dt = group.max(wall_here)
     rep = _trace.report()

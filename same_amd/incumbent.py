@@ -43,63 +43,81 @@ def _default_workers():
     return 2 if share >= 8 else 1       # a second Python thread only pays where there are CPUs to feed it
 
 
-class _Chunks:
-    """The device route's per-window pieces: section rows of the matched cells inside the central trim, in window order."""
+class _TableBuilder:
+    """The device route's result table, built as the windows come: per window the section rows of the matched cells inside the central
+    trim; every `flush_every` windows their columns are gathered from the caller's frames (numpy releases the interpreter lock for the
+    copies, so a worker thread's gathers run beside the other workers and the waits for the Qhull helpers); `chunks` are concatenated
+    once at the end.  Where the frame's own columns are float64 (the usual case) the type columns and the coordinates come from the
+    sections' row-major copies: one pass of 8 (T + 2) bytes per row instead of one cache-missing pass per column."""
 
-    COLS = ("pos", "window_id", "rows_a", "rows_r", "aligned_idx", "ref_idx", "xy_flag", "flip_flag")
-
-    def __init__(self):
-        self.parts = []
+    def __init__(self, job, sections, with_ref_idx, flush_every=8):
+        ref, mov = job.ref, job.moving
+        self.job, self.with_ref_idx, self.flush_every = job, with_ref_idx, flush_every
+        self.cts, self.cid = list(job.commonCT), job.optim_params["cell_id_col"]
+        f64 = np.dtype(np.float64)
+        self.type_block = sections[1].types if (all(mov[c].dtype == f64 for c in self.cts) and len(set(self.cts)) == len(self.cts)) else None
+        self.type_cols = None if self.type_block is not None else [mov[c].to_numpy() for c in self.cts]
+        both_xy = all(df[c].dtype == f64 for df in (ref, mov) for c in ("X", "Y"))
+        self.mov_xy, self.ref_xy = (sections[1].xy, sections[0].xy) if both_xy else (None, None)
+        self.xy_cols = None if both_xy else ([mov[c].to_numpy() for c in ("X", "Y")], [ref[c].to_numpy() for c in ("X", "Y")])
+        self.mov_size = mov["size"].to_numpy() if "size" in mov.columns else None
+        self.ref_size = ref["size"].to_numpy() if "size" in ref.columns else None
+        self.ref_id, self.mov_id = ref[self.cid].to_numpy(), mov[self.cid].to_numpy()
+        self.pending, self.chunks = [], []
 
     def add(self, pos, w, dw, ref_idx=None):
         x, y = dw.axy[:, 0], dw.axy[:, 1]
         tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:565-582), matched cells only
         c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
-        self.parts.append((pos, w["window_id"], dw.rows_m[c], dw.match_row[c], c, None if ref_idx is None else ref_idx[c],
-                           dw.point_flag[c].astype(bool), dw.flip_flag[c].astype(bool)))
+        self.pending.append((pos, w["window_id"], dw.rows_m[c], dw.match_row[c], c, None if ref_idx is None else ref_idx[c],
+                             dw.point_flag[c], dw.flip_flag[c]))
+        if len(self.pending) >= self.flush_every:
+            self.flush()
 
-    def table(self, job, with_ref_idx, sections=None):
-        """One gather per column over all windows' rows: the frame sliding_window_matching would have concatenated.  `sections` = (ref,
-        moving) `windows.Section`s of the frames: where the frame's own columns are float64 (the usual case) the type columns and the
-        coordinates are gathered from their row-major copies -- one pass of 8 (T + 2) bytes per row instead of one cache-missing pass per column."""
-        parts = sorted(self.parts, key=lambda p: p[0])
+    def flush(self):
+        parts, self.pending = self.pending, []
         if not parts or not sum(len(p[2]) for p in parts):
-            return pd.DataFrame()
-        cat = lambda q, dt=None: np.concatenate([p[q] for p in parts]) if dt is None else np.concatenate([p[q] for p in parts]).astype(dt)
+            return
+        cat = lambda q: np.concatenate([p[q] for p in parts])
         ra, rr = cat(2).astype(np.int64), cat(3).astype(np.int64)
-        ref, mov, cid = job.ref, job.moving, job.optim_params["cell_id_col"]
-        cts = list(job.commonCT)
-        f64 = np.dtype(np.float64)
-        out = {"aligned_idx": cat(4, np.int64)}
-        if with_ref_idx:
-            out["ref_idx"] = cat(5, np.int64)
-        if sections is not None and all(mov[c].dtype == f64 for c in cts) and len(set(cts)) == len(cts):
-            block = sections[1].types[ra]                      # (rows, T): the commonCT columns in commonCT order
-            for q, ct in enumerate(cts):
+        out = {"aligned_idx": cat(4).astype(np.int64)}
+        if self.with_ref_idx:
+            out["ref_idx"] = cat(5).astype(np.int64)
+        if self.type_block is not None:
+            block = self.type_block[ra]                      # (rows, T): the commonCT columns in commonCT order
+            for q, ct in enumerate(self.cts):
                 out[ct] = block[:, q]
         else:
-            for ct in cts:
-                out[ct] = mov[ct].to_numpy()[ra]
-        if sections is not None and mov["X"].dtype == f64 and mov["Y"].dtype == f64 and ref["X"].dtype == f64 and ref["Y"].dtype == f64:
-            axy, rxy = sections[1].xy[ra], sections[0].xy[rr]
+            for ct, col in zip(self.cts, self.type_cols):
+                out[ct] = col[ra]
+        if self.mov_xy is not None:
+            axy, rxy = self.mov_xy[ra], self.ref_xy[rr]
             out["X"], out["Y"], out["ref_X"], out["ref_Y"] = axy[:, 0], axy[:, 1], rxy[:, 0], rxy[:, 1]
         else:
-            for ct in ("X", "Y"):
-                out[ct] = mov[ct].to_numpy()[ra]
-            for ct in ("X", "Y"):
-                out[f"ref_{ct}"] = ref[ct].to_numpy()[rr]
-        out["size"] = mov["size"].to_numpy()[ra] if "size" in mov.columns else np.ones(len(ra), np.int64)
-        out["ref_size"] = ref["size"].to_numpy()[rr] if "size" in ref.columns else np.ones(len(rr), np.int64)
-        out[f"Ref_{cid}"] = ref[cid].to_numpy()[rr]
-        out[f"Aligned_{cid}"] = mov[cid].to_numpy()[ra]
+            (mx, my), (rx, ry) = self.xy_cols
+            out["X"], out["Y"], out["ref_X"], out["ref_Y"] = mx[ra], my[ra], rx[rr], ry[rr]
+        out["size"] = self.mov_size[ra] if self.mov_size is not None else np.ones(len(ra), np.int64)
+        out["ref_size"] = self.ref_size[rr] if self.ref_size is not None else np.ones(len(rr), np.int64)
+        out[f"Ref_{self.cid}"] = self.ref_id[rr]
+        out[f"Aligned_{self.cid}"] = self.mov_id[ra]
         out["time_limit_reached"] = np.zeros(len(ra), bool)
-        out["triangle_violation"] = cat(7)
-        out["filtered_violation"] = cat(6)
+        out["triangle_violation"] = cat(7).astype(bool)
+        out["filtered_violation"] = cat(6).astype(bool)
         out["run_time"] = np.zeros(len(ra))
         out["window_id"] = np.concatenate([np.full(len(p[2]), p[1], np.int64) for p in parts])
-        if job.mine is not None:
+        if self.job.mine is not None:
             out["__plan_pos"] = np.concatenate([np.full(len(p[2]), p[0], np.int64) for p in parts])
-        return pd.DataFrame(out, copy=False)       # the arrays were made for this frame: no second copy into consolidated blocks
+        self.chunks.append(out)
+
+    @staticmethod
+    def table(builders):
+        """The builders' chunks laid end to end (each builder walked a contiguous run of the plan, so this is plan order)."""
+        chunks = [c for b in builders for c in b.chunks]
+        if not chunks:
+            return pd.DataFrame()
+        if len(chunks) == 1:
+            return pd.DataFrame({k: np.ascontiguousarray(v) for k, v in chunks[0].items()}, copy=False)
+        return pd.DataFrame({k: np.concatenate([c[k] for c in chunks]) for k in chunks[0]}, copy=False)
 
 
 def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None, use_device=True):
@@ -212,52 +230,47 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
 
 
 def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
-    from . import _lib
-
     n_workers = max(1, int(workers if workers is not None else _default_workers()))
     n_workers = min(n_workers, max(1, len(job.todo)))
-    contexts = [frames.ctx] + [_lib.Context(frames.ctx.device) for _ in range(n_workers - 1)]
-    chunks = [_Chunks() for _ in range(n_workers)]
+    contexts = frames.worker_contexts(n_workers)
+    sections = (frames.ref_sec, frames.mov_sec)
+    builders = [_TableBuilder(job, sections, with_ref_idx) for _ in range(n_workers)]
     lock = threading.Lock()
+    cut = [len(job.todo) * q // n_workers for q in range(n_workers + 1)]          # worker q walks a contiguous run of this process's windows
 
     def walk(q):
-        mine = job.todo[q::n_workers]
+        mine = job.todo[cut[q]:cut[q + 1]]
         for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator)):
             if dw.error is not None:
                 raise dw.error
-            with stage("table rows (central trim)"):
-                chunks[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
+            with stage("table rows (central trim) + columns (every 8 windows)"):
+                builders[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
                 st = dw.stats
                 rec = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
                        "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
             with lock:
                 stats[pos] = rec
+        with stage("table rows (central trim) + columns (every 8 windows)"):
+            builders[q].flush()
 
-    try:
-        if n_workers == 1:
-            walk(0)
-        else:
-            errors = []
+    if n_workers == 1:
+        walk(0)
+    else:
+        errors = []
 
-            def guarded(q):
-                try:
-                    walk(q)
-                except BaseException as e:   # noqa: BLE001 -- re-raised in the calling thread below
-                    errors.append(e)
+        def guarded(q):
+            try:
+                walk(q)
+            except BaseException as e:   # noqa: BLE001 -- re-raised in the calling thread below
+                errors.append(e)
 
-            threads = [threading.Thread(target=guarded, args=(q,), name=f"same-windows-{q}") for q in range(n_workers)]
-            [t.start() for t in threads]
-            [t.join() for t in threads]
-            if errors:
-                raise errors[0]
-    finally:
-        for c in contexts[1:]:
-            c.close()
-    with stage("table columns (one gather over all windows)"):
-        merged = _Chunks()
-        for ch in chunks:
-            merged.parts.extend(ch.parts)
-        table = merged.table(job, with_ref_idx, (frames.ref_sec, frames.mov_sec))
+        threads = [threading.Thread(target=guarded, args=(q,), name=f"same-windows-{q}") for q in range(n_workers)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        if errors:
+            raise errors[0]
+    with stage("table (chunks laid end to end)"):
+        table = _TableBuilder.table(builders)
     if job.all_matches:                      # rows of windows finished by an earlier run (resume)
         table = pd.concat(job.all_matches + ([table] if len(table) else []), ignore_index=True)
     return table

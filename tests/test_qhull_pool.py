@@ -258,7 +258,8 @@ def test_threads_share_the_pool_without_waiting_on_each_other():
 
 def test_triangulation_cache_remembers_windows_by_id(monkeypatch):
     """windows.TriangulationCache (bench.py's diagnostic pass): the first request of a window goes to the helper pool and its answer is
-    kept; the second is answered from memory; a window without an id is never remembered.  The simplices are scipy's either way."""
+    kept under (id, number of points, checksum of their coordinates); the second is answered from memory; other points under the same id
+    ask the pool again; a window without an id is never remembered.  The simplices are scipy's either way."""
     monkeypatch.setenv("SAME_QHULL_WORKERS", "1")
     from same_amd import qhull_pool
     from same_amd.windows import TriangulationCache
@@ -269,10 +270,13 @@ def test_triangulation_cache_remembers_windows_by_id(monkeypatch):
         a, b = rng.uniform(0, 50, (300, 2)), rng.uniform(0, 50, (200, 2))
         cache = TriangulationCache()
         first = cache.submit(a, key=7)
-        assert 7 not in cache.known and np.array_equal(first.result(), Delaunay(a).simplices) and 7 in cache.known
-        again = cache.submit(b, key=7)                  # the id decides, not the points: the remembered answer comes back
-        assert np.array_equal(again.result(), Delaunay(a).simplices)
-        assert np.array_equal(cache.submit(b, key=None).result(), Delaunay(b).simplices) and list(cache.known) == [7]
+        assert not cache.known and np.array_equal(first.result(), Delaunay(a).simplices) and len(cache.known) == 1
+        again = cache.submit(a.copy(), key=7)           # the same window again: answered from memory, no helper asked
+        assert isinstance(again, TriangulationCache._Ready) and np.array_equal(again.result(), Delaunay(a).simplices)
+        # the id alone does not decide: a cache reused with another plan / section whose windows reuse ids must not answer with stale simplices
+        other = cache.submit(b, key=7)
+        assert not isinstance(other, TriangulationCache._Ready) and np.array_equal(other.result(), Delaunay(b).simplices) and len(cache.known) == 2
+        assert np.array_equal(cache.submit(b, key=None).result(), Delaunay(b).simplices) and len(cache.known) == 2
     finally:
         if qhull_pool._pool is not None:
             qhull_pool._pool.close()
