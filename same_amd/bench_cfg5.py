@@ -10,7 +10,7 @@ RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dt
                "windows_per_s_triangulations_given", "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step",
                "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl",
-               "product_function", "api_path_windows_per_s", "api_path")
+               "product_function", "api_path_windows_per_s", "api_path", "window_calls_only_windows_per_s")
 
 
 def record(line):
@@ -150,7 +150,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # DIAGNOSTIC, outside the timed region and never part of `value`: the same pass with every window's triangulation remembered from a
     # first pass -- what the library calls + the Python glue cost once Qhull is out of the picture, i.e. the rate a host with enough
     # CPU per rank could approach (on this box the timed pass is bound by its 16 CPUs' worth of Qhull)
-    no_qhull = None
+    no_qhull = calls_only = None
     if on_device:
         tri_cache[0] = W.TriangulationCache()
         all_ranks(one_pass, my_plan)                       # fills the cache
@@ -159,6 +159,13 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
         for _ in range(2):
             all_ranks(one_pass, my_plan)
         no_qhull = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
+        # ... and the window calls alone (stage + filter_finish in batches, the per-window Python of iter_device_windows; no table): one thread
+        frames_obj = next(iter(resident._frames.values()))
+        tq = time.perf_counter()
+        for _ in range(2):
+            for dw in frames_obj.windows(my_plan, triangulator=tri_cache[0], ctx=ctx):
+                pass
+        calls_only = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
         tri_cache[0] = None
     # what the threads could have used: every worker for the window passes, one thread for the exchange + merge behind them
     thread_seconds = max(pass_seconds[0] * n_workers + (wall_here - pass_seconds[0]), 1e-9)
@@ -166,7 +173,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                 "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / thread_seconds, "threads": n_workers,
                 "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / thread_seconds),
                 "qhull_wait_share": qhull_wait / thread_seconds, "serial_tail_s_per_step": (wall_here - pass_seconds[0]) / steps,
-                "windows_per_s_triangulations_given": no_qhull,
+                "windows_per_s_triangulations_given": no_qhull, "window_calls_only_windows_per_s": calls_only,
                 "runtime_calls_per_window": calls_per_window, "table_allgather_ms": (sum(exchange_ms) / len(exchange_ms)) if exchange_ms else None,
                 "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
@@ -232,6 +239,10 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                "windows_per_s_triangulations_given_means": "DIAGNOSTIC, not a throughput: the rate of two extra passes (windows only: no exchange, no merge) "
                                                            "in which every window's Delaunay simplices are remembered from an earlier pass, summed over "
                                                            "the ranks -- what the library calls and the Python glue allow once Qhull is out of the picture",
+               "window_calls_only_windows_per_s": mine_rec["window_calls_only_windows_per_s"],
+               "window_calls_only_means": "DIAGNOSTIC, rank 0, ONE thread: windows.iter_device_windows over this rank's windows with the triangulations "
+                                          "remembered and nothing done with the results -- the two batched library calls per eight windows and the "
+                                          "generator's own Python; the product function adds the table (about 1 MB of gathered columns per window)",
                "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
                "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued per window on rank 0, "
                                                  "counted by the library itself (same_ctx_stat) over the timed passes; the merge's de-duplication included",
