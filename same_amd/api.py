@@ -655,19 +655,21 @@ class _WindowSubsetter:
 def _window_frame(df, rows, vertex_col=None, aligned=False):
     """Rows `rows` of the caller's frame as the frame run_same holds after its prune: the helper columns of src/same.py:934-970
     (size default, __orig_idx = the caller's index labels, __tri_vid on the aligned side) and the renumbering of src/utils.py:739-740."""
-    out = df.iloc[rows].copy(deep=False)
+    out = df.iloc[rows].copy(deep=False)          # iloc with a row list makes fresh data; the shallow copy only drops pandas' "copy of a slice" mark
+    labels = out.index.to_numpy()
+    out.index = pd.RangeIndex(len(out))           # the renumbering, in place: reset_index(drop=True) would copy every block once more
     if "size" not in out.columns:
         out["size"] = 1
     if "__orig_idx" not in out.columns:
-        out["__orig_idx"] = out.index.to_numpy()
+        out["__orig_idx"] = labels
     if aligned:
         if vertex_col is None:
-            out["__tri_vid"] = out.index.to_numpy()
+            out["__tri_vid"] = labels
         else:
             if vertex_col not in out.columns:
                 raise ValueError(f"aligned_delaunay_vertex_col='{vertex_col}' not in aligned_df")
             out["__tri_vid"] = out[vertex_col].to_numpy()
-    return out.reset_index(drop=True)
+    return out
 
 
 class _DeviceFrames:
