@@ -161,11 +161,26 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
         no_qhull = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
         # ... and the window calls alone (stage + filter_finish in batches, the per-window Python of iter_device_windows; no table): one thread
         frames_obj = next(iter(resident._frames.values()))
-        tq = time.perf_counter()
-        for _ in range(2):
-            for dw in frames_obj.windows(my_plan, triangulator=tri_cache[0], ctx=ctx):
-                pass
-        calls_only = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
+
+        def calls_only_pass(n_threads):
+            import threading
+
+            ctxs = frames_obj.worker_contexts(n_threads)
+            cut = [len(my_plan) * q // n_threads for q in range(n_threads + 1)]
+
+            def walk(q):
+                for _dw in frames_obj.windows(my_plan[cut[q]:cut[q + 1]], triangulator=tri_cache[0], ctx=ctxs[q]):
+                    pass
+
+            tq_ = time.perf_counter()
+            for _ in range(2):
+                threads = [threading.Thread(target=walk, args=(q,)) for q in range(1, n_threads)]
+                [t.start() for t in threads]
+                walk(0)
+                [t.join() for t in threads]
+            return len(my_plan) * 2 / max(time.perf_counter() - tq_, 1e-9)
+
+        calls_only = {"one_thread": calls_only_pass(1), "worker_threads": n_workers, "with_the_worker_threads": calls_only_pass(n_workers)}
         tri_cache[0] = None
     # what the threads could have used: every worker for the window passes, one thread for the exchange + merge behind them
     thread_seconds = max(pass_seconds[0] * n_workers + (wall_here - pass_seconds[0]), 1e-9)
@@ -240,9 +255,10 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                                                            "in which every window's Delaunay simplices are remembered from an earlier pass, summed over "
                                                            "the ranks -- what the library calls and the Python glue allow once Qhull is out of the picture",
                "window_calls_only_windows_per_s": mine_rec["window_calls_only_windows_per_s"],
-               "window_calls_only_means": "DIAGNOSTIC, rank 0, ONE thread: windows.iter_device_windows over this rank's windows with the triangulations "
+               "window_calls_only_means": "DIAGNOSTIC, rank 0: windows.iter_device_windows over this rank's windows with the triangulations "
                                           "remembered and nothing done with the results -- the two batched library calls per eight windows and the "
-                                          "generator's own Python; the product function adds the table (about 1 MB of gathered columns per window)",
+                                          "generator's own Python, on one thread and on the product function's worker threads (a context = stream "
+                                          "each); the product function adds the table (about 1 MB of gathered columns per window)",
                "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
                "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued per window on rank 0, "
                                                  "counted by the library itself (same_ctx_stat) over the timed passes; the merge's de-duplication included",

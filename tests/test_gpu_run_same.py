@@ -786,6 +786,76 @@ def test_incumbent_table_routes_agree():
             same_amd.sliding_window_incumbent(r_far, far, commonCT=cols, optim_params=dict(op), **kw)
 
 
+def test_resident_frames_serve_several_jobs(gp, tmp_path, monkeypatch):
+    """`resident_frames`: the two frames uploaded and binned once, then jobs with other radii, penalties, window sizes and cost types over
+    them -- each result equals the one-off call's; sliding_window_matching takes the same object; foreign frames are refused."""
+    import same_amd
+    from same_amd import _lib
+
+    monkeypatch.chdir(tmp_path)
+    r_big, m_big, cols = _sw_inputs()
+    jobs = [dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60),
+            dict(radius=14, knn=6, window_size=150, overlap=40, min_cells_per_window=60, no_match_penalty=5.0),
+            dict(radius=20, knn=4, window_size=220, overlap=60, min_cells_per_window=60, hip_cost_dtype="float32")]
+    ctx = _lib.default_context()
+    with same_amd.resident_frames(r_big, m_big) as res:
+        for op in jobs:
+            got = same_amd.sliding_window_incumbent(res, res, commonCT=cols, optim_params=dict(op), window_local_indices=True)
+            want = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), window_local_indices=True)
+            assert len(got) > 300 and got.equals(want), op
+        assert len(res._frames) == 2 and len(res.plans) == 2         # sections per (cost type, window grid); plans per (size, overlap, min cells)
+        before = ctx.stats()
+        again = same_amd.sliding_window_incumbent(res, m_big, commonCT=cols, optim_params=dict(jobs[0]), window_local_indices=True)
+        assert again.equals(same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(jobs[0]), window_local_indices=True))
+        assert len(res._frames) == 2 and ctx.stats()["launches"] > before["launches"]
+        # the reference's signature on the same resident frames
+        g = load_golden("run_same_mock")
+        import run_same_record as rec
+        out = same_amd.sliding_window_matching(res, res, commonCT=cols, optim_params=dict(jobs[0]), gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0))
+        rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", out).items()}, g, prefix="sw/res_")
+        with pytest.raises(ValueError, match="other ref / moving objects"):
+            same_amd.sliding_window_incumbent(res, m_big.copy(), commonCT=cols, optim_params=dict(jobs[0]))
+    assert res._frames == {}
+
+
+def _sharded_incumbent_worker(rank, world, out_dir):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import numpy as np
+    from test_gpu_run_same import _sw_inputs
+    import same_amd
+
+    r_big, m_big, cols = _sw_inputs()
+    part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(radius=20, knn=4, window_size=150, overlap=40,
+                                                                                          min_cells_per_window=60), _shard=(rank, world))
+    part.to_pickle(os.path.join(out_dir, f"part{rank}.pkl"))
+
+
+def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path):
+    """sliding_window_incumbent(_shard=(rank, world)) in three processes on the one GPU: each runs its share of the plan; the parts, put
+    back into plan order by their `__plan_pos`, are the single process's table row for row."""
+    import multiprocessing as mp
+    import same_amd
+
+    world = 3
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_incumbent_worker, args=(rank, world, str(tmp_path))) for rank in range(world)]
+    [p.start() for p in procs]
+    [p.join(600) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    parts = [pd.read_pickle(tmp_path / f"part{rank}.pkl") for rank in range(world)]
+    assert all(len(p) > 50 and "__plan_pos" in p.columns for p in parts)
+    merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
+    r_big, m_big, cols = _sw_inputs()
+    whole = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60))
+    assert merged.equals(whole)
+    _assert_incumbent_equals_golden(whole, load_golden("run_same_mock"), "sw", with_ref_idx=False)
+
+
 def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     """collapse both sections -> run_same on a MetaCell object -> unpack with per-match assignments -> windows over MetaCell
     objects: the reference's own pipeline, run there through the solver double, reproduced array for array."""
