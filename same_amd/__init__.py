@@ -16,7 +16,8 @@ from .triangles import (filter_triangles_by_radius, precompute_triangle_info, pr
 from .sweeps import (LazyOrientationSweep, verify_spatial_preservation, print_violation_report,  # noqa: F401
                      triangle_area_flips)
 from .init_helpers import compute_mip_start_pairs, apply_mip_start  # noqa: F401
-from .api import iter_prepared_windows, prepare_same_inputs, resident_frames, run_same, sliding_window_matching, subset_data  # noqa: F401
+from .api import prepare_same_inputs, run_same  # noqa: F401
+from .window_api import iter_prepared_windows, resident_frames, sliding_window_matching, subset_data  # noqa: F401
 from .incumbent import sliding_window_incumbent  # noqa: F401
 from .windows import window_plan  # noqa: F401
 from .metacell_utils import MetaCell, greedy_triangle_collapse, unpack_metacell_matches  # noqa: F401

@@ -463,7 +463,7 @@ def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exch
 
     import pandas as pd
 
-    from .api import sliding_window_matching
+    from .window_api import sliding_window_matching
 
     own_group = None
     if exchange is None:

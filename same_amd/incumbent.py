@@ -31,7 +31,8 @@ import pandas as pd
 
 from . import ops
 from ._trace import stage
-from .api import _WindowJob, _WindowSubsetter, _prepared_from_device, _stage_prune, _staged_from_device, prepare_same_inputs
+from .api import _stage_prune, prepare_same_inputs
+from .window_api import _WindowJob, _WindowSubsetter, _prepared_from_device, _staged_from_device
 
 STAT_KEYS = ("pairs", "triangles", "checked", "flipped", "xy_violations", "area_flips", "matched")
 

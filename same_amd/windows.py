@@ -481,9 +481,11 @@ def filter_finish_windows(states, simplices, radius, angle_enabled, cos_thr, nea
 
 class DeviceWindowResult:
     """What one window of `iter_device_windows` leaves on the host: `rows_m` section rows of the kept aligned cells, `axy` their XY,
-    `triangles` the kept Delaunay triangles over them (None unless asked for or filtered on the host; `n_triangles` always), `match_row` the section row of each cell's matched reference cell (-1 = none),
-    `point_flag` the XY-order sweep's per-cell flag, `flip_flag` 1 for the vertices of triangles whose signed area flips, `stats` the sweeps' counters, `counts` (aligned in box, refs in box, kept, pairs);
-    `state` is the live DeviceWindow while the result is the newest one yielded (pairs, costs, signs ... through `state.fetch`)."""
+    `triangles` the kept Delaunay triangles over them (None unless asked for or filtered on the host; `n_triangles` always),
+    `match_row` the section row of each cell's matched reference cell (-1 = none), `point_flag` the XY-order sweep's per-cell flag,
+    `flip_flag` 1 for the vertices of triangles whose signed area flips, `stats` the sweeps' counters, `counts` (aligned in box, refs in
+    box, kept, pairs); `state` is the live DeviceWindow until the generator is asked for the first window of the next batch (pairs,
+    costs, signs ... through `state.fetch`)."""
 
     __slots__ = ("window", "error", "rows_m", "axy", "triangles", "n_triangles", "match_row", "point_flag", "flip_flag", "stats", "counts", "state")
 

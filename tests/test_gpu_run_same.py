@@ -678,7 +678,7 @@ def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch, pipeline):
 
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("SAME_WINDOW_PIPELINE", pipeline)
-    assert same_amd.api.window_pipeline() == pipeline
+    assert same_amd.window_api.window_pipeline() == pipeline
     g = load_golden("run_same_mock")
     cells = synth.make_cells(1500, 3, seed=51)
     r_big = synth.to_frame(cells)
