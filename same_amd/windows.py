@@ -387,14 +387,15 @@ class DeviceWindow:
         """-> (aligned rows in the box, reference rows in the box, aligned rows kept, pairs)"""
         return stage_windows([self], moving, ref, [box], radius, knn, dist_ct_coeff)[0]
 
+    # what -> (dtype, which count gives the length: 0 aligned in box, 1 refs in box, 2 kept, 3 pairs, 4 triangles, trailing width)
+    _FETCH = {_W_ALIGNED_XY: (np.float64, 2, 2), _W_ALIGNED_ROWS: (np.int32, 2, 0), _W_ROWS_M: (np.int32, 0, 0), _W_ROWS_R: (np.int32, 1, 0),
+              _W_PAIRS: (np.int32, 3, 2), _W_COSTS: (np.float64, 3, 0), _W_KEPT: (np.int32, 2, 0), _W_SIGNS: (np.int8, 4, 0),
+              _W_WEIGHTS: (np.float64, 4, 0), _W_MATCH: (np.int32, 2, 0), _W_TRIANGLES: (np.int32, 4, 3)}
+
     def fetch(self, what):
-        n_m, n_r, kept, pairs = self.counts
-        dtype, shape = {_W_ALIGNED_XY: (np.float64, (kept, 2)), _W_ALIGNED_ROWS: (np.int32, (kept,)), _W_ROWS_M: (np.int32, (n_m,)),
-                        _W_ROWS_R: (np.int32, (n_r,)), _W_PAIRS: (np.int32, (pairs, 2)), _W_COSTS: (np.float64, (pairs,)),
-                        _W_KEPT: (np.int32, (kept,)), _W_SIGNS: (np.int8, (self.n_triangles,)),
-                        _W_WEIGHTS: (np.float64, (self.n_triangles,)), _W_MATCH: (np.int32, (kept,)),
-                        _W_TRIANGLES: (np.int32, (self.n_triangles, 3))}[what]
-        out = np.empty(shape, dtype)
+        dtype, which, width = self._FETCH[what]
+        n = self.n_triangles if which == 4 else self.counts[which]
+        out = np.empty((n, width) if width else (n,), dtype)
         with self.ctx.lock:
             self.ctx.check(self.ctx.lib.same_window_fetch(self.handle, int(what), out.ctypes.data, out.nbytes), "same_window_fetch")
         return out
