@@ -49,13 +49,6 @@ struct same_ctx {
     int nranks = 1, rank = 0;
     std::vector<same_spread_alloc> spread;
     int64_t stats[SAME_STAT_COUNT] = {};   // what the library itself asked of the runtime on this context (same_ctx_stat)
-    // "lanes": extra streams of the context on which the windows of ONE batch call run side by side (their kernels are 4-20 us each and
-    // leave the chip mostly empty: four windows in flight cost about what one does).  Forked from `stream` and joined back into it by
-    // events inside the call, so to everything else the context stays one ordered stream (csrc/window.hip, LaneScope)
-    static constexpr int LANES = 4;
-    hipStream_t lanes[LANES] = {};
-    hipEvent_t lane_done[LANES] = {};
-    hipEvent_t lane_fork = nullptr;
 };
 
 // every kernel launch / fill / copy / wait of the window path and of the cores it shares goes through these, so that the

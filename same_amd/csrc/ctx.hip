@@ -59,11 +59,6 @@ void same_ctx_destroy(same_ctx *ctx) {
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->ev_gathered) (void)hipEventDestroy(ctx->ev_gathered);
     if (ctx->ev_gather0) (void)hipEventDestroy(ctx->ev_gather0);
-    for (int l = 0; l < same_ctx::LANES; ++l) {
-        if (ctx->lanes[l]) { (void)hipStreamSynchronize(ctx->lanes[l]); (void)hipStreamDestroy(ctx->lanes[l]); }
-        if (ctx->lane_done[l]) (void)hipEventDestroy(ctx->lane_done[l]);
-    }
-    if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -33,7 +33,6 @@
 // the column pipeline bit for bit (tests/test_gpu_run_same.py::test_device_windows_*).
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <shared_mutex>
@@ -1109,63 +1108,6 @@ int collect_stage(same_window *w, const StagePlan &sp, int64_t *out_counts) {
     return SAME_OK;
 }
 
-// The windows of one batch call on the context's lanes (common.h).  begin(): the lanes exist and wait for everything enqueued on the
-// context's stream so far; route(i): window i's enqueues go to lane i % n (the enqueue helpers all use ctx->stream, which is
-// pointed at the lane meanwhile -- a context is used by one caller at a time); join(): the stream waits for every lane that was
-// used, so ONE wait on it covers the batch; sync_all(): the error path.  SAME_WINDOW_LANES=1 keeps everything on the one stream.
-struct LaneScope {
-    same_ctx *ctx = nullptr;
-    hipStream_t main = nullptr;
-    int n = 1;
-    bool used[same_ctx::LANES] = {};
-    static int wanted() {
-        static const int w = [] {
-            const char *v = getenv("SAME_WINDOW_LANES");
-            const int x = v ? atoi(v) : same_ctx::LANES;
-            return x < 1 ? 1 : (x > same_ctx::LANES ? same_ctx::LANES : x);
-        }();
-        return w;
-    }
-    int begin(same_ctx *c, int n_windows) {
-        ctx = c;
-        main = c->stream;
-        n = std::min(wanted(), n_windows);
-        if (n <= 1) { n = 1; return SAME_OK; }
-        if (!c->lane_fork) HIP_TRY(c, hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
-        for (int l = 0; l < n; ++l) {
-            if (!c->lanes[l]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lanes[l], hipStreamNonBlocking));
-            if (!c->lane_done[l]) HIP_TRY(c, hipEventCreateWithFlags(&c->lane_done[l], hipEventDisableTiming));
-        }
-        HIP_TRY(c, hipEventRecord(c->lane_fork, main));
-        for (int l = 0; l < n; ++l) HIP_TRY(c, hipStreamWaitEvent(c->lanes[l], c->lane_fork, 0));
-        return SAME_OK;
-    }
-    void route(int i) {
-        if (n > 1) {
-            ctx->stream = ctx->lanes[i % n];
-            used[i % n] = true;
-        }
-    }
-    int join() {
-        ctx->stream = main;
-        for (int l = 0; l < n && n > 1; ++l)
-            if (used[l]) {
-                HIP_TRY(ctx, hipEventRecord(ctx->lane_done[l], ctx->lanes[l]));
-                HIP_TRY(ctx, hipStreamWaitEvent(main, ctx->lane_done[l], 0));
-            }
-        return SAME_OK;
-    }
-    void sync_all() {
-        ctx->stream = main;
-        for (int l = 0; l < n && n > 1; ++l)
-            if (used[l]) (void)hipStreamSynchronize(ctx->lanes[l]);
-        (void)hipStreamSynchronize(main);
-    }
-    ~LaneScope() {
-        if (ctx) ctx->stream = main;
-    }
-};
-
 // a batch call's windows: one context, no window twice
 int check_batch(same_window *const *windows, int n_windows, same_ctx **out_ctx) {
     if (!windows || n_windows < 1 || !windows[0]) return SAME_EINVAL;
@@ -1200,16 +1142,11 @@ int same_window_stage(same_window *const *windows, int n_windows, const same_sec
     // every window's fill, launches and copy back go into the stream one after the other; ONE wait for the batch -- the device works
     // on window i while the host enqueues window i + 1
     std::vector<StagePlan> plans((size_t)n_windows);
-    LaneScope lanes;
-    SAME_TRY(lanes.begin(ctx, n_windows));
     int rc = SAME_OK;
-    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
-        lanes.route(i);
+    for (int i = 0; i < n_windows && rc == SAME_OK; ++i)
         rc = enqueue_stage(windows[i], mov, ref, boxes + 4 * i, k, dist_ct_coeff, ix, &plans[(size_t)i]);
-    }
-    if (rc == SAME_OK) rc = lanes.join();
     if (rc != SAME_OK) {                          // nothing of a failed batch counts; what was enqueued is waited for before returning
-        lanes.sync_all();
+        (void)hipStreamSynchronize(ctx->stream);
         for (int i = 0; i < n_windows; ++i) windows[i]->staged = 0;
         return rc;
     }
@@ -1468,14 +1405,11 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         bool filtered = false, enqueued = false;
     };
     std::vector<Item> items((size_t)n_windows);
-    // every window's filter + finish + copies go into the context's lanes, window i on lane i % 4; ONE wait for the batch
-    LaneScope lanes;
-    SAME_TRY(lanes.begin(ctx, n_windows));
+    // every window's filter + finish + copies go into the stream back to back; ONE wait for the batch
     int rc = SAME_OK;
     for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
         same_window *w = windows[i];
         Item &it = items[(size_t)i];
-        lanes.route(i);
         const int32_t *tri = simplices + 3 * simplex_offsets[i];
         const int64_t Tr = simplex_offsets[i + 1] - simplex_offsets[i];
         w->filtered = w->finished = 0;
@@ -1497,9 +1431,8 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         if (rc == SAME_OK) rc = enqueue_finish_copy(w, &it.plan);
         it.enqueued = rc == SAME_OK;
     }
-    if (rc == SAME_OK) rc = lanes.join();
     if (rc != SAME_OK) {
-        lanes.sync_all();
+        (void)hipStreamSynchronize(ctx->stream);
         return rc;
     }
     SAME_WAIT(ctx);
