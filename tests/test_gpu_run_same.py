@@ -1343,3 +1343,14 @@ def test_window_calls_stay_within_their_launch_budget():
     per = {k: (after[k] - before[k]) / len(preps) for k in after}
     print("per window (iter_prepared_windows):", per)
     assert len(preps) == len(stats) and per["launches"] <= 30 and per["fills"] <= 4 and per["copies"] <= 12 and per["waits"] <= 8, per
+    # ... and through the reference's own signature, with the incumbent standing in for the solver half of run_same
+    from same_amd.incumbent import incumbent_of_prepared
+
+    before = ctx.stats()
+    out = same_amd.sliding_window_matching(r_df, m_df, commonCT=cols, optim_params=dict(op), _solve=lambda prep, _o: (incumbent_of_prepared(prep, cols)[0], {}))
+    after = ctx.stats()
+    per = {k: (after[k] - before[k]) / len(stats) for k in after}
+    print("per window (sliding_window_matching):", per)
+    assert out["window_id"].nunique() == len(stats) and len(out) == len(res)
+    assert per["launches"] <= 30 and per["fills"] <= 4 and per["copies"] <= 12 and per["waits"] <= 8, per
+    assert np.array_equal(out["Aligned_Cell_Num_Old"].to_numpy(), res["Aligned_Cell_Num_Old"].to_numpy()) and np.array_equal(out["Ref_Cell_Num_Old"].to_numpy(), res["Ref_Cell_Num_Old"].to_numpy())
