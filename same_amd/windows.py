@@ -11,11 +11,16 @@ from . import ops
 
 
 def window_grid(ref_xy, mov_xy, window_size, overlap):
-    """src/same.py:481-488."""
-    x_min = min(ref_xy[:, 0].min(), mov_xy[:, 0].min())
-    x_max = max(ref_xy[:, 0].max(), mov_xy[:, 0].max())
-    y_min = min(ref_xy[:, 1].min(), mov_xy[:, 1].min())
-    y_max = max(ref_xy[:, 1].max(), mov_xy[:, 1].max())
+    """src/same.py:481-488.  The reference takes the extent with pandas' min / max, which skip NaN (rows without coordinates are in no
+    window; they do not stop the job): nanmin / nanmax here.  Infinite coordinates reach int() as they do there (OverflowError)."""
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)          # an all-NaN column: NaN, and int(NaN) raises as in the reference
+        x_min = min(np.nanmin(ref_xy[:, 0]), np.nanmin(mov_xy[:, 0]))
+        x_max = max(np.nanmax(ref_xy[:, 0]), np.nanmax(mov_xy[:, 0]))
+        y_min = min(np.nanmin(ref_xy[:, 1]), np.nanmin(mov_xy[:, 1]))
+        y_max = max(np.nanmax(ref_xy[:, 1]), np.nanmax(mov_xy[:, 1]))
     step = window_size - overlap
     xs = list(range(int(x_min), int(x_max), step))
     ys = list(range(int(y_min), int(y_max), step))

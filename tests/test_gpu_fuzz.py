@@ -370,3 +370,99 @@ def test_scans_hold_when_no_block_ever_sees_a_predecessor():
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
     assert " passed" in res.stdout
+
+
+def _assert_prepared_equal(a, b, what):
+    assert type(a) is type(b) or (isinstance(a, Exception) and isinstance(b, Exception)), what
+    if isinstance(a, Exception):
+        assert str(a) == str(b), what
+        return 0
+    assert np.array_equal(np.asarray(a.valid_pairs, dtype=np.int64).reshape(-1, 2), np.asarray(b.valid_pairs, dtype=np.int64).reshape(-1, 2)), what
+    assert np.array_equal(a.costs_array, b.costs_array) and a.costs_array.dtype == b.costs_array.dtype, what
+    assert np.array_equal(a.triangles_array, b.triangles_array), what
+    assert np.array_equal(a.signs_array, b.signs_array) and a.weights_array.dtype == b.weights_array.dtype and np.array_equal(a.weights_array, b.weights_array), what
+    assert (a.n_aligned, a.n_ref) == (b.n_aligned, b.n_ref) == (len(a.aligned_df), len(a.ref_df)), what
+    for fa, fb in ((a.aligned_df, b.aligned_df), (a.ref_df, b.ref_df)):
+        assert list(fa.columns) == list(fb.columns) and fa.equals(fb), what
+    return 1
+
+
+def test_fuzz_window_pipelines_agree():
+    """The two pipelines behind sliding_window_matching -- frames resident on the device vs frames cut on the host -- on random small
+    jobs the fixed tests do not visit: rows with NaN / infinite coordinates, duplicate points and lattices, string or shuffled index
+    labels, integer-typed type columns and sizes, missing `size`, k larger than a window's references, radii from too small for any pair
+    to window-sized, no angle rule, same-type triangles kept, the priority filter, fp32 costs, window sizes whose grid the boxes cut
+    through.  Every window's PreparedInputs (pairs, costs, triangles, weights, signs, BOTH frames) must be equal, errors included, and so
+    must the solver-free tables of all three routes."""
+    import pandas as pd
+
+    import same_amd
+    from same_amd.windows import window_plan
+
+    done = errors = 0
+    for rnd in range(ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"window pipelines soak round {rnd}", flush=True)
+        rng = np.random.default_rng(31337 + 104729 * rnd)
+        for case in range(14):
+            n_r, n_m, T = int(rng.integers(150, 1400)), int(rng.integers(150, 1400)), int(rng.integers(1, 7))
+            side = float(rng.choice([120.0, 400.0]))
+            frames = []
+            for n in (n_r, n_m):
+                xy = _points(rng, n, side, int(rng.choice([0, 0, 0, 1, 2])))
+                df = pd.DataFrame(rng.gamma(0.3, 30.0, (n, T)), columns=[f"t{q}" for q in range(T)])
+                if case % 5 == 1:
+                    df["t0"] = (df["t0"] * 3).astype(np.int64)            # an integer-typed type column
+                df.insert(0, "Y", xy[:, 1])
+                df.insert(0, "X", xy[:, 0])
+                df["cell_type"] = rng.choice(np.array(["a", "b", "c"], dtype=object), n)
+                if case % 3:
+                    df["size"] = rng.integers(1, 4, n) if case % 2 else rng.integers(1, 4, n) * 1.5
+                df["Cell_Num_Old"] = rng.permutation(n) + 10
+                if case % 4 == 2:
+                    df.loc[df.index[rng.integers(0, n, 5)], "X"] = np.nan       # rows no window holds (pandas' min / max skip them: src/same.py:481-482)
+                if case == 13:
+                    df.loc[df.index[rng.integers(0, n, 2)], "Y"] = np.inf       # int(inf): the reference's OverflowError
+                if case % 6 == 3:
+                    df.index = [f"cell{q}" for q in rng.permutation(n)]
+                elif case % 6 == 4:
+                    df.index = rng.permutation(n) * 2
+                frames.append(df)
+            ref, mov = frames
+            cols = [f"t{q}" for q in range(T)]
+            ws = int(rng.choice([60, 90, 150, 400]))
+            op = dict(radius=float(rng.choice([0.5, 6.0, 15.0, 40.0])), knn=int(rng.choice([1, 3, 8, 40])), window_size=ws, overlap=int(rng.choice([0, ws // 4, ws // 3])),
+                      min_cells_per_window=int(rng.choice([5, 30])), dist_ct_coeff=float(rng.choice([1.0, 0.4])), min_angle_deg=[15, None, 30][case % 3],
+                      ignore_same_type_triangles=bool(case % 4), hip_cost_dtype="float32" if case % 3 == 0 else "float64",
+                      no_match_penalty=float(rng.choice([100.0, 2.0])), ignore_knn_if_matched=(case % 7 == 5))
+            try:
+                plan = window_plan(ref[["X", "Y"]].to_numpy(dtype=np.float64), mov[["X", "Y"]].to_numpy(dtype=np.float64), ws, op["overlap"], op["min_cells_per_window"])
+            except OverflowError:        # an infinite extent: int(inf) in the reference's grid (src/same.py:481-488) -- both pipelines raise before any window
+                for pipe in ("device", "frames"):
+                    with pytest.raises(OverflowError):
+                        same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), _pipeline=pipe)
+                errors += 1
+                continue
+            if not plan:
+                continue
+            a = list(same_amd.iter_prepared_windows(ref, mov, cols, plan, optim_params=dict(op), pipeline="device"))
+            b = list(same_amd.iter_prepared_windows(ref, mov, cols, plan, optim_params=dict(op), pipeline="frames"))
+            assert len(a) == len(b) == len(plan)
+            ok = [_assert_prepared_equal(pa, pb, (rnd, case, w["window_id"])) for (w, pa), (_w, pb) in zip(a, b)]
+            tables = []
+            for kw in (dict(_pipeline="device"), dict(_route="general", _pipeline="device"), dict(_route="general", _pipeline="frames")):
+                try:
+                    tables.append(same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), window_local_indices=True, **kw))
+                except ValueError as e:
+                    tables.append(str(e))
+            if sum(ok) < len(ok):                           # a window without pairs: every route raises run_same's error
+                assert all(isinstance(t, str) and t == tables[0] and "No valid_pairs" in t for t in tables), (rnd, case)
+                errors += 1
+            else:
+                assert all(isinstance(t, pd.DataFrame) for t in tables), (rnd, case, tables)
+                for t in tables[1:]:
+                    assert list(t.columns) == list(tables[0].columns) and len(t) == len(tables[0]), (rnd, case)
+                    for c in t.columns:
+                        assert np.array_equal(t[c].to_numpy(), tables[0][c].to_numpy()), (rnd, case, c)
+                done += 1
+    assert done >= 6 * ROUNDS and errors >= 1, (done, errors)
