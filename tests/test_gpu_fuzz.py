@@ -445,8 +445,19 @@ def test_fuzz_window_pipelines_agree():
                 continue
             if not plan:
                 continue
+            from scipy.spatial import QhullError
+
+            try:
+                b = list(same_amd.iter_prepared_windows(ref, mov, cols, plan, optim_params=dict(op), pipeline="frames"))
+            except QhullError:           # a window whose kept cells Qhull cannot triangulate (too few / collinear): run_same dies there, on either pipeline
+                with pytest.raises(QhullError):
+                    list(same_amd.iter_prepared_windows(ref, mov, cols, plan, optim_params=dict(op), pipeline="device"))
+                for pipe in ("device", "frames"):
+                    with pytest.raises((QhullError, ValueError)):
+                        same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), _pipeline=pipe)
+                errors += 1
+                continue
             a = list(same_amd.iter_prepared_windows(ref, mov, cols, plan, optim_params=dict(op), pipeline="device"))
-            b = list(same_amd.iter_prepared_windows(ref, mov, cols, plan, optim_params=dict(op), pipeline="frames"))
             assert len(a) == len(b) == len(plan)
             ok = [_assert_prepared_equal(pa, pb, (rnd, case, w["window_id"])) for (w, pa), (_w, pb) in zip(a, b)]
             tables = []
