@@ -32,7 +32,7 @@ import pandas as pd
 from . import ops
 from ._trace import stage
 from .api import _stage_prune, prepare_same_inputs
-from .window_api import _WindowJob, _WindowSubsetter, _prepared_from_device, _staged_from_device
+from .window_api import _WindowJob, _WindowSubsetter, _prepared_from_device, _staged_from_device, _window_error
 
 STAT_KEYS = ("pairs", "triangles", "checked", "flipped", "xy_violations", "area_flips", "matched")
 
@@ -286,7 +286,7 @@ def _general_route(job, frames, with_ref_idx, stats, ctx):
             plan = [w for _pos, w in job.todo]
             for (pos, w), dw in zip(job.todo, frames.windows(plan, triangulate=not job.caller_triangulation, ctx=ctx, fetch_triangles=True)):
                 if dw.error is not None:
-                    raise dw.error
+                    raise _window_error(dw, op)
                 if job.caller_triangulation:
                     st = _staged_from_device(dw, frames, commonCT, op, gp, job.moving_delaunay, job.vertex_col, verbose=False)
                     yield pos, w, prepare_same_inputs(None, None, commonCT, verbose=False, ctx=ctx, _staged=st)

@@ -156,6 +156,14 @@ class _DeviceFrames:
         self.dref = self.dmov = None
 
 
+def _window_error(dw, optim_params):
+    """What the reference raises for a window whose prune finds no pair: run_same's ValueError (src/same.py:1003) -- unless the
+    cell-type-priority prune is on, whose summary print divides by the number of rows that kept a pair first (src/knn_utils.py:76)."""
+    if optim_params["ignore_knn_if_matched"] and isinstance(dw.error, ValueError) and str(dw.error).startswith("No valid_pairs after KNN filtering"):
+        return ZeroDivisionError("division by zero")
+    return dw.error
+
+
 def _device_pairs(dw):
     """The window's pair list with the reference side compacted the way src/utils.py:734-742 compacts it (np.unique of the used
     reference rows): -> (valid_pairs (P, 2) int64, section rows of the compacted reference cells).  The device keeps reference cells
@@ -424,7 +432,13 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
         frames = _DeviceFrames(ref, moving, commonCT, op, None, ctx=ctx)
         try:
             for w, dw in zip(plan, frames.windows(plan, ctx=ctx)):
-                yield (w, dw.error) if dw.error is not None else (w, _prepared_from_device(dw, frames, op, gp, verbose=verbose))
+                if dw.error is not None:
+                    err = _window_error(dw, op)
+                    if not isinstance(err, ValueError):      # only run_same's own ValueError is a window's answer; anything else ends the walk
+                        raise err
+                    yield w, err
+                else:
+                    yield w, _prepared_from_device(dw, frames, op, gp, verbose=verbose)
         finally:
             frames.close()
         return
@@ -504,7 +518,7 @@ def _solver_windows_on_device(job, frames, run_window, solve=None):
     for (pos, w), dw in zip(job.todo, frames.windows(plan, triangulate=not job.caller_triangulation)):
         staged = prepared = None
         if dw.error is not None:
-            prepared = dw.error                                      # raised by the run_same body, where the reference raises it
+            prepared = _window_error(dw, op)                         # raised by the run_same body, where the reference raises it
         elif job.caller_triangulation:
             staged = _staged_from_device(dw, frames, commonCT, op, gp, job.moving_delaunay, job.vertex_col, verbose=solve is None)
         else:
