@@ -505,9 +505,13 @@ def eager_signs(rxy, triangles, cand):
 
 # --------------------------------------------------------------------------- a13
 def window_grid(ref_xy, mov_xy, window_size, overlap):
-    """src/same.py:481-488."""
-    x_min = min(ref_xy[:, 0].min(), mov_xy[:, 0].min()); x_max = max(ref_xy[:, 0].max(), mov_xy[:, 0].max())
-    y_min = min(ref_xy[:, 1].min(), mov_xy[:, 1].min()); y_max = max(ref_xy[:, 1].max(), mov_xy[:, 1].max())
+    """src/same.py:481-488.  The reference takes min / max of pandas columns, which skip NaN: nanmin / nanmax on the arrays here."""
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            x_min = min(np.nanmin(ref_xy[:, 0]), np.nanmin(mov_xy[:, 0])); x_max = max(np.nanmax(ref_xy[:, 0]), np.nanmax(mov_xy[:, 0]))
+            y_min = min(np.nanmin(ref_xy[:, 1]), np.nanmin(mov_xy[:, 1])); y_max = max(np.nanmax(ref_xy[:, 1]), np.nanmax(mov_xy[:, 1]))
     step = window_size - overlap
     return (list(range(int(x_min), int(x_max), step)), list(range(int(y_min), int(y_max), step)),
             (x_min, x_max, y_min, y_max))

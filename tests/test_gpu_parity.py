@@ -407,6 +407,16 @@ def test_window_plan_vs_oracle(hip, oracle):
                 assert p[key] == o[key], (ws, ov, mc, key)
         merged += sum((p["i"], p["j"]) != (p["i0"], p["j0"]) for p in plan)
     assert merged > 0  # the merge-right / merge-down branches were exercised
+    # rows without coordinates: the reference's extent skips them (pandas min / max, src/same.py:481-482) and no window holds them
+    # (tests/test_oracle_vs_reference_fuzz.py runs the reference's own loop on such layouts against the oracle)
+    rng = np.random.default_rng(8)
+    rn, mn = rxy.copy(), mov["xy"].copy()
+    rn[rng.integers(0, len(rn), 9), 0] = np.nan
+    mn[rng.integers(0, len(mn), 6), 1] = np.nan
+    plan, oplan = hip.window_plan(rn, mn, 300, 100, 450), oracle.window_plan(rn, mn, 300, 100, 450)
+    assert len(plan) == len(oplan) > 0 and all(p[key] == o[key] for p, o in zip(plan, oplan) for key in ("window_id", "box", "trim", "n_ref", "n_mov"))
+    with pytest.raises(OverflowError):
+        hip.window_plan(np.vstack([rxy, [[np.inf, 0.0]]]), mov["xy"], 300, 100, 450)
 
 
 # ------------------------------------------------------------------------------------------ end to end (pre-MIP)
