@@ -189,3 +189,59 @@ def test_window_loop_with_rows_that_have_no_coordinates(ref, oracle):
     finally:
         ref.same.run_same = saved
     assert windows > 60
+
+
+def test_inline_loops_of_run_same(ref, oracle):
+    """run_same's inline pre-MIP and sweep loops (src/same.py:1180-1189 pair costs on object-dtype rows, :1128-1146 weights and source
+    signs, :634-669 the lazy-constraint body, :1362-1402 signed-area flips) cannot be imported; tools/gen_golden.py drives them in the
+    expression order of the cited lines on the reference's own frames (and calls helpers.calculate_signed_area as-is).  The oracle against
+    those drivers on random inputs: type columns with exact zeros, integer and float sizes, collinear triples (sign 0), partial matchings,
+    several pairs above 0.5 for one aligned row (the last one wins)."""
+    from scipy.spatial import Delaunay
+
+    import gen_golden as gg          # tools/ (on sys.path through the `ref` fixture): loads the reference the same way
+
+    rng = np.random.default_rng(505)
+    flips = checked_total = 0
+    for case in range(25):
+        T = int(rng.integers(1, 6))
+        a, r = _cells(rng, int(rng.integers(5, 60)), 40.0, T=T), _cells(rng, int(rng.integers(5, 60)), 40.0, T=T)
+        cols = [f"t{q}" for q in range(T)]
+        for df in (a, r):
+            df[cols] = df[cols].where(rng.random((len(df), T)) > 0.2, 0.0)          # proportions with exact zeros
+        if case % 3 == 0:
+            a["size"] = a["size"] * 1.5
+        if case % 4 == 0:
+            a.loc[a.index[:3], ["X", "Y"]] = [[1.0, 1.0], [2.0, 2.0], [3.0, 3.0]]    # a collinear triple
+        pairs = [(int(i), int(j)) for i in range(len(a)) for j in rng.choice(len(r), int(rng.integers(0, 4)), replace=False)]
+        if not pairs:
+            continue
+        w = float(rng.choice([1.0, 0.37, 2.5]))
+        want_c = gg.ref_pair_costs(a, r, pairs, cols, w)
+        got_c = np.asarray(oracle.pair_costs(a, r, pairs, cols, w), dtype=np.float64)
+        assert np.array_equal(want_c, got_c), case
+        tris = Delaunay(a[["X", "Y"]].to_numpy() + rng.normal(0, 1e-9, (len(a), 2))).simplices        # (jitter only for Qhull: the frames keep the collinear triple)
+        if case % 4 == 0:
+            tris = np.vstack([tris, [[0, 1, 2]]])
+        want_w, want_s = gg.ref_weights_signs(a, tris)
+        assert np.array_equal(np.asarray(oracle.triangle_weights(a, tris), dtype=np.float64), want_w), case
+        got_s = np.asarray(oracle.source_signs(a, tris), dtype=np.float64)
+        assert np.array_equal(got_s, want_s), case
+        x = (rng.random(len(pairs)) < 0.6).astype(float) * rng.choice([0.51, 1.0, 0.99], len(pairs))
+        want_checked, want_viol = gg.ref_lazy_sweep(x, pairs, tris, want_s, r)
+        got_checked, got_viol = oracle.lazy_orientation_sweep(x, pairs, tris, got_s, r[["X", "Y"]].to_numpy(), len(a))
+        assert int(got_checked) == int(want_checked) and [int(v[0]) if np.ndim(v) else int(v) for v in got_viol] == want_viol.tolist(), case
+        a2r = {}
+        for idx, (i, j) in enumerate(pairs):
+            if x[idx] > 0.5:
+                a2r[i] = j
+        wb, wa, wf, wm3 = gg.ref_area_flips(a, r, tris, a2r)
+        match = np.full(len(a), -1, np.int32)
+        for i, j in a2r.items():
+            match[i] = j
+        gb, ga, gm3, gf = oracle.area_flip(a[["X", "Y"]].to_numpy(), r[["X", "Y"]].to_numpy(), np.asarray(tris, dtype=np.int32), match)
+        assert np.array_equal(gb, wb) and np.array_equal(ga, wa, equal_nan=True) and np.array_equal(np.flatnonzero(gf), wf), case
+        assert np.array_equal(np.asarray(gm3, dtype=np.uint8).reshape(-1, 3), wm3.reshape(-1, 3)), case
+        flips += len(wf)
+        checked_total += int(want_checked)
+    assert checked_total > 100 and flips > 10
