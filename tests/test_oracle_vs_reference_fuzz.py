@@ -245,3 +245,26 @@ def test_inline_loops_of_run_same(ref, oracle):
         flips += len(wf)
         checked_total += int(want_checked)
     assert checked_total > 100 and flips > 10
+
+
+def test_metacell_collapse(ref, oracle):
+    """metacell_utils.greedy_triangle_collapse (src/metacell_utils.py:160-561) on random small sections: size limits 1 .. 9, r_max / angle
+    rules on and off, an extra text column carried along."""
+    rng = np.random.default_rng(606)
+    collapsed = 0
+    for case in range(14):
+        df = _cells(rng, int(rng.integers(6, 140)), float(rng.choice([30.0, 60.0])), T=2, with_size=False)
+        df["batch"] = np.where(np.arange(len(df)) % 3 == 0, "b0", "b1")
+        kw = dict(max_metacell_size=int(rng.choice([1, 3, 4, 9])), r_max=[None, 8.0, 25.0][case % 3], min_angle_deg=[10, None, 25][case % 3])
+        want = quiet(ref.metacell_utils.greedy_triangle_collapse, df, use_alpha_shape=False, return_object=True, **kw)
+        gdf, gtri, gorig = oracle.greedy_triangle_collapse(df, **kw)
+        wdf = want.metacell_df
+        assert list(wdf.columns) == list(gdf.columns) and len(wdf) == len(gdf), case
+        assert [list(map(int, m)) for m in wdf["members"]] == [list(map(int, m)) for m in gdf["members"]], case
+        for c in wdf.columns:
+            if c != "members":
+                assert np.array_equal(wdf[c].to_numpy(), gdf[c].to_numpy()), (case, c)
+        assert np.array_equal(np.asarray(want.metacell_delaunay, dtype=np.int64).reshape(-1, 3), np.asarray(gtri, dtype=np.int64).reshape(-1, 3)), case
+        assert np.array_equal(np.asarray(want.original_delaunay, dtype=np.int64).reshape(-1, 3), np.asarray(gorig, dtype=np.int64).reshape(-1, 3)), case
+        collapsed += len(df) - len(wdf)
+    assert collapsed > 100
