@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsame_hip.so")
+LIB_PATH = os.environ.get("SAME_HIP_LIB") or os.path.join(_HERE, "libsame_hip.so")   # SAME_HIP_LIB: a measurement hook (an A/B build of the library)
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
