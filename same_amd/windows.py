@@ -570,7 +570,10 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     depth = qhull_pool.lookahead()
     qhull_pool.warm(min(depth, len(plan)))
     B = max(1, min(int(batch if batch is not None else os.environ.get("SAME_WINDOW_BATCH", "8")), WINDOW_BATCH_MAX, max(len(plan), 1)))
-    ahead_max = max(depth, B)                 # windows staged and not yet finished: about one per helper
+    # windows staged and not yet finished: one per helper BEYOND the batch being finished (a batch's tickets are collected together, and
+    # nothing is handed over meanwhile: with only `depth` in flight, 12 helpers and batches of 8 ran 8 of 12 helpers -- 264 against 431
+    # windows/s for one thread of a rank that shares its host with another)
+    ahead_max = depth + B
     # window states (their device buffers, grown once) are kept with the context from one call to the next: a pass over a plan
     # then makes no device allocation at all.  In use at once: the windows ahead + the batch being staged + the batch last yielded
     cache = ctx.__dict__.setdefault("_device_windows", [])
