@@ -573,7 +573,7 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     # windows staged and not yet finished: one per helper BEYOND the batch being finished (a batch's tickets are collected together, and
     # nothing is handed over meanwhile: with only `depth` in flight, 12 helpers and batches of 8 ran 8 of 12 helpers -- 264 against 431
     # windows/s for one thread of a rank that shares its host with another)
-    ahead_max = depth + B
+    ahead_max = max(B, depth + int(os.environ.get("SAME_WINDOW_AHEAD", str(B))))
     # window states (their device buffers, grown once) are kept with the context from one call to the next: a pass over a plan
     # then makes no device allocation at all.  In use at once: the windows ahead + the batch being staged + the batch last yielded
     cache = ctx.__dict__.setdefault("_device_windows", [])
