@@ -570,6 +570,8 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     depth = qhull_pool.lookahead()
     qhull_pool.warm(min(depth, len(plan)))
     B = max(1, min(int(batch if batch is not None else os.environ.get("SAME_WINDOW_BATCH", "8")), WINDOW_BATCH_MAX, max(len(plan), 1)))
+    if batch is None and depth > 0:
+        B = min(B, max(2, depth))             # a rank with three helpers (eight ranks on a 16-CPU host) gains nothing from collecting eight tickets at once
     # windows staged and not yet finished: one per helper BEYOND the batch being finished (a batch's tickets are collected together, and
     # nothing is handed over meanwhile: with only `depth` in flight, 12 helpers and batches of 8 ran 8 of 12 helpers -- 264 against 431
     # windows/s for one thread of a rank that shares its host with another)
