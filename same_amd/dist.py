@@ -449,6 +449,15 @@ def allgather_table(ctx, comm, group, table):
 
 
 # ---- sliding windows over ranks -------------------------------------------------------------------------
+def sharded_sliding_window_incumbent(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, **kwargs):
+    """`sliding_window_incumbent` (same_amd/incumbent.py: the window loop with the greedy MIP start as every window's solution) on N
+    GPUs, the way `sharded_sliding_window_matching` shards the solver loop: every rank runs its share of the plan on its own GPU, the
+    tables are exchanged once over the host channel, every rank returns the single-process table."""
+    from .incumbent import sliding_window_incumbent
+
+    return _sharded_windows(sliding_window_incumbent, ref, moving, commonCT, group, exchange, rank, world, kwargs)
+
+
 def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, **kwargs):
     """BASELINE cfg 5 on N GPUs: windows are independent, so every rank (one process per GPU) runs its round-robin share of
     the window plan -- heaviest windows first, `windows.assign_windows` -- and the per-window match tables are exchanged once
@@ -459,11 +468,15 @@ def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exch
     launcher can supply its own `exchange(obj) -> [obj of rank 0, ..., obj of rank world-1]` together with `rank` and
     `world` (MPI, files, a queue).  `outprefix`, if given, gets a per-rank subdirectory (`rank{r}`) so ranks never write
     the same CSV."""
+    from .window_api import sliding_window_matching
+
+    return _sharded_windows(sliding_window_matching, ref, moving, commonCT, group, exchange, rank, world, kwargs)
+
+
+def _sharded_windows(run, ref, moving, commonCT, group, exchange, rank, world, kwargs):
     import os
 
     import pandas as pd
-
-    from .window_api import sliding_window_matching
 
     own_group = None
     if exchange is None:
@@ -475,7 +488,7 @@ def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exch
     try:
         if kwargs.get("outprefix"):
             kwargs["outprefix"] = os.path.join(kwargs["outprefix"], f"rank{rank}")
-        part = sliding_window_matching(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world)), **kwargs)
+        part = run(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world)), **kwargs)
         parts = [p for p in exchange(part) if p is not None and len(p)]
     finally:
         if own_group is not None:

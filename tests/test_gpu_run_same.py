@@ -825,34 +825,42 @@ def _sharded_incumbent_worker(rank, world, out_dir):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
-    import numpy as np
     from test_gpu_run_same import _sw_inputs
     import same_amd
+    from same_amd.dist import sharded_sliding_window_incumbent
 
     r_big, m_big, cols = _sw_inputs()
-    part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(radius=20, knn=4, window_size=150, overlap=40,
-                                                                                          min_cells_per_window=60), _shard=(rank, world))
+    op = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
+    if world == 2:     # the package's own wrapper over its plain-Python host group (RANK / WORLD_SIZE / SAME_RDV_DIR): every rank gets the whole table
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
+        part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op))
+    else:              # the share of one rank, as a launcher with its own exchange would take it
+        part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), _shard=(rank, world))
     part.to_pickle(os.path.join(out_dir, f"part{rank}.pkl"))
 
 
-def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path):
-    """sliding_window_incumbent(_shard=(rank, world)) in three processes on the one GPU: each runs its share of the plan; the parts, put
-    back into plan order by their `__plan_pos`, are the single process's table row for row."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world):
+    """sliding_window_incumbent over several processes on the one GPU, each running its share of the plan: through
+    dist.sharded_sliding_window_incumbent (world 2: every rank ends with the whole table) and through `_shard=(rank, world)` by hand
+    (world 3: the parts, put back into plan order by their `__plan_pos`) -- the single process's table row for row."""
     import multiprocessing as mp
     import same_amd
 
-    world = 3
     ctx = mp.get_context("spawn")
     procs = [ctx.Process(target=_sharded_incumbent_worker, args=(rank, world, str(tmp_path))) for rank in range(world)]
     [p.start() for p in procs]
     [p.join(600) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     parts = [pd.read_pickle(tmp_path / f"part{rank}.pkl") for rank in range(world)]
-    assert all(len(p) > 50 and "__plan_pos" in p.columns for p in parts)
-    merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
     r_big, m_big, cols = _sw_inputs()
     whole = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60))
-    assert merged.equals(whole)
+    if world == 2:
+        assert all(p.equals(whole) for p in parts)
+    else:
+        assert all(len(p) > 50 and "__plan_pos" in p.columns for p in parts)
+        merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
+        assert merged.equals(whole)
     _assert_incumbent_equals_golden(whole, load_golden("run_same_mock"), "sw", with_ref_idx=False)
 
 
