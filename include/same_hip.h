@@ -458,10 +458,10 @@ enum {
     SAME_WINDOW_PAIRS = 4,        /* int32[pairs][2]: (kept aligned index, reference index in the window)         */
     SAME_WINDOW_COSTS = 5,        /* double[pairs] (float costs widened)                                           */
     SAME_WINDOW_KEPT = 6,         /* int32[kept]: index of each kept aligned cell among the box's aligned rows     */
-    SAME_WINDOW_SIGNS = 7,        /* int8[triangles]   (after same_window_finish)                                  */
-    SAME_WINDOW_WEIGHTS = 8,      /* double[triangles] (after same_window_finish)                                  */
+    SAME_WINDOW_SIGNS = 7,        /* int8[triangles]   (after same_window_filter_finish)                            */
+    SAME_WINDOW_WEIGHTS = 8,      /* double[triangles] (after same_window_filter_finish)                            */
     SAME_WINDOW_MATCH = 9,        /* int32[kept]: matched reference index in the window or -1 (after finish)       */
-    SAME_WINDOW_TRIANGLES = 10    /* int32[triangles][3]: the kept triangles (after same_window_filter / finish)   */
+    SAME_WINDOW_TRIANGLES = 10    /* int32[triangles][3]: the kept triangles (after ..._filter_finish)           */
 };
 int same_section_create(same_ctx *ctx, const double *xy, const double *types, int T, const double *size,
                         const int32_t *type_id /* may be NULL */, int64_t n, int cost_f32, same_section **out);
