@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, the visit at the round's last tree: GPU suite, smoke, the default line, the cfg 5 line, then the rocprofv3 passes of tools/gpu_profile.sh.
+# Outputs under gpurun_out/<tag>/ ; the summaries that are judged are copied to profiles/r05_* afterwards.
+set -o pipefail
+tag=${1:-r05_final}
+out=gpurun_out/$tag; mkdir -p $out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "== pytest -m gpu" && timeout -k 10 1000 python3 -m pytest tests -m gpu -q --durations=12 > $out/pytest_gpu.log 2>&1; rc=$?; tail -4 $out/pytest_gpu.log; [ $rc -eq 0 ] || exit $rc
+echo "== smoke" && timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
+echo "== bench (default)" && timeout -k 10 600 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || { tail -20 $out/bench_default.err; exit 1; }
+echo "== bench (cfg5)" && timeout -k 10 400 python3 bench.py --workload cfg5 --steps 5 --warmup 1 > $out/bench_cfg5.json 2> $out/bench_cfg5.err || { tail -20 $out/bench_cfg5.err; exit 1; }
+python3 tools/cfg5_lines.py $out/bench_cfg5.json
+bash tools/gpu_profile.sh $tag/prof | tail -16
