@@ -341,6 +341,15 @@ def test_device_window_argument_checks(ops):
         kept_tris = s_.fetch(W._W_TRIANGLES)
         again = s_.finish(kept_tris, 1.0)               # the kept triangles handed back as the caller's own: the same match and sweeps
         assert np.array_equal(again[0], one[3]) and np.array_equal(again[1], one[4]) and again[2] == one[5]
+    # a batch in which ONE window is refused is refused as a whole, before anything is enqueued; the windows stay usable
+    bad_tri = [tri[0], np.array([[0, 1, 10 ** 6]], np.int32)]
+    with pytest.raises(SameHipError):
+        W.filter_finish_windows([st, st2], bad_tri, 10.0, 1, 0.9, 0.0, True, 1.0)
+    with pytest.raises(SameHipError):
+        W.stage_windows([st, st2], da, db, [box, half], 10.0, 4, 1.0)          # sections that do not belong together
+    assert W.stage_windows([st, st2], da, da, [box, half], 10.0, 4, 1.0)[0] == (n_m, n_r, kept, n_pairs)
+    redo = W.filter_finish_windows([st, st2], tri, 10.0, 1, 0.9, 0.0, True, 1.0)
+    assert all(np.array_equal(a_[3], b_[3]) and a_[5] == b_[5] for a_, b_ in zip(redo, both))
     st2.close()
     st3.close()
     other.close()
