@@ -33,6 +33,7 @@
 // the column pipeline bit for bit (tests/test_gpu_run_same.py::test_device_windows_*).
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <shared_mutex>
@@ -639,7 +640,9 @@ struct same_section {
     // prune indices of this section as the REFERENCE side, one per radius used (built on first use, under the lock: sections are
     // shared by the worker threads' contexts)
     std::mutex lock;
-    std::vector<std::pair<double, same_knn_index *>> knn;   // most recently used first; at most MAX_KNN_INDICES (the oldest is dropped)
+    // most recently used first; at most MAX_KNN_INDICES (the oldest is dropped).  Shared: a stage call holds the index it prunes with
+    // until its kernels have finished, so an index dropped from the table meanwhile is freed by its last user
+    std::vector<std::pair<double, std::shared_ptr<same_knn_index>>> knn;
     // grid, order, starts, h_starts: read (shared) by every stage call from cover_of() until its kernels are enqueued, replaced
     // (exclusive, after a device-wide wait: kernels enqueued earlier may still be reading the old arrays) by same_section_bin
     std::shared_mutex grid_lock;
@@ -684,28 +687,31 @@ int ensure_host(same_window *w, size_t bytes) {
     return SAME_OK;
 }
 
-// the prune index of `ref` for this radius (built once, with the caller's context)
-int knn_index_for(same_ctx *ctx, const same_section *ref, double radius, const same_knn_index **out) {
+// the prune index of `ref` for this radius (built once, with the caller's context); the caller keeps *out until its kernels are done
+int knn_index_for(same_ctx *ctx, const same_section *ref, double radius, std::shared_ptr<same_knn_index> *out) {
     same_section *s = const_cast<same_section *>(ref);
-    std::lock_guard<std::mutex> hold(s->lock);
-    for (size_t q = 0; q < s->knn.size(); ++q)
-        if (s->knn[q].first == radius) {
-            if (q) std::rotate(s->knn.begin(), s->knn.begin() + q, s->knn.begin() + q + 1);     // most recently used first
-            *out = s->knn.front().second;
-            return SAME_OK;
+    std::shared_ptr<same_knn_index> dropped;      // freed after the lock is let go (hipFree waits for the device)
+    {
+        std::lock_guard<std::mutex> hold(s->lock);
+        for (size_t q = 0; q < s->knn.size(); ++q)
+            if (s->knn[q].first == radius) {
+                if (q) std::rotate(s->knn.begin(), s->knn.begin() + q, s->knn.begin() + q + 1);     // most recently used first
+                *out = s->knn.front().second;
+                return SAME_OK;
+            }
+        // one index per radius a section is pruned with: a handful in a run, a stream of them in a parameter search over one long-lived
+        // section -- the least recently used one goes when the table is full (each holds a sorted copy of the section's XY and rows).
+        // Calls of other threads that are pruning with it right now hold it too: it is freed when the last of them has waited.
+        constexpr size_t MAX_KNN_INDICES = 16;
+        if (s->knn.size() >= MAX_KNN_INDICES) {
+            dropped = std::move(s->knn.back().second);
+            s->knn.pop_back();
         }
-    // one index per radius a section is pruned with: a handful in a run, a stream of them in a parameter search over one long-lived
-    // section -- the least recently used one goes when the table is full (each holds a sorted copy of the section's XY and rows)
-    constexpr size_t MAX_KNN_INDICES = 16;
-    if (s->knn.size() >= MAX_KNN_INDICES) {
-        HIP_TRY(ctx, hipDeviceSynchronize());       // windows of other contexts may have kernels in flight that read it
-        same_knn_index_destroy(s->knn.back().second);
-        s->knn.pop_back();
+        same_knn_index *ix = nullptr;
+        SAME_TRY(same_knn_index_build(ctx, s->xy, s->n, radius, &ix));
+        s->knn.insert(s->knn.begin(), std::make_pair(radius, std::shared_ptr<same_knn_index>(ix, same_knn_index_destroy)));
+        *out = s->knn.front().second;
     }
-    same_knn_index *ix = nullptr;
-    SAME_TRY(same_knn_index_build(ctx, s->xy, s->n, radius, &ix));
-    s->knn.insert(s->knn.begin(), std::make_pair(radius, ix));
-    *out = ix;
     return SAME_OK;
 }
 
@@ -937,7 +943,7 @@ void same_section_destroy(same_section *s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
     (void)hipDeviceSynchronize();                 // windows of other contexts may still be reading the section
-    for (auto &e : s->knn) same_knn_index_destroy(e.second);
+    s->knn.clear();
     if (s->xy_c && s->xy_c != s->xy) (void)hipFree(s->xy_c);
     if (s->xy) (void)hipFree(s->xy);
     if (s->types_c) (void)hipFree(s->types_c);
@@ -1134,7 +1140,7 @@ int same_window_stage(same_window *const *windows, int n_windows, const same_sec
     SAME_TRY(same_use(ctx));
     for (int i = 0; i < 4 * n_windows; ++i) out_counts[i] = 0;
     for (int i = 0; i < n_windows; ++i) windows[i]->staged = windows[i]->finished = windows[i]->filtered = 0;
-    const same_knn_index *ix = nullptr;
+    std::shared_ptr<same_knn_index> ix;           // held until this call's kernels have finished (both returns below wait first)
     SAME_TRY(knn_index_for(ctx, ref, radius, &ix));
     // both sections' grids stay as they are until this call's kernels are enqueued (same_section_bin waits for this, then for the device)
     std::shared_lock<std::shared_mutex> grid_m(const_cast<same_section *>(mov)->grid_lock), grid_r;
@@ -1144,7 +1150,7 @@ int same_window_stage(same_window *const *windows, int n_windows, const same_sec
     std::vector<StagePlan> plans((size_t)n_windows);
     int rc = SAME_OK;
     for (int i = 0; i < n_windows && rc == SAME_OK; ++i)
-        rc = enqueue_stage(windows[i], mov, ref, boxes + 4 * i, k, dist_ct_coeff, ix, &plans[(size_t)i]);
+        rc = enqueue_stage(windows[i], mov, ref, boxes + 4 * i, k, dist_ct_coeff, ix.get(), &plans[(size_t)i]);
     if (rc != SAME_OK) {                          // nothing of a failed batch counts; what was enqueued is waited for before returning
         (void)hipStreamSynchronize(ctx->stream);
         for (int i = 0; i < n_windows; ++i) windows[i]->staged = 0;

@@ -361,6 +361,52 @@ def test_device_window_argument_checks(ops):
         h.close()
 
 
+def test_prune_indices_dropped_while_other_threads_use_them():
+    """A section keeps at most 16 prune indices (one per radius, least recently used dropped).  Three threads with a context each cycle
+    24 radii over the SAME sections, each in its own order, so that indices are dropped from the table while another thread's stage call
+    prunes with them: every call must still give what a single thread gives for its radius (the call holds its index until it has waited)."""
+    import threading
+
+    from same_amd import _lib
+    from same_amd import windows as W
+
+    rng = np.random.default_rng(11)
+    sec = W.Section(rng.uniform(0, 200, (6000, 2)), rng.random((6000, 3)), None, None)     # >= 2048 rows: grid indices (device arrays of their own)
+    dsec = W.DeviceSection(sec, "float64")
+    radii = [3.0 + 0.37 * q for q in range(24)]
+    box = (0.0, 200.0, 0.0, 200.0)
+    solo = W.DeviceWindow()
+    want = {}
+    for r in radii:
+        counts = solo.stage(dsec, dsec, box, r, 6, 1.0)
+        want[r] = (counts, solo.fetch(W._W_PAIRS).copy(), solo.fetch(W._W_COSTS).copy())
+    solo.close()
+    failures = []
+
+    def walk(seed):
+        ctx = _lib.Context(dsec.ctx.device)
+        st = W.DeviceWindow(ctx)
+        try:
+            order = np.random.default_rng(seed).permutation(len(radii))
+            for rep in range(3):
+                for q in order:
+                    r = radii[int(q)]
+                    counts = st.stage(dsec, dsec, box, r, 6, 1.0)
+                    if counts != want[r][0] or not np.array_equal(st.fetch(W._W_PAIRS), want[r][1]) or not np.array_equal(st.fetch(W._W_COSTS), want[r][2]):
+                        failures.append((seed, rep, r))
+        except BaseException as e:   # noqa: BLE001 -- reported by the assertion below
+            failures.append((seed, repr(e)))
+        finally:
+            st.close()
+            ctx.close()
+
+    threads = [threading.Thread(target=walk, args=(s_,)) for s_ in (1, 2, 3)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    dsec.close()
+    assert not failures, failures[:5]
+
+
 def test_scans_hold_when_no_block_ever_sees_a_predecessor():
     """csrc/scan.h never waits: a block that finds a predecessor's word unpublished recomputes that block's counters from the input.
     In a normal run that path is rare and timing-dependent, so here it carries everything: SAME_SCAN_FORCE_RECOMPUTE=1 makes every
