@@ -105,8 +105,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
         t_pass = time.perf_counter()
         tab, stats = all_ranks(one_pass, my_plan)
         pass_seconds[0] += time.perf_counter() - t_pass
-        mine_tab = {c: (tab[c].to_numpy().astype(dt) if len(tab) else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
-        mine_tab["filtered_violation"] = mine_tab["filtered_violation"].astype(np.uint8)
+        mine_tab = {c: (tab[c].to_numpy().astype(dt, copy=False) if len(tab) else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
+        mine_tab["filtered_violation"] = mine_tab["filtered_violation"].view(np.uint8)
         with _trace.stage("table exchange (all-gather)"):
             every = allgather_table(ctx, comm, group, mine_tab)          # the ONE exchange: one table per rank, a device all-gather
             if comm is not None:
@@ -116,7 +116,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
         merged = None
         if group.rank == 0:                                              # the merged table is the job's result: rank 0 holds it
             with _trace.stage("merge (device de-duplication + host matching)"):
-                frames = [pd.DataFrame(dict(t, filtered_violation=t["filtered_violation"].astype(bool))) for t in every if len(t["X"])]
+                frames = [pd.DataFrame(dict(t, filtered_violation=np.asarray(t["filtered_violation"]).view(bool)), copy=False) for t in every if len(t["X"])]
                 merged = merge_window_matches_unique_ref(frames)
         return merged, stats
 

@@ -127,7 +127,9 @@ class _TableBuilder:
         # interpreter lock; the Qhull helpers are idle by now)
         from concurrent.futures import ThreadPoolExecutor
 
-        with ThreadPoolExecutor(max_workers=4) as pool:
+        from .merge import GATHER_THREADS
+
+        with ThreadPoolExecutor(max_workers=GATHER_THREADS) as pool:
             cols = list(pool.map(join, keys))
         return pd.DataFrame(dict(zip(keys, cols)), copy=False)
 

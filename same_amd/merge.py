@@ -28,6 +28,9 @@ def load_matching_results(outprefix):
             pd.read_csv(os.path.join(outprefix, "matches_df.csv")))
 
 
+GATHER_THREADS = 8      # column-parallel copies of a 10^6-row table (22 columns x 950k rows on a 16-CPU host: 16.9 ms on one thread, 4.5 on four, 1.9 on eight)
+
+
 def _window_codes(window_id):
     """window ids as non-negative int32 in their own order (they are small non-negative ints in every reference flow,
     src/same.py:582; anything else -- negative, huge, float -- is ranked first, which preserves the order)."""
@@ -60,12 +63,25 @@ def _node_numbers(values):
     return codes.astype(np.int64), len(uniques)
 
 
+def _present(codes, n):
+    """bool[n]: which node numbers occur in `codes`"""
+    out = np.zeros(n, bool)
+    out[codes] = True
+    return out
+
+
 def _take_rows(df, rows):
-    """df.iloc[rows].reset_index(drop=True), column by column when every column is a plain numpy dtype (a third faster on a table of
-    10^6 rows: no block bookkeeping); frames with extension dtypes take pandas' own path."""
+    """df.iloc[rows].reset_index(drop=True), column by column when every column is a plain numpy dtype: no block bookkeeping, and the
+    columns of a table of 10^6 rows are gathered side by side (numpy copies without the interpreter lock; the merge runs when the
+    window loop is over, so the host is otherwise idle).  Frames with extension dtypes take pandas' own path."""
     if len(rows) < 50_000 or not all(isinstance(dt, np.dtype) for dt in df.dtypes) or not df.columns.is_unique:
         return df.iloc[rows].reset_index(drop=True)
-    return pd.DataFrame({c: df[c].to_numpy().take(rows) for c in df.columns}, copy=False)
+    from concurrent.futures import ThreadPoolExecutor
+
+    cols = [df[c].to_numpy() for c in df.columns]
+    with ThreadPoolExecutor(max_workers=GATHER_THREADS) as pool:
+        taken = list(pool.map(lambda col: col.take(rows), cols))
+    return pd.DataFrame(dict(zip(df.columns, taken)), copy=False)
 
 
 def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _dedup=None):
@@ -98,16 +114,33 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
         kept = np.asarray(kept, dtype=np.int64)     # rows of merged_df that survive, in the order the reference's frame has after :748-753
     with marked("merge: graph of the surviving pairs"):
         (a_codes, n_a), (r_codes, n_r) = _node_numbers(merged_df[aligned_col].values[kept]), _node_numbers(merged_df[ref_col].values[kept])
-        # every edge carries its frame row (+1: an explicit zero would be dropped), so the rows of the matched edges can be read off
-        # the matrix afterwards without a second sort or a Python dict over a table of 10^6 rows; edges are unique after the
-        # de-duplication, so nothing is summed
-        graph = csr_matrix((np.arange(1, len(a_codes) + 1, dtype=np.int64), (a_codes, r_codes)), shape=(n_a, n_r))
-        graph.sort_indices()   # node numbers come from the sorted ids and every adjacency list is sorted: the matching chosen among equally
-                               # large ones depends on the ids alone, not on the order the window tables arrived in (1 rank or 8)
+        # An edge whose two cells have no other edge is in every maximum matching: only the cells that some window disagrees about
+        # (an aligned cell proposed for two references, a reference proposed to two aligned cells) need the graph algorithm -- in a
+        # tiled run these are the cells of the window overlaps at most.  row_of[a] = the position in `kept` of a's matched edge.
+        deg_a, deg_r = np.bincount(a_codes, minlength=n_a), np.bincount(r_codes, minlength=n_r)
+        lone = (deg_a[a_codes] == 1) & (deg_r[r_codes] == 1)
+        rest = np.flatnonzero(~lone)
+        row_of = np.full(n_a, -1, np.int64)
+        lone_at = np.flatnonzero(lone)
+        row_of[a_codes[lone_at]] = lone_at
+        graph = None
+        if len(rest):
+            # the contested cells renumbered densely IN THE ORDER of their ids (node numbers come from the sorted ids, and every
+            # adjacency list is sorted below): the matching chosen among equally large ones depends on the ids alone, not on the
+            # order the window tables arrived in (1 rank or 8)
+            a_rest, r_rest = a_codes[rest], r_codes[rest]
+            a_new, r_new = np.cumsum(_present(a_rest, n_a)) - 1, np.cumsum(_present(r_rest, n_r)) - 1
+            # every edge carries its position in `kept` (+1: an explicit zero would be dropped), so the rows of the matched edges
+            # can be read off the matrix afterwards without a second sort; edges are unique after the de-duplication: nothing is summed
+            graph = csr_matrix((rest + 1, (a_new[a_rest], r_new[r_rest])), shape=(int(a_new[-1]) + 1, int(r_new[-1]) + 1))
+            graph.sort_indices()
     with marked("merge: maximum matching"):
-        match_r = maximum_bipartite_matching(graph, perm_type="column")      # ref node matched to each aligned node, -1 = none (structure only)
+        if graph is not None:
+            match_r = maximum_bipartite_matching(graph, perm_type="column")  # ref node matched to each aligned node, -1 = none (structure only)
     with marked("merge: rows of the matched pairs"):
-        node_of_edge = np.repeat(np.arange(n_a, dtype=np.int64), np.diff(graph.indptr))
-        matched_edge = match_r[node_of_edge] == graph.indices                 # CSR order = aligned ids ascending (:799-808)
-        selected = graph.data[matched_edge] - 1                                # positions in `kept`
+        if graph is not None:
+            node_of_edge = np.repeat(np.arange(graph.shape[0], dtype=np.int64), np.diff(graph.indptr))
+            won = graph.data[match_r[node_of_edge] == graph.indices] - 1       # positions in `kept` of the contested edges that are matched
+            row_of[a_codes[won]] = won
+        selected = row_of[row_of >= 0]                                         # aligned ids ascending (:799-808)
         return _take_rows(merged_df, kept[selected])                           # ONE gather of the frame: the rows of the matched edges

@@ -224,6 +224,54 @@ def test_merge_window_matches_unique_ref(oracle):
     assert len(got) == 2 and set(got["Ref_Cell_Num_Old"]) == {"r9", "r1"}
 
 
+def test_merge_matching_equals_the_matching_on_the_whole_graph(oracle):
+    """merge_window_matches_unique_ref runs Hopcroft-Karp only on the cells some window disagrees about (an edge whose two cells have no
+    other edge is in every maximum matching) and numbers those cells densely in the order of their ids.  The result must be the table
+    the straightforward statement gives -- ONE graph over all surviving pairs, nodes numbered through the sorted ids
+    (src/helpers.py:755-815) --, row for row: random tables from conflict-free to all-conflict, integer and string ids."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+
+    from same_amd.merge import _node_numbers, merge_window_matches_unique_ref
+
+    def whole_graph(df, kept):
+        (ac, na), (rc, nr) = _node_numbers(df["Aligned_Cell_Num_Old"].values[kept]), _node_numbers(df["Ref_Cell_Num_Old"].values[kept])
+        g = csr_matrix((np.arange(1, len(ac) + 1, dtype=np.int64), (ac, rc)), shape=(na, nr))
+        g.sort_indices()
+        m = maximum_bipartite_matching(g, perm_type="column")
+        node = np.repeat(np.arange(na, dtype=np.int64), np.diff(g.indptr))
+        return df.iloc[kept[g.data[m[node] == g.indices] - 1]].reset_index(drop=True)
+
+    rng = np.random.default_rng(1)
+    rows = lone_only = contested = 0
+    for case in range(240):
+        n = int(rng.choice([1, 2, 5, 50, 300, 3000]))
+        ids = int(rng.choice([1, 3, max(2, n // 3), n, 4 * n, 50 * n]))
+        a, r = rng.integers(0, ids, n), rng.integers(0, ids, n)
+        if case % 3 == 1:                           # a tiled run: one-to-one but for a few cells of the overlaps
+            a, r = rng.permutation(max(n, ids))[:n], rng.permutation(max(n, ids))[:n]
+            if case % 2:
+                q = rng.integers(0, n, max(1, n // 10))
+                a[q] = a[rng.integers(0, n, len(q))]
+        if case % 3 == 2:
+            a, r = np.array([f"c{v}" for v in a], dtype=object), np.array([f"r{v}" for v in r], dtype=object)
+        df = pd.DataFrame({"window_id": rng.integers(0, 5, n), "Aligned_Cell_Num_Old": a, "Ref_Cell_Num_Old": r, "X": rng.random(n), "Y": 0.0,
+                           "filtered_violation": rng.random(n) < 0.3})
+        seen = {}
+
+        def dedup(v, w, ac, rc):
+            seen["kept"] = np.asarray(oracle.merge_dedup(v, w, ac, rc), dtype=np.int64)
+            return seen["kept"]
+
+        got = merge_window_matches_unique_ref([df], _dedup=dedup)
+        want = whole_graph(df, seen["kept"])
+        assert list(got.columns) == list(want.columns) and got.equals(want), (case, n, ids)
+        rows += len(got)
+        lone_only += len(got) == len(seen["kept"])
+        contested += len(got) < len(seen["kept"])
+    assert rows > 50_000 and lone_only > 20 and contested > 100       # both the shortcut alone and the graph path carried cases
+
+
 def test_window_codes_follow_sort_values_for_any_column():
     """The device de-duplication sees window ids as int32 ranks in THEIR order: small non-negative integers as they are, anything
     else ranked -- and a missing id (None / NaN) last, where the reference's sort_values puts it (src/helpers.py:748)."""
