@@ -169,6 +169,18 @@ struct same_greedy_state {
 int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dpairs, const double *dcosts, int64_t P, const unsigned long long *dP,
                             int64_t n_m, int64_t n_r, const same_greedy_state &st, int32_t *dmatch_pair, int first, int count);
 
+// Several independent problems per launch (the windows of a batch call): blockIdx.y = problem, the per-problem arguments travel by
+// value in the kernarg segment -- hence the small bound.
+constexpr int SAME_LAUNCH_WINDOWS = 8;
+struct same_greedy_job {
+    const int32_t *pairs = nullptr;
+    const double *costs = nullptr;
+    int64_t P = 0, n_m = 0, n_r = 0;
+    same_greedy_state st;
+    int32_t *match_pair = nullptr;
+};
+int same_greedy_rounds_batch_core(same_ctx *ctx, const same_greedy_job *jobs, int n_jobs, int first, int count);
+
 // ascending sort of n_pad (a power of two >= 2048) 64-bit keys in place (merge.hip)
 int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad);
 

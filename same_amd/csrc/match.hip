@@ -36,11 +36,11 @@ __device__ __forceinline__ unsigned long long inv_key(double c) {
     return k ? k : 1ull;   // ~key == 0 only for one NaN payload: keep 0 for "nothing yet"
 }
 
-__global__ __launch_bounds__(256) void greedy_min_key_kernel(
-    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
-    uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m, unsigned long long *__restrict__ key) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dP) P = (int64_t)*dP;
+// The three (two) maps of a round as device functions of the pair index p: the single-problem kernels and the batched ones (several
+// independent problems per launch: the windows of a batch call, blockIdx.y = problem) are both thin wrappers.
+__device__ __forceinline__ void min_key_body(const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P,
+                                             uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m,
+                                             unsigned long long *__restrict__ key, int64_t p) {
     if (p >= P || !alive[p]) return;
     const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
     if (used[i] || used[n_m + j]) { alive[p] = 0; return; }
@@ -48,25 +48,29 @@ __global__ __launch_bounds__(256) void greedy_min_key_kernel(
     atomicMax(&key[i], k);
     atomicMax(&key[n_m + j], k);
 }
-
-__global__ __launch_bounds__(256) void greedy_min_idx_kernel(
-    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
-    const uint8_t *__restrict__ alive, int64_t n_m, const unsigned long long *__restrict__ key, unsigned *__restrict__ idx) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dP) P = (int64_t)*dP;
+__device__ __forceinline__ void min_idx_body(const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P,
+                                             const uint8_t *__restrict__ alive, int64_t n_m, const unsigned long long *__restrict__ key,
+                                             unsigned *__restrict__ idx, int64_t p) {
     if (p >= P || !alive[p]) return;
     const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
     const unsigned long long k = inv_key(costs[p]);
     if (k == key[i]) atomicMax(&idx[i], ~(unsigned)p);
     if (k == key[n_m + j]) atomicMax(&idx[n_m + j], ~(unsigned)p);
 }
-
-__global__ __launch_bounds__(256) void greedy_select_kernel(
-    const int32_t *__restrict__ pairs, int64_t P, const unsigned long long *__restrict__ dP, uint8_t *__restrict__ alive,
-    int64_t n_m, int64_t n_ends, const unsigned *__restrict__ idx, uint8_t *__restrict__ used, int32_t *__restrict__ match_pair,
-    unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key, unsigned *__restrict__ next_idx) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dP) P = (int64_t)*dP;
+// only "did this round take anything" is ever asked: one plain store per block that took something (a same-address atomicAdd per wave
+// serialised ~1 800 atomics at one L2 line and was most of the select kernel's time).  Every thread of the block calls this.
+__device__ __forceinline__ void publish_selected(bool sel, unsigned long long *__restrict__ n_selected) {
+    __shared__ int any_sel;
+    if (threadIdx.x == 0) any_sel = 0;
+    __syncthreads();
+    if (__ballot(sel) && (threadIdx.x & 63) == 0) any_sel = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && any_sel) *n_selected = 1ull;
+}
+__device__ __forceinline__ void select_body(const int32_t *__restrict__ pairs, int64_t P, uint8_t *__restrict__ alive, int64_t n_m, int64_t n_ends,
+                                            const unsigned *__restrict__ idx, uint8_t *__restrict__ used, int32_t *__restrict__ match_pair,
+                                            unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key,
+                                            unsigned *__restrict__ next_idx, int64_t p) {
     bool sel = false;
     if (p < P && alive[p]) {
         const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
@@ -79,14 +83,29 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(
         }
     }
     if (p < n_ends) { next_key[p] = 0ull; next_idx[p] = 0u; }   // the other set: nobody reads it in this round
-    // only "did this round take anything" is ever asked: one plain store per block that took something (a same-address atomicAdd
-    // per wave serialised ~1 800 atomics at one L2 line and was most of this kernel's time)
-    __shared__ int any_sel;
-    if (threadIdx.x == 0) any_sel = 0;
-    __syncthreads();
-    if (__ballot(sel) && (threadIdx.x & 63) == 0) any_sel = 1;
-    __syncthreads();
-    if (threadIdx.x == 0 && any_sel) *n_selected = 1ull;
+    publish_selected(sel, n_selected);
+}
+
+__global__ __launch_bounds__(256) void greedy_min_key_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m, unsigned long long *__restrict__ key) {
+    if (dP) P = (int64_t)*dP;
+    min_key_body(pairs, costs, P, alive, used, n_m, key, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void greedy_min_idx_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    const uint8_t *__restrict__ alive, int64_t n_m, const unsigned long long *__restrict__ key, unsigned *__restrict__ idx) {
+    if (dP) P = (int64_t)*dP;
+    min_idx_body(pairs, costs, P, alive, n_m, key, idx, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void greedy_select_kernel(
+    const int32_t *__restrict__ pairs, int64_t P, const unsigned long long *__restrict__ dP, uint8_t *__restrict__ alive,
+    int64_t n_m, int64_t n_ends, const unsigned *__restrict__ idx, uint8_t *__restrict__ used, int32_t *__restrict__ match_pair,
+    unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key, unsigned *__restrict__ next_idx) {
+    if (dP) P = (int64_t)*dP;
+    select_body(pairs, P, alive, n_m, n_ends, idx, used, match_pair, n_selected, next_key, next_idx, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // Rounds for costs that are exactly floats (the fp32-cost windows, cost64 = (double)float): (cost, pair index) fits ONE 64-bit word
@@ -97,11 +116,9 @@ __device__ __forceinline__ unsigned long long packed_key(double c, int64_t p) {
     const unsigned k = (u >> 31) ? ~u : (u | 0x80000000u);      // monotone key of the float
     return ((unsigned long long)(~k) << 32) | (unsigned long long)(~(unsigned)p);   // larger word = smaller (cost, index); never 0: p < 2^32 - 1
 }
-__global__ __launch_bounds__(256) void greedy_min_packed_kernel(
-    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
-    uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m, unsigned long long *__restrict__ key) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dP) P = (int64_t)*dP;
+__device__ __forceinline__ void min_packed_body(const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P,
+                                                uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m,
+                                                unsigned long long *__restrict__ key, int64_t p) {
     if (p >= P || !alive[p]) return;
     const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
     if (used[i] || used[n_m + j]) { alive[p] = 0; return; }
@@ -109,12 +126,11 @@ __global__ __launch_bounds__(256) void greedy_min_packed_kernel(
     atomicMax(&key[i], k);
     atomicMax(&key[n_m + j], k);
 }
-__global__ __launch_bounds__(256) void greedy_select_packed_kernel(
-    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
-    uint8_t *__restrict__ alive, int64_t n_m, int64_t n_ends, const unsigned long long *__restrict__ key, uint8_t *__restrict__ used,
-    int32_t *__restrict__ match_pair, unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dP) P = (int64_t)*dP;
+__device__ __forceinline__ void select_packed_body(const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P,
+                                                   uint8_t *__restrict__ alive, int64_t n_m, int64_t n_ends,
+                                                   const unsigned long long *__restrict__ key, uint8_t *__restrict__ used,
+                                                   int32_t *__restrict__ match_pair, unsigned long long *__restrict__ n_selected,
+                                                   unsigned long long *__restrict__ next_key, int64_t p) {
     bool sel = false;
     if (p < P && alive[p]) {
         const int32_t i = pairs[2 * p], j = pairs[2 * p + 1];
@@ -128,12 +144,48 @@ __global__ __launch_bounds__(256) void greedy_select_packed_kernel(
         }
     }
     if (p < n_ends) next_key[p] = 0ull;
-    __shared__ int any_sel;
-    if (threadIdx.x == 0) any_sel = 0;
-    __syncthreads();
-    if (__ballot(sel) && (threadIdx.x & 63) == 0) any_sel = 1;
-    __syncthreads();
-    if (threadIdx.x == 0 && any_sel) *n_selected = 1ull;
+    publish_selected(sel, n_selected);
+}
+__global__ __launch_bounds__(256) void greedy_min_packed_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_m, unsigned long long *__restrict__ key) {
+    if (dP) P = (int64_t)*dP;
+    min_packed_body(pairs, costs, P, alive, used, n_m, key, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void greedy_select_packed_kernel(
+    const int32_t *__restrict__ pairs, const double *__restrict__ costs, int64_t P, const unsigned long long *__restrict__ dP,
+    uint8_t *__restrict__ alive, int64_t n_m, int64_t n_ends, const unsigned long long *__restrict__ key, uint8_t *__restrict__ used,
+    int32_t *__restrict__ match_pair, unsigned long long *__restrict__ n_selected, unsigned long long *__restrict__ next_key) {
+    if (dP) P = (int64_t)*dP;
+    select_packed_body(pairs, costs, P, alive, n_m, n_ends, key, used, match_pair, n_selected, next_key, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---- the rounds of several independent problems in ONE launch per map (blockIdx.y = problem; the arguments travel by value) ----
+struct GreedyArgs {
+    const int32_t *pairs;
+    const double *costs;
+    int64_t P, n_m, n_ends;
+    uint8_t *alive, *used;
+    unsigned long long *key[2];
+    unsigned *idx[2];
+    unsigned long long *sel;
+    int32_t *match_pair;
+};
+struct GreedyBatch {
+    GreedyArgs w[SAME_LAUNCH_WINDOWS];
+};
+// kind: 0 min key, 1 min idx, 2 select, 3 min packed, 4 select packed; s = the key / idx set of this round, r = the round's slot in sel
+template <int KIND>
+__global__ __launch_bounds__(256) void greedy_batch_kernel(GreedyBatch b, int s, int r) {
+    const GreedyArgs &a = b.w[blockIdx.y];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t span = (KIND == 2 || KIND == 4) ? (a.P > a.n_ends ? a.P : a.n_ends) : a.P;
+    if ((int64_t)blockIdx.x * blockDim.x >= span) return;      // whole block beyond this problem (uniform): the grid is sized by the largest
+    if (KIND == 0) min_key_body(a.pairs, a.costs, a.P, a.alive, a.used, a.n_m, a.key[s], p);
+    if (KIND == 1) min_idx_body(a.pairs, a.costs, a.P, a.alive, a.n_m, a.key[s], a.idx[s], p);
+    if (KIND == 2) select_body(a.pairs, a.P, a.alive, a.n_m, a.n_ends, a.idx[s], a.used, a.match_pair, a.sel + r, a.key[s ^ 1], a.idx[s ^ 1], p);
+    if (KIND == 3) min_packed_body(a.pairs, a.costs, a.P, a.alive, a.used, a.n_m, a.key[s], p);
+    if (KIND == 4) select_packed_body(a.pairs, a.costs, a.P, a.alive, a.n_m, a.n_ends, a.key[s], a.used, a.match_pair, a.sel + r, a.key[s ^ 1], p);
 }
 
 // ---- node-local flip statistics (src/eval_utils.py:66-223) -------------------------------------
@@ -374,6 +426,39 @@ int same_greedy_rounds_core(same_ctx *ctx, const int32_t *dp, const double *dc, 
         SAME_LAUNCH(ctx, greedy_min_idx_kernel, dim3(gp), dim3(256), 0, dp, dc, P, dP, st.alive, n_m, st.key[s], st.idx[s]);
         SAME_LAUNCH(ctx, greedy_select_kernel, dim3(gs), dim3(256), 0, dp, P, dP, st.alive, n_m, n_ends, st.idx[s], st.used, dmatch_pair,
                     st.sel + (r - first), st.key[s ^ 1], st.idx[s ^ 1]);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+// The same rounds for n_jobs <= SAME_LAUNCH_WINDOWS independent problems (jobs with P == 0 are skipped by their blocks): one launch per
+// map for all of them.  All jobs share float_costs.  Enqueue only.
+int same_greedy_rounds_batch_core(same_ctx *ctx, const same_greedy_job *jobs, int n_jobs, int first, int count) {
+    REQUIRE(ctx, n_jobs >= 1 && n_jobs <= SAME_LAUNCH_WINDOWS);
+    GreedyBatch b{};
+    int64_t max_p = 0, max_s = 0;
+    const bool packed = jobs[0].st.float_costs;
+    for (int q = 0; q < n_jobs; ++q) {
+        const same_greedy_job &j = jobs[q];
+        REQUIRE(ctx, j.st.float_costs == packed);
+        const int64_t n_ends = j.n_m + j.n_r;
+        b.w[q] = GreedyArgs{j.pairs, j.costs, j.P, j.n_m, j.P ? n_ends : 0, j.st.alive, j.st.used, {j.st.key[0], j.st.key[1]}, {j.st.idx[0], j.st.idx[1]},
+                            j.st.sel, j.match_pair};
+        max_p = std::max(max_p, j.P);
+        max_s = std::max(max_s, j.P ? std::max(j.P, n_ends) : 0);
+    }
+    if (max_p == 0) return SAME_OK;
+    const dim3 gp(grid_for(max_p), (unsigned)n_jobs), gs(grid_for(max_s), (unsigned)n_jobs);
+    for (int r = first; r < first + count; ++r) {
+        const int s = r & 1;
+        if (packed) {
+            SAME_LAUNCH(ctx, greedy_batch_kernel<3>, gp, dim3(256), 0, b, s, r - first);
+            SAME_LAUNCH(ctx, greedy_batch_kernel<4>, gs, dim3(256), 0, b, s, r - first);
+            continue;
+        }
+        SAME_LAUNCH(ctx, greedy_batch_kernel<0>, gp, dim3(256), 0, b, s, r - first);
+        SAME_LAUNCH(ctx, greedy_batch_kernel<1>, gp, dim3(256), 0, b, s, r - first);
+        SAME_LAUNCH(ctx, greedy_batch_kernel<2>, gs, dim3(256), 0, b, s, r - first);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;

@@ -511,47 +511,67 @@ __global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restr
 enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7, SC_REMAINING = 8, SC_COUNT = 16 };
 constexpr int WINDOW_GREEDY_ROUNDS = 3;   // rounds enqueued before the first look (cfg 5: 1-3 productive rounds per window)
 
+// The finish call's kernels take the windows of a batch in ONE launch: blockIdx.y = window, the per-window arguments travel by value
+// (Batch<A>, at most SAME_LAUNCH_WINDOWS of them); the grid is sized by the largest window, blocks beyond a window's own share leave at once.
+template <typename A>
+struct Batch {
+    A w[SAME_LAUNCH_WINDOWS];
+};
+
 // per kept aligned row: minimum pair cost (src/init_helpers.py:118-122; its pairs are a contiguous run of the pair list), whether
 // it beats the no-match penalty, the row's pairs enter the greedy rule or not, no match yet
-__global__ __launch_bounds__(256) void row_prefer_kernel(const int32_t *__restrict__ prow, const double *__restrict__ cost64,
-                                                          const double *__restrict__ size_c, const unsigned long long *__restrict__ dn,
-                                                          double penalty, uint8_t *__restrict__ alive, int32_t *__restrict__ match_pair) {
+struct PreferArgs {
+    const int32_t *prow;
+    const double *cost64, *size_c;
+    const unsigned long long *dn;
+    uint8_t *alive;
+    int32_t *match_pair;
+    int64_t cap;               // the host's count of kept rows (sizes the launch; *dn is the same number on the device)
+};
+__global__ __launch_bounds__(256) void row_prefer_kernel(Batch<PreferArgs> b, double penalty) {
+    const PreferArgs &w = b.w[blockIdx.y];
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= (int64_t)*dn) return;
-    const int32_t lo = prow[a], hi = prow[a + 1];
+    if (a >= w.cap || a >= (int64_t)*w.dn) return;
+    const int32_t lo = w.prow[a], hi = w.prow[a + 1];
     double best = __builtin_inf();
     for (int32_t p = lo; p < hi; ++p) {
-        const double c = cost64[p];
+        const double c = w.cost64[p];
         if (c < best) best = c;
     }
-    const uint8_t prefer = best < penalty * size_c[a];
-    for (int32_t p = lo; p < hi; ++p) alive[p] = prefer;
-    match_pair[a] = -1;
+    const uint8_t prefer = best < penalty * w.size_c[a];
+    for (int32_t p = lo; p < hi; ++p) w.alive[p] = prefer;
+    w.match_pair[a] = -1;
 }
 // pair per row -> matched reference cell: its number in the window (handed out), its section row (the sweeps and the caller); and
 // whether the greedy rule is finished: a pair still alive whose end points are both free would be taken by a further round
-__global__ __launch_bounds__(256) void match_rows_kernel(const int32_t *__restrict__ match_pair, const int32_t *__restrict__ pairs,
-                                                          const int32_t *__restrict__ jsec, const int32_t *__restrict__ prow,
-                                                          const uint8_t *__restrict__ alive, const uint8_t *__restrict__ used, int64_t n_rows,
-                                                          const unsigned long long *__restrict__ dn, int32_t *__restrict__ match_loc,
-                                                          int32_t *__restrict__ match_row, uint8_t *__restrict__ pflag,
-                                                          unsigned long long *__restrict__ counters) {
+struct MatchRowsArgs {
+    const int32_t *match_pair, *pairs, *jsec, *prow;
+    const uint8_t *alive, *used;
+    int64_t n_rows;
+    const unsigned long long *dn;
+    int32_t *match_loc, *match_row;
+    uint8_t *pflag;
+    unsigned long long *counters;
+};
+__global__ __launch_bounds__(256) void match_rows_kernel(Batch<MatchRowsArgs> b) {
+    const MatchRowsArgs &w = b.w[blockIdx.y];
+    if ((int64_t)blockIdx.x * blockDim.x >= w.n_rows) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool m = false;
     int open = 0;
-    if (i < (int64_t)*dn) {
-        const int32_t p = match_pair[i];
-        match_loc[i] = p >= 0 ? pairs[2 * (int64_t)p + 1] : -1;
-        match_row[i] = p >= 0 ? jsec[p] : -1;
-        pflag[i] = 0;
+    if (i < (int64_t)*w.dn) {
+        const int32_t p = w.match_pair[i];
+        w.match_loc[i] = p >= 0 ? w.pairs[2 * (int64_t)p + 1] : -1;
+        w.match_row[i] = p >= 0 ? w.jsec[p] : -1;
+        w.pflag[i] = 0;
         m = p >= 0;
-        if (!m && !used[i])
-            for (int32_t q = prow[i]; q < prow[i + 1]; ++q) open += alive[q] && !used[n_rows + pairs[2 * (int64_t)q + 1]];
+        if (!m && !w.used[i])
+            for (int32_t q = w.prow[i]; q < w.prow[i + 1]; ++q) open += w.alive[q] && !w.used[w.n_rows + w.pairs[2 * (int64_t)q + 1]];
     }
     const unsigned long long bal = __ballot(m), ob = __ballot(open != 0);
     if ((threadIdx.x & 63) == 0) {
-        if (bal) atomicAdd(&counters[SC_MATCHED], (unsigned long long)__builtin_popcountll(bal));
-        if (ob) atomicAdd(&counters[SC_REMAINING], (unsigned long long)__builtin_popcountll(ob));
+        if (bal) atomicAdd(&w.counters[SC_MATCHED], (unsigned long long)__builtin_popcountll(bal));
+        if (ob) atomicAdd(&w.counters[SC_REMAINING], (unsigned long long)__builtin_popcountll(ob));
     }
 }
 // per-cell flag byte: bit 0 = the XY-order sweep flags the cell (src/violationhelper.py:100-104), bit 1 = the cell is a vertex of a
@@ -562,13 +582,29 @@ __device__ __forceinline__ void cell_flag_or(uint8_t *flags, int32_t i, unsigned
 }
 // one pass over the kept triangles: source sign and weight (src/same.py:1128-1146), the lazy-constraint body under the incumbent
 // (:645-669), the XY-order sweep (src/violationhelper.py:53-117), the signed-area flip (src/same.py:1362-1402; helpers.py:73-77)
-__global__ __launch_bounds__(256) void window_sweeps_kernel(const int32_t *__restrict__ tris, int64_t Tr, const unsigned long long *__restrict__ dTr,
-                                                             const double *__restrict__ axy, const double *__restrict__ size_c,
-                                                             const double *__restrict__ ref_xy, const int32_t *__restrict__ match_row,
-                                                             int8_t *__restrict__ sign, double *__restrict__ weight, uint8_t *__restrict__ pflag,
-                                                             unsigned long long *__restrict__ counters) {
+struct SweepArgs {
+    const int32_t *tris;
+    int64_t Tr;                        // the number of triangles, or (dTr != null) the bound the launch is sized by
+    const unsigned long long *dTr;
+    const double *axy, *size_c, *ref_xy;
+    const int32_t *match_row;
+    int8_t *sign;
+    double *weight;
+    uint8_t *pflag;
+    unsigned long long *counters;
+};
+__global__ __launch_bounds__(256) void window_sweeps_kernel(Batch<SweepArgs> b) {
+    const SweepArgs &w = b.w[blockIdx.y];
+    if ((int64_t)blockIdx.x * blockDim.x >= w.Tr) return;
+    const int32_t *__restrict__ tris = w.tris;
+    const double *__restrict__ axy = w.axy, *__restrict__ size_c = w.size_c, *__restrict__ ref_xy = w.ref_xy;
+    const int32_t *__restrict__ match_row = w.match_row;
+    int8_t *__restrict__ sign = w.sign;
+    double *__restrict__ weight = w.weight;
+    uint8_t *__restrict__ pflag = w.pflag;
+    unsigned long long *__restrict__ counters = w.counters;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (dTr) Tr = (int64_t)*dTr;
+    const int64_t Tr = w.dTr ? (int64_t)*w.dTr : w.Tr;
     int checked = 0, flipped = 0, ncmp = 0, nviol = 0, tv = 0, aflip = 0;
     if (t < Tr) {
         const int32_t v[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
@@ -1261,20 +1297,31 @@ struct FinishPlan {
     const unsigned long long *dTr = nullptr;
 };
 
-int enqueue_tail(same_window *w, FinishPlan *p) {
-    same_ctx *ctx = w->ctx;
-    const int64_t n = w->n_ua;
-    SAME_LAUNCH(ctx, match_rows_kernel, dim3(grid_for(n)), dim3(256), 0, p->match_pair, w->pairs, w->jsec, w->prow, p->gs.alive, p->gs.used, n,
-                w->counts + 2, w->match_loc, p->match_row, p->pflag, p->counters);
-    if (p->cap_tr)
-        SAME_LAUNCH(ctx, window_sweeps_kernel, dim3(grid_for(p->cap_tr)), dim3(256), 0, static_cast<const int32_t *>(w->tris.p), p->cap_tr, p->dTr,
-                    w->axy_c, w->size_c, w->ref->xy, p->match_row, w->sign, w->weight, p->pflag, p->counters);
+// match rows + the one pass over the triangles, for a group of windows (<= SAME_LAUNCH_WINDOWS) in one launch each
+int enqueue_tail(same_ctx *ctx, same_window *const *ws, FinishPlan *const *ps, int n_w) {
+    Batch<MatchRowsArgs> mb{};
+    Batch<SweepArgs> sb{};
+    int64_t max_n = 0, max_tr = 0;
+    for (int q = 0; q < n_w; ++q) {
+        same_window *w = ws[q];
+        FinishPlan *p = ps[q];
+        const int64_t n = w->n_ua;
+        mb.w[q] = MatchRowsArgs{p->match_pair, w->pairs, w->jsec, w->prow, p->gs.alive, p->gs.used, n, w->counts + 2, w->match_loc, p->match_row, p->pflag,
+                                p->counters};
+        sb.w[q] = SweepArgs{static_cast<const int32_t *>(w->tris.p), p->cap_tr, p->dTr, w->axy_c, w->size_c, w->ref->xy, p->match_row, w->sign, w->weight,
+                            p->pflag, p->counters};
+        max_n = std::max(max_n, n);
+        max_tr = std::max(max_tr, p->cap_tr);
+    }
+    if (max_n) SAME_LAUNCH(ctx, match_rows_kernel, dim3(grid_for(max_n), (unsigned)n_w), dim3(256), 0, mb);
+    if (max_tr) SAME_LAUNCH(ctx, window_sweeps_kernel, dim3(grid_for(max_tr), (unsigned)n_w), dim3(256), 0, sb);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
 
-// cap_tr: the number of triangles, or (dTr != null) the bound the launch is sized by with the number itself on the device
-int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, const unsigned long long *dTr, double no_match_penalty, FinishPlan *p) {
+// A window's finish buffer laid out and zeroed, its triangles uploaded (prefiltered form); no launch -- those come per GROUP of windows
+// (launch_finish).  cap_tr: the number of triangles, or (dTr != null) the bound the launch is sized by with the number itself on the device
+int prepare_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, const unsigned long long *dTr, FinishPlan *p) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua, P = w->P, n_ends = n + w->n_r;
     Carver cv;
@@ -1324,11 +1371,31 @@ int enqueue_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     REQUIRE(ctx, w->host_finish_off + p->back_bytes <= w->host_filter_off);   // sized by the stage call
     SAME_FILL(ctx, base, 0, zero_bytes);
     if (host_tris && cap_tr) SAME_COPY(ctx, w->tris.p, host_tris, (size_t)cap_tr * 12, hipMemcpyHostToDevice);
-    // greedy MIP start: per-row minimum, rows that beat their penalty, the scan's matching (one pair per aligned row)
-    SAME_LAUNCH(ctx, row_prefer_kernel, dim3(grid_for(n)), dim3(256), 0, w->prow, w->cost64, w->size_c, w->counts + 2, no_match_penalty, p->gs.alive,
-                p->match_pair);
-    if (P) SAME_TRY(same_greedy_rounds_core(ctx, w->pairs, w->cost64, P, nullptr, n, w->n_r, p->gs, p->match_pair, 0, WINDOW_GREEDY_ROUNDS));
-    return enqueue_tail(w, p);
+    return SAME_OK;
+}
+
+// greedy MIP start of a group of prepared windows -- per-row minimum, rows that beat their penalty, the scan's matching (one pair per
+// aligned row) -- and the tail: one launch per kernel for the whole group (windows of one batch call share the cost type)
+int launch_finish(same_ctx *ctx, same_window *const *ws, FinishPlan *const *ps, int n_w, double no_match_penalty) {
+    Batch<PreferArgs> pb{};
+    same_greedy_job jobs[SAME_LAUNCH_WINDOWS];
+    int64_t max_n = 0;
+    for (int q = 0; q < n_w; ++q) {
+        same_window *w = ws[q];
+        FinishPlan *p = ps[q];
+        pb.w[q] = PreferArgs{w->prow, w->cost64, w->size_c, w->counts + 2, p->gs.alive, p->match_pair, w->n_ua};
+        jobs[q].pairs = w->pairs;
+        jobs[q].costs = w->cost64;
+        jobs[q].P = w->P;
+        jobs[q].n_m = w->n_ua;
+        jobs[q].n_r = w->n_r;
+        jobs[q].st = p->gs;
+        jobs[q].match_pair = p->match_pair;
+        max_n = std::max(max_n, w->n_ua);
+    }
+    if (max_n) SAME_LAUNCH(ctx, row_prefer_kernel, dim3(grid_for(max_n), (unsigned)n_w), dim3(256), 0, pb, no_match_penalty);
+    SAME_TRY(same_greedy_rounds_batch_core(ctx, jobs, n_w, 0, WINDOW_GREEDY_ROUNDS));
+    return enqueue_tail(ctx, ws, ps, n_w);
 }
 
 // the finish call's answers: one copy (enqueue_finish_copy), a wait the CALLER makes (one for a whole batch of windows), then
@@ -1369,7 +1436,7 @@ int read_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *
                 if (batch < SAME_GREEDY_BATCH_MAX) batch *= 2;
             }
             SAME_FILL(ctx, p->counters, 0, SC_COUNT * 8);
-            SAME_TRY(enqueue_tail(w, p));
+            SAME_TRY(enqueue_tail(ctx, &w, &p, 1));
             SAME_COPY(ctx, h, dsel, p->back_bytes, hipMemcpyDeviceToHost);
             SAME_WAIT(ctx);
         }
@@ -1411,8 +1478,11 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         bool filtered = false, enqueued = false;
     };
     std::vector<Item> items((size_t)n_windows);
-    // every window's filter + finish + copies go into the stream back to back; ONE wait for the batch
+    // ONE wait for the batch.  Per window: its filter, its finish buffer zeroed; then per GROUP of SAME_LAUNCH_WINDOWS windows the finish
+    // kernels (one launch each for the whole group); then every window's copies back
     int rc = SAME_OK;
+    std::vector<same_window *> live;
+    std::vector<FinishPlan *> plans;
     for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
         same_window *w = windows[i];
         Item &it = items[(size_t)i];
@@ -1423,16 +1493,27 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         if (w->n_ua == 0) continue;
         if (Tr && !prefiltered) {
             rc = enqueue_filter(w, tri, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &it.fplan);
-            if (rc == SAME_OK) rc = enqueue_finish(w, nullptr, Tr, it.fplan.counters + FC_TR, no_match_penalty, &it.plan);
-            if (rc == SAME_OK) {       // the filter's counters come back beside the finish call's block: one copy from each buffer
-                unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
-                hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-                ++ctx->stats[SAME_STAT_COPIES];
-                if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "filter counters", e);
-            }
+            if (rc == SAME_OK) rc = prepare_finish(w, nullptr, Tr, it.fplan.counters + FC_TR, &it.plan);
             it.filtered = true;
         } else {
-            rc = enqueue_finish(w, Tr ? tri : nullptr, Tr, nullptr, no_match_penalty, &it.plan);     // the caller's kept triangles (or none)
+            rc = prepare_finish(w, Tr ? tri : nullptr, Tr, nullptr, &it.plan);     // the caller's kept triangles (or none)
+        }
+        if (rc == SAME_OK) {
+            live.push_back(w);
+            plans.push_back(&it.plan);
+        }
+    }
+    for (size_t g = 0; g < live.size() && rc == SAME_OK; g += SAME_LAUNCH_WINDOWS)
+        rc = launch_finish(ctx, live.data() + g, plans.data() + g, (int)std::min<size_t>(SAME_LAUNCH_WINDOWS, live.size() - g), no_match_penalty);
+    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
+        same_window *w = windows[i];
+        Item &it = items[(size_t)i];
+        if (w->n_ua == 0) continue;
+        if (it.filtered) {             // the filter's counters come back beside the finish call's block: one copy from each buffer
+            unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
+            hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+            ++ctx->stats[SAME_STAT_COPIES];
+            if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "filter counters", e);
         }
         if (rc == SAME_OK) rc = enqueue_finish_copy(w, &it.plan);
         it.enqueued = rc == SAME_OK;
