@@ -142,7 +142,7 @@ inline unsigned long long *arg(unsigned long long *status) {
     static const bool force = [] { const char *e = getenv("SAME_SCAN_FORCE_RECOMPUTE"); return e && e[0] && e[0] != '0'; }();
     return force ? reinterpret_cast<unsigned long long *>(reinterpret_cast<uintptr_t>(status) | 1u) : status;
 }
-inline unsigned blocks_for(int64_t n) { return (unsigned)((n > 0 ? n + NT - 1 : NT) / NT); }
+__host__ __device__ inline unsigned blocks_for(int64_t n) { return (unsigned)((n > 0 ? n + NT - 1 : NT) / NT); }
 inline size_t status_bytes(int64_t n) { return ((size_t)blocks_for(n) * 8 + 15) & ~size_t(15); }
 
 }  // namespace scan

@@ -412,97 +412,120 @@ __global__ __launch_bounds__(scan::NT) void window_scatter_kernel(ScatterArgs s)
 // counters of the filter: [0] kept (class 0), [1] added back, [2] cosines within `tol` of the threshold, [3] triangles left
 enum { FC_KEEP = 0, FC_ADD = 1, FC_NEAR = 2, FC_TR = 3 };
 
+// The filter's kernels take the windows of a batch in ONE launch each: blockIdx.y = window, the per-window arguments travel by value
+// (Batch<FilterArgs>, at most SAME_LAUNCH_WINDOWS of them); the grid is sized by the largest window, blocks beyond a window's own
+// share leave at once.  The filter settings are the call's: the same for every window.
+template <typename A>
+struct Batch {
+    A w[SAME_LAUNCH_WINDOWS];
+};
+struct FilterArgs {
+    const double *xy;                  // kept aligned cells' XY
+    const int32_t *raw;                // the triangulation's simplices
+    int64_t Tr, n;                     // triangles, kept aligned cells
+    const int32_t *type_id;            // or null
+    uint8_t *cls;
+    double *perim;
+    uint8_t *has_kept, *any_valid;
+    unsigned long long *best_p;        // or null (no re-adding)
+    unsigned *best_t, *first_v;
+    unsigned long long *st_keep, *st_own, *counters;
+    int32_t *klist, *nlist, *out;
+};
+
 // classes; vertices with a kept triangle, vertices with any valid (kept or same-type) triangle; knife-edge cosines
-__global__ __launch_bounds__(256) void filter_classify_kernel(const double *__restrict__ xy, const int32_t *__restrict__ tris, int64_t Tr,
-                                                               double radius, int angle_enabled, double cos_thr, const int32_t *__restrict__ type_id,
-                                                               int near_enabled, double tol, uint8_t *__restrict__ cls,
-                                                               double *__restrict__ perim, uint8_t *__restrict__ has_kept,
-                                                               uint8_t *__restrict__ any_valid, unsigned long long *__restrict__ best_p,
-                                                               unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(256) void filter_classify_kernel(Batch<FilterArgs> b, double radius, int angle_enabled, double cos_thr, int near_enabled,
+                                                               double tol) {
+    const FilterArgs &w = b.w[blockIdx.y];
+    if ((int64_t)blockIdx.x * blockDim.x >= w.Tr) return;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t *__restrict__ tris = w.raw, *__restrict__ type_id = w.type_id;
     bool near = false;
-    if (t < Tr) {
-        const int32_t a = tris[3 * t], b = tris[3 * t + 1], d = tris[3 * t + 2];
-        const TriClass r = classify_triangle(ld2(xy, a), ld2(xy, b), ld2(xy, d), radius, angle_enabled, cos_thr,
-                                             type_id && type_id[a] == type_id[b] && type_id[b] == type_id[d]);
-        cls[t] = r.cls;
-        perim[t] = r.perim;
+    if (t < w.Tr) {
+        const int32_t a = tris[3 * t], bb = tris[3 * t + 1], d = tris[3 * t + 2];
+        const TriClass r = classify_triangle(ld2(w.xy, a), ld2(w.xy, bb), ld2(w.xy, d), radius, angle_enabled, cos_thr,
+                                             type_id && type_id[a] == type_id[bb] && type_id[bb] == type_id[d]);
+        w.cls[t] = r.cls;
+        w.perim[t] = r.perim;
         near = near_enabled && r.cls != 1 && fabs(r.maxcos - cos_thr) <= tol;
         if (r.cls == 0 || r.cls == 3) {
-            any_valid[a] = 1; any_valid[b] = 1; any_valid[d] = 1;
-            if (r.cls == 0) { has_kept[a] = 1; has_kept[b] = 1; has_kept[d] = 1; }
+            w.any_valid[a] = 1; w.any_valid[bb] = 1; w.any_valid[d] = 1;
+            if (r.cls == 0) { w.has_kept[a] = 1; w.has_kept[bb] = 1; w.has_kept[d] = 1; }
         }
         // best same-type triangle of every vertex, first pass (src/helpers.py:334-340): the smallest perimeter, as an atomic maximum
         // over the INVERTED bit pattern (perimeters are >= 0: the order of the bits is theirs; zero = none yet, one fill prepares it)
-        if (best_p && r.cls == 3) {
+        if (w.best_p && r.cls == 3) {
             const unsigned long long key = ~(unsigned long long)__double_as_longlong(r.perim);
-            atomicMax(&best_p[a], key); atomicMax(&best_p[b], key); atomicMax(&best_p[d], key);
+            atomicMax(&w.best_p[a], key); atomicMax(&w.best_p[bb], key); atomicMax(&w.best_p[d], key);
         }
     }
     const unsigned long long nb = __ballot(near);
-    if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&counters[FC_NEAR], (unsigned long long)__builtin_popcountll(nb));
+    if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&w.counters[FC_NEAR], (unsigned long long)__builtin_popcountll(nb));
 }
 // the kept (class 0) triangles in order; and, second pass of the best same-type triangle: the first triangle in input order among
 // a vertex's equal smallest perimeters (an atomic maximum of the inverted triangle index)
-__global__ __launch_bounds__(scan::NT) void filter_keep_kernel(const uint8_t *__restrict__ cls, const double *__restrict__ perim,
-                                                                const int32_t *__restrict__ tris, int64_t Tr, unsigned long long *__restrict__ status,
-                                                                int32_t *__restrict__ keep_list, const unsigned long long *__restrict__ best_p,
-                                                                unsigned *__restrict__ best_t, unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(scan::NT) void filter_keep_kernel(Batch<FilterArgs> b) {
     __shared__ scan::Shared sh;
+    const FilterArgs &w = b.w[blockIdx.y];
+    const int nb = (int)scan::blocks_for(w.Tr);
+    if ((int)blockIdx.x >= nb || w.Tr == 0) return;
+    const int64_t Tr = w.Tr;
+    const uint8_t *__restrict__ cls = w.cls;
     auto val = [&](int64_t t) { return Pair{t < Tr && cls[t] == 0 ? 1u : 0u, 0u}; };
     Pair through;
-    const Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const Pair off = scan::exclusive(w.st_keep, (int)blockIdx.x, val, sh, &through);
     const int64_t t = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
     if (t < Tr) {
         const uint8_t c = cls[t];
-        if (c == 0) keep_list[off.a] = (int32_t)t;
-        if (best_p && c == 3) {
-            const unsigned long long key = ~(unsigned long long)__double_as_longlong(perim[t]);
+        if (c == 0) w.klist[off.a] = (int32_t)t;
+        if (w.best_p && c == 3) {
+            const unsigned long long key = ~(unsigned long long)__double_as_longlong(w.perim[t]);
             for (int q = 0; q < 3; ++q) {
-                const int32_t v = tris[3 * t + q];
-                if (best_p[v] == key) atomicMax(&best_t[v], ~(unsigned)t);
+                const int32_t v = w.raw[3 * t + q];
+                if (w.best_p[v] == key) atomicMax(&w.best_t[v], ~(unsigned)t);
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters[FC_KEEP] = through.a;
+    if ((int)blockIdx.x == nb - 1 && threadIdx.x == 0) w.counters[FC_KEEP] = through.a;
 }
 // nodes without a kept triangle but with a valid one are walked in ascending order and bring their best triangle along unless an
 // earlier node already did (src/helpers.py:365-389): first_v[t] = the first node that asks for t (inverted, zero = nobody) ...
 __device__ __forceinline__ bool asks(const uint8_t *has_kept, const uint8_t *any_valid, const unsigned *best_t, int64_t v) {
     return !has_kept[v] && any_valid[v] && best_t[v] != 0u;
 }
-__global__ __launch_bounds__(256) void filter_first_node_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
-                                                                 const unsigned *__restrict__ best_t, int64_t n, unsigned *__restrict__ first_v) {
+__global__ __launch_bounds__(256) void filter_first_node_kernel(Batch<FilterArgs> b) {
+    const FilterArgs &w = b.w[blockIdx.y];
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !asks(has_kept, any_valid, best_t, v)) return;
-    atomicMax(&first_v[~best_t[v]], ~(unsigned)v);
+    if (v >= w.n || !asks(w.has_kept, w.any_valid, w.best_t, v)) return;
+    atomicMax(&w.first_v[~w.best_t[v]], ~(unsigned)v);
 }
 // ... and the nodes that are the first to ask, compacted in order
-__global__ __launch_bounds__(scan::NT) void filter_owner_kernel(const uint8_t *__restrict__ has_kept, const uint8_t *__restrict__ any_valid,
-                                                                 const unsigned *__restrict__ best_t, const unsigned *__restrict__ first_v, int64_t n,
-                                                                 unsigned long long *__restrict__ status, int32_t *__restrict__ owner_list,
-                                                                 unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(scan::NT) void filter_owner_kernel(Batch<FilterArgs> b) {
     __shared__ scan::Shared sh;
-    auto own = [&](int64_t v) { return v < n && asks(has_kept, any_valid, best_t, v) && first_v[~best_t[v]] == ~(unsigned)v; };
+    const FilterArgs &w = b.w[blockIdx.y];
+    const int nb = (int)scan::blocks_for(w.n);
+    if ((int)blockIdx.x >= nb || w.n == 0) return;
+    const int64_t n = w.n;
+    auto own = [&](int64_t v) { return v < n && asks(w.has_kept, w.any_valid, w.best_t, v) && w.first_v[~w.best_t[v]] == ~(unsigned)v; };
     auto val = [&](int64_t v) { return Pair{own(v) ? 1u : 0u, 0u}; };
     Pair through;
-    const Pair off = scan::exclusive(status, (int)blockIdx.x, val, sh, &through);
+    const Pair off = scan::exclusive(w.st_own, (int)blockIdx.x, val, sh, &through);
     const int64_t v = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
-    if (own(v)) owner_list[off.a] = (int32_t)v;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counters[FC_ADD] = through.a;
+    if (own(v)) w.nlist[off.a] = (int32_t)v;
+    if ((int)blockIdx.x == nb - 1 && threadIdx.x == 0) w.counters[FC_ADD] = through.a;
 }
 // the kept triangles in the reference's order: class-0 triangles ascending, then the added-back ones in walk order
-__global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restrict__ raw, const int32_t *__restrict__ keep_list,
-                                                           const int32_t *__restrict__ owner_list, const unsigned *__restrict__ best_t,
-                                                           unsigned long long *__restrict__ counters, int32_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void filter_emit_kernel(Batch<FilterArgs> b) {
+    const FilterArgs &w = b.w[blockIdx.y];
+    if ((int64_t)blockIdx.x * blockDim.x >= w.Tr) return;
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n_keep = (int64_t)counters[FC_KEEP], n_add = (int64_t)counters[FC_ADD];
-    if (q == 0) counters[FC_TR] = (unsigned long long)(n_keep + n_add);
+    const int64_t n_keep = (int64_t)w.counters[FC_KEEP], n_add = (int64_t)w.counters[FC_ADD];
+    if (q == 0) w.counters[FC_TR] = (unsigned long long)(n_keep + n_add);
     if (q >= n_keep + n_add) return;
-    const int64_t t = q < n_keep ? keep_list[q] : (int64_t)~best_t[owner_list[q - n_keep]];
-    out[3 * q] = raw[3 * t];
-    out[3 * q + 1] = raw[3 * t + 1];
-    out[3 * q + 2] = raw[3 * t + 2];
+    const int64_t t = q < n_keep ? w.klist[q] : (int64_t)~w.best_t[w.nlist[q - n_keep]];
+    w.out[3 * q] = w.raw[3 * t];
+    w.out[3 * q + 1] = w.raw[3 * t + 1];
+    w.out[3 * q + 2] = w.raw[3 * t + 2];
 }
 
 // ---- incumbent and sweeps ---------------------------------------------------------------------------------------------------
@@ -511,13 +534,7 @@ __global__ __launch_bounds__(256) void filter_emit_kernel(const int32_t *__restr
 enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7, SC_REMAINING = 8, SC_COUNT = 16 };
 constexpr int WINDOW_GREEDY_ROUNDS = 3;   // rounds enqueued before the first look (cfg 5: 1-3 productive rounds per window)
 
-// The finish call's kernels take the windows of a batch in ONE launch: blockIdx.y = window, the per-window arguments travel by value
-// (Batch<A>, at most SAME_LAUNCH_WINDOWS of them); the grid is sized by the largest window, blocks beyond a window's own share leave at once.
-template <typename A>
-struct Batch {
-    A w[SAME_LAUNCH_WINDOWS];
-};
-
+// The finish call's kernels take the windows of a batch in one launch each too (Batch<A>, blockIdx.y = window).
 // per kept aligned row: minimum pair cost (src/init_helpers.py:118-122; its pairs are a contiguous run of the pair list), whether
 // it beats the no-match penalty, the row's pairs enter the greedy rule or not, no match yet
 struct PreferArgs {
@@ -1239,12 +1256,13 @@ namespace {
 
 // ---- the filter and the finish as enqueue-only halves + their read-backs, so that the two calls can also run as one ----------
 struct FilterPlan {
+    FilterArgs args{};
     unsigned long long *counters = nullptr;   // [4] FC_*
     bool readd = false;
 };
 
-int enqueue_filter(same_window *w, const int32_t *simplices, int64_t Tr, double radius, int angle_enabled, double cos_thr, double near_tol,
-                   int ignore_same_type, int ensure_min_triangle_per_node, FilterPlan *plan) {
+// A window's filter buffer laid out and zeroed, its simplices uploaded; no launch -- those come per GROUP of windows (launch_filter)
+int prepare_filter(same_window *w, const int32_t *simplices, int64_t Tr, int ignore_same_type, int ensure_min_triangle_per_node, FilterPlan *plan) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua;
     const bool use_type = ignore_same_type && w->has_type;
@@ -1263,25 +1281,49 @@ int enqueue_filter(same_window *w, const int32_t *simplices, int64_t Tr, double 
     auto at = [&](size_t off) { return base + off; };
     unsigned long long *dc = reinterpret_cast<unsigned long long *>(at(o_counters));
     plan->counters = dc;
-    uint8_t *has_kept = reinterpret_cast<uint8_t *>(at(o_has_kept)), *any_valid = reinterpret_cast<uint8_t *>(at(o_any_valid));
-    unsigned long long *best_p = reinterpret_cast<unsigned long long *>(at(o_best_p));
-    unsigned *best_t = reinterpret_cast<unsigned *>(at(o_best_t)), *first_v = reinterpret_cast<unsigned *>(at(o_first_v));
-    int32_t *raw = reinterpret_cast<int32_t *>(at(o_raw)), *klist = reinterpret_cast<int32_t *>(at(o_klist)), *nlist = reinterpret_cast<int32_t *>(at(o_nlist));
-    uint8_t *cls = reinterpret_cast<uint8_t *>(at(o_cls));
-    double *perim = reinterpret_cast<double *>(at(o_perim));
+    FilterArgs &a = plan->args;
+    a.xy = w->axy_c;
+    a.raw = reinterpret_cast<int32_t *>(at(o_raw));
+    a.Tr = Tr;
+    a.n = n;
+    a.type_id = use_type ? w->type_c : nullptr;
+    a.cls = reinterpret_cast<uint8_t *>(at(o_cls));
+    a.perim = reinterpret_cast<double *>(at(o_perim));
+    a.has_kept = reinterpret_cast<uint8_t *>(at(o_has_kept));
+    a.any_valid = reinterpret_cast<uint8_t *>(at(o_any_valid));
+    a.best_p = plan->readd ? reinterpret_cast<unsigned long long *>(at(o_best_p)) : nullptr;
+    a.best_t = reinterpret_cast<unsigned *>(at(o_best_t));
+    a.first_v = reinterpret_cast<unsigned *>(at(o_first_v));
+    a.st_keep = scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_keep)));
+    a.st_own = scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_own)));
+    a.counters = dc;
+    a.klist = reinterpret_cast<int32_t *>(at(o_klist));
+    a.nlist = reinterpret_cast<int32_t *>(at(o_nlist));
+    a.out = static_cast<int32_t *>(w->tris.p);
     SAME_FILL(ctx, base, 0, zero_bytes);
-    SAME_COPY(ctx, raw, simplices, (size_t)Tr * 12, hipMemcpyHostToDevice);
-    const int near_enabled = angle_enabled && cos_thr == cos_thr && cos_thr - cos_thr == 0.0;       // a finite threshold
-    SAME_LAUNCH(ctx, filter_classify_kernel, dim3(grid_for(Tr)), dim3(256), 0, w->axy_c, raw, Tr, radius, angle_enabled, cos_thr,
-                use_type ? w->type_c : nullptr, near_enabled, near_tol, cls, perim, has_kept, any_valid, plan->readd ? best_p : nullptr, dc);
-    SAME_LAUNCH(ctx, filter_keep_kernel, dim3(scan::blocks_for(Tr)), dim3(scan::NT), 0, cls, perim, raw, Tr,
-                scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_keep))), klist, plan->readd ? best_p : nullptr, best_t, dc);
-    if (plan->readd) {
-        SAME_LAUNCH(ctx, filter_first_node_kernel, dim3(grid_for(n)), dim3(256), 0, has_kept, any_valid, best_t, n, first_v);
-        SAME_LAUNCH(ctx, filter_owner_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, has_kept, any_valid, best_t, first_v, n,
-                    scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_own))), nlist, dc);
+    SAME_COPY(ctx, at(o_raw), simplices, (size_t)Tr * 12, hipMemcpyHostToDevice);
+    return SAME_OK;
+}
+
+// the filter of a group of prepared windows (<= SAME_LAUNCH_WINDOWS; the settings are the call's, `readd` follows from them and from
+// the moving section, so it is the group's): three launches, five when same-type triangles come back
+int launch_filter(same_ctx *ctx, FilterPlan *const *plans, int n_w, double radius, int angle_enabled, double cos_thr, double near_tol) {
+    Batch<FilterArgs> b{};
+    int64_t max_tr = 0, max_n = 0;
+    for (int q = 0; q < n_w; ++q) {
+        b.w[q] = plans[q]->args;
+        max_tr = std::max(max_tr, plans[q]->args.Tr);
+        max_n = std::max(max_n, plans[q]->args.n);
     }
-    SAME_LAUNCH(ctx, filter_emit_kernel, dim3(grid_for(Tr)), dim3(256), 0, raw, klist, nlist, best_t, dc, static_cast<int32_t *>(w->tris.p));
+    const unsigned nw = (unsigned)n_w;
+    const int near_enabled = angle_enabled && cos_thr == cos_thr && cos_thr - cos_thr == 0.0;       // a finite threshold
+    SAME_LAUNCH(ctx, filter_classify_kernel, dim3(grid_for(max_tr), nw), dim3(256), 0, b, radius, angle_enabled, cos_thr, near_enabled, near_tol);
+    SAME_LAUNCH(ctx, filter_keep_kernel, dim3(scan::blocks_for(max_tr), nw), dim3(scan::NT), 0, b);
+    if (plans[0]->readd) {
+        SAME_LAUNCH(ctx, filter_first_node_kernel, dim3(grid_for(max_n), nw), dim3(256), 0, b);
+        SAME_LAUNCH(ctx, filter_owner_kernel, dim3(scan::blocks_for(max_n), nw), dim3(scan::NT), 0, b);
+    }
+    SAME_LAUNCH(ctx, filter_emit_kernel, dim3(grid_for(max_tr), nw), dim3(256), 0, b);
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -1478,11 +1520,12 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         bool filtered = false, enqueued = false;
     };
     std::vector<Item> items((size_t)n_windows);
-    // ONE wait for the batch.  Per window: its filter, its finish buffer zeroed; then per GROUP of SAME_LAUNCH_WINDOWS windows the finish
-    // kernels (one launch each for the whole group); then every window's copies back
+    // ONE wait for the batch.  Per window: its filter and finish buffers laid out and zeroed, its simplices uploaded; then per GROUP of
+    // SAME_LAUNCH_WINDOWS windows the filter's and the finish's kernels (one launch each for the whole group); then every window's copies back
     int rc = SAME_OK;
     std::vector<same_window *> live;
     std::vector<FinishPlan *> plans;
+    std::vector<FilterPlan *> fplans;
     for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
         same_window *w = windows[i];
         Item &it = items[(size_t)i];
@@ -1492,8 +1535,9 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         w->Tr = 0;
         if (w->n_ua == 0) continue;
         if (Tr && !prefiltered) {
-            rc = enqueue_filter(w, tri, Tr, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, ensure_min_triangle_per_node, &it.fplan);
+            rc = prepare_filter(w, tri, Tr, ignore_same_type, ensure_min_triangle_per_node, &it.fplan);
             if (rc == SAME_OK) rc = prepare_finish(w, nullptr, Tr, it.fplan.counters + FC_TR, &it.plan);
+            if (rc == SAME_OK) fplans.push_back(&it.fplan);
             it.filtered = true;
         } else {
             rc = prepare_finish(w, Tr ? tri : nullptr, Tr, nullptr, &it.plan);     // the caller's kept triangles (or none)
@@ -1503,8 +1547,16 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
             plans.push_back(&it.plan);
         }
     }
-    for (size_t g = 0; g < live.size() && rc == SAME_OK; g += SAME_LAUNCH_WINDOWS)
-        rc = launch_finish(ctx, live.data() + g, plans.data() + g, (int)std::min<size_t>(SAME_LAUNCH_WINDOWS, live.size() - g), no_match_penalty);
+    // groups of at most SAME_LAUNCH_WINDOWS consecutive windows that agree on what a launch fixes for all of them (windows of one call
+    // usually come from one pair of sections: whether same-type triangles come back, the cost type)
+    for (size_t g = 0, e; g < fplans.size() && rc == SAME_OK; g = e) {
+        for (e = g + 1; e < fplans.size() && e - g < SAME_LAUNCH_WINDOWS && fplans[e]->readd == fplans[g]->readd; ++e) {}
+        rc = launch_filter(ctx, fplans.data() + g, (int)(e - g), radius, angle_enabled, cos_thr, near_tol);
+    }
+    for (size_t g = 0, e; g < live.size() && rc == SAME_OK; g = e) {
+        for (e = g + 1; e < live.size() && e - g < SAME_LAUNCH_WINDOWS && live[e]->cost_f32 == live[g]->cost_f32; ++e) {}
+        rc = launch_finish(ctx, live.data() + g, plans.data() + g, (int)(e - g), no_match_penalty);
+    }
     for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
         same_window *w = windows[i];
         Item &it = items[(size_t)i];
