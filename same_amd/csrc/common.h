@@ -184,11 +184,25 @@ int same_greedy_rounds_batch_core(same_ctx *ctx, const same_greedy_job *jobs, in
 // ascending sort of n_pad (a power of two >= 2048) 64-bit keys in place (merge.hip)
 int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad);
 
-// the window path's prune and candidate-list costs on row lists of the sections (knn.hip, cost.hip)
+// the window path's prune and candidate-list costs on row lists of the sections (knn.hip, cost.hip), for the windows of a batch in one
+// launch each (<= SAME_LAUNCH_WINDOWS jobs)
 struct same_knn_index;
-int same_knn_window_core(same_ctx *ctx, const same_knn_index *ix, const double *dmov_xy, const int32_t *drows_m,
-                         const unsigned long long *dn_m, int64_t cap_m, const int32_t *drows_r, const unsigned long long *dn_r,
-                         const double *box, int k, int32_t *didx, int32_t *dcnt);
-int same_padded_cost_window_core(same_ctx *ctx, int cost_f32, const void *dA, const void *dR, int T, const void *daxy_c, const void *drxy_c,
-                                 const int32_t *drows, const unsigned long long *dn, int64_t cap, int k, const int32_t *didx, double w,
-                                 void *dout_cost);
+struct same_knn_window_job {
+    const int32_t *rows_m = nullptr;            // aligned rows of the window: rows_m[0, *dn_m) into the moving section
+    const unsigned long long *dn_m = nullptr;
+    int64_t cap_m = 0;                          // the bound on *dn_m the launch is sized by
+    const int32_t *rows_r = nullptr;            // reference rows of the window (brute form)
+    const unsigned long long *dn_r = nullptr;
+    double box[4] = {0, 0, 0, 0};
+    int32_t *idx = nullptr, *cnt = nullptr;     // [cap_m][k], [cap_m]
+};
+int same_knn_window_batch_core(same_ctx *ctx, const same_knn_index *ix, const double *dmov_xy, const same_knn_window_job *jobs, int n_jobs, int k);
+struct same_cost_window_job {
+    const int32_t *rows = nullptr;
+    const unsigned long long *dn = nullptr;
+    int64_t cap = 0;
+    const int32_t *idx = nullptr;
+    void *out = nullptr;                        // [cap][k] in the cost type
+};
+int same_padded_cost_window_batch_core(same_ctx *ctx, int cost_f32, const void *dA, const void *dR, int T, const void *daxy_c, const void *drxy_c,
+                                       const same_cost_window_job *jobs, int n_jobs, int k, double w);

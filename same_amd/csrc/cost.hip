@@ -419,15 +419,26 @@ struct WinCost {
     const int32_t *arows;
     const unsigned long long *n_a;
 };
+// the windows of one launch (blockIdx.y = window; by value in the kernarg segment): their row lists, candidate lists and outputs
+struct WinCostBatch {
+    WinCost w[SAME_LAUNCH_WINDOWS];
+    const int32_t *idx[SAME_LAUNCH_WINDOWS];
+    void *out[SAME_LAUNCH_WINDOWS];
+};
 
 // Costs of padded candidate lists idx[(i-row_begin)*k + q] (-1 = empty -> +inf).
 template <typename F, bool WIN = false>
 __global__ __launch_bounds__(256) void padded_cost_kernel(
     const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
-    F w, F dcoef, F *__restrict__ out, WinCost win) {
+    F w, F dcoef, F *__restrict__ out, WinCostBatch wb) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if constexpr (WIN) n_slots = (int64_t)*win.n_a * k;
+    const WinCost &win = wb.w[WIN ? blockIdx.y : 0];
+    if constexpr (WIN) {
+        n_slots = (int64_t)*win.n_a * k;
+        idx = wb.idx[blockIdx.y];
+        out = static_cast<F *>(wb.out[blockIdx.y]);
+    }
     if (q >= n_slots) return;
     const int64_t j = idx[q];
     if (j < 0) { out[q] = inf_of<F>(); return; }
@@ -447,9 +458,14 @@ template <typename F, bool WIN = false>
 __global__ void padded_cost_lds_kernel(
     const F *__restrict__ A, const F *__restrict__ R, int T, const F *__restrict__ axy,
     const F *__restrict__ rxy, int64_t row_begin, int64_t n_slots, int k, const int32_t *__restrict__ idx,
-    F w, F dcoef, F *__restrict__ out, WinCost win) {
+    F w, F dcoef, F *__restrict__ out, WinCostBatch wb) {
     extern __shared__ double lds_raw[];
-    if constexpr (WIN) n_slots = (int64_t)*win.n_a * k;
+    const WinCost &win = wb.w[WIN ? blockIdx.y : 0];
+    if constexpr (WIN) {
+        n_slots = (int64_t)*win.n_a * k;
+        idx = wb.idx[blockIdx.y];
+        out = static_cast<F *>(wb.out[blockIdx.y]);
+    }
     F *lds = reinterpret_cast<F *>(lds_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const int P = T | 1;
@@ -635,10 +651,12 @@ int pair_cost_host(same_ctx *ctx, const F *A, const F *R, int64_t n_m, int64_t n
     return SAME_OK;
 }
 
+// n_win > 0: the window form -- `wb` carries n_win windows' lists and outputs (didx / dout_cost unused), row_end - row_begin is the
+// largest window's bound on its rows
 template <typename F, bool WIN = false>
 int padded_cost_dev(same_ctx *ctx, const F *dA, const F *dR, int T, const F *daxy, const F *drxy, int64_t row_begin,
-                    int64_t row_end, int k, const int32_t *didx, F w, F *dout_cost, WinCost win = WinCost{}) {
-    REQUIRE(ctx, ctx && daxy && drxy && didx && dout_cost && (T == 0 || (dA && dR)));
+                    int64_t row_end, int k, const int32_t *didx, F w, F *dout_cost, const WinCostBatch &wb = WinCostBatch{}, int n_win = 1) {
+    REQUIRE(ctx, ctx && daxy && drxy && (WIN || (didx && dout_cost)) && (T == 0 || (dA && dR)));
     REQUIRE(ctx, T >= 0 && T <= SAME_MAX_TYPES && k >= 1 && row_begin >= 0 && row_end >= row_begin);
     SAME_TRY(same_use(ctx));
     const int64_t n_slots = (row_end - row_begin) * k;   // WIN: the upper bound the launch is sized by
@@ -648,11 +666,11 @@ int padded_cost_dev(same_ctx *ctx, const F *dA, const F *dR, int T, const F *dax
     int waves = (int)std::min<size_t>(4, (size_t)65536 / per_wave);
     if (T >= 2 && waves >= 1 && n_slots >= 64 * 64) {   // LDS-staged rows; tiny inputs and very wide rows: one lane gathers its row
         // the per-wave index list sits after ALL waves' row blocks: keep it 4-byte aligned for float rows of odd pitch
-        SAME_LAUNCH(ctx, (padded_cost_lds_kernel<F, WIN>), dim3((unsigned)ceil_div(n_slots, 64 * waves)), dim3(64 * waves), waves * per_wave,
-                           dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost, win);
+        SAME_LAUNCH(ctx, (padded_cost_lds_kernel<F, WIN>), dim3((unsigned)ceil_div(n_slots, 64 * waves), (unsigned)n_win), dim3(64 * waves),
+                    waves * per_wave, dA, dR, T, daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost, wb);
     } else {
-        SAME_LAUNCH(ctx, (padded_cost_kernel<F, WIN>), dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, dA, dR, T,
-                           daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost, win);
+        SAME_LAUNCH(ctx, (padded_cost_kernel<F, WIN>), dim3((unsigned)ceil_div(n_slots, 256), (unsigned)n_win), dim3(256), 0, dA, dR, T,
+                    daxy, drxy, row_begin, n_slots, k, didx, w, w * F(0.001), dout_cost, wb);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
@@ -679,17 +697,26 @@ int launch_q32_T(same_ctx *ctx, const uint32_t *Aq, const uint32_t *Rq, const do
 
 }  // namespace
 
-// The window path's candidate-list costs (csrc/window.hip; declared in common.h): lists of rows drows[0, *dn) of the moving
-// section, candidates = reference SECTION rows; cap = the upper bound on *dn the launch is sized by.  Enqueue only.
-int same_padded_cost_window_core(same_ctx *ctx, int cost_f32, const void *dA, const void *dR, int T, const void *daxy_c, const void *drxy_c,
-                                 const int32_t *drows, const unsigned long long *dn, int64_t cap, int k, const int32_t *didx, double w,
-                                 void *dout_cost) {
-    const WinCost win{drows, dn};
+// The window path's candidate-list costs (csrc/window.hip; declared in common.h) for the windows of a batch in ONE launch: a job's
+// rows are rows[0, *dn) of the moving section, its candidates reference SECTION rows idx[cap][k]; cap = the upper bound on *dn.
+// Enqueue only.
+int same_padded_cost_window_batch_core(same_ctx *ctx, int cost_f32, const void *dA, const void *dR, int T, const void *daxy_c, const void *drxy_c,
+                                       const same_cost_window_job *jobs, int n_jobs, int k, double w) {
+    REQUIRE(ctx, n_jobs >= 1 && n_jobs <= SAME_LAUNCH_WINDOWS);
+    WinCostBatch wb{};
+    int64_t cap = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        REQUIRE(ctx, jobs[q].cap >= 0 && (jobs[q].cap == 0 || (jobs[q].idx && jobs[q].out)));
+        wb.w[q] = WinCost{jobs[q].rows, jobs[q].dn};
+        wb.idx[q] = jobs[q].idx;
+        wb.out[q] = jobs[q].out;
+        cap = std::max(cap, jobs[q].cap);
+    }
     if (cost_f32)
         return padded_cost_dev<float, true>(ctx, static_cast<const float *>(dA), static_cast<const float *>(dR), T, static_cast<const float *>(daxy_c),
-                                            static_cast<const float *>(drxy_c), 0, cap, k, didx, (float)w, static_cast<float *>(dout_cost), win);
+                                            static_cast<const float *>(drxy_c), 0, cap, k, nullptr, (float)w, nullptr, wb, n_jobs);
     return padded_cost_dev<double, true>(ctx, static_cast<const double *>(dA), static_cast<const double *>(dR), T, static_cast<const double *>(daxy_c),
-                                         static_cast<const double *>(drxy_c), 0, cap, k, didx, w, static_cast<double *>(dout_cost), win);
+                                         static_cast<const double *>(drxy_c), 0, cap, k, nullptr, w, nullptr, wb, n_jobs);
 }
 
 extern "C" {

@@ -76,18 +76,26 @@ struct WinRows {
     const unsigned long long *n_a, *n_r;
     double bx0, bx1, by0, by1;   // the window's box (grid form: a reference cell outside it is not a candidate)
 };
+// the windows of one launch (blockIdx.y = window; by value in the kernarg segment): their row lists and where their lists go
+struct WinBatch {
+    WinRows w[SAME_LAUNCH_WINDOWS];
+    int32_t *out_idx[SAME_LAUNCH_WINDOWS], *out_cnt[SAME_LAUNCH_WINDOWS];
+};
 
 template <int KNN_CAP, int KNN_RW, bool WIN = false>
 __global__ __launch_bounds__(64 * KNN_WAVES) void knn_prune_kernel(
     const double *__restrict__ axy, const double *__restrict__ rxy, int64_t n_r, int64_t row_begin,
     int64_t row_end, double r2, int k, int32_t *__restrict__ out_idx, double *__restrict__ out_d2,
-    int32_t *__restrict__ out_cnt, WinRows win) {
+    int32_t *__restrict__ out_cnt, WinBatch wb) {
     __shared__ RowList<KNN_CAP> lists[KNN_WAVES * KNN_RW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const WinRows &win = wb.w[WIN ? blockIdx.y : 0];
     if constexpr (WIN) {
         row_end = (int64_t)*win.n_a;
         n_r = (int64_t)*win.n_r;
+        out_idx = wb.out_idx[blockIdx.y];
+        out_cnt = wb.out_cnt[blockIdx.y];
     }
     const int64_t row0 = row_begin + ((int64_t)blockIdx.x * KNN_WAVES + wave) * KNN_RW;
     if (row0 >= row_end) return;
@@ -234,11 +242,16 @@ template <int KNN_CAP, bool WIN = false>
 __global__ __launch_bounds__(64 * KNN_WAVES) void knn_grid_kernel(
     const double *__restrict__ axy, const double *__restrict__ sxy, const int32_t *__restrict__ sidx,
     const unsigned *__restrict__ start, GridDesc g, int64_t row_begin, int64_t row_end, double r2, int k,
-    int32_t *__restrict__ out_idx, double *__restrict__ out_d2, int32_t *__restrict__ out_cnt, WinRows win) {
+    int32_t *__restrict__ out_idx, double *__restrict__ out_d2, int32_t *__restrict__ out_cnt, WinBatch wb) {
     __shared__ RowList<KNN_CAP> lists[KNN_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (WIN) row_end = (int64_t)*win.n_a;
+    const WinRows &win = wb.w[WIN ? blockIdx.y : 0];
+    if constexpr (WIN) {
+        row_end = (int64_t)*win.n_a;
+        out_idx = wb.out_idx[blockIdx.y];
+        out_cnt = wb.out_cnt[blockIdx.y];
+    }
     const int64_t i = row_begin + (int64_t)blockIdx.x * KNN_WAVES + wave;
     if (i >= row_end) return;
     RowList<KNN_CAP> &L = lists[wave];
@@ -376,10 +389,10 @@ int grid_query(same_ctx *ctx, const double *daxy, const GridDesc &g, const unsig
     REQUIRE(ctx, ceil_div(rows, KNN_WAVES) < (int64_t)1 << 31);
     if (k <= KNN_CAP_SMALL - 64)
         hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_SMALL>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
+                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt, WinBatch{});
     else
         hipLaunchKernelGGL(knn_grid_kernel<KNN_CAP_LARGE>, dim3((unsigned)ceil_div(rows, KNN_WAVES)), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
+                           daxy, dsxy, dsidx, dhist, g, rb, re, radius * radius, k, didx, dd2, dcnt, WinBatch{});
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -411,10 +424,10 @@ int launch_knn_brute(same_ctx *ctx, const double *daxy, const double *drxy, int6
     REQUIRE(ctx, blocks < (int64_t)1 << 31);
     if (small)
         hipLaunchKernelGGL((knn_prune_kernel<KNN_CAP_SMALL, KNN_RW_SMALL>), dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
+                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt, WinBatch{});
     else
         hipLaunchKernelGGL((knn_prune_kernel<KNN_CAP_LARGE, KNN_RW_LARGE>), dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream,
-                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt, WinRows{});
+                           daxy, drxy, n_r, rb, re, radius * radius, k, didx, dd2, dcnt, WinBatch{});
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
@@ -451,34 +464,42 @@ struct same_knn_index {
     int32_t *sidx = nullptr;
 };
 
-// The window path's prune (csrc/window.hip; declared in common.h): `ix` indexes the reference SECTION (all of its rows, built
-// once per radius); aligned rows are drows_m[0, *dn_m) of the moving section's XY, candidates the reference rows inside `box`
-// (grid form: box test on the swept cells; brute form: the window's own ascending list drows_r[0, *dn_r)).  didx[cap_m][k] gets
-// section rows (-1 padded), dcnt[cap_m] the list lengths; rows past *dn_m are not written.  Enqueue only.
-int same_knn_window_core(same_ctx *ctx, const same_knn_index *ix, const double *dmov_xy, const int32_t *drows_m,
-                         const unsigned long long *dn_m, int64_t cap_m, const int32_t *drows_r, const unsigned long long *dn_r,
-                         const double *box, int k, int32_t *didx, int32_t *dcnt) {
-    REQUIRE(ctx, ix && ix->device == ctx->device && k >= 1 && k <= SAME_MAX_KNN && cap_m >= 0);
-    if (cap_m == 0) return SAME_OK;
-    const WinRows win{drows_m, drows_r, dn_m, dn_r, box[0], box[1], box[2], box[3]};
+// The window path's prune (csrc/window.hip; declared in common.h) for the windows of a batch in ONE launch: `ix` indexes the reference
+// SECTION (all of its rows, built once per radius); a job's aligned rows are rows_m[0, *dn_m) of the moving section's XY, its
+// candidates the reference rows inside its box (grid form: box test on the swept cells; brute form: the window's own ascending list
+// rows_r[0, *dn_r)).  idx[cap_m][k] gets section rows (-1 padded), cnt[cap_m] the list lengths; rows past *dn_m are not written.
+// Enqueue only.
+int same_knn_window_batch_core(same_ctx *ctx, const same_knn_index *ix, const double *dmov_xy, const same_knn_window_job *jobs, int n_jobs, int k) {
+    REQUIRE(ctx, ix && ix->device == ctx->device && k >= 1 && k <= SAME_MAX_KNN && n_jobs >= 1 && n_jobs <= SAME_LAUNCH_WINDOWS);
+    WinBatch wb{};
+    int64_t cap = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const same_knn_window_job &j = jobs[q];
+        REQUIRE(ctx, j.cap_m >= 0);
+        wb.w[q] = WinRows{j.rows_m, j.rows_r, j.dn_m, j.dn_r, j.box[0], j.box[1], j.box[2], j.box[3]};
+        wb.out_idx[q] = j.idx;
+        wb.out_cnt[q] = j.cnt;
+        cap = std::max(cap, j.cap_m);
+    }
+    if (cap == 0) return SAME_OK;
     const bool small = k <= KNN_CAP_SMALL - 64;
     const double r2 = ix->radius * ix->radius;
     if (ix->grid) {
-        const unsigned blocks = (unsigned)ceil_div(cap_m, KNN_WAVES);
+        const dim3 blocks((unsigned)ceil_div(cap, KNN_WAVES), (unsigned)n_jobs);
         if (small)
-            SAME_LAUNCH(ctx, (knn_grid_kernel<KNN_CAP_SMALL, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0, dmov_xy, ix->sxy,
-                               ix->sidx, ix->hist, ix->g, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+            SAME_LAUNCH(ctx, (knn_grid_kernel<KNN_CAP_SMALL, true>), blocks, dim3(64 * KNN_WAVES), 0, dmov_xy, ix->sxy, ix->sidx, ix->hist, ix->g,
+                        (int64_t)0, cap, r2, k, (int32_t *)nullptr, (double *)nullptr, (int32_t *)nullptr, wb);
         else
-            SAME_LAUNCH(ctx, (knn_grid_kernel<KNN_CAP_LARGE, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0, dmov_xy, ix->sxy,
-                               ix->sidx, ix->hist, ix->g, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+            SAME_LAUNCH(ctx, (knn_grid_kernel<KNN_CAP_LARGE, true>), blocks, dim3(64 * KNN_WAVES), 0, dmov_xy, ix->sxy, ix->sidx, ix->hist, ix->g,
+                        (int64_t)0, cap, r2, k, (int32_t *)nullptr, (double *)nullptr, (int32_t *)nullptr, wb);
     } else {
-        const unsigned blocks = (unsigned)ceil_div(cap_m, KNN_WAVES * (small ? KNN_RW_SMALL : KNN_RW_LARGE));
+        const dim3 blocks((unsigned)ceil_div(cap, KNN_WAVES * (small ? KNN_RW_SMALL : KNN_RW_LARGE)), (unsigned)n_jobs);
         if (small)
-            SAME_LAUNCH(ctx, (knn_prune_kernel<KNN_CAP_SMALL, KNN_RW_SMALL, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0,
-                               dmov_xy, ix->drxy, (int64_t)0, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+            SAME_LAUNCH(ctx, (knn_prune_kernel<KNN_CAP_SMALL, KNN_RW_SMALL, true>), blocks, dim3(64 * KNN_WAVES), 0, dmov_xy, ix->drxy, (int64_t)0,
+                        (int64_t)0, cap, r2, k, (int32_t *)nullptr, (double *)nullptr, (int32_t *)nullptr, wb);
         else
-            SAME_LAUNCH(ctx, (knn_prune_kernel<KNN_CAP_LARGE, KNN_RW_LARGE, true>), dim3(blocks), dim3(64 * KNN_WAVES), 0,
-                               dmov_xy, ix->drxy, (int64_t)0, (int64_t)0, cap_m, r2, k, didx, (double *)nullptr, dcnt, win);
+            SAME_LAUNCH(ctx, (knn_prune_kernel<KNN_CAP_LARGE, KNN_RW_LARGE, true>), blocks, dim3(64 * KNN_WAVES), 0, dmov_xy, ix->drxy, (int64_t)0,
+                        (int64_t)0, cap, r2, k, (int32_t *)nullptr, (double *)nullptr, (int32_t *)nullptr, wb);
     }
     HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;

@@ -176,6 +176,14 @@ __global__ __launch_bounds__(256) void to_float_kernel(const double *__restrict_
     if (i < n) dst[i] = (float)src[i];          // round to nearest even, as numpy's astype(float32)
 }
 
+// Every kernel of the window calls takes the windows of a batch in ONE launch: blockIdx.y = window, the per-window arguments travel by
+// value in the kernarg segment (Batch<A>, at most SAME_LAUNCH_WINDOWS windows); the grid is sized by the largest window and blocks
+// beyond a window's own share leave at once.
+template <typename A>
+struct Batch {
+    A w[SAME_LAUNCH_WINDOWS];
+};
+
 // ---- rows of a section inside a box, from the cells the box covers ---------------------------------------------------------
 struct RunDesc {               // one section's share of a window
     const int32_t *order;      // the section's rows by cell
@@ -190,11 +198,19 @@ struct RunDesc {               // one section's share of a window
 
 // One thread per candidate: its place in the ascending list = the number of candidates with a smaller row = the sum over the
 // covered cells of a lower bound in that cell's (ascending) run.  No sort, no scan; rows in different cells are distinct.
-__global__ __launch_bounds__(256) void window_rows_kernel(RunDesc dm, RunDesc dr, unsigned blocks_m, double bx0, double bx1, double by0,
-                                                           double by1) {
+struct RowsArgs {
+    RunDesc dm, dr;
+    unsigned blocks_m, blocks;     // blocks [0, blocks_m) walk the moving section's candidates, [blocks_m, blocks) the reference's
+    double bx0, bx1, by0, by1;
+};
+__global__ __launch_bounds__(256) void window_rows_kernel(Batch<RowsArgs> b) {
     __shared__ unsigned lo[MAX_RUN_CELLS], hi[MAX_RUN_CELLS], pref[MAX_RUN_CELLS + 1];
+    const RowsArgs &wa = b.w[blockIdx.y];
+    if (blockIdx.x >= wa.blocks) return;
+    const unsigned blocks_m = wa.blocks_m;
+    const double bx0 = wa.bx0, bx1 = wa.bx1, by0 = wa.by0, by1 = wa.by1;
     const bool second = blockIdx.x >= blocks_m;
-    const RunDesc &d = second ? dr : dm;
+    const RunDesc &d = second ? wa.dr : wa.dm;
     const int nc = d.ncx * d.ncy;
     if (threadIdx.x < 64) {     // one wave: the cells' runs and the prefix of their lengths
         const int c = threadIdx.x;
@@ -276,12 +292,19 @@ struct RowsCompact {
     int32_t *rows;
     unsigned long long *status, *count;
 };
-__global__ __launch_bounds__(scan::NT) void rows_compact_kernel(RowsCompact cm, RowsCompact cr, unsigned blocks_m) {
+struct CompactArgs {
+    RowsCompact cm, cr;
+    unsigned blocks_m, blocks;
+};
+__global__ __launch_bounds__(scan::NT) void rows_compact_kernel(Batch<CompactArgs> bt) {
     __shared__ scan::Shared sh;
+    const CompactArgs &wa = bt.w[blockIdx.y];
+    if (blockIdx.x >= wa.blocks) return;
+    const unsigned blocks_m = wa.blocks_m;
     const bool second = blockIdx.x >= blocks_m;
-    const RowsCompact &c = second ? cr : cm;
+    const RowsCompact &c = second ? wa.cr : wa.cm;
     const int b = (int)(blockIdx.x - (second ? blocks_m : 0));
-    const int nb = (int)(second ? gridDim.x - blocks_m : blocks_m);
+    const int nb = (int)(second ? wa.blocks - blocks_m : blocks_m);
     auto val = [&](int64_t i) { return Pair{i < c.n_cand && !(c.merged[i] & OUTSIDE) ? 1u : 0u, 0u}; };
     Pair through;
     const Pair off = scan::exclusive(c.status, b, val, sh, &through);
@@ -335,10 +358,13 @@ struct ScatterArgs {
     int32_t *ua, *rows_ua, *type_c, *prow, *pairs, *jsec;
     double *axy_c, *size_c, *cost64;
     int k;
+    unsigned blocks;           // scan blocks of this window (its bound on the aligned rows)
 };
 template <typename F>
-__global__ __launch_bounds__(scan::NT) void window_scatter_kernel(ScatterArgs s) {
+__global__ __launch_bounds__(scan::NT) void window_scatter_kernel(Batch<ScatterArgs> bt) {
     __shared__ scan::Shared sh;
+    const ScatterArgs &s = bt.w[blockIdx.y];
+    if (blockIdx.x >= s.blocks) return;
     const int64_t n_m = (int64_t)s.counts[0], n_r = (int64_t)s.counts[1];
     auto val = [&](int64_t i) {
         const int c = i < n_m ? s.cnt[i] : 0;
@@ -401,7 +427,7 @@ __global__ __launch_bounds__(scan::NT) void window_scatter_kernel(ScatterArgs s)
             }
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (blockIdx.x == s.blocks - 1 && threadIdx.x == 0) {
         s.counts[2] = through.a;
         s.counts[3] = through.p;
         s.prow[through.a] = (int32_t)through.p;
@@ -412,13 +438,8 @@ __global__ __launch_bounds__(scan::NT) void window_scatter_kernel(ScatterArgs s)
 // counters of the filter: [0] kept (class 0), [1] added back, [2] cosines within `tol` of the threshold, [3] triangles left
 enum { FC_KEEP = 0, FC_ADD = 1, FC_NEAR = 2, FC_TR = 3 };
 
-// The filter's kernels take the windows of a batch in ONE launch each: blockIdx.y = window, the per-window arguments travel by value
-// (Batch<FilterArgs>, at most SAME_LAUNCH_WINDOWS of them); the grid is sized by the largest window, blocks beyond a window's own
-// share leave at once.  The filter settings are the call's: the same for every window.
-template <typename A>
-struct Batch {
-    A w[SAME_LAUNCH_WINDOWS];
-};
+// The filter's kernels take the windows of a batch in one launch each (Batch<FilterArgs>, blockIdx.y = window).  The filter settings
+// are the call's: the same for every window.
 struct FilterArgs {
     const double *xy;                  // kept aligned cells' XY
     const int32_t *raw;                // the triangulation's simplices
@@ -1034,11 +1055,16 @@ namespace {
 
 struct StagePlan {
     size_t back_bytes = 0, slots = 0;
+    RowsArgs rows{};            // window_rows_kernel's share (blocks == 0: nothing to walk)
+    CompactArgs compact{};      // rows_compact_kernel's share (blocks == 0: the box is a union of cells, or empty)
+    same_knn_window_job knn;
+    same_cost_window_job cost;
+    ScatterArgs scatter{};
 };
 
-// everything of one window's stage call up to and including its copy back (no wait): the caller holds the sections' grid locks
-int enqueue_stage(same_window *w, const same_section *mov, const same_section *ref, const double *box, int k, double dist_ct_coeff,
-                  const same_knn_index *ix, StagePlan *sp) {
+// One window's stage buffer laid out and zeroed (the whole-section path's lists copied in); no launch -- those come per GROUP of windows
+// (launch_stage).  The caller holds the sections' grid locks.
+int prepare_stage(same_window *w, const same_section *mov, const same_section *ref, const double *box, int k, StagePlan *sp) {
     same_ctx *ctx = w->ctx;
     w->staged = w->finished = w->filtered = 0;
     w->mov = mov;
@@ -1055,7 +1081,6 @@ int enqueue_stage(same_window *w, const same_section *mov, const same_section *r
     REQUIRE(ctx, cap_m * (int64_t)k < ((int64_t)1 << 31) - 1 && cap_r < ((int64_t)1 << 31) - 1);   // offsets and scan totals are 31-bit
     w->cap_m = cap_m;
     w->cap_r = cap_r;
-    const int T = mov->T;
     const size_t cs = w->cost_f32 ? sizeof(float) : sizeof(double);
     const size_t slots = (size_t)cap_m * k, cm1 = (size_t)cap_m + 1;
     const bool compact_m = cm.use_runs && !cm.aligned && cap_m > 0, compact_r = cr.use_runs && !cr.aligned && cap_r > 0;
@@ -1111,42 +1136,80 @@ int enqueue_stage(same_window *w, const same_section *mov, const same_section *r
         SAME_COPY(ctx, w->rows_r, w->full_r.p, (size_t)cap_r * 4, hipMemcpyDeviceToDevice);
         SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, dc + 1, (unsigned long long)cap_r);
     }
-    {
-        RunDesc dm{}, dr{};
-        unsigned bm = 0, br = 0;
-        if (cm.use_runs && cap_m) {
-            dm = RunDesc{mov->order, mov->starts, mov->xy, mov->grid.nx, cm.cx0, cm.ncx, cm.cy0, cm.ncy, (int)cap_m, cm.aligned ? 1 : 0, merged_m, dc};
-            bm = grid_for(cap_m);
-        }
-        if (cr.use_runs && cap_r) {
-            dr = RunDesc{ref->order, ref->starts, ref->xy, ref->grid.nx, cr.cx0, cr.ncx, cr.cy0, cr.ncy, (int)cap_r, cr.aligned ? 1 : 0, merged_r, dc + 1};
-            br = grid_for(cap_r);
-        }
-        if (bm + br) SAME_LAUNCH(ctx, window_rows_kernel, dim3(bm + br), dim3(256), 0, dm, dr, bm, box[0], box[1], box[2], box[3]);
-        if (compact_m || compact_r) {
-            const RowsCompact c_m{merged_m, compact_m ? (int)cap_m : 0, w->rows_m, scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_cm))), dc};
-            const RowsCompact c_r{merged_r, compact_r ? (int)cap_r : 0, w->rows_r, scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_cr))), dc + 1};
-            const unsigned b_m = compact_m ? scan::blocks_for(cap_m) : 0, b_r = compact_r ? scan::blocks_for(cap_r) : 0;
-            SAME_LAUNCH(ctx, rows_compact_kernel, dim3(b_m + b_r), dim3(scan::NT), 0, c_m, c_r, b_m);
-        }
+    RowsArgs &ra = sp->rows;
+    ra = RowsArgs{};
+    ra.bx0 = box[0]; ra.bx1 = box[1]; ra.by0 = box[2]; ra.by1 = box[3];
+    unsigned bm = 0, br = 0;
+    if (cm.use_runs && cap_m) {
+        ra.dm = RunDesc{mov->order, mov->starts, mov->xy, mov->grid.nx, cm.cx0, cm.ncx, cm.cy0, cm.ncy, (int)cap_m, cm.aligned ? 1 : 0, merged_m, dc};
+        bm = grid_for(cap_m);
     }
+    if (cr.use_runs && cap_r) {
+        ra.dr = RunDesc{ref->order, ref->starts, ref->xy, ref->grid.nx, cr.cx0, cr.ncx, cr.cy0, cr.ncy, (int)cap_r, cr.aligned ? 1 : 0, merged_r, dc + 1};
+        br = grid_for(cap_r);
+    }
+    ra.blocks_m = bm;
+    ra.blocks = bm + br;
+    CompactArgs &ca = sp->compact;
+    ca = CompactArgs{};
+    if (compact_m || compact_r) {
+        ca.cm = RowsCompact{merged_m, compact_m ? (int)cap_m : 0, w->rows_m, scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_cm))), dc};
+        ca.cr = RowsCompact{merged_r, compact_r ? (int)cap_r : 0, w->rows_r, scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_cr))), dc + 1};
+        ca.blocks_m = compact_m ? scan::blocks_for(cap_m) : 0;
+        ca.blocks = ca.blocks_m + (compact_r ? scan::blocks_for(cap_r) : 0);
+    }
+    sp->knn = same_knn_window_job{};
+    sp->cost = same_cost_window_job{};
+    sp->scatter = ScatterArgs{};
     if (cap_m) {
-        SAME_TRY(same_knn_window_core(ctx, ix, mov->xy, w->rows_m, dc, cap_m, w->rows_r, dc + 1, box, k, w->idx, w->cnt));
-        SAME_TRY(same_padded_cost_window_core(ctx, w->cost_f32, mov->types_c, ref->types_c, T, mov->xy_c, ref->xy_c, w->rows_m, dc, cap_m, k,
-                                              w->idx, dist_ct_coeff, cost));
-        const ScatterArgs sa{w->idx, cost, w->cnt, w->rows_m, w->rows_r, mov->xy, mov->size, mov->type_id,
-                             scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_scatter))), dc, w->ua, w->rows_ua, w->type_c, w->prow, w->pairs, w->jsec,
-                             w->axy_c, w->size_c, w->cost64, k};
-        if (w->cost_f32)
-            SAME_LAUNCH(ctx, window_scatter_kernel<float>, dim3(scan::blocks_for(cap_m)), dim3(scan::NT), 0, sa);
-        else
-            SAME_LAUNCH(ctx, window_scatter_kernel<double>, dim3(scan::blocks_for(cap_m)), dim3(scan::NT), 0, sa);
+        sp->knn.rows_m = w->rows_m; sp->knn.dn_m = dc; sp->knn.cap_m = cap_m; sp->knn.rows_r = w->rows_r; sp->knn.dn_r = dc + 1;
+        for (int q = 0; q < 4; ++q) sp->knn.box[q] = box[q];
+        sp->knn.idx = w->idx; sp->knn.cnt = w->cnt;
+        sp->cost.rows = w->rows_m; sp->cost.dn = dc; sp->cost.cap = cap_m; sp->cost.idx = w->idx; sp->cost.out = cost;
+        sp->scatter = ScatterArgs{w->idx, cost, w->cnt, w->rows_m, w->rows_r, mov->xy, mov->size, mov->type_id,
+                                  scan::arg(reinterpret_cast<unsigned long long *>(at(o_st_scatter))), dc, w->ua, w->rows_ua, w->type_c, w->prow, w->pairs,
+                                  w->jsec, w->axy_c, w->size_c, w->cost64, k, scan::blocks_for(cap_m)};
+    } else {
+        sp->knn.dn_m = dc; sp->knn.dn_r = dc + 1;     // a window without candidates still names its (zero) counts: its blocks read them and leave
+        sp->cost.dn = dc;
     }
-    HIP_TRY(ctx, hipGetLastError());
-    // ONE copy back: the four counts, then the kept aligned rows' XY and section rows at the capacity cap_m
-    SAME_COPY(ctx, w->host, dc, back_bytes, hipMemcpyDeviceToHost);
     sp->back_bytes = back_bytes;
     sp->slots = slots;
+    return SAME_OK;
+}
+
+// the stage kernels of a group of prepared windows (<= SAME_LAUNCH_WINDOWS, one pair of sections): row lists, prune, candidate costs,
+// compaction -- one launch each for the whole group
+int launch_stage(same_ctx *ctx, same_window *const *ws, StagePlan *const *sps, int n_w, const same_section *mov, const same_section *ref,
+                 const same_knn_index *ix, int k, double dist_ct_coeff) {
+    Batch<RowsArgs> rb{};
+    Batch<CompactArgs> cb{};
+    Batch<ScatterArgs> sb{};
+    same_knn_window_job kj[SAME_LAUNCH_WINDOWS];
+    same_cost_window_job cj[SAME_LAUNCH_WINDOWS];
+    unsigned max_rows = 0, max_compact = 0, max_scatter = 0;
+    for (int q = 0; q < n_w; ++q) {
+        rb.w[q] = sps[q]->rows;
+        cb.w[q] = sps[q]->compact;
+        sb.w[q] = sps[q]->scatter;
+        kj[q] = sps[q]->knn;
+        cj[q] = sps[q]->cost;
+        max_rows = std::max(max_rows, sps[q]->rows.blocks);
+        max_compact = std::max(max_compact, sps[q]->compact.blocks);
+        max_scatter = std::max(max_scatter, sps[q]->scatter.blocks);
+    }
+    const unsigned nw = (unsigned)n_w;
+    if (max_rows) SAME_LAUNCH(ctx, window_rows_kernel, dim3(max_rows, nw), dim3(256), 0, rb);
+    if (max_compact) SAME_LAUNCH(ctx, rows_compact_kernel, dim3(max_compact, nw), dim3(scan::NT), 0, cb);
+    if (max_scatter) {
+        SAME_TRY(same_knn_window_batch_core(ctx, ix, mov->xy, kj, n_w, k));
+        SAME_TRY(same_padded_cost_window_batch_core(ctx, ws[0]->cost_f32, mov->types_c, ref->types_c, mov->T, mov->xy_c, ref->xy_c, cj, n_w, k, dist_ct_coeff));
+        if (ws[0]->cost_f32)
+            SAME_LAUNCH(ctx, window_scatter_kernel<float>, dim3(max_scatter, nw), dim3(scan::NT), 0, sb);
+        else
+            SAME_LAUNCH(ctx, window_scatter_kernel<double>, dim3(max_scatter, nw), dim3(scan::NT), 0, sb);
+    }
+    HIP_TRY(ctx, hipGetLastError());
     return SAME_OK;
 }
 
@@ -1198,12 +1261,23 @@ int same_window_stage(same_window *const *windows, int n_windows, const same_sec
     // both sections' grids stay as they are until this call's kernels are enqueued (same_section_bin waits for this, then for the device)
     std::shared_lock<std::shared_mutex> grid_m(const_cast<same_section *>(mov)->grid_lock), grid_r;
     if (ref != mov) grid_r = std::shared_lock<std::shared_mutex>(const_cast<same_section *>(ref)->grid_lock);
-    // every window's fill, launches and copy back go into the stream one after the other; ONE wait for the batch -- the device works
-    // on window i while the host enqueues window i + 1
+    // every window's buffer is laid out and zeroed, then the kernels run per group of SAME_LAUNCH_WINDOWS windows (one launch each for the
+    // whole group), then every window's copy back; ONE wait for the batch
     std::vector<StagePlan> plans((size_t)n_windows);
     int rc = SAME_OK;
-    for (int i = 0; i < n_windows && rc == SAME_OK; ++i)
-        rc = enqueue_stage(windows[i], mov, ref, boxes + 4 * i, k, dist_ct_coeff, ix.get(), &plans[(size_t)i]);
+    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) rc = prepare_stage(windows[i], mov, ref, boxes + 4 * i, k, &plans[(size_t)i]);
+    for (int g = 0; g < n_windows && rc == SAME_OK; g += SAME_LAUNCH_WINDOWS) {
+        StagePlan *sps[SAME_LAUNCH_WINDOWS];
+        const int n_g = std::min(SAME_LAUNCH_WINDOWS, n_windows - g);
+        for (int q = 0; q < n_g; ++q) sps[q] = &plans[(size_t)(g + q)];
+        rc = launch_stage(ctx, windows + g, sps, n_g, mov, ref, ix.get(), k, dist_ct_coeff);
+    }
+    // ONE copy back per window: the four counts, then the kept aligned rows' XY and section rows at the capacity cap_m
+    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
+        hipError_t e = hipMemcpyAsync(windows[i]->host, windows[i]->counts, plans[(size_t)i].back_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        ++ctx->stats[SAME_STAT_COPIES];
+        if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "stage copy back", e);
+    }
     if (rc != SAME_OK) {                          // nothing of a failed batch counts; what was enqueued is waited for before returning
         (void)hipStreamSynchronize(ctx->stream);
         for (int i = 0; i < n_windows; ++i) windows[i]->staged = 0;
