@@ -184,6 +184,23 @@ struct Batch {
     A w[SAME_LAUNCH_WINDOWS];
 };
 
+// the heads of the windows' buffers zeroed in one launch (scan words, counters, marks): up to two 16-byte aligned regions per window
+struct ZeroArgs {
+    void *p[2];
+    size_t bytes[2];
+};
+__global__ __launch_bounds__(256) void zero_kernel(Batch<ZeroArgs> b) {
+    const ZeroArgs &w = b.w[blockIdx.y];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const size_t n16 = w.bytes[r] >> 4;
+        u4 *dst = static_cast<u4 *>(w.p[r]);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = u4{0u, 0u, 0u, 0u};
+        if (blockIdx.x == 0 && threadIdx.x < (w.bytes[r] & 15)) static_cast<char *>(w.p[r])[(n16 << 4) + threadIdx.x] = 0;
+    }
+}
+
 // ---- rows of a section inside a box, from the cells the box covers ---------------------------------------------------------
 struct RunDesc {               // one section's share of a window
     const int32_t *order;      // the section's rows by cell
@@ -1053,7 +1070,23 @@ void same_window_destroy(same_window *w) {
 
 namespace {
 
+// zero_kernel over a group's regions (grid-stride: at most 128 blocks per window)
+int launch_zero(same_ctx *ctx, const ZeroArgs *regions, int n_w) {
+    Batch<ZeroArgs> zb{};
+    size_t most = 0;
+    for (int q = 0; q < n_w; ++q) {
+        zb.w[q] = regions[q];
+        most = std::max(most, std::max(regions[q].bytes[0], regions[q].bytes[1]));
+    }
+    if (most == 0) return SAME_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>(128, (most + 4095) / 4096);
+    SAME_LAUNCH(ctx, zero_kernel, dim3(blocks, (unsigned)n_w), dim3(256), 0, zb);
+    return SAME_OK;
+}
+
 struct StagePlan {
+    ZeroArgs zero{};            // the head of the stage buffer
+    int64_t full_m = 0, full_r = 0;   // whole-section path: the lists' lengths, copied in after the zeroing
     size_t back_bytes = 0, slots = 0;
     RowsArgs rows{};            // window_rows_kernel's share (blocks == 0: nothing to walk)
     CompactArgs compact{};      // rows_compact_kernel's share (blocks == 0: the box is a union of cells, or empty)
@@ -1127,15 +1160,9 @@ int prepare_stage(same_window *w, const same_section *mov, const same_section *r
     w->cost64 = reinterpret_cast<double *>(at(o_cost64));
     unsigned long long *dc = w->counts;
 
-    SAME_FILL(ctx, base, 0, o_counts + 64);       // scan words + counts: ONE fill
-    if (!cm.use_runs && cap_m) {                  // the whole-section path's list and count take their places
-        SAME_COPY(ctx, w->rows_m, w->full_m.p, (size_t)cap_m * 4, hipMemcpyDeviceToDevice);
-        SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, dc, (unsigned long long)cap_m);
-    }
-    if (!cr.use_runs && cap_r) {
-        SAME_COPY(ctx, w->rows_r, w->full_r.p, (size_t)cap_r * 4, hipMemcpyDeviceToDevice);
-        SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, dc + 1, (unsigned long long)cap_r);
-    }
+    sp->zero = ZeroArgs{{base, nullptr}, {o_counts + 64, 0}};       // scan words + counts, zeroed with the group's (launch_stage)
+    sp->full_m = !cm.use_runs ? cap_m : 0;        // the whole-section path's list and count take their places after that
+    sp->full_r = !cr.use_runs ? cap_r : 0;
     RowsArgs &ra = sp->rows;
     ra = RowsArgs{};
     ra.bx0 = box[0]; ra.bx1 = box[1]; ra.by0 = box[2]; ra.by1 = box[3];
@@ -1199,6 +1226,20 @@ int launch_stage(same_ctx *ctx, same_window *const *ws, StagePlan *const *sps, i
         max_scatter = std::max(max_scatter, sps[q]->scatter.blocks);
     }
     const unsigned nw = (unsigned)n_w;
+    ZeroArgs zr[SAME_LAUNCH_WINDOWS];
+    for (int q = 0; q < n_w; ++q) zr[q] = sps[q]->zero;
+    SAME_TRY(launch_zero(ctx, zr, n_w));
+    for (int q = 0; q < n_w; ++q) {
+        same_window *w = ws[q];
+        if (sps[q]->full_m) {
+            SAME_COPY(ctx, w->rows_m, w->full_m.p, (size_t)sps[q]->full_m * 4, hipMemcpyDeviceToDevice);
+            SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, w->counts, (unsigned long long)sps[q]->full_m);
+        }
+        if (sps[q]->full_r) {
+            SAME_COPY(ctx, w->rows_r, w->full_r.p, (size_t)sps[q]->full_r * 4, hipMemcpyDeviceToDevice);
+            SAME_LAUNCH(ctx, set_count_kernel, dim3(1), dim3(1), 0, w->counts + 1, (unsigned long long)sps[q]->full_r);
+        }
+    }
     if (max_rows) SAME_LAUNCH(ctx, window_rows_kernel, dim3(max_rows, nw), dim3(256), 0, rb);
     if (max_compact) SAME_LAUNCH(ctx, rows_compact_kernel, dim3(max_compact, nw), dim3(scan::NT), 0, cb);
     if (max_scatter) {
@@ -1331,12 +1372,15 @@ namespace {
 // ---- the filter and the finish as enqueue-only halves + their read-backs, so that the two calls can also run as one ----------
 struct FilterPlan {
     FilterArgs args{};
+    void *zero = nullptr;                     // head of the filter buffer, zeroed with the group's
+    size_t zero_bytes = 0;
     unsigned long long *counters = nullptr;   // [4] FC_*
     bool readd = false;
 };
 
-// A window's filter buffer laid out and zeroed, its simplices uploaded; no launch -- those come per GROUP of windows (launch_filter)
-int prepare_filter(same_window *w, const int32_t *simplices, int64_t Tr, int ignore_same_type, int ensure_min_triangle_per_node, FilterPlan *plan) {
+// A window's filter buffer laid out (d_simplices: its triangulation, on the device already); no launch, no fill -- those come per GROUP
+// of windows (launch_filter, and the zeroing with the finish buffers')
+int prepare_filter(same_window *w, const int32_t *d_simplices, int64_t Tr, int ignore_same_type, int ensure_min_triangle_per_node, FilterPlan *plan) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua;
     const bool use_type = ignore_same_type && w->has_type;
@@ -1347,8 +1391,7 @@ int prepare_filter(same_window *w, const int32_t *simplices, int64_t Tr, int ign
                  o_any_valid = cv.take((size_t)n), o_best_p = cv.take((size_t)n * 8), o_best_t = cv.take((size_t)n * 4),
                  o_first_v = cv.take((size_t)Tr * 4);
     const size_t zero_bytes = cv.off;
-    const size_t o_raw = cv.take((size_t)Tr * 12), o_cls = cv.take((size_t)Tr), o_perim = cv.take((size_t)Tr * 8), o_klist = cv.take((size_t)Tr * 4),
-                 o_nlist = cv.take((size_t)n * 4);
+    const size_t o_cls = cv.take((size_t)Tr), o_perim = cv.take((size_t)Tr * 8), o_klist = cv.take((size_t)Tr * 4), o_nlist = cv.take((size_t)n * 4);
     SAME_TRY(ensure(ctx, w->filter, cv.off));
     SAME_TRY(ensure(ctx, w->tris, (size_t)std::max<int64_t>(Tr, 1) * 12));
     char *base = static_cast<char *>(w->filter.p);
@@ -1357,7 +1400,7 @@ int prepare_filter(same_window *w, const int32_t *simplices, int64_t Tr, int ign
     plan->counters = dc;
     FilterArgs &a = plan->args;
     a.xy = w->axy_c;
-    a.raw = reinterpret_cast<int32_t *>(at(o_raw));
+    a.raw = d_simplices;
     a.Tr = Tr;
     a.n = n;
     a.type_id = use_type ? w->type_c : nullptr;
@@ -1374,8 +1417,8 @@ int prepare_filter(same_window *w, const int32_t *simplices, int64_t Tr, int ign
     a.klist = reinterpret_cast<int32_t *>(at(o_klist));
     a.nlist = reinterpret_cast<int32_t *>(at(o_nlist));
     a.out = static_cast<int32_t *>(w->tris.p);
-    SAME_FILL(ctx, base, 0, zero_bytes);
-    SAME_COPY(ctx, at(o_raw), simplices, (size_t)Tr * 12, hipMemcpyHostToDevice);
+    plan->zero = base;
+    plan->zero_bytes = zero_bytes;
     return SAME_OK;
 }
 
@@ -1404,6 +1447,8 @@ int launch_filter(same_ctx *ctx, FilterPlan *const *plans, int n_w, double radiu
 
 struct FinishPlan {
     unsigned long long *zero = nullptr;       // head of the finish buffer: [sel | counters | point flags (padded) | matched rows]
+    void *filter_zero = nullptr;              // head of the window's filter buffer when this call filters it (zeroed in the same launch)
+    size_t filter_zero_bytes = 0;
     size_t zero_bytes = 0, back_off = 0, back_bytes = 0, o_counters = 0, o_pflag = 0, o_match_row = 0;
     same_greedy_state gs;
     int32_t *match_pair = nullptr, *match_row = nullptr;
@@ -1435,8 +1480,8 @@ int enqueue_tail(same_ctx *ctx, same_window *const *ws, FinishPlan *const *ps, i
     return SAME_OK;
 }
 
-// A window's finish buffer laid out and zeroed, its triangles uploaded (prefiltered form); no launch -- those come per GROUP of windows
-// (launch_finish).  cap_tr: the number of triangles, or (dTr != null) the bound the launch is sized by with the number itself on the device
+// A window's finish buffer laid out, its triangles uploaded (prefiltered form); no launch, no fill -- those come per GROUP of windows
+// (launch_finish; p->zero / p->zero_bytes name the head to zero).  cap_tr: the number of triangles, or (dTr != null) the bound the launch is sized by with the number itself on the device
 int prepare_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, const unsigned long long *dTr, FinishPlan *p) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua, P = w->P, n_ends = n + w->n_r;
@@ -1485,7 +1530,6 @@ int prepare_finish(same_window *w, const int32_t *host_tris, int64_t cap_tr, con
     p->cap_tr = cap_tr;
     p->dTr = dTr;
     REQUIRE(ctx, w->host_finish_off + p->back_bytes <= w->host_filter_off);   // sized by the stage call
-    SAME_FILL(ctx, base, 0, zero_bytes);
     if (host_tris && cap_tr) SAME_COPY(ctx, w->tris.p, host_tris, (size_t)cap_tr * 12, hipMemcpyHostToDevice);
     return SAME_OK;
 }
@@ -1594,8 +1638,16 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         bool filtered = false, enqueued = false;
     };
     std::vector<Item> items((size_t)n_windows);
-    // ONE wait for the batch.  Per window: its filter and finish buffers laid out and zeroed, its simplices uploaded; then per GROUP of
-    // SAME_LAUNCH_WINDOWS windows the filter's and the finish's kernels (one launch each for the whole group); then every window's copies back
+    // ONE wait for the batch.  The call's simplices go up in ONE copy (a scratch slot of the context: they are read by this call's filter
+    // only); per window its filter and finish buffers are laid out; then per GROUP of SAME_LAUNCH_WINDOWS windows the zeroing of the
+    // buffers' heads, the filter's and the finish's kernels (one launch each for the whole group); then every window's copies back
+    const int32_t *d_simplices = nullptr;
+    if (!prefiltered && simplex_offsets[n_windows] > 0) {
+        int32_t *d = nullptr;
+        SAME_TRY(slot_as(ctx, SL_TRIS, (size_t)simplex_offsets[n_windows] * 3, &d));
+        SAME_COPY(ctx, d, simplices, (size_t)simplex_offsets[n_windows] * 12, hipMemcpyHostToDevice);
+        d_simplices = d;
+    }
     int rc = SAME_OK;
     std::vector<same_window *> live;
     std::vector<FinishPlan *> plans;
@@ -1609,9 +1661,13 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         w->Tr = 0;
         if (w->n_ua == 0) continue;
         if (Tr && !prefiltered) {
-            rc = prepare_filter(w, tri, Tr, ignore_same_type, ensure_min_triangle_per_node, &it.fplan);
+            rc = prepare_filter(w, d_simplices + 3 * simplex_offsets[i], Tr, ignore_same_type, ensure_min_triangle_per_node, &it.fplan);
             if (rc == SAME_OK) rc = prepare_finish(w, nullptr, Tr, it.fplan.counters + FC_TR, &it.plan);
-            if (rc == SAME_OK) fplans.push_back(&it.fplan);
+            if (rc == SAME_OK) {
+                fplans.push_back(&it.fplan);
+                it.plan.filter_zero = it.fplan.zero;
+                it.plan.filter_zero_bytes = it.fplan.zero_bytes;
+            }
             it.filtered = true;
         } else {
             rc = prepare_finish(w, Tr ? tri : nullptr, Tr, nullptr, &it.plan);     // the caller's kept triangles (or none)
@@ -1620,6 +1676,15 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
             live.push_back(w);
             plans.push_back(&it.plan);
         }
+    }
+    for (size_t g = 0; g < live.size() && rc == SAME_OK; g += SAME_LAUNCH_WINDOWS) {      // the heads of both buffers of every window: one launch per group
+        ZeroArgs zr[SAME_LAUNCH_WINDOWS];
+        const int n_g = (int)std::min<size_t>(SAME_LAUNCH_WINDOWS, live.size() - g);
+        for (int q = 0; q < n_g; ++q) {
+            const FinishPlan *fp = plans[g + (size_t)q];
+            zr[q] = ZeroArgs{{fp->zero, fp->filter_zero}, {fp->zero_bytes, fp->filter_zero_bytes}};
+        }
+        rc = launch_zero(ctx, zr, n_g);
     }
     // groups of at most SAME_LAUNCH_WINDOWS consecutive windows that agree on what a launch fixes for all of them (windows of one call
     // usually come from one pair of sections: whether same-type triangles come back, the cost type)
