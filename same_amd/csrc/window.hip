@@ -201,6 +201,25 @@ __global__ __launch_bounds__(256) void zero_kernel(Batch<ZeroArgs> b) {
     }
 }
 
+struct CopyArgs {
+    const void *src[2];
+    void *dst[2];
+    size_t bytes[2];
+};
+__global__ __launch_bounds__(256) void copy_back_kernel(Batch<CopyArgs> b) {
+    const CopyArgs &w = b.w[blockIdx.y];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const size_t n16 = w.bytes[r] >> 4;
+        const u4 *src = static_cast<const u4 *>(w.src[r]);
+        u4 *dst = static_cast<u4 *>(w.dst[r]);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+        if (blockIdx.x == 0 && threadIdx.x < (w.bytes[r] & 15))
+            static_cast<char *>(w.dst[r])[(n16 << 4) + threadIdx.x] = static_cast<const char *>(w.src[r])[(n16 << 4) + threadIdx.x];
+    }
+}
+
 // ---- rows of a section inside a box, from the cells the box covers ---------------------------------------------------------
 struct RunDesc {               // one section's share of a window
     const int32_t *order;      // the section's rows by cell
@@ -756,6 +775,7 @@ struct same_window {
     double *weight = nullptr;
     int32_t *match_loc = nullptr;
     void *host = nullptr;     // pinned staging for everything that comes back
+    char *host_dev = nullptr; // the same block as the device addresses it (null: not addressable -- copies go through the copy engine)
     size_t host_bytes = 0;
     size_t host_finish_off = 0;   // the pinned block: [stage call's copy | finish call's copy | the filter's counters]
     size_t host_filter_off = 0;
@@ -770,11 +790,15 @@ int ensure_host(same_window *w, size_t bytes) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipHostFree(w->host));
         w->host = nullptr;
+        w->host_dev = nullptr;
         w->host_bytes = 0;
     }
     const size_t want = bytes + bytes / 4 + 4096;
     HIP_TRY(ctx, hipHostMalloc(&w->host, want, hipHostMallocDefault));
     w->host_bytes = want;
+    void *dev = nullptr;
+    w->host_dev = hipHostGetDevicePointer(&dev, w->host, 0) == hipSuccess ? static_cast<char *>(dev) : nullptr;
+    if (!w->host_dev) (void)hipGetLastError();
     return SAME_OK;
 }
 
@@ -1070,6 +1094,21 @@ void same_window_destroy(same_window *w) {
 
 namespace {
 
+// what a group of windows hands back, written straight into the windows' pinned host blocks (device-accessible: hipHostMalloc) in one
+// launch: up to two 16-byte aligned regions per window.  The stream's wait makes them the host's.
+int launch_copy_back(same_ctx *ctx, const CopyArgs *regions, int n_w) {
+    Batch<CopyArgs> cb{};
+    size_t most = 0;
+    for (int q = 0; q < n_w; ++q) {
+        cb.w[q] = regions[q];
+        most = std::max(most, std::max(regions[q].bytes[0], regions[q].bytes[1]));
+    }
+    if (most == 0) return SAME_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>(64, (most + 4095) / 4096);
+    SAME_LAUNCH(ctx, copy_back_kernel, dim3(blocks, (unsigned)n_w), dim3(256), 0, cb);
+    return SAME_OK;
+}
+
 // zero_kernel over a group's regions (grid-stride: at most 128 blocks per window)
 int launch_zero(same_ctx *ctx, const ZeroArgs *regions, int n_w) {
     Batch<ZeroArgs> zb{};
@@ -1313,11 +1352,23 @@ int same_window_stage(same_window *const *windows, int n_windows, const same_sec
         for (int q = 0; q < n_g; ++q) sps[q] = &plans[(size_t)(g + q)];
         rc = launch_stage(ctx, windows + g, sps, n_g, mov, ref, ix.get(), k, dist_ct_coeff);
     }
-    // ONE copy back per window: the four counts, then the kept aligned rows' XY and section rows at the capacity cap_m
-    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
-        hipError_t e = hipMemcpyAsync(windows[i]->host, windows[i]->counts, plans[(size_t)i].back_bytes, hipMemcpyDeviceToHost, ctx->stream);
-        ++ctx->stats[SAME_STAT_COPIES];
-        if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "stage copy back", e);
+    // what comes back per window -- the four counts, then the kept aligned rows' XY and section rows at the capacity cap_m -- in one launch
+    // per group (straight into the pinned blocks), or one copy per window where a block is not device-addressable
+    for (int g = 0; g < n_windows && rc == SAME_OK; g += SAME_LAUNCH_WINDOWS) {
+        CopyArgs ca[SAME_LAUNCH_WINDOWS];
+        const int n_g = std::min(SAME_LAUNCH_WINDOWS, n_windows - g);
+        for (int q = 0; q < n_g && rc == SAME_OK; ++q) {
+            same_window *w = windows[g + q];
+            ca[q] = CopyArgs{};
+            if (w->host_dev) {
+                ca[q] = CopyArgs{{w->counts, nullptr}, {w->host_dev, nullptr}, {plans[(size_t)(g + q)].back_bytes, 0}};
+                continue;
+            }
+            hipError_t e = hipMemcpyAsync(w->host, w->counts, plans[(size_t)(g + q)].back_bytes, hipMemcpyDeviceToHost, ctx->stream);
+            ++ctx->stats[SAME_STAT_COPIES];
+            if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "stage copy back", e);
+        }
+        if (rc == SAME_OK) rc = launch_copy_back(ctx, ca, n_g);
     }
     if (rc != SAME_OK) {                          // nothing of a failed batch counts; what was enqueued is waited for before returning
         (void)hipStreamSynchronize(ctx->stream);
@@ -1696,18 +1747,35 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         for (e = g + 1; e < live.size() && e - g < SAME_LAUNCH_WINDOWS && live[e]->cost_f32 == live[g]->cost_f32; ++e) {}
         rc = launch_finish(ctx, live.data() + g, plans.data() + g, (int)(e - g), no_match_penalty);
     }
-    for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
-        same_window *w = windows[i];
-        Item &it = items[(size_t)i];
-        if (w->n_ua == 0) continue;
-        if (it.filtered) {             // the filter's counters come back beside the finish call's block: one copy from each buffer
-            unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
-            hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-            ++ctx->stats[SAME_STAT_COPIES];
-            if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "filter counters", e);
+    // the finish block of every window and, beside it, the filter's counters: one launch per group straight into the pinned blocks (or
+    // one copy from each buffer where a block is not device-addressable)
+    {
+        CopyArgs ca[SAME_LAUNCH_WINDOWS];
+        int n_g = 0;
+        for (int i = 0; i < n_windows && rc == SAME_OK; ++i) {
+            same_window *w = windows[i];
+            Item &it = items[(size_t)i];
+            if (w->n_ua != 0) {
+                if (w->host_dev) {
+                    ca[n_g++] = CopyArgs{{it.plan.gs.sel, it.filtered ? it.fplan.counters : nullptr},
+                                         {w->host_dev + w->host_finish_off, w->host_dev + w->host_filter_off},
+                                         {it.plan.back_bytes, it.filtered ? 4 * sizeof(unsigned long long) : 0}};
+                } else {
+                    if (it.filtered) {
+                        unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
+                        hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+                        ++ctx->stats[SAME_STAT_COPIES];
+                        if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "filter counters", e);
+                    }
+                    if (rc == SAME_OK) rc = enqueue_finish_copy(w, &it.plan);
+                }
+                it.enqueued = rc == SAME_OK;
+            }
+            if (rc == SAME_OK && n_g && (n_g == SAME_LAUNCH_WINDOWS || i == n_windows - 1)) {
+                rc = launch_copy_back(ctx, ca, n_g);
+                n_g = 0;
+            }
         }
-        if (rc == SAME_OK) rc = enqueue_finish_copy(w, &it.plan);
-        it.enqueued = rc == SAME_OK;
     }
     if (rc != SAME_OK) {
         (void)hipStreamSynchronize(ctx->stream);
