@@ -421,9 +421,10 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *     sections inside the box (ascending row order), radius / k prune (src/utils.py:709-728), candidate costs (src/same.py:1180-1189),
  *     compaction of the aligned cells that have candidates and of the pair list (src/utils.py:734-742).  out_counts[4 i ..] = {aligned
  *     rows in the box, reference rows in the box, aligned rows kept, pairs}.  Reference cells are not renumbered: pair[1] / match index
- *     the window's reference rows.  Per window one fill, at most five launches and one copy back, reading O(rows of the covered cells);
- *     ONE wait for the whole batch -- the device works on window i while the host enqueues window i + 1.  The windows of a batch
- *     belong to one context and are distinct; n_windows <= SAME_WINDOW_BATCH_MAX.  If any window is refused nothing of the batch counts.
+ *     the window's reference rows.  Every kernel takes up to EIGHT windows per launch (blockIdx.y = window, their arguments by value):
+ *     per group of eight one zeroing launch, at most five kernels and one launch that writes what comes back into the windows' pinned
+ *     blocks, reading O(rows of the covered cells); ONE wait for the whole batch.  The windows of a batch belong to one context and
+ *     are distinct; n_windows <= SAME_WINDOW_BATCH_MAX.  If any window is refused nothing of the batch counts.
  *   same_window_filter_finish: for each window of the batch, the Delaunay simplices of its kept aligned cells (window i:
  *     simplices[3 simplex_offsets[i] .. 3 simplex_offsets[i+1]), offsets[0] = 0) ->
  *     - filter_triangles_by_radius on the device (src/helpers.py:233-395: classes :300-330, the keep list, the same-type triangles
@@ -441,9 +442,10 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *     violations, triangles with a violation, area flips, greedy rounds, matched cells}; out_counts[3 i ..] = {kept, added back,
  *     cosines within near_tol of cos_thr} (prefiltered: {n, 0, 0}).  When a window's third count is not zero nothing of that window
  *     counts (its slices of the outputs mean nothing, no triangles are left on the device): the caller re-decides its triangles with
- *     the reference's literal arccos (same_amd/triangles.py) and calls again for that window with prefiltered = 1.  Per window two
- *     fills, 14 launches (17 with fp64 costs) and three copies; ONE wait for the batch (more greedy rounds, in batches with a wait
- *     each, only for a window in which a pair could still be taken after the rounds enqueued up front).
+ *     the reference's literal arccos (same_amd/triangles.py) and calls again for that window with prefiltered = 1.  The call's
+ *     simplices go up in ONE copy; per group of eight windows one zeroing launch, 14 kernels (17 with fp64 costs) and one launch
+ *     that writes the answers into the pinned blocks; ONE wait for the batch (more greedy rounds, in batches with a wait each, only
+ *     for a window in which a pair could still be taken after the rounds enqueued up front).
  * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size.
  * (ABI 6: same_window_stage / same_window_filter_finish take batches; same_window_filter and same_window_finish of ABI 5 are gone --
  * the former is the latter's first half, the latter is prefiltered = 1.) */

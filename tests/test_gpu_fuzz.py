@@ -361,6 +361,68 @@ def test_device_window_argument_checks(ops):
         h.close()
 
 
+def test_window_calls_with_more_windows_than_a_launch_takes():
+    """Every kernel of the two window calls takes up to eight windows per launch (blockIdx.y = window).  A call of 23 windows of very
+    different sizes -- whole section, slivers, empty boxes, boxes that cut through cells -- runs as groups of 8 + 8 + 7; one filter_finish
+    call over windows staged on TWO pairs of sections (fp64 costs with cell types; fp32 costs without) is cut into groups that agree on
+    the cost type and on whether same-type triangles come back.  Every window must get what a call of its own gives."""
+    from scipy.spatial import Delaunay
+
+    from same_amd import windows as W
+
+    rng = np.random.default_rng(21)
+    xy = rng.uniform(0, 300, (9000, 2))
+    a = W.Section(xy, rng.gamma(0.3, 30.0, (9000, 4)), rng.integers(0, 3, 9000).astype(np.int32), rng.integers(1, 4, 9000))
+    b = W.Section(xy + rng.normal(0, 0.5, xy.shape), rng.gamma(0.3, 30.0, (9000, 4)), None, None)
+    da, db = W.DeviceSection(a, "float64"), W.DeviceSection(b, "float32")
+    boxes = [(0.0, 300.0, 0.0, 300.0), (310.0, 320.0, 0.0, 10.0), (0.0, 2.0, 0.0, 300.0)]
+    for _ in range(20):
+        x0, y0 = rng.uniform(0, 250, 2)
+        boxes.append((float(x0), float(x0 + rng.uniform(3, 120)), float(y0), float(y0 + rng.uniform(3, 120))))
+    n = len(boxes)
+    states = [W.DeviceWindow() for _ in range(n)]
+    solo = W.DeviceWindow()
+    kw = (12.0, 6, 1.0)
+    counts = W.stage_windows(states, da, da, boxes, *kw)
+    assert len({c[2] for c in counts}) > 15 and (0, 0, 0, 0) in counts        # sizes from nothing to the whole section
+    tris, want = [], []
+    for st, box, c in zip(states, boxes, counts):
+        assert solo.stage(da, da, box, *kw) == c
+        for what in (W._W_PAIRS, W._W_COSTS, W._W_ROWS_M, W._W_ALIGNED_ROWS):
+            assert np.array_equal(st.fetch(what), solo.fetch(what))
+        pts = st.fetch(W._W_ALIGNED_XY)
+        tris.append(Delaunay(pts).simplices if len(pts) >= 3 else np.zeros((0, 3), np.int32))
+        want.append(solo.filter_finish(tris[-1], 12.0, 1, 0.9, 0.0, True, 50.0) if c[2] else None)
+    # the same boxes' first seven on the other pair of sections, then ONE filter_finish call over all windows, the pairs interleaved
+    states32 = [W.DeviceWindow() for _ in range(7)]
+    counts32 = W.stage_windows(states32, db, db, boxes[:7], *kw)
+    tris32, want32 = [], []
+    for st, box, c in zip(states32, boxes[:7], counts32):
+        assert solo.stage(db, db, box, *kw) == c
+        pts = st.fetch(W._W_ALIGNED_XY)
+        tris32.append(Delaunay(pts).simplices if len(pts) >= 3 else np.zeros((0, 3), np.int32))
+        want32.append(solo.filter_finish(tris32[-1], 12.0, 1, 0.9, 0.0, True, 50.0) if c[2] else None)
+    order = [("a", q) for q in range(n) if counts[q][0] and counts[q][1]]       # a box that is empty on one side is the caller's error case: not finished
+    for q in range(7):
+        if counts32[q][0] and counts32[q][1]:
+            order.insert(3 * q + 1, ("b", q))
+    assert len(order) > 24
+    mixed = [states[q] if k == "a" else states32[q] for k, q in order]
+    got = W.filter_finish_windows(mixed, [tris[q] if k == "a" else tris32[q] for k, q in order], 12.0, 1, 0.9, 0.0, True, 50.0)
+    checked = 0
+    for (k, q), g in zip(order, got):
+        w_ = (want if k == "a" else want32)[q]
+        if w_ is None:
+            continue
+        assert g[:3] == w_[:3] and np.array_equal(g[3], w_[3]) and np.array_equal(g[4], w_[4]) and g[5] == w_[5], (k, q)
+        st = (states if k == "a" else states32)[q]
+        assert len(st.fetch(W._W_TRIANGLES)) == g[0] + g[1]
+        checked += 1
+    assert checked >= 25
+    for h in states + states32 + [solo, da, db]:
+        h.close()
+
+
 def test_prune_indices_dropped_while_other_threads_use_them():
     """A section keeps at most 16 prune indices (one per radius, least recently used dropped).  Three threads with a context each cycle
     24 radii over the SAME sections, each in its own order, so that indices are dropped from the table while another thread's stage call
