@@ -45,15 +45,18 @@ def _default_workers():
 
 
 class _TableBuilder:
-    """The device route's result table, built as the windows come: per window the section rows of the matched cells inside the central
-    trim; every `flush_every` windows their columns are gathered from the caller's frames (numpy releases the interpreter lock for the
-    copies, so a worker thread's gathers run beside the other workers and the waits for the Qhull helpers); `chunks` are concatenated
-    once at the end.  Where the frame's own columns are float64 (the usual case) the type columns and the coordinates come from the
-    sections' row-major copies: one pass of 8 (T + 2) bytes per row instead of one cache-missing pass per column."""
+    """The device route's result table.  As the windows come a builder keeps, per window, the section rows of the matched cells inside the
+    central trim (a few small index arrays); the columns are gathered from the caller's frames ONCE, when the pass is over, by `table()`:
+    the final columns are allocated at their full length and filled slice by slice on `GATHER_THREADS` threads (numpy copies without the
+    interpreter lock; the Qhull helpers are idle by then) -- no per-window frames, no concatenation.  Where the frame's own columns are
+    float64 (the usual case) the type columns and the coordinates come from the sections' row-major copies: a slice's rows are fetched as
+    whole rows (one cache line per row instead of one per column) and laid out as columns while they are in cache."""
 
-    def __init__(self, job, sections, with_ref_idx, flush_every=8):
+    SLICE = 16384        # rows per task: a slice's row-major block of type columns stays in L2 between its gather and its split
+
+    def __init__(self, job, sections, with_ref_idx):
         ref, mov = job.ref, job.moving
-        self.job, self.with_ref_idx, self.flush_every = job, with_ref_idx, flush_every
+        self.job, self.with_ref_idx = job, with_ref_idx
         self.cts, self.cid = list(job.commonCT), job.optim_params["cell_id_col"]
         f64 = np.dtype(np.float64)
         self.type_block = sections[1].types if (all(mov[c].dtype == f64 for c in self.cts) and len(set(self.cts)) == len(self.cts)) else None
@@ -64,74 +67,85 @@ class _TableBuilder:
         self.mov_size = mov["size"].to_numpy() if "size" in mov.columns else None
         self.ref_size = ref["size"].to_numpy() if "size" in ref.columns else None
         self.ref_id, self.mov_id = ref[self.cid].to_numpy(), mov[self.cid].to_numpy()
-        self.pending, self.chunks = [], []
+        self.parts = []
 
     def add(self, pos, w, dw, ref_idx=None):
         x, y = dw.axy[:, 0], dw.axy[:, 1]
         tx0, tx1, ty0, ty1 = w["trim"]                                  # central region (src/same.py:565-582), matched cells only
         c = np.flatnonzero((dw.match_row >= 0) & (x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1))
-        self.pending.append((pos, w["window_id"], dw.rows_m[c], dw.match_row[c], c, None if ref_idx is None else ref_idx[c],
-                             dw.point_flag[c], dw.flip_flag[c]))
-        if len(self.pending) >= self.flush_every:
-            self.flush()
-
-    def flush(self):
-        parts, self.pending = self.pending, []
-        if not parts or not sum(len(p[2]) for p in parts):
-            return
-        cat = lambda q: np.concatenate([p[q] for p in parts])
-        ra, rr = cat(2).astype(np.int64), cat(3).astype(np.int64)
-        take = np.take               # np.take(a, rows, axis=0) copies whole rows: 3-6x the speed of a[rows] on these (n, 8) / (n, 2) blocks
-        out = {"aligned_idx": cat(4).astype(np.int64)}
-        if self.with_ref_idx:
-            out["ref_idx"] = cat(5).astype(np.int64)
-        if self.type_block is not None:
-            block = take(self.type_block, ra, axis=0)        # (rows, T): the commonCT columns in commonCT order
-            for q, ct in enumerate(self.cts):
-                out[ct] = block[:, q]
-        else:
-            for ct, col in zip(self.cts, self.type_cols):
-                out[ct] = take(col, ra)
-        if self.mov_xy is not None:
-            axy, rxy = take(self.mov_xy, ra, axis=0), take(self.ref_xy, rr, axis=0)
-            out["X"], out["Y"], out["ref_X"], out["ref_Y"] = axy[:, 0], axy[:, 1], rxy[:, 0], rxy[:, 1]
-        else:
-            (mx, my), (rx, ry) = self.xy_cols
-            out["X"], out["Y"], out["ref_X"], out["ref_Y"] = take(mx, ra), take(my, ra), take(rx, rr), take(ry, rr)
-        out["size"] = take(self.mov_size, ra) if self.mov_size is not None else np.ones(len(ra), np.int64)
-        out["ref_size"] = take(self.ref_size, rr) if self.ref_size is not None else np.ones(len(rr), np.int64)
-        out[f"Ref_{self.cid}"] = take(self.ref_id, rr)
-        out[f"Aligned_{self.cid}"] = take(self.mov_id, ra)
-        out["time_limit_reached"] = np.zeros(len(ra), bool)
-        out["triangle_violation"] = cat(7).astype(bool)
-        out["filtered_violation"] = cat(6).astype(bool)
-        out["run_time"] = np.zeros(len(ra))
-        out["window_id"] = np.concatenate([np.full(len(p[2]), p[1], np.int64) for p in parts])
-        if self.job.mine is not None:
-            out["__plan_pos"] = np.concatenate([np.full(len(p[2]), p[0], np.int64) for p in parts])
-        self.chunks.append(out)
+        self.parts.append((pos, w["window_id"], dw.rows_m[c], dw.match_row[c], c, None if ref_idx is None else ref_idx[c],
+                           dw.point_flag[c], dw.flip_flag[c]))
 
     @staticmethod
     def table(builders):
-        """The builders' chunks laid end to end (each builder walked a contiguous run of the plan, so this is plan order)."""
-        chunks = [c for b in builders for c in b.chunks]
-        if not chunks:
-            return pd.DataFrame()
-        if len(chunks) == 1:
-            return pd.DataFrame({k: np.ascontiguousarray(v) for k, v in chunks[0].items()}, copy=False)
-        keys = list(chunks[0])
-        join = lambda k: np.concatenate([c[k] for c in chunks])
-        if sum(len(c[keys[0]]) for c in chunks) < 200_000:
-            return pd.DataFrame({k: join(k) for k in keys}, copy=False)
-        # a million rows x 22 columns is ~170 MB to copy once: the columns are joined side by side (numpy copies without the
-        # interpreter lock; the Qhull helpers are idle by now)
+        """The builders' windows laid end to end (each builder walked a contiguous run of the plan, so this is plan order)."""
         from concurrent.futures import ThreadPoolExecutor
 
         from .merge import GATHER_THREADS
 
-        with ThreadPoolExecutor(max_workers=GATHER_THREADS) as pool:
-            cols = list(pool.map(join, keys))
-        return pd.DataFrame(dict(zip(keys, cols)), copy=False)
+        parts = [p for b in builders for p in b.parts]
+        lens = [len(p[2]) for p in parts]
+        n = int(sum(lens))
+        if n == 0:
+            return pd.DataFrame()
+        me = builders[0]                 # the sources are the job's: the same for every builder
+        cat = lambda q, dt: np.concatenate([p[q] for p in parts]).astype(dt, copy=False)
+        ra, rr = cat(2, np.int64), cat(3, np.int64)
+        out = {"aligned_idx": cat(4, np.int64)}
+        if me.with_ref_idx:
+            out["ref_idx"] = cat(5, np.int64)
+        new = lambda like: np.empty(n, like.dtype)
+        for ct, src in zip(me.cts, me.type_cols if me.type_block is None else [me.type_block] * len(me.cts)):
+            out[ct] = new(src)
+        if me.mov_xy is not None:
+            for k in ("X", "Y", "ref_X", "ref_Y"):
+                out[k] = np.empty(n, np.float64)
+        else:
+            (mx, my), (rx, ry) = me.xy_cols
+            out["X"], out["Y"], out["ref_X"], out["ref_Y"] = new(mx), new(my), new(rx), new(ry)
+        out["size"] = new(me.mov_size) if me.mov_size is not None else np.ones(n, np.int64)
+        out["ref_size"] = new(me.ref_size) if me.ref_size is not None else np.ones(n, np.int64)
+        out[f"Ref_{me.cid}"], out[f"Aligned_{me.cid}"] = new(me.ref_id), new(me.mov_id)
+        out["time_limit_reached"] = np.zeros(n, bool)
+        out["triangle_violation"] = cat(7, bool)
+        out["filtered_violation"] = cat(6, bool)
+        out["run_time"] = np.zeros(n)
+        out["window_id"] = np.repeat(np.array([p[1] for p in parts], np.int64), lens)
+        if me.job.mine is not None:
+            out["__plan_pos"] = np.repeat(np.array([p[0] for p in parts], np.int64), lens)
+
+        def fill(lo):
+            hi = min(n, lo + _TableBuilder.SLICE)
+            a, r = ra[lo:hi], rr[lo:hi]
+            take = np.take           # np.take(src, rows, axis=0) copies whole rows: 3-6x the speed of src[rows] on the (n, 8) / (n, 2) blocks
+            if me.type_block is not None:
+                block = take(me.type_block, a, axis=0)       # (rows, T): the commonCT columns in commonCT order
+                for q, ct in enumerate(me.cts):
+                    out[ct][lo:hi] = block[:, q]
+            else:
+                for ct, col in zip(me.cts, me.type_cols):
+                    take(col, a, out=out[ct][lo:hi], mode="clip")       # (rows are valid: "clip" only spares numpy its bounce buffer)
+            if me.mov_xy is not None:
+                axy, rxy = take(me.mov_xy, a, axis=0), take(me.ref_xy, r, axis=0)
+                out["X"][lo:hi], out["Y"][lo:hi], out["ref_X"][lo:hi], out["ref_Y"][lo:hi] = axy[:, 0], axy[:, 1], rxy[:, 0], rxy[:, 1]
+            else:
+                (mx, my), (rx, ry) = me.xy_cols
+                for k, col, rows in (("X", mx, a), ("Y", my, a), ("ref_X", rx, r), ("ref_Y", ry, r)):
+                    take(col, rows, out=out[k][lo:hi], mode="clip")
+            if me.mov_size is not None:
+                take(me.mov_size, a, out=out["size"][lo:hi], mode="clip")
+            if me.ref_size is not None:
+                take(me.ref_size, r, out=out["ref_size"][lo:hi], mode="clip")
+            take(me.ref_id, r, out=out[f"Ref_{me.cid}"][lo:hi], mode="clip")
+            take(me.mov_id, a, out=out[f"Aligned_{me.cid}"][lo:hi], mode="clip")
+
+        starts = range(0, n, _TableBuilder.SLICE)
+        if len(starts) == 1:
+            fill(0)
+        else:
+            with ThreadPoolExecutor(max_workers=GATHER_THREADS) as pool:
+                list(pool.map(fill, starts))
+        return pd.DataFrame(out, copy=False)
 
 
 def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None, use_device=True):
@@ -257,15 +271,13 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
         for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator)):
             if dw.error is not None:
                 raise dw.error
-            with stage("table rows (central trim) + columns (every 8 windows)"):
+            with stage("table rows (central trim)"):
                 builders[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
                 st = dw.stats
                 rec = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
                        "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
             with lock:
                 stats[pos] = rec
-        with stage("table rows (central trim) + columns (every 8 windows)"):
-            builders[q].flush()
 
     if n_workers == 1:
         walk(0)
@@ -283,7 +295,7 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
         [t.join() for t in threads]
         if errors:
             raise errors[0]
-    with stage("table (chunks laid end to end)"):
+    with stage("table (columns gathered on the gather threads)"):
         table = _TableBuilder.table(builders)
     if job.all_matches:                      # rows of windows finished by an earlier run (resume)
         table = pd.concat(job.all_matches + ([table] if len(table) else []), ignore_index=True)

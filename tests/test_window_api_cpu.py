@@ -84,8 +84,8 @@ def _fake_window(rng, n_rows, n_ref, pos, trim):
 
 
 @pytest.mark.parametrize("float_columns", [True, False])
-def test_table_builder_makes_the_reference_table(float_columns):
-    """incumbent._TableBuilder (the device route's result table, gathered per 8 windows) against the same table made the way run_same's
+def test_table_builder_makes_the_reference_table(float_columns, monkeypatch):
+    """incumbent._TableBuilder (the device route's result table, gathered when the pass is over) against the same table made the way run_same's
     post-solve makes it -- `.map` of the source columns by matched row (src/same.py:1264-1278), central trim (:565-582), window id --
     with float64 columns (row-major block gathers) and with integer type / coordinate columns (per-column gathers, dtypes kept)."""
     from same_amd.incumbent import _TableBuilder
@@ -100,9 +100,9 @@ def test_table_builder_makes_the_reference_table(float_columns):
     job = types.SimpleNamespace(ref=ref, moving=mov, commonCT=cts, optim_params={"cell_id_col": "Cell_Num_Old"}, mine=None)
     sections = (Section.from_frame(ref, cts), Section.from_frame(mov, cts))
     rng = np.random.default_rng(9)
-    b = _TableBuilder(job, sections, with_ref_idx=False, flush_every=4)
+    b = _TableBuilder(job, sections, with_ref_idx=False)
     want = []
-    for pos in range(11):                       # 11 windows: two flushes of four + the rest at the end
+    for pos in range(11):
         dw, w = _fake_window(rng, 400, 300, pos, (50.0, 450.0, 100.0, 500.0))
         dw.axy = mov[["X", "Y"]].to_numpy(dtype=np.float64)[dw.rows_m]
         b.add(pos, w, dw)
@@ -125,11 +125,13 @@ def test_table_builder_makes_the_reference_table(float_columns):
         central = t[(t["X"] >= 50.0) & (t["X"] < 450.0) & (t["Y"] >= 100.0) & (t["Y"] < 500.0)].copy()
         central["window_id"] = w["window_id"]
         want.append(central)
-    b.flush()
     got, want = _TableBuilder.table([b]), pd.concat(want, ignore_index=True)
     assert list(got.columns) == list(want.columns) and len(got) == len(want) > 300
     for c in got.columns:
         assert got[c].dtype == want[c].dtype and np.array_equal(got[c].to_numpy(), want[c].to_numpy()), c
+    monkeypatch.setattr(_TableBuilder, "SLICE", 37)              # many slices: the fill runs on the gather threads
+    sliced = _TableBuilder.table([b])
+    assert list(sliced.columns) == list(got.columns) and all(sliced[c].dtype == got[c].dtype for c in got.columns) and sliced.equals(got)
 
 
 def test_timing_double_installs_and_restores_gurobipy():
