@@ -118,11 +118,15 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
         # (an aligned cell proposed for two references, a reference proposed to two aligned cells) need the graph algorithm -- in a
         # tiled run these are the cells of the window overlaps at most.  row_of[a] = the position in `kept` of a's matched edge.
         deg_a, deg_r = np.bincount(a_codes, minlength=n_a), np.bincount(r_codes, minlength=n_r)
-        lone = (deg_a[a_codes] == 1) & (deg_r[r_codes] == 1)
-        rest = np.flatnonzero(~lone)
         row_of = np.full(n_a, -1, np.int64)
-        lone_at = np.flatnonzero(lone)
-        row_of[a_codes[lone_at]] = lone_at
+        if len(a_codes) == 0 or (deg_a.max() <= 1 and deg_r.max() <= 1):      # nobody disagrees (a tiled run whose overlaps agree): all edges stand
+            rest = np.zeros(0, np.int64)
+            row_of[a_codes] = np.arange(len(a_codes), dtype=np.int64)
+        else:
+            lone = (deg_a[a_codes] == 1) & (deg_r[r_codes] == 1)
+            rest = np.flatnonzero(~lone)
+            lone_at = np.flatnonzero(lone)
+            row_of[a_codes[lone_at]] = lone_at
         graph = None
         if len(rest):
             # the contested cells renumbered densely IN THE ORDER of their ids (node numbers come from the sorted ids, and every
