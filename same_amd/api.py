@@ -58,6 +58,7 @@ class PreparedInputs:
         self.optim_params, self.gurobi_params = optim_params, gurobi_params
         self._cache = {}
         self.device = None          # the DeviceWindowResult this was made from (the device-resident window path), else None
+        self.sources = None         # there: (the caller's moving frame, reference frame) -- rows_m / rows_r index them
 
     @property
     def aligned_df(self):

@@ -59,14 +59,17 @@ class _TableBuilder:
         self.job, self.with_ref_idx = job, with_ref_idx
         self.cts, self.cid = list(job.commonCT), job.optim_params["cell_id_col"]
         f64 = np.dtype(np.float64)
+        # a frame's column may be a strided view of its block (a frame made from a 2-D array): np.take would copy such a source whole on
+        # EVERY call, so the 1-D sources are made contiguous here, once per job (no copy where they already are)
+        col = lambda df, c: np.ascontiguousarray(df[c].to_numpy())
         self.type_block = sections[1].types if (all(mov[c].dtype == f64 for c in self.cts) and len(set(self.cts)) == len(self.cts)) else None
-        self.type_cols = None if self.type_block is not None else [mov[c].to_numpy() for c in self.cts]
+        self.type_cols = None if self.type_block is not None else [col(mov, c) for c in self.cts]
         both_xy = all(df[c].dtype == f64 for df in (ref, mov) for c in ("X", "Y"))
         self.mov_xy, self.ref_xy = (sections[1].xy, sections[0].xy) if both_xy else (None, None)
-        self.xy_cols = None if both_xy else ([mov[c].to_numpy() for c in ("X", "Y")], [ref[c].to_numpy() for c in ("X", "Y")])
-        self.mov_size = mov["size"].to_numpy() if "size" in mov.columns else None
-        self.ref_size = ref["size"].to_numpy() if "size" in ref.columns else None
-        self.ref_id, self.mov_id = ref[self.cid].to_numpy(), mov[self.cid].to_numpy()
+        self.xy_cols = None if both_xy else ([col(mov, c) for c in ("X", "Y")], [col(ref, c) for c in ("X", "Y")])
+        self.mov_size = col(mov, "size") if "size" in mov.columns else None
+        self.ref_size = col(ref, "size") if "size" in ref.columns else None
+        self.ref_id, self.mov_id = col(ref, self.cid), col(mov, self.cid)
         self.parts = []
 
     def add(self, pos, w, dw, ref_idx=None):
@@ -206,13 +209,36 @@ def _window_table(prep, commonCT, ai, ri, flip_node, pflag, with_ref_idx):
 
 
 def _table_of_device_window(prep, dw, commonCT, with_ref_idx):
+    """The window's table from what the device left: the columns are read from the CALLER's frames by section row (prep.rows_m, the
+    matched reference's section row), so the window's own two frames -- rows of the caller's, made on first access -- are never made."""
     ai = np.flatnonzero(dw.match_row >= 0)
-    # rows_r (ascending section rows of the compacted reference frame) -> the compacted index of every matched reference cell
-    ri = np.searchsorted(prep.rows_r, dw.match_row[ai])
+    rj = dw.match_row[ai].astype(np.int64)                    # section rows of the matched reference cells
     st = dw.stats
     stats = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
              "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
-    return _window_table(prep, commonCT, ai, ri, dw.flip_flag, dw.point_flag, with_ref_idx), stats
+    sources = getattr(prep, "sources", None)
+    if sources is None:
+        # rows_r (ascending section rows of the compacted reference frame) -> the compacted index of every matched reference cell
+        return _window_table(prep, commonCT, ai, np.searchsorted(prep.rows_r, rj), dw.flip_flag, dw.point_flag, with_ref_idx), stats
+    a_src, r_src = sources
+    ra, cid = np.asarray(prep.rows_m, dtype=np.int64)[ai], prep.optim_params["cell_id_col"]
+    out = {"aligned_idx": ai.astype(np.int64)}
+    if with_ref_idx:
+        out["ref_idx"] = np.searchsorted(prep.rows_r, rj).astype(np.int64)
+    # (plain indexing: a frame's column may be a strided view of its block, which np.take would first copy whole -- once per call)
+    for ct in list(commonCT) + ["X", "Y"]:
+        out[ct] = a_src[ct].to_numpy()[ra]
+    for ct in ("X", "Y"):
+        out[f"ref_{ct}"] = r_src[ct].to_numpy()[rj]
+    out["size"] = a_src["size"].to_numpy()[ra] if "size" in a_src.columns else np.ones(len(ra), np.int64)       # src/same.py:934-940
+    out["ref_size"] = r_src["size"].to_numpy()[rj] if "size" in r_src.columns else np.ones(len(rj), np.int64)
+    out[f"Ref_{cid}"] = r_src[cid].to_numpy()[rj]
+    out[f"Aligned_{cid}"] = a_src[cid].to_numpy()[ra]
+    out["time_limit_reached"] = np.zeros(len(ai), bool)
+    out["triangle_violation"] = dw.flip_flag[ai].astype(bool)
+    out["filtered_violation"] = dw.point_flag[ai].astype(bool)
+    out["run_time"] = np.zeros(len(ai))
+    return pd.DataFrame(out, copy=False), stats      # the columns are this function's own arrays: no consolidating copy
 
 
 def _device_ref_idx(dw):

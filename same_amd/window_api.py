@@ -211,7 +211,7 @@ def _prepared_from_device(dw, frames, optim_params, gurobi_params, verbose=True,
     prep = PreparedInputs(lambda: _window_frame(frames.moving, rows_m, vertex_col, aligned=True), lambda: _window_frame(frames.ref, rows_r),
                           valid_pairs, costs, tris, weights, signs, set(), False, optim_params, gurobi_params,
                           n_aligned=len(rows_m), n_ref=len(rows_r))
-    prep.device, prep.rows_m, prep.rows_r = dw, rows_m, rows_r
+    prep.device, prep.rows_m, prep.rows_r, prep.sources = dw, rows_m, rows_r, (frames.moving, frames.ref)
     return prep
 
 
@@ -408,8 +408,8 @@ class _WindowJob:
         """Central trim + bookkeeping of one window's matches (src/same.py:565-590)."""
         if window_matches.shape[0] > 0:
             tx0, tx1, ty0, ty1 = w["trim"]
-            central = window_matches[(window_matches["X"] >= tx0) & (window_matches["X"] < tx1)
-                                     & (window_matches["Y"] >= ty0) & (window_matches["Y"] < ty1)].copy()
+            x, y = window_matches["X"].to_numpy(), window_matches["Y"].to_numpy()       # the same comparisons on the columns' arrays
+            central = window_matches[(x >= tx0) & (x < tx1) & (y >= ty0) & (y < ty1)].copy()
             central["window_id"] = w["window_id"]
             if self.mine is not None:
                 central["__plan_pos"] = pos          # lets the sharded wrapper restore the single-process window order

@@ -83,7 +83,7 @@ def _fake_window(rng, n_rows, n_ref, pos, trim):
                                  flip_flag=(rng.random(120) < 0.1).astype(np.uint8)), dict(trim=trim, window_id=100 + pos)
 
 
-@pytest.mark.parametrize("float_columns", [True, False])
+@pytest.mark.parametrize("float_columns", [True, False, "strided columns, string ids"])
 def test_table_builder_makes_the_reference_table(float_columns, monkeypatch):
     """incumbent._TableBuilder (the device route's result table, gathered when the pass is over) against the same table made the way run_same's
     post-solve makes it -- `.map` of the source columns by matched row (src/same.py:1264-1278), central trim (:565-582), window id --
@@ -96,6 +96,16 @@ def test_table_builder_makes_the_reference_table(float_columns, monkeypatch):
         for df in (ref, mov):
             df["c1"] = (df["c1"] * 10).astype(np.int64)
             df["X"] = df["X"].round().astype(np.int64)
+    if isinstance(float_columns, str):
+        # frames made from ONE 2-D array: every numeric column is a strided view of the block; ids that are strings (object columns)
+        def restride(df):
+            num = [c for c in df.columns if df[c].dtype.kind in "fi" and c != "Cell_Num_Old"]
+            out = pd.DataFrame(np.ascontiguousarray(df[num].to_numpy(dtype=np.float64)), columns=num)
+            out["cell_type"] = df["cell_type"].to_numpy()
+            out["Cell_Num_Old"] = np.array([f"cell-{v}" for v in df["Cell_Num_Old"]], dtype=object)
+            assert not out["c1"].to_numpy().flags.c_contiguous
+            return out
+        ref, mov = restride(ref), restride(mov)
     mov["size"] = np.arange(400) % 3 + 1
     job = types.SimpleNamespace(ref=ref, moving=mov, commonCT=cts, optim_params={"cell_id_col": "Cell_Num_Old"}, mine=None)
     sections = (Section.from_frame(ref, cts), Section.from_frame(mov, cts))
