@@ -1,31 +1,33 @@
-// window.hip -- one window of the sliding-window path (src/same.py:507-593) with both sections RESIDENT on the device.
+// window.hip -- the windows of the sliding-window path (src/same.py:507-593) with both sections RESIDENT on the device.
 //
 // A section's columns are uploaded once (same_section) and its rows are binned once into a grid of cells
-// (same_section_bin: rows sorted by cell, ascending inside a cell) -- SURVEY a13's "one-pass bin".  A window is then
+// (same_section_bin: rows sorted by cell, ascending inside a cell) -- SURVEY a13's "one-pass bin".  A BATCH of windows is then two calls:
 //
-//   same_window_stage   the rows of both sections inside the box, ascending (= np.flatnonzero of src/same.py:293-295), built from
-//                       the few cells the box covers: a row's place in the list is the number of smaller rows in those cells
-//                       (one binary search per cell), so the call reads O(window) rows whatever the section's size; radius / k
-//                       prune against the reference SECTION's grid index (src/utils.py:709-728; candidates outside the box are
-//                       not candidates), costs of the candidate lists in the cost type (src/same.py:1180-1189), compaction of the
-//                       aligned side and of the pair list (src/utils.py:734-742).  Back to the host in ONE copy: four counts, the
-//                       kept aligned rows and their XY -- the input of the host's Delaunay call (src/same.py:1023).
-//   same_window_filter  the Delaunay simplices in; triangle classes (src/helpers.py:300-330), the keep list and the same-type
-//                       triangles added back so that every node keeps one (src/helpers.py:331-340, :365-389) -- all on the
-//                       device, in the reference's order.  (A cosine within 8 ulp of the angle threshold is left to the host,
-//                       which re-decides it with the reference's literal arccos: the call then only reports it.)
-//   same_window_finish  kept triangles in (or the ones same_window_filter left on the device); source signs / weights
-//                       (src/same.py:1128-1146), per-row minimum and the greedy MIP start (src/init_helpers.py:104-133), the
-//                       lazy-constraint body under that incumbent (src/same.py:645-669), XY-order sweep
-//                       (src/violationhelper.py:53-117), signed-area flips (src/same.py:1362-1402).  Back to the host in ONE copy:
-//                       the matched reference row per kept aligned cell, the per-cell violation flag and eight counters.
-//   same_window_filter_finish = the last two with no host round trip between them.
+//   same_window_stage          per window the rows of both sections inside the box, ascending (= np.flatnonzero of src/same.py:293-295),
+//                              built from the few cells the box covers: a row's place in the list is the number of smaller rows in those
+//                              cells (one binary search per cell), so the call reads O(window) rows whatever the section's size; radius / k
+//                              prune against the reference SECTION's grid index (src/utils.py:709-728; candidates outside the box are
+//                              not candidates), costs of the candidate lists in the cost type (src/same.py:1180-1189), compaction of the
+//                              aligned side and of the pair list (src/utils.py:734-742).  Back to the host: four counts, the kept
+//                              aligned rows and their XY -- the input of the host's Delaunay call (src/same.py:1023).
+//   same_window_filter_finish  per window the Delaunay simplices in; triangle classes (src/helpers.py:300-330), the keep list and the
+//                              same-type triangles added back so that every node keeps one (src/helpers.py:331-340, :365-389) -- all on
+//                              the device, in the reference's order (a cosine within 8 ulp of the angle threshold is left to the host,
+//                              which re-decides it with the reference's literal arccos and calls again with prefiltered = 1: the kept
+//                              triangles in, no filter); source signs / weights (src/same.py:1128-1146), per-row minimum and the greedy
+//                              MIP start (src/init_helpers.py:104-133), the lazy-constraint body under that incumbent
+//                              (src/same.py:645-669), XY-order sweep (src/violationhelper.py:53-117), signed-area flips
+//                              (src/same.py:1362-1402).  Back to the host: the matched reference row per kept aligned cell, the
+//                              per-cell violation flags and eight counters.
 //
-// Nothing a call computes is sized by a number the host has to wait for: lists are allocated for the candidates of the covered
-// cells (known from the host's copy of the cell offsets), their true lengths stay in a counter block on the device and every
-// kernel reads them there.  A call is one fill (its counters and scan words), its launches, one copy back, ONE wait:
-// same_ctx_stat counts them, tests/test_gpu_run_same.py holds the per-window totals.  Ordered compactions are single launches
-// over many blocks (scan.h).
+// Every kernel takes up to SAME_LAUNCH_WINDOWS (8) windows per launch: blockIdx.y = window, the per-window arguments -- pointers into
+// the window's OWN buffers, its counts -- travel by value in the kernarg segment (Batch<Args>), the grid is sized by the group's largest
+// window and blocks beyond a window's share leave at once.  A call lays every window's buffers out (prepare_*), then per group of
+// eight: one launch that zeroes the heads of their buffers (scan words, counters, marks), the kernels, one launch that writes what
+// comes back straight into the windows' pinned host blocks; ONE wait per call.  Nothing a call computes is sized by a number the host
+// has to wait for: lists are allocated for the candidates of the covered cells (known from the host's copy of the cell offsets), their
+// true lengths stay in a counter block on the device and every kernel reads them there.  same_ctx_stat counts the runtime calls,
+// tests/test_gpu_run_same.py holds the per-window totals.  Ordered compactions are single launches over many blocks (scan.h).
 //
 // Reference cells keep their SECTION rows through prune, costs and sweeps; the window's own numbering (position in the ascending
 // list of reference rows in the box -- what the reference's frames would index before src/utils.py:740-742 drops the unreferenced)
