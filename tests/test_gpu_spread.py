@@ -140,7 +140,9 @@ def test_time_bound_stops_the_search_not_the_allocation(ctx, monkeypatch):
     monkeypatch.setenv("SAME_SPREAD_MAX_SECONDS", "0.05")
     b = ctx.alloc_spread(8 << 30)
     si = b.spread_info
-    assert b.ptr and (si["spread"] is False or si["seconds"] < 3.0)
+    # what the bound changes is countable: no chunk beyond the buffer's own eight was taken and labelled (taking and labelling those
+    # eight is already past 0.05 s).  How long that takes is the box's business (1-4 s on this pool): only a hang would fail the time.
+    assert b.ptr and (si["spread"] is False or (si["examined"] == si["chunks_gib"] == 8 and si["seconds"] < 30.0)), si
     ctx.check(ctx.lib.same_dev_memset(ctx.handle, b.ptr, 0x11, 8 << 30), "memset")
     ctx.sync()
     assert (b.download((1 << 20,), np.uint8, offset_bytes=5 << 30) == 0x11).all()
