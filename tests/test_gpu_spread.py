@@ -140,9 +140,11 @@ def test_time_bound_stops_the_search_not_the_allocation(ctx, monkeypatch):
     monkeypatch.setenv("SAME_SPREAD_MAX_SECONDS", "0.05")
     b = ctx.alloc_spread(8 << 30)
     si = b.spread_info
-    # what the bound changes is countable: no chunk beyond the buffer's own eight was taken and labelled (taking and labelling those
-    # eight is already past 0.05 s).  How long that takes is the box's business (1-4 s on this pool): only a hang would fail the time.
-    assert b.ptr and (si["spread"] is False or (si["examined"] == si["chunks_gib"] == 8 and si["seconds"] < 30.0)), si
+    # what the bound changes is countable: the search for better-balanced chunks ends after a handful of extra chunks (taking and
+    # labelling one is ~10 ms: 14 examined on this pool) instead of walking the 128-chunk look-ahead -- by the bound
+    # (`stopped_at_time_bound`) or because the choice was balanced before it.  The call's own time is mostly giving chunks back to the
+    # card and is the box's business (2-4 s on this pool): only a hang would fail it.
+    assert b.ptr and (si["spread"] is False or (8 <= si["examined"] < 8 + 64 and si["seconds"] < 30.0)), si
     ctx.check(ctx.lib.same_dev_memset(ctx.handle, b.ptr, 0x11, 8 << 30), "memset")
     ctx.sync()
     assert (b.download((1 << 20,), np.uint8, offset_bytes=5 << 30) == 0x11).all()
