@@ -9,6 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROUNDS = int(os.environ.get("SAME_FUZZ_ROUNDS", "1"))   # soak runs: more rounds = more seeds (round 0 is the default suite)
+FIRST = int(os.environ.get("SAME_FUZZ_FIRST_ROUND", "0"))   # ... and a later soak continues where an earlier one stopped (other seeds)
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +32,7 @@ def _points(rng, n, side, mode):
 
 
 def test_fuzz_knn_and_costs(ops, oracle):
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"knn/cost soak round {rnd}", flush=True)
         rng = np.random.default_rng(2024 + 7919 * rnd)
@@ -77,7 +78,7 @@ def test_fuzz_knn_and_costs(ops, oracle):
 
 def test_fuzz_triangles_and_sweeps(ops, oracle):
     from scipy.spatial import Delaunay
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"triangle/sweep soak round {rnd}", flush=True)
         rng = np.random.default_rng(77 + 7919 * rnd)
@@ -124,7 +125,7 @@ def test_fuzz_triangles_and_sweeps(ops, oracle):
 
 
 def test_fuzz_matching_from_x_and_greedy(ops, oracle):
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"matching soak round {rnd}", flush=True)
         rng = np.random.default_rng(5 + 7919 * rnd)
@@ -169,7 +170,7 @@ def test_fuzz_knn_index_and_block_sweeps(ops, oracle):
 
     ctx = _lib.default_context()
     L, H = ctx.lib, ctx.handle
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         rng = np.random.default_rng(911 + 7919 * rnd)
         for case in range(40):
             n_m, n_r = int(rng.integers(1, 600)), int(rng.choice([0, 1, 50, 900, 2100, 4000]))
@@ -220,7 +221,7 @@ def test_fuzz_merge_dedup(ops, oracle):
     """The window-merge de-duplication (csrc/merge.hip) against the oracle on random tables: sizes that fall on either side of
     the wave, of the 2 048-key LDS sort block and of the first global bitonic stages; few or many windows (long runs of equal
     sort keys apart from the row index); pair codes drawn from tiny to sparse id spaces; all / none / some rows violating."""
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"merge soak round {rnd}", flush=True)
         rng = np.random.default_rng(77 + 104729 * rnd)
@@ -245,7 +246,7 @@ def test_fuzz_device_windows(ops):
 
     from same_amd import windows as W
 
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"device window soak round {rnd}", flush=True)
         rng = np.random.default_rng(77 + 104729 * rnd)
@@ -517,7 +518,7 @@ def test_fuzz_window_pipelines_agree():
     from same_amd.windows import window_plan
 
     done = errors = 0
-    for rnd in range(ROUNDS):
+    for rnd in range(FIRST, FIRST + ROUNDS):
         if ROUNDS > 1 and rnd % 20 == 0:
             print(f"window pipelines soak round {rnd}", flush=True)
         rng = np.random.default_rng(31337 + 104729 * rnd)
