@@ -273,12 +273,12 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                                  "threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
                "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
                "merged_matches": int(len(merged)),
-               "roofline": {"bound": "hbm", "kernel": "window pipeline: many small gather / latency-bound kernels (the padded / pair cost kernel is the largest)",
+               "roofline": {"bound": "hbm", "kernel": "window pipeline: gather / latency-bound kernels that take a group of eight windows per launch (greedy rounds, prune and the compactions lead)",
                             "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
                             "traffic": None, "algorithmic_bytes_per_step": touched,
                             "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
-                                    "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by launch latency and host "
-                                    "glue, not by HBM -- see host_glue_share"},
+                                    "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by the host's Delaunay "
+                                    "calls (Qhull: qhull_wait_share), not by HBM or by the GPU"},
                "product_function": "same_amd.sliding_window_incumbent (sliding_window_matching's arguments; the greedy MIP start as every window's "
                                    "solution) -- the timed step IS a call of it per rank" + (", on frames made resident before the timed region" if on_device else ""),
                "api_path_windows_per_s": None if api_path is None else api_path["api_path_windows_per_s"], "api_path": api_path,
