@@ -101,7 +101,10 @@ def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _d
         missing = [c for c in required if c not in merged_df.columns]
         if missing:
             raise ValueError(f"Missing required columns in matches: {missing}")
-        merged_df["filtered_violation"] = merged_df["filtered_violation"].fillna(True).astype(bool)
+        fv = merged_df["filtered_violation"]
+        if fv.dtype != bool:          # .fillna(True).astype(bool) of src/helpers.py:746-751 on the column's array (the pandas call warns about its own downcast)
+            v = fv.to_numpy()
+            merged_df["filtered_violation"] = np.where(pd.isna(v), True, v.astype(bool))
     # one row per (aligned, ref) pair: non-violating first, then the smaller window id, then the earlier row (:748-753);
     # the ids may be anything hashable, the device sees integer codes of them (equal id <=> equal code)
     if _dedup is None:
