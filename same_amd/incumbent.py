@@ -187,58 +187,50 @@ def incumbent_of_prepared(prep, commonCT, with_ref_idx=True, ctx=None, use_devic
     return _window_table(prep, commonCT, ai, ri, flip_node, pflag, with_ref_idx), stats
 
 
-def _window_table(prep, commonCT, ai, ri, flip_node, pflag, with_ref_idx):
-    """run_same's post-solve match table (src/same.py:1264-1278, :1464-1470) for matched aligned rows `ai` -> reference rows `ri`"""
-    a_df, r_df, cid = prep.aligned_df, prep.ref_df, prep.optim_params["cell_id_col"]
-    out = {"aligned_idx": ai.astype(np.int64)}
-    if with_ref_idx:
-        out["ref_idx"] = ri.astype(np.int64)
+def _match_table(a_df, r_df, ra, rr, commonCT, cid, aligned_idx, ref_idx, triangle_violation, filtered_violation):
+    """run_same's post-solve match table (src/same.py:1264-1278, :1464-1470): the columns of the matched cells read from `a_df` / `r_df`
+    at rows `ra` / `rr` -- a window's own two frames at its own indices, or the CALLER's frames at section rows (the same values: a
+    window's frames are rows of the caller's).  Plain indexing: a frame's column may be a strided view of its block, which np.take would
+    first copy whole."""
+    out = {"aligned_idx": aligned_idx.astype(np.int64)}
+    if ref_idx is not None:
+        out["ref_idx"] = ref_idx.astype(np.int64)
     for ct in list(commonCT) + ["X", "Y"]:
-        out[ct] = a_df[ct].to_numpy()[ai]
+        out[ct] = a_df[ct].to_numpy()[ra]
     for ct in ("X", "Y"):
-        out[f"ref_{ct}"] = r_df[ct].to_numpy()[ri]
-    out["size"] = a_df["size"].to_numpy()[ai]
-    out["ref_size"] = r_df["size"].to_numpy()[ri]
-    out[f"Ref_{cid}"] = r_df[cid].to_numpy()[ri]
-    out[f"Aligned_{cid}"] = a_df[cid].to_numpy()[ai]
-    out["time_limit_reached"] = np.zeros(len(ai), bool)
-    out["triangle_violation"] = flip_node[ai].astype(bool)
-    out["filtered_violation"] = pflag[ai].astype(bool)
-    out["run_time"] = np.zeros(len(ai))
-    return pd.DataFrame(out)
+        out[f"ref_{ct}"] = r_df[ct].to_numpy()[rr]
+    out["size"] = a_df["size"].to_numpy()[ra] if "size" in a_df.columns else np.ones(len(ra), np.int64)       # src/same.py:934-940
+    out["ref_size"] = r_df["size"].to_numpy()[rr] if "size" in r_df.columns else np.ones(len(rr), np.int64)
+    out[f"Ref_{cid}"] = r_df[cid].to_numpy()[rr]
+    out[f"Aligned_{cid}"] = a_df[cid].to_numpy()[ra]
+    out["time_limit_reached"] = np.zeros(len(ra), bool)
+    out["triangle_violation"] = np.asarray(triangle_violation).astype(bool)
+    out["filtered_violation"] = np.asarray(filtered_violation).astype(bool)
+    out["run_time"] = np.zeros(len(ra))
+    return pd.DataFrame(out, copy=False)      # the columns are this function's own arrays: no consolidating copy
+
+
+def _window_table(prep, commonCT, ai, ri, flip_node, pflag, with_ref_idx):
+    """the table of matched aligned rows `ai` -> reference rows `ri` of the window's own (compacted) frames"""
+    return _match_table(prep.aligned_df, prep.ref_df, ai, ri, commonCT, prep.optim_params["cell_id_col"], ai, ri if with_ref_idx else None,
+                        flip_node[ai], pflag[ai])
 
 
 def _table_of_device_window(prep, dw, commonCT, with_ref_idx):
-    """The window's table from what the device left: the columns are read from the CALLER's frames by section row (prep.rows_m, the
+    """The window's table from what the device left.  The columns are read from the CALLER's frames by section row (prep.rows_m, the
     matched reference's section row), so the window's own two frames -- rows of the caller's, made on first access -- are never made."""
     ai = np.flatnonzero(dw.match_row >= 0)
     rj = dw.match_row[ai].astype(np.int64)                    # section rows of the matched reference cells
     st = dw.stats
     stats = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
              "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
-    sources = getattr(prep, "sources", None)
-    if sources is None:
-        # rows_r (ascending section rows of the compacted reference frame) -> the compacted index of every matched reference cell
-        return _window_table(prep, commonCT, ai, np.searchsorted(prep.rows_r, rj), dw.flip_flag, dw.point_flag, with_ref_idx), stats
-    a_src, r_src = sources
-    ra, cid = np.asarray(prep.rows_m, dtype=np.int64)[ai], prep.optim_params["cell_id_col"]
-    out = {"aligned_idx": ai.astype(np.int64)}
-    if with_ref_idx:
-        out["ref_idx"] = np.searchsorted(prep.rows_r, rj).astype(np.int64)
-    # (plain indexing: a frame's column may be a strided view of its block, which np.take would first copy whole -- once per call)
-    for ct in list(commonCT) + ["X", "Y"]:
-        out[ct] = a_src[ct].to_numpy()[ra]
-    for ct in ("X", "Y"):
-        out[f"ref_{ct}"] = r_src[ct].to_numpy()[rj]
-    out["size"] = a_src["size"].to_numpy()[ra] if "size" in a_src.columns else np.ones(len(ra), np.int64)       # src/same.py:934-940
-    out["ref_size"] = r_src["size"].to_numpy()[rj] if "size" in r_src.columns else np.ones(len(rj), np.int64)
-    out[f"Ref_{cid}"] = r_src[cid].to_numpy()[rj]
-    out[f"Aligned_{cid}"] = a_src[cid].to_numpy()[ra]
-    out["time_limit_reached"] = np.zeros(len(ai), bool)
-    out["triangle_violation"] = dw.flip_flag[ai].astype(bool)
-    out["filtered_violation"] = dw.point_flag[ai].astype(bool)
-    out["run_time"] = np.zeros(len(ai))
-    return pd.DataFrame(out, copy=False), stats      # the columns are this function's own arrays: no consolidating copy
+    # rows_r (ascending section rows of the compacted reference frame) -> the compacted index of every matched reference cell
+    ri = np.searchsorted(prep.rows_r, rj) if (with_ref_idx or prep.sources is None) else None
+    if prep.sources is None:
+        return _window_table(prep, commonCT, ai, ri, dw.flip_flag, dw.point_flag, with_ref_idx), stats
+    a_src, r_src = prep.sources
+    return _match_table(a_src, r_src, np.asarray(prep.rows_m, dtype=np.int64)[ai], rj, commonCT, prep.optim_params["cell_id_col"], ai, ri,
+                        dw.flip_flag[ai], dw.point_flag[ai]), stats
 
 
 def _device_ref_idx(dw):
