@@ -221,9 +221,7 @@ def _table_of_device_window(prep, dw, commonCT, with_ref_idx):
     matched reference's section row), so the window's own two frames -- rows of the caller's, made on first access -- are never made."""
     ai = np.flatnonzero(dw.match_row >= 0)
     rj = dw.match_row[ai].astype(np.int64)                    # section rows of the matched reference cells
-    st = dw.stats
-    stats = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
-             "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
+    stats = _device_stats(dw)
     # rows_r (ascending section rows of the compacted reference frame) -> the compacted index of every matched reference cell
     ri = np.searchsorted(prep.rows_r, rj) if (with_ref_idx or prep.sources is None) else None
     if prep.sources is None:
@@ -231,6 +229,13 @@ def _table_of_device_window(prep, dw, commonCT, with_ref_idx):
     a_src, r_src = prep.sources
     return _match_table(a_src, r_src, np.asarray(prep.rows_m, dtype=np.int64)[ai], rj, commonCT, prep.optim_params["cell_id_col"], ai, ri,
                         dw.flip_flag[ai], dw.point_flag[ai]), stats
+
+
+def _device_stats(dw):
+    """a window's stats record (STAT_KEYS) from what the device counted"""
+    st = dw.stats
+    return {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
+            "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
 
 
 def _device_ref_idx(dw):
@@ -291,9 +296,7 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
                 raise dw.error
             with stage("table rows (central trim)"):
                 builders[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
-                st = dw.stats
-                rec = {"pairs": dw.counts[3], "triangles": dw.n_triangles, "checked": st["checked"], "flipped": st["flipped"],
-                       "xy_violations": st["xy_violations"], "area_flips": st["area_flips"], "matched": st["matched"]}
+                rec = _device_stats(dw)
             with lock:
                 stats[pos] = rec
 
