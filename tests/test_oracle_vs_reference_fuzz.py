@@ -12,6 +12,8 @@ import numpy as np
 import pandas as pd
 import pytest
 
+SEED = 1000 * int(os.environ.get("SAME_REF_FUZZ_SEED", "0"))      # other seeds for a longer run (0 = the suite's own cases)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference is not mounted here")
 
@@ -51,7 +53,7 @@ def _cells(rng, n, side, T=3, with_size=True):
 
 def test_prune_and_priority_filter(ref, oracle):
     """utils.find_knn_within_radius (src/utils.py:709-742) and knn_utils.find_knn_with_cell_type_priority (src/knn_utils.py:5-78)."""
-    rng = np.random.default_rng(101)
+    rng = np.random.default_rng(101 + SEED)
     nonempty = 0
     for case in range(60):
         a, r = _cells(rng, int(rng.integers(1, 120)), 60.0), _cells(rng, int(rng.integers(1, 150)), 60.0)
@@ -74,7 +76,7 @@ def test_triangle_filter_info_and_order_sweep(ref, oracle):
     violationhelper.verify_spatial_preservation (src/violationhelper.py:1-134)."""
     from scipy.spatial import Delaunay
 
-    rng = np.random.default_rng(202)
+    rng = np.random.default_rng(202 + SEED)
     kept_any = violated_any = 0
     for case in range(50):
         a = _cells(rng, int(rng.integers(4, 160)), 80.0)
@@ -125,7 +127,7 @@ def test_triangle_filter_info_and_order_sweep(ref, oracle):
 def test_mip_start_heuristics(ref, oracle):
     """init_helpers.compute_mip_start_pairs (src/init_helpers.py:46-177): greedy with exact cost ties (Python's stable sort decides),
     rows that prefer to stay unmatched, the Hungarian start with its size cut-off."""
-    rng = np.random.default_rng(303)
+    rng = np.random.default_rng(303 + SEED)
     for case in range(80):
         n_a, n_r = int(rng.integers(1, 40)), int(rng.integers(1, 40))
         pairs = [(int(i), int(j)) for i in range(n_a) for j in rng.choice(n_r, int(rng.integers(0, min(n_r, 5) + 1)), replace=False)]
@@ -144,7 +146,7 @@ def test_window_loop_with_rows_that_have_no_coordinates(ref, oracle):
     """sliding_window_matching's tiling / merging / trimming (src/same.py:481-590) RUN AS-IS with run_same replaced by a recorder, on
     layouts in which some rows have NaN coordinates: pandas' min / max skip them (:481-482), no window receives them, and the job runs.
     The oracle's window_plan must name the same windows, hand each the same cells in the same order and keep the same central rows."""
-    rng = np.random.default_rng(404)
+    rng = np.random.default_rng(404 + SEED)
     calls = []
 
     def recorder(aligned_df, ref_df, commonCT, optim_params, gurobi_params, outprefix, aligned_delaunay, aligned_delaunay_vertex_col,
@@ -201,7 +203,7 @@ def test_inline_loops_of_run_same(ref, oracle):
 
     import gen_golden as gg          # tools/ (on sys.path through the `ref` fixture): loads the reference the same way
 
-    rng = np.random.default_rng(505)
+    rng = np.random.default_rng(505 + SEED)
     flips = checked_total = 0
     for case in range(25):
         T = int(rng.integers(1, 6))
@@ -250,7 +252,7 @@ def test_inline_loops_of_run_same(ref, oracle):
 def test_metacell_collapse(ref, oracle):
     """metacell_utils.greedy_triangle_collapse (src/metacell_utils.py:160-561) on random small sections: size limits 1 .. 9, r_max / angle
     rules on and off, an extra text column carried along."""
-    rng = np.random.default_rng(606)
+    rng = np.random.default_rng(606 + SEED)
     collapsed = 0
     for case in range(14):
         df = _cells(rng, int(rng.integers(6, 140)), float(rng.choice([30.0, 60.0])), T=2, with_size=False)
@@ -267,4 +269,4 @@ def test_metacell_collapse(ref, oracle):
         assert np.array_equal(np.asarray(want.metacell_delaunay, dtype=np.int64).reshape(-1, 3), np.asarray(gtri, dtype=np.int64).reshape(-1, 3)), case
         assert np.array_equal(np.asarray(want.original_delaunay, dtype=np.int64).reshape(-1, 3), np.asarray(gorig, dtype=np.int64).reshape(-1, 3)), case
         collapsed += len(df) - len(wdf)
-    assert collapsed > 100
+    assert collapsed > (100 if SEED == 0 else 40)        # coverage of the suite's own seed; other seeds (SAME_REF_FUZZ_SEED) collapse 90-130
