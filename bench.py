@@ -89,6 +89,9 @@ def parse():
                          "host, every kernel through host buffers: the pipeline of rounds 1-3, kept measurable)")
     ap.add_argument("--cfg5-threads", type=int, default=None,
                     help="--workload cfg5: worker threads (contexts) walking this rank's windows (default: 2 on the device pipeline, 4 on the column one)")
+    ap.add_argument("--cfg5-deal", choices=("block", "round_robin"), default="block",
+                    help="--workload cfg5: how the windows are dealt to the ranks: 'block' = runs of the plan (strips of the window grid: the window "
+                         "merge only has the strips' borders to settle between ranks), 'round_robin' = every N-th window, heaviest first")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:

@@ -6,10 +6,11 @@ import time
 
 from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 
-RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s", "aligned_cells_per_window",
-               "windows_per_s_triangulations_given", "per_rank",
-               "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step",
-               "threads_per_rank", "runtime_calls_per_window", "qhull", "table_allgather", "merged_matches", "parity_spot_check", "rccl",
+RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s",
+               "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged", "per_rank",
+               "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
+               "after_windows_s_per_step", "unsharded_s_per_step", "merge_stages_s_per_step_rank0", "amdahl_bound_at_8_ranks", "amdahl",
+               "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "qhull", "merged_matches", "parity_spot_check", "rccl",
                "product_function", "api_path_windows_per_s", "api_path", "window_calls_only_windows_per_s")
 
 
@@ -17,7 +18,8 @@ def record(line):
     """The sub-record a bench line of another workload carries as `cfg5`: the cfg 5 line's own numbers, without its prose."""
     rec = {k_: line.get(k_) for k_ in RECORD_KEYS if k_ in line}
     rec["workload"], rec["pipeline"] = line["config"]["workload"], line["config"]["pipeline"]
-    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks, fp32 costs, all sweeps, tables exchanged once and merged) measured in "
+    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks in runs of the plan, fp32 costs, all sweeps, the window merge per rank "
+                   "with one exchange of the seam rows) measured in "
                    "this job, on its ranks, contexts and communicator, after this line's own timed region; windows_per_s is the whole job's")
     return rec
 
@@ -45,10 +47,9 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     import same_amd
     from same_amd import _lib, _trace, synth
     from same_amd.incumbent import incumbent_of_prepared
-    from same_amd.merge import merge_window_matches_unique_ref
-    from same_amd.dist import allgather_table, last_table_gather
+    from same_amd.dist import MergeChannel
     from same_amd import windows as W
-    from same_amd.windows import assign_windows, window_plan
+    from same_amd.windows import deal_windows, window_plan
 
     _trace.enable(True)
     _lib.instrument()
@@ -60,18 +61,18 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     cols = synth.type_columns(T)
     op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32", window_size=1200, overlap=300, min_cells_per_window=10)
     plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
-    mine = assign_windows(plan, group.world)[group.rank]
-    my_plan = [plan[q] for q in mine]
-    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)}")
+    deal = getattr(args, "cfg5_deal", None) or "block"
+    owner = deal_windows(plan, group.world, deal)
+    my_plan = [plan[q] for q in np.flatnonzero(owner == group.rank)]
+    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)} ({deal} deal)")
 
-    TABLE_COLUMNS = (("Aligned_Cell_Num_Old", np.int64), ("Ref_Cell_Num_Old", np.int64), ("X", np.float64), ("Y", np.float64),
-                     ("filtered_violation", bool), ("window_id", np.int64))
     on_device = args.cfg5_pipeline == "device"
     # device pipeline: the two frames go to the device ONCE, before the timed region (inputs resident, as the bench contract asks), and
     # every step's call names them; frames pipeline: the frames themselves
     resident = same_amd.resident_frames(r_df, m_df, ctx=ctx) if on_device else None
     frame_args = (resident, resident) if on_device else (r_df, m_df)
-    shard = (group.rank, group.world) if group.world > 1 else None
+    shard = (group.rank, group.world, deal) if group.world > 1 else None
+    channel = MergeChannel(group, ctx, comm) if group.world > 1 else None      # carries the seam rows of the window merge (one small all-gather)
 
     from same_amd import qhull_pool as _share
 
@@ -81,10 +82,11 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     tri_cache = [None]        # set for the diagnostic pass after the timed loop (triangulations remembered: Qhull out of the picture)
     worker_ctx = [ctx]        # the product function makes (and closes) the other workers' contexts itself; their calls are summed by _lib.instrument
 
-    def one_pass(_windows=None):
-        """this rank's share of the plan through the product function -> (its table as a frame, per-window stats)"""
+    def one_pass(merge=True):
+        """this rank's share of the plan through the product function, window merge included -> (its part of the merged table, per-window stats)"""
         kw = dict(workers=n_workers, triangulator=tri_cache[0]) if on_device else dict(_route="general", _pipeline="frames")
-        return same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), return_stats=True, ctx=ctx, _shard=shard, **kw)
+        return same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), return_stats=True, ctx=ctx, _shard=shard,
+                                                 merge=merge, _merge_channel=channel if merge else None, **kw)
 
     def all_ranks(fn, *a):
         """fn(*a) on this rank; if ANY rank raised, every rank raises (so that no rank walks into a collective the others never reach)."""
@@ -99,35 +101,18 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
             raise err
         return out
 
-    pass_seconds = [0.0]      # wall time of the window passes inside the timed loop (the threads' capacity is this x threads + the serial rest)
-
     def step():
-        t_pass = time.perf_counter()
-        tab, stats = all_ranks(one_pass, my_plan)
-        pass_seconds[0] += time.perf_counter() - t_pass
-        mine_tab = {c: (tab[c].to_numpy().astype(dt, copy=False) if len(tab) else np.zeros(0, dt)) for c, dt in TABLE_COLUMNS}
-        mine_tab["filtered_violation"] = mine_tab["filtered_violation"].view(np.uint8)
-        with _trace.stage("table exchange (all-gather)"):
-            every = allgather_table(ctx, comm, group, mine_tab)          # the ONE exchange: one table per rank, a device all-gather
-            if comm is not None:
-                ms, nbytes = last_table_gather()
-                exchange_ms.append(ms)
-                exchange_bytes[0] = nbytes
-        merged = None
-        if group.rank == 0:                                              # the merged table is the job's result: rank 0 holds it
-            with _trace.stage("merge (device de-duplication + host matching)"):
-                frames = [pd.DataFrame(dict(t, filtered_violation=np.asarray(t["filtered_violation"]).view(bool)), copy=False) for t in every if len(t["X"])]
-                merged = merge_window_matches_unique_ref(frames)
-        return merged, stats
+        # ONE call of the product function per rank: its windows, the merge of what only this rank can see, the exchange of the seam rows,
+        # the common seam step, the columns of the rows that stay.  The merged table is the job's result and stays dealt over the ranks
+        # (every part in the order of the aligned ids; dist.sharded_merged_window_incumbent(gather=...) joins them where a caller wants one frame)
+        return all_ranks(one_pass)
 
     from same_amd import qhull_pool as _qp
-
-    exchange_ms, exchange_bytes = [], [0]
 
     # warm-up: scratch slots, Qhull helpers, first-launch costs -- and, on the device path, every window state a worker keeps
     # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
     for _ in range(min(warmup, 1)):     # one whole pass: the sections go up and are binned, the plan and the type sets are remembered,
-        all_ranks(one_pass, my_plan)    # every window state a worker keeps in flight gets its buffers (they stay with the contexts)
+        all_ranks(one_pass)             # every window state a worker keeps in flight gets its buffers (they stay with the contexts)
     group.barrier()
     _trace.reset()
     calls0 = [c.stats() for c in worker_ctx]
@@ -150,15 +135,20 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # DIAGNOSTIC, outside the timed region and never part of `value`: the same pass with every window's triangulation remembered from a
     # first pass -- what the library calls + the Python glue cost once Qhull is out of the picture, i.e. the rate a host with enough
     # CPU per rank could approach (on this box the timed pass is bound by its 16 CPUs' worth of Qhull)
-    no_qhull = calls_only = None
+    no_qhull = no_qhull_merged = calls_only = None
     if on_device:
         tri_cache[0] = W.TriangulationCache()
-        all_ranks(one_pass, my_plan)                       # fills the cache
+        all_ranks(one_pass, False)                         # fills the cache
         group.barrier()
         tq = time.perf_counter()
         for _ in range(2):
-            all_ranks(one_pass, my_plan)
+            all_ranks(one_pass, False)                     # the product function's table of every window, as in round 5 (no merge)
         no_qhull = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
+        group.barrier()
+        tq = time.perf_counter()
+        for _ in range(2):
+            all_ranks(one_pass)                            # ... and with the window merge, as the timed step runs it
+        no_qhull_merged = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
         # ... and the window calls alone (stage + filter_finish in batches, the per-window Python of iter_device_windows; no table): one thread
         frames_obj = next(iter(resident._frames.values()))
 
@@ -182,14 +172,25 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
 
         calls_only = {"one_thread": calls_only_pass(1), "worker_threads": n_workers, "with_the_worker_threads": calls_only_pass(n_workers)}
         tri_cache[0] = None
-    # what the threads could have used: every worker for the window passes, one thread for the exchange + merge behind them
-    thread_seconds = max(pass_seconds[0] * n_workers + (wall_here - pass_seconds[0]), 1e-9)
+    # after a rank's last window: the merge (keys, de-duplication, matching; the seam rows' exchange and the common seam step) and the
+    # columns of the rows that stay -- one thread, while the workers' threads are done
+    seconds_of = lambda prefix: sum(sec for name, (_c, sec) in rep.items() if name.startswith(prefix))
+    merge_s, table_s = seconds_of("merge:"), seconds_of("table (columns")
+    unsharded_s = seconds_of("merge: seam rows exchanged") + seconds_of("merge: seam step")
+    walk_s = max(wall_here - merge_s - table_s, 1e-9)
+    # what the threads could have used: every worker for the window passes, one thread for what comes after them
+    thread_seconds = max(walk_s * n_workers + merge_s + table_s, 1e-9)
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * steps / wall_here,
                 "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / thread_seconds, "threads": n_workers,
                 "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / thread_seconds),
-                "qhull_wait_share": qhull_wait / thread_seconds, "serial_tail_s_per_step": (wall_here - pass_seconds[0]) / steps,
-                "windows_per_s_triangulations_given": no_qhull, "window_calls_only_windows_per_s": calls_only,
-                "runtime_calls_per_window": calls_per_window, "table_allgather_ms": (sum(exchange_ms) / len(exchange_ms)) if exchange_ms else None,
+                "qhull_wait_share": qhull_wait / thread_seconds, "serial_tail_s_per_step": merge_s / steps,
+                "table_gather_s_per_step": table_s / steps, "unsharded_s_per_step": unsharded_s / steps,
+                "merge_stages_s_per_step": {name: sec / steps for name, (_c, sec) in sorted(rep.items()) if name.startswith("merge:")},
+                "windows_per_s_triangulations_given": no_qhull, "windows_per_s_triangulations_given_merged": no_qhull_merged,
+                "window_calls_only_windows_per_s": calls_only, "merged_rows": int(len(merged)),
+                "seam_rows_sent_per_step": None if channel is None else channel.sent_rows / max(1, steps + min(warmup, 1) + (2 if on_device else 0)),
+                "seam_gather_ms": None if channel is None else channel.gather_ms / max(1, steps + min(warmup, 1) + (2 if on_device else 0)),
+                "runtime_calls_per_window": calls_per_window,
                 "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
                 "triangles": int(sum(s["triangles"] for s in stats))}
@@ -200,95 +201,182 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     cpu, parity = None, "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
     if group.rank == 0 and group.world == 1 and cpu_baseline is not None:
         cpu, parity = cpu_baseline(dict(plan=plan, my_plan=my_plan, r_df=r_df, m_df=m_df, cols=cols, op=op, ctx=ctx, on_device=on_device))
-    # THE REFERENCE'S OWN SIGNATURE, timed (rank 0, after the timed region, never part of `value`): sliding_window_matching on this job's frames
-    #   (a) with `incumbent_of_prepared` standing in for the solver half of run_same -- the signature, the window loop, the pre-MIP path on
-    #       the device, PreparedInputs (7 arrays fetched per window), a frame per window, the central trim: everything but Gurobi's side;
-    #   (b) on a few windows with a do-nothing `gurobipy` in place (bench_solver_double): run_same's own model assembly, MIP start, lazy
-    #       callback and post-solve tables in Python -- what a licensed run pays per window on top of (a) before the solver does anything.
-    api_path = None
+    # THE REFERENCE'S OWN SIGNATURE, timed (rank 0, after the timed region, never part of `value`): sliding_window_matching on this job's
+    # frames (a) with `incumbent_of_prepared` standing in for the solver half of run_same, (b) on a few windows with a do-nothing
+    # `gurobipy` in place (bench_solver_double): what a licensed run pays per window in Python before the solver does anything.
+    api_path = amdahl = None
     if group.rank == 0 and not getattr(args, "no_extras", False):
         api_path = _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, cols, op, plan, on_device, _trace)
+        kw = dict(workers=n_workers) if on_device else dict(_route="general", _pipeline="frames")
+        whole = same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), ctx=ctx, **kw)
+        amdahl = _amdahl_at_8_ranks(whole, plan, deal, every, steps, group.world)
     out = None
     if group.rank == 0:
-        total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
-        es, k = 4, 8
-        P, Tr = sum(r["pairs"] for r in every), sum(r["triangles"] for r in every)
-        touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)   # SURVEY 8d per-unit figures
-        lib_s = max(r["in_library_s"] for r in every) / steps
-        out = {"metric": baseline_metric(), "value": total_pairs * steps / dt, "unit": "cell-pairs/s", "n_gpus": group.world,
-               "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{int(np.mean([w['n_mov'] for w in plan]))} "
-                                      f"aligned cells each), T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, "
-                                      "orientation + XY-order + area-flip sweeps per window, window tables exchanged once and merged",
-                          "pipeline": ("device: same_amd.sliding_window_incumbent on resident frames -- both sections in HBM, binned on the window grid, "
-                                       "two library calls per window (csrc/window.hip); the host triangulates (Qhull helpers) and receives the match; the "
-                                       "table's columns are gathered once per pass" if on_device
-                                       else "frames: same_amd.sliding_window_incumbent, general route on host frames -- every window's frames cut on the "
-                                            "host, every kernel through host buffers, a DataFrame per window"),
-                          "parallelism": f"whole windows round-robin (heaviest first) x{group.world}; no collective inside a window; one all-gather of the "
-                                         "ranks' match tables per pass" + (f": {transport}" if comm is not None else "")},
-               "windows_per_s": len(plan) * steps / dt,
-               "aligned_cells_per_s": float(sum(w["n_mov"] for w in plan)) * steps / dt,
-               "aligned_cells_per_window": float(np.mean([w["n_mov"] for w in plan])),
-               "per_rank": {"windows": [r["windows"] for r in every], "windows_per_s": [r["windows_per_s"] for r in every],
-                            "host_glue_share": [r["host_glue_share"] for r in every], "python_share": [r["python_share"] for r in every],
-                            "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
-                            "in_library_s_per_step": [r["in_library_s"] / steps for r in every],
-                            "table_allgather_ms": [r["table_allgather_ms"] for r in every], "qhull_helpers": [r["qhull_helpers"] for r in every],
-                            "windows_per_s_triangulations_given": [r["windows_per_s_triangulations_given"] for r in every],
-                            "qhull_l3_domains": [r["qhull_domains"] for r in every]},
-               "host_glue_share": mine_rec["host_glue_share"],
-               "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the window passes x threads + "
-                                        "wall time of the exchange and merge behind them, which one thread runs), "
-                                        "rank 0: Python / numpy / scipy glue, waiting for the Qhull helpers and the table exchange included",
-               "python_share": mine_rec["python_share"],
-               "qhull_wait_share": mine_rec["qhull_wait_share"],
-               "qhull_wait_share_means": "the worker threads' waits for the Qhull helpers (hand-over when all are busy + collecting answers) over the same "
-                                         "capacity: host_glue_share = qhull_wait_share + python_share",
-               "serial_tail_s_per_step": mine_rec["serial_tail_s_per_step"],
-               "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes of the "
-                                     "threads' time (the merge and the table exchange included)",
-               "threads_per_rank": n_workers,
-               "windows_per_s_triangulations_given": None if no_qhull is None else sum(r["windows_per_s_triangulations_given"] or 0.0 for r in every),
-               "windows_per_s_triangulations_given_means": "DIAGNOSTIC, not a throughput: the rate of two extra passes (windows only: no exchange, no merge) "
-                                                           "in which every window's Delaunay simplices are remembered from an earlier pass, summed over "
-                                                           "the ranks -- what the library calls and the Python glue allow once Qhull is out of the picture",
-               "window_calls_only_windows_per_s": mine_rec["window_calls_only_windows_per_s"],
-               "window_calls_only_means": "DIAGNOSTIC, rank 0: windows.iter_device_windows over this rank's windows with the triangulations "
-                                          "remembered and nothing done with the results -- the two batched library calls per eight windows and the "
-                                          "generator's own Python, on one thread and on the product function's worker threads (a context = stream "
-                                          "each); the product function adds the table (about 1 MB of gathered columns per window)",
-               "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
-               "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued per window on rank 0, "
-                                                 "counted by the library itself (same_ctx_stat) over the timed passes; the merge's de-duplication included",
-               "table_allgather": None if comm is None else {
-                   "ms": mine_rec["table_allgather_ms"], "bytes_per_rank": int(exchange_bytes[0]), "bytes_total": int(exchange_bytes[0]) * group.world,
-                   "timed_with": ("HIP events on the stream the all-gather ran on (same_comm_gather_time), rank 0" if not comm.synchronous
-                                  else "host wall time of the host-transport exchange (no RCCL communicator), rank 0")},
-               "qhull": {"helpers": _qp.pool().n, "helpers_all_ranks": sum(r["qhull_helpers"] for r in every), "ranks_on_this_host": every[0]["local_world"],
-                         "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
-                         "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / steps,
-                         "what": "helper processes that run scipy.spatial.Delaunay for the windows ahead (a6 stays on the host); waiting = the worker "
-                                 "threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
-               "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
-               "merged_matches": int(len(merged)),
-               "roofline": {"bound": "hbm", "kernel": "window pipeline: gather / latency-bound kernels that take a group of eight windows per launch (greedy rounds, prune and the compactions lead)",
-                            "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "algorithmic_bytes_per_step": touched,
-                            "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k per aligned "
-                                    "cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by the host's Delaunay "
-                                    "calls (Qhull: qhull_wait_share), not by HBM or by the GPU"},
-               "product_function": "same_amd.sliding_window_incumbent (sliding_window_matching's arguments; the greedy MIP start as every window's "
-                                   "solution) -- the timed step IS a call of it per rank" + (", on frames made resident before the timed region" if on_device else ""),
-               "api_path_windows_per_s": None if api_path is None else api_path["api_path_windows_per_s"], "api_path": api_path,
-               "cpu_baseline": cpu, "parity_spot_check": parity}
+        out = _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device, n_workers,
+                    cpu, parity, api_path, amdahl, _qp)
         if rccl is not None:
             out["rccl"] = rccl
     group.barrier()
     if resident is not None:
         resident.close()
     return out if group.rank == 0 else None
+
+
+def _amdahl_at_8_ranks(whole, plan, deal, every, steps, world):
+    """DIAGNOSTIC (rank 0, after the timed region): what bounds this configuration at 8 ranks, from this job's own stage times.
+
+    A step is this much work: the windows, the columns of the final table, the merge of what a rank can see alone -- all of it dealt
+    with the windows -- and what is NOT dealt: the exchange of the seam rows and the common seam step.  The dealt part is measured
+    by this run (every rank's stage times); the part that is not is measured here for the 8-rank deal of THIS job's table, by running
+    the eight ranks' merge halves one after the other on its rows (merge.part_decided_here per rank, merge.part_after_seam_step once;
+    de-duplication on the device, as in the product)."""
+    import numpy as np
+
+    from . import merge as M
+    from .merge import _device_dedup
+    from .windows import deal_windows
+
+    ranks8 = 8
+    owner = deal_windows(plan, ranks8, deal)
+    pos_of = {w["window_id"]: q for q, w in enumerate(plan)}
+    pos = whole["window_id"].map(pos_of).to_numpy(dtype=np.int64)
+    a, r = whole["Aligned_Cell_Num_Old"].to_numpy(), whole["Ref_Cell_Num_Old"].to_numpy()
+    viol, wid = whole["filtered_violation"].to_numpy(dtype=bool), whole["window_id"].to_numpy()
+    x, y, u, v = (whole[c].to_numpy(dtype=np.float64) for c in ("X", "Y", "ref_X", "ref_Y"))
+    dedup = _device_dedup()
+    local_s, sent, mine = [], [], []
+    for q in range(ranks8):
+        rows = np.flatnonzero(owner[pos] == q)
+        t0 = time.perf_counter()
+        seam = M.seam_rows(pos[rows], lambda b, e: (x[rows[b:e]], y[rows[b:e]], u[rows[b:e]], v[rows[b:e]]), plan, owner, q, 25.0)
+        got, table = M.part_decided_here(a[rows], r[rows], viol[rows], wid[rows], pos[rows], seam, q, dedup)
+        local_s.append(time.perf_counter() - t0)
+        sent.append(table)
+        mine.append((a[rows], got))
+    t0 = time.perf_counter()
+    M.part_after_seam_step(mine[0][0], mine[0][1], sent, 0, dedup)
+    common_s = time.perf_counter() - t0
+    seam_rows = [len(t["row"]) for t in sent]
+    # the dealt work of one step, summed over this run's ranks (at one rank: the step itself), without what the run spent on seams
+    dealt_s = sum(r_["seconds"] / steps - r_["unsharded_s_per_step"] for r_ in every)
+    merge_alone_s = sum(r_["serial_tail_s_per_step"] - r_["unsharded_s_per_step"] for r_ in every)
+    measured_gather = [r_["seam_gather_ms"] for r_ in every if r_.get("seam_gather_ms")]
+    exchange_s = (max(measured_gather) * 1e-3) if measured_gather else 0.5e-3
+    per_rank_8 = (dealt_s - merge_alone_s) / ranks8 + max(local_s)
+    not_dealt_8 = exchange_s + common_s
+    return {"value": (dealt_s + 0.0) / (per_rank_8 + not_dealt_8),
+            "dealt_s_per_step": dealt_s, "of_which_merge_s": merge_alone_s,
+            "at_8_ranks": {"merge_of_own_rows_s_max_over_ranks": max(local_s), "merge_of_own_rows_s_by_rank": local_s,
+                           "seam_rows_by_rank": seam_rows, "seam_rows_share": sum(seam_rows) / max(1, len(whole)),
+                           "common_seam_step_s": common_s, "seam_exchange_s": exchange_s,
+                           "seam_exchange_s_is": "measured by this run's all-gather" if measured_gather else "assumed (one rank: nothing to exchange)"},
+            "means": "speed-up bound at 8 ranks = dealt / ((dealt - merge) / 8 + slowest rank's merge of its own rows + seam exchange + common "
+                     "seam step): the windows, the table and the merge of a rank's own rows are dealt with the windows (Qhull's share scales "
+                     "with the CPUs each rank has); the seam exchange and the common seam step are what every rank repeats whole"}
+
+
+def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device, n_workers,
+          cpu, parity, api_path, amdahl, _qp):
+    import numpy as np
+
+    total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
+    es, k = 4, 8
+    P, Tr = sum(r["pairs"] for r in every), sum(r["triangles"] for r in every)
+    touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)   # SURVEY 8d per-unit figures
+    lib_s = max(r["in_library_s"] for r in every) / steps
+    mean_cells = int(np.mean([w["n_mov"] for w in plan]))
+    by_rank = lambda key: [r.get(key) for r in every]
+    given = [r["windows_per_s_triangulations_given"] for r in every]
+    given_merged = [r["windows_per_s_triangulations_given_merged"] for r in every]
+    return {
+        "metric": baseline_metric(), "value": total_pairs * steps / dt, "unit": "cell-pairs/s", "n_gpus": group.world,
+        "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{mean_cells} aligned cells each), "
+                        f"T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, orientation + "
+                        "XY-order + area-flip sweeps per window, window merge (one row per aligned and per reference cell)",
+            "pipeline": ("device: same_amd.sliding_window_incumbent(merge=True) on resident frames -- both sections in HBM, binned on the "
+                         "window grid, two library calls per window (csrc/window*.hip); the host triangulates (Qhull helpers) and receives "
+                         "the match; the merge reads the rows' keys, only the rows it keeps get their columns" if on_device
+                         else "frames: same_amd.sliding_window_incumbent(merge=True), general route on host frames -- every window's frames "
+                              "cut on the host, every kernel through host buffers, a DataFrame per window"),
+            "parallelism": f"whole windows, {deal} deal x{group.world}; no collective inside a window; every rank merges what only it can "
+                           "see, one all-gather of the seam rows per pass" + (f": {transport}" if comm is not None else "")},
+        "deal": deal,
+        "windows_per_s": len(plan) * steps / dt,
+        "aligned_cells_per_s": float(sum(w["n_mov"] for w in plan)) * steps / dt,
+        "aligned_cells_per_window": float(np.mean([w["n_mov"] for w in plan])),
+        "per_rank": {"windows": by_rank("windows"), "windows_per_s": by_rank("windows_per_s"), "host_glue_share": by_rank("host_glue_share"),
+                     "python_share": by_rank("python_share"), "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
+                     "in_library_s_per_step": [r["in_library_s"] / steps for r in every],
+                     "serial_tail_s_per_step": by_rank("serial_tail_s_per_step"), "table_gather_s_per_step": by_rank("table_gather_s_per_step"),
+                     "unsharded_s_per_step": by_rank("unsharded_s_per_step"), "seam_rows_sent_per_step": by_rank("seam_rows_sent_per_step"),
+                     "seam_gather_ms": by_rank("seam_gather_ms"), "merged_rows": by_rank("merged_rows"),
+                     "qhull_helpers": by_rank("qhull_helpers"), "windows_per_s_triangulations_given": given,
+                     "qhull_l3_domains": by_rank("qhull_domains")},
+        "host_glue_share": mine_rec["host_glue_share"],
+        "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the window walk x "
+                                 "threads + wall time of the merge and the table behind it, which one thread runs), rank 0: Python / numpy "
+                                 "/ scipy glue, waiting for the Qhull helpers and the seam exchange included",
+        "python_share": mine_rec["python_share"],
+        "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes "
+                              "of the threads' time (the merge, the seam exchange and the table included)",
+        "qhull_wait_share": mine_rec["qhull_wait_share"],
+        "qhull_wait_share_means": "the worker threads' waits for the Qhull helpers (hand-over when all are busy + collecting answers) over "
+                                  "the same capacity: host_glue_share = qhull_wait_share + python_share",
+        "serial_tail_s_per_step": max(by_rank("serial_tail_s_per_step")),
+        "serial_tail_means": "slowest rank's time in the window merge per step (stages 'merge: ...' of same_amd/_trace.py: keys, "
+                             "de-duplication on the device, matching of contested cells, the seam rows' exchange, the common seam step) -- "
+                             "what round 5 measured as exchange + merge on rank 0; all of it but `unsharded_s_per_step` is per-rank work on "
+                             "the rank's own rows.  The columns of the rows that stay are `table_gather_s_per_step` (inside the window pass "
+                             "in round 5, when the pre-merge table was laid out first)",
+        "merge_stages_s_per_step_rank0": mine_rec["merge_stages_s_per_step"],
+        "table_gather_s_per_step": max(by_rank("table_gather_s_per_step")),
+        "after_windows_s_per_step": max(a_ + b_ for a_, b_ in zip(by_rank("serial_tail_s_per_step"), by_rank("table_gather_s_per_step"))),
+        "unsharded_s_per_step": max(by_rank("unsharded_s_per_step")),
+        "unsharded_means": "the part of a step that is not dealt with the windows: the all-gather of the seam rows and the common seam "
+                           "step every rank runs on them (0 at one rank)",
+        "amdahl_bound_at_8_ranks": None if amdahl is None else amdahl["value"], "amdahl": amdahl,
+        "seam_exchange": None if comm is None else {
+            "rows_sent_per_step_by_rank": by_rank("seam_rows_sent_per_step"), "ms_by_rank": by_rank("seam_gather_ms"),
+            "bytes_per_row": 41,
+            "timed_with": ("HIP events on the stream the all-gather ran on (same_comm_gather_time)" if not comm.synchronous
+                           else "host wall time of the host-transport exchange (no RCCL communicator)")},
+        "threads_per_rank": n_workers,
+        "windows_per_s_triangulations_given": None if given[0] is None else sum(v or 0.0 for v in given),
+        "windows_per_s_triangulations_given_merged": None if given_merged[0] is None else sum(v or 0.0 for v in given_merged),
+        "windows_per_s_triangulations_given_means": "DIAGNOSTIC, not a throughput: the rate of two extra passes of the product function in "
+                                                    "which every window's Delaunay simplices are remembered from an earlier pass, summed "
+                                                    "over the ranks -- the pre-merge table of every window (as round 5 measured it) and, "
+                                                    "`_merged`, the timed step's own call (window merge included)",
+        "window_calls_only_windows_per_s": mine_rec["window_calls_only_windows_per_s"],
+        "window_calls_only_means": "DIAGNOSTIC, rank 0: windows.iter_device_windows over this rank's windows with the triangulations "
+                                   "remembered and nothing done with the results -- the two batched library calls per eight windows and "
+                                   "the generator's own Python, on one thread and on the product function's worker threads",
+        "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
+        "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued "
+                                          "per window on rank 0, counted by the library itself (same_ctx_stat) over the timed passes; the "
+                                          "merge's de-duplication included",
+        "qhull": {"helpers": _qp.pool().n, "helpers_all_ranks": sum(r["qhull_helpers"] for r in every),
+                  "ranks_on_this_host": every[0]["local_world"], "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
+                  "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / steps,
+                  "what": "helper processes that run scipy.spatial.Delaunay for the windows ahead (a6 stays on the host); waiting = the "
+                          "worker threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
+        "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
+        "merged_matches": int(sum(r["merged_rows"] for r in every)),
+        "roofline": {"bound": "hbm", "kernel": "window pipeline: gather / latency-bound kernels that take a group of eight windows per launch "
+                                               "(greedy rounds, prune and the compactions lead)",
+                     "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_step": touched,
+                     "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k "
+                             "per aligned cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by "
+                             "the host's Delaunay calls (Qhull: qhull_wait_share), not by HBM or by the GPU"},
+        "product_function": "same_amd.sliding_window_incumbent(merge=True) (sliding_window_matching's arguments; the greedy MIP start as every "
+                            "window's solution; merge_window_matches_unique_ref's table) -- the timed step IS a call of it per rank"
+                            + (", on frames made resident before the timed region" if on_device else ""),
+        "api_path_windows_per_s": None if api_path is None else api_path["api_path_windows_per_s"], "api_path": api_path,
+        "cpu_baseline": cpu, "parity_spot_check": parity}
 
 
 def _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, cols, op, plan, on_device, _trace):

@@ -449,20 +449,46 @@ def allgather_table(ctx, comm, group, table):
 
 
 # ---- sliding windows over ranks -------------------------------------------------------------------------
-def sharded_sliding_window_incumbent(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, **kwargs):
+class MergeChannel:
+    """What the per-rank window merge (merge.merged_part_rows) needs from the job: this rank's place, `tables(table)` = every rank's
+    small table of seam rows (numeric columns: ONE device all-gather, `allgather_table`; anything else -- string cell ids -- through the
+    host group's object exchange) and a maximum over ranks.  `ctx` / `comm` None: the host group carries the bytes (CPU tests)."""
+
+    def __init__(self, group, ctx=None, comm=None):
+        self.group, self.ctx, self.comm = group, ctx, comm
+        self.rank, self.world = int(group.rank), int(group.world)
+        self.sent_rows, self.gather_ms = 0, 0.0
+
+    def tables(self, table):
+        self.sent_rows += len(next(iter(table.values()))) if table else 0
+        if all(np.asarray(v).dtype.kind in "biuf" for v in table.values()):
+            out = allgather_table(self.ctx if self.comm is not None else None, self.comm, self.group, table)
+            if self.comm is not None:
+                self.gather_ms += last_table_gather()[0]
+            return out
+        return self.group.allgather_object(table)
+
+    def max(self, v):
+        return self.group.max(float(v))
+
+
+def sharded_sliding_window_incumbent(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, deal="block",
+                                     gather="all", **kwargs):
     """`sliding_window_incumbent` (same_amd/incumbent.py: the window loop with the greedy MIP start as every window's solution) on N
-    GPUs, the way `sharded_sliding_window_matching` shards the solver loop: every rank runs its share of the plan on its own GPU, the
-    tables are exchanged once over the host channel, every rank returns the single-process table."""
+    GPUs, the way `sharded_sliding_window_matching` shards the solver loop."""
     from .incumbent import sliding_window_incumbent
 
-    return _sharded_windows(sliding_window_incumbent, ref, moving, commonCT, group, exchange, rank, world, kwargs)
+    return _sharded_windows(sliding_window_incumbent, ref, moving, commonCT, group, exchange, rank, world, deal, gather, kwargs)
 
 
-def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, **kwargs):
-    """BASELINE cfg 5 on N GPUs: windows are independent, so every rank (one process per GPU) runs its round-robin share of
-    the window plan -- heaviest windows first, `windows.assign_windows` -- and the per-window match tables are exchanged once
-    over a host channel (they are small frames, not a device collective).  Every rank returns the frame a single process
-    would return: windows in plan order, rows in window order.
+def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exchange=None, rank=None, world=None, deal="block",
+                                    gather="all", **kwargs):
+    """BASELINE cfg 5 on N GPUs: windows are independent, so every rank (one process per GPU) runs its share of the window plan -- a
+    contiguous run of the plan (`deal='block'`, windows.assign_window_blocks) or every N-th window, heaviest first (`'round_robin'`) --
+    and the per-window match tables are exchanged once over a host channel.  gather='all': every rank returns the frame a single
+    process would return (windows in plan order, rows in window order); 'root': rank 0 does, the others their own part; 'none':
+    every rank its own part (a run of the plan under the block deal) -- what `sharded_merged_window_matches` takes, which never moves
+    the whole table anywhere.
 
     The host channel is `group.allgather_object` of a `HostGroup` (built from RANK / WORLD_SIZE when none is given); any
     launcher can supply its own `exchange(obj) -> [obj of rank 0, ..., obj of rank world-1]` together with `rank` and
@@ -470,14 +496,16 @@ def sharded_sliding_window_matching(ref, moving, commonCT=None, group=None, exch
     the same CSV."""
     from .window_api import sliding_window_matching
 
-    return _sharded_windows(sliding_window_matching, ref, moving, commonCT, group, exchange, rank, world, kwargs)
+    return _sharded_windows(sliding_window_matching, ref, moving, commonCT, group, exchange, rank, world, deal, gather, kwargs)
 
 
-def _sharded_windows(run, ref, moving, commonCT, group, exchange, rank, world, kwargs):
+def _sharded_windows(run, ref, moving, commonCT, group, exchange, rank, world, deal, gather, kwargs):
     import os
 
     import pandas as pd
 
+    if gather not in ("all", "root", "none"):
+        raise ValueError(f"gather must be 'all', 'root' or 'none', got {gather!r}")
     own_group = None
     if exchange is None:
         if group is None:
@@ -488,12 +516,63 @@ def _sharded_windows(run, ref, moving, commonCT, group, exchange, rank, world, k
     try:
         if kwargs.get("outprefix"):
             kwargs["outprefix"] = os.path.join(kwargs["outprefix"], f"rank{rank}")
-        part = run(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world)), **kwargs)
+        part = run(ref, moving, commonCT=commonCT, _shard=(int(rank), int(world), deal), **kwargs)
+        if gather == "none":
+            return part
         parts = [p for p in exchange(part) if p is not None and len(p)]
     finally:
         if own_group is not None:
             own_group.close()
+    if gather == "root" and rank != 0:
+        return part
     if not parts:
         return pd.DataFrame()
-    merged = pd.concat(parts, ignore_index=True)
-    return merged.sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
+    return _plan_order(parts)
+
+
+def _plan_order(parts):
+    """The ranks' tables -> one table in plan order.  Each part is a sequence of whole windows with ascending `__plan_pos`: the windows'
+    blocks are put in order (a handful of slices under the block deal, where the parts are runs of the plan already) -- no sort of rows."""
+    import pandas as pd
+
+    whole = pd.concat(parts, ignore_index=True)
+    pos = whole["__plan_pos"].to_numpy()
+    whole = whole.drop(columns=["__plan_pos"])
+    if len(pos) and np.all(pos[1:] >= pos[:-1]):
+        return whole
+    cut = np.flatnonzero(np.diff(pos)) + 1
+    begins, ends = np.concatenate(([0], cut)), np.concatenate((cut, [len(pos)]))
+    order = np.argsort(pos[begins], kind="stable")
+    rows = np.concatenate([np.arange(begins[b], ends[b]) for b in order.tolist()])
+    from .merge import _take_rows
+
+    return _take_rows(whole, rows)
+
+
+def sharded_merged_window_incumbent(ref, moving, commonCT=None, group=None, ctx=None, comm=None, deal="block", gather=None, **kwargs):
+    """The window loop AND the window merge (src/same.py:297-595 with the greedy incumbent per window, then src/helpers.py:692-815) on N
+    GPUs without ever bringing the ranks' tables together: every rank runs its share of the plan, de-duplicates and matches what only it
+    can see, and one small all-gather of the seam rows (over `comm` -- RCCL -- on `ctx`; over the host group without them) settles the
+    rest.  -> this rank's part of the merged table (aligned ids ascending); gather='all' / 'root' additionally assembles the single
+    process's table on every rank / on rank 0 (`merge.join_merged_parts`)."""
+    from .incumbent import sliding_window_incumbent
+    from .merge import join_merged_parts
+
+    own_group = None
+    if group is None:
+        group = own_group = HostGroup()
+    try:
+        channel = MergeChannel(group, ctx, comm)
+        shard = (group.rank, group.world, deal) if group.world > 1 else None
+        part = sliding_window_incumbent(ref, moving, commonCT=commonCT, ctx=ctx, merge=True, _shard=shard, _merge_channel=channel, **kwargs)
+        if gather in ("all", "root") and group.world > 1:
+            tab, extra = (part[0], part[1:]) if isinstance(part, tuple) else (part, ())
+            parts = group.allgather_object(tab)
+            if gather == "all" or group.rank == 0:
+                op = kwargs.get("optim_params") or {}
+                tab = join_merged_parts(parts, op.get("cell_id_col") or "Cell_Num_Old")
+            part = (tab,) + tuple(extra) if extra else tab
+        return part
+    finally:
+        if own_group is not None:
+            own_group.close()

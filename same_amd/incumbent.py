@@ -80,19 +80,35 @@ class _TableBuilder:
                            dw.point_flag[c], dw.flip_flag[c]))
 
     @staticmethod
-    def table(builders):
-        """The builders' windows laid end to end (each builder walked a contiguous run of the plan, so this is plan order)."""
+    def keys(builders):
+        """What the window merge reads of the rows, without their columns: (aligned section row, reference section row, XY-order flag,
+        window id, plan position) per row, the builders' windows laid end to end."""
+        parts = [p for b in builders for p in b.parts]
+        lens = [len(p[2]) for p in parts]
+        cat = lambda q, dt: (np.concatenate([p[q] for p in parts]) if parts else np.zeros(0)).astype(dt, copy=False)
+        return (cat(2, np.int64), cat(3, np.int64), cat(6, bool), np.repeat(np.array([p[1] for p in parts], np.int64), lens),
+                np.repeat(np.array([p[0] for p in parts], np.int64), lens))
+
+    @staticmethod
+    def table(builders, select=None, plan_pos=None):
+        """The builders' windows laid end to end (each builder walked a contiguous run of the plan, so this is plan order); `select`:
+        these rows of that table only, in this order (the rows the window merge keeps: the other rows' columns are never gathered)."""
         from concurrent.futures import ThreadPoolExecutor
 
         from .merge import GATHER_THREADS
 
         parts = [p for b in builders for p in b.parts]
         lens = [len(p[2]) for p in parts]
-        n = int(sum(lens))
+        n = int(sum(lens)) if select is None else len(select)
         if n == 0:
             return pd.DataFrame()
         me = builders[0]                 # the sources are the job's: the same for every builder
-        cat = lambda q, dt: np.concatenate([p[q] for p in parts]).astype(dt, copy=False)
+        if select is None:
+            cat = lambda q, dt: np.concatenate([p[q] for p in parts]).astype(dt, copy=False)
+            spread = lambda values: np.repeat(np.array(values, np.int64), lens)
+        else:
+            cat = lambda q, dt: np.concatenate([p[q] for p in parts])[select].astype(dt, copy=False)
+            spread = lambda values: np.repeat(np.array(values, np.int64), lens)[select]
         ra, rr = cat(2, np.int64), cat(3, np.int64)
         out = {"aligned_idx": cat(4, np.int64)}
         if me.with_ref_idx:
@@ -113,9 +129,9 @@ class _TableBuilder:
         out["triangle_violation"] = cat(7, bool)
         out["filtered_violation"] = cat(6, bool)
         out["run_time"] = np.zeros(n)
-        out["window_id"] = np.repeat(np.array([p[1] for p in parts], np.int64), lens)
-        if me.job.mine is not None:
-            out["__plan_pos"] = np.repeat(np.array([p[0] for p in parts], np.int64), lens)
+        out["window_id"] = spread([p[1] for p in parts])
+        if me.job.mine is not None if plan_pos is None else plan_pos:
+            out["__plan_pos"] = spread([p[0] for p in parts])
 
         def fill(lo):
             hi = min(n, lo + _TableBuilder.SLICE)
@@ -252,12 +268,16 @@ def _device_ref_idx(dw):
 
 def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None, moving_delaunay_vertex_col=None,
                              optim_params=None, gurobi_params=None, ignore_precomputed_triangulation=False, *, workers=None,
-                             window_local_indices=False, return_stats=False, triangulator=None, ctx=None, _shard=None, _pipeline=None,
-                             _route=None):
+                             window_local_indices=False, return_stats=False, triangulator=None, ctx=None, merge=False, _shard=None,
+                             _pipeline=None, _route=None, _merge_channel=None):
     """See the module text.  -> DataFrame (with return_stats: (DataFrame, [per-window stats dict in plan order])).
     workers: threads walking this process's windows on the device route (default: 2 where the process has >= 8 CPUs, else 1).
     A window whose prune leaves no pairs raises the ValueError run_same raises for it (src/same.py:1003), as the reference's loop does.
-    `triangulator`: see windows.iter_device_windows.  `_route` = 'device' | 'general' (testing: forces a route)."""
+    `triangulator`: see windows.iter_device_windows.  `_route` = 'device' | 'general' (testing: forces a route).
+    merge=True: the table after `merge_window_matches_unique_ref` (src/helpers.py:692-815) -- one row per aligned and per reference cell,
+    aligned ids ascending -- without the pre-merge table ever being laid out: the merge reads the rows' keys, and only the rows it keeps
+    get their columns.  With `_shard` and a `_merge_channel` (dist.MergeChannel) the result is this rank's PART of the merged table
+    (dist.sharded_merged_window_incumbent)."""
     job = _WindowJob(ref, moving, commonCT, outprefix, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
                      ignore_precomputed_triangulation, _shard)
     frames, own = job.device_frames(_pipeline, ctx=ctx)
@@ -268,10 +288,17 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
         fast = _route == "device"
     stats = {}
     try:
+        if merge and job.all_matches:
+            raise ValueError("merge=True does not resume from an outprefix that already holds windows")
         if fast:
-            table = _device_route(job, frames, workers, window_local_indices, triangulator, stats)
+            table = _device_route(job, frames, workers, window_local_indices, triangulator, stats, merge, _merge_channel)
         else:
             table = _general_route(job, frames, window_local_indices, stats, ctx)
+            if merge:
+                from .merge import merge_table_part
+
+                table = merge_table_part(table, job.plan, job.owner, _merge_channel, job.optim_params["cell_id_col"],
+                                         ids_unique=_ids_unique(job))
     finally:
         if own:
             frames.close()
@@ -280,7 +307,37 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
     return (table, [stats[pos] for pos in sorted(stats)]) if return_stats else table
 
 
-def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
+def _ids_unique(job):
+    """does a cell id name ONE row of its frame (what merge.seam_rows reasons from)?"""
+    cid = job.optim_params["cell_id_col"]
+    return all(cid in df.columns and pd.Index(df[cid].to_numpy()).is_unique for df in (job.ref, job.moving))
+
+
+def _merged_rows(job, frames, builders, channel):
+    """The window merge on the device route's keys -> rows of the builders' table that the merged table keeps, in its order."""
+    from . import merge as M
+
+    a_row, r_row, viol, wid, pos = _TableBuilder.keys(builders)
+    with stage("merge: cell ids of the rows"):
+        (a_code, r_code), unique = frames.id_codes(job.optim_params["cell_id_col"])
+        a_ids, r_ids = a_code[a_row], r_code[r_row]
+    if channel is None or channel.world == 1:
+        return M.merged_part_rows(a_ids, r_ids, viol, wid, None, None)
+    with stage("merge: seam rows marked"):
+        if unique:
+            axy, rxy = frames.mov_sec.xy, frames.ref_sec.xy
+            # rows whose window has no foreign window near are not looked at (seam_rows); the prune's radius bounds a pair's distance
+            def coords(b, e):
+                a, r = axy[a_row[b:e]], rxy[r_row[b:e]]
+                return a[:, 0], a[:, 1], r[:, 0], r[:, 1]
+
+            seam = M.seam_rows(pos, coords, job.plan, job.owner, channel.rank, abs(float(job.optim_params["radius"])))
+        else:
+            seam = np.ones(len(a_row), bool)
+    return M.merged_part_rows(a_ids, r_ids, viol, wid, pos, seam, channel.rank, channel.tables)
+
+
+def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge=False, channel=None):
     n_workers = max(1, int(workers if workers is not None else _default_workers()))
     n_workers = min(n_workers, max(1, len(job.todo)))
     contexts = frames.worker_contexts(n_workers)
@@ -316,8 +373,9 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats):
         [t.join() for t in threads]
         if errors:
             raise errors[0]
+    select = _merged_rows(job, frames, builders, channel) if merge else None
     with stage("table (columns gathered on the gather threads)"):
-        table = _TableBuilder.table(builders)
+        table = _TableBuilder.table(builders, select, plan_pos=False if merge else None)
     if job.all_matches:                      # rows of windows finished by an earlier run (resume)
         table = pd.concat(job.all_matches + ([table] if len(table) else []), ignore_index=True)
     return table

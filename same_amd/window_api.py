@@ -137,6 +137,22 @@ class _DeviceFrames:
         state.stage(self.dmov, self.dref, box, 1.0, 1, 1.0)
         return state.fetch(_W_ROWS_M), state.fetch(_W_ROWS_R)
 
+    def id_codes(self, cid):
+        """((aligned code per moving row, reference code per ref row), whether every id names one row): the cell ids of both frames as
+        int64 ranks in the ORDER of the ids (equal id <=> equal code) -- what the window merge compares and orders by instead of the ids
+        themselves (strings, floats ...).  Made once per frames and id column."""
+        known = self.__dict__.setdefault("_id_codes", {})
+        if cid not in known:
+            def codes(df):
+                ids = df[cid].to_numpy()
+                if ids.dtype.kind in "iu" and (len(ids) < 2 or bool(np.all(ids[1:] > ids[:-1]))):
+                    return np.arange(len(ids), dtype=np.int64), True                 # ascending ids: a row's code is its number
+                c, uniq = pd.factorize(ids, sort=True, use_na_sentinel=False)
+                return c.astype(np.int64), len(uniq) == len(ids)
+            (mc, mu), (rc, ru) = codes(self.moving), codes(self.ref)
+            known[cid] = ((mc, rc), mu and ru)
+        return known[cid]
+
     def worker_contexts(self, n):
         """n contexts on the sections' device for n worker threads: this object's own first, then extra ones that live (with the window
         states they have grown) until close()."""
@@ -377,10 +393,11 @@ class _WindowJob:
             if "window_id" in existing.columns:
                 done_ids = set(int(w) for w in existing["window_id"].unique())
                 self.all_matches.append(existing)
-        self.mine = None
-        if shard is not None:
-            from .windows import assign_windows
-            self.mine = set(assign_windows(plan, int(shard[1]))[int(shard[0])])
+        self.mine = self.owner = None
+        if shard is not None:                    # (rank, world[, deal]): this process runs the windows the deal gives its rank
+            from .windows import deal_windows
+            self.owner = deal_windows(plan, int(shard[1]), shard[2] if len(shard) > 2 else "block")
+            self.mine = set(np.flatnonzero(self.owner == int(shard[0])).tolist())
         self.todo = [(pos, w) for pos, w in enumerate(plan) if w["grid_id"] not in done_ids and (self.mine is None or pos in self.mine)]
 
     def window_outprefix(self, w):

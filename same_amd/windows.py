@@ -104,6 +104,33 @@ def assign_windows(plan, n_ranks):
     return [sorted(s) for s in shards]
 
 
+def assign_window_blocks(plan, n_ranks):
+    """Contiguous runs of the plan per rank, balanced by aligned cells (what a window costs: its triangulation and its pairs).
+    The plan walks the window grid column by column (src/same.py:509-511), so a run is a strip of whole columns plus two partial ones:
+    most overlaps between windows are then overlaps between windows of ONE rank, and the window merge (src/helpers.py:692-815) only
+    has the strips' borders to settle between ranks (merge.seam_rows).  The ranks' tables laid end to end are in plan order."""
+    weight = np.array([max(1, w["n_mov"]) for w in plan], dtype=np.float64)
+    shards = [[] for _ in range(n_ranks)]
+    if len(plan):
+        middle = (np.cumsum(weight) - weight / 2) / weight.sum()              # where a window sits in the job's work, 0..1
+        for w, q in enumerate(np.minimum((middle * n_ranks).astype(np.int64), n_ranks - 1).tolist()):
+            shards[q].append(w)
+    return shards
+
+
+WINDOW_DEALS = ("block", "round_robin")
+
+
+def deal_windows(plan, n_ranks, deal="block"):
+    """-> owner[w] = the rank that runs window w of the plan: 'block' (assign_window_blocks) or 'round_robin' (assign_windows)."""
+    if deal not in WINDOW_DEALS:
+        raise ValueError(f"window deal must be one of {WINDOW_DEALS}, got {deal!r}")
+    owner = np.zeros(len(plan), np.int32)
+    for q, share in enumerate((assign_window_blocks if deal == "block" else assign_windows)(plan, n_ranks)):
+        owner[share] = q
+    return owner
+
+
 class GridRows:
     """Row indices of the points inside half-open boxes [x0, x1) x [y0, y1), for many boxes of one point set: the points are
     binned once into a uniform grid (counting sort by cell), a box gathers the cells it touches (one contiguous run per grid

@@ -522,7 +522,10 @@ def test_bench_cfg5_windows_line(world):
     pr = out["per_rank"]
     assert len(pr["windows"]) == world and sum(pr["windows"]) >= 4 and all(v > 0 for v in pr["windows_per_s"])
     assert all(0.0 <= v < 1.0 for v in pr["host_glue_share"]) and out["windows_per_s"] > 0 and out["merged_matches"] > 1000
-    assert out["config"]["pipeline"].startswith("device: same_amd.sliding_window_incumbent on resident frames")
+    assert out["config"]["pipeline"].startswith("device: same_amd.sliding_window_incumbent(merge=True) on resident frames")
+    am = out["amdahl"]
+    assert out["amdahl_bound_at_8_ranks"] == am["value"] > 1.0 and len(am["at_8_ranks"]["seam_rows_by_rank"]) == 8
+    assert 0.0 < am["at_8_ranks"]["seam_rows_share"] < 1.0 and am["at_8_ranks"]["common_seam_step_s"] > 0
     assert out["product_function"].startswith("same_amd.sliding_window_incumbent")
     assert any(k.startswith("subset + prune") for k in out["stages_rank0"]) and out["library_calls_rank0_top"][0]["seconds"] > 0
     assert {"same_window_stage", "same_window_filter_finish"} <= {e["entry_point"] for e in out["library_calls_rank0_top"]}
@@ -578,10 +581,16 @@ def test_bench_line_embeds_a_cfg5_record(world):
     assert rec["qhull"]["ranks_on_this_host"] == world and rec["qhull"]["helpers_all_ranks"] == sum(pr["qhull_helpers"]) <= max(24, world)
     calls = rec["runtime_calls_per_window"]
     assert calls["launches"] <= 30 and calls["fills"] <= 4 and calls["copies"] <= 4 and calls["waits"] <= 3
+    # the window merge is per rank: only seam rows travel; the record prices what is NOT dealt with the windows and bounds 8 ranks from it
+    assert rec["deal"] == "block" and 0.0 <= rec["unsharded_s_per_step"] <= rec["serial_tail_s_per_step"] <= rec["after_windows_s_per_step"]
+    assert len(pr["serial_tail_s_per_step"]) == len(pr["merged_rows"]) == world and sum(pr["merged_rows"]) == rec["merged_matches"]
     if world == 1:
-        assert "through the device-resident window path" in rec["parity_spot_check"] and rec["table_allgather"] is None
+        assert "through the device-resident window path" in rec["parity_spot_check"] and rec["seam_exchange"] is None
+        assert rec["unsharded_s_per_step"] == 0.0
     else:
-        assert rec["table_allgather"]["ms"] > 0 and rec["table_allgather"]["bytes_per_rank"] > 0 and len(pr["table_allgather_ms"]) == world
+        sx = rec["seam_exchange"]
+        assert len(sx["rows_sent_per_step_by_rank"]) == world and all(0 < v < 0.5 * rec["merged_matches"] for v in sx["rows_sent_per_step_by_rank"])
+        assert rec["unsharded_s_per_step"] > 0.0
 
 
 def test_bench_step_with_the_fixed_point_dense_build():
@@ -818,7 +827,7 @@ def test_resident_frames_serve_several_jobs(gp, tmp_path, monkeypatch):
     assert res._frames == {}
 
 
-def _sharded_incumbent_worker(rank, world, out_dir):
+def _sharded_incumbent_worker(rank, world, deal, out_dir):
     import os
     import sys
 
@@ -827,34 +836,47 @@ def _sharded_incumbent_worker(rank, world, out_dir):
     sys.path.insert(0, os.path.dirname(here))
     from test_gpu_run_same import _sw_inputs
     import same_amd
-    from same_amd.dist import sharded_sliding_window_incumbent
+    from same_amd.dist import MergeChannel, sharded_merged_window_incumbent, sharded_sliding_window_incumbent
+    from same_amd.rendezvous import HostGroup
 
     r_big, m_big, cols = _sw_inputs()
     op = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
-    if world == 2:     # the package's own wrapper over its plain-Python host group (RANK / WORLD_SIZE / SAME_RDV_DIR): every rank gets the whole table
-        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
-        part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
+    if world == 2:     # the package's own wrappers over its plain-Python host group (RANK / WORLD_SIZE / SAME_RDV_DIR)
+        part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)      # every rank: the whole table
+        merged = sharded_merged_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)     # every rank: its part of the merge
     else:              # the share of one rank, as a launcher with its own exchange would take it
-        part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), _shard=(rank, world))
+        part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), _shard=(rank, world, deal))
+        with HostGroup() as g:
+            merged = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), merge=True, _route="general",
+                                                       _pipeline="frames" if rank == 1 else None, _shard=(rank, world, deal),
+                                                       _merge_channel=MergeChannel(g))
+            g.barrier()
     part.to_pickle(os.path.join(out_dir, f"part{rank}.pkl"))
+    merged.to_pickle(os.path.join(out_dir, f"merged{rank}.pkl"))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world):
-    """sliding_window_incumbent over several processes on the one GPU, each running its share of the plan: through
-    dist.sharded_sliding_window_incumbent (world 2: every rank ends with the whole table) and through `_shard=(rank, world)` by hand
-    (world 3: the parts, put back into plan order by their `__plan_pos`) -- the single process's table row for row."""
+@pytest.mark.parametrize("world,deal", [(2, "block"), (2, "round_robin"), (3, "block"), (3, "round_robin")])
+def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world, deal):
+    """sliding_window_incumbent over several processes on the one GPU, each running its share of the plan under either deal: through
+    dist.sharded_sliding_window_incumbent (world 2: every rank ends with the whole table) and through `_shard=(rank, world, deal)` by hand
+    (world 3: the parts, put back into plan order by their `__plan_pos`) -- the single process's table row for row.  And the window
+    merge dealt the same way (dist.sharded_merged_window_incumbent on the device route; `merge=True` with a MergeChannel on the general
+    route, one rank on the frames pipeline): the parts, joined, are merge_window_matches_unique_ref of the single process's table
+    (src/helpers.py:692-815), and every part is in its order."""
     import multiprocessing as mp
     import same_amd
+    from same_amd.merge import join_merged_parts, merge_window_matches_unique_ref
 
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_sharded_incumbent_worker, args=(rank, world, str(tmp_path))) for rank in range(world)]
+    procs = [ctx.Process(target=_sharded_incumbent_worker, args=(rank, world, deal, str(tmp_path))) for rank in range(world)]
     [p.start() for p in procs]
     [p.join(600) for p in procs]
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     parts = [pd.read_pickle(tmp_path / f"part{rank}.pkl") for rank in range(world)]
     r_big, m_big, cols = _sw_inputs()
-    whole = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60))
+    op = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
+    whole = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op))
     if world == 2:
         assert all(p.equals(whole) for p in parts)
     else:
@@ -862,6 +884,14 @@ def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world):
         merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
         assert merged.equals(whole)
     _assert_incumbent_equals_golden(whole, load_golden("run_same_mock"), "sw", with_ref_idx=False)
+    want = merge_window_matches_unique_ref([whole])
+    assert 300 < len(want) < len(whole)                                       # the overlaps do disagree in this job
+    one = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), merge=True)
+    assert list(one.columns) == list(want.columns) and one.equals(want)       # one process: the merge without the pre-merge table
+    mparts = [pd.read_pickle(tmp_path / f"merged{rank}.pkl") for rank in range(world)]
+    assert all(0 < len(p) < len(want) and "__plan_pos" not in p.columns for p in mparts)
+    assert all(np.all(np.diff(p["Aligned_Cell_Num_Old"].to_numpy()) > 0) for p in mparts)
+    assert join_merged_parts(mparts).equals(want)
 
 
 def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
