@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "same_hip.h"
+#include "same_hip_diag.h" /* same_ctx_stat, same_dev_mem_info, same_dev_alloc_spread: measurement hooks, not the path */
 
 #define CHECK(call)                                                                            \
     do {                                                                                       \

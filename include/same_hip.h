@@ -42,7 +42,7 @@ extern "C" {
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
 
-#define SAME_ABI_VERSION 6
+#define SAME_ABI_VERSION 7
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
@@ -50,20 +50,22 @@ typedef struct same_ctx same_ctx;
 typedef struct same_sweep same_sweep; /* resident state of one lazy-constraint sweep (same_sweep_bind) */
 
 /* ---- index of this header ------------------------------------------------------------------------------------------------------
- * part 0  context, device memory, timers, runtime-call counters      same_ctx_*, same_dev_*, same_h2d / d2h / d2d, same_timer_*, same_ctx_stat
+ * part 0  context, device memory                                     same_ctx_*, same_dev_*, same_h2d / d2h / d2d
  * part 1  HOST-BUFFER entry points (caller's arrays in and out; one   same_pair_cost_*, same_dense_cost_f64 / f32, same_knn_prune, same_tri_*, same_sweep_* /
  *         call = upload, kernels, download, wait)                     same_orient_sweep*, same_xyorder_sweep, same_area_flip, same_pair_rowmin,
  *                                                                     same_assign_matrix, same_greedy_*, same_tri_flip_stats, same_collapse_candidates,
  *                                                                     same_batched_assign, same_eager_signs, same_window_count, same_merge_dedup
- * part 2  DEVICE-RESIDENT forms (operands already in HBM; enqueue     same_dense_cost_*_dev, same_quantize_u32_dev, same_dense_cost_q32_dev, same_knn_prune_dev,
- *         only unless noted)                                          same_knn_index_*, same_knn_prune_indexed_dev, same_padded_cost_*_dev, same_tri_*_dev,
+ * part 2  DEVICE-RESIDENT forms (operands already in HBM; enqueue     same_dense_cost_*_dev, same_knn_prune_dev, same_knn_index_*,
+ *         only unless noted)                                          same_knn_prune_indexed_dev, same_padded_cost_*_dev, same_tri_*_dev,
  *                                                                     same_area_flip_dev, same_xyorder_sweep_dev, same_orient_*_dev, same_first_candidate_dev
- * part 3  WINDOW path, sections resident (BASELINE cfg 5)             same_section_*, same_window_*
+ * part 3  WINDOW path, sections resident (BASELINE cfg 5)             same_section_*, same_window_*, same_merge_acc_*
  * part 4  COMM: RCCL collectives between the ranks' contexts          same_comm_*, same_allgather_dev*, same_allreduce_dev
- * Every declaration cites the reference lines it replaces (file:line into the reference tree). */
+ * Every declaration cites the reference lines it replaces (file:line into the reference tree).
+ * Measurement hooks and opt-in controls that are NOT the path -- runtime-call counters, timers, the spread allocator, the fixed-point
+ * dense build, the all-gather's device time -- are declared in same_hip_diag.h (same library). */
 
 /* ======================================================================================================================
- * part 0 -- context, device memory, timers
+ * part 0 -- context, device memory
  * ====================================================================================================================== */
 /* ---- context ------------------------------------------------------------------------- */
 int same_abi_version(void);
@@ -75,60 +77,17 @@ const char *same_strerror(int code);
 const char *same_last_error(same_ctx *ctx);
 /* device name, CU count, HBM bytes (any pointer may be NULL) */
 int same_ctx_info(same_ctx *ctx, char *name, size_t name_len, int *cu_count, int64_t *hbm_bytes);
-/* "domain:bus:device.function" of the context's GPU (names its sysfs directory: power / clock telemetry) */
-int same_ctx_pci_bus_id(same_ctx *ctx, char *out, size_t out_len);
-/* What the library itself has asked of the HIP runtime on this context since it was created, for the entry points that count
- * (the window path, the greedy start): kernel launches, hipMemsetAsync fills, hipMemcpyAsync copies, stream waits, and the
- * device-to-host reads the greedy rounds made.  The difference of two reads around a call is that call's cost in runtime calls --
- * the number a rocprof trace shows, available to a test (tests/test_gpu_run_same.py holds launches / fills / copies / waits per
- * window).  which = SAME_STAT_*. */
-enum { SAME_STAT_LAUNCHES = 0, SAME_STAT_FILLS = 1, SAME_STAT_COPIES = 2, SAME_STAT_WAITS = 3, SAME_STAT_GREEDY_READBACKS = 4, SAME_STAT_COUNT = 5 };
-int same_ctx_stat(same_ctx *ctx, int which, int64_t *out);
-
-/* ---- device memory + timing (for resident operands and in-library kernel timing) ------ */
+/* ---- device memory (for resident operands) ------------------------------------------------ */
 int same_dev_alloc(same_ctx *ctx, size_t bytes, void **out_dptr);
 int same_dev_free(same_ctx *ctx, void *dptr);   /* either kind of buffer */
-/* For LARGE STREAMING OUTPUTS (the dense cost matrix).  MI355X's HBM is three physical regions of 96 GiB and a streaming
- * store confined to one of them runs ~20 % below one spread over two or three (profiles/archive/r02_hbm_regions.md); hipMalloc
- * places a buffer wherever its free lists point.  This call takes the memory in 1 GiB chunks through the virtual-memory
- * API, finds each chunk's region by timed stores and maps the chunks round-robin over the regions into one contiguous
- * range.  The result is used and freed like any same_dev_alloc buffer.
- *  - Cost: 1-4 s once for 75 GiB (most of it the driver's own hipMemCreate); may hold up to 128 GiB more than `bytes`
- *    while it looks for chunks of a second region; all of that goes back to the card before the call returns.
- *  - Buffers under 6 GiB, SAME_SPREAD=0 in the environment, a card without that much free memory, or a failure of the
- *    virtual-memory calls themselves give a plain same_dev_alloc: placement is a matter of speed, never of results
- *    (out_info[0] says which it was; same_last_error() keeps the reason).
- *  - The memory goes back to the card on same_dev_free.  The ADDRESSES of a spread buffer are never used for another
- *    mapping (a ROCm quirk, see spread.hip): they come from a 48 TiB stretch of the process's address space, after which
- *    the plain allocation is used.
- *  - The finished range is checked, not trusted: one store over all of it is timed and sampled neighbouring chunks are
- *    timed against each other; out_info[9] says whether the store ran at the fast level and the pairs behaved as labelled.
- *    An unverified buffer is still returned (and is still correct memory): only its speed is in question.
- *  - Wall time is bounded: past SAME_SPREAD_MAX_SECONDS (default 3) the search for better-balanced chunks stops and the best
- *    choice so far is mapped; past twice that while still taking the buffer's own chunks, the plain allocation is used.
- * out_info (may be NULL), SAME_SPREAD_INFO_LEN int64: [0] 1 = spread, 0 = plain; [1] GiB chunks mapped; [2..4] chunks from
- * region 0/1/2; [5] chunks that straddle regions; [6] chunks examined; [7] microseconds spent; [8] same-region level, GB/s;
- * [9] 1 = verified; [10] GB/s of one store over the finished range; [11] neighbouring pairs timed, [12] of them as labelled;
- * [13] 1 = the search stopped at the time bound. */
-#define SAME_SPREAD_INFO_LEN 14
-int same_dev_alloc_spread(same_ctx *ctx, size_t bytes, void **out_dptr, int64_t *out_info);
 int same_h2d(same_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int same_d2h(same_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int same_dev_memset(same_ctx *ctx, void *dst_dev, int value, size_t bytes);
 /* device-to-device copy, enqueued on the context's stream (no wait) */
 int same_d2d(same_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
-/* free and total bytes of the context's card right now (hipMemGetInfo); either pointer may be NULL */
-int same_dev_mem_info(same_ctx *ctx, int64_t *out_free, int64_t *out_total);
 /* The host-buffer entry points stage through per-context scratch blocks that grow on demand and are
  * reused across calls; this frees them all (same_sweep handles own their blocks and are not affected). */
 int same_ctx_release_scratch(same_ctx *ctx);
-/* HIP events recorded on the context's stream (where the kernels run). */
-int same_timer_start(same_ctx *ctx);
-int same_timer_stop(same_ctx *ctx, float *out_ms); /* records, synchronises, returns elapsed ms */
-/* the same in two steps: mark the end now (no wait), read the elapsed time later */
-int same_timer_mark(same_ctx *ctx);
-int same_timer_read(same_ctx *ctx, float *out_ms);
-
 /* ======================================================================================================================
  * part 1 -- HOST-BUFFER entry points: the caller's (NumPy) arrays in and out; synchronous
  * ====================================================================================================================== */
@@ -316,28 +275,6 @@ int same_dense_cost_f32_dev(same_ctx *ctx, const float *dA, const float *dR, int
                             const float *daxy, const float *drxy, int64_t n_r, int64_t row_begin,
                             int64_t row_end, float w, float *dout, int64_t ld);
 
-/* ---- opt-in fixed-point dense build ---------------------------------------------------------
- * NOT the reference's arithmetic and never a default: the type values are put on a common 32-bit
- * fixed-point grid q(v) = rint((v - offset) * scale), the type sum becomes an exact integer sum of
- * absolute differences (one v_sad_u32 per element instead of two fp64 adds), the rest of the expression
- * is unchanged fp64:  out = w * (double(S_q) * inv_scale) + (w*0.001) * (|ax-rx| + |ay-ry|).
- * Against same_dense_cost_f64_dev: |S_q * inv_scale - S| <= T * inv_scale.  With rel_tol > 0 every type
- * sum of fewer than T / rel_tol + T grid steps (near-identical cells) is recomputed from the fp64
- * matrices dA / dR with the reference's own expression, so EVERY output is within rel_tol (relative) of
- * the fp64 build's -- rel_tol = 1e-6 is BASELINE.json's tolerance for fp64 costs; rel_tol = 0 keeps the
- * pure grid result (dA / dR may then be NULL).  The caller chooses offset / scale so that every
- * row-pair sum fits 32 bits (same_amd.ops.quantize_types); the row pitch ld must be even and columns
- * [n_r, ld) are written too (padding owned by the caller).  T <= SAME_Q32_MAX_TYPES.  Meant for the
- * dense matrix of the Hungarian MIP-start heuristic (src/init_helpers.py:151-155) and as the roofline
- * control of DESIGN.md 5.1 (the same 80 GB of stores without the fp64 adds). */
-#define SAME_Q32_MAX_TYPES 32
-int same_quantize_u32_dev(same_ctx *ctx, const double *dsrc, int64_t n, double offset, double scale,
-                          uint32_t *ddst);
-int same_dense_cost_q32_dev(same_ctx *ctx, const uint32_t *dAq, const uint32_t *dRq, const double *dA,
-                            const double *dR, int T, const double *daxy, const double *drxy, int64_t n_r,
-                            int64_t row_begin, int64_t row_end, double w, double inv_scale,
-                            double rel_tol, double *dout, int64_t ld);
-
 /* ---- a2 on resident operands: the prune of same_knn_prune (part 1) with device pointers, the caller-held index, the costs of
  * the padded candidate lists */
 int same_knn_prune_dev(same_ctx *ctx, const double *daxy, const double *drxy, int64_t n_r,
@@ -447,7 +384,7 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *     that writes the answers into the pinned blocks; ONE wait for the batch (more greedy rounds, in batches with a wait each, only
  *     for a window in which a pair could still be taken after the rounds enqueued up front).
  * same_window_fetch copies one array of the window's state to the host; bytes must be the array's exact size.
- * (ABI 6: same_window_stage / same_window_filter_finish take batches; same_window_filter and same_window_finish of ABI 5 are gone --
+ * (Since ABI 6 same_window_stage / same_window_filter_finish take batches; same_window_filter and same_window_finish of ABI 5 are gone --
  * the former is the latter's first half, the latter is prefiltered = 1.) */
 #define SAME_WINDOW_BATCH_MAX 64
 typedef struct same_section same_section;
@@ -478,6 +415,55 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
                               int prefiltered, double radius, int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
                               int ensure_min_triangle_per_node, double no_match_penalty, int32_t *out_match_row,
                               uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts);
+
+/* ---- f3 on the window path: the window merge where the windows' matches are ------------------------------------------------
+ * The reference trims every window's match table to the window's central region (src/same.py:565-582), concatenates the tables and
+ * merges them (helpers.merge_window_matches_unique_ref, src/helpers.py:692-815: one row per (aligned, ref) pair -- not violating
+ * first, then the smaller window id, then the earlier row --, then one maximum matching of the pairs that are left, rows in the order
+ * of the aligned ids).  In a tiled run nearly every pair stands alone (no other row names either of its cells) and is in the merged
+ * table as it is.  On the device, per pass over a plan (ABI 7):
+ *   same_section_set_codes   codes[row] = rank of the row's cell id among the section's ids, 0 .. n_codes-1 (equal id <=> equal code; the
+ *                            merge compares and orders by them); NULL: a row's code is its number (ids ascending by row).
+ *   same_merge_acc           the rows of one pass (one per context; grows on demand, reused from pass to pass).
+ *   same_merge_acc_begin     a new pass.  expected_rows sizes the arrays up front (an upper bound saves a re-allocation, nothing more).
+ *                            Seams, for a plan dealt over ranks (NULL near_start: one rank, no seams): window (plan position) p of this
+ *                            rank lies near the central regions near_boxes[4 q .. 4 q + 3] = {x0, x1, y0, y1}, q in [near_start[p],
+ *                            near_start[p+1]), of OTHER ranks' windows; a row of p whose aligned cell lies in one of them, or whose
+ *                            reference cell lies within `reach` (the prune's radius) of one, may be named by another rank's table too
+ *                            and is left to the host.  all_seam != 0: every row is (cell ids that name several rows of a frame).
+ *   same_window_collect      after same_window_filter_finish, ENQUEUE ONLY: the matched kept cells of each window whose XY lies in
+ *                            trims[4 i .. 4 i + 3] = {x0, x1, y0, y1} (half open) are appended to the accumulator of the windows'
+ *                            context, windows in call order, cells ascending: (aligned section row, matched reference section row, flag
+ *                            byte, window_ids[i], plan_pos[i], index among the window's kept cells).  Three launches per eight windows.
+ *   same_merge_acc_resolve   the pass is over: the accumulators (accs[0] first -- the call runs on its context; the others are waited
+ *                            for and laid behind it, in order: plan order when the contexts walked consecutive runs of the plan) ->
+ *                            codes, the de-duplication of src/helpers.py:745-753 (merge.hip's kernels, on the device arrays), degrees,
+ *                            classes.  out_counts = {rows, rows after the de-duplication, REST rows, rows final already}.  A surviving row
+ *                            whose two cells are named by no other surviving row and that is not at a seam is final.  The REST --
+ *                            contested or at a seam -- is for the host (same_amd/merge.py: connected components, Hopcroft-Karp, the
+ *                            exchange between ranks): same_merge_acc_fetch(accs[0], SAME_MERGE_REST) = one record per row, in the order
+ *                            the de-duplication left: int32 {row in the accumulator, aligned code, ref code, window id, plan position,
+ *                            index among the window's kept cells}, uint32 flags (bit 0 XY-order flag, bit 1 area-flip flag, bit 2 seam).
+ *   same_merge_acc_finish    winner_rows = the REST rows (accumulator row numbers) the host's matching kept -> the merged table's rows
+ *                            in the order of the aligned codes (src/helpers.py:799-808); same_merge_acc_fetch(.., SAME_MERGE_FINAL) =
+ *                            int32 {aligned section row, reference section row, index among the window's kept cells, window id},
+ *                            uint32 flags (bits 0, 1 as above) per row.  The host gathers the columns of exactly these rows. */
+typedef struct same_merge_acc same_merge_acc;
+#define SAME_MERGE_REST 0
+#define SAME_MERGE_FINAL 1
+#define SAME_MERGE_REST_BYTES 28
+#define SAME_MERGE_FINAL_BYTES 20
+int same_section_set_codes(same_section *section, const int32_t *codes /* may be NULL */, int64_t n_codes);
+int same_merge_acc_create(same_ctx *ctx, same_merge_acc **out);
+void same_merge_acc_destroy(same_merge_acc *acc);
+int same_merge_acc_begin(same_merge_acc *acc, int64_t expected_rows, int n_pos, const int32_t *near_start /* may be NULL */,
+                         const double *near_boxes, double reach, int all_seam);
+int same_window_collect(same_window *const *windows, int n_windows, same_merge_acc *acc, const double *trims,
+                        const int32_t *window_ids, const int32_t *plan_pos);
+int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_section *moving, const same_section *ref,
+                           int64_t *out_counts /* [4] */);
+int same_merge_acc_finish(same_merge_acc *acc, const int32_t *winner_rows, int64_t n_winners, int64_t *out_n_final);
+int same_merge_acc_fetch(same_merge_acc *acc, int what, void *out, int64_t bytes);
 
 /* ======================================================================================================================
  * part 4 -- COMM: one communicator per context, RCCL over xGMI
@@ -516,12 +502,6 @@ int same_comm_group_end(same_ctx *ctx);
 int same_comm_info(same_ctx *ctx, int *out_nranks, int *out_rank, int *out_rccl_version);
 /* ncclCommCuDevice of the communicator (-1 = none) */
 int same_comm_device(same_ctx *ctx, int *out_device);
-/* Device time (HIP events on the stream they ran on) of the all-gathers issued since the last same_comm_wait or the last
- * call of this function, whichever came later -- the overlapped ones, or the in-stream ones issued outside a group -- and the
- * bytes this rank sent in them (may be NULL); waits for the last of them.  0 ms if none.  Reading closes the batch: the next
- * gather starts a new one (a caller that only uses the in-stream form never needs same_comm_wait). */
-int same_comm_gather_time(same_ctx *ctx, float *out_ms, int64_t *out_send_bytes);
-
 #ifdef __cplusplus
 }
 #endif

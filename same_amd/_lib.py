@@ -1,4 +1,4 @@
-"""ctypes binding of libsame_hip.so (include/same_hip.h).
+"""ctypes binding of libsame_hip.so (include/same_hip.h: the path's entry points; include/same_hip_diag.h: measurement hooks).
 
 The product path has no CPU fallback: if the shared library is missing, or no MI355X is
 visible when a compute entry point is called, this module raises.  Nothing here imports the
@@ -21,14 +21,14 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
 SPREAD_INFO_LEN = 14                           # SAME_SPREAD_INFO_LEN
 MAX_KNN = 448
 MAX_TYPES = 4096
 
-# name -> argtypes, exactly the declarations of include/same_hip.h (restype int unless noted)
+# name -> argtypes, exactly the declarations of include/same_hip.h and include/same_hip_diag.h (restype int unless noted)
 _PROTOTYPES = {
     "same_abi_version": [],
     "same_device_count": [ctypes.POINTER(c_int)],
@@ -102,6 +102,14 @@ _PROTOTYPES = {
     "same_window_fetch": [c_vp, c_int, c_vp, c_i64],
     "same_window_filter_finish": [c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
+    "same_section_set_codes": [c_vp, c_vp, c_i64],
+    "same_merge_acc_create": [c_vp, ctypes.POINTER(c_vp)],
+    "same_merge_acc_destroy": [c_vp],
+    "same_merge_acc_begin": [c_vp, c_i64, c_int, c_vp, c_vp, c_dbl, c_int],
+    "same_window_collect": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
+    "same_merge_acc_resolve": [c_vp, c_int, c_vp, c_vp, c_vp],
+    "same_merge_acc_finish": [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)],
+    "same_merge_acc_fetch": [c_vp, c_int, c_vp, c_i64],
     "same_comm_unique_id": [c_vp],
     "same_comm_init": [c_vp, c_int, c_int, c_vp],
     "same_comm_destroy": [c_vp],

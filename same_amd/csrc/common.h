@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "same_hip.h"
+#include "same_hip_diag.h"
 
 struct ncclComm;
 
@@ -183,6 +183,9 @@ int same_greedy_rounds_batch_core(same_ctx *ctx, const same_greedy_job *jobs, in
 
 // ascending sort of n_pad (a power of two >= 2048) 64-bit keys in place (merge.hip)
 int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad);
+// de-duplication of (aligned code, ref code) pairs on device arrays, enqueue only (merge.hip)
+int same_merge_dedup_core(same_ctx *ctx, const uint8_t *dviol, unsigned viol_mask, const int32_t *dwin, const int32_t *da, const int32_t *dr,
+                          int64_t n, int32_t *dout, unsigned long long *dtotal);
 
 // the window path's prune and candidate-list costs on row lists of the sections (knn.hip, cost.hip), for the windows of a batch in one
 // launch each (<= SAME_LAUNCH_WINDOWS jobs)

@@ -25,11 +25,11 @@ namespace {
 
 constexpr int SORT_BLOCK = 2048;   // keys one workgroup sorts in LDS (16 KB)
 
-__global__ __launch_bounds__(256) void merge_key_kernel(const uint8_t *__restrict__ viol, const int32_t *__restrict__ window, int64_t n,
+__global__ __launch_bounds__(256) void merge_key_kernel(const uint8_t *__restrict__ viol, unsigned viol_mask, const int32_t *__restrict__ window, int64_t n,
                                                           int64_t n_pad, unsigned long long *__restrict__ key) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
-    key[i] = i < n ? ((unsigned long long)(viol[i] ? 1 : 0) << 63) | ((unsigned long long)(uint32_t)window[i] << 32) | (unsigned long long)i
+    key[i] = i < n ? ((unsigned long long)((viol[i] & viol_mask) ? 1 : 0) << 63) | ((unsigned long long)(uint32_t)window[i] << 32) | (unsigned long long)i
                    : ~0ull;        // padding sorts last (a real key never has all bits set: i < 2^31)
 }
 
@@ -149,6 +149,36 @@ int same_sort_u64_core(same_ctx *ctx, unsigned long long *dkey, int64_t n_pad) {
     return SAME_OK;
 }
 
+// The de-duplication on DEVICE arrays, enqueue only (the host-buffer entry point below; the merge accumulator of the window path,
+// window_merge.hip): rows whose (aligned code, ref code) pair is the first of its kind in the order (viol & viol_mask != 0, window id,
+// row) -> dout (row indices, in that order), their number -> *dtotal.  Scratch: the context's slots SL_X, SL_OUT0, SL_OUT1, SL_MASK.
+int same_merge_dedup_core(same_ctx *ctx, const uint8_t *dviol, unsigned viol_mask, const int32_t *dwin, const int32_t *da, const int32_t *dr,
+                          int64_t n, int32_t *dout, unsigned long long *dtotal) {
+    REQUIRE(ctx, n > 0 && n < ((int64_t)1 << 30));
+    int64_t n_pad = SORT_BLOCK;
+    while (n_pad < n) n_pad <<= 1;
+    int64_t slots = 2;
+    while (slots < 2 * n) slots <<= 1;
+    unsigned long long *dkey, *dtkey, *dstatus;
+    unsigned int *dtfirst;
+    const size_t st_words = scan::status_bytes(n) / 8;
+    SAME_TRY(slot_as(ctx, SL_X, (size_t)n_pad, &dkey));
+    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)slots, &dtkey));
+    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)slots, &dtfirst));
+    SAME_TRY(slot_as(ctx, SL_MASK, st_words, &dstatus));
+    SAME_FILL(ctx, dtkey, 0xFF, (size_t)slots * 8);
+    SAME_FILL(ctx, dtfirst, 0xFF, (size_t)slots * 4);
+    SAME_FILL(ctx, dstatus, 0, st_words * 8);
+    SAME_LAUNCH(ctx, merge_key_kernel, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, dviol, viol_mask, dwin, n, n_pad, dkey);
+    SAME_TRY(same_sort_u64_core(ctx, dkey, n_pad));
+    const unsigned grid = (unsigned)ceil_div(n, 256);
+    SAME_LAUNCH(ctx, merge_first_kernel, dim3(grid), dim3(256), 0, dkey, n, da, dr, dtkey, dtfirst, slots - 1);
+    SAME_LAUNCH(ctx, merge_compact_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, dkey, n, da, dr, dtkey, dtfirst, slots - 1,
+                scan::arg(dstatus), dout, dtotal);
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
 extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_t *window_id, const int32_t *aligned_code,
                                 const int32_t *ref_code, int64_t n, int32_t *out_rows, int64_t *out_n) {
     REQUIRE(ctx, ctx && out_n && n >= 0 && n < ((int64_t)1 << 30));   // row indices and sorted positions are 32-bit, scan totals 31-bit; 2^30 rows need ~45 GB of scratch
@@ -161,35 +191,16 @@ extern "C" int same_merge_dedup(same_ctx *ctx, const uint8_t *viol, const int32_
             return SAME_ERANGE;
         }
     SAME_TRY(same_use(ctx));
-    int64_t n_pad = SORT_BLOCK;
-    while (n_pad < n) n_pad <<= 1;
-    int64_t slots = 2;
-    while (slots < 2 * n) slots <<= 1;
     uint8_t *dviol;
     int32_t *dwin, *da, *dr, *dout;
-    unsigned long long *dkey, *dtkey, *dstatus, *dtotal;
-    unsigned int *dtfirst;
-    const size_t st_words = scan::status_bytes(n) / 8;
+    unsigned long long *dtotal;
     SAME_TRY(up_as(ctx, SL_FLAG0, viol, (size_t)n, &dviol));
     SAME_TRY(up_as(ctx, SL_PAIRS, window_id, (size_t)n, &dwin));
     SAME_TRY(up_as(ctx, SL_MATCH, aligned_code, (size_t)n, &da));
     SAME_TRY(up_as(ctx, SL_TRIS, ref_code, (size_t)n, &dr));
-    SAME_TRY(slot_as(ctx, SL_X, (size_t)n_pad, &dkey));
-    SAME_TRY(slot_as(ctx, SL_OUT0, (size_t)slots, &dtkey));
-    SAME_TRY(slot_as(ctx, SL_OUT1, (size_t)slots, &dtfirst));
-    SAME_TRY(slot_as(ctx, SL_MASK, st_words + 2, &dstatus));      // the scan's words, then the total
-    SAME_TRY(slot_as(ctx, SL_OUT2, (size_t)n, &dout));
-    dtotal = dstatus + st_words;
-    HIP_TRY(ctx, hipMemsetAsync(dtkey, 0xFF, (size_t)slots * 8, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dtfirst, 0xFF, (size_t)slots * 4, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(dstatus, 0, (st_words + 2) * 8, ctx->stream));
-    hipLaunchKernelGGL(merge_key_kernel, dim3((unsigned)ceil_div(n_pad, 256)), dim3(256), 0, ctx->stream, dviol, dwin, n, n_pad, dkey);
-    SAME_TRY(same_sort_u64_core(ctx, dkey, n_pad));
-    const unsigned grid = (unsigned)ceil_div(n, 256);
-    hipLaunchKernelGGL(merge_first_kernel, dim3(grid), dim3(256), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1);
-    hipLaunchKernelGGL(merge_compact_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, ctx->stream, dkey, n, da, dr, dtkey, dtfirst, slots - 1,
-                       scan::arg(dstatus), dout, dtotal);
-    HIP_TRY(ctx, hipGetLastError());
+    SAME_TRY(slot_as(ctx, SL_OUT2, (size_t)n + 4, &dout));        // the rows, then (8-byte aligned) their number
+    dtotal = reinterpret_cast<unsigned long long *>(dout + (((size_t)n + 1) & ~size_t(1)));
+    SAME_TRY(same_merge_dedup_core(ctx, dviol, 0xFFu, dwin, da, dr, n, dout, dtotal));
     unsigned long long total = 0;
     SAME_TRY(same_down(ctx, &total, dtotal, sizeof total));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

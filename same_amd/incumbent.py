@@ -93,26 +93,29 @@ class _TableBuilder:
     def table(builders, select=None, plan_pos=None):
         """The builders' windows laid end to end (each builder walked a contiguous run of the plan, so this is plan order); `select`:
         these rows of that table only, in this order (the rows the window merge keeps: the other rows' columns are never gathered)."""
+        parts = [p for b in builders for p in b.parts]
+        lens = [len(p[2]) for p in parts]
+        if (int(sum(lens)) if select is None else len(select)) == 0:
+            return pd.DataFrame()
+        me = builders[0]                 # the sources are the job's: the same for every builder
+        pick = (lambda v: v) if select is None else (lambda v: v[select])
+        cat = lambda q, dt: pick(np.concatenate([p[q] for p in parts])).astype(dt, copy=False)
+        spread = lambda values: pick(np.repeat(np.array(values, np.int64), lens))
+        with_pos = me.job.mine is not None if plan_pos is None else plan_pos
+        return me.gather(cat(2, np.int64), cat(3, np.int64), cat(4, np.int64), cat(5, np.int64) if me.with_ref_idx else None, cat(7, bool),
+                         cat(6, bool), spread([p[1] for p in parts]), spread([p[0] for p in parts]) if with_pos else None)
+
+    def gather(self, ra, rr, aligned_idx, ref_idx, triangle_violation, filtered_violation, window_id, plan_pos=None):
+        """The result table of matched cells (moving section rows `ra` -> reference section rows `rr`): the columns of
+        src/same.py:1264-1278, :1464-1470, gathered from the caller's frames slice by slice on the gather threads."""
         from concurrent.futures import ThreadPoolExecutor
 
         from .merge import GATHER_THREADS
 
-        parts = [p for b in builders for p in b.parts]
-        lens = [len(p[2]) for p in parts]
-        n = int(sum(lens)) if select is None else len(select)
-        if n == 0:
-            return pd.DataFrame()
-        me = builders[0]                 # the sources are the job's: the same for every builder
-        if select is None:
-            cat = lambda q, dt: np.concatenate([p[q] for p in parts]).astype(dt, copy=False)
-            spread = lambda values: np.repeat(np.array(values, np.int64), lens)
-        else:
-            cat = lambda q, dt: np.concatenate([p[q] for p in parts])[select].astype(dt, copy=False)
-            spread = lambda values: np.repeat(np.array(values, np.int64), lens)[select]
-        ra, rr = cat(2, np.int64), cat(3, np.int64)
-        out = {"aligned_idx": cat(4, np.int64)}
-        if me.with_ref_idx:
-            out["ref_idx"] = cat(5, np.int64)
+        me, n = self, len(ra)
+        out = {"aligned_idx": aligned_idx}
+        if ref_idx is not None:
+            out["ref_idx"] = ref_idx
         new = lambda like: np.empty(n, like.dtype)
         for ct, src in zip(me.cts, me.type_cols if me.type_block is None else [me.type_block] * len(me.cts)):
             out[ct] = new(src)
@@ -126,12 +129,12 @@ class _TableBuilder:
         out["ref_size"] = new(me.ref_size) if me.ref_size is not None else np.ones(n, np.int64)
         out[f"Ref_{me.cid}"], out[f"Aligned_{me.cid}"] = new(me.ref_id), new(me.mov_id)
         out["time_limit_reached"] = np.zeros(n, bool)
-        out["triangle_violation"] = cat(7, bool)
-        out["filtered_violation"] = cat(6, bool)
+        out["triangle_violation"] = triangle_violation
+        out["filtered_violation"] = filtered_violation
         out["run_time"] = np.zeros(n)
-        out["window_id"] = spread([p[1] for p in parts])
-        if me.job.mine is not None if plan_pos is None else plan_pos:
-            out["__plan_pos"] = spread([p[0] for p in parts])
+        out["window_id"] = window_id
+        if plan_pos is not None:
+            out["__plan_pos"] = plan_pos
 
         def fill(lo):
             hi = min(n, lo + _TableBuilder.SLICE)
@@ -345,14 +348,26 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
     builders = [_TableBuilder(job, sections, with_ref_idx) for _ in range(n_workers)]
     lock = threading.Lock()
     cut = [len(job.todo) * q // n_workers for q in range(n_workers + 1)]          # worker q walks a contiguous run of this process's windows
+    # merge=True: the windows' matches stay where they are.  Every batch's central rows join the pass's accumulator on the device
+    # (csrc/window_merge.hip); the merge runs there, and only what it could not decide alone comes to the host (`_merge_on_device`).
+    # (window_local_indices needs every window's pair list on the host: the keys go through the builders then, `_merged_rows`.)
+    accs = None
+    if merge and not with_ref_idx:
+        accs = _begin_accumulators(job, frames, contexts, cut, channel)
+    pos_of = {id(w): pos for pos, w in job.todo}
 
     def walk(q):
         mine = job.todo[cut[q]:cut[q + 1]]
-        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator)):
+        collector = None
+        if accs is not None:
+            collector = lambda states, windows: accs[q].collect(states, [w["trim"] for w in windows], [w["window_id"] for w in windows],
+                                                                [pos_of[id(w)] for w in windows])
+        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator, collector=collector)):
             if dw.error is not None:
                 raise dw.error
             with stage("table rows (central trim)"):
-                builders[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
+                if accs is None:
+                    builders[q].add(pos, w, dw, _device_ref_idx(dw) if with_ref_idx else None)
                 rec = _device_stats(dw)
             with lock:
                 stats[pos] = rec
@@ -373,12 +388,63 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
         [t.join() for t in threads]
         if errors:
             raise errors[0]
+    if accs is not None:
+        final = _merge_on_device(job, frames, accs, channel)
+        with stage("table (columns gathered on the gather threads)"):
+            flags = final["flags"]
+            return builders[0].gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), final["cidx"].astype(np.int64), None,
+                                      (flags & 2) != 0, (flags & 1) != 0, final["wid"].astype(np.int64)) if len(final) else pd.DataFrame()
     select = _merged_rows(job, frames, builders, channel) if merge else None
     with stage("table (columns gathered on the gather threads)"):
         table = _TableBuilder.table(builders, select, plan_pos=False if merge else None)
     if job.all_matches:                      # rows of windows finished by an earlier run (resume)
         table = pd.concat(job.all_matches + ([table] if len(table) else []), ignore_index=True)
     return table
+
+
+def _begin_accumulators(job, frames, contexts, cut, channel):
+    """A merge accumulator per worker context, begun for this pass: sized for the worker's windows, with the seams of this rank's share
+    of the plan when the plan is dealt over ranks."""
+    from . import merge as M
+
+    accs, unique = frames.accumulators(contexts, job.optim_params["cell_id_col"])
+    near, reach = None, 0.0
+    if channel is not None and channel.world > 1 and unique:
+        reach = abs(float(job.optim_params["radius"]))          # the prune's radius bounds the distance of a pair's two cells
+        known = frames.__dict__.setdefault("_seam_tables", {})
+        key = (channel.rank, channel.world, reach, job.owner.tobytes(), len(job.plan))
+        if key not in known:
+            known[key] = M.seam_tables(job.plan, job.owner, channel.rank, reach)
+        near = known[key]
+    for q, acc in enumerate(accs):
+        expected = sum(w["n_mov"] for _pos, w in job.todo[cut[q]:cut[q + 1]])
+        acc.begin(expected, near, reach, all_seam=channel is not None and channel.world > 1 and not unique)
+    return accs
+
+
+def _merge_on_device(job, frames, accs, channel):
+    """The window merge of the accumulated rows (src/helpers.py:692-815): codes, de-duplication, degrees and the rows that stand alone
+    on the device; components / Hopcroft-Karp of the contested cells, and the seam rows' exchange between ranks, here.
+    -> the merged table's rows (windows.FINAL_RECORD), aligned ids ascending."""
+    from . import merge as M
+    from .windows import resolve_accumulators
+
+    with stage("merge: accumulated rows resolved (device)"):
+        _counts, rest = resolve_accumulators(accs, frames.dmov, frames.dref)
+    a, r, wid = rest["ac"].astype(np.int64), rest["rc"].astype(np.int64), rest["wid"].astype(np.int64)
+    viol = (rest["flags"] & 1) != 0
+    if channel is None or channel.world == 1:
+        rows = M._resolve_rows(a, r, viol, wid, M.already_deduplicated) if len(rest) else np.zeros(0, np.int64)
+    else:
+        seam = (rest["flags"] & 4) != 0
+        mine, sent = M.part_decided_here(a, r, viol, wid, rest["pos"].astype(np.int64), seam, channel.rank, M.already_deduplicated,
+                                         seq=rest["cidx"])
+        with stage("merge: seam rows exchanged"):
+            parts = channel.tables(sent)
+        with stage("merge: seam step (the same on every rank)"):
+            rows = M.part_after_seam_step(None, mine, parts, channel.rank, M._device_dedup())
+    with stage("merge: winners to the device, final rows back"):
+        return accs[0].finish(rest["row"][rows])
 
 
 def _general_route(job, frames, with_ref_idx, stats, ctx):

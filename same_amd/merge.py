@@ -237,6 +237,31 @@ def seam_rows(pos, coords, plan, owner, me, reach):
     return seam
 
 
+def seam_tables(plan, owner, me, reach):
+    """`seam_rows` as tables for the device (same_merge_acc_begin): per plan position of rank `me` the central regions of OTHER ranks'
+    windows that lie within 2 * reach of its own -> (near_start int32[len(plan) + 1], near_boxes float64[.., 4])."""
+    owner = np.asarray(owner)
+    trims = np.array([w["trim"] for w in plan], dtype=np.float64).reshape(-1, 4)
+    foreign = np.flatnonzero(owner != me)
+    ft = trims[foreign]
+    start, boxes = np.zeros(len(plan) + 1, np.int32), []
+    for p in range(len(plan)):
+        if owner[p] == me and len(ft):
+            t = trims[p]
+            near = ft[(ft[:, 0] - reach <= t[1] + reach) & (ft[:, 1] + reach >= t[0] - reach)
+                      & (ft[:, 2] - reach <= t[3] + reach) & (ft[:, 3] + reach >= t[2] - reach)]
+            boxes.append(near)
+            start[p + 1] = start[p] + len(near)
+        else:
+            start[p + 1] = start[p]
+    return start, (np.concatenate(boxes) if boxes else np.zeros((0, 4)))
+
+
+def already_deduplicated(viol, window_id, a_codes, r_codes):
+    """the `dedup` of rows that are one per (aligned, ref) pair already (the device accumulator's REST rows): all of them, in order"""
+    return np.arange(len(a_codes), dtype=np.int64)
+
+
 def merged_part_rows(a_ids, r_ids, viol, window_id, pos, seam, rank=0, exchange=None, _dedup=None):
     """The window merge (src/helpers.py:692-815) of a table that is dealt over ranks, as seen by ONE rank: `a_ids` ... `pos` are the
     columns of this rank's rows (its windows in plan order, rows in window order; `pos` = plan position of the row's window), `seam`
@@ -260,12 +285,14 @@ def merged_part_rows(a_ids, r_ids, viol, window_id, pos, seam, rank=0, exchange=
         return part_after_seam_step(a_ids, mine, parts, rank, dedup)
 
 
-def part_decided_here(a_ids, r_ids, viol, window_id, pos, seam, rank, dedup):
-    """First half of `merged_part_rows`: -> (rows of this rank decided from its own rows, the table of rows it sends to the common step)."""
+def part_decided_here(a_ids, r_ids, viol, window_id, pos, seam, rank, dedup, seq=None):
+    """First half of `merged_part_rows`: -> (rows of this rank decided from its own rows, the table of rows it sends to the common step).
+    seq: a row's place in its window's table (default: its place in this rank's table, which is in window order)."""
     mine, common = _resolve_rows(a_ids, r_ids, viol, window_id, dedup, seam=seam)
     # `order`: the place a row has in the single process's concatenation -- plan position, then the row's place in its window's table
+    place = common if seq is None else np.asarray(seq, dtype=np.int64)[common]
     sent = {"a": a_ids[common], "r": r_ids[common], "viol": viol[common].view(np.uint8), "window": window_id[common],
-            "order": (np.asarray(pos, dtype=np.int64)[common] << 32) | common, "row": common, "rank": np.full(len(common), rank, np.int32)}
+            "order": (np.asarray(pos, dtype=np.int64)[common] << 32) | place, "row": common, "rank": np.full(len(common), rank, np.int32)}
     return mine, sent
 
 
@@ -279,7 +306,7 @@ def part_after_seam_step(a_ids, mine, parts, rank, dedup):
     won = order[_resolve_rows(col("a")[order], col("r")[order], col("viol")[order].view(bool), col("window")[order], dedup, mark=False)]
     won = won[col("rank")[won] == rank]
     mine = np.concatenate((mine, col("row")[won].astype(np.int64)))
-    return mine[np.argsort(a_ids[mine], kind="stable")]
+    return mine if a_ids is None else mine[np.argsort(a_ids[mine], kind="stable")]
 
 
 def join_merged_parts(parts, cell_id_col="Cell_Num_Old"):

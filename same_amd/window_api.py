@@ -120,7 +120,7 @@ class _DeviceFrames:
             return "cell_type missing (priority filter)"
         return None
 
-    def windows(self, plan, triangulate=True, ctx=None, triangulator=None, fetch_triangles=False):
+    def windows(self, plan, triangulate=True, ctx=None, triangulator=None, fetch_triangles=False, collector=None):
         from .windows import iter_device_windows
 
         op = self.op
@@ -128,7 +128,24 @@ class _DeviceFrames:
                                    dist_ct_coeff=op["dist_ct_coeff"], min_angle_deg=op.get("min_angle_deg", 15),
                                    ignore_same_type_triangles=op["ignore_same_type_triangles"], no_match_penalty=op["no_match_penalty"],
                                    ctx=self.ctx if ctx is None else ctx, triangulate=triangulate, triangulator=triangulator,
-                                   fetch_triangles=fetch_triangles)
+                                   fetch_triangles=fetch_triangles, collector=collector)
+
+    def accumulators(self, contexts, cid):
+        """One merge accumulator per worker context (kept with the frames: a pass re-uses the arrays of the last), and the sections' id
+        codes for `cid` on the device.  -> ([accumulator per context], whether every id names one row)."""
+        from .windows import MergeAccumulator
+
+        accs = self.__dict__.setdefault("_accs", {})
+        for c in contexts:
+            if id(c) not in accs:
+                accs[id(c)] = MergeAccumulator(c)
+        (mov_code, ref_code), unique = self.id_codes(cid)
+        if self.__dict__.get("_codes_on_device") != cid:
+            identity = lambda code: len(code) == 0 or (code[0] == 0 and code[-1] == len(code) - 1 and bool(np.all(code[1:] > code[:-1])))
+            for sec, code in ((self.dmov, mov_code), (self.dref, ref_code)):
+                sec.set_codes(None if identity(code) else code, int(code.max()) + 1 if len(code) else 0)
+            self.__dict__["_codes_on_device"] = cid
+        return [accs[id(c)] for c in contexts], unique
 
     def box_rows(self, box, state):
         """(aligned rows, reference rows) of the frames inside the box -- subset_data of both frames, as row positions."""
@@ -163,6 +180,8 @@ class _DeviceFrames:
         return [self.ctx] + self._worker_ctx[:n - 1]
 
     def close(self):
+        for acc in self.__dict__.pop("_accs", {}).values():
+            acc.close()
         for c in self._worker_ctx:
             c.close()
         self._worker_ctx = []

@@ -384,6 +384,13 @@ class DeviceSection:
                            "same_section_bin")
         return self
 
+    def set_codes(self, codes, n_codes):
+        """codes[row] = rank of the row's cell id among the section's ids (what the window merge on the device compares and orders by);
+        None: a row's code is its number."""
+        c = None if codes is None else np.ascontiguousarray(codes, dtype=np.int32)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_section_set_codes(self.handle, None if c is None else c.ctypes.data, int(n_codes)), "same_section_set_codes")
+
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:        # a context that is already gone took its device memory along
             with self.ctx.lock:
@@ -457,6 +464,90 @@ class DeviceWindow:
             self.close()
         except Exception:
             pass
+
+
+REST_RECORD = np.dtype([("row", "<i4"), ("ac", "<i4"), ("rc", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("cidx", "<i4"), ("flags", "<u4")])   # SAME_MERGE_REST
+FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("wid", "<i4"), ("flags", "<u4")])                            # SAME_MERGE_FINAL
+
+
+class MergeAccumulator:
+    """The rows of one pass over a window plan on one context (same_merge_acc, csrc/window_merge.hip): `collect` appends the matched cells
+    of the windows' central regions where they are -- on the device --, `resolve_accumulators` / `finish` run the window merge on them."""
+
+    def __init__(self, ctx=None):
+        import ctypes
+
+        self.ctx = ctx = ops._ctx(ctx)
+        h = ctypes.c_void_p()
+        with ctx.lock:
+            rc = ctx.lib.same_merge_acc_create(ctx.handle, ctypes.byref(h))
+            if rc != 0 and h.value:
+                ctx.lib.same_merge_acc_destroy(h)
+            ctx.check(rc, "same_merge_acc_create")
+        self.handle = h
+
+    def begin(self, expected_rows, near=None, reach=0.0, all_seam=False):
+        """A new pass.  near = (near_start int32[n_pos + 1], near_boxes float64[.., 4]): per plan position the central regions of OTHER
+        ranks' windows close enough to share cells with it (merge.seam_tables); None: one rank."""
+        ctx = self.ctx
+        if near is None:
+            n_pos, ns, nb = 0, None, None
+        else:
+            ns, nb = np.ascontiguousarray(near[0], dtype=np.int32), np.ascontiguousarray(near[1], dtype=np.float64).reshape(-1, 4)
+            n_pos = len(ns) - 1
+        with ctx.lock:
+            ctx.check(ctx.lib.same_merge_acc_begin(self.handle, int(expected_rows), n_pos, None if ns is None else ns.ctypes.data,
+                                                   None if nb is None or len(nb) == 0 else nb.ctypes.data, float(reach), int(bool(all_seam))),
+                      "same_merge_acc_begin")
+
+    def collect(self, states, trims, window_ids, plan_pos):
+        """Enqueue only: the matched cells of the finished windows `states` that lie in their central regions join the accumulator."""
+        ctx, n = self.ctx, len(states)
+        t = np.ascontiguousarray(trims, dtype=np.float64).reshape(n, 4)
+        w, p = np.ascontiguousarray(window_ids, dtype=np.int32), np.ascontiguousarray(plan_pos, dtype=np.int32)
+        with ctx.lock:
+            ctx.check(ctx.lib.same_window_collect(_handles(states), n, self.handle, t.ctypes.data, w.ctypes.data, p.ctypes.data), "same_window_collect")
+
+    def finish(self, winner_rows):
+        """The REST rows the host's matching kept (accumulator row numbers) -> the merged table's rows as FINAL_RECORDs, aligned codes ascending."""
+        import ctypes
+
+        ctx = self.ctx
+        w = np.ascontiguousarray(winner_rows, dtype=np.int32)
+        n = ctypes.c_int64(0)
+        with ctx.lock:
+            ctx.check(ctx.lib.same_merge_acc_finish(self.handle, w.ctypes.data if len(w) else None, len(w), ctypes.byref(n)), "same_merge_acc_finish")
+            out = np.empty(n.value, FINAL_RECORD)
+            ctx.check(ctx.lib.same_merge_acc_fetch(self.handle, 1, out.ctypes.data, out.nbytes), "same_merge_acc_fetch")
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            with self.ctx.lock:
+                self.ctx.lib.same_merge_acc_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resolve_accumulators(accs, dmoving, dref):
+    """The pass is over: the accumulators of the worker contexts (in the order their runs of the plan have) -> ((rows, rows after the
+    de-duplication, rest rows, rows final already), the REST rows as REST_RECORDs): what the device could not decide alone -- cells some
+    window disagrees about, rows at a seam between ranks -- for merge.py's graph step; `accs[0].finish(winners)` completes the merge."""
+    import ctypes
+
+    ctx = accs[0].ctx
+    counts = np.zeros(4, np.int64)
+    handles = (ctypes.c_void_p * len(accs))(*[a.handle.value for a in accs])
+    with ctx.lock:
+        ctx.check(ctx.lib.same_merge_acc_resolve(handles, len(accs), dmoving.handle, dref.handle, counts.ctypes.data), "same_merge_acc_resolve")
+        rest = np.empty(int(counts[2]), REST_RECORD)
+        ctx.check(ctx.lib.same_merge_acc_fetch(accs[0].handle, 0, rest.ctypes.data, rest.nbytes), "same_merge_acc_fetch")
+    return tuple(int(c) for c in counts), rest
 
 
 WINDOW_BATCH_MAX = 64      # SAME_WINDOW_BATCH_MAX
@@ -571,7 +662,7 @@ class TriangulationCache:
 
 def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
                         ignore_same_type_triangles=True, no_match_penalty=100.0, ctx=None, fetch_triangles=False, triangulator=None,
-                        triangulate=True, batch=None):
+                        triangulate=True, batch=None, collector=None):
     """The window path of `iter_window_arrays` + the greedy incumbent and the three sweeps, with both sections resident on the
     device (`dref`, `dmoving`: DeviceSections of `ref`, `moving`): per window the host only triangulates (Qhull helpers, windows
     ahead as before) and receives the match; the triangle filter runs on the device too, unless a cosine sits within 8 ulp of the
@@ -583,7 +674,9 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     enqueues the next.  The states of a batch stay live (`result.state`) until the generator is asked for the first window of the next.
     `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`.
     `triangulate=False` stops after the stage call (rows, prune, costs, compaction): the caller brings its own triangles
-    (api.sliding_window_matching with a caller's triangulation) and reads pairs / costs through `state.fetch`."""
+    (api.sliding_window_matching with a caller's triangulation) and reads pairs / costs through `state.fetch`.
+    `collector(states, windows)` is called once per finished batch with its windows' live states (the window merge's accumulator:
+    MergeAccumulator.collect)."""
     import os
     from collections import deque
 
@@ -676,6 +769,9 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
             out.n_triangles = state.n_triangles
             if fetch_triangles and out.triangles is None:
                 out.triangles = state.fetch(_W_TRIANGLES)
+        if collector is not None:
+            with marked("central rows to the merge accumulator (device, enqueue only)"):
+                collector([st for _o, st, _t in todo], [o.window for o, _s, _t in todo])
 
     pending, live, nxt = deque(), [], 0
     try:

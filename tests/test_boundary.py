@@ -13,13 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_functions():
-    src = open(os.path.join(ROOT, "include", "same_hip.h")).read()
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("same_hip.h", "same_hip_diag.h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(same_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
-    """libsame_hip.so loads without a GPU and exports exactly what include/same_hip.h declares."""
+    """libsame_hip.so loads without a GPU and exports exactly what include/same_hip.h (the path) and include/same_hip_diag.h (measurement
+    hooks, opt-in controls) declare; the diagnostics stay out of the path's header."""
     from same_amd import _lib
 
     lib = _lib.load()
@@ -28,7 +29,10 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in same_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared, "ctypes prototypes and header drifted apart"
-    assert lib.same_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.same_abi_version() == _lib.ABI_VERSION == 7
+    path_header = open(os.path.join(ROOT, "include", "same_hip.h")).read()
+    for hook in ("same_ctx_stat", "same_timer_start", "same_dev_alloc_spread", "same_dense_cost_q32_dev", "same_comm_gather_time"):
+        assert hook + "(" not in path_header, hook
     assert b"range" in lib.same_strerror(-34)
 
 

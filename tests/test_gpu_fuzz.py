@@ -466,6 +466,40 @@ def test_prune_indices_dropped_while_other_threads_use_them():
     threads = [threading.Thread(target=walk, args=(s_,)) for s_ in (1, 2, 3)]
     [t.start() for t in threads]
     [t.join() for t in threads]
+    assert not failures, failures[:5]
+    # Radii nobody has asked for yet, asked for AT THE SAME MOMENT: two threads the same one (the table's lock is not held across a build,
+    # so both build it; the second to finish drops its build and takes the first's), two more a radius each -- while a fifth keeps staging
+    # against a radius that is there.  Everybody gets the single thread's answer; four rounds of fresh radii.
+    fresh = [[40.0 + rnd, 40.0 + rnd, 50.0 + rnd, 60.0 + rnd, radii[0]] for rnd in range(4)]
+    solo = W.DeviceWindow()
+    for r in sorted({r for rnd in fresh for r in rnd}):
+        want[r] = (solo.stage(dsec, dsec, box, r, 6, 1.0), solo.fetch(W._W_PAIRS).copy(), solo.fetch(W._W_COSTS).copy())
+    solo.close()
+    dsec.close()
+    dsec = W.DeviceSection(sec, "float64")            # a section whose table is empty again
+    gate = threading.Barrier(5)
+
+    def race(lane):
+        ctx = _lib.Context(dsec.ctx.device)
+        st = W.DeviceWindow(ctx)
+        try:
+            for rnd in range(4):
+                gate.wait(60)
+                r = fresh[rnd][lane]
+                for _rep in range(3 if lane == 4 else 1):
+                    counts = st.stage(dsec, dsec, box, r, 6, 1.0)
+                    if counts != want[r][0] or not np.array_equal(st.fetch(W._W_PAIRS), want[r][1]) or not np.array_equal(st.fetch(W._W_COSTS), want[r][2]):
+                        failures.append(("race", lane, rnd, r))
+        except BaseException as e:   # noqa: BLE001 -- reported by the assertion below
+            failures.append(("race", lane, repr(e)))
+            gate.abort()
+        finally:
+            st.close()
+            ctx.close()
+
+    threads = [threading.Thread(target=race, args=(lane,)) for lane in range(5)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
     dsec.close()
     assert not failures, failures[:5]
 

@@ -718,6 +718,18 @@ def _sw_inputs():
     return r_big, m_big, synth.type_columns(3)
 
 
+def _sw_inputs_crowded():
+    """The same reference section against TWO jittered copies of it: every reference cell has two suitors, and where they sit in
+    different windows' central regions both windows propose it -- the overlaps disagree, which is what the window merge settles."""
+    from same_amd import synth
+
+    r_big, m_big, cols = _sw_inputs()
+    other = synth.to_frame(synth.make_jittered(synth.make_cells(1500, 3, seed=51), seed=53))
+    m2 = pd.concat([m_big, other], ignore_index=True)
+    m2["Cell_Num_Old"] = np.arange(len(m2)) * 3 + 1
+    return r_big, m2, cols
+
+
 def _assert_incumbent_equals_golden(res, g, prefix, with_ref_idx=True):
     """Every column of the reference's result table that is defined without a solver, and the column order.  `filtered_violation`
     is the XY-order flag here and the flag intersected with the solver's penalised triangles there; `run_time` is the double's."""
@@ -834,21 +846,22 @@ def _sharded_incumbent_worker(rank, world, deal, out_dir):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
-    from test_gpu_run_same import _sw_inputs
+    from test_gpu_run_same import _sw_inputs, _sw_inputs_crowded
     import same_amd
     from same_amd.dist import MergeChannel, sharded_merged_window_incumbent, sharded_sliding_window_incumbent
     from same_amd.rendezvous import HostGroup
 
     r_big, m_big, cols = _sw_inputs()
+    _r, m_two, _c = _sw_inputs_crowded()
     op = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
     if world == 2:     # the package's own wrappers over its plain-Python host group (RANK / WORLD_SIZE / SAME_RDV_DIR)
         part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)      # every rank: the whole table
-        merged = sharded_merged_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)     # every rank: its part of the merge
+        merged = sharded_merged_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op), deal=deal)     # every rank: its part of the merge
     else:              # the share of one rank, as a launcher with its own exchange would take it
         part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), _shard=(rank, world, deal))
         with HostGroup() as g:
-            merged = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), merge=True, _route="general",
+            merged = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op), merge=True, _route="general",
                                                        _pipeline="frames" if rank == 1 else None, _shard=(rank, world, deal),
                                                        _merge_channel=MergeChannel(g))
             g.barrier()
@@ -884,9 +897,11 @@ def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world, 
         merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
         assert merged.equals(whole)
     _assert_incumbent_equals_golden(whole, load_golden("run_same_mock"), "sw", with_ref_idx=False)
-    want = merge_window_matches_unique_ref([whole])
-    assert 300 < len(want) < len(whole)                                       # the overlaps do disagree in this job
-    one = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), merge=True)
+    _r, m_two, _c = _sw_inputs_crowded()
+    crowded = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op))
+    want = merge_window_matches_unique_ref([crowded])
+    assert 300 < len(want) < len(crowded) - 20                                # the overlaps do disagree in this job
+    one = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op), merge=True)
     assert list(one.columns) == list(want.columns) and one.equals(want)       # one process: the merge without the pre-merge table
     mparts = [pd.read_pickle(tmp_path / f"merged{rank}.pkl") for rank in range(world)]
     assert all(0 < len(p) < len(want) and "__plan_pos" not in p.columns for p in mparts)
