@@ -446,13 +446,17 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
  *                            index among the window's kept cells}, uint32 flags (bit 0 XY-order flag, bit 1 area-flip flag, bit 2 seam).
  *   same_merge_acc_finish    winner_rows = the REST rows (accumulator row numbers) the host's matching kept -> the merged table's rows
  *                            in the order of the aligned codes (src/helpers.py:799-808); same_merge_acc_fetch(.., SAME_MERGE_FINAL) =
- *                            int32 {aligned section row, reference section row, index among the window's kept cells, window id},
- *                            uint32 flags (bits 0, 1 as above) per row.  The host gathers the columns of exactly these rows. */
+ *                            int32 {aligned section row, reference section row, index among the window's kept cells, window id, plan
+ *                            position}, uint32 flags (bits 0, 1 as above) per row.  The host gathers the columns of exactly these rows.
+ *   same_merge_acc_load      rows from the HOST instead of from windows (the seam rows of every rank after their exchange: the common step
+ *                            of a merge dealt over ranks, same_amd/merge.py): the accumulator holds exactly these n rows, their "section
+ *                            rows" ARE codes (a_code < n_codes_a, r_code < n_codes_r), ties of the de-duplication go to the earlier row;
+ *                            same_merge_acc_resolve then takes this one accumulator with NULL sections. */
 typedef struct same_merge_acc same_merge_acc;
 #define SAME_MERGE_REST 0
 #define SAME_MERGE_FINAL 1
 #define SAME_MERGE_REST_BYTES 28
-#define SAME_MERGE_FINAL_BYTES 20
+#define SAME_MERGE_FINAL_BYTES 24
 int same_section_set_codes(same_section *section, const int32_t *codes /* may be NULL */, int64_t n_codes);
 int same_merge_acc_create(same_ctx *ctx, same_merge_acc **out);
 void same_merge_acc_destroy(same_merge_acc *acc);
@@ -460,8 +464,10 @@ int same_merge_acc_begin(same_merge_acc *acc, int64_t expected_rows, int n_pos, 
                          const double *near_boxes, double reach, int all_seam);
 int same_window_collect(same_window *const *windows, int n_windows, same_merge_acc *acc, const double *trims,
                         const int32_t *window_ids, const int32_t *plan_pos);
-int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_section *moving, const same_section *ref,
-                           int64_t *out_counts /* [4] */);
+int same_merge_acc_load(same_merge_acc *acc, const int32_t *a_code, const int32_t *r_code, const uint8_t *flags, const int32_t *window_ids,
+                        const int32_t *pos, const int32_t *cidx, int64_t n, int64_t n_codes_a, int64_t n_codes_r);
+int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_section *moving /* NULL after ..._load */,
+                           const same_section *ref /* NULL after ..._load */, int64_t *out_counts /* [4] */);
 int same_merge_acc_finish(same_merge_acc *acc, const int32_t *winner_rows, int64_t n_winners, int64_t *out_n_final);
 int same_merge_acc_fetch(same_merge_acc *acc, int what, void *out, int64_t bytes);
 

@@ -107,6 +107,7 @@ _PROTOTYPES = {
     "same_merge_acc_destroy": [c_vp],
     "same_merge_acc_begin": [c_vp, c_i64, c_int, c_vp, c_vp, c_dbl, c_int],
     "same_window_collect": [c_vp, c_int, c_vp, c_vp, c_vp, c_vp],
+    "same_merge_acc_load": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64],
     "same_merge_acc_resolve": [c_vp, c_int, c_vp, c_vp, c_vp],
     "same_merge_acc_finish": [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)],
     "same_merge_acc_fetch": [c_vp, c_int, c_vp, c_i64],

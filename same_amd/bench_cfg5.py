@@ -10,7 +10,7 @@ RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dt
                "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged", "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
                "after_windows_s_per_step", "unsharded_s_per_step", "merge_stages_s_per_step_rank0", "amdahl_bound_at_8_ranks", "amdahl",
-               "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "qhull", "merged_matches", "parity_spot_check", "rccl",
+               "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull", "merged_matches", "parity_spot_check", "rccl",
                "product_function", "api_path_windows_per_s", "api_path", "window_calls_only_windows_per_s")
 
 
@@ -116,6 +116,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     group.barrier()
     _trace.reset()
     calls0 = [c.stats() for c in worker_ctx]
+    merge_calls = lambda: dict(next(iter(resident._frames.values())).__dict__.get("merge_runtime_calls", {})) if on_device else {}
+    merge_calls0 = merge_calls()
     t0 = time.perf_counter()
     merged = stats = None
     for _ in range(steps):
@@ -125,7 +127,10 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     calls1 = [c.stats() for c in worker_ctx]
     # the calls counted are those of `ctx`: worker 0's windows (the first of n_workers contiguous runs of this rank's share) + the merge's de-duplication
     n_done = max(1, (len(stats) // n_workers) * steps)
-    calls_per_window = {k_: sum(b[k_] - a[k_] for a, b in zip(calls0, calls1)) / n_done for k_ in calls1[0]}
+    # ... without what the merge itself asked for, which is per PASS, not per window (resolve + finish: a sort's worth of launches)
+    merge_calls1 = merge_calls()
+    per_pass = {k_: (merge_calls1.get(k_, 0) - merge_calls0.get(k_, 0)) / steps for k_ in calls1[0]}
+    calls_per_window = {k_: (sum(b[k_] - a[k_] for a, b in zip(calls0, calls1)) - per_pass[k_] * steps) / n_done for k_ in calls1[0]}
     dt = group.max(wall_here)
     rep = _trace.report()
     in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:"))
@@ -190,7 +195,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                 "window_calls_only_windows_per_s": calls_only, "merged_rows": int(len(merged)),
                 "seam_rows_sent_per_step": None if channel is None else channel.sent_rows / max(1, steps + min(warmup, 1) + (2 if on_device else 0)),
                 "seam_gather_ms": None if channel is None else channel.gather_ms / max(1, steps + min(warmup, 1) + (2 if on_device else 0)),
-                "runtime_calls_per_window": calls_per_window,
+                "runtime_calls_per_window": calls_per_window, "runtime_calls_per_pass_merge": per_pass,
                 "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),
                 "triangles": int(sum(s["triangles"] for s in stats))}
@@ -207,9 +212,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     api_path = amdahl = None
     if group.rank == 0 and not getattr(args, "no_extras", False):
         api_path = _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, cols, op, plan, on_device, _trace)
-        kw = dict(workers=n_workers) if on_device else dict(_route="general", _pipeline="frames")
-        whole = same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), ctx=ctx, **kw)
-        amdahl = _amdahl_at_8_ranks(whole, plan, deal, every, steps, group.world)
+        amdahl = _amdahl_at_8_ranks(same_amd, frame_args, cols, op, deal, every, steps, ctx, on_device, n_workers, _trace,
+                                    next(iter(resident._frames.values())) if on_device else None)
     out = None
     if group.rank == 0:
         out = _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device, n_workers,
@@ -222,57 +226,74 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     return out if group.rank == 0 else None
 
 
-def _amdahl_at_8_ranks(whole, plan, deal, every, steps, world):
+class _OneRankOfEight:
+    """dist.MergeChannel's interface for ONE rank of a deal that is not running: what the rank would send is kept, what comes back is its
+    own rows alone (the common step on all eight ranks' rows is timed apart)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.sent, self.sent_rows, self.gather_ms = rank, world, None, 0, 0.0
+
+    def tables(self, table):
+        self.sent = table
+        return [table]
+
+    def max(self, v):
+        return float(v)
+
+
+def _amdahl_at_8_ranks(same_amd, frame_args, cols, op, deal, every, steps, ctx, on_device, n_workers, _trace, frames_obj):
     """DIAGNOSTIC (rank 0, after the timed region): what bounds this configuration at 8 ranks, from this job's own stage times.
 
     A step is this much work: the windows, the columns of the final table, the merge of what a rank can see alone -- all of it dealt
     with the windows -- and what is NOT dealt: the exchange of the seam rows and the common seam step.  The dealt part is measured
-    by this run (every rank's stage times); the part that is not is measured here for the 8-rank deal of THIS job's table, by running
-    the eight ranks' merge halves one after the other on its rows (merge.part_decided_here per rank, merge.part_after_seam_step once;
-    de-duplication on the device, as in the product)."""
+    by this run (every rank's stage times).  The rest is measured here for the 8-rank deal of THIS job: each of the eight shares is run
+    through the product function once, alone (its windows, its accumulator, its seams -- the merge stages of the slowest share are what a
+    rank of eight would spend on its own rows), and the common step is then run once on the seam rows all eight would have sent."""
     import numpy as np
 
+    from . import incumbent
     from . import merge as M
-    from .merge import _device_dedup
-    from .windows import deal_windows
 
     ranks8 = 8
-    owner = deal_windows(plan, ranks8, deal)
-    pos_of = {w["window_id"]: q for q, w in enumerate(plan)}
-    pos = whole["window_id"].map(pos_of).to_numpy(dtype=np.int64)
-    a, r = whole["Aligned_Cell_Num_Old"].to_numpy(), whole["Ref_Cell_Num_Old"].to_numpy()
-    viol, wid = whole["filtered_violation"].to_numpy(dtype=bool), whole["window_id"].to_numpy()
-    x, y, u, v = (whole[c].to_numpy(dtype=np.float64) for c in ("X", "Y", "ref_X", "ref_Y"))
-    dedup = _device_dedup()
-    local_s, sent, mine = [], [], []
+    kw = dict(workers=n_workers) if on_device else dict(_route="general", _pipeline="frames")
+    local_s, sent, windows_s = [], [], []
     for q in range(ranks8):
-        rows = np.flatnonzero(owner[pos] == q)
+        channel = _OneRankOfEight(q, ranks8)
+        _trace.reset()
         t0 = time.perf_counter()
-        seam = M.seam_rows(pos[rows], lambda b, e: (x[rows[b:e]], y[rows[b:e]], u[rows[b:e]], v[rows[b:e]]), plan, owner, q, 25.0)
-        got, table = M.part_decided_here(a[rows], r[rows], viol[rows], wid[rows], pos[rows], seam, q, dedup)
-        local_s.append(time.perf_counter() - t0)
-        sent.append(table)
-        mine.append((a[rows], got))
+        same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), ctx=ctx, merge=True, _shard=(q, ranks8, deal),
+                                          _merge_channel=channel, **kw)
+        windows_s.append(time.perf_counter() - t0)
+        rep = _trace.report()
+        local_s.append(sum(sec for name, (_c, sec) in rep.items() if name.startswith("merge:") and "seam rows exchanged" not in name))
+        sent.append(channel.sent if channel.sent is not None else {"row": np.zeros(0, np.int64)})
     t0 = time.perf_counter()
-    M.part_after_seam_step(mine[0][0], mine[0][1], sent, 0, dedup)
+    if on_device:
+        incumbent._seam_step_on_device(frames_obj, ctx, sent, 0)
+    else:
+        M.part_after_seam_step(None, np.zeros(0, np.int64), sent, 0, M._device_dedup(ctx))
     common_s = time.perf_counter() - t0
     seam_rows = [len(t["row"]) for t in sent]
     # the dealt work of one step, summed over this run's ranks (at one rank: the step itself), without what the run spent on seams
     dealt_s = sum(r_["seconds"] / steps - r_["unsharded_s_per_step"] for r_ in every)
     merge_alone_s = sum(r_["serial_tail_s_per_step"] - r_["unsharded_s_per_step"] for r_ in every)
     measured_gather = [r_["seam_gather_ms"] for r_ in every if r_.get("seam_gather_ms")]
-    exchange_s = (max(measured_gather) * 1e-3) if measured_gather else 0.5e-3
+    exchange_s = (max(measured_gather) * 1e-3) if measured_gather else 1.0e-3
     per_rank_8 = (dealt_s - merge_alone_s) / ranks8 + max(local_s)
     not_dealt_8 = exchange_s + common_s
-    return {"value": (dealt_s + 0.0) / (per_rank_8 + not_dealt_8),
+    return {"value": dealt_s / (per_rank_8 + not_dealt_8),
             "dealt_s_per_step": dealt_s, "of_which_merge_s": merge_alone_s,
             "at_8_ranks": {"merge_of_own_rows_s_max_over_ranks": max(local_s), "merge_of_own_rows_s_by_rank": local_s,
-                           "seam_rows_by_rank": seam_rows, "seam_rows_share": sum(seam_rows) / max(1, len(whole)),
+                           "seam_rows_by_rank": seam_rows, "seam_rows_share": sum(seam_rows) / max(1, sum(r_["merged_rows"] for r_ in every)),
                            "common_seam_step_s": common_s, "seam_exchange_s": exchange_s,
-                           "seam_exchange_s_is": "measured by this run's all-gather" if measured_gather else "assumed (one rank: nothing to exchange)"},
-            "means": "speed-up bound at 8 ranks = dealt / ((dealt - merge) / 8 + slowest rank's merge of its own rows + seam exchange + common "
+                           "seam_exchange_s_is": ("measured by this run's all-gather (slowest rank)" if measured_gather
+                                                  else "assumed (one rank: nothing to exchange; 2 ranks over the host transport measure 1.4-1.8 ms)"),
+                           "one_share_alone_s_by_rank": windows_s},
+            "means": "speed-up bound at 8 ranks = dealt / ((dealt - merge) / 8 + slowest share's merge of its own rows + seam exchange + common "
                      "seam step): the windows, the table and the merge of a rank's own rows are dealt with the windows (Qhull's share scales "
-                     "with the CPUs each rank has); the seam exchange and the common seam step are what every rank repeats whole"}
+                     "with the CPUs each rank has); the seam exchange and the common seam step are what every rank repeats whole.  Each "
+                     "of the eight shares was run through the product function alone for its merge stages, the common step once on all "
+                     "eight shares' seam rows"}
 
 
 def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device, n_workers,
@@ -355,9 +376,11 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                                    "remembered and nothing done with the results -- the two batched library calls per eight windows and "
                                    "the generator's own Python, on one thread and on the product function's worker threads",
         "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
+        "runtime_calls_per_pass_merge": mine_rec["runtime_calls_per_pass_merge"],
         "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued "
-                                          "per window on rank 0, counted by the library itself (same_ctx_stat) over the timed passes; the "
-                                          "merge's de-duplication included",
+                                          "per window on rank 0, counted by the library itself (same_ctx_stat) over the timed passes: the "
+                                          "stage, filter + finish and collect calls; what the window merge asks for once per PASS (resolve + "
+                                          "finish on the accumulated rows: a sort's worth of launches) is runtime_calls_per_pass_merge",
         "qhull": {"helpers": _qp.pool().n, "helpers_all_ranks": sum(r["qhull_helpers"] for r in every),
                   "ranks_on_this_host": every[0]["local_world"], "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
                   "waiting_s_per_step_rank0": sum(v["seconds"] for k_, v in stages.items() if k_.startswith("triangulate")) / steps,

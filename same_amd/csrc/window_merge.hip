@@ -39,6 +39,8 @@ struct same_merge_acc {
     int64_t n_codes_a = 0;
     int64_t n_rows = 0, n_kept = 0, n_rest = 0, n_final = 0;
     int resolved = 0;
+    int loaded = 0;                           // the rows came from the host (same_merge_acc_load): their "section rows" ARE the codes
+    int64_t loaded_codes_a = 0, loaded_codes_r = 0;
     std::vector<char> host;                   // what the last resolve / finish brought back (fetched by same_merge_acc_fetch)
 };
 
@@ -48,7 +50,7 @@ struct RestRec {
     uint32_t flags;               // bit 0 XY-order flag, bit 1 area-flip flag, bit 2 the row is at a seam
 };
 struct FinalRec {
-    int32_t a_row, r_row, cidx, wid;
+    int32_t a_row, r_row, cidx, wid, pos;
     uint32_t flags;
 };
 static_assert(sizeof(RestRec) == SAME_MERGE_REST_BYTES && sizeof(FinalRec) == SAME_MERGE_FINAL_BYTES, "record layouts are part of the ABI");
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(scan::NT) void final_kernel(const int32_t *__restri
     const int64_t c = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
     if (c < n_codes && row_of[c] >= 0) {
         const int32_t row = row_of[c];
-        out[off.a] = FinalRec{acc.a_row[row], acc.r_row[row], acc.cidx[row], acc.wid[row], acc.flags[row] & 3u};
+        out[off.a] = FinalRec{acc.a_row[row], acc.r_row[row], acc.cidx[row], acc.wid[row], acc.pos[row], acc.flags[row] & 3u};
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_total = through.a;
 }
@@ -295,7 +297,7 @@ extern "C" {
 int same_section_set_codes(same_section *s, const int32_t *codes, int64_t n_codes) {
     if (!s) return SAME_EINVAL;
     same_ctx *ctx = s->ctx;
-    REQUIRE(ctx, n_codes >= 0 && n_codes <= std::max<int64_t>(s->n, 0) && (codes || n_codes == 0));
+    REQUIRE(ctx, !codes || (n_codes >= 0 && n_codes <= std::max<int64_t>(s->n, 0)));      // without codes n_codes means nothing
     SAME_TRY(same_use(ctx));
     if (s->id_codes) {
         HIP_TRY(ctx, hipDeviceSynchronize());
@@ -343,6 +345,7 @@ int same_merge_acc_begin(same_merge_acc *a, int64_t expected_rows, int n_pos, co
     REQUIRE(ctx, !near_start || n_pos == 0 || near_boxes || near_start[n_pos] == 0);
     SAME_TRY(same_use(ctx));
     a->resolved = 0;
+    a->loaded = 0;
     a->bound = 0;
     a->n_rows = a->n_kept = a->n_rest = a->n_final = 0;
     a->n_pos = near_start ? n_pos : 0;
@@ -360,6 +363,38 @@ int same_merge_acc_begin(same_merge_acc *a, int64_t expected_rows, int n_pos, co
         if (n_boxes) SAME_COPY(ctx, a->near_boxes.p, near_boxes, (size_t)n_boxes * 4 * sizeof(double), hipMemcpyHostToDevice);
         SAME_WAIT(ctx);                            // the host arrays are the caller's again
     }
+    return SAME_OK;
+}
+
+int same_merge_acc_load(same_merge_acc *a, const int32_t *a_code, const int32_t *r_code, const uint8_t *flags, const int32_t *window_ids,
+                        const int32_t *pos, const int32_t *cidx, int64_t n, int64_t n_codes_a, int64_t n_codes_r) {
+    if (!a) return SAME_EINVAL;
+    same_ctx *ctx = a->ctx;
+    REQUIRE(ctx, n >= 0 && n < ((int64_t)1 << 30) && n_codes_a >= 0 && n_codes_r >= 0 && n_codes_a < ((int64_t)1 << 31) && n_codes_r < ((int64_t)1 << 31));
+    REQUIRE(ctx, n == 0 || (a_code && r_code && flags && window_ids && pos && cidx));
+    SAME_TRY(check_index_range(ctx, a_code, n, 0, std::max<int64_t>(n_codes_a, 1), "aligned codes"));
+    SAME_TRY(check_index_range(ctx, r_code, n, 0, std::max<int64_t>(n_codes_r, 1), "reference codes"));
+    SAME_TRY(check_index_range(ctx, window_ids, n, 0, (int64_t)1 << 31, "window ids"));
+    SAME_TRY(same_use(ctx));
+    a->resolved = 0;
+    a->n_rows = a->n_kept = a->n_rest = a->n_final = 0;
+    a->n_pos = 0;
+    a->all_seam = 0;
+    a->reach = 0.0;
+    SAME_TRY(reserve_rows(a, n, 0));
+    a->bound = n;
+    a->loaded = 1;
+    a->loaded_codes_a = n_codes_a;
+    a->loaded_codes_r = n_codes_r;
+    const unsigned long long cnt[2] = {(unsigned long long)n, 0ull};
+    SAME_COPY(ctx, a->dcount, cnt, sizeof cnt, hipMemcpyHostToDevice);
+    if (n) {
+        int32_t *const dst[5] = {a->a_row, a->r_row, a->wid, a->pos, a->cidx};
+        const int32_t *const src[5] = {a_code, r_code, window_ids, pos, cidx};
+        for (int f = 0; f < 5; ++f) SAME_COPY(ctx, dst[f], src[f], (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice);
+        SAME_COPY(ctx, a->flags, flags, (size_t)n, hipMemcpyHostToDevice);
+    }
+    SAME_WAIT(ctx);                               // the host arrays are the caller's again
     return SAME_OK;
 }
 
@@ -404,7 +439,9 @@ int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_s
     if (!accs || n_accs < 1 || !accs[0]) return SAME_EINVAL;
     same_merge_acc *a = accs[0];
     same_ctx *ctx = a->ctx;
-    REQUIRE(ctx, n_accs <= 64 && mov && ref && out_counts && mov->ctx->device == ctx->device && ref->ctx->device == ctx->device);
+    REQUIRE(ctx, n_accs <= 64 && out_counts);
+    const bool loaded = a->loaded != 0;           // rows that came from the host carry their codes: no sections, one accumulator
+    REQUIRE(ctx, loaded ? n_accs == 1 : (mov && ref && mov->ctx->device == ctx->device && ref->ctx->device == ctx->device));
     for (int q = 0; q < n_accs; ++q) {
         REQUIRE(ctx, accs[q] && accs[q]->ctx->device == ctx->device && !accs[q]->resolved);
         for (int p = 0; p < q; ++p) REQUIRE(ctx, accs[p] != accs[q]);
@@ -440,8 +477,10 @@ int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_s
     }
     for (int q = 0; q < n_accs; ++q) accs[q]->resolved = 1;
     a->n_rows = n;
-    a->n_codes_a = mov->id_codes ? mov->n_codes : mov->n;
-    const int64_t n_codes_a = std::max<int64_t>(a->n_codes_a, 1), n_codes_r = std::max<int64_t>(ref->id_codes ? ref->n_codes : ref->n, 1);
+    a->n_codes_a = loaded ? a->loaded_codes_a : (mov->id_codes ? mov->n_codes : mov->n);
+    const int64_t n_codes_a = std::max<int64_t>(a->n_codes_a, 1),
+                  n_codes_r = std::max<int64_t>(loaded ? a->loaded_codes_r : (ref->id_codes ? ref->n_codes : ref->n), 1);
+    const int32_t *codes_a = loaded ? nullptr : mov->id_codes, *codes_r = loaded ? nullptr : ref->id_codes;
     // layout of the work buffer: [scan words of the rest list | counters] zeroed; codes, survivors, classes, degree tables, the result table
     const int64_t nn = std::max<int64_t>(n, 1);
     Carver cv;
@@ -465,11 +504,11 @@ int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_s
     SAME_TRY(ensure(ctx, a->out, (size_t)nn * sizeof(RestRec)));          // the rest list: at most n records
     RestRec *rest = static_cast<RestRec *>(a->out.p);
     if (n) {
-        SAME_LAUNCH(ctx, codes_kernel, dim3(grid_for(n)), dim3(256), 0, a->a_row, a->r_row, n, mov->id_codes, ref->id_codes, a->ac, a->rc);
+        SAME_LAUNCH(ctx, codes_kernel, dim3(grid_for(n)), dim3(256), 0, a->a_row, a->r_row, n, codes_a, codes_r, a->ac, a->rc);
         SAME_TRY(same_merge_dedup_core(ctx, a->flags, 1u, a->wid, a->ac, a->rc, n, kept, counters));          // counters[0] = survivors
         SAME_LAUNCH(ctx, degree_kernel, dim3(grid_for(n)), dim3(256), 0, kept, counters, n, a->ac, a->rc, deg_a, deg_r);
-        const SeamArgs seams{a->n_pos ? static_cast<const int32_t *>(a->near_start.p) : nullptr, static_cast<const double *>(a->near_boxes.p), mov->xy,
-                             ref->xy, a->n_pos, a->all_seam, a->reach};
+        const SeamArgs seams{a->n_pos ? static_cast<const int32_t *>(a->near_start.p) : nullptr, static_cast<const double *>(a->near_boxes.p),
+                             loaded ? nullptr : mov->xy, loaded ? nullptr : ref->xy, a->n_pos, a->all_seam, a->reach};
         SAME_LAUNCH(ctx, classify_kernel, dim3(grid_for(n)), dim3(256), 0, kept, counters, n, a->ac, a->rc, deg_a, deg_r, a->a_row, a->r_row, a->pos,
                     seams, cls, a->row_of);
         SAME_LAUNCH(ctx, rest_kernel, dim3(scan::blocks_for(n)), dim3(scan::NT), 0, kept, counters, cls, a->ac, a->rc, rows_of(a), scan::arg(status), rest,

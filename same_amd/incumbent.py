@@ -271,12 +271,13 @@ def _device_ref_idx(dw):
 
 def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None, moving_delaunay_vertex_col=None,
                              optim_params=None, gurobi_params=None, ignore_precomputed_triangulation=False, *, workers=None,
-                             window_local_indices=False, return_stats=False, triangulator=None, ctx=None, merge=False, _shard=None,
-                             _pipeline=None, _route=None, _merge_channel=None):
+                             window_local_indices=False, return_stats=False, triangulator=None, ctx=None, merge=False, batch=None,
+                             _shard=None, _pipeline=None, _route=None, _merge_channel=None):
     """See the module text.  -> DataFrame (with return_stats: (DataFrame, [per-window stats dict in plan order])).
     workers: threads walking this process's windows on the device route (default: 2 where the process has >= 8 CPUs, else 1).
     A window whose prune leaves no pairs raises the ValueError run_same raises for it (src/same.py:1003), as the reference's loop does.
-    `triangulator`: see windows.iter_device_windows.  `_route` = 'device' | 'general' (testing: forces a route).
+    `triangulator`, `batch` (windows per library call on the device route): see windows.iter_device_windows.  `_route` = 'device' |
+    'general' (testing: forces a route).
     merge=True: the table after `merge_window_matches_unique_ref` (src/helpers.py:692-815) -- one row per aligned and per reference cell,
     aligned ids ascending -- without the pre-merge table ever being laid out: the merge reads the rows' keys, and only the rows it keeps
     get their columns.  With `_shard` and a `_merge_channel` (dist.MergeChannel) the result is this rank's PART of the merged table
@@ -294,7 +295,7 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
         if merge and job.all_matches:
             raise ValueError("merge=True does not resume from an outprefix that already holds windows")
         if fast:
-            table = _device_route(job, frames, workers, window_local_indices, triangulator, stats, merge, _merge_channel)
+            table = _device_route(job, frames, workers, window_local_indices, triangulator, stats, merge, _merge_channel, batch)
         else:
             table = _general_route(job, frames, window_local_indices, stats, ctx)
             if merge:
@@ -340,7 +341,7 @@ def _merged_rows(job, frames, builders, channel):
     return M.merged_part_rows(a_ids, r_ids, viol, wid, pos, seam, channel.rank, channel.tables)
 
 
-def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge=False, channel=None):
+def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge=False, channel=None, batch=None):
     n_workers = max(1, int(workers if workers is not None else _default_workers()))
     n_workers = min(n_workers, max(1, len(job.todo)))
     contexts = frames.worker_contexts(n_workers)
@@ -362,7 +363,7 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
         if accs is not None:
             collector = lambda states, windows: accs[q].collect(states, [w["trim"] for w in windows], [w["window_id"] for w in windows],
                                                                 [pos_of[id(w)] for w in windows])
-        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator, collector=collector)):
+        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator, collector=collector, batch=batch)):
             if dw.error is not None:
                 raise dw.error
             with stage("table rows (central trim)"):
@@ -416,10 +417,21 @@ def _begin_accumulators(job, frames, contexts, cut, channel):
         if key not in known:
             known[key] = M.seam_tables(job.plan, job.owner, channel.rank, reach)
         near = known[key]
+    calls0 = accs[0].ctx.stats()
     for q, acc in enumerate(accs):
         expected = sum(w["n_mov"] for _pos, w in job.todo[cut[q]:cut[q + 1]])
         acc.begin(expected, near, reach, all_seam=channel is not None and channel.world > 1 and not unique)
+    _count_merge_calls(frames, accs[0].ctx, calls0, passes=0)
     return accs
+
+
+def _count_merge_calls(frames, ctx0, calls0, passes=1):
+    """what the merge itself asked of the runtime on the first worker's context, per PASS (begin, resolve, finish: a sort's worth of launches;
+    the windows' calls are counted per window) -- read by bench.py and by the launch-budget test"""
+    spent = frames.__dict__.setdefault("merge_runtime_calls", {})
+    for k, v in ctx0.stats().items():
+        spent[k] = spent.get(k, 0) + v - calls0[k]
+    spent["passes"] = spent.get("passes", 0) + passes
 
 
 def _merge_on_device(job, frames, accs, channel):
@@ -429,6 +441,8 @@ def _merge_on_device(job, frames, accs, channel):
     from . import merge as M
     from .windows import resolve_accumulators
 
+    ctx0 = accs[0].ctx
+    calls0 = ctx0.stats()
     with stage("merge: accumulated rows resolved (device)"):
         _counts, rest = resolve_accumulators(accs, frames.dmov, frames.dref)
     a, r, wid = rest["ac"].astype(np.int64), rest["rc"].astype(np.int64), rest["wid"].astype(np.int64)
@@ -442,9 +456,40 @@ def _merge_on_device(job, frames, accs, channel):
         with stage("merge: seam rows exchanged"):
             parts = channel.tables(sent)
         with stage("merge: seam step (the same on every rank)"):
-            rows = M.part_after_seam_step(None, mine, parts, channel.rank, M._device_dedup())
+            rows = np.concatenate((mine, _seam_step_on_device(frames, ctx0, parts, channel.rank)))
     with stage("merge: winners to the device, final rows back"):
-        return accs[0].finish(rest["row"][rows])
+        final = accs[0].finish(rest["row"][rows])
+    _count_merge_calls(frames, ctx0, calls0)
+    return final
+
+
+def _seam_step_on_device(frames, ctx, parts, rank):
+    """The common step of a merge dealt over ranks (merge.part_after_seam_step) with the gathered seam rows on the device: they are
+    loaded into an accumulator of their own (their cells named by codes, in the single process's order), de-duplicated, counted and
+    classed there like a pass's own rows; the host matches the few cells that are still contested.  -> this rank's winners (indices into
+    the table it sent)."""
+    from . import merge as M
+    from .windows import MergeAccumulator, resolve_accumulators
+
+    parts = [p for p in parts if len(p["row"])]
+    if not parts:
+        return np.zeros(0, np.int64)
+    col = lambda c: np.concatenate([p[c] for p in parts])
+    order_key = col("order")
+    order = None if bool(np.all(order_key[1:] >= order_key[:-1])) else np.argsort(order_key, kind="stable")
+    take = (lambda c: col(c)) if order is None else (lambda c: col(c)[order])
+    a, r = take("a"), take("r")
+    acc = frames.__dict__.get("_seam_acc")
+    if acc is None or acc.ctx is not ctx:
+        acc = frames.__dict__["_seam_acc"] = MergeAccumulator(ctx)
+        frames.__dict__.setdefault("_accs", {})[("seam", id(ctx))] = acc           # closed with the frames
+    # pos carries the sender's rank, cidx its row in the table it sent: what comes back names the winners by both
+    acc.load(a, r, take("viol"), take("window"), take("rank"), take("row"), int(a.max()) + 1, int(r.max()) + 1)
+    _counts, rest = resolve_accumulators([acc], None, None)
+    won = M._resolve_rows(rest["ac"].astype(np.int64), rest["rc"].astype(np.int64), (rest["flags"] & 1) != 0, rest["wid"].astype(np.int64),
+                          M.already_deduplicated, mark=False) if len(rest) else np.zeros(0, np.int64)
+    final = acc.finish(rest["row"][won])
+    return final["cidx"][final["pos"] == rank].astype(np.int64)
 
 
 def _general_route(job, frames, with_ref_idx, stats, ctx):

@@ -156,10 +156,11 @@ def _resolve_rows(a_ids, r_ids, viol, window_id, dedup, seam=None, mark=True):
     return selected if seam is None else (selected, kept[shared])
 
 
-def _device_dedup():
+def _device_dedup(ctx=None):
+    """the device step (ops.merge_dedup on `ctx`); there is no host substitute in the product: a missing GPU raises SameHipError"""
     from . import ops
 
-    return ops.merge_dedup      # the device step; there is no host substitute in the product (a missing GPU raises SameHipError)
+    return ops.merge_dedup if ctx is None else (lambda viol, window_id, a_code, r_code: ops.merge_dedup(viol, window_id, a_code, r_code, ctx=ctx))
 
 
 def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _dedup=None):

@@ -120,7 +120,7 @@ class _DeviceFrames:
             return "cell_type missing (priority filter)"
         return None
 
-    def windows(self, plan, triangulate=True, ctx=None, triangulator=None, fetch_triangles=False, collector=None):
+    def windows(self, plan, triangulate=True, ctx=None, triangulator=None, fetch_triangles=False, collector=None, batch=None):
         from .windows import iter_device_windows
 
         op = self.op
@@ -128,7 +128,7 @@ class _DeviceFrames:
                                    dist_ct_coeff=op["dist_ct_coeff"], min_angle_deg=op.get("min_angle_deg", 15),
                                    ignore_same_type_triangles=op["ignore_same_type_triangles"], no_match_penalty=op["no_match_penalty"],
                                    ctx=self.ctx if ctx is None else ctx, triangulate=triangulate, triangulator=triangulator,
-                                   fetch_triangles=fetch_triangles, collector=collector)
+                                   fetch_triangles=fetch_triangles, collector=collector, batch=batch)
 
     def accumulators(self, contexts, cid):
         """One merge accumulator per worker context (kept with the frames: a pass re-uses the arrays of the last), and the sections' id

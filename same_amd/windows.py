@@ -467,7 +467,7 @@ class DeviceWindow:
 
 
 REST_RECORD = np.dtype([("row", "<i4"), ("ac", "<i4"), ("rc", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("cidx", "<i4"), ("flags", "<u4")])   # SAME_MERGE_REST
-FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("wid", "<i4"), ("flags", "<u4")])                            # SAME_MERGE_FINAL
+FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("flags", "<u4")])             # SAME_MERGE_FINAL
 
 
 class MergeAccumulator:
@@ -508,6 +508,17 @@ class MergeAccumulator:
         with ctx.lock:
             ctx.check(ctx.lib.same_window_collect(_handles(states), n, self.handle, t.ctypes.data, w.ctypes.data, p.ctypes.data), "same_window_collect")
 
+    def load(self, a_code, r_code, flags, window_ids, pos, cidx, n_codes_a, n_codes_r):
+        """Rows from the host instead of from windows (the ranks' seam rows after their exchange): the accumulator then holds exactly
+        these rows, whose cells are named by codes; `resolve_accumulators([acc], None, None)` and `finish` follow."""
+        ctx = self.ctx
+        i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        a, r, w, p, c = i32(a_code), i32(r_code), i32(window_ids), i32(pos), i32(cidx)
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        with ctx.lock:
+            ctx.check(ctx.lib.same_merge_acc_load(self.handle, a.ctypes.data, r.ctypes.data, f.ctypes.data, w.ctypes.data, p.ctypes.data, c.ctypes.data,
+                                                  len(a), int(n_codes_a), int(n_codes_r)), "same_merge_acc_load")
+
     def finish(self, winner_rows):
         """The REST rows the host's matching kept (accumulator row numbers) -> the merged table's rows as FINAL_RECORDs, aligned codes ascending."""
         import ctypes
@@ -544,7 +555,8 @@ def resolve_accumulators(accs, dmoving, dref):
     counts = np.zeros(4, np.int64)
     handles = (ctypes.c_void_p * len(accs))(*[a.handle.value for a in accs])
     with ctx.lock:
-        ctx.check(ctx.lib.same_merge_acc_resolve(handles, len(accs), dmoving.handle, dref.handle, counts.ctypes.data), "same_merge_acc_resolve")
+        ctx.check(ctx.lib.same_merge_acc_resolve(handles, len(accs), None if dmoving is None else dmoving.handle,
+                                                 None if dref is None else dref.handle, counts.ctypes.data), "same_merge_acc_resolve")
         rest = np.empty(int(counts[2]), REST_RECORD)
         ctx.check(ctx.lib.same_merge_acc_fetch(accs[0].handle, 0, rest.ctypes.data, rest.nbytes), "same_merge_acc_fetch")
     return tuple(int(c) for c in counts), rest

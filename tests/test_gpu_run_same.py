@@ -854,14 +854,15 @@ def _sharded_incumbent_worker(rank, world, deal, out_dir):
     r_big, m_big, cols = _sw_inputs()
     _r, m_two, _c = _sw_inputs_crowded()
     op = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
+    op2 = dict(radius=25, knn=6, window_size=100, overlap=4, min_cells_per_window=20)      # an overlap far below the prune's reach: neighbouring windows see different suitors of a cell and disagree
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
     if world == 2:     # the package's own wrappers over its plain-Python host group (RANK / WORLD_SIZE / SAME_RDV_DIR)
         part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)      # every rank: the whole table
-        merged = sharded_merged_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op), deal=deal)     # every rank: its part of the merge
+        merged = sharded_merged_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op2), deal=deal)     # every rank: its part of the merge
     else:              # the share of one rank, as a launcher with its own exchange would take it
         part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), _shard=(rank, world, deal))
         with HostGroup() as g:
-            merged = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op), merge=True, _route="general",
+            merged = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op2), merge=True, _route="general",
                                                        _pipeline="frames" if rank == 1 else None, _shard=(rank, world, deal),
                                                        _merge_channel=MergeChannel(g))
             g.barrier()
@@ -898,10 +899,12 @@ def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world, 
         assert merged.equals(whole)
     _assert_incumbent_equals_golden(whole, load_golden("run_same_mock"), "sw", with_ref_idx=False)
     _r, m_two, _c = _sw_inputs_crowded()
-    crowded = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op))
+    op2 = dict(radius=25, knn=6, window_size=100, overlap=4, min_cells_per_window=20)
+    crowded = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op2))
     want = merge_window_matches_unique_ref([crowded])
-    assert 300 < len(want) < len(crowded) - 20                                # the overlaps do disagree in this job
-    one = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op), merge=True)
+    print('window disagreements settled by the merge:', len(crowded) - len(want))
+    assert 300 < len(want) <= len(crowded) - 5                                # the overlaps do disagree in this job
+    one = same_amd.sliding_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op2), merge=True)
     assert list(one.columns) == list(want.columns) and one.equals(want)       # one process: the merge without the pre-merge table
     mparts = [pd.read_pickle(tmp_path / f"merged{rank}.pkl") for rank in range(world)]
     assert all(0 < len(p) < len(want) and "__plan_pos" not in p.columns for p in mparts)
@@ -1364,40 +1367,59 @@ def test_window_rows_when_points_sit_on_cell_and_box_edges():
 def test_window_calls_stay_within_their_launch_budget():
     """What a window costs in runtime calls, counted by the library itself (same_ctx_stat), ENTERED THROUGH THE PRODUCT FUNCTIONS.  Every
     kernel of the two window calls takes up to eight windows per launch, the heads of their buffers are zeroed by one launch, the call's
-    simplices go up in one copy and the answers are written into the pinned blocks by one launch: a batch of eight windows is ~40 launches,
-    no fill, one copy and two waits -- per window 5 launches, 0.13 copies, 0.25 waits (round 5 before that: 18 launches, 3 fills, 4 copies;
-    round 4 two waits; round 3 ~80 launches, ~24 fills, ~13 copies and 5-6 waits).  The plan here has a batch of eight and a rest, hence the
-    budgets: 10 launches, 1 fill, 2 copies.  iter_prepared_windows (what sliding_window_matching hands its run_same body) adds the seven
-    arrays it fetches for the solver: pairs, reference rows, costs, triangles, signs, weights."""
+    simplices go up in one copy and the answers are written into the pinned blocks by one launch: a batch of eight windows is 6-7 + 16
+    launches (19 with fp64 costs), no fill, one copy and two waits -- per window 2.75-3.25 launches, 0 fills, 0.125 copies, 0.25 waits,
+    the figures of README.md / profiles/README.md / include/same_hip.h (round 5 before that: 18 launches, 3 fills, 4 copies; round 4 two
+    waits; round 3 ~80 launches, ~24 fills, ~13 copies and 5-6 waits).  The plan here is 16 windows = two whole batches on frames that
+    are resident already (the sections' upload and binning are per JOB, not per window), so the budgets sit right above those figures:
+    a slip back to a launch, a fill or a copy per window fails.  With the window merge on the device (merge=True) a batch adds the three
+    launches of same_window_collect; what the merge asks for once per pass is counted apart.  iter_prepared_windows (what
+    sliding_window_matching hands its run_same body) adds the seven arrays it fetches for the solver: pairs, reference rows, costs,
+    triangles, signs, weights."""
     import same_amd
     from same_amd import _lib, synth
     from same_amd import windows as W
 
     T = 8
-    ref = synth.make_cells(150_000, T, seed=0)
+    ref = synth.make_cells(125_000, T, seed=0)
     mov = synth.make_jittered(ref, seed=1)
     r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
     cols = synth.type_columns(T)
     op = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0, hip_cost_dtype="float32",
               window_size=1200, overlap=300, min_cells_per_window=10)
     plan = W.window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
+    assert len(plan) == 16
     ctx = _lib.default_context()
-    same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), workers=1)          # buffers, helpers, the prune index
-    before = ctx.stats()
-    res, stats = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), workers=1, return_stats=True)
-    after = ctx.stats()
-    # the two section uploads + binnings of the call are part of the count: a handful of launches and copies per JOB, spread over its windows
-    per = {k: (after[k] - before[k]) / len(stats) for k in after}
-    print("per window (sliding_window_incumbent):", per)
-    assert len(stats) == len(plan) >= 9 and sum(s["pairs"] for s in stats) > 100_000 and len(res) > 50_000
-    # windows go to the library in batches of 8: ONE wait per call for the whole batch (it was one per window and call)
-    assert per["launches"] <= 10 and per["fills"] <= 1 and per["copies"] <= 2 and per["waits"] <= 0.6, per
+    with same_amd.resident_frames(r_df, m_df, ctx=ctx) as res_frames:
+        call = lambda **kw: same_amd.sliding_window_incumbent(res_frames, res_frames, commonCT=cols, optim_params=dict(op), workers=1, ctx=ctx,
+                                                              batch=8, return_stats=True, **kw)
+        call()                                                           # buffers, helpers, the prune index, the sections
+        before = ctx.stats()
+        res, stats = call()
+        after = ctx.stats()
+        per = {k: (after[k] - before[k]) / len(stats) for k in after}
+        print("per window (sliding_window_incumbent):", per)
+        assert len(stats) == len(plan) and sum(s["pairs"] for s in stats) > 100_000 and len(res) > 50_000
+        # windows go to the library in batches of 8: ONE wait per call for the whole batch (it was one per window and call)
+        assert per["launches"] <= 3.5 and per["fills"] == 0 and per["copies"] <= 0.3 and per["waits"] <= 0.3, per
+        call(merge=True)                                                 # the accumulator's arrays
+        frames = next(iter(res_frames._frames.values()))
+        spent0, before = dict(frames.merge_runtime_calls), ctx.stats()
+        merged, stats_m = call(merge=True)
+        after, spent1 = ctx.stats(), frames.merge_runtime_calls
+        once = {k: spent1[k] - spent0[k] for k in after}
+        per = {k: (after[k] - before[k] - once[k]) / len(stats_m) for k in after}
+        print("per window (merge=True):", per, "; the merge, once per pass:", once)
+        assert 50_000 < len(merged) <= len(res) and stats_m == stats
+        assert per["launches"] <= 4.0 and per["fills"] == 0 and per["copies"] <= 0.3 and per["waits"] <= 0.3, per
+        assert once["launches"] <= 80 and once["copies"] <= 8 and once["waits"] <= 6, once
     before = ctx.stats()
     preps = [p for _w, p in same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=dict(op)) if not isinstance(p, Exception)]
     after = ctx.stats()
     per = {k: (after[k] - before[k]) / len(preps) for k in after}
     print("per window (iter_prepared_windows):", per)
-    assert len(preps) == len(stats) and per["launches"] <= 10 and per["fills"] <= 1 and per["copies"] <= 9 and per["waits"] <= 8, per
+    # (these two build their sections inside the call: a handful of launches and copies per JOB, spread over 16 windows)
+    assert len(preps) == len(stats) and per["launches"] <= 6 and per["fills"] <= 1 and per["copies"] <= 9 and per["waits"] <= 8, per
     # ... and through the reference's own signature, with the incumbent standing in for the solver half of run_same
     from same_amd.incumbent import incumbent_of_prepared
 
@@ -1407,5 +1429,5 @@ def test_window_calls_stay_within_their_launch_budget():
     per = {k: (after[k] - before[k]) / len(stats) for k in after}
     print("per window (sliding_window_matching):", per)
     assert out["window_id"].nunique() == len(stats) and len(out) == len(res)
-    assert per["launches"] <= 10 and per["fills"] <= 1 and per["copies"] <= 9 and per["waits"] <= 8, per
+    assert per["launches"] <= 6 and per["fills"] <= 1 and per["copies"] <= 9 and per["waits"] <= 8, per
     assert np.array_equal(out["Aligned_Cell_Num_Old"].to_numpy(), res["Aligned_Cell_Num_Old"].to_numpy()) and np.array_equal(out["Ref_Cell_Num_Old"].to_numpy(), res["Ref_Cell_Num_Old"].to_numpy())
