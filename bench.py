@@ -118,13 +118,14 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
     arm_rank_watchdog(group.rank)
     note(group, f"host group up: world {group.world} (rendezvous: loopback TCP, plain Python)")
+    from same_amd import qhull_pool
+
+    qhull_pool.learn_cpu_sharing(group)      # do the ranks on this host share CPUs (divide the Qhull helper budget) or is every rank bound to its own?
 
     if args.dry_launch:   # control-plane check, no GPU: id broadcast, barrier, max -- what the real run does on the host side
         uid = group.bcast_bytes(bytes(range(128)) if group.rank == 0 else b"")
         group.barrier()
         mx = group.max(float(group.rank + 1))
-        from same_amd import qhull_pool
-
         ranks = group.allgather_object({"rank": group.rank, "pid": os.getpid(), "id_ok": uid == bytes(range(128)),
                                         "local_world": qhull_pool.local_world()[0], "qhull_helpers": qhull_pool.default_workers()})
         if group.rank == 0:

@@ -9,7 +9,7 @@ from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s",
                "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged", "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
-               "after_windows_s_per_step", "unsharded_s_per_step", "merge_stages_s_per_step_rank0", "amdahl_bound_at_8_ranks", "amdahl",
+               "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0", "amdahl_bound_at_8_ranks", "amdahl",
                "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull", "merged_matches", "parity_spot_check", "rccl",
                "product_function", "api_path_windows_per_s", "api_path", "window_calls_only_windows_per_s")
 
@@ -181,7 +181,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # columns of the rows that stay -- one thread, while the workers' threads are done
     seconds_of = lambda prefix: sum(sec for name, (_c, sec) in rep.items() if name.startswith(prefix))
     merge_s, table_s = seconds_of("merge:"), seconds_of("table (columns")
-    unsharded_s = seconds_of("merge: seam rows exchanged") + seconds_of("merge: seam step")
+    exchange_s, seam_step_s = seconds_of("merge: seam rows exchanged"), seconds_of("merge: seam step")
+    unsharded_s = exchange_s + seam_step_s
     walk_s = max(wall_here - merge_s - table_s, 1e-9)
     # what the threads could have used: every worker for the window passes, one thread for what comes after them
     thread_seconds = max(walk_s * n_workers + merge_s + table_s, 1e-9)
@@ -190,6 +191,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                 "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / thread_seconds),
                 "qhull_wait_share": qhull_wait / thread_seconds, "serial_tail_s_per_step": merge_s / steps,
                 "table_gather_s_per_step": table_s / steps, "unsharded_s_per_step": unsharded_s / steps,
+                "seam_exchange_s_per_step": exchange_s / steps, "seam_step_s_per_step": seam_step_s / steps,
                 "merge_stages_s_per_step": {name: sec / steps for name, (_c, sec) in sorted(rep.items()) if name.startswith("merge:")},
                 "windows_per_s_triangulations_given": no_qhull, "windows_per_s_triangulations_given_merged": no_qhull_merged,
                 "window_calls_only_windows_per_s": calls_only, "merged_rows": int(len(merged)),
@@ -277,8 +279,10 @@ def _amdahl_at_8_ranks(same_amd, frame_args, cols, op, deal, every, steps, ctx, 
     # the dealt work of one step, summed over this run's ranks (at one rank: the step itself), without what the run spent on seams
     dealt_s = sum(r_["seconds"] / steps - r_["unsharded_s_per_step"] for r_ in every)
     merge_alone_s = sum(r_["serial_tail_s_per_step"] - r_["unsharded_s_per_step"] for r_ in every)
-    measured_gather = [r_["seam_gather_ms"] for r_ in every if r_.get("seam_gather_ms")]
-    exchange_s = (max(measured_gather) * 1e-3) if measured_gather else 1.0e-3
+    # an all-gather ends when the LAST rank arrives: the rank that arrives last sees the exchange itself, the others also their wait for it
+    # (that wait is the deal's imbalance, part of the dealt work's max over ranks -- not something every rank repeats)
+    measured_gather = [r_["seam_exchange_s_per_step"] for r_ in every if len(every) > 1]
+    exchange_s = min(measured_gather) if measured_gather else 1.0e-3
     per_rank_8 = (dealt_s - merge_alone_s) / ranks8 + max(local_s)
     not_dealt_8 = exchange_s + common_s
     return {"value": dealt_s / (per_rank_8 + not_dealt_8),
@@ -286,7 +290,7 @@ def _amdahl_at_8_ranks(same_amd, frame_args, cols, op, deal, every, steps, ctx, 
             "at_8_ranks": {"merge_of_own_rows_s_max_over_ranks": max(local_s), "merge_of_own_rows_s_by_rank": local_s,
                            "seam_rows_by_rank": seam_rows, "seam_rows_share": sum(seam_rows) / max(1, sum(r_["merged_rows"] for r_ in every)),
                            "common_seam_step_s": common_s, "seam_exchange_s": exchange_s,
-                           "seam_exchange_s_is": ("measured by this run's all-gather (slowest rank)" if measured_gather
+                           "seam_exchange_s_is": ("measured by this run: the all-gather as the last rank to arrive saw it" if measured_gather
                                                   else "assumed (one rank: nothing to exchange; 2 ranks over the host transport measure 1.4-1.8 ms)"),
                            "one_share_alone_s_by_rank": windows_s},
             "means": "speed-up bound at 8 ranks = dealt / ((dealt - merge) / 8 + slowest share's merge of its own rows + seam exchange + common "
@@ -332,7 +336,8 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                      "python_share": by_rank("python_share"), "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
                      "in_library_s_per_step": [r["in_library_s"] / steps for r in every],
                      "serial_tail_s_per_step": by_rank("serial_tail_s_per_step"), "table_gather_s_per_step": by_rank("table_gather_s_per_step"),
-                     "unsharded_s_per_step": by_rank("unsharded_s_per_step"), "seam_rows_sent_per_step": by_rank("seam_rows_sent_per_step"),
+                     "unsharded_s_per_step": by_rank("unsharded_s_per_step"), "seam_exchange_s_per_step": by_rank("seam_exchange_s_per_step"),
+                     "seam_step_s_per_step": by_rank("seam_step_s_per_step"), "seam_rows_sent_per_step": by_rank("seam_rows_sent_per_step"),
                      "seam_gather_ms": by_rank("seam_gather_ms"), "merged_rows": by_rank("merged_rows"),
                      "qhull_helpers": by_rank("qhull_helpers"), "windows_per_s_triangulations_given": given,
                      "qhull_l3_domains": by_rank("qhull_domains")},
@@ -355,9 +360,11 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
         "merge_stages_s_per_step_rank0": mine_rec["merge_stages_s_per_step"],
         "table_gather_s_per_step": max(by_rank("table_gather_s_per_step")),
         "after_windows_s_per_step": max(a_ + b_ for a_, b_ in zip(by_rank("serial_tail_s_per_step"), by_rank("table_gather_s_per_step"))),
-        "unsharded_s_per_step": max(by_rank("unsharded_s_per_step")),
-        "unsharded_means": "the part of a step that is not dealt with the windows: the all-gather of the seam rows and the common seam "
-                           "step every rank runs on them (0 at one rank)",
+        "unsharded_s_per_step": min(by_rank("seam_exchange_s_per_step")) + max(by_rank("seam_step_s_per_step")),
+        "unsharded_means": "the part of a step that is not dealt with the windows: the all-gather of the seam rows (as the last rank to "
+                           "arrive sees it: the others' longer stay in the call is their wait for that rank, `seam_wait_s_per_step`, the "
+                           "deal's imbalance) and the common seam step every rank runs on them (0 at one rank)",
+        "seam_wait_s_per_step": max(by_rank("seam_exchange_s_per_step")) - min(by_rank("seam_exchange_s_per_step")),
         "amdahl_bound_at_8_ranks": None if amdahl is None else amdahl["value"], "amdahl": amdahl,
         "seam_exchange": None if comm is None else {
             "rows_sent_per_step_by_rank": by_rank("seam_rows_sent_per_step"), "ms_by_rank": by_rank("seam_gather_ms"),

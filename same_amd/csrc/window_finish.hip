@@ -641,15 +641,19 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
             w->filtered = w->finished = 1;
             continue;
         }
-        SAME_TRY(read_finish(w, &it.plan, out_match_row + cell0, out_point_flag + cell0, stats));
+        int32_t *const match_out = out_match_row + cell0;
+        uint8_t *const flag_out = out_point_flag + cell0;
         cell0 += w->n_ua;
         if (it.filtered) {
+            // the filter's counters first (they are on the host since the batch's one wait): a window with a cosine at the threshold is
+            // redone by the caller with prefiltered = 1, so nothing of it is read back here -- in particular no further greedy rounds
+            // (fills, launches and a wait per batch of rounds) are spent on a matching that is thrown away
             const unsigned long long *hf = reinterpret_cast<const unsigned long long *>(static_cast<const char *>(w->host) + w->host_filter_off);
             const int64_t n_keep = (int64_t)hf[FC_KEEP], n_near = (int64_t)hf[FC_NEAR], n_add = it.fplan.readd ? (int64_t)hf[FC_ADD] : 0;
             counts[0] = n_keep;
             counts[1] = n_add;
             counts[2] = n_near;
-            if (n_near) {             // the caller filters this window on the host and calls again with prefiltered = 1: nothing here counts
+            if (n_near) {
                 for (int q = 0; q < 8; ++q) stats[q] = 0;
                 continue;
             }
@@ -658,6 +662,7 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
             counts[0] = Tr;
             w->Tr = Tr;
         }
+        SAME_TRY(read_finish(w, &it.plan, match_out, flag_out, stats));
         w->filtered = w->finished = 1;
     }
     return SAME_OK;

@@ -511,6 +511,7 @@ def _sharded_windows(run, ref, moving, commonCT, group, exchange, rank, world, d
         if group is None:
             group = own_group = HostGroup()
         world, rank, exchange = group.world, group.rank, group.allgather_object
+        _learn_cpu_sharing(group)
     elif rank is None or world is None:
         raise ValueError("a custom exchange needs rank and world")
     try:
@@ -528,6 +529,19 @@ def _sharded_windows(run, ref, moving, commonCT, group, exchange, rank, world, d
     if not parts:
         return pd.DataFrame()
     return _plan_order(parts)
+
+
+def _learn_cpu_sharing(group):
+    """the Qhull helper budget of a rank depends on whether the ranks of this host share CPUs: settled from their masks, once per group"""
+    if getattr(group, "_cpu_sharing_known", False) or not hasattr(group, "allgather_object"):
+        return
+    from . import qhull_pool
+
+    qhull_pool.learn_cpu_sharing(group)
+    try:
+        group._cpu_sharing_known = True
+    except AttributeError:
+        pass
 
 
 def _plan_order(parts):
@@ -562,6 +576,7 @@ def sharded_merged_window_incumbent(ref, moving, commonCT=None, group=None, ctx=
     if group is None:
         group = own_group = HostGroup()
     try:
+        _learn_cpu_sharing(group)
         channel = MergeChannel(group, ctx, comm)
         shard = (group.rank, group.world, deal) if group.world > 1 else None
         part = sliding_window_incumbent(ref, moving, commonCT=commonCT, ctx=ctx, merge=True, _shard=shard, _merge_channel=channel, **kwargs)

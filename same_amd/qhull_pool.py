@@ -143,12 +143,41 @@ def local_world():
     return n, min(max(0, r or 0), n - 1)
 
 
+_LEARNED_SHARERS = None      # (ranks whose CPUs overlap this rank's, this rank's index among them), from the ranks' own masks (learn_cpu_sharing)
+
+
+def learn_cpu_sharing(group):
+    """Decide from EVIDENCE whether this rank shares its CPUs with other ranks of the job: every rank tells the others (over the host
+    group: dist.py / bench.py call this once the group is up) its host and its affinity mask.  Ranks on this host whose masks overlap
+    this rank's share its CPUs -- a plain launch, or one container cpuset for all ranks (docker --cpuset-cpus=0-15 for eight ranks on a
+    128-CPU host: every rank's mask is 16 CPUs and THE SAME 16) -- and the budget is divided among them; a bound launch (slurm
+    --cpu-bind, numactl, one cpuset per rank) gives pairwise disjoint masks and every rank keeps its whole mask.  -> cpu_sharers()."""
+    global _LEARNED_SHARERS
+    import socket
+
+    try:
+        mask = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        mask = None
+    every = group.allgather_object({"host": socket.gethostname(), "mask": mask, "rank": int(group.rank)})
+    me = every[group.rank]
+    if mask is None:
+        _LEARNED_SHARERS = None
+        return cpu_sharers()
+    mine = set(mask)
+    sharing = sorted(e["rank"] for e in every if e["host"] == me["host"] and (e["mask"] is None or mine & set(e["mask"])))
+    _LEARNED_SHARERS = (len(sharing), sharing.index(int(group.rank)))
+    return _LEARNED_SHARERS
+
+
 def cpu_sharers():
     """(ranks of this job that share the CPUs of `cpu_budget()`, this rank's index among them).  Ranks launched plainly all see the same
-    affinity mask and cgroup quota, and the budget is divided between the `local_world()` of them.  A BOUND launch (slurm --cpu-bind,
-    numactl, one cpuset per rank) hands every rank a mask of its own: `cpu_budget()` is then already this rank's share and dividing it
-    again would leave 1 / L of the helpers (3 instead of 24 at eight ranks).  The two are told apart by the mask itself: one no larger
-    than the rank's 1 / L part of the host's CPUs is taken to be the rank's own.  SAME_CPU_SHARERS overrides the count."""
+    affinity mask and cgroup quota, and the budget is divided between them.  A BOUND launch (slurm --cpu-bind, numactl, one cpuset per
+    rank) hands every rank a mask of its own: `cpu_budget()` is then already this rank's share and dividing it again would leave 1 / L
+    of the helpers (3 instead of 24 at eight ranks).  The two cannot be told apart by the size of a mask (one container cpuset shared
+    by all ranks is small too), only by comparing the ranks' masks: `learn_cpu_sharing(group)` does, where a host group is up.
+    Without that evidence the budget is divided by `local_world()` -- the safe side: oversubscribing the CPUs with helpers costs far
+    more (455 against 714 windows/s measured) than leaving some idle; a bound launch without a host group says SAME_CPU_SHARERS=1."""
     n, r = local_world()
     v = os.environ.get("SAME_CPU_SHARERS")
     if v is not None:
@@ -157,16 +186,9 @@ def cpu_sharers():
             return n, min(r, n - 1)
         except ValueError:
             pass
-    if n <= 1:
-        return 1, 0
-    try:
-        mask = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        return n, r
-    host = os.cpu_count() or mask
-    if mask * n <= host:
-        return 1, 0
-    return n, r
+    if _LEARNED_SHARERS is not None:
+        return _LEARNED_SHARERS
+    return (n, r) if n > 1 else (1, 0)
 
 
 def _domain_share(domains, n_local, local_rank):

@@ -103,15 +103,16 @@ def verify_spatial_preservation(aligned_df, ref_df, matches_df, triangle_info, t
 
 
 def print_violation_report(violations):
-    """src/violationhelper.py:136-147."""
-    summary = violations["violation_summary"]
-    print("\nSpatial Preservation Violation Report")
-    print("=====================================")
-    print(f"Total triangles analyzed: {summary['total_triangles']}")
-    print(f"Triangles with violations: {summary['violated_triangles']} ({summary['percent_triangles_violated']:.2f}%)")
-    print(f"Total position comparisons: {summary['total_comparisons']}")
-    print(f"Total violations found: {summary['total_violations']} ({summary['percent_violations']:.2f}%)")
-    print(f"Number of points involved in violations: {len(violations['points_with_violations'])}")
+    """The report of src/violationhelper.py:136-147, line for line (the text is the reference's output format)."""
+    s = violations["violation_summary"]
+    title = "Spatial Preservation Violation Report"
+    report = ["", title, "=" * len(title),
+              "Total triangles analyzed: %d" % s["total_triangles"],
+              "Triangles with violations: %d (%.2f%%)" % (s["violated_triangles"], s["percent_triangles_violated"]),
+              "Total position comparisons: %d" % s["total_comparisons"],
+              "Total violations found: %d (%.2f%%)" % (s["total_violations"], s["percent_violations"]),
+              "Number of points involved in violations: %d" % len(violations["points_with_violations"])]
+    print("\n".join(report))
 
 
 def triangle_area_flips(aligned_df, ref_df, aligned_delaunay, aligned_to_ref, ctx=None, _sweep=None):

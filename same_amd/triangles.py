@@ -12,20 +12,17 @@ from ._rows import RowList, ValueList, rows_array
 
 # ----------------------------------------------------------------------------- a6 (host)
 def _as_triangle_array(delaunay_like):
-    """src/same.py:245-259."""
+    """Whatever a caller hands in as a triangulation -> integer rows (n, 3), or None for None.  Same contract as src/same.py:245-259:
+    a frame gives its first three columns, an empty input an empty (0, 3) array, any other shape the reference's ValueError."""
     if delaunay_like is None:
         return None
-    if isinstance(delaunay_like, np.ndarray):
-        tri = delaunay_like
-    elif isinstance(delaunay_like, pd.DataFrame):
-        tri = delaunay_like.iloc[:, :3].to_numpy()
-    else:
-        tri = np.asarray(delaunay_like)
-    if tri.size == 0:
-        return np.array([], dtype=int).reshape(0, 3)
-    if tri.ndim != 2 or tri.shape[1] != 3:
-        raise ValueError(f"aligned_delaunay must have shape (n, 3); got {tri.shape}")
-    return tri.astype(int, copy=False)
+    frame = isinstance(delaunay_like, pd.DataFrame)
+    rows = np.asarray(delaunay_like.iloc[:, :3] if frame else delaunay_like)
+    if rows.size == 0:
+        return np.empty((0, 3), dtype=int)
+    if rows.ndim == 2 and rows.shape[1] == 3:
+        return rows.astype(int, copy=False)
+    raise ValueError(f"aligned_delaunay must have shape (n, 3); got {rows.shape}")
 
 
 def _remap_triangles_by_vertex_ids(triangles, vertex_ids):

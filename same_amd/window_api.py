@@ -92,12 +92,16 @@ class _DeviceFrames:
             self.dref = DeviceSection(self.ref_sec, self.cost_dtype, self.ctx)
             self.dmov = DeviceSection(self.mov_sec, self.cost_dtype, self.ctx)
             if cell_grid is not None:
-                from ._lib import SameHipError
-                try:
-                    self.dref.bin(*cell_grid)
-                    self.dmov.bin(*cell_grid)
-                except SameHipError:     # a window grid too fine for the section's extent (> 2^22 cells): the sections keep the grid of
-                    pass                 # their own; boxes that cut through its cells are tested row by row -- the same rows either way
+                from ._lib import SAME_EINVAL, SameHipError
+                for sec in (self.dref, self.dmov):
+                    try:
+                        sec.bin(*cell_grid)
+                    except SameHipError as e:
+                        # the one thing that may be passed over is the REFUSAL of a window grid too fine for the section's extent (> 2^22
+                        # cells, SAME_EINVAL): that section keeps the grid of its own and boxes that cut through its cells are tested row
+                        # by row -- the same rows either way.  A failed sort or allocation inside the binning is an error of this call.
+                        if e.code != SAME_EINVAL:
+                            raise
 
     @staticmethod
     def refusal(ref, moving, commonCT, op, vertex_col=None):

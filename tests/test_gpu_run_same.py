@@ -582,7 +582,8 @@ def test_bench_line_embeds_a_cfg5_record(world):
     calls = rec["runtime_calls_per_window"]
     assert calls["launches"] <= 30 and calls["fills"] <= 4 and calls["copies"] <= 4 and calls["waits"] <= 3
     # the window merge is per rank: only seam rows travel; the record prices what is NOT dealt with the windows and bounds 8 ranks from it
-    assert rec["deal"] == "block" and 0.0 <= rec["unsharded_s_per_step"] <= rec["serial_tail_s_per_step"] <= rec["after_windows_s_per_step"]
+    assert rec["deal"] == "block" and 0.0 <= rec["unsharded_s_per_step"] <= rec["serial_tail_s_per_step"] + 1e-9
+    assert rec["serial_tail_s_per_step"] <= rec["after_windows_s_per_step"] + 1e-9 and rec["seam_wait_s_per_step"] >= 0.0
     assert len(pr["serial_tail_s_per_step"]) == len(pr["merged_rows"]) == world and sum(pr["merged_rows"]) == rec["merged_matches"]
     if world == 1:
         assert "through the device-resident window path" in rec["parity_spot_check"] and rec["seam_exchange"] is None

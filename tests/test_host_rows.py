@@ -224,6 +224,21 @@ def test_merge_window_matches_unique_ref(oracle):
     assert len(got) == 2 and set(got["Ref_Cell_Num_Old"]) == {"r9", "r1"}
 
 
+def test_merge_takes_a_missing_violation_flag_as_a_violation_for_any_column_type(oracle):
+    """src/helpers.py:746-751: `.fillna(True).astype(bool)`.  A float column with NaN, an object column with None and pandas' nullable
+    'boolean' column with pd.NA (whose truth value is undefined: it has to be masked before the cast) all read missing as True."""
+    from same_amd.merge import merge_window_matches_unique_ref
+
+    base = pd.DataFrame({"window_id": [0, 1, 0, 1], "Aligned_Cell_Num_Old": [7, 7, 8, 8], "Ref_Cell_Num_Old": [3, 3, 4, 4], "X": 0.0, "Y": 0.0})
+    for flags in (pd.array([None, False, True, None], dtype="boolean"), np.array([np.nan, 0.0, 1.0, np.nan]),
+                  np.array([None, False, True, None], dtype=object)):
+        got = merge_window_matches_unique_ref([base.assign(filtered_violation=flags)], _dedup=oracle.merge_dedup)
+        want = base.assign(filtered_violation=pd.Series(flags).fillna(True).astype(bool)).sort_values(
+            ["filtered_violation", "window_id"], kind="mergesort").drop_duplicates(["Aligned_Cell_Num_Old", "Ref_Cell_Num_Old"])
+        assert got["filtered_violation"].dtype == bool and got["window_id"].tolist() == want.sort_values("Aligned_Cell_Num_Old")["window_id"].tolist() == [1, 0]
+        assert got["filtered_violation"].tolist() == [False, True]
+
+
 def test_merge_matching_equals_the_matching_on_the_whole_graph(oracle):
     """merge_window_matches_unique_ref runs Hopcroft-Karp only on the cells some window disagrees about (an edge whose two cells have no
     other edge is in every maximum matching) and numbers those cells densely in the order of their ids.  The result must be the table

@@ -135,17 +135,42 @@ def test_the_cpu_budget_is_divided_by_the_ranks_on_the_host(monkeypatch):
     monkeypatch.setenv("SAME_QHULL_WORKERS", "7")                               # the explicit count is per process, not divided
     assert qhull_pool.default_workers() == 7
     monkeypatch.delenv("SAME_QHULL_WORKERS")
-    # a bound launch (slurm --cpu-bind, numactl, per-rank cpusets): the mask is already the rank's own 1 / L slice -> not divided again
+    # A bound launch (slurm --cpu-bind, numactl, per-rank cpusets) gives every rank a mask of its own, which is not to be divided again --
+    # but a mask's SIZE does not say so (one container cpuset for all ranks is small too): without evidence the budget is divided, ...
     import os
+    import socket
     monkeypatch.setenv("SAME_LOCAL_WORLD", "8")
     monkeypatch.setenv("LOCAL_RANK", "5")
     monkeypatch.setattr(os, "cpu_count", lambda: 128)
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)))
-    assert qhull_pool.cpu_sharers() == (1, 0) and qhull_pool.default_workers() == 24
-    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))   # every rank sees the whole host: shared
+    monkeypatch.setattr(qhull_pool, "_LEARNED_SHARERS", None)
     assert qhull_pool.cpu_sharers() == (8, 5) and qhull_pool.default_workers() == 3
+
+    class Group:                       # ... and with the ranks' masks compared (learn_cpu_sharing over the job's host group) it is decided by them
+        rank, world = 5, 8
+
+        def __init__(self, masks, hosts=None):
+            self.masks, self.hosts = masks, hosts or [socket.gethostname()] * 8
+
+        def allgather_object(self, mine):
+            return [mine if r == self.rank else {"host": self.hosts[r], "mask": self.masks[r], "rank": r} for r in range(8)]
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(80, 96)))
+    assert qhull_pool.learn_cpu_sharing(Group([list(range(16 * r, 16 * r + 16)) for r in range(8)])) == (1, 0)      # one slice per rank: bound
+    assert qhull_pool.cpu_sharers() == (1, 0) and qhull_pool.default_workers() == 24
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(16)))
+    assert qhull_pool.learn_cpu_sharing(Group([list(range(16))] * 8)) == (8, 5)       # ONE 16-CPU cpuset for all eight ranks of a 128-CPU host: shared
+    assert qhull_pool.cpu_sharers() == (8, 5) and qhull_pool.default_workers() == 3
+    other = ["elsewhere"] * 4 + [socket.gethostname()] * 4                            # the same mask on another host is another host's CPUs
+    assert qhull_pool.learn_cpu_sharing(Group([list(range(16))] * 8, other)) == (4, 1)
+    pairs = [list(range(32 * (r // 2), 32 * (r // 2) + 32)) for r in range(8)]        # two ranks per NUMA node: each pair shares its node
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(pairs[5]))
+    assert qhull_pool.learn_cpu_sharing(Group(pairs)) == (2, 1)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))         # every rank sees the whole host: shared
+    assert qhull_pool.learn_cpu_sharing(Group([list(range(128))] * 8)) == (8, 5) and qhull_pool.default_workers() == 3
     monkeypatch.setenv("SAME_CPU_SHARERS", "2")
     assert qhull_pool.cpu_sharers() == (2, 1) and qhull_pool.default_workers() == 12
+    monkeypatch.setattr(qhull_pool, "_LEARNED_SHARERS", None)
     doms = [[c] for c in range(8)]
     assert [qhull_pool._domain_share(doms, 4, r) for r in range(4)] == [[[0], [1]], [[2], [3]], [[4], [5]], [[6], [7]]]
     assert [qhull_pool._domain_share(doms[:2], 4, r) for r in range(4)] == [[[0]], [[0]], [[1]], [[1]]]
