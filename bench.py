@@ -20,9 +20,10 @@ At N > 1 the same run then measures BASELINE cfg 4 as a second, embedded record 
   ranks own aligned-row blocks of it (dense build in 25k-row chunks through the resident buffer), all-gather the candidate
   lists, derive the common matching, and sweep disjoint triangle blocks of the one triangulation (flag all-gather + counter
   all-reduce).  `--scaling strong --workload cfg4` runs that configuration as the main record instead.
-`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks, fp32 costs -- see same_amd/bench_cfg5.py;
-  every line of the default workload -- at 1 rank or N -- carries it as the sub-record `cfg5`, measured in the same job after the
-  timed region (on its ranks, contexts and communicator; `--embed-cfg5 off` skips it).
+`--workload cfg5` (BASELINE cfg 5) is a different step -- whole sliding windows dealt to the ranks in runs of the plan, fp32 costs,
+  the window merge per rank with one exchange of the seam rows -- see same_amd/bench_cfg5.py; every line of the default workload -- at
+  1 rank or N -- carries it as the sub-record `cfg5`, measured in the same job after the timed region (on its ranks, contexts and
+  communicator; `--embed-cfg5 off` skips it).
 value = aligned-ref cell pairs covered per second by the whole job.
 
 `roofline` is for the dense kernel: algorithmic bytes s*N_r*rows + s*(T+2)*(N_r+rows) over its mean launch
@@ -33,29 +34,23 @@ loop on the warm chip, `telemetry` is board power / shader clock sampled from sy
 At N > 1 the line explains itself: `rccl` is what the communicator reports (ncclCommCount, not the launcher's word),
 `gather` times the all-gather on its own stream and against a second loop without it, `per_rank_dense_ms` shows slow dies.
 `cpu_baseline` times the CPU oracle (scalar C port of the reference's arithmetic, 1 thread) on a bounded row sample of
-the same workload, rank 0, N=1 only.
+the same workload, rank 0, N=1 only (section bench_oracle_legs at the end of this file; the line itself is put together by
+same_amd/bench_report.py).
 """
 import argparse
 import json
 import os
-import subprocess
 import sys
-import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from same_amd.bench_common import HBM_PEAK_GBS, Env, arm_rank_watchdog, baseline_metric, comm_report, make_comm, note, stats3  # noqa: E402  (no GPU, no torch)
-FP64_ISSUE_PEAK_T = 39.3   # T lane-instructions/s: the 78.6 TFLOP/s fp64 vector spec counts an FMA as two
-SIMDS, FP64_LANES_PER_CLK = 1024, 16   # 256 CUs x 4 SIMDs; a wave64 fp64 instruction occupies its SIMD for 4 cycles
+from same_amd.bench_common import Env, arm_rank_watchdog, comm_report, make_comm, note, stats3          # noqa: E402  (no GPU, no torch)
+from same_amd.bench_problem import STRONG_CHUNK_BYTES, STRONG_OF, WORKLOADS, Problem, gather_report   # noqa: E402,F401
+from same_amd.bench_report import N_GT1_KEYS, N_GT1_STRONG_KEYS, add_multi_rank_parts, dense_line, roofline, strong_record   # noqa: E402
 
-from same_amd.bench_problem import STRONG_CHUNK_BYTES, STRONG_OF, WORKLOADS, Problem, dense_kernel_label, gather_report  # noqa: E402,F401
-
-# what the line carries at N > 1 on top of the N = 1 keys, so that the one 8-GPU run explains itself (checked before the line is written;
-# listed by --dry-launch so the CPU suite can hold the contract)
-N_GT1_KEYS = ("rccl", "gather", "gather_hidden_ms", "per_rank_dense_ms", "per_rank", "cfg5")
-N_GT1_STRONG_KEYS = ("config", "scaling", "value", "ms_per_step", "dense_kernel_ms", "per_rank_dense_ms", "gather", "gather_hidden_ms", "parity_spot_check")
+_OVERLAPPED = " (overlapped on a second stream)"
 
 
 def parse():
@@ -76,22 +71,24 @@ def parse():
                     help="exact: the bit-exact fp64 dense kernel (default, the reported kernel); q32: run the step with the opt-in "
                          "fixed-point build instead (every output within 1e-6 relative of the exact one; NOT reference arithmetic)")
     ap.add_argument("--spread", default="auto", choices=("auto", "on", "off"),
-                    help="where the dense cost block comes from: 'on' = same_dev_alloc_spread (1 GiB chunks laid over the card's three HBM regions), "
-                         "'off' = plain hipMalloc, 'auto' = spread only for store-bound type counts (T <= 12); the T = 20 headline is bound by fp64 "
-                         "issue and runs on a plain block")
+                    help="where the dense cost block comes from: 'on' = same_dev_alloc_spread (1 GiB chunks laid over the card's three "
+                         "HBM regions), 'off' = plain hipMalloc, 'auto' = spread only for store-bound type counts (T <= 12); the T = 20 "
+                         "headline is bound by fp64 issue and runs on a plain block")
     ap.add_argument("--cfg5-cells", type=int, default=1_000_000, help="--workload cfg5: cells per section")
     ap.add_argument("--embed-cfg5", choices=("auto", "on", "off"), default="auto",
-                    help="after the timed loop, run BASELINE cfg 5 (the step of `--workload cfg5`) on this job's ranks and embed its numbers as `cfg5` "
-                         "(auto: with the default workload at any rank count, and with cfg2 / cfg4 at N > 1)")
+                    help="after the timed loop, run BASELINE cfg 5 (the step of `--workload cfg5`) on this job's ranks and embed its "
+                         "numbers as `cfg5` (auto: with the default workload at any rank count, and with cfg2 / cfg4 at N > 1)")
     ap.add_argument("--cfg5-pipeline", choices=("device", "frames"), default="device",
-                    help="--workload cfg5: both run the product function same_amd.sliding_window_incumbent; 'device' on frames resident on the GPU "
-                         "(two library calls per window), 'frames' through its general route on host frames (every window's frames cut on the "
-                         "host, every kernel through host buffers: the pipeline of rounds 1-3, kept measurable)")
+                    help="--workload cfg5: both run the product function same_amd.sliding_window_incumbent; 'device' on frames resident "
+                         "on the GPU (two library calls per window), 'frames' through its general route on host frames (every window's "
+                         "frames cut on the host, every kernel through host buffers: the pipeline of rounds 1-3, kept measurable)")
     ap.add_argument("--cfg5-threads", type=int, default=None,
-                    help="--workload cfg5: worker threads (contexts) walking this rank's windows (default: 2 on the device pipeline, 4 on the column one)")
+                    help="--workload cfg5: worker threads (contexts) walking this rank's windows (default: 2 on the device pipeline where "
+                         "the rank has 8 CPUs or more, else 1)")
     ap.add_argument("--cfg5-deal", choices=("block", "round_robin"), default="block",
-                    help="--workload cfg5: how the windows are dealt to the ranks: 'block' = runs of the plan (strips of the window grid: the window "
-                         "merge only has the strips' borders to settle between ranks), 'round_robin' = every N-th window, heaviest first")
+                    help="--workload cfg5: how the windows are dealt to the ranks: 'block' = runs of the plan (strips of the window grid: "
+                         "the window merge only has the strips' borders to settle between ranks), 'round_robin' = every N-th window, "
+                         "heaviest first")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:
@@ -105,6 +102,7 @@ def parse():
 def run_rank(args):
     import numpy as np
 
+    from same_amd import qhull_pool
     from same_amd.rendezvous import HostGroup
 
     # stdout carries exactly ONE line (the JSON): native libraries print there too (RCCL writes a version banner to
@@ -118,9 +116,8 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", str(group.rank)))
     arm_rank_watchdog(group.rank)
     note(group, f"host group up: world {group.world} (rendezvous: loopback TCP, plain Python)")
-    from same_amd import qhull_pool
-
-    qhull_pool.learn_cpu_sharing(group)      # do the ranks on this host share CPUs (divide the Qhull helper budget) or is every rank bound to its own?
+    # do the ranks on this host share CPUs (then the Qhull helper budget is divided) or is every rank bound to CPUs of its own?
+    qhull_pool.learn_cpu_sharing(group)
 
     if args.dry_launch:   # control-plane check, no GPU: id broadcast, barrier, max -- what the real run does on the host side
         uid = group.bcast_bytes(bytes(range(128)) if group.rank == 0 else b"")
@@ -144,24 +141,23 @@ def run_rank(args):
         return run_cfg5_workload(args, group, json_fd, local_rank)
     strong = args.scaling == "strong"
     ctx = _lib.Context(local_rank % _lib.device_count())          # the dense build's context (one context = one stream)
-    L, H, chk = ctx.lib, ctx.handle, ctx.check
     # The rest of the step (prune, candidate costs, gather, triangle maps, sweeps) does not read the dense block, so it
     # runs on a context of its own: its small latency-bound kernels fill in beside the 16 ms dense kernel instead of
     # queueing behind it, and the per-step read-back of the sweep waits for that stream only.
     tctx = _lib.Context(ctx.device) if args.tail_stream == "own" else ctx
     comm, transport = make_comm(args, group, tctx)
     if comm is not None and not comm.synchronous and not strong:
-        transport += " (overlapped on a second stream)"
+        transport += _OVERLAPPED
     env = Env(args, group, ctx, tctx, comm, transport)
     rccl = comm_report(env, np) if comm is not None else None
 
     prob = Problem(env, args.workload, strong)
-    n_ref, T, k, radius, rows, n_mov, Tr, ld = prob.n_ref, prob.T, prob.k, prob.radius, prob.rows, prob.n_mov, prob.Tr, prob.ld
-    dD, dA, dR, dax, drx = prob.dD, prob.dA, prob.dR, prob.dax, prob.drx
+    n_ref, T, rows, n_mov, Tr, prob_k, prob_radius = prob.n_ref, prob.T, prob.rows, prob.n_mov, prob.Tr, prob.k, prob.radius
+    dD = prob.dD
     # the block the timed loop stores into (the T sweep after it may re-take the block spread over the HBM regions)
     headline_buffer = dict(dD.spread_info) if dD.spread_info else {
         "spread": False, "what": "plain hipMalloc (--spread auto: same_dev_alloc_spread only for store-bound type counts, T <= 12)"}
-    mov, ref, tris, use_q32 = prob.mov, prob.ref, prob.tris, prob.use_q32
+    use_q32, q_l2 = prob.use_q32, getattr(prob, "q_l2", None)
     note(group, f"inputs resident ({rows} of {n_mov} aligned x {n_ref} ref, {Tr} triangles); gather transport: {transport}")
 
     note(group, f"warm-up ({args.warmup}) + timed loop ({args.steps} steps)")
@@ -181,7 +177,8 @@ def run_rank(args):
                 "gather_ms": stats3(gather_steps)}
         every = group.allgather_object(mine)
         per_rank = {"dense_ms_min_mean_max_over_ranks": stats3([r["dense_ms"][1] for r in every]),
-                    "dense_ms_by_rank": [r["dense_ms"][1] for r in every], "gather_ms_by_rank": [(r["gather_ms"] or [None, None])[1] for r in every],
+                    "dense_ms_by_rank": [r["dense_ms"][1] for r in every],
+                    "gather_ms_by_rank": [(r["gather_ms"] or [None, None])[1] for r in every],
                     "device_by_rank": [r["device"] for r in every], "pci_by_rank": [r["pci"] for r in every]}
         prob.step()                                                    # one more step WITH the gather: the lists the check reads
         if group.rank == 0:
@@ -198,93 +195,14 @@ def run_rank(args):
         extras = measure_extras(args, env, prob, headline_buffer)      # may re-take the cost block spread over the HBM regions
         dD = prob.dD
 
-    # ---- CPU baseline leg (rank 0, N=1, untimed region): the oracle runs a bounded sample of the same workload on the
-    # host; its outputs double as a parity check of what the GPU just produced (the only place bench.py touches oracle/) ----
+    # ---- CPU baseline leg (rank 0, N=1, untimed region): see bench_oracle_legs below ------------------------------------
     cpu = None
-    parity = parity_transport or "not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without --no-cpu-baseline)"
+    parity = parity_transport or ("not checked in this run (the oracle only runs in the cpu_baseline leg: N=1 without "
+                                  "--no-cpu-baseline)")
     if group.rank == 0 and group.world == 1 and not args.no_cpu_baseline:
-        from oracle import same_oracle as orc
-
-        if strong or extras:   # the resident block was reused by the probes above: rebuild this rank's first chunk for the check
-            chk(prob.dense_launch(prob.rb, min(prob.rb + prob.chunk_rows, prob.re)), "dense")
-            ctx.sync()
-        S = min(args.cpu_sample_rows, rows, prob.chunk_rows)
-        c0 = time.perf_counter()
-        want_dense = orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, 0, S)
-        exact_dense = want_dense
-        if use_q32:   # the fixed-point build is checked against ITS twin bit for bit, and against the exact costs within the tolerance
-            want_dense = orc.dense_cost_q32(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, prob.q_off, prob.q_l2, 0, S)
-            if float(np.max(np.abs(want_dense - exact_dense) / exact_dense)) > 1e-6:
-                raise SystemExit("fixed-point dense costs are outside 1e-6 relative of the exact ones: refusing to report a number")
-        oi, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, S)
-        rr, cc = np.nonzero(oi >= 0)
-        want_pc = orc.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oi[rr, cc])), 1.0)
-        c1 = time.perf_counter()
-        orc.tri_classify(mov["xy"], tris, radius, 15, mov["cell_type"])
-        orc.tri_sign_weight(mov["xy"], mov["size"], tris)
-        och, oviol, _ = orc.orient_sweep(tris, prob.sign0, ref["xy"], match)
-        orc.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
-        orc.area_flip(mov["xy"], ref["xy"], tris, match)
-        c2 = time.perf_counter()
-        t_cpu = (c1 - c0) + (c2 - c1) * S / n_mov
-        # parity of this run's GPU outputs with what the baseline just computed
-        ok = True
-        for i in np.random.default_rng(0).choice(S, min(8, S), replace=False):
-            ok &= bool(np.array_equal(dD.download((n_ref,), np.float64, offset_bytes=int(i) * ld * 8), want_dense[i]))
-        ok &= bool(np.array_equal(prob.didx.download((S, k), np.int32), oi))
-        got_pc = prob.dcost.download((S, k), np.float64)
-        ok &= bool(np.array_equal(got_pc[rr, cc], want_pc))
-        ok &= (och == prob.last["checked"]) and bool(np.array_equal(oviol, prob.last["viol"]))
-        if not ok:
-            raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
-        parity = f"dense rows, pruned lists and pair costs of rows [0,{S}) and the orientation sweep equal the oracle bit-for-bit"
-        if use_q32:
-            parity = (f"dense rows of [0,{S}) equal the fixed-point build's oracle twin bit-for-bit and are within 1e-6 relative of the exact "
-                      f"fp64 costs on all {S} x {n_ref} pairs; pruned lists, pair costs and the orientation sweep equal the oracle bit-for-bit")
+        cpu, parity = dense_oracle_leg(args, group, ctx, prob, match, rebuild_first_chunk=bool(strong or extras))
         if parity_transport:
             parity += "; " + parity_transport
-        note(group, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
-        del want_dense
-        # best-effort multi-core CPU lines: the dense sample split over host threads (ctypes releases the GIL),
-        # and the radius query + top-k of the prune with scipy's cKDTree on all cores (src/utils.py:714,722 with workers=-1)
-        from concurrent.futures import ThreadPoolExecutor
-        from scipy.spatial import cKDTree
-
-        nthr = max(1, min(16, os.cpu_count() or 1))
-        cuts = np.linspace(0, S, nthr + 1).astype(int)
-        m0 = time.perf_counter()
-        with ThreadPoolExecutor(nthr) as ex:
-            list(ex.map(lambda be: orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(be[0]), int(be[1])),
-                        zip(cuts[:-1], cuts[1:])))
-        t_mt = time.perf_counter() - m0
-        k0 = time.perf_counter()
-        tree = cKDTree(ref["xy"])
-        balls = tree.query_ball_point(mov["xy"][:S], radius, workers=-1)
-        kd_pairs = 0
-        for i, b in enumerate(balls):
-            b = np.asarray(b, dtype=np.int64)
-            d = np.linalg.norm(ref["xy"][b] - mov["xy"][i], axis=1)
-            kd_pairs += len(b[np.argsort(d)[:k]])
-        t_kd = time.perf_counter() - k0
-        cpu_model = "unknown"
-        try:
-            with open("/proc/cpuinfo") as f:
-                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
-        except OSError:
-            pass
-        cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
-               "host_cpus": os.cpu_count(),
-               "dense_only_threaded": {"value": S * n_ref / t_mt, "unit": "cell-pairs/s", "cores": nthr,
-                                       "sample": f"dense cost of the same {S} rows split over {nthr} host threads"},
-               "knn_ckdtree_threaded": {"value": S * n_ref / t_kd, "unit": "dense-equivalent cell-pairs/s", "cores": os.cpu_count(),
-                                        "sample": f"scipy cKDTree(refs) build + query_ball_point(rows [0,{S}), r={radius:g}, workers=-1) + "
-                                                  f"per-row norm/argsort top-{k} as src/utils.py:722-728 ({kd_pairs} pairs kept, {t_kd:.2f} s)"},
-               "sample": f"rows [0,{S}) of {n_mov} x {n_ref} refs: dense cost + knn prune + pair costs "
-                         f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{n_mov} "
-                         f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}",
-               "reference_note": "the reference itself (pure Python/pandas) cannot travel to this box; measured in the survey "
-                                 "container (BASELINE.md section 3, 1 of 8 vCPU): 1.0-1.3e3 pairs/s pair-cost loop, 6.5e3 triangles/s "
-                                 "filter, 2.7e5 triangles/s lazy sweep, 1.6e7 dense-equivalent cell-pairs/s KNN at 10k x 10k"}
 
     # ---- N > 1, weak run: BASELINE cfg 4 as an embedded record (ONE problem over the ranks; the resident block is reused) ----
     if comm is not None and not strong and not args.no_strong_record:
@@ -303,19 +221,7 @@ def run_rank(args):
         sp.step()
         s_check = sp.transport_check() if group.rank == 0 else None
         if group.rank == 0:
-            ms_launch = float(np.mean([m for m, _ in s_dense])) if s_dense else None
-            rows_launch = float(np.mean([r for _, r in s_dense])) if s_dense else 0.0
-            s_bytes = 8.0 * sp.n_ref * rows_launch + 8.0 * (sp.T + 2) * (sp.n_ref + rows_launch)
-            strong_rec = {"config": {"workload": sp.workload_text(),
-                                     "parallelism": f"aligned-row blocks x{group.world}, {transport.replace(' (overlapped on a second stream)', '')}"
-                                                    + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if sp.sharded is not None else "")},
-                          "scaling": "strong", "value": float(sp.n_ref) * sp.n_mov * s_steps / s_dt, "unit": "cell-pairs/s", "steps": s_steps, "warmup": 1,
-                          "ms_per_step": s_dt / s_steps * 1e3, "rows_this_rank": sp.rows, "dense_launches_per_step": sp.n_chunks,
-                          "dense_kernel_ms": ms_launch, "dense_GBs": (s_bytes / (ms_launch * 1e-3) / 1e9) if ms_launch else None,
-                          "dense_frac_of_hbm_peak": (s_bytes / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_launch else None,
-                          "per_rank_dense_ms": stats3([e[1] for e in s_every if e]), "dense_ms_by_rank": [e[1] if e else None for e in s_every],
-                          "gather": s_gather, "gather_hidden_ms": s_hidden, "parity_spot_check": s_check,
-                          "sweep_outputs": {"checked": int(sp.last["checked"]), "flipped": int(len(sp.last["viol"]))}}
+            strong_rec = strong_record(np, group, sp, transport, s_steps, s_dt, s_dense, s_every, s_gather, s_hidden, s_check)
         sp.close(keep_dense=True)
         prob = None
 
@@ -329,158 +235,26 @@ def run_rank(args):
 
         note(group, "embedded cfg5 record: the window configuration on this job's ranks")
         try:
-            line5 = bench_cfg5.run(args, group, tctx, comm, transport.replace(" (overlapped on a second stream)", "").replace("pruned lists", "the ranks' match tables"),
-                                   3, 1, cpu_baseline=cfg5_oracle_leg)   # used at one rank: four windows through the oracle, as parity check and CPU figure
+            what = transport.replace(_OVERLAPPED, "").replace("pruned lists", "the window merge's seam rows")
+            # cpu_baseline is used at one rank: four windows through the oracle, as parity check and CPU figure
+            line5 = bench_cfg5.run(args, group, tctx, comm, what, 3, 1, cpu_baseline=cfg5_oracle_leg)
             cfg5_rec = bench_cfg5.record(line5) if group.rank == 0 else None
         except SystemExit:
             raise                                     # a parity failure inside the record is a failure of the line
-        except Exception as e:  # noqa: BLE001 -- anything else costs the sub-record, never the main line; every rank raises alike or none does
+        except Exception as e:  # noqa: BLE001 -- costs the sub-record, never the main line; every rank raises alike or none does
             cfg5_rec = {"error": f"{type(e).__name__}: {e}"}
         if group.rank == 0:
-            note(group, "embedded cfg5 record: " + (f"{cfg5_rec['windows_per_s']:.0f} windows/s" if "windows_per_s" in cfg5_rec else cfg5_rec.get("error", "?")))
+            said = f"{cfg5_rec['windows_per_s']:.0f} windows/s" if "windows_per_s" in cfg5_rec else cfg5_rec.get("error", "?")
+            note(group, "embedded cfg5 record: " + said)
 
     if group.rank == 0:
-        total_rows = n_mov if strong else rows * group.world
-        pairs_per_step = float(n_ref) * total_rows
-        ms_w = np.array([m for m, _ in dense_ms], float)
-        rows_w = np.array([r for _, r in dense_ms], float)
-        t_dense = float(ms_w.mean()) * 1e-3                       # mean launch duration
-        rows_launch = float(rows_w.mean())                        # rows one launch covers (== rows unless chunked)
-        dense_bytes = 8.0 * n_ref * rows_launch + 8.0 * (T + 2) * (n_ref + rows_launch)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic, traffic_src = tj.get(args.workload), tj.get("_source")
-            except Exception:
-                traffic = None
-        achieved = dense_bytes / t_dense / 1e9
-        lane_instr = (2 * T + 5) * float(n_ref) * rows_launch      # fp64 VALU lane-instructions of one launch
-        valu_rate = lane_instr / t_dense / 1e12
-        if use_q32:
-            dense_bytes = 8.0 * n_ref * rows_launch + (4.0 * T + 16.0) * (n_ref + rows_launch)
-            achieved = dense_bytes / t_dense / 1e9
-            traffic, traffic_src = None, "not collected for the fixed-point build"
-        roof = {"bound": "hbm", "kernel": f"dense_cost_q32_kernel<{T},double> (opt-in fixed-point build, --dense q32)" if use_q32 else dense_kernel_label("f64", T),
-                "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src or "profiles/traffic.json (separate rocprofv3 --pmc passes: WRITE_SIZE + 2*FETCH_SIZE)",
-                "algorithmic_bytes_per_launch": dense_bytes, "kernel_ms": t_dense * 1e3, "launches_timed": len(dense_ms),
-                # secondary ceiling: (2T+5) fp64 VALU lane-instructions per output against the vector issue peak
-                "valu_fp64": None if use_q32 else {"lane_instr_per_output": 2 * T + 5, "achieved_Tinstr_s": valu_rate,
-                                                   "peak_Tinstr_s": FP64_ISSUE_PEAK_T, "frac": valu_rate / FP64_ISSUE_PEAK_T},
-                "valu_floor_ms_at_held_clock": None, "valu_busy_frac": None, "frac_of_measured_copy_bw": None,
-                # `bound` names the roofline BASELINE.json prices the kernel against; what actually limits the T = 20 fp64 kernel is said here
-                "binding": None if use_q32 else ("fp64 VALU issue under the board power cap (T >= ~12: 2T+5 fp64 lane-instructions per 8-byte output; "
-                                                 "HBM only binds at the reference datasets' T = 3 / 5 / 8)" if T >= 12 else "hbm"),
-                "frac_of_binding_ceiling": None, "target_frac": 0.70, "target_met": bool(achieved / HBM_PEAK_GBS >= 0.70)}
-        msg = ["frac is against the 8.0 TB/s HBM spec as BASELINE.json asks (`bound`); `binding` is what limits this kernel on this board and "
-               "`frac_of_binding_ceiling` = valu_floor_ms_at_held_clock / kernel_ms is how close the launch is to THAT ceiling"]
-        if use_q32:
-            msg.append("THIS LINE WAS RUN WITH --dense q32: the step's dense build is the opt-in fixed-point kernel (exact integer type sums on a "
-                       f"2^-{prob.q_l2 if prob else '?'} grid, sums too small for the grid recomputed in fp64: every output within 1e-6 relative of the reference's "
-                       "fp64 cost, which is BASELINE.json's tolerance) -- not the reference's arithmetic; the default run reports the bit-exact kernel")
-        roof["output_buffer"] = headline_buffer
-        if headline_buffer.get("spread"):
-            si = headline_buffer
-            msg.append(f"the cost block is {si['chunks_gib']} GiB mapped round-robin from the card's three HBM regions ({si['per_region']} GiB per region, "
-                       f"{si['straddling']} straddling; found by timed stores in {si['seconds']:.1f} s before the timed region; "
-                       + (f"verified: one store over the finished range ran at {si['final_store_gbps']} GB/s against a same-region level of "
-                          f"{si['same_region_level_gbps']}" if si.get("verified") else "NOT verified: a store over the finished range did not reach the fast level")
-                       + "): a streaming store confined to one region runs ~20 % below one spread over them")
-        if "ceilings" in extras:
-            c = extras["ceilings"]
-            c["frac_of_T0_store_rate"] = achieved / c["same_kernel_T0_store_only_GBs"]
-            roof["measured_ceilings"] = c
-            if c.get("device_copy_GBs"):
-                roof["frac_of_measured_copy_bw"] = achieved / c["device_copy_GBs"]
-                msg.append(f"a device-to-device copy on this box moves {c['device_copy_GBs']:.0f} GB/s (read + written): the kernel's {achieved:.0f} GB/s is "
-                           f"{roof['frac_of_measured_copy_bw']:.2f} of that")
-            if "plain_hipMalloc_buffer" in c:
-                pb = c["plain_hipMalloc_buffer"]
-                msg.append(f"a plain hipMalloc buffer of the same size in this process: T=0 store {pb['same_kernel_T0_store_only_GBs']:.0f} GB/s, "
-                           f"hipMemsetAsync {pb['hipMemsetAsync_GBs']:.0f} GB/s"
-                           + (f", this kernel {pb['bench_kernel_ms']:.2f} ms" if pb.get("bench_kernel_ms") else ""))
-            msg.append(f"on this box the same kernel with T=0 (same stores, 5 instead of {2 * T + 5} VALU ops per output) streams "
-                       f"{c['same_kernel_T0_store_only_GBs']:.0f} GB/s and hipMemsetAsync {c['hipMemsetAsync_GBs']:.0f} GB/s, so the T={T} "
-                       f"build runs at {c['frac_of_T0_store_rate']:.2f} of its own store-only rate")
-        if "telemetry" in extras:
-            t = extras["telemetry"]
-            roof["telemetry"] = t
-            if t.get("available") and t.get("power"):
-                clk = t.get("sclk_steady") or t.get("sclk_hwmon") or t.get("sclk_dpm")
-                pw = t.get("power_steady") or t["power"]
-                if clk and not use_q32:
-                    # every fp64 VALU instruction of a wave64 holds its SIMD for 4 cycles: the time the launch's instructions need
-                    # at the clock the board held while this kernel looped, and the share of the launch they fill
-                    floor_ms = lane_instr / (SIMDS * FP64_LANES_PER_CLK * clk["mean"] * 1e6) * 1e3
-                    roof["valu_floor_ms_at_held_clock"] = floor_ms
-                    roof["valu_busy_frac"] = floor_ms / (t.get("dense_ms_during_window") or t_dense * 1e3)
-                    roof["frac_of_binding_ceiling"] = (floor_ms / (t_dense * 1e3)) if T >= 12 else roof["frac"]
-                    roof["held_clock_mhz"], roof["board_power_w"], roof["board_power_cap_w"] = clk["mean"], pw["mean"], t.get("power_cap_w")
-                msg.append(f"while the kernel looped the board drew {pw['mean']:.0f} W in steady state (max {t['power']['max']:.0f} W"
-                           + (f", cap {t['power_cap_w']:.0f} W" if t.get("power_cap_w") else "") + ")"
-                           + (f" at a shader clock of {clk['mean']:.0f} MHz (min {clk['min']:.0f})" if clk else "")
-                           + ("".join(f", {n} {v['mean']:.0f} C" + (f" (critical {t['temperature_crit_c'][n]:.0f})" if (t.get('temperature_crit_c') or {}).get(n) else "")
-                                      for n, v in (t.get("temperature_steady") or {}).items() if v))
-                           + ("" if use_q32 or not clk else f"; at that clock the {2 * T + 5}-instruction fp64 VALU floor is "
-                              f"{roof['valu_floor_ms_at_held_clock']:.1f} ms of the {t.get('dense_ms_during_window') or t_dense * 1e3:.1f} ms launch "
-                              f"(VALU busy {roof['valu_busy_frac']:.2f}): the bound of this kernel is fp64 issue under the board power cap, not HBM"))
-            else:
-                msg.append("board power / clock could not be read from sysfs on this box")
-        for key in ("pruned_path", "triangle_maps_and_sweeps", "realistic_matching"):
-            if key in extras:
-                roof[key] = extras[key]
-        if "sweep" in extras:
-            roof["sweep"] = extras["sweep"]
-            msg.append("sweep = same measurement at other type counts (the reference's datasets have T = 3, 5, 8)")
-            ctl = [e for e in extras["sweep"] if e.get("opt_in")]
-            if ctl:
-                msg.append(f"control: the opt-in fixed-point build writes the same {dense_bytes / 1e9:.0f} GB with integer v_sad_u32 in place of the "
-                           f"fp64 adds, every output within 1e-6 relative of this kernel's (BASELINE's own tolerance for fp64 costs; max "
-                           f"{ctl[0]['max_rel_diff_vs_exact_on_16_rows']:.1e} on 16 sampled rows), in {ctl[0]['ms']:.2f} ms = {ctl[0]['frac']:.3f} of the "
-                           "HBM spec -- the gap to this kernel is the energy of the fp64 arithmetic, not memory traffic")
-        roof["note"] = "; ".join(msg)
-        chunk_rows = int(rows_launch)
-        wl = (f"{args.workload}: " + (f"ONE problem of {n_mov} aligned x {n_ref} ref cells, aligned-row blocks and triangle "
-                                      f"blocks over {group.world} rank(s), dense build in {chunk_rows}-row chunks"
-                                      if strong else f"{rows} aligned x {n_ref} ref cells per GPU")
-              + f", T={T} type cols, " + ("fixed-point (every output within 1e-6 relative of the fp64 one) " if use_q32 else "fp64 ")
-              + f"dense L1 cost + r={radius:g}/k={k} KNN prune + pair costs + {Tr} Delaunay "
-                "triangles classify/sign + orientation / XY-order / area-flip sweeps")
-        out = {
-            "metric": baseline_metric(),
-            "value": pairs_per_step * args.steps / dt, "unit": "cell-pairs/s",
-            "n_gpus": group.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32+f64" if use_q32 else "f64", "data": "synthetic",
-            "config": {"workload": wl,
-                       "streams": ("dense build on one stream, prune / costs / triangle maps / sweeps on a second (own context)"
-                                   if tctx is not ctx else "one stream, in order"),
-                       "parallelism": f"aligned-row blocks x{group.world}" + (", " + transport if comm is not None else "")
-                                      + (", sweeps over triangle blocks (flag all-gather + counter all-reduce)" if (strong and comm is not None) else "")},
-            "roofline": roof,
-            "cpu_baseline": cpu,
-            "parity_spot_check": parity,
-        }
+        roof, chunk_rows = roofline(args.workload, (n_ref, T, use_q32), dense_ms, extras, headline_buffer, q_l2)
+        shape = (n_ref, T, prob_k, prob_radius, rows, n_mov, Tr, use_q32, strong)
+        out = dense_line(args, group, shape, dt, roof, chunk_rows, tctx is not ctx, comm, transport, cpu, parity)
         if comm is not None:
-            out["rccl"] = rccl
-            out["gather"] = gather
-            out["gather_hidden_ms"] = gather_hidden_ms
-            out["gather_hidden_ms_means"] = ("ms_per_step of the timed loop minus ms_per_step of a second, shorter loop of the same step without the "
-                                             "candidate-list all-gather: what the gather costs the step (about 0 = fully hidden behind the dense build)")
-            out["per_rank_dense_ms"] = per_rank["dense_ms_min_mean_max_over_ranks"]
-            out["per_rank"] = per_rank
-            if strong_rec is not None:
-                out["strong_cfg4" if STRONG_OF.get(args.workload) == "cfg4" else "strong_record"] = strong_rec
-                missing = [k for k in N_GT1_STRONG_KEYS if k not in strong_rec]
-                if missing:
-                    raise SystemExit(f"the embedded strong record lacks {missing}")
-            missing = [k for k in N_GT1_KEYS if out.get(k) is None and k not in ("gather_hidden_ms", "cfg5")]   # cfg5 joins below
-            if missing:
-                raise SystemExit(f"the N > 1 line lacks {missing}")
-        if want_cfg5:
-            out["cfg5"] = cfg5_rec if cfg5_rec is not None else {"error": "no record"}   # an error entry, never a lost line: the headline number does not depend on it
+            add_multi_rank_parts(out, args, rccl, gather, gather_hidden_ms, per_rank, strong_rec)
+        if want_cfg5:   # an error entry, never a lost line: the headline number does not depend on it
+            out["cfg5"] = cfg5_rec if cfg5_rec is not None else {"error": "no record"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     group.barrier()  # rank 0 has finished its spot check / report: tear the communicator down together
     if prob is not None:
@@ -493,15 +267,134 @@ def run_rank(args):
     group.close()
 
 
+def run_cfg5_workload(args, group, json_fd, local_rank):
+    """`--workload cfg5`: the window configuration as the line itself (same_amd/bench_cfg5.py)."""
+    from same_amd import _lib, bench_cfg5
+
+    os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
+    ctx = _lib.default_context()
+    # a device all-gather (RCCL; host transport if that fails)
+    comm, transport = make_comm(args, group, ctx, what="the window merge's seam rows")
+    out = bench_cfg5.run(args, group, ctx, comm, transport, args.steps, args.warmup,
+                         cpu_baseline=None if args.no_cpu_baseline else cfg5_oracle_leg)
+    if group.rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    group.barrier()
+    if comm is not None:
+        comm.close()
+    group.close()
+
+
+# ======================================================================================================================
+# bench_oracle_legs -- the `cpu_baseline` legs: the ONLY code outside tests/ and __graft_entry__.smoke() that imports oracle/.
+# Both run on rank 0 at one rank, after the timed region: the oracle (scalar C port of the reference's arithmetic, one thread)
+# works through a bounded sample of the workload -- that time is `cpu_baseline` -- and its outputs double as the parity check of
+# what the GPU produced in this very run (a mismatch refuses the line).
+# ======================================================================================================================
+def dense_oracle_leg(args, group, ctx, prob, match, rebuild_first_chunk):
+    """The cpu_baseline leg of the default step: rows [0, S) of the dense build, the prune and the pair costs, and the whole triangle /
+    sweep pass, through the oracle (timed) -- and the same outputs of this run's GPU step compared bit for bit.  Also the best-effort
+    multi-core CPU lines of SURVEY 8d.  -> (cpu_baseline record, parity text)."""
+    import numpy as np
+
+    from oracle import same_oracle as orc
+
+    mov, ref, tris, use_q32 = prob.mov, prob.ref, prob.tris, prob.use_q32
+    n_ref, k, radius, rows, n_mov, Tr, ld = prob.n_ref, prob.k, prob.radius, prob.rows, prob.n_mov, prob.Tr, prob.ld
+    if rebuild_first_chunk:   # the resident block was reused by the probes: rebuild this rank's first chunk for the check
+        ctx.check(prob.dense_launch(prob.rb, min(prob.rb + prob.chunk_rows, prob.re)), "dense")
+        ctx.sync()
+    S = min(args.cpu_sample_rows, rows, prob.chunk_rows)
+    c0 = time.perf_counter()
+    want_dense = orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, 0, S)
+    exact_dense = want_dense
+    if use_q32:   # the fixed-point build is checked against ITS twin bit for bit, and against the exact costs within the tolerance
+        want_dense = orc.dense_cost_q32(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, prob.q_off, prob.q_l2, 0, S)
+        if float(np.max(np.abs(want_dense - exact_dense) / exact_dense)) > 1e-6:
+            raise SystemExit("fixed-point dense costs are outside 1e-6 relative of the exact ones: refusing to report a number")
+    oi, _, _ = orc.knn_prune(mov["xy"], ref["xy"], radius, k, 0, S)
+    rr, cc = np.nonzero(oi >= 0)
+    want_pc = orc.pair_cost_arrays(mov["types"], ref["types"], mov["xy"], ref["xy"], np.column_stack((rr, oi[rr, cc])), 1.0)
+    c1 = time.perf_counter()
+    orc.tri_classify(mov["xy"], tris, radius, 15, mov["cell_type"])
+    orc.tri_sign_weight(mov["xy"], mov["size"], tris)
+    och, oviol, _ = orc.orient_sweep(tris, prob.sign0, ref["xy"], match)
+    orc.xyorder_sweep(mov["xy"], ref["xy"], tris, match)
+    orc.area_flip(mov["xy"], ref["xy"], tris, match)
+    c2 = time.perf_counter()
+    t_cpu = (c1 - c0) + (c2 - c1) * S / n_mov
+    # parity of this run's GPU outputs with what the baseline just computed
+    ok = True
+    for i in np.random.default_rng(0).choice(S, min(8, S), replace=False):
+        ok &= bool(np.array_equal(prob.dD.download((n_ref,), np.float64, offset_bytes=int(i) * ld * 8), want_dense[i]))
+    ok &= bool(np.array_equal(prob.didx.download((S, k), np.int32), oi))
+    got_pc = prob.dcost.download((S, k), np.float64)
+    ok &= bool(np.array_equal(got_pc[rr, cc], want_pc))
+    ok &= (och == prob.last["checked"]) and bool(np.array_equal(oviol, prob.last["viol"]))
+    if not ok:
+        raise SystemExit("bench outputs differ from the oracle: refusing to report a number")
+    parity = f"dense rows, pruned lists and pair costs of rows [0,{S}) and the orientation sweep equal the oracle bit-for-bit"
+    if use_q32:
+        parity = (f"dense rows of [0,{S}) equal the fixed-point build's oracle twin bit-for-bit and are within 1e-6 relative of the "
+                  f"exact fp64 costs on all {S} x {n_ref} pairs; pruned lists, pair costs and the orientation sweep equal the oracle "
+                  "bit-for-bit")
+    note(group, f"cpu baseline sample done ({t_cpu:.1f} s), parity check passed")
+    del want_dense
+    # best-effort multi-core CPU lines (SURVEY 8d): the dense sample split over host threads (ctypes releases the GIL),
+    # and the radius query + top-k of the prune with scipy's cKDTree on all cores (src/utils.py:714,722 with workers=-1)
+    from concurrent.futures import ThreadPoolExecutor
+
+    from scipy.spatial import cKDTree
+
+    nthr = max(1, min(16, os.cpu_count() or 1))
+    cuts = np.linspace(0, S, nthr + 1).astype(int)
+    m0 = time.perf_counter()
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(lambda be: orc.dense_cost(mov["types"], ref["types"], mov["xy"], ref["xy"], 1.0, int(be[0]), int(be[1])),
+                    zip(cuts[:-1], cuts[1:])))
+    t_mt = time.perf_counter() - m0
+    k0 = time.perf_counter()
+    tree = cKDTree(ref["xy"])
+    balls = tree.query_ball_point(mov["xy"][:S], radius, workers=-1)
+    kd_pairs = 0
+    for i, b in enumerate(balls):
+        b = np.asarray(b, dtype=np.int64)
+        d = np.linalg.norm(ref["xy"][b] - mov["xy"][i], axis=1)
+        kd_pairs += len(b[np.argsort(d)[:k]])
+    t_kd = time.perf_counter() - k0
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    cpu = {"value": S * n_ref / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
+           "host_cpus": os.cpu_count(),
+           "dense_only_threaded": {"value": S * n_ref / t_mt, "unit": "cell-pairs/s", "cores": nthr,
+                                   "sample": f"dense cost of the same {S} rows split over {nthr} host threads"},
+           "knn_ckdtree_threaded": {"value": S * n_ref / t_kd, "unit": "dense-equivalent cell-pairs/s", "cores": os.cpu_count(),
+                                    "sample": f"scipy cKDTree(refs) build + query_ball_point(rows [0,{S}), r={radius:g}, workers=-1) + "
+                                              f"per-row norm/argsort top-{k} as src/utils.py:722-728 ({kd_pairs} pairs kept, "
+                                              f"{t_kd:.2f} s)"},
+           "sample": f"rows [0,{S}) of {n_mov} x {n_ref} refs: dense cost + knn prune + pair costs "
+                     f"({c1 - c0:.2f} s) plus the full {Tr}-triangle classify/sign/sweep pass scaled by {S}/{n_mov} "
+                     f"({c2 - c1:.3f} s unscaled); oracle/same_oracle.c, gcc -O2, 1 thread of {os.cpu_count()}",
+           "reference_note": "the reference itself (pure Python/pandas) cannot travel to this box; measured in the survey "
+                             "container (BASELINE.md section 3, 1 of 8 vCPU): 1.0-1.3e3 pairs/s pair-cost loop, 6.5e3 triangles/s "
+                             "filter, 2.7e5 triangles/s lazy sweep, 1.6e7 dense-equivalent cell-pairs/s KNN at 10k x 10k"}
+    return cpu, parity
+
+
 def cfg5_oracle_leg(st):
     """The cpu_baseline leg of the cfg 5 step (same_amd/bench_cfg5.py calls it on rank 0 at one rank): four windows through the CPU
     oracle -- timed: that is `cpu_baseline` -- and the same windows on the GPU, through prepare_same_inputs and through the timed
-    device-resident path, compared bit for bit.  Lives here because only bench.py's cpu_baseline leg may import the oracle."""
+    device-resident path, compared bit for bit."""
     import numpy as np
 
     import same_amd
 
-    plan, my_plan, r_df, m_df, cols, op, on_device = st["plan"], st["my_plan"], st["r_df"], st["m_df"], st["cols"], st["op"], st["on_device"]
+    plan, my_plan, r_df, m_df, cols = st["plan"], st["my_plan"], st["r_df"], st["m_df"], st["cols"]
+    op, on_device = st["op"], st["on_device"]
     from scipy.spatial import Delaunay
 
     from oracle import same_oracle as orc
@@ -516,8 +409,9 @@ def cfg5_oracle_leg(st):
         pairs = np.asarray(pairs, dtype=np.int64)
         axy, rxy = na[["X", "Y"]].to_numpy(), nr[["X", "Y"]].to_numpy()
         c32 = orc.pair_cost_arrays(na[cols].to_numpy(), nr[cols].to_numpy(), axy, rxy, pairs, 1.0, dtype=np.float32)
-        tri = np.asarray(orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
-                                                        min_angle_deg=15), dtype=np.int64).reshape(-1, 3)
+        kept = orc.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
+                                              min_angle_deg=15)
+        tri = np.asarray(kept, dtype=np.int64).reshape(-1, 3)
         signs = orc.source_signs(na, tri)
         kw = dict(valid_pairs=[tuple(p) for p in pairs.tolist()], costs=c32.astype(np.float64), n_aligned=len(na), n_ref=len(nr),
                   aligned_sizes=na["size"].to_numpy(dtype=float), no_match_penalty=100, max_matches=1, init_method="greedy", verbose=False)
@@ -529,13 +423,16 @@ def cfg5_oracle_leg(st):
         t_cpu += time.perf_counter() - c0
         # the same window on the GPU, compared
         prep = same_amd.prepare_same_inputs(rs, ms, cols, optim_params=op, verbose=False)
-        ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs) and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
-              and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri) and list(prep.source_signs) == list(signs))
+        ok = (np.array_equal(np.asarray(prep.valid_pairs, dtype=np.int64), pairs)
+              and np.array_equal(np.array(prep.costs).astype(np.float32), c32)
+              and np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri)
+              and list(prep.source_signs) == list(signs))
         gch, _ = same_amd.compute_mip_start_pairs(**dict(kw, valid_pairs=prep.valid_pairs, costs=prep.costs))
         sw = same_amd.LazyOrientationSweep(prep.valid_pairs, tri, prep.source_signs, rxy, prep.n_aligned)
         gchecked, gviol, _ = sw.sweep(xo)
         sw.bound.close()
-        ok = ok and gch == och and gchecked == ochecked and [tuple(int(q) for q in v) for v in gviol] == [tuple(int(q) for q in v) for v in oviol]
+        as_tuples = lambda rows: [tuple(int(q) for q in v) for v in rows]
+        ok = ok and gch == och and gchecked == ochecked and as_tuples(gviol) == as_tuples(oviol)
         checks.append((w, na, nr, pairs, c32, tri, signs, och, ochecked, oviol))
         if not ok:
             raise SystemExit("cfg5 window outputs differ from the oracle: refusing to report a number")
@@ -555,30 +452,16 @@ def cfg5_oracle_leg(st):
                   and np.array_equal(dw.match_row, match_o) and dw.stats["checked"] == ochecked and dw.stats["flipped"] == len(oviol))
             if not ok:
                 raise SystemExit("cfg5 window outputs of the device-resident path differ from the oracle: refusing to report a number")
-    parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under it "
-              "equal the oracle bit-for-bit" + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
+    parity = (f"{len(sample)} windows: pairs, fp32 pair costs, kept triangles, source signs, greedy start and the orientation sweep under "
+              "it equal the oracle bit-for-bit"
+              + (" -- through prepare_same_inputs and through the device-resident window path" if on_device else ""))
     cpu = {"value": done_pairs / t_cpu, "unit": "cell-pairs/s", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
-           "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, orientation sweep) "
-                     f"through oracle/same_oracle.{{c,py}} in {t_cpu:.2f} s, 1 thread (frame subsetting included; the GPU re-runs of the same windows for the "
-                     "comparison are not in this time)",
-           "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on this box"}
+           "sample": f"{len(sample)} of {len(plan)} windows (prune, fp32 pair costs, Qhull + triangle filter, signs, greedy start, "
+                     f"orientation sweep) through oracle/same_oracle.{{c,py}} in {t_cpu:.2f} s, 1 thread (frame subsetting included; the "
+                     "GPU re-runs of the same windows for the comparison are not in this time)",
+           "reference_note": "the reference's own loop (src/same.py:507-593) also solves a MIP per window, which has no counterpart on "
+                             "this box"}
     return cpu, parity
-
-
-def run_cfg5_workload(args, group, json_fd, local_rank):
-    """`--workload cfg5`: the window configuration as the line itself (same_amd/bench_cfg5.py)."""
-    from same_amd import _lib, bench_cfg5
-
-    os.environ.setdefault("SAME_HIP_DEVICE", str(local_rank % _lib.device_count()))
-    ctx = _lib.default_context()
-    comm, transport = make_comm(args, group, ctx, what="the ranks' match tables")   # a device all-gather (RCCL; host transport if that fails)
-    out = bench_cfg5.run(args, group, ctx, comm, transport, args.steps, args.warmup, cpu_baseline=None if args.no_cpu_baseline else cfg5_oracle_leg)
-    if group.rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    group.barrier()
-    if comm is not None:
-        comm.close()
-    group.close()
 
 
 def main():

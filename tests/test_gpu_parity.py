@@ -157,7 +157,8 @@ def test_pair_cost_golden(hip, ops, oracle, case):
     np.testing.assert_allclose(D32, D, rtol=1e-5, atol=1e-6 * 100 * max(len(cols), 1))
 
 
-@pytest.mark.parametrize("T", [0, 1, 2, 7, 20, 24, 25, 33, 48, 49, 55, 56, 64, 70, 129, 300])   # > 48: the row-blocked kernel (pieces of 8 types + remainder)
+# > 48: the row-blocked kernel (pieces of 8 types + remainder)
+@pytest.mark.parametrize("T", [0, 1, 2, 7, 20, 24, 25, 33, 48, 49, 55, 56, 64, 70, 129, 300])
 @pytest.mark.parametrize("w", [1.0, 0.37])
 def test_dense_cost_all_T(ops, oracle, T, w):
     rng = np.random.default_rng(T)
@@ -261,9 +262,11 @@ def test_mip_start_golden(hip, case):
     ch, un = hip.compute_mip_start_pairs(no_match_penalty=g["params"][4], init_method="greedy", **kw)
     assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3), g["greedy_chosen"]) and sorted(un) == g["greedy_unmatched"].tolist()
     ch, un = hip.compute_mip_start_pairs(no_match_penalty=float(g["greedy_lo_penalty"][0]), init_method="greedy", **kw)
-    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3), g["greedy_lo_chosen"]) and sorted(un) == g["greedy_lo_unmatched"].tolist()
+    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3),
+                          g["greedy_lo_chosen"]) and sorted(un) == g["greedy_lo_unmatched"].tolist()
     ch, un = hip.compute_mip_start_pairs(no_match_penalty=g["params"][4], init_method="hungarian", init_hungarian_max_n=100000, **kw)
-    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3), g["hungarian_chosen"]) and sorted(un) == g["hungarian_unmatched"].tolist()
+    assert np.array_equal(np.array(ch, dtype=np.int64).reshape(-1, 3),
+                          g["hungarian_chosen"]) and sorted(un) == g["hungarian_unmatched"].tolist()
     assert hip.compute_mip_start_pairs(no_match_penalty=1.0, init_method="hungarian", init_hungarian_max_n=10, **kw) == ([], set())
     with pytest.raises(ValueError):
         hip.compute_mip_start_pairs(no_match_penalty=1.0, init_method="bogus", **kw)
@@ -414,7 +417,8 @@ def test_window_plan_vs_oracle(hip, oracle):
     rn[rng.integers(0, len(rn), 9), 0] = np.nan
     mn[rng.integers(0, len(mn), 6), 1] = np.nan
     plan, oplan = hip.window_plan(rn, mn, 300, 100, 450), oracle.window_plan(rn, mn, 300, 100, 450)
-    assert len(plan) == len(oplan) > 0 and all(p[key] == o[key] for p, o in zip(plan, oplan) for key in ("window_id", "box", "trim", "n_ref", "n_mov"))
+    keys = ("window_id", "box", "trim", "n_ref", "n_mov")
+    assert len(plan) == len(oplan) > 0 and all(p[key] == o[key] for p, o in zip(plan, oplan) for key in keys)
     with pytest.raises(OverflowError):
         hip.window_plan(np.vstack([rxy, [[np.inf, 0.0]]]), mov["xy"], 300, 100, 450)
 
@@ -541,7 +545,8 @@ def test_sharded_sweeps_rccl_single_rank_and_block_forms(ops, oracle):
     for t0, t1 in ((0, 10), (10, 301), (301, Tr)):
         ctx.check(L.same_orient_flags_dev(sweep, dmatch.ptr, t0, t1, dflag.ptr), "flags")
     ctx.check(L.same_orient_from_flags_dev(sweep, dflag.ptr, ctypes.byref(chk), viol.ctypes.data, ctypes.byref(nv)), "from_flags")
-    assert chk.value == want_checked and np.array_equal(viol[: nv.value], want_viol) and np.array_equal(dflag.download((Tr,), np.uint8), want_flag)
+    assert chk.value == want_checked and np.array_equal(viol[: nv.value], want_viol)
+    assert np.array_equal(dflag.download((Tr,), np.uint8), want_flag)
     assert L.same_orient_flags_dev(sweep, dmatch.ptr, 0, Tr + 1, dflag.ptr) == -22
     # first candidate of a padded list
     didx = ctx.to_device(idx)
@@ -593,7 +598,8 @@ def _sharded_device_worker(rank, world, rdv, out_dir, transport="host"):
         sh = ShardedSweeps(ctx, comm, sweep, dax, drx, dtris, Tr, n_m)           # triangle blocks of the three sweeps
         checked, viol = sh.run(dmatch)
         out = sh.download()
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, cost=cost, checked=checked, viol=viol, match=match, tris=tris, sign=sign, **out)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, cost=cost, checked=checked, viol=viol, match=match, tris=tris,
+                 sign=sign, **out)
         group.barrier()
         L.same_sweep_unbind(sweep)
         comm.close()
@@ -793,7 +799,8 @@ def test_greedy_chain_is_resolved_in_batches(ops, oracle):
     rng = np.random.default_rng(3)
     pi, pj = np.repeat(np.arange(2000), 8), rng.integers(0, 2000, 16000)
     before = ctx.stats()
-    mp, rounds = ops.greedy_match(np.column_stack((pi, pj)).astype(np.int32), rng.gamma(2.0, 20.0, 16000), 2000, 2000, np.ones(2000, np.uint8))
+    mp, rounds = ops.greedy_match(np.column_stack((pi, pj)).astype(np.int32), rng.gamma(2.0, 20.0, 16000), 2000, 2000,
+                                  np.ones(2000, np.uint8))
     readbacks = ctx.stats()["greedy_readbacks"] - before["greedy_readbacks"]
     # the batch schedule is 4, 4, 8, ... rounds per read: up to 4 rounds take ONE read-back, and never more than one per 4 rounds + 1
     assert rounds >= 1 and 1 <= readbacks <= 1 + rounds // 4, (rounds, readbacks)
@@ -802,7 +809,8 @@ def test_greedy_chain_is_resolved_in_batches(ops, oracle):
     # a case that certainly resolves inside the first batch: disjoint pairs -> one round, ONE read
     n1 = 3000
     before = ctx.stats()
-    mp, rounds = ops.greedy_match(np.column_stack((np.arange(n1), np.arange(n1))).astype(np.int32), np.arange(n1, dtype=np.float64), n1, n1, np.ones(n1, np.uint8))
+    mp, rounds = ops.greedy_match(np.column_stack((np.arange(n1), np.arange(n1))).astype(np.int32), np.arange(n1, dtype=np.float64), n1,
+                                  n1, np.ones(n1, np.uint8))
     assert rounds == 1 and np.array_equal(mp, np.arange(n1)) and ctx.stats()["greedy_readbacks"] - before["greedy_readbacks"] == 1
 
 
@@ -872,12 +880,17 @@ def test_c_abi_error_codes(hip):
     z = np.zeros((4, 2))
     idx = np.full((4, 3), 7, np.int32); cnt = np.full(4, 7, np.int32)
     EINVAL, ERANGE = -22, -34
-    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, 1.0, 0, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL     # k = 0
-    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 9, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL     # row_end > n_m
+    # k = 0
+    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, 1.0, 0, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL
+    # row_end > n_m
+    assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 9, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL
     assert L.same_knn_prune(H, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, float("nan"), 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL
-    assert L.same_knn_prune(H, None, 4, z.ctypes.data, 4, 0, 4, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL            # NULL input
-    assert (idx == 7).all() and (cnt == 7).all()                                                                                      # outputs untouched
-    assert L.same_knn_prune(None, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL  # NULL ctx
+    # NULL input
+    assert L.same_knn_prune(H, None, 4, z.ctypes.data, 4, 0, 4, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL
+    # outputs untouched
+    assert (idx == 7).all() and (cnt == 7).all()
+    # NULL ctx
+    assert L.same_knn_prune(None, z.ctypes.data, 4, z.ctypes.data, 4, 0, 4, 1.0, 3, idx.ctypes.data, None, cnt.ctypes.data) == EINVAL
     tri = np.array([[0, 1, 9]], np.int32)
     out = np.zeros(1, np.int8)
     assert L.same_tri_sign_weight(H, z.ctypes.data, None, 4, tri.ctypes.data, 1, out.ctypes.data, None) == ERANGE
@@ -887,19 +900,25 @@ def test_c_abi_error_codes(hip):
     assert L.same_xyorder_sweep(H, z.ctypes.data, 4, z.ctypes.data, 4, np.array([[0, 1, 2]], np.int32).ctypes.data, 1, m.ctypes.data,
                                 o8.ctypes.data, o8.ctypes.data, o8.ctypes.data, o64.ctypes.data) == ERANGE
     chk, nv = ctypes.c_int64(0), ctypes.c_int64(0)
-    assert L.same_orient_sweep(None, m.ctypes.data, 4, ctypes.byref(chk), None, ctypes.byref(nv), None) == EINVAL                       # no sweep handle
+    # no sweep handle
+    assert L.same_orient_sweep(None, m.ctypes.data, 4, ctypes.byref(chk), None, ctypes.byref(nv), None) == EINVAL
     sw = ctypes.c_void_p()
     t1, s1 = np.array([[0, 1, 2]], np.int32), np.ones(1, np.int8)
     assert L.same_sweep_bind(H, t1.ctypes.data, 1, s1.ctypes.data, z.ctypes.data, 4, 4, None, 0, ctypes.byref(sw)) == 0
     v1 = np.zeros(1, np.int32)
-    assert L.same_orient_sweep(sw, m.ctypes.data, 3, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None) == EINVAL             # not the bound length
-    assert L.same_orient_sweep(sw, m.ctypes.data, 4, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None) == ERANGE             # match[3] = 99
-    assert L.same_orient_sweep_x(sw, z.ctypes.data, 2, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None, None, None) == EINVAL  # bound without pairs (P = 0)
+    # not the bound length
+    assert L.same_orient_sweep(sw, m.ctypes.data, 3, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None) == EINVAL
+    # match[3] = 99
+    assert L.same_orient_sweep(sw, m.ctypes.data, 4, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None) == ERANGE
+    # bound without pairs (P = 0)
+    assert L.same_orient_sweep_x(sw, z.ctypes.data, 2, ctypes.byref(chk), v1.ctypes.data, ctypes.byref(nv), None, None, None) == EINVAL
     L.same_sweep_unbind(sw)
     big = ctypes.c_void_p()
-    assert L.same_dev_alloc(H, 1 << 46, ctypes.byref(big)) in (-12, -5)                                                               # 64 TiB: ENOMEM (or EIO)
+    # 64 TiB: ENOMEM (or EIO)
+    assert L.same_dev_alloc(H, 1 << 46, ctypes.byref(big)) in (-12, -5)
     assert L.same_dense_cost_f64_dev(H, None, None, 20, None, None, 10, 0, 5, 1.0, None, 10) == EINVAL
-    assert L.same_dense_cost_f64_dev(H, z.ctypes.data, z.ctypes.data, 5000, z.ctypes.data, z.ctypes.data, 10, 0, 5, 1.0, z.ctypes.data, 10) == EINVAL  # T > SAME_MAX_TYPES
+    assert L.same_dense_cost_f64_dev(H, z.ctypes.data, z.ctypes.data, 5000, z.ctypes.data, z.ctypes.data, 10, 0, 5, 1.0, z.ctypes.data,
+                                     10) == EINVAL  # T > SAME_MAX_TYPES
     assert L.same_ctx_create(99, ctypes.byref(big)) == EINVAL
 
 
@@ -942,7 +961,8 @@ def test_plain_c_abi_demo_runs(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "abi_demo"
     lib_dir = os.path.join(root, "same_amd")
-    subprocess.check_call(["gcc", "-std=c11", f"-I{os.path.join(root, 'include')}", os.path.join(root, "examples", "abi_demo.c"), "-o", str(exe),
+    subprocess.check_call(["gcc", "-std=c11", f"-I{os.path.join(root, 'include')}", os.path.join(root, "examples", "abi_demo.c"), "-o",
+                           str(exe),
                            f"-L{lib_dir}", "-lsame_hip", f"-Wl,-rpath,{lib_dir}", "-lm"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
@@ -1009,7 +1029,8 @@ def test_fp32_pair_and_padded_costs_vs_oracle(hip, oracle, T, k, n_m, n_r):
     D = ops.dense_cost(A, R, axy, rxy, 0.75, dtype=np.float32)
     assert np.array_equal(D[pairs[:, 0], pairs[:, 1]], got)
     c64 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 0.75)
-    mag = 0.75 * ((np.abs(A[pairs[:, 0]]) + np.abs(R[pairs[:, 1]])).sum(axis=1) + 0.001 * (np.abs(axy[pairs[:, 0]]) + np.abs(rxy[pairs[:, 1]])).sum(axis=1))
+    pa, pr = pairs[:, 0], pairs[:, 1]
+    mag = 0.75 * ((np.abs(A[pa]) + np.abs(R[pr])).sum(axis=1) + 0.001 * (np.abs(axy[pa]) + np.abs(rxy[pr])).sum(axis=1))
     assert (np.abs(got.astype(np.float64) - c64) <= (T + 4) * 2.0 ** -24 * mag).all()
     ctx = _lib.default_context()
     f32 = [np.ascontiguousarray(x, dtype=np.float32) for x in (A, R, axy, rxy)]
@@ -1074,10 +1095,14 @@ def test_dense_cost_q32_limits(ops):
     ctx = _lib.default_context()
     z = ctx.alloc(4096)
     L, H = ctx.lib, ctx.handle
-    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, z.ptr, z.ptr, 33, z.ptr, z.ptr, 4, 0, 1, 1.0, 1.0, 1e-6, z.ptr, 4) == -22   # T > SAME_Q32_MAX_TYPES
-    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, z.ptr, z.ptr, 4, z.ptr, z.ptr, 5, 0, 1, 1.0, 1.0, 1e-6, z.ptr, 5) == -22    # odd pitch
-    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, z.ptr, z.ptr, 4, z.ptr, z.ptr, 4, 0, 1, 1.0, 0.0, 1e-6, z.ptr, 4) == -22    # inv_scale must be > 0
-    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, None, None, 4, z.ptr, z.ptr, 4, 0, 1, 1.0, 1.0, 1e-6, z.ptr, 4) == -22      # a tolerance needs the fp64 matrices
+    # T > SAME_Q32_MAX_TYPES
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, z.ptr, z.ptr, 33, z.ptr, z.ptr, 4, 0, 1, 1.0, 1.0, 1e-6, z.ptr, 4) == -22
+    # odd pitch
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, z.ptr, z.ptr, 4, z.ptr, z.ptr, 5, 0, 1, 1.0, 1.0, 1e-6, z.ptr, 5) == -22
+    # inv_scale must be > 0
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, z.ptr, z.ptr, 4, z.ptr, z.ptr, 4, 0, 1, 1.0, 0.0, 1e-6, z.ptr, 4) == -22
+    # a tolerance needs the fp64 matrices
+    assert L.same_dense_cost_q32_dev(H, z.ptr, z.ptr, None, None, 4, z.ptr, z.ptr, 4, 0, 1, 1.0, 1.0, 1e-6, z.ptr, 4) == -22
     with pytest.raises(ValueError):
         ops.quantize_types(np.array([[np.nan, 1.0]]), np.ones((2, 2)))
 
@@ -1094,7 +1119,8 @@ def test_dense_cost_f32_dev_entry_point(hip, oracle):
     dA, dR, dax, drx = (ctx.to_device(x) for x in (A, R, axy, rxy))
     b, e = 33, 650
     out = ctx.alloc((e - b) * n_r * 4)
-    ctx.check(ctx.lib.same_dense_cost_f32_dev(ctx.handle, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_r, b, e, 0.5, out.ptr, n_r), "same_dense_cost_f32_dev")
+    ctx.check(ctx.lib.same_dense_cost_f32_dev(ctx.handle, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_r, b, e, 0.5, out.ptr, n_r),
+              "same_dense_cost_f32_dev")
     got = out.download((e - b, n_r), np.float32)
     assert np.array_equal(got, ops.dense_cost(A, R, axy, rxy, 0.5, b, e, dtype=np.float32))
     assert np.array_equal(got, oracle.dense_cost(A, R, axy, rxy, 0.5, b, e, dtype=np.float32))
@@ -1189,7 +1215,8 @@ def test_orientation_sweep_repeated_and_with_a_long_flipped_list(oracle):
         for q, x in enumerate(xs):
             checked, viol, _ = sw.sweep(x)
             want = oracle.lazy_orientation_sweep(x, pairs, tris, sign, rxy, n_a)
-            assert int(checked) == want[0] and [tuple(int(v) for v in row) for row in viol] == [tuple(int(v) for v in row) for row in want[1]], (rep, q)
+            as_tuples = lambda rows: [tuple(int(v) for v in row) for row in rows]
+            assert int(checked) == want[0] and as_tuples(viol) == as_tuples(want[1]), (rep, q)
     ref = synth.make_cells(30000, 2, seed=11)
     mov = synth.make_jittered(ref, seed=12)
     big_tris = np.ascontiguousarray(Delaunay(mov["xy"]).simplices, dtype=np.int32)
@@ -1235,7 +1262,8 @@ for T in (0, 5, 16, 20):
     out[f"f32_{{T}}"] = ops.dense_cost(*a, 2.5, 7, 1400, dtype=np.float32)
 np.savez({str(tmp_path / 'out.npz')!r}, **out)
 """
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SAME_DENSE_MAP=str(map_mode)), capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SAME_DENSE_MAP=str(map_mode)), capture_output=True, text=True,
+                       timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     got = np.load(tmp_path / "out.npz")
     for T, a in cases.items():

@@ -197,7 +197,8 @@ def test_prepare_default_flags_and_priority_filter(case, oracle):
     a_df, r_df, cols = frames_from_golden(g)
     mad = None if g["params"][2] < 0 else g["params"][2]
     base = dict(radius=g["params"][0], knn=int(g["params"][1]), min_angle_deg=mad, dist_ct_coeff=g["params"][3])
-    prep = same_amd.prepare_same_inputs(r_df, a_df.drop(columns=["size"]), cols, optim_params=base, verbose=False)  # ignore_same_type_triangles=True
+    # ignore_same_type_triangles=True
+    prep = same_amd.prepare_same_inputs(r_df, a_df.drop(columns=["size"]), cols, optim_params=base, verbose=False)
     assert np.array_equal(np.array(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), g["tri_type"])
     assert (prep.aligned_df["size"] == 1).all()                                  # default size column (src/same.py:934-939)
     w, s = oracle.tri_sign_weight(prep.aligned_df[["X", "Y"]].to_numpy(), np.ones(prep.n_aligned), g["tri_type"])
@@ -296,11 +297,13 @@ def test_bench_contract_line(force_comm):
         if rf["telemetry"].get("available") and rf["telemetry"].get("sclk_steady"):
             assert 0.0 < rf["valu_busy_frac"] <= 1.05 and rf["valu_floor_ms_at_held_clock"] > 0 and rf["held_clock_mhz"] > 500
         assert rf["measured_ceilings"]["device_copy_GBs"] > 0 and rf["frac_of_measured_copy_bw"] > 0
-        assert rf["output_buffer"]["spread"] is False       # T = 20 is bound by fp64 issue: the timed loop stores into a plain block (--spread auto)
+        # T = 20 is bound by fp64 issue: the timed loop stores into a plain block (--spread auto)
+        assert rf["output_buffer"]["spread"] is False
         assert all("output_buffer" in e for e in rf["sweep"] if not e.get("opt_in"))
         assert rf["pruned_path"]["cell_pairs_per_s"] > out["value"] and rf["triangle_maps_and_sweeps"]["triangles_per_s"] > 0
         rm = rf["realistic_matching"]        # jittered copy + greedy start: most rows matched, few flips among many checked triangles
-        assert rm["matched_rows"] > 0.8 * 0.9 * 4000 and rm["orientation_checked"] > 1000 and rm["orientation_flipped"] < 0.2 * rm["orientation_checked"]
+        assert rm["matched_rows"] > 0.8 * 0.9 * 4000 and rm["orientation_checked"] > 1000
+        assert rm["orientation_flipped"] < 0.2 * rm["orientation_checked"]
         cb = out["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
         assert "equal the oracle bit-for-bit" in out["parity_spot_check"]
@@ -343,7 +346,8 @@ def test_bench_two_ranks_on_one_gpu_carry_the_diagnosis():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1",
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup",
+                          "1",
                           "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
@@ -373,7 +377,8 @@ def test_window_arrays_equal_prepared_windows(cost_dtype, pipeline):
     m_df["size"] = np.where(np.arange(len(m_df)) % 3 == 0, 2, 1) if cost_dtype == "float32" else m_df["size"].astype(float) * 1.5
     cols = synth.type_columns(T)
     plan = window_plan(r_df[["X", "Y"]].to_numpy(), m_df[["X", "Y"]].to_numpy(), 700, 200, 10)
-    plan = plan[::2] + [dict(plan[0], box=(5000.0, 7100.0, 5000.0, 7100.0))]       # + a window over the clump: aligned cells, no reference cells
+    # + a window over the clump: aligned cells, no reference cells
+    plan = plan[::2] + [dict(plan[0], box=(5000.0, 7100.0, 5000.0, 7100.0))]
     op = dict(radius=30, knn=6, min_angle_deg=12, dist_ct_coeff=1.5, hip_cost_dtype=cost_dtype)
     frames = list(same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=op, pipeline=pipeline))
     arrays = list(iter_window_arrays(Section.from_frame(r_df, cols), Section.from_frame(m_df, cols), plan, radius=30, knn=6,
@@ -423,8 +428,10 @@ def test_device_windows_equal_the_column_pipeline(cost_dtype):
     dref, dmov = W.DeviceSection(ref_sec, cost_dtype), W.DeviceSection(mov_sec, cost_dtype)
     kw = dict(radius=30, knn=6, dist_ct_coeff=1.5, min_angle_deg=12, ignore_same_type_triangles=True)
     arrays = list(W.iter_window_arrays(ref_sec, mov_sec, plan, cost_dtype=cost_dtype, **kw))
-    penalty, errors, windows, n_matched, n_rows = 0.006, 0, 0, 0, 0   # a penalty some rows' best pair does not beat: `prefer` is not all ones
-    for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True, **kw)):
+    # a penalty some rows' best pair does not beat: `prefer` is not all ones
+    penalty, errors, windows, n_matched, n_rows = 0.006, 0, 0, 0, 0
+    for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True,
+                                                    **kw)):
         assert dw.window is wa.window
         if wa.error is not None:
             assert isinstance(dw.error, ValueError) and str(dw.error) == str(wa.error)
@@ -459,7 +466,8 @@ def test_device_windows_equal_the_column_pipeline(cost_dtype):
     assert near > 0 and st.n_triangles == 0 and m0 is None and f0 is None and s0 is None
     with pytest.raises(SameHipError):
         st.fetch(W._W_TRIANGLES)                            # nothing was left on the device
-    host = filter_triangles_by_radius(axy, simplices, 30, ignore_same_type_triangles=True, min_angle_deg=12, verbose=False, _rows_as_array=True,
+    host = filter_triangles_by_radius(axy, simplices, 30, ignore_same_type_triangles=True, min_angle_deg=12, verbose=False,
+                                      _rows_as_array=True,
                                       _type_id=mov_sec.type_id[rows])
     k0, k1, near, a, b, c = st.filter_finish(simplices, 30, en, thr, 0.0, True, penalty)
     assert near == 0 and k0 + k1 == len(host) and k1 > 0
@@ -511,14 +519,16 @@ def test_bench_cfg5_windows_line(world):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SAME_RDV_DIR")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg5", "--cfg5-cells", "60000", "--steps", "1", "--warmup", "1", "--gpus", str(world)]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg5", "--cfg5-cells", "60000", "--steps", "1", "--warmup", "1",
+           "--gpus", str(world)]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["metric"] == json.load(open(os.path.join(root, "BASELINE.json"), encoding="utf-8"))["metric"]
-    assert out["n_gpus"] == world and out["dtype"] == "f32" and out["value"] > 0 and out["config"]["workload"].startswith("cfg5: 60000-cell section")
+    assert out["n_gpus"] == world and out["dtype"] == "f32" and out["value"] > 0
+    assert out["config"]["workload"].startswith("cfg5: 60000-cell section")
     pr = out["per_rank"]
     assert len(pr["windows"]) == world and sum(pr["windows"]) >= 4 and all(v > 0 for v in pr["windows_per_s"])
     assert all(0.0 <= v < 1.0 for v in pr["host_glue_share"]) and out["windows_per_s"] > 0 and out["merged_matches"] > 1000
@@ -542,9 +552,11 @@ def test_bench_cfg5_windows_line(world):
         # of the section with a do-nothing gurobipy (run_same's own Python around the solver)
         ap = out["api_path"]
         assert out["api_path_windows_per_s"] == ap["api_path_windows_per_s"] > 0 and ap["pipeline"] == "device" and ap["matches"] > 1000
-        assert ap["with_solver_double"]["windows"] >= 1 and ap["with_solver_double"]["seconds_per_window"] > ap["with_solver_double"]["solver_side_python_s_per_window"] > 0
+        sd = ap["with_solver_double"]
+        assert sd["windows"] >= 1 and sd["seconds_per_window"] > sd["solver_side_python_s_per_window"] > 0
         # the same function's general route on host frames merges to the same table
-        res = subprocess.run(cmd + ["--cfg5-pipeline", "frames", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        res = subprocess.run(cmd + ["--cfg5-pipeline", "frames", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True,
+                             timeout=900)
         assert res.returncode == 0, res.stderr[-3000:]
         col = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
         assert col["config"]["pipeline"].startswith("frames:") and col["merged_matches"] == out["merged_matches"]
@@ -565,8 +577,10 @@ def test_bench_line_embeds_a_cfg5_record(world):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SAME_RDV_DIR", "SAME_QHULL_WORKERS")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "SAME_RDV_DIR",
+                                                            "SAME_QHULL_WORKERS")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-extras",
            "--no-strong-record", "--embed-cfg5", "on", "--cfg5-cells", "60000", "--gpus", str(world)]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -590,7 +604,8 @@ def test_bench_line_embeds_a_cfg5_record(world):
         assert rec["unsharded_s_per_step"] == 0.0
     else:
         sx = rec["seam_exchange"]
-        assert len(sx["rows_sent_per_step_by_rank"]) == world and all(0 < v < 0.5 * rec["merged_matches"] for v in sx["rows_sent_per_step_by_rank"])
+        sent = sx["rows_sent_per_step_by_rank"]
+        assert len(sent) == world and all(0 < v < 0.5 * rec["merged_matches"] for v in sent)
         assert rec["unsharded_s_per_step"] > 0.0
 
 
@@ -603,7 +618,8 @@ def test_bench_step_with_the_fixed_point_dense_build():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--dense", "q32",
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                          "--dense", "q32",
                           "--no-extras"], cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][0])
@@ -626,13 +642,16 @@ def _mock_inputs():
     tri_all = Delaunay(a_pre[["X", "Y"]].values).simplices
     keep = ~np.isin(tri_all, np.arange(0, len(a_pre), 9)).any(axis=1)
     cases = {
-        "lazy_greedy": (a_df, dict(radius=20, knn=4), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=25), {}),
-        "priority_hungarian": (a_df, dict(radius=20, knn=4, ignore_knn_if_matched=True, min_angle_deg=None, ignore_same_type_triangles=False,
+        "lazy_greedy": (a_df, dict(radius=20, knn=4), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0,
+                                                           lazy_max_cuts_per_incumbent=25), {}),
+        "priority_hungarian": (a_df, dict(radius=20, knn=4, ignore_knn_if_matched=True, min_angle_deg=None,
+                                          ignore_same_type_triangles=False,
                                           dist_ct_coeff=2.5, no_match_penalty=40, penalty_coeff=3.0, delaunay_penalty=7.0),
                                dict(init_method="hungarian", lazy_allowed_flip_fraction=0.0, lazy_max_cuts=9, time_limit=60, mip_focus=1,
                                     cuts=2, heuristics=0.2), {}),
         "eager": (a_df, dict(radius=14, knn=3, lazy_constraints=False), dict(init_method="greedy"), {}),
-        "max_matches2": (a_df, dict(radius=20, knn=5, max_matches=2, min_angle_deg=0), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0), {}),
+        "max_matches2": (a_df, dict(radius=20, knn=5, max_matches=2, min_angle_deg=0),
+                         dict(init_method="greedy", lazy_allowed_flip_fraction=0.0), {}),
         "multiplier": (a_df, dict(radius=25, knn=6, ref_metacell_match_multiplier=2),
                        dict(init_method="hungarian", init_hungarian_max_n=100, lazy_allowed_flip_fraction=0.0), {}),
         "precomputed": (a_pre, dict(radius=20, knn=4), dict(init_method="greedy", lazy_allowed_flip_fraction=0.0),
@@ -670,7 +689,8 @@ def test_run_same_equals_reference_run_same(gp, tag, tmp_path, monkeypatch):
     lv, la, lr, lm = same_amd.load_matching_results(outprefix)
     if var_out:
         back = rec.record_run(lm, lv, gp.Model.last)
-        for k in ("x", "no_match_vars", "area_penalty_vars", "viol_summary", "flipped_triangles", "areas_before", "info_keys", "out__aligned_idx",
+        for k in ("x", "no_match_vars", "area_penalty_vars", "viol_summary", "flipped_triangles", "areas_before", "info_keys",
+                  "out__aligned_idx",
                   "out__ref_idx", "out__triangle_violation"):
             assert np.array_equal(np.asarray(back[k]).astype(float), np.asarray(got[k]).astype(float), equal_nan=True), k
         assert len(la) == len(var_out["no_match_vars"]) and len(lr) == len(var_out["penalty_vars"])
@@ -702,10 +722,12 @@ def test_sliding_window_equals_reference(gp, tmp_path, monkeypatch, pipeline):
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix="sw/res_")
     assert sorted(d for d in os.listdir(sw) if d.startswith("window_")) == list(g["sw/dirs"])
     assert len(pd.read_csv(os.path.join(sw, "matchedDF.csv"))) == int(g["sw/csv_rows"][0])
-    res2 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), commonCT=synth.type_columns(3), outprefix=sw, optim_params=dict(swp),
+    res2 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), commonCT=synth.type_columns(3), outprefix=sw,
+                                            optim_params=dict(swp),
                                             gurobi_params=dict(gpar))
     assert len(res2) == int(g["sw/resume_rows"][0])
-    res3 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), optim_params=dict(swp, window_size=220, overlap=60), gurobi_params=dict(gpar))
+    res3 = same_amd.sliding_window_matching(r_big.copy(), m_big.copy(), optim_params=dict(swp, window_size=220, overlap=60),
+                                            gurobi_params=dict(gpar))
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res3).items()}, g, prefix="sw_infer/res_")
 
 
@@ -757,13 +779,15 @@ def test_incumbent_table_equals_the_reference_window_loop(route, pipeline, tmp_p
     r_big, m_big, cols = _sw_inputs()
     for prefix, ws, ov, ct in (("sw", 150, 40, cols), ("sw_infer", 220, 60, None)):
         op = dict(radius=20, knn=4, window_size=ws, overlap=ov, min_cells_per_window=60)
-        res, stats = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), commonCT=ct, optim_params=dict(op), window_local_indices=True,
+        res, stats = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), commonCT=ct, optim_params=dict(op),
+                                                       window_local_indices=True,
                                                        return_stats=True, _route=route, _pipeline=pipeline)
         _assert_incumbent_equals_golden(res, g, prefix)
         assert len(stats) == res["window_id"].nunique() and all(s["pairs"] > 0 and s["triangles"] > 0 for s in stats)
     if route == "device":
         # without the window-local reference index (the default: no pair list comes back), with two worker threads, into a directory
-        res2 = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), optim_params=dict(op), workers=2, outprefix=str(tmp_path / "inc"))
+        res2 = same_amd.sliding_window_incumbent(r_big.copy(), m_big.copy(), optim_params=dict(op), workers=2,
+                                                 outprefix=str(tmp_path / "inc"))
         assert "ref_idx" not in res2.columns and res2.equals(res.drop(columns=["ref_idx"]))
         assert len(pd.read_csv(tmp_path / "inc" / "matchedDF.csv")) == len(res2)
         # a second call finds every window in the file and runs none
@@ -782,17 +806,20 @@ def test_incumbent_table_routes_agree():
     mov = synth.make_jittered(ref, seed=31)
     r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
     m_df["size"] = np.where(np.arange(len(m_df)) % 3 == 0, 2, 1)
-    op = dict(radius=30, knn=6, min_angle_deg=12, dist_ct_coeff=1.5, hip_cost_dtype="float32", window_size=700, overlap=200, no_match_penalty=0.006,
+    op = dict(radius=30, knn=6, min_angle_deg=12, dist_ct_coeff=1.5, hip_cost_dtype="float32", window_size=700, overlap=200,
+              no_match_penalty=0.006,
               min_cells_per_window=10)
     cols = synth.type_columns(5)
     fast = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), window_local_indices=True, _route="device")
     for pipeline in ("device", "frames"):
-        slow = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), window_local_indices=True, _route="general",
+        slow = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), window_local_indices=True,
+                                                 _route="general",
                                                  _pipeline=pipeline)
         assert list(fast.columns) == list(slow.columns) and len(fast) == len(slow) > 5000
         for c in fast.columns:
             assert np.array_equal(fast[c].to_numpy(), slow[c].to_numpy()), (pipeline, c)
-    assert 0.2 * len(m_df) < fast["Aligned_Cell_Num_Old"].nunique() < 0.98 * len(m_df) and fast["triangle_violation"].any() and fast["filtered_violation"].any()
+    assert 0.2 * len(m_df) < fast["Aligned_Cell_Num_Old"].nunique() < 0.98 * len(m_df)
+    assert fast["triangle_violation"].any() and fast["filtered_violation"].any()
     pri = [same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op, ignore_knn_if_matched=True), _pipeline=p)
            for p in ("device", "frames")]
     assert pri[0].equals(pri[1]) and len(pri[0]) > 5000 and not pri[0].equals(fast.drop(columns=["ref_idx"]))
@@ -825,15 +852,18 @@ def test_resident_frames_serve_several_jobs(gp, tmp_path, monkeypatch):
             got = same_amd.sliding_window_incumbent(res, res, commonCT=cols, optim_params=dict(op), window_local_indices=True)
             want = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), window_local_indices=True)
             assert len(got) > 300 and got.equals(want), op
-        assert len(res._frames) == 2 and len(res.plans) == 2         # sections per (cost type, window grid); plans per (size, overlap, min cells)
+        # sections per (cost type, window grid); plans per (size, overlap, min cells)
+        assert len(res._frames) == 2 and len(res.plans) == 2
         before = ctx.stats()
         again = same_amd.sliding_window_incumbent(res, m_big, commonCT=cols, optim_params=dict(jobs[0]), window_local_indices=True)
-        assert again.equals(same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(jobs[0]), window_local_indices=True))
+        assert again.equals(same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(jobs[0]),
+                                                              window_local_indices=True))
         assert len(res._frames) == 2 and ctx.stats()["launches"] > before["launches"]
         # the reference's signature on the same resident frames
         g = load_golden("run_same_mock")
         import run_same_record as rec
-        out = same_amd.sliding_window_matching(res, res, commonCT=cols, optim_params=dict(jobs[0]), gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0))
+        out = same_amd.sliding_window_matching(res, res, commonCT=cols, optim_params=dict(jobs[0]),
+                                               gurobi_params=dict(init_method="greedy", lazy_allowed_flip_fraction=0.0))
         rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", out).items()}, g, prefix="sw/res_")
         with pytest.raises(ValueError, match="other ref / moving objects"):
             same_amd.sliding_window_incumbent(res, m_big.copy(), commonCT=cols, optim_params=dict(jobs[0]))
@@ -855,11 +885,14 @@ def _sharded_incumbent_worker(rank, world, deal, out_dir):
     r_big, m_big, cols = _sw_inputs()
     _r, m_two, _c = _sw_inputs_crowded()
     op = dict(radius=20, knn=4, window_size=150, overlap=40, min_cells_per_window=60)
-    op2 = dict(radius=25, knn=6, window_size=100, overlap=4, min_cells_per_window=20)      # an overlap far below the prune's reach: neighbouring windows see different suitors of a cell and disagree
+    # an overlap far below the prune's reach: neighbouring windows see different suitors of a cell and disagree
+    op2 = dict(radius=25, knn=6, window_size=100, overlap=4, min_cells_per_window=20)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), SAME_RDV_DIR=os.path.join(out_dir, "rdv"))
     if world == 2:     # the package's own wrappers over its plain-Python host group (RANK / WORLD_SIZE / SAME_RDV_DIR)
-        part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)      # every rank: the whole table
-        merged = sharded_merged_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op2), deal=deal)     # every rank: its part of the merge
+        # every rank: the whole table
+        part = sharded_sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), deal=deal)
+        # every rank: its part of the merge
+        merged = sharded_merged_window_incumbent(r_big, m_two, commonCT=cols, optim_params=dict(op2), deal=deal)
     else:              # the share of one rank, as a launcher with its own exchange would take it
         part = same_amd.sliding_window_incumbent(r_big, m_big, commonCT=cols, optim_params=dict(op), _shard=(rank, world, deal))
         with HostGroup() as g:
@@ -896,7 +929,8 @@ def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world, 
         assert all(p.equals(whole) for p in parts)
     else:
         assert all(len(p) > 50 and "__plan_pos" in p.columns for p in parts)
-        merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable").drop(columns=["__plan_pos"]).reset_index(drop=True)
+        merged = pd.concat(parts, ignore_index=True).sort_values("__plan_pos", kind="stable")
+        merged = merged.drop(columns=["__plan_pos"]).reset_index(drop=True)
         assert merged.equals(whole)
     _assert_incumbent_equals_golden(whole, load_golden("run_same_mock"), "sw", with_ref_idx=False)
     _r, m_two, _c = _sw_inputs_crowded()
@@ -932,7 +966,8 @@ def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     import json
     probe = np.vstack([mc_a.original_delaunay[:5], [[7, 9, 123456789]], mc_a.original_delaunay[5:8]])
     assert np.array_equal(np.asarray(mc_a.original_delaunay), g["mc_helpers/original_delaunay"])
-    assert [json.dumps([int(v) for v in mc_a.metacell_members(k)]) for k in (0, 5, len(mc_a.metacell_df) - 1)] == list(g["mc_helpers/members_0_5_last"])
+    members = [json.dumps([int(v) for v in mc_a.metacell_members(k)]) for k in (0, 5, len(mc_a.metacell_df) - 1)]
+    assert members == list(g["mc_helpers/members_0_5_last"])
     assert np.array_equal(mc_a.original_delaunay_to_row_indices(), g["mc_helpers/rows"])
     assert np.array_equal(mc_a.original_delaunay_to_pos(probe), g["mc_helpers/rows_probe_drop"])
     assert np.array_equal(mc_a.original_delaunay_to_xy(), g["mc_helpers/xy"])
@@ -945,16 +980,19 @@ def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
     mgp = dict(init_method="greedy", lazy_allowed_flip_fraction=0.0, lazy_max_cuts_per_incumbent=40)
     out_df, var_out = same_amd.run_same(mc_r.metacell_df, mc_a, synth.type_columns(3), outprefix=str(tmp_path / "mc"),
                                         optim_params=dict(mop), gurobi_params=dict(mgp))
-    rec.assert_same_record(rec.record_run(out_df.drop(columns=["members"], errors="ignore"), var_out, gp.Model.last), g, prefix="metacell_flow/")
+    rec.assert_same_record(rec.record_run(out_df.drop(columns=["members"], errors="ignore"), var_out, gp.Model.last), g,
+                           prefix="metacell_flow/")
     indiv = same_amd.unpack_metacell_matches(out_df, mc_a.metacell_df, mc_r.metacell_df, aligned_df=a_c, ref_df=r_c, strategy="nearest",
                                              aligned_original_idx_col="Cell_Num_Old", ref_original_idx_col="Cell_Num_Old")
     assert np.array_equal(indiv[["Aligned_cell_id", "Ref_cell_id"]].to_numpy(dtype=np.int64), g["metacell_flow_unpacked"])
     res = same_amd.sliding_window_matching(mc_r, mc_a, commonCT=synth.type_columns(3),
-                                           optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
+                                           optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20),
+                                               gurobi_params=dict(mgp))
     rec.assert_same_record({k[4:]: v for k, v in rec.record_frame("res", res).items()}, g, prefix="sw_metacell/res_")
     # the solver-free product function on the same MetaCell objects (caller's triangulation -> its general route): the reference's table
     inc = same_amd.sliding_window_incumbent(mc_r, mc_a, commonCT=synth.type_columns(3), window_local_indices=True,
-                                            optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20), gurobi_params=dict(mgp))
+                                            optim_params=dict(mop, window_size=200, overlap=50, min_cells_per_window=20),
+                                                gurobi_params=dict(mgp))
     want_cols = [str(c) for c in g["sw_metacell/res_columns"]]
     assert [c for c in inc.columns] == [c for c in want_cols if c in inc.columns] and set(want_cols) - set(inc.columns) <= {"members"}
     for c in inc.columns:
@@ -1199,7 +1237,8 @@ def test_run_same_parameter_sweep_equals_reference(gp, tmp_path, monkeypatch):
         r_df = synth.to_frame(cells)
         a_df = synth.to_frame(synth.make_jittered(cells, seed=800 + q))
         out_df, var_out = same_amd.run_same(r_df.copy(), a_df.copy(), synth.type_columns(T), outprefix=str(tmp_path / f"c{q}"),
-                                            optim_params=same_amd.init_optim_params(**op), gurobi_params=same_amd.init_gurobi_params(**gpar))
+                                            optim_params=same_amd.init_optim_params(**op),
+                                                gurobi_params=same_amd.init_gurobi_params(**gpar))
         rec.assert_same_record(rec.record_run(out_df, var_out, gp.Model.last), g, prefix=f"c{q}/")
 
 
@@ -1293,7 +1332,8 @@ def test_window_rows_do_not_depend_on_the_section_grid():
     ok_r, ok_m = np.isfinite(rxy).all(axis=1), np.isfinite(mxy).all(axis=1)
     xs, ys, _ = W.window_grid(rxy[ok_r], mxy[ok_m], 600, 150)
     plan = W.window_plan(rxy[ok_r], mxy[ok_m], 600, 150, 10)
-    boxes = [w["box"] for w in plan[::5]] + [(101.5, 640.25, 333.0, 1200.0), (-50.0, 90.0, -50.0, 4000.0), (0.0, 1e9, 0.0, 1e9), (5.0, 5.0, 0.0, 9.0)]
+    boxes = [w["box"] for w in plan[::5]] + [(101.5, 640.25, 333.0, 1200.0), (-50.0, 90.0, -50.0, 4000.0), (0.0, 1e9, 0.0, 1e9),
+                                             (5.0, 5.0, 0.0, 9.0)]
     ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
     x0, y0, cell = W.window_cell_grid((xs, ys), 600, 150)
     assert cell == 150.0
@@ -1309,7 +1349,8 @@ def test_window_rows_do_not_depend_on_the_section_grid():
         out = []
         for box in boxes:
             counts = st.stage(dmov, dref, box, 25, 8, 1.0)
-            out.append((counts, st.fetch(W._W_ROWS_M), st.fetch(W._W_ROWS_R), st.fetch(W._W_PAIRS), st.fetch(W._W_COSTS), st.fetch(W._W_ALIGNED_ROWS)))
+            out.append((counts, st.fetch(W._W_ROWS_M), st.fetch(W._W_ROWS_R), st.fetch(W._W_PAIRS), st.fetch(W._W_COSTS),
+                        st.fetch(W._W_ALIGNED_ROWS)))
         got[name] = out
         st.close()
         dref.close()
@@ -1338,26 +1379,31 @@ def test_window_rows_when_points_sit_on_cell_and_box_edges():
         pts = np.array([(x * scale, y * scale) for y in g for x in g])                 # 3 600 lattice points, many exactly on cell edges
         sec = W.Section(pts, np.ones((len(pts), 2)), None, None)
         edges = [0.0, 3 * scale, 10 * scale, 20 * scale, 30 * scale, 0.30000000000000004, 59 * scale, 60 * scale, 12.5 * scale, -4.0, 1e9]
-        boxes = [(a, b, c, d) for a in edges[:6] for b in edges[3:] for (c, d) in ((0.0, 60 * scale), (10 * scale, 30 * scale), (12.5 * scale, 12.5 * scale))]
+        y_spans = ((0.0, 60 * scale), (10 * scale, 30 * scale), (12.5 * scale, 12.5 * scale))
+        boxes = [(a, b, c, d) for a in edges[:6] for b in edges[3:] for (c, d) in y_spans]
         boxes += [(5.0, 5.0, 0.0, 9.0), (9.0, 5.0, 0.0, 9.0), (float("nan"), 5.0, 0.0, 9.0), (-1e300, 1e300, -1e300, 1e300)]
         st = W.DeviceWindow()
-        for origin, cell in (((0.0, 0.0), 10 * scale), ((0.0, 0.0), scale), ((-3.7, 1.3), 4.9 * scale), ((30 * scale, 30 * scale), 10 * scale)):
+        for origin, cell in (((0.0, 0.0), 10 * scale), ((0.0, 0.0), scale), ((-3.7, 1.3), 4.9 * scale),
+                             ((30 * scale, 30 * scale), 10 * scale)):
             dsec = W.DeviceSection(sec, "float64").bin(origin[0], origin[1], cell)
             for box in boxes:
                 x0, x1, y0, y1 = box
                 want = np.flatnonzero((pts[:, 0] >= x0) & (pts[:, 0] < x1) & (pts[:, 1] >= y0) & (pts[:, 1] < y1))
                 n_m, n_r, _k, _p = st.stage(dsec, dsec, box, scale, 2, 1.0)
                 assert n_m == n_r == len(want), (scale, origin, cell, box)
-                assert np.array_equal(st.fetch(W._W_ROWS_M), want) and np.array_equal(st.fetch(W._W_ROWS_R), want), (scale, origin, cell, box)
+                case = (scale, origin, cell, box)
+                assert np.array_equal(st.fetch(W._W_ROWS_M), want) and np.array_equal(st.fetch(W._W_ROWS_R), want), case
             dsec.close()
         st.close()
     # a section without a usable row, and grids the library refuses
     empty = W.DeviceSection(W.Section(np.zeros((0, 2)), np.zeros((0, 1)), None, None), "float64")
     nans = W.DeviceSection(W.Section(np.full((5, 2), np.nan), np.ones((5, 1)), None, None), "float64").bin(0.0, 0.0, 1.0)
     st = W.DeviceWindow()
-    assert st.stage(empty, nans, (0.0, 1.0, 0.0, 1.0), 1.0, 1, 1.0) == (0, 0, 0, 0) and st.stage(nans, empty, (-1e9, 1e9, -1e9, 1e9), 1.0, 1, 1.0) == (0, 0, 0, 0)
+    assert st.stage(empty, nans, (0.0, 1.0, 0.0, 1.0), 1.0, 1, 1.0) == (0, 0, 0, 0)
+    assert st.stage(nans, empty, (-1e9, 1e9, -1e9, 1e9), 1.0, 1, 1.0) == (0, 0, 0, 0)
     some = W.DeviceSection(W.Section(np.array([[0.0, 0.0], [1e6, 1e6]]), np.ones((2, 1)), None, None), "float64")
-    for bad in ((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (float("nan"), 0.0, 1.0), (0.0, float("inf"), 1.0), (0.0, 0.0, 1e-3)):   # the last: 10^18 cells
+    # the last: 10^18 cells
+    for bad in ((0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (float("nan"), 0.0, 1.0), (0.0, float("inf"), 1.0), (0.0, 0.0, 1e-3)):
         with pytest.raises(SameHipError):
             some.bin(*bad)
     assert st.stage(some, some, (0.0, 2e6, 0.0, 2e6), 1.0, 1, 1.0)[:2] == (2, 2)       # a refused grid leaves the old one in place
@@ -1386,13 +1432,15 @@ def test_window_calls_stay_within_their_launch_budget():
     mov = synth.make_jittered(ref, seed=1)
     r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
     cols = synth.type_columns(T)
-    op = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0, hip_cost_dtype="float32",
+    op = dict(radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0,
+              hip_cost_dtype="float32",
               window_size=1200, overlap=300, min_cells_per_window=10)
     plan = W.window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
     assert len(plan) == 16
     ctx = _lib.default_context()
     with same_amd.resident_frames(r_df, m_df, ctx=ctx) as res_frames:
-        call = lambda **kw: same_amd.sliding_window_incumbent(res_frames, res_frames, commonCT=cols, optim_params=dict(op), workers=1, ctx=ctx,
+        call = lambda **kw: same_amd.sliding_window_incumbent(res_frames, res_frames, commonCT=cols, optim_params=dict(op), workers=1,
+                                                              ctx=ctx,
                                                               batch=8, return_stats=True, **kw)
         call()                                                           # buffers, helpers, the prune index, the sections
         before = ctx.stats()
@@ -1425,10 +1473,12 @@ def test_window_calls_stay_within_their_launch_budget():
     from same_amd.incumbent import incumbent_of_prepared
 
     before = ctx.stats()
-    out = same_amd.sliding_window_matching(r_df, m_df, commonCT=cols, optim_params=dict(op), _solve=lambda prep, _o: (incumbent_of_prepared(prep, cols)[0], {}))
+    stand_in = lambda prep, _o: (incumbent_of_prepared(prep, cols)[0], {})
+    out = same_amd.sliding_window_matching(r_df, m_df, commonCT=cols, optim_params=dict(op), _solve=stand_in)
     after = ctx.stats()
     per = {k: (after[k] - before[k]) / len(stats) for k in after}
     print("per window (sliding_window_matching):", per)
     assert out["window_id"].nunique() == len(stats) and len(out) == len(res)
     assert per["launches"] <= 6 and per["fills"] <= 1 and per["copies"] <= 9 and per["waits"] <= 8, per
-    assert np.array_equal(out["Aligned_Cell_Num_Old"].to_numpy(), res["Aligned_Cell_Num_Old"].to_numpy()) and np.array_equal(out["Ref_Cell_Num_Old"].to_numpy(), res["Ref_Cell_Num_Old"].to_numpy())
+    for column in ("Aligned_Cell_Num_Old", "Ref_Cell_Num_Old"):
+        assert np.array_equal(out[column].to_numpy(), res[column].to_numpy())
