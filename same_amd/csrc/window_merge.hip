@@ -29,7 +29,7 @@ struct same_merge_acc {
     unsigned long long *dcount = nullptr;     // [0] rows, [1] pad, [2 .. 2 + SAME_LAUNCH_WINDOWS) per-window counts of the group in flight
     int64_t bound = 0;                        // host: the rows collected since begin cannot exceed this (sum of the windows' kept cells)
     // the seams of this rank's share of the plan (same_merge_acc_begin)
-    win::DevBuf near_start, near_boxes;
+    win::DevBuf near_start, near_boxes, scan_words;   // scan_words: the collect call's look-back words, one run per window of a group
     int n_pos = 0, all_seam = 0;
     double reach = 0.0;
     // resolve / finish
@@ -78,18 +78,22 @@ __device__ __forceinline__ bool central(const CollectArgs &w, int64_t c) {
     return p.x >= w.tx0 && p.x < w.tx1 && p.y >= w.ty0 && p.y < w.ty1;     // the comparisons of src/same.py:575-580
 }
 
-// one block per window: how many of its kept cells are matched and central
-__global__ __launch_bounds__(256) void collect_count_kernel(Batch<CollectArgs> b, unsigned long long *__restrict__ wcount) {
-    const CollectArgs &w = b.w[blockIdx.x];
-    __shared__ unsigned part[4];
-    unsigned mine = 0;
-    for (int64_t c0 = 0; c0 < w.n; c0 += 256) {
-        const unsigned long long bal = __ballot(central(w, c0 + threadIdx.x));
-        mine += (threadIdx.x & 63) == 0 ? (unsigned)__builtin_popcountll(bal) : 0u;
-    }
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+// blocks of 256 cells (blockIdx.x) of up to eight windows (blockIdx.y): how many of a window's kept cells are matched and central;
+// every block also clears its word of the window's scan (collect_write_kernel's look-back runs on them next)
+__global__ __launch_bounds__(scan::NT) void collect_count_kernel(Batch<CollectArgs> b, unsigned long long *__restrict__ wcount,
+                                                                  unsigned long long *__restrict__ status, int64_t status_stride) {
+    const CollectArgs &w = b.w[blockIdx.y];
+    if ((int64_t)blockIdx.x * scan::NT >= w.n) return;
+    __shared__ unsigned part[scan::NT / 64];
+    const unsigned long long bal = __ballot(central(w, (int64_t)blockIdx.x * scan::NT + threadIdx.x));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = (unsigned)__builtin_popcountll(bal);
     __syncthreads();
-    if (threadIdx.x == 0) wcount[blockIdx.x] = (unsigned long long)part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) {
+        unsigned n = 0;
+        for (int q = 0; q < scan::NT / 64; ++q) n += part[q];
+        if (n) atomicAdd(&wcount[blockIdx.y], (unsigned long long)n);
+        status[blockIdx.y * status_stride + blockIdx.x] = 0ull;
+    }
 }
 
 struct AccRows {
@@ -97,51 +101,36 @@ struct AccRows {
     uint8_t *flags;
 };
 
-// one block per window: its rows after those of the group's earlier windows, cells ascending
-__global__ __launch_bounds__(256) void collect_write_kernel(Batch<CollectArgs> b, const unsigned long long *__restrict__ dcount, AccRows acc, int64_t cap) {
-    const CollectArgs &w = b.w[blockIdx.x];
-    __shared__ unsigned wave_n[4];
-    __shared__ unsigned long long base_s;
-    if (threadIdx.x == 0) {
-        unsigned long long base = dcount[0];
-        for (unsigned q = 0; q < blockIdx.x; ++q) base += dcount[2 + q];
-        base_s = base;
-    }
-    __syncthreads();
-    unsigned long long base = base_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t c0 = 0; c0 < w.n; c0 += 256) {
-        const int64_t c = c0 + threadIdx.x;
-        const bool take = central(w, c);
-        const unsigned long long bal = __ballot(take);
-        if (lane == 0) wave_n[wave] = (unsigned)__builtin_popcountll(bal);
-        __syncthreads();
-        unsigned before = (unsigned)__builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        unsigned total = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (q < wave) before += wave_n[q];
-            total += wave_n[q];
-        }
-        if (take) {
-            const unsigned long long at = base + before;
-            if ((int64_t)at < cap) {      // the host sized the arrays by the windows' kept cells: never past them
-                acc.a_row[at] = w.rows_ua[c];
-                acc.r_row[at] = w.match_row[c];
-                acc.flags[at] = w.pflag[c];
-                acc.wid[at] = w.wid;
-                acc.pos[at] = w.pos;
-                acc.cidx[at] = (int32_t)c;
-            }
-        }
-        base += total;
-        __syncthreads();
-    }
+// the same blocks: a window's rows after those of the group's earlier windows, cells ascending (look-back scan over the window's blocks)
+__global__ __launch_bounds__(scan::NT) void collect_write_kernel(Batch<CollectArgs> b, const unsigned long long *__restrict__ dcount,
+                                                                  unsigned long long *__restrict__ status, int64_t status_stride, AccRows acc,
+                                                                  int64_t cap) {
+    __shared__ scan::Shared sh;
+    const CollectArgs &w = b.w[blockIdx.y];
+    if ((int64_t)blockIdx.x * scan::NT >= w.n) return;
+    auto val = [&](int64_t c) { return Pair{central(w, c) ? 1u : 0u, 0u}; };
+    Pair through;
+    const Pair off = scan::exclusive(status + blockIdx.y * status_stride, (int)blockIdx.x, val, sh, &through);   // (a test tag in bit 0 of `status` moves along)
+    const int64_t c = (int64_t)blockIdx.x * scan::NT + threadIdx.x;
+    if (!central(w, c)) return;
+    unsigned long long at = dcount[0] + off.a;
+    for (unsigned q = 0; q < blockIdx.y; ++q) at += dcount[2 + q];
+    if ((int64_t)at >= cap) return;           // the host sized the arrays by the windows' kept cells: never past them
+    acc.a_row[at] = w.rows_ua[c];
+    acc.r_row[at] = w.match_row[c];
+    acc.flags[at] = w.pflag[c];
+    acc.wid[at] = w.wid;
+    acc.pos[at] = w.pos;
+    acc.cidx[at] = (int32_t)c;
 }
 
+// the group's rows are in: count them in, clear the per-window counts for the next group
 __global__ void collect_bump_kernel(unsigned long long *dcount, int n_w) {
     unsigned long long add = 0;
-    for (int q = 0; q < n_w; ++q) add += dcount[2 + q];
+    for (int q = 0; q < n_w; ++q) {
+        add += dcount[2 + q];
+        dcount[2 + q] = 0ull;
+    }
     dcount[0] += add;
 }
 
@@ -333,7 +322,7 @@ void same_merge_acc_destroy(same_merge_acc *a) {
     (void)hipStreamSynchronize(a->ctx->stream);
     free_rows(a);
     if (a->dcount) (void)hipFree(a->dcount);
-    for (DevBuf *b : {&a->near_start, &a->near_boxes, &a->work, &a->out}) release(*b);
+    for (DevBuf *b : {&a->near_start, &a->near_boxes, &a->scan_words, &a->work, &a->out}) release(*b);
     delete a;
 }
 
@@ -417,18 +406,26 @@ int same_window_collect(same_window *const *windows, int n_windows, same_merge_a
         SAME_TRY(reserve_rows(a, a->bound + add, (int64_t)have));
     }
     a->bound += add;
+    int64_t most = 0;
+    for (int i = 0; i < n_windows; ++i) most = std::max(most, windows[i]->n_ua);
+    const int64_t stride = (int64_t)(scan::status_bytes(most) / 8);          // look-back words of one window
+    SAME_TRY(ensure(ctx, a->scan_words, (size_t)stride * 8 * SAME_LAUNCH_WINDOWS));
+    unsigned long long *words = static_cast<unsigned long long *>(a->scan_words.p);
     for (int g = 0; g < n_windows; g += SAME_LAUNCH_WINDOWS) {
         Batch<CollectArgs> b{};
         int n_g = 0;
+        int64_t most_g = 0;
         for (int i = g; i < n_windows && i < g + SAME_LAUNCH_WINDOWS; ++i) {
             const same_window *w = windows[i];
             if (w->n_ua == 0) continue;
             const double *t = trims + 4 * i;
             b.w[n_g++] = CollectArgs{w->match_row, w->pflag, w->rows_ua, w->axy_c, w->n_ua, t[0], t[1], t[2], t[3], window_ids[i], plan_pos[i]};
+            most_g = std::max(most_g, w->n_ua);
         }
         if (!n_g) continue;
-        SAME_LAUNCH(ctx, collect_count_kernel, dim3((unsigned)n_g), dim3(256), 0, b, a->dcount + 2);
-        SAME_LAUNCH(ctx, collect_write_kernel, dim3((unsigned)n_g), dim3(256), 0, b, a->dcount, rows_of(a), a->cap);
+        const dim3 grid(scan::blocks_for(most_g), (unsigned)n_g);
+        SAME_LAUNCH(ctx, collect_count_kernel, grid, dim3(scan::NT), 0, b, a->dcount + 2, words, stride);
+        SAME_LAUNCH(ctx, collect_write_kernel, grid, dim3(scan::NT), 0, b, a->dcount, scan::arg(words), stride, rows_of(a), a->cap);
         SAME_LAUNCH(ctx, collect_bump_kernel, dim3(1), dim3(1), 0, a->dcount, n_g);
     }
     HIP_TRY(ctx, hipGetLastError());
