@@ -445,7 +445,8 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
  *                            the de-duplication left: int32 {row in the accumulator, aligned code, ref code, window id, plan position,
  *                            index among the window's kept cells}, uint32 flags (bit 0 XY-order flag, bit 1 area-flip flag, bit 2 seam).
  *   same_merge_acc_finish    winner_rows = the REST rows (accumulator row numbers) the host's matching kept -> the merged table's rows
- *                            in the order of the aligned codes (src/helpers.py:799-808); same_merge_acc_fetch(.., SAME_MERGE_FINAL) =
+ *                            in the order of the aligned codes (src/helpers.py:799-808), their number in *out_n_final; they stay on the
+ *                            device (same_merge_acc_columns reads them there) unless fetched: same_merge_acc_fetch(.., SAME_MERGE_FINAL) =
  *                            int32 {aligned section row, reference section row, index among the window's kept cells, window id, plan
  *                            position}, uint32 flags (bits 0, 1 as above) per row.  The host gathers the columns of exactly these rows.
  *   same_merge_acc_load      rows from the HOST instead of from windows (the seam rows of every rank after their exchange: the common step
@@ -470,6 +471,20 @@ int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_s
                            const same_section *ref /* NULL after ..._load */, int64_t *out_counts /* [4] */);
 int same_merge_acc_finish(same_merge_acc *acc, const int32_t *winner_rows, int64_t n_winners, int64_t *out_n_final);
 int same_merge_acc_fetch(same_merge_acc *acc, int what, void *out, int64_t bytes);
+/* The merged table's columns, written by the DEVICE (after same_merge_acc_finish; enqueue only -- same_ctx_sync waits) into out_host,
+ * column after column, n_final entries each, in the order of the final rows:
+ *   8-byte columns: the moving section's T type columns (src/same.py:1264-1278 copies them from aligned_df), its X and Y, the reference
+ *   section's X and Y (ref_X, ref_Y); then n_extra_mov columns gathered by moving row and n_extra_ref columns gathered by reference row
+ *   from the caller's DEVICE arrays of 8-byte values (cell ids, sizes: copied as bit patterns, whatever their type; at most 4 each); then
+ *   aligned_idx (the cell's index among its window's kept cells) and window_id as int64;
+ *   byte columns: triangle_violation (the area-flip flag, src/same.py:1464-1469) and the XY-order flag, 0 / 1.
+ * out_host holds (T + 4 + n_extra_mov + n_extra_ref + 2) * 8 * n_final + 2 * n_final bytes and must be host memory the device can write:
+ * same_host_alloc (page-locked, hipHostMalloc; same_host_free returns it).  The float columns are the bytes the caller uploaded with
+ * same_section_create. */
+int same_merge_acc_columns(same_merge_acc *acc, const same_section *moving, const same_section *ref, const void *const *extra_moving,
+                           int n_extra_moving, const void *const *extra_ref, int n_extra_ref, void *out_host, int64_t n_final);
+int same_host_alloc(same_ctx *ctx, size_t bytes, void **out_ptr);
+int same_host_free(same_ctx *ctx, void *ptr);
 
 /* ======================================================================================================================
  * part 4 -- COMM: one communicator per context, RCCL over xGMI

@@ -6,6 +6,7 @@ oracle.
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -111,6 +112,9 @@ _PROTOTYPES = {
     "same_merge_acc_resolve": [c_vp, c_int, c_vp, c_vp, c_vp],
     "same_merge_acc_finish": [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)],
     "same_merge_acc_fetch": [c_vp, c_int, c_vp, c_i64],
+    "same_merge_acc_columns": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_i64],
+    "same_host_alloc": [c_vp, c_sz, ctypes.POINTER(c_vp)],
+    "same_host_free": [c_vp, c_vp],
     "same_comm_unique_id": [c_vp],
     "same_comm_init": [c_vp, c_int, c_int, c_vp],
     "same_comm_destroy": [c_vp],
@@ -335,6 +339,8 @@ class Context:
     def close(self):
         for state in self.__dict__.pop("_device_windows", []):      # window states cached by windows.iter_device_windows
             state.close()
+        if self.handle and "same_amd.windows" in sys.modules:       # page-locked blocks of this context waiting in the table pool
+            sys.modules["same_amd.windows"].PINNED_BLOCKS.drop(self)
         if self.handle:
             self.lib.same_ctx_destroy(self.handle)
             self.handle = None

@@ -281,23 +281,17 @@ int same_section_create(same_ctx *ctx, const double *xy, const double *types, in
     if (!s->cost_f32) {
         s->xy_c = s->xy;
         HIP_TRY(ctx, hipMalloc(&s->types_c, nn * tt * sizeof(double)));
+        s->types64 = static_cast<double *>(s->types_c);
         if (n && T) HIP_TRY(ctx, hipMemcpyAsync(s->types_c, types, (size_t)n * T * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     } else {                                      // the float copies are made here, once: (float) of every operand, as astype(float32)
         HIP_TRY(ctx, hipMalloc(&s->xy_c, nn * 2 * sizeof(float)));
         HIP_TRY(ctx, hipMalloc(&s->types_c, nn * tt * sizeof(float)));
         if (n) {
             hipLaunchKernelGGL(to_float_kernel, dim3(grid_for(n * 2)), dim3(256), 0, ctx->stream, s->xy, n * 2, static_cast<float *>(s->xy_c));
-            if (T) {
-                double *tmp = nullptr;
-                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)n * T * sizeof(double)));
-                hipError_t e = hipMemcpyAsync(tmp, types, (size_t)n * T * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-                if (e == hipSuccess) {
-                    hipLaunchKernelGGL(to_float_kernel, dim3(grid_for(n * T)), dim3(256), 0, ctx->stream, tmp, n * T,
-                                       static_cast<float *>(s->types_c));
-                    e = hipStreamSynchronize(ctx->stream);
-                }
-                (void)hipFree(tmp);
-                if (e != hipSuccess) return same_fail(ctx, SAME_EIO, "section upload", e);
+            if (T) {      // the doubles stay (64 MB for a million cells x 8 types): the merged table's type columns are gathered from them on the device
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&s->types64), (size_t)n * T * sizeof(double)));
+                HIP_TRY(ctx, hipMemcpyAsync(s->types64, types, (size_t)n * T * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(to_float_kernel, dim3(grid_for(n * T)), dim3(256), 0, ctx->stream, s->types64, n * T, static_cast<float *>(s->types_c));
             }
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -321,6 +315,7 @@ void same_section_destroy(same_section *s) {
     s->knn.clear();
     if (s->xy_c && s->xy_c != s->xy) (void)hipFree(s->xy_c);
     if (s->xy) (void)hipFree(s->xy);
+    if (s->types64 && s->types64 != s->types_c) (void)hipFree(s->types64);
     if (s->types_c) (void)hipFree(s->types_c);
     if (s->size) (void)hipFree(s->size);
     if (s->type_id) (void)hipFree(s->type_id);

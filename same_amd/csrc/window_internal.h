@@ -145,6 +145,7 @@ struct same_section {
     double *xy = nullptr;     // [n][2]
     void *xy_c = nullptr;     // [n][2] in the cost type (== xy for fp64 costs)
     void *types_c = nullptr;  // [n][T] in the cost type
+    double *types64 = nullptr; // [n][T] as the caller gave them (== types_c for fp64 costs): what the result table's type columns are read from
     double *size = nullptr;   // [n]
     int32_t *type_id = nullptr;  // [n] codes of the cell type (equal type <=> equal code), or none
     int32_t *id_codes = nullptr; // [n] rank of the row's cell id among the frame's ids (same_section_set_codes), or none: a row's code is its number

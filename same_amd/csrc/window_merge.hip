@@ -39,6 +39,7 @@ struct same_merge_acc {
     int64_t n_codes_a = 0;
     int64_t n_rows = 0, n_kept = 0, n_rest = 0, n_final = 0;
     int resolved = 0;
+    int final_on_host = 0;                    // the final records have been copied to `host` (same_merge_acc_fetch does it on demand)
     int loaded = 0;                           // the rows came from the host (same_merge_acc_load): their "section rows" ARE the codes
     int64_t loaded_codes_a = 0, loaded_codes_r = 0;
     std::vector<char> host;                   // what the last resolve / finish brought back (fetched by same_merge_acc_fetch)
@@ -233,6 +234,40 @@ __global__ __launch_bounds__(scan::NT) void final_kernel(const int32_t *__restri
         out[off.a] = FinalRec{acc.a_row[row], acc.r_row[row], acc.cidx[row], acc.wid[row], acc.pos[row], acc.flags[row] & 3u};
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_total = through.a;
+}
+
+// The merged table's columns, column by column into host memory the device can write.  One thread per row; a column's writes are
+// consecutive.  8-byte columns first: T type columns of the moving section, its X and Y, the reference section's X and Y, then the
+// caller's extra 8-byte columns of the moving rows and of the reference rows (ids, sizes: copied as bit patterns, whatever their
+// type), the cell's index in its window and the window id as int64; then two byte columns: the area-flip flag and the XY-order flag.
+constexpr int MAX_EXTRA_COLUMNS = 4;
+struct ExtraColumns {
+    const unsigned long long *mov[MAX_EXTRA_COLUMNS], *ref[MAX_EXTRA_COLUMNS];
+    int n_mov, n_ref;
+};
+__global__ __launch_bounds__(256) void table_columns_kernel(const FinalRec *__restrict__ rows, int64_t n, const double *__restrict__ mov_types, int T,
+                                                            const double *__restrict__ mov_xy, const double *__restrict__ ref_xy, ExtraColumns ex,
+                                                            unsigned long long *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FinalRec rec = rows[i];
+    const int64_t a = rec.a_row, r = rec.r_row;
+    const unsigned long long *__restrict__ t = reinterpret_cast<const unsigned long long *>(mov_types) + a * T;
+    int64_t col = 0;
+    for (int q = 0; q < T; ++q) out[(col++) * n + i] = t[q];
+    const unsigned long long *pa = reinterpret_cast<const unsigned long long *>(mov_xy) + 2 * a,
+                             *pr = reinterpret_cast<const unsigned long long *>(ref_xy) + 2 * r;
+    out[(col++) * n + i] = pa[0];
+    out[(col++) * n + i] = pa[1];
+    out[(col++) * n + i] = pr[0];
+    out[(col++) * n + i] = pr[1];
+    for (int q = 0; q < ex.n_mov; ++q) out[(col++) * n + i] = ex.mov[q][a];
+    for (int q = 0; q < ex.n_ref; ++q) out[(col++) * n + i] = ex.ref[q][r];
+    out[(col++) * n + i] = (unsigned long long)(long long)rec.cidx;
+    out[(col++) * n + i] = (unsigned long long)(long long)rec.wid;
+    uint8_t *bytes = reinterpret_cast<uint8_t *>(out + col * n);
+    bytes[i] = (uint8_t)((rec.flags >> 1) & 1u);
+    bytes[n + i] = (uint8_t)(rec.flags & 1u);
 }
 
 AccRows rows_of(const same_merge_acc *a) { return AccRows{a->a_row, a->r_row, a->wid, a->pos, a->cidx, a->flags}; }
@@ -555,14 +590,59 @@ int same_merge_acc_finish(same_merge_acc *a, const int32_t *winner_rows, int64_t
     SAME_COPY(ctx, &total, counters + 2, sizeof total, hipMemcpyDeviceToHost);
     SAME_WAIT(ctx);
     REQUIRE(ctx, (int64_t)total <= a->n_kept);
-    a->n_final = (int64_t)total;
-    a->host.resize((size_t)total * sizeof(FinalRec) + 64);
-    if (total) {
-        SAME_COPY(ctx, a->host.data(), fin, (size_t)total * sizeof(FinalRec), hipMemcpyDeviceToHost);
-        SAME_WAIT(ctx);
-    }
+    a->n_final = (int64_t)total;          // the records stay on the device until somebody asks for them (same_merge_acc_fetch, ..._columns)
+    a->final_on_host = 0;
     a->resolved = 2;
     *out_n_final = a->n_final;
+    return SAME_OK;
+}
+
+int same_merge_acc_columns(same_merge_acc *a, const same_section *mov, const same_section *ref, const void *const *extra_mov, int n_extra_mov,
+                           const void *const *extra_ref, int n_extra_ref, void *out_host, int64_t n_final) {
+    if (!a) return SAME_EINVAL;
+    same_ctx *ctx = a->ctx;
+    REQUIRE(ctx, a->resolved == 2 && !a->loaded && mov && ref && n_final == a->n_final && (n_final == 0 || out_host));
+    REQUIRE(ctx, mov->ctx->device == ctx->device && ref->ctx->device == ctx->device && (mov->T == 0 || mov->types64));
+    REQUIRE(ctx, n_extra_mov >= 0 && n_extra_mov <= MAX_EXTRA_COLUMNS && n_extra_ref >= 0 && n_extra_ref <= MAX_EXTRA_COLUMNS);
+    REQUIRE(ctx, (n_extra_mov == 0 || extra_mov) && (n_extra_ref == 0 || extra_ref));
+    if (n_final == 0) return SAME_OK;
+    SAME_TRY(same_use(ctx));
+    void *dev = nullptr;                          // the block as the device addresses it (it must come from same_host_alloc)
+    if (hipHostGetDevicePointer(&dev, out_host, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        ctx->err = "same_merge_acc_columns: the output block is not host memory the device can write (same_host_alloc)";
+        return SAME_EINVAL;
+    }
+    ExtraColumns ex{};
+    ex.n_mov = n_extra_mov;
+    ex.n_ref = n_extra_ref;
+    for (int q = 0; q < n_extra_mov; ++q) {
+        REQUIRE(ctx, extra_mov[q]);
+        ex.mov[q] = static_cast<const unsigned long long *>(extra_mov[q]);
+    }
+    for (int q = 0; q < n_extra_ref; ++q) {
+        REQUIRE(ctx, extra_ref[q]);
+        ex.ref[q] = static_cast<const unsigned long long *>(extra_ref[q]);
+    }
+    SAME_LAUNCH(ctx, table_columns_kernel, dim3(grid_for(n_final)), dim3(256), 0, static_cast<const FinalRec *>(a->out.p), n_final, mov->types64, mov->T,
+                mov->xy, ref->xy, ex, static_cast<unsigned long long *>(dev));
+    HIP_TRY(ctx, hipGetLastError());
+    return SAME_OK;
+}
+
+int same_host_alloc(same_ctx *ctx, size_t bytes, void **out_ptr) {
+    REQUIRE(ctx, ctx && out_ptr && bytes > 0);
+    *out_ptr = nullptr;
+    SAME_TRY(same_use(ctx));
+    HIP_TRY(ctx, hipHostMalloc(out_ptr, bytes, hipHostMallocDefault));
+    return SAME_OK;
+}
+
+int same_host_free(same_ctx *ctx, void *ptr) {
+    REQUIRE(ctx, ctx != nullptr);
+    if (!ptr) return SAME_OK;
+    SAME_TRY(same_use(ctx));
+    HIP_TRY(ctx, hipHostFree(ptr));
     return SAME_OK;
 }
 
@@ -577,6 +657,13 @@ int same_merge_acc_fetch(same_merge_acc *a, int what, void *out, int64_t bytes) 
     } else if (what == SAME_MERGE_FINAL) {
         REQUIRE(ctx, a->resolved == 2);
         want = a->n_final * (int64_t)sizeof(FinalRec);
+        if (bytes == want && want && !a->final_on_host) {
+            SAME_TRY(same_use(ctx));
+            a->host.resize((size_t)want + 64);
+            SAME_COPY(ctx, a->host.data(), a->out.p, (size_t)want, hipMemcpyDeviceToHost);
+            SAME_WAIT(ctx);
+            a->final_on_host = 1;
+        }
     } else {
         REQUIRE(ctx, !"unknown same_merge_acc_fetch selector");
     }

@@ -24,6 +24,7 @@ Two routes produce the same table (tests/test_gpu_run_same.py::test_incumbent_ta
            host-buffer entry points: caller-supplied triangulations (MetaCell inputs), the cell-type-priority filter, inputs the
            sections cannot hold.
 """
+import os
 import threading
 
 import numpy as np
@@ -105,29 +106,37 @@ class _TableBuilder:
         return me.gather(cat(2, np.int64), cat(3, np.int64), cat(4, np.int64), cat(5, np.int64) if me.with_ref_idx else None, cat(7, bool),
                          cat(6, bool), spread([p[1] for p in parts]), spread([p[0] for p in parts]) if with_pos else None)
 
-    def gather(self, ra, rr, aligned_idx, ref_idx, triangle_violation, filtered_violation, window_id, plan_pos=None):
+    def gather(self, ra, rr, aligned_idx, ref_idx, triangle_violation, filtered_violation, window_id, plan_pos=None, only=None):
         """The result table of matched cells (moving section rows `ra` -> reference section rows `rr`): the columns of
-        src/same.py:1264-1278, :1464-1470, gathered from the caller's frames slice by slice on the gather threads."""
+        src/same.py:1264-1278, :1464-1470, gathered from the caller's frames slice by slice on the gather threads.
+        only: gather just these table columns (-> dict of arrays): the ones the device-side gather of `table_from_device` does not cover."""
         from concurrent.futures import ThreadPoolExecutor
 
         from .merge import GATHER_THREADS
 
         me, n = self, len(ra)
+        want = (lambda name: True) if only is None else (lambda name: name in only)
         out = {"aligned_idx": aligned_idx}
         if ref_idx is not None:
             out["ref_idx"] = ref_idx
         new = lambda like: np.empty(n, like.dtype)
+        types_wanted = any(want(ct) for ct in me.cts)
+        xy_wanted = any(want(k) for k in ("X", "Y", "ref_X", "ref_Y"))
         for ct, src in zip(me.cts, me.type_cols if me.type_block is None else [me.type_block] * len(me.cts)):
-            out[ct] = new(src)
-        if me.mov_xy is not None:
+            out[ct] = new(src) if types_wanted else None
+        if not xy_wanted:
+            for k in ("X", "Y", "ref_X", "ref_Y"):
+                out[k] = None
+        elif me.mov_xy is not None:
             for k in ("X", "Y", "ref_X", "ref_Y"):
                 out[k] = np.empty(n, np.float64)
         else:
             (mx, my), (rx, ry) = me.xy_cols
             out["X"], out["Y"], out["ref_X"], out["ref_Y"] = new(mx), new(my), new(rx), new(ry)
-        out["size"] = new(me.mov_size) if me.mov_size is not None else np.ones(n, np.int64)
-        out["ref_size"] = new(me.ref_size) if me.ref_size is not None else np.ones(n, np.int64)
-        out[f"Ref_{me.cid}"], out[f"Aligned_{me.cid}"] = new(me.ref_id), new(me.mov_id)
+        cid_r, cid_a = f"Ref_{me.cid}", f"Aligned_{me.cid}"
+        out["size"] = (new(me.mov_size) if me.mov_size is not None else np.ones(n, np.int64)) if want("size") else None
+        out["ref_size"] = (new(me.ref_size) if me.ref_size is not None else np.ones(n, np.int64)) if want("ref_size") else None
+        out[cid_r], out[cid_a] = new(me.ref_id) if want(cid_r) else None, new(me.mov_id) if want(cid_a) else None
         out["time_limit_reached"] = np.zeros(n, bool)
         out["triangle_violation"] = triangle_violation
         out["filtered_violation"] = filtered_violation
@@ -140,33 +149,79 @@ class _TableBuilder:
             hi = min(n, lo + _TableBuilder.SLICE)
             a, r = ra[lo:hi], rr[lo:hi]
             take = np.take           # np.take(src, rows, axis=0) copies whole rows: 3-6x the speed of src[rows] on the (n, 8) / (n, 2) blocks
-            if me.type_block is not None:
+            if not types_wanted:
+                pass
+            elif me.type_block is not None:
                 block = take(me.type_block, a, axis=0)       # (rows, T): the commonCT columns in commonCT order
                 for q, ct in enumerate(me.cts):
                     out[ct][lo:hi] = block[:, q]
             else:
                 for ct, col in zip(me.cts, me.type_cols):
                     take(col, a, out=out[ct][lo:hi], mode="clip")       # (rows are valid: "clip" only spares numpy its bounce buffer)
-            if me.mov_xy is not None:
+            if not xy_wanted:
+                pass
+            elif me.mov_xy is not None:
                 axy, rxy = take(me.mov_xy, a, axis=0), take(me.ref_xy, r, axis=0)
                 out["X"][lo:hi], out["Y"][lo:hi], out["ref_X"][lo:hi], out["ref_Y"][lo:hi] = axy[:, 0], axy[:, 1], rxy[:, 0], rxy[:, 1]
             else:
                 (mx, my), (rx, ry) = me.xy_cols
                 for k, col, rows in (("X", mx, a), ("Y", my, a), ("ref_X", rx, r), ("ref_Y", ry, r)):
                     take(col, rows, out=out[k][lo:hi], mode="clip")
-            if me.mov_size is not None:
+            if me.mov_size is not None and want("size"):
                 take(me.mov_size, a, out=out["size"][lo:hi], mode="clip")
-            if me.ref_size is not None:
+            if me.ref_size is not None and want("ref_size"):
                 take(me.ref_size, r, out=out["ref_size"][lo:hi], mode="clip")
-            take(me.ref_id, r, out=out[f"Ref_{me.cid}"][lo:hi], mode="clip")
-            take(me.mov_id, a, out=out[f"Aligned_{me.cid}"][lo:hi], mode="clip")
+            if want(cid_r):
+                take(me.ref_id, r, out=out[cid_r][lo:hi], mode="clip")
+            if want(cid_a):
+                take(me.mov_id, a, out=out[cid_a][lo:hi], mode="clip")
 
+        gathers_any = types_wanted or xy_wanted or any(want(k) and src is not None for k, src in
+                                                        (("size", me.mov_size), ("ref_size", me.ref_size), (cid_r, me.ref_id), (cid_a, me.mov_id)))
         starts = range(0, n, _TableBuilder.SLICE)
-        if len(starts) == 1:
+        if not gathers_any:
+            pass
+        elif len(starts) == 1:
             fill(0)
         else:
             with ThreadPoolExecutor(max_workers=GATHER_THREADS) as pool:
                 list(pool.map(fill, starts))
+        return pd.DataFrame(out, copy=False) if only is None else out
+
+    def device_columns_possible(self):
+        """the frame's type columns and coordinates are float64 and the type columns distinct: the sections hold exactly their values"""
+        return self.type_block is not None and self.mov_xy is not None
+
+    def table_from_device(self, frames, acc):
+        """The merged table with its columns gathered where the sections are: the DEVICE writes the type columns, X, Y, ref_X, ref_Y, the
+        8-byte id / size columns of the frames, aligned_idx, window_id and the two flag columns of the final rows straight into a pooled
+        page-locked host block (MergeAccumulator.columns); the table's arrays are views of it.  Columns the device cannot hold (ids that
+        are strings ...) are gathered by the host meanwhile.  None: no block to be had -- the caller gathers on the host."""
+        n = acc.n_final
+        extra = frames.table_columns(self.cid)
+        got = acc.columns(frames.dmov, frames.dref, n, len(self.cts), [b for _n, b, _d in extra["mov"]], [b for _n, b, _d in extra["ref"]])
+        if got is None:
+            return None
+        wide, flags = got
+        names = list(self.cts) + ["X", "Y", "ref_X", "ref_Y"] + [nm for nm, _b, _d in extra["mov"] + extra["ref"]] + ["aligned_idx", "window_id"]
+        dtypes = [np.float64] * (len(self.cts) + 4) + [d for _n, _b, d in extra["mov"] + extra["ref"]] + [np.int64, np.int64]
+        cid_r, cid_a = f"Ref_{self.cid}", f"Aligned_{self.cid}"
+        missing = [k for k in ("size", "ref_size", cid_r, cid_a) if k not in names]
+        host = {}
+        if missing:            # beside the device's gather (which was only enqueued)
+            final = acc.final_rows()
+            host = self.gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), None, None, None, None, None, only=set(missing))
+        with stage("table: wait for the device's columns"):
+            acc.ctx.sync()
+        dev = {nm: wide[q].view(dt) for q, (nm, dt) in enumerate(zip(names, dtypes))}
+        col = lambda k: dev[k] if k in dev else host[k]
+        out = {"aligned_idx": dev["aligned_idx"]}
+        for k in list(self.cts) + ["X", "Y", "ref_X", "ref_Y", "size", "ref_size", cid_r, cid_a]:
+            out[k] = col(k)
+        out["time_limit_reached"] = np.zeros(n, bool)
+        out["triangle_violation"], out["filtered_violation"] = flags[0].view(bool), flags[1].view(bool)
+        out["run_time"] = np.zeros(n)
+        out["window_id"] = dev["window_id"]
         return pd.DataFrame(out, copy=False)
 
 
@@ -390,11 +445,19 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
         if errors:
             raise errors[0]
     if accs is not None:
-        final = _merge_on_device(job, frames, accs, channel)
+        done = _merge_on_device(job, frames, accs, channel)
         with stage("table (columns gathered on the gather threads)"):
+            if not done.n_final:
+                return pd.DataFrame()
+            me = builders[0]
+            if me.device_columns_possible() and os.environ.get("SAME_TABLE_COLUMNS", "device") != "host":
+                table = me.table_from_device(frames, done)           # the columns gathered on the device, into page-locked memory
+                if table is not None:
+                    return table
+            final = done.final_rows()
             flags = final["flags"]
-            return builders[0].gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), final["cidx"].astype(np.int64), None,
-                                      (flags & 2) != 0, (flags & 1) != 0, final["wid"].astype(np.int64)) if len(final) else pd.DataFrame()
+            return me.gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), final["cidx"].astype(np.int64), None,
+                             (flags & 2) != 0, (flags & 1) != 0, final["wid"].astype(np.int64))
     select = _merged_rows(job, frames, builders, channel) if merge else None
     with stage("table (columns gathered on the gather threads)"):
         table = _TableBuilder.table(builders, select, plan_pos=False if merge else None)
@@ -437,7 +500,7 @@ def _count_merge_calls(frames, ctx0, calls0, passes=1):
 def _merge_on_device(job, frames, accs, channel):
     """The window merge of the accumulated rows (src/helpers.py:692-815): codes, de-duplication, degrees and the rows that stand alone
     on the device; components / Hopcroft-Karp of the contested cells, and the seam rows' exchange between ranks, here.
-    -> the merged table's rows (windows.FINAL_RECORD), aligned ids ascending."""
+    -> the accumulator that holds the merged table's rows (aligned ids ascending; `.n_final`, `.final_rows()`)."""
     from . import merge as M
     from .windows import resolve_accumulators
 
@@ -457,10 +520,10 @@ def _merge_on_device(job, frames, accs, channel):
             parts = channel.tables(sent)
         with stage("merge: seam step (the same on every rank)"):
             rows = np.concatenate((mine, _seam_step_on_device(frames, ctx0, parts, channel.rank)))
-    with stage("merge: winners to the device, final rows back"):
-        final = accs[0].finish(rest["row"][rows])
+    with stage("merge: winners to the device, final rows in order"):
+        accs[0].finish(rest["row"][rows], fetch=False)          # the rows stay on the device: the table's columns are gathered from them there
     _count_merge_calls(frames, ctx0, calls0)
-    return final
+    return accs[0]
 
 
 def _seam_step_on_device(frames, ctx, parts, rank):

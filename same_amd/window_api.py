@@ -174,6 +174,23 @@ class _DeviceFrames:
             known[cid] = ((mc, rc), mu and ru)
         return known[cid]
 
+    def table_columns(self, cid):
+        """The frames' columns that are 8-byte numbers and go into the result table besides the sections' own (sizes, cell ids), resident on
+        the device for the device-side gather of the merged table (MergeAccumulator.columns): -> {"mov": [(table column, DeviceBuffer,
+        dtype)], "ref": [...]}; columns of other types are gathered by the host.  Uploaded once per frames and id column."""
+        known = self.__dict__.setdefault("_table_columns", {})
+        if cid not in known:
+            def eligible(df, names):
+                out = []
+                for column, name in names:
+                    if column in df.columns and isinstance(df[column].dtype, np.dtype) and df[column].dtype.kind in "iuf" and df[column].dtype.itemsize == 8:
+                        host = np.ascontiguousarray(df[column].to_numpy())
+                        out.append((name, self.ctx.to_device(host.view(np.uint64)), host.dtype))
+                return out
+            known[cid] = {"mov": eligible(self.moving, (("size", "size"), (cid, f"Aligned_{cid}"))),
+                          "ref": eligible(self.ref, (("size", "ref_size"), (cid, f"Ref_{cid}")))}
+        return known[cid]
+
     def worker_contexts(self, n):
         """n contexts on the sections' device for n worker threads: this object's own first, then extra ones that live (with the window
         states they have grown) until close()."""
@@ -186,6 +203,9 @@ class _DeviceFrames:
     def close(self):
         for acc in self.__dict__.pop("_accs", {}).values():
             acc.close()
+        for held in self.__dict__.pop("_table_columns", {}).values():
+            for _name, buf, _dt in held["mov"] + held["ref"]:
+                buf.free()
         for c in self._worker_ctx:
             c.close()
         self._worker_ctx = []

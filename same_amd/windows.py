@@ -470,6 +470,70 @@ REST_RECORD = np.dtype([("row", "<i4"), ("ac", "<i4"), ("rc", "<i4"), ("wid", "<
 FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("flags", "<u4")])             # SAME_MERGE_FINAL
 
 
+class _PinnedBlocks:
+    """Page-locked host blocks the device writes the merged table's float columns into (same_host_alloc), handed out as numpy arrays.
+    A block goes back to the pool when the last array made of it is gone (a result table is usually dropped before the next pass: the
+    pool then serves every pass from the same block, and no pass pays the pinning again); at most KEEP blocks wait in the pool, and while
+    more than LIMIT are out with callers (tables kept alive) `take` declines -- the caller then gathers on the host as before."""
+
+    KEEP, LIMIT = 2, 4
+
+    def __init__(self):
+        import threading
+
+        self.free, self.out, self.lock = [], 0, threading.Lock()
+
+    def take(self, ctx, nbytes):
+        """-> (ctypes char array over a pinned block of >= nbytes, address) or None"""
+        import ctypes
+        import weakref
+
+        with self.lock:
+            if self.out >= self.LIMIT:
+                return None
+            fit = [q for q, (c, cap, _p) in enumerate(self.free) if c is ctx and cap >= nbytes]
+            if fit:
+                _c, cap, ptr = self.free.pop(min(fit, key=lambda q: self.free[q][1]))
+            else:
+                cap, ptr = (int(nbytes * 1.1) + (1 << 20)) & ~((1 << 20) - 1), ctypes.c_void_p()
+                with ctx.lock:
+                    if ctx.lib.same_host_alloc(ctx.handle, cap, ctypes.byref(ptr)) != 0:
+                        return None
+                ptr = ptr.value
+            self.out += 1
+        buf = (ctypes.c_char * cap).from_address(ptr)
+        weakref.finalize(buf, self._back, ctx, cap, ptr)          # when the last array over `buf` is gone
+        return buf, ptr
+
+    def _back(self, ctx, cap, ptr):
+        with self.lock:
+            self.out -= 1
+            if len(self.free) < self.KEEP and ctx.handle:
+                self.free.append((ctx, cap, ptr))
+                return
+        self._release(ctx, ptr)
+
+    @staticmethod
+    def _release(ctx, ptr):
+        try:
+            if ctx.handle:
+                with ctx.lock:
+                    ctx.lib.same_host_free(ctx.handle, ptr)
+        except Exception:
+            pass
+
+    def drop(self, ctx=None):
+        """free the waiting blocks (of one context, or all)"""
+        with self.lock:
+            gone = [e for e in self.free if ctx is None or e[0] is ctx]
+            self.free = [e for e in self.free if e not in gone]
+        for c, _cap, ptr in gone:
+            self._release(c, ptr)
+
+
+PINNED_BLOCKS = _PinnedBlocks()
+
+
 class MergeAccumulator:
     """The rows of one pass over a window plan on one context (same_merge_acc, csrc/window_merge.hip): `collect` appends the matched cells
     of the windows' central regions where they are -- on the device --, `resolve_accumulators` / `finish` run the window merge on them."""
@@ -519,8 +583,9 @@ class MergeAccumulator:
             ctx.check(ctx.lib.same_merge_acc_load(self.handle, a.ctypes.data, r.ctypes.data, f.ctypes.data, w.ctypes.data, p.ctypes.data, c.ctypes.data,
                                                   len(a), int(n_codes_a), int(n_codes_r)), "same_merge_acc_load")
 
-    def finish(self, winner_rows):
-        """The REST rows the host's matching kept (accumulator row numbers) -> the merged table's rows as FINAL_RECORDs, aligned codes ascending."""
+    def finish(self, winner_rows, fetch=True):
+        """The REST rows the host's matching kept (accumulator row numbers) -> the merged table's rows, aligned codes ascending: as
+        FINAL_RECORDs, or (fetch=False) only their number -- they stay on the device for `columns`; `final_rows()` fetches them later."""
         import ctypes
 
         ctx = self.ctx
@@ -528,9 +593,37 @@ class MergeAccumulator:
         n = ctypes.c_int64(0)
         with ctx.lock:
             ctx.check(ctx.lib.same_merge_acc_finish(self.handle, w.ctypes.data if len(w) else None, len(w), ctypes.byref(n)), "same_merge_acc_finish")
-            out = np.empty(n.value, FINAL_RECORD)
-            ctx.check(ctx.lib.same_merge_acc_fetch(self.handle, 1, out.ctypes.data, out.nbytes), "same_merge_acc_fetch")
+        self.n_final = n.value
+        return self.final_rows() if fetch else self.n_final
+
+    def final_rows(self):
+        out = np.empty(self.n_final, FINAL_RECORD)
+        with self.ctx.lock:
+            self.ctx.check(self.ctx.lib.same_merge_acc_fetch(self.handle, 1, out.ctypes.data, out.nbytes), "same_merge_acc_fetch")
         return out
+
+    def columns(self, dmoving, dref, n_final, n_types, extra_moving=(), extra_ref=()):
+        """After finish(): the merged table's columns written by the device straight into page-locked host memory (enqueue only:
+        `ctx.sync()` before reading): the moving section's type columns, X, Y, the reference's X, Y, the caller's extra 8-byte device
+        columns (DeviceBuffers of 8-byte values per moving / reference row: ids, sizes), aligned_idx and window_id as int64, and the two
+        flag columns.  -> (uint64 array (n_types + 4 + extras + 2, n_final), uint8 array (2, n_final)) over a pooled block, or None when no
+        block is to be had (the caller gathers on the host)."""
+        import ctypes
+
+        n8 = n_types + 4 + len(extra_moving) + len(extra_ref) + 2
+        got = PINNED_BLOCKS.take(self.ctx, max(1, n8 * 8 * n_final + 2 * n_final)) if n_final else None
+        if got is None:
+            return None
+        buf, ptr = got
+        ctx = self.ctx
+        em = (ctypes.c_void_p * max(1, len(extra_moving)))(*[b.ptr for b in extra_moving])
+        er = (ctypes.c_void_p * max(1, len(extra_ref)))(*[b.ptr for b in extra_ref])
+        with ctx.lock:
+            ctx.check(ctx.lib.same_merge_acc_columns(self.handle, dmoving.handle, dref.handle, em, len(extra_moving), er, len(extra_ref), ptr,
+                                                     int(n_final)), "same_merge_acc_columns")
+        wide = np.frombuffer(buf, dtype=np.uint64, count=n8 * n_final).reshape(n8, n_final)
+        flags = np.frombuffer(buf, dtype=np.uint8, count=2 * n_final, offset=n8 * 8 * n_final).reshape(2, n_final)
+        return wide, flags
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:

@@ -126,3 +126,43 @@ def test_accumulator_grows_and_is_reused(oracle):
     with pytest.raises(Exception, match="aligned codes"):
         acc.load(np.array([5]), np.array([0]), np.zeros(1, np.uint8), np.zeros(1), np.zeros(1), np.zeros(1), 3, 3)
     acc.close()
+
+
+def test_table_columns_from_the_device_equal_the_host_gather(monkeypatch):
+    """merge=True on the device route: the merged table's float64 columns (types, X, Y, ref_X, ref_Y) are written by the device into
+    page-locked host memory while the host gathers the rest -- the table is the one the host's own gather makes (SAME_TABLE_COLUMNS=host),
+    bit for bit, also when the pool's blocks are re-used and when callers keep more tables alive than the pool hands out."""
+    import gc
+
+    import same_amd
+    from same_amd import synth
+    from same_amd.windows import PINNED_BLOCKS
+
+    cells = synth.make_cells(60_000, 5, seed=8)
+    r_df = synth.to_frame(cells)
+    m_df = synth.to_frame(synth.make_jittered(cells, seed=9))
+    cols = synth.type_columns(5)
+    op = dict(radius=25, knn=6, window_size=600, overlap=150, min_cells_per_window=20, hip_cost_dtype="float32")
+    with same_amd.resident_frames(r_df, m_df) as res:
+        call = lambda: same_amd.sliding_window_incumbent(res, res, commonCT=cols, optim_params=dict(op), merge=True, workers=2)
+        monkeypatch.setenv("SAME_TABLE_COLUMNS", "host")
+        want = call()
+        monkeypatch.delenv("SAME_TABLE_COLUMNS")
+        assert len(want) > 40_000 and PINNED_BLOCKS.out == 0
+        kept = []
+        for rep in range(PINNED_BLOCKS.LIMIT + 2):          # the first LIMIT tables hold a block each; then the host gathers
+            got = call()
+            assert list(got.columns) == list(want.columns) and got.equals(want), rep
+            assert all(got[c].dtype == want[c].dtype for c in want.columns)
+            kept.append(got)
+        assert PINNED_BLOCKS.out == PINNED_BLOCKS.LIMIT
+        first = kept[0]["X"].to_numpy().copy()
+        del kept[1:], got
+        gc.collect()
+        assert PINNED_BLOCKS.out == 1 and len(PINNED_BLOCKS.free) == PINNED_BLOCKS.KEEP
+        again = call()                                        # a re-used block: the table kept alive is not written over
+        assert again.equals(want) and np.array_equal(kept[0]["X"].to_numpy(), first)
+        assert same_amd.merge_window_matches_unique_ref([same_amd.sliding_window_incumbent(res, res, commonCT=cols, optim_params=dict(op))]).equals(want)
+    del kept, again
+    gc.collect()
+    assert PINNED_BLOCKS.out == 0
