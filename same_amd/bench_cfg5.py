@@ -111,13 +111,20 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
 
     # warm-up: scratch slots, Qhull helpers, first-launch costs -- and, on the device path, every window state a worker keeps
     # in flight gets its buffers (they stay with the context afterwards: the timed passes allocate nothing)
-    for _ in range(min(warmup, 1)):     # one whole pass: the sections go up and are binned, the plan and the type sets are remembered,
-        all_ranks(one_pass)             # every window state a worker keeps in flight gets its buffers (they stay with the contexts)
+    if warmup >= 1:
+        # one whole pass: the sections go up and are binned, the plan and the type sets are remembered, every window state a worker keeps
+        # in flight gets its buffers (they stay with the contexts), the accumulators their arrays -- and a second one while the first one's
+        # table is still alive, as a caller's loop has it: the table's columns live in page-locked blocks (windows.PINNED_BLOCKS), two of
+        # which alternate in steady state, and pinning 140 MB costs ~35 ms once
+        first = all_ranks(one_pass)
+        second = all_ranks(one_pass)
+        del first, second
     group.barrier()
     _trace.reset()
     calls0 = [c.stats() for c in worker_ctx]
     merge_calls = lambda: dict(next(iter(resident._frames.values())).__dict__.get("merge_runtime_calls", {})) if on_device else {}
     merge_calls0 = merge_calls()
+    seam0 = (channel.sent_rows, channel.gather_ms) if channel is not None else (0, 0.0)
     t0 = time.perf_counter()
     merged = stats = None
     for _ in range(steps):
@@ -125,6 +132,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     group.barrier()
     wall_here = time.perf_counter() - t0
     calls1 = [c.stats() for c in worker_ctx]
+    seam1 = (channel.sent_rows, channel.gather_ms) if channel is not None else (0, 0.0)
     # the calls counted are those of `ctx`: worker 0's windows (the first of n_workers contiguous runs of this rank's share) + the merge's de-duplication
     n_done = max(1, (len(stats) // n_workers) * steps)
     # ... without what the merge itself asked for, which is per PASS, not per window (resolve + finish: a sort's worth of launches)
@@ -195,8 +203,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                 "merge_stages_s_per_step": {name: sec / steps for name, (_c, sec) in sorted(rep.items()) if name.startswith("merge:")},
                 "windows_per_s_triangulations_given": no_qhull, "windows_per_s_triangulations_given_merged": no_qhull_merged,
                 "window_calls_only_windows_per_s": calls_only, "merged_rows": int(len(merged)),
-                "seam_rows_sent_per_step": None if channel is None else channel.sent_rows / max(1, steps + min(warmup, 1) + (2 if on_device else 0)),
-                "seam_gather_ms": None if channel is None else channel.gather_ms / max(1, steps + min(warmup, 1) + (2 if on_device else 0)),
+                "seam_rows_sent_per_step": None if channel is None else (seam1[0] - seam0[0]) / steps,
+                "seam_gather_ms": None if channel is None else (seam1[1] - seam0[1]) / steps,
                 "runtime_calls_per_window": calls_per_window, "runtime_calls_per_pass_merge": per_pass,
                 "qhull_helpers": _qp.pool().n, "qhull_domains": len(_qp.pool().domains), "local_world": _qp.local_world()[0],
                 "cells": int(sum(w["n_mov"] for w in my_plan)), "pairs": int(sum(s["pairs"] for s in stats)),

@@ -198,8 +198,9 @@ class _TableBuilder:
         page-locked host block (MergeAccumulator.columns); the table's arrays are views of it.  Columns the device cannot hold (ids that
         are strings ...) are gathered by the host meanwhile.  None: no block to be had -- the caller gathers on the host."""
         n = acc.n_final
-        extra = frames.table_columns(self.cid)
-        got = acc.columns(frames.dmov, frames.dref, n, len(self.cts), [b for _n, b, _d in extra["mov"]], [b for _n, b, _d in extra["ref"]])
+        with stage("table: page-locked block + the device's gather enqueued"):
+            extra = frames.table_columns(self.cid)
+            got = acc.columns(frames.dmov, frames.dref, n, len(self.cts), [b for _n, b, _d in extra["mov"]], [b for _n, b, _d in extra["ref"]])
         if got is None:
             return None
         wide, flags = got
@@ -213,6 +214,11 @@ class _TableBuilder:
             host = self.gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), None, None, None, None, None, only=set(missing))
         with stage("table: wait for the device's columns"):
             acc.ctx.sync()
+        with stage("table: the frame over the block"):
+            return self._frame_over(wide, flags, names, dtypes, host, n)
+
+    def _frame_over(self, wide, flags, names, dtypes, host, n):
+        cid_r, cid_a = f"Ref_{self.cid}", f"Aligned_{self.cid}"
         dev = {nm: wide[q].view(dt) for q, (nm, dt) in enumerate(zip(names, dtypes))}
         col = lambda k: dev[k] if k in dev else host[k]
         out = {"aligned_idx": dev["aligned_idx"]}

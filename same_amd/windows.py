@@ -5,6 +5,8 @@ Windows are the shard unit for very large sections (BASELINE config 5).  Cell co
 box the merge logic can ask about (base, right-merged, down-merged, both) come from one
 batched device pass (csrc/sweep.hip window_count_kernel) instead of one pandas boolean mask
 per window; the sequential walk that decides merges is then pure host lookups."""
+import os
+
 import numpy as np
 
 from . import ops
