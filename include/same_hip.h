@@ -470,15 +470,18 @@ int same_merge_acc_load(same_merge_acc *acc, const int32_t *a_code, const int32_
 int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_section *moving /* NULL after ..._load */,
                            const same_section *ref /* NULL after ..._load */, int64_t *out_counts /* [4] */);
 int same_merge_acc_finish(same_merge_acc *acc, const int32_t *winner_rows, int64_t n_winners, int64_t *out_n_final);
+/* Without the merge: every accumulated row is a final row, in the order the windows were collected (src/same.py:583-590: the window
+ * tables concatenated) -- for the same fetch / same_merge_acc_columns calls.  accs as for same_merge_acc_resolve. */
+int same_merge_acc_plain(same_merge_acc *const *accs, int n_accs, int64_t *out_n_rows);
 int same_merge_acc_fetch(same_merge_acc *acc, int what, void *out, int64_t bytes);
 /* The merged table's columns, written by the DEVICE (after same_merge_acc_finish; enqueue only -- same_ctx_sync waits) into out_host,
  * column after column, n_final entries each, in the order of the final rows:
  *   8-byte columns: the moving section's T type columns (src/same.py:1264-1278 copies them from aligned_df), its X and Y, the reference
  *   section's X and Y (ref_X, ref_Y); then n_extra_mov columns gathered by moving row and n_extra_ref columns gathered by reference row
  *   from the caller's DEVICE arrays of 8-byte values (cell ids, sizes: copied as bit patterns, whatever their type; at most 4 each); then
- *   aligned_idx (the cell's index among its window's kept cells) and window_id as int64;
+ *   aligned_idx (the cell's index among its window's kept cells), window_id and the window's plan position as int64;
  *   byte columns: triangle_violation (the area-flip flag, src/same.py:1464-1469) and the XY-order flag, 0 / 1.
- * out_host holds (T + 4 + n_extra_mov + n_extra_ref + 2) * 8 * n_final + 2 * n_final bytes and must be host memory the device can write:
+ * out_host holds (T + 4 + n_extra_mov + n_extra_ref + 3) * 8 * n_final + 2 * n_final bytes and must be host memory the device can write:
  * same_host_alloc (page-locked, hipHostMalloc; same_host_free returns it).  The float columns are the bytes the caller uploaded with
  * same_section_create. */
 int same_merge_acc_columns(same_merge_acc *acc, const same_section *moving, const same_section *ref, const void *const *extra_moving,

@@ -111,6 +111,7 @@ _PROTOTYPES = {
     "same_merge_acc_load": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64],
     "same_merge_acc_resolve": [c_vp, c_int, c_vp, c_vp, c_vp],
     "same_merge_acc_finish": [c_vp, c_vp, c_i64, ctypes.POINTER(c_i64)],
+    "same_merge_acc_plain": [c_vp, c_int, ctypes.POINTER(c_i64)],
     "same_merge_acc_fetch": [c_vp, c_int, c_vp, c_i64],
     "same_merge_acc_columns": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_i64],
     "same_host_alloc": [c_vp, c_sz, ctypes.POINTER(c_vp)],

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(scan::NT) void final_kernel(const int32_t *__restri
 // The merged table's columns, column by column into host memory the device can write.  One thread per row; a column's writes are
 // consecutive.  8-byte columns first: T type columns of the moving section, its X and Y, the reference section's X and Y, then the
 // caller's extra 8-byte columns of the moving rows and of the reference rows (ids, sizes: copied as bit patterns, whatever their
-// type), the cell's index in its window and the window id as int64; then two byte columns: the area-flip flag and the XY-order flag.
+// type), the cell's index in its window, the window id and its plan position as int64; then two byte columns: the area-flip flag and the
+// XY-order flag.
 constexpr int MAX_EXTRA_COLUMNS = 4;
 struct ExtraColumns {
     const unsigned long long *mov[MAX_EXTRA_COLUMNS], *ref[MAX_EXTRA_COLUMNS];
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void table_columns_kernel(const FinalRec *__re
     for (int q = 0; q < ex.n_ref; ++q) out[(col++) * n + i] = ex.ref[q][r];
     out[(col++) * n + i] = (unsigned long long)(long long)rec.cidx;
     out[(col++) * n + i] = (unsigned long long)(long long)rec.wid;
+    out[(col++) * n + i] = (unsigned long long)(long long)rec.pos;
     uint8_t *bytes = reinterpret_cast<uint8_t *>(out + col * n);
     bytes[i] = (uint8_t)((rec.flags >> 1) & 1u);
     bytes[n + i] = (uint8_t)(rec.flags & 1u);
@@ -312,6 +314,46 @@ int reserve_rows(same_merge_acc *a, int64_t need, int64_t have) {
     a->flags = new_flags;
     a->cap = cap;
     return SAME_OK;
+}
+
+// The accumulators of a pass laid end to end in accs[0] (the other contexts' collect calls only enqueued: their streams are waited for;
+// the worker threads walked consecutive runs of the plan, so the result is in plan order).  -> the number of rows.
+int lay_end_to_end(same_merge_acc *const *accs, int n_accs, int64_t *out_n) {
+    same_merge_acc *a = accs[0];
+    same_ctx *ctx = a->ctx;
+    std::vector<int64_t> have((size_t)n_accs, 0);
+    int64_t n = 0;
+    for (int q = 0; q < n_accs; ++q) {
+        unsigned long long c = 0;
+        HIP_TRY(ctx, hipStreamSynchronize(accs[q]->ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(&c, accs[q]->dcount, sizeof c, hipMemcpyDeviceToHost));
+        REQUIRE(ctx, (int64_t)c <= accs[q]->bound && (int64_t)c <= accs[q]->cap);
+        have[(size_t)q] = (int64_t)c;
+        n += (int64_t)c;
+    }
+    REQUIRE(ctx, n < ((int64_t)1 << 30));
+    if (n_accs > 1) {
+        SAME_TRY(reserve_rows(a, n, have[0]));
+        int64_t at = have[0];
+        for (int q = 1; q < n_accs; ++q) {
+            const same_merge_acc *o = accs[q];
+            const size_t m = (size_t)have[(size_t)q];
+            if (!m) continue;
+            int32_t *const dst[5] = {a->a_row, a->r_row, a->wid, a->pos, a->cidx};
+            const int32_t *const src[5] = {o->a_row, o->r_row, o->wid, o->pos, o->cidx};
+            for (int f = 0; f < 5; ++f) SAME_COPY(ctx, dst[f] + at, src[f], m * sizeof(int32_t), hipMemcpyDeviceToDevice);
+            SAME_COPY(ctx, a->flags + at, o->flags, m, hipMemcpyDeviceToDevice);
+            at += (int64_t)m;
+        }
+    }
+    *out_n = n;
+    return SAME_OK;
+}
+
+// every accumulated row as a final record, in the order it came (same_merge_acc_plain)
+__global__ __launch_bounds__(256) void plain_kernel(AccRows acc, int64_t n, FinalRec *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = FinalRec{acc.a_row[i], acc.r_row[i], acc.cidx[i], acc.wid[i], acc.pos[i], acc.flags[i] & 3u};
 }
 
 }  // namespace
@@ -480,33 +522,8 @@ int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_s
     }
     for (int q = 0; q < 4; ++q) out_counts[q] = 0;
     SAME_TRY(same_use(ctx));
-    // the other contexts' accumulators: their collect calls only enqueued -- wait for those streams, read the counts, lay the rows
-    // after this one's (the worker threads walked consecutive runs of the plan: the result is in plan order)
-    std::vector<int64_t> have((size_t)n_accs, 0);
     int64_t n = 0;
-    for (int q = 0; q < n_accs; ++q) {
-        unsigned long long c = 0;
-        HIP_TRY(ctx, hipStreamSynchronize(accs[q]->ctx->stream));
-        HIP_TRY(ctx, hipMemcpy(&c, accs[q]->dcount, sizeof c, hipMemcpyDeviceToHost));
-        REQUIRE(ctx, (int64_t)c <= accs[q]->bound && (int64_t)c <= accs[q]->cap);
-        have[(size_t)q] = (int64_t)c;
-        n += (int64_t)c;
-    }
-    REQUIRE(ctx, n < ((int64_t)1 << 30));
-    if (n_accs > 1) {
-        SAME_TRY(reserve_rows(a, n, have[0]));
-        int64_t at = have[0];
-        for (int q = 1; q < n_accs; ++q) {
-            const same_merge_acc *o = accs[q];
-            const size_t m = (size_t)have[(size_t)q];
-            if (!m) continue;
-            int32_t *const dst[5] = {a->a_row, a->r_row, a->wid, a->pos, a->cidx};
-            const int32_t *const src[5] = {o->a_row, o->r_row, o->wid, o->pos, o->cidx};
-            for (int f = 0; f < 5; ++f) SAME_COPY(ctx, dst[f] + at, src[f], m * sizeof(int32_t), hipMemcpyDeviceToDevice);
-            SAME_COPY(ctx, a->flags + at, o->flags, m, hipMemcpyDeviceToDevice);
-            at += (int64_t)m;
-        }
-    }
+    SAME_TRY(lay_end_to_end(accs, n_accs, &n));
     for (int q = 0; q < n_accs; ++q) accs[q]->resolved = 1;
     a->n_rows = n;
     a->n_codes_a = loaded ? a->loaded_codes_a : (mov->id_codes ? mov->n_codes : mov->n);
@@ -562,6 +579,30 @@ int same_merge_acc_resolve(same_merge_acc *const *accs, int n_accs, const same_s
     out_counts[1] = a->n_kept;
     out_counts[2] = a->n_rest;
     out_counts[3] = a->n_kept - a->n_rest;
+    return SAME_OK;
+}
+
+int same_merge_acc_plain(same_merge_acc *const *accs, int n_accs, int64_t *out_n_rows) {
+    if (!accs || n_accs < 1 || !accs[0]) return SAME_EINVAL;
+    same_merge_acc *a = accs[0];
+    same_ctx *ctx = a->ctx;
+    REQUIRE(ctx, n_accs <= 64 && out_n_rows && !a->loaded);
+    for (int q = 0; q < n_accs; ++q) {
+        REQUIRE(ctx, accs[q] && accs[q]->ctx->device == ctx->device && !accs[q]->resolved);
+        for (int p = 0; p < q; ++p) REQUIRE(ctx, accs[p] != accs[q]);
+    }
+    *out_n_rows = 0;
+    SAME_TRY(same_use(ctx));
+    int64_t n = 0;
+    SAME_TRY(lay_end_to_end(accs, n_accs, &n));
+    for (int q = 0; q < n_accs; ++q) accs[q]->resolved = 2;
+    a->n_rows = a->n_kept = a->n_final = n;
+    a->n_rest = 0;
+    a->final_on_host = 0;
+    SAME_TRY(ensure(ctx, a->out, (size_t)std::max<int64_t>(n, 1) * sizeof(FinalRec)));
+    if (n) SAME_LAUNCH(ctx, plain_kernel, dim3(grid_for(n)), dim3(256), 0, rows_of(a), n, static_cast<FinalRec *>(a->out.p));
+    HIP_TRY(ctx, hipGetLastError());
+    *out_n_rows = n;
     return SAME_OK;
 }
 

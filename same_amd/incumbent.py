@@ -192,7 +192,7 @@ class _TableBuilder:
         """the frame's type columns and coordinates are float64 and the type columns distinct: the sections hold exactly their values"""
         return self.type_block is not None and self.mov_xy is not None
 
-    def table_from_device(self, frames, acc):
+    def table_from_device(self, frames, acc, with_plan_pos=False):
         """The merged table with its columns gathered where the sections are: the DEVICE writes the type columns, X, Y, ref_X, ref_Y, the
         8-byte id / size columns of the frames, aligned_idx, window_id and the two flag columns of the final rows straight into a pooled
         page-locked host block (MergeAccumulator.columns); the table's arrays are views of it.  Columns the device cannot hold (ids that
@@ -204,8 +204,9 @@ class _TableBuilder:
         if got is None:
             return None
         wide, flags = got
-        names = list(self.cts) + ["X", "Y", "ref_X", "ref_Y"] + [nm for nm, _b, _d in extra["mov"] + extra["ref"]] + ["aligned_idx", "window_id"]
-        dtypes = [np.float64] * (len(self.cts) + 4) + [d for _n, _b, d in extra["mov"] + extra["ref"]] + [np.int64, np.int64]
+        names = (list(self.cts) + ["X", "Y", "ref_X", "ref_Y"] + [nm for nm, _b, _d in extra["mov"] + extra["ref"]]
+                 + ["aligned_idx", "window_id", "__plan_pos"])
+        dtypes = [np.float64] * (len(self.cts) + 4) + [d for _n, _b, d in extra["mov"] + extra["ref"]] + [np.int64, np.int64, np.int64]
         cid_r, cid_a = f"Ref_{self.cid}", f"Aligned_{self.cid}"
         missing = [k for k in ("size", "ref_size", cid_r, cid_a) if k not in names]
         host = {}
@@ -215,9 +216,9 @@ class _TableBuilder:
         with stage("table: wait for the device's columns"):
             acc.ctx.sync()
         with stage("table: the frame over the block"):
-            return self._frame_over(wide, flags, names, dtypes, host, n)
+            return self._frame_over(wide, flags, names, dtypes, host, n, with_plan_pos)
 
-    def _frame_over(self, wide, flags, names, dtypes, host, n):
+    def _frame_over(self, wide, flags, names, dtypes, host, n, with_plan_pos):
         cid_r, cid_a = f"Ref_{self.cid}", f"Aligned_{self.cid}"
         dev = {nm: wide[q].view(dt) for q, (nm, dt) in enumerate(zip(names, dtypes))}
         col = lambda k: dev[k] if k in dev else host[k]
@@ -228,6 +229,8 @@ class _TableBuilder:
         out["triangle_violation"], out["filtered_violation"] = flags[0].view(bool), flags[1].view(bool)
         out["run_time"] = np.zeros(n)
         out["window_id"] = dev["window_id"]
+        if with_plan_pos:
+            out["__plan_pos"] = dev["__plan_pos"]
         return pd.DataFrame(out, copy=False)
 
 
@@ -414,8 +417,9 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
     # (csrc/window_merge.hip); the merge runs there, and only what it could not decide alone comes to the host (`_merge_on_device`).
     # (window_local_indices needs every window's pair list on the host: the keys go through the builders then, `_merged_rows`.)
     accs = None
-    if merge and not with_ref_idx:
-        accs = _begin_accumulators(job, frames, contexts, cut, channel)
+    device_table = builders[0].device_columns_possible() and os.environ.get("SAME_TABLE_COLUMNS", "device") != "host"
+    if not with_ref_idx and (merge or (device_table and not job.all_matches)):
+        accs = _begin_accumulators(job, frames, contexts, cut, channel if merge else None)
     pos_of = {id(w): pos for pos, w in job.todo}
 
     def walk(q):
@@ -451,19 +455,30 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
         if errors:
             raise errors[0]
     if accs is not None:
-        done = _merge_on_device(job, frames, accs, channel)
+        calls0 = accs[0].ctx.stats()
+        if merge:
+            done = _merge_on_device(job, frames, accs, channel)
+        else:               # the windows' tables end to end, as they were collected (src/same.py:583-590)
+            from .windows import plain_accumulators
+
+            with stage("table rows (accumulated on the device, in plan order)"):
+                done = plain_accumulators(accs)
+        with_pos = job.mine is not None and not merge
         with stage("table (columns gathered on the gather threads)"):
             if not done.n_final:
                 return pd.DataFrame()
             me = builders[0]
-            if me.device_columns_possible() and os.environ.get("SAME_TABLE_COLUMNS", "device") != "host":
-                table = me.table_from_device(frames, done)           # the columns gathered on the device, into page-locked memory
+            if device_table:
+                table = me.table_from_device(frames, done, with_pos)     # the columns gathered on the device, into page-locked memory
                 if table is not None:
+                    # (the merge counted its own calls; what is new here: the rows laid end to end, the columns' launch and wait)
+                    _count_merge_calls(frames, accs[0].ctx, accs[0].ctx.stats() if merge else calls0, passes=0 if merge else 1)
                     return table
             final = done.final_rows()
             flags = final["flags"]
             return me.gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), final["cidx"].astype(np.int64), None,
-                             (flags & 2) != 0, (flags & 1) != 0, final["wid"].astype(np.int64))
+                             (flags & 2) != 0, (flags & 1) != 0, final["wid"].astype(np.int64),
+                             final["pos"].astype(np.int64) if with_pos else None)
     select = _merged_rows(job, frames, builders, channel) if merge else None
     with stage("table (columns gathered on the gather threads)"):
         table = _TableBuilder.table(builders, select, plan_pos=False if merge else None)
@@ -495,8 +510,9 @@ def _begin_accumulators(job, frames, contexts, cut, channel):
 
 
 def _count_merge_calls(frames, ctx0, calls0, passes=1):
-    """what the merge itself asked of the runtime on the first worker's context, per PASS (begin, resolve, finish: a sort's worth of launches;
-    the windows' calls are counted per window) -- read by bench.py and by the launch-budget test"""
+    """what a pass asked of the runtime ONCE on the first worker's context -- the accumulator's begin, the merge (resolve, finish: a sort's
+    worth of launches) or the rows laid end to end, the table's columns; the windows' calls are counted per window -- read by bench.py
+    and by the launch-budget test"""
     spent = frames.__dict__.setdefault("merge_runtime_calls", {})
     for k, v in ctx0.stats().items():
         spent[k] = spent.get(k, 0) + v - calls0[k]

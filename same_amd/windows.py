@@ -607,12 +607,12 @@ class MergeAccumulator:
     def columns(self, dmoving, dref, n_final, n_types, extra_moving=(), extra_ref=()):
         """After finish(): the merged table's columns written by the device straight into page-locked host memory (enqueue only:
         `ctx.sync()` before reading): the moving section's type columns, X, Y, the reference's X, Y, the caller's extra 8-byte device
-        columns (DeviceBuffers of 8-byte values per moving / reference row: ids, sizes), aligned_idx and window_id as int64, and the two
-        flag columns.  -> (uint64 array (n_types + 4 + extras + 2, n_final), uint8 array (2, n_final)) over a pooled block, or None when no
+        columns (DeviceBuffers of 8-byte values per moving / reference row: ids, sizes), aligned_idx, window_id and plan position as int64,
+        and the two flag columns.  -> (uint64 array (n_types + 4 + extras + 3, n_final), uint8 array (2, n_final)) over a pooled block, or None when no
         block is to be had (the caller gathers on the host)."""
         import ctypes
 
-        n8 = n_types + 4 + len(extra_moving) + len(extra_ref) + 2
+        n8 = n_types + 4 + len(extra_moving) + len(extra_ref) + 3
         got = PINNED_BLOCKS.take(self.ctx, max(1, n8 * 8 * n_final + 2 * n_final)) if n_final else None
         if got is None:
             return None
@@ -638,6 +638,20 @@ class MergeAccumulator:
             self.close()
         except Exception:
             pass
+
+
+def plain_accumulators(accs):
+    """The pass is over and its table is wanted WITHOUT the merge: every accumulated row is a row of the table, windows in the order they
+    were collected.  -> accs[0], holding the rows (`.n_final`, `.final_rows()`, `.columns(...)`)."""
+    import ctypes
+
+    ctx = accs[0].ctx
+    n = ctypes.c_int64(0)
+    handles = (ctypes.c_void_p * len(accs))(*[a.handle.value for a in accs])
+    with ctx.lock:
+        ctx.check(ctx.lib.same_merge_acc_plain(handles, len(accs), ctypes.byref(n)), "same_merge_acc_plain")
+    accs[0].n_final = n.value
+    return accs[0]
 
 
 def resolve_accumulators(accs, dmoving, dref):

@@ -1443,16 +1443,19 @@ def test_window_calls_stay_within_their_launch_budget():
                                                               ctx=ctx,
                                                               batch=8, return_stats=True, **kw)
         call()                                                           # buffers, helpers, the prune index, the sections
-        before = ctx.stats()
-        res, stats = call()
-        after = ctx.stats()
-        per = {k: (after[k] - before[k]) / len(stats) for k in after}
-        print("per window (sliding_window_incumbent):", per)
-        assert len(stats) == len(plan) and sum(s["pairs"] for s in stats) > 100_000 and len(res) > 50_000
-        # windows go to the library in batches of 8: ONE wait per call for the whole batch (it was one per window and call)
-        assert per["launches"] <= 3.5 and per["fills"] == 0 and per["copies"] <= 0.3 and per["waits"] <= 0.3, per
-        call(merge=True)                                                 # the accumulator's arrays
         frames = next(iter(res_frames._frames.values()))
+        spent0, before = dict(frames.merge_runtime_calls), ctx.stats()
+        res, stats = call()
+        after, spent1 = ctx.stats(), frames.merge_runtime_calls
+        once = {k: spent1[k] - spent0[k] for k in after}                 # per PASS: the accumulator's begin, the rows laid end to end, the columns
+        per = {k: (after[k] - before[k] - once[k]) / len(stats) for k in after}
+        print("per window (sliding_window_incumbent):", per, "; once per pass:", once)
+        assert len(stats) == len(plan) and sum(s["pairs"] for s in stats) > 100_000 and len(res) > 50_000
+        # windows go to the library in batches of 8: ONE wait per call for the whole batch (it was one per window and call); the three
+        # launches of same_window_collect per batch are the windows' too
+        assert per["launches"] <= 3.5 and per["fills"] == 0 and per["copies"] <= 0.3 and per["waits"] <= 0.3, per
+        assert once["launches"] <= 4 and once["fills"] <= 2 and once["copies"] <= 2 and once["waits"] <= 3, once
+        call(merge=True)                                                 # the merge's work buffers
         spent0, before = dict(frames.merge_runtime_calls), ctx.stats()
         merged, stats_m = call(merge=True)
         after, spent1 = ctx.stats(), frames.merge_runtime_calls
@@ -1460,7 +1463,7 @@ def test_window_calls_stay_within_their_launch_budget():
         per = {k: (after[k] - before[k] - once[k]) / len(stats_m) for k in after}
         print("per window (merge=True):", per, "; the merge, once per pass:", once)
         assert 50_000 < len(merged) <= len(res) and stats_m == stats
-        assert per["launches"] <= 4.0 and per["fills"] == 0 and per["copies"] <= 0.3 and per["waits"] <= 0.3, per
+        assert per["launches"] <= 3.5 and per["fills"] == 0 and per["copies"] <= 0.3 and per["waits"] <= 0.3, per
         assert once["launches"] <= 80 and once["copies"] <= 8 and once["waits"] <= 6, once
     before = ctx.stats()
     preps = [p for _w, p in same_amd.iter_prepared_windows(r_df, m_df, cols, plan, optim_params=dict(op)) if not isinstance(p, Exception)]
