@@ -1447,7 +1447,7 @@ def test_window_calls_stay_within_their_launch_budget():
         spent0, before = dict(frames.merge_runtime_calls), ctx.stats()
         res, stats = call()
         after, spent1 = ctx.stats(), frames.merge_runtime_calls
-        once = {k: spent1[k] - spent0[k] for k in after}                 # per PASS: the accumulator's begin, the rows laid end to end, the columns
+        once = {k: spent1[k] - spent0[k] for k in after}      # per PASS: the accumulator's begin, the rows laid end to end, the columns
         per = {k: (after[k] - before[k] - once[k]) / len(stats) for k in after}
         print("per window (sliding_window_incumbent):", per, "; once per pass:", once)
         assert len(stats) == len(plan) and sum(s["pairs"] for s in stats) > 100_000 and len(res) > 50_000
