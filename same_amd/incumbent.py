@@ -365,20 +365,21 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
             if merge:
                 from .merge import merge_table_part
 
-                table = merge_table_part(table, job.plan, job.owner, _merge_channel, job.optim_params["cell_id_col"],
-                                         ids_unique=_ids_unique(job))
+                # (reach: the prune's radius bounds the distance of a pair's two cells on every route -- no collective to measure it, so
+                # ranks on different routes still make the same exchanges)
+                from .window_api import codes_of_ids, frame_id_codes
+
+                cid = job.optim_params["cell_id_col"]
+                _codes, unique, (mov_ids, ref_ids) = frame_id_codes(job.moving, job.ref, cid)
+                to_codes = lambda a, r: (codes_of_ids(mov_ids, a), codes_of_ids(ref_ids, r))       # what the device route exchanges too
+                table = merge_table_part(table, job.plan, job.owner, _merge_channel, cid, reach=abs(float(job.optim_params["radius"])),
+                                         ids_unique=unique, id_codes=to_codes)
     finally:
         if own:
             frames.close()
     if job.output_file and len(table):
         table.to_csv(job.output_file, index=False)
     return (table, [stats[pos] for pos in sorted(stats)]) if return_stats else table
-
-
-def _ids_unique(job):
-    """does a cell id name ONE row of its frame (what merge.seam_rows reasons from)?"""
-    cid = job.optim_params["cell_id_col"]
-    return all(cid in df.columns and pd.Index(df[cid].to_numpy()).is_unique for df in (job.ref, job.moving))
 
 
 def _merged_rows(job, frames, builders, channel):

@@ -319,11 +319,13 @@ def join_merged_parts(parts, cell_id_col="Cell_Num_Old"):
     return _take_rows(whole, np.argsort(whole[f"Aligned_{cell_id_col}"].to_numpy(), kind="stable"))
 
 
-def merge_table_part(table, plan, owner, channel, cell_id_col="Cell_Num_Old", reach=None, ids_unique=True, _dedup=None):
+def merge_table_part(table, plan, owner, channel, cell_id_col="Cell_Num_Old", reach=None, ids_unique=True, id_codes=None, _dedup=None):
     """`merged_part_rows` for a rank's pre-merge table as the window loop leaves it (sliding_window_matching / sliding_window_incumbent with
     `_shard`: the columns of src/same.py:1264-1278 + window_id + `__plan_pos`) -> this rank's part of the merged table, aligned ids
     ascending, `__plan_pos` dropped.  `channel` (dist.MergeChannel; None = one process: the whole merge) carries the seam rows; `reach`
-    None measures the bound seam_rows needs (the largest coordinate distance between a row's two cells, over all ranks)."""
+    None measures the bound seam_rows needs (the largest coordinate distance between a row's two cells, over all ranks).
+    id_codes(aligned ids, ref ids) -> (codes, codes): integer ranks of the ids in the ids' order, the SAME on every rank (window_api.
+    frame_id_codes): the merge then compares and exchanges the codes -- one numeric all-gather whatever the ids are."""
     from ._trace import stage as marked
 
     aligned_col, ref_col = f"Aligned_{cell_id_col}", f"Ref_{cell_id_col}"
@@ -336,6 +338,8 @@ def merge_table_part(table, plan, owner, channel, cell_id_col="Cell_Num_Old", re
         raise ValueError(f"Missing required columns in matches: {missing}")
     viol = _violation_flags(table["filtered_violation"])
     a_ids, r_ids, wid = table[aligned_col].to_numpy(), table[ref_col].to_numpy(), table["window_id"].to_numpy()
+    if id_codes is not None:
+        a_ids, r_ids = id_codes(a_ids, r_ids)
     keep = [c for c in table.columns if c != "__plan_pos"]
     if channel is None or channel.world == 1:
         rows = merged_part_rows(a_ids, r_ids, viol, wid, None, None, _dedup=_dedup)

@@ -75,6 +75,26 @@ def _window_frame(df, rows, vertex_col=None, aligned=False):
     return out
 
 
+def frame_id_codes(moving, ref, cid):
+    """((aligned code per moving row, reference code per ref row), whether every id names one row, (sorted distinct moving ids, sorted
+    distinct ref ids)): the cell ids of both frames as int64 ranks in the ORDER of the ids (equal id <=> equal code) -- what the window
+    merge compares, orders by and exchanges between ranks instead of the ids themselves (strings, floats ...)."""
+    def codes(df):
+        ids = df[cid].to_numpy()
+        if ids.dtype.kind in "iu" and (len(ids) < 2 or bool(np.all(ids[1:] > ids[:-1]))):
+            return np.arange(len(ids), dtype=np.int64), True, ids                 # ascending ids: a row's code is its number
+        c, uniq = pd.factorize(ids, sort=True, use_na_sentinel=False)
+        return c.astype(np.int64), len(uniq) == len(ids), np.asarray(uniq)
+
+    (mc, mu, m_ids), (rc, ru, r_ids) = codes(moving), codes(ref)
+    return (mc, rc), mu and ru, (m_ids, r_ids)
+
+
+def codes_of_ids(sorted_distinct_ids, ids):
+    """the codes `frame_id_codes` gave these ids"""
+    return pd.Index(sorted_distinct_ids).get_indexer(np.asarray(ids)).astype(np.int64)
+
+
 class _DeviceFrames:
     """The two frames of a window loop as sections resident on the device (windows.DeviceSection), binned on the grid on which every
     window box is a union of cells (windows.window_cell_grid).  `windows(plan)` runs the per-window device path over them."""
@@ -159,20 +179,17 @@ class _DeviceFrames:
         return state.fetch(_W_ROWS_M), state.fetch(_W_ROWS_R)
 
     def id_codes(self, cid):
-        """((aligned code per moving row, reference code per ref row), whether every id names one row): the cell ids of both frames as
-        int64 ranks in the ORDER of the ids (equal id <=> equal code) -- what the window merge compares and orders by instead of the ids
-        themselves (strings, floats ...).  Made once per frames and id column."""
+        """((aligned code per moving row, reference code per ref row), whether every id names one row) -- `frame_id_codes`, made once per
+        frames and id column."""
         known = self.__dict__.setdefault("_id_codes", {})
         if cid not in known:
-            def codes(df):
-                ids = df[cid].to_numpy()
-                if ids.dtype.kind in "iu" and (len(ids) < 2 or bool(np.all(ids[1:] > ids[:-1]))):
-                    return np.arange(len(ids), dtype=np.int64), True                 # ascending ids: a row's code is its number
-                c, uniq = pd.factorize(ids, sort=True, use_na_sentinel=False)
-                return c.astype(np.int64), len(uniq) == len(ids)
-            (mc, mu), (rc, ru) = codes(self.moving), codes(self.ref)
-            known[cid] = ((mc, rc), mu and ru)
-        return known[cid]
+            known[cid] = frame_id_codes(self.moving, self.ref, cid)
+        return known[cid][:2]
+
+    def id_uniques(self, cid):
+        """the sorted distinct ids of (moving, ref): code -> id"""
+        self.id_codes(cid)
+        return self._id_codes[cid][2]
 
     def table_columns(self, cid):
         """The frames' columns that are 8-byte numbers and go into the result table besides the sections' own (sizes, cell ids), resident on

@@ -517,7 +517,8 @@ def test_scans_hold_when_no_block_ever_sees_a_predecessor():
     sel = ["tests/test_gpu_fuzz.py::test_fuzz_device_windows", "tests/test_gpu_fuzz.py::test_fuzz_knn_and_costs",
            "tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline",
            "tests/test_gpu_run_same.py::test_window_rows_do_not_depend_on_the_section_grid",
-           "tests/test_gpu_parity.py::test_sharded_sweeps_rccl_single_rank_and_block_forms", "tests/test_host_rows.py::test_merge_dedup_on_device"]
+           "tests/test_gpu_parity.py::test_sharded_sweeps_rccl_single_rank_and_block_forms", "tests/test_host_rows.py::test_merge_dedup_on_device",
+           "tests/test_gpu_merge.py", "tests/test_gpu_fuzz.py::test_fuzz_window_merge_routes_agree"]
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "not scans_hold"] + sel, cwd=root, env=env,
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
@@ -632,3 +633,130 @@ def test_fuzz_window_pipelines_agree():
                         assert np.array_equal(t[c].to_numpy(), tables[0][c].to_numpy()), (rnd, case, c)
                 done += 1
     assert done >= 6 * ROUNDS and errors >= 1, (done, errors)
+
+
+def _random_window_job(rng, case):
+    """two random frames + window parameters (a lighter form of test_fuzz_window_pipelines_agree's generator: jobs whose every window
+    has pairs, crowded so that neighbouring windows disagree about cells)"""
+    import pandas as pd
+
+    n_r, T = int(rng.integers(300, 1500)), int(rng.integers(1, 6))
+    side = float(rng.choice([150.0, 400.0]))
+    rxy = _points(rng, n_r, side, int(rng.choice([0, 0, 0, 1, 2])))
+    copies = int(rng.choice([1, 2, 3]))                         # several suitors per reference cell
+    mxy = np.concatenate([rxy[rng.random(n_r) < 0.9] + rng.normal(0, float(rng.choice([0.5, 3.0])), (1, 2)) for _ in range(copies)])
+    mxy = mxy + rng.normal(0, 2.0, mxy.shape)
+    frames = []
+    for xy in (rxy, mxy):
+        n = len(xy)
+        df = pd.DataFrame(rng.gamma(0.3, 30.0, (n, T)), columns=[f"t{q}" for q in range(T)])
+        if case % 5 == 1:
+            df["t0"] = (df["t0"] * 3).astype(np.int64)            # an integer-typed type column: the table's columns come from the host
+        df.insert(0, "Y", xy[:, 1])
+        df.insert(0, "X", xy[:, 0])
+        df["cell_type"] = rng.choice(np.array(["a", "b", "c"], dtype=object), n)
+        if case % 3:
+            df["size"] = rng.integers(1, 4, n) if case % 2 else rng.integers(1, 4, n) * 1.5
+        ids = rng.permutation(n) * 3 + 10
+        df["Cell_Num_Old"] = ids if case % 4 else np.array([f"c{v:06d}" for v in ids], dtype=object)     # string ids: codes, host-gathered id columns
+        if case % 6 == 2:
+            df.loc[df.index[rng.integers(0, n, 4)], "X"] = np.nan
+        if case % 6 == 3:
+            df.index = [f"cell{q}" for q in rng.permutation(n)]
+        frames.append(df)
+    ws = int(rng.choice([70, 110, 200]))
+    op = dict(radius=float(rng.choice([8.0, 15.0, 30.0])), knn=int(rng.choice([2, 5, 12])), window_size=ws, overlap=int(rng.choice([0, 6, ws // 4])),
+              min_cells_per_window=int(rng.choice([5, 30])), min_angle_deg=[15, None, 30][case % 3], ignore_same_type_triangles=bool(case % 4),
+              hip_cost_dtype="float32" if case % 2 else "float64", no_match_penalty=float(rng.choice([100.0, 5.0])))
+    return frames[0], frames[1], [f"t{q}" for q in range(T)], op
+
+
+class _ThreadHub:
+    def __init__(self, world):
+        import threading
+
+        self.world, self.slots, self.barrier = world, [None] * world, threading.Barrier(world)
+
+
+class _ThreadMergeChannel:
+    """dist.MergeChannel's interface between threads of this process (one rank per thread, a context each)"""
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank, self.world, self.sent_rows, self.gather_ms = hub, rank, hub.world, 0, 0.0
+
+    def _all(self, v):
+        self.hub.slots[self.rank] = v
+        self.hub.barrier.wait(120)
+        out = list(self.hub.slots)
+        self.hub.barrier.wait(120)
+        return out
+
+    def tables(self, table):
+        return self._all(table)
+
+    def max(self, v):
+        return max(self._all(float(v)))
+
+
+def test_fuzz_window_merge_routes_agree(oracle):
+    """The window table and the window merge on random crowded jobs, every way the product can make them: the table through the device
+    accumulator (columns from the device, or from the host where a column is not an 8-byte number) against the per-window host route;
+    merge=True on the device against merge_window_matches_unique_ref of that table, against the general route's merge on row keys, and
+    dealt over 2-3 ranks (threads, a context each) under either deal -- all equal, row for row, including when every scan is forced to
+    recompute (the soak runs this file under SAME_SCAN_FORCE_RECOMPUTE=1 too)."""
+    import threading
+
+    import pandas as pd
+
+    import same_amd
+    from same_amd import _lib
+    from same_amd.merge import join_merged_parts, merge_window_matches_unique_ref
+
+    done = contested = 0
+    for rnd in range(FIRST, FIRST + ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"window merge soak round {rnd}", flush=True)
+        rng = np.random.default_rng(777 + 15485863 * rnd)
+        for case in range(10):
+            ref, mov, cols, op = _random_window_job(rng, case)
+            try:
+                host_table = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), _route="general", _pipeline="device")
+            except Exception as e:  # noqa: BLE001 -- a window without pairs / a set Qhull refuses: every route raises alike
+                with pytest.raises(type(e)):
+                    same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True)
+                continue
+            if len(host_table) == 0:
+                continue
+            table = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op))       # the accumulator, end to end
+            assert list(table.columns) == list(host_table.columns) and len(table) == len(host_table), (rnd, case)
+            for c in table.columns:
+                assert table[c].dtype == host_table[c].dtype and np.array_equal(table[c].to_numpy(), host_table[c].to_numpy()), (rnd, case, c)
+            want = merge_window_matches_unique_ref([host_table], _dedup=oracle.merge_dedup)
+            contested += len(want) < len(host_table)
+            got = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True)
+            assert list(got.columns) == list(want.columns) and got.equals(want), (rnd, case, len(got), len(want))
+            general = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True, _route="general")
+            assert general.equals(want), (rnd, case)
+            world, deal = int(rng.choice([2, 3])), str(rng.choice(["block", "round_robin"]))
+            hub, parts, errors = _ThreadHub(world), [None] * world, []
+
+            def rank_body(rank):
+                ctx = _lib.Context(_lib.default_context().device)
+                try:
+                    route = {} if rank % 2 == 0 else dict(_route="general")        # ranks on different routes send the same seam rows
+                    parts[rank] = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True, ctx=ctx, workers=1,
+                                                                    _shard=(rank, world, deal), _merge_channel=_ThreadMergeChannel(hub, rank), **route)
+                except BaseException as e:  # noqa: BLE001
+                    errors.append(e)
+                    hub.barrier.abort()
+                finally:
+                    ctx.close()
+
+            threads = [threading.Thread(target=rank_body, args=(r,)) for r in range(world)]
+            [t.start() for t in threads]
+            [t.join(300) for t in threads]
+            assert not errors, (rnd, case, world, deal, errors[:1])
+            joined = join_merged_parts(parts, "Cell_Num_Old")
+            assert joined.equals(want), (rnd, case, world, deal)
+            done += 1
+    assert done >= 5 * ROUNDS and contested >= 2 * ROUNDS, (done, contested)
