@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SAME_HIP_LIB") or os.path.join(_HERE, "libsame_hip.so")   # SAME_HIP_LIB: a measurement hook (an A/B build of the library)
+# SAME_HIP_LIB: a measurement hook (an A/B build of the library)
+LIB_PATH = os.environ.get("SAME_HIP_LIB") or os.path.join(_HERE, "libsame_hip.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
@@ -230,7 +231,8 @@ class DeviceBuffer:
         if spread:
             info = (c_i64 * SPREAD_INFO_LEN)()
             ctx.check(ctx.lib.same_dev_alloc_spread(ctx.handle, self.nbytes, ctypes.byref(p), info), "same_dev_alloc_spread")
-            self.spread_info = {"spread": bool(info[0]), "chunks_gib": int(info[1]), "per_region": [int(info[2]), int(info[3]), int(info[4])],
+            self.spread_info = {"spread": bool(info[0]), "chunks_gib": int(info[1]),
+                                "per_region": [int(info[2]), int(info[3]), int(info[4])],
                                 "straddling": int(info[5]), "examined": int(info[6]), "seconds": info[7] * 1e-6,
                                 "same_region_level_gbps": int(info[8]), "verified": bool(info[9]), "final_store_gbps": int(info[10]),
                                 "pairs_checked": int(info[11]), "pairs_as_labelled": int(info[12]), "stopped_at_time_bound": bool(info[13])}

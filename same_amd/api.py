@@ -199,7 +199,8 @@ def _stage_prune_body(st, ref_df, aligned_df, aligned_delaunay, aligned_delaunay
     # KNN prune (src/same.py:972-979)
     with stage("prune+compact"):
         if optim_params["ignore_knn_if_matched"]:
-            aligned_df, ref_df, valid_pairs = find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
+            aligned_df, ref_df, valid_pairs = find_knn_with_cell_type_priority(aligned_df, ref_df, radius, knn=knn, verbose=verbose,
+                                                                      ctx=ctx)
         else:
             aligned_df, ref_df, valid_pairs = find_knn_within_radius(aligned_df, ref_df, radius, knn=knn, verbose=verbose, ctx=ctx)
     st.aligned_df, st.ref_df, st.valid_pairs = aligned_df, ref_df, valid_pairs
@@ -442,7 +443,8 @@ def _run_same(ref_df, aligned_df, commonCT, outprefix, aligned_delaunay, aligned
 
         with stage("solve (incl. lazy sweeps)"):
             if lazy:
-                sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.signs_array, ref_df[["X", "Y"]].to_numpy(dtype=np.float64), n_aligned)
+                sweep = sweeps.LazyOrientationSweep(valid_pairs, tris, prep.signs_array, ref_df[["X", "Y"]].to_numpy(dtype=np.float64),
+                                                    n_aligned)
                 model.optimize(make_lazy_callback(GRB, sweep))
                 print(f"Lazy cuts added: {model._cuts_added}")
             else:

@@ -9,8 +9,10 @@ from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s",
                "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged", "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
-               "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0", "amdahl_bound_at_8_ranks", "amdahl",
-               "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull", "merged_matches", "parity_spot_check", "rccl",
+               "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0",
+               "amdahl_bound_at_8_ranks", "amdahl",
+               "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull",
+               "merged_matches", "parity_spot_check", "rccl",
                "product_function", "api_path_windows_per_s", "api_path", "window_calls_only_windows_per_s")
 
 
@@ -18,9 +20,11 @@ def record(line):
     """The sub-record a bench line of another workload carries as `cfg5`: the cfg 5 line's own numbers, without its prose."""
     rec = {k_: line.get(k_) for k_ in RECORD_KEYS if k_ in line}
     rec["workload"], rec["pipeline"] = line["config"]["workload"], line["config"]["pipeline"]
-    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks in runs of the plan, fp32 costs, all sweeps, the window merge per rank "
+    rec["what"] = ("BASELINE cfg 5 (whole sliding windows dealt to the ranks in runs of the plan, fp32 costs, all sweeps, the window merge "
+                   "per rank "
                    "with one exchange of the seam rows) measured in "
-                   "this job, on its ranks, contexts and communicator, after this line's own timed region; windows_per_s is the whole job's")
+                   "this job, on its ranks, contexts and communicator, after this line's own timed region; windows_per_s is the whole "
+                   "job's")
     return rec
 
 
@@ -64,7 +68,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     deal = getattr(args, "cfg5_deal", None) or "block"
     owner = deal_windows(plan, group.world, deal)
     my_plan = [plan[q] for q in np.flatnonzero(owner == group.rank)]
-    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs {len(my_plan)} ({deal} deal)")
+    note(group, f"cfg5: {n} cells, {len(plan)} windows of ~{int(np.mean([w['n_mov'] for w in plan]))} aligned cells; this rank runs "
+                f"{len(my_plan)} ({deal} deal)")
 
     on_device = args.cfg5_pipeline == "device"
     # device pipeline: the two frames go to the device ONCE, before the timed region (inputs resident, as the bench contract asks), and
@@ -72,7 +77,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     resident = same_amd.resident_frames(r_df, m_df, ctx=ctx) if on_device else None
     frame_args = (resident, resident) if on_device else (r_df, m_df)
     shard = (group.rank, group.world, deal) if group.world > 1 else None
-    channel = MergeChannel(group, ctx, comm) if group.world > 1 else None      # carries the seam rows of the window merge (one small all-gather)
+    # carries the seam rows of the window merge (one small all-gather)
+    channel = MergeChannel(group, ctx, comm) if group.world > 1 else None
 
     from same_amd import qhull_pool as _share
 
@@ -80,12 +86,15 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     default_threads = (2 if cpu_share >= 8 else 1) if on_device else 1  # a second Python thread only pays where there are CPUs to feed it
     n_workers = max(1, int(args.cfg5_threads if args.cfg5_threads is not None else default_threads))
     tri_cache = [None]        # set for the diagnostic pass after the timed loop (triangulations remembered: Qhull out of the picture)
-    worker_ctx = [ctx]        # the product function makes (and closes) the other workers' contexts itself; their calls are summed by _lib.instrument
+    # the product function makes (and closes) the other workers' contexts itself; their calls are summed by _lib.instrument
+    worker_ctx = [ctx]
 
     def one_pass(merge=True):
-        """this rank's share of the plan through the product function, window merge included -> (its part of the merged table, per-window stats)"""
+        """this rank's share of the plan through the product function, window merge included
+        -> (its part of the merged table, per-window stats)"""
         kw = dict(workers=n_workers, triangulator=tri_cache[0]) if on_device else dict(_route="general", _pipeline="frames")
-        return same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), return_stats=True, ctx=ctx, _shard=shard,
+        return same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op), return_stats=True, ctx=ctx,
+                                                 _shard=shard,
                                                  merge=merge, _merge_channel=channel if merge else None, **kw)
 
     def all_ranks(fn, *a):
@@ -104,7 +113,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     def step():
         # ONE call of the product function per rank: its windows, the merge of what only this rank can see, the exchange of the seam rows,
         # the common seam step, the columns of the rows that stay.  The merged table is the job's result and stays dealt over the ranks
-        # (every part in the order of the aligned ids; dist.sharded_merged_window_incumbent(gather=...) joins them where a caller wants one frame)
+        # (every part in the order of the aligned ids; dist.sharded_merged_window_incumbent(gather=...) joins them where a caller wants one
+        # frame)
         return all_ranks(one_pass)
 
     from same_amd import qhull_pool as _qp
@@ -133,7 +143,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     wall_here = time.perf_counter() - t0
     calls1 = [c.stats() for c in worker_ctx]
     seam1 = (channel.sent_rows, channel.gather_ms) if channel is not None else (0, 0.0)
-    # the calls counted are those of `ctx`: worker 0's windows (the first of n_workers contiguous runs of this rank's share) + the merge's de-duplication
+    # the calls counted are those of `ctx`: worker 0's windows (the first of n_workers contiguous runs of this rank's share) + the merge's
+    # de-duplication
     n_done = max(1, (len(stats) // n_workers) * steps)
     # ... without what the merge itself asked for, which is per PASS, not per window (resolve + finish: a sort's worth of launches)
     merge_calls1 = merge_calls()
@@ -162,7 +173,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
         for _ in range(2):
             all_ranks(one_pass)                            # ... and with the window merge, as the timed step runs it
         no_qhull_merged = len(my_plan) * 2 / max(time.perf_counter() - tq, 1e-9)
-        # ... and the window calls alone (stage + filter_finish in batches, the per-window Python of iter_device_windows; no table): one thread
+        # ... and the window calls alone (stage + filter_finish in batches, the per-window Python of iter_device_windows; no table): one
+        # thread
         frames_obj = next(iter(resident._frames.values()))
 
         def calls_only_pass(n_threads):
@@ -226,7 +238,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                                     next(iter(resident._frames.values())) if on_device else None)
     out = None
     if group.rank == 0:
-        out = _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device, n_workers,
+        out = _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device,
+                    n_workers,
                     cpu, parity, api_path, amdahl, _qp)
         if rccl is not None:
             out["rccl"] = rccl
@@ -296,13 +309,18 @@ def _amdahl_at_8_ranks(same_amd, frame_args, cols, op, deal, every, steps, ctx, 
     return {"value": dealt_s / (per_rank_8 + not_dealt_8),
             "dealt_s_per_step": dealt_s, "of_which_merge_s": merge_alone_s,
             "at_8_ranks": {"merge_of_own_rows_s_max_over_ranks": max(local_s), "merge_of_own_rows_s_by_rank": local_s,
-                           "seam_rows_by_rank": seam_rows, "seam_rows_share": sum(seam_rows) / max(1, sum(r_["merged_rows"] for r_ in every)),
+                           "seam_rows_by_rank": seam_rows, "seam_rows_share": sum(seam_rows) / max(1,
+                                                                      sum(r_["merged_rows"] for r_ in every)),
                            "common_seam_step_s": common_s, "seam_exchange_s": exchange_s,
-                           "seam_exchange_s_is": ("measured by this run: the all-gather as the last rank to arrive saw it" if measured_gather
-                                                  else "assumed (one rank: nothing to exchange; 2 ranks over the host transport measure 1.4-1.8 ms)"),
+                           "seam_exchange_s_is": ("measured by this run: the all-gather as the last rank to arrive saw it"
+                                                  if measured_gather
+                                                  else "assumed (one rank: nothing to exchange; 2 ranks over the host transport measure "
+                                                       "1.4-1.8 ms)"),
                            "one_share_alone_s_by_rank": windows_s},
-            "means": "speed-up bound at 8 ranks = dealt / ((dealt - merge) / 8 + slowest share's merge of its own rows + seam exchange + common "
-                     "seam step): the windows, the table and the merge of a rank's own rows are dealt with the windows (Qhull's share scales "
+            "means": "speed-up bound at 8 ranks = dealt / ((dealt - merge) / 8 + slowest share's merge of its own rows + seam exchange + "
+                     "common "
+                     "seam step): the windows, the table and the merge of a rank's own rows are dealt with the windows (Qhull's share "
+                     "scales "
                      "with the CPUs each rank has); the seam exchange and the common seam step are what every rank repeats whole.  Each "
                      "of the eight shares was run through the product function alone for its merge stages, the common step once on all "
                      "eight shares' seam rows"}
@@ -315,7 +333,8 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
     total_pairs = float(sum(w["n_mov"] * w["n_ref"] for w in plan))
     es, k = 4, 8
     P, Tr = sum(r["pairs"] for r in every), sum(r["triangles"] for r in every)
-    touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)   # SURVEY 8d per-unit figures
+    # SURVEY 8d per-unit figures
+    touched = P * (2 * es * (T + 2) + 8 + es) + Tr * (74 + 12 + 3 * 40 + 1) + 16 * k * sum(r["cells"] for r in every)
     lib_s = max(r["in_library_s"] for r in every) / steps
     mean_cells = int(np.mean([w["n_mov"] for w in plan]))
     by_rank = lambda key: [r.get(key) for r in every]
@@ -326,13 +345,15 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
         "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{mean_cells} aligned cells each), "
+            "workload": f"cfg5: {n}-cell section, {len(plan)} sliding windows (window 1200, overlap 300, ~{mean_cells} aligned cells "
+                        f"each), "
                         f"T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, orientation + "
                         "XY-order + area-flip sweeps per window, window merge (one row per aligned and per reference cell)",
             "pipeline": ("device: same_amd.sliding_window_incumbent(merge=True) on resident frames -- both sections in HBM, binned on the "
                          "window grid, two library calls per window (csrc/window*.hip); the host triangulates (Qhull helpers) and receives "
                          "the match; the merge reads the rows' keys, only the rows it keeps get their columns" if on_device
-                         else "frames: same_amd.sliding_window_incumbent(merge=True), general route on host frames -- every window's frames "
+                         else "frames: same_amd.sliding_window_incumbent(merge=True), general route on host frames -- every window's "
+                              "frames "
                               "cut on the host, every kernel through host buffers, a DataFrame per window"),
             "parallelism": f"whole windows, {deal} deal x{group.world}; no collective inside a window; every rank merges what only it can "
                            "see, one all-gather of the seam rows per pass" + (f": {transport}" if comm is not None else "")},
@@ -340,17 +361,21 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
         "windows_per_s": len(plan) * steps / dt,
         "aligned_cells_per_s": float(sum(w["n_mov"] for w in plan)) * steps / dt,
         "aligned_cells_per_window": float(np.mean([w["n_mov"] for w in plan])),
-        "per_rank": {"windows": by_rank("windows"), "windows_per_s": by_rank("windows_per_s"), "host_glue_share": by_rank("host_glue_share"),
+        "per_rank": {"windows": by_rank("windows"), "windows_per_s": by_rank("windows_per_s"),
+                     "host_glue_share": by_rank("host_glue_share"),
                      "python_share": by_rank("python_share"), "qhull_wait_s_per_step": [r["qhull_wait_s"] / steps for r in every],
                      "in_library_s_per_step": [r["in_library_s"] / steps for r in every],
-                     "serial_tail_s_per_step": by_rank("serial_tail_s_per_step"), "table_gather_s_per_step": by_rank("table_gather_s_per_step"),
-                     "unsharded_s_per_step": by_rank("unsharded_s_per_step"), "seam_exchange_s_per_step": by_rank("seam_exchange_s_per_step"),
+                     "serial_tail_s_per_step": by_rank("serial_tail_s_per_step"),
+                     "table_gather_s_per_step": by_rank("table_gather_s_per_step"),
+                     "unsharded_s_per_step": by_rank("unsharded_s_per_step"),
+                     "seam_exchange_s_per_step": by_rank("seam_exchange_s_per_step"),
                      "seam_step_s_per_step": by_rank("seam_step_s_per_step"), "seam_rows_sent_per_step": by_rank("seam_rows_sent_per_step"),
                      "seam_gather_ms": by_rank("seam_gather_ms"), "merged_rows": by_rank("merged_rows"),
                      "qhull_helpers": by_rank("qhull_helpers"), "windows_per_s_triangulations_given": given,
                      "qhull_l3_domains": by_rank("qhull_domains")},
         "host_glue_share": mine_rec["host_glue_share"],
-        "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the window walk x "
+        "host_glue_share_means": "1 - (wall time inside libsame_hip calls, summed over the worker threads) / (wall time of the window walk "
+                                 "x "
                                  "threads + wall time of the merge and the table behind it, which one thread runs), rank 0: Python / numpy "
                                  "/ scipy glue, waiting for the Qhull helpers and the seam exchange included",
         "python_share": mine_rec["python_share"],
@@ -362,8 +387,10 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
         "serial_tail_s_per_step": max(by_rank("serial_tail_s_per_step")),
         "serial_tail_means": "slowest rank's time in the window merge per step (stages 'merge: ...' of same_amd/_trace.py: keys, "
                              "de-duplication on the device, matching of contested cells, the seam rows' exchange, the common seam step) -- "
-                             "what round 5 measured as exchange + merge on rank 0; all of it but `unsharded_s_per_step` is per-rank work on "
-                             "the rank's own rows.  The columns of the rows that stay are `table_gather_s_per_step` (inside the window pass "
+                             "what round 5 measured as exchange + merge on rank 0; all of it but `unsharded_s_per_step` is per-rank work "
+                             "on "
+                             "the rank's own rows.  The columns of the rows that stay are `table_gather_s_per_step` (inside the window "
+                             "pass "
                              "in round 5, when the pre-merge table was laid out first)",
         "merge_stages_s_per_step_rank0": mine_rec["merge_stages_s_per_step"],
         "table_gather_s_per_step": max(by_rank("table_gather_s_per_step")),
@@ -392,9 +419,11 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                                    "the generator's own Python, on one thread and on the product function's worker threads",
         "runtime_calls_per_window": mine_rec["runtime_calls_per_window"],
         "runtime_calls_per_pass_merge": mine_rec["runtime_calls_per_pass_merge"],
-        "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library issued "
+        "runtime_calls_per_window_means": "kernel launches / hipMemsetAsync fills / hipMemcpyAsync copies / stream waits the library "
+                                          "issued "
                                           "per window on rank 0, counted by the library itself (same_ctx_stat) over the timed passes: the "
-                                          "stage, filter + finish and collect calls; what the window merge asks for once per PASS (resolve + "
+                                          "stage, filter + finish and collect calls; what the window merge asks for once per PASS (resolve "
+                                          "+ "
                                           "finish on the accumulated rows: a sort's worth of launches) is runtime_calls_per_pass_merge",
         "qhull": {"helpers": _qp.pool().n, "helpers_all_ranks": sum(r["qhull_helpers"] for r in every),
                   "ranks_on_this_host": every[0]["local_world"], "l3_domains_used": len(_qp.pool().domains), "cpu_budget": _qp.cpu_budget(),
@@ -403,14 +432,17 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                           "worker threads' time in the hand-over (all helpers busy) and in collecting an answer, summed over the threads"},
         "stages_rank0": stages, "library_calls_rank0_top": [{"entry_point": nme, "seconds": sec} for nme, sec in lib_top],
         "merged_matches": int(sum(r["merged_rows"] for r in every)),
-        "roofline": {"bound": "hbm", "kernel": "window pipeline: gather / latency-bound kernels that take a group of eight windows per launch "
+        "roofline": {"bound": "hbm",
+                     "kernel": "window pipeline: gather / latency-bound kernels that take a group of eight windows per launch "
                                                "(greedy rounds, prune and the compactions lead)",
                      "achieved": touched / lib_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": touched / lib_s / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_step": touched,
-                     "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 k "
+                     "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 "
+                             "k "
                              "per aligned cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by "
                              "the host's Delaunay calls (Qhull: qhull_wait_share), not by HBM or by the GPU"},
-        "product_function": "same_amd.sliding_window_incumbent(merge=True) (sliding_window_matching's arguments; the greedy MIP start as every "
+        "product_function": "same_amd.sliding_window_incumbent(merge=True) (sliding_window_matching's arguments; the greedy MIP start as "
+                            "every "
                             "window's solution; merge_window_matches_unique_ref's table) -- the timed step IS a call of it per rank"
                             + (", on frames made resident before the timed region" if on_device else ""),
         "api_path_windows_per_s": None if api_path is None else api_path["api_path_windows_per_s"], "api_path": api_path,
@@ -441,7 +473,8 @@ def _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, co
         with tempfile.TemporaryDirectory() as work:      # run_same writes matching_model.lp into the working directory
             os.chdir(work)
             t0 = time.perf_counter()
-            res_b = same_amd.sliding_window_matching(r_c, m_c, commonCT=cols, optim_params=dict(op), gurobi_params=dict(init_method="greedy"),
+            res_b = same_amd.sliding_window_matching(r_c, m_c, commonCT=cols, optim_params=dict(op),
+                                                     gurobi_params=dict(init_method="greedy"),
                                                      _pipeline=pipeline)
             t_b = time.perf_counter() - t0
     finally:
@@ -450,13 +483,18 @@ def _api_path_record(same_amd, incumbent_of_prepared, frame_args, r_df, m_df, co
     n_b = max(1, int(res_b["window_id"].nunique()) if len(res_b) else 1)
     rep = {name: sec for name, (_c, sec) in _trace.report().items() if not name.startswith("lib:")}
     solver_side = sum(sec for name, sec in rep.items() if name in ("MIP start", "solve (incl. lazy sweeps)", "post-solve sweeps + tables"))
-    return {"what": "sliding_window_matching (the reference's signature, src/same.py:297-307) on this job's frames, after the timed region, rank 0, one "
-                    "thread: (a) all windows with the greedy incumbent standing in for the solver half of run_same; (b) the windows of one corner of "
+    return {"what": "sliding_window_matching (the reference's signature, src/same.py:297-307) on this job's frames, after the timed "
+                    "region, rank 0, one "
+                    "thread: (a) all windows with the greedy incumbent standing in for the solver half of run_same; (b) the windows of one "
+                    "corner of "
                     "the section with a do-nothing gurobipy double: run_same's own Python around the solver",
             "pipeline": pipeline, "windows": len(plan), "seconds": t_a, "api_path_windows_per_s": len(plan) / t_a, "matches": int(len(res)),
-            "with_solver_double": {"windows": n_b, "cells": [int(len(m_c)), int(len(r_c))], "seconds_per_window": t_b / n_b, "windows_per_s": n_b / t_b,
+            "with_solver_double": {"windows": n_b, "cells": [int(len(m_c)), int(len(r_c))], "seconds_per_window": t_b / n_b,
+                                   "windows_per_s": n_b / t_b,
                                    "solver_side_python_s_per_window": solver_side / n_b,
-                                   "solver_side_means": "MIP start + optimize() of the double incl. one lazy callback + post-solve tables (stage "
-                                                        "markers of same_amd/_trace.py); the rest is model assembly (one Python object per pair, "
+                                   "solver_side_means": "MIP start + optimize() of the double incl. one lazy callback + post-solve tables "
+                                                        "(stage "
+                                                        "markers of same_amd/_trace.py); the rest is model assembly (one Python object per "
+                                                        "pair, "
                                                         "constraint and triangle) and the pre-MIP path",
                                    "matches": int(len(res_b))}}

@@ -63,7 +63,8 @@ def make_comm(args, group, tctx, what="pruned lists"):
     for RCCL's own use of the virtual-memory calls).  -> (comm or None, transport text)."""
     from same_amd.dist import HostTransport, RcclGroup
 
-    if not (group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM")):  # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
+    # the env switch exercises the RCCL branch on one GPU (size-1 communicator)
+    if not (group.world > 1 or os.environ.get("SAME_BENCH_FORCE_COMM")):
         return None, "none (single rank)"
     comm = None
     try:
@@ -76,7 +77,8 @@ def make_comm(args, group, tctx, what="pruned lists"):
         limit_s = float(os.environ.get("SAME_BENCH_RCCL_TIMEOUT", "300"))
 
         def stuck():
-            print(f"[rank {group.rank}] RCCL communicator init has not returned after {limit_s:.0f} s; giving up", file=sys.stderr, flush=True)
+            print(f"[rank {group.rank}] RCCL communicator init has not returned after {limit_s:.0f} s; giving up", file=sys.stderr,
+                  flush=True)
             os._exit(3)
 
         watchdog = threading.Timer(limit_s, stuck)

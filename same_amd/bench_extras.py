@@ -37,7 +37,8 @@ def measure_extras(args, env, prob, headline_buffer):
             out.append(ms.value)
         return float(np.mean(out[1:])) * 1e-3   # first launch of a new shape is a warm-up
 
-    t_store_only = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense T=0")
+    t_store_only = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld),
+                            "dense T=0")
     t_memset = timed_ms(lambda: L.same_dev_memset(H, dD.ptr, 0, rows * ld * 8), "memset")
     # device copy of half the block onto the other half: reads N bytes and writes N bytes, 2N bytes of HBM traffic
     half = (rows * ld * 8 // 2) & ~0xFFF
@@ -45,7 +46,8 @@ def measure_extras(args, env, prob, headline_buffer):
     extras["ceilings"] = {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_store_only / 1e9,
                           "hipMemsetAsync_GBs": 8.0 * ld * rows / t_memset / 1e9,
                           "device_copy_GBs": (2.0 * half / t_copy / 1e9) if t_copy else None,
-                          "device_copy_means": f"hipMemcpyAsync device-to-device of {half / 1e9:.1f} GB inside the cost block; read + written bytes over its time",
+                          "device_copy_means": f"hipMemcpyAsync device-to-device of {half / 1e9:.1f} GB inside the cost block; read + "
+                                               f"written bytes over its time",
                           "measured": "after the timed loop, warm chip, mean of 5 launches each"}
     # the same two stores into a plain hipMalloc buffer of this process, when the card has room for a second block
     if dD.spread_info and dD.spread_info["spread"]:
@@ -54,9 +56,11 @@ def measure_extras(args, env, prob, headline_buffer):
         except _lib.SameHipError:
             plain = None
         if plain is not None:
-            t_p = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, plain.ptr, ld), "dense T=0 (plain)")
+            t_p = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, plain.ptr, ld),
+                           "dense T=0 (plain)")
             t_pm = timed_ms(lambda: L.same_dev_memset(H, plain.ptr, 0, rows * ld * 8), "memset (plain)")
-            t_pT = None if use_q32 else timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, plain.ptr, ld), "dense (plain)")
+            t_pT = None if use_q32 else timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, T, dax.ptr, drx.ptr, n_ref, 0, rows,
+                                                                      1.0, plain.ptr, ld), "dense (plain)")
             extras["ceilings"]["plain_hipMalloc_buffer"] = {
                 "same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_p / 1e9, "hipMemsetAsync_GBs": 8.0 * ld * rows / t_pm / 1e9,
                 "bench_kernel_ms": None if t_pT is None else t_pT * 1e3,
@@ -80,13 +84,17 @@ def measure_extras(args, env, prob, headline_buffer):
     pc_bytes = 8.0 * (T + 2) * (n_ref + rows) + 16.0 * k * rows
     extras["pruned_path"] = {"ms": t_pc * 1e3, "cell_pairs_per_s": float(n_ref) * rows / t_pc, "algorithmic_bytes": pc_bytes,
                              "GBs": pc_bytes / t_pc / 1e9,
-                             "what": f"same_knn_prune_indexed_dev (r={radius:g}, k={k}, caller-held grid index) + same_padded_cost_f64_dev for {rows} aligned rows "
-                                     f"against {n_ref} refs, alone on its stream: dense-equivalent pairs covered per second without materialising the matrix "
+                             "what": f"same_knn_prune_indexed_dev (r={radius:g}, k={k}, caller-held grid index) + same_padded_cost_f64_dev "
+                                     f"for {rows} aligned rows "
+                                     f"against {n_ref} refs, alone on its stream: dense-equivalent pairs covered per second without "
+                                     f"materialising the matrix "
                                      "(latency / gather-bound, no roofline fraction claimed)"}
-    sw_bytes = Tr * (74 + (12 + 3 * 40 + 1) + (12 + 12 + 96 + 16 + 4) + (12 + 48 + 12 + 1 + 16) + (12 + 48 + 24 + 1 + 8)) + n_mov   # SURVEY 8d / DESIGN 5 per-unit figures
+    # SURVEY 8d / DESIGN 5 per-unit figures
+    sw_bytes = Tr * (74 + (12 + 3 * 40 + 1) + (12 + 12 + 96 + 16 + 4) + (12 + 48 + 12 + 1 + 16) + (12 + 48 + 24 + 1 + 8)) + n_mov
     extras["triangle_maps_and_sweeps"] = {"ms": t_sw * 1e3, "triangles": Tr, "triangles_per_s": Tr / t_sw, "touched_bytes": sw_bytes,
                                           "GBs": sw_bytes / t_sw / 1e9,
-                                          "what": "classify + weights / signs + XY-order sweep + area flips + orientation sweep incl. its read-back, alone on its stream"}
+                                          "what": "classify + weights / signs + XY-order sweep + area flips + orientation sweep incl. its "
+                                                  "read-back, alone on its stream"}
     # SURVEY 8d's second input variant: moving = refs + N(0, 2^2) jitter with 5 % of the rows dropped, matched by the greedy MIP
     # start (src/init_helpers.py:104-133) -- a realistic matching, so the sweeps see few, local flips instead of the dense
     # disorder of two independent sections.  Through the host-buffer entry points (PCIe included), one pass, untimed region.
@@ -115,8 +123,10 @@ def measure_extras(args, env, prob, headline_buffer):
     _jb, _ja, _jm3, jflip = _ops.area_flip(jm["xy"], ref["xy"], jt, jmatch, ctx=tctx)
     j4 = time.perf_counter()
     extras["realistic_matching"] = {
-        "what": f"moving = refs + N(0, 2^2) jitter, 5 % of rows dropped ({len(jm['xy'])} aligned cells, {len(jt)} triangles); prune (r={radius:g}, k={k}) + "
-                "fp64 pair costs + greedy MIP start on the device, then the three sweeps under that matching; host-buffer entry points, one pass",
+        "what": f"moving = refs + N(0, 2^2) jitter, 5 % of rows dropped ({len(jm['xy'])} aligned cells, {len(jt)} triangles); prune "
+                f"(r={radius:g}, k={k}) + "
+                "fp64 pair costs + greedy MIP start on the device, then the three sweeps under that matching; host-buffer entry points, "
+                "one pass",
         "pairs": int(len(jpairs)), "matched_rows": int(len(jai)), "greedy_rounds": int(jrounds), "prune_costs_start_ms": (j1 - j0) * 1e3,
         "orientation_sweep_ms": (j3 - j2) * 1e3, "orientation_checked": int(jchecked), "orientation_flipped": int(len(jviol)),
         "xyorder_and_area_ms": (j4 - j3) * 1e3, "xy_comparisons": int(jcounts[0]), "xy_violations": int(jcounts[1]),
@@ -134,7 +144,8 @@ def measure_extras(args, env, prob, headline_buffer):
             prob.dense_time(loop_ms)
         tele = tel.stop()
         tele["dense_ms_during_window"] = float(np.mean([m for m, _ in loop_ms]))
-        tele["what"] = f"dense kernel (T={T}, fp64) looped alone for the window ({tele.get('window_s', 0):.1f} s); sysfs read every {tel.period * 1e3:.0f} ms by a side thread"
+        tele["what"] = (f"dense kernel (T={T}, fp64) looped alone for the window ({tele.get('window_s', 0):.1f} s); sysfs read every "
+                        f"{tel.period * 1e3:.0f} ms by a side thread")
     else:
         tele = {"available": False, "reason": f"no readable power/clock nodes under {tel.dev_dir}"}
     extras["telemetry"] = tele
@@ -145,9 +156,11 @@ def measure_extras(args, env, prob, headline_buffer):
         dD = prob.respread()
     sweep_buffer = "spread over the HBM regions" if (dD.spread_info and dD.spread_info["spread"]) else "plain hipMalloc"
     if not headline_buffer.get("spread") and dD.spread_info and dD.spread_info["spread"]:
-        t_sp = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld), "dense T=0 (spread)")
+        t_sp = timed_ms(lambda: L.same_dense_cost_f64_dev(H, dA.ptr, dR.ptr, 0, dax.ptr, drx.ptr, n_ref, 0, rows, 1.0, dD.ptr, ld),
+                        "dense T=0 (spread)")
         extras["ceilings"]["spread_buffer"] = {"same_kernel_T0_store_only_GBs": 8.0 * n_ref * rows / t_sp / 1e9, "info": dD.spread_info,
-                                               "what": "the block re-taken through same_dev_alloc_spread for the T sweep below (after the timed region)"}
+                                               "what": "the block re-taken through same_dev_alloc_spread for the T sweep below (after the "
+                                                       "timed region)"}
     sweep_rows = []
     for dt_name, T_s in (("f64", 3), ("f64", 5), ("f64", 8), ("f64", 16), ("f64", 20), ("f32", 20)):
         npdt = np.float64 if dt_name == "f64" else np.float32
@@ -157,7 +170,8 @@ def measure_extras(args, env, prob, headline_buffer):
                 ctx.to_device(m_s["xy"].astype(npdt)), ctx.to_device(r_s["xy"].astype(npdt))]
         fn = L.same_dense_cost_f64_dev if dt_name == "f64" else L.same_dense_cost_f32_dev
         ld_s = ld if dt_name == "f64" else (n_ref + 3) & ~3
-        t_s = timed_ms(lambda: fn(H, bufs[0].ptr, bufs[1].ptr, T_s, bufs[2].ptr, bufs[3].ptr, n_ref, 0, rows, 1.0, dD.ptr, ld_s), "dense sweep")
+        t_s = timed_ms(lambda: fn(H, bufs[0].ptr, bufs[1].ptr, T_s, bufs[2].ptr, bufs[3].ptr, n_ref, 0, rows, 1.0, dD.ptr, ld_s),
+                       "dense sweep")
         by = es * float(n_ref) * rows + es * (T_s + 2) * (n_ref + rows)
         sweep_rows.append({"dtype": dt_name, "T": T_s, "kernel": dense_kernel_label(dt_name, T_s), "ms": t_s * 1e3,
                            "GBs": by / t_s / 1e9, "frac": by / t_s / 1e9 / HBM_PEAK_GBS, "output_buffer": sweep_buffer})

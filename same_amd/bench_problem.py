@@ -108,7 +108,8 @@ class Problem:
         self.sweep = ctypes.c_void_p()
         chk(L.same_sweep_bind(TH, tris.ctypes.data, Tr, self.sign0.ctypes.data, ref["xy"].ctypes.data, n_ref, n_mov, None, 0,
                               ctypes.byref(self.sweep)), "bind")
-        self.sharded = ShardedSweeps(tctx, comm, self.sweep, self.dax, self.drx, self.dtris, Tr, n_mov) if (strong and comm is not None) else None
+        self.sharded = ShardedSweeps(tctx, comm, self.sweep, self.dax, self.drx, self.dtris, Tr,
+                                     n_mov) if (strong and comm is not None) else None
         self.checked, self.nviol = ctypes.c_int64(0), ctypes.c_int64(0)
         self.viol = np.empty(max(Tr, 1), np.int32)
         self.last = {"checked": 0, "viol": self.viol[:0]}
@@ -157,7 +158,8 @@ class Problem:
 
     def prune_and_costs(self):
         L, TH, chk = self.env.L, self.env.TH, self.env.chk
-        chk(L.same_knn_prune_indexed_dev(TH, self.knn_index, self.dax.ptr, self.rb, self.re, self.k, self.didx.ptr, None, self.dcnt.ptr), "knn")
+        chk(L.same_knn_prune_indexed_dev(TH, self.knn_index, self.dax.ptr, self.rb, self.re, self.k, self.didx.ptr, None, self.dcnt.ptr),
+            "knn")
         chk(L.same_padded_cost_f64_dev(TH, self.dA.ptr, self.dR.ptr, self.T, self.dax.ptr, self.drx.ptr, self.rb, self.re, self.k,
                                        self.didx.ptr, 1.0, self.dcost.ptr), "padded")
 
@@ -171,9 +173,11 @@ class Problem:
         L, TH, chk, c = self.env.L, self.env.TH, self.env.chk, self.ctypes
         chk(L.same_xyorder_sweep_dev(TH, self.dax.ptr, self.n_mov, self.drx.ptr, self.dtris.ptr, self.Tr, self.dmatch.ptr, self.dedge.ptr,
                                      self.dtflag.ptr, self.dpflag.ptr, self.dcounts.ptr), "xy")
-        chk(L.same_area_flip_dev(TH, self.dax.ptr, self.drx.ptr, self.dtris.ptr, self.Tr, self.dmatch.ptr, self.dbefore.ptr, self.dafter.ptr,
+        chk(L.same_area_flip_dev(TH, self.dax.ptr, self.drx.ptr, self.dtris.ptr, self.Tr, self.dmatch.ptr, self.dbefore.ptr,
+                                 self.dafter.ptr,
                                  self.dm3.ptr, self.dflip.ptr), "area")
-        chk(L.same_orient_sweep_dev(self.sweep, self.dmatch.ptr, c.byref(self.checked), self.viol.ctypes.data, c.byref(self.nviol)), "orient")
+        chk(L.same_orient_sweep_dev(self.sweep, self.dmatch.ptr, c.byref(self.checked), self.viol.ctypes.data, c.byref(self.nviol)),
+            "orient")
         self.last["checked"], self.last["viol"] = self.checked.value, self.viol[: self.nviol.value]
 
     def _gather_read(self):
@@ -257,7 +261,8 @@ class Problem:
         pA, pxy = tctx.to_device(peer_mov["types"]), tctx.to_device(peer_mov["xy"])
         pidx, pcost, pcnt = tctx.alloc(S * k * 4), tctx.alloc(S * k * 8), tctx.alloc(S * 4)
         chk(L.same_knn_prune_indexed_dev(TH, self.knn_index, pxy.ptr, p0, p0 + S, k, pidx.ptr, None, pcnt.ptr), "knn")
-        chk(L.same_padded_cost_f64_dev(TH, pA.ptr, self.dR.ptr, self.T, pxy.ptr, self.drx.ptr, p0, p0 + S, k, pidx.ptr, 1.0, pcost.ptr), "padded")
+        chk(L.same_padded_cost_f64_dev(TH, pA.ptr, self.dR.ptr, self.T, pxy.ptr, self.drx.ptr, p0, p0 + S, k, pidx.ptr, 1.0, pcost.ptr),
+            "padded")
         want_i, want_c = pidx.download((S, k), np.int32), pcost.download((S, k), np.float64)
         got_i = self.gidx.download((S, k), np.int32, offset_bytes=peer * self.block * k * 4)
         got_c = self.gcost.download((S, k), np.float64, offset_bytes=peer * self.block * k * 8)

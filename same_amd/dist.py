@@ -359,7 +359,8 @@ class ShardedSweeps:
 
     def close(self):
         """Free the device blocks this object allocated (the bound sweep, the operands and the communicator are the caller's)."""
-        for name in ("flag_l", "flag_g", "edge_l", "edge_g", "tflag_l", "tflag_g", "m3_l", "m3_g", "flip_l", "flip_g", "before_l", "before_g",
+        for name in ("flag_l", "flag_g", "edge_l", "edge_g", "tflag_l", "tflag_g", "m3_l", "m3_g", "flip_l", "flip_g", "before_l",
+                     "before_g",
                      "after_l", "after_g", "pflag", "counts"):
             buf = getattr(self, name, None)
             if buf is not None:
@@ -423,7 +424,8 @@ def allgather_table(ctx, comm, group, table):
     blob = _pack_table(cols, arrs, n)
     if ctx is None:
         return [_unpack_table(raw, cols, arrs, r) for r, raw in enumerate(group.allgather_bytes(blob))]
-    if getattr(comm, "synchronous", False):     # host transport (no RCCL communicator): the block is host bytes already -- no device round trip
+    # host transport (no RCCL communicator): the block is host bytes already -- no device round trip
+    if getattr(comm, "synchronous", False):
         import time
 
         t0 = time.perf_counter()

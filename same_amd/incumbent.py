@@ -63,7 +63,8 @@ class _TableBuilder:
         # a frame's column may be a strided view of its block (a frame made from a 2-D array): np.take would copy such a source whole on
         # EVERY call, so the 1-D sources are made contiguous here, once per job (no copy where they already are)
         col = lambda df, c: np.ascontiguousarray(df[c].to_numpy())
-        self.type_block = sections[1].types if (all(mov[c].dtype == f64 for c in self.cts) and len(set(self.cts)) == len(self.cts)) else None
+        plain_types = all(mov[c].dtype == f64 for c in self.cts) and len(set(self.cts)) == len(self.cts)
+        self.type_block = sections[1].types if plain_types else None
         self.type_cols = None if self.type_block is not None else [col(mov, c) for c in self.cts]
         both_xy = all(df[c].dtype == f64 for df in (ref, mov) for c in ("X", "Y"))
         self.mov_xy, self.ref_xy = (sections[1].xy, sections[0].xy) if both_xy else (None, None)
@@ -148,7 +149,8 @@ class _TableBuilder:
         def fill(lo):
             hi = min(n, lo + _TableBuilder.SLICE)
             a, r = ra[lo:hi], rr[lo:hi]
-            take = np.take           # np.take(src, rows, axis=0) copies whole rows: 3-6x the speed of src[rows] on the (n, 8) / (n, 2) blocks
+            # np.take(src, rows, axis=0) copies whole rows: 3-6x the speed of src[rows] on the (n, 8) / (n, 2) blocks
+            take = np.take
             if not types_wanted:
                 pass
             elif me.type_block is not None:
@@ -177,7 +179,8 @@ class _TableBuilder:
                 take(me.mov_id, a, out=out[cid_a][lo:hi], mode="clip")
 
         gathers_any = types_wanted or xy_wanted or any(want(k) and src is not None for k, src in
-                                                        (("size", me.mov_size), ("ref_size", me.ref_size), (cid_r, me.ref_id), (cid_a, me.mov_id)))
+                                                        (("size", me.mov_size), ("ref_size", me.ref_size), (cid_r, me.ref_id),
+                                                         (cid_a, me.mov_id)))
         starts = range(0, n, _TableBuilder.SLICE)
         if not gathers_any:
             pass
@@ -200,7 +203,8 @@ class _TableBuilder:
         n = acc.n_final
         with stage("table: page-locked block + the device's gather enqueued"):
             extra = frames.table_columns(self.cid)
-            got = acc.columns(frames.dmov, frames.dref, n, len(self.cts), [b for _n, b, _d in extra["mov"]], [b for _n, b, _d in extra["ref"]])
+            got = acc.columns(frames.dmov, frames.dref, n, len(self.cts), [b for _n, b, _d in extra["mov"]],
+                              [b for _n, b, _d in extra["ref"]])
         if got is None:
             return None
         wide, flags = got
@@ -212,7 +216,8 @@ class _TableBuilder:
         host = {}
         if missing:            # beside the device's gather (which was only enqueued)
             final = acc.final_rows()
-            host = self.gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), None, None, None, None, None, only=set(missing))
+            host = self.gather(final["a_row"].astype(np.int64), final["r_row"].astype(np.int64), None, None, None, None, None,
+                               only=set(missing))
         with stage("table: wait for the device's columns"):
             acc.ctx.sync()
         with stage("table: the frame over the block"):
@@ -413,7 +418,8 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
     sections = (frames.ref_sec, frames.mov_sec)
     builders = [_TableBuilder(job, sections, with_ref_idx) for _ in range(n_workers)]
     lock = threading.Lock()
-    cut = [len(job.todo) * q // n_workers for q in range(n_workers + 1)]          # worker q walks a contiguous run of this process's windows
+    # worker q walks a contiguous run of this process's windows
+    cut = [len(job.todo) * q // n_workers for q in range(n_workers + 1)]
     # merge=True: the windows' matches stay where they are.  Every batch's central rows join the pass's accumulator on the device
     # (csrc/window_merge.hip); the merge runs there, and only what it could not decide alone comes to the host (`_merge_on_device`).
     # (window_local_indices needs every window's pair list on the host: the keys go through the builders then, `_merged_rows`.)
@@ -429,7 +435,8 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
         if accs is not None:
             collector = lambda states, windows: accs[q].collect(states, [w["trim"] for w in windows], [w["window_id"] for w in windows],
                                                                 [pos_of[id(w)] for w in windows])
-        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator, collector=collector, batch=batch)):
+        for (pos, w), dw in zip(mine, frames.windows([w for _p, w in mine], ctx=contexts[q], triangulator=triangulator,
+                                                     collector=collector, batch=batch)):
             if dw.error is not None:
                 raise dw.error
             with stage("table rows (central trim)"):
@@ -544,7 +551,8 @@ def _merge_on_device(job, frames, accs, channel):
         with stage("merge: seam step (the same on every rank)"):
             rows = np.concatenate((mine, _seam_step_on_device(frames, ctx0, parts, channel.rank)))
     with stage("merge: winners to the device, final rows in order"):
-        accs[0].finish(rest["row"][rows], fetch=False)          # the rows stay on the device: the table's columns are gathered from them there
+        # the rows stay on the device: the table's columns are gathered from them there
+        accs[0].finish(rest["row"][rows], fetch=False)
     _count_merge_calls(frames, ctx0, calls0)
     return accs[0]
 
@@ -584,7 +592,8 @@ def _general_route(job, frames, with_ref_idx, stats, ctx):
     def prepared():
         if frames is not None:
             plan = [w for _pos, w in job.todo]
-            for (pos, w), dw in zip(job.todo, frames.windows(plan, triangulate=not job.caller_triangulation, ctx=ctx, fetch_triangles=True)):
+            for (pos, w), dw in zip(job.todo, frames.windows(plan, triangulate=not job.caller_triangulation, ctx=ctx,
+                                                             fetch_triangles=True)):
                 if dw.error is not None:
                     raise _window_error(dw, op)
                 if job.caller_triangulation:
@@ -603,7 +612,8 @@ def _general_route(job, frames, with_ref_idx, stats, ctx):
             for nxt in range(q, min(q + 1 + depth, len(job.todo))):
                 if nxt not in ahead:
                     box = job.todo[nxt][1]["box"]
-                    ahead[nxt] = _stage_prune(ref_rows.subset(*box), moving_rows.subset(*box), commonCT, job.moving_delaunay, job.vertex_col, op, gp,
+                    ahead[nxt] = _stage_prune(ref_rows.subset(*box), moving_rows.subset(*box), commonCT, job.moving_delaunay,
+                                              job.vertex_col, op, gp,
                                               job.ignore_pre, False, ctx, prefetch=True, fresh_frames=True)
             yield pos, w, prepare_same_inputs(None, None, commonCT, verbose=False, ctx=ctx, _staged=ahead.pop(q))
 

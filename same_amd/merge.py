@@ -28,7 +28,8 @@ def load_matching_results(outprefix):
             pd.read_csv(os.path.join(outprefix, "matches_df.csv")))
 
 
-GATHER_THREADS = 8      # column-parallel copies of a 10^6-row table (22 columns x 950k rows on a 16-CPU host: 16.9 ms on one thread, 4.5 on four, 1.9 on eight)
+# column-parallel copies of a 10^6-row table (22 columns x 950k rows on a 16-CPU host: 16.9 ms on one thread, 4.5 on four, 1.9 on eight)
+GATHER_THREADS = 8
 
 
 def _window_codes(window_id):
@@ -114,7 +115,8 @@ def _resolve_rows(a_ids, r_ids, viol, window_id, dedup, seam=None, mark=True):
         deg_a, deg_r = np.bincount(a_codes, minlength=n_a), np.bincount(r_codes, minlength=n_r)
         row_of = np.full(n_a, -1, np.int64)
         shared = np.zeros(len(kept), bool) if seam is None else np.asarray(seam, dtype=bool)[kept]
-        if len(a_codes) == 0 or (deg_a.max() <= 1 and deg_r.max() <= 1):      # nobody disagrees (a tiled run whose overlaps agree): all edges stand
+        # nobody disagrees (a tiled run whose overlaps agree): all edges stand
+        if len(a_codes) == 0 or (deg_a.max() <= 1 and deg_r.max() <= 1):
             rest = np.zeros(0, np.int64)
             lone_at = np.flatnonzero(~shared) if seam is not None else np.arange(len(a_codes), dtype=np.int64)
         else:
@@ -133,7 +135,8 @@ def _resolve_rows(a_ids, r_ids, viol, window_id, dedup, seam=None, mark=True):
             n1, n2 = int(a_new[-1]) + 1, int(r_new[-1]) + 1
             if seam is not None and shared.any():
                 # contested rows whose component holds a shared row go to the common step with it; the rest is matched here
-                _n, label = connected_components(coo_matrix((np.ones(len(ai), np.int8), (ai, n1 + ri)), shape=(n1 + n2, n1 + n2)), directed=False)
+                _n, label = connected_components(coo_matrix((np.ones(len(ai), np.int8), (ai, n1 + ri)), shape=(n1 + n2, n1 + n2)),
+                                                 directed=False)
                 tainted = np.zeros(_n, bool)
                 tainted[label[ai[shared[rest]]]] = True
                 away = tainted[label[ai]]
@@ -146,7 +149,8 @@ def _resolve_rows(a_ids, r_ids, viol, window_id, dedup, seam=None, mark=True):
                 graph.sort_indices()
     with marked("merge: maximum matching"):
         if graph is not None:
-            match_r = maximum_bipartite_matching(graph, perm_type="column")  # ref node matched to each aligned node, -1 = none (structure only)
+            # ref node matched to each aligned node, -1 = none (structure only)
+            match_r = maximum_bipartite_matching(graph, perm_type="column")
     with marked("merge: rows of the matched pairs"):
         if graph is not None:
             node_of_edge = np.repeat(np.arange(graph.shape[0], dtype=np.int64), np.diff(graph.indptr))
@@ -160,7 +164,9 @@ def _device_dedup(ctx=None):
     """the device step (ops.merge_dedup on `ctx`); there is no host substitute in the product: a missing GPU raises SameHipError"""
     from . import ops
 
-    return ops.merge_dedup if ctx is None else (lambda viol, window_id, a_code, r_code: ops.merge_dedup(viol, window_id, a_code, r_code, ctx=ctx))
+    if ctx is None:
+        return ops.merge_dedup
+    return lambda viol, window_id, a_code, r_code: ops.merge_dedup(viol, window_id, a_code, r_code, ctx=ctx)
 
 
 def merge_window_matches_unique_ref(matches_list, cell_id_col="Cell_Num_Old", _dedup=None):

@@ -143,7 +143,8 @@ def local_world():
     return n, min(max(0, r or 0), n - 1)
 
 
-_LEARNED_SHARERS = None      # (ranks whose CPUs overlap this rank's, this rank's index among them), from the ranks' own masks (learn_cpu_sharing)
+# (ranks whose CPUs overlap this rank's, this rank's index among them), from the ranks' own masks (learn_cpu_sharing)
+_LEARNED_SHARERS = None
 
 
 def learn_cpu_sharing(group):
@@ -356,7 +357,8 @@ class QhullPool:
             head = p.stdout.read(20)
             if len(head) == 20:
                 magic, seq, n = struct.unpack("<iqq", head)
-                if magic == _MAGIC and seq == ticket.seq and 0 <= n <= 4 * len(ticket.points) + 16:   # a planar triangulation has < 2n triangles
+                # a planar triangulation has < 2n triangles
+                if magic == _MAGIC and seq == ticket.seq and 0 <= n <= 4 * len(ticket.points) + 16:
                     raw = p.stdout.read(12 * n)
                     if len(raw) == 12 * n:
                         return np.frombuffer(raw, np.int32).reshape(n, 3).copy()

@@ -85,7 +85,8 @@ def _enc(o, blobs):
             np.save(buf, np.ascontiguousarray(o), allow_pickle=False)
             blobs.append(buf.getvalue())
             return {"__nd__": len(blobs) - 1}
-        return {"__ndo__": [_enc(x, blobs) for x in o.reshape(-1).tolist()], "shape": list(o.shape), "dtype": o.dtype.str if o.dtype.kind in "US" else "O"}
+        return {"__ndo__": [_enc(x, blobs) for x in o.reshape(-1).tolist()], "shape": list(o.shape),
+                "dtype": o.dtype.str if o.dtype.kind in "US" else "O"}
     if isinstance(o, tuple):
         return {"__t__": [_enc(x, blobs) for x in o]}
     if isinstance(o, (list, set, frozenset)):
@@ -99,7 +100,8 @@ def _enc(o, blobs):
     if pd is not None and isinstance(o, pd.DataFrame):
         return {"__df__": {"columns": [_enc(c, blobs) for c in o.columns], "data": [_enc(o[c].to_numpy(), blobs) for c in o.columns],
                            "index": _enc(o.index.to_numpy(), blobs)}}
-    raise TypeError(f"allgather_object cannot carry a {type(o).__name__} (numbers, strings, lists, dicts, numpy arrays and pandas frames only)")
+    raise TypeError(f"allgather_object cannot carry a {type(o).__name__} (numbers, strings, lists, dicts, numpy arrays and pandas frames "
+                    f"only)")
 
 
 def _dec(o, blobs):

@@ -58,7 +58,8 @@ class _WindowSubsetter:
 def _window_frame(df, rows, vertex_col=None, aligned=False):
     """Rows `rows` of the caller's frame as the frame run_same holds after its prune: the helper columns of src/same.py:934-970
     (size default, __orig_idx = the caller's index labels, __tri_vid on the aligned side) and the renumbering of src/utils.py:739-740."""
-    out = df.iloc[rows].copy(deep=False)          # iloc with a row list makes fresh data; the shallow copy only drops pandas' "copy of a slice" mark
+    # iloc with a row list makes fresh data; the shallow copy only drops pandas' "copy of a slice" mark
+    out = df.iloc[rows].copy(deep=False)
     labels = out.index.to_numpy()
     out.index = pd.RangeIndex(len(out))           # the renumbering, in place: reset_index(drop=True) would copy every block once more
     if "size" not in out.columns:
@@ -200,7 +201,8 @@ class _DeviceFrames:
             def eligible(df, names):
                 out = []
                 for column, name in names:
-                    if column in df.columns and isinstance(df[column].dtype, np.dtype) and df[column].dtype.kind in "iuf" and df[column].dtype.itemsize == 8:
+                    dt = df[column].dtype if column in df.columns else None
+                    if isinstance(dt, np.dtype) and dt.kind in "iuf" and dt.itemsize == 8:
                         host = np.ascontiguousarray(df[column].to_numpy())
                         out.append((name, self.ctx.to_device(host.view(np.uint64)), host.dtype))
                 return out
@@ -235,7 +237,8 @@ class _DeviceFrames:
 def _window_error(dw, optim_params):
     """What the reference raises for a window whose prune finds no pair: run_same's ValueError (src/same.py:1003) -- unless the
     cell-type-priority prune is on, whose summary print divides by the number of rows that kept a pair first (src/knn_utils.py:76)."""
-    if optim_params["ignore_knn_if_matched"] and isinstance(dw.error, ValueError) and str(dw.error).startswith("No valid_pairs after KNN filtering"):
+    no_pairs = isinstance(dw.error, ValueError) and str(dw.error).startswith("No valid_pairs after KNN filtering")
+    if optim_params["ignore_knn_if_matched"] and no_pairs:
         return ZeroDivisionError("division by zero")
     return dw.error
 
@@ -272,7 +275,8 @@ def _prepared_from_device(dw, frames, optim_params, gurobi_params, verbose=True,
 
         n_r = max(len(rows_r), 1)
         kept, same_type, keep_all = priority_filter(valid_pairs, dw.axy, frames.ref_sec.xy[rows_r],
-                                                    frames.moving["cell_type"].to_numpy()[rows_m], frames.ref["cell_type"].to_numpy()[rows_r])
+                                                    frames.moving["cell_type"].to_numpy()[rows_m],
+                                                    frames.ref["cell_type"].to_numpy()[rows_r])
         key = valid_pairs[:, 0] * n_r + valid_pairs[:, 1]
         order = np.argsort(key, kind="stable")
         costs = costs[order[np.searchsorted(key[order], kept[:, 0] * n_r + kept[:, 1])]]
@@ -283,7 +287,8 @@ def _prepared_from_device(dw, frames, optim_params, gurobi_params, verbose=True,
     signs = st.fetch(_W_SIGNS).astype(np.float64)
     weights = st.fetch(_W_WEIGHTS)
     if np.issubdtype(frames.mov_sec.size.dtype, np.integer):
-        weights = weights.astype(np.int64)       # integer size columns sum to integers in the reference (triangles.triangle_weights_and_signs)
+        # integer size columns sum to integers in the reference (triangles.triangle_weights_and_signs)
+        weights = weights.astype(np.int64)
     prep = PreparedInputs(lambda: _window_frame(frames.moving, rows_m, vertex_col, aligned=True), lambda: _window_frame(frames.ref, rows_r),
                           valid_pairs, costs, tris, weights, signs, set(), False, optim_params, gurobi_params,
                           n_aligned=len(rows_m), n_ref=len(rows_r))
@@ -306,7 +311,8 @@ def _staged_from_device(dw, frames, commonCT, optim_params, gurobi_params, calle
         if optim_params["ignore_knn_if_matched"]:
             from .knn import priority_filter
 
-            kept, same_type, keep_all = priority_filter(valid_pairs, dw.axy, frames.ref_sec.xy[rows_r], st.aligned_df["cell_type"].to_numpy(),
+            kept, same_type, keep_all = priority_filter(valid_pairs, dw.axy, frames.ref_sec.xy[rows_r],
+                                                        st.aligned_df["cell_type"].to_numpy(),
                                                         st.ref_df["cell_type"].to_numpy())
             valid_pairs = list(zip(kept[:, 0].tolist(), kept[:, 1].tolist()))
             _say(verbose, f"Total pairs after filtering: {len(valid_pairs)}")
@@ -368,7 +374,8 @@ class _WindowJob:
                  ignore_precomputed_triangulation, shard, resident=None):
         from .windows import window_grid, window_plan
 
-        if isinstance(ref, ResidentFrames):          # the caller's frames are on the device already (resident_frames): both arguments may name it
+        # the caller's frames are on the device already (resident_frames): both arguments may name it
+        if isinstance(ref, ResidentFrames):
             resident = ref
         if isinstance(moving, ResidentFrames):
             resident = moving
@@ -511,7 +518,8 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
             for w, dw in zip(plan, frames.windows(plan, ctx=ctx)):
                 if dw.error is not None:
                     err = _window_error(dw, op)
-                    if not isinstance(err, ValueError):      # only run_same's own ValueError is a window's answer; anything else ends the walk
+                    # only run_same's own ValueError is a window's answer; anything else ends the walk
+                    if not isinstance(err, ValueError):
                         raise err
                     yield w, err
                 else:
@@ -576,7 +584,8 @@ def _solver_windows_on_device(job, frames, run_window, solve=None):
     """The window loop with both frames resident on the device: per window two library calls + the triangulation; the frames a window's
     run_same body reads are made from the device's row lists."""
     commonCT, op, gp = job.commonCT, job.optim_params, job.gurobi_params
-    if run_window is not None:            # a stand-in for run_same takes the window's frames: subset_data of both, from the device's row lists
+    # a stand-in for run_same takes the window's frames: subset_data of both, from the device's row lists
+    if run_window is not None:
         from .windows import DeviceWindow
 
         state = DeviceWindow(frames.ctx)

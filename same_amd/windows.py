@@ -314,7 +314,8 @@ def iter_window_arrays(ref, moving, plan, radius=250, knn=8, dist_ct_coeff=1.0, 
         with marked("triangle filter"):
             tid = moving.g_type_id[pos_m] if (ignore_same_type_triangles and moving.g_type_id is not None) else None
             out.triangles = filter_triangles_by_radius(out.axy, tris, radius, ignore_same_type_triangles=ignore_same_type_triangles,
-                                                       min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
+                                                       min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True,
+                                                       _type_id=tid)
         with marked("triangle weights + source signs"):
             out.size = moving.g_size[pos_m]
             sign, weight = ops.tri_sign_weight(out.axy, out.size.astype(np.float64), out.triangles, ctx=ctx)
@@ -349,8 +350,10 @@ def window_cell_grid(plan_or_grid, window_size, overlap):
     xs, ys = plan_or_grid
     step = int(window_size) - int(overlap)
     cell = float(math.gcd(step, int(window_size)))
-    if window_size / cell > 5:          # a window of more than ~5 x 5 such cells (8 x 8 once merged) would leave the cell-run path (<= 64 cells):
-        cell = window_size / 4.0        # quarter windows instead -- boxes then cut through cells and their candidates are tested, still O(window)
+    # a window of more than ~5 x 5 such cells (8 x 8 once merged) would leave the cell-run path (<= 64 cells):
+    if window_size / cell > 5:
+        # quarter windows instead -- boxes then cut through cells and their candidates are tested, still O(window)
+        cell = window_size / 4.0
     return float(xs[0]), float(ys[0]), cell
 
 
@@ -382,7 +385,8 @@ class DeviceSection:
 
     def bin(self, x0, y0, cell_w, cell_h=None):
         with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_section_bin(self.handle, float(x0), float(y0), float(cell_w), float(cell_w if cell_h is None else cell_h)),
+            self.ctx.check(self.ctx.lib.same_section_bin(self.handle, float(x0), float(y0), float(cell_w),
+                                                         float(cell_w if cell_h is None else cell_h)),
                            "same_section_bin")
         return self
 
@@ -391,7 +395,8 @@ class DeviceSection:
         None: a row's code is its number."""
         c = None if codes is None else np.ascontiguousarray(codes, dtype=np.int32)
         with self.ctx.lock:
-            self.ctx.check(self.ctx.lib.same_section_set_codes(self.handle, None if c is None else c.ctypes.data, int(n_codes)), "same_section_set_codes")
+            self.ctx.check(self.ctx.lib.same_section_set_codes(self.handle, None if c is None else c.ctypes.data, int(n_codes)),
+                           "same_section_set_codes")
 
     def close(self):
         if getattr(self, "handle", None) and self.ctx.handle:        # a context that is already gone took its device memory along
@@ -429,7 +434,8 @@ class DeviceWindow:
         return stage_windows([self], moving, ref, [box], radius, knn, dist_ct_coeff)[0]
 
     # what -> (dtype, which count gives the length: 0 aligned in box, 1 refs in box, 2 kept, 3 pairs, 4 triangles, trailing width)
-    _FETCH = {_W_ALIGNED_XY: (np.float64, 2, 2), _W_ALIGNED_ROWS: (np.int32, 2, 0), _W_ROWS_M: (np.int32, 0, 0), _W_ROWS_R: (np.int32, 1, 0),
+    _FETCH = {_W_ALIGNED_XY: (np.float64, 2, 2), _W_ALIGNED_ROWS: (np.int32, 2, 0), _W_ROWS_M: (np.int32, 0, 0),
+              _W_ROWS_R: (np.int32, 1, 0),
               _W_PAIRS: (np.int32, 3, 2), _W_COSTS: (np.float64, 3, 0), _W_KEPT: (np.int32, 2, 0), _W_SIGNS: (np.int8, 4, 0),
               _W_WEIGHTS: (np.float64, 4, 0), _W_MATCH: (np.int32, 2, 0), _W_TRIANGLES: (np.int32, 4, 3)}
 
@@ -443,7 +449,8 @@ class DeviceWindow:
 
     STAT_NAMES = ("checked", "flipped", "xy_comparisons", "xy_violations", "xy_triangles", "area_flips", "greedy_rounds", "matched")
 
-    def filter_finish(self, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, no_match_penalty, ensure_min_triangle_per_node=True):
+    def filter_finish(self, simplices, radius, angle_enabled, cos_thr, near_tol, ignore_same_type, no_match_penalty,
+                      ensure_min_triangle_per_node=True):
         """filter_triangles_by_radius of the kept aligned cells' Delaunay simplices, then signs, weights, the greedy incumbent and the three
         sweeps, in one call.  -> (kept, added back, near, match_row, flag, stats); with near != 0 (cosines within near_tol of the
         threshold) the last three are None and the caller filters on the host and calls finish() with its triangles."""
@@ -451,8 +458,9 @@ class DeviceWindow:
                                      ensure_min_triangle_per_node)[0]
 
     def finish(self, triangles, no_match_penalty):
-        """The same with triangles the CALLER filtered (kept ones, in the reference's order).  -> (section row of the matched reference cell per
-        kept aligned cell or -1, flag byte per kept cell: bit 0 = XY-order sweep, bit 1 = vertex of an area-flipped triangle; stats dict)."""
+        """The same with triangles the CALLER filtered (kept ones, in the reference's order).  -> (section row of the matched reference
+        cell per kept aligned cell or -1, flag byte per kept cell: bit 0 = XY-order sweep, bit 1 = vertex of an area-flipped triangle;
+        stats dict)."""
         return filter_finish_windows([self], [triangles], 0.0, 0, 0.0, 0.0, False, no_match_penalty, True, prefiltered=True)[0][3:]
 
     def close(self):
@@ -468,8 +476,10 @@ class DeviceWindow:
             pass
 
 
-REST_RECORD = np.dtype([("row", "<i4"), ("ac", "<i4"), ("rc", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("cidx", "<i4"), ("flags", "<u4")])   # SAME_MERGE_REST
-FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("flags", "<u4")])             # SAME_MERGE_FINAL
+# SAME_MERGE_REST
+REST_RECORD = np.dtype([("row", "<i4"), ("ac", "<i4"), ("rc", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("cidx", "<i4"), ("flags", "<u4")])
+# SAME_MERGE_FINAL
+FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("wid", "<i4"), ("pos", "<i4"), ("flags", "<u4")])
 
 
 class _PinnedBlocks:
@@ -563,7 +573,8 @@ class MergeAccumulator:
             n_pos = len(ns) - 1
         with ctx.lock:
             ctx.check(ctx.lib.same_merge_acc_begin(self.handle, int(expected_rows), n_pos, None if ns is None else ns.ctypes.data,
-                                                   None if nb is None or len(nb) == 0 else nb.ctypes.data, float(reach), int(bool(all_seam))),
+                                                   None if nb is None or len(nb) == 0 else nb.ctypes.data, float(reach),
+                                                   int(bool(all_seam))),
                       "same_merge_acc_begin")
 
     def collect(self, states, trims, window_ids, plan_pos):
@@ -572,7 +583,8 @@ class MergeAccumulator:
         t = np.ascontiguousarray(trims, dtype=np.float64).reshape(n, 4)
         w, p = np.ascontiguousarray(window_ids, dtype=np.int32), np.ascontiguousarray(plan_pos, dtype=np.int32)
         with ctx.lock:
-            ctx.check(ctx.lib.same_window_collect(_handles(states), n, self.handle, t.ctypes.data, w.ctypes.data, p.ctypes.data), "same_window_collect")
+            ctx.check(ctx.lib.same_window_collect(_handles(states), n, self.handle, t.ctypes.data, w.ctypes.data, p.ctypes.data),
+                      "same_window_collect")
 
     def load(self, a_code, r_code, flags, window_ids, pos, cidx, n_codes_a, n_codes_r):
         """Rows from the host instead of from windows (the ranks' seam rows after their exchange): the accumulator then holds exactly
@@ -582,7 +594,8 @@ class MergeAccumulator:
         a, r, w, p, c = i32(a_code), i32(r_code), i32(window_ids), i32(pos), i32(cidx)
         f = np.ascontiguousarray(flags, dtype=np.uint8)
         with ctx.lock:
-            ctx.check(ctx.lib.same_merge_acc_load(self.handle, a.ctypes.data, r.ctypes.data, f.ctypes.data, w.ctypes.data, p.ctypes.data, c.ctypes.data,
+            ctx.check(ctx.lib.same_merge_acc_load(self.handle, a.ctypes.data, r.ctypes.data, f.ctypes.data, w.ctypes.data, p.ctypes.data,
+                                                  c.ctypes.data,
                                                   len(a), int(n_codes_a), int(n_codes_r)), "same_merge_acc_load")
 
     def finish(self, winner_rows, fetch=True):
@@ -594,7 +607,8 @@ class MergeAccumulator:
         w = np.ascontiguousarray(winner_rows, dtype=np.int32)
         n = ctypes.c_int64(0)
         with ctx.lock:
-            ctx.check(ctx.lib.same_merge_acc_finish(self.handle, w.ctypes.data if len(w) else None, len(w), ctypes.byref(n)), "same_merge_acc_finish")
+            ctx.check(ctx.lib.same_merge_acc_finish(self.handle, w.ctypes.data if len(w) else None, len(w), ctypes.byref(n)),
+                      "same_merge_acc_finish")
         self.n_final = n.value
         return self.final_rows() if fetch else self.n_final
 
@@ -608,8 +622,8 @@ class MergeAccumulator:
         """After finish(): the merged table's columns written by the device straight into page-locked host memory (enqueue only:
         `ctx.sync()` before reading): the moving section's type columns, X, Y, the reference's X, Y, the caller's extra 8-byte device
         columns (DeviceBuffers of 8-byte values per moving / reference row: ids, sizes), aligned_idx, window_id and plan position as int64,
-        and the two flag columns.  -> (uint64 array (n_types + 4 + extras + 3, n_final), uint8 array (2, n_final)) over a pooled block, or None when no
-        block is to be had (the caller gathers on the host)."""
+        and the two flag columns.  -> (uint64 array (n_types + 4 + extras + 3, n_final), uint8 array (2, n_final)) over a pooled block,
+        or None when no block is to be had (the caller gathers on the host)."""
         import ctypes
 
         n8 = n_types + 4 + len(extra_moving) + len(extra_ref) + 3
@@ -621,7 +635,8 @@ class MergeAccumulator:
         em = (ctypes.c_void_p * max(1, len(extra_moving)))(*[b.ptr for b in extra_moving])
         er = (ctypes.c_void_p * max(1, len(extra_ref)))(*[b.ptr for b in extra_ref])
         with ctx.lock:
-            ctx.check(ctx.lib.same_merge_acc_columns(self.handle, dmoving.handle, dref.handle, em, len(extra_moving), er, len(extra_ref), ptr,
+            ctx.check(ctx.lib.same_merge_acc_columns(self.handle, dmoving.handle, dref.handle, em, len(extra_moving), er, len(extra_ref),
+                                                     ptr,
                                                      int(n_final)), "same_merge_acc_columns")
         wide = np.frombuffer(buf, dtype=np.uint64, count=n8 * n_final).reshape(n8, n_final)
         flags = np.frombuffer(buf, dtype=np.uint8, count=2 * n_final, offset=n8 * 8 * n_final).reshape(2, n_final)
@@ -708,7 +723,8 @@ def filter_finish_windows(states, simplices, radius, angle_enabled, cos_thr, nea
     match_row, flag = np.empty(int(cell_off[-1]), np.int32), np.empty(int(cell_off[-1]), np.uint8)
     stats, counts = np.zeros((n, 8), np.int64), np.zeros((n, 3), np.int64)
     with ctx.lock:
-        ctx.check(ctx.lib.same_window_filter_finish(_handles(states), n, flat.ctypes.data, offsets.ctypes.data, int(bool(prefiltered)), float(radius),
+        ctx.check(ctx.lib.same_window_filter_finish(_handles(states), n, flat.ctypes.data, offsets.ctypes.data, int(bool(prefiltered)),
+                                                    float(radius),
                                                     int(angle_enabled), float(cos_thr), float(near_tol), int(bool(ignore_same_type)),
                                                     int(bool(ensure_min_triangle_per_node)), float(no_match_penalty), match_row.ctypes.data,
                                                     flag.ctypes.data, stats.ctypes.data, counts.ctypes.data), "same_window_filter_finish")
@@ -732,7 +748,8 @@ class DeviceWindowResult:
     box, kept, pairs); `state` is the live DeviceWindow until the generator is asked for the first window of the next batch (pairs,
     costs, signs ... through `state.fetch`)."""
 
-    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "n_triangles", "match_row", "point_flag", "flip_flag", "stats", "counts", "state")
+    __slots__ = ("window", "error", "rows_m", "axy", "triangles", "n_triangles", "match_row", "point_flag", "flip_flag", "stats",
+                 "counts", "state")
 
     def __init__(self, window):
         self.window = window
@@ -812,7 +829,8 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     qhull_pool.warm(min(depth, len(plan)))
     B = max(1, min(int(batch if batch is not None else os.environ.get("SAME_WINDOW_BATCH", "8")), WINDOW_BATCH_MAX, max(len(plan), 1)))
     if batch is None and depth > 0:
-        B = min(B, max(2, depth))             # a rank with three helpers (eight ranks on a 16-CPU host) gains nothing from collecting eight tickets at once
+        # a rank with three helpers (eight ranks on a 16-CPU host) gains nothing from collecting eight tickets at once
+        B = min(B, max(2, depth))
     # windows staged and not yet finished: one per helper BEYOND the batch being finished (a batch's tickets are collected together, and
     # nothing is handed over meanwhile: with only `depth` in flight, 12 helpers and batches of 8 ran 8 of 12 helpers -- 264 against 431
     # windows/s for one thread of a rank that shares its host with another)
@@ -875,18 +893,22 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
         with marked("triangulate (wait for helper)"):
             tris = [ticket.result() for _o, _s, ticket in todo]
         with marked("filter + signs + incumbent + sweeps (device)"):
-            res = filter_finish_windows([st for _o, st, _t in todo], tris, radius, angle_enabled, cos_thr, near_tol, ignore_same_type_triangles,
+            res = filter_finish_windows([st for _o, st, _t in todo], tris, radius, angle_enabled, cos_thr, near_tol,
+                                        ignore_same_type_triangles,
                                         no_match_penalty)
         for (out, state, _t), simplices, (_kept, _added, near, match_row, cell_flags, stats) in zip(todo, tris, res):
             if near:
                 with marked("triangle filter (host: a cosine at the threshold)"):
                     tid = moving.type_id[out.rows_m] if (ignore_same_type_triangles and moving.type_id is not None) else None
-                    out.triangles = filter_triangles_by_radius(out.axy, simplices, radius, ignore_same_type_triangles=ignore_same_type_triangles,
-                                                               min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True, _type_id=tid)
+                    out.triangles = filter_triangles_by_radius(out.axy, simplices, radius,
+                                                               ignore_same_type_triangles=ignore_same_type_triangles,
+                                                               min_angle_deg=min_angle_deg, verbose=False, ctx=ctx, _rows_as_array=True,
+                                                               _type_id=tid)
                 with marked("signs + incumbent + sweeps (device)"):
                     match_row, cell_flags, stats = state.finish(out.triangles, no_match_penalty)
             out.match_row, out.stats = match_row, stats
-            out.point_flag, out.flip_flag = cell_flags & 1, (cell_flags >> 1) & 1        # the library packs both per-cell flags into one byte
+            # the library packs both per-cell flags into one byte
+            out.point_flag, out.flip_flag = cell_flags & 1, (cell_flags >> 1) & 1
             out.n_triangles = state.n_triangles
             if fetch_triangles and out.triangles is None:
                 out.triangles = state.fetch(_W_TRIANGLES)

@@ -166,3 +166,37 @@ def test_table_columns_from_the_device_equal_the_host_gather(monkeypatch):
     del kept, again
     gc.collect()
     assert PINNED_BLOCKS.out == 0
+
+
+def test_merge_channel_over_a_real_rccl_communicator(tmp_path):
+    """dist.MergeChannel with an RCCL communicator (size 1 on this GPU: what a rank of N does, with itself as the only peer): the seam
+    rows' table goes through allgather_table's device path -- size exchange over the host group, upload, ncclAllGather on the context's
+    stream, download -- and comes back as it was; an empty table too.  Then a whole merged pass with that channel in place."""
+    import same_amd
+    from same_amd import _lib, synth
+    from same_amd.dist import MergeChannel, RcclGroup
+    from same_amd.rendezvous import HostGroup
+
+    ctx = _lib.Context(0)
+    with HostGroup(0, 1, rdv_dir=str(tmp_path / "rdv"), timeout=60) as group:
+        comm = RcclGroup(ctx, 1, 0, lambda b: b)
+        try:
+            channel = MergeChannel(group, ctx, comm)
+            rng = np.random.default_rng(1)
+            for n in (0, 1, 3000):
+                sent = {"a": rng.integers(0, 10 ** 6, n), "r": rng.integers(0, 10 ** 6, n), "viol": (rng.random(n) < 0.5).astype(np.uint8),
+                        "window": rng.integers(0, 99, n), "order": rng.integers(0, 2 ** 40, n), "row": np.arange(n), "rank": np.zeros(n, np.int32)}
+                (back,) = channel.tables(sent)
+                assert list(back) == list(sent) and all(np.array_equal(back[k], sent[k]) and back[k].dtype == sent[k].dtype for k in sent)
+            assert channel.sent_rows == 3001 and channel.gather_ms > 0.0
+            cells = synth.make_cells(30_000, 4, seed=5)
+            r_df, m_df = synth.to_frame(cells), synth.to_frame(synth.make_jittered(cells, seed=6))
+            cols = synth.type_columns(4)
+            op = dict(radius=25, knn=6, window_size=600, overlap=150, min_cells_per_window=20, hip_cost_dtype="float32")
+            want = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), merge=True, ctx=ctx)
+            # world 1 behind a channel: no seams, nothing to exchange, the same table
+            got = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), merge=True, ctx=ctx, _merge_channel=channel)
+            assert len(want) > 20_000 and got.equals(want)
+        finally:
+            comm.close()
+    ctx.close()

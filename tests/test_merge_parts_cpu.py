@@ -295,3 +295,36 @@ def test_matching_of_components_equals_the_whole():
         assert np.array_equal(np.where(part >= 0, cols[np.maximum(part, 0)], -1), want), case
         checked += 1
     assert checked > 200
+
+
+def test_sharded_window_tables_come_back_in_plan_order_without_a_sort():
+    """dist._sharded_windows: the ranks' tables are put in plan order by whole windows (runs of the plan under the block deal: nothing
+    to do at all), on every rank (`gather='all'`), on rank 0 only (`'root'`), or not at all (`'none'`)."""
+    from same_amd import dist
+    from same_amd.windows import deal_windows
+
+    plan, _w, _h = _plan(5, 4)
+    rng = np.random.default_rng(0)
+    tables = [pd.DataFrame({"v": rng.random(int(rng.integers(0, 7))), "window_id": w["window_id"], "__plan_pos": pos}) for pos, w in enumerate(plan)]
+    whole = pd.concat(tables, ignore_index=True).drop(columns=["__plan_pos"])
+    for deal in ("block", "round_robin"):
+        for world in (1, 2, 3):
+            owner = deal_windows(plan, world, deal)
+
+            def run(ref, moving, commonCT=None, _shard=None, **_kw):
+                assert _shard[2] == deal
+                mine = [tables[p] for p in np.flatnonzero(owner == _shard[0])]
+                return pd.concat(mine, ignore_index=True) if mine else pd.DataFrame()
+
+            parts = [run(None, None, _shard=(r, world, deal)) for r in range(world)]
+            for rank in range(world):
+                for gather in ("all", "root", "none"):
+                    got = dist._sharded_windows(run, None, None, None, None, lambda part: parts, rank, world, deal, gather, {})
+                    if gather == "none" or (gather == "root" and rank != 0):
+                        assert got.equals(parts[rank])
+                    else:
+                        assert list(got.columns) == ["v", "window_id"] and got.equals(whole), (deal, world, rank, gather)
+    with pytest.raises(ValueError, match="gather"):
+        dist._sharded_windows(run, None, None, None, None, lambda part: parts, 0, 3, "block", "some", {})
+    assert dist._plan_order([tables[3], tables[1], tables[7]])["window_id"].tolist() == \
+        pd.concat([tables[1], tables[3], tables[7]])["window_id"].tolist()

@@ -91,7 +91,7 @@ def _break_line(line, limit, in_brackets_at_start):
             if stack_cols:
                 stack_cols.pop()
         elif t.type == tokenize.OP and t.string == "," and depth >= 1 and t.end[1] < limit - 1:
-            cont = stack_cols[-1] if stack_cols else indent + 4
+            cont = stack_cols[-1] if stack_cols else (indent if in_brackets_at_start else indent + 4)   # a continuation line keeps its column
             cand = (depth, t.end[1], cont)
             if best is None or cand[0] < best[0] or (cand[0] == best[0] and cand[1] > best[1]) or (best[1] < limit // 2 and cand[1] > best[1]):
                 best = cand
@@ -127,6 +127,7 @@ def wrap_source(src, limit=LIMIT):
     lines = src.split("\n")
     # bracket depth at the start of every physical line
     depth_at = [0] * (len(lines) + 1)
+    in_string = set()        # physical lines (0-based) that belong to a string literal spanning several lines: text, not code
     try:
         depth = 0
         for t in tokenize.generate_tokens(io.StringIO(src).readline):
@@ -134,12 +135,17 @@ def wrap_source(src, limit=LIMIT):
                 depth += 1
             elif t.type == tokenize.OP and t.string in ")]}":
                 depth -= 1
+            if t.type == tokenize.STRING and t.end[0] > t.start[0]:
+                in_string.update(range(t.start[0] - 1, t.end[0]))
             if t.type in (tokenize.NL, tokenize.NEWLINE):
                 depth_at[t.end[0]] = depth
     except tokenize.TokenError:
         return src
     out = []
     for no, line in enumerate(lines):
+        if no in in_string:
+            out.append(line)
+            continue
         inside = depth_at[no] > 0 if no < len(depth_at) else False
         work = [line]
         for _ in range(12):
