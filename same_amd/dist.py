@@ -593,3 +593,41 @@ def sharded_merged_window_incumbent(ref, moving, commonCT=None, group=None, ctx=
     finally:
         if own_group is not None:
             own_group.close()
+
+
+def sharded_merged_window_matches(ref, moving, commonCT=None, group=None, ctx=None, comm=None, deal="block", gather=None, outprefix=None,
+                                  moving_delaunay=None, moving_delaunay_vertex_col=None, optim_params=None, gurobi_params=None,
+                                  ignore_precomputed_triangulation=False, **kwargs):
+    """The SOLVER loop on N GPUs followed by the window merge: `sliding_window_matching` (src/same.py:297-595) on every rank's run of the
+    plan, then `merge_window_matches_unique_ref` (src/helpers.py:692-815) dealt the same way -- every rank merges its own table, one
+    all-gather of the seam rows (as id codes: numeric whatever the ids are) settles the rest.  -> this rank's part of the merged table
+    (aligned ids ascending); gather='all' / 'root' joins the parts.  kwargs: sliding_window_matching's private switches (`_pipeline`,
+    `_solve`, `_run_window`)."""
+    import os
+
+    from .merge import join_merged_parts, merge_table_part
+    from .window_api import _WindowJob, codes_of_ids, frame_id_codes, sliding_window_matching
+
+    own_group = None
+    if group is None:
+        group = own_group = HostGroup()
+    try:
+        _learn_cpu_sharing(group)
+        if outprefix:
+            outprefix = os.path.join(outprefix, f"rank{group.rank}")
+        job = _WindowJob(ref, moving, commonCT, outprefix, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
+                         ignore_precomputed_triangulation, (group.rank, group.world, deal))
+        part = sliding_window_matching(ref, moving, _job=job, **kwargs)
+        cid = job.optim_params["cell_id_col"]
+        _codes, unique, (mov_ids, ref_ids) = frame_id_codes(job.moving, job.ref, cid)
+        merged = merge_table_part(part, job.plan, job.owner, MergeChannel(group, ctx, comm), cid,
+                                  reach=abs(float(job.optim_params["radius"])),
+                                  ids_unique=unique, id_codes=lambda a, r: (codes_of_ids(mov_ids, a), codes_of_ids(ref_ids, r)))
+        if gather in ("all", "root") and group.world > 1:
+            parts = group.allgather_object(merged)
+            if gather == "all" or group.rank == 0:
+                merged = join_merged_parts(parts, cid)
+        return merged
+    finally:
+        if own_group is not None:
+            own_group.close()

@@ -549,14 +549,17 @@ def iter_prepared_windows(ref, moving, commonCT, plan, optim_params=None, gurobi
 def sliding_window_matching(ref, moving, commonCT=None, outprefix=None, moving_delaunay=None,
                             moving_delaunay_vertex_col=None, optim_params: Optional[Dict[str, Any]] = None,
                             gurobi_params: Optional[Dict[str, Any]] = None,
-                            ignore_precomputed_triangulation: bool = False, _run_window=None, _shard=None, _pipeline=None, _solve=None):
+                            ignore_precomputed_triangulation: bool = False, _run_window=None, _shard=None, _pipeline=None, _solve=None,
+                            _job=None):
     """Same contract as src/same.py:297-595.  `_run_window` (testing hook) replaces run_same; `_shard=(rank, world)` makes this
     call process only its share of the window plan (same_amd.dist.sharded_sliding_window_matching); `_pipeline` = 'device' | 'frames'
     (default: $SAME_WINDOW_PIPELINE, else 'device': both frames resident on the GPU for the whole loop, see the note above);
     `_solve(prep: PreparedInputs, outprefix) -> (matches_df, var_out)` stands in for the solver half of run_same (model assembly, solve,
-    post-solve tables) behind the unchanged pre-MIP half -- how bench.py times this signature without a Gurobi licence."""
-    job = _WindowJob(ref, moving, commonCT, outprefix, moving_delaunay, moving_delaunay_vertex_col, optim_params, gurobi_params,
-                     ignore_precomputed_triangulation, _shard)
+    post-solve tables) behind the unchanged pre-MIP half -- how bench.py times this signature without a Gurobi licence.  `_job`: the
+    job as a caller already settled it (dist.sharded_merged_window_matches reads its plan and deal afterwards)."""
+    job = _job if _job is not None else _WindowJob(ref, moving, commonCT, outprefix, moving_delaunay, moving_delaunay_vertex_col,
+                                                   optim_params,
+                                                   gurobi_params, ignore_precomputed_triangulation, _shard)
     frames, own = job.device_frames(_pipeline)
     try:
         if frames is not None:

@@ -902,6 +902,14 @@ def _sharded_incumbent_worker(rank, world, deal, out_dir):
             g.barrier()
     part.to_pickle(os.path.join(out_dir, f"part{rank}.pkl"))
     merged.to_pickle(os.path.join(out_dir, f"merged{rank}.pkl"))
+    # the solver loop's form: sliding_window_matching per rank (the incumbent standing in for the solver half), then the merge
+    if world == 2:
+        from same_amd.dist import sharded_merged_window_matches
+        from same_amd.incumbent import incumbent_of_prepared
+
+        stand_in = lambda prep, _o: (incumbent_of_prepared(prep, cols, False)[0], {})
+        solved = sharded_merged_window_matches(r_big, m_two, commonCT=cols, optim_params=dict(op2), deal=deal, _solve=stand_in)
+        solved.to_pickle(os.path.join(out_dir, f"solved{rank}.pkl"))
 
 
 @pytest.mark.parametrize("world,deal", [(2, "block"), (2, "round_robin"), (3, "block"), (3, "round_robin")])
@@ -945,6 +953,11 @@ def test_sharded_incumbent_parts_make_the_single_process_table(tmp_path, world, 
     assert all(0 < len(p) < len(want) and "__plan_pos" not in p.columns for p in mparts)
     assert all(np.all(np.diff(p["Aligned_Cell_Num_Old"].to_numpy()) > 0) for p in mparts)
     assert join_merged_parts(mparts).equals(want)
+    if world == 2:     # dist.sharded_merged_window_matches: the reference's own loop per rank, merged the same way
+        sparts = [pd.read_pickle(tmp_path / f"solved{rank}.pkl") for rank in range(world)]
+        stand_in = lambda prep, _o: (same_amd.incumbent.incumbent_of_prepared(prep, cols, False)[0], {})
+        solver_table = same_amd.sliding_window_matching(r_big, m_two, commonCT=cols, optim_params=dict(op2), _solve=stand_in)
+        assert join_merged_parts(sparts).equals(merge_window_matches_unique_ref([solver_table]))
 
 
 def test_metacell_flow_equals_reference(gp, tmp_path, monkeypatch):
