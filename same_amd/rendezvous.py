@@ -27,6 +27,7 @@ import stat
 import socket
 import struct
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -188,6 +189,9 @@ def _recv_frame(sock, seq):
 class HostGroup:
     """rank/world as given (or from RANK / WORLD_SIZE); world 1 needs no sockets."""
 
+    _made = {}       # (rendezvous directory, rank) -> groups this process has made there so far
+    _made_lock = threading.Lock()
+
     def __init__(self, rank=None, world=None, rdv_dir=None, timeout=600.0):
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
@@ -202,7 +206,14 @@ class HostGroup:
         if self.world == 1:
             return
         self._dir = rdv_dir or default_rdv_dir()
-        hub_file = os.path.join(self._dir, "hub.json")
+        # One rendezvous file per group a process makes in this directory, numbered in the order they are made (the ranks of a job make
+        # their groups in the same order): a rank that is already starting its next group while rank 0 has not yet closed the last one
+        # must not read the LAST group's file -- it would say hello to a listener that is about to go away and wait for an answer.
+        with HostGroup._made_lock:
+            nth = HostGroup._made.get((self._dir, self.rank), 0)        # (per rank: tests run several ranks of a group as threads of one process)
+            HostGroup._made[(self._dir, self.rank)] = nth + 1
+        self._hub_name = "hub.json" if nth == 0 else f"hub.{nth}.json"
+        hub_file = os.path.join(self._dir, self._hub_name)
         if self.rank == 0:
             os.makedirs(self._dir, mode=0o700, exist_ok=True)
             if os.lstat(self._dir).st_uid == os.getuid():
@@ -321,7 +332,7 @@ class HostGroup:
         self._peers, self._hub, self._listener = {}, None, None
         if self.rank == 0 and self._dir:
             try:
-                os.remove(os.path.join(self._dir, "hub.json"))
+                os.remove(os.path.join(self._dir, self._hub_name))
                 os.rmdir(self._dir)
             except OSError:
                 pass

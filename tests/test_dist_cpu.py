@@ -467,3 +467,32 @@ def test_window_round_robin():
     loads = [sum(plan[w]["n_ref"] * plan[w]["n_mov"] for w in s) for s in shards]
     assert max(loads) <= 3600 + 2000  # heaviest-first keeps the big windows apart
     assert assign_windows([], 4) == [[], [], [], []]
+
+
+def _two_groups_worker(rank, rdv, out_dir):
+    _setup_paths()
+    import time
+
+    from same_amd.rendezvous import HostGroup
+
+    got = []
+    for k in range(4):           # four groups one after the other in ONE rendezvous directory, the ranks out of step between them
+        with HostGroup(rank, 2, rdv_dir=rdv, timeout=60) as g:
+            got.append(g.allgather_object({"k": k, "rank": rank}))
+            if rank == 0:
+                time.sleep(0.3)  # rank 1 is already making its next group while this one's rendezvous file still stands
+    ok = all(got[k] == [{"k": k, "rank": 0}, {"k": k, "rank": 1}] for k in range(4))
+    open(os.path.join(out_dir, f"seq{rank}.txt"), "w").write(str(ok))
+
+
+def test_groups_made_one_after_the_other_do_not_meet_each_others_files(tmp_path):
+    """A rank that starts its next HostGroup while rank 0 has not yet closed the last one must not read the LAST group's rendezvous file
+    (dist's wrappers make a group per call when none is passed): the files are numbered per group."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_two_groups_worker, args=(r, str(tmp_path / "rdv"), str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert [open(tmp_path / f"seq{r}.txt").read() for r in range(2)] == ["True", "True"]
