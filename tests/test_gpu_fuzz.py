@@ -117,7 +117,8 @@ def test_fuzz_triangles_and_sweeps(ops, oracle):
             assert np.array_equal(e, oe) and np.array_equal(tf, otf) and np.array_equal(pf, opf) and np.array_equal(counts, oc), case
             b, a, m3, fl = ops.area_flip(xy, rxy, tris, match)
             ob, oa, om3, ofl = oracle.area_flip(xy, rxy, tris, match)
-            assert np.array_equal(b, ob) and np.array_equal(a, oa, equal_nan=True) and np.array_equal(m3, om3) and np.array_equal(fl, ofl), case
+            assert np.array_equal(b, ob) and np.array_equal(a, oa, equal_nan=True) and np.array_equal(m3, om3) and np.array_equal(fl,
+                                                                      ofl), case
             mapped = np.where((match >= 0)[:, None], rxy[np.maximum(match, 0)], 0.0)
             f, nt, nf = ops.tri_flip_stats(xy, mapped, (match >= 0), tris, tid)
             of, ont, onf = oracle.tri_flip_stats(xy, mapped, (match >= 0), tris, tid)
@@ -155,7 +156,8 @@ def test_fuzz_matching_from_x_and_greedy(ops, oracle):
             assert np.array_equal(mp, want), case
             un = rng.uniform(1, 100, n_m)
             assert np.array_equal(ops.pair_rowmin(pairs, costs, n_m),
-                                  np.array([costs[pairs[:, 0] == i].min() if (pairs[:, 0] == i).any() else np.inf for i in range(n_m)])), case
+                                  np.array([costs[pairs[:, 0] == i].min() if (pairs[:,
+                                                                      0] == i).any() else np.inf for i in range(n_m)])), case
             o = np.empty((n_m, n_r + n_m))
             oracle.lib().orc_assign_matrix(pairs, costs, P, un, n_m, n_r, 1e9, o.reshape(-1))
             assert np.array_equal(ops.assign_matrix(pairs, costs, un, n_m, n_r, 1e9), o), case
@@ -201,7 +203,8 @@ def test_fuzz_knn_index_and_block_sweeps(ops, oracle):
             world = int(rng.choice([1, 2, 3, 5, 8]))
             with ctx.lock:
                 sw = ctypes.c_void_p()
-                ctx.check(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign.ctypes.data, rr.ctypes.data, len(rr), n, None, 0, ctypes.byref(sw)), "bind")
+                ctx.check(L.same_sweep_bind(H, tris.ctypes.data, Tr, sign.ctypes.data, rr.ctypes.data, len(rr), n, None, 0,
+                                            ctypes.byref(sw)), "bind")
                 dmatch = ctx.to_device(match)
                 _, _, block = tri_block(Tr, world, 0)
                 dflag = ctx.alloc(block * world)
@@ -226,7 +229,8 @@ def test_fuzz_merge_dedup(ops, oracle):
             print(f"merge soak round {rnd}", flush=True)
         rng = np.random.default_rng(77 + 104729 * rnd)
         for case in range(60):
-            n = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 2047, 2048, 2049, 4095, 4097, int(rng.integers(3, 9000)), int(rng.integers(9000, 40000))]))
+            n = int(rng.choice([0, 1, 2, 63, 64, 65, 127, 2047, 2048, 2049, 4095, 4097, int(rng.integers(3, 9000)),
+                                int(rng.integers(9000, 40000))]))
             n_win = int(rng.choice([1, 2, 7, 300, 2 ** 31 - 1]))
             ids = int(rng.choice([1, 3, 50, 5000, 2 ** 31 - 1]))
             viol = rng.random(n) < float(rng.choice([0.0, 0.3, 1.0]))
@@ -271,12 +275,14 @@ def test_fuzz_device_windows(ops):
             penalty = float(rng.choice([100.0, 5.0, 0.05]))
             try:
                 arrays = list(W.iter_window_arrays(ref_sec, mov_sec, plan, cost_dtype=dt, **kw))
-            except (QhullError, ValueError):      # a window whose kept cells Qhull cannot triangulate (collinear / too few): both forms raise
+            # a window whose kept cells Qhull cannot triangulate (collinear / too few): both forms raise
+            except (QhullError, ValueError):
                 with pytest.raises((QhullError, ValueError)):
                     list(W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True, **kw))
                 errors += 1
                 continue
-            for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty, fetch_triangles=True, **kw)):
+            for wa, dw in zip(arrays, W.iter_device_windows(ref_sec, mov_sec, dref, dmov, plan, no_match_penalty=penalty,
+                                                            fetch_triangles=True, **kw)):
                 assert (wa.error is None) == (dw.error is None), (case, wa.window)
                 if wa.error is None:
                     check_window(W, ops, wa, dw, penalty)
@@ -285,7 +291,8 @@ def test_fuzz_device_windows(ops):
             dref.close()
             dmov.close()
         assert done > 30, (done, errors)
-        assert max_rounds > 3, max_rounds     # some window needs more greedy rounds than the finish call enqueues up front: the "keep going" path ran
+        # some window needs more greedy rounds than the finish call enqueues up front: the "keep going" path ran
+        assert max_rounds > 3, max_rounds
 
 
 def test_device_window_argument_checks(ops):
@@ -318,7 +325,8 @@ def test_device_window_argument_checks(ops):
     with pytest.raises(SameHipError):
         st.ctx.check(st.ctx.lib.same_window_fetch(st.handle, W._W_PAIRS, np.zeros(4, np.int32).ctypes.data, 16), "fetch")   # wrong size
     with pytest.raises(SameHipError):
-        st.ctx.check(st.ctx.lib.same_window_fetch(st.handle, 99, np.zeros(4, np.int32).ctypes.data, 16), "fetch")            # unknown selector
+        # unknown selector
+        st.ctx.check(st.ctx.lib.same_window_fetch(st.handle, 99, np.zeros(4, np.int32).ctypes.data, 16), "fetch")
     with pytest.raises(SameHipError):
         st.finish(np.array([[0, 1, 400]], np.int32), 1.0)            # vertex out of range: reported, not dereferenced
     with pytest.raises(SameHipError):
@@ -332,7 +340,8 @@ def test_device_window_argument_checks(ops):
             W.stage_windows(bad, da, da, [box] * len(bad), 10.0, 4, 1.0)
     # ... and a batch of two gives what two single calls give (the first window of the batch is the one staged above)
     half = (0.0, 50.0, 0.0, 100.0)
-    assert W.stage_windows([st, st2], da, da, [box, half], 10.0, 4, 1.0) == [(n_m, n_r, kept, n_pairs), st2.stage(da, da, half, 10.0, 4, 1.0)]
+    assert W.stage_windows([st, st2], da, da, [box, half], 10.0, 4, 1.0) == [(n_m, n_r, kept, n_pairs),
+                                                                      st2.stage(da, da, half, 10.0, 4, 1.0)]
     from scipy.spatial import Delaunay
     tri = [Delaunay(s_.fetch(W._W_ALIGNED_XY)).simplices for s_ in (st, st2)]
     both = W.filter_finish_windows([st, st2], tri, 10.0, 1, 0.9, 0.0, True, 1.0)
@@ -403,7 +412,8 @@ def test_window_calls_with_more_windows_than_a_launch_takes():
         pts = st.fetch(W._W_ALIGNED_XY)
         tris32.append(Delaunay(pts).simplices if len(pts) >= 3 else np.zeros((0, 3), np.int32))
         want32.append(solo.filter_finish(tris32[-1], 12.0, 1, 0.9, 0.0, True, 50.0) if c[2] else None)
-    order = [("a", q) for q in range(n) if counts[q][0] and counts[q][1]]       # a box that is empty on one side is the caller's error case: not finished
+    # a box that is empty on one side is the caller's error case: not finished
+    order = [("a", q) for q in range(n) if counts[q][0] and counts[q][1]]
     for q in range(7):
         if counts32[q][0] and counts32[q][1]:
             order.insert(3 * q + 1, ("b", q))
@@ -434,7 +444,8 @@ def test_prune_indices_dropped_while_other_threads_use_them():
     from same_amd import windows as W
 
     rng = np.random.default_rng(11)
-    sec = W.Section(rng.uniform(0, 200, (6000, 2)), rng.random((6000, 3)), None, None)     # >= 2048 rows: grid indices (device arrays of their own)
+    # >= 2048 rows: grid indices (device arrays of their own)
+    sec = W.Section(rng.uniform(0, 200, (6000, 2)), rng.random((6000, 3)), None, None)
     dsec = W.DeviceSection(sec, "float64")
     radii = [3.0 + 0.37 * q for q in range(24)]
     box = (0.0, 200.0, 0.0, 200.0)
@@ -455,7 +466,8 @@ def test_prune_indices_dropped_while_other_threads_use_them():
                 for q in order:
                     r = radii[int(q)]
                     counts = st.stage(dsec, dsec, box, r, 6, 1.0)
-                    if counts != want[r][0] or not np.array_equal(st.fetch(W._W_PAIRS), want[r][1]) or not np.array_equal(st.fetch(W._W_COSTS), want[r][2]):
+                    if counts != want[r][0] or not np.array_equal(st.fetch(W._W_PAIRS),
+                                                                  want[r][1]) or not np.array_equal(st.fetch(W._W_COSTS), want[r][2]):
                         failures.append((seed, rep, r))
         except BaseException as e:   # noqa: BLE001 -- reported by the assertion below
             failures.append((seed, repr(e)))
@@ -488,7 +500,8 @@ def test_prune_indices_dropped_while_other_threads_use_them():
                 r = fresh[rnd][lane]
                 for _rep in range(3 if lane == 4 else 1):
                     counts = st.stage(dsec, dsec, box, r, 6, 1.0)
-                    if counts != want[r][0] or not np.array_equal(st.fetch(W._W_PAIRS), want[r][1]) or not np.array_equal(st.fetch(W._W_COSTS), want[r][2]):
+                    if counts != want[r][0] or not np.array_equal(st.fetch(W._W_PAIRS),
+                                                                  want[r][1]) or not np.array_equal(st.fetch(W._W_COSTS), want[r][2]):
                         failures.append(("race", lane, rnd, r))
         except BaseException as e:   # noqa: BLE001 -- reported by the assertion below
             failures.append(("race", lane, repr(e)))
@@ -517,7 +530,8 @@ def test_scans_hold_when_no_block_ever_sees_a_predecessor():
     sel = ["tests/test_gpu_fuzz.py::test_fuzz_device_windows", "tests/test_gpu_fuzz.py::test_fuzz_knn_and_costs",
            "tests/test_gpu_run_same.py::test_device_windows_equal_the_column_pipeline",
            "tests/test_gpu_run_same.py::test_window_rows_do_not_depend_on_the_section_grid",
-           "tests/test_gpu_parity.py::test_sharded_sweeps_rccl_single_rank_and_block_forms", "tests/test_host_rows.py::test_merge_dedup_on_device",
+           "tests/test_gpu_parity.py::test_sharded_sweeps_rccl_single_rank_and_block_forms",
+           "tests/test_host_rows.py::test_merge_dedup_on_device",
            "tests/test_gpu_merge.py", "tests/test_gpu_fuzz.py::test_fuzz_window_merge_routes_agree"]
     res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "not scans_hold"] + sel, cwd=root, env=env,
                          capture_output=True, text=True, timeout=1500)
@@ -530,10 +544,13 @@ def _assert_prepared_equal(a, b, what):
     if isinstance(a, Exception):
         assert str(a) == str(b), what
         return 0
-    assert np.array_equal(np.asarray(a.valid_pairs, dtype=np.int64).reshape(-1, 2), np.asarray(b.valid_pairs, dtype=np.int64).reshape(-1, 2)), what
+    assert np.array_equal(np.asarray(a.valid_pairs, dtype=np.int64).reshape(-1, 2),
+                          np.asarray(b.valid_pairs, dtype=np.int64).reshape(-1, 2)), what
     assert np.array_equal(a.costs_array, b.costs_array) and a.costs_array.dtype == b.costs_array.dtype, what
     assert np.array_equal(a.triangles_array, b.triangles_array), what
-    assert np.array_equal(a.signs_array, b.signs_array) and a.weights_array.dtype == b.weights_array.dtype and np.array_equal(a.weights_array, b.weights_array), what
+    assert np.array_equal(a.signs_array,
+                          b.signs_array) and a.weights_array.dtype == b.weights_array.dtype and np.array_equal(a.weights_array,
+                                                                      b.weights_array), what
     assert (a.n_aligned, a.n_ref) == (b.n_aligned, b.n_ref) == (len(a.aligned_df), len(a.ref_df)), what
     for fa, fb in ((a.aligned_df, b.aligned_df), (a.ref_df, b.ref_df)):
         assert list(fa.columns) == list(fb.columns) and fa.equals(fb), what
@@ -573,7 +590,8 @@ def test_fuzz_window_pipelines_agree():
                     df["size"] = rng.integers(1, 4, n) if case % 2 else rng.integers(1, 4, n) * 1.5
                 df["Cell_Num_Old"] = rng.permutation(n) + 10
                 if case % 4 == 2:
-                    df.loc[df.index[rng.integers(0, n, 5)], "X"] = np.nan       # rows no window holds (pandas' min / max skip them: src/same.py:481-482)
+                    # rows no window holds (pandas' min / max skip them: src/same.py:481-482)
+                    df.loc[df.index[rng.integers(0, n, 5)], "X"] = np.nan
                 if case == 13:
                     df.loc[df.index[rng.integers(0, n, 2)], "Y"] = np.inf       # int(inf): the reference's OverflowError
                 if case % 6 == 3:
@@ -584,13 +602,17 @@ def test_fuzz_window_pipelines_agree():
             ref, mov = frames
             cols = [f"t{q}" for q in range(T)]
             ws = int(rng.choice([60, 90, 150, 400]))
-            op = dict(radius=float(rng.choice([0.5, 6.0, 15.0, 40.0])), knn=int(rng.choice([1, 3, 8, 40])), window_size=ws, overlap=int(rng.choice([0, ws // 4, ws // 3])),
-                      min_cells_per_window=int(rng.choice([5, 30])), dist_ct_coeff=float(rng.choice([1.0, 0.4])), min_angle_deg=[15, None, 30][case % 3],
+            op = dict(radius=float(rng.choice([0.5, 6.0, 15.0, 40.0])), knn=int(rng.choice([1, 3, 8, 40])), window_size=ws,
+                      overlap=int(rng.choice([0, ws // 4, ws // 3])),
+                      min_cells_per_window=int(rng.choice([5, 30])), dist_ct_coeff=float(rng.choice([1.0, 0.4])),
+                      min_angle_deg=[15, None, 30][case % 3],
                       ignore_same_type_triangles=bool(case % 4), hip_cost_dtype="float32" if case % 3 == 0 else "float64",
                       no_match_penalty=float(rng.choice([100.0, 2.0])), ignore_knn_if_matched=(case % 7 == 5))
             try:
-                plan = window_plan(ref[["X", "Y"]].to_numpy(dtype=np.float64), mov[["X", "Y"]].to_numpy(dtype=np.float64), ws, op["overlap"], op["min_cells_per_window"])
-            except OverflowError:        # an infinite extent: int(inf) in the reference's grid (src/same.py:481-488) -- both pipelines raise before any window
+                plan = window_plan(ref[["X", "Y"]].to_numpy(dtype=np.float64), mov[["X", "Y"]].to_numpy(dtype=np.float64), ws,
+                                   op["overlap"], op["min_cells_per_window"])
+            # an infinite extent: int(inf) in the reference's grid (src/same.py:481-488) -- both pipelines raise before any window
+            except OverflowError:
                 for pipe in ("device", "frames"):
                     with pytest.raises(OverflowError):
                         same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), _pipeline=pipe)
@@ -619,7 +641,8 @@ def test_fuzz_window_pipelines_agree():
             tables = []
             for kw in (dict(_pipeline="device"), dict(_route="general", _pipeline="device"), dict(_route="general", _pipeline="frames")):
                 try:
-                    tables.append(same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), window_local_indices=True, **kw))
+                    tables.append(same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op),
+                                                                    window_local_indices=True, **kw))
                 except ValueError as e:
                     tables.append(str(e))
             if sum(ok) < len(ok):                           # a window without pairs: every route raises run_same's error
@@ -658,15 +681,18 @@ def _random_window_job(rng, case):
         if case % 3:
             df["size"] = rng.integers(1, 4, n) if case % 2 else rng.integers(1, 4, n) * 1.5
         ids = rng.permutation(n) * 3 + 10
-        df["Cell_Num_Old"] = ids if case % 4 else np.array([f"c{v:06d}" for v in ids], dtype=object)     # string ids: codes, host-gathered id columns
+        # string ids: codes, host-gathered id columns
+        df["Cell_Num_Old"] = ids if case % 4 else np.array([f"c{v:06d}" for v in ids], dtype=object)
         if case % 6 == 2:
             df.loc[df.index[rng.integers(0, n, 4)], "X"] = np.nan
         if case % 6 == 3:
             df.index = [f"cell{q}" for q in rng.permutation(n)]
         frames.append(df)
     ws = int(rng.choice([70, 110, 200]))
-    op = dict(radius=float(rng.choice([8.0, 15.0, 30.0])), knn=int(rng.choice([2, 5, 12])), window_size=ws, overlap=int(rng.choice([0, 6, ws // 4])),
-              min_cells_per_window=int(rng.choice([5, 30])), min_angle_deg=[15, None, 30][case % 3], ignore_same_type_triangles=bool(case % 4),
+    op = dict(radius=float(rng.choice([8.0, 15.0, 30.0])), knn=int(rng.choice([2, 5, 12])), window_size=ws,
+              overlap=int(rng.choice([0, 6, ws // 4])),
+              min_cells_per_window=int(rng.choice([5, 30])), min_angle_deg=[15, None, 30][case % 3],
+              ignore_same_type_triangles=bool(case % 4),
               hip_cost_dtype="float32" if case % 2 else "float64", no_match_penalty=float(rng.choice([100.0, 5.0])))
     return frames[0], frames[1], [f"t{q}" for q in range(T)], op
 
@@ -720,7 +746,8 @@ def test_fuzz_window_merge_routes_agree(oracle):
         for case in range(10):
             ref, mov, cols, op = _random_window_job(rng, case)
             try:
-                host_table = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), _route="general", _pipeline="device")
+                host_table = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), _route="general",
+                                                               _pipeline="device")
             except Exception as e:  # noqa: BLE001 -- a window without pairs / a set Qhull refuses: every route raises alike
                 with pytest.raises(type(e)):
                     same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True)
@@ -730,13 +757,20 @@ def test_fuzz_window_merge_routes_agree(oracle):
             table = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op))       # the accumulator, end to end
             assert list(table.columns) == list(host_table.columns) and len(table) == len(host_table), (rnd, case)
             for c in table.columns:
-                assert table[c].dtype == host_table[c].dtype and np.array_equal(table[c].to_numpy(), host_table[c].to_numpy()), (rnd, case, c)
+                assert table[c].dtype == host_table[c].dtype and np.array_equal(table[c].to_numpy(), host_table[c].to_numpy()), (rnd,
+                                                                      case, c)
             want = merge_window_matches_unique_ref([host_table], _dedup=oracle.merge_dedup)
             contested += len(want) < len(host_table)
             got = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True)
             assert list(got.columns) == list(want.columns) and got.equals(want), (rnd, case, len(got), len(want))
             general = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True, _route="general")
             assert general.equals(want), (rnd, case)
+            if case % 3 == 0:        # with the windows' own reference indices: the keys go through the host-side builders
+                with_idx = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), window_local_indices=True)
+                merged_idx = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), window_local_indices=True,
+                                                               merge=True)
+                assert merged_idx.equals(merge_window_matches_unique_ref([with_idx], _dedup=oracle.merge_dedup)), (rnd, case)
+                assert merged_idx.drop(columns=["ref_idx"]).equals(want), (rnd, case)
             world, deal = int(rng.choice([2, 3])), str(rng.choice(["block", "round_robin"]))
             hub, parts, errors = _ThreadHub(world), [None] * world, []
 
@@ -744,8 +778,10 @@ def test_fuzz_window_merge_routes_agree(oracle):
                 ctx = _lib.Context(_lib.default_context().device)
                 try:
                     route = {} if rank % 2 == 0 else dict(_route="general")        # ranks on different routes send the same seam rows
-                    parts[rank] = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True, ctx=ctx, workers=1,
-                                                                    _shard=(rank, world, deal), _merge_channel=_ThreadMergeChannel(hub, rank), **route)
+                    parts[rank] = same_amd.sliding_window_incumbent(ref, mov, commonCT=cols, optim_params=dict(op), merge=True, ctx=ctx,
+                                                                    workers=1,
+                                                                    _shard=(rank, world, deal),
+                                                                    _merge_channel=_ThreadMergeChannel(hub, rank), **route)
                 except BaseException as e:  # noqa: BLE001
                     errors.append(e)
                     hub.barrier.abort()
