@@ -143,6 +143,35 @@ int main(void) {
            same_window ? "the same answers" : "DIFFERENT ANSWERS", (long long)(c1[0] - c0[0]), (long long)(c1[1] - c0[1]),
            (long long)(c1[2] - c0[2]), (long long)(c1[3] - c0[3]));
     if (!same_window || c1[0] - c0[0] > 60 || c1[3] - c0[3] > 2) return 6;
+    /* the window merge where the matches are (src/helpers.py:692-815): both windows' central rows go to an accumulator on the device
+     * (enqueue only), the merge keeps one row per (aligned, ref) pair -- here every pair was proposed by both windows: window 0's rows win --,
+     * settles the rows that stand alone, and writes the merged table's columns into host memory the device can write */
+    same_merge_acc *acc = NULL;
+    const int32_t wids[2] = {0, 1}, ppos[2] = {0, 1};
+    int64_t mc[4], n_final = 0;
+    CHECK(same_merge_acc_create(ctx, &acc));
+    CHECK(same_merge_acc_begin(acc, 2 * NM, 0, NULL, NULL, 0.0, 0));
+    CHECK(same_window_collect(pair, 2, acc, boxes2, wids, ppos));
+    CHECK(same_merge_acc_resolve(&acc, 1, smov, sref, mc));
+    CHECK(same_merge_acc_finish(acc, NULL, 0, &n_final));      /* no row was contested: nothing for a matching to decide */
+    struct { int32_t a_row, r_row, cidx, wid, pos; uint32_t flags; } fin[NM];
+    if (n_final > NM || sizeof fin[0] != SAME_MERGE_FINAL_BYTES) return 7;
+    CHECK(same_merge_acc_fetch(acc, SAME_MERGE_FINAL, fin, n_final * SAME_MERGE_FINAL_BYTES));
+    void *block = NULL;
+    const size_t n8 = (size_t)T + 4 + 3;                       /* type columns, X, Y, ref_X, ref_Y, aligned_idx, window_id, plan position */
+    CHECK(same_host_alloc(ctx, n8 * 8 * (size_t)n_final + 2 * (size_t)n_final + 8, &block));
+    CHECK(same_merge_acc_columns(acc, smov, sref, NULL, 0, NULL, 0, block, n_final));
+    CHECK(same_ctx_sync(ctx));
+    const double *col = (const double *)block;
+    int merged_ok = mc[0] == 2 * mc[1] && mc[2] == 0 && mc[3] == n_final && n_final == mc[1];
+    for (int64_t i = 0; merged_ok && i < n_final; ++i)
+        merged_ok = fin[i].wid == 0 && fin[i].r_row == mrow[fin[i].cidx] && col[(size_t)T * n_final + i] == axy[2 * fin[i].a_row]
+                    && col[((size_t)T + 2) * n_final + i] == rxy[2 * fin[i].r_row] && (i == 0 || fin[i].a_row > fin[i - 1].a_row);
+    printf("window merge on the device: %lld rows from two windows -> %lld after the de-duplication, %lld left to the host, %lld merged rows (%s)\n",
+           (long long)mc[0], (long long)mc[1], (long long)mc[2], (long long)n_final, merged_ok ? "window 0's, aligned rows ascending" : "WRONG");
+    CHECK(same_host_free(ctx, block));
+    same_merge_acc_destroy(acc);
+    if (!merged_ok) return 7;
     same_window_destroy(win_b);
     same_window_destroy(win);
     same_section_destroy(smov);
