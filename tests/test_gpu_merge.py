@@ -200,3 +200,58 @@ def test_merge_channel_over_a_real_rccl_communicator(tmp_path):
         finally:
             comm.close()
     ctx.close()
+
+
+def test_ranks_without_windows_still_take_part():
+    """More ranks than windows: the ranks the deal leaves empty-handed make the same exchange as the others (with nothing to send) and
+    return an empty part; the parts together are the single process's merged table."""
+    import threading
+
+    import same_amd
+    from same_amd import _lib, synth
+    from same_amd.merge import join_merged_parts
+    from same_amd.windows import window_plan
+
+    cells = synth.make_cells(4000, 3, seed=21)
+    r_df = synth.to_frame(cells)
+    m_df = synth.to_frame(synth.make_jittered(cells, seed=22))
+    cols = synth.type_columns(3)
+    op = dict(radius=25, knn=5, window_size=400, overlap=20, min_cells_per_window=20)
+    plan = window_plan(cells["xy"], m_df[["X", "Y"]].to_numpy(), 400, 20, 20)
+    world = len(plan) + 2
+    assert 2 <= len(plan) <= 5
+    want = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), merge=True)
+
+    class Hub:
+        slots, barrier = [None] * world, threading.Barrier(world)
+
+    class Channel:
+        def __init__(self, rank):
+            self.rank, self.world, self.sent_rows, self.gather_ms = rank, world, 0, 0.0
+
+        def tables(self, table):
+            Hub.slots[self.rank] = table
+            Hub.barrier.wait(120)
+            out = list(Hub.slots)
+            Hub.barrier.wait(120)
+            return out
+
+    for deal in ("block", "round_robin"):
+        parts, errors = [None] * world, []
+
+        def body(rank):
+            ctx = _lib.Context(_lib.default_context().device)
+            try:
+                parts[rank] = same_amd.sliding_window_incumbent(r_df, m_df, commonCT=cols, optim_params=dict(op), merge=True, ctx=ctx, workers=1,
+                                                                _shard=(rank, world, deal), _merge_channel=Channel(rank))
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                Hub.barrier.abort()
+            finally:
+                ctx.close()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        [t.start() for t in threads]
+        [t.join(300) for t in threads]
+        assert not errors, (deal, errors[:1])
+        assert sum(len(p) == 0 for p in parts) >= 2 and join_merged_parts(parts).equals(want), deal
