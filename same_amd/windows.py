@@ -483,36 +483,44 @@ FINAL_RECORD = np.dtype([("a_row", "<i4"), ("r_row", "<i4"), ("cidx", "<i4"), ("
 
 
 class _PinnedBlocks:
-    """Page-locked host blocks the device writes the merged table's float columns into (same_host_alloc), handed out as numpy arrays.
+    """Page-locked host blocks the device writes the merged table's columns into (same_host_alloc), handed out as numpy arrays.
     A block goes back to the pool when the last array made of it is gone (a result table is usually dropped before the next pass: the
     pool then serves every pass from the same block, and no pass pays the pinning again); at most KEEP blocks wait in the pool, and while
-    more than LIMIT are out with callers (tables kept alive) `take` declines -- the caller then gathers on the host as before."""
+    more than LIMIT are out with callers (tables kept alive) `take` declines -- the caller then gathers on the host as before.
+    A block comes back from a finalizer, i.e. wherever the interpreter happens to drop the last reference (possibly inside `take` itself,
+    during a garbage collection): that path only moves entries between lists under a re-entrant lock; memory the pool does not keep is
+    handed back to the driver by the next `take` / `drop`, never from the finalizer."""
 
     KEEP, LIMIT = 2, 4
 
     def __init__(self):
         import threading
 
-        self.free, self.out, self.lock = [], 0, threading.Lock()
+        self.free, self.surplus, self.out, self.lock = [], [], 0, threading.RLock()
 
     def take(self, ctx, nbytes):
         """-> (ctypes char array over a pinned block of >= nbytes, address) or None"""
         import ctypes
         import weakref
 
+        self._release_surplus()
         with self.lock:
             if self.out >= self.LIMIT:
                 return None
-            fit = [q for q, (c, cap, _p) in enumerate(self.free) if c is ctx and cap >= nbytes]
-            if fit:
-                _c, cap, ptr = self.free.pop(min(fit, key=lambda q: self.free[q][1]))
-            else:
-                cap, ptr = (int(nbytes * 1.1) + (1 << 20)) & ~((1 << 20) - 1), ctypes.c_void_p()
-                with ctx.lock:
-                    if ctx.lib.same_host_alloc(ctx.handle, cap, ctypes.byref(ptr)) != 0:
-                        return None
-                ptr = ptr.value
+            fit = [q for q, (c, cap, _p) in enumerate(list(self.free)) if c is ctx and cap >= nbytes]
+            got = self.free.pop(min(fit, key=lambda q: self.free[q][1])) if fit else None
             self.out += 1
+        if got is not None:
+            _c, cap, ptr = got
+        else:
+            cap, ptr = (int(nbytes * 1.1) + (1 << 20)) & ~((1 << 20) - 1), ctypes.c_void_p()
+            with ctx.lock:
+                rc = ctx.lib.same_host_alloc(ctx.handle, cap, ctypes.byref(ptr))
+            if rc != 0:
+                with self.lock:
+                    self.out -= 1
+                return None
+            ptr = ptr.value
         buf = (ctypes.c_char * cap).from_address(ptr)
         weakref.finalize(buf, self._back, ctx, cap, ptr)          # when the last array over `buf` is gone
         return buf, ptr
@@ -520,10 +528,13 @@ class _PinnedBlocks:
     def _back(self, ctx, cap, ptr):
         with self.lock:
             self.out -= 1
-            if len(self.free) < self.KEEP and ctx.handle:
-                self.free.append((ctx, cap, ptr))
-                return
-        self._release(ctx, ptr)
+            (self.free if len(self.free) < self.KEEP and ctx.handle else self.surplus).append((ctx, cap, ptr))
+
+    def _release_surplus(self):
+        with self.lock:
+            gone, self.surplus = self.surplus, []
+        for ctx, _cap, ptr in gone:
+            self._release(ctx, ptr)
 
     @staticmethod
     def _release(ctx, ptr):
@@ -541,6 +552,7 @@ class _PinnedBlocks:
             self.free = [e for e in self.free if e not in gone]
         for c, _cap, ptr in gone:
             self._release(c, ptr)
+        self._release_surplus()
 
 
 PINNED_BLOCKS = _PinnedBlocks()
