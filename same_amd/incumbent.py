@@ -472,7 +472,7 @@ def _device_route(job, frames, workers, with_ref_idx, triangulator, stats, merge
             with stage("table rows (accumulated on the device, in plan order)"):
                 done = plain_accumulators(accs)
         with_pos = job.mine is not None and not merge
-        with stage("table (columns gathered on the gather threads)"):
+        with stage("table (columns of the rows that stay: by the device into page-locked memory, else on the gather threads)"):
             if not done.n_final:
                 return pd.DataFrame()
             me = builders[0]
