@@ -557,6 +557,9 @@ def test_sharded_sweeps_rccl_single_rank_and_block_forms(ops, oracle):
     ctx.close()
 
 
+_SHARDED_WINDOW_PARAMS = dict(radius=25, knn=6, window_size=300, overlap=20, min_cells_per_window=20, hip_cost_dtype="float32")
+
+
 def _sharded_device_worker(rank, world, rdv, out_dir, transport="host"):
     """One rank of `world`: device-side sharded prune + cost and ShardedSweeps; every rank's complete outputs are written for
     the parent to check.  transport "host": all ranks on GPU 0, exchanging through the host transport (RCCL refuses several
@@ -600,6 +603,13 @@ def _sharded_device_worker(rank, world, rdv, out_dir, transport="host"):
         out = sh.download()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, cost=cost, checked=checked, viol=viol, match=match, tris=tris,
                  sign=sign, **out)
+        # whole windows in runs of the plan + the window merge per rank, the seam rows over the same communicator (dist.MergeChannel)
+        from same_amd.dist import sharded_merged_window_incumbent
+
+        merged = sharded_merged_window_incumbent(synth.to_frame(ref), synth.to_frame(mov), commonCT=synth.type_columns(5), group=group,
+                                                 ctx=ctx,
+                                                 comm=comm, optim_params=_SHARDED_WINDOW_PARAMS)
+        merged.to_pickle(os.path.join(out_dir, f"merged{rank}.pkl"))
         group.barrier()
         L.same_sweep_unbind(sweep)
         comm.close()
@@ -626,6 +636,16 @@ def _check_sharded_rank_outputs(tmp_path, oracle, world):
         ob, oa, om3, ofl = oracle.area_flip(mov["xy"], ref["xy"], tris, match)
         assert np.array_equal(o["before"], ob) and np.array_equal(o["after"], oa, equal_nan=True)
         assert np.array_equal(o["matched3"], om3) and np.array_equal(o["flipped"], ofl)
+    # the window merge dealt over the ranks, its seam rows exchanged over the ranks' transport: the parts are the single process's table
+    import pandas as pd
+
+    import same_amd
+    from same_amd.merge import join_merged_parts
+
+    want = same_amd.sliding_window_incumbent(synth.to_frame(ref), synth.to_frame(mov), commonCT=synth.type_columns(5),
+                                             optim_params=dict(_SHARDED_WINDOW_PARAMS), merge=True)
+    parts = [pd.read_pickle(tmp_path / f"merged{r}.pkl") for r in range(world)]
+    assert len(want) > 5000 and all(0 < len(p) < len(want) for p in parts) and join_merged_parts(parts).equals(want)
 
 
 def test_rccl_between_devices_sharded_paths(tmp_path, oracle):
