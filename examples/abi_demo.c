@@ -102,7 +102,7 @@ int main(void) {
     CHECK(same_window_create(ctx, &win_b));
     const double box[4] = {-100.0, 100.0, -100.0, 100.0};
     const int64_t one_window[2] = {0, 4};          /* simplex offsets: window 0 owns triangles [0, 4) */
-    int64_t wc[4], fc[3], st[8];
+    int64_t wc[4], fc[4], st[8];
     CHECK(same_window_stage(&win, 1, smov, sref, box, 12.0, K, 1.0, wc));
     double wcost[NM * K];
     CHECK(same_window_fetch(win, SAME_WINDOW_COSTS, wcost, wc[3] * (int64_t)sizeof(double)));
@@ -125,7 +125,7 @@ int main(void) {
     const int64_t two_windows[3] = {0, 4, 8};
     int32_t tris2[24];
     for (int q = 0; q < 24; ++q) tris2[q] = tris[q % 12];
-    int64_t c0[4], c1[4], wc2[8], fc2[6], st2[16];
+    int64_t c0[4], c1[4], wc2[8], fc2[8], st2[16];
     int32_t mrow2[2 * NM];
     uint8_t pflag2[2 * NM];
     for (int q = 0; q < 4; ++q) CHECK(same_ctx_stat(ctx, q, &c0[q]));
@@ -134,7 +134,7 @@ int main(void) {
     for (int q = 0; q < 4; ++q) CHECK(same_ctx_stat(ctx, q, &c1[q]));
     int same_window = 1;
     for (int b = 0; b < 2; ++b) {
-        same_window = same_window && fc2[3 * b] == fc[0] && fc2[3 * b + 1] == fc[1];
+        same_window = same_window && fc2[4 * b] == fc[0] && fc2[4 * b + 1] == fc[1];
         for (int q = 0; q < 4; ++q) same_window = same_window && wc2[4 * b + q] == wc[q];
         for (int q = 0; q < 8; ++q) same_window = same_window && st2[8 * b + q] == st[q];
         for (int i = 0; i < wc[2]; ++i) same_window = same_window && mrow2[b * wc[2] + i] == mrow[i] && pflag2[b * wc[2] + i] == pflag[i];

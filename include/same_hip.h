@@ -41,8 +41,9 @@ extern "C" {
 #define SAME_EIO (-5)       /* HIP or RCCL call failed; see same_last_error() */
 #define SAME_ENODEV (-19)   /* no usable GPU */
 #define SAME_ERANGE (-34)   /* an index in pairs/triangles/match is out of range */
+#define SAME_EUNSURE (-11)  /* same_delaunay2d only: not an error -- the points are too close to degenerate to answer for Qhull */
 
-#define SAME_ABI_VERSION 7
+#define SAME_ABI_VERSION 8
 #define SAME_MAX_KNN 448     /* largest k supported by the prune kernel (k <= 64 runs the 8-rows-per-wave form) */
 #define SAME_MAX_TYPES 4096  /* largest T (type columns) */
 
@@ -58,7 +59,7 @@ typedef struct same_sweep same_sweep; /* resident state of one lazy-constraint s
  * part 2  DEVICE-RESIDENT forms (operands already in HBM; enqueue     same_dense_cost_*_dev, same_knn_prune_dev, same_knn_index_*,
  *         only unless noted)                                          same_knn_prune_indexed_dev, same_padded_cost_*_dev, same_tri_*_dev,
  *                                                                     same_area_flip_dev, same_xyorder_sweep_dev, same_orient_*_dev, same_first_candidate_dev
- * part 3  WINDOW path, sections resident (BASELINE cfg 5)             same_section_*, same_window_*, same_merge_acc_*
+ * part 3  WINDOW path, sections resident (BASELINE cfg 5)             same_section_*, same_window_*, same_merge_acc_*, same_delaunay2d (host)
  * part 4  COMM: RCCL collectives between the ranks' contexts          same_comm_*, same_allgather_dev*, same_allreduce_dev
  * Every declaration cites the reference lines it replaces (file:line into the reference tree).
  * Measurement hooks and opt-in controls that are NOT the path -- runtime-call counters, timers, the spread allocator, the fixed-point
@@ -376,10 +377,16 @@ int same_first_candidate_dev(same_ctx *ctx, const int32_t *didx, int64_t rows, i
  *     stage call's out_counts[4 i + 2]); out_match_row = SECTION row of the matched reference cell or -1; out_point_flag = per-cell
  *     flag byte: bit 0 the XY-order sweep flags the cell (src/violationhelper.py:100-104), bit 1 the cell is a vertex of a triangle
  *     whose signed area flips (src/same.py:1464-1469); out_stats[8 i ..] = {orientation checked, flipped, XY comparisons, XY
- *     violations, triangles with a violation, area flips, greedy rounds, matched cells}; out_counts[3 i ..] = {kept, added back,
- *     cosines within near_tol of cos_thr} (prefiltered: {n, 0, 0}).  When a window's third count is not zero nothing of that window
- *     counts (its slices of the outputs mean nothing, no triangles are left on the device): the caller re-decides its triangles with
- *     the reference's literal arccos (same_amd/triangles.py) and calls again for that window with prefiltered = 1.  The call's
+ *     violations, triangles with a violation, area flips, greedy rounds, matched cells}; out_counts[4 i ..] = {kept, added back,
+ *     cosines within near_tol of cos_thr, order ties} (prefiltered: {n, 0, 0, order ties}).  When a window's third count is not zero
+ *     nothing of that window counts (its slices of the outputs mean nothing, no triangles are left on the device): the caller
+ *     re-decides its triangles with the reference's literal arccos (same_amd/triangles.py) and calls again for that window with
+ *     prefiltered = 1.  ORDER TIES (ABI 8) count the places where the reference's answer depends on the order in which the
+ *     triangulation lists its triangles or their corners, beyond which triangles there are: an edge of the XY-order sweep whose
+ *     ends share an x or a y (`<` is not symmetric, src/violationhelper.py:68-75), a signed area or orientation within rounding of
+ *     zero (src/same.py:1401, :658), two same-type triangles of one node whose perimeters agree to the rounding of a three-term
+ *     sum (src/helpers.py:334-340 keeps the first).  With Qhull's own simplices the count is of no consequence; a caller that
+ *     triangulates otherwise (same_delaunay2d: same triangles, another order) asks Qhull for a window whose count is not zero.  The call's
  *     simplices go up in ONE copy; per group of eight windows one zeroing launch, 14 kernels (17 with fp64 costs) and one launch
  *     that writes the answers into the pinned blocks; ONE wait for the batch (more greedy rounds, in batches with a wait each, only
  *     for a window in which a pair could still be taken after the rounds enqueued up front).
@@ -415,6 +422,23 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
                               int prefiltered, double radius, int angle_enabled, double cos_thr, double near_tol, int ignore_same_type,
                               int ensure_min_triangle_per_node, double no_match_penalty, int32_t *out_match_row,
                               uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_counts);
+
+/* ---- a6 on the window path without the library call --------------------------------------------------------------------------
+ * The reference triangulates every window's kept aligned cells with scipy.spatial.Delaunay (Qhull; src/same.py:1023), on the host
+ * -- three quarters of a cfg 5 pass.  same_delaunay2d is this library's own triangulator (HOST code, no device, no context, safe to
+ * call from many threads at once): a sweep-hull construction with edge flips, every sign it relies on clear of its rounding bound by
+ * three orders of magnitude.  It ANSWERS only when the answer is beyond doubt the set of triangles Qhull gives: after the
+ * construction every interior edge and hull corner is measured the way Qhull sees it (distance of the fourth point from the lifted
+ * triangle's plane in 'Qbb'-scaled paraboloid coordinates, against Qhull's round-off allowance for these coordinates), and when the
+ * smallest of these ratios (*out_margin) is not above `guard`, or a sign was in doubt on the way (duplicate, collinear, cocircular
+ * points), the return is SAME_EUNSURE and the caller asks Qhull as the reference does.  Measured against scipy 1.15.3 on 1 900 sets
+ * (uniform, blobs, clusters, strips; offsets to 3e8): Qhull's triangles differ from the exact Delaunay triangulation only where the
+ * margin is below 0.07 (tools/delaunay_margin.py, profiles/r06_delaunay_margin.md); same_amd uses guard = 16.
+ * xy: n points (x, y) interleaved.  out_tris: room for `cap` triangles (2 n - 5 always suffices); *out_n_tris triangles are written,
+ * counter-clockwise, in this function's own order (Qhull's order and corner order are its own: see the ORDER TIES of
+ * same_window_filter_finish for what that touches).  SAME_OK | SAME_EUNSURE | SAME_EINVAL (NULL, n < 0, cap too small) | SAME_ENOMEM. */
+int same_delaunay2d(const double *xy, int64_t n, int32_t *out_tris, int64_t cap, int64_t *out_n_tris, double guard,
+                    double *out_margin /* may be NULL */);
 
 /* ---- f3 on the window path: the window merge where the windows' matches are ------------------------------------------------
  * The reference trims every window's match table to the window's central region (src/same.py:565-582), concatenates the tables and

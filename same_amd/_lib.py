@@ -23,7 +23,7 @@ c_vp = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_U8, DT_I32, DT_U64, DT_F64 = 0, 1, 2, 3     # SAME_DT_*
 OP_SUM, OP_MAX, OP_MIN = 0, 1, 2               # SAME_OP_*
 SPREAD_INFO_LEN = 14                           # SAME_SPREAD_INFO_LEN
@@ -104,6 +104,7 @@ _PROTOTYPES = {
     "same_window_fetch": [c_vp, c_int, c_vp, c_i64],
     "same_window_filter_finish": [c_vp, c_int, c_vp, c_vp, c_int, c_dbl, c_int, c_dbl, c_dbl, c_int, c_int, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "same_merge_dedup": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(c_i64)],
+    "same_delaunay2d": [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_i64), c_dbl, ctypes.POINTER(c_dbl)],
     "same_section_set_codes": [c_vp, c_vp, c_i64],
     "same_merge_acc_create": [c_vp, ctypes.POINTER(c_vp)],
     "same_merge_acc_destroy": [c_vp],
@@ -133,7 +134,7 @@ _PROTOTYPES = {
 EXPORTS = tuple(_PROTOTYPES)
 
 
-SAME_EINVAL, SAME_ENOMEM, SAME_EIO, SAME_ENODEV, SAME_ERANGE = -22, -12, -5, -19, -34   # include/same_hip.h
+SAME_EINVAL, SAME_ENOMEM, SAME_EIO, SAME_ENODEV, SAME_ERANGE, SAME_EUNSURE = -22, -12, -5, -19, -34, -11   # include/same_hip.h
 
 
 class SameHipError(RuntimeError):

@@ -7,7 +7,8 @@ import time
 from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 
 RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s",
-               "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged", "per_rank",
+               "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged",
+               "native_delaunay", "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
                "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0",
                "amdahl_bound_at_8_ranks", "amdahl",
@@ -197,6 +198,31 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
 
         calls_only = {"one_thread": calls_only_pass(1), "worker_threads": n_workers, "with_the_worker_threads": calls_only_pass(n_workers)}
         tri_cache[0] = None
+    # OPT-IN, outside the timed region and never part of `value`: the timed step itself with optim_params["hip_delaunay"] = "native" --
+    # the windows triangulated by libsame_hip's own triangulator on threads of this process wherever its answer is provably Qhull's set
+    # of triangles, windows that count an order tie finished again with scipy's (same_amd/delaunay.py).  Its table must BE the timed step's
+    native = None
+    if on_device and not getattr(args, "no_extras", False):
+        from same_amd import delaunay as _del
+
+        tr = _del.shared()
+
+        def native_pass():
+            return same_amd.sliding_window_incumbent(*frame_args, commonCT=cols, optim_params=dict(op, hip_delaunay="native"),
+                                                     return_stats=True, ctx=ctx, _shard=shard, merge=True, _merge_channel=channel,
+                                                     workers=n_workers)
+
+        first = all_ranks(native_pass)
+        identical = bool(first[0].equals(merged)) and first[1] == stats
+        del first
+        before, passes = (tr.submitted, tr.asked_qhull), 3
+        group.barrier()
+        tq = time.perf_counter()
+        for _ in range(passes):
+            all_ranks(native_pass)
+        group.barrier()
+        native = {"seconds": time.perf_counter() - tq, "passes": passes, "windows": len(my_plan), "identical": identical,
+                  "triangulated": tr.submitted - before[0], "sent_back_to_qhull": tr.asked_qhull - before[1], "threads": tr.threads}
     # after a rank's last window: the merge (keys, de-duplication, matching; the seam rows' exchange and the common seam step) and the
     # columns of the rows that stay -- one thread, while the workers' threads are done
     seconds_of = lambda prefix: sum(sec for name, (_c, sec) in rep.items() if name.startswith(prefix))
@@ -214,7 +240,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
                 "seam_exchange_s_per_step": exchange_s / steps, "seam_step_s_per_step": seam_step_s / steps,
                 "merge_stages_s_per_step": {name: sec / steps for name, (_c, sec) in sorted(rep.items()) if name.startswith("merge:")},
                 "windows_per_s_triangulations_given": no_qhull, "windows_per_s_triangulations_given_merged": no_qhull_merged,
-                "window_calls_only_windows_per_s": calls_only, "merged_rows": int(len(merged)),
+                "window_calls_only_windows_per_s": calls_only, "native_delaunay": native, "merged_rows": int(len(merged)),
                 "seam_rows_sent_per_step": None if channel is None else (seam1[0] - seam0[0]) / steps,
                 "seam_gather_ms": None if channel is None else (seam1[1] - seam0[1]) / steps,
                 "runtime_calls_per_window": calls_per_window, "runtime_calls_per_pass_merge": per_pass,
@@ -326,6 +352,23 @@ def _amdahl_at_8_ranks(same_amd, frame_args, cols, op, deal, every, steps, ctx, 
                      "eight shares' seam rows"}
 
 
+def _native_record(every):
+    recs = [r.get("native_delaunay") for r in every]
+    if any(r is None for r in recs):
+        return None
+    return {"windows_per_s": sum(r["windows"] * r["passes"] for r in recs) / max(r["seconds"] for r in recs),
+            "table_identical_to_the_timed_step": all(r["identical"] for r in recs),
+            "windows_triangulated": sum(r["triangulated"] for r in recs), "sent_back_to_qhull": sum(r["sent_back_to_qhull"] for r in recs),
+            "threads_per_rank": recs[0]["threads"], "passes": recs[0]["passes"],
+            "what": "OPT-IN (optim_params['hip_delaunay'] = 'native'), measured after the timed region and never part of `value`: the "
+                    "timed step's own call with the windows triangulated by libsame_hip's triangulator (same_delaunay2d, host threads of "
+                    "this "
+                    "process, no helper processes) wherever its answer is beyond doubt Qhull's set of triangles; a window in which the "
+                    "device counts an order tie -- a place where the reference's numbers hang on Qhull's ORDER of triangles or corners -- "
+                    "is finished again with scipy's simplices (`sent_back_to_qhull`).  `table_identical_to_the_timed_step`: this rank's "
+                    "part of the merged table and every window's counters equal the timed (scipy) step's, checked in this run"}
+
+
 def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib_top, steps, warmup, dt, n, T, on_device, n_workers,
           cpu, parity, api_path, amdahl, _qp):
     import numpy as np
@@ -413,6 +456,7 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                                                     "which every window's Delaunay simplices are remembered from an earlier pass, summed "
                                                     "over the ranks -- the pre-merge table of every window (as round 5 measured it) and, "
                                                     "`_merged`, the timed step's own call (window merge included)",
+        "native_delaunay": _native_record(every),
         "window_calls_only_windows_per_s": mine_rec["window_calls_only_windows_per_s"],
         "window_calls_only_means": "DIAGNOSTIC, rank 0: windows.iter_device_windows over this rank's windows with the triangulations "
                                    "remembered and nothing done with the results -- the two batched library calls per eight windows and "

@@ -59,6 +59,16 @@ __device__ __forceinline__ int8_t orient_sign(double2_t a, double2_t b, double2_
     return (int8_t)((v > 0.0) - (v < 0.0));
 }
 
+// The orientation (:57-60) or the signed area (below) of a, b, c is so close to zero that the corners taken in another order could
+// give the other sign, or zero: both forms are sums of products of coordinates or coordinate differences, each bounded by
+// (|largest coordinate| + longest side) x longest side, with a handful of roundings
+__device__ __forceinline__ bool sign_in_doubt(double2_t a, double2_t b, double2_t c) {
+    const double v = (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x);
+    const double side = fmax(fmax(fabs(b.x - a.x) + fabs(b.y - a.y), fabs(c.x - a.x) + fabs(c.y - a.y)), fabs(c.x - b.x) + fabs(c.y - b.y));
+    const double reach = fmax(fmax(fabs(a.x), fabs(b.x)), fabs(c.x)) + side;
+    return fabs(v) <= 3.6e-15 * reach * side;       // 16 eps
+}
+
 // src/helpers.py:73-77
 __device__ __forceinline__ double signed_area(double2_t p1, double2_t p2, double2_t p3) {
     return 0.5 * (p1.x * (p2.y - p3.y) + p2.x * (p3.y - p1.y) + p3.x * (p1.y - p2.y));

@@ -118,6 +118,20 @@ __global__ __launch_bounds__(256) void filter_emit_kernel(Batch<FilterArgs> b) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n_keep = (int64_t)w.counters[FC_KEEP], n_add = (int64_t)w.counters[FC_ADD];
     if (q == 0) w.counters[FC_TR] = (unsigned long long)(n_keep + n_add);
+    // ORDER TIES (FC_TIES, SC_TIES): places where the reference's answer depends on the ORDER Qhull lists triangles or their corners
+    // in, not only on which triangles there are -- counted so that a caller whose triangulation is not Qhull's (same_delaunay2d) knows
+    // when to ask Qhull after all.  Here: a node that asks for its best same-type triangle and has a second one whose perimeter is
+    // within the rounding of a three-term sum (the sum's order is the corners' order; equal perimeters go to the first triangle)
+    if (w.best_p && q < w.Tr && w.cls[q] == 3) {
+        bool tie = false;
+        for (int c = 0; c < 3; ++c) {
+            const int32_t v = w.raw[3 * q + c];
+            if (!asks(w.has_kept, w.any_valid, w.best_t, v)) continue;
+            const int64_t best = (int64_t)~w.best_t[v];
+            tie |= best != q && fabs(w.perim[q] - w.perim[best]) <= 1.8e-15 * w.perim[best];
+        }
+        if (tie) atomicAdd(&w.counters[FC_TIES], 1ull);
+    }
     if (q >= n_keep + n_add) return;
     const int64_t t = q < n_keep ? w.klist[q] : (int64_t)~w.best_t[w.nlist[q - n_keep]];
     w.out[3 * q] = w.raw[3 * t];
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(256) void window_sweeps_kernel(Batch<SweepArgs> b) 
     unsigned long long *__restrict__ counters = w.counters;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t Tr = w.dTr ? (int64_t)*w.dTr : w.Tr;
-    int checked = 0, flipped = 0, ncmp = 0, nviol = 0, tv = 0, aflip = 0;
+    int checked = 0, flipped = 0, ncmp = 0, nviol = 0, tv = 0, aflip = 0, ties = 0;
     if (t < Tr) {
         const int32_t v[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
         const int32_t m[3] = {match_row[v[0]], match_row[v[1]], match_row[v[2]]};
@@ -241,6 +255,8 @@ __global__ __launch_bounds__(256) void window_sweeps_kernel(Batch<SweepArgs> b) 
             if (m[p] >= 0 && m[q] >= 0) {  // both matched (implies >= 2 matched vertices, violationhelper.py:58-60)
                 ++ncmp;
                 const uint8_t e2 = xyorder_edge(a[p], a[q], r[p], r[q]);
+                // equal coordinates at an edge's ends: `<` one way round is not `<` the other way round (order tie, see filter_emit_kernel)
+                ties |= a[p].x == a[q].x || a[p].y == a[q].y || r[p].x == r[q].x || r[p].y == r[q].y;
                 nviol += ((e2 >> 1) & 1) + ((e2 >> 2) & 1);
                 if (e2) { tv = 1; cell_flag_or(pflag, v[p], 1u); cell_flag_or(pflag, v[q], 1u); }
             }
@@ -248,22 +264,24 @@ __global__ __launch_bounds__(256) void window_sweeps_kernel(Batch<SweepArgs> b) 
         if (all3) {
             const double bf = signed_area(a[0], a[1], a[2]), af = signed_area(r[0], r[1], r[2]);
             aflip = bf * af < 0.0;                                         // src/same.py:1401
+            // a sign within rounding of zero may come out the other way with the corners in another order (order tie)
+            ties |= sign_in_doubt(a[0], a[1], a[2]) || sign_in_doubt(r[0], r[1], r[2]);
             if (aflip)
                 for (int q = 0; q < 3; ++q) cell_flag_or(pflag, v[q], 2u);
         }
     }
-    int vals[6] = {checked, flipped, ncmp, nviol, tv, aflip};
+    int vals[7] = {checked, flipped, ncmp, nviol, tv, aflip, ties};
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < 7; ++q)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vals[q] += __shfl_down(vals[q], off, 64);
-    __shared__ int part[4][6];
+    __shared__ int part[4][7];
     if ((threadIdx.x & 63) == 0)
-        for (int q = 0; q < 6; ++q) part[threadIdx.x >> 6][q] = vals[q];
+        for (int q = 0; q < 7; ++q) part[threadIdx.x >> 6][q] = vals[q];
     __syncthreads();
-    if (threadIdx.x < 6) {      // one atomic per block per counter (integer sums: order-independent)
+    if (threadIdx.x < 7) {      // one atomic per block per counter (integer sums: order-independent); SC_CHECKED .. SC_AFLIP, then SC_TIES
         const int s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        if (s) atomicAdd(&counters[threadIdx.x], (unsigned long long)s);
+        if (s) atomicAdd(&counters[threadIdx.x < 6 ? threadIdx.x : SC_TIES], (unsigned long long)s);
     }
 }
 
@@ -272,7 +290,7 @@ struct FilterPlan {
     FilterArgs args{};
     void *zero = nullptr;                     // head of the filter buffer, zeroed with the group's
     size_t zero_bytes = 0;
-    unsigned long long *counters = nullptr;   // [4] FC_*
+    unsigned long long *counters = nullptr;   // FC_*
     bool readd = false;
 };
 
@@ -466,7 +484,7 @@ int enqueue_finish_copy(same_window *w, FinishPlan *p) {
     return SAME_OK;
 }
 
-int read_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats) {
+int read_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *out_point_flag, int64_t *out_stats, int64_t *out_ties) {
     same_ctx *ctx = w->ctx;
     const int64_t n = w->n_ua, P = w->P;
     char *h = static_cast<char *>(w->host) + w->host_finish_off;
@@ -503,6 +521,7 @@ int read_finish(same_window *w, FinishPlan *p, int32_t *out_match_row, uint8_t *
     }
     for (int q = 0; q < 8; ++q) out_stats[q] = (int64_t)cnt[q];
     out_stats[SC_ROUNDS] = rounds;
+    *out_ties += (int64_t)cnt[SC_TIES];
     memcpy(out_match_row, h + p->o_match_row, (size_t)n * sizeof(int32_t));
     memcpy(out_point_flag, h + p->o_pflag, (size_t)n);
     return SAME_OK;
@@ -526,7 +545,7 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         n_cells += windows[i]->n_ua;
     }
     REQUIRE(ctx, (simplex_offsets[n_windows] == 0 || simplices) && (n_cells == 0 || (out_match_row && out_point_flag)));
-    for (int q = 0; q < 3 * n_windows; ++q) out_counts[q] = 0;
+    for (int q = 0; q < 4 * n_windows; ++q) out_counts[q] = 0;
     for (int q = 0; q < 8 * n_windows; ++q) out_stats[q] = 0;
     SAME_TRY(same_use(ctx));
     for (int i = 0; i < n_windows; ++i)
@@ -608,11 +627,11 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
                 if (w->host_dev) {
                     ca[n_g++] = CopyArgs{{it.plan.gs.sel, it.filtered ? it.fplan.counters : nullptr},
                                          {w->host_dev + w->host_finish_off, w->host_dev + w->host_filter_off},
-                                         {it.plan.back_bytes, it.filtered ? 4 * sizeof(unsigned long long) : 0}};
+                                         {it.plan.back_bytes, it.filtered ? FC_COPIED * sizeof(unsigned long long) : 0}};
                 } else {
                     if (it.filtered) {
                         unsigned long long *hf = reinterpret_cast<unsigned long long *>(static_cast<char *>(w->host) + w->host_filter_off);
-                        hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+                        hipError_t e = hipMemcpyAsync(hf, it.fplan.counters, FC_COPIED * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
                         ++ctx->stats[SAME_STAT_COPIES];
                         if (e != hipSuccess) rc = same_fail(ctx, SAME_EIO, "filter counters", e);
                     }
@@ -636,7 +655,7 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
         same_window *w = windows[i];
         Item &it = items[(size_t)i];
         const int64_t Tr = simplex_offsets[i + 1] - simplex_offsets[i];
-        int64_t *counts = out_counts + 3 * i, *stats = out_stats + 8 * i;
+        int64_t *counts = out_counts + 4 * i, *stats = out_stats + 8 * i;
         if (!it.enqueued) {                 // no kept aligned cell: nothing to match, nothing to sweep
             w->filtered = w->finished = 1;
             continue;
@@ -653,6 +672,7 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
             counts[0] = n_keep;
             counts[1] = n_add;
             counts[2] = n_near;
+            counts[3] = (int64_t)hf[FC_TIES];
             if (n_near) {
                 for (int q = 0; q < 8; ++q) stats[q] = 0;
                 continue;
@@ -662,7 +682,7 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
             counts[0] = Tr;
             w->Tr = Tr;
         }
-        SAME_TRY(read_finish(w, &it.plan, match_out, flag_out, stats));
+        SAME_TRY(read_finish(w, &it.plan, match_out, flag_out, stats, counts + 3));
         w->filtered = w->finished = 1;
     }
     return SAME_OK;

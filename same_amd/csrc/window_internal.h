@@ -130,10 +130,10 @@ struct Cover {
 };
 
 // counters of the filter: [0] kept (class 0), [1] added back, [2] cosines within `tol` of the threshold, [3] triangles left
-enum { FC_KEEP = 0, FC_ADD = 1, FC_NEAR = 2, FC_TR = 3 };
+enum { FC_KEEP = 0, FC_ADD = 1, FC_NEAR = 2, FC_TR = 3, FC_TIES = 4, FC_COPIED = 5 };
 // counters of the finish call: [0] orientation checked, [1] flipped, [2] XY comparisons, [3] XY violations, [4] triangles with
 // one, [5] area flips, [6] (host) greedy rounds, [7] matched aligned cells, [8] pairs the greedy rule could still take
-enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7, SC_REMAINING = 8, SC_COUNT = 16 };
+enum { SC_CHECKED = 0, SC_FLIPPED = 1, SC_CMP = 2, SC_VIOL = 3, SC_TVIOL = 4, SC_AFLIP = 5, SC_ROUNDS = 6, SC_MATCHED = 7, SC_REMAINING = 8, SC_TIES = 9, SC_COUNT = 16 };
 
 }  // namespace win
 

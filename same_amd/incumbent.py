@@ -346,7 +346,8 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
     workers: threads walking this process's windows on the device route (default: 2 where the process has >= 8 CPUs, else 1).
     A window whose prune leaves no pairs raises the ValueError run_same raises for it (src/same.py:1003), as the reference's loop does.
     `triangulator`, `batch` (windows per library call on the device route): see windows.iter_device_windows.  `_route` = 'device' |
-    'general' (testing: forces a route).
+    'general' (testing: forces a route).  optim_params["hip_delaunay"] = "native" (device route): the windows are triangulated by
+    libsame_hip's own triangulator where that is provably the same as asking scipy (delaunay.py); the table is the same.
     merge=True: the table after `merge_window_matches_unique_ref` (src/helpers.py:692-815) -- one row per aligned and per reference cell,
     aligned ids ascending -- without the pre-merge table ever being laid out: the merge reads the rows' keys, and only the rows it keeps
     get their columns.  With `_shard` and a `_merge_channel` (dist.MergeChannel) the result is this rank's PART of the merged table
@@ -364,6 +365,11 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
         if merge and job.all_matches:
             raise ValueError("merge=True does not resume from an outprefix that already holds windows")
         if fast:
+            if triangulator is None:
+                from . import delaunay
+
+                if delaunay.mode(job.optim_params) == "native":       # optim_params["hip_delaunay"] / $SAME_DELAUNAY (delaunay.py)
+                    triangulator = delaunay.shared()
             table = _device_route(job, frames, workers, window_local_indices, triangulator, stats, merge, _merge_channel, batch)
         else:
             table = _general_route(job, frames, window_local_indices, stats, ctx)

@@ -724,7 +724,8 @@ def filter_finish_windows(states, simplices, radius, angle_enabled, cos_thr, nea
                           ensure_min_triangle_per_node=True, prefiltered=False):
     """same_window_filter_finish for a batch (one wait for all of them): `simplices[i]` are window i's Delaunay simplices, or with
     `prefiltered` its kept triangles.  -> [(kept, added back, near, match_row, flag byte, stats dict) per window]; a window with near != 0
-    has None for the last three."""
+    has None for the last three.  Every state's `order_ties` is set to the call's count of places where the answer hangs on the ORDER
+    of the triangles or of their corners (include/same_hip.h; of consequence only when the simplices are not Qhull's own)."""
     ctx, n = states[0].ctx, len(states)
     tris = [ops._tris(t) for t in simplices]
     offsets = np.zeros(n + 1, np.int64)
@@ -733,7 +734,7 @@ def filter_finish_windows(states, simplices, radius, angle_enabled, cos_thr, nea
     kept_cells = [s.counts[2] for s in states]
     cell_off = np.concatenate(([0], np.cumsum(kept_cells))).astype(np.int64)
     match_row, flag = np.empty(int(cell_off[-1]), np.int32), np.empty(int(cell_off[-1]), np.uint8)
-    stats, counts = np.zeros((n, 8), np.int64), np.zeros((n, 3), np.int64)
+    stats, counts = np.zeros((n, 8), np.int64), np.zeros((n, 4), np.int64)
     with ctx.lock:
         ctx.check(ctx.lib.same_window_filter_finish(_handles(states), n, flat.ctypes.data, offsets.ctypes.data, int(bool(prefiltered)),
                                                     float(radius),
@@ -742,7 +743,7 @@ def filter_finish_windows(states, simplices, radius, angle_enabled, cos_thr, nea
                                                     flag.ctypes.data, stats.ctypes.data, counts.ctypes.data), "same_window_filter_finish")
     out = []
     for i, s in enumerate(states):
-        kept, added, near = (int(c) for c in counts[i])
+        kept, added, near, s.order_ties = (int(c) for c in counts[i])
         s.n_triangles = 0 if near else kept + added
         if near:
             out.append((kept, added, near, None, None, None))
@@ -822,7 +823,8 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     Windows go to the library in BATCHES of `batch` (default $SAME_WINDOW_BATCH, else 8): one stage call, and later one filter + finish
     call, for up to that many windows -- one wait per call instead of one per window, and the device works on one window while the host
     enqueues the next.  The states of a batch stay live (`result.state`) until the generator is asked for the first window of the next.
-    `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`.
+    `triangulator` (default: the Qhull helper pool) is anything with `submit(points, key=...) -> ticket with .result()`; a ticket
+    whose `.native` is true after `.result()` brought simplices that are not scipy's own and has `.qhull()` for those (delaunay.py).
     `triangulate=False` stops after the stage call (rows, prune, costs, compaction): the caller brings its own triangles
     (api.sliding_window_matching with a caller's triangulation) and reads pairs / costs through `state.fetch`.
     `collector(states, windows)` is called once per finished batch with its windows' live states (the window merge's accumulator:
@@ -837,8 +839,10 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
     ctx = ops._ctx(ctx)
     angle_enabled, cos_thr = cos_threshold(min_angle_deg)
     near_tol = float(8 * np.spacing(abs(cos_thr))) if (angle_enabled and np.isfinite(cos_thr)) else 0.0
-    depth = qhull_pool.lookahead()
-    qhull_pool.warm(min(depth, len(plan)))
+    own_threads = getattr(triangulator, "threads", None)        # a triangulator with threads of its own (delaunay.NativeTriangulator)
+    depth = qhull_pool.lookahead() if own_threads is None else int(own_threads)
+    if own_threads is None:
+        qhull_pool.warm(min(depth, len(plan)))
     B = max(1, min(int(batch if batch is not None else os.environ.get("SAME_WINDOW_BATCH", "8")), WINDOW_BATCH_MAX, max(len(plan), 1)))
     if batch is None and depth > 0:
         # a rank with three helpers (eight ranks on a 16-CPU host) gains nothing from collecting eight tickets at once
@@ -908,6 +912,15 @@ def iter_device_windows(ref, moving, dref, dmoving, plan, radius=250, knn=8, dis
             res = filter_finish_windows([st for _o, st, _t in todo], tris, radius, angle_enabled, cos_thr, near_tol,
                                         ignore_same_type_triangles,
                                         no_match_penalty)
+        # simplices that are not Qhull's own (delaunay.py: the same triangles in another order): where the window's numbers hang on that
+        # order -- the device counted such places, or a cosine sits at the threshold and the host is about to re-decide the filter --
+        # the window is finished again with scipy's
+        for q, ((_o, state, ticket), r) in enumerate(zip(todo, res)):
+            if getattr(ticket, "native", False) and (state.order_ties or r[2]):
+                with marked("order ties: the window again with Qhull's simplices"):
+                    tris[q] = ticket.qhull()
+                    res[q] = filter_finish_windows([state], [tris[q]], radius, angle_enabled, cos_thr, near_tol,
+                                                   ignore_same_type_triangles, no_match_penalty)[0]
         for (out, state, _t), simplices, (_kept, _added, near, match_row, cell_flags, stats) in zip(todo, tris, res):
             if near:
                 with marked("triangle filter (host: a cosine at the threshold)"):

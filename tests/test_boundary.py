@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in same_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == declared, "ctypes prototypes and header drifted apart"
-    assert lib.same_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.same_abi_version() == _lib.ABI_VERSION == 8
     path_header = open(os.path.join(ROOT, "include", "same_hip.h")).read()
     for hook in ("same_ctx_stat", "same_timer_start", "same_dev_alloc_spread", "same_dense_cost_q32_dev", "same_comm_gather_time"):
         assert hook + "(" not in path_header, hook
