@@ -115,6 +115,20 @@ int main(void) {
            (long long)wc[0], (long long)wc[1], (long long)wc[2], (long long)wc[3], same_costs ? "equal" : "DIFFER FROM", (long long)fc[0]);
     for (int i = 0; i < wc[2]; ++i) printf(" %d", mrow[i]);
     printf("; orientation checked %lld flipped %lld\n", (long long)st[0], (long long)st[1]);
+    /* a6 without scipy (ABI 8): the library's own triangulator, host code.  It answers only when its triangles are beyond doubt the
+     * SET Qhull gives; the aligned cells above have three hull points on one line, which is exactly where it says "ask Qhull"
+     * (SAME_EUNSURE, not an error); the same cells bent off the line are answered.  fc[3] counts the window's ORDER TIES -- places
+     * where the sweeps' numbers hang on the order of the triangles or their corners, which only Qhull's own simplices may decide */
+    double bent[NM * 2], margin = 0.0;
+    for (int i = 0; i < NM; ++i) { bent[2 * i] = axy[2 * i]; bent[2 * i + 1] = axy[2 * i + 1] + 0.37 * i * i; }
+    int32_t own[(2 * NM) * 3];
+    int64_t n_own = 0, n_bent = 0;
+    const int rc_line = same_delaunay2d(axy, NM, own, 2 * NM, &n_own, 16.0, NULL);
+    const int rc_bent = same_delaunay2d(bent, NM, own, 2 * NM, &n_bent, 16.0, &margin);
+    printf("own triangulator: the cells above %s; bent off the line %s, %lld triangles; order ties of the window: %lld\n",
+           rc_line == SAME_EUNSURE ? "are left to Qhull" : "UNEXPECTED", rc_bent == SAME_OK && margin > 16.0 ? "answered" : "UNEXPECTED",
+           (long long)n_bent, (long long)fc[3]);
+    if (rc_line != SAME_EUNSURE || rc_bent != SAME_OK || n_bent != 5) return 6;
     /* the same window TWICE in one batch (two window states), with the sections re-binned on a 50-unit grid from (-100, -100) -- the box is
      * then a union of cells and no row is tested; the runtime calls the library issued for the batch are read from its counters: per window
      * the launches of before, and ONE wait per call for the two windows together */

@@ -796,3 +796,46 @@ def test_fuzz_window_merge_routes_agree(oracle):
             assert joined.equals(want), (rnd, case, world, deal)
             done += 1
     assert done >= 5 * ROUNDS and contested >= 2 * ROUNDS, (done, contested)
+
+
+def test_fuzz_native_triangulator_gives_the_same_tables():
+    """Random crowded jobs (the window-merge family's generator, with coordinate styles that provoke order ties: reference cells on whole
+    coordinates, aligned cells sharing x values) through `sliding_window_incumbent` with optim_params["hip_delaunay"] = "native" and with
+    the default (scipy): the plain table with every window's counters, and the merged table, are identical -- whether a window was
+    answered by libsame_hip's triangulator, left to Qhull by it (lattices, duplicates), or finished again with scipy's simplices after
+    an order tie.  Errors (a window without pairs, a set Qhull refuses) are the same errors."""
+    import same_amd
+    from same_amd import delaunay
+
+    tr = delaunay.shared()
+    done = native_windows = sent_back = 0
+    for rnd in range(FIRST, FIRST + ROUNDS):
+        if ROUNDS > 1 and rnd % 20 == 0:
+            print(f"native triangulator soak round {rnd}", flush=True)
+        rng = np.random.default_rng(4242 + 104729 * rnd)
+        for case in range(10):
+            ref, mov, cols, op = _random_window_job(rng, case)
+            style = int(rng.integers(0, 4))
+            if style == 1:
+                ref[["X", "Y"]] = np.round(ref[["X", "Y"]].to_numpy())
+            elif style == 2:
+                mov["X"] = np.round(mov["X"].to_numpy() * 2) / 2
+            elif style == 3:
+                ref[["X", "Y"]] = ref[["X", "Y"]].to_numpy() + 2.0e4          # far from the origin: Qhull's allowance grows, margins shrink
+                mov[["X", "Y"]] = mov[["X", "Y"]].to_numpy() + 2.0e4
+            for merge in (False, True):
+                kw = dict(commonCT=cols, merge=merge, return_stats=True)
+                try:
+                    want = same_amd.sliding_window_incumbent(ref, mov, optim_params=dict(op), **kw)
+                except Exception as e:  # noqa: BLE001
+                    with pytest.raises(type(e)):
+                        same_amd.sliding_window_incumbent(ref, mov, optim_params=dict(op, hip_delaunay="native"), **kw)
+                    continue
+                before = (tr.submitted, tr.asked_qhull)
+                got = same_amd.sliding_window_incumbent(ref, mov, optim_params=dict(op, hip_delaunay="native"), **kw)
+                assert list(got[0].columns) == list(want[0].columns) and got[0].equals(want[0]), (rnd, case, style, merge)
+                assert got[1] == want[1], (rnd, case, style, merge)
+                native_windows += tr.submitted - before[0]
+                sent_back += tr.asked_qhull - before[1]
+                done += 1
+    assert done >= 10 * ROUNDS and native_windows > 20 * ROUNDS and 0 < sent_back < native_windows, (done, native_windows, sent_back)

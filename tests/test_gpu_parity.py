@@ -990,6 +990,12 @@ def test_plain_c_abi_demo_runs(tmp_path):
     assert "merge de-duplication keeps 4 of 6 rows: 3 2 1 4" in r.stdout
     assert "window: 6 aligned, 7 ref, 6 kept" in r.stdout and "(costs equal the pair list's); 4 of 4 triangles kept" in r.stdout
     assert sum(line.startswith("pair (") for line in r.stdout.splitlines()) >= 6
+    # the demo's aligned cells sit on two horizontal lines: every edge along a line is an order tie of the XY-order sweep
+    import re
+
+    own = re.search(r"own triangulator: the cells above are left to Qhull; bent off the line answered, 5 triangles; "
+                    r"order ties of the window: (\d+)", r.stdout)
+    assert own and int(own.group(1)) > 0
     # the two windows of the batch merged on the device: every pair proposed twice, window 0's rows stay, nothing is left to the host
     said = "window merge on the device: 12 rows from two windows -> 6 after the de-duplication, 0 left to the host, 6 merged rows"
     assert said in r.stdout

@@ -16,4 +16,7 @@ python3 tools/cfg5_lines.py $out/bench_cfg5_2ranks.json
 echo "== bench (cfg5, 2 ranks, round-robin deal)" && timeout -k 10 400 python3 bench.py --workload cfg5 --steps 5 --warmup 1 --gpus 2 --cfg5-deal round_robin --no-extras > $out/bench_cfg5_2ranks_round_robin.json 2> $out/bench_cfg5_2ranks_rr.err || { tail -20 $out/bench_cfg5_2ranks_rr.err; exit 1; }
 python3 tools/cfg5_lines.py $out/bench_cfg5_2ranks_round_robin.json
 echo "== product function profile" && timeout -k 10 300 python3 tools/incumbent_profile.py 1000000 1 > $out/incumbent_profile_merged.log 2>&1 && timeout -k 10 300 python3 tools/incumbent_profile.py 1000000 0 > $out/incumbent_profile_plain.log 2>&1; head -4 $out/incumbent_profile_merged.log
+echo "== own triangulator (opt-in): profile, fuzz soak" && timeout -k 10 400 python3 tools/native_delaunay_profile.py > $out/native_delaunay.log 2>&1 || { tail -20 $out/native_delaunay.log; exit 1; }
+grep "workers\|same_delaunay2d\|scipy" $out/native_delaunay.log | tail -22
+SAME_FUZZ_ROUNDS=${NATIVE_SOAK_ROUNDS:-40} timeout -k 10 600 python3 -m pytest tests/test_gpu_fuzz.py -q -m gpu -s -k native_triangulator > $out/fuzz_native_soak.log 2>&1; rc=$?; tail -3 $out/fuzz_native_soak.log; [ $rc -eq 0 ] || exit $rc
 bash tools/gpu_r06_profile.sh $tag/prof | tail -30
