@@ -33,6 +33,8 @@ struct Tri {
     std::vector<int32_t> tri, half;      // 3 per triangle: vertex at the start of the half-edge; the twin half-edge or -1
     std::vector<int32_t> hprev, hnext, htri, hash;
     std::vector<int32_t> stack;
+    std::vector<std::pair<double, int32_t>> order;   // the points by distance from the seed's circumcentre
+    std::vector<double> judge;                       // per triangle: what turns an in-circle determinant into distance / allowance
     int64_t len = 0;
     int32_t hash_size = 0, hull_start = 0;
     double cx = 0, cy = 0;
@@ -153,7 +155,7 @@ struct Tri {
             cx = X(i0) + (ey * bl - dy * cl) * 0.5 / d;
             cy = Y(i0) + (dx * cl - ex * bl) * 0.5 / d;
         }
-        std::vector<std::pair<double, int32_t>> order;
+        order.clear();
         order.reserve((size_t)n);
         for (int32_t i = 0; i < n; ++i)
             if (i != i0 && i != i1 && i != i2) order.emplace_back(d2(i, cx, cy), i);
@@ -161,11 +163,13 @@ struct Tri {
 
         hash_size = (int32_t)std::ceil(std::sqrt((double)n));
         hash.assign((size_t)hash_size, -1);
-        hprev.assign((size_t)n, 0); hnext.assign((size_t)n, 0); htri.assign((size_t)n, 0);
-        const int64_t max_tris = std::max<int64_t>(2 * n - 5, 1);
-        tri.assign((size_t)max_tris * 3, 0);
-        half.assign((size_t)max_tris * 3, -1);
-        stack.assign(512, 0);
+        // every entry of the arrays below is written before it is read (a vertex's hull links when it joins the hull, a triangle's
+        // corners and twins when it is added): the thread's arrays of its previous call are reused as they are, no fill, no allocation
+        if (hprev.size() < (size_t)n) { hprev.resize((size_t)n); hnext.resize((size_t)n); htri.resize((size_t)n); }
+        const size_t max_halves = (size_t)std::max<int64_t>(2 * n - 5, 1) * 3;
+        if (tri.size() < max_halves) { tri.resize(max_halves); half.resize(max_halves); }
+        if (stack.size() < 512) stack.resize(512);
+        len = 0;
         hull_start = i0;
         hnext[i0] = hprev[i2] = i1;
         hnext[i1] = hprev[i0] = i2;
@@ -228,7 +232,7 @@ struct Tri {
     // is within a few DISTround = eps * (3 * sqrt(3) * 1.01 + 1) * m; z itself carries eps * z of rounding before the scaling.
     // worst = the smallest (distance / allowance) over interior edges (the neighbour's far corner against the triangle's plane) and
     // hull corners (the corner's distance from the chord of its neighbours, and every hull triangle's height over its hull edge).
-    double worst_margin() const {
+    double worst_margin() {
         double m = 0, zmin = std::numeric_limits<double>::infinity(), zmax = 0;
         for (int64_t i = 0; i < n; ++i) {
             const double x = X((int32_t)i), y = Y((int32_t)i), z = x * x + y * y;
@@ -238,31 +242,36 @@ struct Tri {
         const double s = zmax > zmin ? m / (zmax - zmin) : 1.0;                      // Qbb's scale of the lifted coordinate
         const double allow = EPS * (6.25 * m + zmax * s);                            // plane distance Qhull cannot tell from zero
         double worst = std::numeric_limits<double>::infinity();
+        // per triangle (p0, p1, p2): the plane of the lifted triangle is z = 2 c . x + const, c its circumcentre -- slope 2 |c| before the
+        // scaling; a thin triangle's plane is known that much worse (longest side over height); the distance of a point with in-circle
+        // determinant det is s * det / (2 area) / sqrt(1 + slope^2)
+        const int64_t n_tri = len / 3;
+        judge.resize((size_t)n_tri);
+        for (int64_t t = 0; t < n_tri; ++t) {
+            const int32_t p0 = tri[3 * t], p1 = tri[3 * t + 1], p2 = tri[3 * t + 2];
+            const double dx = X(p1) - X(p0), dy = Y(p1) - Y(p0), ex = X(p2) - X(p0), ey = Y(p2) - Y(p0);
+            const double bl = dx * dx + dy * dy, cl = ex * ex + ey * ey, d = dx * ey - dy * ex, area2 = std::fabs(d);
+            const double ccx = X(p0) + (ey * bl - dy * cl) * 0.5 / d, ccy = Y(p0) + (dx * cl - ex * bl) * 0.5 / d;
+            const double slope2 = 4 * s * s * (ccx * ccx + ccy * ccy);
+            const double l2 = std::max(bl, std::max(cl, (ex - dx) * (ex - dx) + (ey - dy) * (ey - dy)));
+            judge[(size_t)t] = s / (area2 * std::sqrt(1 + slope2) * allow * std::max(1.0, l2 / area2));
+        }
         for (int32_t a = 0; a < (int32_t)len; ++a) {
             const int32_t b = half[a];
             const int32_t a0 = a - a % 3;
             const int32_t p0 = tri[a0 + (a + 2) % 3], pr = tri[a], pl = tri[a0 + (a + 1) % 3];
-            const double area2 = std::fabs((X(pr) - X(p0)) * (Y(pl) - Y(p0)) - (Y(pr) - Y(p0)) * (X(pl) - X(p0)));
             if (b < 0) {
                 // a hull edge pr -> pl with p0 behind it: the height of p0 over the edge, in plain coordinates (the facet next to it
                 // is vertical: it holds the point at infinity of 'Qz')
+                const double area2 = std::fabs((X(pr) - X(p0)) * (Y(pl) - Y(p0)) - (Y(pr) - Y(p0)) * (X(pl) - X(p0)));
                 const double edge = std::hypot(X(pl) - X(pr), Y(pl) - Y(pr));
                 worst = std::min(worst, area2 / edge / allow);
                 continue;
             }
             if (b < a) continue;
-            const int32_t b0 = b - b % 3, p1 = tri[b0 + (b + 2) % 3];
+            const int32_t p1 = tri[b - b % 3 + (b + 2) % 3];
             const double det = std::fabs(incircle(X(p0), Y(p0), X(pr), Y(pr), X(pl), Y(pl), X(p1), Y(p1)));
-            // the plane of the lifted triangle is z = 2 c . x + const, c its circumcentre: slope 2 |c| before the scaling
-            const double dx = X(pr) - X(p0), dy = Y(pr) - Y(p0), ex = X(pl) - X(p0), ey = Y(pl) - Y(p0);
-            const double bl = dx * dx + dy * dy, cl = ex * ex + ey * ey, d = dx * ey - dy * ex;
-            const double ccx = X(p0) + (ey * bl - dy * cl) * 0.5 / d, ccy = Y(p0) + (dx * cl - ex * bl) * 0.5 / d;
-            const double slope = 2 * s * std::hypot(ccx, ccy);
-            const double dist = s * det / area2 / std::sqrt(1 + slope * slope);
-            // a thin triangle's plane is known that much worse: longest edge over height
-            const double l2 = std::max(bl, std::max(cl, (ex - dx) * (ex - dx) + (ey - dy) * (ey - dy)));
-            const double thin = std::max(1.0, l2 / area2);
-            worst = std::min(worst, dist / (allow * thin));
+            worst = std::min(worst, det * judge[(size_t)(a0 / 3)]);
         }
         // hull corners: the corner against the chord of its neighbours
         int32_t e = hull_start;
@@ -284,7 +293,7 @@ extern "C" int same_delaunay2d(const double *xy, int64_t n, int32_t *tris, int64
     if (margin) *margin = 0.0;
     if (n < 3) return SAME_EUNSURE;
     try {
-        Tri t;
+        static thread_local Tri t;       // a thread's working arrays stay with it from call to call (a window: ~1.5 MB)
         t.xy = xy;
         t.n = n;
         t.run();

@@ -25,7 +25,7 @@ import numpy as np
 
 from . import _lib
 
-GUARD = 16.0   # x Qhull's round-off allowance; Qhull's triangles were never seen to differ from the exact ones above 0.07
+GUARD = 64.0   # x Qhull's round-off allowance; over 6 000 calibration sets Qhull's triangles never differed from the exact ones above 0.27
 
 
 def mode(optim_params=None):
