@@ -123,10 +123,10 @@ int main(void) {
     for (int i = 0; i < NM; ++i) { bent[2 * i] = axy[2 * i]; bent[2 * i + 1] = axy[2 * i + 1] + 0.37 * i * i; }
     int32_t own[(2 * NM) * 3];
     int64_t n_own = 0, n_bent = 0;
-    const int rc_line = same_delaunay2d(axy, NM, own, 2 * NM, &n_own, 64.0, NULL);
-    const int rc_bent = same_delaunay2d(bent, NM, own, 2 * NM, &n_bent, 64.0, &margin);
+    const int rc_line = same_delaunay2d(axy, NM, own, 2 * NM, &n_own, 16.0, NULL);
+    const int rc_bent = same_delaunay2d(bent, NM, own, 2 * NM, &n_bent, 16.0, &margin);
     printf("own triangulator: the cells above %s; bent off the line %s, %lld triangles; order ties of the window: %lld\n",
-           rc_line == SAME_EUNSURE ? "are left to Qhull" : "UNEXPECTED", rc_bent == SAME_OK && margin > 64.0 ? "answered" : "UNEXPECTED",
+           rc_line == SAME_EUNSURE ? "are left to Qhull" : "UNEXPECTED", rc_bent == SAME_OK && margin > 16.0 ? "answered" : "UNEXPECTED",
            (long long)n_bent, (long long)fc[3]);
     if (rc_line != SAME_EUNSURE || rc_bent != SAME_OK || n_bent != 5) return 6;
     /* the same window TWICE in one batch (two window states), with the sections re-binned on a 50-unit grid from (-100, -100) -- the box is

@@ -433,7 +433,7 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
  * smallest of these ratios (*out_margin) is not above `guard`, or a sign was in doubt on the way (duplicate, collinear, cocircular
  * points), the return is SAME_EUNSURE and the caller asks Qhull as the reference does.  Measured against scipy 1.15.3 on 6 000 sets
  * (uniform, blobs, clusters, strips; offsets to 3e8): Qhull's triangles differ from the exact Delaunay triangulation only where the
- * margin is below 0.3 (tools/delaunay_margin.py, profiles/r06_delaunay_margin.md: 6 000 sets); same_amd uses guard = 64.
+ * margin is below 0.3 (tools/delaunay_margin.py, profiles/r06_delaunay_margin.md: 6 000 sets); same_amd uses guard = 16 (60 x that).
  * xy: n points (x, y) interleaved.  out_tris: room for `cap` triangles (2 n - 5 always suffices); *out_n_tris triangles are written,
  * counter-clockwise, in this function's own order (Qhull's order and corner order are its own: see the ORDER TIES of
  * same_window_filter_finish for what that touches).  SAME_OK | SAME_EUNSURE | SAME_EINVAL (NULL, n < 0, cap too small) | SAME_ENOMEM. */

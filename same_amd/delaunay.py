@@ -25,7 +25,8 @@ import numpy as np
 
 from . import _lib
 
-GUARD = 64.0   # x Qhull's round-off allowance; over 6 000 calibration sets Qhull's triangles never differed from the exact ones above 0.27
+GUARD = 16.0   # x Qhull's round-off allowance: 60 x the largest ratio (0.27) at which Qhull's triangles differed from the exact ones in 6 000
+               # calibration sets (an edge's property, not a set's: larger sets have smaller margins only because they have more edges)
 
 
 def mode(optim_params=None):
@@ -63,27 +64,52 @@ class _Ticket:
         self.owner, self.points, self.future, self.native, self._qhull = owner, points, future, False, None
 
     def result(self):
-        tris = self.future.result()
-        if tris is None:
-            return self.qhull()
+        tris, asked = self.future.result()
+        if tris is None:                        # left to Qhull by the library: a helper has been at it since
+            if self._qhull is None:
+                self._qhull = asked.result()
+                self.owner._note(True)
+            return self._qhull
         self.native = True
+        self.owner._note(False)
         return tris
 
     def qhull(self):
+        """scipy's simplices for a window whose numbers hang on Qhull's order (asked for now: nobody could know before)"""
         if self._qhull is None:
             from . import qhull_pool
 
-            self.owner.asked_qhull += 1
-            self.native = False
             self._qhull = qhull_pool.pool().submit(self.points).result()
+            self.owner._note(True)
+        self.native = False
         return self._qhull
+
+
+class _QhullTicket:
+    """a ticket of the Qhull helper pool behind the same face (`native` stays false)"""
+    native = False
+
+    def __init__(self, ticket):
+        self.ticket = ticket
+
+    def result(self):
+        return self.ticket.result()
+
+    qhull = result
 
 
 class NativeTriangulator:
     """`submit(points, key=None) -> ticket` like the Qhull helper pool's, answered by same_delaunay2d on a thread of this process
-    (ctypes drops the GIL for the call).  `threads`: default one and a half per CPU of this process's share ($SAME_DELAUNAY_THREADS)."""
+    (ctypes drops the GIL for the call).  `threads`: default one and a half per CPU of this process's share ($SAME_DELAUNAY_THREADS).
+    A set the library leaves to Qhull goes to a Qhull helper from the triangulator's thread, windows ahead of its use.  Where most
+    windows end up with scipy anyway (sections on a lattice; whole-number coordinates: order ties in every window) the triangulator
+    steps aside: after `WINDOW` tickets of which more than half went back to scipy, the next `BYPASS` go to the helpers directly."""
+
+    WINDOW, BYPASS = 16, 128
 
     def __init__(self, threads=None, guard=GUARD):
+        from collections import deque
+
         from . import qhull_pool
 
         if threads is None:
@@ -93,13 +119,45 @@ class NativeTriangulator:
             threads = int(os.environ.get("SAME_DELAUNAY_THREADS", "0")) or min(32, max(1, int(1.5 * share)))
         self.threads, self.guard = max(1, int(threads)), float(guard)
         self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="same-delaunay")
-        self.submitted = self.asked_qhull = 0
+        self.submitted = self.asked_qhull = self.bypassed = 0
+        self._recent, self._bypass, self._lock = deque(maxlen=self.WINDOW), 0, threading.Lock()
         _lib.load()
+
+    def _note(self, sent_back):
+        with self._lock:
+            self.asked_qhull += bool(sent_back)
+            self._recent.append(bool(sent_back))
+            if len(self._recent) == self.WINDOW and 2 * sum(self._recent) > self.WINDOW:
+                self._bypass = self.BYPASS
+                self._recent.clear()
+
+    def _work(self, pts):
+        tris = native_simplices(pts, self.guard)
+        if tris is not None:
+            return tris, None
+        from . import qhull_pool
+
+        return None, qhull_pool.pool().submit(pts)
 
     def submit(self, points, key=None):
         pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
-        self.submitted += 1
-        return _Ticket(self, pts, self.pool.submit(native_simplices, pts, self.guard))
+        with self._lock:
+            self.submitted += 1
+            bypass = self._bypass > 0
+            if bypass:
+                self._bypass -= 1
+                self.bypassed += 1
+        if bypass:
+            from . import qhull_pool
+
+            return _QhullTicket(qhull_pool.pool().submit(pts))
+        return _Ticket(self, pts, self.pool.submit(self._work, pts))
+
+    def reset(self):
+        """forget what the recent windows did (a new job may be nothing like the last)"""
+        with self._lock:
+            self._recent.clear()
+            self._bypass = 0
 
     def close(self):
         self.pool.shutdown(wait=True)

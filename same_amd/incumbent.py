@@ -370,6 +370,7 @@ def sliding_window_incumbent(ref, moving, commonCT=None, outprefix=None, moving_
 
                 if delaunay.mode(job.optim_params) == "native":       # optim_params["hip_delaunay"] / $SAME_DELAUNAY (delaunay.py)
                     triangulator = delaunay.shared()
+                    triangulator.reset()
             table = _device_route(job, frames, workers, window_local_indices, triangulator, stats, merge, _merge_channel, batch)
         else:
             table = _general_route(job, frames, window_local_indices, stats, ctx)

@@ -115,3 +115,23 @@ def test_mode_switch(monkeypatch):
     assert delaunay.mode(None) == "native" and delaunay.mode({"hip_delaunay": "qhull"}) == "qhull"
     with pytest.raises(ValueError):
         delaunay.mode({"hip_delaunay": "cgal"})
+
+
+def test_triangulator_steps_aside_where_most_windows_go_back(monkeypatch):
+    """Lattices only: after WINDOW tickets that all went to scipy the next ones go to the helper pool directly (`bypassed`), and
+    `reset()` ends that."""
+    monkeypatch.setenv("SAME_QHULL_WORKERS", "0")
+    tr = delaunay.NativeTriangulator(threads=2)
+    try:
+        gx, gy = np.meshgrid(np.arange(9.0), np.arange(9.0))
+        lattice = np.c_[gx.ravel(), gy.ravel()]
+        want = Delaunay(lattice).simplices
+        for q in range(tr.WINDOW + 5):
+            t = tr.submit(lattice)
+            assert np.array_equal(t.result(), want) and not t.native
+        assert tr.asked_qhull == tr.WINDOW and tr.bypassed == 5
+        tr.reset()
+        t = tr.submit(np.random.default_rng(0).uniform(0, 100, (200, 2)))
+        assert t.result() is not None and t.native and tr.bypassed == 5
+    finally:
+        tr.close()

@@ -4,7 +4,7 @@ coordinates have it) and (Qhull's round-off allowance for these coordinates): it
 margins span many decades -- by moving generic sets away from the origin, which costs Qhull's uncentred lifted coordinate its
 digits -- and compares scipy.spatial.Delaunay's simplices with the exact triangulation (same_delaunay2d with guard = 0: its signs
 are computed on centred differences and do not care about the offset).  Printed per decade of the margin: sets, sets whose scipy
-triangles differ.  The largest margin at which a difference is seen calibrates delaunay.GUARD (64: more than two orders above it).
+triangles differ.  The largest margin at which a difference is seen calibrates delaunay.GUARD (16: 60 x it).
 CPU only.  Usage: python3 tools/delaunay_margin.py [seed=11] [sets=500]"""
 import math
 import os
