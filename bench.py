@@ -89,6 +89,10 @@ def parse():
                     help="--workload cfg5: how the windows are dealt to the ranks: 'block' = runs of the plan (strips of the window grid: "
                          "the window merge only has the strips' borders to settle between ranks), 'round_robin' = every N-th window, "
                          "heaviest first")
+    ap.add_argument("--cfg5-delaunay", choices=("qhull", "native"), default="qhull",
+                    help="--workload cfg5: who triangulates the windows in the TIMED step: 'qhull' = scipy.spatial.Delaunay in helper "
+                         "processes, the reference's own call (default; the opt-in route is then measured after the timed region as "
+                         "`native_delaunay`), 'native' = optim_params['hip_delaunay'] = 'native' (same_amd/delaunay.py)")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous (no GPU): launcher / control-plane check")
     args = ap.parse_args()
     if args.workload is None:

@@ -12,7 +12,7 @@ RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dt
                "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
                "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0",
                "amdahl_bound_at_8_ranks", "amdahl",
-               "seam_exchange", "deal", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull",
+               "seam_exchange", "deal", "delaunay", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull",
                "merged_matches", "parity_spot_check", "rccl",
                "product_function", "api_path_windows_per_s", "api_path", "window_calls_only_windows_per_s")
 
@@ -65,6 +65,9 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     r_df["Cell_Num_Old"], m_df["Cell_Num_Old"] = np.arange(len(r_df)), np.arange(len(m_df))
     cols = synth.type_columns(T)
     op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32", window_size=1200, overlap=300, min_cells_per_window=10)
+    timed_native = getattr(args, "cfg5_delaunay", "qhull") == "native"
+    if timed_native:
+        op["hip_delaunay"] = "native"            # the timed step itself on the opt-in route (same_amd/delaunay.py)
     plan = window_plan(ref["xy"], mov["xy"], 1200, 300, 10)
     deal = getattr(args, "cfg5_deal", None) or "block"
     owner = deal_windows(plan, group.world, deal)
@@ -202,7 +205,7 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     # the windows triangulated by libsame_hip's own triangulator on threads of this process wherever its answer is provably Qhull's set
     # of triangles, windows that count an order tie finished again with scipy's (same_amd/delaunay.py).  Its table must BE the timed step's
     native = None
-    if on_device and not getattr(args, "no_extras", False):
+    if on_device and not timed_native and not getattr(args, "no_extras", False):
         from same_amd import delaunay as _del
 
         tr = _del.shared()
@@ -393,14 +396,18 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                         f"T={T}, r=25 / k={k} prune, fp32 pair costs, Delaunay filter / weights / signs, greedy incumbent, orientation + "
                         "XY-order + area-flip sweeps per window, window merge (one row per aligned and per reference cell)",
             "pipeline": ("device: same_amd.sliding_window_incumbent(merge=True) on resident frames -- both sections in HBM, binned on the "
-                         "window grid, two library calls per window (csrc/window*.hip); the host triangulates (Qhull helpers) and receives "
-                         "the match; the merge reads the rows' keys, only the rows it keeps get their columns" if on_device
+                         "window grid, two library calls per window (csrc/window*.hip); the host triangulates ("
+                         + ("libsame_hip's own triangulator on threads of the process, windows with an order tie and sets it will not "
+                            "answer for go to scipy: optim_params['hip_delaunay'] = 'native'" if getattr(args, "cfg5_delaunay",
+                                                                      "qhull") == "native"
+                            else "scipy.spatial.Delaunay in helper processes, the reference's call")
+                         + ") and receives the match; the merge reads the rows' keys, only the rows it keeps get their columns" if on_device
                          else "frames: same_amd.sliding_window_incumbent(merge=True), general route on host frames -- every window's "
                               "frames "
                               "cut on the host, every kernel through host buffers, a DataFrame per window"),
             "parallelism": f"whole windows, {deal} deal x{group.world}; no collective inside a window; every rank merges what only it can "
                            "see, one all-gather of the seam rows per pass" + (f": {transport}" if comm is not None else "")},
-        "deal": deal,
+        "deal": deal, "delaunay": getattr(args, "cfg5_delaunay", "qhull"),
         "windows_per_s": len(plan) * steps / dt,
         "aligned_cells_per_s": float(sum(w["n_mov"] for w in plan)) * steps / dt,
         "aligned_cells_per_window": float(np.mean([w["n_mov"] for w in plan])),

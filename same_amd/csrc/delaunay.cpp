@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <limits>
 #include <vector>
 
@@ -33,35 +34,65 @@ struct Tri {
     std::vector<int32_t> tri, half;      // 3 per triangle: vertex at the start of the half-edge; the twin half-edge or -1
     std::vector<int32_t> hprev, hnext, htri, hash;
     std::vector<int32_t> stack;
-    std::vector<std::pair<double, int32_t>> order;   // the points by distance from the seed's circumcentre
+    std::vector<uint64_t> order, order_tmp;          // (squared distance from the seed's circumcentre as a float's bits, point), ascending
+    std::vector<int32_t> ids;                        // place in the insertion order -> the caller's point
+    std::vector<double> pxy;                         // the points in insertion order
+    const double *cur = nullptr;                     // the coordinates X() / Y() read: the caller's until the order is known, then pxy
     std::vector<double> judge;                       // per triangle: what turns an in-circle determinant into distance / allowance
     int64_t len = 0;
     int32_t hash_size = 0, hull_start = 0;
     double cx = 0, cy = 0;
+    // |det| above these clears SIGN_MARGIN x (the sum of its products) whatever the points: every coordinate difference is at most the
+    // set's extent w, so the orientation's products sum to <= 2 w^2 and the in-circle's to <= 12 w^4
+    double sure_cross = 0, sure_incircle = 0;
 
-    double X(int32_t i) const { return xy[2 * (int64_t)i]; }
-    double Y(int32_t i) const { return xy[2 * (int64_t)i + 1]; }
+    double X(int32_t i) const { return cur[2 * (int64_t)i]; }
+    double Y(int32_t i) const { return cur[2 * (int64_t)i + 1]; }
 
     // > 0: a, b, c counter-clockwise
-    static double cross(double ax, double ay, double bx, double by, double px, double py) {
+    static double cross(double ax, double ay, double bx, double by, double px, double py, double surely = std::numeric_limits<double>::infinity()) {
         const double l = (ax - px) * (by - py), r = (ay - py) * (bx - px);
         const double det = l - r;
+        if (std::fabs(det) > surely) return det;                 // clear of the bound for ANY three points of this set
         if (!(std::fabs(det) > SIGN_MARGIN * (std::fabs(l) + std::fabs(r)))) throw Unsure{};
         return det;
     }
-    bool ccw(int32_t a, int32_t b, int32_t c) const { return cross(X(a), Y(a), X(b), Y(b), X(c), Y(c)) > 0; }
+    bool ccw(int32_t a, int32_t b, int32_t c) const { return cross(X(a), Y(a), X(b), Y(b), X(c), Y(c), sure_cross) > 0; }
     // > 0: p inside the circle through a, b, c (counter-clockwise)
-    static double incircle(double ax, double ay, double bx, double by, double cx, double cy, double px, double py, double *perm = nullptr) {
+    static double incircle(double ax, double ay, double bx, double by, double cx, double cy, double px, double py,
+                           double surely = std::numeric_limits<double>::infinity()) {
         const double dx = ax - px, dy = ay - py, ex = bx - px, ey = by - py, fx = cx - px, fy = cy - py;
         const double ap = dx * dx + dy * dy, bp = ex * ex + ey * ey, cp = fx * fx + fy * fy;
         const double det = dx * (ey * cp - bp * fy) - dy * (ex * cp - bp * fx) + ap * (ex * fy - ey * fx);
+        if (std::fabs(det) > surely) return det;
         const double permanent = (std::fabs(ey * cp) + std::fabs(bp * fy)) * std::fabs(dx) + (std::fabs(ex * cp) + std::fabs(bp * fx)) * std::fabs(dy) +
                                  (std::fabs(ex * fy) + std::fabs(ey * fx)) * ap;
         if (!(std::fabs(det) > SIGN_MARGIN * permanent)) throw Unsure{};
-        if (perm) *perm = permanent;
         return det;
     }
-    bool inside(int32_t a, int32_t b, int32_t c, int32_t p) const { return incircle(X(a), Y(a), X(b), Y(b), X(c), Y(c), X(p), Y(p)) > 0; }
+    bool inside(int32_t a, int32_t b, int32_t c, int32_t p) const {
+        return incircle(X(a), Y(a), X(b), Y(b), X(c), Y(c), X(p), Y(p), sure_incircle) > 0;
+    }
+
+    static uint32_t float_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+    // Three counting passes over the 32 distance bits (11 + 11 + 10): non-negative floats order as their bits.  Single precision may
+    // swap two points whose distances agree to seven digits; the later one is then still outside the hull of the earlier ones (a hull's
+    // edges lie inside the circle through its farthest point by far more than that) -- and if it ever were not, the walk along the hull
+    // finds no edge that sees it and the answer is SAME_EUNSURE
+    void sort_by_distance() {
+        order_tmp.resize(order.size());
+        uint32_t count[2048];
+        const int shifts[3] = {32, 43, 54}, bits[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            const uint32_t mask = (1u << bits[pass]) - 1;
+            std::fill(count, count + 2048, 0u);
+            for (uint64_t v : order) ++count[(v >> shifts[pass]) & mask];
+            uint32_t sum = 0;
+            for (uint32_t q = 0; q <= mask; ++q) { const uint32_t c = count[q]; count[q] = sum; sum += c; }
+            for (uint64_t v : order) order_tmp[count[(v >> shifts[pass]) & mask]++] = v;
+            order.swap(order_tmp);
+        }
+    }
 
     int32_t key(double x, double y) const {
         const double dx = x - cx, dy = y - cy;
@@ -121,6 +152,7 @@ struct Tri {
     }
 
     void run() {
+        cur = xy;
         double minx = std::numeric_limits<double>::infinity(), miny = minx, maxx = -minx, maxy = -minx;
         for (int64_t i = 0; i < n; ++i) {
             const double x = X((int32_t)i), y = Y((int32_t)i);
@@ -129,6 +161,9 @@ struct Tri {
             miny = std::min(miny, y); maxy = std::max(maxy, y);
         }
         const double mx = (minx + maxx) / 2, my = (miny + maxy) / 2;
+        const double w = std::max(maxx - minx, maxy - miny);
+        sure_cross = SIGN_MARGIN * 2 * w * w;
+        sure_incircle = SIGN_MARGIN * 12 * w * w * w * w;
         auto d2 = [&](int32_t i, double x, double y) { const double dx = X(i) - x, dy = Y(i) - y; return dx * dx + dy * dy; };
         int32_t i0 = 0, i1 = -1, i2 = -1;
         double best = std::numeric_limits<double>::infinity();
@@ -158,8 +193,17 @@ struct Tri {
         order.clear();
         order.reserve((size_t)n);
         for (int32_t i = 0; i < n; ++i)
-            if (i != i0 && i != i1 && i != i2) order.emplace_back(d2(i, cx, cy), i);
-        std::sort(order.begin(), order.end());
+            if (i != i0 && i != i1 && i != i2) order.push_back(((uint64_t)float_bits((float)d2(i, cx, cy)) << 32) | (uint32_t)i);
+        sort_by_distance();
+        // from here on the points go by their place in the insertion order (seed first): a new point's neighbours on the hull and in the
+        // triangle list are recent points -- their coordinates, hull links and triangles sit together in memory
+        ids.resize((size_t)n);
+        pxy.resize((size_t)n * 2);
+        ids[0] = i0; ids[1] = i1; ids[2] = i2;
+        for (int64_t q = 0; q < (int64_t)order.size(); ++q) ids[(size_t)q + 3] = (int32_t)(uint32_t)order[(size_t)q];
+        for (int64_t q = 0; q < n; ++q) { pxy[2 * q] = xy[2 * (int64_t)ids[(size_t)q]]; pxy[2 * q + 1] = xy[2 * (int64_t)ids[(size_t)q] + 1]; }
+        cur = pxy.data();
+        i0 = 0; i1 = 1; i2 = 2;
 
         hash_size = (int32_t)std::ceil(std::sqrt((double)n));
         hash.assign((size_t)hash_size, -1);
@@ -182,8 +226,7 @@ struct Tri {
 
         // the hull runs counter-clockwise; the edge e -> next(e) is seen from p when p lies to its right
         auto sees = [&](int32_t p, int32_t e, int32_t q) { return !ccw(e, q, p); };
-        for (const auto &it : order) {
-            const int32_t i = it.second;
+        for (int32_t i = 3; i < (int32_t)n; ++i) {
             const double x = X(i), y = Y(i);
             int32_t start = 0;
             const int32_t k = key(x, y);
@@ -302,7 +345,7 @@ extern "C" int same_delaunay2d(const double *xy, int64_t n, int32_t *tris, int64
         if (!(worst > guard)) return SAME_EUNSURE;
         const int64_t count = t.len / 3;
         if (count > cap) return SAME_EINVAL;
-        std::copy(t.tri.begin(), t.tri.begin() + t.len, tris);
+        for (int64_t q = 0; q < t.len; ++q) tris[q] = t.ids[(size_t)t.tri[(size_t)q]];
         *n_tris = count;
         return SAME_OK;
     } catch (const Unsure &) {

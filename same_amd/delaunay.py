@@ -25,7 +25,8 @@ import numpy as np
 
 from . import _lib
 
-GUARD = 16.0   # x Qhull's round-off allowance: 60 x the largest ratio (0.27) at which Qhull's triangles differed from the exact ones in 6 000
+# x Qhull's round-off allowance: 60 x the largest ratio (0.27) at which Qhull's triangles differed from the exact ones in 6 000
+GUARD = 16.0
                # calibration sets (an edge's property, not a set's: larger sets have smaller margins only because they have more edges)
 
 
@@ -114,7 +115,8 @@ class NativeTriangulator:
 
         if threads is None:
             # one and a half threads per CPU of this process's share, as the Qhull helpers have it: a thread whose answer is ready sits
-            # idle until a worker picks it up (16 CPUs: 3 500 windows/s with 16 threads, 4 000-4 200 with 24; profiles/r06_native_delaunay.log)
+            # idle until a worker picks it up (16 CPUs: 3 500 windows/s with 16 threads, 4 000-4 200 with 24;
+            # profiles/r06_native_delaunay.log)
             share = qhull_pool.cpu_budget() / qhull_pool.cpu_sharers()[0]
             threads = int(os.environ.get("SAME_DELAUNAY_THREADS", "0")) or min(32, max(1, int(1.5 * share)))
         self.threads, self.guard = max(1, int(threads)), float(guard)

@@ -135,3 +135,19 @@ def test_triangulator_steps_aside_where_most_windows_go_back(monkeypatch):
         assert t.result() is not None and t.native and tr.bypassed == 5
     finally:
         tr.close()
+
+
+def test_triangulator_under_the_sanitizers(tmp_path):
+    """csrc/delaunay.cpp built with -fsanitize=address,undefined and driven from C++ (tests/native/delaunay_test.cpp): random and
+    degenerate sets, bad arguments, eight threads at once; every answer checked for the local Delaunay property."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "delaunay_test"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-pthread",
+                    "-ffp-contract=off", "-I", os.path.join(root, "include"), os.path.join(root, "same_amd", "csrc", "delaunay.cpp"),
+                    os.path.join(root, "tests", "native", "delaunay_test.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

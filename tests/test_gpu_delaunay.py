@@ -126,9 +126,11 @@ def test_tables_with_the_native_triangulator_are_the_tables_with_scipy(integer_r
     tr = delaunay.shared()
     try:
         for merge in (True, False):
-            want = same_amd.sliding_window_incumbent(resident, resident, commonCT=cols, optim_params=dict(op), merge=merge, return_stats=True)
+            want = same_amd.sliding_window_incumbent(resident, resident, commonCT=cols, optim_params=dict(op), merge=merge,
+                                                     return_stats=True)
             before = (tr.submitted, tr.asked_qhull)
-            got = same_amd.sliding_window_incumbent(resident, resident, commonCT=cols, optim_params=dict(op, hip_delaunay="native"), merge=merge,
+            got = same_amd.sliding_window_incumbent(resident, resident, commonCT=cols, optim_params=dict(op, hip_delaunay="native"),
+                                                    merge=merge,
                                                     return_stats=True)
             asked, back = tr.submitted - before[0], tr.asked_qhull - before[1]
             assert len(want[0]) > 15000 and got[0].equals(want[0]) and list(got[0].columns) == list(want[0].columns)

@@ -54,6 +54,7 @@ for margin, same, kind in rows:
     d[2] += same is None
 print(f"seed {seed}, {n_sets} sets (uniform squares, anisotropic blobs, clusters, strips; 50-5000 points; offsets 1e2..3e8, either sign)")
 for b in sorted(bins):
-    print(f"margin in [1e{b}, 1e{b + 1}): sets {bins[b][0]:4d}   scipy's triangles differ from the exact ones in {bins[b][1]:4d}   no exact answer {bins[b][2]}")
+    print(f"margin in [1e{b}, 1e{b + 1}): sets {bins[b][0]:4d}   scipy's triangles differ from the exact ones in {bins[b][1]:4d}   no "
+          f"exact answer {bins[b][2]}")
 worst = max(((m, kinds[k]) for m, same, k in rows if same is False), default=None)
 print("largest margin at which scipy's triangles differ:", worst, "-- delaunay.GUARD =", delaunay.GUARD)

@@ -56,7 +56,8 @@ with same_amd.resident_frames(r_df, m_df) as res:
                 call()
             dt = (time.perf_counter() - t0) / 3
             rate = len(stats) / dt
-            print(f"triangulator threads {tri_threads:2d}, workers {workers}: {len(stats)} windows in {dt * 1e3:.1f} ms = {rate:.0f} windows/s; "
+            print(f"triangulator threads {tri_threads:2d}, workers {workers}: {len(stats)} windows in {dt * 1e3:.1f} ms = {rate:.0f} "
+                  f"windows/s; "
                   f"sent back to Qhull {tr.asked_qhull} of {tr.submitted}", flush=True)
             if rate > best[0]:
                 best = (rate, (tri_threads, workers, {k: v for k, v in _trace.report().items()}))
