@@ -15,6 +15,10 @@ echo "== bench (cfg5, 2 ranks on the one GPU)" && timeout -k 10 400 python3 benc
 python3 tools/cfg5_lines.py $out/bench_cfg5_2ranks.json
 echo "== bench (cfg5, 2 ranks, round-robin deal)" && timeout -k 10 400 python3 bench.py --workload cfg5 --steps 5 --warmup 1 --gpus 2 --cfg5-deal round_robin --no-extras > $out/bench_cfg5_2ranks_round_robin.json 2> $out/bench_cfg5_2ranks_rr.err || { tail -20 $out/bench_cfg5_2ranks_rr.err; exit 1; }
 python3 tools/cfg5_lines.py $out/bench_cfg5_2ranks_round_robin.json
+echo "== bench (cfg5, 1 rank, the timed step on the opt-in triangulator)" && timeout -k 10 400 python3 bench.py --workload cfg5 --steps 5 --warmup 1 --cfg5-delaunay native > $out/bench_cfg5_native.json 2> $out/bench_cfg5_native.err || { tail -20 $out/bench_cfg5_native.err; exit 1; }
+python3 tools/cfg5_lines.py $out/bench_cfg5_native.json
+echo "== bench (cfg5, 2 ranks on the one GPU, opt-in triangulator)" && timeout -k 10 400 python3 bench.py --workload cfg5 --steps 5 --warmup 1 --gpus 2 --cfg5-delaunay native --no-extras > $out/bench_cfg5_native_2ranks.json 2> $out/bench_cfg5_native_2ranks.err || { tail -20 $out/bench_cfg5_native_2ranks.err; exit 1; }
+python3 tools/cfg5_lines.py $out/bench_cfg5_native_2ranks.json
 echo "== product function profile" && timeout -k 10 300 python3 tools/incumbent_profile.py 1000000 1 > $out/incumbent_profile_merged.log 2>&1 && timeout -k 10 300 python3 tools/incumbent_profile.py 1000000 0 > $out/incumbent_profile_plain.log 2>&1; head -4 $out/incumbent_profile_merged.log
 echo "== own triangulator (opt-in): profile, fuzz soak" && timeout -k 10 400 python3 tools/native_delaunay_profile.py > $out/native_delaunay.log 2>&1 || { tail -20 $out/native_delaunay.log; exit 1; }
 grep "workers\|same_delaunay2d\|scipy" $out/native_delaunay.log | tail -22
