@@ -9,7 +9,8 @@ from .bench_common import HBM_PEAK_GBS, Env, baseline_metric, comm_report, note
 RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dtype", "windows_per_s", "aligned_cells_per_s",
                "aligned_cells_per_window", "windows_per_s_triangulations_given", "windows_per_s_triangulations_given_merged",
                "native_delaunay", "per_rank",
-               "host_glue_share", "python_share", "qhull_wait_share", "serial_tail_s_per_step", "table_gather_s_per_step",
+               "host_glue_share", "python_share", "qhull_wait_share", "own_triangulator_thread_s_per_step", "serial_tail_s_per_step",
+               "table_gather_s_per_step",
                "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0",
                "amdahl_bound_at_8_ranks", "amdahl",
                "seam_exchange", "deal", "delaunay", "threads_per_rank", "runtime_calls_per_window", "runtime_calls_per_pass_merge", "qhull",
@@ -156,9 +157,12 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     calls_per_window = {k_: (sum(b[k_] - a[k_] for a, b in zip(calls0, calls1)) - per_pass[k_] * steps) / n_done for k_ in calls1[0]}
     dt = group.max(wall_here)
     rep = _trace.report()
-    in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:"))
+    # same_delaunay2d is host work on the triangulator's own threads (opt-in route): not part of the worker threads' time in the library
+    own_tri_s = sum(sec for name, (_c, sec) in rep.items() if name == "lib:same_delaunay2d")
+    in_lib = sum(sec for name, (_c, sec) in rep.items() if name.startswith("lib:")) - own_tri_s
     stages = {name: {"calls": c, "seconds": sec} for name, (c, sec) in sorted(rep.items()) if not name.startswith("lib:")}
-    lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:")), key=lambda e: -e[1])[:8]
+    lib_top = sorted(((name[4:], sec) for name, (_c, sec) in rep.items() if name.startswith("lib:") and name != "lib:same_delaunay2d"),
+                     key=lambda e: -e[1])[:8]
     qhull_wait = sum(sec for name, (_c, sec) in rep.items() if name.startswith("triangulate"))
     # DIAGNOSTIC, outside the timed region and never part of `value`: the same pass with every window's triangulation remembered from a
     # first pass -- what the library calls + the Python glue cost once Qhull is out of the picture, i.e. the rate a host with enough
@@ -237,7 +241,8 @@ def run(args, group, ctx, comm, transport, steps, warmup, cpu_baseline=None):
     thread_seconds = max(walk_s * n_workers + merge_s + table_s, 1e-9)
     mine_rec = {"rank": group.rank, "windows": len(my_plan), "seconds": wall_here, "windows_per_s": len(my_plan) * steps / wall_here,
                 "in_library_s": in_lib, "host_glue_share": 1.0 - in_lib / thread_seconds, "threads": n_workers,
-                "qhull_wait_s": qhull_wait, "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / thread_seconds),
+                "qhull_wait_s": qhull_wait, "own_triangulator_thread_s_per_step": own_tri_s / steps,
+                "python_share": max(0.0, 1.0 - (in_lib + qhull_wait) / thread_seconds),
                 "qhull_wait_share": qhull_wait / thread_seconds, "serial_tail_s_per_step": merge_s / steps,
                 "table_gather_s_per_step": table_s / steps, "unsharded_s_per_step": unsharded_s / steps,
                 "seam_exchange_s_per_step": exchange_s / steps, "seam_step_s_per_step": seam_step_s / steps,
@@ -432,8 +437,15 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
         "python_share_means": "host_glue_share without the worker threads' waits for the Qhull helpers: what Python / numpy itself takes "
                               "of the threads' time (the merge, the seam exchange and the table included)",
         "qhull_wait_share": mine_rec["qhull_wait_share"],
-        "qhull_wait_share_means": "the worker threads' waits for the Qhull helpers (hand-over when all are busy + collecting answers) over "
-                                  "the same capacity: host_glue_share = qhull_wait_share + python_share",
+        "qhull_wait_share_means": "the worker threads' waits for whoever triangulates -- the Qhull helpers, or with --cfg5-delaunay native "
+                                  "the triangulator's threads -- (hand-over when all are busy + collecting answers) over the same "
+                                  "capacity: "
+                                  "host_glue_share = qhull_wait_share + python_share",
+        "own_triangulator_thread_s_per_step": mine_rec["own_triangulator_thread_s_per_step"],
+        "own_triangulator_thread_s_means": "--cfg5-delaunay native: seconds inside same_delaunay2d per step, summed over the "
+                                           "triangulator's "
+                                           "threads (host work beside the worker threads, not part of the shares above); 0 on the default "
+                                           "route",
         "serial_tail_s_per_step": max(by_rank("serial_tail_s_per_step")),
         "serial_tail_means": "slowest rank's time in the window merge per step (stages 'merge: ...' of same_amd/_trace.py: keys, "
                              "de-duplication on the device, matching of contested cells, the seam rows' exchange, the common seam step) -- "
