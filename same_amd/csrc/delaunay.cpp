@@ -95,8 +95,9 @@ struct Tri {
     }
 
     int32_t key(double x, double y) const {
-        const double dx = x - cx, dy = y - cy;
-        const double p = dx / (std::fabs(dx) + std::fabs(dy));
+        const double dx = x - cx, dy = y - cy, den = std::fabs(dx) + std::fabs(dy);
+        if (!(den > 0)) return 0;                                      // a point AT the seed's circumcentre (it is then refused: no hull edge sees it)
+        const double p = dx / den;
         const double a = (dy > 0 ? 3 - p : 1 + p) / 4;                 // [0, 1], grows counter-clockwise
         return (int32_t)((int64_t)std::floor(a * hash_size) % hash_size);
     }
@@ -331,7 +332,8 @@ struct Tri {
 }  // namespace
 
 extern "C" int same_delaunay2d(const double *xy, int64_t n, int32_t *tris, int64_t cap, int64_t *n_tris, double guard, double *margin) {
-    if (!xy || !tris || !n_tris || n < 0 || cap < 0 || n > (int64_t)1 << 30 || !(guard >= 0.0)) return SAME_EINVAL;
+    // half-edge numbers (three per triangle, fewer than 2 n triangles) are 32-bit
+    if (!xy || !tris || !n_tris || n < 0 || cap < 0 || n > (int64_t)350000000 || !(guard >= 0.0)) return SAME_EINVAL;
     *n_tris = 0;
     if (margin) *margin = 0.0;
     if (n < 3) return SAME_EUNSURE;

@@ -76,6 +76,17 @@ int main() {
         const int rc = one_set(n, kind, &answered);
         if (rc) { std::printf("set %d (kind %d, n %lld): %d\n", round, kind, (long long)n, rc); return 1; }
     }
+    // a point exactly at the seed triangle's circumcentre (a square's four corners and its centre, among others): refused, not crashed
+    {
+        std::vector<double> xy;
+        for (int gy = 0; gy < 9; ++gy)
+            for (int gx = 0; gx < 9; ++gx) { xy.push_back(gx * 2.0); xy.push_back(gy * 2.0); }
+        xy.push_back(9.0); xy.push_back(9.0);
+        const int64_t n = (int64_t)xy.size() / 2;
+        std::vector<int32_t> t((size_t)(2 * n) * 3);
+        int64_t n_t = 0;
+        if (same_delaunay2d(xy.data(), n, t.data(), 2 * n, &n_t, 16.0, nullptr) != SAME_EUNSURE) { std::printf("centre\n"); return 1; }
+    }
     // bad arguments
     int64_t nt = 0;
     int32_t t3[3];
