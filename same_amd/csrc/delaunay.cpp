@@ -314,7 +314,7 @@ struct Tri {
             }
             if (b < a) continue;
             const int32_t p1 = tri[b - b % 3 + (b + 2) % 3];
-            const double det = std::fabs(incircle(X(p0), Y(p0), X(pr), Y(pr), X(pl), Y(pl), X(p1), Y(p1)));
+            const double det = std::fabs(incircle(X(p0), Y(p0), X(pr), Y(pr), X(pl), Y(pl), X(p1), Y(p1), sure_incircle));
             worst = std::min(worst, det * judge[(size_t)(a0 / 3)]);
         }
         // hull corners: the corner against the chord of its neighbours
