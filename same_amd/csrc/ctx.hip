@@ -80,6 +80,7 @@ const char *same_strerror(int code) {
         case SAME_EIO: return "HIP/RCCL runtime failure";
         case SAME_ENODEV: return "no usable GPU device";
         case SAME_ERANGE: return "index out of range";
+        case SAME_EUNSURE: return "points too close to degenerate to answer for Qhull (not an error: ask Qhull)";
         default: return "unknown error";
     }
 }
