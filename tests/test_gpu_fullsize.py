@@ -244,10 +244,12 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
         # magnitude ~1e4, so a pair of near-identical cells (cost ~1e-3 here: jittered copies) keeps only the absolute
         # accuracy of its operands: (T + 4) roundings of 2^-24 on the operand magnitudes
         c64 = oracle.pair_cost_arrays(A, R, axy, rxy, pairs, 1.0)
-        mag = (np.abs(A[pairs[:, 0]]) + np.abs(R[pairs[:, 1]])).sum(axis=1) + 0.001 * (np.abs(axy[pairs[:, 0]]) + np.abs(rxy[pairs[:, 1]])).sum(axis=1)
+        mag = (np.abs(A[pairs[:, 0]]) + np.abs(R[pairs[:, 1]])).sum(axis=1)
+        mag = mag + 0.001 * (np.abs(axy[pairs[:, 0]]) + np.abs(rxy[pairs[:, 1]])).sum(axis=1)
         assert (np.abs(got_c - c64) <= (T + 4) * 2.0 ** -24 * mag).all()
         # a6-a8: triangulation (Qhull on the host, as in the reference), filter, weights, signs
-        tri = oracle.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True, min_angle_deg=15)
+        tri = oracle.filter_triangles_by_radius(axy, Delaunay(axy).simplices, 25, aligned_df=na, ignore_same_type_triangles=True,
+                                                min_angle_deg=15)
         tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
         assert np.array_equal(np.asarray(prep.aligned_delaunay, dtype=np.int64).reshape(-1, 3), tri)
         assert prep.triangle_weights == oracle.triangle_weights(na, tri) and prep.source_signs == oracle.source_signs(na, tri)
@@ -278,17 +280,18 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
         assert np.array_equal(np.array([before[t] for t in range(len(tri))]), ob)
         assert np.array_equal(np.array([np.nan if after[t] is None else after[t] for t in range(len(tri))]), oa, equal_nan=True)
         assert flipped == np.flatnonzero(ofl).tolist()
-        expect.append(dict(window=w, rows_m=na["Cell_Num_Old"].to_numpy(), rows_r=nr["Cell_Num_Old"].to_numpy(), pairs=pairs, c32=c32, tri=tri,
-                           signs=np.asarray(prep.source_signs, dtype=np.int8), chosen=och, checked=ochecked, flipped=len(oviol),
+        expect.append(dict(window=w, rows_m=na["Cell_Num_Old"].to_numpy(), rows_r=nr["Cell_Num_Old"].to_numpy(), pairs=pairs, c32=c32,
+                           tri=tri, signs=np.asarray(prep.source_signs, dtype=np.int8), chosen=och, checked=ochecked, flipped=len(oviol),
                            area_flips=int(np.count_nonzero(ofl)), xy=orep["violation_summary"]))
     # the same four windows with both 1M-cell sections resident on the device (csrc/window.hip: what bench.py --workload cfg5 times)
     from same_amd import windows as W
 
-    assert np.array_equal(r_df["Cell_Num_Old"].to_numpy(), np.arange(len(r_df))) and np.array_equal(m_df["Cell_Num_Old"].to_numpy(), np.arange(len(m_df)))
+    assert np.array_equal(r_df["Cell_Num_Old"].to_numpy(), np.arange(len(r_df)))
+    assert np.array_equal(m_df["Cell_Num_Old"].to_numpy(), np.arange(len(m_df)))
     ref_sec, mov_sec = W.Section.from_frame(r_df, cols), W.Section.from_frame(m_df, cols)
     dref, dmov = W.DeviceSection(ref_sec, "float32"), W.DeviceSection(mov_sec, "float32")
-    got = W.iter_device_windows(ref_sec, mov_sec, dref, dmov, [e["window"] for e in expect], radius=25, knn=8, dist_ct_coeff=1.0, min_angle_deg=15,
-                                ignore_same_type_triangles=True, no_match_penalty=100.0, fetch_triangles=True)
+    got = W.iter_device_windows(ref_sec, mov_sec, dref, dmov, [e["window"] for e in expect], radius=25, knn=8, dist_ct_coeff=1.0,
+                                min_angle_deg=15, ignore_same_type_triangles=True, no_match_penalty=100.0, fetch_triangles=True)
     for e, dw in zip(expect, got):
         assert dw.error is None and np.array_equal(dw.rows_m, e["rows_m"])
         dp, rows_r = dw.state.fetch(W._W_PAIRS), dw.state.fetch(W._W_ROWS_R)
@@ -300,7 +303,8 @@ def test_cfg5_1m_cells_windows_fp32(env, oracle):
             match_o[i] = e["rows_r"][j]
         assert np.array_equal(dw.match_row, match_o)
         st = dw.stats
-        assert (st["checked"], st["flipped"], st["area_flips"], st["matched"]) == (e["checked"], e["flipped"], e["area_flips"], len(e["chosen"]))
+        want_counts = (e["checked"], e["flipped"], e["area_flips"], len(e["chosen"]))
+        assert (st["checked"], st["flipped"], st["area_flips"], st["matched"]) == want_counts
         assert st["xy_comparisons"] == e["xy"]["total_comparisons"] and st["xy_violations"] == e["xy"]["total_violations"]
     dref.close()
     dmov.close()
@@ -341,10 +345,12 @@ def test_window_stage_with_thousands_of_scan_blocks(env):
         assert (n_m, n_r, n_kept, n_pairs) == (n, n, len(kept), len(want_pairs)), name
         assert np.array_equal(st.fetch(W._W_ROWS_M), np.arange(n)) and np.array_equal(st.fetch(W._W_ALIGNED_ROWS), kept), name
         got = st.fetch(W._W_PAIRS)
-        assert np.array_equal(kept[got[:, 0]], want_pairs[:, 0]) and np.array_equal(got[:, 1], want_pairs[:, 1]), name   # all refs in the box: window number = row
+        # all refs in the box: window number = row
+        assert np.array_equal(kept[got[:, 0]], want_pairs[:, 0]) and np.array_equal(got[:, 1], want_pairs[:, 1]), name
         # half the section: the box cuts through a column of cells (7 x 7) / covers too many cells (25-unit)
         n_m, n_r, _nk, _np = st.stage(dmov, dref, half, r, k, 1.0)
-        assert (n_m, n_r) == (len(in_m), len(in_r)) and np.array_equal(st.fetch(W._W_ROWS_M), in_m) and np.array_equal(st.fetch(W._W_ROWS_R), in_r), name
+        assert (n_m, n_r) == (len(in_m), len(in_r)), name
+        assert np.array_equal(st.fetch(W._W_ROWS_M), in_m) and np.array_equal(st.fetch(W._W_ROWS_R), in_r), name
         gp, rows_r, rows_ua = st.fetch(W._W_PAIRS), st.fetch(W._W_ROWS_R), st.fetch(W._W_ALIGNED_ROWS)
         sel = np.isin(want_pairs[:, 0], in_m)          # pairs of aligned rows in the box whose reference cell is in the box as well ...
         # ... as long as no in-box row loses a nearer out-of-box candidate to the k limit: compare rows whose whole list is inside
@@ -354,7 +360,8 @@ def test_window_stage_with_thousands_of_scan_blocks(env):
         bad_rows = np.unique(want_pairs[outside[want_pairs[:, 1]], 0])
         full[bad_rows] = False
         keep_rows = full[rows_ua[gp[:, 0]]]
-        assert np.array_equal(np.column_stack((rows_ua[gp[:, 0]], rows_r[gp[:, 1]]))[keep_rows], want_pairs[sel & full[want_pairs[:, 0]]]), name
+        assert np.array_equal(np.column_stack((rows_ua[gp[:, 0]], rows_r[gp[:, 1]]))[keep_rows],
+                              want_pairs[sel & full[want_pairs[:, 0]]]), name
         dref.close()
         dmov.close()
     st.close()
@@ -383,3 +390,29 @@ def test_merge_dedup_properties_at_cfg5_scale(env):
     assert np.array_equal(np.sort(first), np.sort(kept.astype(np.int64)))
     again = ops.merge_dedup(viol[kept], win[kept], a[kept], r[kept])
     assert np.array_equal(again, np.arange(len(kept)))                            # idempotent
+
+
+def test_cfg5_1m_cells_own_triangulator_gives_the_same_merged_table(env):
+    """BASELINE config 5 at full size through the product function, window merge included, with the windows triangulated by
+    libsame_hip's own triangulator (optim_params["hip_delaunay"] = "native") and by scipy: the 950k-row merged tables and every window's
+    counters are identical, and nearly every window (13 600 aligned cells each) is answered by the library itself."""
+    import same_amd
+    from same_amd import delaunay
+
+    _lib, ops, synth = env
+    T = 8
+    ref = synth.make_cells(1_000_000, T, seed=0)
+    mov = synth.make_jittered(ref, seed=1)
+    r_df, m_df = synth.to_frame(ref), synth.to_frame(mov)
+    r_df["Cell_Num_Old"], m_df["Cell_Num_Old"] = np.arange(len(r_df)), np.arange(len(m_df))
+    cols = synth.type_columns(T)
+    op = dict(radius=25, knn=8, no_match_penalty=100, hip_cost_dtype="float32", window_size=1200, overlap=300, min_cells_per_window=10)
+    tr = delaunay.shared()
+    with same_amd.resident_frames(r_df, m_df) as res:
+        want, want_stats = same_amd.sliding_window_incumbent(res, res, commonCT=cols, optim_params=dict(op), merge=True, return_stats=True)
+        before = (tr.submitted, tr.asked_qhull)
+        got, got_stats = same_amd.sliding_window_incumbent(res, res, commonCT=cols, optim_params=dict(op, hip_delaunay="native"),
+                                                           merge=True, return_stats=True)
+    windows, sent_back = tr.submitted - before[0], tr.asked_qhull - before[1]
+    assert len(want) > 900_000 and got.equals(want) and got_stats == want_stats
+    assert windows == len(want_stats) > 100 and sent_back <= windows // 10, (windows, sent_back)
