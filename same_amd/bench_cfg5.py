@@ -11,6 +11,7 @@ RECORD_KEYS = ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "dt
                "windows_per_s_triangulations_given_best_pass", "windows_per_s_triangulations_given_merged_best_pass", "native_delaunay",
                "per_rank",
                "host_glue_share", "python_share", "qhull_wait_share", "own_triangulator_thread_s_per_step", "serial_tail_s_per_step",
+               "serial_tail_without_wait_s_per_step",
                "table_gather_s_per_step",
                "after_windows_s_per_step", "unsharded_s_per_step", "seam_wait_s_per_step", "merge_stages_s_per_step_rank0",
                "amdahl_bound_at_8_ranks", "amdahl",
@@ -460,6 +461,14 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                              "the rank's own rows.  The columns of the rows that stay are `table_gather_s_per_step` (inside the window "
                              "pass "
                              "in round 5, when the pre-merge table was laid out first)",
+        "serial_tail_without_wait_s_per_step": max(t_ - (x_ - min(by_rank("seam_exchange_s_per_step")))
+                                                   for t_, x_ in zip(by_rank("serial_tail_s_per_step"),
+                                                                     by_rank("seam_exchange_s_per_step"))),
+        "serial_tail_without_wait_means": "serial_tail_s_per_step without a rank's WAIT for the last rank to reach the seam exchange (its "
+                                          "time "
+                                          "in the all-gather beyond the last arriver's): the merge WORK after a rank's last window.  The "
+                                          "wait is the deal's imbalance as the host's CPUs made it (`seam_wait_s_per_step`) and already in "
+                                          "`value`: the step ends when the last rank ends",
         "merge_stages_s_per_step_rank0": mine_rec["merge_stages_s_per_step"],
         "table_gather_s_per_step": max(by_rank("table_gather_s_per_step")),
         "after_windows_s_per_step": max(a_ + b_ for a_, b_ in zip(by_rank("serial_tail_s_per_step"), by_rank("table_gather_s_per_step"))),
