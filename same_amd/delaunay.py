@@ -101,7 +101,7 @@ class _QhullTicket:
 
 class NativeTriangulator:
     """`submit(points, key=None) -> ticket` like the Qhull helper pool's, answered by same_delaunay2d on a thread of this process
-    (ctypes drops the GIL for the call).  `threads`: default one per CPU of this process's share ($SAME_DELAUNAY_THREADS).
+    (ctypes drops the GIL for the call).  `threads`: default one and a half per CPU of this process's share ($SAME_DELAUNAY_THREADS).
     A set the library leaves to Qhull goes to a Qhull helper from the triangulator's thread, windows ahead of its use.  Where most
     windows end up with scipy anyway (sections on a lattice; whole-number coordinates: order ties in every window) the triangulator
     steps aside: after `WINDOW` tickets of which more than half went back to scipy, the next `BYPASS` go to the helpers directly."""
@@ -114,10 +114,12 @@ class NativeTriangulator:
         from . import qhull_pool
 
         if threads is None:
-            # one thread per CPU of this process's share: with 2.5-3 ms per window a thread is seldom idle, and more threads than CPUs only
-            # add contention (16 CPUs, three sweeps: 3 600-5 100 windows/s with 16 threads, 3 300-4 400 with 24; profiles/r06_native_delaunay*.log)
+            # one and a half threads per CPU of this process's share (as the Qhull helpers have it): the worker threads and the runtime's
+            # own threads take CPU time too, and a triangulator thread that is descheduled holds a window back.  Same lease, back to back
+            # (profiles/r06_native_threads_ab.log): two ranks on 16 CPUs 4 400-4 850 windows/s with 8 threads each, 5 260-5 350 with 12;
+            # one rank 3 930-4 280 with 16 and 3 630-4 330 with 24 (no difference beyond the lease's noise)
             share = qhull_pool.cpu_budget() / qhull_pool.cpu_sharers()[0]
-            threads = int(os.environ.get("SAME_DELAUNAY_THREADS", "0")) or min(32, max(1, int(share)))
+            threads = int(os.environ.get("SAME_DELAUNAY_THREADS", "0")) or min(32, max(1, int(1.5 * share)))
         self.threads, self.guard = max(1, int(threads)), float(guard)
         self.pool = ThreadPoolExecutor(self.threads, thread_name_prefix="same-delaunay")
         self.submitted = self.asked_qhull = self.bypassed = 0
