@@ -151,3 +151,34 @@ def test_triangulator_under_the_sanitizers(tmp_path):
                     os.path.join(root, "tests", "native", "delaunay_test.cpp"), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def test_qhull_is_exact_wherever_the_margin_is_clear_of_its_allowance():
+    """The model behind the guard, pinned (tools/delaunay_margin.py runs it at scale): sets pushed so far from the origin that Qhull's
+    uncentred lifted coordinate runs out of digits.  With guard = 0 the library gives the EXACT triangulation (its signs are computed on
+    centred differences) and the set's margin; scipy's triangles must be the exact ones wherever the margin is 1 or more -- the library
+    only ever answers above 16 -- and, far enough out, some sets must show scipy erring (or the test is not testing anything)."""
+    rng = np.random.default_rng(17)
+    clear = erred = 0
+    for _ in range(60):
+        n = int(rng.integers(50, 1500))
+        off = 10.0 ** rng.uniform(4, 8.5) * rng.choice([-1, 1], 2)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            pts = rng.uniform(0, 1200, (n, 2))
+        elif kind == 1:
+            c = rng.uniform(0, 1200, (max(n // 40, 1), 2))
+            pts = c[rng.integers(0, len(c), n)] + rng.normal(0, rng.uniform(0.5, 20), (n, 2))
+        else:
+            pts = np.c_[rng.uniform(0, 3000, n), rng.uniform(0, 30, n)]
+        pts = pts + off
+        exact, margin = delaunay.native_simplices(pts, guard=0.0, with_margin=True)
+        if exact is None:
+            continue
+        qhull = Delaunay(pts).simplices
+        same = len(exact) == len(qhull) and np.array_equal(_canonical(exact), _canonical(qhull))
+        if margin >= 1.0:
+            assert same, (margin, n, kind, off)
+            clear += 1
+        erred += not same
+    assert clear >= 15 and erred >= 5, (clear, erred)
