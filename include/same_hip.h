@@ -436,7 +436,8 @@ int same_window_filter_finish(same_window *const *windows, int n_windows, const 
  * margin is below 0.3 (tools/delaunay_margin.py, profiles/r06_delaunay_margin.md: 6 000 sets); same_amd uses guard = 16 (60 x that).
  * xy: n points (x, y) interleaved.  out_tris: room for `cap` triangles (2 n - 5 always suffices); *out_n_tris triangles are written,
  * counter-clockwise, in this function's own order (Qhull's order and corner order are its own: see the ORDER TIES of
- * same_window_filter_finish for what that touches).  SAME_OK | SAME_EUNSURE | SAME_EINVAL (NULL, n < 0, cap too small) | SAME_ENOMEM. */
+ * same_window_filter_finish for what that touches).  SAME_OK | SAME_EUNSURE | SAME_EINVAL (NULL, n < 0 or above 3.5e8, cap too small) |
+ * SAME_ENOMEM. */
 int same_delaunay2d(const double *xy, int64_t n, int32_t *out_tris, int64_t cap, int64_t *out_n_tris, double guard,
                     double *out_margin /* may be NULL */);
 
