@@ -525,7 +525,9 @@ def _line(args, group, comm, transport, plan, deal, every, mine_rec, stages, lib
                      "note": "touched bytes per step (SURVEY 8d per-unit figures: pairs x (2 s (T+2) + 8 + s), triangles x (74 + 133), 16 "
                              "k "
                              "per aligned cell) over the slowest rank's time inside libsame_hip per step; this configuration is bound by "
-                             "the host's Delaunay calls (Qhull: qhull_wait_share), not by HBM or by the GPU"},
+                             + ("the host -- the triangulator's threads (own_triangulator_thread_s_per_step) and what a process can submit "
+                                "per second --, not by HBM or by the GPU" if getattr(args, "cfg5_delaunay", "qhull") == "native"
+                                else "the host's Delaunay calls (Qhull: qhull_wait_share), not by HBM or by the GPU")},
         "product_function": "same_amd.sliding_window_incumbent(merge=True) (sliding_window_matching's arguments; the greedy MIP start as "
                             "every "
                             "window's solution; merge_window_matches_unique_ref's table) -- the timed step IS a call of it per rank"
